@@ -1,0 +1,764 @@
+/*
+ * rten_oracle.c -- CPU restatement of the RTen hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the parity oracle for the MI355X backend: a plain-C restatement of the
+ * arithmetic the reference (robertknight/rten v0.25.0, CPU) performs on the path
+ * rten-gemm / rten-vecmath behind src/ops/{matmul,conv,attention,norm,pooling,quantize}.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ * The product (librten_hip.so) never links or calls anything in here.
+ *
+ * Pinning: the reference is Rust and cannot be compiled in the build container (no
+ * cargo/rustc), so the oracle is pinned against the literal golden vectors of the
+ * reference's own tests (JSON files under tests/golden/, each citing file:line) and the pinned
+ * RNG streams (rten-tensor/src/rng.rs:70-123).  See tests/test_oracle_golden.py.
+ *
+ * Every function cites the reference file:line it follows (paths relative to the
+ * reference checkout).  Floating point is restated operation-for-operation: fused
+ * multiply-adds where the reference uses `mul_add`, separate roundings elsewhere.
+ * Compile with -ffp-contract=off so the compiler adds no contractions of its own.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define RTO_API __attribute__((visibility("default")))
+
+static inline float fma32(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+/* ------------------------------------------------------------------------------------
+ * RNG clones -- rten-tensor/src/rng.rs:6-66, rten-gemm/src/reduced_range_rng.rs:24-57
+ * ---------------------------------------------------------------------------------- */
+static inline uint64_t xorshift_next(uint64_t *state) {
+    uint64_t t = *state;
+    t ^= t << 13;
+    t ^= t >> 7;
+    t ^= t << 17;
+    *state = t;
+    return t;
+}
+
+/* rng.rs:26-32: top 40 bits scaled by 2^-40 */
+RTO_API void rto_rng_f32(uint64_t *state, int64_t n, float *out) {
+    const float scale = 1.0f / (float)(1ull << 40);
+    for (int64_t i = 0; i < n; i++) {
+        uint64_t v = xorshift_next(state) >> (64 - 40);
+        out[i] = (float)v * scale;
+    }
+}
+/* rng.rs:49-66: low bits of the 64-bit value */
+RTO_API void rto_rng_u8(uint64_t *state, int64_t n, uint8_t *out) {
+    for (int64_t i = 0; i < n; i++) out[i] = (uint8_t)xorshift_next(state);
+}
+RTO_API void rto_rng_i8(uint64_t *state, int64_t n, int8_t *out) {
+    for (int64_t i = 0; i < n; i++) out[i] = (int8_t)xorshift_next(state);
+}
+RTO_API void rto_rng_i32(uint64_t *state, int64_t n, int32_t *out) {
+    for (int64_t i = 0; i < n; i++) out[i] = (int32_t)xorshift_next(state);
+}
+/* reduced_range_rng.rs:38-57 */
+RTO_API void rto_rng_i8_reduced(uint64_t *state, int64_t n, int8_t *out) {
+    for (int64_t i = 0; i < n; i++) out[i] = (int8_t)((int16_t)(xorshift_next(state) % 128) - 64);
+}
+RTO_API void rto_rng_u8_reduced(uint64_t *state, int64_t n, uint8_t *out) {
+    for (int64_t i = 0; i < n; i++) out[i] = (uint8_t)(xorshift_next(state) % 128);
+}
+
+/* ------------------------------------------------------------------------------------
+ * Output size / padding -- src/ops/pooling.rs:63-159
+ * pad_mode: 0 = fixed pads[4] = top,left,bottom,right ; 1 = SAME (SAME_UPPER)
+ * round_mode: 0 floor, 1 ceil.  Returns 0 on success, else an error code whose message is
+ * the reference's OpError string (see rto_strerror).
+ * ---------------------------------------------------------------------------------- */
+enum {
+    RTO_OK = 0,
+    RTO_E_DILATION = 1,   /* "Dilations must be > 0" */
+    RTO_E_KERNEL = 2,     /* "Kernel size must be > 0" */
+    RTO_E_STRIDE = 3,     /* "Strides must be > 0" */
+    RTO_E_TOO_SMALL = 4,  /* "Input too small for kernel size" */
+};
+
+RTO_API const char *rto_strerror(int code) {
+    switch (code) {
+    case RTO_OK: return "ok";
+    case RTO_E_DILATION: return "Dilations must be > 0";
+    case RTO_E_KERNEL: return "Kernel size must be > 0";
+    case RTO_E_STRIDE: return "Strides must be > 0";
+    case RTO_E_TOO_SMALL: return "Input too small for kernel size";
+    default: return "unknown";
+    }
+}
+
+static int axis_out_pad(int64_t in, int64_t k, int64_t stride, int same, int64_t ps, int64_t pe,
+                        int64_t dil, int ceil_mode, int64_t *out, int64_t *pad_s, int64_t *pad_e) {
+    if (dil <= 0) return RTO_E_DILATION;     /* pooling.rs:71 */
+    if (k <= 0) return RTO_E_KERNEL;         /* pooling.rs:72 */
+    if (stride <= 0) return RTO_E_STRIDE;    /* pooling.rs:73 */
+    if (same) {                              /* pooling.rs:76-93 */
+        int64_t o = (in + stride - 1) / stride;
+        int64_t need = (o - 1) * stride + (k - 1) * dil + 1;
+        int64_t total = need > in ? need - in : 0;
+        *out = o;
+        *pad_s = total / 2;
+        *pad_e = (total + 1) / 2;
+        return RTO_OK;
+    }
+    int64_t padded = in + ps + pe;           /* pooling.rs:94-122 */
+    int64_t dk = k + (k - 1) * (dil - 1);
+    if (padded < dk) return RTO_E_TOO_SMALL;
+    int64_t win = padded - dil * (k - 1) - 1;
+    int64_t o = ceil_mode ? (win + stride - 1) / stride + 1 : win / stride + 1;
+    if (ceil_mode && (o - 1) * stride >= in + ps) o -= 1;
+    *out = o;
+    *pad_s = ps;
+    *pad_e = pe;
+    return RTO_OK;
+}
+
+RTO_API int rto_calc_output_size_and_padding(int64_t in_h, int64_t in_w, int64_t k_h, int64_t k_w,
+                                             int64_t s_h, int64_t s_w, int same,
+                                             const int64_t pads[4], int64_t d_h, int64_t d_w,
+                                             int ceil_mode, int64_t out[2], int64_t out_pads[4]) {
+    int64_t pt = same ? 0 : pads[0], pl = same ? 0 : pads[1];
+    int64_t pb = same ? 0 : pads[2], pr = same ? 0 : pads[3];
+    int rc = axis_out_pad(in_h, k_h, s_h, same, pt, pb, d_h, ceil_mode, &out[0], &out_pads[0], &out_pads[2]);
+    if (rc) return rc;
+    rc = axis_out_pad(in_w, k_w, s_w, same, pl, pr, d_w, ceil_mode, &out[1], &out_pads[1], &out_pads[3]);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------
+ * f32 GEMM -- rten-gemm/src/lib.rs:794-1093 (gemm_impl), :1128-1259 (gemm_block),
+ * kernels/simd_generic.rs:285-414 (micro-kernel incl. alpha/beta store cases).
+ *
+ * Numerics restated: depth is split into blocks of kc = min(256, K) (lib.rs:630-633,
+ * 1024/size_of::<f32>()).  Per output element and depth block the micro-kernel runs a
+ * k-ordered fused-multiply-add chain starting from 0.0 (simd_generic.rs:326-367) and then
+ * stores with one of four (alpha,beta) forms (:378-414); the first block uses the caller's
+ * beta, later blocks beta = 1 (lib.rs:1008-1013 `effective_beta`).  The bias is added after
+ * the first depth block only (lib.rs:1221-1255).  Every output element is an independent
+ * chain, so the result does not depend on MR/NR, thread count or ISA (all f32 kernels use
+ * fused mul_add).  The M == 1 gemv fast path (lib.rs:876-891, simd_generic.rs:14-197) uses
+ * ISA-dependent orders and is NOT restated; M == 1 goes through the same blocked order and
+ * parity for it is by tolerance only.
+ *
+ * B is "virtual": element (k, n) comes from a callback so that dense, transposed and im2col
+ * inputs share the code (the reference does the same via packing, lib.rs:958-1003).
+ * ---------------------------------------------------------------------------------- */
+#define RTO_KC_F32 256
+#define RTO_NR 64
+#define RTO_MR 4
+
+typedef struct {
+    /* dense */
+    const float *b;
+    int64_t rs, cs;
+    /* im2col (rten-gemm/src/im2col.rs:56-88,145-208): row r -> (chan, ky, kx); col c -> (oy, ox) */
+    const float *img;
+    int64_t C, H, W, kh, kw, OH, OW, sy, sx, dy, dx, pt, pl;
+    int is_im2col;
+} bsrc_f32;
+
+/* pack rows [k0,k1) x cols [n0,n0+nr) of virtual B into panel[(k-k0)*RTO_NR + j] (zero padded) */
+static void pack_b_f32(const bsrc_f32 *s, int64_t k0, int64_t k1, int64_t n0, int64_t nr, float *panel) {
+    if (!s->is_im2col) {
+        for (int64_t k = k0; k < k1; k++) {
+            float *row = panel + (k - k0) * RTO_NR;
+            const float *src = s->b + k * s->rs + n0 * s->cs;
+            if (s->cs == 1) {
+                memcpy(row, src, (size_t)nr * sizeof(float));
+            } else {
+                for (int64_t j = 0; j < nr; j++) row[j] = src[j * s->cs];
+            }
+            for (int64_t j = nr; j < RTO_NR; j++) row[j] = 0.f;
+        }
+        return;
+    }
+    const int64_t khw = s->kh * s->kw;
+    for (int64_t k = k0; k < k1; k++) {
+        float *row = panel + (k - k0) * RTO_NR;
+        int64_t c = k / khw, rem = k % khw, ky = rem / s->kw, kx = rem % s->kw;
+        const float *chan = s->img + c * s->H * s->W;
+        int64_t oy = n0 / s->OW, ox = n0 % s->OW;
+        for (int64_t j = 0; j < nr; j++) {
+            int64_t iy = oy * s->sy + ky * s->dy - s->pt;
+            int64_t ix = ox * s->sx + kx * s->dx - s->pl;
+            /* im2col.rs:188-203: out-of-image elements are written as 0 */
+            row[j] = (iy >= 0 && iy < s->H && ix >= 0 && ix < s->W) ? chan[iy * s->W + ix] : 0.f;
+            if (++ox == s->OW) { ox = 0; oy++; }
+        }
+        for (int64_t j = nr; j < RTO_NR; j++) row[j] = 0.f;
+    }
+}
+
+/* bias_kind: 0 none, 1 per-row (BiasVector::Column, indexed by m), 2 per-column (BiasVector::Row, by n) */
+static void gemm_f32_core(int64_t M, int64_t N, int64_t K, const float *A, int64_t a_rs, int64_t a_cs,
+                          const bsrc_f32 *bs, float *C, int64_t ldc, float alpha, float beta,
+                          const float *bias, int bias_kind) {
+    if (M == 0 || N == 0) return;              /* lib.rs:835-839 */
+    if (K == 0) {                              /* lib.rs:843-873 */
+        for (int64_t m = 0; m < M; m++)
+            for (int64_t n = 0; n < N; n++) {
+                float v = (beta == 0.f) ? 0.f : C[m * ldc + n] * beta;
+                if (bias_kind == 1) v = v + bias[m];
+                else if (bias_kind == 2) v = v + bias[n];
+                C[m * ldc + n] = v;
+            }
+        return;
+    }
+    const int64_t kc = K < RTO_KC_F32 ? K : RTO_KC_F32;
+    float *panel = (float *)aligned_alloc(64, (size_t)kc * RTO_NR * sizeof(float));
+    float *apack = (float *)aligned_alloc(64, (size_t)kc * RTO_MR * sizeof(float) + 64);
+    for (int64_t n0 = 0; n0 < N; n0 += RTO_NR) {
+        int64_t nr = N - n0 < RTO_NR ? N - n0 : RTO_NR;
+        for (int64_t k0 = 0; k0 < K; k0 += kc) {
+            int64_t k1 = k0 + kc < K ? k0 + kc : K;
+            int64_t depth = k1 - k0;
+            pack_b_f32(bs, k0, k1, n0, nr, panel);
+            float eff_beta = (k0 == 0) ? beta : 1.f;
+            for (int64_t m0 = 0; m0 < M; m0 += RTO_MR) {
+                int64_t mr = M - m0 < RTO_MR ? M - m0 : RTO_MR;
+                for (int64_t k = 0; k < depth; k++)
+                    for (int64_t i = 0; i < RTO_MR; i++)
+                        apack[k * RTO_MR + i] = i < mr ? A[(m0 + i) * a_rs + (k0 + k) * a_cs] : 0.f;
+                float acc[RTO_MR][RTO_NR];
+                for (int i = 0; i < RTO_MR; i++)
+                    for (int j = 0; j < RTO_NR; j++) acc[i][j] = 0.f;
+                for (int64_t k = 0; k < depth; k++) {
+                    const float *brow = panel + k * RTO_NR;
+                    for (int i = 0; i < RTO_MR; i++) {
+                        float a = apack[k * RTO_MR + i];
+                        for (int j = 0; j < RTO_NR; j++) acc[i][j] = fma32(a, brow[j], acc[i][j]);
+                    }
+                }
+                for (int64_t i = 0; i < mr; i++) {
+                    float *crow = C + (m0 + i) * ldc + n0;
+                    for (int64_t j = 0; j < nr; j++) {
+                        float t = acc[i][j], v;
+                        /* simd_generic.rs:378-414 */
+                        if (eff_beta == 0.f && alpha == 1.f) v = t;
+                        else if (eff_beta == 1.f && alpha == 1.f) v = crow[j] + t;
+                        else if (eff_beta == 0.f) v = t * alpha;
+                        else v = fma32(t, alpha, crow[j] * eff_beta);
+                        if (k0 == 0) {        /* lib.rs:1221-1255 */
+                            if (bias_kind == 1) v = v + bias[m0 + i];
+                            else if (bias_kind == 2) v = v + bias[n0 + j];
+                        }
+                        crow[j] = v;
+                    }
+                }
+            }
+        }
+    }
+    free(panel);
+    free(apack);
+}
+
+RTO_API void rto_gemm_f32(int64_t M, int64_t N, int64_t K, const float *A, int64_t a_rs, int64_t a_cs,
+                          const float *B, int64_t b_rs, int64_t b_cs, float *C, int64_t ldc,
+                          float alpha, float beta, const float *bias, int bias_kind) {
+    bsrc_f32 bs;
+    memset(&bs, 0, sizeof bs);
+    bs.b = B; bs.rs = b_rs; bs.cs = b_cs;
+    gemm_f32_core(M, N, K, A, a_rs, a_cs, &bs, C, ldc, alpha, beta, bias, bias_kind);
+}
+
+/* batched: rten-gemm/src/lib.rs:329-372.  Strides in elements; a stride of 0 broadcasts. */
+RTO_API void rto_gemm_f32_batched(int64_t batch, int64_t M, int64_t N, int64_t K, const float *A,
+                                  int64_t a_rs, int64_t a_cs, int64_t a_bs, const float *B, int64_t b_rs,
+                                  int64_t b_cs, int64_t b_bs, float *C, int64_t ldc, int64_t c_bs,
+                                  float alpha, const float *bias, int bias_kind) {
+#pragma omp parallel for schedule(dynamic)
+    for (int64_t i = 0; i < batch; i++)
+        rto_gemm_f32(M, N, K, A + i * a_bs, a_rs, a_cs, B + i * b_bs, b_rs, b_cs, C + i * c_bs, ldc,
+                     alpha, 0.f, bias, bias_kind);
+}
+
+/* ------------------------------------------------------------------------------------
+ * f32 Conv -- src/ops/conv.rs:124-365 (conv_impl), :33-87 (pointwise), conv/im2col.rs:11-128.
+ * NCHW input, OIHW kernel (I = C/groups), NCHW output.  Per image and group:
+ * out[O_g, OH*OW] = W_g[O_g, C_g*kh*kw] . im2col(x)[C_g*kh*kw, OH*OW] with bias per out channel
+ * (BiasVector::Column).  The pointwise fast path (conv.rs:250-267) is the same GEMM with the
+ * image viewed as a [C, H*W] matrix, so a single restatement covers both.  The depthwise path
+ * (conv/depthwise.rs) is out of scope (not in the configs) -- depthwise shapes
+ * run through the generic path here, which is what the reference's own tests compare against
+ * (reference_conv, conv.rs:629-747).
+ * Fused extras (not in the reference Conv op; restated as the op sequence the reference graph
+ * runs): residual Add (binary_elementwise.rs:476-495) then Relu (unary_elementwise.rs:611-613).
+ * ---------------------------------------------------------------------------------- */
+RTO_API int rto_conv2d_f32(int64_t N, int64_t C, int64_t H, int64_t W, int64_t O, int64_t kh, int64_t kw,
+                           const int64_t pads[4], const int64_t strides[2], const int64_t dil[2],
+                           int64_t groups, const float *X, const float *Wt, const float *bias,
+                           const float *residual, int relu, float *Y, int64_t OH, int64_t OW) {
+    const int64_t Cg = C / groups, Og = O / groups, Kg = Cg * kh * kw, P = OH * OW;
+#pragma omp parallel for collapse(2) schedule(dynamic)
+    for (int64_t n = 0; n < N; n++) {
+        for (int64_t g = 0; g < groups; g++) {
+            bsrc_f32 bs;
+            memset(&bs, 0, sizeof bs);
+            bs.is_im2col = 1;
+            bs.img = X + (n * C + g * Cg) * H * W;
+            bs.C = Cg; bs.H = H; bs.W = W; bs.kh = kh; bs.kw = kw; bs.OH = OH; bs.OW = OW;
+            bs.sy = strides[0]; bs.sx = strides[1]; bs.dy = dil[0]; bs.dx = dil[1];
+            bs.pt = pads[0]; bs.pl = pads[1];
+            float *out = Y + (n * O + g * Og) * P;
+            gemm_f32_core(Og, P, Kg, Wt + g * Og * Kg, Kg, 1, &bs, out, P, 1.f, 0.f,
+                          bias ? bias + g * Og : NULL, bias ? 1 : 0);
+            if (residual || relu) {
+                const float *res = residual ? residual + (n * O + g * Og) * P : NULL;
+                for (int64_t i = 0; i < Og * P; i++) {
+                    float v = out[i];
+                    if (res) v = v + res[i];
+                    if (relu) v = fmaxf(v, 0.f); /* f32::max: NaN -> 0 */
+                    out[i] = v;
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * Integer GEMM -- rten-gemm/src/kernels/generic.rs:274-366 and tests.rs:90-133:
+ *   C[m,n] (+)= sum_k (A[m,k] - a_zp[m]) * (B[k,n] - b_zp[n])   in wrapping i32
+ * The reference's kernels take u8 LHS x i8 RHS; the operator front-ends shift-cast other
+ * signedness combos (src/shift_cast.rs:39-50), which leaves the mathematical value of every
+ * (x - zp) unchanged, so the oracle works on widened integers directly.
+ * a_signed / b_signed select how the raw bytes are interpreted.
+ * ---------------------------------------------------------------------------------- */
+static inline int32_t ld8(const void *p, int64_t i, int is_signed) {
+    return is_signed ? (int32_t)((const int8_t *)p)[i] : (int32_t)((const uint8_t *)p)[i];
+}
+
+RTO_API void rto_gemm_int8(int64_t M, int64_t N, int64_t K, const void *A, int a_signed, int64_t a_rs,
+                           int64_t a_cs, const void *B, int b_signed, int64_t b_rs, int64_t b_cs,
+                           int32_t *C, int64_t ldc, const void *a_zp, int64_t a_zp_len, const void *b_zp,
+                           int64_t b_zp_len, int beta) {
+#pragma omp parallel for schedule(static)
+    for (int64_t m = 0; m < M; m++) {
+        int32_t az = a_zp ? ld8(a_zp, a_zp_len == 1 ? 0 : m, a_signed) : 0;
+        for (int64_t n = 0; n < N; n++) {
+            int32_t bz = b_zp ? ld8(b_zp, b_zp_len == 1 ? 0 : n, b_signed) : 0;
+            uint32_t acc = 0;
+            for (int64_t k = 0; k < K; k++) {
+                int32_t a = ld8(A, m * a_rs + k * a_cs, a_signed) - az;
+                int32_t b = ld8(B, k * b_rs + n * b_cs, b_signed) - bz;
+                acc += (uint32_t)(a * b);
+            }
+            if (beta) acc += (uint32_t)C[m * ldc + n];
+            C[m * ldc + n] = (int32_t)acc;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------
+ * Integer Conv -- src/ops/conv.rs:421-476 (conv_integer) -> conv_impl::<i8,u8,i32>.
+ * Y_i32[n,o,p] = sum_k (W[o,k] - w_zp[o]) * (col[k,p] - x_zp)
+ * pad_mode selects what a padded (out-of-image) im2col element is worth, SURVEY App. C.1:
+ *   0 ZERO_POINT : contributes 0 (ONNX / depthwise semantics, conv/depthwise.rs:160-182)
+ *   1 RAW0_I8    : x86/generic reference: raw 0 written AFTER the u8->i8 shift cast
+ *                  (rten-gemm/src/im2col.rs:194-198,351-357) == original-domain value of
+ *                  (x_signed ? 0 : 128)
+ *   2 RAW0_U8    : Arm/wasm reference (im2col.rs:349-353): raw 0 in the u8 domain == original-
+ *                  domain value (x_signed ? -128 : 0)
+ * ---------------------------------------------------------------------------------- */
+RTO_API int rto_conv2d_int8(int64_t N, int64_t C, int64_t H, int64_t W, int64_t O, int64_t kh, int64_t kw,
+                            const int64_t pads[4], const int64_t strides[2], const int64_t dil[2],
+                            int64_t groups, const void *X, int x_signed, const void *Wt, int w_signed,
+                            int32_t x_zp, const void *w_zp, int64_t w_zp_len, int pad_mode, int32_t *Y,
+                            int64_t OH, int64_t OW) {
+    const int64_t Cg = C / groups, Og = O / groups, P = OH * OW;
+    int32_t pad_val;
+    if (pad_mode == 0) pad_val = x_zp;
+    else if (pad_mode == 1) pad_val = x_signed ? 0 : 128;
+    else pad_val = x_signed ? -128 : 0;
+#pragma omp parallel for collapse(2) schedule(dynamic)
+    for (int64_t n = 0; n < N; n++) {
+        for (int64_t o = 0; o < O; o++) {
+            int64_t g = o / Og;
+            int32_t wz = w_zp ? ld8(w_zp, w_zp_len == 1 ? 0 : o, w_signed) : 0;
+            for (int64_t oy = 0; oy < OH; oy++)
+                for (int64_t ox = 0; ox < OW; ox++) {
+                    uint32_t acc = 0;
+                    for (int64_t c = 0; c < Cg; c++)
+                        for (int64_t ky = 0; ky < kh; ky++)
+                            for (int64_t kx = 0; kx < kw; kx++) {
+                                int64_t iy = oy * strides[0] + ky * dil[0] - pads[0];
+                                int64_t ix = ox * strides[1] + kx * dil[1] - pads[1];
+                                int32_t xv = (iy >= 0 && iy < H && ix >= 0 && ix < W)
+                                                 ? ld8(X, ((n * C + g * Cg + c) * H + iy) * W + ix, x_signed)
+                                                 : pad_val;
+                                int32_t wv = ld8(Wt, ((o * Cg + c) * kh + ky) * kw + kx, w_signed);
+                                acc += (uint32_t)((wv - wz) * (xv - x_zp));
+                            }
+                    Y[(n * O + o) * P + oy * OW + ox] = (int32_t)acc;
+                }
+        }
+    }
+    return 0;
+}
+
+/* cast_scale -- src/ops/matmul.rs:734-773: (i32 as f32) * scale, scalar or per last-axis column */
+RTO_API void rto_cast_scale(int64_t n, const int32_t *x, const float *scale, int64_t scale_len, float *y) {
+    for (int64_t i = 0; i < n; i++) y[i] = (float)x[i] * scale[scale_len == 1 ? 0 : i % scale_len];
+}
+
+/* ------------------------------------------------------------------------------------
+ * DynamicQuantizeLinear -- src/ops/quantize.rs:352-436, :171-176,
+ * rten-vecmath/src/quantize.rs:39-79, min_max.rs:20-44.
+ * ---------------------------------------------------------------------------------- */
+static inline float f32_min(float a, float b) { return fminf(a, b); } /* Rust f32::min: ignores NaN */
+static inline float f32_max(float a, float b) { return fmaxf(a, b); }
+
+static inline uint8_t sat_u8_from_f32(float v) { /* Rust `as u8`: saturating, NaN -> 0 */
+    if (!(v == v)) return 0;
+    if (v <= 0.f) return 0;
+    if (v >= 255.f) return 255;
+    return (uint8_t)v;
+}
+
+RTO_API void rto_dynamic_quantize_linear(int64_t n, const float *x, uint8_t *y, float *scale_out,
+                                         uint8_t *zp_out) {
+    if (n == 0) { *scale_out = 1.f; *zp_out = 0; return; } /* quantize.rs:385-392 */
+    float x_min = INFINITY, x_max = -INFINITY;
+    for (int64_t i = 0; i < n; i++) {
+        /* SIMD min/max (min_max.rs:24-31) drop NaNs the way x86 min/max(x, acc) do: if x is NaN the
+           accumulator is returned.  fminf/fmaxf have the same NaN-ignoring result. */
+        x_min = f32_min(x[i], x_min);
+        x_max = f32_max(x[i], x_max);
+    }
+    float x_min_adj = f32_min(x_min, 0.f);
+    float x_max_adj = f32_max(x_max, 0.f);
+    float range = x_max_adj - x_min_adj;
+    float scale = range / 255.f;
+    float min_scaled = x_min_adj / scale;
+    float init_zp = 0.f - min_scaled;
+    /* f32::clamp(0,255): NaN stays NaN */
+    float clipped = init_zp < 0.f ? 0.f : (init_zp > 255.f ? 255.f : init_zp);
+    float rounded = nearbyintf(clipped); /* round_ties_even under default rounding mode */
+    uint8_t zp = sat_u8_from_f32(rounded < 0.f ? 0.f : (rounded > 255.f ? 255.f : rounded));
+    if (!(rounded == rounded)) zp = 0;
+    *scale_out = scale;
+    *zp_out = zp;
+    float inv_scale = 1.f / scale; /* quantize.rs:210 */
+    for (int64_t i = 0; i < n; i++) {
+        /* vecmath/quantize.rs:57-62 (SIMD body) and :70-74 (tail) agree for all finite products:
+           round-to-nearest-even to i32, add zero point as integer, saturate to [0,255].
+           Non-finite products: the SIMD path converts NaN/out-of-range to i32::MIN -> 0; the scalar
+           path's `as i32` gives 0 for NaN (then + zp).  Both give 0 when zp == 0, which is the only
+           case reachable from DQL (scale == 0 => zp == 0). */
+        float p = x[i] * inv_scale;
+        int32_t q;
+        if (!(p == p)) q = INT32_MIN;
+        else if (p >= 2147483648.f || p < -2147483648.f) q = INT32_MIN;
+        else q = (int32_t)nearbyintf(p);
+        int64_t t = (int64_t)q + (int64_t)zp;
+        y[i] = (uint8_t)(t < 0 ? 0 : (t > 255 ? 255 : t));
+    }
+}
+
+/* ------------------------------------------------------------------------------------
+ * exp / erf / gelu -- rten-vecmath/src/exp.rs:59-132 (Exp), :140-190 (ReducedRangeExp),
+ * erf.rs:21-76.  All elementwise, restated op-for-op (mul_add -> fmaf) => bit-exact.
+ * ---------------------------------------------------------------------------------- */
+static const float INV_LOG2 = 1.44269504088896340736f; /* std::f32::consts::LOG2_E */
+static const float ROUNDING_MAGIC = 12582912.f;
+static const float LOG2_HI = -6.93145752e-1f;
+static const float LOG2_LO = -1.42860677e-6f;
+static const float EXP_P0 = 1.0f, EXP_P1 = 1.0f, EXP_P2 = 4.99999851e-1f, EXP_P3 = 1.66664720e-1f,
+                   EXP_P4 = 4.16695364e-2f, EXP_P5 = 8.37312452e-3f, EXP_P6 = 1.37805939e-3f;
+
+static inline float bits_f32(int32_t i) { float f; memcpy(&f, &i, 4); return f; }
+
+static inline float exp_poly_reduce(float x, float *jout) {
+    float j = fma32(x, INV_LOG2, ROUNDING_MAGIC);
+    j = j - ROUNDING_MAGIC;
+    float r = fma32(j, LOG2_HI, x);
+    r = fma32(j, LOG2_LO, r);
+    float t = EXP_P6;
+    t = fma32(t, r, EXP_P5);
+    t = fma32(t, r, EXP_P4);
+    t = fma32(t, r, EXP_P3);
+    t = fma32(t, r, EXP_P2);
+    t = fma32(t, r, EXP_P1);
+    r = fma32(t, r, EXP_P0);
+    *jout = j;
+    return r;
+}
+
+RTO_API float rto_exp_f32(float x) { /* exp.rs:59-132 */
+    float j;
+    float r = exp_poly_reduce(x, &j);
+    int32_t k = (int32_t)j; /* to_int_trunc; j is integral */
+    int32_t ia = (k > 0) ? 0 : (int32_t)0x83000000u;
+    int32_t is = (int32_t)((uint32_t)ia + 0x7f000000u);
+    int32_t it = (int32_t)(((uint32_t)k << 23) - (uint32_t)ia);
+    r = r * bits_f32(is);
+    r = r * bits_f32(it);
+    if (x >= 104.0f) r = INFINITY;
+    if (x <= -104.0f) r = 0.f;
+    return r;
+}
+
+static const float EXP_LOWER_CUTOFF = -126.5f * 0.693147180559945309417f + 0.01f; /* exp.rs:131 */
+
+RTO_API float rto_exp_reduced_f32(float x) { /* exp.rs:140-190; requires x <= 0 */
+    float j;
+    float r = exp_poly_reduce(x, &j);
+    int32_t k = (int32_t)j;
+    int32_t kp = (int32_t)((uint32_t)(k + 127) << 23);
+    r = r * bits_f32(kp);
+    if (x < EXP_LOWER_CUTOFF) r = 0.f;
+    return r;
+}
+
+RTO_API float rto_erf_f32(float x0) { /* erf.rs:21-59 */
+    int neg = x0 < 0.f;
+    float x = neg ? (0.f - x0) : x0; /* abs via select(neg(x), x, x<0) (ops.rs:649-651) */
+    const float p = 0.3275911f;
+    const float a0 = 0.254829592f, a1 = -0.284496736f, a2 = 1.421413741f, a3 = -1.453152027f,
+                a4 = 1.061405429f;
+    float t = 1.0f / fma32(x, p, 1.0f);
+    /* poly_eval (rten-simd/src/ops.rs:571-577): Horner from the last coeff, then * t */
+    float y = a4;
+    y = fma32(y, t, a3);
+    y = fma32(y, t, a2);
+    y = fma32(y, t, a1);
+    y = fma32(y, t, a0);
+    float at = y * t;
+    float xm2 = 0.f - (x * x);
+    float e = rto_exp_reduced_f32(xm2);
+    float r = 1.0f - at * e;
+    return neg ? (0.f - r) : r;
+}
+
+static const float SQRT_2_RCP = 0.70710678118654752440f; /* 1.0 / SQRT_2 in f32 (erf.rs:61) */
+
+RTO_API float rto_gelu_f32(float x) { /* erf.rs:63-76 */
+    float half_x = x * 0.5f;
+    float y = x * SQRT_2_RCP;
+    y = rto_erf_f32(y) + 1.0f;
+    return half_x * y;
+}
+
+RTO_API void rto_gelu(int64_t n, const float *x, float *y) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) y[i] = rto_gelu_f32(x[i]);
+}
+RTO_API void rto_erf(int64_t n, const float *x, float *y) {
+    for (int64_t i = 0; i < n; i++) y[i] = rto_erf_f32(x[i]);
+}
+RTO_API void rto_exp(int64_t n, const float *x, float *y) {
+    for (int64_t i = 0; i < n; i++) y[i] = rto_exp_f32(x[i]);
+}
+/* Relu -- unary_elementwise.rs:611-613 `val.max(0.)` */
+RTO_API void rto_relu(int64_t n, const float *x, float *y) {
+    for (int64_t i = 0; i < n; i++) y[i] = fmaxf(x[i], 0.f);
+}
+/* Add (same shape, or b broadcast with period b_len along the flattened index) --
+   binary_elementwise.rs:476-495 */
+RTO_API void rto_add(int64_t n, const float *a, const float *b, int64_t b_len, float *y) {
+    for (int64_t i = 0; i < n; i++) y[i] = a[i] + b[b_len == n ? i : i % b_len];
+}
+
+/* ------------------------------------------------------------------------------------
+ * SIMD-ordered reductions.  The reference's vecmath reductions keep V-lane partial sums and
+ * combine them at the end (rten-simd/src/iter.rs:97-120 fold_unroll<4>, sum.rs:27-33), so the
+ * result depends on the ISA's lane count V (16 for AVX-512, 8 AVX2, 4 NEON/wasm/generic? see
+ * `lanes` argument).  The oracle reproduces the order for a given V; GPU parity for reductions is
+ * by tolerance, with V = 16 (the GPU box class host, AVX-512) as the default.
+ *   fold_unroll<4>: 4 vector accumulators over chunks of 4V, acc0 += acc1, += acc2, += acc3,
+ *   then remaining full vectors fold into acc0, then a masked tail (iter.rs fold: masked lanes keep
+ *   their old value), then lanes are summed left to right starting from 0.
+ * kind: 0 sum(x), 1 sum((x-off)^2) via mul_add, 2 sum(x*x) via mul_add
+ * ---------------------------------------------------------------------------------- */
+static float simd_reduce(const float *x, int64_t n, int V, int kind, float off) {
+    float acc[4][64];
+    for (int u = 0; u < 4; u++)
+        for (int l = 0; l < V; l++) acc[u][l] = 0.f;
+    int64_t i = 0;
+    for (; i + 4 * V <= n; i += 4 * V)
+        for (int u = 0; u < 4; u++)
+            for (int l = 0; l < V; l++) {
+                float v = x[i + u * V + l];
+                if (kind == 0) acc[u][l] = acc[u][l] + v;
+                else if (kind == 1) { float d = v - off; acc[u][l] = fma32(d, d, acc[u][l]); }
+                else acc[u][l] = fma32(v, v, acc[u][l]);
+            }
+    for (int u = 1; u < 4; u++)
+        for (int l = 0; l < V; l++) acc[0][l] = acc[0][l] + acc[u][l];
+    for (; i + V <= n; i += V)
+        for (int l = 0; l < V; l++) {
+            float v = x[i + l];
+            if (kind == 0) acc[0][l] = acc[0][l] + v;
+            else if (kind == 1) { float d = v - off; acc[0][l] = fma32(d, d, acc[0][l]); }
+            else acc[0][l] = fma32(v, v, acc[0][l]);
+        }
+    for (int l = 0; i + l < n; l++) {
+        float v = x[i + l];
+        if (kind == 0) acc[0][l] = acc[0][l] + v;
+        else if (kind == 1) { float d = v - off; acc[0][l] = fma32(d, d, acc[0][l]); }
+        else acc[0][l] = fma32(v, v, acc[0][l]);
+    }
+    float s = 0.f;
+    for (int l = 0; l < V; l++) s = s + acc[0][l];
+    return s;
+}
+
+RTO_API float rto_simd_sum(const float *x, int64_t n, int lanes) { return simd_reduce(x, n, lanes, 0, 0.f); }
+
+/* Softmax -- rten-vecmath/src/softmax.rs:60-100,178-228.  max starts at f32::MIN; exp via
+   ReducedRangeExp(x - max); sum in V-lane order (single accumulator, softmax.rs:204-224);
+   normalise by multiplying with reciprocal(sum) = 1/sum (ops.rs:639-641). */
+RTO_API void rto_softmax_row(int64_t n, const float *x, const float *addend, float *y, int flush_nan,
+                             int lanes) {
+    if (n == 0) return;
+    float tmp_stack[1024];
+    float *t = n <= 1024 ? tmp_stack : (float *)malloc((size_t)n * sizeof(float));
+    for (int64_t i = 0; i < n; i++) t[i] = addend ? x[i] + addend[i] : x[i]; /* attention.rs:59-61 */
+    float mx = -FLT_MAX;
+    for (int64_t i = 0; i < n; i++) mx = fmaxf(mx, t[i]); /* softmax.rs:180-192; order-independent for non-NaN data */
+    float acc[64];
+    for (int l = 0; l < lanes; l++) acc[l] = 0.f;
+    for (int64_t i = 0; i < n; i++) {
+        float e = rto_exp_reduced_f32(t[i] - mx);
+        t[i] = e;
+        acc[i % lanes] = acc[i % lanes] + e;
+    }
+    float s = 0.f;
+    for (int l = 0; l < lanes; l++) s = s + acc[l];
+    float inv = 1.0f / s;
+    for (int64_t i = 0; i < n; i++) {
+        float v = t[i] * inv;
+        if (flush_nan && !(v == v)) v = 0.f;
+        y[i] = v;
+    }
+    if (t != tmp_stack) free(t);
+}
+
+/* rows x cols softmax along the last axis.  addend (optional) is broadcast: row r uses
+   addend + (r / add_div % add_mod) * cols -- covers the [B,1,1,S] mask against [B,H,S,S] scores
+   (add_div = H*S, add_mod = B) and the same-shape case (add_div = 1, add_mod = rows). */
+RTO_API void rto_softmax(int64_t rows, int64_t cols, const float *x, const float *addend, int64_t add_div,
+                         int64_t add_mod, float *y, int flush_nan, int lanes) {
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < rows; r++) {
+        const float *a = addend ? addend + ((r / add_div) % add_mod) * cols : NULL;
+        rto_softmax_row(cols, x + r * cols, a, y + r * cols, flush_nan, lanes);
+    }
+}
+
+/* LayerNormalization -- src/ops/norm.rs:103-161 (normalize_slice), :456-529;
+   rten-vecmath/src/normalize.rs:82-170.  gamma/beta: NULL => use the scalars. */
+RTO_API void rto_layer_norm(int64_t rows, int64_t cols, const float *x, const float *gamma,
+                            const float *beta, float gamma_scalar, float beta_scalar, float eps, float *y,
+                            int lanes) {
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < rows; r++) {
+        const float *in = x + r * cols;
+        float *out = y + r * cols;
+        float mean = simd_reduce(in, cols, lanes, 0, 0.f) / (float)cols;          /* norm.rs:124 */
+        float var = simd_reduce(in, cols, lanes, 1, mean) / (float)cols;         /* norm.rs:125 */
+        float ssr = gamma_scalar / sqrtf(var + eps);                             /* norm.rs:146 */
+        if (!gamma && !beta) {               /* normalize.rs:112-127 */
+            for (int64_t i = 0; i < cols; i++) out[i] = fma32(in[i] - mean, ssr, beta_scalar);
+        } else if (gamma && !beta && beta_scalar == 0.f) { /* normalize.rs:128-145 */
+            for (int64_t i = 0; i < cols; i++) out[i] = (in[i] - mean) * (gamma[i] * ssr);
+        } else {                             /* normalize.rs:146-166 */
+            for (int64_t i = 0; i < cols; i++) {
+                float sv = (gamma ? gamma[i] : 1.0f) * ssr;
+                float bv = (beta ? beta[i] : 0.f) + beta_scalar;
+                out[i] = fma32(in[i] - mean, sv, bv);
+            }
+        }
+    }
+}
+
+/* BatchNormalization (inference) -- norm.rs:194-224 + normalize.rs:112-127:
+   y = fma(x - mean_c, scale_c / sqrt(var_c + eps), bias_c) */
+RTO_API void rto_batch_norm(int64_t N, int64_t C, int64_t inner, const float *x, const float *scale,
+                            const float *bias, const float *mean, const float *var, float eps, float *y) {
+    for (int64_t n = 0; n < N; n++)
+        for (int64_t c = 0; c < C; c++) {
+            float ssr = scale[c] / sqrtf(var[c] + eps);
+            const float *in = x + (n * C + c) * inner;
+            float *out = y + (n * C + c) * inner;
+            for (int64_t i = 0; i < inner; i++) out[i] = fma32(in[i] - mean[c], ssr, bias[c]);
+        }
+}
+
+/* ------------------------------------------------------------------------------------
+ * Pooling -- src/ops/pooling.rs:174-389 (pool_impl), :392-417 (average), :581-600 (max),
+ * :477-521 (global).  Padding cells are skipped; window is walked ky-major then kx.
+ * ---------------------------------------------------------------------------------- */
+RTO_API void rto_pool2d(int64_t N, int64_t C, int64_t H, int64_t W, int64_t kh, int64_t kw, int64_t sh,
+                        int64_t sw, int64_t pt, int64_t pl, int64_t OH, int64_t OW, const float *x,
+                        float *y, int is_max, int count_include_pad) {
+#pragma omp parallel for schedule(static)
+    for (int64_t nc = 0; nc < N * C; nc++) {
+        const float *in = x + nc * H * W;
+        float *out = y + nc * OH * OW;
+        for (int64_t oy = 0; oy < OH; oy++)
+            for (int64_t ox = 0; ox < OW; ox++) {
+                float acc = is_max ? -INFINITY : 0.f;
+                int64_t cnt = 0;
+                for (int64_t ky = 0; ky < kh; ky++)
+                    for (int64_t kx = 0; kx < kw; kx++) {
+                        int64_t iy = oy * sh + ky, ix = ox * sw + kx;
+                        if (iy >= pt && iy < H + pt && ix >= pl && ix < W + pl) {
+                            float v = in[(iy - pt) * W + (ix - pl)];
+                            acc = is_max ? fmaxf(acc, v) : acc + v;
+                            cnt++;
+                        }
+                    }
+                if (!is_max) acc = count_include_pad ? acc / (float)(kh * kw) : acc / (float)cnt;
+                out[oy * OW + ox] = acc;
+            }
+    }
+}
+
+/* GlobalAveragePool -- pooling.rs:516-521: vecmath::Sum / len */
+RTO_API void rto_global_avg_pool(int64_t NC, int64_t inner, const float *x, float *y, int lanes) {
+    for (int64_t i = 0; i < NC; i++) y[i] = simd_reduce(x + i * inner, inner, lanes, 0, 0.f) / (float)inner;
+}
+
+/* ------------------------------------------------------------------------------------
+ * Scaled dot-product attention for one (batch, head) -- src/ops/attention.rs:518-562:
+ * scores = scale * Q K^T (gemm alpha), row softmax with NaN flush (+ optional additive mask row
+ * applied by score_mod), out = scores . V
+ * q:[S,D] k:[T,D] v:[T,Dv] mask:[S,T] or NULL (mask_rs: row stride, 0 = broadcast row)
+ * ---------------------------------------------------------------------------------- */
+RTO_API void rto_sdpa_head(int64_t S, int64_t T, int64_t D, int64_t Dv, const float *q, const float *k,
+                           const float *v, const float *mask, int64_t mask_rs, float scale, float *out,
+                           int lanes) {
+    float *scores = (float *)malloc((size_t)S * T * sizeof(float));
+    rto_gemm_f32(S, T, D, q, D, 1, k, 1, D, scores, T, scale, 0.f, NULL, 0);
+    for (int64_t s = 0; s < S; s++)
+        rto_softmax_row(T, scores + s * T, mask ? mask + s * mask_rs : NULL, scores + s * T, 1, lanes);
+    rto_gemm_f32(S, Dv, T, scores, T, 1, v, Dv, 1, out, Dv, 1.f, 0.f, NULL, 0);
+    free(scores);
+}
+
+RTO_API void rto_sdpa(int64_t BH, int64_t S, int64_t T, int64_t D, int64_t Dv, const float *q,
+                      const float *k, const float *v, const float *mask, int64_t mask_bh_div,
+                      int64_t mask_rs, float scale, float *out, int lanes) {
+#pragma omp parallel for schedule(dynamic)
+    for (int64_t i = 0; i < BH; i++) {
+        const float *m = mask ? mask + (i / mask_bh_div) * (mask_rs ? S * T : T) : NULL;
+        rto_sdpa_head(S, T, D, Dv, q + i * S * D, k + i * T * D, v + i * T * Dv, m, mask_rs, scale,
+                      out + i * S * Dv, lanes);
+    }
+}
+
+RTO_API int rto_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
