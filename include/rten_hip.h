@@ -1,0 +1,246 @@
+/*
+ * rten_hip.h -- C ABI of the MI355X (gfx950) operator backend for RTen.
+ *
+ * This is the drop-in boundary: the entry points a Rust `Operator` implementation in RTen binds
+ * through `extern "C"` to replace the rten-gemm / rten-vecmath CPU micro-kernels behind
+ * src/ops/{matmul,conv,attention,norm,pooling,quantize}.  Each declaration cites the reference
+ * interface it replaces (paths relative to the robertknight/rten v0.25.0 checkout); the Rust-side
+ * binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - Plain C types only.  Every tensor pointer is a DEVICE pointer unless the parameter name ends
+ *    in `_host`.  Tensors are contiguous row-major unless strides are given explicitly (strides
+ *    are in ELEMENTS, as in rten-tensor layouts).
+ *  - Every function returns an int32 status (0 = ok).  Validation that the reference performs in
+ *    Rust before touching data (shape checks, error strings) stays on the host side of the ABI;
+ *    the ABI reports RTEN_HIP_ERR_INVALID_VALUE for arguments it cannot execute and
+ *    RTEN_HIP_ERR_HIP for runtime failures, with text in rten_hip_last_error().
+ *  - All work is enqueued on the context's HIP stream and is asynchronous w.r.t. the host;
+ *    rten_hip_sync() (or a D2H copy) makes results visible.  A context is not thread-safe: use one
+ *    context per host thread (Graph::run_plan executes operators sequentially, src/graph.rs:880).
+ *  - Numerics: integer paths are bit-exact w.r.t. the reference.  f32 GEMM/conv reproduce the
+ *    reference's accumulation order exactly (k-ordered FMA chains in depth blocks of 256,
+ *    rten-gemm/src/lib.rs:630-633 + kernels/simd_generic.rs:326-414), element-wise kernels
+ *    (Gelu/Erf/Relu/Add/cast_scale/DQL) are operation-for-operation restatements; only
+ *    reductions (softmax sum, LayerNorm mean/variance, GlobalAveragePool) differ in summation
+ *    order and are held to a stated tolerance.
+ */
+#ifndef RTEN_HIP_H
+#define RTEN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTEN_HIP_ABI_VERSION 1
+
+/* ---- status codes (map onto OpError variants, src/operator.rs:116-144) ---- */
+#define RTEN_HIP_OK 0
+#define RTEN_HIP_ERR_INVALID_VALUE 1 /* -> OpError::InvalidValue */
+#define RTEN_HIP_ERR_INCOMPATIBLE_SHAPES 2 /* -> OpError::IncompatibleInputShapes */
+#define RTEN_HIP_ERR_UNSUPPORTED 3 /* -> OpError::UnsupportedValue */
+#define RTEN_HIP_ERR_HIP 4 /* HIP runtime error; see rten_hip_last_error */
+#define RTEN_HIP_ERR_NO_DEVICE 5 /* no gfx950 device / extension unusable: callers must fail loudly */
+
+typedef struct rten_hip_ctx rten_hip_ctx;
+
+/* ---- context, memory, stream plumbing (new: the reference has no device boundary) ---- */
+
+/* Create a context on `device_id`.  `external_stream` may be NULL (the context creates its own
+ * stream) or a hipStream_t owned by the caller (e.g. torch's current stream). */
+int32_t rten_hip_init(int32_t device_id, void *external_stream, rten_hip_ctx **out_ctx);
+int32_t rten_hip_destroy(rten_hip_ctx *ctx);
+const char *rten_hip_last_error(rten_hip_ctx *ctx);
+int32_t rten_hip_abi_version(void);
+int32_t rten_hip_sync(rten_hip_ctx *ctx);
+/* Device properties used by the measurement harness. */
+int32_t rten_hip_device_info(rten_hip_ctx *ctx, char *name_buf, int32_t name_len, int32_t *compute_units,
+                             int32_t *clock_mhz, int64_t *total_mem_bytes);
+
+int32_t rten_hip_malloc(rten_hip_ctx *ctx, size_t bytes, void **out_dptr);
+int32_t rten_hip_free(rten_hip_ctx *ctx, void *dptr);
+int32_t rten_hip_memcpy_h2d(rten_hip_ctx *ctx, void *dst, const void *src_host, size_t bytes);
+int32_t rten_hip_memcpy_d2h(rten_hip_ctx *ctx, void *dst_host, const void *src, size_t bytes); /* syncs */
+int32_t rten_hip_memcpy_d2d(rten_hip_ctx *ctx, void *dst, const void *src, size_t bytes);
+int32_t rten_hip_memset(rten_hip_ctx *ctx, void *dst, int32_t byte_value, size_t bytes);
+
+/* Event timers on the context's stream (slot in [0, 64)). */
+int32_t rten_hip_timer_start(rten_hip_ctx *ctx, int32_t slot);
+int32_t rten_hip_timer_stop(rten_hip_ctx *ctx, int32_t slot);
+int32_t rten_hip_timer_elapsed_ms(rten_hip_ctx *ctx, int32_t slot, float *out_ms); /* syncs on stop event */
+
+/* hipGraph capture of a launch sequence (the executor's per-run plan, src/graph.rs:880-1286). */
+int32_t rten_hip_graph_begin(rten_hip_ctx *ctx);
+int32_t rten_hip_graph_end(rten_hip_ctx *ctx, uint64_t *out_graph);
+int32_t rten_hip_graph_launch(rten_hip_ctx *ctx, uint64_t graph);
+int32_t rten_hip_graph_destroy(rten_hip_ctx *ctx, uint64_t graph);
+
+/* Per-kernel-class profiling: when enabled, every conv/gemm launch is bracketed by events and its
+ * time and algorithmic work are accumulated per kernel name (Profiler, src/timing.rs).  Not usable
+ * during graph capture. */
+int32_t rten_hip_profile_enable(rten_hip_ctx *ctx, int32_t on);
+int32_t rten_hip_profile_reset(rten_hip_ctx *ctx);
+/* Writes a JSON array [{"kernel":..,"launches":..,"ms":..,"flops":..,"bytes":..},...] (NUL-terminated). */
+int32_t rten_hip_profile_report(rten_hip_ctx *ctx, char *buf, int32_t buf_len);
+
+/* ---- shapes: calc_output_size_and_padding, src/ops/pooling.rs:139-159 (shared by conv + pool) ----
+ * same_padding != 0 selects Padding::Same (SAME_UPPER); otherwise pads = top,left,bottom,right.
+ * Returns RTEN_HIP_ERR_INVALID_VALUE with the reference's message in *err_msg (static string). */
+int32_t rten_hip_calc_output_size_and_padding(int32_t in_h, int32_t in_w, int32_t k_h, int32_t k_w,
+                                              int32_t stride_h, int32_t stride_w, int32_t same_padding,
+                                              const int32_t pads[4], int32_t dil_h, int32_t dil_w,
+                                              int32_t ceil_mode, int32_t out_hw[2], int32_t out_pads[4],
+                                              const char **err_msg);
+
+/* ---- f32 GEMM: GemmExecutor::gemm / gemm_uninit / batched_gemm_uninit,
+ *      rten-gemm/src/lib.rs:255-372 (called from src/ops/matmul.rs:32-104,208-385) ---- */
+#define RTEN_HIP_BIAS_NONE 0
+#define RTEN_HIP_BIAS_PER_ROW 1 /* BiasVector::Column: bias[m] */
+#define RTEN_HIP_BIAS_PER_COL 2 /* BiasVector::Row:    bias[n] */
+#define RTEN_HIP_ACT_NONE 0
+#define RTEN_HIP_ACT_RELU 1 /* Relu, src/ops/unary_elementwise.rs:611-613 */
+#define RTEN_HIP_ACT_GELU 2 /* Gelu, rten-vecmath/src/erf.rs:61-76 */
+
+typedef struct {
+    int32_t m, n, k;
+    int64_t a_rs, a_cs; /* A[m,k] element strides (transposes are strides, matmul.rs:47-48) */
+    int64_t b_rs, b_cs; /* B[k,n] element strides */
+    int64_t ldc;        /* C row stride; C columns are contiguous */
+    int32_t batch;      /* >= 1; batched_gemm_uninit */
+    int64_t a_bs, b_bs, c_bs; /* batch strides in elements; 0 broadcasts that operand */
+    float alpha, beta;  /* C = alpha*A.B + beta*C ; beta == 0 => C is never read */
+    int32_t bias_kind;  /* RTEN_HIP_BIAS_* */
+    int32_t act;        /* RTEN_HIP_ACT_* applied after bias (fused follow-on op) */
+} rten_hip_gemm_desc;
+
+int32_t rten_hip_gemm_f32(rten_hip_ctx *ctx, const rten_hip_gemm_desc *desc, const float *a, const float *b,
+                          const float *bias, float *c);
+
+/* ---- int8 GEMM: GemmExecutor<u8,i8,i32>, kernels/generic.rs:274-366; front-ends
+ *      matmul_integer / MatMulIntegerToFloat, src/ops/matmul.rs:582-647,789-794 ----
+ * C_i32[m,n] = sum_k (A[m,k]-a_zp[m]) * (B[k,n]-b_zp[n]).  A and B may each be u8 or i8 (the four
+ * signedness combos of matmul.rs:684-690); zero points have the operand's type, length 1 or M / N.
+ * If `scale` is non-NULL the output is f32: (acc as f32) * scale[0 or n]  (cast_scale, :734-773). */
+typedef struct {
+    int32_t m, n, k;
+    int64_t a_rs, a_cs, b_rs, b_cs, ldc;
+    int32_t a_signed, b_signed;
+    int32_t a_zp_len, b_zp_len; /* 0 (none), 1 (scalar) or m / n */
+    int32_t scale_len;          /* 0 (i32 output), 1 or n */
+} rten_hip_gemm_int8_desc;
+
+int32_t rten_hip_gemm_int8(rten_hip_ctx *ctx, const rten_hip_gemm_int8_desc *desc, const void *a, const void *b,
+                           const void *a_zp, const void *b_zp, const float *scale, void *c);
+
+/* ---- Conv (f32): Conv::run -> conv_impl, src/ops/conv.rs:124-365,384-400 ----
+ * X [n,c,h,w], W [o, c/groups, kh, kw], bias [o] or NULL, Y [n,o,oh,ow]; pads are the FIXED pads
+ * (top,left,bottom,right) produced by rten_hip_calc_output_size_and_padding. */
+typedef struct {
+    int32_t n, c, h, w;
+    int32_t o, kh, kw;
+    int32_t pads[4];
+    int32_t stride_h, stride_w, dil_h, dil_w;
+    int32_t groups;
+    int32_t out_h, out_w;
+} rten_hip_conv2d_desc;
+
+#define RTEN_HIP_CONV_RELU 1u     /* fuse the following Relu */
+#define RTEN_HIP_CONV_RESIDUAL 2u /* fuse the following Add(residual) (before Relu) */
+
+/* Load-time weight staging (the GPU analogue of PrepackedInput / Graph::prepack_weights,
+ * src/operator.rs:25-66, src/graph.rs:488-562): re-lays W out as [groups][K][O/groups] for
+ * coalesced MFMA tile loads.  `packed` must hold rten_hip_conv2d_f32_packed_bytes() bytes. */
+size_t rten_hip_conv2d_f32_packed_bytes(const rten_hip_conv2d_desc *desc);
+int32_t rten_hip_conv2d_f32_prepack(rten_hip_ctx *ctx, const rten_hip_conv2d_desc *desc, const float *w,
+                                    float *packed);
+/* weights_packed != 0: `w` is a prepacked buffer; else `w` is the plain OIHW tensor. */
+int32_t rten_hip_conv2d_f32(rten_hip_ctx *ctx, const rten_hip_conv2d_desc *desc, const float *x, const float *w,
+                            int32_t weights_packed, const float *bias, const float *residual, uint32_t flags,
+                            float *y);
+
+/* ---- Conv (int8): ConvInteger / ConvIntegerToFloat, src/ops/conv.rs:421-476,495-526,571-578 ----
+ * x u8|i8 NCHW, w i8|u8 OIHW, x_zp: device scalar of x's type, w_zp: device, length 1 or o.
+ * pad_mode: value of out-of-image taps: */
+#define RTEN_HIP_PAD_ZERO_POINT 0 /* contributes 0 (ONNX semantics) */
+#define RTEN_HIP_PAD_RAW0_I8 1    /* x86 reference: raw 0 after the u8->i8 shift cast */
+#define RTEN_HIP_PAD_RAW0_U8 2    /* Arm/wasm reference */
+typedef struct {
+    rten_hip_conv2d_desc conv;
+    int32_t x_signed, w_signed;
+    int32_t w_zp_len; /* 0, 1 or o */
+    int32_t pad_mode;
+} rten_hip_conv2d_int8_desc;
+/* scale == NULL: y is i32 (ConvInteger).  scale != NULL (device scalar): y is f32 =
+ * (acc as f32) * scale[0], then optional bias[o] add (the Add node that follows in ort-quantized
+ * graphs), optional residual add and Relu per `flags`. */
+int32_t rten_hip_conv2d_int8(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *desc, const void *x, const void *w,
+                             const void *x_zp, const void *w_zp, const float *scale, const float *bias,
+                             const float *residual, uint32_t flags, void *y);
+
+/* ---- DynamicQuantizeLinear, src/ops/quantize.rs:352-436 + rten-vecmath/src/quantize.rs:39-79 ---- */
+int32_t rten_hip_dynamic_quantize_linear(rten_hip_ctx *ctx, int64_t n, const float *x, uint8_t *y, float *scale,
+                                         uint8_t *zero_point);
+/* cast_scale, src/ops/matmul.rs:734-773: y = (x as f32) * scale[scale_len == 1 ? 0 : i % scale_len] */
+int32_t rten_hip_cast_scale(rten_hip_ctx *ctx, int64_t n, const int32_t *x, const float *scale, int32_t scale_len,
+                            float *y);
+
+/* ---- Softmax / AddSoftmax: src/ops/norm.rs:825-840, src/ops/attention.rs:30-68,
+ *      rten-vecmath/src/softmax.rs:60-100 ----
+ * rows x cols, softmax along cols.  addend (optional) is added first; row r uses addend row
+ * (r / add_div) % add_mod  (covers [B,1,1,S] masks against [B,H,S,S] scores and same-shape). */
+int32_t rten_hip_softmax_f32(rten_hip_ctx *ctx, int64_t rows, int32_t cols, const float *x, const float *addend,
+                             int64_t add_div, int64_t add_mod, int32_t flush_nan_to_zero, float *y);
+
+/* ---- LayerNormalization: src/ops/norm.rs:456-529 + rten-vecmath/src/normalize.rs:82-170 ----
+ * gamma/beta NULL => gamma_scalar/beta_scalar (scalar-broadcast scale / absent bias). */
+int32_t rten_hip_layer_norm_f32(rten_hip_ctx *ctx, int64_t rows, int32_t cols, const float *x, const float *gamma,
+                                const float *beta, float gamma_scalar, float beta_scalar, float epsilon,
+                                float *y);
+/* BatchNormalization (inference), src/ops/norm.rs:194-224 */
+int32_t rten_hip_batch_norm_f32(rten_hip_ctx *ctx, int32_t n, int32_t c, int64_t inner, const float *x,
+                                const float *scale, const float *bias, const float *mean, const float *var,
+                                float epsilon, float *y);
+
+/* ---- element-wise: src/ops/unary_elementwise.rs:399-420,611-613; binary_elementwise.rs:476-495 ---- */
+int32_t rten_hip_relu_f32(rten_hip_ctx *ctx, int64_t n, const float *x, float *y);
+int32_t rten_hip_gelu_f32(rten_hip_ctx *ctx, int64_t n, const float *x, float *y);
+int32_t rten_hip_erf_f32(rten_hip_ctx *ctx, int64_t n, const float *x, float *y);
+/* y[i] = a[i] + b[i % b_len] (b_len == n: same shape; b_len < n: trailing-dims broadcast) */
+int32_t rten_hip_add_f32(rten_hip_ctx *ctx, int64_t n, const float *a, const float *b, int64_t b_len, float *y);
+int32_t rten_hip_mul_f32(rten_hip_ctx *ctx, int64_t n, const float *a, const float *b, int64_t b_len, float *y);
+/* y[(i / inner) ...] += bias[c]: per-channel bias add for NCHW tensors ([1,O,1,1] constant Add) */
+int32_t rten_hip_add_channel_bias_f32(rten_hip_ctx *ctx, int32_t n, int32_t c, int64_t inner, const float *x,
+                                      const float *bias, float *y);
+
+/* ---- pooling: src/ops/pooling.rs:174-389,392-417,516-521,581-600 ---- */
+typedef struct {
+    int32_t n, c, h, w;
+    int32_t kh, kw, stride_h, stride_w;
+    int32_t pads[4];
+    int32_t out_h, out_w;
+    int32_t count_include_pad; /* AveragePool only */
+} rten_hip_pool2d_desc;
+int32_t rten_hip_max_pool2d_f32(rten_hip_ctx *ctx, const rten_hip_pool2d_desc *desc, const float *x, float *y);
+int32_t rten_hip_average_pool2d_f32(rten_hip_ctx *ctx, const rten_hip_pool2d_desc *desc, const float *x, float *y);
+int32_t rten_hip_global_average_pool_f32(rten_hip_ctx *ctx, int64_t nc, int32_t inner, const float *x, float *y);
+
+/* ---- fused attention: sdpa_head / sdpa_multi_head, src/ops/attention.rs:518-626 ----
+ * q [bh, s, d], k [bh, t, d], v [bh, t, dv] contiguous; mask NULL or additive f32 with
+ * mask row for (i in bh, query s) = mask + (i / mask_bh_div) * mask_batch_stride + s * mask_row_stride. */
+int32_t rten_hip_sdpa_f32(rten_hip_ctx *ctx, int32_t bh, int32_t s, int32_t t, int32_t d, int32_t dv,
+                          const float *q, const float *k, const float *v, const float *mask,
+                          int32_t mask_bh_div, int64_t mask_batch_stride, int64_t mask_row_stride, float scale,
+                          float *out);
+
+/* ---- tuning: per-shape kernel-variant selection by measurement at load time ----
+ * variant < 0 restores the built-in heuristic.  Used by the harness's autotuner. */
+int32_t rten_hip_set_gemm_variant_override(rten_hip_ctx *ctx, int32_t variant);
+int32_t rten_hip_num_gemm_variants(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTEN_HIP_H */

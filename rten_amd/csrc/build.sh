@@ -1,0 +1,18 @@
+#!/bin/bash
+# Builds librten_hip.so for gfx950 (cross-compiles without a GPU).  Usage: build.sh [extra hipcc flags]
+set -e
+cd "$(dirname "$0")"
+OUT=../librten_hip.so
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result"
+mkdir -p ../_build
+pids=()
+for f in *.hip; do
+  o=../_build/${f%.hip}.o
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ internal.h -nt "$o" ] || [ vecmath.h -nt "$o" ] || [ ../../include/rten_hip.h -nt "$o" ]; then
+    /opt/rocm/bin/hipcc $FLAGS "$@" -c "$f" -o "$o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT ../_build/*.o
+echo "built $OUT"

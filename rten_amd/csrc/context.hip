@@ -1,0 +1,341 @@
+// Context, device memory, stream/event/graph plumbing of librten_hip.so.
+#include <cstdarg>
+#include <cstring>
+
+#include "internal.h"
+
+int32_t rten_set_error(rten_hip_ctx *ctx, int32_t code, const char *fmt, ...) {
+    if (ctx) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        ctx->last_error = buf;
+    }
+    return code;
+}
+
+int32_t rten_check_hip(rten_hip_ctx *ctx, hipError_t e, const char *what) {
+    if (e == hipSuccess) return RTEN_HIP_OK;
+    return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+void *rten_scratch(rten_hip_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->scratch_bytes) return ctx->scratch;
+    if (ctx->capturing) return nullptr; // cannot grow during capture
+    if (ctx->scratch) {
+        hipStreamSynchronize(ctx->stream);
+        hipFree(ctx->scratch);
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+    }
+    size_t want = bytes + bytes / 4;
+    if (hipMalloc(&ctx->scratch, want) != hipSuccess) return nullptr;
+    ctx->scratch_bytes = want;
+    return ctx->scratch;
+}
+
+static hipEvent_t get_event(rten_hip_ctx *ctx) {
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
+
+ProfScope::ProfScope(rten_hip_ctx *c, const char *n, double fl, double by) : ctx(c), name(n), flops(fl), bytes(by) {
+    if (ctx->profiling && !ctx->capturing) {
+        e0 = get_event(ctx);
+        e1 = get_event(ctx);
+        hipEventRecord(e0, ctx->stream);
+    }
+}
+
+ProfScope::~ProfScope() {
+    if (e0) {
+        hipEventRecord(e1, ctx->stream);
+        ProfEntry &pe = ctx->prof[name];
+        pe.pending.emplace_back(e0, e1);
+        pe.pending_work.emplace_back(flops, bytes);
+    }
+}
+
+static void prof_resolve(rten_hip_ctx *ctx) {
+    hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->prof) {
+        ProfEntry &pe = kv.second;
+        for (size_t i = 0; i < pe.pending.size(); i++) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pe.pending[i].first, pe.pending[i].second) == hipSuccess) {
+                pe.launches++;
+                pe.ms += ms;
+                pe.flops += pe.pending_work[i].first;
+                pe.bytes += pe.pending_work[i].second;
+            }
+            ctx->event_pool.push_back(pe.pending[i].first);
+            ctx->event_pool.push_back(pe.pending[i].second);
+        }
+        pe.pending.clear();
+        pe.pending_work.clear();
+    }
+}
+
+RTEN_EXPORT int32_t rten_hip_abi_version(void) { return RTEN_HIP_ABI_VERSION; }
+
+RTEN_EXPORT int32_t rten_hip_init(int32_t device_id, void *external_stream, rten_hip_ctx **out_ctx) {
+    if (!out_ctx) return RTEN_HIP_ERR_INVALID_VALUE;
+    *out_ctx = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return RTEN_HIP_ERR_NO_DEVICE;
+    if (device_id < 0 || device_id >= count) return RTEN_HIP_ERR_NO_DEVICE;
+    if (hipSetDevice(device_id) != hipSuccess) return RTEN_HIP_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return RTEN_HIP_ERR_NO_DEVICE;
+    // This library carries gfx950 code objects only.
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return RTEN_HIP_ERR_NO_DEVICE;
+    rten_hip_ctx *ctx = new rten_hip_ctx();
+    ctx->device = device_id;
+    ctx->num_cus = prop.multiProcessorCount;
+    if (external_stream) {
+        ctx->stream = (hipStream_t)external_stream;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete ctx;
+            return RTEN_HIP_ERR_HIP;
+        }
+        ctx->own_stream = true;
+    }
+    *out_ctx = ctx;
+    return RTEN_HIP_OK;
+}
+
+RTEN_EXPORT int32_t rten_hip_destroy(rten_hip_ctx *ctx) {
+    if (!ctx) return RTEN_HIP_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->prof)
+        for (auto &p : kv.second.pending) {
+            hipEventDestroy(p.first);
+            hipEventDestroy(p.second);
+        }
+    for (hipEvent_t e : ctx->event_pool) hipEventDestroy(e);
+    for (auto &t : ctx->timers)
+        for (hipEvent_t e : t)
+            if (e) hipEventDestroy(e);
+    if (ctx->scratch) hipFree(ctx->scratch);
+    if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return RTEN_HIP_OK;
+}
+
+RTEN_EXPORT const char *rten_hip_last_error(rten_hip_ctx *ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+
+RTEN_EXPORT int32_t rten_hip_sync(rten_hip_ctx *ctx) {
+    RTEN_CHECK_CTX(ctx);
+    RTEN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RTEN_HIP_OK;
+}
+
+RTEN_EXPORT int32_t rten_hip_device_info(rten_hip_ctx *ctx, char *name_buf, int32_t name_len, int32_t *compute_units,
+                                         int32_t *clock_mhz, int64_t *total_mem_bytes) {
+    RTEN_CHECK_CTX(ctx);
+    hipDeviceProp_t prop;
+    RTEN_HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    if (name_buf && name_len > 0) snprintf(name_buf, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (clock_mhz) *clock_mhz = prop.clockRate / 1000;
+    if (total_mem_bytes) *total_mem_bytes = (int64_t)prop.totalGlobalMem;
+    return RTEN_HIP_OK;
+}
+
+RTEN_EXPORT int32_t rten_hip_malloc(rten_hip_ctx *ctx, size_t bytes, void **out_dptr) {
+    RTEN_CHECK_CTX(ctx);
+    if (!out_dptr) return RTEN_HIP_ERR_INVALID_VALUE;
+    *out_dptr = nullptr;
+    if (bytes == 0) bytes = 16;
+    RTEN_HIP_TRY(ctx, hipMalloc(out_dptr, bytes));
+    return RTEN_HIP_OK;
+}
+
+RTEN_EXPORT int32_t rten_hip_free(rten_hip_ctx *ctx, void *dptr) {
+    RTEN_CHECK_CTX(ctx);
+    if (!dptr) return RTEN_HIP_OK;
+    RTEN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    RTEN_HIP_TRY(ctx, hipFree(dptr));
+    return RTEN_HIP_OK;
+}
+
+RTEN_EXPORT int32_t rten_hip_memcpy_h2d(rten_hip_ctx *ctx, void *dst, const void *src_host, size_t bytes) {
+    RTEN_CHECK_CTX(ctx);
+    if (bytes == 0) return RTEN_HIP_OK;
+    // Pageable host memory: the async copy is staged by the runtime; sync so the caller may reuse src.
+    RTEN_HIP_TRY(ctx, hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    RTEN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RTEN_HIP_OK;
+}
+
+RTEN_EXPORT int32_t rten_hip_memcpy_d2h(rten_hip_ctx *ctx, void *dst_host, const void *src, size_t bytes) {
+    RTEN_CHECK_CTX(ctx);
+    if (bytes == 0) return RTEN_HIP_OK;
+    RTEN_HIP_TRY(ctx, hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    RTEN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RTEN_HIP_OK;
+}
+
+RTEN_EXPORT int32_t rten_hip_memcpy_d2d(rten_hip_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    RTEN_CHECK_CTX(ctx);
+    if (bytes == 0) return RTEN_HIP_OK;
+    RTEN_HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return RTEN_HIP_OK;
+}
+
+RTEN_EXPORT int32_t rten_hip_memset(rten_hip_ctx *ctx, void *dst, int32_t byte_value, size_t bytes) {
+    RTEN_CHECK_CTX(ctx);
+    if (bytes == 0) return RTEN_HIP_OK;
+    RTEN_HIP_TRY(ctx, hipMemsetAsync(dst, byte_value, bytes, ctx->stream));
+    return RTEN_HIP_OK;
+}
+
+RTEN_EXPORT int32_t rten_hip_timer_start(rten_hip_ctx *ctx, int32_t slot) {
+    RTEN_CHECK_CTX(ctx);
+    if (slot < 0 || slot >= 64) return RTEN_HIP_ERR_INVALID_VALUE;
+    for (int i = 0; i < 2; i++)
+        if (!ctx->timers[slot][i]) RTEN_HIP_TRY(ctx, hipEventCreate(&ctx->timers[slot][i]));
+    RTEN_HIP_TRY(ctx, hipEventRecord(ctx->timers[slot][0], ctx->stream));
+    return RTEN_HIP_OK;
+}
+
+RTEN_EXPORT int32_t rten_hip_timer_stop(rten_hip_ctx *ctx, int32_t slot) {
+    RTEN_CHECK_CTX(ctx);
+    if (slot < 0 || slot >= 64 || !ctx->timers[slot][1]) return RTEN_HIP_ERR_INVALID_VALUE;
+    RTEN_HIP_TRY(ctx, hipEventRecord(ctx->timers[slot][1], ctx->stream));
+    return RTEN_HIP_OK;
+}
+
+RTEN_EXPORT int32_t rten_hip_timer_elapsed_ms(rten_hip_ctx *ctx, int32_t slot, float *out_ms) {
+    RTEN_CHECK_CTX(ctx);
+    if (slot < 0 || slot >= 64 || !ctx->timers[slot][1] || !out_ms) return RTEN_HIP_ERR_INVALID_VALUE;
+    RTEN_HIP_TRY(ctx, hipEventSynchronize(ctx->timers[slot][1]));
+    RTEN_HIP_TRY(ctx, hipEventElapsedTime(out_ms, ctx->timers[slot][0], ctx->timers[slot][1]));
+    return RTEN_HIP_OK;
+}
+
+RTEN_EXPORT int32_t rten_hip_graph_begin(rten_hip_ctx *ctx) {
+    RTEN_CHECK_CTX(ctx);
+    if (ctx->capturing) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "graph capture already active");
+    RTEN_HIP_TRY(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    ctx->capturing = true;
+    return RTEN_HIP_OK;
+}
+
+RTEN_EXPORT int32_t rten_hip_graph_end(rten_hip_ctx *ctx, uint64_t *out_graph) {
+    RTEN_CHECK_CTX(ctx);
+    if (!ctx->capturing || !out_graph) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "no active capture");
+    ctx->capturing = false;
+    hipGraph_t graph = nullptr;
+    RTEN_HIP_TRY(ctx, hipStreamEndCapture(ctx->stream, &graph));
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e != hipSuccess) return rten_check_hip(ctx, e, "hipGraphInstantiate");
+    *out_graph = (uint64_t)(uintptr_t)exec;
+    return RTEN_HIP_OK;
+}
+
+RTEN_EXPORT int32_t rten_hip_graph_launch(rten_hip_ctx *ctx, uint64_t graph) {
+    RTEN_CHECK_CTX(ctx);
+    if (!graph) return RTEN_HIP_ERR_INVALID_VALUE;
+    RTEN_HIP_TRY(ctx, hipGraphLaunch((hipGraphExec_t)(uintptr_t)graph, ctx->stream));
+    return RTEN_HIP_OK;
+}
+
+RTEN_EXPORT int32_t rten_hip_graph_destroy(rten_hip_ctx *ctx, uint64_t graph) {
+    RTEN_CHECK_CTX(ctx);
+    if (!graph) return RTEN_HIP_OK;
+    RTEN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    RTEN_HIP_TRY(ctx, hipGraphExecDestroy((hipGraphExec_t)(uintptr_t)graph));
+    return RTEN_HIP_OK;
+}
+
+RTEN_EXPORT int32_t rten_hip_profile_enable(rten_hip_ctx *ctx, int32_t on) {
+    RTEN_CHECK_CTX(ctx);
+    ctx->profiling = on != 0;
+    return RTEN_HIP_OK;
+}
+
+RTEN_EXPORT int32_t rten_hip_profile_reset(rten_hip_ctx *ctx) {
+    RTEN_CHECK_CTX(ctx);
+    prof_resolve(ctx);
+    ctx->prof.clear();
+    return RTEN_HIP_OK;
+}
+
+RTEN_EXPORT int32_t rten_hip_profile_report(rten_hip_ctx *ctx, char *buf, int32_t buf_len) {
+    RTEN_CHECK_CTX(ctx);
+    if (!buf || buf_len <= 2) return RTEN_HIP_ERR_INVALID_VALUE;
+    prof_resolve(ctx);
+    std::string s = "[";
+    bool first = true;
+    for (auto &kv : ctx->prof) {
+        char line[512];
+        snprintf(line, sizeof line, "%s{\"kernel\":\"%s\",\"launches\":%d,\"ms\":%.6f,\"flops\":%.6e,\"bytes\":%.6e}",
+                 first ? "" : ",", kv.first.c_str(), kv.second.launches, kv.second.ms, kv.second.flops,
+                 kv.second.bytes);
+        s += line;
+        first = false;
+    }
+    s += "]";
+    if ((int)s.size() + 1 > buf_len) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "report buffer too small");
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return RTEN_HIP_OK;
+}
+
+// calc_output_size_and_padding -- src/ops/pooling.rs:63-159.  Host-side shape logic shared by the
+// conv and pooling operators; error strings are the reference's, verbatim.
+static const char *axis_out_pad(int64_t in, int64_t k, int64_t stride, bool same, int64_t ps, int64_t pe, int64_t dil,
+                                bool ceil_mode, int32_t *out, int32_t *pad_s, int32_t *pad_e) {
+    if (dil <= 0) return "Dilations must be > 0";
+    if (k <= 0) return "Kernel size must be > 0";
+    if (stride <= 0) return "Strides must be > 0";
+    if (same) {
+        int64_t o = (in + stride - 1) / stride;
+        int64_t need = (o - 1) * stride + (k - 1) * dil + 1;
+        int64_t total = need > in ? need - in : 0;
+        *out = (int32_t)o;
+        *pad_s = (int32_t)(total / 2);
+        *pad_e = (int32_t)((total + 1) / 2);
+        return nullptr;
+    }
+    int64_t padded = in + ps + pe;
+    int64_t dk = k + (k - 1) * (dil - 1);
+    if (padded < dk) return "Input too small for kernel size";
+    int64_t win = padded - dil * (k - 1) - 1;
+    int64_t o = ceil_mode ? (win + stride - 1) / stride + 1 : win / stride + 1;
+    if (ceil_mode && (o - 1) * stride >= in + ps) o -= 1;
+    *out = (int32_t)o;
+    *pad_s = (int32_t)ps;
+    *pad_e = (int32_t)pe;
+    return nullptr;
+}
+
+RTEN_EXPORT int32_t rten_hip_calc_output_size_and_padding(int32_t in_h, int32_t in_w, int32_t k_h, int32_t k_w,
+                                                          int32_t stride_h, int32_t stride_w, int32_t same_padding,
+                                                          const int32_t pads[4], int32_t dil_h, int32_t dil_w,
+                                                          int32_t ceil_mode, int32_t out_hw[2], int32_t out_pads[4],
+                                                          const char **err_msg) {
+    if (!out_hw || !out_pads) return RTEN_HIP_ERR_INVALID_VALUE;
+    if (!same_padding && !pads) return RTEN_HIP_ERR_INVALID_VALUE;
+    int64_t pt = same_padding ? 0 : pads[0], pl = same_padding ? 0 : pads[1];
+    int64_t pb = same_padding ? 0 : pads[2], pr = same_padding ? 0 : pads[3];
+    const char *e = axis_out_pad(in_h, k_h, stride_h, same_padding != 0, pt, pb, dil_h, ceil_mode != 0, &out_hw[0],
+                                 &out_pads[0], &out_pads[2]);
+    if (!e)
+        e = axis_out_pad(in_w, k_w, stride_w, same_padding != 0, pl, pr, dil_w, ceil_mode != 0, &out_hw[1],
+                         &out_pads[1], &out_pads[3]);
+    if (err_msg) *err_msg = e;
+    return e ? RTEN_HIP_ERR_INVALID_VALUE : RTEN_HIP_OK;
+}

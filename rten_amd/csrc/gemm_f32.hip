@@ -1,0 +1,697 @@
+// MFMA f32 tiled GEMM / implicit-GEMM convolution for gfx950 (MI355X).
+//
+// Replaces: GemmExecutor::gemm / gemm_uninit / batched_gemm_uninit (rten-gemm/src/lib.rs:255-372,
+// gemm_impl :794-1093), the f32 micro-kernel (kernels/simd_generic.rs:285-414), the virtual
+// im2col packing (rten-gemm/src/im2col.rs:56-212, src/ops/conv/im2col.rs:11-128) and conv_impl /
+// conv_2d_pointwise (src/ops/conv.rs:33-87,124-365).
+//
+// One kernel template covers GEMM and convolution:
+//     C[m, n] = epilogue( sum_k A[m, k] * B[k, n] )
+//   * conv:  m = output channel, k = (c, ky, kx), n = (image, oy, ox) flattened over the WHOLE batch, so
+//            late ResNet stages (7x7 / 14x14 maps) still produce thousands of columns per launch.
+//            B is never materialised: the im2col gather is fused into the global->LDS tile load.
+//            1x1/stride-1 convs skip the gather and read the NCHW tensor as a "two-level" matrix
+//            (column n -> image n / P, pixel n % P).
+//   * C is written straight into NCHW (row m, two-level column n), with bias / residual Add / Relu /
+//     Gelu fused into the epilogue.
+//
+// MI355X mapping: v_mfma_f32_32x32x2_f32 (exact f32, 64 FLOP/clk/SIMD == the f32 peak, 157 TF).  256
+// threads = 4 waves per workgroup, each wave owns TM x TN accumulator tiles of 32x32.  A and B tiles
+// are staged through LDS k-major ([BK][BM+pad], [BK][BN+pad]) so the MFMA operand fetch
+// (lane -> row k0 + lane/32, column lane%32) is a conflict-free ds_read_b32; tiles are double
+// buffered and the next tile's global loads are issued before the current tile's MFMAs so that
+// HBM/L2 latency hides under the matrix pipe (one barrier per k-tile).  Workgroup ids are remapped
+// so that each XCD (private L2) owns a contiguous range of tiles that share the same B panel.
+//
+// Numerics: accumulation order is the reference's, exactly: k-ordered FMA chain per depth block of
+// kc = 256 starting from 0, blocks combined with separate adds, bias added after the first block
+// (rten-gemm/src/lib.rs:630-633,1008-1013,1221-1255; simd_generic.rs:378-414).  MFMA f32 is a
+// k-ordered fmaf chain bit for bit, so outputs are bit-identical to the oracle for M > 1.
+#include "internal.h"
+#include "vecmath.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BK = 16;            // k-tile depth
+constexpr int KC_TILES = 256 / BK; // reference depth block (kc = 256 for f32)
+constexpr int NTHREADS = 256;
+
+enum ALoad { A_M4 = 0, A_K4 = 1, A_SCALAR = 2 };
+enum BLoad { B_N4 = 0, B_K4 = 1, B_SCALAR = 2, B_IM2COL = 3 };
+
+struct GemmArgs {
+    const float *A;
+    const float *B;
+    float *C;
+    const float *bias;
+    const float *res;
+    int M, N, K;
+    long long a_rs, a_cs, a_bs;       // A[z*a_bs + m*a_rs + k*a_cs]
+    long long b_rs, b_cs, b_ns, b_bs; // B[z*b_bs + k*b_rs + (n/Pn)*b_ns + (n%Pn)*b_cs]
+    long long c_rs, c_ns, c_bs;       // C[z*c_bs + m*c_rs + (n/Pn)*c_ns + (n%Pn)]
+    long long bias_bs;
+    int Pn;
+    float alpha, beta;
+    int bias_kind, act;
+    int tiles_m, tiles_n;
+    int a_dir_m, b_dir_n; // scalar loaders: lanes run along m / n (1) or along k (0)
+    // im2col geometry (B_IM2COL): image z/group base = B + z*b_bs + (n/Pn)*b_ns
+    int H, W, HW, KHW, KW, OW, sy, sx, dy, dx, pt, pl;
+    unsigned magic_khw, magic_kw;
+};
+
+__device__ __forceinline__ unsigned fastdiv(unsigned n, unsigned magic, unsigned d) {
+    // exact for n*d < 2^32 (magic = ceil(2^32 / d)); d == 1 is handled by the caller passing magic = 0
+    return magic ? __umulhi(n, magic) : n;
+}
+
+__device__ __forceinline__ float combine(float t, float c, float alpha, float beta) {
+    // the four store forms of the reference micro-kernel, simd_generic.rs:378-414
+    if (beta == 0.f) return alpha == 1.f ? t : t * alpha;
+    if (beta == 1.f && alpha == 1.f) return c + t;
+    return vm::fma(t, alpha, c * beta);
+}
+
+template <int BM, int BN, int AL, int BL, bool MULTI_KC>
+__global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_kernel(const GemmArgs p) {
+    constexpr int WM = 2, WN = 2;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    constexpr int A_ELEMS = BK * BM / NTHREADS, B_ELEMS = BK * BN / NTHREADS; // per-thread elements per tile
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA + LDB)];
+    float *const As0 = smem;
+    float *const Bs0 = smem + 2 * BK * LDA;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int z = blockIdx.y;
+
+    // ---- XCD-aware tile mapping: consecutive ids on one XCD walk down a column of tiles (same B panel)
+    int tile;
+    {
+        const int nt = p.tiles_m * p.tiles_n;
+        const int id = blockIdx.x;
+        const int xcd = id & 7, q = nt >> 3, r = nt & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    }
+    const int bm = tile % p.tiles_m, bn = tile / p.tiles_m;
+    const int m0 = bm * BM, n0 = bn * BN;
+
+    const float *__restrict__ Ab = p.A + (long long)z * p.a_bs;
+    const float *__restrict__ Bb = p.B + (long long)z * p.b_bs;
+
+    // ---- per-thread loader state (fixed across the K loop)
+    // A
+    [[maybe_unused]] long long a_off[A_ELEMS];   // scalar path: base offset of element j (without k-tile advance)
+    [[maybe_unused]] bool a_ok[A_ELEMS];
+    // B (dense)
+    [[maybe_unused]] long long b_off[B_ELEMS];
+    [[maybe_unused]] bool b_ok[B_ELEMS];
+    // B (im2col): one column per thread
+    [[maybe_unused]] long long im_base = 0;
+    [[maybe_unused]] int im_iy0 = 0, im_ix0 = 0;
+    [[maybe_unused]] bool im_ok = false;
+
+    if constexpr (AL == A_M4) {
+        // float4 along m: idx -> (k = idx / (BM/4), m4 = idx % (BM/4))
+#pragma unroll
+        for (int j = 0; j < A_ELEMS / 4; j++) {
+            const int idx = t + j * NTHREADS;
+            const int k = idx / (BM / 4), m = m0 + (idx % (BM / 4)) * 4;
+            a_off[j] = (long long)k * p.a_cs + m;
+            a_ok[j] = m < p.M; // M % 4 == 0 on this path
+        }
+    } else if constexpr (AL == A_K4) {
+        // float4 along k: idx -> (k4 = idx % (BK/4), m = idx / (BK/4))
+#pragma unroll
+        for (int j = 0; j < A_ELEMS / 4; j++) {
+            const int idx = t + j * NTHREADS;
+            const int k = (idx % (BK / 4)) * 4, m = m0 + idx / (BK / 4);
+            a_off[j] = (long long)m * p.a_rs + k;
+            a_ok[j] = m < p.M;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < A_ELEMS; j++) {
+            const int idx = t + j * NTHREADS;
+            const int k = p.a_dir_m ? idx / BM : idx % BK;
+            const int m = m0 + (p.a_dir_m ? idx % BM : idx / BK);
+            a_off[j] = (long long)m * p.a_rs + (long long)k * p.a_cs;
+            a_ok[j] = m < p.M;
+        }
+    }
+    if constexpr (BL == B_N4) {
+#pragma unroll
+        for (int j = 0; j < B_ELEMS / 4; j++) {
+            const int idx = t + j * NTHREADS;
+            const int k = idx / (BN / 4), n = n0 + (idx % (BN / 4)) * 4;
+            const int nb = n / p.Pn, np = n - nb * p.Pn;
+            b_off[j] = (long long)k * p.b_rs + (long long)nb * p.b_ns + np;
+            b_ok[j] = n < p.N; // N % 4 == 0, Pn % 4 == 0 on this path
+        }
+    } else if constexpr (BL == B_K4) {
+#pragma unroll
+        for (int j = 0; j < B_ELEMS / 4; j++) {
+            const int idx = t + j * NTHREADS;
+            const int k = (idx % (BK / 4)) * 4, n = n0 + idx / (BK / 4);
+            const int nb = n / p.Pn, np = n - nb * p.Pn;
+            b_off[j] = (long long)nb * p.b_ns + (long long)np * p.b_cs + k;
+            b_ok[j] = n < p.N;
+        }
+    } else if constexpr (BL == B_SCALAR) {
+#pragma unroll
+        for (int j = 0; j < B_ELEMS; j++) {
+            const int idx = t + j * NTHREADS;
+            const int k = p.b_dir_n ? idx / BN : idx % BK;
+            const int n = n0 + (p.b_dir_n ? idx % BN : idx / BK);
+            const int nb = n / p.Pn, np = n - nb * p.Pn;
+            b_off[j] = (long long)k * p.b_rs + (long long)nb * p.b_ns + (long long)np * p.b_cs;
+            b_ok[j] = n < p.N;
+        }
+    } else { // B_IM2COL: idx -> (k = idx / BN, col = idx % BN); 256 % BN == 0 so the column is fixed per thread
+        const int n = n0 + (t % BN);
+        im_ok = n < p.N;
+        const int nn = im_ok ? n : 0;
+        const int nb = nn / p.Pn, np = nn - nb * p.Pn;
+        const int oy = np / p.OW, ox = np - oy * p.OW;
+        im_iy0 = oy * p.sy - p.pt;
+        im_ix0 = ox * p.sx - p.pl;
+        im_base = (long long)nb * p.b_ns;
+    }
+
+    // ---- prefetch registers
+    float ra[A_ELEMS], rb[B_ELEMS];
+
+    auto load_a = [&](int kt) {
+        const int k0 = kt * BK;
+        if constexpr (AL == A_M4) {
+#pragma unroll
+            for (int j = 0; j < A_ELEMS / 4; j++) {
+                const int idx = t + j * NTHREADS;
+                const int k = k0 + idx / (BM / 4);
+                const bool ok = a_ok[j] && k < p.K;
+                f32x4 v = *reinterpret_cast<const f32x4 *>(Ab + (ok ? a_off[j] + (long long)k0 * p.a_cs : 0ll));
+                if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                ra[4 * j + 0] = v[0]; ra[4 * j + 1] = v[1]; ra[4 * j + 2] = v[2]; ra[4 * j + 3] = v[3];
+            }
+        } else if constexpr (AL == A_K4) {
+#pragma unroll
+            for (int j = 0; j < A_ELEMS / 4; j++) {
+                const int idx = t + j * NTHREADS;
+                const int k = k0 + (idx % (BK / 4)) * 4;
+                const bool ok = a_ok[j] && k < p.K; // K % 4 == 0
+                f32x4 v = *reinterpret_cast<const f32x4 *>(Ab + (ok ? a_off[j] + k0 : 0ll));
+                if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                ra[4 * j + 0] = v[0]; ra[4 * j + 1] = v[1]; ra[4 * j + 2] = v[2]; ra[4 * j + 3] = v[3];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < A_ELEMS; j++) {
+                const int idx = t + j * NTHREADS;
+                const int k = k0 + (p.a_dir_m ? idx / BM : idx % BK);
+                const bool ok = a_ok[j] && k < p.K;
+                const float v = Ab[ok ? a_off[j] + (long long)k0 * p.a_cs : 0ll];
+                ra[j] = ok ? v : 0.f;
+            }
+        }
+    };
+
+    auto load_b = [&](int kt) {
+        const int k0 = kt * BK;
+        if constexpr (BL == B_N4) {
+#pragma unroll
+            for (int j = 0; j < B_ELEMS / 4; j++) {
+                const int idx = t + j * NTHREADS;
+                const int k = k0 + idx / (BN / 4);
+                const bool ok = b_ok[j] && k < p.K;
+                f32x4 v = *reinterpret_cast<const f32x4 *>(Bb + (ok ? b_off[j] + (long long)k0 * p.b_rs : 0ll));
+                if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                rb[4 * j + 0] = v[0]; rb[4 * j + 1] = v[1]; rb[4 * j + 2] = v[2]; rb[4 * j + 3] = v[3];
+            }
+        } else if constexpr (BL == B_K4) {
+#pragma unroll
+            for (int j = 0; j < B_ELEMS / 4; j++) {
+                const int idx = t + j * NTHREADS;
+                const int k = k0 + (idx % (BK / 4)) * 4;
+                const bool ok = b_ok[j] && k < p.K;
+                f32x4 v = *reinterpret_cast<const f32x4 *>(Bb + (ok ? b_off[j] + k0 : 0ll));
+                if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                rb[4 * j + 0] = v[0]; rb[4 * j + 1] = v[1]; rb[4 * j + 2] = v[2]; rb[4 * j + 3] = v[3];
+            }
+        } else if constexpr (BL == B_SCALAR) {
+#pragma unroll
+            for (int j = 0; j < B_ELEMS; j++) {
+                const int idx = t + j * NTHREADS;
+                const int k = k0 + (p.b_dir_n ? idx / BN : idx % BK);
+                const bool ok = b_ok[j] && k < p.K;
+                const float v = Bb[ok ? b_off[j] + (long long)k0 * p.b_rs : 0ll];
+                rb[j] = ok ? v : 0.f;
+            }
+        } else {
+            // virtual im2col row k -> (c, ky, kx)  (rten-gemm/src/im2col.rs:145-208: out-of-image -> 0)
+#pragma unroll
+            for (int j = 0; j < B_ELEMS; j++) {
+                int k = k0 + t / BN + j * (NTHREADS / BN);
+                if constexpr (BN >= 64) k = __builtin_amdgcn_readfirstlane(k); // wave-uniform: scalar index math
+                const unsigned c = fastdiv((unsigned)k, p.magic_khw, (unsigned)p.KHW);
+                const unsigned rem = (unsigned)k - c * (unsigned)p.KHW;
+                const unsigned ky = fastdiv(rem, p.magic_kw, (unsigned)p.KW);
+                const unsigned kx = rem - ky * (unsigned)p.KW;
+                const int iy = im_iy0 + (int)ky * p.dy;
+                const int ix = im_ix0 + (int)kx * p.dx;
+                const bool ok = im_ok && k < p.K && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                const long long off = im_base + (long long)c * p.HW + (long long)iy * p.W + ix;
+                const float v = Bb[ok ? off : 0ll]; // branch-free: clamp the address, select the value
+                rb[j] = ok ? v : 0.f;
+            }
+        }
+    };
+
+    auto store_a = [&](int buf) {
+        float *As = As0 + buf * BK * LDA;
+        if constexpr (AL == A_M4) {
+#pragma unroll
+            for (int j = 0; j < A_ELEMS / 4; j++) {
+                const int idx = t + j * NTHREADS;
+                const int k = idx / (BM / 4), m = (idx % (BM / 4)) * 4;
+                f32x4 v = {ra[4 * j], ra[4 * j + 1], ra[4 * j + 2], ra[4 * j + 3]};
+                *reinterpret_cast<f32x4 *>(As + k * LDA + m) = v;
+            }
+        } else if constexpr (AL == A_K4) {
+#pragma unroll
+            for (int j = 0; j < A_ELEMS / 4; j++) {
+                const int idx = t + j * NTHREADS;
+                const int k = (idx % (BK / 4)) * 4, m = idx / (BK / 4);
+#pragma unroll
+                for (int i = 0; i < 4; i++) As[(k + i) * LDA + m] = ra[4 * j + i];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < A_ELEMS; j++) {
+                const int idx = t + j * NTHREADS;
+                const int k = p.a_dir_m ? idx / BM : idx % BK;
+                const int m = p.a_dir_m ? idx % BM : idx / BK;
+                As[k * LDA + m] = ra[j];
+            }
+        }
+    };
+
+    auto store_b = [&](int buf) {
+        float *Bs = Bs0 + buf * BK * LDB;
+        if constexpr (BL == B_N4) {
+#pragma unroll
+            for (int j = 0; j < B_ELEMS / 4; j++) {
+                const int idx = t + j * NTHREADS;
+                const int k = idx / (BN / 4), n = (idx % (BN / 4)) * 4;
+                f32x4 v = {rb[4 * j], rb[4 * j + 1], rb[4 * j + 2], rb[4 * j + 3]};
+                *reinterpret_cast<f32x4 *>(Bs + k * LDB + n) = v;
+            }
+        } else if constexpr (BL == B_K4) {
+#pragma unroll
+            for (int j = 0; j < B_ELEMS / 4; j++) {
+                const int idx = t + j * NTHREADS;
+                const int k = (idx % (BK / 4)) * 4, n = idx / (BK / 4);
+#pragma unroll
+                for (int i = 0; i < 4; i++) Bs[(k + i) * LDB + n] = rb[4 * j + i];
+            }
+        } else if constexpr (BL == B_SCALAR) {
+#pragma unroll
+            for (int j = 0; j < B_ELEMS; j++) {
+                const int idx = t + j * NTHREADS;
+                const int k = p.b_dir_n ? idx / BN : idx % BK;
+                const int n = p.b_dir_n ? idx % BN : idx / BK;
+                Bs[k * LDB + n] = rb[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < B_ELEMS; j++) {
+                const int k = t / BN + j * (NTHREADS / BN);
+                Bs[k * LDB + (t % BN)] = rb[j];
+            }
+        }
+    };
+
+    // ---- accumulators
+    const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+    f32x16 acc[TM][TN];
+    [[maybe_unused]] f32x16 tot[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    // C addressing for this lane: column n fixed per (j), rows by register
+    long long c_col[TN];
+    bool c_col_ok[TN];
+    int c_n[TN];
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int n = n0 + wn0 + j * 32 + l31;
+        c_n[j] = n;
+        c_col_ok[j] = n < p.N;
+        const int nn = c_col_ok[j] ? n : 0;
+        const int nb = nn / p.Pn, np = nn - nb * p.Pn;
+        c_col[j] = (long long)z * p.c_bs + (long long)nb * p.c_ns + np;
+    }
+    const float *__restrict__ biasb = p.bias ? p.bias + (long long)z * p.bias_bs : nullptr;
+
+    // value of an output element after the FIRST depth block: combine with C (beta), then bias
+    auto first_value = [&](float a, int j, int m, long long ccol, int cn, bool cok) -> float {
+        float cin = 0.f;
+        if (p.beta != 0.f && m < p.M && cok) cin = p.C[ccol + (long long)m * p.c_rs];
+        float v = combine(a, cin, p.alpha, p.beta);
+        if (p.bias_kind == RTEN_HIP_BIAS_PER_ROW) {
+            if (m < p.M) v = v + biasb[m];
+        } else if (p.bias_kind == RTEN_HIP_BIAS_PER_COL) {
+            if (cok) v = v + biasb[cn];
+        }
+        return v;
+    };
+    // in-loop flush of one finished depth block into `tot` (MULTI_KC only).  The row/column bases are
+    // laundered through an empty asm so that the (rare) flush's address arithmetic is recomputed here
+    // instead of being hoisted out of the K loop, where it would cost ~100 live VGPRs.
+    [[maybe_unused]] auto flush = [&](bool first) {
+        int mb = m0 + wm0 + 4 * half;
+        int nb0 = n0 + wn0 + l31;
+        asm volatile("" : "+v"(mb), "+v"(nb0));
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int n = nb0 + j * 32;
+            const bool cok = n < p.N;
+            long long ccol = 0;
+            if (first) {
+                const int nn = cok ? n : 0;
+                const int nb = nn / p.Pn, np = nn - nb * p.Pn;
+                ccol = (long long)z * p.c_bs + (long long)nb * p.c_ns + np;
+            }
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int m = mb + i * 32 + (r & 3) + 8 * (r >> 2);
+                    tot[i][j][r] = first ? first_value(acc[i][j][r], j, m, ccol, n, cok)
+                                         : combine(acc[i][j][r], tot[i][j][r], p.alpha, 1.f);
+                    acc[i][j][r] = 0.f;
+                }
+        }
+    };
+
+    // ---- main loop
+    const int nk = (p.K + BK - 1) / BK;
+    if (nk > 0) {
+        load_a(0);
+        load_b(0);
+        store_a(0);
+        store_b(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt++) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            load_a(kt + 1);
+            load_b(kt + 1);
+        }
+        const float *As = As0 + cur * BK * LDA + wm0 + l31;
+        const float *Bs = Bs0 + cur * BK * LDB + wn0 + l31;
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; kk++) {
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; i++) af[i] = As[(2 * kk + half) * LDA + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; j++) bf[j] = Bs[(2 * kk + half) * LDB + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            store_a(cur ^ 1);
+            store_b(cur ^ 1);
+        }
+        if constexpr (MULTI_KC) {
+            if (more && ((kt + 1) % KC_TILES) == 0) flush(kt + 1 == KC_TILES);
+        }
+        __syncthreads();
+    }
+
+    // ---- final depth block + fused epilogue (residual Add, activation), NCHW / row-major store
+    const float *__restrict__ resb = p.res;
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                float v;
+                if constexpr (MULTI_KC) {
+                    v = (nk > KC_TILES) ? combine(acc[i][j][r], tot[i][j][r], p.alpha, 1.f)
+                                        : first_value(acc[i][j][r], j, m, c_col[j], c_n[j], c_col_ok[j]);
+                } else {
+                    v = first_value(acc[i][j][r], j, m, c_col[j], c_n[j], c_col_ok[j]);
+                }
+                if (m < p.M && c_col_ok[j]) {
+                    const long long off = c_col[j] + (long long)m * p.c_rs;
+                    if (resb) v = v + resb[off];
+                    if (p.act == RTEN_HIP_ACT_RELU) v = vm::relu(v);
+                    else if (p.act == RTEN_HIP_ACT_GELU) v = vm::gelu(v);
+                    p.C[off] = v;
+                }
+            }
+}
+
+} // namespace
+
+// =====================================================================================================
+// Host side: variant selection and the C-ABI entry points
+// =====================================================================================================
+namespace {
+
+struct TileCfg { int bm, bn; float penalty; };
+// variant ids are part of the tuning interface (rten_hip_set_gemm_variant_override)
+constexpr TileCfg kCfgs[4] = {{128, 128, 1.00f}, {128, 64, 1.04f}, {64, 128, 1.04f}, {64, 64, 1.12f}};
+
+template <int BM, int BN, int AL, int BL>
+int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z, const char *name) {
+    a.tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = (a.N + BN - 1) / BN;
+    dim3 grid((unsigned)(a.tiles_m * a.tiles_n), (unsigned)Z);
+    const double flops = 2.0 * a.M * (double)a.N * a.K * Z;
+    const double bytes = 4.0 * Z * ((double)a.M * a.K + (double)a.K * a.N + (double)a.M * a.N);
+    char kname[96];
+    const bool multi = a.K > 256;
+    snprintf(kname, sizeof kname, "igemm_f32_kernel<%d,%d,%d,%d,%d>", BM, BN, AL, BL, multi ? 1 : 0);
+    (void)name;
+    ProfScope ps(ctx, kname, flops, bytes);
+    if (multi)
+        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, AL, BL, true>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, AL, BL, false>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+    RTEN_LAUNCH_CHECK(ctx, "igemm_f32_kernel launch");
+    return RTEN_HIP_OK;
+}
+
+template <int AL, int BL>
+int32_t launch_variant(rten_hip_ctx *ctx, GemmArgs &a, int Z, int cfg) {
+    switch (cfg) {
+    case 0: return launch_cfg<128, 128, AL, BL>(ctx, a, Z, "");
+    case 1: return launch_cfg<128, 64, AL, BL>(ctx, a, Z, "");
+    case 2: return launch_cfg<64, 128, AL, BL>(ctx, a, Z, "");
+    default: return launch_cfg<64, 64, AL, BL>(ctx, a, Z, "");
+    }
+}
+
+int pick_cfg(rten_hip_ctx *ctx, int M, long long N, int Z) {
+    if (ctx->gemm_variant_override >= 0 && ctx->gemm_variant_override < 4) return ctx->gemm_variant_override;
+    int best = 3;
+    double best_cost = 1e300;
+    for (int c = 0; c < 4; c++) {
+        const TileCfg &t = kCfgs[c];
+        const long long tiles = (long long)((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn) * Z;
+        const long long rounds = (tiles + ctx->num_cus - 1) / ctx->num_cus;
+        const double cost = (double)rounds * t.bm * t.bn * t.penalty;
+        if (cost < best_cost) { best_cost = cost; best = c; }
+    }
+    return best;
+}
+
+inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
+
+unsigned magic_for(unsigned d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + d - 1) / d); }
+
+int32_t dispatch(rten_hip_ctx *ctx, GemmArgs &a, int Z, int al, int bl) {
+    const int cfg = pick_cfg(ctx, a.M, a.N, Z);
+    if (al == A_M4 && bl == B_N4) return launch_variant<A_M4, B_N4>(ctx, a, Z, cfg);
+    if (al == A_M4 && bl == B_IM2COL) return launch_variant<A_M4, B_IM2COL>(ctx, a, Z, cfg);
+    if (al == A_K4 && bl == B_N4) return launch_variant<A_K4, B_N4>(ctx, a, Z, cfg);
+    if (al == A_K4 && bl == B_K4) return launch_variant<A_K4, B_K4>(ctx, a, Z, cfg);
+    if (bl == B_IM2COL) return launch_variant<A_SCALAR, B_IM2COL>(ctx, a, Z, cfg);
+    return launch_variant<A_SCALAR, B_SCALAR>(ctx, a, Z, cfg == 0 ? 1 : cfg); // 128x128 all-scalar spills
+}
+
+} // namespace
+
+RTEN_EXPORT int32_t rten_hip_num_gemm_variants(void) { return 4; }
+
+RTEN_EXPORT int32_t rten_hip_set_gemm_variant_override(rten_hip_ctx *ctx, int32_t variant) {
+    RTEN_CHECK_CTX(ctx);
+    ctx->gemm_variant_override = variant;
+    return RTEN_HIP_OK;
+}
+
+RTEN_EXPORT int32_t rten_hip_gemm_f32(rten_hip_ctx *ctx, const rten_hip_gemm_desc *d, const float *a, const float *b,
+                                      const float *bias, float *c) {
+    RTEN_CHECK_CTX(ctx);
+    if (!d) return RTEN_HIP_ERR_INVALID_VALUE;
+    if (d->m < 0 || d->n < 0 || d->k < 0 || d->batch < 0)
+        return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "gemm: negative dimension");
+    if (d->bias_kind != RTEN_HIP_BIAS_NONE && !bias)
+        return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "gemm: bias_kind set but bias is NULL");
+    if (d->m == 0 || d->n == 0 || d->batch == 0) return RTEN_HIP_OK; // rten-gemm/src/lib.rs:835-839
+    if (!c || (d->k > 0 && (!a || !b))) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "gemm: NULL operand");
+    if (d->ldc < d->n) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "gemm: ldc < n");
+
+    GemmArgs g = {};
+    g.A = a; g.B = b; g.C = c; g.bias = bias; g.res = nullptr;
+    g.M = d->m; g.N = d->n; g.K = d->k;
+    g.a_rs = d->a_rs; g.a_cs = d->a_cs; g.a_bs = d->a_bs;
+    g.b_rs = d->b_rs; g.b_cs = d->b_cs; g.b_ns = 0; g.b_bs = d->b_bs;
+    g.c_rs = d->ldc; g.c_ns = 0; g.c_bs = d->c_bs;
+    g.bias_bs = 0;
+    g.Pn = d->n;
+    g.alpha = d->alpha; g.beta = d->beta;
+    g.bias_kind = d->bias_kind; g.act = d->act;
+    g.a_dir_m = (d->a_rs == 1 && d->a_cs != 1) ? 1 : 0;
+    g.b_dir_n = (d->b_cs == 1 || d->b_rs != 1) ? 1 : 0;
+
+    int al = A_SCALAR, bl = B_SCALAR;
+    if (d->k > 0) {
+        if (d->a_rs == 1 && d->a_cs % 4 == 0 && d->m % 4 == 0 && d->a_bs % 4 == 0 && aligned16(a)) al = A_M4;
+        else if (d->a_cs == 1 && d->a_rs % 4 == 0 && d->k % 4 == 0 && d->a_bs % 4 == 0 && aligned16(a)) al = A_K4;
+        if (d->b_cs == 1 && d->b_rs % 4 == 0 && d->n % 4 == 0 && d->b_bs % 4 == 0 && aligned16(b)) bl = B_N4;
+        else if (d->b_rs == 1 && d->b_cs % 4 == 0 && d->k % 4 == 0 && d->b_bs % 4 == 0 && aligned16(b)) bl = B_K4;
+        const bool have = (al == A_M4 && bl == B_N4) || (al == A_K4 && bl == B_N4) || (al == A_K4 && bl == B_K4);
+        if (!have) { al = A_SCALAR; bl = B_SCALAR; }
+    }
+    return dispatch(ctx, g, d->batch, al, bl);
+}
+
+// ---- conv weight staging: W[g][m][k] (OIHW) -> packed[g][k][Og4], zero padded (Og4 = round_up(O/g, 4))
+namespace {
+__global__ void conv_prepack_f32_kernel(const float *__restrict__ w, float *__restrict__ packed, int groups, int Og,
+                                        int K, int Og4) {
+    const long long total = (long long)groups * K * Og4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(i % Og4);
+        const long long r = i / Og4;
+        const int k = (int)(r % K);
+        const int g = (int)(r / K);
+        packed[i] = m < Og ? w[((long long)g * Og + m) * K + k] : 0.f;
+    }
+}
+
+int32_t check_conv_desc(rten_hip_ctx *ctx, const rten_hip_conv2d_desc *d) {
+    if (!d) return RTEN_HIP_ERR_INVALID_VALUE;
+    if (d->groups <= 0) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "Group count must be > 0");
+    if (d->c % d->groups != 0)
+        return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "Input channel count not divisible by groups");
+    if (d->o % d->groups != 0)
+        return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "Output channel count not divisible by groups");
+    if (d->n < 0 || d->c <= 0 || d->h <= 0 || d->w <= 0 || d->o <= 0 || d->kh <= 0 || d->kw <= 0 || d->stride_h <= 0 ||
+        d->stride_w <= 0 || d->dil_h <= 0 || d->dil_w <= 0 || d->out_h < 0 || d->out_w < 0)
+        return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "conv: invalid geometry");
+    const long long in_elems = (long long)d->n * d->c * d->h * d->w;
+    const long long out_elems = (long long)d->n * d->o * d->out_h * d->out_w;
+    if (in_elems >= (1ll << 31) || out_elems >= (1ll << 31))
+        return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "conv: tensors above 2^31 elements are not supported");
+    return RTEN_HIP_OK;
+}
+} // namespace
+
+RTEN_EXPORT size_t rten_hip_conv2d_f32_packed_bytes(const rten_hip_conv2d_desc *d) {
+    if (!d || d->groups <= 0) return 0;
+    const int Og = d->o / d->groups, Og4 = (Og + 3) & ~3;
+    const long long K = (long long)(d->c / d->groups) * d->kh * d->kw;
+    return (size_t)d->groups * K * Og4 * sizeof(float);
+}
+
+RTEN_EXPORT int32_t rten_hip_conv2d_f32_prepack(rten_hip_ctx *ctx, const rten_hip_conv2d_desc *d, const float *w,
+                                                float *packed) {
+    RTEN_CHECK_CTX(ctx);
+    int32_t rc = check_conv_desc(ctx, d);
+    if (rc) return rc;
+    if (!w || !packed) return RTEN_HIP_ERR_INVALID_VALUE;
+    const int Og = d->o / d->groups, Og4 = (Og + 3) & ~3;
+    const int K = (d->c / d->groups) * d->kh * d->kw;
+    const long long total = (long long)d->groups * K * Og4;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(conv_prepack_f32_kernel, dim3(blocks), dim3(256), 0, ctx->stream, w, packed, d->groups, Og, K,
+                       Og4);
+    RTEN_LAUNCH_CHECK(ctx, "conv_prepack_f32_kernel launch");
+    return RTEN_HIP_OK;
+}
+
+RTEN_EXPORT int32_t rten_hip_conv2d_f32(rten_hip_ctx *ctx, const rten_hip_conv2d_desc *d, const float *x, const float *w,
+                                        int32_t weights_packed, const float *bias, const float *residual,
+                                        uint32_t flags, float *y) {
+    RTEN_CHECK_CTX(ctx);
+    int32_t rc = check_conv_desc(ctx, d);
+    if (rc) return rc;
+    if (!x || !w || !y) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "conv: NULL operand");
+    if ((flags & RTEN_HIP_CONV_RESIDUAL) && !residual)
+        return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "conv: residual flag without residual tensor");
+    if (d->n == 0 || d->out_h == 0 || d->out_w == 0) return RTEN_HIP_OK;
+    const int Cg = d->c / d->groups, Og = d->o / d->groups, Og4 = (Og + 3) & ~3;
+    const int K = Cg * d->kh * d->kw;
+    const int P = d->out_h * d->out_w;
+    const long long HW = (long long)d->h * d->w;
+
+    GemmArgs g = {};
+    g.A = w; g.B = x; g.C = y; g.bias = bias; g.res = (flags & RTEN_HIP_CONV_RESIDUAL) ? residual : nullptr;
+    g.M = Og; g.N = d->n * P; g.K = K;
+    int al;
+    if (weights_packed) {
+        g.a_rs = 1; g.a_cs = Og4; g.a_bs = (long long)K * Og4;
+        al = aligned16(w) ? A_M4 : A_SCALAR;
+        g.a_dir_m = 1;
+    } else {
+        g.a_rs = K; g.a_cs = 1; g.a_bs = (long long)Og * K;
+        al = A_SCALAR;
+        g.a_dir_m = 0;
+    }
+    g.b_bs = (long long)Cg * HW;
+    g.b_ns = (long long)d->c * HW;
+    g.c_rs = P; g.c_ns = (long long)d->o * P; g.c_bs = (long long)Og * P;
+    g.bias_bs = Og;
+    g.Pn = P;
+    g.alpha = 1.f; g.beta = 0.f;
+    g.bias_kind = bias ? RTEN_HIP_BIAS_PER_ROW : RTEN_HIP_BIAS_NONE;
+    g.act = (flags & RTEN_HIP_CONV_RELU) ? RTEN_HIP_ACT_RELU : RTEN_HIP_ACT_NONE;
+
+    const bool pointwise = d->kh == 1 && d->kw == 1 && d->stride_h == 1 && d->stride_w == 1 && d->pads[0] == 0 &&
+                           d->pads[1] == 0 && d->pads[2] == 0 && d->pads[3] == 0; // conv.rs:250-258 (dilation is moot)
+    int bl = B_IM2COL;
+    if (pointwise && al == A_M4 && (P % 4) == 0 && aligned16(x)) {
+        // the image batch is a two-level [C, (n, H*W)] matrix: no gather needed
+        bl = B_N4;
+        g.b_rs = HW; g.b_cs = 1;
+    } else {
+        g.H = d->h; g.W = d->w; g.HW = (int)HW; g.KHW = d->kh * d->kw; g.KW = d->kw; g.OW = d->out_w;
+        g.sy = d->stride_h; g.sx = d->stride_w; g.dy = d->dil_h; g.dx = d->dil_w;
+        g.pt = d->pads[0]; g.pl = d->pads[1];
+        g.magic_khw = magic_for((unsigned)g.KHW);
+        g.magic_kw = magic_for((unsigned)g.KW);
+    }
+    g.b_dir_n = 1;
+    return dispatch(ctx, g, d->groups, al, bl);
+}

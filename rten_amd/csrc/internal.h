@@ -1,0 +1,73 @@
+// Internal declarations shared by the translation units of librten_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/rten_hip.h"
+
+#define RTEN_EXPORT extern "C" __attribute__((visibility("default")))
+
+struct ProfEntry {
+    int launches = 0;
+    double ms = 0.0;
+    double flops = 0.0;
+    double bytes = 0.0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; // events not yet resolved
+    std::vector<std::pair<double, double>> pending_work;    // (flops, bytes) per pending launch
+};
+
+struct rten_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string last_error;
+    hipEvent_t timers[64][2] = {};
+    bool capturing = false;
+    // profiling
+    bool profiling = false;
+    std::map<std::string, ProfEntry> prof;
+    std::vector<hipEvent_t> event_pool;
+    // scratch (grown on demand, never during capture)
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    int gemm_variant_override = -1;
+    int num_cus = 256;
+};
+
+int32_t rten_set_error(rten_hip_ctx *ctx, int32_t code, const char *fmt, ...);
+int32_t rten_check_hip(rten_hip_ctx *ctx, hipError_t e, const char *what);
+void *rten_scratch(rten_hip_ctx *ctx, size_t bytes);
+
+// Profiling bracket around one kernel launch.
+struct ProfScope {
+    rten_hip_ctx *ctx;
+    const char *name;
+    double flops, bytes;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProfScope(rten_hip_ctx *c, const char *n, double fl, double by);
+    ~ProfScope();
+};
+
+#define RTEN_CHECK_CTX(ctx)                 \
+    do {                                    \
+        if (!(ctx)) return RTEN_HIP_ERR_INVALID_VALUE; \
+    } while (0)
+
+#define RTEN_HIP_TRY(ctx, expr)                                  \
+    do {                                                         \
+        hipError_t _e = (expr);                                  \
+        if (_e != hipSuccess) return rten_check_hip(ctx, _e, #expr); \
+    } while (0)
+
+#define RTEN_LAUNCH_CHECK(ctx, what)                             \
+    do {                                                         \
+        hipError_t _e = hipGetLastError();                       \
+        if (_e != hipSuccess) return rten_check_hip(ctx, _e, what); \
+    } while (0)
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,311 @@
+// Wavefront-per-row reduction kernels: Softmax / AddSoftmax, LayerNormalization, GlobalAveragePool.
+// Replaces rten-vecmath/src/softmax.rs:60-100,178-228, sum.rs:12-34,100-130, normalize.rs:82-170 and
+// their operator front-ends src/ops/norm.rs:103-161,456-529,825-840, src/ops/attention.rs:30-68,
+// src/ops/pooling.rs:477-521.
+//
+// MI355X mapping: one 64-lane wavefront owns one row; the row lives in registers (up to 16 values
+// per lane) so HBM sees exactly one read and one write per element; 4 rows per 256-thread workgroup.
+//
+// Reduction order: the reference keeps V-lane SIMD partial sums and adds the lanes left to right at
+// the end (rten-simd/src/iter.rs:97-120 fold_unroll<4>, sum.rs:27-33).  A 64-lane wavefront IS four
+// 16-lane AVX-512 vectors side by side, so the kernels below reproduce the V = 16 order exactly:
+// lane t = 16u + l accumulates x[64c + t] over chunks c (the four unrolled accumulators), lanes 0..15
+// then fold acc[l+16], acc[l+32], acc[l+48] in that order, absorb the remaining <4 full vectors and the
+// masked tail, and the 16 lane totals are added sequentially.  Results are therefore bit-identical to
+// the reference running on an AVX-512 host (and to oracle lanes=16); hosts with another SIMD width
+// differ by reduction-order rounding only (tolerance in DESIGN.md).
+#include "internal.h"
+#include "vecmath.h"
+
+namespace {
+
+constexpr int ROWS_PER_BLOCK = 4;
+constexpr int MAX_CH = 16; // register-resident rows up to 1024 columns
+
+__device__ __forceinline__ float lane_bcast(float v, int src_lane) { return __shfl(v, src_lane, 64); }
+
+// fold_unroll<4> order (sum.rs:27-33,110-127).  kind 0: sum x ; kind 1: sum (x-off)^2 via mul_add.
+// `get(i)` returns element i (i < n).  All lanes return the same total.
+template <int KIND, typename Get>
+__device__ __forceinline__ float simd16_reduce(Get get, int n, float off, int lane) {
+    auto f = [&](float acc, float x) -> float {
+        if constexpr (KIND == 0) return acc + x;
+        else { const float d = x - off; return vm::fma(d, d, acc); }
+    };
+    float acc = 0.f;
+    const int full4 = n / 64;
+    for (int c = 0; c < full4; c++) acc = f(acc, get(c * 64 + lane));
+    // acc0 += acc1; += acc2; += acc3  (lanes 0..15 hold the running vector)
+    float a = acc;
+    a = a + lane_bcast(acc, (lane & 15) + 16);
+    a = a + lane_bcast(acc, (lane & 15) + 32);
+    a = a + lane_bcast(acc, (lane & 15) + 48);
+    int i0 = full4 * 64;
+    const int l = lane & 15;
+    for (; i0 + 16 <= n; i0 += 16) a = f(a, get(i0 + l));
+    if (i0 + l < n) a = f(a, get(i0 + l)); // masked tail: other lanes keep their value
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) s = s + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), k));
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Softmax: max (f32::MIN start), e = ReducedRangeExp(x - max), sum in single-accumulator 16-lane order
+// (softmax.rs:194-228), y = e * (1 / sum), optional NaN -> 0.
+// ------------------------------------------------------------------------------------------------
+template <int CH>
+__global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void softmax_kernel(int64_t rows, int cols, const float *__restrict__ x,
+                                                                      const float *__restrict__ addend, int64_t add_div,
+                                                                      int64_t add_mod, int flush_nan,
+                                                                      float *__restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *xr = x + row * cols;
+    const float *ar = addend ? addend + ((row / add_div) % add_mod) * cols : nullptr;
+    float v[CH];
+    float mx = -3.40282347e+38f; // f32::MIN (softmax.rs:181)
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const int i = c * 64 + lane;
+        float t = -3.40282347e+38f;
+        if (i < cols) {
+            t = xr[i];
+            if (ar) t = t + ar[i]; // `*qk += m` (attention.rs:59-61)
+            mx = fmaxf(mx, t);
+        }
+        v[c] = t;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    // exp + 16-lane ordered sum: lane l < 16 adds e[64c + l], e[64c + l + 16], e[64c + l + 32], e[64c + l + 48]
+    float a = 0.f;
+    const int l = lane & 15;
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const int i = c * 64 + lane;
+        const float e = i < cols ? vm::exp_reduced(v[c] - mx) : 0.f;
+        v[c] = e;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float eq = lane_bcast(e, l + 16 * q);
+            if (c * 64 + l + 16 * q < cols) a = a + eq;
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) s = s + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), k));
+    const float inv = 1.0f / s;
+    float *yr = y + row * cols;
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const int i = c * 64 + lane;
+        if (i < cols) {
+            float r = v[c] * inv;
+            if (flush_nan && !(r == r)) r = 0.f;
+            yr[i] = r;
+        }
+    }
+}
+
+// Generic fallback for long rows: same order, row re-read from global (L2 resident).
+__global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void softmax_long_kernel(int64_t rows, int cols,
+                                                                           const float *__restrict__ x,
+                                                                           const float *__restrict__ addend,
+                                                                           int64_t add_div, int64_t add_mod,
+                                                                           int flush_nan, float *__restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *xr = x + row * cols;
+    const float *ar = addend ? addend + ((row / add_div) % add_mod) * cols : nullptr;
+    float *yr = y + row * cols;
+    float mx = -3.40282347e+38f;
+    for (int i = lane; i < cols; i += 64) {
+        float t = xr[i];
+        if (ar) t = t + ar[i];
+        mx = fmaxf(mx, t);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float a = 0.f;
+    const int l = lane & 15;
+    const int nch = (cols + 63) / 64;
+    for (int c = 0; c < nch; c++) {
+        const int i = c * 64 + lane;
+        float e = 0.f;
+        if (i < cols) {
+            float t = xr[i];
+            if (ar) t = t + ar[i];
+            e = vm::exp_reduced(t - mx);
+            yr[i] = e;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float eq = lane_bcast(e, l + 16 * q);
+            if (c * 64 + l + 16 * q < cols) a = a + eq;
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) s = s + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), k));
+    const float inv = 1.0f / s;
+    for (int i = lane; i < cols; i += 64) {
+        float r = yr[i] * inv;
+        if (flush_nan && !(r == r)) r = 0.f;
+        yr[i] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNormalization (norm.rs:103-161): mean = Sum/n, var = SumSquareSub(mean)/n (two-pass),
+// ssr = gamma_scalar / sqrt(var + eps), then one of the three Normalize forms (normalize.rs:112-166).
+// ------------------------------------------------------------------------------------------------
+template <int CH>
+__global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void layer_norm_kernel(int64_t rows, int cols,
+                                                                         const float *__restrict__ x,
+                                                                         const float *__restrict__ gamma,
+                                                                         const float *__restrict__ beta,
+                                                                         float gamma_scalar, float beta_scalar,
+                                                                         float eps, float *__restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *xr = x + row * cols;
+    float *yr = y + row * cols;
+    [[maybe_unused]] float v[CH > 0 ? CH : 1];
+    if constexpr (CH > 0) {
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const int i = c * 64 + lane;
+            v[c] = i < cols ? xr[i] : 0.f;
+        }
+    }
+    // element fetch by index for the ordered reduction: register-resident rows are indexed through
+    // their owning lane (i % 64 == this lane for the unrolled part; the <64-element remainder needs a
+    // cross-lane read, served from global/L1 instead of a dynamic register index).
+    auto get = [&](int i) -> float { return xr[i]; };
+    float mean, var;
+    if constexpr (CH > 0) {
+        // Same order as simd16_reduce, but the full-chunk part reads registers.
+        auto red = [&](auto f) -> float {
+            float acc = 0.f;
+            const int full4 = cols / 64;
+#pragma unroll
+            for (int c = 0; c < CH; c++)
+                if (c < full4) acc = f(acc, v[c]);
+            float a = acc;
+            a = a + lane_bcast(acc, (lane & 15) + 16);
+            a = a + lane_bcast(acc, (lane & 15) + 32);
+            a = a + lane_bcast(acc, (lane & 15) + 48);
+            int i0 = full4 * 64;
+            const int l = lane & 15;
+            for (; i0 + 16 <= cols; i0 += 16) a = f(a, get(i0 + l));
+            if (i0 + l < cols) a = f(a, get(i0 + l));
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; k++) s = s + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), k));
+            return s;
+        };
+        mean = red([](float acc, float xv) { return acc + xv; }) / (float)cols;
+        const float m = mean;
+        var = red([m](float acc, float xv) { const float d = xv - m; return vm::fma(d, d, acc); }) / (float)cols;
+    } else {
+        mean = simd16_reduce<0>(get, cols, 0.f, lane) / (float)cols;
+        var = simd16_reduce<1>(get, cols, mean, lane) / (float)cols;
+    }
+    const float ssr = gamma_scalar / sqrtf(var + eps);
+    const int mode = (!gamma && !beta) ? 0 : ((gamma && !beta && beta_scalar == 0.f) ? 1 : 2);
+    auto norm = [&](float xv, int i) -> float {
+        if (mode == 0) return vm::fma(xv - mean, ssr, beta_scalar);
+        if (mode == 1) return (xv - mean) * (gamma[i] * ssr);
+        const float sv = (gamma ? gamma[i] : 1.0f) * ssr;
+        const float bv = (beta ? beta[i] : 0.f) + beta_scalar;
+        return vm::fma(xv - mean, sv, bv);
+    };
+    if constexpr (CH > 0) {
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const int i = c * 64 + lane;
+            if (i < cols) yr[i] = norm(v[c], i);
+        }
+    } else {
+        for (int i = lane; i < cols; i += 64) yr[i] = norm(xr[i], i);
+    }
+}
+
+// GlobalAveragePool (pooling.rs:516-521): Sum(chan) / len in the same SIMD order.
+__global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void global_avg_pool_kernel(int64_t rows, int inner,
+                                                                              const float *__restrict__ x,
+                                                                              float *__restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *xr = x + row * inner;
+    auto get = [&](int i) -> float { return xr[i]; };
+    const float s = simd16_reduce<0>(get, inner, 0.f, lane);
+    if (lane == 0) y[row] = s / (float)inner;
+}
+
+} // namespace
+
+RTEN_EXPORT int32_t rten_hip_softmax_f32(rten_hip_ctx *ctx, int64_t rows, int32_t cols, const float *x,
+                                         const float *addend, int64_t add_div, int64_t add_mod,
+                                         int32_t flush_nan_to_zero, float *y) {
+    RTEN_CHECK_CTX(ctx);
+    if (rows < 0 || cols < 0) return RTEN_HIP_ERR_INVALID_VALUE;
+    if (rows == 0 || cols == 0) return RTEN_HIP_OK; // norm.rs:711-713
+    if (!x || !y) return RTEN_HIP_ERR_INVALID_VALUE;
+    if (addend && (add_div <= 0 || add_mod <= 0))
+        return rten_set_error(ctx, RTEN_HIP_ERR_INCOMPATIBLE_SHAPES, "Cannot broadcast inputs");
+    if (!addend) { add_div = 1; add_mod = 1; }
+    const dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(64 * ROWS_PER_BLOCK);
+    ProfScope ps(ctx, "softmax_f32", 0.0, 8.0 * rows * cols);
+#define SM_LAUNCH(CH) hipLaunchKernelGGL((softmax_kernel<CH>), grid, block, 0, ctx->stream, rows, cols, x, addend, add_div, add_mod, flush_nan_to_zero, y)
+    if (cols <= 64) SM_LAUNCH(1);
+    else if (cols <= 128) SM_LAUNCH(2);
+    else if (cols <= 256) SM_LAUNCH(4);
+    else if (cols <= 512) SM_LAUNCH(8);
+    else if (cols <= 1024) SM_LAUNCH(16);
+    else
+        hipLaunchKernelGGL(softmax_long_kernel, grid, block, 0, ctx->stream, rows, cols, x, addend, add_div, add_mod,
+                           flush_nan_to_zero, y);
+#undef SM_LAUNCH
+    RTEN_LAUNCH_CHECK(ctx, "softmax_kernel");
+    return RTEN_HIP_OK;
+}
+
+RTEN_EXPORT int32_t rten_hip_layer_norm_f32(rten_hip_ctx *ctx, int64_t rows, int32_t cols, const float *x,
+                                            const float *gamma, const float *beta, float gamma_scalar,
+                                            float beta_scalar, float epsilon, float *y) {
+    RTEN_CHECK_CTX(ctx);
+    if (rows < 0 || cols < 0) return RTEN_HIP_ERR_INVALID_VALUE;
+    if (rows == 0 || cols == 0) return RTEN_HIP_OK;
+    if (!x || !y) return RTEN_HIP_ERR_INVALID_VALUE;
+    const dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(64 * ROWS_PER_BLOCK);
+    ProfScope ps(ctx, "layer_norm_f32", 0.0, 8.0 * rows * cols);
+#define LN_LAUNCH(CH) hipLaunchKernelGGL((layer_norm_kernel<CH>), grid, block, 0, ctx->stream, rows, cols, x, gamma, beta, gamma_scalar, beta_scalar, epsilon, y)
+    if (cols <= 128) LN_LAUNCH(2);
+    else if (cols <= 256) LN_LAUNCH(4);
+    else if (cols <= 512) LN_LAUNCH(8);
+    else if (cols <= 768) LN_LAUNCH(12);
+    else if (cols <= 1024) LN_LAUNCH(16);
+    else LN_LAUNCH(0);
+#undef LN_LAUNCH
+    RTEN_LAUNCH_CHECK(ctx, "layer_norm_kernel");
+    return RTEN_HIP_OK;
+}
+
+RTEN_EXPORT int32_t rten_hip_global_average_pool_f32(rten_hip_ctx *ctx, int64_t nc, int32_t inner, const float *x,
+                                                     float *y) {
+    RTEN_CHECK_CTX(ctx);
+    if (nc < 0 || inner <= 0) return RTEN_HIP_ERR_INVALID_VALUE;
+    if (nc == 0) return RTEN_HIP_OK;
+    if (!x || !y) return RTEN_HIP_ERR_INVALID_VALUE;
+    const dim3 grid((unsigned)((nc + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(64 * ROWS_PER_BLOCK);
+    ProfScope ps(ctx, "global_average_pool_f32", 0.0, 4.0 * nc * (inner + 1));
+    hipLaunchKernelGGL(global_avg_pool_kernel, grid, block, 0, ctx->stream, nc, inner, x, y);
+    RTEN_LAUNCH_CHECK(ctx, "global_avg_pool_kernel");
+    return RTEN_HIP_OK;
+}

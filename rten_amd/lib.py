@@ -1,0 +1,221 @@
+"""ctypes binding of the C ABI in include/rten_hip.h (librten_hip.so, gfx950 only).
+
+This is plumbing: it declares the C structs / prototypes and raises when the native library is
+missing or reports an error.  There is deliberately NO fallback path: if the HIP extension cannot be
+loaded or no MI355X is visible, every operator raises (`BackendUnavailable`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "librten_hip.so")
+
+OK = 0
+ERR_INVALID_VALUE, ERR_INCOMPATIBLE_SHAPES, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE = 1, 2, 3, 4, 5
+
+BIAS_NONE, BIAS_PER_ROW, BIAS_PER_COL = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+CONV_RELU, CONV_RESIDUAL = 1, 2
+PAD_ZERO_POINT, PAD_RAW0_I8, PAD_RAW0_U8 = 0, 1, 2
+
+
+class BackendUnavailable(RuntimeError):
+    """The HIP extension is missing or no gfx950 device is usable."""
+
+
+class HipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"rten_hip error {code}: {msg}")
+        self.code = code
+        self.msg = msg
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32),
+                ("a_rs", C.c_int64), ("a_cs", C.c_int64), ("b_rs", C.c_int64), ("b_cs", C.c_int64),
+                ("ldc", C.c_int64), ("batch", C.c_int32),
+                ("a_bs", C.c_int64), ("b_bs", C.c_int64), ("c_bs", C.c_int64),
+                ("alpha", C.c_float), ("beta", C.c_float), ("bias_kind", C.c_int32), ("act", C.c_int32)]
+
+
+class GemmInt8Desc(C.Structure):
+    _fields_ = [("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32),
+                ("a_rs", C.c_int64), ("a_cs", C.c_int64), ("b_rs", C.c_int64), ("b_cs", C.c_int64),
+                ("ldc", C.c_int64), ("a_signed", C.c_int32), ("b_signed", C.c_int32),
+                ("a_zp_len", C.c_int32), ("b_zp_len", C.c_int32), ("scale_len", C.c_int32)]
+
+
+class Conv2dDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("c", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
+                ("o", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
+                ("pads", C.c_int32 * 4),
+                ("stride_h", C.c_int32), ("stride_w", C.c_int32), ("dil_h", C.c_int32), ("dil_w", C.c_int32),
+                ("groups", C.c_int32), ("out_h", C.c_int32), ("out_w", C.c_int32)]
+
+
+class Conv2dInt8Desc(C.Structure):
+    _fields_ = [("conv", Conv2dDesc), ("x_signed", C.c_int32), ("w_signed", C.c_int32),
+                ("w_zp_len", C.c_int32), ("pad_mode", C.c_int32)]
+
+
+class Pool2dDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("c", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
+                ("kh", C.c_int32), ("kw", C.c_int32), ("stride_h", C.c_int32), ("stride_w", C.c_int32),
+                ("pads", C.c_int32 * 4), ("out_h", C.c_int32), ("out_w", C.c_int32),
+                ("count_include_pad", C.c_int32)]
+
+
+# every symbol include/rten_hip.h declares (checked by tests/test_abi.py against the header)
+_VP, _I32, _I64, _F32, _U32, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32, C.c_size_t
+PROTOTYPES = {
+    "rten_hip_init": (_I32, [_I32, _VP, C.POINTER(_VP)]),
+    "rten_hip_destroy": (_I32, [_VP]),
+    "rten_hip_last_error": (C.c_char_p, [_VP]),
+    "rten_hip_abi_version": (_I32, []),
+    "rten_hip_sync": (_I32, [_VP]),
+    "rten_hip_device_info": (_I32, [_VP, C.c_char_p, _I32, C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I64)]),
+    "rten_hip_malloc": (_I32, [_VP, _SZ, C.POINTER(_VP)]),
+    "rten_hip_free": (_I32, [_VP, _VP]),
+    "rten_hip_memcpy_h2d": (_I32, [_VP, _VP, _VP, _SZ]),
+    "rten_hip_memcpy_d2h": (_I32, [_VP, _VP, _VP, _SZ]),
+    "rten_hip_memcpy_d2d": (_I32, [_VP, _VP, _VP, _SZ]),
+    "rten_hip_memset": (_I32, [_VP, _VP, _I32, _SZ]),
+    "rten_hip_timer_start": (_I32, [_VP, _I32]),
+    "rten_hip_timer_stop": (_I32, [_VP, _I32]),
+    "rten_hip_timer_elapsed_ms": (_I32, [_VP, _I32, C.POINTER(_F32)]),
+    "rten_hip_graph_begin": (_I32, [_VP]),
+    "rten_hip_graph_end": (_I32, [_VP, C.POINTER(C.c_uint64)]),
+    "rten_hip_graph_launch": (_I32, [_VP, C.c_uint64]),
+    "rten_hip_graph_destroy": (_I32, [_VP, C.c_uint64]),
+    "rten_hip_profile_enable": (_I32, [_VP, _I32]),
+    "rten_hip_profile_reset": (_I32, [_VP]),
+    "rten_hip_profile_report": (_I32, [_VP, C.c_char_p, _I32]),
+    "rten_hip_calc_output_size_and_padding": (_I32, [_I32] * 7 + [C.POINTER(_I32), _I32, _I32, _I32, C.POINTER(_I32),
+                                                                 C.POINTER(_I32), C.POINTER(C.c_char_p)]),
+    "rten_hip_gemm_f32": (_I32, [_VP, C.POINTER(GemmDesc), _VP, _VP, _VP, _VP]),
+    "rten_hip_gemm_int8": (_I32, [_VP, C.POINTER(GemmInt8Desc), _VP, _VP, _VP, _VP, _VP, _VP]),
+    "rten_hip_conv2d_f32_packed_bytes": (_SZ, [C.POINTER(Conv2dDesc)]),
+    "rten_hip_conv2d_f32_prepack": (_I32, [_VP, C.POINTER(Conv2dDesc), _VP, _VP]),
+    "rten_hip_conv2d_f32": (_I32, [_VP, C.POINTER(Conv2dDesc), _VP, _VP, _I32, _VP, _VP, _U32, _VP]),
+    "rten_hip_conv2d_int8": (_I32, [_VP, C.POINTER(Conv2dInt8Desc), _VP, _VP, _VP, _VP, _VP, _VP, _VP, _U32, _VP]),
+    "rten_hip_dynamic_quantize_linear": (_I32, [_VP, _I64, _VP, _VP, _VP, _VP]),
+    "rten_hip_cast_scale": (_I32, [_VP, _I64, _VP, _VP, _I32, _VP]),
+    "rten_hip_softmax_f32": (_I32, [_VP, _I64, _I32, _VP, _VP, _I64, _I64, _I32, _VP]),
+    "rten_hip_layer_norm_f32": (_I32, [_VP, _I64, _I32, _VP, _VP, _VP, _F32, _F32, _F32, _VP]),
+    "rten_hip_batch_norm_f32": (_I32, [_VP, _I32, _I32, _I64, _VP, _VP, _VP, _VP, _VP, _F32, _VP]),
+    "rten_hip_relu_f32": (_I32, [_VP, _I64, _VP, _VP]),
+    "rten_hip_gelu_f32": (_I32, [_VP, _I64, _VP, _VP]),
+    "rten_hip_erf_f32": (_I32, [_VP, _I64, _VP, _VP]),
+    "rten_hip_add_f32": (_I32, [_VP, _I64, _VP, _VP, _I64, _VP]),
+    "rten_hip_mul_f32": (_I32, [_VP, _I64, _VP, _VP, _I64, _VP]),
+    "rten_hip_add_channel_bias_f32": (_I32, [_VP, _I32, _I32, _I64, _VP, _VP, _VP]),
+    "rten_hip_max_pool2d_f32": (_I32, [_VP, C.POINTER(Pool2dDesc), _VP, _VP]),
+    "rten_hip_average_pool2d_f32": (_I32, [_VP, C.POINTER(Pool2dDesc), _VP, _VP]),
+    "rten_hip_global_average_pool_f32": (_I32, [_VP, _I64, _I32, _VP, _VP]),
+    "rten_hip_sdpa_f32": (_I32, [_VP, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP, _I32, _I64, _I64, _F32, _VP]),
+    "rten_hip_set_gemm_variant_override": (_I32, [_VP, _I32]),
+    "rten_hip_num_gemm_variants": (_I32, []),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen librten_hip.so and bind every prototype.  Works without a GPU (symbols only)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise BackendUnavailable(f"{SO_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = C.CDLL(SO_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class Context:
+    """RAII wrapper of rten_hip_ctx.  `stream` may be a raw hipStream_t (e.g. torch's current stream)."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.rten_hip_init(device, C.c_void_p(stream) if stream else None, C.byref(h))
+        if rc == ERR_NO_DEVICE:
+            raise BackendUnavailable("no usable gfx950 (MI355X) device: the HIP backend has no CPU fallback")
+        if rc != OK:
+            raise HipError(rc, "rten_hip_init failed")
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rten_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc: int):
+        if rc != OK:
+            raise HipError(rc, self.lib.rten_hip_last_error(self.h).decode(errors="replace"))
+
+    def call(self, name: str, *args):
+        self.check(getattr(self.lib, name)(self.h, *args))
+
+    def sync(self):
+        self.call("rten_hip_sync")
+
+    def device_info(self):
+        name = C.create_string_buffer(128)
+        cus, mhz, mem = C.c_int32(), C.c_int32(), C.c_int64()
+        self.call("rten_hip_device_info", name, 128, C.byref(cus), C.byref(mhz), C.byref(mem))
+        return {"name": name.value.decode(), "compute_units": cus.value, "clock_mhz": mhz.value, "mem_bytes": mem.value}
+
+    # timers / graphs / profiling
+    def timer_start(self, slot=0):
+        self.call("rten_hip_timer_start", slot)
+
+    def timer_stop(self, slot=0):
+        self.call("rten_hip_timer_stop", slot)
+
+    def timer_ms(self, slot=0) -> float:
+        ms = C.c_float()
+        self.call("rten_hip_timer_elapsed_ms", slot, C.byref(ms))
+        return ms.value
+
+    def graph_begin(self):
+        self.call("rten_hip_graph_begin")
+
+    def graph_end(self) -> int:
+        g = C.c_uint64()
+        self.call("rten_hip_graph_end", C.byref(g))
+        return g.value
+
+    def graph_launch(self, g: int):
+        self.call("rten_hip_graph_launch", C.c_uint64(g))
+
+    def graph_destroy(self, g: int):
+        self.call("rten_hip_graph_destroy", C.c_uint64(g))
+
+    def profile(self, on: bool):
+        self.call("rten_hip_profile_enable", 1 if on else 0)
+
+    def profile_reset(self):
+        self.call("rten_hip_profile_reset")
+
+    def profile_report(self):
+        buf = C.create_string_buffer(1 << 16)
+        self.call("rten_hip_profile_report", buf, len(buf))
+        return json.loads(buf.value.decode())
+
+    def set_gemm_variant(self, v: int):
+        self.call("rten_hip_set_gemm_variant_override", v)

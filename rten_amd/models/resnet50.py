@@ -1,0 +1,231 @@
+"""ResNet-50 v1.5 (timm/torchvision layout, 224x224) as the RTen executor sees it, on the HIP backend.
+
+Graph: BatchNorm is pre-folded into conv weight/bias by the exporter, so the
+reference graph is Conv(+bias) -> Relu ... Conv(+bias) -> Add(residual) -> Relu, MaxPool, GlobalAveragePool,
+Flatten, Gemm(transB=1).  The device graph fuses Relu / residual Add into the conv epilogue
+(rten_hip_conv2d_f32 flags) -- same operations, same order, same rounding.
+
+There is no network in the build image, so weights are synthetic: He-normal, seed 1234, BN folded
+(`make_weights`).  The same spec + weights drive the CPU oracle in tests/ for parity.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .. import lib as L
+from ..tensor import DeviceTensor
+
+STAGES = [(64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)]  # (bottleneck width, blocks, first stride)
+
+
+def conv_specs():
+    """Ordered list of conv layers: dict(name, cin, cout, k, stride, pad, relu, residual_from, input_from).
+    Activations are named; 'x' is the network input."""
+    layers = [dict(name="stem", cin=3, cout=64, k=7, stride=2, pad=3, relu=True, src="x", res=None, dst="stem")]
+    cur, cin = "pool", 64
+    for si, (width, blocks, stride) in enumerate(STAGES):
+        for bi in range(blocks):
+            s = stride if bi == 0 else 1
+            pre = f"s{si}b{bi}"
+            cout = width * 4
+            layers.append(dict(name=pre + "c1", cin=cin, cout=width, k=1, stride=1, pad=0, relu=True, src=cur, res=None, dst=pre + "t1"))
+            layers.append(dict(name=pre + "c2", cin=width, cout=width, k=3, stride=s, pad=1, relu=True, src=pre + "t1", res=None, dst=pre + "t2"))
+            if bi == 0:
+                layers.append(dict(name=pre + "ds", cin=cin, cout=cout, k=1, stride=s, pad=0, relu=False, src=cur, res=None, dst=pre + "id"))
+                ident = pre + "id"
+            else:
+                ident = cur
+            layers.append(dict(name=pre + "c3", cin=width, cout=cout, k=1, stride=1, pad=0, relu=True, src=pre + "t2", res=ident, dst=pre + "out"))
+            cur, cin = pre + "out", cout
+    return layers
+
+
+def make_weights(seed=1234, num_classes=1000):
+    """Synthetic BN-folded weights.  Returns {name: (W [O,C,k,k] f32, bias [O] f32)} + 'fc': (W [1000,2048], b)."""
+    rng = np.random.default_rng(seed)
+    w = {}
+    for l in conv_specs():
+        fan_in = l["cin"] * l["k"] * l["k"]
+        std = np.sqrt(2.0 / fan_in)
+        if l["name"].endswith("c3"):
+            std *= 0.5  # keep the residual stream from growing without BN statistics
+        w[l["name"]] = (rng.normal(0.0, std, (l["cout"], l["cin"], l["k"], l["k"])).astype(np.float32),
+                        rng.normal(0.0, 0.05, (l["cout"],)).astype(np.float32))
+    w["fc"] = (rng.normal(0.0, np.sqrt(1.0 / 2048), (num_classes, 2048)).astype(np.float32),
+               rng.normal(0.0, 0.05, (num_classes,)).astype(np.float32))
+    return w
+
+
+def conv_flops_per_image():
+    total, hw = 0.0, 224
+    sizes = {"x": 224}
+    for l in conv_specs():
+        h = sizes.get(l["src"], None)
+        if h is None:
+            h = sizes["pool"] if l["src"] == "pool" else hw
+        oh = (h + 2 * l["pad"] - l["k"]) // l["stride"] + 1
+        sizes[l["dst"]] = oh
+        if l["dst"] == "stem":
+            sizes["pool"] = (oh + 2 - 3) // 2 + 1
+        total += 2.0 * l["cout"] * l["cin"] * l["k"] * l["k"] * oh * oh
+    return total
+
+
+class ResNet50:
+    """Device-resident ResNet-50 forward for a fixed batch size (static plan, optional hipGraph)."""
+
+    def __init__(self, ctx, batch, weights=None, image=224, num_classes=1000, arena_ptr=None, arena_keepalive=None):
+        self.ctx, self.batch, self.image, self.num_classes = ctx, batch, image, num_classes
+        self.weights = weights if weights is not None else make_weights(num_classes=num_classes)
+        self.specs = conv_specs()
+        self.graph = None
+        self.variants = {}
+        self._plan(arena_ptr, arena_keepalive)
+
+    # ---- static plan: shapes, weight arena, activation buffers, launch list
+    def _plan(self, arena_ptr, arena_keepalive):
+        ctx, N = self.ctx, self.batch
+        shapes = {"x": (N, 3, self.image, self.image)}
+        descs = {}
+        for l in self.specs:
+            n, c, h, w = shapes["pool" if l["src"] == "pool" else l["src"]] if l["src"] != "x" else shapes["x"]
+            oh = (h + 2 * l["pad"] - l["k"]) // l["stride"] + 1
+            ow = (w + 2 * l["pad"] - l["k"]) // l["stride"] + 1
+            descs[l["name"]] = L.Conv2dDesc(n, c, h, w, l["cout"], l["k"], l["k"], (C.c_int32 * 4)(l["pad"], l["pad"], l["pad"], l["pad"]),
+                                            l["stride"], l["stride"], 1, 1, 1, oh, ow)
+            shapes[l["dst"]] = (n, l["cout"], oh, ow)
+            if l["dst"] == "stem":
+                ph = (oh + 2 - 3) // 2 + 1
+                shapes["pool"] = (n, l["cout"], ph, ph)
+        self.shapes, self.descs = shapes, descs
+        # weight arena: [packed conv weights | biases | fc W | fc b], one allocation so it can be broadcast
+        offs, total = {}, 0
+        for l in self.specs:
+            nb = ctx.lib.rten_hip_conv2d_f32_packed_bytes(C.byref(descs[l["name"]]))
+            offs[l["name"]] = (total, total + nb)
+            total += nb + l["cout"] * 4
+            total = (total + 255) & ~255
+        fc_w, fc_b = self.weights["fc"]
+        offs["fc"] = (total, total + fc_w.nbytes)
+        total += fc_w.nbytes + fc_b.nbytes
+        total = (total + 255) & ~255
+        self.arena_bytes = total
+        self.arena = DeviceTensor(ctx, (total,), np.uint8, ptr=arena_ptr, keepalive=arena_keepalive)
+        self.w_off = offs
+        # activation buffers with liveness-based reuse: op i's output is taken from the free list, then the
+        # inputs whose last consumer is op i are released (so an output never aliases a live input).
+        ops = [(["x"], "stem"), (["stem"], "pool")]
+        for l in self.specs[1:]:
+            ops.append(([l["src"]] + ([l["res"]] if l["res"] else []), l["dst"]))
+        last_use = {}
+        for i, (ins, _) in enumerate(ops):
+            for nm in ins:
+                last_use[nm] = i
+        last_use[ops[-1][1]] = len(ops)  # final activation is read by GlobalAveragePool
+        free, self.bufs = [], {}
+        self.x = DeviceTensor(ctx, shapes["x"], np.float32)
+        for i, (ins, out) in enumerate(ops):
+            need = int(np.prod(shapes[out])) * 4
+            best = None
+            for bfr in free:
+                if bfr.nbytes >= need and (best is None or bfr.nbytes < best.nbytes):
+                    best = bfr
+            if best is not None:
+                free.remove(best)
+            else:
+                best = DeviceTensor(ctx, (need // 4,), np.float32)
+            self.bufs[out] = best
+            for nm in ins:
+                if nm != "x" and last_use[nm] == i:
+                    free.append(self.bufs[nm])
+        self.gap = DeviceTensor(ctx, (N, 2048), np.float32)
+        self.logits = DeviceTensor(ctx, (N, self.num_classes), np.float32)
+        p = self.shapes["stem"]
+        self.pool_desc = L.Pool2dDesc(p[0], p[1], p[2], p[3], 3, 3, 2, 2, (C.c_int32 * 4)(1, 1, 1, 1), self.shapes["pool"][2],
+                                      self.shapes["pool"][3], 0)
+        self.fc_desc = L.GemmDesc(N, self.num_classes, 2048, 2048, 1, 1, 2048, self.num_classes, 1, 0, 0, 0, 1.0, 0.0,
+                                  L.BIAS_PER_COL, L.ACT_NONE)
+
+    def _wptr(self, name, which):
+        a, b = self.w_off[name]
+        return C.c_void_p(self.arena.ptr + (a if which == 0 else b))
+
+    def upload_weights(self):
+        """Stage all weights into the arena (rank 0 of a multi-GPU job; others receive the broadcast)."""
+        ctx = self.ctx
+        for l in self.specs:
+            w, b = self.weights[l["name"]]
+            tmp = DeviceTensor.from_numpy(ctx, w)
+            ctx.call("rten_hip_conv2d_f32_prepack", C.byref(self.descs[l["name"]]), tmp.vp, self._wptr(l["name"], 0))
+            ctx.call("rten_hip_memcpy_h2d", self._wptr(l["name"], 1), b.ctypes.data_as(C.c_void_p), C.c_size_t(b.nbytes))
+            ctx.sync()
+            tmp.free()
+        fc_w, fc_b = self.weights["fc"]
+        ctx.call("rten_hip_memcpy_h2d", self._wptr("fc", 0), fc_w.ctypes.data_as(C.c_void_p), C.c_size_t(fc_w.nbytes))
+        ctx.call("rten_hip_memcpy_h2d", self._wptr("fc", 1), fc_b.ctypes.data_as(C.c_void_p), C.c_size_t(fc_b.nbytes))
+
+    def _act(self, name):
+        return self.x if name == "x" else self.bufs[name]
+
+    def _conv(self, l):
+        ctx = self.ctx
+        v = self.variants.get(l["name"])
+        if v is not None:
+            ctx.set_gemm_variant(v)
+        flags = (L.CONV_RELU if l["relu"] else 0) | (L.CONV_RESIDUAL if l["res"] else 0)
+        ctx.call("rten_hip_conv2d_f32", C.byref(self.descs[l["name"]]), self._act(l["src"]).vp, self._wptr(l["name"], 0), 1,
+                 self._wptr(l["name"], 1), self._act(l["res"]).vp if l["res"] else None, flags, self._act(l["dst"]).vp)
+        if v is not None:
+            ctx.set_gemm_variant(-1)
+
+    def forward(self):
+        """Enqueue one forward pass over self.x -> self.logits (asynchronous)."""
+        ctx = self.ctx
+        self._conv(self.specs[0])
+        ctx.call("rten_hip_max_pool2d_f32", C.byref(self.pool_desc), self.bufs["stem"].vp, self.bufs["pool"].vp)
+        for l in self.specs[1:]:
+            self._conv(l)
+        last = self.specs[-1]["dst"]
+        n, c, h, w = self.shapes[last]
+        ctx.call("rten_hip_global_average_pool_f32", n * c, h * w, self.bufs[last].vp, self.gap.vp)
+        ctx.call("rten_hip_gemm_f32", C.byref(self.fc_desc), self.gap.vp, self._wptr("fc", 0), self._wptr("fc", 1), self.logits.vp)
+
+    def capture(self):
+        """Capture the forward pass into a hipGraph (one host call per inference afterwards)."""
+        self.forward()  # warm-up: scratch allocations, code objects
+        self.ctx.sync()
+        self.ctx.graph_begin()
+        self.forward()
+        self.graph = self.ctx.graph_end()
+        return self.graph
+
+    def run(self):
+        if self.graph:
+            self.ctx.graph_launch(self.graph)
+        else:
+            self.forward()
+
+    def autotune(self, reps=3):
+        """Pick the fastest GEMM tile variant per conv layer by measurement (load-time, like the
+        reference picks kernels per ISA at start-up, rten-gemm/src/lib.rs:534-547)."""
+        ctx = self.ctx
+        nvar = ctx.lib.rten_hip_num_gemm_variants()
+        table = {}
+        for l in self.specs:
+            best, best_ms, row = None, 1e30, []
+            for v in range(nvar):
+                self.variants[l["name"]] = v
+                self._conv(l)  # warm
+                ctx.timer_start(1)
+                for _ in range(reps):
+                    self._conv(l)
+                ctx.timer_stop(1)
+                ms = ctx.timer_ms(1) / reps
+                row.append(ms)
+                if ms < best_ms:
+                    best, best_ms = v, ms
+            self.variants[l["name"]] = best
+            table[l["name"]] = row
+        return table

@@ -1,0 +1,788 @@
+"""Host-side mirror of RTen's operator interface for the hot path (src/operator.rs:486-613, src/ops/*).
+
+Each class mirrors the reference operator of the same name: same attribute names, same input order,
+same validation and the same `OpError` messages (asserted verbatim by the reference's tests, e.g.
+src/ops/conv.rs:1182-1268, src/ops/matmul.rs:1284-1333).  Validation runs on the host before any
+launch; the arithmetic is done by librten_hip.so through the C ABI (include/rten_hip.h) on
+device-resident tensors.  There is no CPU fallback: without the HIP library / an MI355X every `run`
+raises.
+
+The Rust reference cannot be compiled in this image (no cargo), so this mirror stands where the Rust
+`Operator` impls of INTEGRATION.md would; the registry below mirrors `OpRegistry`
+(src/op_registry.rs:25-72).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import lib as L
+from .lib import Context
+from .tensor import DeviceTensor
+
+
+class OpError(Exception):
+    """Mirrors rten::ops::OpError (src/operator.rs:116-144)."""
+
+    def __init__(self, kind: str, msg: str = ""):
+        super().__init__(f"{kind}({msg!r})" if msg else kind)
+        self.kind = kind
+        self.msg = msg
+
+    def __eq__(self, other):
+        return isinstance(other, OpError) and (self.kind, self.msg) == (other.kind, other.msg)
+
+    __hash__ = Exception.__hash__
+
+
+def InvalidValue(m):
+    return OpError("InvalidValue", m)
+
+
+def IncompatibleInputShapes(m):
+    return OpError("IncompatibleInputShapes", m)
+
+
+def UnsupportedValue(m):
+    return OpError("UnsupportedValue", m)
+
+
+UnsupportedType = OpError("UnsupportedType")
+MissingInputs = OpError("MissingInputs")
+
+
+def _vp(t):
+    return None if t is None else C.c_void_p(t.ptr)
+
+
+def _require(inputs, i):
+    if i >= len(inputs) or inputs[i] is None:
+        raise MissingInputs
+    return inputs[i]
+
+
+def _get(inputs, i):
+    return inputs[i] if i < len(inputs) else None
+
+
+def _want(t, dtype):
+    if t.dtype != np.dtype(dtype):
+        raise OpError("InputCastFailed", f"expected {np.dtype(dtype).name} tensor")
+    return t
+
+
+def calc_output_size_and_padding(ctx, in_size, kernel, strides, padding, dilations=(1, 1), ceil_mode=False):
+    """src/ops/pooling.rs:139-159 via the C ABI.  padding: "same" or [top, left, bottom, right]."""
+    same = isinstance(padding, str)
+    if not same and len(padding) != 4:
+        raise InvalidValue("Expected 4 padding values")
+    pads = (C.c_int32 * 4)(*([0, 0, 0, 0] if same else [int(p) for p in padding]))
+    out = (C.c_int32 * 2)()
+    opads = (C.c_int32 * 4)()
+    msg = C.c_char_p()
+    rc = ctx.lib.rten_hip_calc_output_size_and_padding(
+        in_size[0], in_size[1], kernel[0], kernel[1], strides[0], strides[1], 1 if same else 0, pads,
+        dilations[0], dilations[1], 1 if ceil_mode else 0, out, opads, C.byref(msg))
+    if rc:
+        raise InvalidValue(msg.value.decode())
+    return out[0], out[1], [opads[i] for i in range(4)]
+
+
+class Operator:
+    """Mirror of `trait Operator` (src/operator.rs:486-613): name(), run(ctx, inputs) -> [outputs]."""
+
+    def name(self) -> str:
+        return type(self).__name__
+
+    def max_inputs(self):
+        return None
+
+    def run(self, ctx: Context, inputs):
+        raise NotImplementedError
+
+    # weight staging hook (prepack_inputs / prepack, operator.rs:586-601)
+    def prepack_inputs(self):
+        return []
+
+
+# ------------------------------------------------------------------------------------------ Conv
+class Conv(Operator):
+    """src/ops/conv.rs:367-403.  inputs: X [N,C,H,W] (or [N,C,W]), W [O,C/g,kh,kw], bias [O]?
+    Extra (backend fusion of the following graph ops): `fuse_relu`, and a 4th input =
+    residual tensor added before the Relu."""
+
+    def __init__(self, groups=1, dilations=(1, 1), padding=(0, 0, 0, 0), strides=(1, 1), fuse_relu=False):
+        self.groups = groups
+        self.dilations = list(dilations)
+        self.padding = padding
+        self.strides = list(strides)
+        self.fuse_relu = fuse_relu
+        self._packed = {}
+
+    def max_inputs(self):
+        return 4
+
+    def prepack_inputs(self):
+        return [1]
+
+    def _geometry(self, ctx, xs, ws):
+        if len(xs) == 3:  # 1D conv -> 2D (conv.rs:142-182)
+            if len(ws) != 3:
+                raise InvalidValue("kernel must have 3 dims (OCW)")
+            raise UnsupportedValue("1D convolution: expand to 2D on the host before calling the backend")
+        if len(xs) != 4:
+            raise InvalidValue("input must have 4 dims (NCHW)")
+        if len(ws) != 4:
+            raise InvalidValue("kernel must have 4 dims (OCHW)")
+        if len(self.strides) != 2:
+            raise InvalidValue("expected 2 stride values")
+        if len(self.dilations) != 2:
+            raise InvalidValue("expected 2 dilation values")
+        n, c, h, w = xs
+        o, kc, kh, kw = ws
+        oh, ow, pads = calc_output_size_and_padding(ctx, (h, w), (kh, kw), self.strides, self.padding, self.dilations)
+        if self.groups == 0:
+            raise InvalidValue("Group count must be > 0")
+        if c % self.groups != 0:
+            raise InvalidValue("Input channel count not divisible by groups")
+        if c // self.groups != kc:
+            raise IncompatibleInputShapes("Input channels (per group) does not match kernel input channels")
+        if o % self.groups != 0:
+            raise InvalidValue("Output channel count not divisible by groups")
+        d = L.Conv2dDesc(n, c, h, w, o, kh, kw, (C.c_int32 * 4)(*pads), self.strides[0], self.strides[1],
+                         self.dilations[0], self.dilations[1], self.groups, oh, ow)
+        return d
+
+    def prepack(self, ctx, weight: DeviceTensor, desc=None):
+        """Stage weights once (GPU analogue of PrepackedInput, operator.rs:25-66)."""
+        if desc is None:
+            o, kc, kh, kw = weight.shape
+            desc = L.Conv2dDesc(1, kc * self.groups, max(kh, 1), max(kw, 1), o, kh, kw, (C.c_int32 * 4)(0, 0, 0, 0),
+                                1, 1, 1, 1, self.groups, 1, 1)
+        nbytes = ctx.lib.rten_hip_conv2d_f32_packed_bytes(C.byref(desc))
+        packed = DeviceTensor(ctx, (nbytes // 4,), np.float32)
+        ctx.call("rten_hip_conv2d_f32_prepack", C.byref(desc), weight.vp, packed.vp)
+        return packed
+
+    def run(self, ctx, inputs, packed_weight: DeviceTensor | None = None, out: DeviceTensor | None = None):
+        x = _want(_require(inputs, 0), np.float32)
+        w = _want(_require(inputs, 1), np.float32)
+        bias = _get(inputs, 2)
+        residual = _get(inputs, 3)
+        d = self._geometry(ctx, x.shape, w.shape)
+        if bias is not None and bias.shape[0] != d.o:
+            raise IncompatibleInputShapes("bias.size(0) != out_channels")
+        y = out if out is not None else DeviceTensor(ctx, (d.n, d.o, d.out_h, d.out_w), np.float32)
+        flags = (L.CONV_RELU if self.fuse_relu else 0) | (L.CONV_RESIDUAL if residual is not None else 0)
+        wt = packed_weight if packed_weight is not None else w
+        ctx.call("rten_hip_conv2d_f32", C.byref(d), x.vp, wt.vp, 1 if packed_weight is not None else 0, _vp(bias),
+                 _vp(residual), flags, y.vp)
+        return [y]
+
+
+class ConvInteger(Operator):
+    """src/ops/conv.rs:478-526.  inputs: X u8|i8, W i8|u8, x_zero_point (scalar)?, w_zero_point (scalar|[O])?"""
+
+    def __init__(self, groups=1, dilations=(1, 1), padding=(0, 0, 0, 0), strides=(1, 1), pad_mode=L.PAD_RAW0_I8):
+        self._conv = Conv(groups, dilations, padding, strides)
+        self.pad_mode = pad_mode
+
+    def max_inputs(self):
+        return 4
+
+    def _desc(self, ctx, x, w, x_zp, w_zp):
+        if x.dtype not in (np.uint8, np.int8) or w.dtype not in (np.uint8, np.int8):
+            raise UnsupportedType
+        o = w.shape[0] if len(w.shape) >= 1 else 0
+        if x_zp is not None and x_zp.size != 1:
+            raise InvalidValue("input zero point must be a scalar")
+        w_zp_len = _zp_len(w_zp, o, "w")  # zero_point_to_vec, matmul.rs:513-531
+        d = self._conv._geometry(ctx, x.shape, w.shape)
+        return L.Conv2dInt8Desc(d, 1 if x.dtype == np.int8 else 0, 1 if w.dtype == np.int8 else 0, w_zp_len, self.pad_mode)
+
+    def run(self, ctx, inputs, scale=None, bias=None, residual=None, relu=False, out=None):
+        x = _require(inputs, 0)
+        w = _require(inputs, 1)
+        x_zp, w_zp = _get(inputs, 2), _get(inputs, 3)
+        di = self._desc(ctx, x, w, x_zp, w_zp)
+        d = di.conv
+        y = out if out is not None else DeviceTensor(ctx, (d.n, d.o, d.out_h, d.out_w), np.float32 if scale is not None else np.int32)
+        flags = (L.CONV_RELU if relu else 0) | (L.CONV_RESIDUAL if residual is not None else 0)
+        ctx.call("rten_hip_conv2d_int8", C.byref(di), x.vp, w.vp, _vp(x_zp), _vp(w_zp), _vp(scale), _vp(bias),
+                 _vp(residual), flags, y.vp)
+        return [y]
+
+
+class ConvIntegerToFloat(Operator):
+    """src/ops/conv.rs:552-587.  inputs: X, W, x_zp, w_zp, scale (scalar).
+    Backend fusion extras: bias (the following Add of a [1,O,1,1] constant), residual, relu."""
+
+    def __init__(self, conv: ConvInteger, fuse_relu=False):
+        self.conv = conv
+        self.fuse_relu = fuse_relu
+
+    def max_inputs(self):
+        return 7
+
+    def run(self, ctx, inputs, out=None):
+        scale = _want(_require(inputs, 4), np.float32)
+        if scale.size != 1:
+            raise InvalidValue("scale should be a scalar")
+        return self.conv.run(ctx, inputs[:4], scale=scale, bias=_get(inputs, 5), residual=_get(inputs, 6),
+                             relu=self.fuse_relu, out=out)
+
+
+# ------------------------------------------------------------------------------------------ MatMul family
+def _broadcast_shapes(a, b):
+    try:
+        return tuple(np.broadcast_shapes(tuple(a), tuple(b)))
+    except ValueError:
+        return None
+
+
+def _matmul(ctx, a: DeviceTensor, b: DeviceTensor, bias=None, alpha=None, act=L.ACT_NONE, b_transposed=False):
+    """numpy.matmul rules, src/ops/matmul.rs:208-385.  Contiguous inputs; `b_transposed` reads B as
+    [..., N, K] (TransformInputs / transB folded into strides, matmul.rs:47-48, fusions.rs:1066)."""
+    ash, bsh = list(a.shape), list(b.shape)
+    if len(ash) < 1 or len(bsh) < 1:
+        raise InvalidValue("Inputs must have >= 1 dimensions")
+    a_vec, b_vec = len(ash) == 1, len(bsh) == 1
+    if a_vec:
+        ash = [1] + ash
+    if b_vec:
+        bsh = bsh + [1] if not b_transposed else [1] + bsh
+    if b_transposed:
+        bsh = bsh[:-2] + [bsh[-1], bsh[-2]]
+    m, k = ash[-2], ash[-1]
+    kb, n = bsh[-2], bsh[-1]
+    if k != kb:
+        raise IncompatibleInputShapes("Columns of first matrix does not match rows of second matrix")
+    pre = _broadcast_shapes(ash[:-2], bsh[:-2])
+    if pre is None:
+        raise IncompatibleInputShapes("Cannot broadcast shapes")
+    out_shape = list(pre) + [m, n]
+    na = int(np.prod(ash[:-2], dtype=np.int64))
+    nb = int(np.prod(bsh[:-2], dtype=np.int64))
+    b_rs, b_cs = (1, k) if b_transposed else (n, 1)
+    y = DeviceTensor(ctx, out_shape, np.float32)
+    if int(np.prod(out_shape, dtype=np.int64)) > 0:
+        if na > 1 and nb == 1:  # matmul.rs:266-297: one [A*M, K] x [K, N] GEMM
+            d = L.GemmDesc(na * m, n, k, k, 1, b_rs, b_cs, n, 1, 0, 0, 0, alpha if alpha is not None else 1.0, 0.0,
+                           L.BIAS_PER_COL if bias is not None else L.BIAS_NONE, act)
+        else:
+            batch = int(np.prod(pre, dtype=np.int64)) if len(pre) else 1
+            if na not in (1, batch) or nb not in (1, batch):
+                raise UnsupportedValue("partial batch broadcasting is not supported by the device path")
+            d = L.GemmDesc(m, n, k, k, 1, b_rs, b_cs, n, batch, m * k if na > 1 else 0, k * n if nb > 1 else 0, m * n,
+                           alpha if alpha is not None else 1.0, 0.0,
+                           L.BIAS_PER_COL if bias is not None else L.BIAS_NONE, act)
+        ctx.call("rten_hip_gemm_f32", C.byref(d), a.vp, b.vp, _vp(bias), y.vp)
+    if a_vec:
+        out_shape.pop(-2)
+    if b_vec:
+        out_shape.pop(-1)
+    return y.reshape(out_shape) if (a_vec or b_vec) else y
+
+
+class MatMul(Operator):
+    """src/ops/matmul.rs:387-428"""
+
+    def max_inputs(self):
+        return 2
+
+    def run(self, ctx, inputs):
+        a = _want(_require(inputs, 0), np.float32)
+        b = _want(_require(inputs, 1), np.float32)
+        return [_matmul(ctx, a, b)]
+
+
+class FusedMatMul(Operator):
+    """src/ops/matmul.rs:455-510: MatMul + bias (per column) + alpha.  `act` is a backend fusion extra
+    (GELU epilogue for the BERT FFN)."""
+
+    def __init__(self, alpha=None, act=L.ACT_NONE, transpose_b=False):
+        self.alpha = alpha
+        self.act = act
+        self.transpose_b = transpose_b
+
+    def max_inputs(self):
+        return 3
+
+    def run(self, ctx, inputs):
+        a = _want(_require(inputs, 0), np.float32)
+        b = _want(_require(inputs, 1), np.float32)
+        bias = _get(inputs, 2)
+        if bias is not None and len(bias.shape) != 1:
+            raise OpError("InputCastFailed", "expected tensor with 1 dims")
+        return [_matmul(ctx, a, b, bias=bias, alpha=self.alpha, act=self.act, b_transposed=self.transpose_b)]
+
+
+class Gemm(Operator):
+    """src/ops/matmul.rs:106-156: c = alpha * (a b) + beta * c with transA / transB."""
+
+    def __init__(self, alpha=1.0, beta=1.0, transpose_a=False, transpose_b=False):
+        self.alpha, self.beta, self.transpose_a, self.transpose_b = alpha, beta, transpose_a, transpose_b
+
+    def max_inputs(self):
+        return 3
+
+    def run(self, ctx, inputs):
+        a = _want(_require(inputs, 0), np.float32)
+        b = _want(_require(inputs, 1), np.float32)
+        c = _get(inputs, 2)
+        if len(a.shape) != 2:
+            raise InvalidValue("a must have 2 dims")
+        if len(b.shape) != 2:
+            raise InvalidValue("b must have 2 dims")
+        m, k = (a.shape[1], a.shape[0]) if self.transpose_a else a.shape
+        kb, n = (b.shape[1], b.shape[0]) if self.transpose_b else b.shape
+        if k != kb:
+            raise IncompatibleInputShapes("Columns of first matrix does not match rows of second matrix")
+        a_rs, a_cs = (1, a.shape[1]) if self.transpose_a else (a.shape[1], 1)
+        b_rs, b_cs = (1, b.shape[1]) if self.transpose_b else (b.shape[1], 1)
+        y = DeviceTensor(ctx, (m, n), np.float32)
+        beta = self.beta if c is not None else 0.0
+        if c is not None and beta != 0.0:
+            # expand_to(c, out_shape) then gemm with beta (matmul.rs:63-82)
+            cs = tuple(c.shape)
+            if _broadcast_shapes(cs, (m, n)) != (m, n):
+                raise IncompatibleInputShapes("Cannot broadcast c to output shape")
+            if cs == (m, n):
+                ctx.call("rten_hip_memcpy_d2d", y.vp, c.vp, C.c_size_t(y.nbytes))
+            else:  # row / column / scalar broadcast: materialise via add to zeros
+                ctx.call("rten_hip_memset", y.vp, 0, C.c_size_t(y.nbytes))
+                if cs in ((n,), (1, n)) or c.size == 1:
+                    ctx.call("rten_hip_add_f32", m * n, y.vp, c.vp, c.size, y.vp)
+                elif cs == (m, 1):
+                    ctx.call("rten_hip_add_channel_bias_f32", 1, m, n, y.vp, c.vp, y.vp)
+                else:
+                    raise IncompatibleInputShapes("Cannot broadcast c to output shape")
+        if m * n > 0:
+            d = L.GemmDesc(m, n, k, a_rs, a_cs, b_rs, b_cs, n, 1, 0, 0, 0, self.alpha, beta, L.BIAS_NONE, L.ACT_NONE)
+            ctx.call("rten_hip_gemm_f32", C.byref(d), a.vp, b.vp, None, y.vp)
+        return [y]
+
+
+def _zp_len(zp, expected, what):
+    if zp is None:
+        return 0
+    if len(zp.shape) == 0:
+        return 1
+    if len(zp.shape) == 1:
+        if zp.shape[0] != expected:
+            raise InvalidValue("Zero point has incorrect size")
+        return expected if expected != 1 else 1
+    raise UnsupportedValue("Only scalar or vector zero points are supported")
+
+
+class MatMulInteger(Operator):
+    """src/ops/matmul.rs:649-700.  inputs: A u8|i8 [M,K], B i8|u8 [K,N], a_zero_point?, b_zero_point?"""
+
+    def max_inputs(self):
+        return 4
+
+    def run(self, ctx, inputs, scale=None):
+        a = _require(inputs, 0)
+        b = _require(inputs, 1)
+        if a.dtype not in (np.uint8, np.int8) or b.dtype not in (np.uint8, np.int8):
+            raise UnsupportedType
+        a_zp, b_zp = _get(inputs, 2), _get(inputs, 3)
+        ash, bsh = list(a.shape), list(b.shape)
+        if len(ash) < 1 or len(bsh) < 1:
+            raise InvalidValue("Inputs must have >= 1 dimensions")
+        if len(bsh) != 2:
+            raise UnsupportedValue("batched RHS is not supported by the device int8 path")
+        rows = ash[-2] if len(ash) > 1 else 1
+        k = ash[-1]
+        kb, n = bsh
+        azl = _zp_len(a_zp, rows, "a")
+        bzl = _zp_len(b_zp, n, "b")
+        if k != kb:
+            raise IncompatibleInputShapes("Columns of first matrix does not match rows of second matrix")
+        m_total = int(np.prod(ash[:-1], dtype=np.int64)) if len(ash) > 1 else 1
+        if azl > 1 and m_total != rows:
+            raise UnsupportedValue("per-row zero point with batched LHS is not supported by the device path")
+        sl = 0
+        if scale is not None:
+            if len(scale.shape) > 1:
+                raise InvalidValue("scale should have rank 0 or 1")
+            sl = 1 if scale.size == 1 else scale.size
+            if sl > 1 and sl != n:
+                raise IncompatibleInputShapes("Scale length does not match tensor columns")
+        out_shape = (ash[:-1] if len(ash) > 1 else []) + [n]
+        y = DeviceTensor(ctx, out_shape, np.float32 if scale is not None else np.int32)
+        d = L.GemmInt8Desc(m_total, n, k, k, 1, n, 1, n, 1 if a.dtype == np.int8 else 0, 1 if b.dtype == np.int8 else 0,
+                           azl, bzl, sl)
+        ctx.call("rten_hip_gemm_int8", C.byref(d), a.vp, b.vp, _vp(a_zp), _vp(b_zp), _vp(scale), y.vp)
+        return [y]
+
+
+class MatMulIntegerToFloat(Operator):
+    """src/ops/matmul.rs:775-810.  inputs: A, B, a_zp, b_zp, scale (scalar or [N])."""
+
+    def __init__(self):
+        self.matmul = MatMulInteger()
+
+    def max_inputs(self):
+        return 5
+
+    def run(self, ctx, inputs):
+        scale = _want(_require(inputs, 4), np.float32)
+        return self.matmul.run(ctx, inputs[:4], scale=scale)
+
+
+# ------------------------------------------------------------------------------------------ norm / softmax
+def _resolve_axis(ndim, axis):
+    if axis < -ndim or axis >= ndim:
+        raise InvalidValue("Axis is invalid")
+    return axis + ndim if axis < 0 else axis
+
+
+class Softmax(Operator):
+    """src/ops/norm.rs:842-900 (last axis on device; other axes need a host-side transpose)."""
+
+    def __init__(self, axis=-1, flush_nans_to_zero=False):
+        self.axis = axis
+        self.flush_nans_to_zero = flush_nans_to_zero
+
+    def max_inputs(self):
+        return 1
+
+    def run(self, ctx, inputs):
+        x = _want(_require(inputs, 0), np.float32)
+        ax = _resolve_axis(len(x.shape), self.axis)
+        if ax != len(x.shape) - 1:
+            raise UnsupportedValue("device softmax runs along the last axis")
+        y = DeviceTensor(ctx, x.shape, np.float32)
+        cols = x.shape[-1]
+        ctx.call("rten_hip_softmax_f32", x.size // max(cols, 1), cols, x.vp, None, 1, 1, 1 if self.flush_nans_to_zero else 0, y.vp)
+        return [y]
+
+
+class AddSoftmax(Operator):
+    """src/ops/attention.rs:70-156: Softmax(Add(qk, m), axis=-1); `m` broadcast to qk."""
+
+    def __init__(self, flush_nans_to_zero=False):
+        self.flush_nans_to_zero = flush_nans_to_zero
+
+    def max_inputs(self):
+        return 2
+
+    def run(self, ctx, inputs):
+        x = _want(_require(inputs, 0), np.float32)
+        y_in = _want(_require(inputs, 1), np.float32)
+        qk, m = (x, y_in) if x.size > y_in.size else (y_in, x)
+        if _broadcast_shapes(qk.shape, m.shape) != tuple(qk.shape):
+            if _broadcast_shapes(qk.shape, m.shape) is None:
+                raise IncompatibleInputShapes("Cannot broadcast inputs")
+            raise UnsupportedValue("device AddSoftmax needs one input to have the output shape")
+        cols = qk.shape[-1]
+        rows = qk.size // max(cols, 1)
+        msh = (1,) * (len(qk.shape) - len(m.shape)) + tuple(m.shape)
+        if msh[-1] != cols:
+            raise UnsupportedValue("mask must be contiguous along the softmax axis")
+        # supported broadcast patterns: same shape, or a leading block + ones ([B,1,1,S] against [B,H,S,S])
+        lead = msh[:-1]
+        qlead = tuple(qk.shape[:-1])
+        nz = [i for i, s in enumerate(lead) if s != 1]
+        if lead == qlead:
+            add_div, add_mod = 1, rows
+        elif not nz:
+            add_div, add_mod = max(rows, 1), 1
+        elif nz == list(range(nz[-1] + 1)) and all(lead[i] == qlead[i] for i in nz):
+            inner = int(np.prod(qlead[nz[-1] + 1:], dtype=np.int64))
+            add_div, add_mod = inner, int(np.prod([lead[i] for i in nz], dtype=np.int64))
+        else:
+            raise UnsupportedValue("unsupported mask broadcast pattern on the device path")
+        out = DeviceTensor(ctx, qk.shape, np.float32)
+        ctx.call("rten_hip_softmax_f32", rows, cols, qk.vp, m.vp, add_div, add_mod, 1 if self.flush_nans_to_zero else 0, out.vp)
+        return [out]
+
+
+class LayerNormalization(Operator):
+    """src/ops/norm.rs:531-580.  inputs: X, scale, bias?"""
+
+    def __init__(self, axis=-1, epsilon=None):
+        self.axis = axis
+        self.epsilon = epsilon
+
+    def max_inputs(self):
+        return 3
+
+    def run(self, ctx, inputs):
+        x = _want(_require(inputs, 0), np.float32)
+        scale = _want(_require(inputs, 1), np.float32)
+        bias = _get(inputs, 2)
+        ax = _resolve_axis(len(x.shape), self.axis)
+        norm_shape = tuple(x.shape[ax:])
+        cols = int(np.prod(norm_shape, dtype=np.int64))
+        gamma = beta = None
+        gs, bs = 1.0, 0.0
+        if scale.size == 1 and len(scale.shape) == 0:
+            gs = float(scale.numpy().reshape(()))
+        else:
+            if _broadcast_shapes(scale.shape, norm_shape) != norm_shape:
+                raise InvalidValue("`scale` is not broadcastable to normalized axes of input")
+            if int(np.prod(scale.shape, dtype=np.int64)) != cols:
+                raise UnsupportedValue("device path needs scale already expanded to the normalized shape")
+            gamma = scale
+        if bias is not None:
+            if bias.size == 1 and len(bias.shape) == 0:
+                bs = float(bias.numpy().reshape(()))
+            else:
+                if _broadcast_shapes(bias.shape, norm_shape) != norm_shape:
+                    raise InvalidValue("`bias` is not broadcastable to normalized axes of input")
+                if int(np.prod(bias.shape, dtype=np.int64)) != cols:
+                    raise UnsupportedValue("device path needs bias already expanded to the normalized shape")
+                beta = bias
+        y = DeviceTensor(ctx, x.shape, np.float32)
+        eps = 1e-5 if self.epsilon is None else self.epsilon
+        ctx.call("rten_hip_layer_norm_f32", x.size // max(cols, 1), cols, x.vp, _vp(gamma), _vp(beta), gs, bs, eps, y.vp)
+        return [y]
+
+
+class BatchNormalization(Operator):
+    """src/ops/norm.rs:194-290.  inputs: X, scale, bias, mean, var"""
+
+    def __init__(self, epsilon=1e-5):
+        self.epsilon = epsilon
+
+    def max_inputs(self):
+        return 5
+
+    def run(self, ctx, inputs):
+        x = _want(_require(inputs, 0), np.float32)
+        scale, bias, mean, var = (_require(inputs, i) for i in range(1, 5))
+        if len(x.shape) < 1:
+            raise InvalidValue("Input must have at least 1 dim")
+        chans = x.shape[1] if len(x.shape) >= 2 else 1
+        for t, nm in ((scale, "scale"), (bias, "bias"), (mean, "mean"), (var, "var")):
+            if t.shape[0] != chans:
+                raise IncompatibleInputShapes(f"{nm}.size(0) != channels")
+        n = x.shape[0]
+        inner = x.size // max(n * chans, 1)
+        y = DeviceTensor(ctx, x.shape, np.float32)
+        ctx.call("rten_hip_batch_norm_f32", n, chans, inner, x.vp, scale.vp, bias.vp, mean.vp, var.vp, self.epsilon, y.vp)
+        return [y]
+
+
+# ------------------------------------------------------------------------------------------ elementwise
+class _Unary(Operator):
+    fn = ""
+
+    def max_inputs(self):
+        return 1
+
+    def run(self, ctx, inputs, in_place=False):
+        x = _want(_require(inputs, 0), np.float32)
+        y = x if in_place else DeviceTensor(ctx, x.shape, np.float32)
+        ctx.call(self.fn, x.size, x.vp, y.vp)
+        return [y]
+
+
+class Relu(_Unary):
+    """src/ops/unary_elementwise.rs:611-613"""
+    fn = "rten_hip_relu_f32"
+
+
+class Gelu(_Unary):
+    """src/ops/unary_elementwise.rs:399-420 (exact erf form)"""
+    fn = "rten_hip_gelu_f32"
+
+
+class Erf(_Unary):
+    fn = "rten_hip_erf_f32"
+
+
+class _Binary(Operator):
+    fn = ""
+
+    def max_inputs(self):
+        return 2
+
+    def run(self, ctx, inputs, in_place=False):
+        a = _want(_require(inputs, 0), np.float32)
+        b = _want(_require(inputs, 1), np.float32)
+        if b.size > a.size:  # commutative: largest input is the in-place candidate (graph.rs:977-990)
+            a, b = b, a
+        bshape = _broadcast_shapes(a.shape, b.shape)
+        if bshape is None:
+            raise IncompatibleInputShapes("Cannot broadcast inputs")
+        if bshape != tuple(a.shape):
+            raise UnsupportedValue("device path needs one input to have the output shape")
+        y = a if in_place else DeviceTensor(ctx, a.shape, np.float32)
+        bsh = (1,) * (len(a.shape) - len(b.shape)) + tuple(b.shape)
+        # trailing-dims broadcast (b == a's trailing block) or per-channel [1,C,1,1]
+        k = 0
+        while k < len(bsh) and bsh[k] == 1:
+            k += 1
+        if tuple(bsh[k:]) == tuple(a.shape[k:]):
+            ctx.call(self.fn, a.size, a.vp, b.vp, b.size, y.vp)
+        elif self.fn == "rten_hip_add_f32" and len(a.shape) >= 2 and bsh[1] == a.shape[1] and b.size == a.shape[1]:
+            inner = a.size // (a.shape[0] * a.shape[1])
+            ctx.call("rten_hip_add_channel_bias_f32", a.shape[0], a.shape[1], inner, a.vp, b.vp, y.vp)
+        else:
+            raise UnsupportedValue("unsupported broadcast pattern on the device path")
+        return [y]
+
+
+class Add(_Binary):
+    """src/ops/binary_elementwise.rs:476-495"""
+    fn = "rten_hip_add_f32"
+
+
+class Mul(_Binary):
+    fn = "rten_hip_mul_f32"
+
+
+# ------------------------------------------------------------------------------------------ pooling
+class _Pool(Operator):
+    fn = ""
+
+    def __init__(self, kernel_size, padding=(0, 0, 0, 0), strides=None, ceil_mode=False, count_include_pad=False):
+        self.kernel_size = list(kernel_size)
+        self.padding = padding
+        self.strides = list(strides) if strides is not None else [1] * len(self.kernel_size)
+        self.ceil_mode = ceil_mode
+        self.count_include_pad = count_include_pad
+
+    def max_inputs(self):
+        return 1
+
+    def run(self, ctx, inputs):
+        x = _want(_require(inputs, 0), np.float32)
+        spatial = max(len(x.shape) - 2, 0)
+        if len(self.kernel_size) != spatial:
+            raise InvalidValue("kernel_size len does not match spatial dims")
+        if len(self.strides) != spatial:
+            raise InvalidValue("strides len does not match spatial dims")
+        if spatial != 2:
+            raise UnsupportedValue("Only inputs with 1 or 2 spatial dims are supported")
+        n, c, h, w = x.shape
+        oh, ow, pads = calc_output_size_and_padding(ctx, (h, w), self.kernel_size, self.strides, self.padding, (1, 1), self.ceil_mode)
+        d = L.Pool2dDesc(n, c, h, w, self.kernel_size[0], self.kernel_size[1], self.strides[0], self.strides[1],
+                         (C.c_int32 * 4)(*pads), oh, ow, 1 if self.count_include_pad else 0)
+        y = DeviceTensor(ctx, (n, c, oh, ow), np.float32)
+        ctx.call(self.fn, C.byref(d), x.vp, y.vp)
+        return [y]
+
+
+class MaxPool(_Pool):
+    """src/ops/pooling.rs:602-660"""
+    fn = "rten_hip_max_pool2d_f32"
+
+
+class AveragePool(_Pool):
+    """src/ops/pooling.rs:419-475"""
+    fn = "rten_hip_average_pool2d_f32"
+
+
+class GlobalAveragePool(Operator):
+    """src/ops/pooling.rs:516-545"""
+
+    def max_inputs(self):
+        return 1
+
+    def run(self, ctx, inputs):
+        x = _want(_require(inputs, 0), np.float32)
+        if len(x.shape) < 2:
+            raise InvalidValue("Input must have at least 2 dims")
+        n, c = x.shape[:2]
+        inner = x.size // max(n * c, 1)
+        y = DeviceTensor(ctx, (n, c) + (1,) * (len(x.shape) - 2), np.float32)
+        ctx.call("rten_hip_global_average_pool_f32", n * c, inner, x.vp, y.vp)
+        return [y]
+
+
+class Flatten(Operator):
+    """src/ops/layout.rs:264: zero-copy view on device."""
+
+    def __init__(self, axis=1):
+        self.axis = axis
+
+    def run(self, ctx, inputs):
+        x = _require(inputs, 0)
+        ax = _resolve_axis(len(x.shape) + 1, self.axis) if self.axis != len(x.shape) else self.axis
+        outer = int(np.prod(x.shape[:ax], dtype=np.int64))
+        return [x.reshape(outer, -1)]
+
+
+# ------------------------------------------------------------------------------------------ quantization
+class DynamicQuantizeLinear(Operator):
+    """src/ops/quantize.rs:438-478 -> [y u8, y_scale f32 scalar, y_zero_point u8 scalar] (all on device)."""
+
+    def max_inputs(self):
+        return 1
+
+    def run(self, ctx, inputs):
+        x = _want(_require(inputs, 0), np.float32)
+        y = DeviceTensor(ctx, x.shape, np.uint8)
+        scale = DeviceTensor(ctx, (), np.float32)
+        zp = DeviceTensor(ctx, (), np.uint8)
+        ctx.call("rten_hip_dynamic_quantize_linear", x.size, x.vp, y.vp, scale.vp, zp.vp)
+        return [y, scale, zp]
+
+
+# ------------------------------------------------------------------------------------------ attention
+class Attention(Operator):
+    """ONNX Attention restricted to the BERT path (src/ops/attention.rs:645-905): 4-D Q/K/V
+    [B,H,S,D], optional additive float mask [B,1,1,T] or [B,1,S,T]; no KV cache / GQA / causal."""
+
+    def __init__(self, scale=None):
+        self.scale = scale
+
+    def max_inputs(self):
+        return 4
+
+    def run(self, ctx, inputs):
+        q = _want(_require(inputs, 0), np.float32)
+        k = _want(_require(inputs, 1), np.float32)
+        v = _want(_require(inputs, 2), np.float32)
+        mask = _get(inputs, 3)
+        if len(q.shape) != 4 or len(k.shape) != 4 or len(v.shape) != 4:
+            raise UnsupportedValue("device Attention needs 4-D Q/K/V")
+        B, H, S, D = q.shape
+        T, Dv = k.shape[2], v.shape[3]
+        if k.shape[:2] != (B, H) or v.shape[:3] != (B, H, T) or k.shape[3] != D:
+            raise IncompatibleInputShapes("Q/K/V shapes are inconsistent")
+        scale = self.scale if self.scale is not None else 1.0 / math.sqrt(D)
+        mbd, mbs, mrs = 1, 0, 0
+        if mask is not None:
+            if mask.dtype != np.float32:
+                raise UnsupportedValue("device Attention supports additive float masks")
+            if tuple(mask.shape) == (B, 1, 1, T):
+                mbd, mbs, mrs = H, T, 0
+            elif tuple(mask.shape) == (B, 1, S, T):
+                mbd, mbs, mrs = H, S * T, T
+            else:
+                raise UnsupportedValue("mask must be [B,1,1,T] or [B,1,S,T]")
+        out = DeviceTensor(ctx, (B, H, S, Dv), np.float32)
+        ctx.call("rten_hip_sdpa_f32", B * H, S, T, D, Dv, q.vp, k.vp, v.vp, _vp(mask), mbd, mbs, mrs, scale, out.vp)
+        return [out]
+
+
+class OpRegistry:
+    """Mirror of OpRegistry (src/op_registry.rs:25-72): op_type -> operator class for the hot path."""
+
+    def __init__(self):
+        self._ops = {}
+
+    @classmethod
+    def with_all_ops(cls):
+        r = cls()
+        for op in (Conv, ConvInteger, ConvIntegerToFloat, MatMul, FusedMatMul, Gemm, MatMulInteger, MatMulIntegerToFloat,
+                   Softmax, AddSoftmax, LayerNormalization, BatchNormalization, Relu, Gelu, Erf, Add, Mul, MaxPool,
+                   AveragePool, GlobalAveragePool, Flatten, DynamicQuantizeLinear, Attention):
+            r.register_op(op)
+        return r
+
+    def register_op(self, op_cls):
+        self._ops[op_cls.__name__] = op_cls
+
+    def get(self, op_type: str):
+        return self._ops.get(op_type)
+
+    def op_types(self):
+        return sorted(self._ops)

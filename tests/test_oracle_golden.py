@@ -1,0 +1,290 @@
+"""Pins the CPU oracle (oracle/rten_oracle.c) against the reference's own golden vectors
+(tests/golden/reference_literals.json, each entry citing the reference test it was copied from)."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ref
+
+G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_literals.json")))
+
+
+def eq_1e4(a, b):  # expect_eq_1e4, src/ops/mod.rs:407-412
+    np.testing.assert_allclose(np.asarray(a, np.float64), np.asarray(b, np.float64), rtol=0, atol=1e-4)
+
+
+def expect_equal(a, b):  # rten-tensor/src/test_util.rs:47-71
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert np.all(np.abs(a - b) <= 1e-8 + 1e-5 * np.abs(b)), np.abs(a - b).max()
+
+
+def test_rng_streams():
+    g = G["rng"]
+    assert ref.XorShiftRng(g["seed"]).f32(10).tolist() == [np.float32(v) for v in g["f32"]]
+    assert ref.XorShiftRng(g["seed"]).i8(10).tolist() == g["i8"]
+    assert ref.XorShiftRng(g["seed"]).u8(10).tolist() == g["u8"]
+    assert ref.XorShiftRng(g["seed"]).i32(10).tolist() == g["i32"]
+    r = ref.XorShiftRng(1234)
+    for _ in range(50):  # reduced_range_rng.rs:63-73
+        assert -64 <= int(r.i8(1, reduced=True)[0]) <= 63
+        assert 0 <= int(r.u8(1, reduced=True)[0]) <= 127
+
+
+def test_conv_literals():
+    g = G["conv"]
+    k = np.array(g["kernel"], np.float32).reshape(1, 1, 3, 3)
+    x = np.array(g["input"], np.float32).reshape(1, 1, 3, 3)
+    eq_1e4(ref.conv2d_f32(x, k, pads=(1, 1, 1, 1)).ravel(), g["expected_same_padding"])
+    eq_1e4(ref.conv2d_f32(x, k).ravel(), g["expected_no_padding"])
+    eq_1e4(ref.conv2d_f32(x, k, bias=np.array([1.0], np.float32)).ravel(), g["expected_with_bias_1"])
+    # Padding::Same == [1,1,1,1] here (conv.rs:845-883)
+    oh, ow, pads = ref.calc_output_size_and_padding((3, 3), (3, 3), (1, 1), "same")
+    assert (oh, ow, pads) == (3, 3, [1, 1, 1, 1])
+
+
+def test_layer_norm_literals():
+    for c in G["layer_norm"]["cases"]:
+        x = np.array(c["input"], np.float32)
+        if c["axis"] == -2:
+            xs = x.reshape(x.shape[0], -1)
+            n = xs.shape[-1]
+            y = ref.layer_norm(xs, gamma=np.full(n, c["scale_full"], np.float32), beta=np.full(n, c["bias_full"], np.float32))
+        elif "scale_scalar" in c:
+            y = ref.layer_norm(x, gamma_scalar=c["scale_scalar"], beta_scalar=c.get("bias_scalar", 0.0))
+        else:
+            y = ref.layer_norm(x, gamma=np.array(c["scale"], np.float32), beta=np.array(c["bias"], np.float32))
+        eq_1e4(y.reshape(np.array(c["expected"]).shape), c["expected"])
+
+
+def test_softmax_literals():
+    for lanes in (4, 8, 16):
+        for c in G["softmax"]["cases"]:
+            eq_1e4(ref.softmax(np.array(c["input"], np.float32), lanes=lanes), c["expected"])
+    # all -inf: NaN unless flushed (attention.rs:1088-1106)
+    x = np.full((1, 3), -np.inf, np.float32)
+    assert np.isnan(ref.softmax(x)).all()
+    assert ref.softmax(x, flush_nan=True).tolist() == [[0.0, 0.0, 0.0]]
+    assert ref.softmax(np.zeros((0, 4), np.float32)).shape == (0, 4)
+
+
+def test_add_softmax_equals_add_then_softmax():
+    # test_add_softmax (attention.rs:1003-1088): AddSoftmax == Softmax(Add(qk, m))
+    rng = ref.XorShiftRng(1234)
+    qk = rng.f32(1 * 8 * 32 * 32).reshape(1, 8, 32, 32)
+    m = rng.f32(32 * 32).reshape(1, 1, 32, 32)
+    fused = ref.softmax(qk, addend=m, add_div=1, add_mod=32)
+    plain = ref.softmax(ref.add(qk, m))
+    assert np.array_equal(fused, plain)
+
+
+def test_cast_scale_literals():
+    for c in G["cast_scale"]["cases"]:
+        y = ref.cast_scale(np.array(c["input"], np.int32), np.array(c["scale"], np.float32))
+        assert y.tolist() == c["expected"]
+
+
+def test_pool_literals():
+    g = G["pool"]
+    x = np.array(g["input4"], np.float32).reshape(1, 1, 4, 4)
+    for c in g["average"]:
+        expect_equal(ref.average_pool(x, c["kernel"], c["strides"])[0, 0], c["expected"])
+    for c in g["max"]:
+        expect_equal(ref.max_pool(x, c["kernel"], c["strides"])[0, 0], c["expected"])
+    xp = np.broadcast_to(np.array(g["padding_input"], np.float32), (1, 5, 4, 4)).copy()
+    y = ref.average_pool(xp, (2, 2), (2, 2), (1, 1, 1, 1))
+    for ch in range(5):
+        eq_1e4(y[0, ch], g["padding_expected"])
+    y = ref.average_pool(xp, (2, 2), (2, 2), (1, 1, 1, 1), count_include_pad=True)
+    eq_1e4(y[0, 0], g["padding_expected_include_pad"])
+    ga = g["global_average"]
+    for lanes in (4, 16):
+        expect_equal(ref.global_average_pool(np.array(ga["input"], np.float32).reshape(ga["shape"]), lanes=lanes).ravel(), ga["expected"])
+
+
+def test_output_size_literals():
+    for c in G["output_size"]["cases"]:
+        args = dict(in_size=c.get("in_size", [5, 5]), kernel=c.get("kernel", [3, 3]), strides=c.get("strides", [1, 1]),
+                    padding=c.get("padding", [0, 0, 0, 0]), dilations=c.get("dilations", [1, 1]), ceil_mode=c.get("ceil", False))
+        if "error" in c:
+            with pytest.raises(ref.OpError, match=c["error"]):
+                ref.calc_output_size_and_padding(**args)
+        else:
+            oh, ow, pads = ref.calc_output_size_and_padding(**args)
+            assert [oh, ow, pads] == c["expected"]
+
+
+def test_erf_gelu_exp_error_bounds():
+    xs = np.arange(-6.0, 6.0, 1e-3, dtype=np.float32)
+    truth = np.array([math.erf(float(v)) for v in xs])
+    err = np.abs(ref.erf(xs).astype(np.float64) - truth).max()
+    assert err <= G["erf"]["max_abs_error"] * 1.05 + 6e-8, err  # erf.rs:127-156 (libm::erff is itself ~0.5 ULP off)
+    g_truth = 0.5 * xs.astype(np.float64) * (1 + np.array([math.erf(float(v) / math.sqrt(2)) for v in xs]))
+    assert np.abs(ref.gelu(xs) - g_truth).max() < 3e-6
+    # Exp: <= 1 ULP vs a correctly rounded exp (exp.rs:30-31)
+    xe = np.linspace(-87.0, 88.0, 20001, dtype=np.float32)
+    got = ref.exp(xe)
+    want = np.exp(xe.astype(np.float64))
+    ulp = np.abs(got.astype(np.float64) - want) / np.spacing(want.astype(np.float32)).astype(np.float64)
+    assert ulp.max() <= 1.0 + 1e-6, ulp.max()
+    assert ref.exp(np.array([104.0, -104.0, 0.0], np.float32)).tolist() == [np.inf, 0.0, 1.0]
+
+
+def test_dynamic_quantize_linear():
+    # quantize.rs:704-767: dequantisation error bound + spec examples; exact algebra restated below
+    for x in (np.array([-234.56], np.float32), np.array([234.56], np.float32), np.arange(-0.1, 0.1, 0.01, dtype=np.float32),
+              ref.XorShiftRng(5).f32(1000) * 6 - 3):
+        q, scale, zp = ref.dynamic_quantize_linear(x)
+        deq = (q.astype(np.float32) - np.float32(zp)) * scale
+        assert np.abs(deq - x).max() <= scale / 2 + 1e-6
+        # independent numpy restatement of the operator definition (ONNX spec formula, quantize.rs:365-383)
+        mn, mx = min(x.min(), np.float32(0)), max(x.max(), np.float32(0))
+        s = np.float32(mx - mn) / np.float32(255)
+        z = np.clip(np.rint(np.clip(np.float32(0) - mn / s, 0, 255)), 0, 255).astype(np.uint8)
+        assert scale == s and zp == z
+        want = np.clip(np.rint(x * (np.float32(1) / s)).astype(np.int64) + int(z), 0, 255).astype(np.uint8)
+        assert np.array_equal(q, want)
+    q, scale, zp = ref.dynamic_quantize_linear(np.zeros((0,), np.float32))
+    assert (scale, zp) == (1.0, 0)
+    q, scale, zp = ref.dynamic_quantize_linear(np.zeros((7,), np.float32))  # all zero -> scale 0, codes 0
+    assert scale == 0.0 and zp == 0 and not q.any()
+
+
+def reference_gemm_f64(a, b, alpha=1.0, beta=0.0, c=None, bias=None, bias_kind=0):
+    acc = a.astype(np.float64) @ b.astype(np.float64) * alpha
+    if c is not None and beta != 0:
+        acc = acc + beta * c
+    if bias is not None:
+        acc = acc + (bias[:, None] if bias_kind == 1 else bias[None, :])
+    return acc
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 1, 1), (2, 5, 20), (8, 8, 256), (10, 1025, 300), (64, 65, 257), (80, 4, 1), (16, 1024, 0), (0, 5, 3)])
+def test_gemm_f32_vs_f64_truth(m, n, k):
+    # size matrix in the spirit of rten-gemm/src/tests.rs:336-362; tolerance: f32 accumulation error bound
+    rng = ref.XorShiftRng(1234)
+    a = rng.f32(m * k).reshape(m, k) - 0.5
+    b = rng.f32(k * n).reshape(k, n) - 0.5
+    got = ref.gemm_f32(a, b)
+    want = reference_gemm_f64(a, b)
+    assert got.shape == (m, n)
+    if got.size:
+        assert np.abs(got - want).max() <= 1e-6 * max(k, 1)
+
+
+def test_gemm_f32_options():
+    rng = ref.XorShiftRng(7)
+    a = rng.f32(20 * 300).reshape(20, 300) - 0.5
+    b = rng.f32(300 * 33).reshape(300, 33) - 0.5
+    c = rng.f32(20 * 33).reshape(20, 33)
+    bias_r, bias_c = rng.f32(20), rng.f32(33)
+    for alpha, beta in ((1.0, 0.0), (1.0, 1.0), (0.5, 0.0), (0.5, 2.0)):
+        got = ref.gemm_f32(a, b, c=c, alpha=alpha, beta=beta)
+        np.testing.assert_allclose(got, reference_gemm_f64(a, b, alpha, beta, c), rtol=0, atol=5e-5)
+    # beta == 0 must not read C (NaN-poisoned output, tests.rs:632-674)
+    got = ref.gemm_f32(a, b, c=np.full((20, 33), np.nan, np.float32), beta=0.0)
+    assert not np.isnan(got).any()
+    np.testing.assert_allclose(ref.gemm_f32(a, b, bias=bias_r, bias_kind=ref.BIAS_PER_ROW), reference_gemm_f64(a, b, bias=bias_r, bias_kind=1), atol=5e-5)
+    np.testing.assert_allclose(ref.gemm_f32(a, b, bias=bias_c, bias_kind=ref.BIAS_PER_COL), reference_gemm_f64(a, b, bias=bias_c, bias_kind=2), atol=5e-5)
+    # transposed / strided operands give bit-identical results (strides only change addressing, tests.rs:523-569)
+    assert np.array_equal(ref.gemm_f32(np.ascontiguousarray(a.T).T, np.ascontiguousarray(b.T).T), ref.gemm_f32(a, b))
+
+
+def test_gemm_f32_accumulation_order_is_kc_blocked():
+    # depth blocks of 256 with k-ordered fma chains (rten-gemm/src/lib.rs:630-633, simd_generic.rs:326-344)
+    rng = ref.XorShiftRng(99)
+    K = 600
+    a = rng.f32(K).reshape(1 + 0, K)
+    a = np.vstack([a, a])  # M = 2 (avoid the gemv path semantics note)
+    b = rng.f32(K * 3).reshape(K, 3)
+    bias = np.array([0.25, -0.5], np.float32)
+    got = ref.gemm_f32(a, b, bias=bias, bias_kind=ref.BIAS_PER_ROW)
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    libm.fmaf.restype = ctypes.c_float
+    libm.fmaf.argtypes = [ctypes.c_float] * 3
+    for j in range(3):
+        total = None
+        for k0 in range(0, K, 256):
+            acc = np.float32(0)
+            for k in range(k0, min(k0 + 256, K)):
+                acc = np.float32(libm.fmaf(float(a[0, k]), float(b[k, j]), float(acc)))
+            total = np.float32(acc + bias[0]) if total is None else np.float32(total + acc)
+        assert got[0, j] == total
+
+
+def reference_gemm_int(a, b, a_zp, b_zp):
+    az = np.zeros(a.shape[0], np.int64) if a_zp is None else np.broadcast_to(np.asarray(a_zp, np.int64), (a.shape[0],))
+    bz = np.zeros(b.shape[1], np.int64) if b_zp is None else np.broadcast_to(np.asarray(b_zp, np.int64), (b.shape[1],))
+    r = (a.astype(np.int64) - az[:, None]) @ (b.astype(np.int64) - bz[None, :])
+    return ((r + 2**31) % 2**32 - 2**31).astype(np.int32)
+
+
+@pytest.mark.parametrize("adt,bdt", [(np.uint8, np.int8), (np.uint8, np.uint8), (np.int8, np.int8), (np.int8, np.uint8)])
+def test_gemm_int8_all_signedness(adt, bdt):
+    # src/ops/matmul.rs:1365-1750 (16 cases + 4 signedness macros vs reference_matmul_integer)
+    rng = ref.XorShiftRng(1234)
+    for (m, n, k) in ((1, 1, 1), (5, 7, 3), (16, 33, 64), (8, 4, 300)):
+        a = (rng.u8(m * k) if adt == np.uint8 else rng.i8(m * k)).reshape(m, k)
+        b = (rng.u8(k * n) if bdt == np.uint8 else rng.i8(k * n)).reshape(k, n)
+        for a_zp, b_zp in ((None, None), (np.array([3], adt), np.array([5], bdt)),
+                           ((rng.u8(m) if adt == np.uint8 else rng.i8(m)), (rng.u8(n) if bdt == np.uint8 else rng.i8(n)))):
+            got = ref.gemm_int8(a, b, a_zp, b_zp)
+            assert np.array_equal(got, reference_gemm_int(a, b, a_zp, b_zp))
+
+
+def test_conv_int8_against_integer_definition():
+    import torch
+    rng = ref.XorShiftRng(11)
+    x = rng.u8(2 * 4 * 7 * 6).reshape(2, 4, 7, 6)
+    w = rng.i8(6 * 2 * 3 * 3, reduced=True).reshape(6, 2, 3, 3)
+    w_zp = rng.i8(6, reduced=True)
+    # no padding: all pad modes agree (the reference's own int8 conv tests use Padding::zero, conv.rs:1505)
+    outs = [ref.conv2d_int8(x, w, x_zp=9, w_zp=w_zp, groups=2, strides=(2, 1), pad_mode=pm) for pm in (0, 1, 2)]
+    want = torch.nn.functional.conv2d(torch.tensor(x.astype(np.float64) - 9),
+                                      torch.tensor(w.astype(np.float64)) - torch.tensor(w_zp.astype(np.float64)).view(6, 1, 1, 1),
+                                      stride=(2, 1), groups=2).numpy()
+    for o in outs:
+        assert np.array_equal(o, want.astype(np.int32))
+    # with padding: ZERO_POINT == ONNX semantics; RAW0_I8 == padding with u8 value 128
+    zp_out = ref.conv2d_int8(x, w, x_zp=9, w_zp=w_zp, groups=2, pads=(1, 1, 1, 1), pad_mode=ref.PAD_ZERO_POINT)
+    xpad = np.pad(x.astype(np.float64), ((0, 0), (0, 0), (1, 1), (1, 1)), constant_values=9)
+    want = torch.nn.functional.conv2d(torch.tensor(xpad - 9), torch.tensor(w.astype(np.float64)) - torch.tensor(w_zp.astype(np.float64)).view(6, 1, 1, 1), groups=2).numpy()
+    assert np.array_equal(zp_out, want.astype(np.int32))
+    raw_out = ref.conv2d_int8(x, w, x_zp=9, w_zp=w_zp, groups=2, pads=(1, 1, 1, 1), pad_mode=ref.PAD_RAW0_I8)
+    xpad = np.pad(x.astype(np.float64), ((0, 0), (0, 0), (1, 1), (1, 1)), constant_values=128)
+    want = torch.nn.functional.conv2d(torch.tensor(xpad - 9), torch.tensor(w.astype(np.float64)) - torch.tensor(w_zp.astype(np.float64)).view(6, 1, 1, 1), groups=2).numpy()
+    assert np.array_equal(raw_out, want.astype(np.int32))
+
+
+def test_conv_f32_vs_torch_sweep():
+    import torch
+    rng = ref.XorShiftRng(3)
+    cases = [dict(N=2, C=8, H=9, W=11, O=6, k=(3, 3), pads=(1, 1, 1, 1), strides=(1, 1), dil=(1, 1), groups=1),
+             dict(N=1, C=4, H=12, W=12, O=8, k=(3, 3), pads=(0, 1, 2, 1), strides=(2, 2), dil=(1, 1), groups=2),
+             dict(N=3, C=6, H=10, W=7, O=6, k=(1, 1), pads=(0, 0, 0, 0), strides=(1, 1), dil=(1, 1), groups=1),
+             dict(N=1, C=3, H=16, W=16, O=4, k=(7, 7), pads=(3, 3, 3, 3), strides=(2, 2), dil=(1, 1), groups=1),
+             dict(N=1, C=2, H=14, W=14, O=2, k=(3, 3), pads=(2, 2, 2, 2), strides=(1, 1), dil=(2, 2), groups=1)]
+    for c in cases:
+        x = rng.f32(c["N"] * c["C"] * c["H"] * c["W"]).reshape(c["N"], c["C"], c["H"], c["W"]) - 0.5
+        w = rng.f32(c["O"] * (c["C"] // c["groups"]) * c["k"][0] * c["k"][1]).reshape(c["O"], c["C"] // c["groups"], *c["k"]) - 0.5
+        b = rng.f32(c["O"])
+        got = ref.conv2d_f32(x, w, b, pads=c["pads"], strides=c["strides"], dilations=c["dil"], groups=c["groups"])
+        pt, pl, pb, pr = c["pads"]
+        xp = torch.nn.functional.pad(torch.tensor(x), (pl, pr, pt, pb))
+        want = torch.nn.functional.conv2d(xp, torch.tensor(w), torch.tensor(b), stride=c["strides"], dilation=c["dil"], groups=c["groups"]).numpy()
+        expect_equal(got, want) if False else np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)
+
+
+def test_sdpa_vs_torch():
+    import torch
+    rng = ref.XorShiftRng(21)
+    q = rng.f32(2 * 3 * 16 * 8).reshape(2, 3, 16, 8) - 0.5
+    k = rng.f32(2 * 3 * 16 * 8).reshape(2, 3, 16, 8) - 0.5
+    v = rng.f32(2 * 3 * 16 * 8).reshape(2, 3, 16, 8) - 0.5
+    mask = np.where(rng.f32(2 * 16).reshape(2, 1, 1, 16) > 0.3, 0.0, -np.inf).astype(np.float32)
+    got = ref.sdpa(q, k, v, mask=mask)
+    want = torch.nn.functional.scaled_dot_product_attention(torch.tensor(q), torch.tensor(k), torch.tensor(v), attn_mask=torch.tensor(mask)).numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)
