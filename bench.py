@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- ResNet-50 f32, batch 32 per GPU, on the HIP backend (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one forward pass of ResNet-50 (53 convs + maxpool + global-avg-pool + fc) over one batch of
+32 synthetic 224x224 images that is already resident in HBM.  One process per GPU; batches are
+independent, so the path shards with no data-path collective (weak scaling: 32 images per GPU); the only
+collective is the one-time RCCL broadcast of the prepacked weight arena from rank 0 at load.
+
+Rank 0 prints ONE JSON line: metric/value (whole-job inferences/s), roofline of the dominant kernel
+(measured live with HIP events on the backend's stream in an instrumented pass over the same K steps),
+and cpu_baseline (the CPU oracle -- a port of the reference algorithm -- timed on this host's cores on a
+bounded sample; N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+F32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X v_mfma_f32_32x32x2_f32 peak (MI355X_MICROARCH.md)
+BATCH_PER_GPU = 32
+
+
+def cpu_baseline(specs, weights, budget_s=12.0):
+    """Times the CPU oracle (reference algorithm port, OpenMP) on a bounded sample of the same workload."""
+    from oracle import models as omodels
+    from oracle import ref
+    threads = ref.num_threads()
+    x = ref.XorShiftRng(7).f32(2 * 3 * 224 * 224).reshape(2, 3, 224, 224)
+    t0 = time.perf_counter()
+    omodels.resnet50_forward(specs, weights, x)
+    t_first = time.perf_counter() - t0
+    reps = int(max(1, min(16, budget_s / max(t_first, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        omodels.resnet50_forward(specs, weights, x)
+    dt = time.perf_counter() - t0
+    imgs = 2 * reps
+    return {"value": round(imgs / dt, 3), "unit": "inferences/s", "cores": threads, "kind": "port",
+            "sample": f"{imgs} images (batch 2 x {reps} forward passes) of the same ResNet-50 graph through oracle/rten_oracle.c "
+                      f"({threads} OpenMP threads, {dt:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-autotune", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layer-table", action="store_true", help="print the per-layer autotune table to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n_gpus = args.gpus
+    dist = None
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    from rten_amd import lib
+    from rten_amd.models import resnet50
+    from rten_amd.parallel import broadcast_weight_arena
+
+    ctx = lib.Context(local_rank)  # no CPU fallback: raises if the HIP extension / MI355X is missing
+    weights = resnet50.make_weights()
+    # weight arena lives in a torch allocation so RCCL can broadcast it
+    net = None
+    arena_t = None
+    if world > 1:
+        tmp = resnet50.ResNet50(ctx, BATCH_PER_GPU, weights)
+        nbytes = tmp.arena_bytes
+        del tmp
+        arena_t = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{local_rank}")
+        net = resnet50.ResNet50(ctx, BATCH_PER_GPU, weights, arena_ptr=arena_t.data_ptr(), arena_keepalive=arena_t)
+        if rank == 0:
+            net.upload_weights()
+        ctx.sync()
+        broadcast_weight_arena(arena_t, src=0)  # RCCL over xGMI, once
+        torch.cuda.synchronize()
+    else:
+        net = resnet50.ResNet50(ctx, BATCH_PER_GPU, weights)
+        net.upload_weights()
+
+    # each rank gets its own (independent) synthetic batch, resident in HBM before timing starts
+    x = np.random.default_rng(1234 + rank).random((BATCH_PER_GPU, 3, 224, 224), dtype=np.float32)
+    net.x.upload(x)
+    ctx.sync()
+
+    table = None
+    if not args.no_autotune:
+        table = net.autotune(reps=3)
+        if args.layer_table and rank == 0:
+            for l in net.specs:
+                d = net.descs[l["name"]]
+                fl = 2.0 * d.o * d.c * d.kh * d.kw * d.out_h * d.out_w * d.n
+                row = table[l["name"]]
+                print(f"[layer] {l['name']:8s} O={d.o:4d} C={d.c:4d} k={d.kh} s={d.stride_h} {d.h:3d}->{d.out_h:3d} "
+                      + " ".join(f"v{v}={ms*1e3:7.1f}us" for v, ms in enumerate(row))
+                      + f"  best=v{net.variants[l['name']]} {fl / (min(row) * 1e-3) / 1e12:6.1f} TF/s", file=sys.stderr)
+    if not args.no_graph:
+        net.capture()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        net.run()
+    ctx.sync()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        net.run()
+    ctx.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- p50 latency per batch (separate pass, host-timed per step)
+    lat = []
+    for _ in range(min(args.steps, 20)):
+        t1 = time.perf_counter()
+        net.run()
+        ctx.sync()
+        lat.append((time.perf_counter() - t1) * 1e3)
+    p50 = float(np.median(lat))
+
+    # ---- roofline of the dominant kernel: instrumented eager pass over the same K steps (HIP events per launch
+    #      on the backend's stream).  Kept out of the timed region so `value` is not perturbed.
+    roof = None
+    if rank == 0:
+        ctx.profile_reset()
+        ctx.profile(True)
+        saved_graph, net.graph = net.graph, None
+        for _ in range(args.steps):
+            net.forward()
+        ctx.sync()
+        ctx.profile(False)
+        net.graph = saved_graph
+        rep = ctx.profile_report()
+        conv = [r for r in rep if r["kernel"].startswith("igemm_f32")]
+        tot_ms = sum(r["ms"] for r in rep)
+        if conv:
+            dom = max(conv, key=lambda r: r["ms"])
+            fam_ms = sum(r["ms"] for r in conv)
+            fam_fl = sum(r["flops"] for r in conv)
+            roof = {"bound": "mfma", "kernel": dom["kernel"],
+                    "achieved": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12, 3), "peak": F32_MATRIX_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12 / F32_MATRIX_PEAK_TFLOPS, 4),
+                    "traffic": None,
+                    "avg_launch_us": round(dom["ms"] * 1e3 / max(dom["launches"], 1), 2), "launches": dom["launches"],
+                    "flops_per_launch": dom["flops"] / max(dom["launches"], 1),
+                    "kernel_share_of_step": round(dom["ms"] / max(tot_ms, 1e-9), 4),
+                    "igemm_family": {"achieved": round(fam_fl / (fam_ms * 1e-3) / 1e12, 3),
+                                     "frac": round(fam_fl / (fam_ms * 1e-3) / 1e12 / F32_MATRIX_PEAK_TFLOPS, 4),
+                                     "share_of_step": round(fam_ms / max(tot_ms, 1e-9), 4),
+                                     "variants": {r["kernel"]: {"launches": r["launches"], "ms": round(r["ms"], 4),
+                                                                "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2)} for r in conv}}}
+
+    if rank == 0:
+        global_batch = BATCH_PER_GPU * n_gpus
+        value = global_batch * args.steps / elapsed
+        out = {
+            "metric": "inferences/sec, ResNet-50 f32 batch 32 per GPU",
+            "value": round(value, 2), "unit": "inferences/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "p50_latency_ms": round(p50, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ResNet-50 v1.5 f32 inference, 224x224, batch 32 per GPU (BASELINE configs[1]); "
+                                   "synthetic He-normal BN-folded weights (seed 1234), inputs U[0,1) resident in HBM",
+                       "global_batch": global_batch, "parallelism": f"batch-shard x{n_gpus} (weights RCCL-broadcast once)" if n_gpus > 1 else "single GPU",
+                       "launch": "eager" if args.no_graph else "hipGraph replay", "autotuned_tiles": not args.no_autotune,
+                       "gflop_per_image": round((resnet50.conv_flops_per_image() + 2 * 2048 * 1000) / 1e9, 3),
+                       "device": ctx.device_info()},
+            "roofline": roof,
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(net.specs, weights)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -342,13 +342,13 @@ class Gemm(Operator):
             raise IncompatibleInputShapes("Columns of first matrix does not match rows of second matrix")
         a_rs, a_cs = (1, a.shape[1]) if self.transpose_a else (a.shape[1], 1)
         b_rs, b_cs = (1, b.shape[1]) if self.transpose_b else (b.shape[1], 1)
-        y = DeviceTensor(ctx, (m, n), np.float32)
         beta = self.beta if c is not None else 0.0
+        if c is not None and beta != 0.0 and _broadcast_shapes(tuple(c.shape), (m, n)) != (m, n):
+            raise IncompatibleInputShapes("Cannot broadcast c to output shape")
+        y = DeviceTensor(ctx, (m, n), np.float32)
         if c is not None and beta != 0.0:
             # expand_to(c, out_shape) then gemm with beta (matmul.rs:63-82)
             cs = tuple(c.shape)
-            if _broadcast_shapes(cs, (m, n)) != (m, n):
-                raise IncompatibleInputShapes("Cannot broadcast c to output shape")
             if cs == (m, n):
                 ctx.call("rten_hip_memcpy_d2d", y.vp, c.vp, C.c_size_t(y.nbytes))
             else:  # row / column / scalar broadcast: materialise via add to zeros
@@ -483,22 +483,49 @@ class AddSoftmax(Operator):
         msh = (1,) * (len(qk.shape) - len(m.shape)) + tuple(m.shape)
         if msh[-1] != cols:
             raise UnsupportedValue("mask must be contiguous along the softmax axis")
-        # supported broadcast patterns: same shape, or a leading block + ones ([B,1,1,S] against [B,H,S,S])
+        # Broadcast patterns expressible as addend_row = (row // div) % mod:
+        #   same shape; all-ones; prefix [B,1,1] (mask [B,1,1,S] vs scores [B,H,S,S]); suffix [1,1,S].
+        # [B,1,S] (prefix + suffix) is run as one launch per leading index.
         lead = msh[:-1]
         qlead = tuple(qk.shape[:-1])
-        nz = [i for i, s in enumerate(lead) if s != 1]
-        if lead == qlead:
-            add_div, add_mod = 1, rows
-        elif not nz:
-            add_div, add_mod = max(rows, 1), 1
-        elif nz == list(range(nz[-1] + 1)) and all(lead[i] == qlead[i] for i in nz):
-            inner = int(np.prod(qlead[nz[-1] + 1:], dtype=np.int64))
-            add_div, add_mod = inner, int(np.prod([lead[i] for i in nz], dtype=np.int64))
-        else:
-            raise UnsupportedValue("unsupported mask broadcast pattern on the device path")
+        flush = 1 if self.flush_nans_to_zero else 0
         out = DeviceTensor(ctx, qk.shape, np.float32)
-        ctx.call("rten_hip_softmax_f32", rows, cols, qk.vp, m.vp, add_div, add_mod, 1 if self.flush_nans_to_zero else 0, out.vp)
-        return [out]
+
+        def prod(t):
+            return int(np.prod(t, dtype=np.int64)) if len(t) else 1
+
+        def pattern(ld, ql):
+            if ld == ql:
+                return 1, max(prod(ql), 1)
+            if all(v == 1 for v in ld):
+                return max(prod(ql), 1), 1
+            i = len(ld)
+            while i > 0 and ld[i - 1] == 1:
+                i -= 1
+            if ld[:i] == ql[:i]:
+                return prod(ql[i:]), prod(ql[:i])
+            j = 0
+            while j < len(ld) and ld[j] == 1:
+                j += 1
+            if ld[j:] == ql[j:]:
+                return 1, prod(ql[j:])
+            return None
+
+        pat = pattern(lead, qlead)
+        if pat is not None:
+            ctx.call("rten_hip_softmax_f32", rows, cols, qk.vp, m.vp, pat[0], pat[1], flush, out.vp)
+            return [out]
+        if len(lead) >= 2 and lead[0] == qlead[0]:
+            sub = pattern(lead[1:], qlead[1:])
+            if sub is not None:
+                rows_b = prod(qlead[1:])
+                m_rows_b = prod(lead[1:])
+                for b in range(qlead[0]):
+                    ctx.call("rten_hip_softmax_f32", rows_b, cols, C.c_void_p(qk.ptr + b * rows_b * cols * 4),
+                             C.c_void_p(m.ptr + b * m_rows_b * cols * 4), sub[0], sub[1], flush,
+                             C.c_void_p(out.ptr + b * rows_b * cols * 4))
+                return [out]
+        raise UnsupportedValue("unsupported mask broadcast pattern on the device path")
 
 
 class LayerNormalization(Operator):

@@ -1,0 +1,97 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/rten_hip.h declares.
+No compute calls here (no GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "rten_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rten_hip_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from rten_amd import lib
+    so = lib.load()
+    syms = header_symbols()
+    assert len(syms) >= 40
+    for s in syms:
+        assert hasattr(so, s), f"librten_hip.so does not export {s}"
+    # and the python binding declares a prototype for each of them
+    assert sorted(lib.PROTOTYPES) == syms
+
+
+def test_abi_version_and_variants():
+    from rten_amd import lib
+    so = lib.load()
+    assert so.rten_hip_abi_version() == 1
+    assert so.rten_hip_num_gemm_variants() == 4
+
+
+def test_struct_layouts_match_header():
+    # sizes computed by the C compiler for the header's structs must match the ctypes mirrors
+    import subprocess
+    import tempfile
+    from rten_amd import lib
+    src = r'''
+    #include <stdio.h>
+    #include "rten_hip.h"
+    int main(void) {
+        printf("%zu %zu %zu %zu %zu\n", sizeof(rten_hip_gemm_desc), sizeof(rten_hip_gemm_int8_desc),
+               sizeof(rten_hip_conv2d_desc), sizeof(rten_hip_conv2d_int8_desc), sizeof(rten_hip_pool2d_desc));
+        return 0;
+    }'''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
+        sizes = [int(v) for v in subprocess.check_output([os.path.join(d, "t")]).split()]
+    assert sizes == [ctypes.sizeof(lib.GemmDesc), ctypes.sizeof(lib.GemmInt8Desc), ctypes.sizeof(lib.Conv2dDesc),
+                     ctypes.sizeof(lib.Conv2dInt8Desc), ctypes.sizeof(lib.Pool2dDesc)]
+
+
+def test_output_size_through_abi_matches_reference_cases():
+    import json
+    from rten_amd import lib, ops
+    so = lib.load()
+
+    class _Ctx:  # calc_output_size_and_padding is host-side shape logic: needs no device
+        lib = so
+
+    G = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_literals.json")))
+    for c in G["output_size"]["cases"]:
+        args = dict(in_size=c.get("in_size", [5, 5]), kernel=c.get("kernel", [3, 3]), strides=c.get("strides", [1, 1]),
+                    padding=c.get("padding", [0, 0, 0, 0]), dilations=c.get("dilations", [1, 1]), ceil_mode=c.get("ceil", False))
+        if "error" in c:
+            with pytest.raises(ops.OpError) as e:
+                ops.calc_output_size_and_padding(_Ctx, **args)
+            assert e.value == ops.InvalidValue(c["error"])
+        else:
+            oh, ow, pads = ops.calc_output_size_and_padding(_Ctx, **args)
+            assert [oh, ow, pads] == c["expected"]
+    with pytest.raises(ops.OpError) as e:  # pooling.rs:1165-1169
+        ops.calc_output_size_and_padding(_Ctx, (5, 5), (3, 3), (1, 1), [0, 0])
+    assert e.value == ops.InvalidValue("Expected 4 padding values")
+
+
+def test_no_silent_cpu_fallback():
+    """Without a GPU the backend must refuse to run (BackendUnavailable), never compute on the CPU."""
+    import torch
+    from rten_amd import lib
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the -m gpu tests")
+    with pytest.raises(lib.BackendUnavailable):
+        lib.Context(0)
+
+
+def test_product_never_imports_oracle():
+    """oracle/ is test infrastructure: nothing under rten_amd/ (or bench.py's product path) may import it."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "rten_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".sh")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "from oracle" not in text and "import oracle" not in text and "rten_oracle" not in text, f

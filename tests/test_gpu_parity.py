@@ -1,0 +1,456 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bars (DESIGN.md section "Parity"):
+  * integer / byte work (int8 GEMM + conv, DQL codes, zero points): bit-exact
+  * f32 GEMM / conv (M > 1), element-wise ops, pooling: bit-exact vs the oracle's restatement of the
+    reference's accumulation order
+  * reductions (softmax, LayerNorm, GlobalAveragePool): bit-exact vs oracle lanes=16 (AVX-512 order);
+    tolerance 1e-6 relative vs other lane counts
+  * M == 1 GEMM (reference gemv path): tolerance 1e-5 relative (tests state it where used)
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import ref
+from rten_amd import lib as L
+from rten_amd import ops
+from rten_amd.tensor import DeviceTensor
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(ctx, a):
+    return DeviceTensor.from_numpy(ctx, a)
+
+
+def bits_equal(a, b):
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if a.dtype == np.float32:
+        # +0 / -0 compare equal; NaNs must coincide
+        same = (a == b) | (np.isnan(a) & np.isnan(b))
+        if not same.all():
+            idx = np.argwhere(~same)[0]
+            raise AssertionError(f"{(~same).sum()} of {a.size} elements differ; first at {tuple(idx)}: {a[tuple(idx)]!r} vs {b[tuple(idx)]!r}; "
+                                 f"max abs diff {np.nanmax(np.abs(a.astype(np.float64) - b.astype(np.float64)))}")
+    else:
+        assert np.array_equal(a, b), f"{(a != b).sum()} of {a.size} elements differ"
+
+
+def gpu_gemm(ctx, a, b, c=None, alpha=1.0, beta=0.0, bias=None, bias_kind=0, act=0, variant=None):
+    M, K = a.shape
+    N = b.shape[1]
+    ad, bd = dev(ctx, a), dev(ctx, b)  # contiguous copies of whatever layout `a`/`b` views have
+    # preserve the logical strides of the views
+    a_rs, a_cs = (a.strides[0] // 4, a.strides[1] // 4) if a.size else (K, 1)
+    b_rs, b_cs = (b.strides[0] // 4, b.strides[1] // 4) if b.size else (N, 1)
+    if not (a.flags.c_contiguous or a.T.flags.c_contiguous):
+        raise AssertionError("test helper supports plain or transposed views")
+    if a.T.flags.c_contiguous and not a.flags.c_contiguous:
+        ad = dev(ctx, np.ascontiguousarray(a.T))
+    if b.T.flags.c_contiguous and not b.flags.c_contiguous:
+        bd = dev(ctx, np.ascontiguousarray(b.T))
+    cd = dev(ctx, c if c is not None else np.full((M, N), np.nan, np.float32))
+    biasd = dev(ctx, bias) if bias is not None else None
+    d = L.GemmDesc(M, N, K, a_rs, a_cs, b_rs, b_cs, N, 1, 0, 0, 0, alpha, beta, bias_kind if bias is not None else 0, act)
+    if variant is not None:
+        ctx.set_gemm_variant(variant)
+    ctx.call("rten_hip_gemm_f32", C.byref(d), ad.vp, bd.vp, biasd.vp if biasd else None, cd.vp)
+    ctx.set_gemm_variant(-1)
+    return cd.numpy()
+
+
+# ------------------------------------------------------------------------------------------ f32 GEMM
+@pytest.mark.parametrize("m", [2, 8, 10, 64, 80, 130])
+def test_gemm_f32_bit_exact_size_matrix(ctx, m):
+    # size matrix of rten-gemm/src/tests.rs:336-362 (rows x depth x cols)
+    rng = ref.XorShiftRng(1234 + m)
+    for k in (0, 1, 2, 20, 256, 300, 700):
+        for n in (1, 2, 4, 5, 8, 129, 1024, 1025):
+            a = rng.f32(m * k).reshape(m, k) - 0.5
+            b = rng.f32(k * n).reshape(k, n) - 0.5
+            bits_equal(gpu_gemm(ctx, a, b), ref.gemm_f32(a, b))
+
+
+def test_gemm_f32_all_tile_variants_agree(ctx):
+    rng = ref.XorShiftRng(5)
+    a = rng.f32(200 * 520).reshape(200, 520) - 0.5
+    b = rng.f32(520 * 264).reshape(520, 264) - 0.5
+    want = ref.gemm_f32(a, b)
+    for v in range(4):
+        bits_equal(gpu_gemm(ctx, a, b, variant=v), want)
+
+
+def test_gemm_f32_options_bit_exact(ctx):
+    rng = ref.XorShiftRng(7)
+    a = rng.f32(72 * 300).reshape(72, 300) - 0.5
+    b = rng.f32(300 * 132).reshape(300, 132) - 0.5
+    c = rng.f32(72 * 132).reshape(72, 132)
+    br, bc = rng.f32(72), rng.f32(132)
+    for alpha, beta in ((1.0, 0.0), (1.0, 1.0), (0.5, 0.0), (0.5, 2.0), (0.125, 1.0)):
+        bits_equal(gpu_gemm(ctx, a, b, c=c, alpha=alpha, beta=beta), ref.gemm_f32(a, b, c=c, alpha=alpha, beta=beta))
+    # beta == 0 never reads C (NaN-poisoned): tests.rs:632-674
+    assert not np.isnan(gpu_gemm(ctx, a, b, c=np.full((72, 132), np.nan, np.float32), beta=0.0)).any()
+    bits_equal(gpu_gemm(ctx, a, b, bias=br, bias_kind=L.BIAS_PER_ROW), ref.gemm_f32(a, b, bias=br, bias_kind=ref.BIAS_PER_ROW))
+    bits_equal(gpu_gemm(ctx, a, b, bias=bc, bias_kind=L.BIAS_PER_COL), ref.gemm_f32(a, b, bias=bc, bias_kind=ref.BIAS_PER_COL))
+    # transposed operands are strides (tests.rs:523-569); all four loader combinations
+    at, bt = np.ascontiguousarray(a.T).T, np.ascontiguousarray(b.T).T
+    want = ref.gemm_f32(a, b)
+    for aa, bb in ((a, b), (at, b), (a, bt), (at, bt)):
+        bits_equal(gpu_gemm(ctx, aa, bb), want)
+    # fused activations == the separate ops
+    bits_equal(gpu_gemm(ctx, a, b, bias=bc, bias_kind=L.BIAS_PER_COL, act=L.ACT_RELU), ref.relu(ref.gemm_f32(a, b, bias=bc, bias_kind=ref.BIAS_PER_COL)))
+    bits_equal(gpu_gemm(ctx, a, b, bias=bc, bias_kind=L.BIAS_PER_COL, act=L.ACT_GELU), ref.gelu(ref.gemm_f32(a, b, bias=bc, bias_kind=ref.BIAS_PER_COL)))
+
+
+def test_gemm_f32_gemv_tolerance(ctx):
+    # M == 1: the reference takes its ISA-dependent gemv path; parity by tolerance (rtol 1e-5 of sum|a||b|)
+    rng = ref.XorShiftRng(11)
+    a = rng.f32(2048).reshape(1, 2048) - 0.5
+    b = rng.f32(2048 * 1000).reshape(2048, 1000) - 0.5
+    got = gpu_gemm(ctx, a, b)
+    want = a.astype(np.float64) @ b.astype(np.float64)
+    assert np.abs(got - want).max() <= 1e-5 * (np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64)).max()
+
+
+def test_matmul_ops_broadcast_and_batched(ctx):
+    # src/ops/matmul.rs:1096-1183 shape/broadcast matrix (the device-supported subset)
+    rng = ref.XorShiftRng(13)
+
+    def r(*s):
+        return rng.f32(int(np.prod(s))).reshape(s) - 0.5
+    for ash, bsh in (((3, 10), (10, 8)), ((2, 3, 10), (10, 8)), ((4, 5, 10), (4, 10, 8)), ((2, 2, 5, 10), (10, 8)), ((10,), (10, 8)), ((3, 10), (10,))):
+        a, b = r(*ash), r(*bsh)
+        got = ops.MatMul().run(ctx, [dev(ctx, a), dev(ctx, b)])[0].numpy()
+        want = ref.matmul_f32(a, b) if a.ndim > 1 and b.ndim > 1 else None
+        if want is None:
+            want = (a.astype(np.float64) @ b.astype(np.float64)).astype(np.float32)
+            np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+        elif a.shape[-2] == 1 or (a.ndim == 2 and a.shape[0] == 1):
+            np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+        else:
+            bits_equal(got, want)
+    # FusedMatMul: bias + alpha (matmul.rs:1242-1281)
+    a, b, bias = r(6, 12, 40), r(40, 24), r(24)
+    got = ops.FusedMatMul(alpha=0.125).run(ctx, [dev(ctx, a), dev(ctx, b), dev(ctx, bias)])[0].numpy()
+    bits_equal(got, ref.matmul_f32(a, b, alpha=0.125, bias=bias))
+    # Gemm op: transB + C broadcast with beta (ResNet fc), matmul.rs:32-104
+    x, w, cb = r(32, 200), r(50, 200), r(50)
+    got = ops.Gemm(alpha=1.0, beta=1.0, transpose_b=True).run(ctx, [dev(ctx, x), dev(ctx, w), dev(ctx, cb)])[0].numpy()
+    want = ref.gemm_f32(x, w.T, c=np.broadcast_to(cb, (32, 50)).astype(np.float32), alpha=1.0, beta=1.0)
+    bits_equal(got, want)
+
+
+# ------------------------------------------------------------------------------------------ f32 conv
+def gpu_conv(ctx, x, w, bias=None, pads=(0, 0, 0, 0), strides=(1, 1), dilations=(1, 1), groups=1, residual=None, relu=False, prepack=True, variant=None):
+    op = ops.Conv(groups=groups, dilations=dilations, padding=list(pads), strides=strides, fuse_relu=relu)
+    xd, wd = dev(ctx, x), dev(ctx, w)
+    packed = None
+    if prepack:
+        d = op._geometry(ctx, x.shape, w.shape)
+        packed = op.prepack(ctx, wd, d)
+    ins = [xd, wd, dev(ctx, bias) if bias is not None else None, dev(ctx, residual) if residual is not None else None]
+    if variant is not None:
+        ctx.set_gemm_variant(variant)
+    y = op.run(ctx, ins, packed_weight=packed)[0].numpy()
+    ctx.set_gemm_variant(-1)
+    return y
+
+
+CONV_CASES = [
+    # N, C, H, W, O, kh, kw, pads, strides, dil, groups   (src/ops/conv.rs:885-1319 sweeps)
+    (2, 8, 9, 11, 6, 3, 3, (1, 1, 1, 1), (1, 1), (1, 1), 1),
+    (1, 4, 12, 12, 8, 3, 3, (0, 1, 2, 1), (2, 2), (1, 1), 2),
+    (3, 6, 10, 7, 6, 1, 1, (0, 0, 0, 0), (1, 1), (1, 1), 1),
+    (2, 16, 8, 8, 12, 1, 1, (0, 0, 0, 0), (1, 1), (1, 1), 1),      # pointwise, P % 4 == 0 -> dense vectorised path
+    (2, 16, 7, 7, 12, 1, 1, (0, 0, 0, 0), (1, 1), (1, 1), 1),      # pointwise, P = 49 -> gather path
+    (2, 16, 8, 8, 8, 1, 1, (0, 0, 0, 0), (2, 2), (1, 1), 1),       # 1x1 stride-2 downsample
+    (1, 3, 32, 32, 16, 7, 7, (3, 3, 3, 3), (2, 2), (1, 1), 1),     # stem-like, K = 147
+    (1, 2, 14, 14, 2, 3, 3, (2, 2, 2, 2), (1, 1), (2, 2), 1),      # dilation
+    (2, 4, 6, 6, 4, 3, 3, (1, 1, 1, 1), (1, 1), (1, 1), 4),        # depthwise shape through the generic path
+    (1, 40, 9, 9, 70, 3, 3, (1, 1, 1, 1), (1, 1), (1, 1), 1),      # K = 360 > 256: two depth blocks
+    (5, 1, 5, 5, 1, 5, 5, (2, 2, 2, 2), (1, 1), (1, 1), 1),
+    (1, 8, 1, 20, 5, 1, 3, (0, 1, 0, 1), (1, 1), (1, 1), 1),       # 1-D conv expanded to 2-D (conv.rs:142-182)
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_f32_bit_exact(ctx, case):
+    N, Cc, H, W, O, kh, kw, pads, strides, dil, groups = case
+    rng = ref.XorShiftRng(1234)
+    x = rng.f32(N * Cc * H * W).reshape(N, Cc, H, W) - 0.5
+    w = rng.f32(O * (Cc // groups) * kh * kw).reshape(O, Cc // groups, kh, kw) - 0.5
+    b = rng.f32(O) - 0.5
+    want = ref.conv2d_f32(x, w, b, pads=pads, strides=strides, dilations=dil, groups=groups)
+    for prepack in (True, False):
+        bits_equal(gpu_conv(ctx, x, w, b, pads, strides, dil, groups, prepack=prepack), want)
+    res = rng.f32(want.size).reshape(want.shape) - 0.5
+    bits_equal(gpu_conv(ctx, x, w, b, pads, strides, dil, groups, residual=res, relu=True),
+               ref.conv2d_f32(x, w, b, pads=pads, strides=strides, dilations=dil, groups=groups, residual=res, relu=True))
+    bits_equal(gpu_conv(ctx, x, w, None, pads, strides, dil, groups, relu=True),
+               ref.conv2d_f32(x, w, None, pads=pads, strides=strides, dilations=dil, groups=groups, relu=True))
+
+
+def test_conv_f32_reference_literals(ctx):
+    import json, os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_literals.json")))["conv"]
+    k = np.array(g["kernel"], np.float32).reshape(1, 1, 3, 3)
+    x = np.array(g["input"], np.float32).reshape(1, 1, 3, 3)
+    np.testing.assert_allclose(gpu_conv(ctx, x, k, pads=(1, 1, 1, 1)).ravel(), g["expected_same_padding"], atol=1e-4)
+    np.testing.assert_allclose(gpu_conv(ctx, x, k).ravel(), g["expected_no_padding"], atol=1e-4)
+    np.testing.assert_allclose(gpu_conv(ctx, x, k, bias=np.array([1.0], np.float32)).ravel(), g["expected_with_bias_1"], atol=1e-4)
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 56, 3, 1, 1), (256, 64, 56, 1, 1, 0), (128, 128, 28, 3, 1, 1), (512, 256, 28, 1, 2, 0),
+                                   (256, 256, 14, 3, 1, 1), (2048, 512, 7, 1, 1, 0), (512, 512, 7, 3, 1, 1), (64, 3, 224, 7, 2, 3)])
+def test_conv_f32_resnet_layer_shapes_all_variants(ctx, shape):
+    # real ResNet-50 layer geometries at batch 2, every tile variant
+    O, Cc, H, k, s, pad = shape
+    rng = ref.XorShiftRng(77)
+    x = rng.f32(2 * Cc * H * H).reshape(2, Cc, H, H) - 0.5
+    w = (rng.f32(O * Cc * k * k).reshape(O, Cc, k, k) - 0.5) * 0.1
+    b = rng.f32(O) - 0.5
+    want = ref.conv2d_f32(x, w, b, pads=(pad,) * 4, strides=(s, s), relu=True)
+    for v in range(4):
+        bits_equal(gpu_conv(ctx, x, w, b, (pad,) * 4, (s, s), relu=True, variant=v), want)
+
+
+# ------------------------------------------------------------------------------------------ int8
+@pytest.mark.parametrize("adt,bdt", [(np.uint8, np.int8), (np.uint8, np.uint8), (np.int8, np.int8), (np.int8, np.uint8)])
+def test_matmul_integer_bit_exact(ctx, adt, bdt):
+    # src/ops/matmul.rs:1365-1750
+    rng = ref.XorShiftRng(1234)
+    for (m, n, k) in ((1, 1, 1), (5, 7, 3), (16, 33, 64), (70, 130, 300), (64, 64, 128), (3, 1000, 17)):
+        a = (rng.u8(m * k) if adt == np.uint8 else rng.i8(m * k)).reshape(m, k)
+        b = (rng.u8(k * n) if bdt == np.uint8 else rng.i8(k * n)).reshape(k, n)
+        zps = [(None, None), (np.array(3, adt), np.array(5, bdt)),
+               ((rng.u8(m) if adt == np.uint8 else rng.i8(m)), (rng.u8(n) if bdt == np.uint8 else rng.i8(n)))]
+        for a_zp, b_zp in zps:
+            ins = [dev(ctx, a), dev(ctx, b), dev(ctx, a_zp) if a_zp is not None else None, dev(ctx, b_zp) if b_zp is not None else None]
+            got = ops.MatMulInteger().run(ctx, ins)[0].numpy()
+            bits_equal(got, ref.gemm_int8(a, b, a_zp, b_zp))
+    # MatMulIntegerToFloat with scalar and per-column scale (matmul.rs:718-729)
+    a = rng.u8(20 * 48).reshape(20, 48)
+    b = rng.i8(48 * 12, reduced=True).reshape(48, 12)
+    azp, bzp = np.array(7, np.uint8), rng.i8(12, reduced=True)
+    acc = ref.gemm_int8(a, b, azp, bzp)
+    for scale in (np.array(0.02, np.float32), (rng.f32(12) * 0.1).astype(np.float32)):
+        got = ops.MatMulIntegerToFloat().run(ctx, [dev(ctx, a), dev(ctx, b), dev(ctx, azp), dev(ctx, bzp), dev(ctx, scale)])[0].numpy()
+        bits_equal(got, ref.cast_scale(acc, scale))
+
+
+@pytest.mark.parametrize("xdt,wdt", [(np.uint8, np.int8), (np.uint8, np.uint8), (np.int8, np.int8), (np.int8, np.uint8)])
+def test_conv_integer_bit_exact(ctx, xdt, wdt):
+    # src/ops/conv.rs:1370-1527 (all four signedness combos) + padded cases for every pad_mode
+    rng = ref.XorShiftRng(42)
+    for (N, Cc, H, W, O, k, pads, strides, groups) in ((2, 4, 7, 6, 6, 3, (0, 0, 0, 0), (1, 1), 1), (1, 8, 9, 9, 4, 3, (1, 1, 1, 1), (2, 2), 2),
+                                                        (2, 16, 7, 7, 20, 1, (0, 0, 0, 0), (1, 1), 1), (1, 3, 20, 20, 8, 7, (3, 3, 3, 3), (2, 2), 1)):
+        x = (rng.u8(N * Cc * H * W) if xdt == np.uint8 else rng.i8(N * Cc * H * W)).reshape(N, Cc, H, W)
+        wn = O * (Cc // groups) * k * k
+        w = (rng.u8(wn, reduced=True) if wdt == np.uint8 else rng.i8(wn, reduced=True)).reshape(O, Cc // groups, k, k)
+        x_zp = np.array(rng.u8(1)[0] if xdt == np.uint8 else rng.i8(1)[0], xdt)
+        for w_zp in (None, np.array(2, wdt), (rng.u8(O, reduced=True) if wdt == np.uint8 else rng.i8(O, reduced=True))):
+            for pm in (L.PAD_ZERO_POINT, L.PAD_RAW0_I8, L.PAD_RAW0_U8):
+                op = ops.ConvInteger(groups=groups, padding=list(pads), strides=strides, pad_mode=pm)
+                got = op.run(ctx, [dev(ctx, x), dev(ctx, w), dev(ctx, x_zp), dev(ctx, w_zp) if w_zp is not None else None])[0].numpy()
+                want = ref.conv2d_int8(x, w, x_zp=int(x_zp), w_zp=w_zp, pads=pads, strides=strides, groups=groups, pad_mode=pm)
+                bits_equal(got, want)
+
+
+def test_conv_integer_to_float_fused_epilogue(ctx):
+    # test_conv_integer_to_float (conv.rs:1530-1604) + the ort-quantized graph tail: Add(bias) -> Add(residual) -> Relu
+    rng = ref.XorShiftRng(8)
+    x = rng.u8(2 * 8 * 10 * 10).reshape(2, 8, 10, 10)
+    w = rng.i8(12 * 8 * 3 * 3, reduced=True).reshape(12, 8, 3, 3)
+    x_zp, scale = np.array(120, np.uint8), np.array(0.0123, np.float32)
+    bias = rng.f32(12) - 0.5
+    acc = ref.conv2d_int8(x, w, x_zp=120, pads=(1, 1, 1, 1), pad_mode=ref.PAD_RAW0_I8)
+    f = ref.cast_scale(acc, scale)
+    res = rng.f32(f.size).reshape(f.shape) - 0.5
+    op = ops.ConvIntegerToFloat(ops.ConvInteger(padding=[1, 1, 1, 1]))
+    got = op.run(ctx, [dev(ctx, x), dev(ctx, w), dev(ctx, x_zp), None, dev(ctx, scale)])[0].numpy()
+    bits_equal(got, f)
+    op = ops.ConvIntegerToFloat(ops.ConvInteger(padding=[1, 1, 1, 1]), fuse_relu=True)
+    got = op.run(ctx, [dev(ctx, x), dev(ctx, w), dev(ctx, x_zp), None, dev(ctx, scale), dev(ctx, bias), dev(ctx, res)])[0].numpy()
+    want = ref.relu(ref.add(f + bias[None, :, None, None], res))
+    bits_equal(got, want)
+
+
+def test_dynamic_quantize_linear_bit_exact(ctx):
+    rng = ref.XorShiftRng(3)
+    for x in (rng.f32(100000) * 6 - 3, rng.f32(4097), -rng.f32(1001), np.zeros(64, np.float32), np.array([-234.56], np.float32),
+              np.arange(-0.1, 0.1, 0.001, dtype=np.float32), (rng.f32(3 * 64 * 28 * 28) - 0.2).reshape(3, 64, 28, 28)):
+        y, s, z = ops.DynamicQuantizeLinear().run(ctx, [dev(ctx, x)])
+        qy, qs, qz = ref.dynamic_quantize_linear(x)
+        assert s.numpy().reshape(()) == qs and z.numpy().reshape(()) == qz
+        bits_equal(y.numpy(), qy)
+    y, s, z = ops.DynamicQuantizeLinear().run(ctx, [dev(ctx, np.zeros((0,), np.float32))])
+    assert float(s.numpy()) == 1.0 and int(z.numpy()) == 0
+
+
+def test_int8_resnet_block_chain(ctx):
+    # DQL -> ConvIntegerToFloat(+bias, relu) chained on device: scale = x_scale * w_scale computed by a device Mul
+    rng = ref.XorShiftRng(17)
+    x = (rng.f32(2 * 16 * 14 * 14) - 0.3).reshape(2, 16, 14, 14)
+    w = rng.i8(24 * 16 * 3 * 3, reduced=True).reshape(24, 16, 3, 3)
+    w_scale, bias = np.array(0.004, np.float32), rng.f32(24) - 0.5
+    xq, xs, xz = ops.DynamicQuantizeLinear().run(ctx, [dev(ctx, x)])
+    sc = ops.Mul().run(ctx, [xs.reshape(1), dev(ctx, w_scale.reshape(1))])[0]
+    got = ops.ConvIntegerToFloat(ops.ConvInteger(padding=[1, 1, 1, 1]), fuse_relu=True).run(
+        ctx, [xq, dev(ctx, w), xz, None, sc.reshape(()), dev(ctx, bias)])[0].numpy()
+    q, s, z = ref.dynamic_quantize_linear(x)
+    acc = ref.conv2d_int8(q, w, x_zp=int(z), pads=(1, 1, 1, 1), pad_mode=ref.PAD_RAW0_I8)
+    want = ref.relu(ref.cast_scale(acc, np.float32(s * w_scale)) + bias[None, :, None, None])
+    bits_equal(got, want)
+
+
+# ------------------------------------------------------------------------------------------ row-wise / element-wise / pooling
+@pytest.mark.parametrize("cols", [1, 3, 6, 16, 17, 64, 100, 128, 129, 384, 768, 1000, 1024, 1500, 3000])
+def test_softmax_bit_exact_avx512_order(ctx, cols):
+    rng = ref.XorShiftRng(cols)
+    x = (rng.f32(37 * cols).reshape(37, cols) - 0.5) * 8
+    got = ops.Softmax(axis=-1).run(ctx, [dev(ctx, x)])[0].numpy()
+    bits_equal(got, ref.softmax(x, lanes=16))
+    np.testing.assert_allclose(got, ref.softmax(x, lanes=4), rtol=1e-6, atol=0)
+
+
+def test_add_softmax_bert_mask(ctx):
+    rng = ref.XorShiftRng(2)
+    qk = (rng.f32(2 * 12 * 128 * 128).reshape(2, 12, 128, 128) - 0.5) * 4
+    mask = np.where(rng.f32(2 * 128).reshape(2, 1, 1, 128) > 0.2, 0.0, -np.inf).astype(np.float32)
+    got = ops.AddSoftmax(flush_nans_to_zero=True).run(ctx, [dev(ctx, qk), dev(ctx, mask)])[0].numpy()
+    bits_equal(got, ref.softmax(qk, addend=mask, add_div=12 * 128, add_mod=2, flush_nan=True))
+    m2 = rng.f32(2 * 128 * 128).reshape(2, 1, 128, 128)
+    # [B,1,S,S] mask: per-batch addend rows
+    want = np.stack([ref.softmax(qk[b], addend=m2[b], add_div=1, add_mod=128) for b in range(2)])
+    got = np.stack([ops.AddSoftmax().run(ctx, [dev(ctx, qk[b:b + 1]), dev(ctx, m2[b:b + 1])])[0].numpy()[0] for b in range(2)])
+    bits_equal(got, want)
+    # all -inf rows: NaN unless flushed (attention.rs:1088-1106)
+    ninf = np.full((1, 3), -np.inf, np.float32)
+    assert np.isnan(ops.AddSoftmax().run(ctx, [dev(ctx, ninf), dev(ctx, np.zeros((1, 3), np.float32))])[0].numpy()).all()
+    assert ops.AddSoftmax(flush_nans_to_zero=True).run(ctx, [dev(ctx, ninf), dev(ctx, np.zeros((1, 3), np.float32))])[0].numpy().tolist() == [[0, 0, 0]]
+
+
+@pytest.mark.parametrize("cols", [2, 10, 64, 100, 256, 768, 1024, 2000])
+def test_layer_norm_bit_exact_avx512_order(ctx, cols):
+    rng = ref.XorShiftRng(cols + 1)
+    x = (rng.f32(29 * cols).reshape(29, cols) - 0.5) * 3
+    g, b = rng.f32(cols) + 0.5, rng.f32(cols) - 0.5
+    for gamma, beta, gs, bs in ((g, b, 1.0, 0.0), (g, None, 1.0, 0.0), (None, None, 2.0, 0.5)):
+        ins = [dev(ctx, x), dev(ctx, gamma) if gamma is not None else dev(ctx, np.array(gs, np.float32)),
+               (dev(ctx, beta) if beta is not None else (dev(ctx, np.array(bs, np.float32)) if bs else None))]
+        got = ops.LayerNormalization(axis=-1).run(ctx, ins)[0].numpy()
+        bits_equal(got, ref.layer_norm(x, gamma, beta, gs, bs, lanes=16))
+        np.testing.assert_allclose(got, ref.layer_norm(x, gamma, beta, gs, bs, lanes=4), rtol=2e-5, atol=2e-6)
+
+
+def test_layer_norm_reference_literals(ctx):
+    import json, os
+    for c in json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_literals.json")))["layer_norm"]["cases"]:
+        x = np.array(c["input"], np.float32)
+        if "scale" not in c:
+            continue
+        got = ops.LayerNormalization(axis=-1).run(ctx, [dev(ctx, x), dev(ctx, np.array(c["scale"], np.float32)), dev(ctx, np.array(c["bias"], np.float32))])[0].numpy()
+        np.testing.assert_allclose(got, c["expected"], atol=1e-4)
+
+
+def test_elementwise_bit_exact(ctx):
+    rng = ref.XorShiftRng(9)
+    x = np.concatenate([(rng.f32(100003) - 0.5) * 12, np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-40, -1e-40, 88.0, -88.0], np.float32)])
+    bits_equal(ops.Gelu().run(ctx, [dev(ctx, x)])[0].numpy(), ref.gelu(x))
+    bits_equal(ops.Erf().run(ctx, [dev(ctx, x)])[0].numpy(), ref.erf(x))
+    r = ops.Relu().run(ctx, [dev(ctx, x)])[0].numpy()
+    bits_equal(r, ref.relu(x))
+    assert r[-5] == 0.0  # relu(NaN) == 0 (f32::max semantics, unary_elementwise.rs:611-613)
+    y = (rng.f32(x.size) - 0.5).astype(np.float32)
+    bits_equal(ops.Add().run(ctx, [dev(ctx, x), dev(ctx, y)])[0].numpy(), x + y)
+    a4 = rng.f32(2 * 6 * 5 * 5).reshape(2, 6, 5, 5)
+    cb = rng.f32(6).reshape(1, 6, 1, 1)
+    bits_equal(ops.Add().run(ctx, [dev(ctx, a4), dev(ctx, cb)])[0].numpy(), a4 + cb)
+    bits_equal(ops.Add().run(ctx, [dev(ctx, a4), dev(ctx, a4[0, 0])])[0].numpy(), a4 + a4[0, 0])
+    sc, bi, me, va = rng.f32(6) + 0.5, rng.f32(6), rng.f32(6), rng.f32(6) + 0.1
+    bits_equal(ops.BatchNormalization().run(ctx, [dev(ctx, a4), dev(ctx, sc), dev(ctx, bi), dev(ctx, me), dev(ctx, va)])[0].numpy(),
+               ref.batch_norm(a4, sc, bi, me, va))
+    acc = rng.i32(1000).reshape(10, 100)
+    for s in (np.array([0.37], np.float32), rng.f32(100)):
+        out = DeviceTensor(ctx, acc.shape, np.float32)
+        ctx.call("rten_hip_cast_scale", acc.size, dev(ctx, acc).vp, dev(ctx, s).vp, s.size, out.vp)
+        bits_equal(out.numpy(), ref.cast_scale(acc, s))
+
+
+def test_pooling_bit_exact(ctx):
+    import json, os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_literals.json")))["pool"]
+    x4 = np.array(g["input4"], np.float32).reshape(1, 1, 4, 4)
+    for c in g["max"]:
+        np.testing.assert_allclose(ops.MaxPool(c["kernel"], strides=c["strides"]).run(ctx, [dev(ctx, x4)])[0].numpy()[0, 0], c["expected"], rtol=1e-6)
+    for c in g["average"]:
+        np.testing.assert_allclose(ops.AveragePool(c["kernel"], strides=c["strides"]).run(ctx, [dev(ctx, x4)])[0].numpy()[0, 0], c["expected"], rtol=1e-5)
+    rng = ref.XorShiftRng(4)
+    x = rng.f32(3 * 5 * 23 * 19).reshape(3, 5, 23, 19) - 0.5
+    for k, s, p, ceil in (((3, 3), (2, 2), (1, 1, 1, 1), False), ((2, 2), (2, 2), (0, 0, 0, 0), True), ((3, 2), (1, 2), (1, 0, 1, 1), False)):
+        bits_equal(ops.MaxPool(k, padding=list(p), strides=s, ceil_mode=ceil).run(ctx, [dev(ctx, x)])[0].numpy(), ref.max_pool(x, k, s, p, ceil))
+        for cip in (False, True):
+            bits_equal(ops.AveragePool(k, padding=list(p), strides=s, ceil_mode=ceil, count_include_pad=cip).run(ctx, [dev(ctx, x)])[0].numpy(),
+                       ref.average_pool(x, k, s, p, cip, ceil))
+    for inner in ((7, 7), (1, 1), (4, 4), (9, 9), (30, 30)):
+        xg = rng.f32(2 * 10 * inner[0] * inner[1]).reshape(2, 10, *inner)
+        bits_equal(ops.GlobalAveragePool().run(ctx, [dev(ctx, xg)])[0].numpy(), ref.global_average_pool(xg, lanes=16))
+
+
+def test_sdpa_bit_exact(ctx):
+    rng = ref.XorShiftRng(21)
+    for (B, H, S, D) in ((2, 3, 16, 8), (2, 12, 128, 64), (1, 2, 40, 24)):
+        q = rng.f32(B * H * S * D).reshape(B, H, S, D) - 0.5
+        k = rng.f32(B * H * S * D).reshape(B, H, S, D) - 0.5
+        v = rng.f32(B * H * S * D).reshape(B, H, S, D) - 0.5
+        mask = np.where(rng.f32(B * S).reshape(B, 1, 1, S) > 0.3, 0.0, -np.inf).astype(np.float32)
+        for m in (None, mask):
+            ins = [dev(ctx, q), dev(ctx, k), dev(ctx, v)] + ([dev(ctx, m)] if m is not None else [])
+            bits_equal(ops.Attention().run(ctx, ins)[0].numpy(), ref.sdpa(q, k, v, mask=m, lanes=16))
+
+
+# ------------------------------------------------------------------------------------------ end to end
+def test_resnet50_end_to_end_bit_exact_and_graph_replay(ctx):
+    from oracle import models as omodels
+    from rten_amd.models import resnet50
+    w = resnet50.make_weights()
+    net = resnet50.ResNet50(ctx, batch=2, weights=w)
+    net.upload_weights()
+    x = ref.XorShiftRng(1234).f32(2 * 3 * 224 * 224).reshape(2, 3, 224, 224)  # U[0,1) like rten-cli (input_generator.rs:139-144)
+    net.x.upload(x)
+    net.forward()
+    logits = net.logits.numpy()
+    want, acts = omodels.resnet50_forward(net.specs, w, x, return_activations=True)
+    bits_equal(net.bufs[net.specs[-1]["dst"]].numpy().reshape(acts[net.specs[-1]["dst"]].shape), acts[net.specs[-1]["dst"]])
+    bits_equal(logits, want)
+    assert np.array_equal(np.argsort(-logits, 1)[:, :5], np.argsort(-want, 1)[:, :5])
+    # hipGraph replay == eager
+    net.capture()
+    net.logits.upload(np.zeros_like(logits))
+    net.run()
+    bits_equal(net.logits.numpy(), want)
+    # autotuned variants leave the result unchanged
+    net.graph = None
+    net.autotune(reps=1)
+    net.forward()
+    bits_equal(net.logits.numpy(), want)
+
+
+def test_resnet50_batch32_batch_independence(ctx):
+    # BASELINE config 2 at full size: every image of a batch-32 run equals the oracle's batch-1 run of that image
+    from oracle import models as omodels
+    from rten_amd.models import resnet50
+    w = resnet50.make_weights()
+    net = resnet50.ResNet50(ctx, batch=32, weights=w)
+    net.upload_weights()
+    x = ref.XorShiftRng(99).f32(32 * 3 * 224 * 224).reshape(32, 3, 224, 224)
+    net.x.upload(x)
+    net.forward()
+    logits = net.logits.numpy()
+    assert np.isfinite(logits).all()
+    for i in (0, 13, 31):
+        bits_equal(logits[i:i + 1], omodels.resnet50_forward(net.specs, w, x[i:i + 1]) if False else omodels.resnet50_forward(net.specs, w, np.concatenate([x[i:i + 1], x[i:i + 1]]))[:1])
