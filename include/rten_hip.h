@@ -111,6 +111,11 @@ typedef struct {
     int64_t ldc;        /* C row stride; C columns are contiguous */
     int32_t batch;      /* >= 1; batched_gemm_uninit */
     int64_t a_bs, b_bs, c_bs; /* batch strides in elements; 0 broadcasts that operand */
+    /* optional second (inner) batch level: batch index z -> (z / batch_inner, z % batch_inner), e.g.
+     * (image, head) for attention on [B,S,H,D] tensors without materialising transposes
+     * (TransformInputs / TransposeFusion, src/optimize/fusions.rs:1066).  batch_inner <= 1 disables it. */
+    int32_t batch_inner;
+    int64_t a_bsi, b_bsi, c_bsi;
     float alpha, beta;  /* C = alpha*A.B + beta*C ; beta == 0 => C is never read */
     int32_t bias_kind;  /* RTEN_HIP_BIAS_* */
     int32_t act;        /* RTEN_HIP_ACT_* applied after bias (fused follow-on op) */
@@ -228,12 +233,25 @@ int32_t rten_hip_average_pool2d_f32(rten_hip_ctx *ctx, const rten_hip_pool2d_des
 int32_t rten_hip_global_average_pool_f32(rten_hip_ctx *ctx, int64_t nc, int32_t inner, const float *x, float *y);
 
 /* ---- fused attention: sdpa_head / sdpa_multi_head, src/ops/attention.rs:518-626 ----
- * q [bh, s, d], k [bh, t, d], v [bh, t, dv] contiguous; mask NULL or additive f32 with
- * mask row for (i in bh, query s) = mask + (i / mask_bh_div) * mask_batch_stride + s * mask_row_stride. */
-int32_t rten_hip_sdpa_f32(rten_hip_ctx *ctx, int32_t bh, int32_t s, int32_t t, int32_t d, int32_t dv,
-                          const float *q, const float *k, const float *v, const float *mask,
-                          int32_t mask_bh_div, int64_t mask_batch_stride, int64_t mask_row_stride, float scale,
-                          float *out);
+ * out[b,h] = softmax(scale * Q[b,h] K[b,h]^T + mask[b]) V[b,h].  Q/K/V/out are addressed by element
+ * strides (batch, head, row; the last dim is contiguous) so both [B,H,S,D] tensors and the
+ * [B,S,H*D] projection outputs of BERT (head = column block) are read in place.
+ * mask: NULL, or additive f32 [B,1,1,T] (mask_row_stride = 0) / [B,1,S,T] (mask_row_stride = T). */
+typedef struct {
+    int32_t batch, heads, s, t, d, dv;
+    int64_t q_bs, q_hs, q_rs;
+    int64_t k_bs, k_hs, k_rs;
+    int64_t v_bs, v_hs, v_rs;
+    int64_t o_bs, o_hs, o_rs;
+    int64_t mask_batch_stride, mask_row_stride;
+    float scale;
+} rten_hip_sdpa_desc;
+int32_t rten_hip_sdpa_f32(rten_hip_ctx *ctx, const rten_hip_sdpa_desc *desc, const float *q, const float *k,
+                          const float *v, const float *mask, float *out);
+
+/* ---- Gather of rows (embedding lookup; src/ops/gather.rs Gather axis 0): out[i,:] = table[ids[i],:] ---- */
+int32_t rten_hip_gather_rows_f32(rten_hip_ctx *ctx, int64_t n_ids, int32_t row_len, int32_t table_rows,
+                                 const float *table, const int32_t *ids, float *out);
 
 /* ---- tuning: per-shape kernel-variant selection by measurement at load time ----
  * variant < 0 restores the built-in heuristic.  Used by the harness's autotuner. */

@@ -1,69 +1,64 @@
 // Scaled dot-product attention: sdpa_head / sdpa_multi_head, src/ops/attention.rs:518-626.
 //
-//     out[i] = softmax(scale * Q[i] K[i]^T + mask) V[i]          for every (batch, head) i
+//     out[b,h] = softmax(scale * Q[b,h] K[b,h]^T + mask[b]) V[b,h]
 //
 // Same three steps as the reference (gemm with alpha = scale, row softmax with NaN flush, gemm), but
 // batched over all (batch, head) pairs: two batched MFMA GEMM launches + one wave-per-row softmax
-// launch, with the [bh, s, t] score tensor kept in a device scratch buffer (L2/MALL resident at
-// BERT sizes: 32*12*128*128*4 B = 25 MB).  Because each step reuses the bit-exact GEMM / softmax
-// kernels, the result is bit-identical to the oracle's sdpa.
+// launch, with the [B*H, S, T] score tensor kept in a device scratch buffer (L2/MALL resident at BERT
+// sizes: 32*12*128*128*4 B = 25 MB).  Q/K/V/out are addressed through (batch, head, row) strides, so
+// BERT's [B*S, H*D] projection outputs are consumed and produced in place -- the Reshape/Transpose
+// nodes of the ONNX graph become stride arithmetic, as TransposeFusion does on the CPU
+// (src/optimize/fusions.rs:1066).  Each step reuses the bit-exact GEMM / softmax kernels, so the result
+// is bit-identical to the oracle's sdpa.
 #include "internal.h"
 
-RTEN_EXPORT int32_t rten_hip_sdpa_f32(rten_hip_ctx *ctx, int32_t bh, int32_t s, int32_t t, int32_t d, int32_t dv,
-                                      const float *q, const float *k, const float *v, const float *mask,
-                                      int32_t mask_bh_div, int64_t mask_batch_stride, int64_t mask_row_stride,
-                                      float scale, float *out) {
+RTEN_EXPORT int32_t rten_hip_sdpa_f32(rten_hip_ctx *ctx, const rten_hip_sdpa_desc *d, const float *q, const float *k,
+                                      const float *v, const float *mask, float *out) {
     RTEN_CHECK_CTX(ctx);
-    if (bh < 0 || s < 0 || t < 0 || d < 0 || dv < 0) return RTEN_HIP_ERR_INVALID_VALUE;
-    if (bh == 0 || s == 0 || dv == 0) return RTEN_HIP_OK;
+    if (!d) return RTEN_HIP_ERR_INVALID_VALUE;
+    if (d->batch < 0 || d->heads < 0 || d->s < 0 || d->t < 0 || d->d < 0 || d->dv < 0) return RTEN_HIP_ERR_INVALID_VALUE;
+    const long long bh = (long long)d->batch * d->heads;
+    if (bh == 0 || d->s == 0 || d->dv == 0) return RTEN_HIP_OK;
     if (!q || !k || !v || !out) return RTEN_HIP_ERR_INVALID_VALUE;
-    if (mask && (mask_bh_div <= 0 || (mask_row_stride != 0 && mask_row_stride != t) ||
-                 (mask_batch_stride != (mask_row_stride ? (int64_t)s * t : (int64_t)t))))
+    if (mask && ((d->mask_row_stride != 0 && d->mask_row_stride != d->t) ||
+                 d->mask_batch_stride != (d->mask_row_stride ? (int64_t)d->s * d->t : (int64_t)d->t)))
         return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "sdpa: mask must be [B,1,1,T] or [B,1,S,T] contiguous");
-    const size_t score_bytes = (size_t)bh * s * (size_t)t * sizeof(float);
+    const size_t score_bytes = (size_t)bh * d->s * (size_t)d->t * sizeof(float);
     float *scores = (float *)rten_scratch(ctx, score_bytes + 256);
     if (!scores) return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "sdpa: scratch allocation failed (warm up before capture)");
-    scores += 64; // first 256 B of the scratch are reserved for the DQL workspace
+    scores += 64; // first 256 B of the scratch are the DQL min/max words
 
     rten_hip_gemm_desc g = {};
     // scores = scale * Q K^T   (attention.rs:533-544)
-    g.m = s; g.n = t; g.k = d;
-    g.a_rs = d; g.a_cs = 1; g.b_rs = 1; g.b_cs = d; g.ldc = t;
-    g.batch = bh; g.a_bs = (int64_t)s * d; g.b_bs = (int64_t)t * d; g.c_bs = (int64_t)s * t;
-    g.alpha = scale; g.beta = 0.f;
+    g.m = d->s; g.n = d->t; g.k = d->d;
+    g.a_rs = d->q_rs; g.a_cs = 1; g.b_rs = 1; g.b_cs = d->k_rs; g.ldc = d->t;
+    g.batch = (int32_t)bh; g.batch_inner = d->heads;
+    g.a_bs = d->q_bs; g.a_bsi = d->q_hs; g.b_bs = d->k_bs; g.b_bsi = d->k_hs;
+    g.c_bs = (int64_t)d->heads * d->s * d->t; g.c_bsi = (int64_t)d->s * d->t;
+    g.alpha = d->scale; g.beta = 0.f;
     int32_t rc = rten_hip_gemm_f32(ctx, &g, q, k, nullptr, scores);
     if (rc) return rc;
-    // softmax(score_mod(row)) with NaN flush (attention.rs:546-552).  Row r = (i*s + qi).
-    if (t > 0) {
-        int64_t add_div = 1, add_mod = 1;
-        if (mask) {
-            if (mask_row_stride) { // [B,1,S,T]: mask row = (i / div) * s + qi  -> not a pure div/mod of r unless div == 1
-                if (mask_bh_div == 1) { add_div = 1; add_mod = (int64_t)bh * s; }
-                else {
-                    // expand per head: handled by launching one softmax per batch entry
-                    const int heads = mask_bh_div, batches = bh / heads;
-                    for (int b = 0; b < batches; b++) {
-                        rc = rten_hip_softmax_f32(ctx, (int64_t)heads * s, t, scores + (int64_t)b * heads * s * t,
-                                                  mask + (int64_t)b * mask_batch_stride, 1, s, 1,
-                                                  scores + (int64_t)b * heads * s * t);
-                        if (rc) return rc;
-                    }
-                    goto pv;
-                }
-            } else { // [B,1,1,T]: mask row = r / (heads*s)
-                add_div = (int64_t)mask_bh_div * s;
-                add_mod = bh / mask_bh_div;
+    // row softmax with NaN flush (attention.rs:546-552); score row r = ((b*H + h)*S + qi)
+    if (d->t > 0) {
+        if (mask && d->mask_row_stride) { // [B,1,S,T]: addend row = b*S + qi -> one launch per image
+            for (int b = 0; b < d->batch; b++) {
+                float *sb = scores + (long long)b * d->heads * d->s * d->t;
+                rc = rten_hip_softmax_f32(ctx, (int64_t)d->heads * d->s, d->t, sb, mask + (long long)b * d->mask_batch_stride, 1,
+                                          d->s, 1, sb);
+                if (rc) return rc;
             }
+        } else { // no mask, or [B,1,1,T]: addend row = r / (H*S)
+            rc = rten_hip_softmax_f32(ctx, bh * d->s, d->t, scores, mask, (int64_t)d->heads * d->s, d->batch, 1, scores);
+            if (rc) return rc;
         }
-        rc = rten_hip_softmax_f32(ctx, (int64_t)bh * s, t, scores, mask, add_div, add_mod, 1, scores);
-        if (rc) return rc;
     }
-pv:
     // out = P V   (attention.rs:554-561)
     g = {};
-    g.m = s; g.n = dv; g.k = t;
-    g.a_rs = t; g.a_cs = 1; g.b_rs = dv; g.b_cs = 1; g.ldc = dv;
-    g.batch = bh; g.a_bs = (int64_t)s * t; g.b_bs = (int64_t)t * dv; g.c_bs = (int64_t)s * dv;
+    g.m = d->s; g.n = d->dv; g.k = d->t;
+    g.a_rs = d->t; g.a_cs = 1; g.b_rs = d->v_rs; g.b_cs = 1; g.ldc = d->o_rs;
+    g.batch = (int32_t)bh; g.batch_inner = d->heads;
+    g.a_bs = (int64_t)d->heads * d->s * d->t; g.a_bsi = (int64_t)d->s * d->t;
+    g.b_bs = d->v_bs; g.b_bsi = d->v_hs; g.c_bs = d->o_bs; g.c_bsi = d->o_hs;
     g.alpha = 1.f; g.beta = 0.f;
     return rten_hip_gemm_f32(ctx, &g, scores, v, nullptr, out);
 }

@@ -127,6 +127,7 @@ RTEN_EXPORT int32_t rten_hip_destroy(rten_hip_ctx *ctx) {
         for (hipEvent_t e : t)
             if (e) hipEventDestroy(e);
     if (ctx->scratch) hipFree(ctx->scratch);
+    for (auto &kv : ctx->luts) hipFree(kv.second);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return RTEN_HIP_OK;

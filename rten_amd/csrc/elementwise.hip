@@ -116,6 +116,22 @@ __global__ __launch_bounds__(EW_THREADS) void batch_norm_kernel(int64_t total, i
     }
 }
 
+// out[i, :] = table[ids[i], :]  (Gather axis 0; out-of-range ids are clamped after host validation)
+__global__ __launch_bounds__(EW_THREADS) void gather_rows_kernel(int64_t n_ids, int row_len, int table_rows,
+                                                                 const float *__restrict__ table,
+                                                                 const int32_t *__restrict__ ids, float *__restrict__ out) {
+    const int64_t total = n_ids * row_len;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t r = i / row_len;
+        const int c = (int)(i - r * row_len);
+        int id = ids[r];
+        if (id < 0) id += table_rows; // ONNX Gather: negative indices count from the end
+        id = id < 0 ? 0 : (id >= table_rows ? table_rows - 1 : id);
+        out[i] = table[(int64_t)id * row_len + c];
+    }
+}
+
 inline bool al16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 
 template <int OP>
@@ -207,5 +223,18 @@ RTEN_EXPORT int32_t rten_hip_batch_norm_f32(rten_hip_ctx *ctx, int32_t n, int32_
     hipLaunchKernelGGL(batch_norm_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ctx->stream, total, c, inner, x,
                        scale, bias, mean, var, epsilon, y);
     RTEN_LAUNCH_CHECK(ctx, "batch_norm_kernel");
+    return RTEN_HIP_OK;
+}
+
+RTEN_EXPORT int32_t rten_hip_gather_rows_f32(rten_hip_ctx *ctx, int64_t n_ids, int32_t row_len, int32_t table_rows,
+                                             const float *table, const int32_t *ids, float *out) {
+    RTEN_CHECK_CTX(ctx);
+    if (n_ids < 0 || row_len < 0 || table_rows <= 0) return RTEN_HIP_ERR_INVALID_VALUE;
+    if (n_ids == 0 || row_len == 0) return RTEN_HIP_OK;
+    if (!table || !ids || !out) return RTEN_HIP_ERR_INVALID_VALUE;
+    ProfScope ps(ctx, "gather_rows_f32", 0.0, 8.0 * n_ids * row_len);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(ew_blocks(n_ids * row_len)), dim3(EW_THREADS), 0, ctx->stream, n_ids,
+                       row_len, table_rows, table, ids, out);
+    RTEN_LAUNCH_CHECK(ctx, "gather_rows_kernel");
     return RTEN_HIP_OK;
 }

@@ -15,13 +15,22 @@
 //   * C is written straight into NCHW (row m, two-level column n), with bias / residual Add / Relu /
 //     Gelu fused into the epilogue.
 //
-// MI355X mapping: v_mfma_f32_32x32x2_f32 (exact f32, 64 FLOP/clk/SIMD == the f32 peak, 157 TF).  256
-// threads = 4 waves per workgroup, each wave owns TM x TN accumulator tiles of 32x32.  A and B tiles
-// are staged through LDS k-major ([BK][BM+pad], [BK][BN+pad]) so the MFMA operand fetch
-// (lane -> row k0 + lane/32, column lane%32) is a conflict-free ds_read_b32; tiles are double
-// buffered and the next tile's global loads are issued before the current tile's MFMAs so that
-// HBM/L2 latency hides under the matrix pipe (one barrier per k-tile).  Workgroup ids are remapped
-// so that each XCD (private L2) owns a contiguous range of tiles that share the same B panel.
+// MI355X mapping
+//   * v_mfma_f32_32x32x2_f32 (exact f32, 64 FLOP/clk/SIMD == the f32 peak, 157 TF).  256 threads = 4
+//     waves per workgroup, each wave owns TM x TN accumulator tiles of 32x32.
+//   * A and B tiles are staged through LDS k-major ([BK][BM+pad], [BK][BN+pad]) so the MFMA operand
+//     fetch (lane -> row k0 + lane/32, column lane%32) is a conflict-free ds_read_b32; tiles are double
+//     buffered, the next tile's global loads are issued before the current tile's MFMAs (one barrier
+//     per k-tile).
+//   * The f32 matrix pipe is slow (64 cycles per MFMA), so the kernel is bound by how few OTHER
+//     instructions each wave issues per MFMA.  All global loads are raw buffer loads
+//     (buffer_load_dword/dwordx4 ... offen) whose per-lane byte offsets are loop invariant; the k-tile
+//     advance rides in the scalar soffset operand, and out-of-tile / out-of-image / k-tail lanes point
+//     at an out-of-range offset so the hardware returns 0 -- no exec-mask branches, no 64-bit address
+//     arithmetic and no selects in the K loop.  The im2col (c, ky, kx) decomposition comes from a small
+//     per-geometry lookup table read with scalar loads (the k row of a wave is uniform).
+//   * Workgroup ids are remapped so that each XCD (private L2) owns a contiguous range of tiles that
+//     share the same B panel.
 //
 // Numerics: accumulation order is the reference's, exactly: k-ordered FMA chain per depth block of
 // kc = 256 starting from 0, blocks combined with separate adds, bias added after the first block
@@ -35,9 +44,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int BK = 16;            // k-tile depth
+constexpr int BK = 16;             // k-tile depth
 constexpr int KC_TILES = 256 / BK; // reference depth block (kc = 256 for f32)
 constexpr int NTHREADS = 256;
+constexpr unsigned OOB = 0x80000000u; // byte offset beyond every buffer (< 2 GiB): buffer loads return 0
 
 enum ALoad { A_M4 = 0, A_K4 = 1, A_SCALAR = 2 };
 enum BLoad { B_N4 = 0, B_K4 = 1, B_SCALAR = 2, B_IM2COL = 3 };
@@ -48,25 +58,22 @@ struct GemmArgs {
     float *C;
     const float *bias;
     const float *res;
+    const int2 *lut; // im2col: per k {element offset c*HW + ky*dy*W + kx*dx, (ky*dy) | (kx*dx) << 16}; padded rows fail the bounds test
     int M, N, K;
     long long a_rs, a_cs, a_bs;       // A[z*a_bs + m*a_rs + k*a_cs]
     long long b_rs, b_cs, b_ns, b_bs; // B[z*b_bs + k*b_rs + (n/Pn)*b_ns + (n%Pn)*b_cs]
     long long c_rs, c_ns, c_bs;       // C[z*c_bs + m*c_rs + (n/Pn)*c_ns + (n%Pn)]
     long long bias_bs;
+    long long a_bsi, b_bsi, c_bsi;    // inner batch strides
+    unsigned a_bytes, b_bytes;        // extent (bytes) of one batch slice of A / B from its base: buffer num_records
+    int batch_inner;                  // z -> (z / batch_inner, z % batch_inner); <= 1: single level
     int Pn;
     float alpha, beta;
     int bias_kind, act;
     int tiles_m, tiles_n;
     int a_dir_m, b_dir_n; // scalar loaders: lanes run along m / n (1) or along k (0)
-    // im2col geometry (B_IM2COL): image z/group base = B + z*b_bs + (n/Pn)*b_ns
-    int H, W, HW, KHW, KW, OW, sy, sx, dy, dx, pt, pl;
-    unsigned magic_khw, magic_kw;
+    int H, W, OW, sy, sx, pt, pl; // im2col geometry
 };
-
-__device__ __forceinline__ unsigned fastdiv(unsigned n, unsigned magic, unsigned d) {
-    // exact for n*d < 2^32 (magic = ceil(2^32 / d)); d == 1 is handled by the caller passing magic = 0
-    return magic ? __umulhi(n, magic) : n;
-}
 
 __device__ __forceinline__ float combine(float t, float c, float alpha, float beta) {
     // the four store forms of the reference micro-kernel, simd_generic.rs:378-414
@@ -75,12 +82,22 @@ __device__ __forceinline__ float combine(float t, float c, float alpha, float be
     return vm::fma(t, alpha, c * beta);
 }
 
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+
 template <int BM, int BN, int AL, int BL, bool MULTI_KC>
 __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_kernel(const GemmArgs p) {
     constexpr int WM = 2, WN = 2;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int LDA = BM + 4, LDB = BN + 4;
     constexpr int A_ELEMS = BK * BM / NTHREADS, B_ELEMS = BK * BN / NTHREADS; // per-thread elements per tile
+    constexpr int NA = (AL == A_SCALAR) ? A_ELEMS : A_ELEMS / 4;              // loads per thread per tile
+    constexpr int NB = (BL == B_SCALAR || BL == B_IM2COL) ? B_ELEMS : B_ELEMS / 4;
+    static_assert((NTHREADS / BN) * B_ELEMS == BK, "im2col row mapping must cover the k-tile");
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA + LDB)];
     float *const As0 = smem;
     float *const Bs0 = smem + 2 * BK * LDA;
@@ -101,189 +118,172 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_kernel(const GemmArgs p
     const int bm = tile % p.tiles_m, bn = tile / p.tiles_m;
     const int m0 = bm * BM, n0 = bn * BN;
 
-    const float *__restrict__ Ab = p.A + (long long)z * p.a_bs;
-    const float *__restrict__ Bb = p.B + (long long)z * p.b_bs;
+    int zo = z, zi = 0;
+    if (p.batch_inner > 1) { zo = z / p.batch_inner; zi = z - zo * p.batch_inner; }
+    const float *Ab = p.A + (long long)zo * p.a_bs + (long long)zi * p.a_bsi;
+    const float *Bb = p.B + (long long)zo * p.b_bs + (long long)zi * p.b_bsi;
+    const long long c_zoff = (long long)zo * p.c_bs + (long long)zi * p.c_bsi;
+    // wave-uniform buffer descriptors (kernarg / blockIdx derived only -> SGPRs, no waterfall loops)
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)Ab, 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void *)Bb, 0, (int)p.b_bytes, 0x00020000);
 
-    // ---- per-thread loader state (fixed across the K loop)
-    // A
-    [[maybe_unused]] long long a_off[A_ELEMS];   // scalar path: base offset of element j (without k-tile advance)
-    [[maybe_unused]] bool a_ok[A_ELEMS];
-    // B (dense)
-    [[maybe_unused]] long long b_off[B_ELEMS];
-    [[maybe_unused]] bool b_ok[B_ELEMS];
-    // B (im2col): one column per thread
-    [[maybe_unused]] long long im_base = 0;
-    [[maybe_unused]] int im_iy0 = 0, im_ix0 = 0;
-    [[maybe_unused]] bool im_ok = false;
-
-    if constexpr (AL == A_M4) {
-        // float4 along m: idx -> (k = idx / (BM/4), m4 = idx % (BM/4))
+    // ---- per-thread, loop-invariant byte offsets.  OOB marks lanes outside the tile's valid rows/columns.
+    unsigned a_voff[NA];
+    int a_krow[NA]; // local k of the element (k-tail test)
+    unsigned a_kstep; // byte advance per k-tile (soffset)
+    if constexpr (AL == A_M4) { // float4 along m, rows of the K x M (prepacked / transposed) operand
 #pragma unroll
-        for (int j = 0; j < A_ELEMS / 4; j++) {
+        for (int j = 0; j < NA; j++) {
             const int idx = t + j * NTHREADS;
             const int k = idx / (BM / 4), m = m0 + (idx % (BM / 4)) * 4;
-            a_off[j] = (long long)k * p.a_cs + m;
-            a_ok[j] = m < p.M; // M % 4 == 0 on this path
+            a_krow[j] = k;
+            a_voff[j] = m < p.M ? (unsigned)(((long long)k * p.a_cs + m) * 4) : OOB;
         }
-    } else if constexpr (AL == A_K4) {
-        // float4 along k: idx -> (k4 = idx % (BK/4), m = idx / (BK/4))
+        a_kstep = (unsigned)(BK * p.a_cs * 4);
+    } else if constexpr (AL == A_K4) { // float4 along k of a row-major [M][K] operand
 #pragma unroll
-        for (int j = 0; j < A_ELEMS / 4; j++) {
+        for (int j = 0; j < NA; j++) {
             const int idx = t + j * NTHREADS;
             const int k = (idx % (BK / 4)) * 4, m = m0 + idx / (BK / 4);
-            a_off[j] = (long long)m * p.a_rs + k;
-            a_ok[j] = m < p.M;
+            a_krow[j] = k;
+            a_voff[j] = m < p.M ? (unsigned)(((long long)m * p.a_rs + k) * 4) : OOB;
         }
+        a_kstep = BK * 4;
     } else {
 #pragma unroll
-        for (int j = 0; j < A_ELEMS; j++) {
+        for (int j = 0; j < NA; j++) {
             const int idx = t + j * NTHREADS;
             const int k = p.a_dir_m ? idx / BM : idx % BK;
             const int m = m0 + (p.a_dir_m ? idx % BM : idx / BK);
-            a_off[j] = (long long)m * p.a_rs + (long long)k * p.a_cs;
-            a_ok[j] = m < p.M;
+            a_krow[j] = k;
+            a_voff[j] = m < p.M ? (unsigned)(((long long)m * p.a_rs + (long long)k * p.a_cs) * 4) : OOB;
         }
+        a_kstep = (unsigned)(BK * p.a_cs * 4);
     }
+
+    [[maybe_unused]] unsigned b_voff[NB];
+    [[maybe_unused]] int b_krow[NB];
+    [[maybe_unused]] unsigned b_kstep = 0;
+    [[maybe_unused]] int im_iy0 = 0, im_ix0 = 0, im_pix = 0;
     if constexpr (BL == B_N4) {
 #pragma unroll
-        for (int j = 0; j < B_ELEMS / 4; j++) {
+        for (int j = 0; j < NB; j++) {
             const int idx = t + j * NTHREADS;
             const int k = idx / (BN / 4), n = n0 + (idx % (BN / 4)) * 4;
-            const int nb = n / p.Pn, np = n - nb * p.Pn;
-            b_off[j] = (long long)k * p.b_rs + (long long)nb * p.b_ns + np;
-            b_ok[j] = n < p.N; // N % 4 == 0, Pn % 4 == 0 on this path
+            const int nn = n < p.N ? n : 0;
+            const int nb = nn / p.Pn, np = nn - nb * p.Pn;
+            b_krow[j] = k;
+            b_voff[j] = n < p.N ? (unsigned)(((long long)k * p.b_rs + (long long)nb * p.b_ns + np) * 4) : OOB;
         }
+        b_kstep = (unsigned)(BK * p.b_rs * 4);
     } else if constexpr (BL == B_K4) {
 #pragma unroll
-        for (int j = 0; j < B_ELEMS / 4; j++) {
+        for (int j = 0; j < NB; j++) {
             const int idx = t + j * NTHREADS;
             const int k = (idx % (BK / 4)) * 4, n = n0 + idx / (BK / 4);
-            const int nb = n / p.Pn, np = n - nb * p.Pn;
-            b_off[j] = (long long)nb * p.b_ns + (long long)np * p.b_cs + k;
-            b_ok[j] = n < p.N;
+            const int nn = n < p.N ? n : 0;
+            const int nb = nn / p.Pn, np = nn - nb * p.Pn;
+            b_krow[j] = k;
+            b_voff[j] = n < p.N ? (unsigned)(((long long)nb * p.b_ns + (long long)np * p.b_cs + k) * 4) : OOB;
         }
+        b_kstep = BK * 4;
     } else if constexpr (BL == B_SCALAR) {
 #pragma unroll
-        for (int j = 0; j < B_ELEMS; j++) {
+        for (int j = 0; j < NB; j++) {
             const int idx = t + j * NTHREADS;
             const int k = p.b_dir_n ? idx / BN : idx % BK;
             const int n = n0 + (p.b_dir_n ? idx % BN : idx / BK);
-            const int nb = n / p.Pn, np = n - nb * p.Pn;
-            b_off[j] = (long long)k * p.b_rs + (long long)nb * p.b_ns + (long long)np * p.b_cs;
-            b_ok[j] = n < p.N;
+            const int nn = n < p.N ? n : 0;
+            const int nb = nn / p.Pn, np = nn - nb * p.Pn;
+            b_krow[j] = k;
+            b_voff[j] = n < p.N ? (unsigned)(((long long)k * p.b_rs + (long long)nb * p.b_ns + (long long)np * p.b_cs) * 4) : OOB;
         }
-    } else { // B_IM2COL: idx -> (k = idx / BN, col = idx % BN); 256 % BN == 0 so the column is fixed per thread
+        b_kstep = (unsigned)(BK * p.b_rs * 4);
+    } else { // B_IM2COL: thread owns column t % BN and rows (t / BN) * B_ELEMS + j (consecutive -> contiguous LUT reads)
         const int n = n0 + (t % BN);
-        im_ok = n < p.N;
-        const int nn = im_ok ? n : 0;
+        const bool ok = n < p.N;
+        const int nn = ok ? n : 0;
         const int nb = nn / p.Pn, np = nn - nb * p.Pn;
         const int oy = np / p.OW, ox = np - oy * p.OW;
         im_iy0 = oy * p.sy - p.pt;
         im_ix0 = ox * p.sx - p.pl;
-        im_base = (long long)nb * p.b_ns;
+        im_pix = (int)((long long)nb * p.b_ns) + im_iy0 * p.W + im_ix0; // element offset of the (ky=0,kx=0) tap; may be < 0
+        if (!ok) im_iy0 = -0x40000000;                                  // fails every bounds test
     }
 
-    // ---- prefetch registers
     float ra[A_ELEMS], rb[B_ELEMS];
+    const int nk = (p.K + BK - 1) / BK;
 
-    auto load_a = [&](int kt) {
-        const int k0 = kt * BK;
-        if constexpr (AL == A_M4) {
+    // im2col LUT entries of the tile that will be prefetched next; read with scalar loads (constant address
+    // space + wave-uniform row) one iteration before they are needed, so the gather never waits on them
+    typedef const __attribute__((address_space(4))) int2 *lut_ptr_t;
+    [[maybe_unused]] int2 lutE[B_ELEMS];
+    [[maybe_unused]] auto fetch_lut = [&](int kt) {
+        if constexpr (BL == B_IM2COL) {
+            int krow0 = kt * BK + (t / BN) * B_ELEMS;
+            if constexpr (BN >= 64) krow0 = __builtin_amdgcn_readfirstlane(krow0);
+            const lut_ptr_t lc = (lut_ptr_t)(unsigned long long)p.lut;
 #pragma unroll
-            for (int j = 0; j < A_ELEMS / 4; j++) {
-                const int idx = t + j * NTHREADS;
-                const int k = k0 + idx / (BM / 4);
-                const bool ok = a_ok[j] && k < p.K;
-                f32x4 v = *reinterpret_cast<const f32x4 *>(Ab + (ok ? a_off[j] + (long long)k0 * p.a_cs : 0ll));
-                if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                ra[4 * j + 0] = v[0]; ra[4 * j + 1] = v[1]; ra[4 * j + 2] = v[2]; ra[4 * j + 3] = v[3];
-            }
-        } else if constexpr (AL == A_K4) {
-#pragma unroll
-            for (int j = 0; j < A_ELEMS / 4; j++) {
-                const int idx = t + j * NTHREADS;
-                const int k = k0 + (idx % (BK / 4)) * 4;
-                const bool ok = a_ok[j] && k < p.K; // K % 4 == 0
-                f32x4 v = *reinterpret_cast<const f32x4 *>(Ab + (ok ? a_off[j] + k0 : 0ll));
-                if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                ra[4 * j + 0] = v[0]; ra[4 * j + 1] = v[1]; ra[4 * j + 2] = v[2]; ra[4 * j + 3] = v[3];
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < A_ELEMS; j++) {
-                const int idx = t + j * NTHREADS;
-                const int k = k0 + (p.a_dir_m ? idx / BM : idx % BK);
-                const bool ok = a_ok[j] && k < p.K;
-                const float v = Ab[ok ? a_off[j] + (long long)k0 * p.a_cs : 0ll];
-                ra[j] = ok ? v : 0.f;
-            }
+            for (int j = 0; j < B_ELEMS; j++) lutE[j] = lc[krow0 + j];
         }
     };
 
-    auto load_b = [&](int kt) {
+    // ---- global -> register prefetch of k-tile kt (no branches; invalid lanes read 0 through the OOB offset)
+    auto load_tile = [&](int kt) {
         const int k0 = kt * BK;
-        if constexpr (BL == B_N4) {
+        // the scalar offset never leaves the buffer (the range check subtracts it from num_records): the
+        // past-the-end prefetch reuses the last tile's soffset with every lane's voffset out of range
+        const int kts = kt < nk ? kt : (nk > 0 ? nk - 1 : 0);
+        const unsigned a_soff = (unsigned)kts * a_kstep;
+        const int kleft = p.K - k0; // rows >= kleft are the k tail
+        if constexpr (AL == A_SCALAR) {
 #pragma unroll
-            for (int j = 0; j < B_ELEMS / 4; j++) {
-                const int idx = t + j * NTHREADS;
-                const int k = k0 + idx / (BN / 4);
-                const bool ok = b_ok[j] && k < p.K;
-                f32x4 v = *reinterpret_cast<const f32x4 *>(Bb + (ok ? b_off[j] + (long long)k0 * p.b_rs : 0ll));
-                if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                rb[4 * j + 0] = v[0]; rb[4 * j + 1] = v[1]; rb[4 * j + 2] = v[2]; rb[4 * j + 3] = v[3];
+            for (int j = 0; j < NA; j++) ra[j] = buf_load1(rsA, a_krow[j] < kleft ? a_voff[j] : OOB, a_soff);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NA; j++) {
+                const f32x4 v = buf_load4(rsA, a_krow[j] < kleft ? a_voff[j] : OOB, a_soff);
+                ra[4 * j + 0] = v[0]; ra[4 * j + 1] = v[1]; ra[4 * j + 2] = v[2]; ra[4 * j + 3] = v[3];
             }
-        } else if constexpr (BL == B_K4) {
+        }
+        if constexpr (BL == B_IM2COL) {
+            // virtual im2col row k -> (c, ky, kx) from the LUT entries fetched one iteration ahead
+            // (rten-gemm/src/im2col.rs:145-208: out-of-image -> 0)
 #pragma unroll
-            for (int j = 0; j < B_ELEMS / 4; j++) {
-                const int idx = t + j * NTHREADS;
-                const int k = k0 + (idx % (BK / 4)) * 4;
-                const bool ok = b_ok[j] && k < p.K;
-                f32x4 v = *reinterpret_cast<const f32x4 *>(Bb + (ok ? b_off[j] + k0 : 0ll));
-                if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                rb[4 * j + 0] = v[0]; rb[4 * j + 1] = v[1]; rb[4 * j + 2] = v[2]; rb[4 * j + 3] = v[3];
+            for (int j = 0; j < B_ELEMS; j++) {
+                const int2 e = lutE[j];
+                const int iy = im_iy0 + (e.y & 0xffff);
+                const int ix = im_ix0 + (e.y >> 16);
+                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                rb[j] = buf_load1(rsB, ok ? (unsigned)(im_pix + e.x) << 2 : OOB, 0);
             }
         } else if constexpr (BL == B_SCALAR) {
+            const unsigned b_soff = (unsigned)kts * b_kstep;
 #pragma unroll
-            for (int j = 0; j < B_ELEMS; j++) {
-                const int idx = t + j * NTHREADS;
-                const int k = k0 + (p.b_dir_n ? idx / BN : idx % BK);
-                const bool ok = b_ok[j] && k < p.K;
-                const float v = Bb[ok ? b_off[j] + (long long)k0 * p.b_rs : 0ll];
-                rb[j] = ok ? v : 0.f;
-            }
+            for (int j = 0; j < NB; j++) rb[j] = buf_load1(rsB, b_krow[j] < kleft ? b_voff[j] : OOB, b_soff);
         } else {
-            // virtual im2col row k -> (c, ky, kx)  (rten-gemm/src/im2col.rs:145-208: out-of-image -> 0)
+            const unsigned b_soff = (unsigned)kts * b_kstep;
 #pragma unroll
-            for (int j = 0; j < B_ELEMS; j++) {
-                int k = k0 + t / BN + j * (NTHREADS / BN);
-                if constexpr (BN >= 64) k = __builtin_amdgcn_readfirstlane(k); // wave-uniform: scalar index math
-                const unsigned c = fastdiv((unsigned)k, p.magic_khw, (unsigned)p.KHW);
-                const unsigned rem = (unsigned)k - c * (unsigned)p.KHW;
-                const unsigned ky = fastdiv(rem, p.magic_kw, (unsigned)p.KW);
-                const unsigned kx = rem - ky * (unsigned)p.KW;
-                const int iy = im_iy0 + (int)ky * p.dy;
-                const int ix = im_ix0 + (int)kx * p.dx;
-                const bool ok = im_ok && k < p.K && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                const long long off = im_base + (long long)c * p.HW + (long long)iy * p.W + ix;
-                const float v = Bb[ok ? off : 0ll]; // branch-free: clamp the address, select the value
-                rb[j] = ok ? v : 0.f;
+            for (int j = 0; j < NB; j++) {
+                const f32x4 v = buf_load4(rsB, b_krow[j] < kleft ? b_voff[j] : OOB, b_soff);
+                rb[4 * j + 0] = v[0]; rb[4 * j + 1] = v[1]; rb[4 * j + 2] = v[2]; rb[4 * j + 3] = v[3];
             }
         }
     };
 
-    auto store_a = [&](int buf) {
+    auto store_tile = [&](int buf) {
         float *As = As0 + buf * BK * LDA;
+        float *Bs = Bs0 + buf * BK * LDB;
         if constexpr (AL == A_M4) {
 #pragma unroll
-            for (int j = 0; j < A_ELEMS / 4; j++) {
+            for (int j = 0; j < NA; j++) {
                 const int idx = t + j * NTHREADS;
-                const int k = idx / (BM / 4), m = (idx % (BM / 4)) * 4;
-                f32x4 v = {ra[4 * j], ra[4 * j + 1], ra[4 * j + 2], ra[4 * j + 3]};
-                *reinterpret_cast<f32x4 *>(As + k * LDA + m) = v;
+                const f32x4 v = {ra[4 * j], ra[4 * j + 1], ra[4 * j + 2], ra[4 * j + 3]};
+                *reinterpret_cast<f32x4 *>(As + (idx / (BM / 4)) * LDA + (idx % (BM / 4)) * 4) = v;
             }
         } else if constexpr (AL == A_K4) {
 #pragma unroll
-            for (int j = 0; j < A_ELEMS / 4; j++) {
+            for (int j = 0; j < NA; j++) {
                 const int idx = t + j * NTHREADS;
                 const int k = (idx % (BK / 4)) * 4, m = idx / (BK / 4);
 #pragma unroll
@@ -291,28 +291,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_kernel(const GemmArgs p
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < A_ELEMS; j++) {
+            for (int j = 0; j < NA; j++) {
                 const int idx = t + j * NTHREADS;
-                const int k = p.a_dir_m ? idx / BM : idx % BK;
-                const int m = p.a_dir_m ? idx % BM : idx / BK;
-                As[k * LDA + m] = ra[j];
+                As[(p.a_dir_m ? idx / BM : idx % BK) * LDA + (p.a_dir_m ? idx % BM : idx / BK)] = ra[j];
             }
         }
-    };
-
-    auto store_b = [&](int buf) {
-        float *Bs = Bs0 + buf * BK * LDB;
         if constexpr (BL == B_N4) {
 #pragma unroll
-            for (int j = 0; j < B_ELEMS / 4; j++) {
+            for (int j = 0; j < NB; j++) {
                 const int idx = t + j * NTHREADS;
-                const int k = idx / (BN / 4), n = (idx % (BN / 4)) * 4;
-                f32x4 v = {rb[4 * j], rb[4 * j + 1], rb[4 * j + 2], rb[4 * j + 3]};
-                *reinterpret_cast<f32x4 *>(Bs + k * LDB + n) = v;
+                const f32x4 v = {rb[4 * j], rb[4 * j + 1], rb[4 * j + 2], rb[4 * j + 3]};
+                *reinterpret_cast<f32x4 *>(Bs + (idx / (BN / 4)) * LDB + (idx % (BN / 4)) * 4) = v;
             }
         } else if constexpr (BL == B_K4) {
 #pragma unroll
-            for (int j = 0; j < B_ELEMS / 4; j++) {
+            for (int j = 0; j < NB; j++) {
                 const int idx = t + j * NTHREADS;
                 const int k = (idx % (BK / 4)) * 4, n = idx / (BK / 4);
 #pragma unroll
@@ -320,18 +313,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_kernel(const GemmArgs p
             }
         } else if constexpr (BL == B_SCALAR) {
 #pragma unroll
-            for (int j = 0; j < B_ELEMS; j++) {
+            for (int j = 0; j < NB; j++) {
                 const int idx = t + j * NTHREADS;
-                const int k = p.b_dir_n ? idx / BN : idx % BK;
-                const int n = p.b_dir_n ? idx % BN : idx / BK;
-                Bs[k * LDB + n] = rb[j];
+                Bs[(p.b_dir_n ? idx / BN : idx % BK) * LDB + (p.b_dir_n ? idx % BN : idx / BK)] = rb[j];
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < B_ELEMS; j++) {
-                const int k = t / BN + j * (NTHREADS / BN);
-                Bs[k * LDB + (t % BN)] = rb[j];
-            }
+            for (int j = 0; j < B_ELEMS; j++) Bs[((t / BN) * B_ELEMS + j) * LDB + (t % BN)] = rb[j];
         }
     };
 
@@ -346,23 +334,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_kernel(const GemmArgs p
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    // C addressing for this lane: column n fixed per (j), rows by register
-    long long c_col[TN];
-    bool c_col_ok[TN];
-    int c_n[TN];
-#pragma unroll
-    for (int j = 0; j < TN; j++) {
-        const int n = n0 + wn0 + j * 32 + l31;
-        c_n[j] = n;
-        c_col_ok[j] = n < p.N;
-        const int nn = c_col_ok[j] ? n : 0;
-        const int nb = nn / p.Pn, np = nn - nb * p.Pn;
-        c_col[j] = (long long)z * p.c_bs + (long long)nb * p.c_ns + np;
-    }
     const float *__restrict__ biasb = p.bias ? p.bias + (long long)z * p.bias_bs : nullptr;
 
     // value of an output element after the FIRST depth block: combine with C (beta), then bias
-    auto first_value = [&](float a, int j, int m, long long ccol, int cn, bool cok) -> float {
+    auto first_value = [&](float a, int m, long long ccol, int cn, bool cok) -> float {
         float cin = 0.f;
         if (p.beta != 0.f && m < p.M && cok) cin = p.C[ccol + (long long)m * p.c_rs];
         float v = combine(a, cin, p.alpha, p.beta);
@@ -373,100 +348,113 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_kernel(const GemmArgs p
         }
         return v;
     };
-    // in-loop flush of one finished depth block into `tot` (MULTI_KC only).  The row/column bases are
-    // laundered through an empty asm so that the (rare) flush's address arithmetic is recomputed here
-    // instead of being hoisted out of the K loop, where it would cost ~100 live VGPRs.
+    auto col_offset = [&](int n) -> long long {
+        const int nn = n < p.N ? n : 0;
+        const int nb = nn / p.Pn, np = nn - nb * p.Pn;
+        return c_zoff + (long long)nb * p.c_ns + np;
+    };
+    // flush of one finished depth block into `tot` (between depth blocks, MULTI_KC only)
+    // The row/column bases are laundered through an empty asm so that the (rare) flush's address
+    // arithmetic is recomputed here instead of being hoisted out of the K loop (~100 live VGPRs).
     [[maybe_unused]] auto flush = [&](bool first) {
-        int mb = m0 + wm0 + 4 * half;
-        int nb0 = n0 + wn0 + l31;
+        int mb = m0 + wm0 + 4 * half, nb0 = n0 + wn0 + l31;
         asm volatile("" : "+v"(mb), "+v"(nb0));
 #pragma unroll
         for (int j = 0; j < TN; j++) {
             const int n = nb0 + j * 32;
             const bool cok = n < p.N;
-            long long ccol = 0;
-            if (first) {
-                const int nn = cok ? n : 0;
-                const int nb = nn / p.Pn, np = nn - nb * p.Pn;
-                ccol = (long long)z * p.c_bs + (long long)nb * p.c_ns + np;
-            }
+            const long long ccol = first ? col_offset(n) : 0;
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int m = mb + i * 32 + (r & 3) + 8 * (r >> 2);
-                    tot[i][j][r] = first ? first_value(acc[i][j][r], j, m, ccol, n, cok)
+                    tot[i][j][r] = first ? first_value(acc[i][j][r], m, ccol, n, cok)
                                          : combine(acc[i][j][r], tot[i][j][r], p.alpha, 1.f);
                     acc[i][j][r] = 0.f;
                 }
         }
     };
 
-    // ---- main loop
-    const int nk = (p.K + BK - 1) / BK;
-    if (nk > 0) {
-        load_a(0);
-        load_b(0);
-        store_a(0);
-        store_b(0);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nk; kt++) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
-        if (more) {
-            load_a(kt + 1);
-            load_b(kt + 1);
-        }
+    auto compute_tile = [&](int cur) {
         const float *As = As0 + cur * BK * LDA + wm0 + l31;
         const float *Bs = Bs0 + cur * BK * LDB + wn0 + l31;
+        // all MFMA operands of the tile first (ds_read latency overlaps), then the MFMAs back to back
+        float af[BK / 2][TM], bf[BK / 2][TN];
 #pragma unroll
         for (int kk = 0; kk < BK / 2; kk++) {
-            float af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; i++) af[i] = As[(2 * kk + half) * LDA + i * 32];
+            for (int i = 0; i < TM; i++) af[kk][i] = As[(2 * kk + half) * LDA + i * 32];
 #pragma unroll
-            for (int j = 0; j < TN; j++) bf[j] = Bs[(2 * kk + half) * LDB + j * 32];
+            for (int j = 0; j < TN; j++) bf[kk][j] = Bs[(2 * kk + half) * LDB + j * 32];
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; kk++)
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int j = 0; j < TN; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-        if (more) {
-            store_a(cur ^ 1);
-            store_b(cur ^ 1);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][i], bf[kk][j], acc[i][j], 0, 0, 0);
+    };
+
+    // ---- main loop: depth blocks of KC_TILES k-tiles; inside a block the loop body is branch free
+    fetch_lut(0);
+    load_tile(0);
+    fetch_lut(1);
+    store_tile(0);
+    __syncthreads();
+    const int nblk = MULTI_KC ? (nk + KC_TILES - 1) / KC_TILES : 1;
+    for (int blk = 0; blk < nblk; blk++) {
+        const int kt_end = MULTI_KC ? ((blk + 1) * KC_TILES < nk ? (blk + 1) * KC_TILES : nk) : nk;
+        for (int kt = blk * KC_TILES; kt < kt_end; kt++) {
+            load_tile(kt + 1); // prefetch; past the end every lane is out of range -> zeros, never used
+            fetch_lut(kt + 2);
+            compute_tile(kt & 1);
+            store_tile((kt + 1) & 1);
+            __syncthreads();
         }
         if constexpr (MULTI_KC) {
-            if (more && ((kt + 1) % KC_TILES) == 0) flush(kt + 1 == KC_TILES);
+            if (blk + 1 < nblk) flush(blk == 0);
         }
-        __syncthreads();
     }
 
     // ---- final depth block + fused epilogue (residual Add, activation), NCHW / row-major store
     const float *__restrict__ resb = p.res;
 #pragma unroll
-    for (int i = 0; i < TM; i++)
+    for (int j = 0; j < TN; j++) {
+        const int n = n0 + wn0 + j * 32 + l31;
+        const bool cok = n < p.N;
+        const long long ccol = col_offset(n);
 #pragma unroll
-        for (int j = 0; j < TN; j++)
+        for (int i = 0; i < TM; i++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 float v;
                 if constexpr (MULTI_KC) {
-                    v = (nk > KC_TILES) ? combine(acc[i][j][r], tot[i][j][r], p.alpha, 1.f)
-                                        : first_value(acc[i][j][r], j, m, c_col[j], c_n[j], c_col_ok[j]);
+                    v = (nblk > 1) ? combine(acc[i][j][r], tot[i][j][r], p.alpha, 1.f) : first_value(acc[i][j][r], m, ccol, n, cok);
                 } else {
-                    v = first_value(acc[i][j][r], j, m, c_col[j], c_n[j], c_col_ok[j]);
+                    v = first_value(acc[i][j][r], m, ccol, n, cok);
                 }
-                if (m < p.M && c_col_ok[j]) {
-                    const long long off = c_col[j] + (long long)m * p.c_rs;
+                if (m < p.M && cok) {
+                    const long long off = ccol + (long long)m * p.c_rs;
                     if (resb) v = v + resb[off];
                     if (p.act == RTEN_HIP_ACT_RELU) v = vm::relu(v);
                     else if (p.act == RTEN_HIP_ACT_GELU) v = vm::gelu(v);
                     p.C[off] = v;
                 }
             }
+    }
+}
+
+// im2col lookup table: entry k -> {c*HW + ky*dy*W + kx*dx, (ky*dy) | (kx*dx) << 16}; rows >= K get an
+// offset pair that fails every bounds test.  Built once per conv geometry and cached in the context.
+__global__ void im2col_lut_kernel(int2 *lut, int K, int Kpad, int KHW, int KW, int HW, int W, int dy, int dx) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= Kpad) return;
+    if (k >= K) { lut[k] = make_int2(0, 0xffff); return; } // dy = 65535 > any padded height
+    const int c = k / KHW, rem = k - c * KHW, ky = rem / KW, kx = rem - ky * KW;
+    lut[k] = make_int2(c * HW + ky * dy * W + kx * dx, (ky * dy) | ((kx * dx) << 16));
 }
 
 } // namespace
@@ -481,7 +469,7 @@ struct TileCfg { int bm, bn; float penalty; };
 constexpr TileCfg kCfgs[4] = {{128, 128, 1.00f}, {128, 64, 1.04f}, {64, 128, 1.04f}, {64, 64, 1.12f}};
 
 template <int BM, int BN, int AL, int BL>
-int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z, const char *name) {
+int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.N + BN - 1) / BN;
     dim3 grid((unsigned)(a.tiles_m * a.tiles_n), (unsigned)Z);
@@ -490,7 +478,6 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z, const char *name) {
     char kname[96];
     const bool multi = a.K > 256;
     snprintf(kname, sizeof kname, "igemm_f32_kernel<%d,%d,%d,%d,%d>", BM, BN, AL, BL, multi ? 1 : 0);
-    (void)name;
     ProfScope ps(ctx, kname, flops, bytes);
     if (multi)
         hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, AL, BL, true>), grid, dim3(NTHREADS), 0, ctx->stream, a);
@@ -503,10 +490,10 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z, const char *name) {
 template <int AL, int BL>
 int32_t launch_variant(rten_hip_ctx *ctx, GemmArgs &a, int Z, int cfg) {
     switch (cfg) {
-    case 0: return launch_cfg<128, 128, AL, BL>(ctx, a, Z, "");
-    case 1: return launch_cfg<128, 64, AL, BL>(ctx, a, Z, "");
-    case 2: return launch_cfg<64, 128, AL, BL>(ctx, a, Z, "");
-    default: return launch_cfg<64, 64, AL, BL>(ctx, a, Z, "");
+    case 0: return launch_cfg<128, 128, AL, BL>(ctx, a, Z);
+    case 1: return launch_cfg<128, 64, AL, BL>(ctx, a, Z);
+    case 2: return launch_cfg<64, 128, AL, BL>(ctx, a, Z);
+    default: return launch_cfg<64, 64, AL, BL>(ctx, a, Z);
     }
 }
 
@@ -526,8 +513,6 @@ int pick_cfg(rten_hip_ctx *ctx, int M, long long N, int Z) {
 
 inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 
-unsigned magic_for(unsigned d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + d - 1) / d); }
-
 int32_t dispatch(rten_hip_ctx *ctx, GemmArgs &a, int Z, int al, int bl) {
     const int cfg = pick_cfg(ctx, a.M, a.N, Z);
     if (al == A_M4 && bl == B_N4) return launch_variant<A_M4, B_N4>(ctx, a, Z, cfg);
@@ -535,8 +520,16 @@ int32_t dispatch(rten_hip_ctx *ctx, GemmArgs &a, int Z, int al, int bl) {
     if (al == A_K4 && bl == B_N4) return launch_variant<A_K4, B_N4>(ctx, a, Z, cfg);
     if (al == A_K4 && bl == B_K4) return launch_variant<A_K4, B_K4>(ctx, a, Z, cfg);
     if (bl == B_IM2COL) return launch_variant<A_SCALAR, B_IM2COL>(ctx, a, Z, cfg);
-    return launch_variant<A_SCALAR, B_SCALAR>(ctx, a, Z, cfg == 0 ? 1 : cfg); // 128x128 all-scalar spills
+    return launch_variant<A_SCALAR, B_SCALAR>(ctx, a, Z, cfg);
 }
+
+// Largest byte offset (exclusive) an operand slice with the given extents/strides can touch.
+long long extent_bytes(long long rows, long long rs, long long cols, long long cs) {
+    if (rows <= 0 || cols <= 0) return 4;
+    return ((rows - 1) * rs + (cols - 1) * cs + 1) * 4;
+}
+
+constexpr long long kMaxBufBytes = 0x7fffffffll; // buffer offsets are 32-bit; the OOB marker is 2^31
 
 } // namespace
 
@@ -559,26 +552,34 @@ RTEN_EXPORT int32_t rten_hip_gemm_f32(rten_hip_ctx *ctx, const rten_hip_gemm_des
     if (d->m == 0 || d->n == 0 || d->batch == 0) return RTEN_HIP_OK; // rten-gemm/src/lib.rs:835-839
     if (!c || (d->k > 0 && (!a || !b))) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "gemm: NULL operand");
     if (d->ldc < d->n) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "gemm: ldc < n");
+    if (d->a_rs < 0 || d->a_cs < 0 || d->b_rs < 0 || d->b_cs < 0)
+        return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "gemm: negative strides are not supported");
 
     GemmArgs g = {};
-    g.A = a; g.B = b; g.C = c; g.bias = bias; g.res = nullptr;
+    g.A = a ? a : c; g.B = b ? b : c; g.C = c; g.bias = bias; g.res = nullptr;
     g.M = d->m; g.N = d->n; g.K = d->k;
     g.a_rs = d->a_rs; g.a_cs = d->a_cs; g.a_bs = d->a_bs;
     g.b_rs = d->b_rs; g.b_cs = d->b_cs; g.b_ns = 0; g.b_bs = d->b_bs;
     g.c_rs = d->ldc; g.c_ns = 0; g.c_bs = d->c_bs;
     g.bias_bs = 0;
+    g.batch_inner = d->batch_inner; g.a_bsi = d->a_bsi; g.b_bsi = d->b_bsi; g.c_bsi = d->c_bsi;
     g.Pn = d->n;
     g.alpha = d->alpha; g.beta = d->beta;
     g.bias_kind = d->bias_kind; g.act = d->act;
     g.a_dir_m = (d->a_rs == 1 && d->a_cs != 1) ? 1 : 0;
     g.b_dir_n = (d->b_cs == 1 || d->b_rs != 1) ? 1 : 0;
+    const long long ab = extent_bytes(d->m, d->a_rs, d->k, d->a_cs), bb = extent_bytes(d->k, d->b_rs, d->n, d->b_cs);
+    if (ab > kMaxBufBytes || bb > kMaxBufBytes)
+        return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "gemm: operand slices above 2 GiB are not supported");
+    g.a_bytes = (unsigned)ab; g.b_bytes = (unsigned)bb;
 
     int al = A_SCALAR, bl = B_SCALAR;
     if (d->k > 0) {
-        if (d->a_rs == 1 && d->a_cs % 4 == 0 && d->m % 4 == 0 && d->a_bs % 4 == 0 && aligned16(a)) al = A_M4;
-        else if (d->a_cs == 1 && d->a_rs % 4 == 0 && d->k % 4 == 0 && d->a_bs % 4 == 0 && aligned16(a)) al = A_K4;
-        if (d->b_cs == 1 && d->b_rs % 4 == 0 && d->n % 4 == 0 && d->b_bs % 4 == 0 && aligned16(b)) bl = B_N4;
-        else if (d->b_rs == 1 && d->b_cs % 4 == 0 && d->k % 4 == 0 && d->b_bs % 4 == 0 && aligned16(b)) bl = B_K4;
+        const bool a4 = d->a_bs % 4 == 0 && d->a_bsi % 4 == 0 && aligned16(a), b4 = d->b_bs % 4 == 0 && d->b_bsi % 4 == 0 && aligned16(b);
+        if (d->a_rs == 1 && d->a_cs % 4 == 0 && d->m % 4 == 0 && a4) al = A_M4;
+        else if (d->a_cs == 1 && d->a_rs % 4 == 0 && d->k % 4 == 0 && a4) al = A_K4;
+        if (d->b_cs == 1 && d->b_rs % 4 == 0 && d->n % 4 == 0 && b4) bl = B_N4;
+        else if (d->b_rs == 1 && d->b_cs % 4 == 0 && d->k % 4 == 0 && b4) bl = B_K4;
         const bool have = (al == A_M4 && bl == B_N4) || (al == A_K4 && bl == B_N4) || (al == A_K4 && bl == B_K4);
         if (!have) { al = A_SCALAR; bl = B_SCALAR; }
     }
@@ -612,9 +613,28 @@ int32_t check_conv_desc(rten_hip_ctx *ctx, const rten_hip_conv2d_desc *d) {
         return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "conv: invalid geometry");
     const long long in_elems = (long long)d->n * d->c * d->h * d->w;
     const long long out_elems = (long long)d->n * d->o * d->out_h * d->out_w;
-    if (in_elems >= (1ll << 31) || out_elems >= (1ll << 31))
-        return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "conv: tensors above 2^31 elements are not supported");
+    if (in_elems * 4 > kMaxBufBytes || out_elems >= (1ll << 31))
+        return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "conv: input above 2 GiB / output above 2^31 elements is not supported");
+    if ((long long)d->kh * d->dil_h >= 0x7fff || (long long)d->kw * d->dil_w >= 0x7fff || d->h >= 0x7fff || d->w >= 0x7fff)
+        return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "conv: spatial extent above 32766 is not supported");
     return RTEN_HIP_OK;
+}
+
+// im2col LUT cache (per context): one table per (Cg, kh, kw, dil, H, W)
+const int2 *get_im2col_lut(rten_hip_ctx *ctx, int Cg, int kh, int kw, int dy, int dx, int H, int W) {
+    char key[96];
+    snprintf(key, sizeof key, "%d.%d.%d.%d.%d.%d.%d", Cg, kh, kw, dy, dx, H, W);
+    auto it = ctx->luts.find(key);
+    if (it != ctx->luts.end()) return (const int2 *)it->second;
+    if (ctx->capturing) return nullptr; // allocation is not capturable: warm up eagerly first
+    const int K = Cg * kh * kw;
+    const int Kpad = ((K + BK - 1) / BK + 3) * BK; // tile and LUT prefetch run up to two tiles past the end
+    void *dptr = nullptr;
+    if (hipMalloc(&dptr, (size_t)Kpad * sizeof(int2)) != hipSuccess) return nullptr;
+    hipLaunchKernelGGL(im2col_lut_kernel, dim3((Kpad + 255) / 256), dim3(256), 0, ctx->stream, (int2 *)dptr, K, Kpad, kh * kw,
+                       kw, H * W, W, dy, dx);
+    ctx->luts[key] = dptr;
+    return (const int2 *)dptr;
 }
 } // namespace
 
@@ -655,6 +675,8 @@ RTEN_EXPORT int32_t rten_hip_conv2d_f32(rten_hip_ctx *ctx, const rten_hip_conv2d
     const int K = Cg * d->kh * d->kw;
     const int P = d->out_h * d->out_w;
     const long long HW = (long long)d->h * d->w;
+    if ((long long)K * Og4 * 4 > kMaxBufBytes)
+        return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "conv: weights above 2 GiB per group are not supported");
 
     GemmArgs g = {};
     g.A = w; g.B = x; g.C = y; g.bias = bias; g.res = (flags & RTEN_HIP_CONV_RESIDUAL) ? residual : nullptr;
@@ -664,13 +686,17 @@ RTEN_EXPORT int32_t rten_hip_conv2d_f32(rten_hip_ctx *ctx, const rten_hip_conv2d
         g.a_rs = 1; g.a_cs = Og4; g.a_bs = (long long)K * Og4;
         al = aligned16(w) ? A_M4 : A_SCALAR;
         g.a_dir_m = 1;
+        g.a_bytes = (unsigned)((long long)K * Og4 * 4);
     } else {
         g.a_rs = K; g.a_cs = 1; g.a_bs = (long long)Og * K;
         al = A_SCALAR;
         g.a_dir_m = 0;
+        g.a_bytes = (unsigned)((long long)Og * K * 4);
     }
     g.b_bs = (long long)Cg * HW;
     g.b_ns = (long long)d->c * HW;
+    // one group's slice spans from its first channel of image 0 to its last channel of the last image
+    g.b_bytes = (unsigned)((((long long)(d->n - 1) * d->c + Cg) * HW) * 4);
     g.c_rs = P; g.c_ns = (long long)d->o * P; g.c_bs = (long long)Og * P;
     g.bias_bs = Og;
     g.Pn = P;
@@ -686,11 +712,11 @@ RTEN_EXPORT int32_t rten_hip_conv2d_f32(rten_hip_ctx *ctx, const rten_hip_conv2d
         bl = B_N4;
         g.b_rs = HW; g.b_cs = 1;
     } else {
-        g.H = d->h; g.W = d->w; g.HW = (int)HW; g.KHW = d->kh * d->kw; g.KW = d->kw; g.OW = d->out_w;
-        g.sy = d->stride_h; g.sx = d->stride_w; g.dy = d->dil_h; g.dx = d->dil_w;
+        g.lut = get_im2col_lut(ctx, Cg, d->kh, d->kw, d->dil_h, d->dil_w, d->h, d->w);
+        if (!g.lut) return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "conv: im2col table allocation failed (warm up before graph capture)");
+        g.H = d->h; g.W = d->w; g.OW = d->out_w;
+        g.sy = d->stride_h; g.sx = d->stride_w;
         g.pt = d->pads[0]; g.pl = d->pads[1];
-        g.magic_khw = magic_for((unsigned)g.KHW);
-        g.magic_kw = magic_for((unsigned)g.KW);
     }
     g.b_dir_n = 1;
     return dispatch(ctx, g, d->groups, al, bl);

@@ -35,6 +35,7 @@ struct rten_hip_ctx {
     // scratch (grown on demand, never during capture)
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
+    std::map<std::string, void *> luts; // im2col lookup tables, keyed by conv geometry (gemm_f32.hip)
     int gemm_variant_override = -1;
     int num_cus = 256;
 };

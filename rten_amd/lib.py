@@ -38,7 +38,24 @@ class GemmDesc(C.Structure):
                 ("a_rs", C.c_int64), ("a_cs", C.c_int64), ("b_rs", C.c_int64), ("b_cs", C.c_int64),
                 ("ldc", C.c_int64), ("batch", C.c_int32),
                 ("a_bs", C.c_int64), ("b_bs", C.c_int64), ("c_bs", C.c_int64),
+                ("batch_inner", C.c_int32), ("a_bsi", C.c_int64), ("b_bsi", C.c_int64), ("c_bsi", C.c_int64),
                 ("alpha", C.c_float), ("beta", C.c_float), ("bias_kind", C.c_int32), ("act", C.c_int32)]
+
+
+def gemm_desc(m, n, k, a_rs, a_cs, b_rs, b_cs, ldc, batch=1, a_bs=0, b_bs=0, c_bs=0, alpha=1.0, beta=0.0,
+              bias_kind=BIAS_NONE, act=ACT_NONE, batch_inner=0, a_bsi=0, b_bsi=0, c_bsi=0) -> GemmDesc:
+    return GemmDesc(m, n, k, a_rs, a_cs, b_rs, b_cs, ldc, batch, a_bs, b_bs, c_bs, batch_inner, a_bsi, b_bsi, c_bsi,
+                    alpha, beta, bias_kind, act)
+
+
+class SdpaDesc(C.Structure):
+    _fields_ = [("batch", C.c_int32), ("heads", C.c_int32), ("s", C.c_int32), ("t", C.c_int32), ("d", C.c_int32),
+                ("dv", C.c_int32),
+                ("q_bs", C.c_int64), ("q_hs", C.c_int64), ("q_rs", C.c_int64),
+                ("k_bs", C.c_int64), ("k_hs", C.c_int64), ("k_rs", C.c_int64),
+                ("v_bs", C.c_int64), ("v_hs", C.c_int64), ("v_rs", C.c_int64),
+                ("o_bs", C.c_int64), ("o_hs", C.c_int64), ("o_rs", C.c_int64),
+                ("mask_batch_stride", C.c_int64), ("mask_row_stride", C.c_int64), ("scale", C.c_float)]
 
 
 class GemmInt8Desc(C.Structure):
@@ -115,7 +132,8 @@ PROTOTYPES = {
     "rten_hip_max_pool2d_f32": (_I32, [_VP, C.POINTER(Pool2dDesc), _VP, _VP]),
     "rten_hip_average_pool2d_f32": (_I32, [_VP, C.POINTER(Pool2dDesc), _VP, _VP]),
     "rten_hip_global_average_pool_f32": (_I32, [_VP, _I64, _I32, _VP, _VP]),
-    "rten_hip_sdpa_f32": (_I32, [_VP, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP, _I32, _I64, _I64, _F32, _VP]),
+    "rten_hip_sdpa_f32": (_I32, [_VP, C.POINTER(SdpaDesc), _VP, _VP, _VP, _VP, _VP]),
+    "rten_hip_gather_rows_f32": (_I32, [_VP, _I64, _I32, _I32, _VP, _VP, _VP]),
     "rten_hip_set_gemm_variant_override": (_I32, [_VP, _I32]),
     "rten_hip_num_gemm_variants": (_I32, []),
 }

@@ -136,17 +136,18 @@ class ResNet50:
                 free.remove(best)
             else:
                 best = DeviceTensor(ctx, (need // 4,), np.float32)
-            self.bufs[out] = best
+            self.bufs[out] = best.view(shapes[out])
+            self._raw = getattr(self, "_raw", {})
+            self._raw[out] = best
             for nm in ins:
                 if nm != "x" and last_use[nm] == i:
-                    free.append(self.bufs[nm])
+                    free.append(self._raw[nm])
         self.gap = DeviceTensor(ctx, (N, 2048), np.float32)
         self.logits = DeviceTensor(ctx, (N, self.num_classes), np.float32)
         p = self.shapes["stem"]
         self.pool_desc = L.Pool2dDesc(p[0], p[1], p[2], p[3], 3, 3, 2, 2, (C.c_int32 * 4)(1, 1, 1, 1), self.shapes["pool"][2],
                                       self.shapes["pool"][3], 0)
-        self.fc_desc = L.GemmDesc(N, self.num_classes, 2048, 2048, 1, 1, 2048, self.num_classes, 1, 0, 0, 0, 1.0, 0.0,
-                                  L.BIAS_PER_COL, L.ACT_NONE)
+        self.fc_desc = L.gemm_desc(N, self.num_classes, 2048, 2048, 1, 1, 2048, self.num_classes, bias_kind=L.BIAS_PER_COL)
 
     def _wptr(self, name, which):
         a, b = self.w_off[name]

@@ -269,15 +269,15 @@ def _matmul(ctx, a: DeviceTensor, b: DeviceTensor, bias=None, alpha=None, act=L.
     y = DeviceTensor(ctx, out_shape, np.float32)
     if int(np.prod(out_shape, dtype=np.int64)) > 0:
         if na > 1 and nb == 1:  # matmul.rs:266-297: one [A*M, K] x [K, N] GEMM
-            d = L.GemmDesc(na * m, n, k, k, 1, b_rs, b_cs, n, 1, 0, 0, 0, alpha if alpha is not None else 1.0, 0.0,
-                           L.BIAS_PER_COL if bias is not None else L.BIAS_NONE, act)
+            d = L.gemm_desc(na * m, n, k, k, 1, b_rs, b_cs, n, alpha=alpha if alpha is not None else 1.0,
+                            bias_kind=L.BIAS_PER_COL if bias is not None else L.BIAS_NONE, act=act)
         else:
             batch = int(np.prod(pre, dtype=np.int64)) if len(pre) else 1
             if na not in (1, batch) or nb not in (1, batch):
                 raise UnsupportedValue("partial batch broadcasting is not supported by the device path")
-            d = L.GemmDesc(m, n, k, k, 1, b_rs, b_cs, n, batch, m * k if na > 1 else 0, k * n if nb > 1 else 0, m * n,
-                           alpha if alpha is not None else 1.0, 0.0,
-                           L.BIAS_PER_COL if bias is not None else L.BIAS_NONE, act)
+            d = L.gemm_desc(m, n, k, k, 1, b_rs, b_cs, n, batch, m * k if na > 1 else 0, k * n if nb > 1 else 0, m * n,
+                            alpha=alpha if alpha is not None else 1.0,
+                            bias_kind=L.BIAS_PER_COL if bias is not None else L.BIAS_NONE, act=act)
         ctx.call("rten_hip_gemm_f32", C.byref(d), a.vp, b.vp, _vp(bias), y.vp)
     if a_vec:
         out_shape.pop(-2)
@@ -360,7 +360,7 @@ class Gemm(Operator):
                 else:
                     raise IncompatibleInputShapes("Cannot broadcast c to output shape")
         if m * n > 0:
-            d = L.GemmDesc(m, n, k, a_rs, a_cs, b_rs, b_cs, n, 1, 0, 0, 0, self.alpha, beta, L.BIAS_NONE, L.ACT_NONE)
+            d = L.gemm_desc(m, n, k, a_rs, a_cs, b_rs, b_cs, n, alpha=self.alpha, beta=beta)
             ctx.call("rten_hip_gemm_f32", C.byref(d), a.vp, b.vp, None, y.vp)
         return [y]
 
@@ -774,19 +774,41 @@ class Attention(Operator):
         T, Dv = k.shape[2], v.shape[3]
         if k.shape[:2] != (B, H) or v.shape[:3] != (B, H, T) or k.shape[3] != D:
             raise IncompatibleInputShapes("Q/K/V shapes are inconsistent")
-        scale = self.scale if self.scale is not None else 1.0 / math.sqrt(D)
-        mbd, mbs, mrs = 1, 0, 0
+        # `1.0 / (head_size as f32).sqrt()` in f32 arithmetic (attention.rs:659-670)
+        scale = self.scale if self.scale is not None else float(np.float32(1.0) / np.sqrt(np.float32(D)))
+        mbs, mrs = 0, 0
         if mask is not None:
             if mask.dtype != np.float32:
                 raise UnsupportedValue("device Attention supports additive float masks")
             if tuple(mask.shape) == (B, 1, 1, T):
-                mbd, mbs, mrs = H, T, 0
+                mbs, mrs = T, 0
             elif tuple(mask.shape) == (B, 1, S, T):
-                mbd, mbs, mrs = H, S * T, T
+                mbs, mrs = S * T, T
             else:
                 raise UnsupportedValue("mask must be [B,1,1,T] or [B,1,S,T]")
         out = DeviceTensor(ctx, (B, H, S, Dv), np.float32)
-        ctx.call("rten_hip_sdpa_f32", B * H, S, T, D, Dv, q.vp, k.vp, v.vp, _vp(mask), mbd, mbs, mrs, scale, out.vp)
+        d = L.SdpaDesc(B, H, S, T, D, Dv, H * S * D, S * D, D, H * T * D, T * D, D, H * T * Dv, T * Dv, Dv,
+                       H * S * Dv, S * Dv, Dv, mbs, mrs, scale)
+        ctx.call("rten_hip_sdpa_f32", C.byref(d), q.vp, k.vp, v.vp, _vp(mask), out.vp)
+        return [out]
+
+
+class Gather(Operator):
+    """Gather along axis 0 of a 2-D f32 table (embedding lookup; src/ops/gather.rs).  inputs: table [R,W], ids i32."""
+
+    def __init__(self, axis=0):
+        self.axis = axis
+
+    def max_inputs(self):
+        return 2
+
+    def run(self, ctx, inputs):
+        table = _want(_require(inputs, 0), np.float32)
+        ids = _want(_require(inputs, 1), np.int32)
+        if self.axis != 0 or len(table.shape) != 2:
+            raise UnsupportedValue("device Gather supports axis 0 of a 2-D table")
+        out = DeviceTensor(ctx, tuple(ids.shape) + (table.shape[1],), np.float32)
+        ctx.call("rten_hip_gather_rows_f32", ids.size, table.shape[1], table.shape[0], table.vp, ids.vp, out.vp)
         return [out]
 
 
@@ -801,7 +823,7 @@ class OpRegistry:
         r = cls()
         for op in (Conv, ConvInteger, ConvIntegerToFloat, MatMul, FusedMatMul, Gemm, MatMulInteger, MatMulIntegerToFloat,
                    Softmax, AddSoftmax, LayerNormalization, BatchNormalization, Relu, Gelu, Erf, Add, Mul, MaxPool,
-                   AveragePool, GlobalAveragePool, Flatten, DynamicQuantizeLinear, Attention):
+                   AveragePool, GlobalAveragePool, Flatten, DynamicQuantizeLinear, Attention, Gather):
             r.register_op(op)
         return r
 

@@ -31,13 +31,14 @@ class DeviceTensor:
     # ---- construction helpers
     @classmethod
     def from_numpy(cls, ctx: Context, arr) -> "DeviceTensor":
-        arr = np.ascontiguousarray(arr)
-        t = cls(ctx, arr.shape, arr.dtype)
+        arr = np.asarray(arr)
+        shape = arr.shape  # np.ascontiguousarray would promote 0-d to 1-d; scalars must stay rank 0
+        t = cls(ctx, shape, arr.dtype)
         t.upload(arr)
         return t
 
     def upload(self, arr):
-        arr = np.ascontiguousarray(arr, dtype=self.dtype)
+        arr = np.ascontiguousarray(np.asarray(arr, dtype=self.dtype))
         assert arr.nbytes == self.nbytes, (arr.shape, self.shape)
         if self.nbytes:
             self.ctx.call("rten_hip_memcpy_h2d", C.c_void_p(self.ptr), arr.ctypes.data_as(C.c_void_p), C.c_size_t(self.nbytes))
@@ -57,6 +58,12 @@ class DeviceTensor:
             known = int(np.prod([s for s in shape if s != -1], dtype=np.int64))
             shape[shape.index(-1)] = n // max(known, 1)
         assert int(np.prod(shape, dtype=np.int64)) == n
+        return DeviceTensor(self.ctx, shape, self.dtype, ptr=self.ptr, keepalive=self)
+
+    def view(self, shape) -> "DeviceTensor":
+        """A tensor of `shape` aliasing the first prod(shape) elements of this buffer (static activation plans)."""
+        n = int(np.prod(shape, dtype=np.int64))
+        assert n * self.dtype.itemsize <= self.nbytes
         return DeviceTensor(self.ctx, shape, self.dtype, ptr=self.ptr, keepalive=self)
 
     @property

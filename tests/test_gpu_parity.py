@@ -55,7 +55,7 @@ def gpu_gemm(ctx, a, b, c=None, alpha=1.0, beta=0.0, bias=None, bias_kind=0, act
         bd = dev(ctx, np.ascontiguousarray(b.T))
     cd = dev(ctx, c if c is not None else np.full((M, N), np.nan, np.float32))
     biasd = dev(ctx, bias) if bias is not None else None
-    d = L.GemmDesc(M, N, K, a_rs, a_cs, b_rs, b_cs, N, 1, 0, 0, 0, alpha, beta, bias_kind if bias is not None else 0, act)
+    d = L.gemm_desc(M, N, K, a_rs, a_cs, b_rs, b_cs, N, alpha=alpha, beta=beta, bias_kind=bias_kind if bias is not None else 0, act=act)
     if variant is not None:
         ctx.set_gemm_variant(variant)
     ctx.call("rten_hip_gemm_f32", C.byref(d), ad.vp, bd.vp, biasd.vp if biasd else None, cd.vp)
@@ -377,7 +377,8 @@ def test_elementwise_bit_exact(ctx):
     acc = rng.i32(1000).reshape(10, 100)
     for s in (np.array([0.37], np.float32), rng.f32(100)):
         out = DeviceTensor(ctx, acc.shape, np.float32)
-        ctx.call("rten_hip_cast_scale", acc.size, dev(ctx, acc).vp, dev(ctx, s).vp, s.size, out.vp)
+        accd, sd = dev(ctx, acc), dev(ctx, s)  # keep the device buffers alive across the async launch
+        ctx.call("rten_hip_cast_scale", acc.size, accd.vp, sd.vp, s.size, out.vp)
         bits_equal(out.numpy(), ref.cast_scale(acc, s))
 
 
@@ -425,7 +426,9 @@ def test_resnet50_end_to_end_bit_exact_and_graph_replay(ctx):
     net.forward()
     logits = net.logits.numpy()
     want, acts = omodels.resnet50_forward(net.specs, w, x, return_activations=True)
-    bits_equal(net.bufs[net.specs[-1]["dst"]].numpy().reshape(acts[net.specs[-1]["dst"]].shape), acts[net.specs[-1]["dst"]])
+    for name in ("stem", "pool", "s0b0out", "s1b3out", "s2b5out", net.specs[-1]["dst"]):
+        if name in (net.specs[-1]["dst"],):  # earlier buffers have been recycled by the static plan
+            bits_equal(net.bufs[name].numpy(), acts[name])
     bits_equal(logits, want)
     assert np.array_equal(np.argsort(-logits, 1)[:, :5], np.argsort(-want, 1)[:, :5])
     # hipGraph replay == eager
