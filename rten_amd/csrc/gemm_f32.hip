@@ -41,6 +41,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -58,7 +59,7 @@ struct GemmArgs {
     float *C;
     const float *bias;
     const float *res;
-    const int2 *lut; // im2col: per k {element offset c*HW + ky*dy*W + kx*dx, (ky*dy) | (kx*dx) << 16}; padded rows fail the bounds test
+    const i32x2 *lut; // im2col: per k {element offset c*HW + ky*dy*W + kx*dx, (ky*dy) | (kx*dx) << 16}; padded rows fail the bounds test
     int M, N, K;
     long long a_rs, a_cs, a_bs;       // A[z*a_bs + m*a_rs + k*a_cs]
     long long b_rs, b_cs, b_ns, b_bs; // B[z*b_bs + k*b_rs + (n/Pn)*b_ns + (n%Pn)*b_cs]
@@ -216,8 +217,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_kernel(const GemmArgs p
 
     // im2col LUT entries of the tile that will be prefetched next; read with scalar loads (constant address
     // space + wave-uniform row) one iteration before they are needed, so the gather never waits on them
-    typedef const __attribute__((address_space(4))) int2 *lut_ptr_t;
-    [[maybe_unused]] int2 lutE[B_ELEMS];
+    typedef const __attribute__((address_space(4))) i32x2 *lut_ptr_t;
+    [[maybe_unused]] i32x2 lutE[B_ELEMS];
     [[maybe_unused]] auto fetch_lut = [&](int kt) {
         if constexpr (BL == B_IM2COL) {
             int krow0 = kt * BK + (t / BN) * B_ELEMS;
@@ -251,11 +252,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_kernel(const GemmArgs p
             // (rten-gemm/src/im2col.rs:145-208: out-of-image -> 0)
 #pragma unroll
             for (int j = 0; j < B_ELEMS; j++) {
-                const int2 e = lutE[j];
-                const int iy = im_iy0 + (e.y & 0xffff);
-                const int ix = im_ix0 + (e.y >> 16);
+                const i32x2 e = lutE[j];
+                const int iy = im_iy0 + (e[1] & 0xffff);
+                const int ix = im_ix0 + (e[1] >> 16);
                 const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                rb[j] = buf_load1(rsB, ok ? (unsigned)(im_pix + e.x) << 2 : OOB, 0);
+                rb[j] = buf_load1(rsB, ok ? (unsigned)(im_pix + e[0]) << 2 : OOB, 0);
             }
         } else if constexpr (BL == B_SCALAR) {
             const unsigned b_soff = (unsigned)kts * b_kstep;
@@ -449,12 +450,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_kernel(const GemmArgs p
 
 // im2col lookup table: entry k -> {c*HW + ky*dy*W + kx*dx, (ky*dy) | (kx*dx) << 16}; rows >= K get an
 // offset pair that fails every bounds test.  Built once per conv geometry and cached in the context.
-__global__ void im2col_lut_kernel(int2 *lut, int K, int Kpad, int KHW, int KW, int HW, int W, int dy, int dx) {
+__global__ void im2col_lut_kernel(i32x2 *lut, int K, int Kpad, int KHW, int KW, int HW, int W, int dy, int dx) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= Kpad) return;
-    if (k >= K) { lut[k] = make_int2(0, 0xffff); return; } // dy = 65535 > any padded height
+    if (k >= K) { lut[k] = i32x2{0, 0xffff}; return; } // dy = 65535 > any padded height
     const int c = k / KHW, rem = k - c * KHW, ky = rem / KW, kx = rem - ky * KW;
-    lut[k] = make_int2(c * HW + ky * dy * W + kx * dx, (ky * dy) | ((kx * dx) << 16));
+    lut[k] = i32x2{c * HW + ky * dy * W + kx * dx, (ky * dy) | ((kx * dx) << 16)};
 }
 
 } // namespace
@@ -621,20 +622,20 @@ int32_t check_conv_desc(rten_hip_ctx *ctx, const rten_hip_conv2d_desc *d) {
 }
 
 // im2col LUT cache (per context): one table per (Cg, kh, kw, dil, H, W)
-const int2 *get_im2col_lut(rten_hip_ctx *ctx, int Cg, int kh, int kw, int dy, int dx, int H, int W) {
+const i32x2 *get_im2col_lut(rten_hip_ctx *ctx, int Cg, int kh, int kw, int dy, int dx, int H, int W) {
     char key[96];
     snprintf(key, sizeof key, "%d.%d.%d.%d.%d.%d.%d", Cg, kh, kw, dy, dx, H, W);
     auto it = ctx->luts.find(key);
-    if (it != ctx->luts.end()) return (const int2 *)it->second;
+    if (it != ctx->luts.end()) return (const i32x2 *)it->second;
     if (ctx->capturing) return nullptr; // allocation is not capturable: warm up eagerly first
     const int K = Cg * kh * kw;
     const int Kpad = ((K + BK - 1) / BK + 3) * BK; // tile and LUT prefetch run up to two tiles past the end
     void *dptr = nullptr;
-    if (hipMalloc(&dptr, (size_t)Kpad * sizeof(int2)) != hipSuccess) return nullptr;
-    hipLaunchKernelGGL(im2col_lut_kernel, dim3((Kpad + 255) / 256), dim3(256), 0, ctx->stream, (int2 *)dptr, K, Kpad, kh * kw,
+    if (hipMalloc(&dptr, (size_t)Kpad * sizeof(i32x2)) != hipSuccess) return nullptr;
+    hipLaunchKernelGGL(im2col_lut_kernel, dim3((Kpad + 255) / 256), dim3(256), 0, ctx->stream, (i32x2 *)dptr, K, Kpad, kh * kw,
                        kw, H * W, W, dy, dx);
     ctx->luts[key] = dptr;
-    return (const int2 *)dptr;
+    return (const i32x2 *)dptr;
 }
 } // namespace
 
