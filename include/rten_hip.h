@@ -245,6 +245,7 @@ typedef struct {
     int64_t o_bs, o_hs, o_rs;
     int64_t mask_batch_stride, mask_row_stride;
     float scale;
+    int32_t flush_nan_to_zero; /* 1: sdpa_head semantics (attention.rs:551); 0: the FusedMatMul -> AddSoftmax -> MatMul graph */
 } rten_hip_sdpa_desc;
 int32_t rten_hip_sdpa_f32(rten_hip_ctx *ctx, const rten_hip_sdpa_desc *desc, const float *q, const float *k,
                           const float *v, const float *mask, float *out);

@@ -26,3 +26,31 @@ def resnet50_forward(specs, weights, x, return_activations=False):
     c0 = np.broadcast_to(fc_b, (gap.shape[0], fc_w.shape[0])).astype(np.float32)
     logits = ref.gemm_f32(gap, fc_w.T, c=c0, alpha=1.0, beta=1.0)
     return (logits, acts) if return_activations else logits
+
+
+def bert_forward(cfg, w, input_ids, attention_mask, token_type_ids, lanes=ref.LANES):
+    """BERT encoder with the oracle's operators in the reference's post-fusion op order."""
+    ids = np.asarray(input_ids).reshape(-1)
+    tts = np.asarray(token_type_ids).reshape(-1)
+    B, S = np.asarray(input_ids).shape
+    H, nh = cfg.hidden, cfg.heads
+    dh = H // nh
+    m = np.asarray(attention_mask, np.float32)
+    mask = ((np.float32(1.0) - m) * np.finfo(np.float32).min).reshape(B, 1, 1, S).astype(np.float32)
+    x = ref.add(w["word"][ids], w["type"][tts])
+    x = ref.add(x, w["pos"][:S])                     # broadcast over the batch (period S*H)
+    x = ref.layer_norm(x, w["emb_ln_g"], w["emb_ln_b"], eps=cfg.eps, lanes=lanes)
+    scale = float(np.float32(1.0) / np.sqrt(np.float32(dh)))
+    for lw in w["layers"]:
+        q = ref.matmul_f32(x, lw["wq"], bias=lw["bq"]).reshape(B, S, nh, dh).transpose(0, 2, 1, 3)
+        k = ref.matmul_f32(x, lw["wk"], bias=lw["bk"]).reshape(B, S, nh, dh).transpose(0, 2, 1, 3)
+        v = ref.matmul_f32(x, lw["wv"], bias=lw["bv"]).reshape(B, S, nh, dh).transpose(0, 2, 1, 3)
+        # FusedMatMul(alpha) -> AddSoftmax (no NaN flush) -> MatMul
+        att = ref.sdpa(q, k, v, mask=mask, scale=scale, lanes=lanes, flush_nan=False)
+        att = np.ascontiguousarray(att.transpose(0, 2, 1, 3)).reshape(B * S, H)
+        y = ref.add(ref.matmul_f32(att, lw["wo"], bias=lw["bo"]), x)
+        x = ref.layer_norm(y, lw["ln1_g"], lw["ln1_b"], eps=cfg.eps, lanes=lanes)
+        h = ref.gelu(ref.matmul_f32(x, lw["w1"], bias=lw["b1"]))
+        y = ref.add(ref.matmul_f32(h, lw["w2"], bias=lw["b2"]), x)
+        x = ref.layer_norm(y, lw["ln2_g"], lw["ln2_b"], eps=cfg.eps, lanes=lanes)
+    return x

@@ -323,7 +323,7 @@ def global_average_pool(x, lanes=LANES):
 
 
 # ---------------------------------------------------------------- attention
-def sdpa(q, k, v, mask=None, scale=None, lanes=LANES):
+def sdpa(q, k, v, mask=None, scale=None, lanes=LANES, flush_nan=True):
     """softmax(scale*Q K^T + mask) V per (batch, head) (src/ops/attention.rs:518-626).
     q:[B,H,S,D] k:[B,H,T,D] v:[B,H,T,Dv]; mask: None, [B,1,1,T] or [B,1,S,T] additive f32."""
     q = _f32(q)
@@ -333,7 +333,7 @@ def sdpa(q, k, v, mask=None, scale=None, lanes=LANES):
     T = k.shape[2]
     Dv = v.shape[3]
     if scale is None:
-        scale = 1.0 / np.sqrt(np.float32(D))
+        scale = float(np.float32(1.0) / np.sqrt(np.float32(D)))  # f32 arithmetic, attention.rs:659-670
     out = np.empty((B, H, S, Dv), np.float32)
     mask_rs = 0
     if mask is not None:
@@ -341,7 +341,7 @@ def sdpa(q, k, v, mask=None, scale=None, lanes=LANES):
         assert mask.shape[0] == B and mask.shape[1] == 1 and mask.shape[3] == T
         mask_rs = T if mask.shape[2] == S and S > 1 else 0
     lib().rto_sdpa(i64(B * H), i64(S), i64(T), i64(D), i64(Dv), _p(q), _p(k), _p(v), _p(mask), i64(H), i64(mask_rs),
-                   C.c_float(scale), _p(out), C.c_int(lanes))
+                   C.c_float(scale), _p(out), C.c_int(lanes), C.c_int(1 if flush_nan else 0))
     return out
 
 

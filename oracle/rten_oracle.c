@@ -735,23 +735,23 @@ RTO_API void rto_global_avg_pool(int64_t NC, int64_t inner, const float *x, floa
  * ---------------------------------------------------------------------------------- */
 RTO_API void rto_sdpa_head(int64_t S, int64_t T, int64_t D, int64_t Dv, const float *q, const float *k,
                            const float *v, const float *mask, int64_t mask_rs, float scale, float *out,
-                           int lanes) {
+                           int lanes, int flush_nan) {
     float *scores = (float *)malloc((size_t)S * T * sizeof(float));
     rto_gemm_f32(S, T, D, q, D, 1, k, 1, D, scores, T, scale, 0.f, NULL, 0);
     for (int64_t s = 0; s < S; s++)
-        rto_softmax_row(T, scores + s * T, mask ? mask + s * mask_rs : NULL, scores + s * T, 1, lanes);
+        rto_softmax_row(T, scores + s * T, mask ? mask + s * mask_rs : NULL, scores + s * T, flush_nan, lanes);
     rto_gemm_f32(S, Dv, T, scores, T, 1, v, Dv, 1, out, Dv, 1.f, 0.f, NULL, 0);
     free(scores);
 }
 
 RTO_API void rto_sdpa(int64_t BH, int64_t S, int64_t T, int64_t D, int64_t Dv, const float *q,
                       const float *k, const float *v, const float *mask, int64_t mask_bh_div,
-                      int64_t mask_rs, float scale, float *out, int lanes) {
+                      int64_t mask_rs, float scale, float *out, int lanes, int flush_nan) {
 #pragma omp parallel for schedule(dynamic)
     for (int64_t i = 0; i < BH; i++) {
         const float *m = mask ? mask + (i / mask_bh_div) * (mask_rs ? S * T : T) : NULL;
         rto_sdpa_head(S, T, D, Dv, q + i * S * D, k + i * T * D, v + i * T * Dv, m, mask_rs, scale,
-                      out + i * S * Dv, lanes);
+                      out + i * S * Dv, lanes, flush_nan);
     }
 }
 

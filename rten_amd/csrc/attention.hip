@@ -44,11 +44,11 @@ RTEN_EXPORT int32_t rten_hip_sdpa_f32(rten_hip_ctx *ctx, const rten_hip_sdpa_des
             for (int b = 0; b < d->batch; b++) {
                 float *sb = scores + (long long)b * d->heads * d->s * d->t;
                 rc = rten_hip_softmax_f32(ctx, (int64_t)d->heads * d->s, d->t, sb, mask + (long long)b * d->mask_batch_stride, 1,
-                                          d->s, 1, sb);
+                                          d->s, d->flush_nan_to_zero, sb);
                 if (rc) return rc;
             }
         } else { // no mask, or [B,1,1,T]: addend row = r / (H*S)
-            rc = rten_hip_softmax_f32(ctx, bh * d->s, d->t, scores, mask, (int64_t)d->heads * d->s, d->batch, 1, scores);
+            rc = rten_hip_softmax_f32(ctx, bh * d->s, d->t, scores, mask, (int64_t)d->heads * d->s, d->batch, d->flush_nan_to_zero, scores);
             if (rc) return rc;
         }
     }

@@ -448,6 +448,281 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_kernel(const GemmArgs p
     }
 }
 
+
+// =====================================================================================================
+// LDS-DMA variant (conv paths: A = prepacked [K][M] weights, B = dense two-level or im2col gather).
+//
+// Tiles go HBM/L2 -> LDS directly (`buffer_load_dword[x4] ... offen lds`): no staging VGPRs, no ds_write
+// pass, and three LDS stages keep TWO k-tiles in flight behind the one being multiplied, so the
+// ~1200-cycle load latency hides under the matrix pipe even when only one or two workgroups fit on a CU.
+// Per k-tile: counted `s_waitcnt vmcnt(N)` (never 0 inside the loop) -> raw s_barrier -> issue the DMA of
+// tile kt+2 into the stage that was just freed -> MFMAs of tile kt (operand fragments double buffered in
+// registers so ds_read latency overlaps the previous MFMA group).  All LDS lives in ONE __shared__
+// array (a second object would make hipcc drain vmcnt before every ds_read -- cdna_hip_programming.md).
+// LDS image: As[BK][BM], Bs[BK][BN] unpadded (DMA writes are lane-linear); MFMA operand reads walk
+// consecutive columns, so they are conflict-free without padding.
+// =====================================================================================================
+constexpr int NSTAGE = 3;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int BL, bool MULTI_KC>
+__global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmArgs p) {
+    static_assert(BL == B_N4 || BL == B_IM2COL, "DMA kernel covers the conv operand layouts");
+    constexpr int WM = 2, WN = 2;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int STAGE = BK * (BM + BN); // floats per stage
+    constexpr int NA = BK * BM / 256 / 4; // dwordx4 DMA instructions per wave per tile (A)
+    constexpr int NBV = BK * BN / 256 / 4; // dwordx4 (dense B)
+    constexpr int NBG = BK * BN / 64 / 4;  // dword gathers per wave per tile (im2col B)
+    constexpr int PER_TILE = NA + (BL == B_N4 ? NBV : NBG);
+    static_assert(NA >= 1 && NBV >= 1, "tile too small for 4-wave DMA split");
+    __shared__ __attribute__((aligned(16))) float smem[NSTAGE * STAGE];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int z = blockIdx.y;
+
+    int tile;
+    {
+        const int nt = p.tiles_m * p.tiles_n;
+        const int id = blockIdx.x;
+        const int xcd = id & 7, q = nt >> 3, r = nt & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    }
+    const int bm = tile % p.tiles_m, bn = tile / p.tiles_m;
+    const int m0 = bm * BM, n0 = bn * BN;
+
+    int zo = z, zi = 0;
+    if (p.batch_inner > 1) { zo = z / p.batch_inner; zi = z - zo * p.batch_inner; }
+    const float *Ab = p.A + (long long)zo * p.a_bs + (long long)zi * p.a_bsi;
+    const float *Bb = p.B + (long long)zo * p.b_bs + (long long)zi * p.b_bsi;
+    const long long c_zoff = (long long)zo * p.c_bs + (long long)zi * p.c_bsi;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)Ab, 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void *)Bb, 0, (int)p.b_bytes, 0x00020000);
+    const int nk = (p.K + BK - 1) / BK;
+
+    // ---- loop-invariant DMA source offsets.  Wave w issues instructions q = w*N + j; instruction q covers
+    // the flat tile range [q*256, q*256+256) floats (dwordx4) or [q*64, q*64+64) (dword gather).
+    unsigned a_voff[NA];
+#pragma unroll
+    for (int j = 0; j < NA; j++) {
+        const int f = (wave * NA + j) * 256 + lane * 4;
+        const int k = f / BM, m = m0 + f % BM;
+        // rows >= K lie past the end of the [K][M4] buffer (hardware range check); columns >= M4 must not wrap
+        a_voff[j] = m < (int)p.a_cs ? (unsigned)(((long long)k * p.a_cs + m) * 4) : OOB;
+    }
+    const unsigned a_kstep = (unsigned)(BK * p.a_cs * 4);
+
+    [[maybe_unused]] unsigned b_voff[BL == B_N4 ? NBV : 1];
+    [[maybe_unused]] int b_krow[BL == B_N4 ? NBV : 1];
+    [[maybe_unused]] unsigned b_kstep = 0;
+    [[maybe_unused]] int im_iy0[BL == B_IM2COL && BN == 128 ? 2 : 1], im_ix0[BL == B_IM2COL && BN == 128 ? 2 : 1],
+        im_pix[BL == B_IM2COL && BN == 128 ? 2 : 1];
+    if constexpr (BL == B_N4) {
+#pragma unroll
+        for (int j = 0; j < NBV; j++) {
+            const int f = (wave * NBV + j) * 256 + lane * 4;
+            const int k = f / BN, n = n0 + f % BN;
+            const int nn = n < p.N ? n : 0;
+            const int nb = nn / p.Pn, np = nn - nb * p.Pn;
+            b_krow[j] = k;
+            b_voff[j] = n < p.N ? (unsigned)(((long long)k * p.b_rs + (long long)nb * p.b_ns + np) * 4) : OOB;
+        }
+        b_kstep = (unsigned)(BK * p.b_rs * 4);
+    } else {
+        // gather instruction q = wave*NBG + j covers row q / (BN/64), columns (q % (BN/64))*64 + lane.
+        // A lane therefore sees at most BN/64 distinct columns.
+#pragma unroll
+        for (int c = 0; c < BN / 64; c++) {
+            const int n = n0 + c * 64 + lane;
+            const bool ok = n < p.N;
+            const int nn = ok ? n : 0;
+            const int nb = nn / p.Pn, np = nn - nb * p.Pn;
+            const int oy = np / p.OW, ox = np - oy * p.OW;
+            im_iy0[c] = ok ? oy * p.sy - p.pt : -0x40000000;
+            im_ix0[c] = ox * p.sx - p.pl;
+            im_pix[c] = (int)((long long)nb * p.b_ns) + (oy * p.sy - p.pt) * p.W + im_ix0[c];
+        }
+    }
+
+    // im2col LUT entries (scalar loads) for the tile whose DMA is issued NEXT
+    typedef const __attribute__((address_space(4))) i32x2 *lut_ptr_t;
+    constexpr int LROWS = BK / 4; // rows of a tile handled by one wave (NBG / (BN/64))
+    [[maybe_unused]] i32x2 lutE[LROWS];
+    [[maybe_unused]] auto fetch_lut = [&](int kt) {
+        if constexpr (BL == B_IM2COL) {
+            const int krow0 = kt * BK + wave * LROWS;
+            const lut_ptr_t lc = (lut_ptr_t)(unsigned long long)p.lut;
+#pragma unroll
+            for (int j = 0; j < LROWS; j++) lutE[j] = lc[krow0 + j];
+        }
+    };
+
+    typedef __attribute__((address_space(3))) void *lds_ptr_t;
+    auto issue_tile = [&](int kt, int stage) {
+        float *As = smem + stage * STAGE;
+        float *Bs = As + BK * BM;
+        const int kts = kt < nk ? kt : (nk > 0 ? nk - 1 : 0); // keep the scalar offset inside the buffer
+        const bool past = kt >= nk;
+        const unsigned a_soff = (unsigned)kts * a_kstep;
+#pragma unroll
+        for (int j = 0; j < NA; j++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(As + (wave * NA + j) * 256), 16,
+                                                     (int)(past ? OOB : a_voff[j]), (int)a_soff, 0, 0);
+        if constexpr (BL == B_N4) {
+            const int kleft = p.K - kt * BK;
+            const unsigned b_soff = (unsigned)kts * b_kstep;
+#pragma unroll
+            for (int j = 0; j < NBV; j++)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(Bs + (wave * NBV + j) * 256), 16,
+                                                         (int)(b_krow[j] < kleft ? b_voff[j] : OOB), (int)b_soff, 0, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NBG; j++) {
+                constexpr int CPR = BN / 64;            // gather instructions per tile row
+                const int r = j / CPR, c = j % CPR;     // row within this wave's LROWS, column chunk
+                const i32x2 e = lutE[r];
+                const int iy = im_iy0[c] + (e[1] & 0xffff);
+                const int ix = im_ix0[c] + (e[1] >> 16);
+                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(Bs + (wave * LROWS + r) * BN + c * 64), 4,
+                                                         (int)(ok ? (unsigned)(im_pix[c] + e[0]) << 2 : OOB), 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- accumulators / epilogue helpers (same numerics as igemm_f32_kernel)
+    const int wq = t >> 6; // per-lane copy of the wave id for address math
+    const int wm0 = (wq / WN) * (BM / WM), wn0 = (wq % WN) * (BN / WN);
+    f32x16 acc[TM][TN];
+    [[maybe_unused]] f32x16 tot[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    const float *__restrict__ biasb = p.bias ? p.bias + (long long)z * p.bias_bs : nullptr;
+    auto first_value = [&](float a, int m, long long ccol, int cn, bool cok) -> float {
+        float cin = 0.f;
+        if (p.beta != 0.f && m < p.M && cok) cin = p.C[ccol + (long long)m * p.c_rs];
+        float v = combine(a, cin, p.alpha, p.beta);
+        if (p.bias_kind == RTEN_HIP_BIAS_PER_ROW) {
+            if (m < p.M) v = v + biasb[m];
+        } else if (p.bias_kind == RTEN_HIP_BIAS_PER_COL) {
+            if (cok) v = v + biasb[cn];
+        }
+        return v;
+    };
+    auto col_offset = [&](int n) -> long long {
+        const int nn = n < p.N ? n : 0;
+        const int nb = nn / p.Pn, np = nn - nb * p.Pn;
+        return c_zoff + (long long)nb * p.c_ns + np;
+    };
+    [[maybe_unused]] auto flush = [&](bool first) {
+        int mb = m0 + wm0 + 4 * half, nb0 = n0 + wn0 + l31;
+        asm volatile("" : "+v"(mb), "+v"(nb0));
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int n = nb0 + j * 32;
+            const bool cok = n < p.N;
+            const long long ccol = first ? col_offset(n) : 0;
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int m = mb + i * 32 + (r & 3) + 8 * (r >> 2);
+                    tot[i][j][r] = first ? first_value(acc[i][j][r], m, ccol, n, cok)
+                                         : combine(acc[i][j][r], tot[i][j][r], p.alpha, 1.f);
+                    acc[i][j][r] = 0.f;
+                }
+        }
+    };
+
+    auto compute_tile = [&](int stage) {
+        const float *As = smem + stage * STAGE + wm0 + l31;
+        const float *Bs = smem + stage * STAGE + BK * BM + wn0 + l31;
+        float af[2][TM], bf[2][TN]; // operand fragments, double buffered across k-pairs
+#pragma unroll
+        for (int i = 0; i < TM; i++) af[0][i] = As[half * BM + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; j++) bf[0][j] = Bs[half * BN + j * 32];
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; kk++) {
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < BK / 2) {
+#pragma unroll
+                for (int i = 0; i < TM; i++) af[nxt][i] = As[(2 * (kk + 1) + half) * BM + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; j++) bf[nxt][j] = Bs[(2 * (kk + 1) + half) * BN + j * 32];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // ---- software pipeline: tiles kt+1 and kt+2 are in flight while tile kt is multiplied
+    fetch_lut(0);
+    issue_tile(0, 0);
+    fetch_lut(1);
+    issue_tile(1, 1);
+    fetch_lut(2);
+    const int nblk = MULTI_KC ? (nk + KC_TILES - 1) / KC_TILES : 1;
+    int stage = 0;
+    for (int blk = 0; blk < nblk; blk++) {
+        const int kt_end = MULTI_KC ? ((blk + 1) * KC_TILES < nk ? (blk + 1) * KC_TILES : nk) : nk;
+        for (int kt = blk * KC_TILES; kt < kt_end; kt++) {
+            wait_vmcnt<PER_TILE>();       // this wave's DMA for tile kt has landed (tile kt+1 may still be in flight)
+            __builtin_amdgcn_s_barrier(); // ... and everyone else's; all waves are done reading stage (kt+2)%3
+            const int st2 = stage == 0 ? 2 : stage - 1; // (kt + 2) % 3
+            issue_tile(kt + 2, st2);
+            fetch_lut(kt + 3);
+            compute_tile(stage);
+            stage = stage == 2 ? 0 : stage + 1;
+        }
+        if constexpr (MULTI_KC) {
+            if (blk + 1 < nblk) flush(blk == 0);
+        }
+    }
+    wait_vmcnt<0>(); // drain the two (out-of-range, zero-filling) look-ahead tiles before the LDS goes away
+
+    const float *__restrict__ resb = p.res;
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int n = n0 + wn0 + j * 32 + l31;
+        const bool cok = n < p.N;
+        const long long ccol = col_offset(n);
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                float v;
+                if constexpr (MULTI_KC) {
+                    v = (nblk > 1) ? combine(acc[i][j][r], tot[i][j][r], p.alpha, 1.f) : first_value(acc[i][j][r], m, ccol, n, cok);
+                } else {
+                    v = first_value(acc[i][j][r], m, ccol, n, cok);
+                }
+                if (m < p.M && cok) {
+                    const long long off = ccol + (long long)m * p.c_rs;
+                    if (resb) v = v + resb[off];
+                    if (p.act == RTEN_HIP_ACT_RELU) v = vm::relu(v);
+                    else if (p.act == RTEN_HIP_ACT_GELU) v = vm::gelu(v);
+                    p.C[off] = v;
+                }
+            }
+    }
+}
+
 // im2col lookup table: entry k -> {c*HW + ky*dy*W + kx*dx, (ky*dy) | (kx*dx) << 16}; rows >= K get an
 // offset pair that fails every bounds test.  Built once per conv geometry and cached in the context.
 __global__ void im2col_lut_kernel(i32x2 *lut, int K, int Kpad, int KHW, int KW, int HW, int W, int dy, int dx) {
@@ -478,6 +753,19 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
     const double bytes = 4.0 * Z * ((double)a.M * a.K + (double)a.K * a.N + (double)a.M * a.N);
     char kname[96];
     const bool multi = a.K > 256;
+    constexpr bool kDma = AL == A_M4 && (BL == B_N4 || BL == B_IM2COL);
+    if constexpr (kDma) {
+        if (ctx->use_dma) {
+            snprintf(kname, sizeof kname, "igemm_f32_dma_kernel<%d,%d,%d,%d>", BM, BN, BL, multi ? 1 : 0);
+            ProfScope ps(ctx, kname, flops, bytes);
+            if (multi)
+                hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, BL, true>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+            else
+                hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, BL, false>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+            RTEN_LAUNCH_CHECK(ctx, "igemm_f32_dma_kernel launch");
+            return RTEN_HIP_OK;
+        }
+    }
     snprintf(kname, sizeof kname, "igemm_f32_kernel<%d,%d,%d,%d,%d>", BM, BN, AL, BL, multi ? 1 : 0);
     ProfScope ps(ctx, kname, flops, bytes);
     if (multi)
@@ -499,7 +787,7 @@ int32_t launch_variant(rten_hip_ctx *ctx, GemmArgs &a, int Z, int cfg) {
 }
 
 int pick_cfg(rten_hip_ctx *ctx, int M, long long N, int Z) {
-    if (ctx->gemm_variant_override >= 0 && ctx->gemm_variant_override < 4) return ctx->gemm_variant_override;
+    if (ctx->gemm_variant_override >= 0 && ctx->gemm_variant_override < 8) return ctx->gemm_variant_override & 3;
     int best = 3;
     double best_cost = 1e300;
     for (int c = 0; c < 4; c++) {
@@ -534,11 +822,14 @@ constexpr long long kMaxBufBytes = 0x7fffffffll; // buffer offsets are 32-bit; t
 
 } // namespace
 
-RTEN_EXPORT int32_t rten_hip_num_gemm_variants(void) { return 4; }
+// Variants 0..3: tile shapes {128x128, 128x64, 64x128, 64x64} with the LDS-DMA pipeline on the conv paths;
+// variants 4..7: the same tile shapes with the register-staged pipeline (kept for A/B measurement).
+RTEN_EXPORT int32_t rten_hip_num_gemm_variants(void) { return 8; }
 
 RTEN_EXPORT int32_t rten_hip_set_gemm_variant_override(rten_hip_ctx *ctx, int32_t variant) {
     RTEN_CHECK_CTX(ctx);
     ctx->gemm_variant_override = variant;
+    ctx->use_dma = !(variant >= 4 && variant < 8);
     return RTEN_HIP_OK;
 }
 
@@ -629,7 +920,7 @@ const i32x2 *get_im2col_lut(rten_hip_ctx *ctx, int Cg, int kh, int kw, int dy, i
     if (it != ctx->luts.end()) return (const i32x2 *)it->second;
     if (ctx->capturing) return nullptr; // allocation is not capturable: warm up eagerly first
     const int K = Cg * kh * kw;
-    const int Kpad = ((K + BK - 1) / BK + 3) * BK; // tile and LUT prefetch run up to two tiles past the end
+    const int Kpad = ((K + BK - 1) / BK + 4) * BK; // tile / LUT look-ahead runs up to three tiles past the end
     void *dptr = nullptr;
     if (hipMalloc(&dptr, (size_t)Kpad * sizeof(i32x2)) != hipSuccess) return nullptr;
     hipLaunchKernelGGL(im2col_lut_kernel, dim3((Kpad + 255) / 256), dim3(256), 0, ctx->stream, (i32x2 *)dptr, K, Kpad, kh * kw,

@@ -55,7 +55,8 @@ class SdpaDesc(C.Structure):
                 ("k_bs", C.c_int64), ("k_hs", C.c_int64), ("k_rs", C.c_int64),
                 ("v_bs", C.c_int64), ("v_hs", C.c_int64), ("v_rs", C.c_int64),
                 ("o_bs", C.c_int64), ("o_hs", C.c_int64), ("o_rs", C.c_int64),
-                ("mask_batch_stride", C.c_int64), ("mask_row_stride", C.c_int64), ("scale", C.c_float)]
+                ("mask_batch_stride", C.c_int64), ("mask_row_stride", C.c_int64), ("scale", C.c_float),
+                ("flush_nan_to_zero", C.c_int32)]
 
 
 class GemmInt8Desc(C.Structure):

@@ -1,0 +1,128 @@
+"""BERT-base encoder (BASELINE config 4: f32, seq 128, batch 32) as the RTen executor sees it after its
+fusion passes, on the HIP backend:
+
+    LayerNormalization(Gather(word) + Gather(type) + pos)                         embeddings
+    per layer:  FusedMatMul(x, Wq|Wk|Wv, bias)                                    (MatMulAddFusion)
+                FusedMatMul(Q, K^T, alpha=1/sqrt(d)) -> AddSoftmax(mask) -> MatMul(P, V)   (MatMulScale / AddSoftmax fusions)
+                FusedMatMul(ctx, Wo, bias) -> Add(residual) -> LayerNormalization
+                FusedMatMul(x, W1, bias) -> Gelu -> FusedMatMul(h, W2, bias) -> Add -> LayerNormalization
+
+On the device the Reshape/Transpose nodes around attention are stride arithmetic (rten_hip_sdpa_f32 reads the
+[B*S, H*d] projection outputs in place, TransposeFusion's GPU analogue) and Gelu is fused into the FFN-1 GEMM
+epilogue.  Weights are synthetic (normal(0, 0.02), seed 1234): there is no network for checkpoints.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .. import lib as L
+from ..tensor import DeviceTensor
+
+
+class BertConfig:
+    def __init__(self, hidden=768, heads=12, layers=12, ffn=3072, vocab=30522, max_pos=512, type_vocab=2, eps=1e-12):
+        self.hidden, self.heads, self.layers, self.ffn = hidden, heads, layers, ffn
+        self.vocab, self.max_pos, self.type_vocab, self.eps = vocab, max_pos, type_vocab, eps
+        assert hidden % heads == 0
+
+
+def make_weights(cfg: BertConfig, seed=1234):
+    rng = np.random.default_rng(seed)
+
+    def n(*s, std=0.02):
+        return rng.normal(0.0, std, s).astype(np.float32)
+    w = {"word": n(cfg.vocab, cfg.hidden), "pos": n(cfg.max_pos, cfg.hidden), "type": n(cfg.type_vocab, cfg.hidden),
+         "emb_ln_g": (1 + n(cfg.hidden, std=0.1)), "emb_ln_b": n(cfg.hidden, std=0.1), "layers": []}
+    for _ in range(cfg.layers):
+        w["layers"].append({
+            "wq": n(cfg.hidden, cfg.hidden), "bq": n(cfg.hidden), "wk": n(cfg.hidden, cfg.hidden), "bk": n(cfg.hidden),
+            "wv": n(cfg.hidden, cfg.hidden), "bv": n(cfg.hidden), "wo": n(cfg.hidden, cfg.hidden), "bo": n(cfg.hidden),
+            "ln1_g": (1 + n(cfg.hidden, std=0.1)), "ln1_b": n(cfg.hidden, std=0.1),
+            "w1": n(cfg.hidden, cfg.ffn), "b1": n(cfg.ffn), "w2": n(cfg.ffn, cfg.hidden), "b2": n(cfg.hidden),
+            "ln2_g": (1 + n(cfg.hidden, std=0.1)), "ln2_b": n(cfg.hidden, std=0.1)})
+    return w
+
+
+def additive_mask(attention_mask):
+    """HF-style extended mask: (1 - mask) * finfo(f32).min, shape [B,1,1,S] (graph input preprocessing)."""
+    m = np.asarray(attention_mask, np.float32)
+    return ((np.float32(1.0) - m) * np.finfo(np.float32).min).reshape(m.shape[0], 1, 1, m.shape[1]).astype(np.float32)
+
+
+def flops_per_sequence(cfg: BertConfig, seq):
+    h, f = cfg.hidden, cfg.ffn
+    per_layer = 2 * seq * h * h * 4 + 2 * seq * h * f * 2 + 2 * 2 * seq * seq * h
+    return cfg.layers * per_layer
+
+
+class Bert:
+    """Device-resident BERT encoder forward for a fixed (batch, seq)."""
+
+    def __init__(self, ctx, cfg: BertConfig, batch, seq, weights=None):
+        self.ctx, self.cfg, self.B, self.S = ctx, cfg, batch, seq
+        self.weights = weights if weights is not None else make_weights(cfg)
+        self.graph = None
+        w = self.weights
+        up = lambda a: DeviceTensor.from_numpy(ctx, a)
+        self.d = {k: up(w[k]) for k in ("word", "pos", "type", "emb_ln_g", "emb_ln_b")}
+        self.dl = [{k: up(v) for k, v in lw.items()} for lw in w["layers"]]
+        T, H = batch * seq, cfg.hidden
+        f32 = np.float32
+        self.ids = DeviceTensor(ctx, (T,), np.int32)
+        self.tts = DeviceTensor(ctx, (T,), np.int32)
+        self.mask = DeviceTensor(ctx, (batch, 1, 1, seq), f32)
+        self.x = DeviceTensor(ctx, (T, H), f32)
+        self.tmp = DeviceTensor(ctx, (T, H), f32)
+        self.q, self.k, self.v, self.att = (DeviceTensor(ctx, (T, H), f32) for _ in range(4))
+        self.h = DeviceTensor(ctx, (T, cfg.ffn), f32)
+        dh = H // cfg.heads
+        scale = float(np.float32(1.0) / np.sqrt(np.float32(dh)))
+        self.sdpa_desc = L.SdpaDesc(batch, cfg.heads, seq, seq, dh, dh, seq * H, dh, H, seq * H, dh, H, seq * H, dh, H,
+                                    seq * H, dh, H, seq, 0, scale, 0)
+
+    def set_inputs(self, input_ids, attention_mask, token_type_ids):
+        self.ids.upload(np.asarray(input_ids, np.int32).reshape(-1))
+        self.tts.upload(np.asarray(token_type_ids, np.int32).reshape(-1))
+        self.mask.upload(additive_mask(attention_mask))
+
+    def _linear(self, x, w, b, out, n, k, act=L.ACT_NONE):
+        d = L.gemm_desc(self.B * self.S, n, k, k, 1, n, 1, n, bias_kind=L.BIAS_PER_COL, act=act)
+        self.ctx.call("rten_hip_gemm_f32", C.byref(d), x.vp, w.vp, b.vp, out.vp)
+
+    def forward(self):
+        ctx, cfg, T, H = self.ctx, self.cfg, self.B * self.S, self.cfg.hidden
+        d = self.d
+        # embeddings: (word[ids] + type[tt]) + pos[0:S], then LayerNorm
+        ctx.call("rten_hip_gather_rows_f32", T, H, cfg.vocab, d["word"].vp, self.ids.vp, self.x.vp)
+        ctx.call("rten_hip_gather_rows_f32", T, H, cfg.type_vocab, d["type"].vp, self.tts.vp, self.tmp.vp)
+        ctx.call("rten_hip_add_f32", T * H, self.x.vp, self.tmp.vp, T * H, self.x.vp)
+        ctx.call("rten_hip_add_f32", T * H, self.x.vp, d["pos"].vp, self.S * H, self.x.vp)
+        ctx.call("rten_hip_layer_norm_f32", T, H, self.x.vp, d["emb_ln_g"].vp, d["emb_ln_b"].vp, 1.0, 0.0, cfg.eps, self.x.vp)
+        for lw in self.dl:
+            self._linear(self.x, lw["wq"], lw["bq"], self.q, H, H)
+            self._linear(self.x, lw["wk"], lw["bk"], self.k, H, H)
+            self._linear(self.x, lw["wv"], lw["bv"], self.v, H, H)
+            ctx.call("rten_hip_sdpa_f32", C.byref(self.sdpa_desc), self.q.vp, self.k.vp, self.v.vp, self.mask.vp, self.att.vp)
+            self._linear(self.att, lw["wo"], lw["bo"], self.tmp, H, H)
+            ctx.call("rten_hip_add_f32", T * H, self.tmp.vp, self.x.vp, T * H, self.tmp.vp)
+            ctx.call("rten_hip_layer_norm_f32", T, H, self.tmp.vp, lw["ln1_g"].vp, lw["ln1_b"].vp, 1.0, 0.0, cfg.eps, self.x.vp)
+            self._linear(self.x, lw["w1"], lw["b1"], self.h, cfg.ffn, H, act=L.ACT_GELU)
+            self._linear(self.h, lw["w2"], lw["b2"], self.tmp, H, cfg.ffn)
+            ctx.call("rten_hip_add_f32", T * H, self.tmp.vp, self.x.vp, T * H, self.tmp.vp)
+            ctx.call("rten_hip_layer_norm_f32", T, H, self.tmp.vp, lw["ln2_g"].vp, lw["ln2_b"].vp, 1.0, 0.0, cfg.eps, self.x.vp)
+        return self.x  # last_hidden_state [B*S, H]
+
+    def capture(self):
+        self.forward()
+        self.ctx.sync()
+        self.ctx.graph_begin()
+        self.forward()
+        self.graph = self.ctx.graph_end()
+
+    def run(self):
+        if self.graph:
+            self.ctx.graph_launch(self.graph)
+        else:
+            self.forward()

@@ -788,7 +788,7 @@ class Attention(Operator):
                 raise UnsupportedValue("mask must be [B,1,1,T] or [B,1,S,T]")
         out = DeviceTensor(ctx, (B, H, S, Dv), np.float32)
         d = L.SdpaDesc(B, H, S, T, D, Dv, H * S * D, S * D, D, H * T * D, T * D, D, H * T * Dv, T * Dv, Dv,
-                       H * S * Dv, S * Dv, Dv, mbs, mrs, scale)
+                       H * S * Dv, S * Dv, Dv, mbs, mrs, scale, 1)
         ctx.call("rten_hip_sdpa_f32", C.byref(d), q.vp, k.vp, v.vp, _vp(mask), out.vp)
         return [out]
 

@@ -80,7 +80,7 @@ def test_gemm_f32_all_tile_variants_agree(ctx):
     a = rng.f32(200 * 520).reshape(200, 520) - 0.5
     b = rng.f32(520 * 264).reshape(520, 264) - 0.5
     want = ref.gemm_f32(a, b)
-    for v in range(4):
+    for v in range(ctx.lib.rten_hip_num_gemm_variants()):
         bits_equal(gpu_gemm(ctx, a, b, variant=v), want)
 
 
@@ -214,7 +214,7 @@ def test_conv_f32_resnet_layer_shapes_all_variants(ctx, shape):
     w = (rng.f32(O * Cc * k * k).reshape(O, Cc, k, k) - 0.5) * 0.1
     b = rng.f32(O) - 0.5
     want = ref.conv2d_f32(x, w, b, pads=(pad,) * 4, strides=(s, s), relu=True)
-    for v in range(4):
+    for v in range(ctx.lib.rten_hip_num_gemm_variants()):  # 0..3 LDS-DMA pipeline, 4..7 register-staged
         bits_equal(gpu_conv(ctx, x, w, b, (pad,) * 4, (s, s), relu=True, variant=v), want)
 
 
@@ -457,3 +457,25 @@ def test_resnet50_batch32_batch_independence(ctx):
     assert np.isfinite(logits).all()
     for i in (0, 13, 31):
         bits_equal(logits[i:i + 1], omodels.resnet50_forward(net.specs, w, x[i:i + 1]) if False else omodels.resnet50_forward(net.specs, w, np.concatenate([x[i:i + 1], x[i:i + 1]]))[:1])
+
+
+def test_bert_encoder_bit_exact(ctx):
+    # BASELINE config 4 topology (reduced width/depth so the oracle finishes in seconds) + one full-width layer
+    from oracle import models as omodels
+    from rten_amd.models import bert
+    for cfg, B, S in ((bert.BertConfig(hidden=128, heads=4, layers=2, ffn=256, vocab=1000, max_pos=64), 3, 40),
+                      (bert.BertConfig(hidden=768, heads=12, layers=1, ffn=3072, vocab=2000, max_pos=128), 2, 128)):
+        w = bert.make_weights(cfg)
+        rng = np.random.default_rng(5)
+        ids = rng.integers(0, cfg.vocab, (B, S))
+        tts = rng.integers(0, 2, (B, S))
+        am = np.ones((B, S), np.float32)
+        am[0, S - 7:] = 0  # padded tail on one sequence
+        net = bert.Bert(ctx, cfg, B, S, w)
+        net.set_inputs(ids, am, tts)
+        got = net.forward().numpy()
+        want = omodels.bert_forward(cfg, w, ids, am, tts)
+        bits_equal(got, want)
+        net.capture()
+        net.run()
+        bits_equal(net.x.numpy(), want)
