@@ -723,6 +723,277 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
     }
 }
 
+template <int BM, int BN, int BL, bool MULTI_KC>
+__global__ __launch_bounds__(2 * NTHREADS, 2) void igemm_f32_ws_kernel(const GemmArgs p) {
+    static_assert(BL == B_N4 || BL == B_IM2COL, "DMA kernel covers the conv operand layouts");
+    constexpr int WM = 2, WN = 2;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int STAGE = BK * (BM + BN); // floats per stage
+    constexpr int NA = BK * BM / 256 / 4; // dwordx4 DMA instructions per wave per tile (A)
+    constexpr int NBV = BK * BN / 256 / 4; // dwordx4 (dense B)
+    constexpr int NBG = BK * BN / 64 / 4;  // dword gathers per wave per tile (im2col B)
+    constexpr int PER_TILE = NA + (BL == B_N4 ? NBV : NBG);
+    static_assert(NA >= 1 && NBV >= 1, "tile too small for 4-wave DMA split");
+    __shared__ __attribute__((aligned(16))) float smem[NSTAGE * STAGE];
+
+    // 8 waves: 0..3 multiply (one per SIMD), 4..7 are loader waves that only issue LDS-DMA.  The two roles share
+    // each SIMD, so address arithmetic / DMA issue of the loader overlaps the MFMA wave's matrix-pipe time even
+    // when this is the only workgroup on the CU.
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(t >> 6);
+    const bool is_loader = wave_all >= 4;
+    const int wave = wave_all & 3; // loader index or MFMA wave index
+    const int l31 = lane & 31, half = lane >> 5;
+    const int z = blockIdx.y;
+
+    int tile;
+    {
+        const int nt = p.tiles_m * p.tiles_n;
+        const int id = blockIdx.x;
+        const int xcd = id & 7, q = nt >> 3, r = nt & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    }
+    const int bm = tile % p.tiles_m, bn = tile / p.tiles_m;
+    const int m0 = bm * BM, n0 = bn * BN;
+
+    int zo = z, zi = 0;
+    if (p.batch_inner > 1) { zo = z / p.batch_inner; zi = z - zo * p.batch_inner; }
+    const float *Ab = p.A + (long long)zo * p.a_bs + (long long)zi * p.a_bsi;
+    const float *Bb = p.B + (long long)zo * p.b_bs + (long long)zi * p.b_bsi;
+    const long long c_zoff = (long long)zo * p.c_bs + (long long)zi * p.c_bsi;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)Ab, 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void *)Bb, 0, (int)p.b_bytes, 0x00020000);
+    const int nk = (p.K + BK - 1) / BK;
+
+    // ---- loop-invariant DMA source offsets.  Wave w issues instructions q = w*N + j; instruction q covers
+    // the flat tile range [q*256, q*256+256) floats (dwordx4) or [q*64, q*64+64) (dword gather).
+    unsigned a_voff[NA];
+#pragma unroll
+    for (int j = 0; j < NA; j++) {
+        const int f = (wave * NA + j) * 256 + lane * 4;
+        const int k = f / BM, m = m0 + f % BM;
+        // rows >= K lie past the end of the [K][M4] buffer (hardware range check); columns >= M4 must not wrap
+        a_voff[j] = m < (int)p.a_cs ? (unsigned)(((long long)k * p.a_cs + m) * 4) : OOB;
+    }
+    const unsigned a_kstep = (unsigned)(BK * p.a_cs * 4);
+
+    [[maybe_unused]] unsigned b_voff[BL == B_N4 ? NBV : 1];
+    [[maybe_unused]] int b_krow[BL == B_N4 ? NBV : 1];
+    [[maybe_unused]] unsigned b_kstep = 0;
+    [[maybe_unused]] int im_iy0[BL == B_IM2COL && BN == 128 ? 2 : 1], im_ix0[BL == B_IM2COL && BN == 128 ? 2 : 1],
+        im_pix[BL == B_IM2COL && BN == 128 ? 2 : 1];
+    if constexpr (BL == B_N4) {
+#pragma unroll
+        for (int j = 0; j < NBV; j++) {
+            const int f = (wave * NBV + j) * 256 + lane * 4;
+            const int k = f / BN, n = n0 + f % BN;
+            const int nn = n < p.N ? n : 0;
+            const int nb = nn / p.Pn, np = nn - nb * p.Pn;
+            b_krow[j] = k;
+            b_voff[j] = n < p.N ? (unsigned)(((long long)k * p.b_rs + (long long)nb * p.b_ns + np) * 4) : OOB;
+        }
+        b_kstep = (unsigned)(BK * p.b_rs * 4);
+    } else {
+        // gather instruction q = wave*NBG + j covers row q / (BN/64), columns (q % (BN/64))*64 + lane.
+        // A lane therefore sees at most BN/64 distinct columns.
+#pragma unroll
+        for (int c = 0; c < BN / 64; c++) {
+            const int n = n0 + c * 64 + lane;
+            const bool ok = n < p.N;
+            const int nn = ok ? n : 0;
+            const int nb = nn / p.Pn, np = nn - nb * p.Pn;
+            const int oy = np / p.OW, ox = np - oy * p.OW;
+            im_iy0[c] = ok ? oy * p.sy - p.pt : -0x40000000;
+            im_ix0[c] = ox * p.sx - p.pl;
+            im_pix[c] = (int)((long long)nb * p.b_ns) + (oy * p.sy - p.pt) * p.W + im_ix0[c];
+        }
+    }
+
+    // im2col LUT entries (scalar loads) for the tile whose DMA is issued NEXT
+    typedef const __attribute__((address_space(4))) i32x2 *lut_ptr_t;
+    constexpr int LROWS = BK / 4; // rows of a tile handled by one wave (NBG / (BN/64))
+    [[maybe_unused]] i32x2 lutE[LROWS];
+    [[maybe_unused]] auto fetch_lut = [&](int kt) {
+        if constexpr (BL == B_IM2COL) {
+            const int krow0 = kt * BK + wave * LROWS;
+            const lut_ptr_t lc = (lut_ptr_t)(unsigned long long)p.lut;
+#pragma unroll
+            for (int j = 0; j < LROWS; j++) lutE[j] = lc[krow0 + j];
+        }
+    };
+
+    typedef __attribute__((address_space(3))) void *lds_ptr_t;
+    auto issue_tile = [&](int kt, int stage) {
+        float *As = smem + stage * STAGE;
+        float *Bs = As + BK * BM;
+        const int kts = kt < nk ? kt : (nk > 0 ? nk - 1 : 0); // keep the scalar offset inside the buffer
+        const bool past = kt >= nk;
+        const unsigned a_soff = (unsigned)kts * a_kstep;
+#pragma unroll
+        for (int j = 0; j < NA; j++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(As + (wave * NA + j) * 256), 16,
+                                                     (int)(past ? OOB : a_voff[j]), (int)a_soff, 0, 0);
+        if constexpr (BL == B_N4) {
+            const int kleft = p.K - kt * BK;
+            const unsigned b_soff = (unsigned)kts * b_kstep;
+#pragma unroll
+            for (int j = 0; j < NBV; j++)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(Bs + (wave * NBV + j) * 256), 16,
+                                                         (int)(b_krow[j] < kleft ? b_voff[j] : OOB), (int)b_soff, 0, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NBG; j++) {
+                constexpr int CPR = BN / 64;            // gather instructions per tile row
+                const int r = j / CPR, c = j % CPR;     // row within this wave's LROWS, column chunk
+                const i32x2 e = lutE[r];
+                const int iy = im_iy0[c] + (e[1] & 0xffff);
+                const int ix = im_ix0[c] + (e[1] >> 16);
+                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(Bs + (wave * LROWS + r) * BN + c * 64), 4,
+                                                         (int)(ok ? (unsigned)(im_pix[c] + e[0]) << 2 : OOB), 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- accumulators / epilogue helpers (same numerics as igemm_f32_kernel)
+    const int wq = (t >> 6) & 3; // per-lane copy of the MFMA wave id for address math
+    const int wm0 = (wq / WN) * (BM / WM), wn0 = (wq % WN) * (BN / WN);
+    f32x16 acc[TM][TN];
+    [[maybe_unused]] f32x16 tot[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    const float *__restrict__ biasb = p.bias ? p.bias + (long long)z * p.bias_bs : nullptr;
+    auto first_value = [&](float a, int m, long long ccol, int cn, bool cok) -> float {
+        float cin = 0.f;
+        if (p.beta != 0.f && m < p.M && cok) cin = p.C[ccol + (long long)m * p.c_rs];
+        float v = combine(a, cin, p.alpha, p.beta);
+        if (p.bias_kind == RTEN_HIP_BIAS_PER_ROW) {
+            if (m < p.M) v = v + biasb[m];
+        } else if (p.bias_kind == RTEN_HIP_BIAS_PER_COL) {
+            if (cok) v = v + biasb[cn];
+        }
+        return v;
+    };
+    auto col_offset = [&](int n) -> long long {
+        const int nn = n < p.N ? n : 0;
+        const int nb = nn / p.Pn, np = nn - nb * p.Pn;
+        return c_zoff + (long long)nb * p.c_ns + np;
+    };
+    [[maybe_unused]] auto flush = [&](bool first) {
+        int mb = m0 + wm0 + 4 * half, nb0 = n0 + wn0 + l31;
+        asm volatile("" : "+v"(mb), "+v"(nb0));
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int n = nb0 + j * 32;
+            const bool cok = n < p.N;
+            const long long ccol = first ? col_offset(n) : 0;
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int m = mb + i * 32 + (r & 3) + 8 * (r >> 2);
+                    tot[i][j][r] = first ? first_value(acc[i][j][r], m, ccol, n, cok)
+                                         : combine(acc[i][j][r], tot[i][j][r], p.alpha, 1.f);
+                    acc[i][j][r] = 0.f;
+                }
+        }
+    };
+
+    auto compute_tile = [&](int stage) {
+        const float *As = smem + stage * STAGE + wm0 + l31;
+        const float *Bs = smem + stage * STAGE + BK * BM + wn0 + l31;
+        float af[2][TM], bf[2][TN]; // operand fragments, double buffered across k-pairs
+#pragma unroll
+        for (int i = 0; i < TM; i++) af[0][i] = As[half * BM + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; j++) bf[0][j] = Bs[half * BN + j * 32];
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; kk++) {
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < BK / 2) {
+#pragma unroll
+                for (int i = 0; i < TM; i++) af[nxt][i] = As[(2 * (kk + 1) + half) * BM + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; j++) bf[nxt][j] = Bs[(2 * (kk + 1) + half) * BN + j * 32];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // ---- software pipeline: tiles kt+1 and kt+2 are in flight while tile kt is multiplied.  One s_barrier per
+    // k-tile, executed by all 8 waves: loaders arrive after their DMA of tile kt has landed, MFMA waves after they
+    // finished tile kt-1; past the barrier the loaders refill the freed stage while the MFMA waves multiply.
+    const int nblk = MULTI_KC ? (nk + KC_TILES - 1) / KC_TILES : 1;
+    if (is_loader) {
+        fetch_lut(0);
+        issue_tile(0, 0);
+        fetch_lut(1);
+        issue_tile(1, 1);
+        fetch_lut(2);
+        int stage = 0;
+        for (int kt = 0; kt < nk; kt++) {
+            wait_vmcnt<PER_TILE>();
+            __builtin_amdgcn_s_barrier();
+            const int st2 = stage == 0 ? 2 : stage - 1; // (kt + 2) % 3
+            issue_tile(kt + 2, st2);
+            fetch_lut(kt + 3);
+            stage = stage == 2 ? 0 : stage + 1;
+        }
+        wait_vmcnt<0>(); // the look-ahead tiles (out of range, zero fill) must land before the LDS goes away
+        return;
+    }
+    {
+        int stage = 0;
+        for (int blk = 0; blk < nblk; blk++) {
+            const int kt_end = MULTI_KC ? ((blk + 1) * KC_TILES < nk ? (blk + 1) * KC_TILES : nk) : nk;
+            for (int kt = blk * KC_TILES; kt < kt_end; kt++) {
+                __builtin_amdgcn_s_barrier();
+                compute_tile(stage);
+                stage = stage == 2 ? 0 : stage + 1;
+            }
+            if constexpr (MULTI_KC) {
+                if (blk + 1 < nblk) flush(blk == 0);
+            }
+        }
+    }
+
+    const float *__restrict__ resb = p.res;
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int n = n0 + wn0 + j * 32 + l31;
+        const bool cok = n < p.N;
+        const long long ccol = col_offset(n);
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                float v;
+                if constexpr (MULTI_KC) {
+                    v = (nblk > 1) ? combine(acc[i][j][r], tot[i][j][r], p.alpha, 1.f) : first_value(acc[i][j][r], m, ccol, n, cok);
+                } else {
+                    v = first_value(acc[i][j][r], m, ccol, n, cok);
+                }
+                if (m < p.M && cok) {
+                    const long long off = ccol + (long long)m * p.c_rs;
+                    if (resb) v = v + resb[off];
+                    if (p.act == RTEN_HIP_ACT_RELU) v = vm::relu(v);
+                    else if (p.act == RTEN_HIP_ACT_GELU) v = vm::gelu(v);
+                    p.C[off] = v;
+                }
+            }
+    }
+}
+
 // im2col lookup table: entry k -> {c*HW + ky*dy*W + kx*dx, (ky*dy) | (kx*dx) << 16}; rows >= K get an
 // offset pair that fails every bounds test.  Built once per conv geometry and cached in the context.
 __global__ void im2col_lut_kernel(i32x2 *lut, int K, int Kpad, int KHW, int KW, int HW, int W, int dy, int dx) {
@@ -755,7 +1026,17 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
     const bool multi = a.K > 256;
     constexpr bool kDma = AL == A_M4 && (BL == B_N4 || BL == B_IM2COL);
     if constexpr (kDma) {
-        if (ctx->use_dma) {
+        if (ctx->pipeline == 2) {
+            snprintf(kname, sizeof kname, "igemm_f32_ws_kernel<%d,%d,%d,%d>", BM, BN, BL, multi ? 1 : 0);
+            ProfScope ps(ctx, kname, flops, bytes);
+            if (multi)
+                hipLaunchKernelGGL((igemm_f32_ws_kernel<BM, BN, BL, true>), grid, dim3(2 * NTHREADS), 0, ctx->stream, a);
+            else
+                hipLaunchKernelGGL((igemm_f32_ws_kernel<BM, BN, BL, false>), grid, dim3(2 * NTHREADS), 0, ctx->stream, a);
+            RTEN_LAUNCH_CHECK(ctx, "igemm_f32_ws_kernel launch");
+            return RTEN_HIP_OK;
+        }
+        if (ctx->pipeline == 1) {
             snprintf(kname, sizeof kname, "igemm_f32_dma_kernel<%d,%d,%d,%d>", BM, BN, BL, multi ? 1 : 0);
             ProfScope ps(ctx, kname, flops, bytes);
             if (multi)
@@ -787,7 +1068,7 @@ int32_t launch_variant(rten_hip_ctx *ctx, GemmArgs &a, int Z, int cfg) {
 }
 
 int pick_cfg(rten_hip_ctx *ctx, int M, long long N, int Z) {
-    if (ctx->gemm_variant_override >= 0 && ctx->gemm_variant_override < 8) return ctx->gemm_variant_override & 3;
+    if (ctx->gemm_variant_override >= 0 && ctx->gemm_variant_override < 12) return ctx->gemm_variant_override & 3;
     int best = 3;
     double best_cost = 1e300;
     for (int c = 0; c < 4; c++) {
@@ -823,13 +1104,15 @@ constexpr long long kMaxBufBytes = 0x7fffffffll; // buffer offsets are 32-bit; t
 } // namespace
 
 // Variants 0..3: tile shapes {128x128, 128x64, 64x128, 64x64} with the LDS-DMA pipeline on the conv paths;
-// variants 4..7: the same tile shapes with the register-staged pipeline (kept for A/B measurement).
-RTEN_EXPORT int32_t rten_hip_num_gemm_variants(void) { return 8; }
+// variants 4..7: the same tile shapes with the register-staged pipeline; variants 8..11: LDS-DMA with
+// wave specialisation (4 MFMA waves + 4 loader waves).  Non-conv operand layouts always use the
+// register-staged kernel.
+RTEN_EXPORT int32_t rten_hip_num_gemm_variants(void) { return 12; }
 
 RTEN_EXPORT int32_t rten_hip_set_gemm_variant_override(rten_hip_ctx *ctx, int32_t variant) {
     RTEN_CHECK_CTX(ctx);
     ctx->gemm_variant_override = variant;
-    ctx->use_dma = !(variant >= 4 && variant < 8);
+    ctx->pipeline = (variant >= 8 && variant < 12) ? 2 : ((variant >= 4 && variant < 8) ? 0 : 1);
     return RTEN_HIP_OK;
 }
 

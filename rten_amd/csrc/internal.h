@@ -37,7 +37,7 @@ struct rten_hip_ctx {
     size_t scratch_bytes = 0;
     std::map<std::string, void *> luts; // im2col lookup tables, keyed by conv geometry (gemm_f32.hip)
     int gemm_variant_override = -1;
-    bool use_dma = true; // conv paths: LDS-DMA pipeline (variants 0..3) vs register-staged (4..7)
+    int pipeline = 1; // conv paths: 0 register-staged, 1 LDS-DMA, 2 LDS-DMA + wave specialisation
     int num_cus = 256;
 };
 
