@@ -396,6 +396,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_kernel(const GemmArgs p
 #pragma unroll
                 for (int j = 0; j < TN; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][i], bf[kk][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_iglp_opt(0);
     };
 
     // ---- main loop: depth blocks of KC_TILES k-tiles; inside a block the loop body is branch free
@@ -668,6 +669,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
                 for (int j = 0; j < TN; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
         }
+        __builtin_amdgcn_iglp_opt(0);
     };
 
     // ---- software pipeline: tiles kt+1 and kt+2 are in flight while tile kt is multiplied
@@ -927,6 +929,7 @@ __global__ __launch_bounds__(2 * NTHREADS, 2) void igemm_f32_ws_kernel(const Gem
                 for (int j = 0; j < TN; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
         }
+        __builtin_amdgcn_iglp_opt(0); // interleave the next group's ds_reads behind the current group's first MFMA
     };
 
     // ---- software pipeline: tiles kt+1 and kt+2 are in flight while tile kt is multiplied.  One s_barrier per
