@@ -454,7 +454,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_kernel(const GemmArgs p
 // LDS-DMA variant (conv paths: A = prepacked [K][M] weights, B = dense two-level or im2col gather).
 //
 // Tiles go HBM/L2 -> LDS directly (`buffer_load_dword[x4] ... offen lds`): no staging VGPRs, no ds_write
-// pass, and three LDS stages keep TWO k-tiles in flight behind the one being multiplied, so the
+// pass, and 4-6 LDS stages keep several k-tiles (~40-50 KB per workgroup) in flight behind the one being multiplied, so the
 // ~1200-cycle load latency hides under the matrix pipe even when only one or two workgroups fit on a CU.
 // Per k-tile: counted `s_waitcnt vmcnt(N)` (never 0 inside the loop) -> raw s_barrier -> issue the DMA of
 // tile kt+2 into the stage that was just freed -> MFMAs of tile kt (operand fragments double buffered in
@@ -463,7 +463,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_kernel(const GemmArgs p
 // LDS image: As[BK][BM], Bs[BK][BN] unpadded (DMA writes are lane-linear); MFMA operand reads walk
 // consecutive columns, so they are conflict-free without padding.
 // =====================================================================================================
-constexpr int NSTAGE = 3;
+// LDS stages per tile shape: enough bytes in flight per CU (~50 KB) to cover HBM/fabric latency
+constexpr int nstage_for(int bm, int bn) { return (bm == 128 && bn == 128) ? 4 : ((bm == 64 && bn == 64) ? 6 : 5); }
+constexpr int MAX_NSTAGE = 6;
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -481,6 +483,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
     constexpr int NBG = BK * BN / 64 / 4;  // dword gathers per wave per tile (im2col B)
     constexpr int PER_TILE = NA + (BL == B_N4 ? NBV : NBG);
     static_assert(NA >= 1 && NBV >= 1, "tile too small for 4-wave DMA split");
+    constexpr int NSTAGE = nstage_for(BM, BN);
     __shared__ __attribute__((aligned(16))) float smem[NSTAGE * STAGE];
 
     const int t = threadIdx.x;
@@ -674,22 +677,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
 
     // ---- software pipeline: tiles kt+1 and kt+2 are in flight while tile kt is multiplied
     fetch_lut(0);
-    issue_tile(0, 0);
-    fetch_lut(1);
-    issue_tile(1, 1);
-    fetch_lut(2);
+#pragma unroll
+    for (int i = 0; i < NSTAGE - 1; i++) {
+        issue_tile(i, i);
+        fetch_lut(i + 1);
+    }
     const int nblk = MULTI_KC ? (nk + KC_TILES - 1) / KC_TILES : 1;
     int stage = 0;
     for (int blk = 0; blk < nblk; blk++) {
         const int kt_end = MULTI_KC ? ((blk + 1) * KC_TILES < nk ? (blk + 1) * KC_TILES : nk) : nk;
         for (int kt = blk * KC_TILES; kt < kt_end; kt++) {
-            wait_vmcnt<PER_TILE>();       // this wave's DMA for tile kt has landed (tile kt+1 may still be in flight)
-            __builtin_amdgcn_s_barrier(); // ... and everyone else's; all waves are done reading stage (kt+2)%3
-            const int st2 = stage == 0 ? 2 : stage - 1; // (kt + 2) % 3
-            issue_tile(kt + 2, st2);
-            fetch_lut(kt + 3);
+            wait_vmcnt<PER_TILE *(NSTAGE - 2)>(); // this wave's DMA for tile kt has landed; NSTAGE-2 later tiles stay in flight
+            __builtin_amdgcn_s_barrier();         // ... and everyone else's; all waves are done reading the stage of tile kt-1
+            const int stp = stage == 0 ? NSTAGE - 1 : stage - 1; // (kt + NSTAGE - 1) % NSTAGE: the stage tile kt-1 used
+            issue_tile(kt + NSTAGE - 1, stp);
+            fetch_lut(kt + NSTAGE);
             compute_tile(stage);
-            stage = stage == 2 ? 0 : stage + 1;
+            stage = stage == NSTAGE - 1 ? 0 : stage + 1;
         }
         if constexpr (MULTI_KC) {
             if (blk + 1 < nblk) flush(blk == 0);
@@ -736,6 +740,7 @@ __global__ __launch_bounds__(2 * NTHREADS, 2) void igemm_f32_ws_kernel(const Gem
     constexpr int NBG = BK * BN / 64 / 4;  // dword gathers per wave per tile (im2col B)
     constexpr int PER_TILE = NA + (BL == B_N4 ? NBV : NBG);
     static_assert(NA >= 1 && NBV >= 1, "tile too small for 4-wave DMA split");
+    constexpr int NSTAGE = nstage_for(BM, BN);
     __shared__ __attribute__((aligned(16))) float smem[NSTAGE * STAGE];
 
     // 8 waves: 0..3 multiply (one per SIMD), 4..7 are loader waves that only issue LDS-DMA.  The two roles share
@@ -938,18 +943,19 @@ __global__ __launch_bounds__(2 * NTHREADS, 2) void igemm_f32_ws_kernel(const Gem
     const int nblk = MULTI_KC ? (nk + KC_TILES - 1) / KC_TILES : 1;
     if (is_loader) {
         fetch_lut(0);
-        issue_tile(0, 0);
-        fetch_lut(1);
-        issue_tile(1, 1);
-        fetch_lut(2);
+#pragma unroll
+        for (int i = 0; i < NSTAGE - 1; i++) {
+            issue_tile(i, i);
+            fetch_lut(i + 1);
+        }
         int stage = 0;
         for (int kt = 0; kt < nk; kt++) {
-            wait_vmcnt<PER_TILE>();
+            wait_vmcnt<PER_TILE *(NSTAGE - 2)>();
             __builtin_amdgcn_s_barrier();
-            const int st2 = stage == 0 ? 2 : stage - 1; // (kt + 2) % 3
-            issue_tile(kt + 2, st2);
-            fetch_lut(kt + 3);
-            stage = stage == 2 ? 0 : stage + 1;
+            const int stp = stage == 0 ? NSTAGE - 1 : stage - 1;
+            issue_tile(kt + NSTAGE - 1, stp);
+            fetch_lut(kt + NSTAGE);
+            stage = stage == NSTAGE - 1 ? 0 : stage + 1;
         }
         wait_vmcnt<0>(); // the look-ahead tiles (out of range, zero fill) must land before the LDS goes away
         return;
@@ -961,7 +967,7 @@ __global__ __launch_bounds__(2 * NTHREADS, 2) void igemm_f32_ws_kernel(const Gem
             for (int kt = blk * KC_TILES; kt < kt_end; kt++) {
                 __builtin_amdgcn_s_barrier();
                 compute_tile(stage);
-                stage = stage == 2 ? 0 : stage + 1;
+                stage = stage == NSTAGE - 1 ? 0 : stage + 1;
             }
             if constexpr (MULTI_KC) {
                 if (blk + 1 < nblk) flush(blk == 0);
@@ -1206,7 +1212,7 @@ const i32x2 *get_im2col_lut(rten_hip_ctx *ctx, int Cg, int kh, int kw, int dy, i
     if (it != ctx->luts.end()) return (const i32x2 *)it->second;
     if (ctx->capturing) return nullptr; // allocation is not capturable: warm up eagerly first
     const int K = Cg * kh * kw;
-    const int Kpad = ((K + BK - 1) / BK + 4) * BK; // tile / LUT look-ahead runs up to three tiles past the end
+    const int Kpad = ((K + BK - 1) / BK + MAX_NSTAGE + 2) * BK; // tile / LUT look-ahead runs up to NSTAGE tiles past the end
     void *dptr = nullptr;
     if (hipMalloc(&dptr, (size_t)Kpad * sizeof(i32x2)) != hipSuccess) return nullptr;
     hipLaunchKernelGGL(im2col_lut_kernel, dim3((Kpad + 255) / 256), dim3(256), 0, ctx->stream, (i32x2 *)dptr, K, Kpad, kh * kw,
