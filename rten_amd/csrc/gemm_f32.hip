@@ -74,6 +74,7 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int a_dir_m, b_dir_n; // scalar loaders: lanes run along m / n (1) or along k (0)
     int H, W, OW, sy, sx, pt, pl; // im2col geometry
+    int debug; // ablation switches for tuning runs (RTEN_HIP_DEBUG): 1 = loaders skip the DMA, 2 = MFMA waves skip the MFMAs
 };
 
 __device__ __forceinline__ float combine(float t, float c, float alpha, float beta) {
@@ -88,6 +89,45 @@ __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned vo
 }
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+
+
+// Fused epilogue shared by the three kernels: last depth block, bias, residual Add, activation and the
+// NCHW / row-major store.  Buffer loads/stores with 32-bit offsets: rows >= M / columns >= N get an
+// out-of-range offset (store dropped, load returns 0), so there is no exec-mask branching and no 64-bit
+// address arithmetic per element.
+template <int TM, int TN, bool MULTI_KC, typename FirstValue>
+__device__ __forceinline__ void igemm_epilogue(const GemmArgs &p, f32x16 (&acc)[TM][TN], f32x16 (&tot)[TM][TN], bool multi_blocks,
+                                               int m_base, int n_base, long long c_zoff, FirstValue first_value) {
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void *)(p.C + c_zoff), 0, 0x7ffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void *)((p.res ? p.res : p.C) + c_zoff), 0, 0x7ffffffc, 0x00020000);
+    const bool has_res = p.res != nullptr;
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int n = n_base + j * 32;
+        const bool cok = n < p.N;
+        const int nn = cok ? n : 0;
+        const int nb = nn / p.Pn, np = nn - nb * p.Pn;
+        const unsigned col = (unsigned)((long long)nb * p.c_ns + np);
+        const long long ccol = c_zoff + (long long)nb * p.c_ns + np;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = m_base + i * 32 + (r & 3) + 8 * (r >> 2);
+                float v;
+                if constexpr (MULTI_KC) {
+                    v = multi_blocks ? combine(acc[i][j][r], tot[i][j][r], p.alpha, 1.f) : first_value(acc[i][j][r], m, ccol, n, cok);
+                } else {
+                    v = first_value(acc[i][j][r], m, ccol, n, cok);
+                }
+                const unsigned voff = (m < p.M && cok) ? (col + (unsigned)m * (unsigned)p.c_rs) << 2 : OOB;
+                if (has_res) v = v + buf_load1(rsR, voff, 0);
+                if (p.act == RTEN_HIP_ACT_RELU) v = vm::relu(v);
+                else if (p.act == RTEN_HIP_ACT_GELU) v = vm::gelu(v);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, (int)voff, 0, 0);
+            }
+    }
 }
 
 template <int BM, int BN, int AL, int BL, bool MULTI_KC>
@@ -335,18 +375,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_kernel(const GemmArgs p
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    const float *__restrict__ biasb = p.bias ? p.bias + (long long)z * p.bias_bs : nullptr;
+    const __amdgpu_buffer_rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc((void *)((p.bias ? p.bias : p.C) + (long long)z * p.bias_bs), 0, 0x7ffffffc, 0x00020000);
 
     // value of an output element after the FIRST depth block: combine with C (beta), then bias
     auto first_value = [&](float a, int m, long long ccol, int cn, bool cok) -> float {
         float cin = 0.f;
         if (p.beta != 0.f && m < p.M && cok) cin = p.C[ccol + (long long)m * p.c_rs];
         float v = combine(a, cin, p.alpha, p.beta);
-        if (p.bias_kind == RTEN_HIP_BIAS_PER_ROW) {
-            if (m < p.M) v = v + biasb[m];
-        } else if (p.bias_kind == RTEN_HIP_BIAS_PER_COL) {
-            if (cok) v = v + biasb[cn];
-        }
+        // bias through a buffer load: rows/columns outside the matrix read 0 (they are never stored)
+        if (p.bias_kind == RTEN_HIP_BIAS_PER_ROW) v = v + buf_load1(rsBias, m < p.M ? (unsigned)m << 2 : OOB, 0);
+        else if (p.bias_kind == RTEN_HIP_BIAS_PER_COL) v = v + buf_load1(rsBias, cok ? (unsigned)cn << 2 : OOB, 0);
         return v;
     };
     auto col_offset = [&](int n) -> long long {
@@ -421,32 +459,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_kernel(const GemmArgs p
     }
 
     // ---- final depth block + fused epilogue (residual Add, activation), NCHW / row-major store
-    const float *__restrict__ resb = p.res;
-#pragma unroll
-    for (int j = 0; j < TN; j++) {
-        const int n = n0 + wn0 + j * 32 + l31;
-        const bool cok = n < p.N;
-        const long long ccol = col_offset(n);
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                float v;
-                if constexpr (MULTI_KC) {
-                    v = (nblk > 1) ? combine(acc[i][j][r], tot[i][j][r], p.alpha, 1.f) : first_value(acc[i][j][r], m, ccol, n, cok);
-                } else {
-                    v = first_value(acc[i][j][r], m, ccol, n, cok);
-                }
-                if (m < p.M && cok) {
-                    const long long off = ccol + (long long)m * p.c_rs;
-                    if (resb) v = v + resb[off];
-                    if (p.act == RTEN_HIP_ACT_RELU) v = vm::relu(v);
-                    else if (p.act == RTEN_HIP_ACT_GELU) v = vm::gelu(v);
-                    p.C[off] = v;
-                }
-            }
-    }
+    igemm_epilogue<TM, TN, MULTI_KC>(p, acc, tot, nblk > 1, m0 + wm0 + 4 * half, n0 + wn0 + l31, c_zoff, first_value);
 }
 
 
@@ -454,7 +467,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_kernel(const GemmArgs p
 // LDS-DMA variant (conv paths: A = prepacked [K][M] weights, B = dense two-level or im2col gather).
 //
 // Tiles go HBM/L2 -> LDS directly (`buffer_load_dword[x4] ... offen lds`): no staging VGPRs, no ds_write
-// pass, and 4-6 LDS stages keep several k-tiles (~40-50 KB per workgroup) in flight behind the one being multiplied, so the
+// pass, and three LDS stages keep two k-tiles in flight behind the one being multiplied, so the
 // ~1200-cycle load latency hides under the matrix pipe even when only one or two workgroups fit on a CU.
 // Per k-tile: counted `s_waitcnt vmcnt(N)` (never 0 inside the loop) -> raw s_barrier -> issue the DMA of
 // tile kt+2 into the stage that was just freed -> MFMAs of tile kt (operand fragments double buffered in
@@ -463,8 +476,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_kernel(const GemmArgs p
 // LDS image: As[BK][BM], Bs[BK][BN] unpadded (DMA writes are lane-linear); MFMA operand reads walk
 // consecutive columns, so they are conflict-free without padding.
 // =====================================================================================================
-// LDS stages per tile shape: enough bytes in flight per CU (~50 KB) to cover HBM/fabric latency
-constexpr int nstage_for(int bm, int bn) { return (bm == 128 && bn == 128) ? 4 : ((bm == 64 && bn == 64) ? 6 : 5); }
+// LDS stages per tile shape (measured: 4-6 stages cost occupancy and do not speed up a lone workgroup)
+constexpr int nstage_for(int bm, int bn) { return 3; } // deeper rings measured slower: LDS-limited occupancy, no gain for a lone workgroup
 constexpr int MAX_NSTAGE = 6;
 
 template <int N>
@@ -612,16 +625,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
         for (int j = 0; j < TN; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-    const float *__restrict__ biasb = p.bias ? p.bias + (long long)z * p.bias_bs : nullptr;
+    const __amdgpu_buffer_rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc((void *)((p.bias ? p.bias : p.C) + (long long)z * p.bias_bs), 0, 0x7ffffffc, 0x00020000);
     auto first_value = [&](float a, int m, long long ccol, int cn, bool cok) -> float {
         float cin = 0.f;
         if (p.beta != 0.f && m < p.M && cok) cin = p.C[ccol + (long long)m * p.c_rs];
         float v = combine(a, cin, p.alpha, p.beta);
-        if (p.bias_kind == RTEN_HIP_BIAS_PER_ROW) {
-            if (m < p.M) v = v + biasb[m];
-        } else if (p.bias_kind == RTEN_HIP_BIAS_PER_COL) {
-            if (cok) v = v + biasb[cn];
-        }
+        // bias through a buffer load: rows/columns outside the matrix read 0 (they are never stored)
+        if (p.bias_kind == RTEN_HIP_BIAS_PER_ROW) v = v + buf_load1(rsBias, m < p.M ? (unsigned)m << 2 : OOB, 0);
+        else if (p.bias_kind == RTEN_HIP_BIAS_PER_COL) v = v + buf_load1(rsBias, cok ? (unsigned)cn << 2 : OOB, 0);
         return v;
     };
     auto col_offset = [&](int n) -> long long {
@@ -701,32 +712,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
     }
     wait_vmcnt<0>(); // drain the two (out-of-range, zero-filling) look-ahead tiles before the LDS goes away
 
-    const float *__restrict__ resb = p.res;
-#pragma unroll
-    for (int j = 0; j < TN; j++) {
-        const int n = n0 + wn0 + j * 32 + l31;
-        const bool cok = n < p.N;
-        const long long ccol = col_offset(n);
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                float v;
-                if constexpr (MULTI_KC) {
-                    v = (nblk > 1) ? combine(acc[i][j][r], tot[i][j][r], p.alpha, 1.f) : first_value(acc[i][j][r], m, ccol, n, cok);
-                } else {
-                    v = first_value(acc[i][j][r], m, ccol, n, cok);
-                }
-                if (m < p.M && cok) {
-                    const long long off = ccol + (long long)m * p.c_rs;
-                    if (resb) v = v + resb[off];
-                    if (p.act == RTEN_HIP_ACT_RELU) v = vm::relu(v);
-                    else if (p.act == RTEN_HIP_ACT_GELU) v = vm::gelu(v);
-                    p.C[off] = v;
-                }
-            }
-    }
+    igemm_epilogue<TM, TN, MULTI_KC>(p, acc, tot, nblk > 1, m0 + wm0 + 4 * half, n0 + wn0 + l31, c_zoff, first_value);
 }
 
 template <int BM, int BN, int BL, bool MULTI_KC>
@@ -874,16 +860,14 @@ __global__ __launch_bounds__(2 * NTHREADS, 2) void igemm_f32_ws_kernel(const Gem
         for (int j = 0; j < TN; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-    const float *__restrict__ biasb = p.bias ? p.bias + (long long)z * p.bias_bs : nullptr;
+    const __amdgpu_buffer_rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc((void *)((p.bias ? p.bias : p.C) + (long long)z * p.bias_bs), 0, 0x7ffffffc, 0x00020000);
     auto first_value = [&](float a, int m, long long ccol, int cn, bool cok) -> float {
         float cin = 0.f;
         if (p.beta != 0.f && m < p.M && cok) cin = p.C[ccol + (long long)m * p.c_rs];
         float v = combine(a, cin, p.alpha, p.beta);
-        if (p.bias_kind == RTEN_HIP_BIAS_PER_ROW) {
-            if (m < p.M) v = v + biasb[m];
-        } else if (p.bias_kind == RTEN_HIP_BIAS_PER_COL) {
-            if (cok) v = v + biasb[cn];
-        }
+        // bias through a buffer load: rows/columns outside the matrix read 0 (they are never stored)
+        if (p.bias_kind == RTEN_HIP_BIAS_PER_ROW) v = v + buf_load1(rsBias, m < p.M ? (unsigned)m << 2 : OOB, 0);
+        else if (p.bias_kind == RTEN_HIP_BIAS_PER_COL) v = v + buf_load1(rsBias, cok ? (unsigned)cn << 2 : OOB, 0);
         return v;
     };
     auto col_offset = [&](int n) -> long long {
@@ -953,7 +937,7 @@ __global__ __launch_bounds__(2 * NTHREADS, 2) void igemm_f32_ws_kernel(const Gem
             wait_vmcnt<PER_TILE *(NSTAGE - 2)>();
             __builtin_amdgcn_s_barrier();
             const int stp = stage == 0 ? NSTAGE - 1 : stage - 1;
-            issue_tile(kt + NSTAGE - 1, stp);
+            if (!(p.debug & 1)) issue_tile(kt + NSTAGE - 1, stp);
             fetch_lut(kt + NSTAGE);
             stage = stage == NSTAGE - 1 ? 0 : stage + 1;
         }
@@ -966,7 +950,7 @@ __global__ __launch_bounds__(2 * NTHREADS, 2) void igemm_f32_ws_kernel(const Gem
             const int kt_end = MULTI_KC ? ((blk + 1) * KC_TILES < nk ? (blk + 1) * KC_TILES : nk) : nk;
             for (int kt = blk * KC_TILES; kt < kt_end; kt++) {
                 __builtin_amdgcn_s_barrier();
-                compute_tile(stage);
+                if (!(p.debug & 2)) compute_tile(stage);
                 stage = stage == NSTAGE - 1 ? 0 : stage + 1;
             }
             if constexpr (MULTI_KC) {
@@ -975,32 +959,7 @@ __global__ __launch_bounds__(2 * NTHREADS, 2) void igemm_f32_ws_kernel(const Gem
         }
     }
 
-    const float *__restrict__ resb = p.res;
-#pragma unroll
-    for (int j = 0; j < TN; j++) {
-        const int n = n0 + wn0 + j * 32 + l31;
-        const bool cok = n < p.N;
-        const long long ccol = col_offset(n);
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                float v;
-                if constexpr (MULTI_KC) {
-                    v = (nblk > 1) ? combine(acc[i][j][r], tot[i][j][r], p.alpha, 1.f) : first_value(acc[i][j][r], m, ccol, n, cok);
-                } else {
-                    v = first_value(acc[i][j][r], m, ccol, n, cok);
-                }
-                if (m < p.M && cok) {
-                    const long long off = ccol + (long long)m * p.c_rs;
-                    if (resb) v = v + resb[off];
-                    if (p.act == RTEN_HIP_ACT_RELU) v = vm::relu(v);
-                    else if (p.act == RTEN_HIP_ACT_GELU) v = vm::gelu(v);
-                    p.C[off] = v;
-                }
-            }
-    }
+    igemm_epilogue<TM, TN, MULTI_KC>(p, acc, tot, nblk > 1, m0 + wm0 + 4 * half, n0 + wn0 + l31, c_zoff, first_value);
 }
 
 // im2col lookup table: entry k -> {c*HW + ky*dy*W + kx*dx, (ky*dy) | (kx*dx) << 16}; rows >= K get an
@@ -1153,7 +1112,7 @@ RTEN_EXPORT int32_t rten_hip_gemm_f32(rten_hip_ctx *ctx, const rten_hip_gemm_des
     g.a_dir_m = (d->a_rs == 1 && d->a_cs != 1) ? 1 : 0;
     g.b_dir_n = (d->b_cs == 1 || d->b_rs != 1) ? 1 : 0;
     const long long ab = extent_bytes(d->m, d->a_rs, d->k, d->a_cs), bb = extent_bytes(d->k, d->b_rs, d->n, d->b_cs);
-    if (ab > kMaxBufBytes || bb > kMaxBufBytes)
+    if (ab > kMaxBufBytes || bb > kMaxBufBytes || extent_bytes(d->m, d->ldc, d->n, 1) > kMaxBufBytes)
         return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "gemm: operand slices above 2 GiB are not supported");
     g.a_bytes = (unsigned)ab; g.b_bytes = (unsigned)bb;
 
@@ -1197,8 +1156,8 @@ int32_t check_conv_desc(rten_hip_ctx *ctx, const rten_hip_conv2d_desc *d) {
         return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "conv: invalid geometry");
     const long long in_elems = (long long)d->n * d->c * d->h * d->w;
     const long long out_elems = (long long)d->n * d->o * d->out_h * d->out_w;
-    if (in_elems * 4 > kMaxBufBytes || out_elems >= (1ll << 31))
-        return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "conv: input above 2 GiB / output above 2^31 elements is not supported");
+    if (in_elems * 4 > kMaxBufBytes || out_elems * 4 > kMaxBufBytes)
+        return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "conv: tensors above 2 GiB are not supported");
     if ((long long)d->kh * d->dil_h >= 0x7fff || (long long)d->kw * d->dil_w >= 0x7fff || d->h >= 0x7fff || d->w >= 0x7fff)
         return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "conv: spatial extent above 32766 is not supported");
     return RTEN_HIP_OK;
@@ -1303,5 +1262,6 @@ RTEN_EXPORT int32_t rten_hip_conv2d_f32(rten_hip_ctx *ctx, const rten_hip_conv2d
         g.pt = d->pads[0]; g.pl = d->pads[1];
     }
     g.b_dir_n = 1;
+    g.debug = ctx->debug;
     return dispatch(ctx, g, d->groups, al, bl);
 }
