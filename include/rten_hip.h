@@ -21,9 +21,11 @@
  *  - Numerics: integer paths are bit-exact w.r.t. the reference.  f32 GEMM/conv reproduce the
  *    reference's accumulation order exactly (k-ordered FMA chains in depth blocks of 256,
  *    rten-gemm/src/lib.rs:630-633 + kernels/simd_generic.rs:326-414), element-wise kernels
- *    (Gelu/Erf/Relu/Add/cast_scale/DQL) are operation-for-operation restatements; only
- *    reductions (softmax sum, LayerNorm mean/variance, GlobalAveragePool) differ in summation
- *    order and are held to a stated tolerance.
+ *    (Gelu/Erf/Relu/Add/cast_scale/DQL) are operation-for-operation restatements; reductions
+ *    (softmax sum, LayerNorm mean/variance, GlobalAveragePool) reproduce the reference's 16-lane
+ *    (AVX-512) partial-sum order bit for bit and differ from its other ISA widths only by
+ *    summation-order rounding.  The M == 1 gemv fast path (ISA-dependent in the reference) is
+ *    held to rtol 1e-5.
  */
 #ifndef RTEN_HIP_H
 #define RTEN_HIP_H

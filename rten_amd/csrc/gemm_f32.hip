@@ -74,7 +74,7 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int a_dir_m, b_dir_n; // scalar loaders: lanes run along m / n (1) or along k (0)
     int H, W, OW, sy, sx, pt, pl; // im2col geometry
-    int debug; // ablation switches for tuning runs (RTEN_HIP_DEBUG): 1 = loaders skip the DMA, 2 = MFMA waves skip the MFMAs
+    int debug; // ablation switches for tuning runs (RTEN_HIP_DEBUG): 1 = skip the in-loop DMA, 2 = skip the MFMAs, 4 = skip the epilogue
 };
 
 __device__ __forceinline__ float combine(float t, float c, float alpha, float beta) {
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_kernel(const GemmArgs p
     }
 
     // ---- final depth block + fused epilogue (residual Add, activation), NCHW / row-major store
-    igemm_epilogue<TM, TN, MULTI_KC>(p, acc, tot, nblk > 1, m0 + wm0 + 4 * half, n0 + wn0 + l31, c_zoff, first_value);
+    if (!(p.debug & 4)) igemm_epilogue<TM, TN, MULTI_KC>(p, acc, tot, nblk > 1, m0 + wm0 + 4 * half, n0 + wn0 + l31, c_zoff, first_value);
 }
 
 
@@ -699,11 +699,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
         const int kt_end = MULTI_KC ? ((blk + 1) * KC_TILES < nk ? (blk + 1) * KC_TILES : nk) : nk;
         for (int kt = blk * KC_TILES; kt < kt_end; kt++) {
             wait_vmcnt<PER_TILE *(NSTAGE - 2)>(); // this wave's DMA for tile kt has landed; NSTAGE-2 later tiles stay in flight
-            __builtin_amdgcn_s_barrier();         // ... and everyone else's; all waves are done reading the stage of tile kt-1
+            if (!(p.debug & 8)) __builtin_amdgcn_s_barrier(); // ... and everyone else's; all waves are done reading the stage of tile kt-1
             const int stp = stage == 0 ? NSTAGE - 1 : stage - 1; // (kt + NSTAGE - 1) % NSTAGE: the stage tile kt-1 used
-            issue_tile(kt + NSTAGE - 1, stp);
+            if (!(p.debug & 1)) issue_tile(kt + NSTAGE - 1, stp);
             fetch_lut(kt + NSTAGE);
-            compute_tile(stage);
+            if (p.debug & 16) { // ablation: MFMAs on register operands only (no ds_read)
+                float fa = (float)kt, fb = (float)lane;
+#pragma unroll
+                for (int kk = 0; kk < BK / 2; kk++)
+#pragma unroll
+                    for (int i = 0; i < TM; i++)
+#pragma unroll
+                        for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[i][j], 0, 0, 0);
+            } else if (!(p.debug & 2)) compute_tile(stage);
             stage = stage == NSTAGE - 1 ? 0 : stage + 1;
         }
         if constexpr (MULTI_KC) {
@@ -712,7 +720,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
     }
     wait_vmcnt<0>(); // drain the two (out-of-range, zero-filling) look-ahead tiles before the LDS goes away
 
-    igemm_epilogue<TM, TN, MULTI_KC>(p, acc, tot, nblk > 1, m0 + wm0 + 4 * half, n0 + wn0 + l31, c_zoff, first_value);
+    if (!(p.debug & 4)) igemm_epilogue<TM, TN, MULTI_KC>(p, acc, tot, nblk > 1, m0 + wm0 + 4 * half, n0 + wn0 + l31, c_zoff, first_value);
 }
 
 template <int BM, int BN, int BL, bool MULTI_KC>
@@ -959,7 +967,7 @@ __global__ __launch_bounds__(2 * NTHREADS, 2) void igemm_f32_ws_kernel(const Gem
         }
     }
 
-    igemm_epilogue<TM, TN, MULTI_KC>(p, acc, tot, nblk > 1, m0 + wm0 + 4 * half, n0 + wn0 + l31, c_zoff, first_value);
+    if (!(p.debug & 4)) igemm_epilogue<TM, TN, MULTI_KC>(p, acc, tot, nblk > 1, m0 + wm0 + 4 * half, n0 + wn0 + l31, c_zoff, first_value);
 }
 
 // im2col lookup table: entry k -> {c*HW + ky*dy*W + kx*dx, (ky*dy) | (kx*dx) << 16}; rows >= K get an
