@@ -112,9 +112,12 @@ def main():
                 d = net.descs[l["name"]]
                 fl = 2.0 * d.o * d.c * d.kh * d.kw * d.out_h * d.out_w * d.n
                 row = table[l["name"]]
-                print(f"[layer] {l['name']:8s} O={d.o:4d} C={d.c:4d} k={d.kh} s={d.stride_h} {d.h:3d}->{d.out_h:3d} "
-                      + " ".join(f"v{v}={ms*1e3:7.1f}us" for v, ms in enumerate(row))
-                      + f"  best=v{net.variants[l['name']]} {fl / (min(row) * 1e-3) / 1e12:6.1f} TF/s", file=sys.stderr)
+                best_ms = min(ms for _, ms in row)
+                nosplit = " ".join(f"v{p[0]}={ms*1e3:6.1f}" for p, ms in row if p[1] == 0)
+                split = sorted(((ms, p) for p, ms in row if p[1] != 0))[:3]
+                print(f"[layer] {l['name']:8s} O={d.o:4d} C={d.c:4d} k={d.kh} s={d.stride_h} {d.h:3d}->{d.out_h:3d} us: {nosplit}"
+                      + " | split " + " ".join(f"v{p[0]}m{p[1]}g{p[2]}={ms*1e3:6.1f}" for ms, p in split)
+                      + f"  best={net.variants[l['name']]} {fl / (best_ms * 1e-3) / 1e12:6.1f} TF/s", file=sys.stderr)
     if not args.no_graph:
         net.capture()
 

@@ -75,6 +75,11 @@ struct GemmArgs {
     int a_dir_m, b_dir_n; // scalar loaders: lanes run along m / n (1) or along k (0)
     int H, W, OW, sy, sx, pt, pl; // im2col geometry
     int debug; // ablation switches for tuning runs (RTEN_HIP_DEBUG): 1 = skip the in-loop DMA, 2 = skip the MFMAs, 4 = skip the epilogue
+    // exact split-K (LDS-DMA kernel, MODE 2): tiles >= split_t1 are cut along K at depth-block (kc) boundaries into
+    // split_s groups of split_g blocks; each block's raw accumulator is parked in slab slot `blk` of its tile and
+    // the fixup kernel replays the unsplit fold over the slots in block order -> bit-identical to the unsplit chain.
+    float *slab;
+    int split_t1, split_s, split_g, split_slots, split_ntail;
 };
 
 __device__ __forceinline__ float combine(float t, float c, float alpha, float beta) {
@@ -485,8 +490,12 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int BL, bool MULTI_KC>
+// MODE 0: K <= 256 (one depth block); 1: several depth blocks folded in registers; 2: split-K producer -- every
+// workgroup computes one group of depth blocks of one split tile and parks each block's raw accumulator in the slab
+// (no fold, no epilogue: igemm_f32_fixup_kernel finishes the tile).
+template <int BM, int BN, int BL, int MODE>
 __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmArgs p) {
+    constexpr bool MULTI_KC = MODE == 1, SPLIT = MODE == 2;
     static_assert(BL == B_N4 || BL == B_IM2COL, "DMA kernel covers the conv operand layouts");
     constexpr int WM = 2, WN = 2;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -505,12 +514,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
     const int l31 = lane & 31, half = lane >> 5;
     const int z = blockIdx.y;
 
-    int tile;
+    int tile, grp = -1; // grp >= 0: this workgroup computes one K group of a split tile
     {
-        const int nt = p.tiles_m * p.tiles_n;
+        const int nt = gridDim.x;
         const int id = blockIdx.x;
         const int xcd = id & 7, q = nt >> 3, r = nt & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+        if constexpr (SPLIT) {
+            const int rr = tile;
+            tile = p.split_t1 + rr / p.split_s;
+            grp = rr - (rr / p.split_s) * p.split_s;
+        }
     }
     const int bm = tile % p.tiles_m, bn = tile / p.tiles_m;
     const int m0 = bm * BM, n0 = bn * BN;
@@ -686,17 +700,39 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
         __builtin_amdgcn_iglp_opt(0);
     };
 
+    // raw accumulator image of this workgroup's tile in the split-K slab: [wave][i][j][quad][lane] float4
+    [[maybe_unused]] auto store_raw = [&](f32x16 (&v)[TM][TN], int slot) {
+        int loff = wq * (TM * TN * 16 * 64) + lane * 4;
+        asm volatile("" : "+v"(loff)); // keep the address math at the use (not hoisted across the K loop)
+        float *base = p.slab + (((long long)z * p.split_ntail + (tile - p.split_t1)) * p.split_slots + slot) * (long long)(BM * BN) + loff;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    f32x4 o = {v[i][j][4 * q], v[i][j][4 * q + 1], v[i][j][4 * q + 2], v[i][j][4 * q + 3]};
+                    *(f32x4 *)(base + ((i * TN + j) * 4 + q) * 256) = o;
+                }
+    };
+
     // ---- software pipeline: tiles kt+1 and kt+2 are in flight while tile kt is multiplied
-    fetch_lut(0);
+    const int nblk = (MULTI_KC || SPLIT) ? (nk + KC_TILES - 1) / KC_TILES : 1;
+    int blk0 = 0, blk1 = nblk;
+    if constexpr (SPLIT) {
+        blk0 = grp * p.split_g;
+        blk1 = blk0 + p.split_g < nblk ? blk0 + p.split_g : nblk;
+    }
+    const int kt0 = blk0 * KC_TILES;
+    fetch_lut(kt0);
 #pragma unroll
     for (int i = 0; i < NSTAGE - 1; i++) {
-        issue_tile(i, i);
-        fetch_lut(i + 1);
+        issue_tile(kt0 + i, i);
+        fetch_lut(kt0 + i + 1);
     }
-    const int nblk = MULTI_KC ? (nk + KC_TILES - 1) / KC_TILES : 1;
     int stage = 0;
-    for (int blk = 0; blk < nblk; blk++) {
-        const int kt_end = MULTI_KC ? ((blk + 1) * KC_TILES < nk ? (blk + 1) * KC_TILES : nk) : nk;
+    for (int blk = blk0; blk < blk1; blk++) {
+        const int kt_end = (MULTI_KC || SPLIT) ? ((blk + 1) * KC_TILES < nk ? (blk + 1) * KC_TILES : nk) : nk;
         for (int kt = blk * KC_TILES; kt < kt_end; kt++) {
             wait_vmcnt<PER_TILE *(NSTAGE - 2)>(); // this wave's DMA for tile kt has landed; NSTAGE-2 later tiles stay in flight
             if (!(p.debug & 8)) __builtin_amdgcn_s_barrier(); // ... and everyone else's; all waves are done reading the stage of tile kt-1
@@ -714,13 +750,97 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
             } else if (!(p.debug & 2)) compute_tile(stage);
             stage = stage == NSTAGE - 1 ? 0 : stage + 1;
         }
+        if constexpr (SPLIT) {
+            store_raw(acc, blk);
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+        }
         if constexpr (MULTI_KC) {
             if (blk + 1 < nblk) flush(blk == 0);
         }
     }
-    wait_vmcnt<0>(); // drain the two (out-of-range, zero-filling) look-ahead tiles before the LDS goes away
+    wait_vmcnt<0>(); // drain the two look-ahead tiles before the LDS goes away
 
-    if (!(p.debug & 4)) igemm_epilogue<TM, TN, MULTI_KC>(p, acc, tot, nblk > 1, m0 + wm0 + 4 * half, n0 + wn0 + l31, c_zoff, first_value);
+    if constexpr (!SPLIT) {
+        if (!(p.debug & 4)) igemm_epilogue<TM, TN, MULTI_KC>(p, acc, tot, nblk > 1, m0 + wm0 + 4 * half, n0 + wn0 + l31, c_zoff, first_value);
+    }
+}
+
+// Split-K fixup: one workgroup per split tile, same thread <-> element mapping as the GEMM kernels.  Replays the
+// unsplit kernel's fold over the parked per-block accumulators in depth-block order (first block: beta*C + bias;
+// later blocks: separate adds), then runs the shared epilogue (residual, activation, store).
+template <int BM, int BN>
+__global__ __launch_bounds__(NTHREADS) void igemm_f32_fixup_kernel(const GemmArgs p) {
+    constexpr int WM = 2, WN = 2;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    const int t = threadIdx.x, lane = t & 63, wq = t >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int z = blockIdx.y;
+    const int tile = p.split_t1 + blockIdx.x;
+    const int bm = tile % p.tiles_m, bn = tile / p.tiles_m;
+    const int m0 = bm * BM, n0 = bn * BN;
+    int zo = z, zi = 0;
+    if (p.batch_inner > 1) { zo = z / p.batch_inner; zi = z - zo * p.batch_inner; }
+    const long long c_zoff = (long long)zo * p.c_bs + (long long)zi * p.c_bsi;
+    const int wm0 = (wq / WN) * (BM / WM), wn0 = (wq % WN) * (BN / WN);
+    const float *base = p.slab + ((long long)z * p.split_ntail + blockIdx.x) * p.split_slots * (long long)(BM * BN) +
+                        wq * (TM * TN * 16 * 64) + lane * 4;
+    f32x16 acc[TM][TN], tot[TM][TN];
+    auto load_raw = [&](f32x16 (&v)[TM][TN], int slot) {
+        const float *b = base + (long long)slot * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const f32x4 o = *(const f32x4 *)(b + ((i * TN + j) * 4 + q) * 256);
+                    v[i][j][4 * q] = o[0]; v[i][j][4 * q + 1] = o[1]; v[i][j][4 * q + 2] = o[2]; v[i][j][4 * q + 3] = o[3];
+                }
+    };
+    const __amdgpu_buffer_rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc((void *)((p.bias ? p.bias : p.C) + (long long)z * p.bias_bs), 0, 0x7ffffffc, 0x00020000);
+    auto first_value = [&](float a, int m, long long ccol, int cn, bool cok) -> float {
+        float cin = 0.f;
+        if (p.beta != 0.f && m < p.M && cok) cin = p.C[ccol + (long long)m * p.c_rs];
+        float v = combine(a, cin, p.alpha, p.beta);
+        if (p.bias_kind == RTEN_HIP_BIAS_PER_ROW) v = v + buf_load1(rsBias, m < p.M ? (unsigned)m << 2 : OOB, 0);
+        else if (p.bias_kind == RTEN_HIP_BIAS_PER_COL) v = v + buf_load1(rsBias, cok ? (unsigned)cn << 2 : OOB, 0);
+        return v;
+    };
+    load_raw(acc, 0);
+    {
+        const int mb = m0 + wm0 + 4 * half, nb0 = n0 + wn0 + l31;
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int n = nb0 + j * 32;
+            const bool cok = n < p.N;
+            const int nn = cok ? n : 0;
+            const int nb = nn / p.Pn, np = nn - nb * p.Pn;
+            const long long ccol = c_zoff + (long long)nb * p.c_ns + np;
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int m = mb + i * 32 + (r & 3) + 8 * (r >> 2);
+                    tot[i][j][r] = first_value(acc[i][j][r], m, ccol, n, cok);
+                }
+        }
+    }
+    for (int s = 1; s + 1 < p.split_slots; s++) {
+        load_raw(acc, s);
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) tot[i][j][r] = combine(acc[i][j][r], tot[i][j][r], p.alpha, 1.f);
+    }
+    load_raw(acc, p.split_slots - 1);
+    igemm_epilogue<TM, TN, true>(p, acc, tot, true, m0 + wm0 + 4 * half, n0 + wn0 + l31, c_zoff, first_value);
 }
 
 template <int BM, int BN, int BL, bool MULTI_KC>
@@ -1013,13 +1133,48 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
             return RTEN_HIP_OK;
         }
         if (ctx->pipeline == 1) {
-            snprintf(kname, sizeof kname, "igemm_f32_dma_kernel<%d,%d,%d,%d>", BM, BN, BL, multi ? 1 : 0);
-            ProfScope ps(ctx, kname, flops, bytes);
-            if (multi)
-                hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, BL, true>), grid, dim3(NTHREADS), 0, ctx->stream, a);
-            else
-                hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, BL, false>), grid, dim3(NTHREADS), 0, ctx->stream, a);
-            RTEN_LAUNCH_CHECK(ctx, "igemm_f32_dma_kernel launch");
+            // exact split-K plan (see GemmArgs): only depth-block boundaries are legal cut points
+            const int nblk = (a.K + 255) / 256;
+            const int T = a.tiles_m * a.tiles_n;
+            int ntail = 0, t1 = T, S = 1;
+            if (multi && ctx->split_mode > 0 && ctx->split_s > 1) {
+                const int s_req = ctx->split_s < nblk ? ctx->split_s : nblk;
+                const int G = (nblk + s_req - 1) / s_req;
+                S = (nblk + G - 1) / G;
+                t1 = ctx->split_mode == 2 ? 0 : (T / ctx->num_cus) * ctx->num_cus;
+                if (S > 1 && t1 < T) {
+                    ntail = T - t1;
+                    a.split_t1 = t1; a.split_s = S; a.split_g = G; a.split_slots = nblk; a.split_ntail = ntail;
+                    const size_t need = 4096 + (size_t)Z * ntail * nblk * BM * BN * sizeof(float);
+                    char *sc = (char *)rten_scratch(ctx, need);
+                    if (!sc) return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "split-K slab allocation failed (or attempted during graph capture)");
+                    a.slab = (float *)(sc + 4096);
+                } else {
+                    t1 = T;
+                }
+            }
+            if (t1 > 0) { // whole tiles [0, t1)
+                snprintf(kname, sizeof kname, "igemm_f32_dma_kernel<%d,%d,%d,%d>", BM, BN, BL, multi ? 1 : 0);
+                ProfScope ps(ctx, kname, flops * t1 / T, bytes * t1 / T);
+                grid.x = (unsigned)t1;
+                if (multi)
+                    hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, BL, 1>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+                else
+                    hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, BL, 0>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+                RTEN_LAUNCH_CHECK(ctx, "igemm_f32_dma_kernel launch");
+            }
+            if (ntail > 0) { // split tiles [t1, T): producers, then the ordered fold + epilogue
+                {
+                    snprintf(kname, sizeof kname, "igemm_f32_dma_kernel<%d,%d,%d,2>", BM, BN, BL);
+                    ProfScope ps(ctx, kname, flops * ntail / T, bytes * ntail / T);
+                    hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, BL, 2>), dim3((unsigned)(ntail * S), (unsigned)Z), dim3(NTHREADS), 0, ctx->stream, a);
+                    RTEN_LAUNCH_CHECK(ctx, "igemm_f32_dma_kernel (split-K) launch");
+                }
+                snprintf(kname, sizeof kname, "igemm_f32_fixup_kernel<%d,%d>", BM, BN);
+                ProfScope ps(ctx, kname, 0.0, 8.0 * Z * ntail * nblk * BM * BN);
+                hipLaunchKernelGGL((igemm_f32_fixup_kernel<BM, BN>), dim3((unsigned)ntail, (unsigned)Z), dim3(NTHREADS), 0, ctx->stream, a);
+                RTEN_LAUNCH_CHECK(ctx, "igemm_f32_fixup_kernel launch");
+            }
             return RTEN_HIP_OK;
         }
     }
@@ -1089,6 +1244,16 @@ RTEN_EXPORT int32_t rten_hip_set_gemm_variant_override(rten_hip_ctx *ctx, int32_
     RTEN_CHECK_CTX(ctx);
     ctx->gemm_variant_override = variant;
     ctx->pipeline = (variant >= 8 && variant < 12) ? 2 : ((variant >= 4 && variant < 8) ? 0 : 1);
+    return RTEN_HIP_OK;
+}
+
+// Exact split-K plan for the LDS-DMA conv kernels: mode 0 = off, 1 = split only the tiles past the last full
+// round of num_cus workgroups (tail balancing), 2 = split every tile; `groups` = K groups per split tile.
+RTEN_EXPORT int32_t rten_hip_set_gemm_split(rten_hip_ctx *ctx, int32_t mode, int32_t groups) {
+    RTEN_CHECK_CTX(ctx);
+    if (mode < 0 || mode > 2 || groups < 0) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "set_gemm_split: bad mode/groups");
+    ctx->split_mode = mode;
+    ctx->split_s = groups;
     return RTEN_HIP_OK;
 }
 

@@ -137,6 +137,7 @@ PROTOTYPES = {
     "rten_hip_gather_rows_f32": (_I32, [_VP, _I64, _I32, _I32, _VP, _VP, _VP]),
     "rten_hip_set_gemm_variant_override": (_I32, [_VP, _I32]),
     "rten_hip_num_gemm_variants": (_I32, []),
+    "rten_hip_set_gemm_split": (_I32, [_VP, _I32, _I32]),
 }
 
 _lib = None

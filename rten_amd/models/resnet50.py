@@ -172,14 +172,17 @@ class ResNet50:
 
     def _conv(self, l):
         ctx = self.ctx
-        v = self.variants.get(l["name"])
-        if v is not None:
+        plan = self.variants.get(l["name"])
+        if plan is not None:
+            v, mode, groups = plan if isinstance(plan, tuple) else (plan, 0, 1)
             ctx.set_gemm_variant(v)
+            ctx.call("rten_hip_set_gemm_split", mode, groups)
         flags = (L.CONV_RELU if l["relu"] else 0) | (L.CONV_RESIDUAL if l["res"] else 0)
         ctx.call("rten_hip_conv2d_f32", C.byref(self.descs[l["name"]]), self._act(l["src"]).vp, self._wptr(l["name"], 0), 1,
                  self._wptr(l["name"], 1), self._act(l["res"]).vp if l["res"] else None, flags, self._act(l["dst"]).vp)
-        if v is not None:
+        if plan is not None:
             ctx.set_gemm_variant(-1)
+            ctx.call("rten_hip_set_gemm_split", 0, 1)
 
     def forward(self):
         """Enqueue one forward pass over self.x -> self.logits (asynchronous)."""
@@ -208,25 +211,39 @@ class ResNet50:
         else:
             self.forward()
 
+    def candidate_plans(self, l):
+        """(variant, split mode, K groups) plans worth timing for one conv layer.  Split-K plans exist for
+        the LDS-DMA variants (0..3) when K spans more than one depth block of 256."""
+        nvar = self.ctx.lib.rten_hip_num_gemm_variants()
+        plans = [(v, 0, 1) for v in range(nvar)]
+        d = self.descs[l["name"]]
+        nblk = (d.c // d.groups * d.kh * d.kw + 255) // 256
+        if nblk > 1:
+            for v in range(4):
+                for groups in sorted({2, 3, 4, 6, nblk} & set(range(2, nblk + 1))):
+                    plans.append((v, 1, groups))
+                    plans.append((v, 2, groups))
+        return plans
+
     def autotune(self, reps=3):
-        """Pick the fastest GEMM tile variant per conv layer by measurement (load-time, like the
-        reference picks kernels per ISA at start-up, rten-gemm/src/lib.rs:534-547)."""
+        """Pick the fastest (tile variant, split-K plan) per conv layer by measurement (load-time, like the
+        reference picks kernels per ISA at start-up, rten-gemm/src/lib.rs:534-547).  Returns
+        {layer: [(plan, ms), ...]}."""
         ctx = self.ctx
-        nvar = ctx.lib.rten_hip_num_gemm_variants()
         table = {}
         for l in self.specs:
             best, best_ms, row = None, 1e30, []
-            for v in range(nvar):
-                self.variants[l["name"]] = v
-                self._conv(l)  # warm
+            for plan in self.candidate_plans(l):
+                self.variants[l["name"]] = plan
+                self._conv(l)  # warm (also grows the split-K slab scratch before any graph capture)
                 ctx.timer_start(1)
                 for _ in range(reps):
                     self._conv(l)
                 ctx.timer_stop(1)
                 ms = ctx.timer_ms(1) / reps
-                row.append(ms)
+                row.append((plan, ms))
                 if ms < best_ms:
-                    best, best_ms = v, ms
+                    best, best_ms = plan, ms
             self.variants[l["name"]] = best
             table[l["name"]] = row
         return table

@@ -218,6 +218,34 @@ def test_conv_f32_resnet_layer_shapes_all_variants(ctx, shape):
         bits_equal(gpu_conv(ctx, x, w, b, (pad,) * 4, (s, s), relu=True, variant=v), want)
 
 
+@pytest.mark.parametrize("shape", [(128, 128, 28, 3, 1, 1), (256, 256, 14, 3, 1, 1), (512, 512, 7, 3, 1, 1), (512, 2048, 7, 1, 1, 0),
+                                   (128, 512, 28, 1, 1, 0), (40, 70, 9, 3, 1, 1),
+                                   (64, 32, 96, 3, 1, 1)])  # last: 288 tiles of 64x64 -> tail mode splits only tiles 256..287
+def test_conv_f32_split_k_bit_exact(ctx, shape):
+    # exact split-K: K cut at the reference's depth-block boundaries (rten-gemm/src/lib.rs:630-633), partial sums
+    # added in block order -> same bits as the unsplit chain, with bias / residual / relu in the fixup epilogue
+    O, Cc, H, k, s, pad = shape
+    rng = ref.XorShiftRng(99)
+    x = rng.f32(2 * Cc * H * H).reshape(2, Cc, H, H) - 0.5
+    w = (rng.f32(O * Cc * k * k).reshape(O, Cc, k, k) - 0.5) * 0.1
+    b = rng.f32(O) - 0.5
+    want0 = ref.conv2d_f32(x, w, b, pads=(pad,) * 4, strides=(s, s), relu=True)
+    res = rng.f32(want0.size).reshape(want0.shape) - 0.5
+    want = ref.conv2d_f32(x, w, b, pads=(pad,) * 4, strides=(s, s), residual=res, relu=True)
+    nblk = (Cc * k * k + 255) // 256
+    try:
+        for v in range(4):
+            for mode in (1, 2):
+                for groups in sorted({2, 3, nblk}):
+                    ctx.call("rten_hip_set_gemm_split", mode, groups)
+                    bits_equal(gpu_conv(ctx, x, w, b, (pad,) * 4, (s, s), residual=res, relu=True, variant=v), want)
+        ctx.call("rten_hip_set_gemm_split", 2, 2)
+        bits_equal(gpu_conv(ctx, x, w, None, (pad,) * 4, (s, s), variant=3),
+                   ref.conv2d_f32(x, w, None, pads=(pad,) * 4, strides=(s, s)))
+    finally:
+        ctx.call("rten_hip_set_gemm_split", 0, 1)
+
+
 # ------------------------------------------------------------------------------------------ int8
 @pytest.mark.parametrize("adt,bdt", [(np.uint8, np.int8), (np.uint8, np.uint8), (np.int8, np.int8), (np.int8, np.uint8)])
 def test_matmul_integer_bit_exact(ctx, adt, bdt):
