@@ -48,10 +48,17 @@ namespace {
 constexpr int BK = 16;             // k-tile depth
 constexpr int KC_TILES = 256 / BK; // reference depth block (kc = 256 for f32)
 constexpr int NTHREADS = 256;
+// Ablation switches (RTEN_HIP_DEBUG bits) exist only in -DRTEN_ABLATE tuning builds: a runtime test inside the K loop
+// costs the production kernels accumulator copies and exec-mask branches.
+#ifdef RTEN_ABLATE
+#define ABLATE(p) ((p).debug)
+#else
+#define ABLATE(p) 0
+#endif
 constexpr unsigned OOB = 0x80000000u; // byte offset beyond every buffer (< 2 GiB): buffer loads return 0
 
 enum ALoad { A_M4 = 0, A_K4 = 1, A_SCALAR = 2 };
-enum BLoad { B_N4 = 0, B_K4 = 1, B_SCALAR = 2, B_IM2COL = 3 };
+enum BLoad { B_N4 = 0, B_K4 = 1, B_SCALAR = 2, B_IM2COL = 3, B_IM2COL_TAPS = 4 }; // TAPS: <= 31 kernel taps, per-lane validity bitmask
 
 struct GemmArgs {
     const float *A;
@@ -74,6 +81,7 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int a_dir_m, b_dir_n; // scalar loaders: lanes run along m / n (1) or along k (0)
     int H, W, OW, sy, sx, pt, pl; // im2col geometry
+    int KH, KW, dy, dx;           // kernel taps / dilation (B_IM2COL_TAPS validity masks)
     int debug; // ablation switches for tuning runs (RTEN_HIP_DEBUG): 1 = skip the in-loop DMA, 2 = skip the MFMAs, 4 = skip the epilogue
     // exact split-K (LDS-DMA kernel, MODE 2): tiles >= split_t1 are cut along K at depth-block (kc) boundaries into
     // split_s groups of split_g blocks; each block's raw accumulator is parked in slab slot `blk` of its tile and
@@ -464,7 +472,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_kernel(const GemmArgs p
     }
 
     // ---- final depth block + fused epilogue (residual Add, activation), NCHW / row-major store
-    if (!(p.debug & 4)) igemm_epilogue<TM, TN, MULTI_KC>(p, acc, tot, nblk > 1, m0 + wm0 + 4 * half, n0 + wn0 + l31, c_zoff, first_value);
+    if (!(ABLATE(p) & 4)) igemm_epilogue<TM, TN, MULTI_KC>(p, acc, tot, nblk > 1, m0 + wm0 + 4 * half, n0 + wn0 + l31, c_zoff, first_value);
 }
 
 
@@ -496,7 +504,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 template <int BM, int BN, int BL, int MODE>
 __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmArgs p) {
     constexpr bool MULTI_KC = MODE == 1, SPLIT = MODE == 2;
-    static_assert(BL == B_N4 || BL == B_IM2COL, "DMA kernel covers the conv operand layouts");
+    static_assert(BL == B_N4 || BL == B_IM2COL || BL == B_IM2COL_TAPS, "DMA kernel covers the conv operand layouts");
     constexpr int WM = 2, WN = 2;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int STAGE = BK * (BM + BN); // floats per stage
@@ -553,8 +561,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
     [[maybe_unused]] unsigned b_voff[BL == B_N4 ? NBV : 1];
     [[maybe_unused]] int b_krow[BL == B_N4 ? NBV : 1];
     [[maybe_unused]] unsigned b_kstep = 0;
-    [[maybe_unused]] int im_iy0[BL == B_IM2COL && BN == 128 ? 2 : 1], im_ix0[BL == B_IM2COL && BN == 128 ? 2 : 1],
-        im_pix[BL == B_IM2COL && BN == 128 ? 2 : 1];
+    constexpr bool IM2COL = BL == B_IM2COL || BL == B_IM2COL_TAPS, TAPS = BL == B_IM2COL_TAPS;
+    constexpr int NCOL = IM2COL && BN == 128 ? 2 : 1;
+    [[maybe_unused]] int im_iy0[NCOL], im_ix0[NCOL], im_pix[NCOL];
+    [[maybe_unused]] unsigned im_inv[NCOL]; // TAPS: bit t set = tap t of this lane's pixel is padding; bit 31 always set (k-tail rows)
     if constexpr (BL == B_N4) {
 #pragma unroll
         for (int j = 0; j < NBV; j++) {
@@ -579,6 +589,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
             im_iy0[c] = ok ? oy * p.sy - p.pt : -0x40000000;
             im_ix0[c] = ox * p.sx - p.pl;
             im_pix[c] = (int)((long long)nb * p.b_ns) + (oy * p.sy - p.pt) * p.W + im_ix0[c];
+            if constexpr (TAPS) {
+                unsigned colbad = 0; // bit kx set: column tap kx falls outside the image
+                for (int kx = 0; kx < p.KW; kx++) colbad |= ((unsigned)(im_ix0[c] + kx * p.dx) >= (unsigned)p.W ? 1u : 0u) << kx;
+                const unsigned allbad = (1u << p.KW) - 1u;
+                unsigned inv = 0x80000000u;
+                for (int ky = 0; ky < p.KH; ky++)
+                    inv |= ((unsigned)(im_iy0[c] + ky * p.dy) >= (unsigned)p.H ? allbad : colbad) << (ky * p.KW);
+                im_inv[c] = inv;
+            }
         }
     }
 
@@ -587,7 +606,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
     constexpr int LROWS = BK / 4; // rows of a tile handled by one wave (NBG / (BN/64))
     [[maybe_unused]] i32x2 lutE[LROWS];
     [[maybe_unused]] auto fetch_lut = [&](int kt) {
-        if constexpr (BL == B_IM2COL) {
+        if constexpr (IM2COL) {
             const int krow0 = kt * BK + wave * LROWS;
             const lut_ptr_t lc = (lut_ptr_t)(unsigned long long)p.lut;
 #pragma unroll
@@ -619,11 +638,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
                 constexpr int CPR = BN / 64;            // gather instructions per tile row
                 const int r = j / CPR, c = j % CPR;     // row within this wave's LROWS, column chunk
                 const i32x2 e = lutE[r];
-                const int iy = im_iy0[c] + (e[1] & 0xffff);
-                const int ix = im_ix0[c] + (e[1] >> 16);
-                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(Bs + (wave * LROWS + r) * BN + c * 64), 4,
-                                                         (int)(ok ? (unsigned)(im_pix[c] + e[0]) << 2 : OOB), 0, 0, 0);
+                unsigned voff;
+                if constexpr (TAPS) {
+                    // e[1] = 31 - tap: the tap's padding bit moves to bit 31 and pushes the offset out of range
+                    voff = ((im_inv[c] << e[1]) & 0x80000000u) | ((unsigned)(im_pix[c] + e[0]) << 2);
+                } else {
+                    const int iy = im_iy0[c] + (e[1] & 0xffff);
+                    const int ix = im_ix0[c] + (e[1] >> 16);
+                    const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+                    voff = ok ? (unsigned)(im_pix[c] + e[0]) << 2 : OOB;
+                }
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(Bs + (wave * LROWS + r) * BN + c * 64), 4, (int)voff, 0, 0, 0);
             }
         }
     };
@@ -735,11 +760,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
         const int kt_end = (MULTI_KC || SPLIT) ? ((blk + 1) * KC_TILES < nk ? (blk + 1) * KC_TILES : nk) : nk;
         for (int kt = blk * KC_TILES; kt < kt_end; kt++) {
             wait_vmcnt<PER_TILE *(NSTAGE - 2)>(); // this wave's DMA for tile kt has landed; NSTAGE-2 later tiles stay in flight
-            if (!(p.debug & 8)) __builtin_amdgcn_s_barrier(); // ... and everyone else's; all waves are done reading the stage of tile kt-1
+            if (!(ABLATE(p) & 8)) __builtin_amdgcn_s_barrier(); // ... and everyone else's; all waves are done reading the stage of tile kt-1
             const int stp = stage == 0 ? NSTAGE - 1 : stage - 1; // (kt + NSTAGE - 1) % NSTAGE: the stage tile kt-1 used
-            if (!(p.debug & 1)) issue_tile(kt + NSTAGE - 1, stp);
+            if (!(ABLATE(p) & 1)) issue_tile(kt + NSTAGE - 1, stp);
             fetch_lut(kt + NSTAGE);
-            if (p.debug & 16) { // ablation: MFMAs on register operands only (no ds_read)
+            if (ABLATE(p) & 16) { // ablation: MFMAs on register operands only (no ds_read)
                 float fa = (float)kt, fb = (float)lane;
 #pragma unroll
                 for (int kk = 0; kk < BK / 2; kk++)
@@ -747,7 +772,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
                     for (int i = 0; i < TM; i++)
 #pragma unroll
                         for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[i][j], 0, 0, 0);
-            } else if (!(p.debug & 2)) compute_tile(stage);
+            } else if (!(ABLATE(p) & 2)) compute_tile(stage);
             stage = stage == NSTAGE - 1 ? 0 : stage + 1;
         }
         if constexpr (SPLIT) {
@@ -766,7 +791,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
     wait_vmcnt<0>(); // drain the two look-ahead tiles before the LDS goes away
 
     if constexpr (!SPLIT) {
-        if (!(p.debug & 4)) igemm_epilogue<TM, TN, MULTI_KC>(p, acc, tot, nblk > 1, m0 + wm0 + 4 * half, n0 + wn0 + l31, c_zoff, first_value);
+        if (!(ABLATE(p) & 4)) igemm_epilogue<TM, TN, MULTI_KC>(p, acc, tot, nblk > 1, m0 + wm0 + 4 * half, n0 + wn0 + l31, c_zoff, first_value);
     }
 }
 
@@ -845,7 +870,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_f32_fixup_kernel(const GemmArg
 
 template <int BM, int BN, int BL, bool MULTI_KC>
 __global__ __launch_bounds__(2 * NTHREADS, 2) void igemm_f32_ws_kernel(const GemmArgs p) {
-    static_assert(BL == B_N4 || BL == B_IM2COL, "DMA kernel covers the conv operand layouts");
+    static_assert(BL == B_N4 || BL == B_IM2COL || BL == B_IM2COL_TAPS, "DMA kernel covers the conv operand layouts");
     constexpr int WM = 2, WN = 2;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int STAGE = BK * (BM + BN); // floats per stage
@@ -902,8 +927,10 @@ __global__ __launch_bounds__(2 * NTHREADS, 2) void igemm_f32_ws_kernel(const Gem
     [[maybe_unused]] unsigned b_voff[BL == B_N4 ? NBV : 1];
     [[maybe_unused]] int b_krow[BL == B_N4 ? NBV : 1];
     [[maybe_unused]] unsigned b_kstep = 0;
-    [[maybe_unused]] int im_iy0[BL == B_IM2COL && BN == 128 ? 2 : 1], im_ix0[BL == B_IM2COL && BN == 128 ? 2 : 1],
-        im_pix[BL == B_IM2COL && BN == 128 ? 2 : 1];
+    constexpr bool IM2COL = BL == B_IM2COL || BL == B_IM2COL_TAPS, TAPS = BL == B_IM2COL_TAPS;
+    constexpr int NCOL = IM2COL && BN == 128 ? 2 : 1;
+    [[maybe_unused]] int im_iy0[NCOL], im_ix0[NCOL], im_pix[NCOL];
+    [[maybe_unused]] unsigned im_inv[NCOL]; // TAPS: bit t set = tap t of this lane's pixel is padding; bit 31 always set (k-tail rows)
     if constexpr (BL == B_N4) {
 #pragma unroll
         for (int j = 0; j < NBV; j++) {
@@ -928,6 +955,15 @@ __global__ __launch_bounds__(2 * NTHREADS, 2) void igemm_f32_ws_kernel(const Gem
             im_iy0[c] = ok ? oy * p.sy - p.pt : -0x40000000;
             im_ix0[c] = ox * p.sx - p.pl;
             im_pix[c] = (int)((long long)nb * p.b_ns) + (oy * p.sy - p.pt) * p.W + im_ix0[c];
+            if constexpr (TAPS) {
+                unsigned colbad = 0; // bit kx set: column tap kx falls outside the image
+                for (int kx = 0; kx < p.KW; kx++) colbad |= ((unsigned)(im_ix0[c] + kx * p.dx) >= (unsigned)p.W ? 1u : 0u) << kx;
+                const unsigned allbad = (1u << p.KW) - 1u;
+                unsigned inv = 0x80000000u;
+                for (int ky = 0; ky < p.KH; ky++)
+                    inv |= ((unsigned)(im_iy0[c] + ky * p.dy) >= (unsigned)p.H ? allbad : colbad) << (ky * p.KW);
+                im_inv[c] = inv;
+            }
         }
     }
 
@@ -936,7 +972,7 @@ __global__ __launch_bounds__(2 * NTHREADS, 2) void igemm_f32_ws_kernel(const Gem
     constexpr int LROWS = BK / 4; // rows of a tile handled by one wave (NBG / (BN/64))
     [[maybe_unused]] i32x2 lutE[LROWS];
     [[maybe_unused]] auto fetch_lut = [&](int kt) {
-        if constexpr (BL == B_IM2COL) {
+        if constexpr (IM2COL) {
             const int krow0 = kt * BK + wave * LROWS;
             const lut_ptr_t lc = (lut_ptr_t)(unsigned long long)p.lut;
 #pragma unroll
@@ -968,11 +1004,17 @@ __global__ __launch_bounds__(2 * NTHREADS, 2) void igemm_f32_ws_kernel(const Gem
                 constexpr int CPR = BN / 64;            // gather instructions per tile row
                 const int r = j / CPR, c = j % CPR;     // row within this wave's LROWS, column chunk
                 const i32x2 e = lutE[r];
-                const int iy = im_iy0[c] + (e[1] & 0xffff);
-                const int ix = im_ix0[c] + (e[1] >> 16);
-                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(Bs + (wave * LROWS + r) * BN + c * 64), 4,
-                                                         (int)(ok ? (unsigned)(im_pix[c] + e[0]) << 2 : OOB), 0, 0, 0);
+                unsigned voff;
+                if constexpr (TAPS) {
+                    // e[1] = 31 - tap: the tap's padding bit moves to bit 31 and pushes the offset out of range
+                    voff = ((im_inv[c] << e[1]) & 0x80000000u) | ((unsigned)(im_pix[c] + e[0]) << 2);
+                } else {
+                    const int iy = im_iy0[c] + (e[1] & 0xffff);
+                    const int ix = im_ix0[c] + (e[1] >> 16);
+                    const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+                    voff = ok ? (unsigned)(im_pix[c] + e[0]) << 2 : OOB;
+                }
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(Bs + (wave * LROWS + r) * BN + c * 64), 4, (int)voff, 0, 0, 0);
             }
         }
     };
@@ -1065,7 +1107,7 @@ __global__ __launch_bounds__(2 * NTHREADS, 2) void igemm_f32_ws_kernel(const Gem
             wait_vmcnt<PER_TILE *(NSTAGE - 2)>();
             __builtin_amdgcn_s_barrier();
             const int stp = stage == 0 ? NSTAGE - 1 : stage - 1;
-            if (!(p.debug & 1)) issue_tile(kt + NSTAGE - 1, stp);
+            if (!(ABLATE(p) & 1)) issue_tile(kt + NSTAGE - 1, stp);
             fetch_lut(kt + NSTAGE);
             stage = stage == NSTAGE - 1 ? 0 : stage + 1;
         }
@@ -1078,7 +1120,7 @@ __global__ __launch_bounds__(2 * NTHREADS, 2) void igemm_f32_ws_kernel(const Gem
             const int kt_end = MULTI_KC ? ((blk + 1) * KC_TILES < nk ? (blk + 1) * KC_TILES : nk) : nk;
             for (int kt = blk * KC_TILES; kt < kt_end; kt++) {
                 __builtin_amdgcn_s_barrier();
-                if (!(p.debug & 2)) compute_tile(stage);
+                if (!(ABLATE(p) & 2)) compute_tile(stage);
                 stage = stage == NSTAGE - 1 ? 0 : stage + 1;
             }
             if constexpr (MULTI_KC) {
@@ -1087,17 +1129,19 @@ __global__ __launch_bounds__(2 * NTHREADS, 2) void igemm_f32_ws_kernel(const Gem
         }
     }
 
-    if (!(p.debug & 4)) igemm_epilogue<TM, TN, MULTI_KC>(p, acc, tot, nblk > 1, m0 + wm0 + 4 * half, n0 + wn0 + l31, c_zoff, first_value);
+    if (!(ABLATE(p) & 4)) igemm_epilogue<TM, TN, MULTI_KC>(p, acc, tot, nblk > 1, m0 + wm0 + 4 * half, n0 + wn0 + l31, c_zoff, first_value);
 }
 
 // im2col lookup table: entry k -> {c*HW + ky*dy*W + kx*dx, (ky*dy) | (kx*dx) << 16}; rows >= K get an
-// offset pair that fails every bounds test.  Built once per conv geometry and cached in the context.
-__global__ void im2col_lut_kernel(i32x2 *lut, int K, int Kpad, int KHW, int KW, int HW, int W, int dy, int dx) {
+// offset pair that fails every bounds test.  taps != 0 (B_IM2COL_TAPS): the second word is 31 - (ky*KW + kx), the
+// left shift that moves the tap's padding bit of the per-lane mask to bit 31; rows >= K use shift 0 (bit 31 is
+// always set in the masks).  Built once per conv geometry and cached in the context.
+__global__ void im2col_lut_kernel(i32x2 *lut, int K, int Kpad, int KHW, int KW, int HW, int W, int dy, int dx, int taps) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= Kpad) return;
-    if (k >= K) { lut[k] = i32x2{0, 0xffff}; return; } // dy = 65535 > any padded height
+    if (k >= K) { lut[k] = taps ? i32x2{0, 0} : i32x2{0, 0xffff}; return; } // dy = 65535 > any padded height
     const int c = k / KHW, rem = k - c * KHW, ky = rem / KW, kx = rem - ky * KW;
-    lut[k] = i32x2{c * HW + ky * dy * W + kx * dx, (ky * dy) | ((kx * dx) << 16)};
+    lut[k] = i32x2{c * HW + ky * dy * W + kx * dx, taps ? 31 - rem : (ky * dy) | ((kx * dx) << 16)};
 }
 
 } // namespace
@@ -1120,7 +1164,7 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
     const double bytes = 4.0 * Z * ((double)a.M * a.K + (double)a.K * a.N + (double)a.M * a.N);
     char kname[96];
     const bool multi = a.K > 256;
-    constexpr bool kDma = AL == A_M4 && (BL == B_N4 || BL == B_IM2COL);
+    constexpr bool kDma = AL == A_M4 && (BL == B_N4 || BL == B_IM2COL || BL == B_IM2COL_TAPS);
     if constexpr (kDma) {
         if (ctx->pipeline == 2) {
             snprintf(kname, sizeof kname, "igemm_f32_ws_kernel<%d,%d,%d,%d>", BM, BN, BL, multi ? 1 : 0);
@@ -1178,14 +1222,18 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
             return RTEN_HIP_OK;
         }
     }
-    snprintf(kname, sizeof kname, "igemm_f32_kernel<%d,%d,%d,%d,%d>", BM, BN, AL, BL, multi ? 1 : 0);
-    ProfScope ps(ctx, kname, flops, bytes);
-    if (multi)
-        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, AL, BL, true>), grid, dim3(NTHREADS), 0, ctx->stream, a);
-    else
-        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, AL, BL, false>), grid, dim3(NTHREADS), 0, ctx->stream, a);
-    RTEN_LAUNCH_CHECK(ctx, "igemm_f32_kernel launch");
-    return RTEN_HIP_OK;
+    if constexpr (BL == B_IM2COL_TAPS) {
+        return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "internal: tap-mask im2col needs an LDS-DMA pipeline");
+    } else {
+        snprintf(kname, sizeof kname, "igemm_f32_kernel<%d,%d,%d,%d,%d>", BM, BN, AL, BL, multi ? 1 : 0);
+        ProfScope ps(ctx, kname, flops, bytes);
+        if (multi)
+            hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, AL, BL, true>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+        else
+            hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, AL, BL, false>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+        RTEN_LAUNCH_CHECK(ctx, "igemm_f32_kernel launch");
+        return RTEN_HIP_OK;
+    }
 }
 
 template <int AL, int BL>
@@ -1218,6 +1266,7 @@ int32_t dispatch(rten_hip_ctx *ctx, GemmArgs &a, int Z, int al, int bl) {
     const int cfg = pick_cfg(ctx, a.M, a.N, Z);
     if (al == A_M4 && bl == B_N4) return launch_variant<A_M4, B_N4>(ctx, a, Z, cfg);
     if (al == A_M4 && bl == B_IM2COL) return launch_variant<A_M4, B_IM2COL>(ctx, a, Z, cfg);
+    if (al == A_M4 && bl == B_IM2COL_TAPS) return launch_variant<A_M4, B_IM2COL_TAPS>(ctx, a, Z, cfg);
     if (al == A_K4 && bl == B_N4) return launch_variant<A_K4, B_N4>(ctx, a, Z, cfg);
     if (al == A_K4 && bl == B_K4) return launch_variant<A_K4, B_K4>(ctx, a, Z, cfg);
     if (bl == B_IM2COL) return launch_variant<A_SCALAR, B_IM2COL>(ctx, a, Z, cfg);
@@ -1337,9 +1386,9 @@ int32_t check_conv_desc(rten_hip_ctx *ctx, const rten_hip_conv2d_desc *d) {
 }
 
 // im2col LUT cache (per context): one table per (Cg, kh, kw, dil, H, W)
-const i32x2 *get_im2col_lut(rten_hip_ctx *ctx, int Cg, int kh, int kw, int dy, int dx, int H, int W) {
+const i32x2 *get_im2col_lut(rten_hip_ctx *ctx, int Cg, int kh, int kw, int dy, int dx, int H, int W, int taps) {
     char key[96];
-    snprintf(key, sizeof key, "%d.%d.%d.%d.%d.%d.%d", Cg, kh, kw, dy, dx, H, W);
+    snprintf(key, sizeof key, "%d.%d.%d.%d.%d.%d.%d.%d", Cg, kh, kw, dy, dx, H, W, taps);
     auto it = ctx->luts.find(key);
     if (it != ctx->luts.end()) return (const i32x2 *)it->second;
     if (ctx->capturing) return nullptr; // allocation is not capturable: warm up eagerly first
@@ -1348,7 +1397,7 @@ const i32x2 *get_im2col_lut(rten_hip_ctx *ctx, int Cg, int kh, int kw, int dy, i
     void *dptr = nullptr;
     if (hipMalloc(&dptr, (size_t)Kpad * sizeof(i32x2)) != hipSuccess) return nullptr;
     hipLaunchKernelGGL(im2col_lut_kernel, dim3((Kpad + 255) / 256), dim3(256), 0, ctx->stream, (i32x2 *)dptr, K, Kpad, kh * kw,
-                       kw, H * W, W, dy, dx);
+                       kw, H * W, W, dy, dx, taps);
     ctx->luts[key] = dptr;
     return (const i32x2 *)dptr;
 }
@@ -1428,7 +1477,11 @@ RTEN_EXPORT int32_t rten_hip_conv2d_f32(rten_hip_ctx *ctx, const rten_hip_conv2d
         bl = B_N4;
         g.b_rs = HW; g.b_cs = 1;
     } else {
-        g.lut = get_im2col_lut(ctx, Cg, d->kh, d->kw, d->dil_h, d->dil_w, d->h, d->w);
+        // <= 31 kernel taps on an LDS-DMA pipeline: per-lane padding bitmask instead of per-gather bounds tests
+        const int taps = (al == A_M4 && ctx->pipeline != 0 && d->kh * d->kw <= 31) ? 1 : 0;
+        if (taps) bl = B_IM2COL_TAPS;
+        g.KH = d->kh; g.KW = d->kw; g.dy = d->dil_h; g.dx = d->dil_w;
+        g.lut = get_im2col_lut(ctx, Cg, d->kh, d->kw, d->dil_h, d->dil_w, d->h, d->w, taps);
         if (!g.lut) return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "conv: im2col table allocation failed (warm up before graph capture)");
         g.H = d->h; g.W = d->w; g.OW = d->out_w;
         g.sy = d->stride_h; g.sx = d->stride_w;
