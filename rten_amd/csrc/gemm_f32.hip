@@ -105,41 +105,128 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned vo
 }
 
 
-// Fused epilogue shared by the three kernels: last depth block, bias, residual Add, activation and the
-// NCHW / row-major store.  Buffer loads/stores with 32-bit offsets: rows >= M / columns >= N get an
-// out-of-range offset (store dropped, load returns 0), so there is no exec-mask branching and no 64-bit
-// address arithmetic per element.
-template <int TM, int TN, bool MULTI_KC, typename FirstValue>
-__device__ __forceinline__ void igemm_epilogue(const GemmArgs &p, f32x16 (&acc)[TM][TN], f32x16 (&tot)[TM][TN], bool multi_blocks,
-                                               int m_base, int n_base, long long c_zoff, FirstValue first_value) {
+// ---- fold / epilogue helpers shared by all kernels.  Every uniform condition (alpha/beta form, bias kind,
+// residual, activation) is tested ONCE per 32x32 accumulator block around straight-line code, and the block's 16
+// loads are issued back to back before the first use -- a per-element chain of uniform branches serialises every
+// load behind an s_waitcnt vmcnt(0).
+// Row of accumulator register r inside a 32x32 MFMA block (lanes 32..63 sit 4 rows lower: part of the lane's base).
+__device__ __forceinline__ constexpr int acc_row(int r) { return (r & 3) + 8 * (r >> 2); }
+
+// First depth block: out = alpha*acc + beta*C, then the bias (rten-gemm/src/lib.rs:1008-1013,1221-1255;
+// the four store forms of simd_generic.rs:378-414).  `out` may alias `acc`.
+template <int TM, int TN>
+__device__ __forceinline__ void fold_first(const GemmArgs &p, int z, f32x16 (&acc)[TM][TN], f32x16 (&out)[TM][TN], int mb, int nb0,
+                                           long long c_zoff) {
+    const __amdgpu_buffer_rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc((void *)((p.bias ? p.bias : p.C) + (long long)z * p.bias_bs), 0, 0x7ffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void *)(p.C + c_zoff), 0, 0x7ffffffc, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int mrow = mb + i * 32;
+        float brow[16];
+        if (p.bias_kind == RTEN_HIP_BIAS_PER_ROW) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) brow[r] = buf_load1(rsBias, mrow + acc_row(r) < p.M ? (unsigned)(mrow + acc_row(r)) << 2 : OOB, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int n = nb0 + j * 32;
+            const bool cok = n < p.N;
+            f32x16 v = acc[i][j];
+            if (p.beta == 0.f) {
+                if (p.alpha != 1.f) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) v[r] = v[r] * p.alpha;
+                }
+            } else {
+                const int nn = cok ? n : 0;
+                const int nb = nn / p.Pn, np = nn - nb * p.Pn;
+                const unsigned col = (unsigned)((long long)nb * p.c_ns + np);
+                float cin[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int m = mrow + acc_row(r);
+                    cin[r] = buf_load1(rsC, (m < p.M && cok) ? (col + (unsigned)m * (unsigned)p.c_rs) << 2 : OOB, 0);
+                }
+                if (p.beta == 1.f && p.alpha == 1.f) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) v[r] = cin[r] + v[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) v[r] = vm::fma(v[r], p.alpha, cin[r] * p.beta);
+                }
+            }
+            if (p.bias_kind == RTEN_HIP_BIAS_PER_ROW) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) v[r] = v[r] + brow[r];
+            } else if (p.bias_kind == RTEN_HIP_BIAS_PER_COL) {
+                const float bcol = buf_load1(rsBias, cok ? (unsigned)n << 2 : OOB, 0);
+#pragma unroll
+                for (int r = 0; r < 16; r++) v[r] = v[r] + bcol;
+            }
+            out[i][j] = v;
+        }
+    }
+}
+
+// Later depth blocks: tot = tot + alpha*acc with the reference's beta = 1 store forms (lib.rs:1008-1013).
+template <int TM, int TN>
+__device__ __forceinline__ void fold_next(const GemmArgs &p, f32x16 (&acc)[TM][TN], f32x16 (&tot)[TM][TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            if (p.alpha == 1.f) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) tot[i][j][r] = tot[i][j][r] + acc[i][j][r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; r++) tot[i][j][r] = vm::fma(acc[i][j][r], p.alpha, tot[i][j][r]);
+            }
+        }
+}
+
+// Residual Add, activation and the NCHW / row-major store of finished values.  Buffer loads/stores with 32-bit
+// offsets: the lane part (column, first row of the block) is one VGPR per block, the register's row rides in the
+// scalar offset; rows >= M / columns >= N get an out-of-range lane offset (store dropped, load returns 0).
+template <int TM, int TN>
+__device__ __forceinline__ void store_out(const GemmArgs &p, f32x16 (&val)[TM][TN], int mb, int nb0, long long c_zoff) {
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void *)(p.C + c_zoff), 0, 0x7ffffffc, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void *)((p.res ? p.res : p.C) + c_zoff), 0, 0x7ffffffc, 0x00020000);
     const bool has_res = p.res != nullptr;
+    const unsigned rs4 = (unsigned)p.c_rs << 2;
 #pragma unroll
     for (int j = 0; j < TN; j++) {
-        const int n = n_base + j * 32;
+        const int n = nb0 + j * 32;
         const bool cok = n < p.N;
         const int nn = cok ? n : 0;
         const int nb = nn / p.Pn, np = nn - nb * p.Pn;
         const unsigned col = (unsigned)((long long)nb * p.c_ns + np);
-        const long long ccol = c_zoff + (long long)nb * p.c_ns + np;
 #pragma unroll
-        for (int i = 0; i < TM; i++)
+        for (int i = 0; i < TM; i++) {
+            const int mrow = mb + i * 32;
+            const unsigned base = cok ? (col + (unsigned)mrow * (unsigned)p.c_rs) << 2 : OOB;
+            f32x16 v = val[i][j];
+            unsigned voff[16];
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int m = m_base + i * 32 + (r & 3) + 8 * (r >> 2);
-                float v;
-                if constexpr (MULTI_KC) {
-                    v = multi_blocks ? combine(acc[i][j][r], tot[i][j][r], p.alpha, 1.f) : first_value(acc[i][j][r], m, ccol, n, cok);
-                } else {
-                    v = first_value(acc[i][j][r], m, ccol, n, cok);
-                }
-                const unsigned voff = (m < p.M && cok) ? (col + (unsigned)m * (unsigned)p.c_rs) << 2 : OOB;
-                if (has_res) v = v + buf_load1(rsR, voff, 0);
-                if (p.act == RTEN_HIP_ACT_RELU) v = vm::relu(v);
-                else if (p.act == RTEN_HIP_ACT_GELU) v = vm::gelu(v);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, (int)voff, 0, 0);
+            for (int r = 0; r < 16; r++) voff[r] = mrow < p.M - acc_row(r) ? base : OOB;
+            if (has_res) {
+                float rr[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) rr[r] = buf_load1(rsR, voff[r], (unsigned)acc_row(r) * rs4);
+#pragma unroll
+                for (int r = 0; r < 16; r++) v[r] = v[r] + rr[r];
             }
+            if (p.act == RTEN_HIP_ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) v[r] = vm::relu(v[r]);
+            } else if (p.act == RTEN_HIP_ACT_GELU) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) v[r] = vm::gelu(v[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), rsC, (int)voff[r], (int)((unsigned)acc_row(r) * rs4), 0);
+        }
     }
 }
 
@@ -388,44 +475,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_kernel(const GemmArgs p
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    const __amdgpu_buffer_rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc((void *)((p.bias ? p.bias : p.C) + (long long)z * p.bias_bs), 0, 0x7ffffffc, 0x00020000);
-
-    // value of an output element after the FIRST depth block: combine with C (beta), then bias
-    auto first_value = [&](float a, int m, long long ccol, int cn, bool cok) -> float {
-        float cin = 0.f;
-        if (p.beta != 0.f && m < p.M && cok) cin = p.C[ccol + (long long)m * p.c_rs];
-        float v = combine(a, cin, p.alpha, p.beta);
-        // bias through a buffer load: rows/columns outside the matrix read 0 (they are never stored)
-        if (p.bias_kind == RTEN_HIP_BIAS_PER_ROW) v = v + buf_load1(rsBias, m < p.M ? (unsigned)m << 2 : OOB, 0);
-        else if (p.bias_kind == RTEN_HIP_BIAS_PER_COL) v = v + buf_load1(rsBias, cok ? (unsigned)cn << 2 : OOB, 0);
-        return v;
-    };
-    auto col_offset = [&](int n) -> long long {
-        const int nn = n < p.N ? n : 0;
-        const int nb = nn / p.Pn, np = nn - nb * p.Pn;
-        return c_zoff + (long long)nb * p.c_ns + np;
-    };
     // flush of one finished depth block into `tot` (between depth blocks, MULTI_KC only)
     // The row/column bases are laundered through an empty asm so that the (rare) flush's address
     // arithmetic is recomputed here instead of being hoisted out of the K loop (~100 live VGPRs).
     [[maybe_unused]] auto flush = [&](bool first) {
         int mb = m0 + wm0 + 4 * half, nb0 = n0 + wn0 + l31;
         asm volatile("" : "+v"(mb), "+v"(nb0));
+        if (first) fold_first<TM, TN>(p, z, acc, tot, mb, nb0, c_zoff);
+        else fold_next<TM, TN>(p, acc, tot);
 #pragma unroll
-        for (int j = 0; j < TN; j++) {
-            const int n = nb0 + j * 32;
-            const bool cok = n < p.N;
-            const long long ccol = first ? col_offset(n) : 0;
+        for (int i = 0; i < TM; i++)
 #pragma unroll
-            for (int i = 0; i < TM; i++)
+            for (int j = 0; j < TN; j++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int m = mb + i * 32 + (r & 3) + 8 * (r >> 2);
-                    tot[i][j][r] = first ? first_value(acc[i][j][r], m, ccol, n, cok)
-                                         : combine(acc[i][j][r], tot[i][j][r], p.alpha, 1.f);
-                    acc[i][j][r] = 0.f;
-                }
-        }
+                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
     };
 
     auto compute_tile = [&](int cur) {
@@ -472,7 +535,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_kernel(const GemmArgs p
     }
 
     // ---- final depth block + fused epilogue (residual Add, activation), NCHW / row-major store
-    if (!(ABLATE(p) & 4)) igemm_epilogue<TM, TN, MULTI_KC>(p, acc, tot, nblk > 1, m0 + wm0 + 4 * half, n0 + wn0 + l31, c_zoff, first_value);
+    if (!(ABLATE(p) & 4)) {
+        const int mb = m0 + wm0 + 4 * half, nb0 = n0 + wn0 + l31;
+        if constexpr (MULTI_KC) { // launched only for K > 256: at least two depth blocks
+            fold_next<TM, TN>(p, acc, tot);
+            store_out<TM, TN>(p, tot, mb, nb0, c_zoff);
+        } else {
+            fold_first<TM, TN>(p, z, acc, acc, mb, nb0, c_zoff);
+            store_out<TM, TN>(p, acc, mb, nb0, c_zoff);
+        }
+    }
 }
 
 
@@ -664,39 +736,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
         for (int j = 0; j < TN; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-    const __amdgpu_buffer_rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc((void *)((p.bias ? p.bias : p.C) + (long long)z * p.bias_bs), 0, 0x7ffffffc, 0x00020000);
-    auto first_value = [&](float a, int m, long long ccol, int cn, bool cok) -> float {
-        float cin = 0.f;
-        if (p.beta != 0.f && m < p.M && cok) cin = p.C[ccol + (long long)m * p.c_rs];
-        float v = combine(a, cin, p.alpha, p.beta);
-        // bias through a buffer load: rows/columns outside the matrix read 0 (they are never stored)
-        if (p.bias_kind == RTEN_HIP_BIAS_PER_ROW) v = v + buf_load1(rsBias, m < p.M ? (unsigned)m << 2 : OOB, 0);
-        else if (p.bias_kind == RTEN_HIP_BIAS_PER_COL) v = v + buf_load1(rsBias, cok ? (unsigned)cn << 2 : OOB, 0);
-        return v;
-    };
-    auto col_offset = [&](int n) -> long long {
-        const int nn = n < p.N ? n : 0;
-        const int nb = nn / p.Pn, np = nn - nb * p.Pn;
-        return c_zoff + (long long)nb * p.c_ns + np;
-    };
     [[maybe_unused]] auto flush = [&](bool first) {
         int mb = m0 + wm0 + 4 * half, nb0 = n0 + wn0 + l31;
         asm volatile("" : "+v"(mb), "+v"(nb0));
+        if (first) fold_first<TM, TN>(p, z, acc, tot, mb, nb0, c_zoff);
+        else fold_next<TM, TN>(p, acc, tot);
 #pragma unroll
-        for (int j = 0; j < TN; j++) {
-            const int n = nb0 + j * 32;
-            const bool cok = n < p.N;
-            const long long ccol = first ? col_offset(n) : 0;
+        for (int i = 0; i < TM; i++)
 #pragma unroll
-            for (int i = 0; i < TM; i++)
+            for (int j = 0; j < TN; j++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int m = mb + i * 32 + (r & 3) + 8 * (r >> 2);
-                    tot[i][j][r] = first ? first_value(acc[i][j][r], m, ccol, n, cok)
-                                         : combine(acc[i][j][r], tot[i][j][r], p.alpha, 1.f);
-                    acc[i][j][r] = 0.f;
-                }
-        }
+                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
     };
 
     auto compute_tile = [&](int stage) {
@@ -791,30 +841,41 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
     wait_vmcnt<0>(); // drain the two look-ahead tiles before the LDS goes away
 
     if constexpr (!SPLIT) {
-        if (!(ABLATE(p) & 4)) igemm_epilogue<TM, TN, MULTI_KC>(p, acc, tot, nblk > 1, m0 + wm0 + 4 * half, n0 + wn0 + l31, c_zoff, first_value);
+        if (!(ABLATE(p) & 4)) {
+        const int mb = m0 + wm0 + 4 * half, nb0 = n0 + wn0 + l31;
+        if constexpr (MULTI_KC) { // launched only for K > 256: at least two depth blocks
+            fold_next<TM, TN>(p, acc, tot);
+            store_out<TM, TN>(p, tot, mb, nb0, c_zoff);
+        } else {
+            fold_first<TM, TN>(p, z, acc, acc, mb, nb0, c_zoff);
+            store_out<TM, TN>(p, acc, mb, nb0, c_zoff);
+        }
+    }
     }
 }
 
-// Split-K fixup: one workgroup per split tile, same thread <-> element mapping as the GEMM kernels.  Replays the
-// unsplit kernel's fold over the parked per-block accumulators in depth-block order (first block: beta*C + bias;
-// later blocks: separate adds), then runs the shared epilogue (residual, activation, store).
+// Split-K fixup: one WAVE per quadrant of a split tile (grid = 4 x split tiles, 64 threads), same lane <-> element
+// mapping as the GEMM kernels.  Replays the unsplit kernel's fold over the parked per-block accumulators in
+// depth-block order (first block: beta*C + bias; later blocks: separate adds), then the shared epilogue (residual,
+// activation, store).  Slots are fetched U at a time so several loads are in flight per lane.
 template <int BM, int BN>
-__global__ __launch_bounds__(NTHREADS) void igemm_f32_fixup_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(64) void igemm_f32_fixup_kernel(const GemmArgs p) {
     constexpr int WM = 2, WN = 2;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    const int t = threadIdx.x, lane = t & 63, wq = t >> 6;
+    constexpr int U = TM * TN >= 4 ? 1 : 4 / (TM * TN); // slots per batch: 64 floats per lane in flight
+    const int lane = threadIdx.x, wq = blockIdx.x & 3, ti = blockIdx.x >> 2;
     const int l31 = lane & 31, half = lane >> 5;
     const int z = blockIdx.y;
-    const int tile = p.split_t1 + blockIdx.x;
+    const int tile = p.split_t1 + ti;
     const int bm = tile % p.tiles_m, bn = tile / p.tiles_m;
     const int m0 = bm * BM, n0 = bn * BN;
     int zo = z, zi = 0;
     if (p.batch_inner > 1) { zo = z / p.batch_inner; zi = z - zo * p.batch_inner; }
     const long long c_zoff = (long long)zo * p.c_bs + (long long)zi * p.c_bsi;
     const int wm0 = (wq / WN) * (BM / WM), wn0 = (wq % WN) * (BN / WN);
-    const float *base = p.slab + ((long long)z * p.split_ntail + blockIdx.x) * p.split_slots * (long long)(BM * BN) +
+    const float *base = p.slab + ((long long)z * p.split_ntail + ti) * p.split_slots * (long long)(BM * BN) +
                         wq * (TM * TN * 16 * 64) + lane * 4;
-    f32x16 acc[TM][TN], tot[TM][TN];
+    f32x16 acc[U][TM][TN], tot[TM][TN];
     auto load_raw = [&](f32x16 (&v)[TM][TN], int slot) {
         const float *b = base + (long long)slot * (BM * BN);
 #pragma unroll
@@ -827,45 +888,21 @@ __global__ __launch_bounds__(NTHREADS) void igemm_f32_fixup_kernel(const GemmArg
                     v[i][j][4 * q] = o[0]; v[i][j][4 * q + 1] = o[1]; v[i][j][4 * q + 2] = o[2]; v[i][j][4 * q + 3] = o[3];
                 }
     };
-    const __amdgpu_buffer_rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc((void *)((p.bias ? p.bias : p.C) + (long long)z * p.bias_bs), 0, 0x7ffffffc, 0x00020000);
-    auto first_value = [&](float a, int m, long long ccol, int cn, bool cok) -> float {
-        float cin = 0.f;
-        if (p.beta != 0.f && m < p.M && cok) cin = p.C[ccol + (long long)m * p.c_rs];
-        float v = combine(a, cin, p.alpha, p.beta);
-        if (p.bias_kind == RTEN_HIP_BIAS_PER_ROW) v = v + buf_load1(rsBias, m < p.M ? (unsigned)m << 2 : OOB, 0);
-        else if (p.bias_kind == RTEN_HIP_BIAS_PER_COL) v = v + buf_load1(rsBias, cok ? (unsigned)cn << 2 : OOB, 0);
-        return v;
-    };
-    load_raw(acc, 0);
-    {
-        const int mb = m0 + wm0 + 4 * half, nb0 = n0 + wn0 + l31;
+    const int mb = m0 + wm0 + 4 * half, nb0 = n0 + wn0 + l31;
+    load_raw(acc[0], 0);
+    fold_first<TM, TN>(p, z, acc[0], tot, mb, nb0, c_zoff);
+    int s = 1;
+    for (; s + U <= p.split_slots; s += U) {
 #pragma unroll
-        for (int j = 0; j < TN; j++) {
-            const int n = nb0 + j * 32;
-            const bool cok = n < p.N;
-            const int nn = cok ? n : 0;
-            const int nb = nn / p.Pn, np = nn - nb * p.Pn;
-            const long long ccol = c_zoff + (long long)nb * p.c_ns + np;
+        for (int u = 0; u < U; u++) load_raw(acc[u], s + u);
 #pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int m = mb + i * 32 + (r & 3) + 8 * (r >> 2);
-                    tot[i][j][r] = first_value(acc[i][j][r], m, ccol, n, cok);
-                }
-        }
+        for (int u = 0; u < U; u++) fold_next<TM, TN>(p, acc[u], tot);
     }
-    for (int s = 1; s + 1 < p.split_slots; s++) {
-        load_raw(acc, s);
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-            for (int j = 0; j < TN; j++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) tot[i][j][r] = combine(acc[i][j][r], tot[i][j][r], p.alpha, 1.f);
+    for (; s < p.split_slots; s++) {
+        load_raw(acc[0], s);
+        fold_next<TM, TN>(p, acc[0], tot);
     }
-    load_raw(acc, p.split_slots - 1);
-    igemm_epilogue<TM, TN, true>(p, acc, tot, true, m0 + wm0 + 4 * half, n0 + wn0 + l31, c_zoff, first_value);
+    store_out<TM, TN>(p, tot, mb, nb0, c_zoff);
 }
 
 template <int BM, int BN, int BL, bool MULTI_KC>
@@ -1030,39 +1067,17 @@ __global__ __launch_bounds__(2 * NTHREADS, 2) void igemm_f32_ws_kernel(const Gem
         for (int j = 0; j < TN; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-    const __amdgpu_buffer_rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc((void *)((p.bias ? p.bias : p.C) + (long long)z * p.bias_bs), 0, 0x7ffffffc, 0x00020000);
-    auto first_value = [&](float a, int m, long long ccol, int cn, bool cok) -> float {
-        float cin = 0.f;
-        if (p.beta != 0.f && m < p.M && cok) cin = p.C[ccol + (long long)m * p.c_rs];
-        float v = combine(a, cin, p.alpha, p.beta);
-        // bias through a buffer load: rows/columns outside the matrix read 0 (they are never stored)
-        if (p.bias_kind == RTEN_HIP_BIAS_PER_ROW) v = v + buf_load1(rsBias, m < p.M ? (unsigned)m << 2 : OOB, 0);
-        else if (p.bias_kind == RTEN_HIP_BIAS_PER_COL) v = v + buf_load1(rsBias, cok ? (unsigned)cn << 2 : OOB, 0);
-        return v;
-    };
-    auto col_offset = [&](int n) -> long long {
-        const int nn = n < p.N ? n : 0;
-        const int nb = nn / p.Pn, np = nn - nb * p.Pn;
-        return c_zoff + (long long)nb * p.c_ns + np;
-    };
     [[maybe_unused]] auto flush = [&](bool first) {
         int mb = m0 + wm0 + 4 * half, nb0 = n0 + wn0 + l31;
         asm volatile("" : "+v"(mb), "+v"(nb0));
+        if (first) fold_first<TM, TN>(p, z, acc, tot, mb, nb0, c_zoff);
+        else fold_next<TM, TN>(p, acc, tot);
 #pragma unroll
-        for (int j = 0; j < TN; j++) {
-            const int n = nb0 + j * 32;
-            const bool cok = n < p.N;
-            const long long ccol = first ? col_offset(n) : 0;
+        for (int i = 0; i < TM; i++)
 #pragma unroll
-            for (int i = 0; i < TM; i++)
+            for (int j = 0; j < TN; j++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int m = mb + i * 32 + (r & 3) + 8 * (r >> 2);
-                    tot[i][j][r] = first ? first_value(acc[i][j][r], m, ccol, n, cok)
-                                         : combine(acc[i][j][r], tot[i][j][r], p.alpha, 1.f);
-                    acc[i][j][r] = 0.f;
-                }
-        }
+                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
     };
 
     auto compute_tile = [&](int stage) {
@@ -1129,7 +1144,16 @@ __global__ __launch_bounds__(2 * NTHREADS, 2) void igemm_f32_ws_kernel(const Gem
         }
     }
 
-    if (!(ABLATE(p) & 4)) igemm_epilogue<TM, TN, MULTI_KC>(p, acc, tot, nblk > 1, m0 + wm0 + 4 * half, n0 + wn0 + l31, c_zoff, first_value);
+    if (!(ABLATE(p) & 4)) {
+        const int mb = m0 + wm0 + 4 * half, nb0 = n0 + wn0 + l31;
+        if constexpr (MULTI_KC) { // launched only for K > 256: at least two depth blocks
+            fold_next<TM, TN>(p, acc, tot);
+            store_out<TM, TN>(p, tot, mb, nb0, c_zoff);
+        } else {
+            fold_first<TM, TN>(p, z, acc, acc, mb, nb0, c_zoff);
+            store_out<TM, TN>(p, acc, mb, nb0, c_zoff);
+        }
+    }
 }
 
 // im2col lookup table: entry k -> {c*HW + ky*dy*W + kx*dx, (ky*dy) | (kx*dx) << 16}; rows >= K get an
@@ -1216,7 +1240,7 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
                 }
                 snprintf(kname, sizeof kname, "igemm_f32_fixup_kernel<%d,%d>", BM, BN);
                 ProfScope ps(ctx, kname, 0.0, 8.0 * Z * ntail * nblk * BM * BN);
-                hipLaunchKernelGGL((igemm_f32_fixup_kernel<BM, BN>), dim3((unsigned)ntail, (unsigned)Z), dim3(NTHREADS), 0, ctx->stream, a);
+                hipLaunchKernelGGL((igemm_f32_fixup_kernel<BM, BN>), dim3((unsigned)ntail * 4u, (unsigned)Z), dim3(64), 0, ctx->stream, a);
                 RTEN_LAUNCH_CHECK(ctx, "igemm_f32_fixup_kernel launch");
             }
             return RTEN_HIP_OK;
