@@ -224,8 +224,10 @@ __device__ __forceinline__ void store_out(const GemmArgs &p, f32x16 (&val)[TM][T
                 for (int r = 0; r < 16; r++) v[r] = vm::gelu(v[r]);
             }
 #pragma unroll
-            for (int r = 0; r < 16; r++)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), rsC, (int)voff[r], (int)((unsigned)acc_row(r) * rs4), 0);
+            for (int r = 0; r < 16; r++) {
+                const float x = v[r];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), rsC, (int)voff[r], (int)((unsigned)acc_row(r) * rs4), 0);
+            }
         }
     }
 }
