@@ -260,10 +260,11 @@ int32_t rten_hip_gather_rows_f32(rten_hip_ctx *ctx, int64_t n_ids, int32_t row_l
  * variant < 0 restores the built-in heuristic.  Used by the harness's autotuner. */
 int32_t rten_hip_set_gemm_variant_override(rten_hip_ctx *ctx, int32_t variant);
 int32_t rten_hip_num_gemm_variants(void);
-/* Exact split-K for the conv GEMMs (results stay bit-identical: K is only cut at the reference's depth-block
- * boundaries, rten-gemm/src/lib.rs:630-633, and partial sums are added in block order).  mode 0 = off,
- * 1 = split only the tiles beyond the last full round of compute units, 2 = split every tile;
- * groups = K groups per split tile.  A tuning knob like the variant override: sticky until changed. */
+/* Exact split-K for GEMM / conv (results stay bit-identical: K is only cut at the reference's depth-block
+ * boundaries, rten-gemm/src/lib.rs:630-633, and the per-block partial sums are added in block order by a fixup
+ * kernel).  mode 0 = off, 1 = split only the tiles beyond the last full round of compute units, 2 = split every
+ * tile, 3 = automatic (default: split every tile when the launch would have fewer workgroups than half the compute
+ * units); groups = K groups per split tile (modes 1, 2).  A tuning knob like the variant override: sticky. */
 int32_t rten_hip_set_gemm_split(rten_hip_ctx *ctx, int32_t mode, int32_t groups);
 
 #ifdef __cplusplus

@@ -232,8 +232,10 @@ __device__ __forceinline__ void store_out(const GemmArgs &p, f32x16 (&val)[TM][T
     }
 }
 
-template <int BM, int BN, int AL, int BL, bool MULTI_KC>
+// MODE: 0 = one depth block, 1 = several depth blocks folded in registers, 2 = split-K producer (see the LDS-DMA kernel).
+template <int BM, int BN, int AL, int BL, int MODE>
 __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_kernel(const GemmArgs p) {
+    constexpr bool MULTI_KC = MODE == 1, SPLIT = MODE == 2;
     constexpr int WM = 2, WN = 2;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int LDA = BM + 4, LDB = BN + 4;
@@ -251,12 +253,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_kernel(const GemmArgs p
     const int z = blockIdx.y;
 
     // ---- XCD-aware tile mapping: consecutive ids on one XCD walk down a column of tiles (same B panel)
-    int tile;
+    int tile, grp = -1; // grp >= 0: this workgroup computes one K group of a split tile
     {
-        const int nt = p.tiles_m * p.tiles_n;
+        const int nt = gridDim.x;
         const int id = blockIdx.x;
         const int xcd = id & 7, q = nt >> 3, r = nt & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+        if constexpr (SPLIT) {
+            const int rr = tile;
+            tile = p.split_t1 + rr / p.split_s;
+            grp = rr - (rr / p.split_s) * p.split_s;
+        }
     }
     const int bm = tile % p.tiles_m, bn = tile / p.tiles_m;
     const int m0 = bm * BM, n0 = bn * BN;
@@ -515,15 +522,36 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_kernel(const GemmArgs p
         __builtin_amdgcn_iglp_opt(0);
     };
 
+    [[maybe_unused]] auto store_raw = [&](f32x16 (&v)[TM][TN], int slot) {
+        int loff = wave * (TM * TN * 16 * 64) + lane * 4;
+        asm volatile("" : "+v"(loff));
+        float *base = p.slab + (((long long)z * p.split_ntail + (tile - p.split_t1)) * p.split_slots + slot) * (long long)(BM * BN) + loff;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    f32x4 o = {v[i][j][4 * q], v[i][j][4 * q + 1], v[i][j][4 * q + 2], v[i][j][4 * q + 3]};
+                    *(f32x4 *)(base + ((i * TN + j) * 4 + q) * 256) = o;
+                }
+    };
+
     // ---- main loop: depth blocks of KC_TILES k-tiles; inside a block the loop body is branch free
-    fetch_lut(0);
-    load_tile(0);
-    fetch_lut(1);
+    const int nblk = (MULTI_KC || SPLIT) ? (nk + KC_TILES - 1) / KC_TILES : 1;
+    int blk0 = 0, blk1 = nblk;
+    if constexpr (SPLIT) {
+        blk0 = grp * p.split_g;
+        blk1 = blk0 + p.split_g < nblk ? blk0 + p.split_g : nblk;
+    }
+    const int kt0 = blk0 * KC_TILES; // even: the double-buffer parity of tile kt stays kt & 1
+    fetch_lut(kt0);
+    load_tile(kt0);
+    fetch_lut(kt0 + 1);
     store_tile(0);
     __syncthreads();
-    const int nblk = MULTI_KC ? (nk + KC_TILES - 1) / KC_TILES : 1;
-    for (int blk = 0; blk < nblk; blk++) {
-        const int kt_end = MULTI_KC ? ((blk + 1) * KC_TILES < nk ? (blk + 1) * KC_TILES : nk) : nk;
+    for (int blk = blk0; blk < blk1; blk++) {
+        const int kt_end = (MULTI_KC || SPLIT) ? ((blk + 1) * KC_TILES < nk ? (blk + 1) * KC_TILES : nk) : nk;
         for (int kt = blk * KC_TILES; kt < kt_end; kt++) {
             load_tile(kt + 1); // prefetch; past the end every lane is out of range -> zeros, never used
             fetch_lut(kt + 2);
@@ -531,20 +559,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_kernel(const GemmArgs p
             store_tile((kt + 1) & 1);
             __syncthreads();
         }
+        if constexpr (SPLIT) {
+            store_raw(acc, blk);
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+        }
         if constexpr (MULTI_KC) {
             if (blk + 1 < nblk) flush(blk == 0);
         }
     }
 
     // ---- final depth block + fused epilogue (residual Add, activation), NCHW / row-major store
-    if (!(ABLATE(p) & 4)) {
-        const int mb = m0 + wm0 + 4 * half, nb0 = n0 + wn0 + l31;
-        if constexpr (MULTI_KC) { // launched only for K > 256: at least two depth blocks
-            fold_next<TM, TN>(p, acc, tot);
-            store_out<TM, TN>(p, tot, mb, nb0, c_zoff);
-        } else {
-            fold_first<TM, TN>(p, z, acc, acc, mb, nb0, c_zoff);
-            store_out<TM, TN>(p, acc, mb, nb0, c_zoff);
+    if constexpr (!SPLIT) {
+        if (!(ABLATE(p) & 4)) {
+            const int mb = m0 + wm0 + 4 * half, nb0 = n0 + wn0 + l31;
+            if constexpr (MULTI_KC) { // launched only for K > 256: at least two depth blocks
+                fold_next<TM, TN>(p, acc, tot);
+                store_out<TM, TN>(p, tot, mb, nb0, c_zoff);
+            } else {
+                fold_first<TM, TN>(p, z, acc, acc, mb, nb0, c_zoff);
+                store_out<TM, TN>(p, acc, mb, nb0, c_zoff);
+            }
         }
     }
 }
@@ -1181,85 +1220,94 @@ struct TileCfg { int bm, bn; float penalty; };
 // variant ids are part of the tuning interface (rten_hip_set_gemm_variant_override)
 constexpr TileCfg kCfgs[4] = {{128, 128, 1.00f}, {128, 64, 1.04f}, {64, 128, 1.04f}, {64, 64, 1.12f}};
 
+// One launch plan for every pipeline: whole tiles [0, t1) by the folding kernel (MODE 0/1), split tiles [t1, T) by
+// the split-K producer (MODE 2) followed by the ordered fixup.  Only depth-block boundaries are legal K cuts.
 template <int BM, int BN, int AL, int BL>
 int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.N + BN - 1) / BN;
-    dim3 grid((unsigned)(a.tiles_m * a.tiles_n), (unsigned)Z);
     const double flops = 2.0 * a.M * (double)a.N * a.K * Z;
     const double bytes = 4.0 * Z * ((double)a.M * a.K + (double)a.K * a.N + (double)a.M * a.N);
     char kname[96];
     const bool multi = a.K > 256;
     constexpr bool kDma = AL == A_M4 && (BL == B_N4 || BL == B_IM2COL || BL == B_IM2COL_TAPS);
-    if constexpr (kDma) {
-        if (ctx->pipeline == 2) {
-            snprintf(kname, sizeof kname, "igemm_f32_ws_kernel<%d,%d,%d,%d>", BM, BN, BL, multi ? 1 : 0);
-            ProfScope ps(ctx, kname, flops, bytes);
-            if (multi)
-                hipLaunchKernelGGL((igemm_f32_ws_kernel<BM, BN, BL, true>), grid, dim3(2 * NTHREADS), 0, ctx->stream, a);
-            else
-                hipLaunchKernelGGL((igemm_f32_ws_kernel<BM, BN, BL, false>), grid, dim3(2 * NTHREADS), 0, ctx->stream, a);
-            RTEN_LAUNCH_CHECK(ctx, "igemm_f32_ws_kernel launch");
-            return RTEN_HIP_OK;
-        }
-        if (ctx->pipeline == 1) {
-            // exact split-K plan (see GemmArgs): only depth-block boundaries are legal cut points
-            const int nblk = (a.K + 255) / 256;
-            const int T = a.tiles_m * a.tiles_n;
-            int ntail = 0, t1 = T, S = 1;
-            if (multi && ctx->split_mode > 0 && ctx->split_s > 1) {
-                const int s_req = ctx->split_s < nblk ? ctx->split_s : nblk;
-                const int G = (nblk + s_req - 1) / s_req;
-                S = (nblk + G - 1) / G;
-                t1 = ctx->split_mode == 2 ? 0 : (T / ctx->num_cus) * ctx->num_cus;
-                if (S > 1 && t1 < T) {
-                    ntail = T - t1;
-                    a.split_t1 = t1; a.split_s = S; a.split_g = G; a.split_slots = nblk; a.split_ntail = ntail;
-                    const size_t need = 4096 + (size_t)Z * ntail * nblk * BM * BN * sizeof(float);
-                    char *sc = (char *)rten_scratch(ctx, need);
-                    if (!sc) return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "split-K slab allocation failed (or attempted during graph capture)");
-                    a.slab = (float *)(sc + 4096);
-                } else {
-                    t1 = T;
-                }
-            }
-            if (t1 > 0) { // whole tiles [0, t1)
-                snprintf(kname, sizeof kname, "igemm_f32_dma_kernel<%d,%d,%d,%d>", BM, BN, BL, multi ? 1 : 0);
-                ProfScope ps(ctx, kname, flops * t1 / T, bytes * t1 / T);
-                grid.x = (unsigned)t1;
-                if (multi)
-                    hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, BL, 1>), grid, dim3(NTHREADS), 0, ctx->stream, a);
-                else
-                    hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, BL, 0>), grid, dim3(NTHREADS), 0, ctx->stream, a);
-                RTEN_LAUNCH_CHECK(ctx, "igemm_f32_dma_kernel launch");
-            }
-            if (ntail > 0) { // split tiles [t1, T): producers, then the ordered fold + epilogue
-                {
-                    snprintf(kname, sizeof kname, "igemm_f32_dma_kernel<%d,%d,%d,2>", BM, BN, BL);
-                    ProfScope ps(ctx, kname, flops * ntail / T, bytes * ntail / T);
-                    hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, BL, 2>), dim3((unsigned)(ntail * S), (unsigned)Z), dim3(NTHREADS), 0, ctx->stream, a);
-                    RTEN_LAUNCH_CHECK(ctx, "igemm_f32_dma_kernel (split-K) launch");
-                }
-                snprintf(kname, sizeof kname, "igemm_f32_fixup_kernel<%d,%d>", BM, BN);
-                ProfScope ps(ctx, kname, 0.0, 8.0 * Z * ntail * nblk * BM * BN);
-                hipLaunchKernelGGL((igemm_f32_fixup_kernel<BM, BN>), dim3((unsigned)ntail * 4u, (unsigned)Z), dim3(64), 0, ctx->stream, a);
-                RTEN_LAUNCH_CHECK(ctx, "igemm_f32_fixup_kernel launch");
-            }
-            return RTEN_HIP_OK;
-        }
-    }
+    const int pipe = kDma ? ctx->pipeline : 0;
     if constexpr (BL == B_IM2COL_TAPS) {
-        return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "internal: tap-mask im2col needs an LDS-DMA pipeline");
-    } else {
-        snprintf(kname, sizeof kname, "igemm_f32_kernel<%d,%d,%d,%d,%d>", BM, BN, AL, BL, multi ? 1 : 0);
-        ProfScope ps(ctx, kname, flops, bytes);
-        if (multi)
-            hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, AL, BL, true>), grid, dim3(NTHREADS), 0, ctx->stream, a);
-        else
-            hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, AL, BL, false>), grid, dim3(NTHREADS), 0, ctx->stream, a);
-        RTEN_LAUNCH_CHECK(ctx, "igemm_f32_kernel launch");
-        return RTEN_HIP_OK;
+        if (pipe == 0) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "internal: tap-mask im2col needs an LDS-DMA pipeline");
     }
+
+    const int nblk = (a.K + 255) / 256;
+    const int T = a.tiles_m * a.tiles_n;
+    int ntail = 0, t1 = T, S = 1;
+    a.split_s = 1;
+    int split_mode = ctx->split_mode, split_req = ctx->split_s;
+    if (split_mode == 3) { // auto: too few tiles to fill the chip -> cut every tile so that ~num_cus workgroups exist
+        const long long wgs = (long long)T * Z;
+        split_mode = (multi && wgs * 2 <= ctx->num_cus) ? 2 : 0;
+        split_req = (int)(ctx->num_cus / (wgs > 0 ? wgs : 1));
+    }
+    if (multi && pipe != 2 && split_mode > 0 && split_req > 1) {
+        const int s_req = split_req < nblk ? split_req : nblk;
+        const int G = (nblk + s_req - 1) / s_req;
+        S = (nblk + G - 1) / G;
+        t1 = split_mode == 2 ? 0 : (T / ctx->num_cus) * ctx->num_cus;
+        if (S > 1 && t1 < T) {
+            ntail = T - t1;
+            a.split_t1 = t1; a.split_s = S; a.split_g = G; a.split_slots = nblk; a.split_ntail = ntail;
+            const size_t need = 4096 + (size_t)Z * ntail * nblk * BM * BN * sizeof(float);
+            char *sc = (char *)rten_scratch(ctx, need);
+            if (!sc) return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "split-K slab allocation failed (or attempted during graph capture)");
+            a.slab = (float *)(sc + 4096);
+        } else {
+            t1 = T;
+        }
+    }
+
+    auto launch = [&](int mode, unsigned gx, double fl, double by) -> int32_t {
+        const dim3 grid(gx, (unsigned)Z);
+        if constexpr (kDma) {
+            if (pipe == 2) {
+                snprintf(kname, sizeof kname, "igemm_f32_ws_kernel<%d,%d,%d,%d>", BM, BN, BL, mode);
+                ProfScope ps(ctx, kname, fl, by);
+                if (mode == 1) hipLaunchKernelGGL((igemm_f32_ws_kernel<BM, BN, BL, true>), grid, dim3(2 * NTHREADS), 0, ctx->stream, a);
+                else hipLaunchKernelGGL((igemm_f32_ws_kernel<BM, BN, BL, false>), grid, dim3(2 * NTHREADS), 0, ctx->stream, a);
+                RTEN_LAUNCH_CHECK(ctx, "igemm_f32_ws_kernel launch");
+                return RTEN_HIP_OK;
+            }
+            if (pipe == 1) {
+                snprintf(kname, sizeof kname, "igemm_f32_dma_kernel<%d,%d,%d,%d>", BM, BN, BL, mode);
+                ProfScope ps(ctx, kname, fl, by);
+                if (mode == 2) hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, BL, 2>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+                else if (mode == 1) hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, BL, 1>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+                else hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, BL, 0>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+                RTEN_LAUNCH_CHECK(ctx, "igemm_f32_dma_kernel launch");
+                return RTEN_HIP_OK;
+            }
+        }
+        if constexpr (BL != B_IM2COL_TAPS) {
+            snprintf(kname, sizeof kname, "igemm_f32_kernel<%d,%d,%d,%d,%d>", BM, BN, AL, BL, mode);
+            ProfScope ps(ctx, kname, fl, by);
+            if (mode == 2) hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, AL, BL, 2>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+            else if (mode == 1) hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, AL, BL, 1>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+            else hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, AL, BL, 0>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+            RTEN_LAUNCH_CHECK(ctx, "igemm_f32_kernel launch");
+        }
+        return RTEN_HIP_OK;
+    };
+
+    if (t1 > 0) {
+        const int32_t rc = launch(multi ? 1 : 0, (unsigned)t1, flops * t1 / T, bytes * t1 / T);
+        if (rc) return rc;
+    }
+    if (ntail > 0) {
+        const int32_t rc = launch(2, (unsigned)(ntail * S), flops * ntail / T, bytes * ntail / T);
+        if (rc) return rc;
+        snprintf(kname, sizeof kname, "igemm_f32_fixup_kernel<%d,%d>", BM, BN);
+        ProfScope ps(ctx, kname, 0.0, 8.0 * Z * ntail * nblk * BM * BN);
+        hipLaunchKernelGGL((igemm_f32_fixup_kernel<BM, BN>), dim3((unsigned)ntail * 4u, (unsigned)Z), dim3(64), 0, ctx->stream, a);
+        RTEN_LAUNCH_CHECK(ctx, "igemm_f32_fixup_kernel launch");
+    }
+    return RTEN_HIP_OK;
 }
 
 template <int AL, int BL>
@@ -1322,11 +1370,12 @@ RTEN_EXPORT int32_t rten_hip_set_gemm_variant_override(rten_hip_ctx *ctx, int32_
     return RTEN_HIP_OK;
 }
 
-// Exact split-K plan for the LDS-DMA conv kernels: mode 0 = off, 1 = split only the tiles past the last full
-// round of num_cus workgroups (tail balancing), 2 = split every tile; `groups` = K groups per split tile.
+// Exact split-K plan: mode 0 = off, 1 = split only the tiles past the last full round of num_cus workgroups (tail
+// balancing), 2 = split every tile, 3 = automatic (default: split every tile when fewer than num_cus/2 workgroups
+// would exist); `groups` = K groups per split tile (modes 1, 2).
 RTEN_EXPORT int32_t rten_hip_set_gemm_split(rten_hip_ctx *ctx, int32_t mode, int32_t groups) {
     RTEN_CHECK_CTX(ctx);
-    if (mode < 0 || mode > 2 || groups < 0) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "set_gemm_split: bad mode/groups");
+    if (mode < 0 || mode > 3 || groups < 0) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "set_gemm_split: bad mode/groups");
     ctx->split_mode = mode;
     ctx->split_s = groups;
     return RTEN_HIP_OK;

@@ -182,7 +182,7 @@ class ResNet50:
                  self._wptr(l["name"], 1), self._act(l["res"]).vp if l["res"] else None, flags, self._act(l["dst"]).vp)
         if plan is not None:
             ctx.set_gemm_variant(-1)
-            ctx.call("rten_hip_set_gemm_split", 0, 1)
+            ctx.call("rten_hip_set_gemm_split", 3, 1)  # back to the automatic plan
 
     def forward(self):
         """Enqueue one forward pass over self.x -> self.logits (asynchronous)."""

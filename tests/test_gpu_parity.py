@@ -106,6 +106,30 @@ def test_gemm_f32_options_bit_exact(ctx):
     bits_equal(gpu_gemm(ctx, a, b, bias=bc, bias_kind=L.BIAS_PER_COL, act=L.ACT_GELU), ref.gelu(ref.gemm_f32(a, b, bias=bc, bias_kind=ref.BIAS_PER_COL)))
 
 
+def test_gemm_f32_split_k_bit_exact(ctx):
+    # exact split-K on the generic GEMM path (every operand layout, alpha/beta/bias/act in the fixup epilogue);
+    # the default automatic plan splits skinny products such as the ResNet classifier [32, 2048] x [2048, 1000]
+    rng = ref.XorShiftRng(11)
+    try:
+        for (m, k, n) in ((32, 2048, 1000), (70, 700, 130), (2, 1030, 5)):
+            a = rng.f32(m * k).reshape(m, k) - 0.5
+            b = rng.f32(k * n).reshape(k, n) - 0.5
+            c = rng.f32(m * n).reshape(m, n)
+            bc = rng.f32(n)
+            at, bt = np.ascontiguousarray(a.T).T, np.ascontiguousarray(b.T).T
+            want = ref.gemm_f32(a, b)
+            want2 = ref.gelu(ref.gemm_f32(a, b, c=c, alpha=0.5, beta=2.0, bias=bc, bias_kind=ref.BIAS_PER_COL))
+            for mode, groups in ((3, 1), (2, 2), (2, 3), (2, 64), (1, 4)):
+                ctx.call("rten_hip_set_gemm_split", mode, groups)
+                for aa, bb in ((a, b), (at, b), (a, bt), (at, bt)):
+                    bits_equal(gpu_gemm(ctx, aa, bb), want)
+                bits_equal(gpu_gemm(ctx, a, bt, c=c, alpha=0.5, beta=2.0, bias=bc, bias_kind=L.BIAS_PER_COL, act=L.ACT_GELU), want2)
+                for v in (0, 3):
+                    bits_equal(gpu_gemm(ctx, a, b, variant=v), want)
+    finally:
+        ctx.call("rten_hip_set_gemm_split", 3, 1)
+
+
 def test_gemm_f32_gemv_tolerance(ctx):
     # M == 1: the reference takes its ISA-dependent gemv path; parity by tolerance (rtol 1e-5 of sum|a||b|)
     rng = ref.XorShiftRng(11)
@@ -243,7 +267,7 @@ def test_conv_f32_split_k_bit_exact(ctx, shape):
         bits_equal(gpu_conv(ctx, x, w, None, (pad,) * 4, (s, s), variant=3),
                    ref.conv2d_f32(x, w, None, pads=(pad,) * 4, strides=(s, s)))
     finally:
-        ctx.call("rten_hip_set_gemm_split", 0, 1)
+        ctx.call("rten_hip_set_gemm_split", 3, 1)
 
 
 # ------------------------------------------------------------------------------------------ int8
