@@ -59,6 +59,9 @@ def main():
     ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layer-table", action="store_true", help="print the per-layer autotune table to stderr")
+    ap.add_argument("--save-plan", default=None, help="write the autotuned per-layer plans (variant, split mode, groups) as JSON")
+    ap.add_argument("--load-plan", default=None, help="use per-layer plans from a JSON file instead of autotuning (profiling runs)")
+    ap.add_argument("--no-concurrent", action="store_true", help="keep the projection shortcuts on the main stream")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,8 +108,14 @@ def main():
     ctx.sync()
 
     table = None
+    net.concurrent = not args.no_concurrent
+    if args.load_plan:
+        net.variants = {k: tuple(v) for k, v in json.load(open(args.load_plan)).items()}
+        args.no_autotune = True
     if not args.no_autotune:
         table = net.autotune(reps=3)
+        if args.save_plan and rank == 0:
+            json.dump({k: list(v) for k, v in net.variants.items()}, open(args.save_plan, "w"))
         if args.layer_table and rank == 0:
             for l in net.specs:
                 d = net.descs[l["name"]]
@@ -159,11 +168,12 @@ def main():
         ctx.profile_reset()
         ctx.profile(True)
         saved_graph, net.graph = net.graph, None
+        saved_conc, net.concurrent = net.concurrent, False  # serialised launches: clean per-kernel durations
         for _ in range(args.steps):
             net.forward()
         ctx.sync()
         ctx.profile(False)
-        net.graph = saved_graph
+        net.graph, net.concurrent = saved_graph, saved_conc
         rep = ctx.profile_report()
         conv = [r for r in rep if r["kernel"].startswith("igemm_f32")]
         tot_ms = sum(r["ms"] for r in rep)
@@ -195,7 +205,7 @@ def main():
             "config": {"workload": "ResNet-50 v1.5 f32 inference, 224x224, batch 32 per GPU (BASELINE configs[1]); "
                                    "synthetic He-normal BN-folded weights (seed 1234), inputs U[0,1) resident in HBM",
                        "global_batch": global_batch, "parallelism": f"batch-shard x{n_gpus} (weights RCCL-broadcast once)" if n_gpus > 1 else "single GPU",
-                       "launch": "eager" if args.no_graph else "hipGraph replay", "autotuned_tiles": not args.no_autotune,
+                       "launch": "eager" if args.no_graph else "hipGraph replay", "autotuned_tiles": bool(net.variants), "shortcut_branch": "second stream" if net.concurrent else "main stream",
                        "gflop_per_image": round((resnet50.conv_flops_per_image() + 2 * 2048 * 1000) / 1e9, 3),
                        "device": ctx.device_info()},
             "roofline": roof,

@@ -80,6 +80,12 @@ int32_t rten_hip_graph_end(rten_hip_ctx *ctx, uint64_t *out_graph);
 int32_t rten_hip_graph_launch(rten_hip_ctx *ctx, uint64_t graph);
 int32_t rten_hip_graph_destroy(rten_hip_ctx *ctx, uint64_t graph);
 
+/* Order two contexts (streams) of one device: work enqueued on `waiter` after the call runs after everything
+ * enqueued on `signaler` so far.  Independent operators (e.g. a residual block's downsample branch) can run on a
+ * second context concurrently; inside a capture the second context becomes a parallel branch of the same graph and
+ * must be joined back (rten_hip_stream_wait(capturing_ctx, side_ctx)) before rten_hip_graph_end. */
+int32_t rten_hip_stream_wait(rten_hip_ctx *waiter, rten_hip_ctx *signaler);
+
 /* Per-kernel-class profiling: when enabled, every conv/gemm launch is bracketed by events and its
  * time and algorithmic work are accumulated per kernel name (Profiler, src/timing.rs).  Not usable
  * during graph capture. */

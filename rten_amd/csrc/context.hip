@@ -125,6 +125,7 @@ RTEN_EXPORT int32_t rten_hip_destroy(rten_hip_ctx *ctx) {
             hipEventDestroy(p.second);
         }
     for (hipEvent_t e : ctx->event_pool) hipEventDestroy(e);
+    for (hipEvent_t e : ctx->sync_events) hipEventDestroy(e);
     for (auto &t : ctx->timers)
         for (hipEvent_t e : t)
             if (e) hipEventDestroy(e);
@@ -246,6 +247,28 @@ RTEN_EXPORT int32_t rten_hip_graph_end(rten_hip_ctx *ctx, uint64_t *out_graph) {
     hipGraphDestroy(graph);
     if (e != hipSuccess) return rten_check_hip(ctx, e, "hipGraphInstantiate");
     *out_graph = (uint64_t)(uintptr_t)exec;
+    return RTEN_HIP_OK;
+}
+
+// Cross-stream ordering between two contexts on the same device: work enqueued on `waiter` after this call runs
+// after everything enqueued on `signaler` so far.  During graph capture this is how a second context joins (and
+// later re-joins) the capturing context's graph, giving parallel branches.
+RTEN_EXPORT int32_t rten_hip_stream_wait(rten_hip_ctx *waiter, rten_hip_ctx *signaler) {
+    RTEN_CHECK_CTX(waiter);
+    if (!signaler || signaler->device != waiter->device)
+        return rten_set_error(waiter, RTEN_HIP_ERR_INVALID_VALUE, "stream_wait: contexts must share a device");
+    if (waiter == signaler) return RTEN_HIP_OK;
+    if (waiter->sync_events.size() < 64) {
+        hipEvent_t e = nullptr;
+        RTEN_HIP_TRY(waiter, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        waiter->sync_events.push_back(e);
+    }
+    hipEvent_t ev = waiter->sync_events[waiter->sync_next++ % waiter->sync_events.size()];
+    RTEN_HIP_TRY(waiter, hipEventRecord(ev, signaler->stream));
+    RTEN_HIP_TRY(waiter, hipStreamWaitEvent(waiter->stream, ev, 0));
+    // capture bookkeeping: a context forked from a capturing one must not allocate either; the join hands it back
+    if (signaler->capturing && !waiter->capturing) { waiter->capturing = true; waiter->capture_origin = signaler->capture_origin ? signaler->capture_origin : signaler; }
+    else if (signaler->capturing && waiter->capturing && signaler->capture_origin == waiter) { signaler->capturing = false; signaler->capture_origin = nullptr; }
     return RTEN_HIP_OK;
 }
 

@@ -28,6 +28,9 @@ struct rten_hip_ctx {
     std::string last_error;
     hipEvent_t timers[64][2] = {};
     bool capturing = false;
+    rten_hip_ctx *capture_origin = nullptr;  // set on contexts that joined another context's capture (stream_wait)
+    std::vector<hipEvent_t> sync_events;     // cross-context ordering events (round robin)
+    size_t sync_next = 0;
     // profiling
     bool profiling = false;
     std::map<std::string, ProfEntry> prof;

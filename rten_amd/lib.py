@@ -138,6 +138,7 @@ PROTOTYPES = {
     "rten_hip_set_gemm_variant_override": (_I32, [_VP, _I32]),
     "rten_hip_num_gemm_variants": (_I32, []),
     "rten_hip_set_gemm_split": (_I32, [_VP, _I32, _I32]),
+    "rten_hip_stream_wait": (_I32, [_VP, _VP]),
 }
 
 _lib = None
@@ -236,6 +237,10 @@ class Context:
         buf = C.create_string_buffer(1 << 16)
         self.call("rten_hip_profile_report", buf, len(buf))
         return json.loads(buf.value.decode())
+
+    def wait(self, other: "Context"):
+        """Work enqueued on this context from now on runs after everything enqueued on `other` so far."""
+        self.call("rten_hip_stream_wait", other.h)
 
     def set_gemm_variant(self, v: int):
         self.call("rten_hip_set_gemm_variant_override", v)

@@ -30,13 +30,15 @@ def conv_specs():
             s = stride if bi == 0 else 1
             pre = f"s{si}b{bi}"
             cout = width * 4
-            layers.append(dict(name=pre + "c1", cin=cin, cout=width, k=1, stride=1, pad=0, relu=True, src=cur, res=None, dst=pre + "t1"))
-            layers.append(dict(name=pre + "c2", cin=width, cout=width, k=3, stride=s, pad=1, relu=True, src=pre + "t1", res=None, dst=pre + "t2"))
+            # the projection shortcut comes first: it only depends on the block input, so the runner can put it on a
+            # second stream next to c1 -> c2 (its output stays live until c3 either way)
             if bi == 0:
                 layers.append(dict(name=pre + "ds", cin=cin, cout=cout, k=1, stride=s, pad=0, relu=False, src=cur, res=None, dst=pre + "id"))
                 ident = pre + "id"
             else:
                 ident = cur
+            layers.append(dict(name=pre + "c1", cin=cin, cout=width, k=1, stride=1, pad=0, relu=True, src=cur, res=None, dst=pre + "t1"))
+            layers.append(dict(name=pre + "c2", cin=width, cout=width, k=3, stride=s, pad=1, relu=True, src=pre + "t1", res=None, dst=pre + "t2"))
             layers.append(dict(name=pre + "c3", cin=width, cout=cout, k=1, stride=1, pad=0, relu=True, src=pre + "t2", res=ident, dst=pre + "out"))
             cur, cin = pre + "out", cout
     return layers
@@ -82,6 +84,8 @@ class ResNet50:
         self.specs = conv_specs()
         self.graph = None
         self.variants = {}
+        self.side = None          # second context (stream) for the projection shortcuts
+        self.concurrent = True    # run ds convs next to c1 -> c2
         self._plan(arena_ptr, arena_keepalive)
 
     # ---- static plan: shapes, weight arena, activation buffers, launch list
@@ -117,8 +121,14 @@ class ResNet50:
         # activation buffers with liveness-based reuse: op i's output is taken from the free list, then the
         # inputs whose last consumer is op i are released (so an output never aliases a live input).
         ops = [(["x"], "stem"), (["stem"], "pool")]
+        ds_src = {}
         for l in self.specs[1:]:
-            ops.append(([l["src"]] + ([l["res"]] if l["res"] else []), l["dst"]))
+            ins = [l["src"]] + ([l["res"]] if l["res"] else [])
+            if l["name"].endswith("ds"):
+                ds_src[l["dst"]] = l["src"]
+            if l["res"] in ds_src:
+                ins.append(ds_src[l["res"]])  # the side stream may still be reading the block input until the join at c3
+            ops.append((ins, l["dst"]))
         last_use = {}
         for i, (ins, _) in enumerate(ops):
             for nm in ins:
@@ -170,8 +180,8 @@ class ResNet50:
     def _act(self, name):
         return self.x if name == "x" else self.bufs[name]
 
-    def _conv(self, l):
-        ctx = self.ctx
+    def _conv(self, l, ctx=None):
+        ctx = ctx or self.ctx
         plan = self.variants.get(l["name"])
         if plan is not None:
             v, mode, groups = plan if isinstance(plan, tuple) else (plan, 0, 1)
@@ -185,11 +195,23 @@ class ResNet50:
             ctx.call("rten_hip_set_gemm_split", 3, 1)  # back to the automatic plan
 
     def forward(self):
-        """Enqueue one forward pass over self.x -> self.logits (asynchronous)."""
+        """Enqueue one forward pass over self.x -> self.logits (asynchronous).  With `concurrent`, each projection
+        shortcut runs on a second context (stream) next to c1 -> c2 and is joined before c3 reads it."""
         ctx = self.ctx
+        if self.concurrent and self.side is None:
+            self.side = L.Context(ctx.device)
         self._conv(self.specs[0])
         ctx.call("rten_hip_max_pool2d_f32", C.byref(self.pool_desc), self.bufs["stem"].vp, self.bufs["pool"].vp)
+        pending = set()  # shortcut outputs produced on the side stream and not yet joined
         for l in self.specs[1:]:
+            if self.concurrent and l["name"].endswith("ds"):
+                self.side.wait(ctx)           # block input is ready
+                self._conv(l, self.side)
+                pending.add(l["dst"])
+                continue
+            if l["res"] in pending:
+                ctx.wait(self.side)
+                pending.discard(l["res"])
             self._conv(l)
         last = self.specs[-1]["dst"]
         n, c, h, w = self.shapes[last]
@@ -219,7 +241,7 @@ class ResNet50:
         d = self.descs[l["name"]]
         nblk = (d.c // d.groups * d.kh * d.kw + 255) // 256
         if nblk > 1:
-            for v in range(4):
+            for v in range(8):  # LDS-DMA and register-staged pipelines; the wave-specialised kernel has no split form
                 for groups in sorted({2, 3, 4, 6, nblk} & set(range(2, nblk + 1))):
                     plans.append((v, 1, groups))
                     plans.append((v, 2, groups))

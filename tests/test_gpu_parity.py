@@ -493,6 +493,11 @@ def test_resnet50_end_to_end_bit_exact_and_graph_replay(ctx):
     net.autotune(reps=1)
     net.forward()
     bits_equal(net.logits.numpy(), want)
+    # projection shortcuts on the main stream instead of the second context
+    net.concurrent = False
+    net.logits.upload(np.zeros_like(logits))
+    net.forward()
+    bits_equal(net.logits.numpy(), want)
 
 
 def test_resnet50_batch32_batch_independence(ctx):

@@ -11,5 +11,5 @@ else
   timeout 1200 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/${TAG}_pytest_gpu.log 2>&1
 fi
 echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest_gpu.log
-timeout 900 python bench.py --layer-table > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$?" >> gpurun_out/${TAG}_bench.err
+timeout 900 python bench.py --layer-table --save-plan gpurun_out/${TAG}_plan.json > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$?" >> gpurun_out/${TAG}_bench.err
 tail -15 gpurun_out/${TAG}_pytest_gpu.log; head -c 2500 gpurun_out/${TAG}_bench.json; tail -5 gpurun_out/${TAG}_bench.err
