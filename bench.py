@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--layer-table", action="store_true", help="print the per-layer autotune table to stderr")
     ap.add_argument("--save-plan", default=None, help="write the autotuned per-layer plans (variant, split mode, groups) as JSON")
     ap.add_argument("--load-plan", default=None, help="use per-layer plans from a JSON file instead of autotuning (profiling runs)")
-    ap.add_argument("--no-concurrent", action="store_true", help="keep the projection shortcuts on the main stream")
+    ap.add_argument("--concurrent", action="store_true", help="run the projection shortcuts on a second stream (parallel graph branches)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -108,7 +108,7 @@ def main():
     ctx.sync()
 
     table = None
-    net.concurrent = not args.no_concurrent
+    net.concurrent = args.concurrent
     if args.load_plan:
         net.variants = {k: tuple(v) for k, v in json.load(open(args.load_plan)).items()}
         args.no_autotune = True

@@ -85,7 +85,7 @@ class ResNet50:
         self.graph = None
         self.variants = {}
         self.side = None          # second context (stream) for the projection shortcuts
-        self.concurrent = True    # run ds convs next to c1 -> c2
+        self.concurrent = False   # True: run ds convs next to c1 -> c2 (measured: no gain at batch 32, kernels already fill the chip)
         self._plan(arena_ptr, arena_keepalive)
 
     # ---- static plan: shapes, weight arena, activation buffers, launch list

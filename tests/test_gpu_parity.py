@@ -493,10 +493,14 @@ def test_resnet50_end_to_end_bit_exact_and_graph_replay(ctx):
     net.autotune(reps=1)
     net.forward()
     bits_equal(net.logits.numpy(), want)
-    # projection shortcuts on the main stream instead of the second context
-    net.concurrent = False
+    # projection shortcuts on a second context (stream): eager and as parallel hipGraph branches
+    net.concurrent = True
     net.logits.upload(np.zeros_like(logits))
     net.forward()
+    bits_equal(net.logits.numpy(), want)
+    net.capture()
+    net.logits.upload(np.zeros_like(logits))
+    net.run()
     bits_equal(net.logits.numpy(), want)
 
 

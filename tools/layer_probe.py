@@ -17,7 +17,8 @@ from rten_amd.models import resnet50  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--layers", default="s0b0c2,s0b0c3,s2b1c1,s2b1c2,s3b1c2")
-    ap.add_argument("--variants", default="0,3")
+    ap.add_argument("--variants", default="0,3", help="comma list of variant or variant:splitmode:groups")
+    ap.add_argument("--plan", default=None, help="JSON plan file written by bench.py --save-plan: probe each layer with its tuned plan")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32)
     args = ap.parse_args()
@@ -32,7 +33,13 @@ def main():
         l = by_name[name]
         d = net.descs[name]
         fl = 2.0 * d.o * d.c * d.kh * d.kw * d.out_h * d.out_w * d.n
-        for v in [int(x) for x in args.variants.split(",")]:
+        plans = args.variants.split(",")
+        if args.plan:
+            import json
+            plans = [":".join(str(x) for x in json.load(open(args.plan))[name])]
+        for vs in plans:
+            f = [int(x) for x in vs.split(":")]
+            v = tuple(f) if len(f) == 3 else (f[0], 0, 1)
             net.variants[name] = v
             net._conv(l)
             ctx.timer_start(2)
@@ -40,7 +47,7 @@ def main():
                 net._conv(l)
             ctx.timer_stop(2)
             ms = ctx.timer_ms(2) / args.reps
-            print(f"{name} v{v}: {ms*1e3:8.1f} us  {fl/ms/1e9:6.1f} TF/s  (M={d.o} K={d.c*d.kh*d.kw} N={d.n*d.out_h*d.out_w})", flush=True)
+            print(f"{name} plan{v}: {ms*1e3:8.1f} us  {fl/ms/1e9:6.1f} TF/s  (M={d.o} K={d.c*d.kh*d.kw} N={d.n*d.out_h*d.out_w})", flush=True)
 
 
 if __name__ == "__main__":
