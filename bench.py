@@ -122,10 +122,10 @@ def main():
                 fl = 2.0 * d.o * d.c * d.kh * d.kw * d.out_h * d.out_w * d.n
                 row = table[l["name"]]
                 best_ms = min(ms for _, ms in row)
-                nosplit = " ".join(f"v{p[0]}={ms*1e3:6.1f}" for p, ms in row if p[1] == 0)
-                split = sorted(((ms, p) for p, ms in row if p[1] != 0))[:3]
+                nosplit = " ".join(f"v{p[0]}={ms*1e3:6.1f}" for p, ms in row if p[1] == 0 and p[3] == 0)
+                split = sorted(((ms, p) for p, ms in row if p[1] != 0 or p[3] != 0))[:4]
                 print(f"[layer] {l['name']:8s} O={d.o:4d} C={d.c:4d} k={d.kh} s={d.stride_h} {d.h:3d}->{d.out_h:3d} us: {nosplit}"
-                      + " | split " + " ".join(f"v{p[0]}m{p[1]}g{p[2]}={ms*1e3:6.1f}" for ms, p in split)
+                      + " | split " + " ".join(f"v{p[0]}m{p[1]}g{p[2]}o{p[3]}={ms*1e3:6.1f}" for ms, p in split)
                       + f"  best={net.variants[l['name']]} {fl / (best_ms * 1e-3) / 1e12:6.1f} TF/s", file=sys.stderr)
     if not args.no_graph:
         net.capture()

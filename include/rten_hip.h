@@ -272,6 +272,10 @@ int32_t rten_hip_num_gemm_variants(void);
  * tile, 3 = automatic (default: split every tile when the launch would have fewer workgroups than half the compute
  * units); groups = K groups per split tile (modes 1, 2).  A tuning knob like the variant override: sticky. */
 int32_t rten_hip_set_gemm_split(rten_hip_ctx *ctx, int32_t mode, int32_t groups);
+/* Workgroup -> tile order (tuning knob, sticky, default 0): bit 0 = tiles walk n fastest instead of m fastest;
+ * bit 1 = split-K workgroups walk tiles fastest and K groups slowest, so that each XCD's private L2 holds one K
+ * slice of both operands. */
+int32_t rten_hip_set_gemm_order(rten_hip_ctx *ctx, int32_t order);
 
 #ifdef __cplusplus
 }

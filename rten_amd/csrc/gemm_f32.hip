@@ -88,6 +88,7 @@ struct GemmArgs {
     // the fixup kernel replays the unsplit fold over the slots in block order -> bit-identical to the unsplit chain.
     float *slab;
     int split_t1, split_s, split_g, split_slots, split_ntail;
+    int order; // bit 0: tiles walk n fastest (default m fastest); bit 1: split workgroups walk tiles fastest, K groups slowest
 };
 
 __device__ __forceinline__ float combine(float t, float c, float alpha, float beta) {
@@ -261,11 +262,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_kernel(const GemmArgs p
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
         if constexpr (SPLIT) {
             const int rr = tile;
-            tile = p.split_t1 + rr / p.split_s;
-            grp = rr - (rr / p.split_s) * p.split_s;
+            if (p.order & 2) { // K group slowest: an XCD's contiguous id range is one K slice of many tiles
+                grp = rr / p.split_ntail;
+                tile = p.split_t1 + rr - grp * p.split_ntail;
+            } else {           // K group fastest: an XCD's range is all K slices of a few tiles
+                tile = p.split_t1 + rr / p.split_s;
+                grp = rr - (rr / p.split_s) * p.split_s;
+            }
         }
     }
-    const int bm = tile % p.tiles_m, bn = tile / p.tiles_m;
+    const int bm = (p.order & 1) ? tile / p.tiles_n : tile % p.tiles_m, bn = (p.order & 1) ? tile % p.tiles_n : tile / p.tiles_m;
     const int m0 = bm * BM, n0 = bn * BN;
 
     int zo = z, zi = 0;
@@ -643,11 +649,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
         if constexpr (SPLIT) {
             const int rr = tile;
-            tile = p.split_t1 + rr / p.split_s;
-            grp = rr - (rr / p.split_s) * p.split_s;
+            if (p.order & 2) { // K group slowest: an XCD's contiguous id range is one K slice of many tiles
+                grp = rr / p.split_ntail;
+                tile = p.split_t1 + rr - grp * p.split_ntail;
+            } else {           // K group fastest: an XCD's range is all K slices of a few tiles
+                tile = p.split_t1 + rr / p.split_s;
+                grp = rr - (rr / p.split_s) * p.split_s;
+            }
         }
     }
-    const int bm = tile % p.tiles_m, bn = tile / p.tiles_m;
+    const int bm = (p.order & 1) ? tile / p.tiles_n : tile % p.tiles_m, bn = (p.order & 1) ? tile % p.tiles_n : tile / p.tiles_m;
     const int m0 = bm * BM, n0 = bn * BN;
 
     int zo = z, zi = 0;
@@ -908,7 +919,7 @@ __global__ __launch_bounds__(64) void igemm_f32_fixup_kernel(const GemmArgs p) {
     const int l31 = lane & 31, half = lane >> 5;
     const int z = blockIdx.y;
     const int tile = p.split_t1 + ti;
-    const int bm = tile % p.tiles_m, bn = tile / p.tiles_m;
+    const int bm = (p.order & 1) ? tile / p.tiles_n : tile % p.tiles_m, bn = (p.order & 1) ? tile % p.tiles_n : tile / p.tiles_m;
     const int m0 = bm * BM, n0 = bn * BN;
     int zo = z, zi = 0;
     if (p.batch_inner > 1) { zo = z / p.batch_inner; zi = z - zo * p.batch_inner; }
@@ -978,7 +989,7 @@ __global__ __launch_bounds__(2 * NTHREADS, 2) void igemm_f32_ws_kernel(const Gem
         const int xcd = id & 7, q = nt >> 3, r = nt & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
     }
-    const int bm = tile % p.tiles_m, bn = tile / p.tiles_m;
+    const int bm = (p.order & 1) ? tile / p.tiles_n : tile % p.tiles_m, bn = (p.order & 1) ? tile % p.tiles_n : tile / p.tiles_m;
     const int m0 = bm * BM, n0 = bn * BN;
 
     int zo = z, zi = 0;
@@ -1240,6 +1251,7 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
     const int T = a.tiles_m * a.tiles_n;
     int ntail = 0, t1 = T, S = 1;
     a.split_s = 1;
+    a.order = ctx->tile_order;
     int split_mode = ctx->split_mode, split_req = ctx->split_s;
     if (split_mode == 3) { // auto: too few tiles to fill the chip -> cut every tile so that ~num_cus workgroups exist
         const long long wgs = (long long)T * Z;
@@ -1378,6 +1390,15 @@ RTEN_EXPORT int32_t rten_hip_set_gemm_split(rten_hip_ctx *ctx, int32_t mode, int
     if (mode < 0 || mode > 3 || groups < 0) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "set_gemm_split: bad mode/groups");
     ctx->split_mode = mode;
     ctx->split_s = groups;
+    return RTEN_HIP_OK;
+}
+
+// Workgroup -> tile order (tuning knob, sticky): bit 0 = tiles walk n fastest instead of m fastest; bit 1 = split-K
+// workgroups walk tiles fastest and K groups slowest (each XCD's L2 then holds one K slice of both operands).
+RTEN_EXPORT int32_t rten_hip_set_gemm_order(rten_hip_ctx *ctx, int32_t order) {
+    RTEN_CHECK_CTX(ctx);
+    if (order < 0 || order > 3) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "set_gemm_order: order must be 0..3");
+    ctx->tile_order = order;
     return RTEN_HIP_OK;
 }
 

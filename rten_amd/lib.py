@@ -139,6 +139,7 @@ PROTOTYPES = {
     "rten_hip_num_gemm_variants": (_I32, []),
     "rten_hip_set_gemm_split": (_I32, [_VP, _I32, _I32]),
     "rten_hip_stream_wait": (_I32, [_VP, _VP]),
+    "rten_hip_set_gemm_order": (_I32, [_VP, _I32]),
 }
 
 _lib = None

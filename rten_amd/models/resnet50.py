@@ -184,15 +184,17 @@ class ResNet50:
         ctx = ctx or self.ctx
         plan = self.variants.get(l["name"])
         if plan is not None:
-            v, mode, groups = plan if isinstance(plan, tuple) else (plan, 0, 1)
+            v, mode, groups, order = (tuple(plan) + (0,))[:4] if isinstance(plan, (tuple, list)) else (plan, 0, 1, 0)
             ctx.set_gemm_variant(v)
             ctx.call("rten_hip_set_gemm_split", mode, groups)
+            ctx.call("rten_hip_set_gemm_order", order)
         flags = (L.CONV_RELU if l["relu"] else 0) | (L.CONV_RESIDUAL if l["res"] else 0)
         ctx.call("rten_hip_conv2d_f32", C.byref(self.descs[l["name"]]), self._act(l["src"]).vp, self._wptr(l["name"], 0), 1,
                  self._wptr(l["name"], 1), self._act(l["res"]).vp if l["res"] else None, flags, self._act(l["dst"]).vp)
         if plan is not None:
             ctx.set_gemm_variant(-1)
             ctx.call("rten_hip_set_gemm_split", 3, 1)  # back to the automatic plan
+            ctx.call("rten_hip_set_gemm_order", 0)
 
     def forward(self):
         """Enqueue one forward pass over self.x -> self.logits (asynchronous).  With `concurrent`, each projection
@@ -234,17 +236,18 @@ class ResNet50:
             self.forward()
 
     def candidate_plans(self, l):
-        """(variant, split mode, K groups) plans worth timing for one conv layer.  Split-K plans exist for
+        """(variant, split mode, K groups, tile order) plans worth timing for one conv layer.  Split-K plans exist for
         the LDS-DMA variants (0..3) when K spans more than one depth block of 256."""
         nvar = self.ctx.lib.rten_hip_num_gemm_variants()
-        plans = [(v, 0, 1) for v in range(nvar)]
+        plans = [(v, 0, 1, o) for v in range(nvar) for o in (0, 1)]
         d = self.descs[l["name"]]
         nblk = (d.c // d.groups * d.kh * d.kw + 255) // 256
         if nblk > 1:
             for v in range(8):  # LDS-DMA and register-staged pipelines; the wave-specialised kernel has no split form
                 for groups in sorted({2, 3, 4, 6, nblk} & set(range(2, nblk + 1))):
-                    plans.append((v, 1, groups))
-                    plans.append((v, 2, groups))
+                    plans.append((v, 1, groups, 0))
+                    for o in (0, 2, 3):
+                        plans.append((v, 2, groups, o))
         return plans
 
     def autotune(self, reps=3):

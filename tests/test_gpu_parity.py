@@ -240,6 +240,12 @@ def test_conv_f32_resnet_layer_shapes_all_variants(ctx, shape):
     want = ref.conv2d_f32(x, w, b, pads=(pad,) * 4, strides=(s, s), relu=True)
     for v in range(ctx.lib.rten_hip_num_gemm_variants()):  # 0..3 LDS-DMA pipeline, 4..7 register-staged
         bits_equal(gpu_conv(ctx, x, w, b, (pad,) * 4, (s, s), relu=True, variant=v), want)
+    try:
+        ctx.call("rten_hip_set_gemm_order", 1)  # tiles walk n fastest
+        for v in (0, 3, 7, 11):
+            bits_equal(gpu_conv(ctx, x, w, b, (pad,) * 4, (s, s), relu=True, variant=v), want)
+    finally:
+        ctx.call("rten_hip_set_gemm_order", 0)
 
 
 @pytest.mark.parametrize("shape", [(128, 128, 28, 3, 1, 1), (256, 256, 14, 3, 1, 1), (512, 512, 7, 3, 1, 1), (512, 2048, 7, 1, 1, 0),
@@ -262,12 +268,16 @@ def test_conv_f32_split_k_bit_exact(ctx, shape):
             for mode in (1, 2):
                 for groups in sorted({2, 3, nblk}):
                     ctx.call("rten_hip_set_gemm_split", mode, groups)
-                    bits_equal(gpu_conv(ctx, x, w, b, (pad,) * 4, (s, s), residual=res, relu=True, variant=v), want)
+                    for order in ((0, 1, 2, 3) if v == 3 else (0, 3)):  # workgroup -> tile orders
+                        ctx.call("rten_hip_set_gemm_order", order)
+                        bits_equal(gpu_conv(ctx, x, w, b, (pad,) * 4, (s, s), residual=res, relu=True, variant=v), want)
+                    ctx.call("rten_hip_set_gemm_order", 0)
         ctx.call("rten_hip_set_gemm_split", 2, 2)
         bits_equal(gpu_conv(ctx, x, w, None, (pad,) * 4, (s, s), variant=3),
                    ref.conv2d_f32(x, w, None, pads=(pad,) * 4, strides=(s, s)))
     finally:
         ctx.call("rten_hip_set_gemm_split", 3, 1)
+        ctx.call("rten_hip_set_gemm_order", 0)
 
 
 # ------------------------------------------------------------------------------------------ int8

@@ -39,7 +39,7 @@ def main():
             plans = [":".join(str(x) for x in json.load(open(args.plan))[name])]
         for vs in plans:
             f = [int(x) for x in vs.split(":")]
-            v = tuple(f) if len(f) == 3 else (f[0], 0, 1)
+            v = tuple(f) if len(f) >= 3 else (f[0], 0, 1)
             net.variants[name] = v
             net._conv(l)
             ctx.timer_start(2)

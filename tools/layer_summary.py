@@ -7,7 +7,7 @@ for l in open(sys.argv[1]):
     name = l.split()[1]
     ns = re.search(r'us: (.*?) \| split (.*?)  best=(\(.*?\))\s+([\d.]+) TF', l)
     v = dict((k, float(x)) for k, x in re.findall(r'(v\d+)=\s*([\d.]+)', ns.group(1)))
-    sp = re.findall(r'(v\d+m\d+g\d+)=\s*([\d.]+)', ns.group(2))
+    sp = re.findall(r'(v\d+m\d+g\d+o\d+)=\s*([\d.]+)', ns.group(2))
     bestv = min(v, key=v.get)
     b = min([v[bestv]] + [float(x) for _, x in sp])
     tot += b
