@@ -276,6 +276,9 @@ int32_t rten_hip_set_gemm_split(rten_hip_ctx *ctx, int32_t mode, int32_t groups)
  * bit 1 = split-K workgroups walk tiles fastest and K groups slowest, so that each XCD's private L2 holds one K
  * slice of both operands. */
 int32_t rten_hip_set_gemm_order(rten_hip_ctx *ctx, int32_t order);
+/* int8 kernels: 0 = automatic (operands staged k-contiguous / padded NHWC + 16-byte LDS-DMA MFMA kernel whenever it
+ * covers the call), 1 = generic byte-gather kernel only.  Both produce the reference's bits. */
+int32_t rten_hip_set_int8_path(rten_hip_ctx *ctx, int32_t mode);
 
 #ifdef __cplusplus
 }

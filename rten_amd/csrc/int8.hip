@@ -25,6 +25,12 @@
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 
+// int8_fast.hip: k-contiguous staging + LDS-DMA MFMA kernel; RTEN_HIP_ERR_UNSUPPORTED = not covered, use the generic kernel
+int32_t rten_i8_fast_gemm(rten_hip_ctx *ctx, const rten_hip_gemm_int8_desc *d, const void *a, const void *b, const void *a_zp,
+                          const void *b_zp, const float *scale, void *c);
+int32_t rten_i8_fast_conv(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di, const void *x, const void *w, const void *x_zp,
+                          const void *w_zp, const float *scale, const float *bias, const float *residual, uint32_t flags, void *y);
+
 namespace {
 
 constexpr int IBM = 64, IBN = 64, IBK = 64;
@@ -266,6 +272,10 @@ RTEN_EXPORT int32_t rten_hip_gemm_int8(rten_hip_ctx *ctx, const rten_hip_gemm_in
         return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "Zero point has incorrect size"); // matmul.rs:523
     if (d->scale_len != 0 && d->scale_len != 1 && d->scale_len != d->n)
         return rten_set_error(ctx, RTEN_HIP_ERR_INCOMPATIBLE_SHAPES, "Scale length does not match tensor columns");
+    if (ctx->int8_path == 0 && d->k > 0) {
+        const int32_t rc = rten_i8_fast_gemm(ctx, d, a, b, a_zp, b_zp, scale, c);
+        if (rc != RTEN_HIP_ERR_UNSUPPORTED) return rc;
+    }
     I8Args g = {};
     g.A = (const uint8_t *)a; g.B = (const uint8_t *)b; g.C = c;
     g.a_zp = d->a_zp_len ? (const uint8_t *)a_zp : nullptr;
@@ -301,6 +311,10 @@ RTEN_EXPORT int32_t rten_hip_conv2d_int8(rten_hip_ctx *ctx, const rten_hip_conv2
     const long long HW = (long long)d->h * d->w;
     if ((long long)d->n * d->c * HW >= (1ll << 31) || (long long)d->n * d->o * P >= (1ll << 31))
         return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "conv: tensors above 2^31 elements are not supported");
+    if (ctx->int8_path == 0) {
+        const int32_t rc = rten_i8_fast_conv(ctx, di, x, w, x_zp, w_zp, scale, bias, residual, flags, y);
+        if (rc != RTEN_HIP_ERR_UNSUPPORTED) return rc;
+    }
     I8Args g = {};
     // kernel is the LHS (conv.rs:461-474): A = W[o][k], B = im2col(x)
     g.A = (const uint8_t *)w; g.B = (const uint8_t *)x; g.C = y;
@@ -326,4 +340,12 @@ RTEN_EXPORT int32_t rten_hip_conv2d_int8(rten_hip_ctx *ctx, const rten_hip_conv2
     g.magic_khw = magic_for((unsigned)g.KHW); g.magic_kw = magic_for((unsigned)g.KW);
     g.pad_mode = di->pad_mode;
     return launch_i8(ctx, g, d->groups);
+}
+
+// 0 = automatic (k-contiguous staging + LDS-DMA kernel whenever it covers the call), 1 = generic kernel only.
+RTEN_EXPORT int32_t rten_hip_set_int8_path(rten_hip_ctx *ctx, int32_t mode) {
+    RTEN_CHECK_CTX(ctx);
+    if (mode < 0 || mode > 1) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "set_int8_path: mode must be 0 or 1");
+    ctx->int8_path = mode;
+    return RTEN_HIP_OK;
 }

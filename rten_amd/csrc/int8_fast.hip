@@ -1,0 +1,436 @@
+// Fast int8 GEMM / convolution path for gfx950: v_mfma_i32_32x32x32_i8 fed by 16-byte LDS-DMA.
+//
+// Replaces (together with int8.hip, which stays as the generic fallback): GemmExecutor<u8,i8,i32> and its packing
+// (rten-gemm/src/kernels/generic.rs:274-366, packing/int8.rs), the int8 im2col (im2col.rs:264-389) and the
+// front-ends conv_integer / ConvIntegerToFloat / matmul_integer (src/ops/conv.rs:421-587, matmul.rs:582-810).
+//
+// Integer sums are exact in any order, so -- unlike the f32 path -- the K dimension may be re-ordered.  That is
+// what makes the int8 path fast on this machine:
+//   * Both MFMA operands want 16 CONSECUTIVE k bytes per lane.  Operands are therefore staged once per call as
+//     "k-contiguous signed rows": weights as [rows][Kp] (conv: k = (ky, kx, c), channels padded to 16), with their
+//     row sums; conv activations as a zero-point-PADDED NHWC image [N][H+pads][W+pads][Cp], so that the im2col
+//     gather of one (tap, 16-channel) chunk is one aligned 16-byte load per pixel and needs no bounds tests at all
+//     (the spatial border holds the reference's padding value for the selected pad mode).
+//     u8 operands move to the signed domain (x ^ 0x80) during staging; (x - zp) is invariant under that shift.
+//   * Main loop: tiles go L2 -> LDS with `buffer_load_dwordx4 ... lds` (1 KiB per wave instruction), chunk-major
+//     LDS image [4 chunks][rows][16 B] (the DMA's lane-linear destination), so an MFMA operand fetch is one
+//     conflict-free ds_read_b128.  Three LDS stages, counted vmcnt waits, one barrier per 64-byte k-tile.
+//     Per-lane offsets are loop invariant; the k advance (conv: the (ky, kx, c) chunk walk) is scalar.
+//   * Zero-point algebra of the reference (simd_generic.rs:676-746): C = dot - b_zp*rowsum(A) - a_zp*colsum(B)
+//     + K*a_zp*b_zp with weight sums from the staging pass; the activation-side sums are only accumulated
+//     (v_dot4 on the operand fragments) when the weight zero point can be non-zero.
+//   * Epilogue fuses cast_scale, bias, residual Add and Relu; i32 or f32 output straight into NCHW / row-major.
+#include "internal.h"
+#include "vecmath.h"
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int KT = 64;          // k bytes per tile (4 chunks of 16)
+constexpr int NSTAGE = 3;
+constexpr unsigned OOB = 0x80000000u;
+
+struct FastArgs {
+    const uint8_t *A;      // [M][Kp] signed rows
+    const uint8_t *B;      // GEMM: [N][Kp] signed rows; conv: padded NHWC image
+    const int *rsum;       // [M] sums of A rows
+    const int *csum;       // [N] sums of B rows (GEMM) or NULL (conv: accumulated in-kernel when needed)
+    void *C;
+    const uint8_t *a_zp, *b_zp;
+    const float *scale, *bias, *res;
+    int M, N, Kp, Kreal;
+    unsigned a_bytes, b_bytes;
+    long long c_rs, c_ns;
+    int Pn;
+    int a_signed, b_signed, a_zp_len, b_zp_len, scale_len, relu, need_csum;
+    int tiles_m, tiles_n;
+    // conv geometry (padded image)
+    int conv, OW, sy, sx, Hp, Wp, Cp, KH, KW, dy, dx;
+};
+
+__device__ __forceinline__ int zp_signed(const uint8_t *zp, int idx, int is_signed) {
+    if (!zp) return is_signed ? 0 : -128;
+    return is_signed ? (int)(int8_t)zp[idx] : (int)zp[idx] - 128;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ constexpr int acc_row(int r) { return (r & 3) + 8 * (r >> 2); }
+
+// ---------------------------------------------------------------------------------------------------------
+// staging kernels
+// ---------------------------------------------------------------------------------------------------------
+
+// rows of a strided u8/i8 matrix -> k-contiguous signed rows [rows][Kp] (+ row sums).  With khw > 1 the source k
+// index is (c, tap) (OIHW weights) and the destination k index is (tap, c) with channels padded to Cp.
+__global__ __launch_bounds__(256) void i8_pack_rows_kernel(const uint8_t *__restrict__ src, long long row_stride, long long k_stride, int K,
+                                                          int C, int khw, int Cp, int Kp, unsigned flip, uint8_t *__restrict__ dst,
+                                                          int *__restrict__ sums) {
+    const int r = blockIdx.x;
+    const uint8_t *s = src + (long long)r * row_stride;
+    uint8_t *d = dst + (long long)r * Kp;
+    int sum = 0;
+    for (int kq = threadIdx.x * 4; kq < Kp; kq += 1024) {
+        unsigned w = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int kd = kq + b;
+            const int tap = kd / Cp, c = kd - tap * Cp;
+            const bool ok = tap < khw && c < C;
+            const int ks = c * khw + tap;
+            const unsigned v = ok ? ((unsigned)s[(long long)(ks < K ? ks : 0) * k_stride] ^ flip) & 0xffu : 0u;
+            w |= v << (8 * b);
+        }
+        *reinterpret_cast<unsigned *>(d + kq) = w;
+        sum = __builtin_amdgcn_sdot4((int)w, 0x01010101, sum, false);
+    }
+    __shared__ int red[4];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[r] = red[0] + red[1] + red[2] + red[3];
+}
+
+// NCHW u8/i8 -> padded NHWC signed bytes [N][Hp][Wp][Cp]; border = pad value of the selected mode, padded channels 0.
+__global__ __launch_bounds__(256) void i8_nhwc_pad_kernel(const uint8_t *__restrict__ x, uint8_t *__restrict__ xp, int C, int H, int W, int Hp,
+                                                         int Wp, int Cp, int pt, int pl, unsigned flip, const uint8_t *__restrict__ x_zp,
+                                                         int x_signed, int pad_mode) {
+    __shared__ uint8_t tile[64][64 + 16];
+    const int t = threadIdx.x;
+    const int x0 = blockIdx.x * 64, yp = blockIdx.y, n = blockIdx.z;
+    const int y = yp - pt;
+    int pad_s = 0;
+    if (pad_mode == RTEN_HIP_PAD_ZERO_POINT) pad_s = zp_signed(x_zp, 0, x_signed);
+    else if (pad_mode == RTEN_HIP_PAD_RAW0_U8) pad_s = -128;
+    const unsigned fill = (unsigned)pad_s & 0xffu;
+    const bool yin = (unsigned)y < (unsigned)H;
+    for (int c0 = 0; c0 < Cp; c0 += 64) {
+        const int xl = t & 63, xs = x0 + xl - pl;
+        const bool xin = yin && (unsigned)xs < (unsigned)W;
+#pragma unroll
+        for (int pass = 0; pass < 16; pass++) {
+            const int cl = pass * 4 + (t >> 6), c = c0 + cl;
+            unsigned v = c < C ? fill : 0u;
+            if (xin && c < C) v = ((unsigned)x[(((long long)n * C + c) * H + y) * W + xs] ^ flip) & 0xffu;
+            tile[xl][cl] = (uint8_t)v;
+        }
+        __syncthreads();
+        const int px = t >> 2, ch = t & 3;
+        if (x0 + px < Wp && c0 + ch * 16 < Cp)
+            *reinterpret_cast<uint4 *>(xp + (((long long)n * Hp + yp) * Wp + x0 + px) * Cp + c0 + ch * 16) = *reinterpret_cast<const uint4 *>(&tile[px][ch * 16]);
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// main kernel
+// ---------------------------------------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p) {
+    constexpr int WM = 2, WN = 2;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int RA = BM / 64, RB = BN / 64;      // DMA instructions per chunk (64 rows each)
+    constexpr int PER_TILE = RA + RB;              // per wave: wave w moves chunk w of the tile
+    constexpr int STAGE = (BM + BN) * KT;          // bytes
+    __shared__ __attribute__((aligned(16))) uint8_t smem[NSTAGE * STAGE];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wq = t >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    int tile;
+    {
+        const int nt = gridDim.x, id = blockIdx.x;
+        const int xcd = id & 7, q = nt >> 3, r = nt & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    }
+    const int bm = tile % p.tiles_m, bn = tile / p.tiles_m;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)p.A, 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void *)p.B, 0, (int)p.b_bytes, 0x00020000);
+
+    // loop-invariant per-lane row bases (bytes)
+    unsigned a_voff[RA], b_voff[RB];
+#pragma unroll
+    for (int j = 0; j < RA; j++) {
+        const int m = m0 + j * 64 + lane;
+        a_voff[j] = m < p.M ? (unsigned)m * (unsigned)p.Kp : OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < RB; j++) {
+        const int n = n0 + j * 64 + lane;
+        if (n < p.N) {
+            if (p.conv) {
+                const int nb = n / p.Pn, np = n - nb * p.Pn;
+                const int oy = np / p.OW, ox = np - oy * p.OW;
+                b_voff[j] = (unsigned)(((nb * p.Hp + oy * p.sy) * p.Wp + ox * p.sx) * p.Cp);
+            } else {
+                b_voff[j] = (unsigned)n * (unsigned)p.Kp;
+            }
+        } else {
+            b_voff[j] = OOB;
+        }
+    }
+
+    // this wave's chunk walk: chunk index wave, wave + 4, ...  (conv: (ky, kx, c16) odometer, no divisions)
+    const int nchunks = p.Kp / 16;
+    const int cpc = p.conv ? p.Cp / 16 : 1; // chunks per tap
+    int ch_idx = wave;                      // chunk index of the next tile to issue
+    int ch_c = 0, ch_kx = 0, ch_ky = 0;
+    if (p.conv) {
+        ch_c = wave;
+        while (ch_c >= cpc) { ch_c -= cpc; if (++ch_kx == p.KW) { ch_kx = 0; ch_ky++; } }
+    }
+    typedef __attribute__((address_space(3))) void *lds_ptr_t;
+    auto issue_tile = [&](int stage) {
+        uint8_t *As = smem + stage * STAGE + wave * BM * 16;
+        uint8_t *Bs = smem + stage * STAGE + BM * KT + wave * BN * 16;
+        const bool live = ch_idx < nchunks;
+        const unsigned a_soff = live ? (unsigned)ch_idx * 16u : 0u;
+        unsigned b_soff = a_soff;
+        bool b_live = live;
+        if (p.conv) {
+            b_live = live && ch_ky < p.KH;
+            b_soff = b_live ? (unsigned)(((ch_ky * p.dy) * p.Wp + ch_kx * p.dx) * p.Cp + ch_c * 16) : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < RA; j++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(As + j * 1024), 16, (int)(live ? a_voff[j] : OOB), (int)a_soff, 0, 0);
+#pragma unroll
+        for (int j = 0; j < RB; j++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(Bs + j * 1024), 16, (int)(b_live ? b_voff[j] : OOB), (int)b_soff, 0, 0);
+        ch_idx += 4;
+        if (p.conv) {
+            ch_c += 4;
+            while (ch_c >= cpc) { ch_c -= cpc; if (++ch_kx == p.KW) { ch_kx = 0; ch_ky++; } }
+        }
+    };
+
+    const int wm0 = (wq / WN) * (BM / WM), wn0 = (wq % WN) * (BN / WN);
+    i32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0;
+    int cs[TN];
+#pragma unroll
+    for (int j = 0; j < TN; j++) cs[j] = 0;
+
+    auto compute_tile = [&](int stage) {
+        const uint8_t *As = smem + stage * STAGE + (wm0 + l31) * 16;
+        const uint8_t *Bs = smem + stage * STAGE + BM * KT + (wn0 + l31) * 16;
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            i32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; i++) af[i] = *reinterpret_cast<const i32x4 *>(As + ((2 * s + half) * BM + i * 32) * 16);
+#pragma unroll
+            for (int j = 0; j < TN; j++) bf[j] = *reinterpret_cast<const i32x4 *>(Bs + ((2 * s + half) * BN + j * 32) * 16);
+            if (p.need_csum) {
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) cs[j] = __builtin_amdgcn_sdot4(bf[j][q], 0x01010101, cs[j], false);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const int nk = (p.Kp + KT - 1) / KT;
+#pragma unroll
+    for (int i = 0; i < NSTAGE - 1; i++) issue_tile(i);
+    int stage = 0;
+    for (int kt = 0; kt < nk; kt++) {
+        wait_vmcnt<PER_TILE *(NSTAGE - 2)>();
+        __builtin_amdgcn_s_barrier();
+        const int stp = stage == 0 ? NSTAGE - 1 : stage - 1;
+        issue_tile(stp);
+        compute_tile(stage);
+        stage = stage == NSTAGE - 1 ? 0 : stage + 1;
+    }
+    wait_vmcnt<0>();
+
+    // ---- epilogue: zero-point algebra, optional cast_scale / bias / residual / relu, store
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void *)p.C, 0, 0x7ffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void *)(p.res ? (const void *)p.res : (const void *)p.C), 0, 0x7ffffffc, 0x00020000);
+    const unsigned rs4 = (unsigned)p.c_rs << 2;
+    const int mb = m0 + wm0 + 4 * half;
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int n = n0 + wn0 + j * 32 + l31;
+        const bool cok = n < p.N;
+        const int nn = cok ? n : 0;
+        const int nb = nn / p.Pn, np = nn - nb * p.Pn;
+        const unsigned col = (unsigned)((long long)nb * p.c_ns + np);
+        const unsigned bz = (unsigned)zp_signed(p.b_zp, p.b_zp_len == 1 ? 0 : nn, p.b_signed);
+        unsigned csn;
+        if (p.csum) csn = (unsigned)p.csum[nn];
+        else csn = (unsigned)(cs[j] + __shfl_xor(cs[j], 32, 64)); // the two k halves of the column
+        const float sc = p.scale ? p.scale[p.scale_len == 1 ? 0 : nn] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            const int mrow = mb + i * 32;
+            const unsigned base = cok ? (col + (unsigned)mrow * (unsigned)p.c_rs) << 2 : OOB;
+#pragma unroll
+            for (int h8 = 0; h8 < 2; h8++) { // 8 registers at a time: keeps the epilogue's temporaries out of scratch
+                unsigned voff[8], v[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int r = h8 * 8 + q;
+                    const int m = mrow + acc_row(r);
+                    const bool mok = m < p.M;
+                    voff[q] = mok ? base : OOB;
+                    const int mm = mok ? m : 0;
+                    const unsigned az = (unsigned)zp_signed(p.a_zp, p.a_zp_len == 1 ? 0 : mm, p.a_signed);
+                    v[q] = (unsigned)acc[i][j][r] - bz * (unsigned)p.rsum[mm] - az * csn + (unsigned)p.Kreal * az * bz;
+                }
+                if (p.scale) {
+                    float f[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) f[q] = (float)(int)v[q] * sc; // cast_scale (matmul.rs:751,761)
+                    if (p.bias) {
+#pragma unroll
+                        for (int q = 0; q < 8; q++) {
+                            const int m = mrow + acc_row(h8 * 8 + q);
+                            f[q] = f[q] + p.bias[m < p.M ? m : 0];
+                        }
+                    }
+                    if (p.res) {
+                        float rr[8];
+#pragma unroll
+                        for (int q = 0; q < 8; q++)
+                            rr[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)voff[q], (int)((unsigned)acc_row(h8 * 8 + q) * rs4), 0));
+#pragma unroll
+                        for (int q = 0; q < 8; q++) f[q] = f[q] + rr[q];
+                    }
+                    if (p.relu) {
+#pragma unroll
+                        for (int q = 0; q < 8; q++) f[q] = vm::relu(f[q]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const float x = f[q];
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), rsC, (int)voff[q], (int)((unsigned)acc_row(h8 * 8 + q) * rs4), 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const unsigned x = v[q];
+                        __builtin_amdgcn_raw_buffer_store_b32(x, rsC, (int)voff[q], (int)((unsigned)acc_row(h8 * 8 + q) * rs4), 0);
+                    }
+                }
+            }
+        }
+    }
+}
+
+inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+template <int BM, int BN>
+void launch_fast(rten_hip_ctx *ctx, FastArgs &a, const char *name, double ops, double bytes) {
+    a.tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = (a.N + BN - 1) / BN;
+    ProfScope ps(ctx, name, ops, bytes);
+    hipLaunchKernelGGL((igemm_i8_fast_kernel<BM, BN>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), 0, ctx->stream, a);
+}
+
+int32_t dispatch_fast(rten_hip_ctx *ctx, FastArgs &a, double ops, double bytes) {
+    // tile choice: largest tile that still gives every CU work
+    const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    const long long t12864 = (long long)((a.M + 127) / 128) * ((a.N + 63) / 64);
+    if (a.M > 64 && t128 >= ctx->num_cus) launch_fast<128, 128>(ctx, a, "igemm_i8_fast_kernel<128,128>", ops, bytes);
+    else if (a.M > 64 && t12864 >= ctx->num_cus / 2) launch_fast<128, 64>(ctx, a, "igemm_i8_fast_kernel<128,64>", ops, bytes);
+    else if (a.M > 64) launch_fast<128, 64>(ctx, a, "igemm_i8_fast_kernel<128,64>", ops, bytes);
+    else launch_fast<64, 128>(ctx, a, "igemm_i8_fast_kernel<64,128>", ops, bytes);
+    RTEN_LAUNCH_CHECK(ctx, "igemm_i8_fast_kernel launch");
+    return RTEN_HIP_OK;
+}
+
+} // namespace
+
+// Entry points used by int8.hip: return RTEN_HIP_ERR_UNSUPPORTED when the fast path does not cover the call
+// (the caller then falls back to the generic kernel).
+int32_t rten_i8_fast_gemm(rten_hip_ctx *ctx, const rten_hip_gemm_int8_desc *d, const void *a, const void *b, const void *a_zp,
+                          const void *b_zp, const float *scale, void *c) {
+    const int Kp = (d->k + KT - 1) / KT * KT;
+    if (d->k <= 0 || (long long)d->m * Kp >= (1ll << 31) || (long long)d->n * Kp >= (1ll << 31) || (long long)d->m * d->ldc >= (1ll << 29))
+        return RTEN_HIP_ERR_UNSUPPORTED;
+    const size_t offA = 4096, offRs = offA + up256((size_t)d->m * Kp), offB = offRs + up256((size_t)d->m * 4),
+                 offCs = offB + up256((size_t)d->n * Kp), total = offCs + up256((size_t)d->n * 4);
+    char *sc = (char *)rten_scratch(ctx, total);
+    if (!sc) return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "int8 staging allocation failed (or attempted during graph capture)");
+    hipLaunchKernelGGL(i8_pack_rows_kernel, dim3((unsigned)d->m), dim3(256), 0, ctx->stream, (const uint8_t *)a, (long long)d->a_rs, (long long)d->a_cs,
+                       d->k, d->k, 1, Kp, Kp, d->a_signed ? 0u : 0x80u, (uint8_t *)(sc + offA), (int *)(sc + offRs));
+    hipLaunchKernelGGL(i8_pack_rows_kernel, dim3((unsigned)d->n), dim3(256), 0, ctx->stream, (const uint8_t *)b, (long long)d->b_cs, (long long)d->b_rs,
+                       d->k, d->k, 1, Kp, Kp, d->b_signed ? 0u : 0x80u, (uint8_t *)(sc + offB), (int *)(sc + offCs));
+    RTEN_LAUNCH_CHECK(ctx, "i8_pack_rows_kernel launch");
+    FastArgs g = {};
+    g.A = (const uint8_t *)(sc + offA); g.B = (const uint8_t *)(sc + offB);
+    g.rsum = (const int *)(sc + offRs); g.csum = (const int *)(sc + offCs);
+    g.C = c;
+    g.a_zp = d->a_zp_len ? (const uint8_t *)a_zp : nullptr;
+    g.b_zp = d->b_zp_len ? (const uint8_t *)b_zp : nullptr;
+    g.scale = d->scale_len ? scale : nullptr;
+    g.M = d->m; g.N = d->n; g.Kp = Kp; g.Kreal = d->k;
+    g.a_bytes = (unsigned)((size_t)d->m * Kp); g.b_bytes = (unsigned)((size_t)d->n * Kp);
+    g.c_rs = d->ldc; g.c_ns = 0; g.Pn = d->n;
+    g.a_signed = d->a_signed; g.b_signed = d->b_signed;
+    g.a_zp_len = d->a_zp_len; g.b_zp_len = d->b_zp_len; g.scale_len = d->scale_len;
+    return dispatch_fast(ctx, g, 2.0 * d->m * (double)d->n * d->k, (double)d->m * d->k + (double)d->k * d->n + 4.0 * d->m * d->n);
+}
+
+int32_t rten_i8_fast_conv(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di, const void *x, const void *w, const void *x_zp,
+                          const void *w_zp, const float *scale, const float *bias, const float *residual, uint32_t flags, void *y) {
+    const rten_hip_conv2d_desc *d = &di->conv;
+    if (d->groups != 1) return RTEN_HIP_ERR_UNSUPPORTED;
+    const int Cp = (d->c + 15) / 16 * 16;
+    const int Hp = d->h + d->pads[0] + d->pads[2], Wp = d->w + d->pads[1] + d->pads[3];
+    const int taps = d->kh * d->kw;
+    const int Kreal = d->c * taps;
+    const int Kp = (taps * Cp + KT - 1) / KT * KT;
+    const int P = d->out_h * d->out_w;
+    const size_t img = (size_t)d->n * Hp * Wp * Cp;
+    // the odometer walks taps on the padded image: the window must fit (it does for valid conv geometry)
+    if ((d->out_h - 1) * d->stride_h + (d->kh - 1) * d->dil_h >= Hp || (d->out_w - 1) * d->stride_w + (d->kw - 1) * d->dil_w >= Wp)
+        return RTEN_HIP_ERR_UNSUPPORTED;
+    if (img >= (1ull << 31) || (size_t)d->o * Kp >= (1ull << 31) || (long long)d->n * d->o * P >= (1ll << 29)) return RTEN_HIP_ERR_UNSUPPORTED;
+    const size_t offA = 4096, offRs = offA + up256((size_t)d->o * Kp), offB = offRs + up256((size_t)d->o * 4), total = offB + up256(img);
+    char *sc = (char *)rten_scratch(ctx, total);
+    if (!sc) return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "int8 staging allocation failed (or attempted during graph capture)");
+    hipLaunchKernelGGL(i8_pack_rows_kernel, dim3((unsigned)d->o), dim3(256), 0, ctx->stream, (const uint8_t *)w, (long long)Kreal, 1ll, Kreal, d->c, taps,
+                       Cp, Kp, di->w_signed ? 0u : 0x80u, (uint8_t *)(sc + offA), (int *)(sc + offRs));
+    hipLaunchKernelGGL(i8_nhwc_pad_kernel, dim3((unsigned)((Wp + 63) / 64), (unsigned)Hp, (unsigned)d->n), dim3(256), 0, ctx->stream, (const uint8_t *)x,
+                       (uint8_t *)(sc + offB), d->c, d->h, d->w, Hp, Wp, Cp, d->pads[0], d->pads[1], di->x_signed ? 0u : 0x80u, (const uint8_t *)x_zp,
+                       di->x_signed, di->pad_mode);
+    RTEN_LAUNCH_CHECK(ctx, "int8 staging launch");
+    FastArgs g = {};
+    g.A = (const uint8_t *)(sc + offA); g.B = (const uint8_t *)(sc + offB);
+    g.rsum = (const int *)(sc + offRs); g.csum = nullptr;
+    g.C = y;
+    g.a_zp = di->w_zp_len ? (const uint8_t *)w_zp : nullptr;
+    g.b_zp = (const uint8_t *)x_zp;
+    g.scale = scale; g.bias = bias;
+    g.res = (flags & RTEN_HIP_CONV_RESIDUAL) ? residual : nullptr;
+    g.relu = (flags & RTEN_HIP_CONV_RELU) ? 1 : 0;
+    g.M = d->o; g.N = d->n * P; g.Kp = Kp; g.Kreal = Kreal;
+    g.a_bytes = (unsigned)((size_t)d->o * Kp); g.b_bytes = (unsigned)img;
+    g.c_rs = P; g.c_ns = (long long)d->o * P; g.Pn = P;
+    g.a_signed = di->w_signed; g.b_signed = di->x_signed;
+    g.a_zp_len = di->w_zp_len; g.b_zp_len = x_zp ? 1 : 0;
+    g.scale_len = scale ? 1 : 0;
+    g.need_csum = (di->w_zp_len != 0 || !di->w_signed) ? 1 : 0; // weight zero point may be non-zero in the signed domain
+    g.conv = 1; g.OW = d->out_w; g.sy = d->stride_h; g.sx = d->stride_w; g.Hp = Hp; g.Wp = Wp; g.Cp = Cp;
+    g.KH = d->kh; g.KW = d->kw; g.dy = d->dil_h; g.dx = d->dil_w;
+    return dispatch_fast(ctx, g, 2.0 * d->o * (double)g.N * Kreal, (double)d->o * Kreal + (double)d->n * d->c * d->h * d->w + 4.0 * d->o * g.N);
+}

@@ -281,11 +281,19 @@ def test_conv_f32_split_k_bit_exact(ctx, shape):
 
 
 # ------------------------------------------------------------------------------------------ int8
+@pytest.fixture(params=[0, 1], ids=["i8staged", "i8generic"])
+def i8path(request, ctx):
+    """Both int8 implementations: k-contiguous staging + LDS-DMA kernel (automatic) and the generic byte-gather kernel."""
+    ctx.call("rten_hip_set_int8_path", request.param)
+    yield request.param
+    ctx.call("rten_hip_set_int8_path", 0)
+
+
 @pytest.mark.parametrize("adt,bdt", [(np.uint8, np.int8), (np.uint8, np.uint8), (np.int8, np.int8), (np.int8, np.uint8)])
-def test_matmul_integer_bit_exact(ctx, adt, bdt):
+def test_matmul_integer_bit_exact(ctx, i8path, adt, bdt):
     # src/ops/matmul.rs:1365-1750
     rng = ref.XorShiftRng(1234)
-    for (m, n, k) in ((1, 1, 1), (5, 7, 3), (16, 33, 64), (70, 130, 300), (64, 64, 128), (3, 1000, 17)):
+    for (m, n, k) in ((1, 1, 1), (5, 7, 3), (16, 33, 64), (70, 130, 300), (64, 64, 128), (3, 1000, 17), (200, 260, 520), (130, 64, 1)):
         a = (rng.u8(m * k) if adt == np.uint8 else rng.i8(m * k)).reshape(m, k)
         b = (rng.u8(k * n) if bdt == np.uint8 else rng.i8(k * n)).reshape(k, n)
         zps = [(None, None), (np.array(3, adt), np.array(5, bdt)),
@@ -305,11 +313,13 @@ def test_matmul_integer_bit_exact(ctx, adt, bdt):
 
 
 @pytest.mark.parametrize("xdt,wdt", [(np.uint8, np.int8), (np.uint8, np.uint8), (np.int8, np.int8), (np.int8, np.uint8)])
-def test_conv_integer_bit_exact(ctx, xdt, wdt):
+def test_conv_integer_bit_exact(ctx, i8path, xdt, wdt):
     # src/ops/conv.rs:1370-1527 (all four signedness combos) + padded cases for every pad_mode
     rng = ref.XorShiftRng(42)
     for (N, Cc, H, W, O, k, pads, strides, groups) in ((2, 4, 7, 6, 6, 3, (0, 0, 0, 0), (1, 1), 1), (1, 8, 9, 9, 4, 3, (1, 1, 1, 1), (2, 2), 2),
-                                                        (2, 16, 7, 7, 20, 1, (0, 0, 0, 0), (1, 1), 1), (1, 3, 20, 20, 8, 7, (3, 3, 3, 3), (2, 2), 1)):
+                                                        (2, 16, 7, 7, 20, 1, (0, 0, 0, 0), (1, 1), 1), (1, 3, 20, 20, 8, 7, (3, 3, 3, 3), (2, 2), 1),
+                                                        (3, 40, 13, 11, 70, 3, (1, 0, 2, 1), (1, 1), 1), (2, 64, 14, 14, 130, 3, (1, 1, 1, 1), (1, 1), 1),
+                                                        (2, 128, 8, 8, 32, 1, (0, 0, 0, 0), (2, 2), 1)):
         x = (rng.u8(N * Cc * H * W) if xdt == np.uint8 else rng.i8(N * Cc * H * W)).reshape(N, Cc, H, W)
         wn = O * (Cc // groups) * k * k
         w = (rng.u8(wn, reduced=True) if wdt == np.uint8 else rng.i8(wn, reduced=True)).reshape(O, Cc // groups, k, k)
@@ -322,7 +332,7 @@ def test_conv_integer_bit_exact(ctx, xdt, wdt):
                 bits_equal(got, want)
 
 
-def test_conv_integer_to_float_fused_epilogue(ctx):
+def test_conv_integer_to_float_fused_epilogue(ctx, i8path):
     # test_conv_integer_to_float (conv.rs:1530-1604) + the ort-quantized graph tail: Add(bias) -> Add(residual) -> Relu
     rng = ref.XorShiftRng(8)
     x = rng.u8(2 * 8 * 10 * 10).reshape(2, 8, 10, 10)
@@ -353,7 +363,7 @@ def test_dynamic_quantize_linear_bit_exact(ctx):
     assert float(s.numpy()) == 1.0 and int(z.numpy()) == 0
 
 
-def test_int8_resnet_block_chain(ctx):
+def test_int8_resnet_block_chain(ctx, i8path):
     # DQL -> ConvIntegerToFloat(+bias, relu) chained on device: scale = x_scale * w_scale computed by a device Mul
     rng = ref.XorShiftRng(17)
     x = (rng.f32(2 * 16 * 14 * 14) - 0.3).reshape(2, 16, 14, 14)
