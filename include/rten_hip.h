@@ -185,10 +185,17 @@ typedef struct {
     int32_t x_signed, w_signed;
     int32_t w_zp_len; /* 0, 1 or o */
     int32_t pad_mode;
+    int32_t weights_packed; /* != 0: `w` is a buffer written by rten_hip_conv2d_int8_prepack */
 } rten_hip_conv2d_int8_desc;
 /* scale == NULL: y is i32 (ConvInteger).  scale != NULL (device scalar): y is f32 =
  * (acc as f32) * scale[0], then optional bias[o] add (the Add node that follows in ort-quantized
  * graphs), optional residual add and Relu per `flags`. */
+/* Load-time staging of constant ConvInteger weights (PrepackedInput / Graph::prepack_weights analogue,
+ * src/operator.rs:25-66): (ky, kx, c)-ordered signed rows with channels padded to 16, followed by the row sums the
+ * zero-point epilogue needs (packing/int8.rs).  packed_bytes returns 0 when the staged kernel does not cover the
+ * geometry (grouped convolution): pass the plain OIHW tensor then. */
+size_t rten_hip_conv2d_int8_packed_bytes(const rten_hip_conv2d_int8_desc *desc);
+int32_t rten_hip_conv2d_int8_prepack(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *desc, const void *w, void *packed);
 int32_t rten_hip_conv2d_int8(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *desc, const void *x, const void *w,
                              const void *x_zp, const void *w_zp, const float *scale, const float *bias,
                              const float *residual, uint32_t flags, void *y);

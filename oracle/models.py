@@ -54,3 +54,41 @@ def bert_forward(cfg, w, input_ids, attention_mask, token_type_ids, lanes=ref.LA
         y = ref.add(ref.matmul_f32(h, lw["w2"], bias=lw["b2"]), x)
         x = ref.layer_norm(y, lw["ln2_g"], lw["ln2_b"], eps=cfg.eps, lanes=lanes)
     return x
+
+
+def quantize_weights_int8(weights):
+    """Symmetric per-tensor i8 weights for the dynamically-quantized graphs: {name: (wq i8, w_scale f32, bias f32)}."""
+    out = {}
+    for name, (w, b) in weights.items():
+        s = np.float32(np.abs(w).max() / 127.0)
+        q = np.clip(np.rint(w / s), -127, 127).astype(np.int8)
+        out[name] = (q, s, b)
+    return out
+
+
+def resnet50_int8_forward(specs, qweights, x, pad_mode=ref.PAD_RAW0_I8):
+    """ResNet-50 as an ort-dynamically-quantized graph (BASELINE configs[2]): every Conv becomes
+    DynamicQuantizeLinear -> ConvInteger -> Cast -> Mul(x_scale * w_scale) -> Add(bias) [-> Add(residual)] [-> Relu]
+    (the ConvIntegerToFloat fusion of the reference, src/ops/conv.rs:495-587), the classifier
+    DynamicQuantizeLinear -> MatMulInteger -> Cast -> Mul -> Add."""
+    acts = {"x": np.ascontiguousarray(x, np.float32)}
+    for i, l in enumerate(specs):
+        wq, ws, b = qweights[l["name"]]
+        q, s, z = ref.dynamic_quantize_linear(acts[l["src"]])
+        acc = ref.conv2d_int8(q, wq, x_zp=int(z), pads=(l["pad"],) * 4, strides=(l["stride"],) * 2, pad_mode=pad_mode)
+        f = ref.cast_scale(acc, np.float32(np.float32(s) * np.float32(ws)))
+        f = ref.add(f, np.ascontiguousarray(np.broadcast_to(b[None, :, None, None], f.shape)))
+        if l["res"]:
+            f = ref.add(f, acts[l["res"]])
+        if l["relu"]:
+            f = ref.relu(f)
+        acts[l["dst"]] = f
+        if i == 0:
+            acts["pool"] = ref.max_pool(acts["stem"], (3, 3), (2, 2), (1, 1, 1, 1))
+    last = acts[specs[-1]["dst"]]
+    gap = ref.global_average_pool(last).reshape(last.shape[0], -1)
+    wq, ws, b = qweights["fc"]
+    q, s, z = ref.dynamic_quantize_linear(gap)
+    acc = ref.gemm_int8(q, np.ascontiguousarray(wq.T), np.array(z, np.uint8), None)
+    f = ref.cast_scale(acc, np.float32(np.float32(s) * np.float32(ws)))
+    return ref.add(f, np.ascontiguousarray(np.broadcast_to(b[None, :], f.shape)))

@@ -261,50 +261,61 @@ __global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p)
     }
     wait_vmcnt<0>();
 
-    // ---- epilogue: zero-point algebra, optional cast_scale / bias / residual / relu, store
+    // ---- epilogue: zero-point algebra, optional cast_scale / bias / residual / relu, store.
+    // Row constants (weight row sum, weight zero point, bias) are fetched once per 32-row block and reused across
+    // the block's columns; 8 accumulator registers are finished at a time to keep temporaries in registers.
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void *)p.C, 0, 0x7ffffffc, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void *)(p.res ? (const void *)p.res : (const void *)p.C), 0, 0x7ffffffc, 0x00020000);
     const unsigned rs4 = (unsigned)p.c_rs << 2;
     const int mb = m0 + wm0 + 4 * half;
+    unsigned colv[TN], bzv[TN], csv[TN];
+    float scv[TN];
+    bool cokv[TN];
 #pragma unroll
     for (int j = 0; j < TN; j++) {
         const int n = n0 + wn0 + j * 32 + l31;
-        const bool cok = n < p.N;
-        const int nn = cok ? n : 0;
+        cokv[j] = n < p.N;
+        const int nn = cokv[j] ? n : 0;
         const int nb = nn / p.Pn, np = nn - nb * p.Pn;
-        const unsigned col = (unsigned)((long long)nb * p.c_ns + np);
-        const unsigned bz = (unsigned)zp_signed(p.b_zp, p.b_zp_len == 1 ? 0 : nn, p.b_signed);
-        unsigned csn;
-        if (p.csum) csn = (unsigned)p.csum[nn];
-        else csn = (unsigned)(cs[j] + __shfl_xor(cs[j], 32, 64)); // the two k halves of the column
-        const float sc = p.scale ? p.scale[p.scale_len == 1 ? 0 : nn] : 0.f;
+        colv[j] = (unsigned)((long long)nb * p.c_ns + np);
+        bzv[j] = (unsigned)zp_signed(p.b_zp, p.b_zp_len == 1 ? 0 : nn, p.b_signed);
+        if (p.csum) csv[j] = (unsigned)p.csum[nn];
+        else csv[j] = (unsigned)(cs[j] + __shfl_xor(cs[j], 32, 64)); // the two k halves of the column
+        scv[j] = p.scale ? p.scale[p.scale_len == 1 ? 0 : nn] : 0.f;
+    }
 #pragma unroll
-        for (int i = 0; i < TM; i++) {
-            const int mrow = mb + i * 32;
-            const unsigned base = cok ? (col + (unsigned)mrow * (unsigned)p.c_rs) << 2 : OOB;
+    for (int i = 0; i < TM; i++) {
+        const int mrow = mb + i * 32;
 #pragma unroll
-            for (int h8 = 0; h8 < 2; h8++) { // 8 registers at a time: keeps the epilogue's temporaries out of scratch
+        for (int h8 = 0; h8 < 2; h8++) {
+            unsigned rsv[8], azv[8];
+            float bv[8];
+            bool mok[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int m = mrow + acc_row(h8 * 8 + q);
+                mok[q] = m < p.M;
+                const int mm = mok[q] ? m : 0;
+                rsv[q] = (unsigned)p.rsum[mm];
+                azv[q] = (unsigned)zp_signed(p.a_zp, p.a_zp_len == 1 ? 0 : mm, p.a_signed);
+                bv[q] = p.bias ? p.bias[mm] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                const unsigned base = cokv[j] ? (colv[j] + (unsigned)mrow * (unsigned)p.c_rs) << 2 : OOB;
                 unsigned voff[8], v[8];
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
-                    const int r = h8 * 8 + q;
-                    const int m = mrow + acc_row(r);
-                    const bool mok = m < p.M;
-                    voff[q] = mok ? base : OOB;
-                    const int mm = mok ? m : 0;
-                    const unsigned az = (unsigned)zp_signed(p.a_zp, p.a_zp_len == 1 ? 0 : mm, p.a_signed);
-                    v[q] = (unsigned)acc[i][j][r] - bz * (unsigned)p.rsum[mm] - az * csn + (unsigned)p.Kreal * az * bz;
+                    voff[q] = mok[q] ? base : OOB;
+                    v[q] = (unsigned)acc[i][j][h8 * 8 + q] - bzv[j] * rsv[q] - azv[q] * csv[j] + (unsigned)p.Kreal * azv[q] * bzv[j];
                 }
                 if (p.scale) {
                     float f[8];
 #pragma unroll
-                    for (int q = 0; q < 8; q++) f[q] = (float)(int)v[q] * sc; // cast_scale (matmul.rs:751,761)
+                    for (int q = 0; q < 8; q++) f[q] = (float)(int)v[q] * scv[j]; // cast_scale (matmul.rs:751,761)
                     if (p.bias) {
 #pragma unroll
-                        for (int q = 0; q < 8; q++) {
-                            const int m = mrow + acc_row(h8 * 8 + q);
-                            f[q] = f[q] + p.bias[m < p.M ? m : 0];
-                        }
+                        for (int q = 0; q < 8; q++) f[q] = f[q] + bv[q];
                     }
                     if (p.res) {
                         float rr[8];
@@ -333,6 +344,43 @@ __global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p)
             }
         }
     }
+}
+
+// Transposing variant of the row packer for operands whose rows are NOT k-contiguous (e.g. MatMulInteger weights
+// [K][N]: row n walks k with stride N).  64 x 64 byte tiles through LDS: coalesced reads along the source's
+// contiguous axis, 4-byte writes along k.  Row sums via atomics into a zeroed array.
+__global__ __launch_bounds__(256) void i8_pack_rows_t_kernel(const uint8_t *__restrict__ src, long long row_stride, long long k_stride, int rows,
+                                                            int K, int Kp, unsigned flip, uint8_t *__restrict__ dst, int *__restrict__ sums) {
+    __shared__ uint8_t tile[64][64 + 4];
+    const int t = threadIdx.x;
+    const int r0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+    // read: consecutive threads walk rows (the source's contiguous axis when row_stride == 1)
+#pragma unroll
+    for (int pass = 0; pass < 16; pass++) {
+        const int rl = t & 63, kl = pass * 4 + (t >> 6);
+        const int r = r0 + rl, k = k0 + kl;
+        unsigned v = 0;
+        if (r < rows && k < K) v = ((unsigned)src[(long long)r * row_stride + (long long)k * k_stride] ^ flip) & 0xffu;
+        tile[rl][kl] = (uint8_t)v;
+    }
+    __syncthreads();
+    // write: thread -> (row, 16-byte group); k0 + 64 <= Kp always (Kp is a multiple of 64)
+    const int rl = t >> 2, g = t & 3;
+    const int r = r0 + rl;
+    int sum = 0;
+    if (r < rows) {
+        unsigned w[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            w[q] = (unsigned)tile[rl][g * 16 + q * 4] | ((unsigned)tile[rl][g * 16 + q * 4 + 1] << 8) | ((unsigned)tile[rl][g * 16 + q * 4 + 2] << 16) |
+                   ((unsigned)tile[rl][g * 16 + q * 4 + 3] << 24);
+            sum = __builtin_amdgcn_sdot4((int)w[q], 0x01010101, sum, false);
+        }
+        *reinterpret_cast<uint4 *>(dst + (long long)r * Kp + k0 + g * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    if (g == 0 && r < rows) atomicAdd(&sums[r], sum);
 }
 
 inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -370,10 +418,18 @@ int32_t rten_i8_fast_gemm(rten_hip_ctx *ctx, const rten_hip_gemm_int8_desc *d, c
                  offCs = offB + up256((size_t)d->n * Kp), total = offCs + up256((size_t)d->n * 4);
     char *sc = (char *)rten_scratch(ctx, total);
     if (!sc) return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "int8 staging allocation failed (or attempted during graph capture)");
-    hipLaunchKernelGGL(i8_pack_rows_kernel, dim3((unsigned)d->m), dim3(256), 0, ctx->stream, (const uint8_t *)a, (long long)d->a_rs, (long long)d->a_cs,
-                       d->k, d->k, 1, Kp, Kp, d->a_signed ? 0u : 0x80u, (uint8_t *)(sc + offA), (int *)(sc + offRs));
-    hipLaunchKernelGGL(i8_pack_rows_kernel, dim3((unsigned)d->n), dim3(256), 0, ctx->stream, (const uint8_t *)b, (long long)d->b_cs, (long long)d->b_rs,
-                       d->k, d->k, 1, Kp, Kp, d->b_signed ? 0u : 0x80u, (uint8_t *)(sc + offB), (int *)(sc + offCs));
+    auto pack = [&](const void *src, long long row_stride, long long k_stride, int rows, unsigned flip, char *dst, char *sums) {
+        if (k_stride == 1) {
+            hipLaunchKernelGGL(i8_pack_rows_kernel, dim3((unsigned)rows), dim3(256), 0, ctx->stream, (const uint8_t *)src, row_stride, k_stride, d->k, d->k, 1,
+                               Kp, Kp, flip, (uint8_t *)dst, (int *)sums);
+        } else {
+            hipMemsetAsync(sums, 0, (size_t)rows * 4, ctx->stream);
+            hipLaunchKernelGGL(i8_pack_rows_t_kernel, dim3((unsigned)((rows + 63) / 64), (unsigned)(Kp / 64)), dim3(256), 0, ctx->stream, (const uint8_t *)src,
+                               row_stride, k_stride, rows, d->k, Kp, flip, (uint8_t *)dst, (int *)sums);
+        }
+    };
+    pack(a, d->a_rs, d->a_cs, d->m, d->a_signed ? 0u : 0x80u, sc + offA, sc + offRs);
+    pack(b, d->b_cs, d->b_rs, d->n, d->b_signed ? 0u : 0x80u, sc + offB, sc + offCs);
     RTEN_LAUNCH_CHECK(ctx, "i8_pack_rows_kernel launch");
     FastArgs g = {};
     g.A = (const uint8_t *)(sc + offA); g.B = (const uint8_t *)(sc + offB);
@@ -390,47 +446,86 @@ int32_t rten_i8_fast_gemm(rten_hip_ctx *ctx, const rten_hip_gemm_int8_desc *d, c
     return dispatch_fast(ctx, g, 2.0 * d->m * (double)d->n * d->k, (double)d->m * d->k + (double)d->k * d->n + 4.0 * d->m * d->n);
 }
 
+namespace {
+struct ConvGeom { int Cp, Hp, Wp, taps, Kreal, Kp, P; size_t img; bool ok; };
+ConvGeom conv_geom(const rten_hip_conv2d_int8_desc *di) {
+    const rten_hip_conv2d_desc *d = &di->conv;
+    ConvGeom g = {};
+    g.Cp = (d->c + 15) / 16 * 16;
+    g.Hp = d->h + d->pads[0] + d->pads[2];
+    g.Wp = d->w + d->pads[1] + d->pads[3];
+    g.taps = d->kh * d->kw;
+    g.Kreal = d->c * g.taps;
+    g.Kp = (g.taps * g.Cp + KT - 1) / KT * KT;
+    g.P = d->out_h * d->out_w;
+    g.img = (size_t)d->n * g.Hp * g.Wp * g.Cp;
+    g.ok = d->groups == 1 && d->c > 0 && d->o > 0 &&
+           // the chunk walk addresses taps on the padded image: the window must fit (true for valid conv geometry)
+           (d->out_h - 1) * d->stride_h + (d->kh - 1) * d->dil_h < g.Hp && (d->out_w - 1) * d->stride_w + (d->kw - 1) * d->dil_w < g.Wp &&
+           g.img < (1ull << 31) && (size_t)d->o * g.Kp < (1ull << 31) && (long long)d->n * d->o * g.P < (1ll << 29);
+    return g;
+}
+} // namespace
+
+RTEN_EXPORT size_t rten_hip_conv2d_int8_packed_bytes(const rten_hip_conv2d_int8_desc *di) {
+    if (!di) return 0;
+    const ConvGeom g = conv_geom(di);
+    return g.ok ? up256((size_t)di->conv.o * g.Kp) + (size_t)di->conv.o * 4 : 0;
+}
+
+RTEN_EXPORT int32_t rten_hip_conv2d_int8_prepack(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di, const void *w, void *packed) {
+    RTEN_CHECK_CTX(ctx);
+    if (!di || !w || !packed) return RTEN_HIP_ERR_INVALID_VALUE;
+    const ConvGeom g = conv_geom(di);
+    if (!g.ok) return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "conv_int8 prepack: geometry not covered by the staged kernel (packed_bytes == 0)");
+    const rten_hip_conv2d_desc *d = &di->conv;
+    hipLaunchKernelGGL(i8_pack_rows_kernel, dim3((unsigned)d->o), dim3(256), 0, ctx->stream, (const uint8_t *)w, (long long)g.Kreal, 1ll, g.Kreal, d->c, g.taps,
+                       g.Cp, g.Kp, di->w_signed ? 0u : 0x80u, (uint8_t *)packed, (int *)((char *)packed + up256((size_t)d->o * g.Kp)));
+    RTEN_LAUNCH_CHECK(ctx, "i8_pack_rows_kernel launch");
+    return RTEN_HIP_OK;
+}
+
 int32_t rten_i8_fast_conv(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di, const void *x, const void *w, const void *x_zp,
                           const void *w_zp, const float *scale, const float *bias, const float *residual, uint32_t flags, void *y) {
     const rten_hip_conv2d_desc *d = &di->conv;
-    if (d->groups != 1) return RTEN_HIP_ERR_UNSUPPORTED;
-    const int Cp = (d->c + 15) / 16 * 16;
-    const int Hp = d->h + d->pads[0] + d->pads[2], Wp = d->w + d->pads[1] + d->pads[3];
-    const int taps = d->kh * d->kw;
-    const int Kreal = d->c * taps;
-    const int Kp = (taps * Cp + KT - 1) / KT * KT;
-    const int P = d->out_h * d->out_w;
-    const size_t img = (size_t)d->n * Hp * Wp * Cp;
-    // the odometer walks taps on the padded image: the window must fit (it does for valid conv geometry)
-    if ((d->out_h - 1) * d->stride_h + (d->kh - 1) * d->dil_h >= Hp || (d->out_w - 1) * d->stride_w + (d->kw - 1) * d->dil_w >= Wp)
-        return RTEN_HIP_ERR_UNSUPPORTED;
-    if (img >= (1ull << 31) || (size_t)d->o * Kp >= (1ull << 31) || (long long)d->n * d->o * P >= (1ll << 29)) return RTEN_HIP_ERR_UNSUPPORTED;
-    const size_t offA = 4096, offRs = offA + up256((size_t)d->o * Kp), offB = offRs + up256((size_t)d->o * 4), total = offB + up256(img);
+    const ConvGeom cg = conv_geom(di);
+    if (!cg.ok) return di->weights_packed ? rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "conv_int8: packed weights for an unsupported geometry") : RTEN_HIP_ERR_UNSUPPORTED;
+    const size_t wbytes = di->weights_packed ? 0 : up256((size_t)d->o * cg.Kp) + up256((size_t)d->o * 4);
+    const size_t offA = 4096, offB = offA + wbytes, total = offB + up256(cg.img);
     char *sc = (char *)rten_scratch(ctx, total);
     if (!sc) return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "int8 staging allocation failed (or attempted during graph capture)");
-    hipLaunchKernelGGL(i8_pack_rows_kernel, dim3((unsigned)d->o), dim3(256), 0, ctx->stream, (const uint8_t *)w, (long long)Kreal, 1ll, Kreal, d->c, taps,
-                       Cp, Kp, di->w_signed ? 0u : 0x80u, (uint8_t *)(sc + offA), (int *)(sc + offRs));
-    hipLaunchKernelGGL(i8_nhwc_pad_kernel, dim3((unsigned)((Wp + 63) / 64), (unsigned)Hp, (unsigned)d->n), dim3(256), 0, ctx->stream, (const uint8_t *)x,
-                       (uint8_t *)(sc + offB), d->c, d->h, d->w, Hp, Wp, Cp, d->pads[0], d->pads[1], di->x_signed ? 0u : 0x80u, (const uint8_t *)x_zp,
+    const uint8_t *Ap;
+    const int *rsum;
+    if (di->weights_packed) {
+        Ap = (const uint8_t *)w;
+        rsum = (const int *)((const char *)w + up256((size_t)d->o * cg.Kp));
+    } else {
+        Ap = (const uint8_t *)(sc + offA);
+        rsum = (const int *)(sc + offA + up256((size_t)d->o * cg.Kp));
+        hipLaunchKernelGGL(i8_pack_rows_kernel, dim3((unsigned)d->o), dim3(256), 0, ctx->stream, (const uint8_t *)w, (long long)cg.Kreal, 1ll, cg.Kreal, d->c,
+                           cg.taps, cg.Cp, cg.Kp, di->w_signed ? 0u : 0x80u, (uint8_t *)Ap, (int *)rsum);
+    }
+    hipLaunchKernelGGL(i8_nhwc_pad_kernel, dim3((unsigned)((cg.Wp + 63) / 64), (unsigned)cg.Hp, (unsigned)d->n), dim3(256), 0, ctx->stream, (const uint8_t *)x,
+                       (uint8_t *)(sc + offB), d->c, d->h, d->w, cg.Hp, cg.Wp, cg.Cp, d->pads[0], d->pads[1], di->x_signed ? 0u : 0x80u, (const uint8_t *)x_zp,
                        di->x_signed, di->pad_mode);
     RTEN_LAUNCH_CHECK(ctx, "int8 staging launch");
     FastArgs g = {};
-    g.A = (const uint8_t *)(sc + offA); g.B = (const uint8_t *)(sc + offB);
-    g.rsum = (const int *)(sc + offRs); g.csum = nullptr;
+    g.A = Ap; g.B = (const uint8_t *)(sc + offB);
+    g.rsum = rsum; g.csum = nullptr;
     g.C = y;
     g.a_zp = di->w_zp_len ? (const uint8_t *)w_zp : nullptr;
     g.b_zp = (const uint8_t *)x_zp;
     g.scale = scale; g.bias = bias;
     g.res = (flags & RTEN_HIP_CONV_RESIDUAL) ? residual : nullptr;
     g.relu = (flags & RTEN_HIP_CONV_RELU) ? 1 : 0;
-    g.M = d->o; g.N = d->n * P; g.Kp = Kp; g.Kreal = Kreal;
-    g.a_bytes = (unsigned)((size_t)d->o * Kp); g.b_bytes = (unsigned)img;
-    g.c_rs = P; g.c_ns = (long long)d->o * P; g.Pn = P;
+    g.M = d->o; g.N = d->n * cg.P; g.Kp = cg.Kp; g.Kreal = cg.Kreal;
+    g.a_bytes = (unsigned)((size_t)d->o * cg.Kp); g.b_bytes = (unsigned)cg.img;
+    g.c_rs = cg.P; g.c_ns = (long long)d->o * cg.P; g.Pn = cg.P;
     g.a_signed = di->w_signed; g.b_signed = di->x_signed;
     g.a_zp_len = di->w_zp_len; g.b_zp_len = x_zp ? 1 : 0;
     g.scale_len = scale ? 1 : 0;
     g.need_csum = (di->w_zp_len != 0 || !di->w_signed) ? 1 : 0; // weight zero point may be non-zero in the signed domain
-    g.conv = 1; g.OW = d->out_w; g.sy = d->stride_h; g.sx = d->stride_w; g.Hp = Hp; g.Wp = Wp; g.Cp = Cp;
+    g.conv = 1; g.OW = d->out_w; g.sy = d->stride_h; g.sx = d->stride_w; g.Hp = cg.Hp; g.Wp = cg.Wp; g.Cp = cg.Cp;
     g.KH = d->kh; g.KW = d->kw; g.dy = d->dil_h; g.dx = d->dil_w;
-    return dispatch_fast(ctx, g, 2.0 * d->o * (double)g.N * Kreal, (double)d->o * Kreal + (double)d->n * d->c * d->h * d->w + 4.0 * d->o * g.N);
+    return dispatch_fast(ctx, g, 2.0 * d->o * (double)g.N * cg.Kreal, (double)d->o * cg.Kreal + (double)d->n * d->c * d->h * d->w + 4.0 * d->o * g.N);
 }

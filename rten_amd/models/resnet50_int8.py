@@ -1,0 +1,96 @@
+"""ResNet-50 as a dynamically quantized int8 graph (BASELINE configs[2]: ort-quantized ResNet-50) on the HIP backend.
+
+Every Conv node of the f32 graph becomes the chain the reference executes for ort-quantized models
+(DynamicQuantizeLinear -> ConvInteger -> Cast -> Mul -> Add [-> Add] [-> Relu]; fused by the reference into
+ConvIntegerToFloat, src/ops/conv.rs:495-587): here one quantize kernel pair, one scalar Mul and one int8 conv launch with
+the cast_scale / bias / residual / Relu epilogue.  Weights are staged once (rten_hip_conv2d_int8_prepack).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .. import lib as L
+from ..tensor import DeviceTensor
+from .resnet50 import ResNet50
+
+
+def quantize_weights(weights):
+    """Symmetric per-tensor i8 weights: {name: (wq i8, w_scale f32, bias f32)} (same recipe as oracle.models)."""
+    out = {}
+    for name, (w, b) in weights.items():
+        s = np.float32(np.abs(w).max() / 127.0)
+        out[name] = (np.clip(np.rint(w / s), -127, 127).astype(np.int8), s, b)
+    return out
+
+
+class ResNet50Int8(ResNet50):
+    def __init__(self, ctx, batch, weights=None, pad_mode=L.PAD_RAW0_I8, **kw):
+        super().__init__(ctx, batch, weights, **kw)
+        self.pad_mode = pad_mode
+        self.q = quantize_weights(self.weights)
+        n_max = max(int(np.prod(s)) for s in self.shapes.values())
+        self.xq = DeviceTensor(ctx, (n_max,), np.uint8)
+        self.xs = DeviceTensor(ctx, (1,), np.float32)
+        self.xz = DeviceTensor(ctx, (1,), np.uint8)
+        self.sc = DeviceTensor(ctx, (1,), np.float32)
+        self.idesc, self.wq, self.ws, self.bq = {}, {}, {}, {}
+        for l in self.specs:
+            d = self.descs[l["name"]]
+            self.idesc[l["name"]] = L.Conv2dInt8Desc(d, 0, 1, 0, pad_mode, 1)
+        self.fc_tmp = DeviceTensor(ctx, (batch, self.num_classes), np.float32)
+        self.fc_idesc = L.GemmInt8Desc(batch, self.num_classes, 2048, 2048, 1, 1, 2048, self.num_classes, 0, 1, 1, 0, 1)
+
+    def upload_weights(self):
+        ctx = self.ctx
+        for l in self.specs:
+            wq, ws, b = self.q[l["name"]]
+            d = self.idesc[l["name"]]
+            nbytes = ctx.lib.rten_hip_conv2d_int8_packed_bytes(C.byref(d))
+            if nbytes == 0:
+                raise RuntimeError("int8 conv geometry not covered by the staged kernel: " + l["name"])
+            raw = DeviceTensor.from_numpy(ctx, wq)
+            packed = DeviceTensor(ctx, (nbytes,), np.uint8)
+            ctx.call("rten_hip_conv2d_int8_prepack", C.byref(d), raw.vp, packed.vp)
+            ctx.sync()
+            raw.free()
+            self.wq[l["name"]] = packed
+            self.ws[l["name"]] = DeviceTensor.from_numpy(ctx, np.array([ws], np.float32))
+            self.bq[l["name"]] = DeviceTensor.from_numpy(ctx, b)
+        wq, ws, b = self.q["fc"]
+        self.wq["fc"] = DeviceTensor.from_numpy(ctx, wq)  # [1000, 2048]: B[k, n] = wq[n, k] via strides
+        self.ws["fc"] = DeviceTensor.from_numpy(ctx, np.array([ws], np.float32))
+        self.bq["fc"] = DeviceTensor.from_numpy(ctx, b)
+
+    def _quantize(self, src, n):
+        ctx = self.ctx
+        ctx.call("rten_hip_dynamic_quantize_linear", n, src.vp, self.xq.vp, self.xs.vp, self.xz.vp)
+
+    def _conv(self, l, ctx=None):
+        ctx = self.ctx
+        name = l["name"]
+        src = self._act(l["src"])
+        self._quantize(src, int(np.prod(self.shapes[l["src"]])))
+        ctx.call("rten_hip_mul_f32", 1, self.xs.vp, self.ws[name].vp, 1, self.sc.vp)  # Mul(x_scale, w_scale)
+        flags = (L.CONV_RELU if l["relu"] else 0) | (L.CONV_RESIDUAL if l["res"] else 0)
+        ctx.call("rten_hip_conv2d_int8", C.byref(self.idesc[name]), self.xq.vp, self.wq[name].vp, self.xz.vp, None, self.sc.vp,
+                 self.bq[name].vp, self._act(l["res"]).vp if l["res"] else None, flags, self._act(l["dst"]).vp)
+
+    def forward(self):
+        ctx = self.ctx
+        self._conv(self.specs[0])
+        ctx.call("rten_hip_max_pool2d_f32", C.byref(self.pool_desc), self.bufs["stem"].vp, self.bufs["pool"].vp)
+        for l in self.specs[1:]:
+            self._conv(l)
+        last = self.specs[-1]["dst"]
+        n, c, h, w = self.shapes[last]
+        ctx.call("rten_hip_global_average_pool_f32", n * c, h * w, self.bufs[last].vp, self.gap.vp)
+        # classifier: DynamicQuantizeLinear -> MatMulIntegerToFloat -> Add(bias)
+        self._quantize(self.gap, n * c)
+        ctx.call("rten_hip_mul_f32", 1, self.xs.vp, self.ws["fc"].vp, 1, self.sc.vp)
+        ctx.call("rten_hip_gemm_int8", C.byref(self.fc_idesc), self.xq.vp, self.wq["fc"].vp, self.xz.vp, None, self.sc.vp, self.fc_tmp.vp)
+        ctx.call("rten_hip_add_f32", n * self.num_classes, self.fc_tmp.vp, self.bq["fc"].vp, self.num_classes, self.logits.vp)
+
+    def autotune(self, reps=3):  # the int8 kernels pick their tile by shape; nothing to tune yet
+        return {}

@@ -524,6 +524,40 @@ def test_resnet50_end_to_end_bit_exact_and_graph_replay(ctx):
     bits_equal(net.logits.numpy(), want)
 
 
+def test_resnet50_int8_end_to_end_bit_exact(ctx):
+    # BASELINE configs[2]: dynamically quantized ResNet-50 (DynamicQuantizeLinear -> ConvIntegerToFloat chain per conv)
+    from oracle import models as omodels
+    from rten_amd.models import resnet50, resnet50_int8
+    w = resnet50.make_weights()
+    net = resnet50_int8.ResNet50Int8(ctx, batch=2, weights=w)
+    net.upload_weights()
+    x = ref.XorShiftRng(99).f32(2 * 3 * 224 * 224).reshape(2, 3, 224, 224)
+    net.x.upload(x)
+    net.forward()
+    got = net.logits.numpy()
+    qw = omodels.quantize_weights_int8(w)
+    for name in ("stem", "s2b1c2", "fc"):
+        assert np.array_equal(qw[name][0], net.q[name][0]) and qw[name][1] == net.q[name][1]
+    want = omodels.resnet50_int8_forward(net.specs, qw, x)
+    bits_equal(got, want)
+    net.capture()
+    net.logits.upload(np.zeros_like(got))
+    net.run()
+    bits_equal(net.logits.numpy(), want)
+    # the generic int8 kernel gives the same bits through the plain (unpacked) operator path
+    ctx.call("rten_hip_set_int8_path", 1)
+    try:
+        l = net.specs[5]
+        wq, ws, b = net.q[l["name"]]
+        xin = (ref.XorShiftRng(5).f32(int(np.prod(net.shapes[l["src"]]))) - 0.3).reshape(net.shapes[l["src"]])
+        q, s, z = ref.dynamic_quantize_linear(xin)
+        op = ops.ConvInteger(padding=[l["pad"]] * 4, strides=(l["stride"],) * 2)
+        acc = op.run(ctx, [dev(ctx, q), dev(ctx, wq), dev(ctx, np.array(z, np.uint8)), None])[0].numpy()
+        bits_equal(acc, ref.conv2d_int8(q, wq, x_zp=int(z), pads=(l["pad"],) * 4, strides=(l["stride"],) * 2, pad_mode=ref.PAD_RAW0_I8))
+    finally:
+        ctx.call("rten_hip_set_int8_path", 0)
+
+
 def test_resnet50_batch32_batch_independence(ctx):
     # BASELINE config 2 at full size: every image of a batch-32 run equals the oracle's batch-1 run of that image
     from oracle import models as omodels

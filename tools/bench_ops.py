@@ -27,6 +27,7 @@ I8_PEAK_TOPS = 5033.0   # v_mfma_i32_32x32x32_i8: 32768 MAC / 16 cycles per CU -
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--only", default="", help="substring filter on the op name (e.g. Integer)")
     args = ap.parse_args()
     ctx = L.Context(0)
     rng = np.random.default_rng(0)
@@ -47,12 +48,21 @@ def main():
         ctx.timer_stop(3)
         return ctx.timer_ms(3) / args.reps * 1e3  # us
 
-    def hbm(op, shape, us, nbytes):
+    def want(op):
+        return args.only.lower() in op.lower()
+
+    def hbm(op, shape, fn, nbytes):
+        if not want(op):
+            return
+        us = timeit(fn)
         gbs = nbytes / us / 1e3
         rows.append({"op": op, "shape": shape, "us": round(us, 2), "bound": "hbm", "achieved": round(gbs, 1), "unit": "GB/s",
                      "peak": HBM_PEAK_GBS, "frac": round(gbs / HBM_PEAK_GBS, 3), "algorithmic_bytes": int(nbytes)})
 
-    def mfma(op, shape, us, flops, peak, unit):
+    def mfma(op, shape, fn, flops, peak, unit):
+        if not want(op):
+            return
+        us = timeit(fn)
         t = flops / us / 1e6
         rows.append({"op": op, "shape": shape, "us": round(us, 2), "bound": "mfma", "achieved": round(t, 2), "unit": unit,
                      "peak": peak, "frac": round(t / peak, 3), "algorithmic_ops": int(flops)})
@@ -62,37 +72,37 @@ def main():
     x = dev(rng.standard_normal(n_act, dtype=np.float32))
     x2 = dev(rng.standard_normal(n_act, dtype=np.float32))
     y = empty((n_act,))
-    hbm("Relu", f"n={n_act}", timeit(lambda: ctx.call("rten_hip_relu_f32", n_act, x.vp, y.vp)), 8.0 * n_act)
-    hbm("Add", f"n={n_act}", timeit(lambda: ctx.call("rten_hip_add_f32", n_act, x.vp, x2.vp, n_act, y.vp)), 12.0 * n_act)
+    hbm("Relu", f"n={n_act}", (lambda: ctx.call("rten_hip_relu_f32", n_act, x.vp, y.vp)), 8.0 * n_act)
+    hbm("Add", f"n={n_act}", (lambda: ctx.call("rten_hip_add_f32", n_act, x.vp, x2.vp, n_act, y.vp)), 12.0 * n_act)
     n_ffn = 4096 * 3072
-    hbm("Gelu", f"n={n_ffn}", timeit(lambda: ctx.call("rten_hip_gelu_f32", n_ffn, x.vp, y.vp)), 8.0 * n_ffn)
-    hbm("Erf", f"n={n_ffn}", timeit(lambda: ctx.call("rten_hip_erf_f32", n_ffn, x.vp, y.vp)), 8.0 * n_ffn)
+    hbm("Gelu", f"n={n_ffn}", (lambda: ctx.call("rten_hip_gelu_f32", n_ffn, x.vp, y.vp)), 8.0 * n_ffn)
+    hbm("Erf", f"n={n_ffn}", (lambda: ctx.call("rten_hip_erf_f32", n_ffn, x.vp, y.vp)), 8.0 * n_ffn)
     r, c = 32 * 12 * 128, 128
-    hbm("Softmax", f"rows={r} cols={c}", timeit(lambda: ctx.call("rten_hip_softmax_f32", r, c, x.vp, None, 1, 1, 0, y.vp)), 8.0 * r * c)
+    hbm("Softmax", f"rows={r} cols={c}", (lambda: ctx.call("rten_hip_softmax_f32", r, c, x.vp, None, 1, 1, 0, y.vp)), 8.0 * r * c)
     r, c = 4096, 768
     g, b = dev(np.ones(c, np.float32)), dev(np.zeros(c, np.float32))
     hbm("LayerNormalization", f"rows={r} cols={c}",
-        timeit(lambda: ctx.call("rten_hip_layer_norm_f32", r, c, x.vp, g.vp, b.vp, C.c_float(1.0), C.c_float(0.0), C.c_float(1e-12), y.vp)), 8.0 * r * c)
+        (lambda: ctx.call("rten_hip_layer_norm_f32", r, c, x.vp, g.vp, b.vp, C.c_float(1.0), C.c_float(0.0), C.c_float(1e-12), y.vp)), 8.0 * r * c)
     u8 = empty((n_act,), np.uint8)
     sc, zp = empty((1,)), empty((1,), np.uint8)
-    hbm("DynamicQuantizeLinear", f"n={n_act}", timeit(lambda: ctx.call("rten_hip_dynamic_quantize_linear", n_act, x.vp, u8.vp, sc.vp, zp.vp)), 9.0 * n_act)
+    hbm("DynamicQuantizeLinear", f"n={n_act}", (lambda: ctx.call("rten_hip_dynamic_quantize_linear", n_act, x.vp, u8.vp, sc.vp, zp.vp)), 9.0 * n_act)
     xi = dev(rng.integers(-1000, 1000, n_act).astype(np.int32))
-    hbm("cast_scale", f"n={n_act}", timeit(lambda: ctx.call("rten_hip_cast_scale", n_act, xi.vp, sc.vp, 1, y.vp)), 8.0 * n_act)
+    hbm("cast_scale", f"n={n_act}", (lambda: ctx.call("rten_hip_cast_scale", n_act, xi.vp, sc.vp, 1, y.vp)), 8.0 * n_act)
     pd = L.Pool2dDesc(32, 64, 112, 112, 3, 3, 2, 2, (C.c_int32 * 4)(1, 1, 1, 1), 56, 56, 0)
     n_in, n_out = 32 * 64 * 112 * 112, 32 * 64 * 56 * 56
-    hbm("MaxPool 3x3/2", "32x64x112x112", timeit(lambda: ctx.call("rten_hip_max_pool2d_f32", C.byref(pd), x.vp, y.vp)), 4.0 * (n_in + n_out))
-    hbm("GlobalAveragePool", "32x2048x7x7", timeit(lambda: ctx.call("rten_hip_global_average_pool_f32", 32 * 2048, 49, x.vp, y.vp)), 4.0 * 32 * 2048 * 50)
+    hbm("MaxPool 3x3/2", "32x64x112x112", (lambda: ctx.call("rten_hip_max_pool2d_f32", C.byref(pd), x.vp, y.vp)), 4.0 * (n_in + n_out))
+    hbm("GlobalAveragePool", "32x2048x7x7", (lambda: ctx.call("rten_hip_global_average_pool_f32", 32 * 2048, 49, x.vp, y.vp)), 4.0 * 32 * 2048 * 50)
 
     # ---- f32 GEMM on BERT-base shapes (batch 32 x 128 tokens)
     for (m, k, n, act, name) in ((4096, 768, 768, 0, "MatMul proj"), (4096, 768, 3072, L.ACT_GELU, "MatMul FFN1 + Gelu"), (4096, 3072, 768, 0, "MatMul FFN2")):
         a, w, bias, out = dev(rng.standard_normal((m, k), dtype=np.float32)), dev(rng.standard_normal((k, n), dtype=np.float32)), dev(np.zeros(n, np.float32)), empty((m, n))
         d = L.gemm_desc(m, n, k, k, 1, n, 1, n, bias_kind=L.BIAS_PER_COL, act=act)
-        mfma(name, f"{m}x{k}x{n}", timeit(lambda: ctx.call("rten_hip_gemm_f32", C.byref(d), a.vp, w.vp, bias.vp, out.vp)), 2.0 * m * k * n, F32_PEAK_TF, "TFLOP/s")
+        mfma(name, f"{m}x{k}x{n}", (lambda: ctx.call("rten_hip_gemm_f32", C.byref(d), a.vp, w.vp, bias.vp, out.vp)), 2.0 * m * k * n, F32_PEAK_TF, "TFLOP/s")
     # attention core, 12 heads x 64 on [B, S, H*D] projections (strided heads)
     B, S, H, D = 32, 128, 12, 64
     q, kk, v, o = (dev(rng.standard_normal((B, S, H * D), dtype=np.float32)) for _ in range(4))
     sd = L.SdpaDesc(B, H, S, S, D, D, S * H * D, D, H * D, S * H * D, D, H * D, S * H * D, D, H * D, S * H * D, D, H * D, 0, 0, 0.125, 0)
-    mfma("sdpa (QK^T, softmax, PV)", f"b={B} h={H} s={S} d={D}", timeit(lambda: ctx.call("rten_hip_sdpa_f32", C.byref(sd), q.vp, kk.vp, v.vp, None, o.vp)),
+    mfma("sdpa (QK^T, softmax, PV)", f"b={B} h={H} s={S} d={D}", (lambda: ctx.call("rten_hip_sdpa_f32", C.byref(sd), q.vp, kk.vp, v.vp, None, o.vp)),
          4.0 * B * H * S * S * D, F32_PEAK_TF, "TFLOP/s")
 
     # ---- int8 GEMM / conv (u8 activations x i8 weights)
@@ -100,7 +110,7 @@ def main():
         a = dev(rng.integers(0, 255, (m, k)).astype(np.uint8)); w = dev(rng.integers(-127, 127, (k, n)).astype(np.int8))
         az, wz, out = dev(np.array(128, np.uint8)), dev(np.zeros(n, np.int8)), empty((m, n), np.int32)
         d = L.GemmInt8Desc(m, n, k, k, 1, n, 1, n, 0, 1, 1, n, 0)
-        mfma("MatMulInteger", f"{m}x{k}x{n}", timeit(lambda: ctx.call("rten_hip_gemm_int8", C.byref(d), a.vp, w.vp, az.vp, wz.vp, None, out.vp)), 2.0 * m * k * n, I8_PEAK_TOPS, "TOP/s")
+        mfma("MatMulInteger", f"{m}x{k}x{n}", (lambda: ctx.call("rten_hip_gemm_int8", C.byref(d), a.vp, w.vp, az.vp, wz.vp, None, out.vp)), 2.0 * m * k * n, I8_PEAK_TOPS, "TOP/s")
     for (o_, c_, hw, k_, s_, p_, name) in ((64, 64, 56, 3, 1, 1, "s0 3x3"), (256, 256, 14, 3, 1, 1, "s2 3x3"), (256, 64, 56, 1, 1, 0, "s0 1x1 expand")):
         xq = dev(rng.integers(0, 255, (32, c_, hw, hw)).astype(np.uint8)); wq = dev(rng.integers(-127, 127, (o_, c_, k_, k_)).astype(np.int8))
         xz, wz = dev(np.array(128, np.uint8)), dev(np.zeros(o_, np.int8))
@@ -109,7 +119,7 @@ def main():
         cd = L.Conv2dDesc(32, c_, hw, hw, o_, k_, k_, (C.c_int32 * 4)(p_, p_, p_, p_), s_, s_, 1, 1, 1, oh, oh)
         d = L.Conv2dInt8Desc(cd, 0, 1, o_, 1)
         mfma(f"ConvInteger {name}", f"32x{c_}x{hw}x{hw} -> {o_}, k{k_}",
-             timeit(lambda: ctx.call("rten_hip_conv2d_int8", C.byref(d), xq.vp, wq.vp, xz.vp, wz.vp, None, None, None, 0, out.vp)),
+             (lambda: ctx.call("rten_hip_conv2d_int8", C.byref(d), xq.vp, wq.vp, xz.vp, wz.vp, None, None, None, 0, out.vp)),
              2.0 * 32 * o_ * c_ * k_ * k_ * oh * oh, I8_PEAK_TOPS, "TOP/s")
 
     print(json.dumps({"device": ctx.device_info(), "reps": args.reps, "rows": rows}, indent=1))
