@@ -620,7 +620,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // MODE 0: K <= 256 (one depth block); 1: several depth blocks folded in registers; 2: split-K producer -- every
 // workgroup computes one group of depth blocks of one split tile and parks each block's raw accumulator in the slab
 // (no fold, no epilogue: igemm_f32_fixup_kernel finishes the tile).
-template <int BM, int BN, int BL, int MODE>
+template <int BM, int BN, int BL, int MODE, int NST = 3>
 __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmArgs p) {
     constexpr bool MULTI_KC = MODE == 1, SPLIT = MODE == 2;
     static_assert(BL == B_N4 || BL == B_IM2COL || BL == B_IM2COL_TAPS, "DMA kernel covers the conv operand layouts");
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
     constexpr int NBG = BK * BN / 64 / 4;  // dword gathers per wave per tile (im2col B)
     constexpr int PER_TILE = NA + (BL == B_N4 ? NBV : NBG);
     static_assert(NA >= 1 && NBV >= 1, "tile too small for 4-wave DMA split");
-    constexpr int NSTAGE = nstage_for(BM, BN);
+    constexpr int NSTAGE = NST;
     __shared__ __attribute__((aligned(16))) float smem[NSTAGE * STAGE];
 
     const int t = threadIdx.x;
@@ -1295,6 +1295,15 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
                 RTEN_LAUNCH_CHECK(ctx, "igemm_f32_dma_kernel launch");
                 return RTEN_HIP_OK;
             }
+            if (pipe == 3) { // four LDS stages: three k-tiles in flight behind the one being multiplied
+                snprintf(kname, sizeof kname, "igemm_f32_dma_kernel<%d,%d,%d,%d,4>", BM, BN, BL, mode);
+                ProfScope ps(ctx, kname, fl, by);
+                if (mode == 2) hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, BL, 2, 4>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+                else if (mode == 1) hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, BL, 1, 4>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+                else hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, BL, 0, 4>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+                RTEN_LAUNCH_CHECK(ctx, "igemm_f32_dma_kernel launch");
+                return RTEN_HIP_OK;
+            }
         }
         if constexpr (BL != B_IM2COL_TAPS) {
             snprintf(kname, sizeof kname, "igemm_f32_kernel<%d,%d,%d,%d,%d>", BM, BN, AL, BL, mode);
@@ -1333,7 +1342,7 @@ int32_t launch_variant(rten_hip_ctx *ctx, GemmArgs &a, int Z, int cfg) {
 }
 
 int pick_cfg(rten_hip_ctx *ctx, int M, long long N, int Z) {
-    if (ctx->gemm_variant_override >= 0 && ctx->gemm_variant_override < 12) return ctx->gemm_variant_override & 3;
+    if (ctx->gemm_variant_override >= 0 && ctx->gemm_variant_override < 16) return ctx->gemm_variant_override & 3;
     int best = 3;
     double best_cost = 1e300;
     for (int c = 0; c < 4; c++) {
@@ -1371,14 +1380,14 @@ constexpr long long kMaxBufBytes = 0x7fffffffll; // buffer offsets are 32-bit; t
 
 // Variants 0..3: tile shapes {128x128, 128x64, 64x128, 64x64} with the LDS-DMA pipeline on the conv paths;
 // variants 4..7: the same tile shapes with the register-staged pipeline; variants 8..11: LDS-DMA with
-// wave specialisation (4 MFMA waves + 4 loader waves).  Non-conv operand layouts always use the
-// register-staged kernel.
-RTEN_EXPORT int32_t rten_hip_num_gemm_variants(void) { return 12; }
+// wave specialisation (4 MFMA waves + 4 loader waves); variants 12..15: LDS-DMA with four LDS stages.  Non-conv
+// operand layouts always use the register-staged kernel.
+RTEN_EXPORT int32_t rten_hip_num_gemm_variants(void) { return 16; }
 
 RTEN_EXPORT int32_t rten_hip_set_gemm_variant_override(rten_hip_ctx *ctx, int32_t variant) {
     RTEN_CHECK_CTX(ctx);
     ctx->gemm_variant_override = variant;
-    ctx->pipeline = (variant >= 8 && variant < 12) ? 2 : ((variant >= 4 && variant < 8) ? 0 : 1);
+    ctx->pipeline = (variant >= 12 && variant < 16) ? 3 : (variant >= 8 && variant < 12) ? 2 : ((variant >= 4 && variant < 8) ? 0 : 1);
     return RTEN_HIP_OK;
 }
 

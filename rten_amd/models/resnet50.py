@@ -243,7 +243,7 @@ class ResNet50:
         d = self.descs[l["name"]]
         nblk = (d.c // d.groups * d.kh * d.kw + 255) // 256
         if nblk > 1:
-            for v in range(8):  # LDS-DMA and register-staged pipelines; the wave-specialised kernel has no split form
+            for v in (0, 1, 2, 3, 4, 5, 6, 7, 12, 13, 14, 15):  # LDS-DMA (3/4 stages) and register-staged pipelines; the wave-specialised kernel has no split form
                 for groups in sorted({2, 3, 4, 6, nblk} & set(range(2, nblk + 1))):
                     plans.append((v, 1, groups, 0))
                     for o in (0, 2, 3):
