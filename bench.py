@@ -50,6 +50,59 @@ def cpu_baseline(specs, weights, budget_s=12.0):
                       f"({threads} OpenMP threads, {dt:.1f} s)"}
 
 
+def cpu_op_baselines():
+    """cpu_baseline leg for the per-kernel table (tools/bench_ops.py --cpu-baseline): the CPU oracle timed on a bounded
+    sample of each kernel's shape, scaled linearly to the full shape.  Returns {op: {"us": ..., "sample": ...}}."""
+    from oracle import ref
+    rng = np.random.default_rng(0)
+    out = {}
+
+    def t(fn, reps=3):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return (time.perf_counter() - t0) / reps * 1e6
+
+    def put(op, us, scale, sample):
+        out[op] = {"us": round(us * scale, 1), "cores": ref.num_threads(), "kind": "port", "sample": f"{sample}, scaled x{scale:g}"}
+
+    n = 1 << 22
+    x, x2 = rng.standard_normal(n, dtype=np.float32), rng.standard_normal(n, dtype=np.float32)
+    full = 32 * 256 * 56 * 56
+    put("Relu", t(lambda: ref.relu(x)), full / n, f"n={n}")
+    put("Add", t(lambda: ref.add(x, x2)), full / n, f"n={n}")
+    put("Gelu", t(lambda: ref.gelu(x)), 4096 * 3072 / n, f"n={n}")
+    put("Erf", t(lambda: ref.erf(x)), 4096 * 3072 / n, f"n={n}")
+    put("DynamicQuantizeLinear", t(lambda: ref.dynamic_quantize_linear(x)), full / n, f"n={n}")
+    xi = rng.integers(-1000, 1000, n).astype(np.int32)
+    put("cast_scale", t(lambda: ref.cast_scale(xi, np.float32(0.01))), full / n, f"n={n}")
+    sm = x[:4096 * 128].reshape(4096, 128)
+    put("Softmax", t(lambda: ref.softmax(sm)), 12, "rows=4096 cols=128")
+    ln = x[:4096 * 768].reshape(4096, 768)
+    g, b = np.ones(768, np.float32), np.zeros(768, np.float32)
+    put("LayerNormalization", t(lambda: ref.layer_norm(ln, g, b, eps=1e-12)), 1, "rows=4096 cols=768")
+    mp = x[:2 * 64 * 112 * 112].reshape(2, 64, 112, 112)
+    put("MaxPool 3x3/2", t(lambda: ref.max_pool(mp, (3, 3), (2, 2), (1, 1, 1, 1))), 16, "2x64x112x112")
+    gp = x[:32 * 2048 * 49].reshape(32, 2048, 7, 7)
+    put("GlobalAveragePool", t(lambda: ref.global_average_pool(gp)), 1, "32x2048x7x7")
+    for (m, k, nn, name) in ((4096, 768, 768, "MatMul proj"), (4096, 768, 3072, "MatMul FFN1 + Gelu"), (4096, 3072, 768, "MatMul FFN2")):
+        a, w, bias = rng.standard_normal((512, k), dtype=np.float32), rng.standard_normal((k, nn), dtype=np.float32), np.zeros(nn, np.float32)
+        if "Gelu" in name:
+            put(name, t(lambda: ref.gelu(ref.matmul_f32(a, w, bias=bias)), 2), 8, f"512x{k}x{nn}")
+        else:
+            put(name, t(lambda: ref.matmul_f32(a, w, bias=bias), 2), 8, f"512x{k}x{nn}")
+    q, kk, v = (rng.standard_normal((2, 12, 128, 64), dtype=np.float32) for _ in range(3))
+    put("sdpa (QK^T, softmax, PV)", t(lambda: ref.sdpa(q, kk, v, scale=0.125), 2), 16, "b=2 h=12 s=128 d=64")
+    for (m, k, nn) in ((4096, 768, 768), (4096, 768, 3072)):
+        a, w = rng.integers(0, 255, (512, k)).astype(np.uint8), rng.integers(-127, 127, (k, nn)).astype(np.int8)
+        put(f"MatMulInteger {m}x{k}x{nn}", t(lambda: ref.gemm_int8(a, w, np.array(128, np.uint8), None), 2), 8, f"512x{k}x{nn}")
+    for (o_, c_, hw, k_, p_, name) in ((64, 64, 56, 3, 1, "s0 3x3"), (256, 256, 14, 3, 1, "s2 3x3"), (256, 64, 56, 1, 0, "s0 1x1 expand")):
+        xq, wq = rng.integers(0, 255, (2, c_, hw, hw)).astype(np.uint8), rng.integers(-127, 127, (o_, c_, k_, k_)).astype(np.int8)
+        put(f"ConvInteger {name}", t(lambda: ref.conv2d_int8(xq, wq, x_zp=128, pads=(p_,) * 4), 2), 16, f"2x{c_}x{hw}x{hw}")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)

@@ -28,6 +28,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="", help="substring filter on the op name (e.g. Integer)")
+    ap.add_argument("--cpu-baseline", action="store_true", help="add bench.py's CPU-oracle timing (cpu_baseline leg) beside every row")
     args = ap.parse_args()
     ctx = L.Context(0)
     rng = np.random.default_rng(0)
@@ -122,6 +123,15 @@ def main():
              (lambda: ctx.call("rten_hip_conv2d_int8", C.byref(d), xq.vp, wq.vp, xz.vp, wz.vp, None, None, None, 0, out.vp)),
              2.0 * 32 * o_ * c_ * k_ * k_ * oh * oh, I8_PEAK_TOPS, "TOP/s")
 
+    if args.cpu_baseline:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench  # the oracle is only ever touched through bench.py's cpu_baseline leg
+        base = bench.cpu_op_baselines()
+        for r in rows:
+            key = r["op"] if r["op"] in base else f"{r['op']} {r['shape']}"
+            if key in base:
+                r["cpu_baseline"] = base[key]
+                r["speedup_vs_cpu_port"] = round(base[key]["us"] / r["us"], 1)
     print(json.dumps({"device": ctx.device_info(), "reps": args.reps, "rows": rows}, indent=1))
 
 
