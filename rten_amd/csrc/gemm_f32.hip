@@ -620,9 +620,12 @@ __device__ __forceinline__ void wait_vmcnt() {
 // MODE 0: K <= 256 (one depth block); 1: several depth blocks folded in registers; 2: split-K producer -- every
 // workgroup computes one group of depth blocks of one split tile and parks each block's raw accumulator in the slab
 // (no fold, no epilogue: igemm_f32_fixup_kernel finishes the tile).
-template <int BM, int BN, int BL, int MODE, int NST = 3>
+// AL: A_M4 = k-major A ([K][M], prepacked conv weights, transposed GEMM operands); A_K4 = row-major A ([M][K], the
+// plain MatMul layout): one DMA instruction then moves 64 rows x one k-quad and the LDS image is [k-quad][m][4].
+template <int BM, int BN, int AL, int BL, int MODE, int NST = 3>
 __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmArgs p) {
     constexpr bool MULTI_KC = MODE == 1, SPLIT = MODE == 2;
+    static_assert(AL == A_M4 || AL == A_K4, "DMA kernel: A is k-major or row-major with 16-byte rows");
     static_assert(BL == B_N4 || BL == B_IM2COL || BL == B_IM2COL_TAPS, "DMA kernel covers the conv operand layouts");
     constexpr int WM = 2, WN = 2;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -673,14 +676,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
     // ---- loop-invariant DMA source offsets.  Wave w issues instructions q = w*N + j; instruction q covers
     // the flat tile range [q*256, q*256+256) floats (dwordx4) or [q*64, q*64+64) (dword gather).
     unsigned a_voff[NA];
+    [[maybe_unused]] int a_kq[NA]; // A_K4: first local k of the instruction's k-quad (k-tail test)
 #pragma unroll
     for (int j = 0; j < NA; j++) {
-        const int f = (wave * NA + j) * 256 + lane * 4;
-        const int k = f / BM, m = m0 + f % BM;
-        // rows >= K lie past the end of the [K][M4] buffer (hardware range check); columns >= M4 must not wrap
-        a_voff[j] = m < (int)p.a_cs ? (unsigned)(((long long)k * p.a_cs + m) * 4) : OOB;
+        if constexpr (AL == A_M4) {
+            const int f = (wave * NA + j) * 256 + lane * 4;
+            const int k = f / BM, m = m0 + f % BM;
+            // rows >= K lie past the end of the [K][M4] buffer (hardware range check); columns >= M4 must not wrap
+            a_voff[j] = m < (int)p.a_cs ? (unsigned)(((long long)k * p.a_cs + m) * 4) : OOB;
+        } else {
+            const int q = wave * NA + j, kq = q / (BM / 64), m = m0 + (q % (BM / 64)) * 64 + lane;
+            a_kq[j] = kq * 4;
+            a_voff[j] = m < p.M ? (unsigned)(((long long)m * p.a_rs + kq * 4) * 4) : OOB;
+        }
     }
-    const unsigned a_kstep = (unsigned)(BK * p.a_cs * 4);
+    const unsigned a_kstep = AL == A_M4 ? (unsigned)(BK * p.a_cs * 4) : (unsigned)(BK * 4);
 
     [[maybe_unused]] unsigned b_voff[BL == B_N4 ? NBV : 1];
     [[maybe_unused]] int b_krow[BL == B_N4 ? NBV : 1];
@@ -746,9 +756,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
         const bool past = kt >= nk;
         const unsigned a_soff = (unsigned)kts * a_kstep;
 #pragma unroll
-        for (int j = 0; j < NA; j++)
+        for (int j = 0; j < NA; j++) {
+            bool dead = past;
+            if constexpr (AL == A_K4) dead = a_kq[j] >= p.K - kt * BK; // k-tail quads (and every quad past the end) read as zeros
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(As + (wave * NA + j) * 256), 16,
-                                                     (int)(past ? OOB : a_voff[j]), (int)a_soff, 0, 0);
+                                                     (int)(dead ? OOB : a_voff[j]), (int)a_soff, 0, 0);
+        }
         if constexpr (BL == B_N4) {
             const int kleft = p.K - kt * BK;
             const unsigned b_soff = (unsigned)kts * b_kstep;
@@ -802,11 +815,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
     };
 
     auto compute_tile = [&](int stage) {
-        const float *As = smem + stage * STAGE + wm0 + l31;
+        // A fragment of k-pair kk, block i: k = 2*kk + half.  k-major image: As[k][m]; row-major image: [k/4][m][4]
+        // (k and k+1 share a quad, so `half` is part of the lane's base and the rest is an immediate).
+        const float *As = smem + stage * STAGE + (AL == A_M4 ? wm0 + l31 + half * BM : (wm0 + l31) * 4 + half);
+        auto a_idx = [](int kk, int i) { return AL == A_M4 ? 2 * kk * BM + i * 32 : (kk >> 1) * BM * 4 + ((2 * kk) & 3) + i * 128; };
         const float *Bs = smem + stage * STAGE + BK * BM + wn0 + l31;
         float af[2][TM], bf[2][TN]; // operand fragments, double buffered across k-pairs
 #pragma unroll
-        for (int i = 0; i < TM; i++) af[0][i] = As[half * BM + i * 32];
+        for (int i = 0; i < TM; i++) af[0][i] = As[a_idx(0, i)];
 #pragma unroll
         for (int j = 0; j < TN; j++) bf[0][j] = Bs[half * BN + j * 32];
 #pragma unroll
@@ -814,7 +830,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
             const int cur = kk & 1, nxt = cur ^ 1;
             if (kk + 1 < BK / 2) {
 #pragma unroll
-                for (int i = 0; i < TM; i++) af[nxt][i] = As[(2 * (kk + 1) + half) * BM + i * 32];
+                for (int i = 0; i < TM; i++) af[nxt][i] = As[a_idx(kk + 1, i)];
 #pragma unroll
                 for (int j = 0; j < TN; j++) bf[nxt][j] = Bs[(2 * (kk + 1) + half) * BN + j * 32];
             }
@@ -1241,8 +1257,9 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
     const double bytes = 4.0 * Z * ((double)a.M * a.K + (double)a.K * a.N + (double)a.M * a.N);
     char kname[96];
     const bool multi = a.K > 256;
-    constexpr bool kDma = AL == A_M4 && (BL == B_N4 || BL == B_IM2COL || BL == B_IM2COL_TAPS);
-    const int pipe = kDma ? ctx->pipeline : 0;
+    constexpr bool kDma = (AL == A_M4 || AL == A_K4) && (BL == B_N4 || BL == B_IM2COL || BL == B_IM2COL_TAPS);
+    int pipe = kDma ? ctx->pipeline : 0;
+    if (AL == A_K4 && pipe == 2) pipe = 1; // the wave-specialised kernel only takes k-major A
     if constexpr (BL == B_IM2COL_TAPS) {
         if (pipe == 0) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "internal: tap-mask im2col needs an LDS-DMA pipeline");
     }
@@ -1287,20 +1304,20 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
                 return RTEN_HIP_OK;
             }
             if (pipe == 1) {
-                snprintf(kname, sizeof kname, "igemm_f32_dma_kernel<%d,%d,%d,%d>", BM, BN, BL, mode);
+                snprintf(kname, sizeof kname, "igemm_f32_dma_kernel<%d,%d,%d,%d,%d>", BM, BN, AL, BL, mode);
                 ProfScope ps(ctx, kname, fl, by);
-                if (mode == 2) hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, BL, 2>), grid, dim3(NTHREADS), 0, ctx->stream, a);
-                else if (mode == 1) hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, BL, 1>), grid, dim3(NTHREADS), 0, ctx->stream, a);
-                else hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, BL, 0>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+                if (mode == 2) hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, AL, BL, 2>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+                else if (mode == 1) hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, AL, BL, 1>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+                else hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, AL, BL, 0>), grid, dim3(NTHREADS), 0, ctx->stream, a);
                 RTEN_LAUNCH_CHECK(ctx, "igemm_f32_dma_kernel launch");
                 return RTEN_HIP_OK;
             }
             if (pipe == 3) { // four LDS stages: three k-tiles in flight behind the one being multiplied
-                snprintf(kname, sizeof kname, "igemm_f32_dma_kernel<%d,%d,%d,%d,4>", BM, BN, BL, mode);
+                snprintf(kname, sizeof kname, "igemm_f32_dma_kernel<%d,%d,%d,%d,%d,4>", BM, BN, AL, BL, mode);
                 ProfScope ps(ctx, kname, fl, by);
-                if (mode == 2) hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, BL, 2, 4>), grid, dim3(NTHREADS), 0, ctx->stream, a);
-                else if (mode == 1) hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, BL, 1, 4>), grid, dim3(NTHREADS), 0, ctx->stream, a);
-                else hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, BL, 0, 4>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+                if (mode == 2) hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, AL, BL, 2, 4>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+                else if (mode == 1) hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, AL, BL, 1, 4>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+                else hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, AL, BL, 0, 4>), grid, dim3(NTHREADS), 0, ctx->stream, a);
                 RTEN_LAUNCH_CHECK(ctx, "igemm_f32_dma_kernel launch");
                 return RTEN_HIP_OK;
             }
