@@ -624,7 +624,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 // plain MatMul layout): one DMA instruction then moves 64 rows x one k-quad and the LDS image is [k-quad][m][4].
 template <int BM, int BN, int AL, int BL, int MODE, int NST = 3>
 __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmArgs p) {
-    constexpr bool MULTI_KC = MODE == 1, SPLIT = MODE == 2;
+    // MODE 3 ("mixed"): one launch holds the whole tiles [0, split_t1) (fold + epilogue, as MODE 1) AND the split-K
+    // producers of the tail tiles (as MODE 2), so the tail's small workgroups fill the last round next to the whole
+    // tiles instead of running alone afterwards.
+    constexpr bool MIXED = MODE == 3, MULTI_KC = MODE == 1 || MIXED, SPLIT = MODE == 2;
     static_assert(AL == A_M4 || AL == A_K4, "DMA kernel: A is k-major or row-major with 16-byte rows");
     static_assert(BL == B_N4 || BL == B_IM2COL || BL == B_IM2COL_TAPS, "DMA kernel covers the conv operand layouts");
     constexpr int WM = 2, WN = 2;
@@ -646,12 +649,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
 
     int tile, grp = -1; // grp >= 0: this workgroup computes one K group of a split tile
     {
-        const int nt = gridDim.x;
         const int id = blockIdx.x;
+        const int nt = MIXED ? p.split_t1 : (int)gridDim.x; // whole tiles are XCD-chunked; mixed-mode producers keep dispatch order
         const int xcd = id & 7, q = nt >> 3, r = nt & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
-        if constexpr (SPLIT) {
-            const int rr = tile;
+        if (SPLIT || (MIXED && id >= p.split_t1)) {
+            const int rr = MIXED ? id - p.split_t1 : tile;
             if (p.order & 2) { // K group slowest: an XCD's contiguous id range is one K slice of many tiles
                 grp = rr / p.split_ntail;
                 tile = p.split_t1 + rr - grp * p.split_ntail;
@@ -862,7 +865,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
     // ---- software pipeline: tiles kt+1 and kt+2 are in flight while tile kt is multiplied
     const int nblk = (MULTI_KC || SPLIT) ? (nk + KC_TILES - 1) / KC_TILES : 1;
     int blk0 = 0, blk1 = nblk;
-    if constexpr (SPLIT) {
+    if (SPLIT || (MIXED && grp >= 0)) {
         blk0 = grp * p.split_g;
         blk1 = blk0 + p.split_g < nblk ? blk0 + p.split_g : nblk;
     }
@@ -893,7 +896,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
             } else if (!(ABLATE(p) & 2)) compute_tile(stage);
             stage = stage == NSTAGE - 1 ? 0 : stage + 1;
         }
-        if constexpr (SPLIT) {
+        if (SPLIT || (MIXED && grp >= 0)) {
             store_raw(acc, blk);
 #pragma unroll
             for (int i = 0; i < TM; i++)
@@ -901,24 +904,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
                 for (int j = 0; j < TN; j++)
 #pragma unroll
                     for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-        }
-        if constexpr (MULTI_KC) {
+        } else if constexpr (MULTI_KC) {
             if (blk + 1 < nblk) flush(blk == 0);
         }
     }
     wait_vmcnt<0>(); // drain the two look-ahead tiles before the LDS goes away
 
     if constexpr (!SPLIT) {
+        if (MIXED && grp >= 0) return;
         if (!(ABLATE(p) & 4)) {
-        const int mb = m0 + wm0 + 4 * half, nb0 = n0 + wn0 + l31;
-        if constexpr (MULTI_KC) { // launched only for K > 256: at least two depth blocks
-            fold_next<TM, TN>(p, acc, tot);
-            store_out<TM, TN>(p, tot, mb, nb0, c_zoff);
-        } else {
-            fold_first<TM, TN>(p, z, acc, acc, mb, nb0, c_zoff);
-            store_out<TM, TN>(p, acc, mb, nb0, c_zoff);
+            const int mb = m0 + wm0 + 4 * half, nb0 = n0 + wn0 + l31;
+            if constexpr (MULTI_KC) { // launched only for K > 256: at least two depth blocks
+                fold_next<TM, TN>(p, acc, tot);
+                store_out<TM, TN>(p, tot, mb, nb0, c_zoff);
+            } else {
+                fold_first<TM, TN>(p, z, acc, acc, mb, nb0, c_zoff);
+                store_out<TM, TN>(p, acc, mb, nb0, c_zoff);
+            }
         }
-    }
     }
 }
 
@@ -1333,13 +1336,24 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
         return RTEN_HIP_OK;
     };
 
-    if (t1 > 0) {
+    bool mixed = false;
+    if constexpr (kDma && BM * BN < 128 * 128) mixed = pipe == 1 && ntail > 0 && t1 > 0;
+    if (mixed) { // whole tiles and the tail's split-K producers in ONE launch (co-resident), then the fixup
+        if constexpr (kDma && BM * BN < 128 * 128) {
+            snprintf(kname, sizeof kname, "igemm_f32_dma_kernel<%d,%d,%d,%d,3>", BM, BN, AL, BL);
+            ProfScope ps(ctx, kname, flops, bytes);
+            hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, AL, BL, 3>), dim3((unsigned)(t1 + ntail * S), (unsigned)Z), dim3(NTHREADS), 0, ctx->stream, a);
+            RTEN_LAUNCH_CHECK(ctx, "igemm_f32_dma_kernel (mixed) launch");
+        }
+    } else if (t1 > 0) {
         const int32_t rc = launch(multi ? 1 : 0, (unsigned)t1, flops * t1 / T, bytes * t1 / T);
         if (rc) return rc;
     }
     if (ntail > 0) {
-        const int32_t rc = launch(2, (unsigned)(ntail * S), flops * ntail / T, bytes * ntail / T);
-        if (rc) return rc;
+        if (!mixed) {
+            const int32_t rc = launch(2, (unsigned)(ntail * S), flops * ntail / T, bytes * ntail / T);
+            if (rc) return rc;
+        }
         snprintf(kname, sizeof kname, "igemm_f32_fixup_kernel<%d,%d>", BM, BN);
         ProfScope ps(ctx, kname, 0.0, 8.0 * Z * ntail * nblk * BM * BN);
         hipLaunchKernelGGL((igemm_f32_fixup_kernel<BM, BN>), dim3((unsigned)ntail * 4u, (unsigned)Z), dim3(64), 0, ctx->stream, a);
