@@ -186,6 +186,7 @@ typedef struct {
     int32_t w_zp_len; /* 0, 1 or o */
     int32_t pad_mode;
     int32_t weights_packed; /* != 0: `w` is a buffer written by rten_hip_conv2d_int8_prepack */
+    int32_t x_staged;       /* != 0: `x` is a staged image written by rten_hip_dynamic_quantize_linear_staged */
 } rten_hip_conv2d_int8_desc;
 /* scale == NULL: y is i32 (ConvInteger).  scale != NULL (device scalar): y is f32 =
  * (acc as f32) * scale[0], then optional bias[o] add (the Add node that follows in ort-quantized
@@ -196,6 +197,15 @@ typedef struct {
  * geometry (grouped convolution): pass the plain OIHW tensor then. */
 size_t rten_hip_conv2d_int8_packed_bytes(const rten_hip_conv2d_int8_desc *desc);
 int32_t rten_hip_conv2d_int8_prepack(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *desc, const void *w, void *packed);
+/* DynamicQuantizeLinear fused with the activation staging of the ConvInteger that consumes it (the reference runs
+ * DynamicQuantizeLinear -> ConvInteger back to back in ort-quantized graphs, src/ops/quantize.rs:352-436 ->
+ * src/ops/conv.rs:421-476): same scale / zero point / u8 codes bit for bit, but the codes are written once, directly
+ * in the layout the int8 kernel gathers from (zero-point-padded NHWC, signed domain) instead of as an NCHW u8 tensor.
+ * `desc` is the consumer's descriptor (x_signed must be 0: DynamicQuantizeLinear produces u8); staged_bytes returns 0
+ * when the staged kernel does not cover the geometry. */
+size_t rten_hip_conv2d_int8_staged_bytes(const rten_hip_conv2d_int8_desc *desc);
+int32_t rten_hip_dynamic_quantize_linear_staged(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *desc, const float *x,
+                                                void *staged, float *scale, uint8_t *zero_point);
 int32_t rten_hip_conv2d_int8(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *desc, const void *x, const void *w,
                              const void *x_zp, const void *w_zp, const float *scale, const float *bias,
                              const float *residual, uint32_t flags, void *y);

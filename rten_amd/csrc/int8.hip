@@ -311,7 +311,7 @@ RTEN_EXPORT int32_t rten_hip_conv2d_int8(rten_hip_ctx *ctx, const rten_hip_conv2
     const long long HW = (long long)d->h * d->w;
     if ((long long)d->n * d->c * HW >= (1ll << 31) || (long long)d->n * d->o * P >= (1ll << 31))
         return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "conv: tensors above 2^31 elements are not supported");
-    if (ctx->int8_path == 0 || di->weights_packed) {
+    if (ctx->int8_path == 0 || di->weights_packed || di->x_staged) {
         const int32_t rc = rten_i8_fast_conv(ctx, di, x, w, x_zp, w_zp, scale, bias, residual, flags, y);
         if (rc != RTEN_HIP_ERR_UNSUPPORTED) return rc;
     }

@@ -21,6 +21,7 @@
 //     (v_dot4 on the operand fragments) when the weight zero point can be non-zero.
 //   * Epilogue fuses cast_scale, bias, residual Add and Relu; i32 or f32 output straight into NCHW / row-major.
 #include "internal.h"
+#include "quantize.h"
 #include "vecmath.h"
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -118,6 +119,40 @@ __global__ __launch_bounds__(256) void i8_nhwc_pad_kernel(const uint8_t *__restr
             const int cl = pass * 4 + (t >> 6), c = c0 + cl;
             unsigned v = c < C ? fill : 0u;
             if (xin && c < C) v = ((unsigned)x[(((long long)n * C + c) * H + y) * W + xs] ^ flip) & 0xffu;
+            tile[xl][cl] = (uint8_t)v;
+        }
+        __syncthreads();
+        const int px = t >> 2, ch = t & 3;
+        if (x0 + px < Wp && c0 + ch * 16 < Cp)
+            *reinterpret_cast<uint4 *>(xp + (((long long)n * Hp + yp) * Wp + x0 + px) * Cp + c0 + ch * 16) = *reinterpret_cast<const uint4 *>(&tile[px][ch * 16]);
+        __syncthreads();
+    }
+}
+
+// DynamicQuantizeLinear's quantize sweep fused with the staging above: f32 NCHW -> u8 codes (bit-identical to
+// quantize.hip: same scale / zero-point algebra, same to_int_round + saturate) written as padded NHWC signed bytes.
+__global__ __launch_bounds__(256) void i8_quantize_stage_kernel(const float *__restrict__ x, const unsigned *__restrict__ ws, uint8_t *__restrict__ xp,
+                                                               int C, int H, int W, int Hp, int Wp, int Cp, int pt, int pl, int pad_mode,
+                                                               float *scale_out, uint8_t *zp_out) {
+    __shared__ uint8_t tile[64][64 + 16];
+    const dql::QParams q = dql::dql_params(dql::ord2f(ws[0]), dql::ord2f(ws[1]));
+    const int t = threadIdx.x;
+    const int x0 = blockIdx.x * 64, yp = blockIdx.y, n = blockIdx.z;
+    if (t == 0 && blockIdx.x == 0 && yp == 0 && n == 0) { *scale_out = q.scale; *zp_out = (uint8_t)q.zp; }
+    const int y = yp - pt;
+    int pad_s = 0; // signed-domain padding value
+    if (pad_mode == RTEN_HIP_PAD_ZERO_POINT) pad_s = q.zp - 128;
+    else if (pad_mode == RTEN_HIP_PAD_RAW0_U8) pad_s = -128;
+    const unsigned fill = (unsigned)pad_s & 0xffu;
+    const bool yin = (unsigned)y < (unsigned)H;
+    for (int c0 = 0; c0 < Cp; c0 += 64) {
+        const int xl = t & 63, xs = x0 + xl - pl;
+        const bool xin = yin && (unsigned)xs < (unsigned)W;
+#pragma unroll
+        for (int pass = 0; pass < 16; pass++) {
+            const int cl = pass * 4 + (t >> 6), c = c0 + cl;
+            unsigned v = c < C ? fill : 0u;
+            if (xin && c < C) v = dql::quant_u8(x[(((long long)n * C + c) * H + y) * W + xs], q.inv_scale, q.zp) ^ 0x80u;
             tile[xl][cl] = (uint8_t)v;
         }
         __syncthreads();
@@ -485,13 +520,38 @@ RTEN_EXPORT int32_t rten_hip_conv2d_int8_prepack(rten_hip_ctx *ctx, const rten_h
     return RTEN_HIP_OK;
 }
 
+RTEN_EXPORT size_t rten_hip_conv2d_int8_staged_bytes(const rten_hip_conv2d_int8_desc *di) {
+    if (!di || di->x_signed) return 0;
+    const ConvGeom g = conv_geom(di);
+    return g.ok ? up256(g.img) : 0;
+}
+
+RTEN_EXPORT int32_t rten_hip_dynamic_quantize_linear_staged(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di, const float *x, void *staged,
+                                                            float *scale, uint8_t *zero_point) {
+    RTEN_CHECK_CTX(ctx);
+    if (!di || !x || !staged || !scale || !zero_point) return RTEN_HIP_ERR_INVALID_VALUE;
+    const ConvGeom g = conv_geom(di);
+    if (!g.ok || di->x_signed) return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "quantize_staged: geometry not covered by the staged kernel (staged_bytes == 0)");
+    const rten_hip_conv2d_desc *d = &di->conv;
+    const int64_t n = (int64_t)d->n * d->c * d->h * d->w;
+    ProfScope ps(ctx, "dynamic_quantize_linear_staged", 0.0, 8.0 * n + (double)g.img);
+    unsigned *ws = rten_dql_minmax(ctx, n, x);
+    if (!ws) return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "dql: scratch allocation failed");
+    hipLaunchKernelGGL(i8_quantize_stage_kernel, dim3((unsigned)((g.Wp + 63) / 64), (unsigned)g.Hp, (unsigned)d->n), dim3(256), 0, ctx->stream, x, ws,
+                       (uint8_t *)staged, d->c, d->h, d->w, g.Hp, g.Wp, g.Cp, d->pads[0], d->pads[1], di->pad_mode, scale, zero_point);
+    RTEN_LAUNCH_CHECK(ctx, "i8_quantize_stage_kernel launch");
+    return RTEN_HIP_OK;
+}
+
 int32_t rten_i8_fast_conv(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di, const void *x, const void *w, const void *x_zp,
                           const void *w_zp, const float *scale, const float *bias, const float *residual, uint32_t flags, void *y) {
     const rten_hip_conv2d_desc *d = &di->conv;
     const ConvGeom cg = conv_geom(di);
-    if (!cg.ok) return di->weights_packed ? rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "conv_int8: packed weights for an unsupported geometry") : RTEN_HIP_ERR_UNSUPPORTED;
+    if (!cg.ok)
+        return (di->weights_packed || di->x_staged) ? rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "conv_int8: staged operands for an unsupported geometry")
+                                                    : RTEN_HIP_ERR_UNSUPPORTED;
     const size_t wbytes = di->weights_packed ? 0 : up256((size_t)d->o * cg.Kp) + up256((size_t)d->o * 4);
-    const size_t offA = 4096, offB = offA + wbytes, total = offB + up256(cg.img);
+    const size_t offA = 4096, offB = offA + wbytes, total = offB + (di->x_staged ? 0 : up256(cg.img));
     char *sc = (char *)rten_scratch(ctx, total);
     if (!sc) return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "int8 staging allocation failed (or attempted during graph capture)");
     const uint8_t *Ap;
@@ -505,12 +565,13 @@ int32_t rten_i8_fast_conv(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di
         hipLaunchKernelGGL(i8_pack_rows_kernel, dim3((unsigned)d->o), dim3(256), 0, ctx->stream, (const uint8_t *)w, (long long)cg.Kreal, 1ll, cg.Kreal, d->c,
                            cg.taps, cg.Cp, cg.Kp, di->w_signed ? 0u : 0x80u, (uint8_t *)Ap, (int *)rsum);
     }
-    hipLaunchKernelGGL(i8_nhwc_pad_kernel, dim3((unsigned)((cg.Wp + 63) / 64), (unsigned)cg.Hp, (unsigned)d->n), dim3(256), 0, ctx->stream, (const uint8_t *)x,
-                       (uint8_t *)(sc + offB), d->c, d->h, d->w, cg.Hp, cg.Wp, cg.Cp, d->pads[0], d->pads[1], di->x_signed ? 0u : 0x80u, (const uint8_t *)x_zp,
-                       di->x_signed, di->pad_mode);
+    if (!di->x_staged)
+        hipLaunchKernelGGL(i8_nhwc_pad_kernel, dim3((unsigned)((cg.Wp + 63) / 64), (unsigned)cg.Hp, (unsigned)d->n), dim3(256), 0, ctx->stream, (const uint8_t *)x,
+                           (uint8_t *)(sc + offB), d->c, d->h, d->w, cg.Hp, cg.Wp, cg.Cp, d->pads[0], d->pads[1], di->x_signed ? 0u : 0x80u,
+                           (const uint8_t *)x_zp, di->x_signed, di->pad_mode);
     RTEN_LAUNCH_CHECK(ctx, "int8 staging launch");
     FastArgs g = {};
-    g.A = Ap; g.B = (const uint8_t *)(sc + offB);
+    g.A = Ap; g.B = di->x_staged ? (const uint8_t *)x : (const uint8_t *)(sc + offB);
     g.rsum = rsum; g.csum = nullptr;
     g.C = y;
     g.a_zp = di->w_zp_len ? (const uint8_t *)w_zp : nullptr;

@@ -6,21 +6,12 @@
 // (range/255, min/scale, clamp, round-ties-even), so the u8 codes, scale and zero point are
 // bit-identical.  The scale and zero point stay in device memory for the following
 // ConvIntegerToFloat / MatMulIntegerToFloat epilogue -- no host round trip.
-#include "internal.h"
+#include "quantize.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+using namespace dql;
 
 namespace {
-
-// order-preserving float <-> uint mapping for atomic min/max
-__device__ __forceinline__ unsigned f2ord(float f) {
-    const unsigned b = __float_as_uint(f);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-__device__ __forceinline__ float ord2f(unsigned u) {
-    const unsigned b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
-    return __uint_as_float(b);
-}
 
 __global__ void minmax_init_kernel(unsigned *ws) {
     ws[0] = f2ord(__builtin_inff());  // running min
@@ -59,37 +50,6 @@ __global__ __launch_bounds__(256) void minmax_kernel(int64_t n, const float *__r
     }
 }
 
-struct QParams { float scale, inv_scale; int zp; };
-
-// quantize.rs:411-419 (scalar algebra) -- identical operation sequence
-__device__ __forceinline__ QParams dql_params(float x_min, float x_max) {
-    const float x_min_adj = fminf(x_min, 0.f);
-    const float x_max_adj = fmaxf(x_max, 0.f);
-    const float range = x_max_adj - x_min_adj;
-    const float scale = range / 255.f;
-    const float min_scaled = x_min_adj / scale;
-    const float init_zp = 0.f - min_scaled;
-    const float clipped = init_zp < 0.f ? 0.f : (init_zp > 255.f ? 255.f : init_zp); // f32::clamp keeps NaN
-    const float rounded = rintf(clipped);                                            // round_ties_even
-    int zp = 0;
-    if (rounded == rounded) zp = (int)(rounded < 0.f ? 0.f : (rounded > 255.f ? 255.f : rounded)); // saturating cast
-    QParams q;
-    q.scale = scale;
-    q.inv_scale = 1.f / scale; // quantize.rs:210
-    q.zp = zp;
-    return q;
-}
-
-// vecmath/quantize.rs:57-62: to_int_round (cvtps2dq: NaN / out of range -> i32::MIN), + zp, saturate to u8
-__device__ __forceinline__ unsigned quant_u8(float x, float inv_scale, int zp) {
-    const float p = x * inv_scale;
-    int q;
-    if (!(p == p) || p >= 2147483648.f || p < -2147483648.f) q = (int)0x80000000;
-    else q = (int)rintf(p);
-    long long t = (long long)q + zp;
-    t = t < 0 ? 0 : (t > 255 ? 255 : t);
-    return (unsigned)t;
-}
 
 __global__ __launch_bounds__(256) void quantize_kernel(int64_t n, const float *__restrict__ x, const unsigned *ws,
                                                        uint8_t *__restrict__ y, float *scale_out, uint8_t *zp_out,
@@ -120,6 +80,18 @@ __global__ void dql_empty_kernel(float *scale_out, uint8_t *zp_out) {
 
 } // namespace
 
+unsigned *rten_dql_minmax(rten_hip_ctx *ctx, int64_t n, const float *x) {
+    unsigned *ws = (unsigned *)rten_scratch(ctx, 256); // first 256 B of the scratch: DQL min/max words
+    if (!ws) return nullptr;
+    const int vec_in = (((uintptr_t)x & 15u) == 0);
+    const int64_t items = vec_in ? n / 4 : n;
+    int blocks = (int)((items + 255) / 256 > 2048 ? 2048 : (items + 255) / 256);
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, ctx->stream, ws);
+    hipLaunchKernelGGL(minmax_kernel, dim3(blocks), dim3(256), 0, ctx->stream, n, x, ws, vec_in);
+    return ws;
+}
+
 RTEN_EXPORT int32_t rten_hip_dynamic_quantize_linear(rten_hip_ctx *ctx, int64_t n, const float *x, uint8_t *y,
                                                      float *scale, uint8_t *zero_point) {
     RTEN_CHECK_CTX(ctx);
@@ -130,16 +102,14 @@ RTEN_EXPORT int32_t rten_hip_dynamic_quantize_linear(rten_hip_ctx *ctx, int64_t 
         return RTEN_HIP_OK;
     }
     if (!x || !y) return RTEN_HIP_ERR_INVALID_VALUE;
-    unsigned *ws = (unsigned *)rten_scratch(ctx, 256); // first 256 B of the scratch: DQL min/max words
-    if (!ws) return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "dql: scratch allocation failed");
     const int vec_in = (((uintptr_t)x & 15u) == 0);
     const int vec_q = vec_in && (((uintptr_t)y & 3u) == 0);
     int64_t items = vec_in ? n / 4 : n;
     int blocks = (int)((items + 255) / 256 > 2048 ? 2048 : (items + 255) / 256);
     if (blocks < 1) blocks = 1;
     ProfScope ps(ctx, "dynamic_quantize_linear", 0.0, 9.0 * n);
-    hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, ctx->stream, ws);
-    hipLaunchKernelGGL(minmax_kernel, dim3(blocks), dim3(256), 0, ctx->stream, n, x, ws, vec_in);
+    unsigned *ws = rten_dql_minmax(ctx, n, x);
+    if (!ws) return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "dql: scratch allocation failed");
     hipLaunchKernelGGL(quantize_kernel, dim3(blocks), dim3(256), 0, ctx->stream, n, x, ws, y, scale, zero_point, vec_q);
     RTEN_LAUNCH_CHECK(ctx, "dynamic_quantize_linear");
     return RTEN_HIP_OK;

@@ -76,7 +76,7 @@ class Conv2dDesc(C.Structure):
 
 class Conv2dInt8Desc(C.Structure):
     _fields_ = [("conv", Conv2dDesc), ("x_signed", C.c_int32), ("w_signed", C.c_int32),
-                ("w_zp_len", C.c_int32), ("pad_mode", C.c_int32), ("weights_packed", C.c_int32)]
+                ("w_zp_len", C.c_int32), ("pad_mode", C.c_int32), ("weights_packed", C.c_int32), ("x_staged", C.c_int32)]
 
 
 class Pool2dDesc(C.Structure):
@@ -121,6 +121,8 @@ PROTOTYPES = {
     "rten_hip_conv2d_int8": (_I32, [_VP, C.POINTER(Conv2dInt8Desc), _VP, _VP, _VP, _VP, _VP, _VP, _VP, _U32, _VP]),
     "rten_hip_conv2d_int8_packed_bytes": (_SZ, [C.POINTER(Conv2dInt8Desc)]),
     "rten_hip_conv2d_int8_prepack": (_I32, [_VP, C.POINTER(Conv2dInt8Desc), _VP, _VP]),
+    "rten_hip_conv2d_int8_staged_bytes": (_SZ, [C.POINTER(Conv2dInt8Desc)]),
+    "rten_hip_dynamic_quantize_linear_staged": (_I32, [_VP, C.POINTER(Conv2dInt8Desc), _VP, _VP, _VP, _VP]),
     "rten_hip_dynamic_quantize_linear": (_I32, [_VP, _I64, _VP, _VP, _VP, _VP]),
     "rten_hip_cast_scale": (_I32, [_VP, _I64, _VP, _VP, _I32, _VP]),
     "rten_hip_softmax_f32": (_I32, [_VP, _I64, _I32, _VP, _VP, _I64, _I64, _I32, _VP]),

@@ -36,9 +36,12 @@ class ResNet50Int8(ResNet50):
         self.xz = DeviceTensor(ctx, (1,), np.uint8)
         self.sc = DeviceTensor(ctx, (1,), np.float32)
         self.idesc, self.wq, self.ws, self.bq = {}, {}, {}, {}
+        staged_max = 0
         for l in self.specs:
             d = self.descs[l["name"]]
-            self.idesc[l["name"]] = L.Conv2dInt8Desc(d, 0, 1, 0, pad_mode, 1)
+            self.idesc[l["name"]] = L.Conv2dInt8Desc(d, 0, 1, 0, pad_mode, 1, 1)
+            staged_max = max(staged_max, ctx.lib.rten_hip_conv2d_int8_staged_bytes(C.byref(self.idesc[l["name"]])))
+        self.staged = DeviceTensor(ctx, (max(staged_max, 256),), np.uint8)  # quantized activations in the int8 kernel's layout
         self.fc_tmp = DeviceTensor(ctx, (batch, self.num_classes), np.float32)
         self.fc_idesc = L.GemmInt8Desc(batch, self.num_classes, 2048, 2048, 1, 1, 2048, self.num_classes, 0, 1, 1, 0, 1)
 
@@ -71,10 +74,11 @@ class ResNet50Int8(ResNet50):
         ctx = self.ctx
         name = l["name"]
         src = self._act(l["src"])
-        self._quantize(src, int(np.prod(self.shapes[l["src"]])))
+        # DynamicQuantizeLinear, writing the codes straight into the consumer's staged layout
+        ctx.call("rten_hip_dynamic_quantize_linear_staged", C.byref(self.idesc[name]), src.vp, self.staged.vp, self.xs.vp, self.xz.vp)
         ctx.call("rten_hip_mul_f32", 1, self.xs.vp, self.ws[name].vp, 1, self.sc.vp)  # Mul(x_scale, w_scale)
         flags = (L.CONV_RELU if l["relu"] else 0) | (L.CONV_RESIDUAL if l["res"] else 0)
-        ctx.call("rten_hip_conv2d_int8", C.byref(self.idesc[name]), self.xq.vp, self.wq[name].vp, self.xz.vp, None, self.sc.vp,
+        ctx.call("rten_hip_conv2d_int8", C.byref(self.idesc[name]), self.staged.vp, self.wq[name].vp, self.xz.vp, None, self.sc.vp,
                  self.bq[name].vp, self._act(l["res"]).vp if l["res"] else None, flags, self._act(l["dst"]).vp)
 
     def forward(self):

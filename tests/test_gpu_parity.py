@@ -379,6 +379,33 @@ def test_int8_resnet_block_chain(ctx, i8path):
     bits_equal(got, want)
 
 
+@pytest.mark.parametrize("pm", [L.PAD_ZERO_POINT, L.PAD_RAW0_I8, L.PAD_RAW0_U8])
+def test_dql_staged_conv_bit_exact(ctx, pm):
+    # DynamicQuantizeLinear fused with the consumer's activation staging + prepacked weights == the separate ops
+    rng = ref.XorShiftRng(23)
+    for (N, Cc, H, W, O, k, pad, stride) in ((2, 20, 9, 11, 24, 3, 1, 1), (1, 64, 14, 14, 70, 3, 1, 2), (3, 3, 16, 16, 8, 7, 3, 2), (2, 32, 7, 7, 16, 1, 0, 1)):
+        x = (rng.f32(N * Cc * H * W) - 0.4).reshape(N, Cc, H, W) * 3
+        w = rng.i8(O * Cc * k * k, reduced=True).reshape(O, Cc, k, k)
+        w_scale, bias = np.array([0.003], np.float32), rng.f32(O) - 0.5
+        oh, ow = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        cd = L.Conv2dDesc(N, Cc, H, W, O, k, k, (C.c_int32 * 4)(pad, pad, pad, pad), stride, stride, 1, 1, 1, oh, ow)
+        d = L.Conv2dInt8Desc(cd, 0, 1, 0, pm, 1, 1)
+        staged = DeviceTensor(ctx, (ctx.lib.rten_hip_conv2d_int8_staged_bytes(C.byref(d)),), np.uint8)
+        packed = DeviceTensor(ctx, (ctx.lib.rten_hip_conv2d_int8_packed_bytes(C.byref(d)),), np.uint8)
+        xd, wd, bd, wsd = dev(ctx, x), dev(ctx, w), dev(ctx, bias), dev(ctx, w_scale)
+        xs, xz, sc = DeviceTensor(ctx, (1,), np.float32), DeviceTensor(ctx, (1,), np.uint8), DeviceTensor(ctx, (1,), np.float32)
+        out = DeviceTensor(ctx, (N, O, oh, ow), np.float32)
+        ctx.call("rten_hip_conv2d_int8_prepack", C.byref(d), wd.vp, packed.vp)
+        ctx.call("rten_hip_dynamic_quantize_linear_staged", C.byref(d), xd.vp, staged.vp, xs.vp, xz.vp)
+        ctx.call("rten_hip_mul_f32", 1, xs.vp, wsd.vp, 1, sc.vp)
+        ctx.call("rten_hip_conv2d_int8", C.byref(d), staged.vp, packed.vp, xz.vp, None, sc.vp, bd.vp, None, L.CONV_RELU, out.vp)
+        q, s, z = ref.dynamic_quantize_linear(x)
+        assert xs.numpy()[0] == s and xz.numpy()[0] == z
+        acc = ref.conv2d_int8(q, w, x_zp=int(z), pads=(pad,) * 4, strides=(stride,) * 2, pad_mode=pm)
+        want = ref.relu(ref.cast_scale(acc, np.float32(np.float32(s) * w_scale[0])) + bias[None, :, None, None])
+        bits_equal(out.numpy(), want)
+
+
 # ------------------------------------------------------------------------------------------ row-wise / element-wise / pooling
 @pytest.mark.parametrize("cols", [1, 3, 6, 16, 17, 64, 100, 128, 129, 384, 768, 1000, 1024, 1500, 3000])
 def test_softmax_bit_exact_avx512_order(ctx, cols):
