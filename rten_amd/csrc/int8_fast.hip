@@ -98,35 +98,45 @@ __global__ __launch_bounds__(256) void i8_pack_rows_kernel(const uint8_t *__rest
     if (threadIdx.x == 0) sums[r] = red[0] + red[1] + red[2] + red[3];
 }
 
-// NCHW u8/i8 -> padded NHWC signed bytes [N][Hp][Wp][Cp]; border = pad value of the selected mode, padded channels 0.
-__global__ __launch_bounds__(256) void i8_nhwc_pad_kernel(const uint8_t *__restrict__ x, uint8_t *__restrict__ xp, int C, int H, int W, int Hp,
-                                                         int Wp, int Cp, int pt, int pl, unsigned flip, const uint8_t *__restrict__ x_zp,
-                                                         int x_signed, int pad_mode) {
+// Staging of conv activations: NCHW -> padded NHWC signed bytes [N][Hp][Wp][Cp]; border = pad value of the selected
+// mode, padded channels 0.  A workgroup handles 64 consecutive PADDED pixel positions of one image (so small feature
+// maps still fill the lanes) x 64 channels at a time: coalesced reads along the source's pixel axis, 16-byte writes
+// along the channel axis through an LDS transpose.  `Load` maps a source element to its signed-domain byte.
+template <typename T, typename Load>
+__device__ __forceinline__ void stage_nhwc_tile(const T *__restrict__ x, uint8_t *__restrict__ xp, int C, int H, int W, int Hp, int Wp, int Cp, int pt, int pl,
+                                                unsigned fill, Load load) {
     __shared__ uint8_t tile[64][64 + 16];
     const int t = threadIdx.x;
-    const int x0 = blockIdx.x * 64, yp = blockIdx.y, n = blockIdx.z;
-    const int y = yp - pt;
-    int pad_s = 0;
-    if (pad_mode == RTEN_HIP_PAD_ZERO_POINT) pad_s = zp_signed(x_zp, 0, x_signed);
-    else if (pad_mode == RTEN_HIP_PAD_RAW0_U8) pad_s = -128;
-    const unsigned fill = (unsigned)pad_s & 0xffu;
-    const bool yin = (unsigned)y < (unsigned)H;
+    const int pp0 = blockIdx.x * 64, n = blockIdx.y;
+    const int npix = Hp * Wp;
+    const int pl_ = t & 63, pp = pp0 + pl_;
+    const int yp = pp / Wp, xq = pp - yp * Wp;
+    const int y = yp - pt, xs = xq - pl;
+    const bool in = pp < npix && (unsigned)y < (unsigned)H && (unsigned)xs < (unsigned)W;
+    const long long src0 = ((long long)n * C * H + (in ? y : 0)) * W + (in ? xs : 0); // + c * H * W
     for (int c0 = 0; c0 < Cp; c0 += 64) {
-        const int xl = t & 63, xs = x0 + xl - pl;
-        const bool xin = yin && (unsigned)xs < (unsigned)W;
 #pragma unroll
         for (int pass = 0; pass < 16; pass++) {
             const int cl = pass * 4 + (t >> 6), c = c0 + cl;
             unsigned v = c < C ? fill : 0u;
-            if (xin && c < C) v = ((unsigned)x[(((long long)n * C + c) * H + y) * W + xs] ^ flip) & 0xffu;
-            tile[xl][cl] = (uint8_t)v;
+            if (in && c < C) v = load(x[src0 + (long long)c * H * W]);
+            tile[pl_][cl] = (uint8_t)v;
         }
         __syncthreads();
         const int px = t >> 2, ch = t & 3;
-        if (x0 + px < Wp && c0 + ch * 16 < Cp)
-            *reinterpret_cast<uint4 *>(xp + (((long long)n * Hp + yp) * Wp + x0 + px) * Cp + c0 + ch * 16) = *reinterpret_cast<const uint4 *>(&tile[px][ch * 16]);
+        if (pp0 + px < npix && c0 + ch * 16 < Cp)
+            *reinterpret_cast<uint4 *>(xp + ((long long)n * npix + pp0 + px) * Cp + c0 + ch * 16) = *reinterpret_cast<const uint4 *>(&tile[px][ch * 16]);
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(256) void i8_nhwc_pad_kernel(const uint8_t *__restrict__ x, uint8_t *__restrict__ xp, int C, int H, int W, int Hp,
+                                                         int Wp, int Cp, int pt, int pl, unsigned flip, const uint8_t *__restrict__ x_zp,
+                                                         int x_signed, int pad_mode) {
+    int pad_s = 0;
+    if (pad_mode == RTEN_HIP_PAD_ZERO_POINT) pad_s = zp_signed(x_zp, 0, x_signed);
+    else if (pad_mode == RTEN_HIP_PAD_RAW0_U8) pad_s = -128;
+    stage_nhwc_tile(x, xp, C, H, W, Hp, Wp, Cp, pt, pl, (unsigned)pad_s & 0xffu, [flip](uint8_t b) { return ((unsigned)b ^ flip) & 0xffu; });
 }
 
 // DynamicQuantizeLinear's quantize sweep fused with the staging above: f32 NCHW -> u8 codes (bit-identical to
@@ -134,33 +144,13 @@ __global__ __launch_bounds__(256) void i8_nhwc_pad_kernel(const uint8_t *__restr
 __global__ __launch_bounds__(256) void i8_quantize_stage_kernel(const float *__restrict__ x, const unsigned *__restrict__ ws, uint8_t *__restrict__ xp,
                                                                int C, int H, int W, int Hp, int Wp, int Cp, int pt, int pl, int pad_mode,
                                                                float *scale_out, uint8_t *zp_out) {
-    __shared__ uint8_t tile[64][64 + 16];
     const dql::QParams q = dql::dql_params(dql::ord2f(ws[0]), dql::ord2f(ws[1]));
-    const int t = threadIdx.x;
-    const int x0 = blockIdx.x * 64, yp = blockIdx.y, n = blockIdx.z;
-    if (t == 0 && blockIdx.x == 0 && yp == 0 && n == 0) { *scale_out = q.scale; *zp_out = (uint8_t)q.zp; }
-    const int y = yp - pt;
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) { *scale_out = q.scale; *zp_out = (uint8_t)q.zp; }
     int pad_s = 0; // signed-domain padding value
     if (pad_mode == RTEN_HIP_PAD_ZERO_POINT) pad_s = q.zp - 128;
     else if (pad_mode == RTEN_HIP_PAD_RAW0_U8) pad_s = -128;
-    const unsigned fill = (unsigned)pad_s & 0xffu;
-    const bool yin = (unsigned)y < (unsigned)H;
-    for (int c0 = 0; c0 < Cp; c0 += 64) {
-        const int xl = t & 63, xs = x0 + xl - pl;
-        const bool xin = yin && (unsigned)xs < (unsigned)W;
-#pragma unroll
-        for (int pass = 0; pass < 16; pass++) {
-            const int cl = pass * 4 + (t >> 6), c = c0 + cl;
-            unsigned v = c < C ? fill : 0u;
-            if (xin && c < C) v = dql::quant_u8(x[(((long long)n * C + c) * H + y) * W + xs], q.inv_scale, q.zp) ^ 0x80u;
-            tile[xl][cl] = (uint8_t)v;
-        }
-        __syncthreads();
-        const int px = t >> 2, ch = t & 3;
-        if (x0 + px < Wp && c0 + ch * 16 < Cp)
-            *reinterpret_cast<uint4 *>(xp + (((long long)n * Hp + yp) * Wp + x0 + px) * Cp + c0 + ch * 16) = *reinterpret_cast<const uint4 *>(&tile[px][ch * 16]);
-        __syncthreads();
-    }
+    stage_nhwc_tile(x, xp, C, H, W, Hp, Wp, Cp, pt, pl, (unsigned)pad_s & 0xffu,
+                    [q](float f) { return dql::quant_u8(f, q.inv_scale, q.zp) ^ 0x80u; });
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -537,7 +527,7 @@ RTEN_EXPORT int32_t rten_hip_dynamic_quantize_linear_staged(rten_hip_ctx *ctx, c
     ProfScope ps(ctx, "dynamic_quantize_linear_staged", 0.0, 8.0 * n + (double)g.img);
     unsigned *ws = rten_dql_minmax(ctx, n, x);
     if (!ws) return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "dql: scratch allocation failed");
-    hipLaunchKernelGGL(i8_quantize_stage_kernel, dim3((unsigned)((g.Wp + 63) / 64), (unsigned)g.Hp, (unsigned)d->n), dim3(256), 0, ctx->stream, x, ws,
+    hipLaunchKernelGGL(i8_quantize_stage_kernel, dim3((unsigned)((g.Hp * g.Wp + 63) / 64), (unsigned)d->n), dim3(256), 0, ctx->stream, x, ws,
                        (uint8_t *)staged, d->c, d->h, d->w, g.Hp, g.Wp, g.Cp, d->pads[0], d->pads[1], di->pad_mode, scale, zero_point);
     RTEN_LAUNCH_CHECK(ctx, "i8_quantize_stage_kernel launch");
     return RTEN_HIP_OK;
@@ -566,7 +556,7 @@ int32_t rten_i8_fast_conv(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di
                            cg.taps, cg.Cp, cg.Kp, di->w_signed ? 0u : 0x80u, (uint8_t *)Ap, (int *)rsum);
     }
     if (!di->x_staged)
-        hipLaunchKernelGGL(i8_nhwc_pad_kernel, dim3((unsigned)((cg.Wp + 63) / 64), (unsigned)cg.Hp, (unsigned)d->n), dim3(256), 0, ctx->stream, (const uint8_t *)x,
+        hipLaunchKernelGGL(i8_nhwc_pad_kernel, dim3((unsigned)((cg.Hp * cg.Wp + 63) / 64), (unsigned)d->n), dim3(256), 0, ctx->stream, (const uint8_t *)x,
                            (uint8_t *)(sc + offB), d->c, d->h, d->w, cg.Hp, cg.Wp, cg.Cp, d->pads[0], d->pads[1], di->x_signed ? 0u : 0x80u,
                            (const uint8_t *)x_zp, di->x_signed, di->pad_mode);
     RTEN_LAUNCH_CHECK(ctx, "int8 staging launch");

@@ -25,12 +25,22 @@ __global__ __launch_bounds__(256) void minmax_kernel(int64_t n, const float *__r
     // fminf/fmaxf drop NaNs like the reference's SIMD min(x, acc) / max(x, acc) (min_max.rs:27-30)
     if (vec) {
         const int64_t n4 = n >> 2;
-        for (int64_t i = tid; i < n4; i += stride) {
+        int64_t i = tid;
+        for (; i + 3 * stride < n4; i += 4 * stride) { // four 16-byte loads in flight per lane
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = reinterpret_cast<const f32x4 *>(x)[i + u * stride];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) { mn = fminf(v[u][k], mn); mx = fmaxf(v[u][k], mx); }
+        }
+        for (; i < n4; i += stride) {
             const f32x4 v = reinterpret_cast<const f32x4 *>(x)[i];
 #pragma unroll
             for (int k = 0; k < 4; k++) { mn = fminf(v[k], mn); mx = fmaxf(v[k], mx); }
         }
-        for (int64_t i = (n4 << 2) + tid; i < n; i += stride) { mn = fminf(x[i], mn); mx = fmaxf(x[i], mx); }
+        for (int64_t j = (n4 << 2) + tid; j < n; j += stride) { mn = fminf(x[j], mn); mx = fmaxf(x[j], mx); }
     } else {
         for (int64_t i = tid; i < n; i += stride) { mn = fminf(x[i], mn); mx = fmaxf(x[i], mx); }
     }
@@ -45,11 +55,10 @@ __global__ __launch_bounds__(256) void minmax_kernel(int64_t n, const float *__r
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < 4; w++) { mn = fminf(mn, smn[w]); mx = fmaxf(mx, smx[w]); }
-        atomicMin(&ws[0], f2ord(mn));
+        atomicMin(&ws[0], f2ord(mn)); // one pair of same-address atomics per workgroup: keep the grid small (rten_dql_minmax)
         atomicMax(&ws[1], f2ord(mx));
     }
 }
-
 
 __global__ __launch_bounds__(256) void quantize_kernel(int64_t n, const float *__restrict__ x, const unsigned *ws,
                                                        uint8_t *__restrict__ y, float *scale_out, uint8_t *zp_out,
@@ -85,7 +94,9 @@ unsigned *rten_dql_minmax(rten_hip_ctx *ctx, int64_t n, const float *x) {
     if (!ws) return nullptr;
     const int vec_in = (((uintptr_t)x & 15u) == 0);
     const int64_t items = vec_in ? n / 4 : n;
-    int blocks = (int)((items + 255) / 256 > 2048 ? 2048 : (items + 255) / 256);
+    // about 8 items per lane, at most 2 workgroups per CU: the closing atomics hit two words and serialise in L2
+    const int64_t want = (items + 256 * 8 - 1) / (256 * 8);
+    int blocks = (int)(want > 2 * ctx->num_cus ? 2 * ctx->num_cus : want);
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, ctx->stream, ws);
     hipLaunchKernelGGL(minmax_kernel, dim3(blocks), dim3(256), 0, ctx->stream, n, x, ws, vec_in);
