@@ -114,20 +114,25 @@ __device__ __forceinline__ void stage_nhwc_tile(const T *__restrict__ x, uint8_t
     const int y = yp - pt, xs = xq - pl;
     const bool in = pp < npix && (unsigned)y < (unsigned)H && (unsigned)xs < (unsigned)W;
     const long long src0 = ((long long)n * C * H + (in ? y : 0)) * W + (in ? xs : 0); // + c * H * W
-    for (int c0 = 0; c0 < Cp; c0 += 64) {
+    const int c0 = blockIdx.z * 64; // one 64-channel slab per workgroup: small feature maps still give thousands of workgroups
+    // thread -> (pixel, 4 consecutive channels) per pass: four loads, one packed dword into the LDS tile
 #pragma unroll
-        for (int pass = 0; pass < 16; pass++) {
-            const int cl = pass * 4 + (t >> 6), c = c0 + cl;
+    for (int pass = 0; pass < 4; pass++) {
+        const int cl = pass * 16 + (t >> 6) * 4;
+        unsigned w = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int c = c0 + cl + b;
             unsigned v = c < C ? fill : 0u;
-            if (in && c < C) v = load(x[src0 + (long long)c * H * W]);
-            tile[pl_][cl] = (uint8_t)v;
+            if (in && c < C) v = load(x[src0 + (long long)c * H * W]) & 0xffu;
+            w |= v << (8 * b);
         }
-        __syncthreads();
-        const int px = t >> 2, ch = t & 3;
-        if (pp0 + px < npix && c0 + ch * 16 < Cp)
-            *reinterpret_cast<uint4 *>(xp + ((long long)n * npix + pp0 + px) * Cp + c0 + ch * 16) = *reinterpret_cast<const uint4 *>(&tile[px][ch * 16]);
-        __syncthreads();
+        *reinterpret_cast<unsigned *>(&tile[pl_][cl]) = w;
     }
+    __syncthreads();
+    const int px = t >> 2, ch = t & 3;
+    if (pp0 + px < npix && c0 + ch * 16 < Cp)
+        *reinterpret_cast<uint4 *>(xp + ((long long)n * npix + pp0 + px) * Cp + c0 + ch * 16) = *reinterpret_cast<const uint4 *>(&tile[px][ch * 16]);
 }
 
 __global__ __launch_bounds__(256) void i8_nhwc_pad_kernel(const uint8_t *__restrict__ x, uint8_t *__restrict__ xp, int C, int H, int W, int Hp,
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(256) void i8_quantize_stage_kernel(const float *__r
                                                                int C, int H, int W, int Hp, int Wp, int Cp, int pt, int pl, int pad_mode,
                                                                float *scale_out, uint8_t *zp_out) {
     const dql::QParams q = dql::dql_params(dql::ord2f(ws[0]), dql::ord2f(ws[1]));
-    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) { *scale_out = q.scale; *zp_out = (uint8_t)q.zp; }
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) { *scale_out = q.scale; *zp_out = (uint8_t)q.zp; }
     int pad_s = 0; // signed-domain padding value
     if (pad_mode == RTEN_HIP_PAD_ZERO_POINT) pad_s = q.zp - 128;
     else if (pad_mode == RTEN_HIP_PAD_RAW0_U8) pad_s = -128;
@@ -527,7 +532,7 @@ RTEN_EXPORT int32_t rten_hip_dynamic_quantize_linear_staged(rten_hip_ctx *ctx, c
     ProfScope ps(ctx, "dynamic_quantize_linear_staged", 0.0, 8.0 * n + (double)g.img);
     unsigned *ws = rten_dql_minmax(ctx, n, x);
     if (!ws) return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "dql: scratch allocation failed");
-    hipLaunchKernelGGL(i8_quantize_stage_kernel, dim3((unsigned)((g.Hp * g.Wp + 63) / 64), (unsigned)d->n), dim3(256), 0, ctx->stream, x, ws,
+    hipLaunchKernelGGL(i8_quantize_stage_kernel, dim3((unsigned)((g.Hp * g.Wp + 63) / 64), (unsigned)d->n, (unsigned)((g.Cp + 63) / 64)), dim3(256), 0, ctx->stream, x, ws,
                        (uint8_t *)staged, d->c, d->h, d->w, g.Hp, g.Wp, g.Cp, d->pads[0], d->pads[1], di->pad_mode, scale, zero_point);
     RTEN_LAUNCH_CHECK(ctx, "i8_quantize_stage_kernel launch");
     return RTEN_HIP_OK;
@@ -556,7 +561,7 @@ int32_t rten_i8_fast_conv(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di
                            cg.taps, cg.Cp, cg.Kp, di->w_signed ? 0u : 0x80u, (uint8_t *)Ap, (int *)rsum);
     }
     if (!di->x_staged)
-        hipLaunchKernelGGL(i8_nhwc_pad_kernel, dim3((unsigned)((cg.Hp * cg.Wp + 63) / 64), (unsigned)d->n), dim3(256), 0, ctx->stream, (const uint8_t *)x,
+        hipLaunchKernelGGL(i8_nhwc_pad_kernel, dim3((unsigned)((cg.Hp * cg.Wp + 63) / 64), (unsigned)d->n, (unsigned)((cg.Cp + 63) / 64)), dim3(256), 0, ctx->stream, (const uint8_t *)x,
                            (uint8_t *)(sc + offB), d->c, d->h, d->w, cg.Hp, cg.Wp, cg.Cp, d->pads[0], d->pads[1], di->x_signed ? 0u : 0x80u,
                            (const uint8_t *)x_zp, di->x_signed, di->pad_mode);
     RTEN_LAUNCH_CHECK(ctx, "int8 staging launch");
