@@ -202,10 +202,12 @@ int32_t rten_hip_conv2d_int8_prepack(rten_hip_ctx *ctx, const rten_hip_conv2d_in
  * src/ops/conv.rs:421-476): same scale / zero point / u8 codes bit for bit, but the codes are written once, directly
  * in the layout the int8 kernel gathers from (zero-point-padded NHWC, signed domain) instead of as an NCHW u8 tensor.
  * `desc` is the consumer's descriptor (x_signed must be 0: DynamicQuantizeLinear produces u8); staged_bytes returns 0
- * when the staged kernel does not cover the geometry. */
+ * when the staged kernel does not cover the geometry.  `mul_by` / `product` fold the Mul(x_scale, w_scale) node that
+ * follows in ort-quantized graphs (one f32 multiply, same bits). */
 size_t rten_hip_conv2d_int8_staged_bytes(const rten_hip_conv2d_int8_desc *desc);
 int32_t rten_hip_dynamic_quantize_linear_staged(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *desc, const float *x,
-                                                void *staged, float *scale, uint8_t *zero_point);
+                                                void *staged, float *scale, uint8_t *zero_point,
+                                                const float *mul_by /* optional */, float *product /* = scale * mul_by[0] */);
 int32_t rten_hip_conv2d_int8(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *desc, const void *x, const void *w,
                              const void *x_zp, const void *w_zp, const float *scale, const float *bias,
                              const float *residual, uint32_t flags, void *y);

@@ -146,11 +146,17 @@ __global__ __launch_bounds__(256) void i8_nhwc_pad_kernel(const uint8_t *__restr
 
 // DynamicQuantizeLinear's quantize sweep fused with the staging above: f32 NCHW -> u8 codes (bit-identical to
 // quantize.hip: same scale / zero-point algebra, same to_int_round + saturate) written as padded NHWC signed bytes.
-__global__ __launch_bounds__(256) void i8_quantize_stage_kernel(const float *__restrict__ x, const unsigned *__restrict__ ws, uint8_t *__restrict__ xp,
+__global__ __launch_bounds__(256) void i8_quantize_stage_kernel(const float *__restrict__ x, const float *__restrict__ ws, int nparts, uint8_t *__restrict__ xp,
                                                                int C, int H, int W, int Hp, int Wp, int Cp, int pt, int pl, int pad_mode,
-                                                               float *scale_out, uint8_t *zp_out) {
-    const dql::QParams q = dql::dql_params(dql::ord2f(ws[0]), dql::ord2f(ws[1]));
-    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) { *scale_out = q.scale; *zp_out = (uint8_t)q.zp; }
+                                                               float *scale_out, uint8_t *zp_out, const float *mul_by, float *product_out) {
+    float x_min, x_max;
+    dql::block_minmax(ws, nparts, x_min, x_max);
+    const dql::QParams q = dql::dql_params(x_min, x_max);
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+        *scale_out = q.scale;
+        *zp_out = (uint8_t)q.zp;
+        if (mul_by) *product_out = q.scale * mul_by[0]; // the Mul(x_scale, w_scale) node that follows in ort-quantized graphs
+    }
     int pad_s = 0; // signed-domain padding value
     if (pad_mode == RTEN_HIP_PAD_ZERO_POINT) pad_s = q.zp - 128;
     else if (pad_mode == RTEN_HIP_PAD_RAW0_U8) pad_s = -128;
@@ -522,18 +528,20 @@ RTEN_EXPORT size_t rten_hip_conv2d_int8_staged_bytes(const rten_hip_conv2d_int8_
 }
 
 RTEN_EXPORT int32_t rten_hip_dynamic_quantize_linear_staged(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di, const float *x, void *staged,
-                                                            float *scale, uint8_t *zero_point) {
+                                                            float *scale, uint8_t *zero_point, const float *mul_by, float *product) {
     RTEN_CHECK_CTX(ctx);
-    if (!di || !x || !staged || !scale || !zero_point) return RTEN_HIP_ERR_INVALID_VALUE;
+    if (!di || !x || !staged || !scale || !zero_point || (mul_by && !product)) return RTEN_HIP_ERR_INVALID_VALUE;
     const ConvGeom g = conv_geom(di);
     if (!g.ok || di->x_signed) return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "quantize_staged: geometry not covered by the staged kernel (staged_bytes == 0)");
     const rten_hip_conv2d_desc *d = &di->conv;
     const int64_t n = (int64_t)d->n * d->c * d->h * d->w;
     ProfScope ps(ctx, "dynamic_quantize_linear_staged", 0.0, 8.0 * n + (double)g.img);
-    unsigned *ws = rten_dql_minmax(ctx, n, x);
+    int nparts = 0;
+    const float *ws = rten_dql_minmax(ctx, n, x, &nparts);
     if (!ws) return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "dql: scratch allocation failed");
-    hipLaunchKernelGGL(i8_quantize_stage_kernel, dim3((unsigned)((g.Hp * g.Wp + 63) / 64), (unsigned)d->n, (unsigned)((g.Cp + 63) / 64)), dim3(256), 0, ctx->stream, x, ws,
-                       (uint8_t *)staged, d->c, d->h, d->w, g.Hp, g.Wp, g.Cp, d->pads[0], d->pads[1], di->pad_mode, scale, zero_point);
+    hipLaunchKernelGGL(i8_quantize_stage_kernel, dim3((unsigned)((g.Hp * g.Wp + 63) / 64), (unsigned)d->n, (unsigned)((g.Cp + 63) / 64)), dim3(256), 0, ctx->stream,
+                       x, ws, nparts, (uint8_t *)staged, d->c, d->h, d->w, g.Hp, g.Wp, g.Cp, d->pads[0], d->pads[1], di->pad_mode, scale, zero_point, mul_by,
+                       product);
     RTEN_LAUNCH_CHECK(ctx, "i8_quantize_stage_kernel launch");
     return RTEN_HIP_OK;
 }

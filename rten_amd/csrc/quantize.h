@@ -50,8 +50,24 @@ __device__ __forceinline__ unsigned quant_u8(float x, float inv_scale, int zp) {
 }
 
 
+// Second stage of the min/max reduction: every workgroup of the consuming kernel folds the per-workgroup partials
+// the sweep left in `ws` (pairs {min, max}; min/max are order independent, so this equals the one-pass result).
+// Must be called by all 256 threads of the workgroup.
+__device__ __forceinline__ void block_minmax(const float *__restrict__ ws, int nparts, float &mn, float &mx) {
+    __shared__ float s_mn[4], s_mx[4];
+    float a = __builtin_inff(), b = -__builtin_inff();
+    for (int i = threadIdx.x; i < nparts; i += 256) { a = fminf(ws[2 * i], a); b = fmaxf(ws[2 * i + 1], b); }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { a = fminf(a, __shfl_xor(a, o, 64)); b = fmaxf(b, __shfl_xor(b, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6] = a; s_mx[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    mn = fminf(fminf(s_mn[0], s_mn[1]), fminf(s_mn[2], s_mn[3]));
+    mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
+}
+
 } // namespace dql
 
-// Enqueues the min/max sweep of x[0..n) into the first two words of the context scratch (ordered-uint encoding);
-// returns the device pointer to the two words, or nullptr on allocation failure.  (quantize.hip)
-unsigned *rten_dql_minmax(rten_hip_ctx *ctx, int64_t n, const float *x);
+// Enqueues the min/max sweep of x[0..n): one {min, max} pair per workgroup at the start of the context scratch (no
+// atomics, nothing to initialise); returns the device pointer and the number of pairs, or nullptr on allocation
+// failure.  The consumer folds the pairs with dql::block_minmax.  (quantize.hip)
+const float *rten_dql_minmax(rten_hip_ctx *ctx, int64_t n, const float *x, int *nparts);

@@ -13,12 +13,7 @@ using namespace dql;
 
 namespace {
 
-__global__ void minmax_init_kernel(unsigned *ws) {
-    ws[0] = f2ord(__builtin_inff());  // running min
-    ws[1] = f2ord(-__builtin_inff()); // running max
-}
-
-__global__ __launch_bounds__(256) void minmax_kernel(int64_t n, const float *__restrict__ x, unsigned *ws, int vec) {
+__global__ __launch_bounds__(256) void minmax_kernel(int64_t n, const float *__restrict__ x, float *ws, int vec) {
     float mn = __builtin_inff(), mx = -__builtin_inff();
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -55,15 +50,17 @@ __global__ __launch_bounds__(256) void minmax_kernel(int64_t n, const float *__r
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < 4; w++) { mn = fminf(mn, smn[w]); mx = fmaxf(mx, smx[w]); }
-        atomicMin(&ws[0], f2ord(mn)); // one pair of same-address atomics per workgroup: keep the grid small (rten_dql_minmax)
-        atomicMax(&ws[1], f2ord(mx));
+        ws[2 * blockIdx.x] = mn; // per-workgroup partial; the consumer folds them (dql::block_minmax)
+        ws[2 * blockIdx.x + 1] = mx;
     }
 }
 
-__global__ __launch_bounds__(256) void quantize_kernel(int64_t n, const float *__restrict__ x, const unsigned *ws,
+__global__ __launch_bounds__(256) void quantize_kernel(int64_t n, const float *__restrict__ x, const float *ws, int nparts,
                                                        uint8_t *__restrict__ y, float *scale_out, uint8_t *zp_out,
                                                        int vec) {
-    const QParams q = dql_params(ord2f(ws[0]), ord2f(ws[1]));
+    float x_min, x_max;
+    block_minmax(ws, nparts, x_min, x_max);
+    const QParams q = dql_params(x_min, x_max);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid == 0) { *scale_out = q.scale; *zp_out = (uint8_t)q.zp; }
@@ -89,17 +86,18 @@ __global__ void dql_empty_kernel(float *scale_out, uint8_t *zp_out) {
 
 } // namespace
 
-unsigned *rten_dql_minmax(rten_hip_ctx *ctx, int64_t n, const float *x) {
-    unsigned *ws = (unsigned *)rten_scratch(ctx, 256); // first 256 B of the scratch: DQL min/max words
+constexpr int kMaxMinMaxParts = 480; // 480 pairs = 3840 B: inside the 4 KiB scratch header
+
+const float *rten_dql_minmax(rten_hip_ctx *ctx, int64_t n, const float *x, int *nparts) {
+    float *ws = (float *)rten_scratch(ctx, 4096);
     if (!ws) return nullptr;
     const int vec_in = (((uintptr_t)x & 15u) == 0);
     const int64_t items = vec_in ? n / 4 : n;
-    // about 8 items per lane, at most 2 workgroups per CU: the closing atomics hit two words and serialise in L2
-    const int64_t want = (items + 256 * 8 - 1) / (256 * 8);
-    int blocks = (int)(want > 2 * ctx->num_cus ? 2 * ctx->num_cus : want);
+    const int64_t want = (items + 256 * 8 - 1) / (256 * 8); // about 8 items per lane
+    int blocks = (int)(want > kMaxMinMaxParts ? kMaxMinMaxParts : want);
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, ctx->stream, ws);
     hipLaunchKernelGGL(minmax_kernel, dim3(blocks), dim3(256), 0, ctx->stream, n, x, ws, vec_in);
+    *nparts = blocks;
     return ws;
 }
 
@@ -119,9 +117,10 @@ RTEN_EXPORT int32_t rten_hip_dynamic_quantize_linear(rten_hip_ctx *ctx, int64_t 
     int blocks = (int)((items + 255) / 256 > 2048 ? 2048 : (items + 255) / 256);
     if (blocks < 1) blocks = 1;
     ProfScope ps(ctx, "dynamic_quantize_linear", 0.0, 9.0 * n);
-    unsigned *ws = rten_dql_minmax(ctx, n, x);
+    int nparts = 0;
+    const float *ws = rten_dql_minmax(ctx, n, x, &nparts);
     if (!ws) return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "dql: scratch allocation failed");
-    hipLaunchKernelGGL(quantize_kernel, dim3(blocks), dim3(256), 0, ctx->stream, n, x, ws, y, scale, zero_point, vec_q);
+    hipLaunchKernelGGL(quantize_kernel, dim3(blocks), dim3(256), 0, ctx->stream, n, x, ws, nparts, y, scale, zero_point, vec_q);
     RTEN_LAUNCH_CHECK(ctx, "dynamic_quantize_linear");
     return RTEN_HIP_OK;
 }

@@ -75,8 +75,9 @@ class ResNet50Int8(ResNet50):
         name = l["name"]
         src = self._act(l["src"])
         # DynamicQuantizeLinear, writing the codes straight into the consumer's staged layout
-        ctx.call("rten_hip_dynamic_quantize_linear_staged", C.byref(self.idesc[name]), src.vp, self.staged.vp, self.xs.vp, self.xz.vp)
-        ctx.call("rten_hip_mul_f32", 1, self.xs.vp, self.ws[name].vp, 1, self.sc.vp)  # Mul(x_scale, w_scale)
+        # ... and the Mul(x_scale, w_scale) that feeds the conv's cast_scale
+        ctx.call("rten_hip_dynamic_quantize_linear_staged", C.byref(self.idesc[name]), src.vp, self.staged.vp, self.xs.vp, self.xz.vp,
+                 self.ws[name].vp, self.sc.vp)
         flags = (L.CONV_RELU if l["relu"] else 0) | (L.CONV_RESIDUAL if l["res"] else 0)
         ctx.call("rten_hip_conv2d_int8", C.byref(self.idesc[name]), self.staged.vp, self.wq[name].vp, self.xz.vp, None, self.sc.vp,
                  self.bq[name].vp, self._act(l["res"]).vp if l["res"] else None, flags, self._act(l["dst"]).vp)

@@ -396,8 +396,11 @@ def test_dql_staged_conv_bit_exact(ctx, pm):
         xs, xz, sc = DeviceTensor(ctx, (1,), np.float32), DeviceTensor(ctx, (1,), np.uint8), DeviceTensor(ctx, (1,), np.float32)
         out = DeviceTensor(ctx, (N, O, oh, ow), np.float32)
         ctx.call("rten_hip_conv2d_int8_prepack", C.byref(d), wd.vp, packed.vp)
-        ctx.call("rten_hip_dynamic_quantize_linear_staged", C.byref(d), xd.vp, staged.vp, xs.vp, xz.vp)
-        ctx.call("rten_hip_mul_f32", 1, xs.vp, wsd.vp, 1, sc.vp)
+        if k == 1:  # the following Mul(x_scale, w_scale) either folded into the staging kernel or as its own op
+            ctx.call("rten_hip_dynamic_quantize_linear_staged", C.byref(d), xd.vp, staged.vp, xs.vp, xz.vp, None, None)
+            ctx.call("rten_hip_mul_f32", 1, xs.vp, wsd.vp, 1, sc.vp)
+        else:
+            ctx.call("rten_hip_dynamic_quantize_linear_staged", C.byref(d), xd.vp, staged.vp, xs.vp, xz.vp, wsd.vp, sc.vp)
         ctx.call("rten_hip_conv2d_int8", C.byref(d), staged.vp, packed.vp, xz.vp, None, sc.vp, bd.vp, None, L.CONV_RELU, out.vp)
         q, s, z = ref.dynamic_quantize_linear(x)
         assert xs.numpy()[0] == s and xz.numpy()[0] == z
