@@ -1,0 +1,645 @@
+// rten_hip_ops.hpp -- C++ host side above the C ABI (include/rten_hip.h): the reference's operator interface for the hot
+// path, mirrored in C++ because the reference is compiled code and its own toolchain (Rust) is not in this image.
+//
+// What is mirrored (same names, attribute meaning, input order, validation order and OpError messages, which the
+// reference's tests assert verbatim -- src/ops/conv.rs:1182-1268, src/ops/matmul.rs:1284-1333):
+//   * `Operator` / `OpRunContext` / `OpRegistry`   src/operator.rs:486-613, src/op_registry.rs:25-72
+//   * `OpError`                                    src/operator.rs:116-144
+//   * Conv, ConvInteger, ConvIntegerToFloat        src/ops/conv.rs:367-403, 478-587
+//   * MatMul, FusedMatMul, Gemm, MatMulInteger(ToFloat)   src/ops/matmul.rs:106-156, 387-510, 582-810
+//   * Softmax, LayerNormalization                  src/ops/norm.rs:456-529, 825-840
+//   * Gelu, Erf, Relu, Add, Mul                    src/ops/unary_elementwise.rs, binary_elementwise.rs:476-495
+//   * MaxPool, AveragePool, GlobalAveragePool      src/ops/pooling.rs:174-521
+//   * DynamicQuantizeLinear                        src/ops/quantize.rs:352-436
+// Validation runs on the host before any launch; arithmetic is done by librten_hip.so on device-resident tensors.  There
+// is no CPU fallback: without a gfx950 device `Context` throws.  Header only; C++17.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <numeric>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "rten_hip.h"
+
+namespace rten_hip {
+
+// ---- OpError (src/operator.rs:116-144)
+struct OpError : std::runtime_error {
+    enum Kind { InvalidValue, IncompatibleInputShapes, UnsupportedValue, UnsupportedType, MissingInputs, InputCastFailed, BackendUnavailable, Hip };
+    Kind kind;
+    std::string msg;
+    OpError(Kind k, std::string m) : std::runtime_error(kind_name(k) + (m.empty() ? "" : "(\"" + m + "\")")), kind(k), msg(std::move(m)) {}
+    static std::string kind_name(Kind k) {
+        static const char *n[] = {"InvalidValue", "IncompatibleInputShapes", "UnsupportedValue", "UnsupportedType", "MissingInputs", "InputCastFailed",
+                                  "BackendUnavailable", "Hip"};
+        return n[k];
+    }
+};
+
+// ---- Context: RAII over rten_hip_ctx.  One per host thread (Graph::run_plan runs operators sequentially).
+class Context {
+  public:
+    explicit Context(int device = 0, void *stream = nullptr) {
+        const int32_t rc = rten_hip_init(device, stream, &h_);
+        if (rc == RTEN_HIP_ERR_NO_DEVICE) throw OpError(OpError::BackendUnavailable, "no usable gfx950 (MI355X) device: the HIP backend has no CPU fallback");
+        if (rc != RTEN_HIP_OK) throw OpError(OpError::Hip, "rten_hip_init failed");
+    }
+    ~Context() { if (h_) rten_hip_destroy(h_); }
+    Context(const Context &) = delete;
+    Context &operator=(const Context &) = delete;
+    rten_hip_ctx *raw() const { return h_; }
+    void sync() { check(rten_hip_sync(h_)); }
+    // maps ABI status codes onto OpError variants (include/rten_hip.h, "status codes")
+    void check(int32_t rc) const {
+        if (rc == RTEN_HIP_OK) return;
+        const std::string m = rten_hip_last_error(h_);
+        switch (rc) {
+        case RTEN_HIP_ERR_INVALID_VALUE: throw OpError(OpError::InvalidValue, m);
+        case RTEN_HIP_ERR_INCOMPATIBLE_SHAPES: throw OpError(OpError::IncompatibleInputShapes, m);
+        case RTEN_HIP_ERR_UNSUPPORTED: throw OpError(OpError::UnsupportedValue, m);
+        default: throw OpError(OpError::Hip, m);
+        }
+    }
+
+  private:
+    rten_hip_ctx *h_ = nullptr;
+};
+
+// ---- device tensor (the backend's `Value`: contiguous, row-major, device resident)
+enum class DType { F32, I32, U8, I8 };
+inline size_t dtype_size(DType t) { return (t == DType::F32 || t == DType::I32) ? 4 : 1; }
+
+class Tensor {
+  public:
+    Tensor() = default;
+    Tensor(Context &ctx, std::vector<int64_t> shape, DType dt) : ctx_(&ctx), shape_(std::move(shape)), dtype_(dt) {
+        const size_t n = bytes();
+        ctx.check(rten_hip_malloc(ctx.raw(), n ? n : 4, &ptr_));
+    }
+    template <typename T>
+    static Tensor from_host(Context &ctx, std::vector<int64_t> shape, const T *data) {
+        Tensor t(ctx, std::move(shape), dtype_of<T>());
+        if (t.bytes()) ctx.check(rten_hip_memcpy_h2d(ctx.raw(), t.ptr_, data, t.bytes()));
+        return t;
+    }
+    ~Tensor() { release(); }
+    Tensor(Tensor &&o) noexcept { *this = std::move(o); }
+    Tensor &operator=(Tensor &&o) noexcept {
+        if (this != &o) { release(); ctx_ = o.ctx_; ptr_ = o.ptr_; shape_ = std::move(o.shape_); dtype_ = o.dtype_; o.ptr_ = nullptr; }
+        return *this;
+    }
+    Tensor(const Tensor &) = delete;
+    Tensor &operator=(const Tensor &) = delete;
+
+    const std::vector<int64_t> &shape() const { return shape_; }
+    int64_t size(int i) const { return shape_[(size_t)i]; }
+    int ndim() const { return (int)shape_.size(); }
+    int64_t len() const { return std::accumulate(shape_.begin(), shape_.end(), (int64_t)1, std::multiplies<int64_t>()); }
+    size_t bytes() const { return (size_t)len() * dtype_size(dtype_); }
+    DType dtype() const { return dtype_; }
+    void *ptr() const { return ptr_; }
+    template <typename T> std::vector<T> to_host() const {
+        std::vector<T> out((size_t)len());
+        if (bytes()) ctx_->check(rten_hip_memcpy_d2h(ctx_->raw(), out.data(), ptr_, bytes())); // synchronises
+        return out;
+    }
+    void reshape(std::vector<int64_t> s) { shape_ = std::move(s); }
+
+    template <typename T> static DType dtype_of() {
+        if (std::is_same<T, float>::value) return DType::F32;
+        if (std::is_same<T, int32_t>::value) return DType::I32;
+        if (std::is_same<T, uint8_t>::value) return DType::U8;
+        return DType::I8;
+    }
+
+  private:
+    void release() { if (ptr_ && ctx_) rten_hip_free(ctx_->raw(), ptr_); ptr_ = nullptr; }
+    Context *ctx_ = nullptr;
+    void *ptr_ = nullptr;
+    std::vector<int64_t> shape_;
+    DType dtype_ = DType::F32;
+};
+
+// ---- Operator interface (src/operator.rs:486-613).  Optional inputs are null pointers (InputList::get).
+using InputList = std::vector<const Tensor *>;
+using OutputList = std::vector<Tensor>;
+
+inline const Tensor &require(const InputList &in, size_t i) {
+    if (i >= in.size() || !in[i]) throw OpError(OpError::MissingInputs, "");
+    return *in[i];
+}
+inline const Tensor *get(const InputList &in, size_t i) { return i < in.size() ? in[i] : nullptr; }
+inline const Tensor &want(const Tensor &t, DType dt, const char *what) {
+    if (t.dtype() != dt) throw OpError(OpError::InputCastFailed, std::string("expected ") + what + " tensor");
+    return t;
+}
+inline void *vp(const Tensor *t) { return t ? t->ptr() : nullptr; }
+
+class Operator {
+  public:
+    virtual ~Operator() = default;
+    virtual const char *name() const = 0;
+    virtual int max_inputs() const { return -1; } // < 0: unbounded (Operator::max_inputs -> None)
+    virtual OutputList run(Context &ctx, const InputList &inputs) const = 0;
+};
+
+// Padding::Same / Padding::Fixed (src/ops/mod.rs)
+struct Padding {
+    bool same = false;
+    std::vector<int> fixed{0, 0, 0, 0};
+    static Padding Same() { Padding p; p.same = true; return p; }
+    static Padding Fixed(std::vector<int> v) { Padding p; p.fixed = std::move(v); return p; }
+};
+
+struct OutputSize { int oh, ow; int pads[4]; };
+// calc_output_size_and_padding (src/ops/pooling.rs:139-159): same error strings through the ABI
+inline OutputSize calc_output_size_and_padding(int h, int w, int kh, int kw, const std::vector<int> &strides, const Padding &padding,
+                                               const std::vector<int> &dilations = {1, 1}, bool ceil_mode = false) {
+    if (!padding.same && padding.fixed.size() != 4) throw OpError(OpError::InvalidValue, "Expected 4 padding values");
+    int32_t pads[4] = {0, 0, 0, 0}, out[2], opads[4];
+    if (!padding.same) for (int i = 0; i < 4; i++) pads[i] = padding.fixed[(size_t)i];
+    const char *msg = nullptr;
+    const int32_t rc = rten_hip_calc_output_size_and_padding(h, w, kh, kw, strides[0], strides[1], padding.same ? 1 : 0, pads, dilations[0], dilations[1],
+                                                             ceil_mode ? 1 : 0, out, opads, &msg);
+    if (rc) throw OpError(OpError::InvalidValue, msg ? msg : "");
+    return OutputSize{out[0], out[1], {opads[0], opads[1], opads[2], opads[3]}};
+}
+
+// ------------------------------------------------------------------------------------------------ Conv
+struct Conv : Operator {
+    int groups = 1;
+    std::vector<int> dilations{1, 1};
+    Padding padding;
+    std::vector<int> strides{1, 1};
+    bool fuse_relu = false; // backend fusion of the following Relu; a 4th input is the residual Add operand
+
+    const char *name() const override { return "Conv"; }
+    int max_inputs() const override { return 4; }
+
+    // shape checks in the reference's order with its messages (src/ops/conv.rs:136-214)
+    rten_hip_conv2d_desc geometry(const std::vector<int64_t> &xs, const std::vector<int64_t> &ws) const {
+        if (xs.size() == 3) {
+            if (ws.size() != 3) throw OpError(OpError::InvalidValue, "kernel must have 3 dims (OCW)");
+            throw OpError(OpError::UnsupportedValue, "1D convolution: expand to 2D on the host before calling the backend");
+        }
+        if (xs.size() != 4) throw OpError(OpError::InvalidValue, "input must have 4 dims (NCHW)");
+        if (ws.size() != 4) throw OpError(OpError::InvalidValue, "kernel must have 4 dims (OCHW)");
+        if (strides.size() != 2) throw OpError(OpError::InvalidValue, "expected 2 stride values");
+        if (dilations.size() != 2) throw OpError(OpError::InvalidValue, "expected 2 dilation values");
+        const int n = (int)xs[0], c = (int)xs[1], h = (int)xs[2], w = (int)xs[3];
+        const int o = (int)ws[0], kc = (int)ws[1], kh = (int)ws[2], kw = (int)ws[3];
+        const OutputSize os = calc_output_size_and_padding(h, w, kh, kw, strides, padding, dilations);
+        if (groups == 0) throw OpError(OpError::InvalidValue, "Group count must be > 0");
+        if (c % groups != 0) throw OpError(OpError::InvalidValue, "Input channel count not divisible by groups");
+        if (c / groups != kc) throw OpError(OpError::IncompatibleInputShapes, "Input channels (per group) does not match kernel input channels");
+        if (o % groups != 0) throw OpError(OpError::InvalidValue, "Output channel count not divisible by groups");
+        rten_hip_conv2d_desc d{};
+        d.n = n; d.c = c; d.h = h; d.w = w; d.o = o; d.kh = kh; d.kw = kw;
+        for (int i = 0; i < 4; i++) d.pads[i] = os.pads[i];
+        d.stride_h = strides[0]; d.stride_w = strides[1]; d.dil_h = dilations[0]; d.dil_w = dilations[1];
+        d.groups = groups; d.out_h = os.oh; d.out_w = os.ow;
+        return d;
+    }
+
+    // PrepackedInput analogue (src/operator.rs:25-66): stage the constant weight once
+    Tensor prepack(Context &ctx, const Tensor &weight) const {
+        rten_hip_conv2d_desc d{};
+        d.n = 1; d.c = (int)weight.size(1) * groups; d.h = d.w = 1; d.o = (int)weight.size(0); d.kh = (int)weight.size(2); d.kw = (int)weight.size(3);
+        d.stride_h = d.stride_w = d.dil_h = d.dil_w = 1; d.groups = groups; d.out_h = d.out_w = 1;
+        Tensor packed(ctx, {(int64_t)(rten_hip_conv2d_f32_packed_bytes(&d) / 4)}, DType::F32);
+        ctx.check(rten_hip_conv2d_f32_prepack(ctx.raw(), &d, (const float *)weight.ptr(), (float *)packed.ptr()));
+        return packed;
+    }
+
+    OutputList run(Context &ctx, const InputList &in) const override { return run_packed(ctx, in, nullptr); }
+    OutputList run_packed(Context &ctx, const InputList &in, const Tensor *packed_weight) const {
+        const Tensor &x = want(require(in, 0), DType::F32, "float32");
+        const Tensor &w = want(require(in, 1), DType::F32, "float32");
+        const Tensor *bias = get(in, 2), *residual = get(in, 3);
+        const rten_hip_conv2d_desc d = geometry(x.shape(), w.shape());
+        if (bias && bias->size(0) != d.o) throw OpError(OpError::IncompatibleInputShapes, "bias.size(0) != out_channels");
+        Tensor y(ctx, {d.n, d.o, d.out_h, d.out_w}, DType::F32);
+        const uint32_t flags = (fuse_relu ? RTEN_HIP_CONV_RELU : 0u) | (residual ? RTEN_HIP_CONV_RESIDUAL : 0u);
+        ctx.check(rten_hip_conv2d_f32(ctx.raw(), &d, (const float *)x.ptr(), (const float *)(packed_weight ? packed_weight->ptr() : w.ptr()),
+                                      packed_weight ? 1 : 0, (const float *)vp(bias), (const float *)vp(residual), flags, (float *)y.ptr()));
+        OutputList out;
+        out.push_back(std::move(y));
+        return out;
+    }
+};
+
+// zero_point_to_vec (src/ops/matmul.rs:513-531)
+inline int zero_point_len(const Tensor *zp, int64_t expected) {
+    if (!zp) return 0;
+    if (zp->ndim() == 0 || zp->len() == 1) return 1;
+    if (zp->ndim() == 1 && zp->len() == expected) return (int)expected;
+    throw OpError(OpError::InvalidValue, "Zero point has incorrect size");
+}
+
+struct ConvInteger : Operator {
+    Conv conv; // geometry attributes (groups, dilations, padding, strides)
+    int pad_mode = RTEN_HIP_PAD_RAW0_I8; // value of padded taps; x86 reference default
+    const char *name() const override { return "ConvInteger"; }
+    int max_inputs() const override { return 4; }
+
+    rten_hip_conv2d_int8_desc desc(const Tensor &x, const Tensor &w, const Tensor *x_zp, const Tensor *w_zp) const {
+        auto is8 = [](DType t) { return t == DType::U8 || t == DType::I8; };
+        if (!is8(x.dtype()) || !is8(w.dtype())) throw OpError(OpError::UnsupportedType, "");
+        if (x_zp && x_zp->len() != 1) throw OpError(OpError::InvalidValue, "input zero point must be a scalar");
+        const int wz = zero_point_len(w_zp, w.ndim() ? w.size(0) : 0);
+        rten_hip_conv2d_int8_desc di{};
+        di.conv = conv.geometry(x.shape(), w.shape());
+        di.x_signed = x.dtype() == DType::I8; di.w_signed = w.dtype() == DType::I8; di.w_zp_len = wz; di.pad_mode = pad_mode;
+        return di;
+    }
+    OutputList run(Context &ctx, const InputList &in) const override { return run_fused(ctx, in, nullptr, nullptr, nullptr, false); }
+    // scale != null: ConvIntegerToFloat epilogue (cast_scale, then the following Add(bias) / Add(residual) / Relu)
+    OutputList run_fused(Context &ctx, const InputList &in, const Tensor *scale, const Tensor *bias, const Tensor *residual, bool relu) const {
+        const Tensor &x = require(in, 0), &w = require(in, 1);
+        const Tensor *x_zp = get(in, 2), *w_zp = get(in, 3);
+        const rten_hip_conv2d_int8_desc di = desc(x, w, x_zp, w_zp);
+        Tensor y(ctx, {di.conv.n, di.conv.o, di.conv.out_h, di.conv.out_w}, scale ? DType::F32 : DType::I32);
+        const uint32_t flags = (relu ? RTEN_HIP_CONV_RELU : 0u) | (residual ? RTEN_HIP_CONV_RESIDUAL : 0u);
+        ctx.check(rten_hip_conv2d_int8(ctx.raw(), &di, x.ptr(), w.ptr(), vp(x_zp), vp(w_zp), (const float *)vp(scale), (const float *)vp(bias),
+                                       (const float *)vp(residual), flags, y.ptr()));
+        OutputList out;
+        out.push_back(std::move(y));
+        return out;
+    }
+};
+
+struct ConvIntegerToFloat : Operator { // src/ops/conv.rs:552-587: inputs X, W, x_zp, w_zp, scale (+ bias, residual: backend fusion)
+    ConvInteger conv;
+    bool fuse_relu = false;
+    const char *name() const override { return "ConvIntegerToFloat"; }
+    int max_inputs() const override { return 7; }
+    OutputList run(Context &ctx, const InputList &in) const override {
+        const Tensor &scale = want(require(in, 4), DType::F32, "float32");
+        if (scale.len() != 1) throw OpError(OpError::InvalidValue, "scale should be a scalar");
+        return conv.run_fused(ctx, InputList(in.begin(), in.begin() + 4), &scale, get(in, 5), get(in, 6), fuse_relu);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ MatMul family
+namespace detail {
+inline int64_t prod(const std::vector<int64_t> &v, size_t b, size_t e) {
+    int64_t p = 1;
+    for (size_t i = b; i < e; i++) p *= v[i];
+    return p;
+}
+// numpy.matmul shape rules (src/ops/matmul.rs:208-385); contiguous inputs; b_transposed folds transB into strides
+inline Tensor matmul(Context &ctx, const Tensor &a, const Tensor &b, const Tensor *bias, float alpha, int act, bool b_transposed) {
+    std::vector<int64_t> as = a.shape(), bs = b.shape();
+    if (as.empty() || bs.empty()) throw OpError(OpError::InvalidValue, "Inputs must have >= 1 dimensions");
+    const bool a_vec = as.size() == 1, b_vec = bs.size() == 1;
+    if (a_vec) as.insert(as.begin(), 1);
+    if (b_vec) { if (b_transposed) bs.insert(bs.begin(), 1); else bs.push_back(1); }
+    if (b_transposed) std::swap(bs[bs.size() - 1], bs[bs.size() - 2]);
+    const int64_t m = as[as.size() - 2], k = as.back(), kb = bs[bs.size() - 2], n = bs.back();
+    if (k != kb) throw OpError(OpError::IncompatibleInputShapes, "Columns of first matrix does not match rows of second matrix");
+    const int64_t na = prod(as, 0, as.size() - 2), nb = prod(bs, 0, bs.size() - 2);
+    // broadcast the batch prefixes
+    std::vector<int64_t> pa(as.begin(), as.end() - 2), pb(bs.begin(), bs.end() - 2), pre;
+    const size_t r = std::max(pa.size(), pb.size());
+    pa.insert(pa.begin(), r - pa.size(), 1);
+    pb.insert(pb.begin(), r - pb.size(), 1);
+    for (size_t i = 0; i < r; i++) {
+        if (pa[i] != pb[i] && pa[i] != 1 && pb[i] != 1) throw OpError(OpError::IncompatibleInputShapes, "Cannot broadcast shapes");
+        pre.push_back(std::max(pa[i], pb[i]));
+    }
+    std::vector<int64_t> oshape = pre;
+    oshape.push_back(m);
+    oshape.push_back(n);
+    Tensor y(ctx, oshape, DType::F32);
+    if (y.len() > 0) {
+        rten_hip_gemm_desc d{};
+        d.k = (int)k; d.n = (int)n; d.a_rs = k; d.a_cs = 1; d.b_rs = b_transposed ? 1 : n; d.b_cs = b_transposed ? k : 1; d.ldc = n;
+        d.alpha = alpha; d.beta = 0.f; d.bias_kind = bias ? RTEN_HIP_BIAS_PER_COL : RTEN_HIP_BIAS_NONE; d.act = act;
+        if (na > 1 && nb == 1) { // matmul.rs:266-297: one [A*M, K] x [K, N] product
+            d.m = (int)(na * m); d.batch = 1;
+        } else {
+            const int64_t batch = prod(pre, 0, pre.size());
+            if ((na != 1 && na != batch) || (nb != 1 && nb != batch)) throw OpError(OpError::UnsupportedValue, "partial batch broadcasting is not supported by the device path");
+            d.m = (int)m; d.batch = (int)batch; d.a_bs = na > 1 ? m * k : 0; d.b_bs = nb > 1 ? k * n : 0; d.c_bs = m * n;
+        }
+        ctx.check(rten_hip_gemm_f32(ctx.raw(), &d, (const float *)a.ptr(), (const float *)b.ptr(), (const float *)vp(bias), (float *)y.ptr()));
+    }
+    if (a_vec) oshape.erase(oshape.end() - 2);
+    if (b_vec) oshape.pop_back();
+    y.reshape(oshape);
+    return y;
+}
+} // namespace detail
+
+struct MatMul : Operator { // src/ops/matmul.rs:387-428
+    const char *name() const override { return "MatMul"; }
+    int max_inputs() const override { return 2; }
+    OutputList run(Context &ctx, const InputList &in) const override {
+        OutputList out;
+        out.push_back(detail::matmul(ctx, want(require(in, 0), DType::F32, "float32"), want(require(in, 1), DType::F32, "float32"), nullptr, 1.f, RTEN_HIP_ACT_NONE, false));
+        return out;
+    }
+};
+
+struct FusedMatMul : Operator { // src/ops/matmul.rs:455-510: MatMul + per-column bias + alpha (act: backend fusion of the following Gelu / Relu)
+    float alpha = 1.f;
+    int act = RTEN_HIP_ACT_NONE;
+    bool transpose_b = false;
+    const char *name() const override { return "FusedMatMul"; }
+    int max_inputs() const override { return 3; }
+    OutputList run(Context &ctx, const InputList &in) const override {
+        const Tensor *bias = get(in, 2);
+        if (bias && bias->ndim() != 1) throw OpError(OpError::InputCastFailed, "expected tensor with 1 dims");
+        OutputList out;
+        out.push_back(detail::matmul(ctx, want(require(in, 0), DType::F32, "float32"), want(require(in, 1), DType::F32, "float32"), bias, alpha, act, transpose_b));
+        return out;
+    }
+};
+
+struct Gemm : Operator { // src/ops/matmul.rs:106-156: c = alpha * (a b) + beta * c with transA / transB
+    float alpha = 1.f, beta = 1.f;
+    bool transpose_a = false, transpose_b = false;
+    const char *name() const override { return "Gemm"; }
+    int max_inputs() const override { return 3; }
+    OutputList run(Context &ctx, const InputList &in) const override {
+        const Tensor &a = want(require(in, 0), DType::F32, "float32"), &b = want(require(in, 1), DType::F32, "float32");
+        const Tensor *c = get(in, 2);
+        if (a.ndim() != 2 || b.ndim() != 2) throw OpError(OpError::InputCastFailed, "expected tensor with 2 dims");
+        const int64_t m = transpose_a ? a.size(1) : a.size(0), k = transpose_a ? a.size(0) : a.size(1);
+        const int64_t kb = transpose_b ? b.size(1) : b.size(0), n = transpose_b ? b.size(0) : b.size(1);
+        if (k != kb) throw OpError(OpError::IncompatibleInputShapes, "Columns of first matrix does not match rows of second matrix");
+        // `c` must broadcast to [m, n] (matmul.rs:63-70); the backend takes a row vector [n] or a full matrix
+        int bias_kind = RTEN_HIP_BIAS_NONE;
+        bool full_c = false;
+        if (c) {
+            if (c->len() == n && (c->ndim() == 1 || (c->ndim() == 2 && c->size(0) == 1))) bias_kind = RTEN_HIP_BIAS_PER_COL;
+            else if (c->ndim() == 2 && c->size(0) == m && c->size(1) == n) full_c = true;
+            else throw OpError(OpError::IncompatibleInputShapes, "Cannot broadcast c to output shape");
+        }
+        Tensor y(ctx, {m, n}, DType::F32);
+        rten_hip_gemm_desc d{};
+        d.m = (int)m; d.n = (int)n; d.k = (int)k; d.batch = 1; d.ldc = n; d.alpha = alpha;
+        d.a_rs = transpose_a ? 1 : k; d.a_cs = transpose_a ? m : 1; d.b_rs = transpose_b ? 1 : n; d.b_cs = transpose_b ? k : 1;
+        if (full_c) { // output = c; gemm(beta) (matmul.rs:72-82)
+            ctx.check(rten_hip_memcpy_d2d(ctx.raw(), y.ptr(), c->ptr(), y.bytes()));
+            d.beta = beta;
+            ctx.check(rten_hip_gemm_f32(ctx.raw(), &d, (const float *)a.ptr(), (const float *)b.ptr(), nullptr, (float *)y.ptr()));
+        } else if (c && beta == 1.f && alpha == 1.f) { // row vector, c + ab: the per-column bias epilogue adds in the same place
+            d.beta = 0.f; d.bias_kind = bias_kind;
+            ctx.check(rten_hip_gemm_f32(ctx.raw(), &d, (const float *)a.ptr(), (const float *)b.ptr(), (const float *)c->ptr(), (float *)y.ptr()));
+        } else if (c) { // general case: output = expand(c), then gemm(alpha, beta) (matmul.rs:63-82)
+            ctx.check(rten_hip_memset(ctx.raw(), y.ptr(), 0, y.bytes()));
+            ctx.check(rten_hip_add_f32(ctx.raw(), y.len(), (const float *)y.ptr(), (const float *)c->ptr(), n, (float *)y.ptr()));
+            d.beta = beta;
+            ctx.check(rten_hip_gemm_f32(ctx.raw(), &d, (const float *)a.ptr(), (const float *)b.ptr(), nullptr, (float *)y.ptr()));
+        } else {
+            d.beta = 0.f;
+            ctx.check(rten_hip_gemm_f32(ctx.raw(), &d, (const float *)a.ptr(), (const float *)b.ptr(), nullptr, (float *)y.ptr()));
+        }
+        OutputList out;
+        out.push_back(std::move(y));
+        return out;
+    }
+};
+
+struct MatMulInteger : Operator { // src/ops/matmul.rs:582-647; scale != null: MatMulIntegerToFloat (:789-794)
+    const char *name() const override { return "MatMulInteger"; }
+    int max_inputs() const override { return 4; }
+    OutputList run(Context &ctx, const InputList &in) const override { return run_scaled(ctx, in, nullptr); }
+    OutputList run_scaled(Context &ctx, const InputList &in, const Tensor *scale) const {
+        const Tensor &a = require(in, 0), &b = require(in, 1);
+        auto is8 = [](DType t) { return t == DType::U8 || t == DType::I8; };
+        if (!is8(a.dtype()) || !is8(b.dtype())) throw OpError(OpError::UnsupportedType, "");
+        if (a.ndim() != 2 || b.ndim() != 2) throw OpError(OpError::UnsupportedValue, "MatMulInteger: only 2-D operands on the device path");
+        const int64_t m = a.size(0), k = a.size(1), n = b.size(1);
+        if (k != b.size(0)) throw OpError(OpError::IncompatibleInputShapes, "Columns of first matrix does not match rows of second matrix");
+        const Tensor *a_zp = get(in, 2), *b_zp = get(in, 3);
+        rten_hip_gemm_int8_desc d{};
+        d.m = (int)m; d.n = (int)n; d.k = (int)k; d.a_rs = k; d.a_cs = 1; d.b_rs = n; d.b_cs = 1; d.ldc = n;
+        d.a_signed = a.dtype() == DType::I8; d.b_signed = b.dtype() == DType::I8;
+        d.a_zp_len = zero_point_len(a_zp, m); d.b_zp_len = zero_point_len(b_zp, n);
+        if (scale) {
+            if (scale->len() != 1 && scale->len() != n) throw OpError(OpError::IncompatibleInputShapes, "Scale length does not match tensor columns");
+            d.scale_len = (int)scale->len();
+        }
+        Tensor y(ctx, {m, n}, scale ? DType::F32 : DType::I32);
+        ctx.check(rten_hip_gemm_int8(ctx.raw(), &d, a.ptr(), b.ptr(), vp(a_zp), vp(b_zp), (const float *)vp(scale), y.ptr()));
+        OutputList out;
+        out.push_back(std::move(y));
+        return out;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ row-wise / element-wise
+inline int resolve_axis(int axis, int ndim) { // resolve_axis (src/ops/mod.rs): same message
+    const int a = axis < 0 ? axis + ndim : axis;
+    if (a < 0 || a >= ndim) throw OpError(OpError::InvalidValue, "Axis is invalid");
+    return a;
+}
+
+struct Softmax : Operator { // src/ops/norm.rs:825-840 (last-axis lanes contiguous: other axes need a transpose first)
+    int axis = -1;
+    const char *name() const override { return "Softmax"; }
+    int max_inputs() const override { return 1; }
+    OutputList run(Context &ctx, const InputList &in) const override {
+        const Tensor &x = want(require(in, 0), DType::F32, "float32");
+        const int a = resolve_axis(axis, x.ndim());
+        if (a != x.ndim() - 1) throw OpError(OpError::UnsupportedValue, "Softmax: only the last axis on the device path");
+        const int64_t cols = x.size(a), rows = cols ? x.len() / cols : 0;
+        Tensor y(ctx, x.shape(), DType::F32);
+        if (x.len()) ctx.check(rten_hip_softmax_f32(ctx.raw(), rows, (int)cols, (const float *)x.ptr(), nullptr, 1, 1, 0, (float *)y.ptr()));
+        OutputList out;
+        out.push_back(std::move(y));
+        return out;
+    }
+};
+
+struct LayerNormalization : Operator { // src/ops/norm.rs:456-529
+    int axis = -1;
+    float epsilon = 1e-5f;
+    const char *name() const override { return "LayerNormalization"; }
+    int max_inputs() const override { return 3; }
+    OutputList run(Context &ctx, const InputList &in) const override {
+        const Tensor &x = want(require(in, 0), DType::F32, "float32");
+        const Tensor &scale = want(require(in, 1), DType::F32, "float32");
+        const Tensor *bias = get(in, 2);
+        const int a = resolve_axis(axis, x.ndim());
+        const int64_t cols = detail::prod(x.shape(), (size_t)a, x.shape().size()), rows = cols ? x.len() / cols : 0;
+        if (scale.len() != cols) throw OpError(OpError::IncompatibleInputShapes, "Cannot broadcast scale to input shape");
+        if (bias && bias->len() != cols) throw OpError(OpError::IncompatibleInputShapes, "Cannot broadcast bias to input shape");
+        Tensor y(ctx, x.shape(), DType::F32);
+        if (x.len())
+            ctx.check(rten_hip_layer_norm_f32(ctx.raw(), rows, (int)cols, (const float *)x.ptr(), (const float *)scale.ptr(), (const float *)vp(bias), 1.f, 0.f, epsilon,
+                                              (float *)y.ptr()));
+        OutputList out;
+        out.push_back(std::move(y));
+        return out;
+    }
+};
+
+template <int32_t (*FN)(rten_hip_ctx *, int64_t, const float *, float *)>
+struct UnaryOp : Operator {
+    const char *nm;
+    explicit UnaryOp(const char *n) : nm(n) {}
+    const char *name() const override { return nm; }
+    int max_inputs() const override { return 1; }
+    OutputList run(Context &ctx, const InputList &in) const override {
+        const Tensor &x = want(require(in, 0), DType::F32, "float32");
+        Tensor y(ctx, x.shape(), DType::F32);
+        if (x.len()) ctx.check(FN(ctx.raw(), x.len(), (const float *)x.ptr(), (float *)y.ptr()));
+        OutputList out;
+        out.push_back(std::move(y));
+        return out;
+    }
+};
+struct Relu : UnaryOp<rten_hip_relu_f32> { Relu() : UnaryOp("Relu") {} };
+struct Gelu : UnaryOp<rten_hip_gelu_f32> { Gelu() : UnaryOp("Gelu") {} };
+struct Erf : UnaryOp<rten_hip_erf_f32> { Erf() : UnaryOp("Erf") {} };
+
+template <int32_t (*FN)(rten_hip_ctx *, int64_t, const float *, const float *, int64_t, float *)>
+struct BinaryOp : Operator { // binary_elementwise.rs:476-495; device path: equal shapes or `b` broadcast over leading dims
+    const char *nm;
+    explicit BinaryOp(const char *n) : nm(n) {}
+    const char *name() const override { return nm; }
+    int max_inputs() const override { return 2; }
+    OutputList run(Context &ctx, const InputList &in) const override {
+        const Tensor &a = want(require(in, 0), DType::F32, "float32"), &b = want(require(in, 1), DType::F32, "float32");
+        const int64_t n = a.len(), bl = b.len();
+        bool ok = bl > 0 && n % bl == 0 && b.ndim() <= a.ndim();
+        for (int i = 0; ok && i < b.ndim(); i++) {
+            const int64_t bd = b.size(b.ndim() - 1 - i), ad = a.size(a.ndim() - 1 - i);
+            if (bd != ad && !(bd == 1 && detail::prod(b.shape(), 0, (size_t)(b.ndim() - 1 - i)) == 1)) ok = false;
+        }
+        if (!ok) throw OpError(OpError::IncompatibleInputShapes, "Cannot broadcast inputs to same shape");
+        Tensor y(ctx, a.shape(), DType::F32);
+        if (n) ctx.check(FN(ctx.raw(), n, (const float *)a.ptr(), (const float *)b.ptr(), bl, (float *)y.ptr()));
+        OutputList out;
+        out.push_back(std::move(y));
+        return out;
+    }
+};
+struct Add : BinaryOp<rten_hip_add_f32> { Add() : BinaryOp("Add") {} };
+struct Mul : BinaryOp<rten_hip_mul_f32> { Mul() : BinaryOp("Mul") {} };
+
+// ------------------------------------------------------------------------------------------------ pooling
+struct PoolBase : Operator {
+    std::vector<int> kernel_size{1, 1}, strides{1, 1};
+    Padding padding;
+    bool ceil_mode = false;
+    rten_hip_pool2d_desc desc(const Tensor &x, bool count_include_pad) const {
+        if (x.ndim() != 4) throw OpError(OpError::InvalidValue, "input must have 4 dims (NCHW)");
+        const OutputSize os = calc_output_size_and_padding((int)x.size(2), (int)x.size(3), kernel_size[0], kernel_size[1], strides, padding, {1, 1}, ceil_mode);
+        rten_hip_pool2d_desc d{};
+        d.n = (int)x.size(0); d.c = (int)x.size(1); d.h = (int)x.size(2); d.w = (int)x.size(3);
+        d.kh = kernel_size[0]; d.kw = kernel_size[1]; d.stride_h = strides[0]; d.stride_w = strides[1];
+        for (int i = 0; i < 4; i++) d.pads[i] = os.pads[i];
+        d.out_h = os.oh; d.out_w = os.ow; d.count_include_pad = count_include_pad;
+        return d;
+    }
+};
+struct MaxPool : PoolBase { // src/ops/pooling.rs:477-521
+    const char *name() const override { return "MaxPool"; }
+    int max_inputs() const override { return 1; }
+    OutputList run(Context &ctx, const InputList &in) const override {
+        const Tensor &x = want(require(in, 0), DType::F32, "float32");
+        const rten_hip_pool2d_desc d = desc(x, false);
+        Tensor y(ctx, {d.n, d.c, d.out_h, d.out_w}, DType::F32);
+        ctx.check(rten_hip_max_pool2d_f32(ctx.raw(), &d, (const float *)x.ptr(), (float *)y.ptr()));
+        OutputList out;
+        out.push_back(std::move(y));
+        return out;
+    }
+};
+struct AveragePool : PoolBase { // src/ops/pooling.rs:174-389
+    bool count_include_pad = false;
+    const char *name() const override { return "AveragePool"; }
+    int max_inputs() const override { return 1; }
+    OutputList run(Context &ctx, const InputList &in) const override {
+        const Tensor &x = want(require(in, 0), DType::F32, "float32");
+        const rten_hip_pool2d_desc d = desc(x, count_include_pad);
+        Tensor y(ctx, {d.n, d.c, d.out_h, d.out_w}, DType::F32);
+        ctx.check(rten_hip_average_pool2d_f32(ctx.raw(), &d, (const float *)x.ptr(), (float *)y.ptr()));
+        OutputList out;
+        out.push_back(std::move(y));
+        return out;
+    }
+};
+struct GlobalAveragePool : Operator { // src/ops/pooling.rs:392-417
+    const char *name() const override { return "GlobalAveragePool"; }
+    int max_inputs() const override { return 1; }
+    OutputList run(Context &ctx, const InputList &in) const override {
+        const Tensor &x = want(require(in, 0), DType::F32, "float32");
+        if (x.ndim() != 4) throw OpError(OpError::InvalidValue, "input must have 4 dims (NCHW)");
+        Tensor y(ctx, {x.size(0), x.size(1), 1, 1}, DType::F32);
+        if (x.len()) ctx.check(rten_hip_global_average_pool_f32(ctx.raw(), x.size(0) * x.size(1), (int)(x.size(2) * x.size(3)), (const float *)x.ptr(), (float *)y.ptr()));
+        OutputList out;
+        out.push_back(std::move(y));
+        return out;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ quantization
+struct DynamicQuantizeLinear : Operator { // src/ops/quantize.rs:352-436: outputs y (u8), y_scale (f32 scalar), y_zero_point (u8 scalar)
+    const char *name() const override { return "DynamicQuantizeLinear"; }
+    int max_inputs() const override { return 1; }
+    OutputList run(Context &ctx, const InputList &in) const override {
+        const Tensor &x = want(require(in, 0), DType::F32, "float32");
+        Tensor y(ctx, x.shape(), DType::U8), s(ctx, {}, DType::F32), z(ctx, {}, DType::U8);
+        ctx.check(rten_hip_dynamic_quantize_linear(ctx.raw(), x.len(), (const float *)x.ptr(), (uint8_t *)y.ptr(), (float *)s.ptr(), (uint8_t *)z.ptr()));
+        OutputList out;
+        out.push_back(std::move(y));
+        out.push_back(std::move(s));
+        out.push_back(std::move(z));
+        return out;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ registry (src/op_registry.rs:25-72)
+class OpRegistry {
+  public:
+    using Factory = std::function<std::unique_ptr<Operator>()>;
+    template <typename Op> void register_op(const std::string &name) { factories_[name] = [] { return std::unique_ptr<Operator>(new Op()); }; }
+    std::unique_ptr<Operator> create(const std::string &name) const {
+        auto it = factories_.find(name);
+        if (it == factories_.end()) throw OpError(OpError::UnsupportedValue, "operator not registered: " + name); // ReadOpError::OperatorUnavailable
+        return it->second();
+    }
+    bool contains(const std::string &name) const { return factories_.count(name) != 0; }
+    std::vector<std::string> names() const {
+        std::vector<std::string> v;
+        for (auto &kv : factories_) v.push_back(kv.first);
+        return v;
+    }
+    static OpRegistry with_all_ops() { // every hot-path operator this backend overrides
+        OpRegistry r;
+        r.register_op<Conv>("Conv");
+        r.register_op<ConvInteger>("ConvInteger");
+        r.register_op<ConvIntegerToFloat>("ConvIntegerToFloat");
+        r.register_op<MatMul>("MatMul");
+        r.register_op<FusedMatMul>("FusedMatMul");
+        r.register_op<Gemm>("Gemm");
+        r.register_op<MatMulInteger>("MatMulInteger");
+        r.register_op<Softmax>("Softmax");
+        r.register_op<LayerNormalization>("LayerNormalization");
+        r.register_op<Relu>("Relu");
+        r.register_op<Gelu>("Gelu");
+        r.register_op<Erf>("Erf");
+        r.register_op<Add>("Add");
+        r.register_op<Mul>("Mul");
+        r.register_op<MaxPool>("MaxPool");
+        r.register_op<AveragePool>("AveragePool");
+        r.register_op<GlobalAveragePool>("GlobalAveragePool");
+        r.register_op<DynamicQuantizeLinear>("DynamicQuantizeLinear");
+        return r;
+    }
+
+  private:
+    std::map<std::string, Factory> factories_;
+};
+
+} // namespace rten_hip
