@@ -237,7 +237,7 @@ def main():
             roof = {"bound": "mfma", "kernel": dom["kernel"],
                     "achieved": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12, 3), "peak": F32_MATRIX_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12 / F32_MATRIX_PEAK_TFLOPS, 4),
-                    "traffic": None,
+                    "traffic": None, "traffic_source": None,
                     "avg_launch_us": round(dom["ms"] * 1e3 / max(dom["launches"], 1), 2), "launches": dom["launches"],
                     "flops_per_launch": dom["flops"] / max(dom["launches"], 1),
                     "kernel_share_of_step": round(dom["ms"] / max(tot_ms, 1e-9), 4),
@@ -247,6 +247,16 @@ def main():
                                      "variants": {r["kernel"]: {"launches": r["launches"], "ms": round(r["ms"], 4),
                                                                 "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2)} for r in conv}}}
 
+    if rank == 0 and roof:
+        # HBM bytes per launch of the dominant kernel from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, collected separately by
+        # tools_gpu_traffic.sh over the same tuned plan -- counters cannot be collected inside the timed run)
+        import glob
+        for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*", "hbm_traffic_per_kernel.json")), reverse=True):
+            t = json.load(open(path)).get("kernels", {}).get(roof["kernel"].replace(" ", ""))
+            if t:
+                roof["traffic"] = t["hbm_read_bytes_per_launch"] + t["hbm_write_bytes_per_launch"]
+                roof["traffic_source"] = os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))
+                break
     if rank == 0:
         global_batch = BATCH_PER_GPU * n_gpus
         value = global_batch * args.steps / elapsed

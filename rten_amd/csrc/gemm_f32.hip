@@ -1299,7 +1299,7 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
         const dim3 grid(gx, (unsigned)Z);
         if constexpr (kDma) {
             if (pipe == 2) {
-                snprintf(kname, sizeof kname, "igemm_f32_ws_kernel<%d,%d,%d,%d>", BM, BN, BL, mode);
+                snprintf(kname, sizeof kname, "igemm_f32_ws_kernel<%d,%d,%d,%s>", BM, BN, BL, mode == 1 ? "true" : "false");
                 ProfScope ps(ctx, kname, fl, by);
                 if (mode == 1) hipLaunchKernelGGL((igemm_f32_ws_kernel<BM, BN, BL, true>), grid, dim3(2 * NTHREADS), 0, ctx->stream, a);
                 else hipLaunchKernelGGL((igemm_f32_ws_kernel<BM, BN, BL, false>), grid, dim3(2 * NTHREADS), 0, ctx->stream, a);
@@ -1307,7 +1307,7 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
                 return RTEN_HIP_OK;
             }
             if (pipe == 1) {
-                snprintf(kname, sizeof kname, "igemm_f32_dma_kernel<%d,%d,%d,%d,%d>", BM, BN, AL, BL, mode);
+                snprintf(kname, sizeof kname, "igemm_f32_dma_kernel<%d,%d,%d,%d,%d,3>", BM, BN, AL, BL, mode);
                 ProfScope ps(ctx, kname, fl, by);
                 if (mode == 2) hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, AL, BL, 2>), grid, dim3(NTHREADS), 0, ctx->stream, a);
                 else if (mode == 1) hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, AL, BL, 1>), grid, dim3(NTHREADS), 0, ctx->stream, a);
@@ -1340,7 +1340,7 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
     if constexpr (kDma && BM * BN < 128 * 128) mixed = pipe == 1 && ntail > 0 && t1 > 0;
     if (mixed) { // whole tiles and the tail's split-K producers in ONE launch (co-resident), then the fixup
         if constexpr (kDma && BM * BN < 128 * 128) {
-            snprintf(kname, sizeof kname, "igemm_f32_dma_kernel<%d,%d,%d,%d,3>", BM, BN, AL, BL);
+            snprintf(kname, sizeof kname, "igemm_f32_dma_kernel<%d,%d,%d,%d,3,3>", BM, BN, AL, BL);
             ProfScope ps(ctx, kname, flops, bytes);
             hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, AL, BL, 3>), dim3((unsigned)(t1 + ntail * S), (unsigned)Z), dim3(NTHREADS), 0, ctx->stream, a);
             RTEN_LAUNCH_CHECK(ctx, "igemm_f32_dma_kernel (mixed) launch");

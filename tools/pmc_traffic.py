@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --load-plan ... --no-graph` into HBM bytes per
+launch per kernel (FETCH_SIZE doubled per MI355X_MICROARCH.md: gfx950 reports half of wide coalesced reads; both
+counters are in KiB).   usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> > out.json"""
+import collections, csv, json, re, sys
+
+
+def norm(name):
+    m = re.search(r"(igemm_\w+<[^>]*>|\w+_kernel\b[^()]*|\w+)", name.replace("(anonymous namespace)::", "").replace("void ", ""))
+    return m.group(1).replace(" ", "") if m else name
+
+
+def load(path, counter):
+    acc = collections.defaultdict(lambda: [0, 0.0])
+    seen = set()
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] != counter:
+                continue
+            k = norm(r["Kernel_Name"])
+            acc[k][1] += float(r["Counter_Value"])
+            if r["Dispatch_Id"] not in seen:
+                seen.add(r["Dispatch_Id"])
+                acc[k][0] += 1
+    return acc
+
+
+fe, wr = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+out = {}
+for k in sorted(set(fe) | set(wr)):
+    n = max(fe[k][0], wr[k][0], 1)
+    out[k] = {"launches": n, "hbm_read_bytes_per_launch": round(2 * 1024 * fe[k][1] / n), "hbm_write_bytes_per_launch": round(1024 * wr[k][1] / n)}
+json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 (gfx950 correction), eager replay of the tuned plan",
+           "kernels": out}, sys.stdout, indent=1)
