@@ -187,9 +187,11 @@ typedef struct {
     int32_t pad_mode;
     int32_t weights_packed; /* != 0: `w` is a buffer written by rten_hip_conv2d_int8_prepack */
     int32_t x_staged;       /* != 0: `x` is a staged image written by rten_hip_dynamic_quantize_linear_staged */
+    int32_t scale_len;      /* 0 or 1: scalar scale (ConvIntegerToFloat, fusions.rs:1046-1049); o: per-output-channel
+                             * scale (the unfused ConvInteger -> Cast -> Mul([1,O,1,1]) form of per-channel weights) */
 } rten_hip_conv2d_int8_desc;
-/* scale == NULL: y is i32 (ConvInteger).  scale != NULL (device scalar): y is f32 =
- * (acc as f32) * scale[0], then optional bias[o] add (the Add node that follows in ort-quantized
+/* scale == NULL: y is i32 (ConvInteger).  scale != NULL (device scalar, or [o] with desc.scale_len == o): y is f32 =
+ * (acc as f32) * scale[0 or o], then optional bias[o] add (the Add node that follows in ort-quantized
  * graphs), optional residual add and Relu per `flags`. */
 /* Load-time staging of constant ConvInteger weights (PrepackedInput / Graph::prepack_weights analogue,
  * src/operator.rs:25-66): (ky, kx, c)-ordered signed rows with channels padded to 16, followed by the row sums the

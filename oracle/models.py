@@ -60,8 +60,8 @@ def quantize_weights_int8(weights):
     """Symmetric per-tensor i8 weights for the dynamically-quantized graphs: {name: (wq i8, w_scale f32, bias f32)}."""
     out = {}
     for name, (w, b) in weights.items():
-        s = np.float32(np.abs(w).max() / 127.0)
-        q = np.clip(np.rint(w / s), -127, 127).astype(np.int8)
+        s = np.float32(np.abs(w).max() / 64.0)  # reduce_range=True: 7-bit weights (tools/ort-quantize.py:124-137)
+        q = np.clip(np.rint(w / s), -64, 64).astype(np.int8)
         out[name] = (q, s, b)
     return out
 

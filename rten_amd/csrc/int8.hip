@@ -54,6 +54,7 @@ struct I8Args {
     int a_signed, b_signed;
     int a_zp_len, b_zp_len, a_zp_bs; // a_zp index = z*a_zp_bs + (len==1 ? 0 : m)
     int scale_len;
+    int scale_per_row; // conv: per-output-channel scale
     int bias_bs;
     int relu;
     int tiles_m, tiles_n;
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_i8_kernel(const I8Args p) {
     const long long ccol = (long long)z * p.c_bs + (long long)nb * p.c_ns + np;
     const unsigned bz = (unsigned)zp_signed(p.b_zp, p.b_zp_len == 1 ? 0 : n, p.b_signed);
     const unsigned cs = (unsigned)csum[wn0 + l31];
-    const float sc = p.scale ? p.scale[p.scale_len == 1 ? 0 : n] : 0.f;
+    const float sc = (p.scale && !p.scale_per_row) ? p.scale[p.scale_len == 1 ? 0 : n] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const int ml = wm0 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_i8_kernel(const I8Args p) {
         const unsigned v = (unsigned)acc[r] - bz * (unsigned)rsum[ml] - az * cs + (unsigned)p.K * az * bz;
         const long long off = ccol + (long long)m * p.c_rs;
         if (p.scale) {
-            float f = (float)(int)v * sc;                    // cast_scale (matmul.rs:751,761)
+            float f = (float)(int)v * (p.scale_per_row ? p.scale[z * p.bias_bs + m] : sc); // cast_scale (matmul.rs:751,761)
             if (p.bias) f = f + p.bias[z * p.bias_bs + m];   // following Add(bias [1,O,1,1])
             if (p.res) f = f + p.res[off];                   // following residual Add
             if (p.relu) f = vm::relu(f);
@@ -305,6 +306,8 @@ RTEN_EXPORT int32_t rten_hip_conv2d_int8(rten_hip_ctx *ctx, const rten_hip_conv2
     if (!x || !w || !y) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "conv_int8: NULL operand");
     if (!scale && (bias || residual || (flags & RTEN_HIP_CONV_RELU)))
         return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "conv_int8: float epilogue needs a scale");
+    if (di->scale_len != 0 && di->scale_len != 1 && di->scale_len != d->o)
+        return rten_set_error(ctx, RTEN_HIP_ERR_INCOMPATIBLE_SHAPES, "conv_int8: scale must be a scalar or have one value per output channel");
     if (d->n == 0 || d->out_h == 0 || d->out_w == 0) return RTEN_HIP_OK;
     const int Cg = d->c / d->groups, Og = d->o / d->groups;
     const int K = Cg * d->kh * d->kw, P = d->out_h * d->out_w;
@@ -332,6 +335,7 @@ RTEN_EXPORT int32_t rten_hip_conv2d_int8(rten_hip_ctx *ctx, const rten_hip_conv2
     g.a_zp_len = di->w_zp_len; g.a_zp_bs = di->w_zp_len > 1 ? Og : 0;
     g.b_zp_len = x_zp ? 1 : 0;
     g.scale_len = scale ? 1 : 0;
+    g.scale_per_row = (scale && di->scale_len > 1) ? 1 : 0;
     g.bias_bs = Og;
     g.im2col = 1;
     g.H = d->h; g.W = d->w; g.HW = (int)HW; g.KHW = d->kh * d->kw; g.KW = d->kw; g.OW = d->out_w;

@@ -46,6 +46,7 @@ struct FastArgs {
     long long c_rs, c_ns;
     int Pn;
     int a_signed, b_signed, a_zp_len, b_zp_len, scale_len, relu, need_csum;
+    int scale_per_row; // conv: scale[m] per output channel instead of scale[0] / scale[n]
     int tiles_m, tiles_n;
     // conv geometry (padded image)
     int conv, OW, sy, sx, Hp, Wp, Cp, KH, KW, dy, dx;
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p)
         bzv[j] = (unsigned)zp_signed(p.b_zp, p.b_zp_len == 1 ? 0 : nn, p.b_signed);
         if (p.csum) csv[j] = (unsigned)p.csum[nn];
         else csv[j] = (unsigned)(cs[j] + __shfl_xor(cs[j], 32, 64)); // the two k halves of the column
-        scv[j] = p.scale ? p.scale[p.scale_len == 1 ? 0 : nn] : 0.f;
+        scv[j] = (p.scale && !p.scale_per_row) ? p.scale[p.scale_len == 1 ? 0 : nn] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < TM; i++) {
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p)
 #pragma unroll
         for (int h8 = 0; h8 < 2; h8++) {
             unsigned rsv[8], azv[8];
-            float bv[8];
+            float bv[8], srow[8];
             bool mok[8];
 #pragma unroll
             for (int q = 0; q < 8; q++) {
@@ -335,6 +336,7 @@ __global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p)
                 rsv[q] = (unsigned)p.rsum[mm];
                 azv[q] = (unsigned)zp_signed(p.a_zp, p.a_zp_len == 1 ? 0 : mm, p.a_signed);
                 bv[q] = p.bias ? p.bias[mm] : 0.f;
+                srow[q] = p.scale_per_row ? p.scale[mm] : 0.f;
             }
 #pragma unroll
             for (int j = 0; j < TN; j++) {
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p)
                 if (p.scale) {
                     float f[8];
 #pragma unroll
-                    for (int q = 0; q < 8; q++) f[q] = (float)(int)v[q] * scv[j]; // cast_scale (matmul.rs:751,761)
+                    for (int q = 0; q < 8; q++) f[q] = (float)(int)v[q] * (p.scale_per_row ? srow[q] : scv[j]); // cast_scale (matmul.rs:751,761)
                     if (p.bias) {
 #pragma unroll
                         for (int q = 0; q < 8; q++) f[q] = f[q] + bv[q];
@@ -588,6 +590,7 @@ int32_t rten_i8_fast_conv(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di
     g.a_signed = di->w_signed; g.b_signed = di->x_signed;
     g.a_zp_len = di->w_zp_len; g.b_zp_len = x_zp ? 1 : 0;
     g.scale_len = scale ? 1 : 0;
+    g.scale_per_row = (scale && di->scale_len > 1) ? 1 : 0;
     g.need_csum = (di->w_zp_len != 0 || !di->w_signed) ? 1 : 0; // weight zero point may be non-zero in the signed domain
     g.conv = 1; g.OW = d->out_w; g.sy = d->stride_h; g.sx = d->stride_w; g.Hp = cg.Hp; g.Wp = cg.Wp; g.Cp = cg.Cp;
     g.KH = d->kh; g.KW = d->kw; g.dy = d->dil_h; g.dx = d->dil_w;

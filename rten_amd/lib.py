@@ -76,7 +76,7 @@ class Conv2dDesc(C.Structure):
 
 class Conv2dInt8Desc(C.Structure):
     _fields_ = [("conv", Conv2dDesc), ("x_signed", C.c_int32), ("w_signed", C.c_int32),
-                ("w_zp_len", C.c_int32), ("pad_mode", C.c_int32), ("weights_packed", C.c_int32), ("x_staged", C.c_int32)]
+                ("w_zp_len", C.c_int32), ("pad_mode", C.c_int32), ("weights_packed", C.c_int32), ("x_staged", C.c_int32), ("scale_len", C.c_int32)]
 
 
 class Pool2dDesc(C.Structure):

@@ -20,8 +20,8 @@ def quantize_weights(weights):
     """Symmetric per-tensor i8 weights: {name: (wq i8, w_scale f32, bias f32)} (same recipe as oracle.models)."""
     out = {}
     for name, (w, b) in weights.items():
-        s = np.float32(np.abs(w).max() / 127.0)
-        out[name] = (np.clip(np.rint(w / s), -127, 127).astype(np.int8), s, b)
+        s = np.float32(np.abs(w).max() / 64.0)  # reduce_range=True: 7-bit weights (tools/ort-quantize.py:124-137)
+        out[name] = (np.clip(np.rint(w / s), -64, 64).astype(np.int8), s, b)
     return out
 
 
