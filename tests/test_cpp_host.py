@@ -19,8 +19,8 @@ def build_binary():
     L.load()  # raises if librten_hip.so is missing: the C++ layer has no other backend
     os.makedirs(os.path.dirname(BIN), exist_ok=True)
     src = os.path.join(ROOT, "tests", "cpp", "test_host_ops.cpp")
-    hdr = os.path.join(ROOT, "include", "rten_hip_ops.hpp")
-    if not os.path.exists(BIN) or os.path.getmtime(BIN) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    deps = [src, os.path.join(ROOT, "include", "rten_hip_ops.hpp"), os.path.join(ROOT, "include", "rten_hip.h")]
+    if not os.path.exists(BIN) or os.path.getmtime(BIN) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), src, "-o", BIN,
                                "-L" + os.path.join(ROOT, "rten_amd"), "-lrten_hip", "-L" + os.path.join(ROOT, "oracle", "_build"), "-lrten_oracle",
                                "-Wl,-rpath," + os.path.join(ROOT, "rten_amd"), "-Wl,-rpath," + os.path.join(ROOT, "oracle", "_build"),
