@@ -300,6 +300,9 @@ int32_t rten_hip_set_gemm_order(rten_hip_ctx *ctx, int32_t order);
 /* int8 kernels: 0 = automatic (operands staged k-contiguous / padded NHWC + 16-byte LDS-DMA MFMA kernel whenever it
  * covers the call), 1 = generic byte-gather kernel only.  Both produce the reference's bits. */
 int32_t rten_hip_set_int8_path(rten_hip_ctx *ctx, int32_t mode);
+/* attention: 0 = automatic (one fused kernel for head size 64 and key length <= 128: QK^T, mask, softmax and PV without
+ * a score tensor in memory), 1 = composed path only (batched GEMM, row softmax, batched GEMM).  Same bits either way. */
+int32_t rten_hip_set_sdpa_path(rten_hip_ctx *ctx, int32_t mode);
 
 #ifdef __cplusplus
 }

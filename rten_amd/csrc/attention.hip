@@ -12,6 +12,17 @@
 // is bit-identical to the oracle's sdpa.
 #include "internal.h"
 
+// attention_fused.hip: single-kernel path for head size 64, key length <= 128; RTEN_HIP_ERR_UNSUPPORTED = not covered
+int32_t rten_sdpa_fused(rten_hip_ctx *ctx, const rten_hip_sdpa_desc *d, const float *q, const float *k, const float *v, const float *mask, float *out);
+
+// 0 = automatic (fused kernel whenever it covers the shape), 1 = composed path only (GEMM, softmax, GEMM).
+RTEN_EXPORT int32_t rten_hip_set_sdpa_path(rten_hip_ctx *ctx, int32_t mode) {
+    RTEN_CHECK_CTX(ctx);
+    if (mode < 0 || mode > 1) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "set_sdpa_path: mode must be 0 or 1");
+    ctx->sdpa_path = mode;
+    return RTEN_HIP_OK;
+}
+
 RTEN_EXPORT int32_t rten_hip_sdpa_f32(rten_hip_ctx *ctx, const rten_hip_sdpa_desc *d, const float *q, const float *k,
                                       const float *v, const float *mask, float *out) {
     RTEN_CHECK_CTX(ctx);
@@ -23,6 +34,10 @@ RTEN_EXPORT int32_t rten_hip_sdpa_f32(rten_hip_ctx *ctx, const rten_hip_sdpa_des
     if (mask && ((d->mask_row_stride != 0 && d->mask_row_stride != d->t) ||
                  d->mask_batch_stride != (d->mask_row_stride ? (int64_t)d->s * d->t : (int64_t)d->t)))
         return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "sdpa: mask must be [B,1,1,T] or [B,1,S,T] contiguous");
+    if (ctx->sdpa_path == 0) {
+        const int32_t rc = rten_sdpa_fused(ctx, d, q, k, v, mask, out);
+        if (rc != RTEN_HIP_ERR_UNSUPPORTED) return rc;
+    }
     const size_t score_bytes = (size_t)bh * d->s * (size_t)d->t * sizeof(float);
     float *scores = (float *)rten_scratch(ctx, score_bytes + 256);
     if (!scores) return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "sdpa: scratch allocation failed (warm up before capture)");

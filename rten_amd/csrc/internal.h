@@ -42,6 +42,7 @@ struct rten_hip_ctx {
     int gemm_variant_override = -1;
     int pipeline = 1; // conv paths: 0 register-staged, 1 LDS-DMA, 2 LDS-DMA + wave specialisation
     int num_cus = 256;
+    int sdpa_path = 0;  // 0 automatic (fused attention kernel when it covers the shape), 1 composed path only
     int int8_path = 0;  // 0 automatic (fast staging path when it covers the call), 1 generic kernel only
     int tile_order = 0; // workgroup -> tile order bits (rten_hip_set_gemm_order)
     int split_mode = 3, split_s = 1; // exact split-K plan: 0 off, 1 tail tiles, 2 all tiles, 3 automatic (gemm_f32.hip)

@@ -145,6 +145,7 @@ PROTOTYPES = {
     "rten_hip_stream_wait": (_I32, [_VP, _VP]),
     "rten_hip_set_gemm_order": (_I32, [_VP, _I32]),
     "rten_hip_set_int8_path": (_I32, [_VP, _I32]),
+    "rten_hip_set_sdpa_path": (_I32, [_VP, _I32]),
 }
 
 _lib = None

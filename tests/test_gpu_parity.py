@@ -530,6 +530,34 @@ def test_sdpa_bit_exact(ctx):
             bits_equal(ops.Attention().run(ctx, ins)[0].numpy(), ref.sdpa(q, k, v, mask=m, lanes=16))
 
 
+@pytest.mark.parametrize("path", [0, 1], ids=["fused", "composed"])
+def test_sdpa_head64_shapes_bit_exact(ctx, path):
+    # head size 64: the fused attention kernel (key length <= 128) and the composed GEMM / softmax / GEMM path, same bits.
+    # Ragged query / key lengths, both mask forms, fully masked rows with and without the NaN flush.
+    rng = ref.XorShiftRng(31)
+    ctx.call("rten_hip_set_sdpa_path", path)
+    try:
+        for (B, H, S, T) in ((1, 2, 40, 40), (2, 3, 200, 100), (1, 1, 128, 128), (2, 2, 33, 7), (1, 2, 64, 129)):
+            q = rng.f32(B * H * S * 64).reshape(B, H, S, 64) - 0.5
+            k = rng.f32(B * H * T * 64).reshape(B, H, T, 64) - 0.5
+            v = rng.f32(B * H * T * 64).reshape(B, H, T, 64) - 0.5
+            m1 = np.where(rng.f32(B * T).reshape(B, 1, 1, T) > 0.3, 0.0, -np.inf).astype(np.float32)
+            m1[0, 0, 0, :] = -np.inf  # a fully masked batch item: NaN rows unless flushed
+            m2 = ((rng.f32(B * S * T).reshape(B, 1, S, T) - 0.5) * 4).astype(np.float32)
+            for m in (None, m1, m2):
+                for flush in (True, False):
+                    mbs, mrs = (0, 0) if m is None else ((T, 0) if m.shape[2] == 1 else (S * T, T))
+                    d = L.SdpaDesc(B, H, S, T, 64, 64, H * S * 64, S * 64, 64, H * T * 64, T * 64, 64, H * T * 64, T * 64, 64, H * S * 64, S * 64, 64,
+                                   mbs, mrs, 0.125, 1 if flush else 0)
+                    out = DeviceTensor(ctx, (B, H, S, 64), np.float32)
+                    qd, kd, vd = dev(ctx, q), dev(ctx, k), dev(ctx, v)
+                    md = dev(ctx, m) if m is not None else None
+                    ctx.call("rten_hip_sdpa_f32", C.byref(d), qd.vp, kd.vp, vd.vp, md.vp if md is not None else None, out.vp)
+                    bits_equal(out.numpy(), ref.sdpa(q, k, v, mask=m, scale=0.125, lanes=16, flush_nan=flush))
+    finally:
+        ctx.call("rten_hip_set_sdpa_path", 0)
+
+
 # ------------------------------------------------------------------------------------------ end to end
 def test_resnet50_end_to_end_bit_exact_and_graph_replay(ctx):
     from oracle import models as omodels
