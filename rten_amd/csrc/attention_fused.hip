@@ -10,10 +10,14 @@
 //   * softmax: max from f32::MIN, ReducedRangeExp, the 16-lane (AVX-512) ordered partial sums and their left-to-right
 //     fold, `e * (1/sum)`, optional NaN flush -- the same operation sequence as rowwise.hip's softmax_kernel;
 //   * PV: v_mfma over t = 0..T-1 in order (T <= 128 < kc: one depth block), plain store.
-// Mapping: 256 threads; wave w owns query rows [32w, 32w+32) and ALL key columns, so the row softmax needs no
-// cross-wave traffic: a row's T scores sit in 4 accumulator blocks x 32 lanes of one half-wave.  Q and K are staged
-// in LDS as [d-quad][row][4] (16-byte global loads, k-contiguous operands like the GEMM's row-major-A image); the
-// probabilities go back through LDS ([t][32 rows + 1] per wave) to become the A operand of PV; V is staged [t][64].
+// Mapping: 256 threads; the kernel computes the TRANSPOSED score tile S^T = K Q^T (products commute, so every score is
+// the same d-ordered chain): wave w owns query columns [32w, 32w+32) and all key rows, so one lane-pair (l, l+32) holds
+// a whole softmax row in registers -- the max and the 16 ordered partial sums are plain in-lane register arithmetic
+// (key index t = 32j + acc_row(r) + 4*half, hence t mod 16 is fixed per register), and the left-to-right fold of the 16
+// partials crosses between the two half-waves four times.  The probabilities never leave registers either: eight
+// v_permlane32_swap per 32 keys re-pair them into the MFMA A operand (k = t, even t in lanes 0-31, odd t in lanes
+// 32-63) for PV.  Q and K are staged in LDS as [d-quad][row][4] (16-byte global loads); V replaces K after phase 1.
+// 64 KB of LDS and < 128 VGPRs: two workgroups per CU.
 #include "internal.h"
 #include "vecmath.h"
 
@@ -25,8 +29,6 @@ namespace {
 constexpr int SQ = 128; // query rows per workgroup
 constexpr int TT = 128; // key columns (upper bound; shorter T is zero-filled and masked)
 constexpr int HD = 64;  // head size (q/k depth and v width)
-constexpr int PLD = 33; // row pitch of the per-wave probability panel [t][32 rows]: odd -> conflict-free transposed stores
-
 struct SdpaArgs {
     const float *q, *k, *v, *mask;
     float *out;
@@ -40,11 +42,12 @@ struct SdpaArgs {
 
 __device__ __forceinline__ constexpr int acc_row(int r) { return (r & 3) + 8 * (r >> 2); }
 
-__global__ __launch_bounds__(256, 1) void sdpa_fused_kernel(const SdpaArgs p) {
-    // phase 1: Qs [16][SQ][4] + Ks [16][TT][4] = 64 KB; phase 3: Ps 4 x [TT][PLD] (66 KB, over Qs/Ks) + Vs [TT][HD] (32 KB)
-    __shared__ __attribute__((aligned(16))) float smem[4 * TT * PLD + TT * HD];
-    float *const Qs = smem, *const Ks = smem + 16 * SQ * 4;
-    float *const Vs = smem + 4 * TT * PLD;
+// register of key row tb (0..31) inside a 32x32 accumulator block, for the half-wave that holds it ((tb >> 2) & 1)
+__device__ __forceinline__ constexpr int reg_of(int tb) { return (tb & 3) + 4 * (tb >> 3); }
+
+__global__ __launch_bounds__(256, 2) void sdpa_fused_kernel(const SdpaArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[16 * SQ * 4 + 16 * TT * 4]; // Qs | Ks (phase 1) -> Vs [TT][HD] (phase 3)
+    float *const Qs = smem, *const Ks = smem + 16 * SQ * 4, *const Vs = Ks;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, half = lane >> 5;
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(256, 1) void sdpa_fused_kernel(const SdpaArgs p) {
     const float *vb = p.v + (long long)b * p.v_bs + (long long)h * p.v_hs;
     float *ob = p.out + (long long)b * p.o_bs + (long long)h * p.o_hs;
 
-    // ---- stage Q, K ([d-quad][row][4]) and V ([t][64]); rows past S / T are zero
+    // ---- stage Q and K ([d-quad][row][4]); rows past S / T are zero.  V is fetched now and parked in registers.
 #pragma unroll
     for (int i = 0; i < SQ * 16 / 256; i++) {
         const int f = i * 256 + t, row = f >> 4, dq = f & 15;
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(256, 1) void sdpa_fused_kernel(const SdpaArgs p) {
         if (row < p.t) v = *reinterpret_cast<const f32x4 *>(kb + (long long)row * p.k_rs + dq * 4);
         *reinterpret_cast<f32x4 *>(Ks + (dq * TT + row) * 4) = v;
     }
-    f32x4 vreg[TT * 16 / 256]; // V goes to LDS after phase 1 (its region overlaps nothing, but keep the loads early)
+    f32x4 vreg[TT * 16 / 256];
 #pragma unroll
     for (int i = 0; i < TT * 16 / 256; i++) {
         const int f = i * 256 + t, row = f >> 4, dq = f & 15;
@@ -80,101 +83,126 @@ __global__ __launch_bounds__(256, 1) void sdpa_fused_kernel(const SdpaArgs p) {
     }
     __syncthreads();
 
-    // ---- phase 1: scores[32 rows of this wave][TT] = Q K^T, k = d in order
+    // ---- phase 1: S^T[t][s] for this wave's 32 query columns: A = K rows (m = t), B = Q rows (n = s), k = d in order
     f32x16 sc[4];
 #pragma unroll
     for (int j = 0; j < 4; j++)
 #pragma unroll
         for (int r = 0; r < 16; r++) sc[j][r] = 0.f;
     {
-        const float *Aq = Qs + (wave * 32 + l31) * 4 + half; // k = 2kk + half: same quad as 2kk, next element
-        const float *Bk = Ks + l31 * 4 + half;
+        const float *Ak = Ks + l31 * 4 + half;               // k = 2kk + half: same quad as 2kk, next element
+        const float *Bq = Qs + (wave * 32 + l31) * 4 + half;
 #pragma unroll
         for (int kk = 0; kk < HD / 2; kk++) {
-            const float a = Aq[(kk >> 1) * SQ * 4 + ((2 * kk) & 3)];
+            const float bq = Bq[(kk >> 1) * SQ * 4 + ((2 * kk) & 3)];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const float bv = Bk[(kk >> 1) * TT * 4 + ((2 * kk) & 3) + j * 32 * 4];
-                sc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, sc[j], 0, 0, 0);
+                const float ak = Ak[(kk >> 1) * TT * 4 + ((2 * kk) & 3) + j * 32 * 4];
+                sc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ak, bq, sc[j], 0, 0, 0);
             }
         }
     }
-    __syncthreads(); // everyone is done with Qs / Ks: the region becomes the probability panels
-
-    // ---- phase 2: row softmax in registers.  Register r of block j holds row acc_row(r) + 4*half, column j*32 + l31.
-    float *const Ps = smem + wave * (TT * PLD);
-    const int up = (lane & 32) | ((lane & 15) + 16); // the lane holding column + 16 of the same row
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int row = s0 + wave * 32 + acc_row(r) + 4 * half;
-        const float *mrow = nullptr;
-        if (p.mask) mrow = p.mask + (long long)b * p.mask_bs + (long long)(row < p.s ? row : 0) * p.mask_rs;
-        float x[4], mx = -3.40282347e+38f; // f32::MIN (softmax.rs:181)
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int col = j * 32 + l31;
-            float v = sc[j][r] * p.scale;                 // gemm store form: t * alpha
-            if (mrow && col < p.t) v = v + mrow[col];     // `*qk += m`
-            x[j] = v;
-            if (col < p.t) mx = fmaxf(mx, v);
-        }
-#pragma unroll
-        for (int o = 16; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64)); // stays inside the 32-lane half
-        // exp, then the 16-lane ordered partial sums: lane l < 16 adds e[l], e[l+16], e[l+32], ... in that order
-        float a = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int col = j * 32 + l31;
-            const float e = col < p.t ? vm::exp_reduced(x[j] - mx) : 0.f;
-            x[j] = e;
-            const float e_up = __shfl(e, up, 64);
-            a = a + e;    // column j*32 + l      (a masked column adds +0: sums of exps are >= 0, so the bits do not change)
-            a = a + e_up; // column j*32 + l + 16
-        }
-        float ssum = 0.f;
-#pragma unroll
-        for (int k2 = 0; k2 < 16; k2++) ssum = ssum + __shfl(a, (lane & 32) | k2, 64);
-        const float inv = 1.0f / ssum;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            float pr = x[j] * inv;
-            if (p.flush_nan && !(pr == pr)) pr = 0.f;
-            // transposed store: panel[t][row]; columns >= T hold 0 * inv (or NaN when the row is all masked): zero them
-            Ps[(j * 32 + l31) * PLD + acc_row(r) + 4 * half] = (j * 32 + l31 < p.t) ? pr : 0.f;
-        }
-    }
-    // V into LDS
+    __syncthreads(); // Ks is free: park V there ([t][64]) for phase 3
 #pragma unroll
     for (int i = 0; i < TT * 16 / 256; i++) {
         const int f = i * 256 + t, row = f >> 4, dq = f & 15;
         *reinterpret_cast<f32x4 *>(Vs + row * HD + dq * 4) = vreg[i];
     }
-    __syncthreads();
 
-    // ---- phase 3: out[32 rows][64] = P V, k = t in order (columns >= T contribute p = 0 exactly as if absent? no: see below)
-    // Only t < T may enter the chain: an fma with a zero product still leaves the accumulator unchanged (x + 0*v = x for
-    // finite v; V rows >= T are zero-filled, so 0*0), hence looping to the padded TT is bit-neutral.
+    // ---- phase 2: softmax of query row s = s0 + 32*wave + l31, spread over this lane and lane ^ 32.
+    // sc[j][r] is key t = 32j + acc_row(r) + 4*half.
+    const int srow = s0 + wave * 32 + l31;
+    const float *mrow = nullptr;
+    if (p.mask) mrow = p.mask + (long long)b * p.mask_bs + (long long)(srow < p.s ? srow : 0) * p.mask_rs;
+    float mx = -3.40282347e+38f; // f32::MIN (softmax.rs:181)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int tk = 32 * j + acc_row(r) + 4 * half;
+            float v = sc[j][r] * p.scale;               // the GEMM's `t * alpha` store form
+            if (mrow && tk < p.t) v = v + mrow[tk];     // `*qk += m`
+            sc[j][r] = v;
+            if (tk < p.t) mx = fmaxf(mx, v);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    // exp and the 16 ordered partial sums of the reference's 16-lane SIMD order: partial l adds keys l, l+16, l+32, ...
+    // This lane holds l = c + 4*half (registers r = c, c+8 of each block) and l = 8 + c + 4*half (r = 4+c, 12+c).
+    float lo[4] = {0.f, 0.f, 0.f, 0.f}, hi[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int tk = 32 * j + acc_row(r) + 4 * half;
+            sc[j][r] = tk < p.t ? vm::exp_reduced(sc[j][r] - mx) : 0.f; // a masked key adds +0: the sums are >= 0, bits unchanged
+        }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int g = 0; g < 2; g++) // keys 32j + 16g + ...: ascending key order within every partial
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                lo[c] = lo[c] + sc[j][8 * g + c];
+                hi[c] = hi[c] + sc[j][8 * g + 4 + c];
+            }
+    // fold partials 0..15 left to right: 0-3 live in half 0 (lo), 4-7 in half 1 (lo), 8-11 in half 0 (hi), 12-15 in half 1 (hi)
+    auto add4 = [](float x, const float (&a)[4]) { return (((x + a[0]) + a[1]) + a[2]) + a[3]; };
+    float run = add4(0.f, lo);                      // valid in half 0
+    run = add4(__shfl_xor(run, 32, 64), lo);        // valid in half 1
+    run = add4(__shfl_xor(run, 32, 64), hi);        // valid in half 0
+    run = add4(__shfl_xor(run, 32, 64), hi);        // valid in half 1: the row sum
+    const float other = __shfl_xor(run, 32, 64);
+    const float ssum = half ? run : other;
+    const float inv = 1.0f / ssum;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int tk = 32 * j + acc_row(r) + 4 * half;
+            float pr = sc[j][r] * inv;
+            if (p.flush_nan && !(pr == pr)) pr = 0.f;
+            sc[j][r] = tk < p.t ? pr : 0.f; // padded keys: exactly 0 (also when the row is all masked and inv is NaN)
+        }
+    // re-pair into MFMA A operands: after the swaps register 4g+c holds keys (8g+c | 8g+c+1) in (half 0 | half 1) and
+    // register 4g+c+1 holds keys (8g+4+c | 8g+4+c+1), c in {0, 2}: k-pairs in ascending key order.
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+#pragma unroll
+            for (int c = 0; c < 4; c += 2) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, (float)sc[j][4 * g + c]),
+                                                                 __builtin_bit_cast(unsigned, (float)sc[j][4 * g + c + 1]), false, false);
+                sc[j][4 * g + c] = __builtin_bit_cast(float, sw[0]);
+                sc[j][4 * g + c + 1] = __builtin_bit_cast(float, sw[1]);
+            }
+    __syncthreads(); // V is in LDS
+
+    // ---- phase 3: out[s][dv] = sum_t P[s][t] V[t][dv], t ascending (padded keys are 0 * 0: bit-neutral)
     f32x16 oc[2];
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+    for (int jn = 0; jn < 2; jn++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) oc[j][r] = 0.f;
+        for (int r = 0; r < 16; r++) oc[jn][r] = 0.f;
     {
-        const float *Ap = Ps + half * PLD + l31;
         const float *Bv = Vs + half * HD + l31;
-        const int kend = (p.t + 1) / 2;
-        for (int kk = 0; kk < kend; kk++) {
-            const float a = Ap[2 * kk * PLD];
 #pragma unroll
-            for (int j = 0; j < 2; j++) oc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bv[2 * kk * HD + j * 32], oc[j], 0, 0, 0);
-        }
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int kl = 0; kl < 16; kl++) { // k-pair kl of block j: keys 32j + 2kl, 32j + 2kl + 1
+                const int t0 = 2 * kl, g = t0 >> 3, off = t0 & 7;
+                const float a = sc[j][off < 4 ? 4 * g + off : 4 * g + (off - 4) + 1];
+#pragma unroll
+                for (int jn = 0; jn < 2; jn++) oc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bv[(32 * j + t0) * HD + jn * 32], oc[jn], 0, 0, 0);
+            }
     }
+    // C layout of out: lane column = dv (jn*32 + l31), register r = query row acc_row(r) + 4*half of this wave's 32
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+    for (int jn = 0; jn < 2; jn++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int row = s0 + wave * 32 + acc_row(r) + 4 * half;
-            if (row < p.s) ob[(long long)row * p.o_rs + j * 32 + l31] = oc[j][r];
+            if (row < p.s) ob[(long long)row * p.o_rs + jn * 32 + l31] = oc[jn][r];
         }
 }
 
