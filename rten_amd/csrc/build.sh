@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../librten_hip.so
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result ${RTEN_EXTRA_FLAGS:-}"
 mkdir -p ../_build
 pids=()
 for f in *.hip; do
