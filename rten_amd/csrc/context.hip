@@ -31,7 +31,11 @@ void *rten_scratch(rten_hip_ctx *ctx, size_t bytes) {
         ctx->scratch = nullptr;
         ctx->scratch_bytes = 0;
     }
+    // Grow rarely: a captured hipGraph holds the scratch pointer, so a later, larger request must not free the buffer a
+    // live graph replays from in the common case.  288 GB of HBM make a generous floor cheap.
     size_t want = bytes + bytes / 4;
+    const size_t floor_bytes = (size_t)512 << 20;
+    if (want < floor_bytes) want = floor_bytes;
     if (hipMalloc(&ctx->scratch, want) != hipSuccess) return nullptr;
     ctx->scratch_bytes = want;
     return ctx->scratch;
