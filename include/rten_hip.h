@@ -214,6 +214,19 @@ int32_t rten_hip_conv2d_int8(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc 
                              const void *x_zp, const void *w_zp, const float *scale, const float *bias,
                              const float *residual, uint32_t flags, void *y);
 
+/* Producer-side statistics: a ConvIntegerToFloat whose output is quantized next (DynamicQuantizeLinear -> ConvInteger, the
+ * shape of every layer of an ort-quantized CNN) accumulates the output's min / max in its epilogue, and the quantize step
+ * reads them instead of sweeping the tensor a first time.  Same statistics (min / max are order independent), same bits.
+ * `stats` is a device buffer of rten_hip_minmax_stats_bytes(), reset before each producer. */
+size_t rten_hip_minmax_stats_bytes(void);
+int32_t rten_hip_minmax_stats_reset(rten_hip_ctx *ctx, void *stats);
+int32_t rten_hip_conv2d_int8_stats(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *desc, const void *x, const void *w,
+                                   const void *x_zp, const void *w_zp, const float *scale, const float *bias,
+                                   const float *residual, uint32_t flags, void *y, void *stats);
+int32_t rten_hip_dynamic_quantize_linear_staged_stats(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *desc, const float *x,
+                                                      const void *stats, void *staged, float *scale, uint8_t *zero_point,
+                                                      const float *mul_by, float *product);
+
 /* ---- DynamicQuantizeLinear, src/ops/quantize.rs:352-436 + rten-vecmath/src/quantize.rs:39-79 ---- */
 int32_t rten_hip_dynamic_quantize_linear(rten_hip_ctx *ctx, int64_t n, const float *x, uint8_t *y, float *scale,
                                          uint8_t *zero_point);

@@ -29,7 +29,7 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 int32_t rten_i8_fast_gemm(rten_hip_ctx *ctx, const rten_hip_gemm_int8_desc *d, const void *a, const void *b, const void *a_zp,
                           const void *b_zp, const float *scale, void *c);
 int32_t rten_i8_fast_conv(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di, const void *x, const void *w, const void *x_zp,
-                          const void *w_zp, const float *scale, const float *bias, const float *residual, uint32_t flags, void *y);
+                          const void *w_zp, const float *scale, const float *bias, const float *residual, uint32_t flags, void *y, void *stats);
 
 namespace {
 
@@ -290,9 +290,30 @@ RTEN_EXPORT int32_t rten_hip_gemm_int8(rten_hip_ctx *ctx, const rten_hip_gemm_in
     return launch_i8(ctx, g, 1);
 }
 
+namespace {
+int32_t conv2d_int8_impl(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di, const void *x, const void *w, const void *x_zp, const void *w_zp,
+                         const float *scale, const float *bias, const float *residual, uint32_t flags, void *y, void *stats);
+}
+
 RTEN_EXPORT int32_t rten_hip_conv2d_int8(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di, const void *x,
                                          const void *w, const void *x_zp, const void *w_zp, const float *scale,
                                          const float *bias, const float *residual, uint32_t flags, void *y) {
+    return conv2d_int8_impl(ctx, di, x, w, x_zp, w_zp, scale, bias, residual, flags, y, nullptr);
+}
+
+// Same, and the float outputs' min/max are accumulated into `stats` (rten_hip_minmax_stats_reset first) for the
+// DynamicQuantizeLinear that quantizes them next: that operator's first sweep disappears.  Needs the staged kernel
+// (RTEN_HIP_ERR_UNSUPPORTED otherwise: call rten_hip_conv2d_int8 and quantize with the two-sweep form).
+RTEN_EXPORT int32_t rten_hip_conv2d_int8_stats(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di, const void *x,
+                                               const void *w, const void *x_zp, const void *w_zp, const float *scale,
+                                               const float *bias, const float *residual, uint32_t flags, void *y, void *stats) {
+    if (!stats || !scale) return RTEN_HIP_ERR_INVALID_VALUE;
+    return conv2d_int8_impl(ctx, di, x, w, x_zp, w_zp, scale, bias, residual, flags, y, stats);
+}
+
+namespace {
+int32_t conv2d_int8_impl(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di, const void *x, const void *w, const void *x_zp, const void *w_zp,
+                         const float *scale, const float *bias, const float *residual, uint32_t flags, void *y, void *stats) {
     RTEN_CHECK_CTX(ctx);
     if (!di) return RTEN_HIP_ERR_INVALID_VALUE;
     const rten_hip_conv2d_desc *d = &di->conv;
@@ -314,10 +335,11 @@ RTEN_EXPORT int32_t rten_hip_conv2d_int8(rten_hip_ctx *ctx, const rten_hip_conv2
     const long long HW = (long long)d->h * d->w;
     if ((long long)d->n * d->c * HW >= (1ll << 31) || (long long)d->n * d->o * P >= (1ll << 31))
         return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "conv: tensors above 2^31 elements are not supported");
-    if (ctx->int8_path == 0 || di->weights_packed || di->x_staged) {
-        const int32_t rc = rten_i8_fast_conv(ctx, di, x, w, x_zp, w_zp, scale, bias, residual, flags, y);
+    if (ctx->int8_path == 0 || di->weights_packed || di->x_staged || stats) {
+        const int32_t rc = rten_i8_fast_conv(ctx, di, x, w, x_zp, w_zp, scale, bias, residual, flags, y, stats);
         if (rc != RTEN_HIP_ERR_UNSUPPORTED) return rc;
     }
+    if (stats) return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "conv_int8_stats: geometry not covered by the staged kernel");
     I8Args g = {};
     // kernel is the LHS (conv.rs:461-474): A = W[o][k], B = im2col(x)
     g.A = (const uint8_t *)w; g.B = (const uint8_t *)x; g.C = y;
@@ -345,6 +367,7 @@ RTEN_EXPORT int32_t rten_hip_conv2d_int8(rten_hip_ctx *ctx, const rten_hip_conv2
     g.pad_mode = di->pad_mode;
     return launch_i8(ctx, g, d->groups);
 }
+} // namespace
 
 // 0 = automatic (k-contiguous staging + LDS-DMA kernel whenever it covers the call), 1 = generic kernel only.
 RTEN_EXPORT int32_t rten_hip_set_int8_path(rten_hip_ctx *ctx, int32_t mode) {

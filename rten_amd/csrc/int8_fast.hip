@@ -47,6 +47,7 @@ struct FastArgs {
     int Pn;
     int a_signed, b_signed, a_zp_len, b_zp_len, scale_len, relu, need_csum;
     int scale_per_row; // conv: scale[m] per output channel instead of scale[0] / scale[n]
+    unsigned *stats;   // optional: min/max of the f32 outputs, accumulated for the DynamicQuantizeLinear that consumes them
     int tiles_m, tiles_n;
     // conv geometry (padded image)
     int conv, OW, sy, sx, Hp, Wp, Cp, KH, KW, dy, dx;
@@ -151,7 +152,8 @@ __global__ __launch_bounds__(256) void i8_quantize_stage_kernel(const float *__r
                                                                int C, int H, int W, int Hp, int Wp, int Cp, int pt, int pl, int pad_mode,
                                                                float *scale_out, uint8_t *zp_out, const float *mul_by, float *product_out) {
     float x_min, x_max;
-    dql::block_minmax(ws, nparts, x_min, x_max);
+    if (nparts < 0) dql::block_minmax_slots(reinterpret_cast<const unsigned *>(ws), x_min, x_max); // producer-accumulated statistics
+    else dql::block_minmax(ws, nparts, x_min, x_max);
     const dql::QParams q = dql::dql_params(x_min, x_max);
     if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
         *scale_out = q.scale;
@@ -305,6 +307,7 @@ __global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p)
     const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void *)(p.res ? (const void *)p.res : (const void *)p.C), 0, 0x7ffffffc, 0x00020000);
     const unsigned rs4 = (unsigned)p.c_rs << 2;
     const int mb = m0 + wm0 + 4 * half;
+    float st_mn = __builtin_inff(), st_mx = -__builtin_inff(); // output statistics for the consuming DynamicQuantizeLinear
     unsigned colv[TN], bzv[TN], csv[TN];
     float scv[TN];
     bool cokv[TN];
@@ -367,6 +370,11 @@ __global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p)
 #pragma unroll
                         for (int q = 0; q < 8; q++) f[q] = vm::relu(f[q]);
                     }
+                    if (p.stats) { // fminf / fmaxf drop NaNs like the reference's min/max sweep (min_max.rs:27-30)
+#pragma unroll
+                        for (int q = 0; q < 8; q++)
+                            if (mok[q] && cokv[j]) { st_mn = fminf(f[q], st_mn); st_mx = fmaxf(f[q], st_mx); }
+                    }
 #pragma unroll
                     for (int q = 0; q < 8; q++) {
                         const float x = f[q];
@@ -380,6 +388,15 @@ __global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p)
                     }
                 }
             }
+        }
+    }
+    if (p.stats) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { st_mn = fminf(st_mn, __shfl_xor(st_mn, o, 64)); st_mx = fmaxf(st_mx, __shfl_xor(st_mx, o, 64)); }
+        if (lane == 0) {
+            const unsigned slot = (blockIdx.x * 4u + (unsigned)wq) % (unsigned)dql::kStatSlots;
+            atomicMin(&p.stats[slot], dql::f2ord(st_mn));
+            atomicMax(&p.stats[dql::kStatSlots + slot], dql::f2ord(st_mx));
         }
     }
 }
@@ -548,8 +565,33 @@ RTEN_EXPORT int32_t rten_hip_dynamic_quantize_linear_staged(rten_hip_ctx *ctx, c
     return RTEN_HIP_OK;
 }
 
+RTEN_EXPORT size_t rten_hip_minmax_stats_bytes(void) { return 2 * dql::kStatSlots * sizeof(unsigned); }
+
+RTEN_EXPORT int32_t rten_hip_minmax_stats_reset(rten_hip_ctx *ctx, void *stats) {
+    RTEN_CHECK_CTX(ctx);
+    if (!stats) return RTEN_HIP_ERR_INVALID_VALUE;
+    RTEN_HIP_TRY(ctx, hipMemsetAsync(stats, 0xff, dql::kStatSlots * sizeof(unsigned), ctx->stream));                                // minima: +inf side
+    RTEN_HIP_TRY(ctx, hipMemsetAsync((char *)stats + dql::kStatSlots * sizeof(unsigned), 0, dql::kStatSlots * sizeof(unsigned), ctx->stream)); // maxima
+    return RTEN_HIP_OK;
+}
+
+RTEN_EXPORT int32_t rten_hip_dynamic_quantize_linear_staged_stats(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di, const float *x, const void *stats,
+                                                                  void *staged, float *scale, uint8_t *zero_point, const float *mul_by, float *product) {
+    RTEN_CHECK_CTX(ctx);
+    if (!di || !x || !stats || !staged || !scale || !zero_point || (mul_by && !product)) return RTEN_HIP_ERR_INVALID_VALUE;
+    const ConvGeom g = conv_geom(di);
+    if (!g.ok || di->x_signed) return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "quantize_staged: geometry not covered by the staged kernel (staged_bytes == 0)");
+    const rten_hip_conv2d_desc *d = &di->conv;
+    ProfScope ps(ctx, "dynamic_quantize_linear_staged_stats", 0.0, 4.0 * d->n * d->c * (double)d->h * d->w + (double)g.img);
+    hipLaunchKernelGGL(i8_quantize_stage_kernel, dim3((unsigned)((g.Hp * g.Wp + 63) / 64), (unsigned)d->n, (unsigned)((g.Cp + 63) / 64)), dim3(256), 0, ctx->stream,
+                       x, (const float *)stats, -1, (uint8_t *)staged, d->c, d->h, d->w, g.Hp, g.Wp, g.Cp, d->pads[0], d->pads[1], di->pad_mode, scale, zero_point,
+                       mul_by, product);
+    RTEN_LAUNCH_CHECK(ctx, "i8_quantize_stage_kernel launch");
+    return RTEN_HIP_OK;
+}
+
 int32_t rten_i8_fast_conv(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di, const void *x, const void *w, const void *x_zp,
-                          const void *w_zp, const float *scale, const float *bias, const float *residual, uint32_t flags, void *y) {
+                          const void *w_zp, const float *scale, const float *bias, const float *residual, uint32_t flags, void *y, void *stats) {
     const rten_hip_conv2d_desc *d = &di->conv;
     const ConvGeom cg = conv_geom(di);
     if (!cg.ok)
@@ -591,6 +633,7 @@ int32_t rten_i8_fast_conv(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di
     g.a_zp_len = di->w_zp_len; g.b_zp_len = x_zp ? 1 : 0;
     g.scale_len = scale ? 1 : 0;
     g.scale_per_row = (scale && di->scale_len > 1) ? 1 : 0;
+    g.stats = scale ? (unsigned *)stats : nullptr;
     g.need_csum = (di->w_zp_len != 0 || !di->w_signed) ? 1 : 0; // weight zero point may be non-zero in the signed domain
     g.conv = 1; g.OW = d->out_w; g.sy = d->stride_h; g.sx = d->stride_w; g.Hp = cg.Hp; g.Wp = cg.Wp; g.Cp = cg.Cp;
     g.KH = d->kh; g.KW = d->kw; g.dy = d->dil_h; g.dx = d->dil_w;

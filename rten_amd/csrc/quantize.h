@@ -65,6 +65,21 @@ __device__ __forceinline__ void block_minmax(const float *__restrict__ ws, int n
     mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
 }
 
+// Min/max statistics accumulated by a producing kernel's epilogue: kStatSlots ordered-uint minima followed by kStatSlots
+// ordered-uint maxima (reset to 0xffffffff / 0 by rten_hip_minmax_stats_reset; producers hit slot = id % kStatSlots).
+constexpr int kStatSlots = 256;
+__device__ __forceinline__ void block_minmax_slots(const unsigned *__restrict__ stats, float &mn, float &mx) {
+    __shared__ float s_mn[4], s_mx[4];
+    float a = __builtin_inff(), b = -__builtin_inff();
+    if (threadIdx.x < kStatSlots) { a = ord2f(stats[threadIdx.x]); b = ord2f(stats[kStatSlots + threadIdx.x]); }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { a = fminf(a, __shfl_xor(a, o, 64)); b = fmaxf(b, __shfl_xor(b, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6] = a; s_mx[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    mn = fminf(fminf(s_mn[0], s_mn[1]), fminf(s_mn[2], s_mn[3]));
+    mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
+}
+
 } // namespace dql
 
 // Enqueues the min/max sweep of x[0..n): one {min, max} pair per workgroup at the start of the context scratch (no

@@ -29,6 +29,8 @@ class ResNet50Int8(ResNet50):
     def __init__(self, ctx, batch, weights=None, pad_mode=L.PAD_RAW0_I8, **kw):
         super().__init__(ctx, batch, weights, **kw)
         self.pad_mode = pad_mode
+        self.producer_stats = True   # conv epilogues accumulate the min/max the next DynamicQuantizeLinear needs
+        self.stats = {}
         self.q = quantize_weights(self.weights)
         n_max = max(int(np.prod(s)) for s in self.shapes.values())
         self.xq = DeviceTensor(ctx, (n_max,), np.uint8)
@@ -74,13 +76,25 @@ class ResNet50Int8(ResNet50):
         ctx = self.ctx
         name = l["name"]
         src = self._act(l["src"])
-        # DynamicQuantizeLinear, writing the codes straight into the consumer's staged layout
-        # ... and the Mul(x_scale, w_scale) that feeds the conv's cast_scale
-        ctx.call("rten_hip_dynamic_quantize_linear_staged", C.byref(self.idesc[name]), src.vp, self.staged.vp, self.xs.vp, self.xz.vp,
-                 self.ws[name].vp, self.sc.vp)
+        d = self.idesc[name]
+        # DynamicQuantizeLinear, writing the codes straight into the consumer's staged layout, and the Mul(x_scale, w_scale)
+        # that feeds the conv's cast_scale.  When the producing conv left min/max statistics, the first sweep is skipped.
+        st = self.stats.get(l["src"]) if self.producer_stats else None
+        if st is not None:
+            ctx.call("rten_hip_dynamic_quantize_linear_staged_stats", C.byref(d), src.vp, st.vp, self.staged.vp, self.xs.vp, self.xz.vp,
+                     self.ws[name].vp, self.sc.vp)
+        else:
+            ctx.call("rten_hip_dynamic_quantize_linear_staged", C.byref(d), src.vp, self.staged.vp, self.xs.vp, self.xz.vp,
+                     self.ws[name].vp, self.sc.vp)
         flags = (L.CONV_RELU if l["relu"] else 0) | (L.CONV_RESIDUAL if l["res"] else 0)
-        ctx.call("rten_hip_conv2d_int8", C.byref(self.idesc[name]), self.staged.vp, self.wq[name].vp, self.xz.vp, None, self.sc.vp,
-                 self.bq[name].vp, self._act(l["res"]).vp if l["res"] else None, flags, self._act(l["dst"]).vp)
+        args = (C.byref(d), self.staged.vp, self.wq[name].vp, self.xz.vp, None, self.sc.vp, self.bq[name].vp,
+                self._act(l["res"]).vp if l["res"] else None, flags, self._act(l["dst"]).vp)
+        if self.producer_stats:
+            out_st = self.stats.setdefault(l["dst"], DeviceTensor(ctx, (ctx.lib.rten_hip_minmax_stats_bytes(),), np.uint8))
+            ctx.call("rten_hip_minmax_stats_reset", out_st.vp)
+            ctx.call("rten_hip_conv2d_int8_stats", *args, out_st.vp)
+        else:
+            ctx.call("rten_hip_conv2d_int8", *args)
 
     def forward(self):
         ctx = self.ctx

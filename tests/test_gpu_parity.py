@@ -616,6 +616,11 @@ def test_resnet50_int8_end_to_end_bit_exact(ctx):
     net.logits.upload(np.zeros_like(got))
     net.run()
     bits_equal(net.logits.numpy(), want)
+    # two-sweep DynamicQuantizeLinear everywhere (no producer-side statistics): same bits
+    net.graph, net.producer_stats = None, False
+    net.logits.upload(np.zeros_like(got))
+    net.forward()
+    bits_equal(net.logits.numpy(), want)
     # the generic int8 kernel gives the same bits through the plain (unpacked) operator path
     ctx.call("rten_hip_set_int8_path", 1)
     try:
