@@ -30,7 +30,7 @@ class ResNet50Int8(ResNet50):
         super().__init__(ctx, batch, weights, **kw)
         self.pad_mode = pad_mode
         self.producer_stats = True   # conv epilogues accumulate the min/max the next DynamicQuantizeLinear needs
-        self.stats = {}
+        self.stats = {l["dst"]: DeviceTensor(ctx, (ctx.lib.rten_hip_minmax_stats_bytes(),), np.uint8) for l in self.specs}
         self.q = quantize_weights(self.weights)
         n_max = max(int(np.prod(s)) for s in self.shapes.values())
         self.xq = DeviceTensor(ctx, (n_max,), np.uint8)
@@ -90,7 +90,7 @@ class ResNet50Int8(ResNet50):
         args = (C.byref(d), self.staged.vp, self.wq[name].vp, self.xz.vp, None, self.sc.vp, self.bq[name].vp,
                 self._act(l["res"]).vp if l["res"] else None, flags, self._act(l["dst"]).vp)
         if self.producer_stats:
-            out_st = self.stats.setdefault(l["dst"], DeviceTensor(ctx, (ctx.lib.rten_hip_minmax_stats_bytes(),), np.uint8))
+            out_st = self.stats[l["dst"]]
             ctx.call("rten_hip_minmax_stats_reset", out_st.vp)
             ctx.call("rten_hip_conv2d_int8_stats", *args, out_st.vp)
         else:
