@@ -217,9 +217,10 @@ int32_t rten_hip_conv2d_int8(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc 
 /* Producer-side statistics: a ConvIntegerToFloat whose output is quantized next (DynamicQuantizeLinear -> ConvInteger, the
  * shape of every layer of an ort-quantized CNN) accumulates the output's min / max in its epilogue, and the quantize step
  * reads them instead of sweeping the tensor a first time.  Same statistics (min / max are order independent), same bits.
- * `stats` is a device buffer of rten_hip_minmax_stats_bytes(), reset before each producer. */
+ * `stats` is a device buffer of rten_hip_minmax_stats_bytes(), reset before its producer runs; `count` consecutive
+ * buffers (e.g. one per layer of a model, in one allocation) are reset by a single launch. */
 size_t rten_hip_minmax_stats_bytes(void);
-int32_t rten_hip_minmax_stats_reset(rten_hip_ctx *ctx, void *stats);
+int32_t rten_hip_minmax_stats_reset(rten_hip_ctx *ctx, void *stats, int32_t count);
 int32_t rten_hip_conv2d_int8_stats(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *desc, const void *x, const void *w,
                                    const void *x_zp, const void *w_zp, const float *scale, const float *bias,
                                    const float *residual, uint32_t flags, void *y, void *stats);

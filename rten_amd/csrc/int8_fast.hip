@@ -567,11 +567,19 @@ RTEN_EXPORT int32_t rten_hip_dynamic_quantize_linear_staged(rten_hip_ctx *ctx, c
 
 RTEN_EXPORT size_t rten_hip_minmax_stats_bytes(void) { return 2 * dql::kStatSlots * sizeof(unsigned); }
 
-RTEN_EXPORT int32_t rten_hip_minmax_stats_reset(rten_hip_ctx *ctx, void *stats) {
+namespace {
+__global__ void stats_reset_kernel(unsigned *stats, int count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x; // one thread per slot word
+    if (i < count * 2 * dql::kStatSlots) stats[i] = (i % (2 * dql::kStatSlots)) < dql::kStatSlots ? 0xffffffffu : 0u; // minima | maxima
+}
+} // namespace
+
+RTEN_EXPORT int32_t rten_hip_minmax_stats_reset(rten_hip_ctx *ctx, void *stats, int32_t count) {
     RTEN_CHECK_CTX(ctx);
-    if (!stats) return RTEN_HIP_ERR_INVALID_VALUE;
-    RTEN_HIP_TRY(ctx, hipMemsetAsync(stats, 0xff, dql::kStatSlots * sizeof(unsigned), ctx->stream));                                // minima: +inf side
-    RTEN_HIP_TRY(ctx, hipMemsetAsync((char *)stats + dql::kStatSlots * sizeof(unsigned), 0, dql::kStatSlots * sizeof(unsigned), ctx->stream)); // maxima
+    if (!stats || count < 1) return RTEN_HIP_ERR_INVALID_VALUE;
+    const int n = count * 2 * dql::kStatSlots;
+    hipLaunchKernelGGL(stats_reset_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (unsigned *)stats, count);
+    RTEN_LAUNCH_CHECK(ctx, "stats_reset_kernel launch");
     return RTEN_HIP_OK;
 }
 

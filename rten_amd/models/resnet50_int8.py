@@ -30,7 +30,9 @@ class ResNet50Int8(ResNet50):
         super().__init__(ctx, batch, weights, **kw)
         self.pad_mode = pad_mode
         self.producer_stats = True   # conv epilogues accumulate the min/max the next DynamicQuantizeLinear needs
-        self.stats = {l["dst"]: DeviceTensor(ctx, (ctx.lib.rten_hip_minmax_stats_bytes(),), np.uint8) for l in self.specs}
+        sb = ctx.lib.rten_hip_minmax_stats_bytes()
+        self.stats_arena = DeviceTensor(ctx, (sb * len(self.specs),), np.uint8)  # one statistics block per conv output
+        self.stats = {l["dst"]: C.c_void_p(self.stats_arena.ptr + i * sb) for i, l in enumerate(self.specs)}
         self.q = quantize_weights(self.weights)
         n_max = max(int(np.prod(s)) for s in self.shapes.values())
         self.xq = DeviceTensor(ctx, (n_max,), np.uint8)
@@ -81,7 +83,7 @@ class ResNet50Int8(ResNet50):
         # that feeds the conv's cast_scale.  When the producing conv left min/max statistics, the first sweep is skipped.
         st = self.stats.get(l["src"]) if self.producer_stats else None
         if st is not None:
-            ctx.call("rten_hip_dynamic_quantize_linear_staged_stats", C.byref(d), src.vp, st.vp, self.staged.vp, self.xs.vp, self.xz.vp,
+            ctx.call("rten_hip_dynamic_quantize_linear_staged_stats", C.byref(d), src.vp, st, self.staged.vp, self.xs.vp, self.xz.vp,
                      self.ws[name].vp, self.sc.vp)
         else:
             ctx.call("rten_hip_dynamic_quantize_linear_staged", C.byref(d), src.vp, self.staged.vp, self.xs.vp, self.xz.vp,
@@ -90,14 +92,14 @@ class ResNet50Int8(ResNet50):
         args = (C.byref(d), self.staged.vp, self.wq[name].vp, self.xz.vp, None, self.sc.vp, self.bq[name].vp,
                 self._act(l["res"]).vp if l["res"] else None, flags, self._act(l["dst"]).vp)
         if self.producer_stats:
-            out_st = self.stats[l["dst"]]
-            ctx.call("rten_hip_minmax_stats_reset", out_st.vp)
-            ctx.call("rten_hip_conv2d_int8_stats", *args, out_st.vp)
+            ctx.call("rten_hip_conv2d_int8_stats", *args, self.stats[l["dst"]])
         else:
             ctx.call("rten_hip_conv2d_int8", *args)
 
     def forward(self):
         ctx = self.ctx
+        if self.producer_stats:
+            ctx.call("rten_hip_minmax_stats_reset", self.stats_arena.vp, len(self.specs))  # one launch for every layer's block
         self._conv(self.specs[0])
         ctx.call("rten_hip_max_pool2d_f32", C.byref(self.pool_desc), self.bufs["stem"].vp, self.bufs["pool"].vp)
         for l in self.specs[1:]:
