@@ -893,7 +893,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
                     for (int i = 0; i < TM; i++)
 #pragma unroll
                         for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[i][j], 0, 0, 0);
-            } else if (!(ABLATE(p) & 2)) compute_tile(stage);
+            } else if (!(ABLATE(p) & 2)) compute_tile(stage); // (s_setprio around the matrix phase: measured, no gain)
             stage = stage == NSTAGE - 1 ? 0 : stage + 1;
         }
         if (SPLIT || (MIXED && grp >= 0)) {
