@@ -741,24 +741,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
     // im2col LUT entries (scalar loads) for the tile whose DMA is issued NEXT
     typedef const __attribute__((address_space(4))) i32x2 *lut_ptr_t;
     constexpr int LROWS = BK / 4; // rows of a tile handled by one wave (NBG / (BN/64))
-    // lutE: entries of the tile issued next; lutN: entries fetched at the TOP of an iteration for the tile after that.
-    // The scalar load is issued before the vmcnt wait / barrier so that it has landed long before the operand ds_reads
-    // need an lgkmcnt wait (SMEM and LDS share that counter: an s_load in flight turns every LDS wait into a full wait).
-    [[maybe_unused]] i32x2 lutE[LROWS], lutN[LROWS];
+    [[maybe_unused]] i32x2 lutE[LROWS];
     [[maybe_unused]] auto fetch_lut = [&](int kt) {
         if constexpr (IM2COL) {
             const int krow0 = kt * BK + wave * LROWS;
             const lut_ptr_t lc = (lut_ptr_t)(unsigned long long)p.lut;
 #pragma unroll
             for (int j = 0; j < LROWS; j++) lutE[j] = lc[krow0 + j];
-        }
-    };
-    [[maybe_unused]] auto fetch_lut_next = [&](int kt) {
-        if constexpr (IM2COL) {
-            const int krow0 = kt * BK + wave * LROWS;
-            const lut_ptr_t lc = (lut_ptr_t)(unsigned long long)p.lut;
-#pragma unroll
-            for (int j = 0; j < LROWS; j++) lutN[j] = lc[krow0 + j];
         }
     };
 
@@ -891,11 +880,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
     for (int blk = blk0; blk < blk1; blk++) {
         const int kt_end = (MULTI_KC || SPLIT) ? ((blk + 1) * KC_TILES < nk ? (blk + 1) * KC_TILES : nk) : nk;
         for (int kt = blk * KC_TILES; kt < kt_end; kt++) {
-            fetch_lut_next(kt + NSTAGE);
             wait_vmcnt<PER_TILE *(NSTAGE - 2)>(); // this wave's DMA for tile kt has landed; NSTAGE-2 later tiles stay in flight
             if (!(ABLATE(p) & 8)) __builtin_amdgcn_s_barrier(); // ... and everyone else's; all waves are done reading the stage of tile kt-1
             const int stp = stage == 0 ? NSTAGE - 1 : stage - 1; // (kt + NSTAGE - 1) % NSTAGE: the stage tile kt-1 used
             if (!(ABLATE(p) & 1)) issue_tile(kt + NSTAGE - 1, stp);
+            fetch_lut(kt + NSTAGE);
             if (ABLATE(p) & 16) { // ablation: MFMAs on register operands only (no ds_read)
                 float fa = (float)kt, fb = (float)lane;
 #pragma unroll
@@ -905,10 +894,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
 #pragma unroll
                         for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[i][j], 0, 0, 0);
             } else if (!(ABLATE(p) & 2)) compute_tile(stage); // (s_setprio around the matrix phase: measured, no gain)
-            if constexpr (IM2COL) {
-#pragma unroll
-                for (int j = 0; j < LROWS; j++) lutE[j] = lutN[j];
-            }
             stage = stage == NSTAGE - 1 ? 0 : stage + 1;
         }
         if (SPLIT || (MIXED && grp >= 0)) {
