@@ -247,6 +247,11 @@ int32_t rten_hip_softmax_f32(rten_hip_ctx *ctx, int64_t rows, int32_t cols, cons
 int32_t rten_hip_layer_norm_f32(rten_hip_ctx *ctx, int64_t rows, int32_t cols, const float *x, const float *gamma,
                                 const float *beta, float gamma_scalar, float beta_scalar, float epsilon,
                                 float *y);
+/* LayerNormalization(x + addend): the Add -> LayerNormalization pair of every transformer block as one kernel (the sum is
+ * formed with the same f32 add and never written to memory; bit-identical to the two operators).  y may alias x / addend. */
+int32_t rten_hip_add_layer_norm_f32(rten_hip_ctx *ctx, int64_t rows, int32_t cols, const float *x, const float *addend,
+                                    const float *gamma, const float *beta, float gamma_scalar, float beta_scalar,
+                                    float epsilon, float *y);
 /* BatchNormalization (inference), src/ops/norm.rs:194-224 */
 int32_t rten_hip_batch_norm_f32(rten_hip_ctx *ctx, int32_t n, int32_t c, int64_t inner, const float *x,
                                 const float *scale, const float *bias, const float *mean, const float *var,

@@ -168,24 +168,28 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void layer_norm_kernel(int64_t
                                                                          const float *__restrict__ gamma,
                                                                          const float *__restrict__ beta,
                                                                          float gamma_scalar, float beta_scalar,
-                                                                         float eps, float *__restrict__ y) {
+                                                                         float eps, const float *addend, float *y) {
+    // addend != nullptr: the Add that precedes the LayerNormalization in transformer blocks, fused (x + addend is formed
+    // once, with the same single f32 add, and never written to memory).  y may alias x or addend: a wave reads its whole
+    // row before it stores.
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float *xr = x + row * cols;
+    const float *ar = addend ? addend + row * cols : nullptr;
     float *yr = y + row * cols;
     [[maybe_unused]] float v[CH > 0 ? CH : 1];
     if constexpr (CH > 0) {
 #pragma unroll
         for (int c = 0; c < CH; c++) {
             const int i = c * 64 + lane;
-            v[c] = i < cols ? xr[i] : 0.f;
+            v[c] = i < cols ? (ar ? xr[i] + ar[i] : xr[i]) : 0.f;
         }
     }
     // element fetch by index for the ordered reduction: register-resident rows are indexed through
     // their owning lane (i % 64 == this lane for the unrolled part; the <64-element remainder needs a
     // cross-lane read, served from global/L1 instead of a dynamic register index).
-    auto get = [&](int i) -> float { return xr[i]; };
+    auto get = [&](int i) -> float { return ar ? xr[i] + ar[i] : xr[i]; };
     float mean, var;
     if constexpr (CH > 0) {
         // Same order as simd16_reduce, but the full-chunk part reads registers.
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void layer_norm_kernel(int64_t
             if (i < cols) yr[i] = norm(v[c], i);
         }
     } else {
-        for (int i = lane; i < cols; i += 64) yr[i] = norm(xr[i], i);
+        for (int i = lane; i < cols; i += 64) yr[i] = norm(get(i), i);
     }
 }
 
@@ -276,16 +280,15 @@ RTEN_EXPORT int32_t rten_hip_softmax_f32(rten_hip_ctx *ctx, int64_t rows, int32_
     return RTEN_HIP_OK;
 }
 
-RTEN_EXPORT int32_t rten_hip_layer_norm_f32(rten_hip_ctx *ctx, int64_t rows, int32_t cols, const float *x,
-                                            const float *gamma, const float *beta, float gamma_scalar,
-                                            float beta_scalar, float epsilon, float *y) {
+static int32_t layer_norm_launch(rten_hip_ctx *ctx, int64_t rows, int32_t cols, const float *x, const float *addend, const float *gamma,
+                                 const float *beta, float gamma_scalar, float beta_scalar, float epsilon, float *y) {
     RTEN_CHECK_CTX(ctx);
     if (rows < 0 || cols < 0) return RTEN_HIP_ERR_INVALID_VALUE;
     if (rows == 0 || cols == 0) return RTEN_HIP_OK;
     if (!x || !y) return RTEN_HIP_ERR_INVALID_VALUE;
     const dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(64 * ROWS_PER_BLOCK);
-    ProfScope ps(ctx, "layer_norm_f32", 0.0, 8.0 * rows * cols);
-#define LN_LAUNCH(CH) hipLaunchKernelGGL((layer_norm_kernel<CH>), grid, block, 0, ctx->stream, rows, cols, x, gamma, beta, gamma_scalar, beta_scalar, epsilon, y)
+    ProfScope ps(ctx, addend ? "add_layer_norm_f32" : "layer_norm_f32", 0.0, (addend ? 12.0 : 8.0) * rows * cols);
+#define LN_LAUNCH(CH) hipLaunchKernelGGL((layer_norm_kernel<CH>), grid, block, 0, ctx->stream, rows, cols, x, gamma, beta, gamma_scalar, beta_scalar, epsilon, addend, y)
     if (cols <= 128) LN_LAUNCH(2);
     else if (cols <= 256) LN_LAUNCH(4);
     else if (cols <= 512) LN_LAUNCH(8);
@@ -295,6 +298,21 @@ RTEN_EXPORT int32_t rten_hip_layer_norm_f32(rten_hip_ctx *ctx, int64_t rows, int
 #undef LN_LAUNCH
     RTEN_LAUNCH_CHECK(ctx, "layer_norm_kernel");
     return RTEN_HIP_OK;
+}
+
+RTEN_EXPORT int32_t rten_hip_layer_norm_f32(rten_hip_ctx *ctx, int64_t rows, int32_t cols, const float *x,
+                                            const float *gamma, const float *beta, float gamma_scalar,
+                                            float beta_scalar, float epsilon, float *y) {
+    return layer_norm_launch(ctx, rows, cols, x, nullptr, gamma, beta, gamma_scalar, beta_scalar, epsilon, y);
+}
+
+// LayerNormalization(x + addend): the residual Add of a transformer block fused into the normalisation that consumes it
+// (same f32 add, same reductions: bit-identical to Add followed by LayerNormalization).  `addend` has x's shape.
+RTEN_EXPORT int32_t rten_hip_add_layer_norm_f32(rten_hip_ctx *ctx, int64_t rows, int32_t cols, const float *x, const float *addend,
+                                                const float *gamma, const float *beta, float gamma_scalar, float beta_scalar,
+                                                float epsilon, float *y) {
+    if (!addend) return RTEN_HIP_ERR_INVALID_VALUE;
+    return layer_norm_launch(ctx, rows, cols, x, addend, gamma, beta, gamma_scalar, beta_scalar, epsilon, y);
 }
 
 RTEN_EXPORT int32_t rten_hip_global_average_pool_f32(rten_hip_ctx *ctx, int64_t nc, int32_t inner, const float *x,

@@ -131,6 +131,7 @@ PROTOTYPES = {
     "rten_hip_cast_scale": (_I32, [_VP, _I64, _VP, _VP, _I32, _VP]),
     "rten_hip_softmax_f32": (_I32, [_VP, _I64, _I32, _VP, _VP, _I64, _I64, _I32, _VP]),
     "rten_hip_layer_norm_f32": (_I32, [_VP, _I64, _I32, _VP, _VP, _VP, _F32, _F32, _F32, _VP]),
+    "rten_hip_add_layer_norm_f32": (_I32, [_VP, _I64, _I32, _VP, _VP, _VP, _VP, _F32, _F32, _F32, _VP]),
     "rten_hip_batch_norm_f32": (_I32, [_VP, _I32, _I32, _I64, _VP, _VP, _VP, _VP, _VP, _F32, _VP]),
     "rten_hip_relu_f32": (_I32, [_VP, _I64, _VP, _VP]),
     "rten_hip_gelu_f32": (_I32, [_VP, _I64, _VP, _VP]),

@@ -106,12 +106,11 @@ class Bert:
             self._linear(self.x, lw["wv"], lw["bv"], self.v, H, H)
             ctx.call("rten_hip_sdpa_f32", C.byref(self.sdpa_desc), self.q.vp, self.k.vp, self.v.vp, self.mask.vp, self.att.vp)
             self._linear(self.att, lw["wo"], lw["bo"], self.tmp, H, H)
-            ctx.call("rten_hip_add_f32", T * H, self.tmp.vp, self.x.vp, T * H, self.tmp.vp)
-            ctx.call("rten_hip_layer_norm_f32", T, H, self.tmp.vp, lw["ln1_g"].vp, lw["ln1_b"].vp, 1.0, 0.0, cfg.eps, self.x.vp)
+            # Add(residual) -> LayerNormalization as one kernel
+            ctx.call("rten_hip_add_layer_norm_f32", T, H, self.tmp.vp, self.x.vp, lw["ln1_g"].vp, lw["ln1_b"].vp, 1.0, 0.0, cfg.eps, self.x.vp)
             self._linear(self.x, lw["w1"], lw["b1"], self.h, cfg.ffn, H, act=L.ACT_GELU)
             self._linear(self.h, lw["w2"], lw["b2"], self.tmp, H, cfg.ffn)
-            ctx.call("rten_hip_add_f32", T * H, self.tmp.vp, self.x.vp, T * H, self.tmp.vp)
-            ctx.call("rten_hip_layer_norm_f32", T, H, self.tmp.vp, lw["ln2_g"].vp, lw["ln2_b"].vp, 1.0, 0.0, cfg.eps, self.x.vp)
+            ctx.call("rten_hip_add_layer_norm_f32", T, H, self.tmp.vp, self.x.vp, lw["ln2_g"].vp, lw["ln2_b"].vp, 1.0, 0.0, cfg.eps, self.x.vp)
         return self.x  # last_hidden_state [B*S, H]
 
     def capture(self):

@@ -463,6 +463,22 @@ def test_layer_norm_bit_exact_avx512_order(ctx, cols):
         np.testing.assert_allclose(got, ref.layer_norm(x, gamma, beta, gs, bs, lanes=4), rtol=2e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("cols", [10, 100, 768, 1024, 2000])
+def test_add_layer_norm_fused_bit_exact(ctx, cols):
+    # Add -> LayerNormalization as one kernel == the two operators, also when the output aliases an input (BERT's residual stream)
+    rng = ref.XorShiftRng(cols + 7)
+    x = (rng.f32(29 * cols).reshape(29, cols) - 0.5) * 3
+    r = (rng.f32(29 * cols).reshape(29, cols) - 0.5) * 2
+    g, b = rng.f32(cols) + 0.5, rng.f32(cols) - 0.5
+    want = ref.layer_norm(ref.add(x, r), g, b, 1.0, 0.0, eps=1e-12, lanes=16)
+    xd, rd, gd, bd = dev(ctx, x), dev(ctx, r), dev(ctx, g), dev(ctx, b)
+    out = DeviceTensor(ctx, (29, cols), np.float32)
+    ctx.call("rten_hip_add_layer_norm_f32", 29, cols, xd.vp, rd.vp, gd.vp, bd.vp, 1.0, 0.0, 1e-12, out.vp)
+    bits_equal(out.numpy(), want)
+    ctx.call("rten_hip_add_layer_norm_f32", 29, cols, xd.vp, rd.vp, gd.vp, bd.vp, 1.0, 0.0, 1e-12, rd.vp)  # in place over the addend
+    bits_equal(rd.numpy(), want)
+
+
 def test_layer_norm_reference_literals(ctx):
     import json, os
     for c in json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_literals.json")))["layer_norm"]["cases"]:
