@@ -42,9 +42,6 @@ struct SdpaArgs {
 
 __device__ __forceinline__ constexpr int acc_row(int r) { return (r & 3) + 8 * (r >> 2); }
 
-// register of key row tb (0..31) inside a 32x32 accumulator block, for the half-wave that holds it ((tb >> 2) & 1)
-__device__ __forceinline__ constexpr int reg_of(int tb) { return (tb & 3) + 4 * (tb >> 3); }
-
 __global__ __launch_bounds__(256, 2) void sdpa_fused_kernel(const SdpaArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[16 * SQ * 4 + 16 * TT * 4]; // Qs | Ks (phase 1) -> Vs [TT][HD] (phase 3)
     float *const Qs = smem, *const Ks = smem + 16 * SQ * 4, *const Vs = Ks;

@@ -91,12 +91,6 @@ struct GemmArgs {
     int order; // bit 0: tiles walk n fastest (default m fastest); bit 1: split workgroups walk tiles fastest, K groups slowest
 };
 
-__device__ __forceinline__ float combine(float t, float c, float alpha, float beta) {
-    // the four store forms of the reference micro-kernel, simd_generic.rs:378-414
-    if (beta == 0.f) return alpha == 1.f ? t : t * alpha;
-    if (beta == 1.f && alpha == 1.f) return c + t;
-    return vm::fma(t, alpha, c * beta);
-}
 
 __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
