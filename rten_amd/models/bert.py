@@ -64,6 +64,7 @@ class Bert:
         self.ctx, self.cfg, self.B, self.S = ctx, cfg, batch, seq
         self.weights = weights if weights is not None else make_weights(cfg)
         self.graph = None
+        self.variants = {}  # (n, k) -> GEMM tile variant chosen by autotune()
         w = self.weights
         up = lambda a: DeviceTensor.from_numpy(ctx, a)
         self.d = {k: up(w[k]) for k in ("word", "pos", "type", "emb_ln_g", "emb_ln_b")}
@@ -89,7 +90,37 @@ class Bert:
 
     def _linear(self, x, w, b, out, n, k, act=L.ACT_NONE):
         d = L.gemm_desc(self.B * self.S, n, k, k, 1, n, 1, n, bias_kind=L.BIAS_PER_COL, act=act)
+        v = self.variants.get((n, k))
+        if v is not None:
+            self.ctx.set_gemm_variant(v)
         self.ctx.call("rten_hip_gemm_f32", C.byref(d), x.vp, w.vp, b.vp, out.vp)
+        if v is not None:
+            self.ctx.set_gemm_variant(-1)
+
+    def autotune(self, reps=3):
+        """Pick the fastest GEMM tile variant per distinct projection shape by measurement (load-time, like the reference
+        picks kernels per ISA at start-up, rten-gemm/src/lib.rs:534-547).  Returns {(n, k): [(variant, ms), ...]}."""
+        ctx, cfg, H = self.ctx, self.cfg, self.cfg.hidden
+        lw = self.dl[0]
+        shapes = {(H, H): (self.x, lw["wq"], lw["bq"], self.q, L.ACT_NONE), (cfg.ffn, H): (self.x, lw["w1"], lw["b1"], self.h, L.ACT_GELU),
+                  (H, cfg.ffn): (self.h, lw["w2"], lw["b2"], self.tmp, L.ACT_NONE)}
+        table = {}
+        for (n, k), (x, w, b, out, act) in shapes.items():
+            row = []
+            for v in (0, 1, 2, 3, 12, 13, 14, 15):  # LDS-DMA pipeline, three / four stages (row-major A)
+                self.variants[(n, k)] = v
+                self._linear(x, w, b, out, n, k, act)
+                ms = 1e30
+                for _ in range(2):
+                    ctx.timer_start(1)
+                    for _ in range(reps):
+                        self._linear(x, w, b, out, n, k, act)
+                    ctx.timer_stop(1)
+                    ms = min(ms, ctx.timer_ms(1) / reps)
+                row.append((v, ms))
+            self.variants[(n, k)] = min(row, key=lambda r: r[1])[0]
+            table[(n, k)] = row
+        return table
 
     def forward(self):
         ctx, cfg, T, H = self.ctx, self.cfg, self.B * self.S, self.cfg.hidden

@@ -18,6 +18,7 @@ cfg = bert.BertConfig()
 net = bert.Bert(ctx, cfg, args.batch, args.seq)
 rng = np.random.default_rng(0)
 net.set_inputs(rng.integers(0, cfg.vocab, (args.batch, args.seq)), np.ones((args.batch, args.seq), np.float32), np.zeros((args.batch, args.seq), np.int64))
+tune = net.autotune()
 net.capture()
 for _ in range(args.warmup):
     net.run()
@@ -43,4 +44,5 @@ print(json.dumps({"metric": "sequences/sec, BERT-base encoder f32, batch 32 x 12
                   "roofline": {"bound": "mfma", "kernel": "igemm_f32 family (projections, FFN, attention GEMMs)", "achieved": round(gfl / (ms * 1e-3) / 1e12, 2), "peak": 157.3,
                                "unit": "TFLOP/s", "frac": round(gfl / (ms * 1e-3) / 1e12 / 157.3, 4), "kernel_ms_per_step": round(ms / args.steps, 4),
                                "all_kernels_ms_per_step": round(sum(r["ms"] for r in rep) / args.steps, 4)},
+                  "autotuned_variants": {f"n={n},k={k}": net.variants[(n, k)] for (n, k) in net.variants},
                   "kernels": {r["kernel"]: round(r["ms"] / args.steps, 4) for r in sorted(rep, key=lambda r: -r["ms"])[:12]}}))
