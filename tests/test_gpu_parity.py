@@ -280,6 +280,22 @@ def test_conv_f32_split_k_bit_exact(ctx, shape):
         ctx.call("rten_hip_set_gemm_order", 0)
 
 
+def test_conv_f32_grouped_split_k_bit_exact(ctx):
+    # grouped convolution (grid.y = group) with K = 576 per group: split-K slabs are indexed per group
+    rng = ref.XorShiftRng(123)
+    x = rng.f32(2 * 128 * 12 * 12).reshape(2, 128, 12, 12) - 0.5
+    w = (rng.f32(96 * 64 * 3 * 3).reshape(96, 64, 3, 3) - 0.5) * 0.1
+    b = rng.f32(96) - 0.5
+    want = ref.conv2d_f32(x, w, b, pads=(1, 1, 1, 1), groups=2, relu=True)
+    try:
+        for v in (3, 7, 1):
+            for mode, groups in ((0, 1), (2, 2), (2, 3), (1, 3)):
+                ctx.call("rten_hip_set_gemm_split", mode, groups)
+                bits_equal(gpu_conv(ctx, x, w, b, (1, 1, 1, 1), (1, 1), (1, 1), 2, relu=True, variant=v), want)
+    finally:
+        ctx.call("rten_hip_set_gemm_split", 3, 1)
+
+
 # ------------------------------------------------------------------------------------------ int8
 @pytest.fixture(params=[0, 1], ids=["i8staged", "i8generic"])
 def i8path(request, ctx):
