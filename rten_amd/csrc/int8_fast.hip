@@ -117,7 +117,16 @@ __device__ __forceinline__ void stage_nhwc_tile(const T *__restrict__ x, uint8_t
     const bool in = pp < npix && (unsigned)y < (unsigned)H && (unsigned)xs < (unsigned)W;
     const long long src0 = ((long long)n * C * H + (in ? y : 0)) * W + (in ? xs : 0); // + c * H * W
     const int c0 = blockIdx.z * 64; // one 64-channel slab per workgroup: small feature maps still give thousands of workgroups
-    // thread -> (pixel, 4 consecutive channels) per pass: four loads, one packed dword into the LDS tile
+    // thread -> (pixel, 4 consecutive channels) per pass.  All 16 loads are issued first (clamped address, no branch
+    // around a load), then converted and packed: one dword per pass into the LDS tile.
+    T raw[16];
+#pragma unroll
+    for (int pass = 0; pass < 4; pass++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int c = c0 + pass * 16 + (t >> 6) * 4 + b;
+            raw[pass * 4 + b] = x[(in && c < C) ? src0 + (long long)c * H * W : 0];
+        }
 #pragma unroll
     for (int pass = 0; pass < 4; pass++) {
         const int cl = pass * 16 + (t >> 6) * 4;
@@ -125,8 +134,7 @@ __device__ __forceinline__ void stage_nhwc_tile(const T *__restrict__ x, uint8_t
 #pragma unroll
         for (int b = 0; b < 4; b++) {
             const int c = c0 + cl + b;
-            unsigned v = c < C ? fill : 0u;
-            if (in && c < C) v = load(x[src0 + (long long)c * H * W]) & 0xffu;
+            const unsigned v = (in && c < C) ? load(raw[pass * 4 + b]) & 0xffu : (c < C ? fill : 0u);
             w |= v << (8 * b);
         }
         *reinterpret_cast<unsigned *>(&tile[pl_][cl]) = w;
