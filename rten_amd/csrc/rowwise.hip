@@ -221,21 +221,42 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void layer_norm_kernel(int64_t
     }
     const float ssr = gamma_scalar / sqrtf(var + eps);
     const int mode = (!gamma && !beta) ? 0 : ((gamma && !beta && beta_scalar == 0.f) ? 1 : 2);
-    auto norm = [&](float xv, int i) -> float {
+    auto norm = [&](float xv, float gv, float bv) -> float { // the three Normalize forms, normalize.rs:112-166
         if (mode == 0) return vm::fma(xv - mean, ssr, beta_scalar);
-        if (mode == 1) return (xv - mean) * (gamma[i] * ssr);
-        const float sv = (gamma ? gamma[i] : 1.0f) * ssr;
-        const float bv = (beta ? beta[i] : 0.f) + beta_scalar;
-        return vm::fma(xv - mean, sv, bv);
+        if (mode == 1) return (xv - mean) * (gv * ssr);
+        return vm::fma(xv - mean, gv * ssr, bv + beta_scalar);
     };
     if constexpr (CH > 0) {
+        // per-column scale / bias: all loads of the row's columns issued back to back (uniform `mode` tests hoisted out
+        // of the element loop -- a test per element serialises every load behind a waitcnt)
+        float gv[CH], bv[CH];
+#pragma unroll
+        for (int c = 0; c < CH; c++) { gv[c] = 1.0f; bv[c] = 0.f; }
+        if (gamma) {
+#pragma unroll
+            for (int c = 0; c < CH; c++) { const int i = c * 64 + lane; gv[c] = gamma[i < cols ? i : 0]; }
+        }
+        if (beta) {
+#pragma unroll
+            for (int c = 0; c < CH; c++) { const int i = c * 64 + lane; bv[c] = beta[i < cols ? i : 0]; }
+        }
+        if (mode == 0) {
+#pragma unroll
+            for (int c = 0; c < CH; c++) v[c] = vm::fma(v[c] - mean, ssr, beta_scalar);
+        } else if (mode == 1) {
+#pragma unroll
+            for (int c = 0; c < CH; c++) v[c] = (v[c] - mean) * (gv[c] * ssr);
+        } else {
+#pragma unroll
+            for (int c = 0; c < CH; c++) v[c] = vm::fma(v[c] - mean, gv[c] * ssr, bv[c] + beta_scalar);
+        }
 #pragma unroll
         for (int c = 0; c < CH; c++) {
             const int i = c * 64 + lane;
-            if (i < cols) yr[i] = norm(v[c], i);
+            if (i < cols) yr[i] = v[c];
         }
     } else {
-        for (int i = lane; i < cols; i += 64) yr[i] = norm(get(i), i);
+        for (int i = lane; i < cols; i += 64) yr[i] = norm(get(i), gamma ? gamma[i] : 1.0f, beta ? beta[i] : 0.f);
     }
 }
 
