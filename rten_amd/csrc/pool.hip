@@ -9,33 +9,54 @@
 
 namespace {
 
-template <bool IS_MAX>
+// One thread per output element; grid.x = (image, channel) plane, grid.y = 256-output slabs of the plane, so the
+// index arithmetic stays 32-bit.  With a compile-time window (KH, KW > 0) every tap's load is issued unconditionally
+// from a clamped address before the first compare/add, i.e. KH*KW loads in flight per lane instead of one; taps are
+// folded in (ky, kx) order either way (the order the header comment cites).
+template <bool IS_MAX, int KH, int KW>
 __global__ __launch_bounds__(256) void pool2d_kernel(const rten_hip_pool2d_desc d, const float *__restrict__ x,
                                                      float *__restrict__ y) {
-    const long long total = (long long)d.n * d.c * d.out_h * d.out_w;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int ox = (int)(i % d.out_w);
-        const long long r = i / d.out_w;
-        const int oy = (int)(r % d.out_h);
-        const long long nc = r / d.out_h;
-        const float *in = x + nc * (long long)d.h * d.w;
-        float acc = IS_MAX ? -__builtin_inff() : 0.f;
-        int cnt = 0;
+    const int plane = d.out_h * d.out_w;
+    const int o = blockIdx.y * 256 + threadIdx.x;
+    if (o >= plane) return;
+    const int oy = o / d.out_w, ox = o - oy * d.out_w;
+    const float *in = x + (long long)blockIdx.x * d.h * d.w;
+    float acc = IS_MAX ? -__builtin_inff() : 0.f;
+    int cnt = 0;
+    const int y0 = oy * d.stride_h - d.pads[0], x0 = ox * d.stride_w - d.pads[1];
+    if constexpr (KH > 0) {
+        float raw[KH * KW];
+        bool ok[KH * KW];
+#pragma unroll
+        for (int ky = 0; ky < KH; ky++)
+#pragma unroll
+            for (int kx = 0; kx < KW; kx++) {
+                const int iy = y0 + ky, ix = x0 + kx;
+                const bool in_range = (unsigned)iy < (unsigned)d.h && (unsigned)ix < (unsigned)d.w;
+                ok[ky * KW + kx] = in_range;
+                raw[ky * KW + kx] = in[in_range ? iy * d.w + ix : 0];
+            }
+#pragma unroll
+        for (int t = 0; t < KH * KW; t++)
+            if (ok[t]) {
+                acc = IS_MAX ? fmaxf(acc, raw[t]) : acc + raw[t];
+                cnt++;
+            }
+    } else {
         for (int ky = 0; ky < d.kh; ky++) {
-            const int iy = oy * d.stride_h + ky - d.pads[0];
+            const int iy = y0 + ky;
             if ((unsigned)iy >= (unsigned)d.h) continue;
             for (int kx = 0; kx < d.kw; kx++) {
-                const int ix = ox * d.stride_w + kx - d.pads[1];
+                const int ix = x0 + kx;
                 if ((unsigned)ix >= (unsigned)d.w) continue;
-                const float v = in[(long long)iy * d.w + ix];
+                const float v = in[iy * d.w + ix];
                 acc = IS_MAX ? fmaxf(acc, v) : acc + v;
                 cnt++;
             }
         }
-        if (!IS_MAX) acc = d.count_include_pad ? acc / (float)(d.kh * d.kw) : acc / (float)cnt;
-        y[i] = acc;
     }
+    if (!IS_MAX) acc = d.count_include_pad ? acc / (float)(d.kh * d.kw) : acc / (float)cnt;
+    y[(long long)blockIdx.x * plane + o] = acc;
 }
 
 template <bool IS_MAX>
@@ -48,10 +69,14 @@ int32_t run_pool(rten_hip_ctx *ctx, const rten_hip_pool2d_desc *d, const float *
     const long long total = (long long)d->n * d->c * d->out_h * d->out_w;
     if (total == 0) return RTEN_HIP_OK;
     if (!x || !y) return RTEN_HIP_ERR_INVALID_VALUE;
-    long long blocks = (total + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
+    const long long planes = (long long)d->n * d->c, plane_in = (long long)d->h * d->w, plane_out = (long long)d->out_h * d->out_w;
+    if (planes > 0x7fffffffLL || plane_in > 0x7fffffffLL || plane_out > 65535LL * 256)
+        return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "pool: plane too large");
+    const dim3 grid((unsigned)planes, (unsigned)((plane_out + 255) / 256));
     ProfScope ps(ctx, name, 0.0, 4.0 * ((double)d->n * d->c * d->h * d->w + (double)total));
-    hipLaunchKernelGGL((pool2d_kernel<IS_MAX>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, *d, x, y);
+    if (d->kh == 3 && d->kw == 3) hipLaunchKernelGGL((pool2d_kernel<IS_MAX, 3, 3>), grid, dim3(256), 0, ctx->stream, *d, x, y);
+    else if (d->kh == 2 && d->kw == 2) hipLaunchKernelGGL((pool2d_kernel<IS_MAX, 2, 2>), grid, dim3(256), 0, ctx->stream, *d, x, y);
+    else hipLaunchKernelGGL((pool2d_kernel<IS_MAX, 0, 0>), grid, dim3(256), 0, ctx->stream, *d, x, y);
     RTEN_LAUNCH_CHECK(ctx, name);
     return RTEN_HIP_OK;
 }

@@ -268,8 +268,25 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void global_avg_pool_kernel(in
     const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float *xr = x + row * inner;
-    auto get = [&](int i) -> float { return xr[i]; };
-    const float s = simd16_reduce<0>(get, inner, 0.f, lane);
+    float s;
+    if (inner <= 64) {
+        // ResNet's 7x7 map: one load per lane, then the 16-lane partial sums of simd16_reduce built from lane
+        // broadcasts in the same order (chunk q adds element q*16 + l to partial l, masked past the end).
+        const float v = xr[lane < inner ? lane : 0];
+        const int l = lane & 15;
+        float a = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float e = lane_bcast(v, q * 16 + l);
+            if (q * 16 + l < inner) a = a + e;
+        }
+        s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) s = s + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), k));
+    } else {
+        auto get = [&](int i) -> float { return xr[i]; };
+        s = simd16_reduce<0>(get, inner, 0.f, lane);
+    }
     if (lane == 0) y[row] = s / (float)inner;
 }
 
