@@ -294,6 +294,54 @@ __global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p)
         }
     };
 
+    // ---- epilogue operands, requested BEFORE the main loop so that their latency hides behind it (these short-K
+    // products are otherwise epilogue-latency bound): per-row constants by threads 0..BM-1 (parked in LDS once the
+    // stage buffers are free), per-column constants and the residual tile straight into registers.  They are older
+    // than every LDS-DMA load, so the counted vmcnt waits of the main loop cover them.
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void *)p.C, 0, 0x7ffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void *)(p.res ? (const void *)p.res : (const void *)p.C), 0, 0x7ffffffc, 0x00020000);
+    const unsigned rs4 = (unsigned)p.c_rs << 2;
+    const int mb = m0 + wm0 + 4 * half;
+    int rc_rsum = 0, rc_az = 0;
+    float rc_bias = 0.f, rc_srow = 0.f;
+    if (t < BM) {
+        const int m = m0 + t < p.M ? m0 + t : 0;
+        rc_rsum = p.rsum[m];
+        rc_az = zp_signed(p.a_zp, p.a_zp_len == 1 ? 0 : m, p.a_signed);
+        rc_bias = p.bias ? p.bias[m] : 0.f;
+        rc_srow = (p.scale && p.scale_per_row) ? p.scale[m] : 0.f;
+    }
+    unsigned basev[TN], bzv[TN], csv[TN];
+    float scv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int n = n0 + wn0 + j * 32 + l31;
+        const bool cok = n < p.N;
+        const int nn = cok ? n : 0;
+        const int nb = nn / p.Pn, np = nn - nb * p.Pn;
+        basev[j] = cok ? (unsigned)((long long)nb * p.c_ns + np) << 2 : OOB; // byte offset of (row 0, column n); rows ride the scalar offset
+        bzv[j] = (unsigned)zp_signed(p.b_zp, p.b_zp_len == 1 ? 0 : nn, p.b_signed);
+        csv[j] = p.csum ? (unsigned)p.csum[nn] : 0u;
+        scv[j] = (p.scale && !p.scale_per_row) ? p.scale[p.scale_len == 1 ? 0 : nn] : 0.f;
+    }
+    // row r of 32-row block i sits at scalar byte offset (mb_u + i*32 + acc_row(r)) * rs4, with mb_u wave-uniform and the lane's
+    // half (rows +4) folded into the vector offset
+    const unsigned half_off = (unsigned)(4 * half) * rs4;
+    const int mb_u = m0 + (wave / WN) * (BM / WM);
+    float rr[TM][TN][16];
+    if (p.res) {
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int m = mb + i * 32 + acc_row(r);
+                    const unsigned vo = (m < p.M && basev[j] != OOB) ? basev[j] + half_off : OOB;
+                    rr[i][j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)vo, (int)((unsigned)(mb_u + i * 32 + acc_row(r)) * rs4), 0));
+                }
+    }
+
     const int nk = (p.Kp + KT - 1) / KT;
 #pragma unroll
     for (int i = 0; i < NSTAGE - 1; i++) issue_tile(i);
@@ -307,94 +355,74 @@ __global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p)
         stage = stage == NSTAGE - 1 ? 0 : stage + 1;
     }
     wait_vmcnt<0>();
-
-    // ---- epilogue: zero-point algebra, optional cast_scale / bias / residual / relu, store.
-    // Row constants (weight row sum, weight zero point, bias) are fetched once per 32-row block and reused across
-    // the block's columns; 8 accumulator registers are finished at a time to keep temporaries in registers.
-    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void *)p.C, 0, 0x7ffffffc, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void *)(p.res ? (const void *)p.res : (const void *)p.C), 0, 0x7ffffffc, 0x00020000);
-    const unsigned rs4 = (unsigned)p.c_rs << 2;
-    const int mb = m0 + wm0 + 4 * half;
-    float st_mn = __builtin_inff(), st_mx = -__builtin_inff(); // output statistics for the consuming DynamicQuantizeLinear
-    unsigned colv[TN], bzv[TN], csv[TN];
-    float scv[TN];
-    bool cokv[TN];
-#pragma unroll
-    for (int j = 0; j < TN; j++) {
-        const int n = n0 + wn0 + j * 32 + l31;
-        cokv[j] = n < p.N;
-        const int nn = cokv[j] ? n : 0;
-        const int nb = nn / p.Pn, np = nn - nb * p.Pn;
-        colv[j] = (unsigned)((long long)nb * p.c_ns + np);
-        bzv[j] = (unsigned)zp_signed(p.b_zp, p.b_zp_len == 1 ? 0 : nn, p.b_signed);
-        if (p.csum) csv[j] = (unsigned)p.csum[nn];
-        else csv[j] = (unsigned)(cs[j] + __shfl_xor(cs[j], 32, 64)); // the two k halves of the column
-        scv[j] = (p.scale && !p.scale_per_row) ? p.scale[p.scale_len == 1 ? 0 : nn] : 0.f;
+    __syncthreads(); // every wave is done with the stage buffers: park the row constants there
+    int *rowc = reinterpret_cast<int *>(smem); // [4][BM]: row sum, a_zp, bias, per-row scale
+    if (t < BM) {
+        rowc[t] = rc_rsum;
+        rowc[BM + t] = rc_az;
+        rowc[2 * BM + t] = __builtin_bit_cast(int, rc_bias);
+        rowc[3 * BM + t] = __builtin_bit_cast(int, rc_srow);
     }
+    __syncthreads();
+    if (!p.csum) {
+#pragma unroll
+        for (int j = 0; j < TN; j++) csv[j] = (unsigned)(cs[j] + __shfl_xor(cs[j], 32, 64)); // the two k halves of the column
+    }
+
+    // ---- epilogue: zero-point algebra, optional cast_scale / bias / residual / relu, store.  16 accumulator
+    // registers (one 32 x 32 block) are finished at a time; all of a block's stores are issued back to back.
+    float st_mn = __builtin_inff(), st_mx = -__builtin_inff(); // output statistics for the consuming DynamicQuantizeLinear
+    const int ml0 = wm0 + 4 * half;
 #pragma unroll
     for (int i = 0; i < TM; i++) {
-        const int mrow = mb + i * 32;
+        unsigned rsv[16], azv[16];
+        float bv[16], srow[16];
+        bool mok[16];
 #pragma unroll
-        for (int h8 = 0; h8 < 2; h8++) {
-            unsigned rsv[8], azv[8];
-            float bv[8], srow[8];
-            bool mok[8];
+        for (int r = 0; r < 16; r++) {
+            const int ml = ml0 + i * 32 + acc_row(r);
+            mok[r] = m0 + ml < p.M;
+            rsv[r] = (unsigned)rowc[ml];
+            azv[r] = (unsigned)rowc[BM + ml];
+            bv[r] = __builtin_bit_cast(float, rowc[2 * BM + ml]);
+            srow[r] = __builtin_bit_cast(float, rowc[3 * BM + ml]);
+        }
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const int m = mrow + acc_row(h8 * 8 + q);
-                mok[q] = m < p.M;
-                const int mm = mok[q] ? m : 0;
-                rsv[q] = (unsigned)p.rsum[mm];
-                azv[q] = (unsigned)zp_signed(p.a_zp, p.a_zp_len == 1 ? 0 : mm, p.a_signed);
-                bv[q] = p.bias ? p.bias[mm] : 0.f;
-                srow[q] = p.scale_per_row ? p.scale[mm] : 0.f;
+        for (int j = 0; j < TN; j++) {
+            const bool cok = basev[j] != OOB;
+            unsigned v[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                v[r] = (unsigned)acc[i][j][r] - bzv[j] * rsv[r] - azv[r] * csv[j] + (unsigned)p.Kreal * azv[r] * bzv[j];
+            if (p.scale) {
+                float f[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) f[r] = (float)(int)v[r] * (p.scale_per_row ? srow[r] : scv[j]); // cast_scale (matmul.rs:751,761)
+                if (p.bias) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) f[r] = f[r] + bv[r];
+                }
+                if (p.res) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) f[r] = f[r] + rr[i][j][r];
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) f[r] = vm::relu(f[r]);
+                }
+                if (p.stats) { // fminf / fmaxf drop NaNs like the reference's min/max sweep (min_max.rs:27-30)
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        if (mok[r] && cok) { st_mn = fminf(f[r], st_mn); st_mx = fmaxf(f[r], st_mx); }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r++) v[r] = __builtin_bit_cast(unsigned, f[r]);
             }
 #pragma unroll
-            for (int j = 0; j < TN; j++) {
-                const unsigned base = cokv[j] ? (colv[j] + (unsigned)mrow * (unsigned)p.c_rs) << 2 : OOB;
-                unsigned voff[8], v[8];
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    voff[q] = mok[q] ? base : OOB;
-                    v[q] = (unsigned)acc[i][j][h8 * 8 + q] - bzv[j] * rsv[q] - azv[q] * csv[j] + (unsigned)p.Kreal * azv[q] * bzv[j];
-                }
-                if (p.scale) {
-                    float f[8];
-#pragma unroll
-                    for (int q = 0; q < 8; q++) f[q] = (float)(int)v[q] * (p.scale_per_row ? srow[q] : scv[j]); // cast_scale (matmul.rs:751,761)
-                    if (p.bias) {
-#pragma unroll
-                        for (int q = 0; q < 8; q++) f[q] = f[q] + bv[q];
-                    }
-                    if (p.res) {
-                        float rr[8];
-#pragma unroll
-                        for (int q = 0; q < 8; q++)
-                            rr[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)voff[q], (int)((unsigned)acc_row(h8 * 8 + q) * rs4), 0));
-#pragma unroll
-                        for (int q = 0; q < 8; q++) f[q] = f[q] + rr[q];
-                    }
-                    if (p.relu) {
-#pragma unroll
-                        for (int q = 0; q < 8; q++) f[q] = vm::relu(f[q]);
-                    }
-                    if (p.stats) { // fminf / fmaxf drop NaNs like the reference's min/max sweep (min_max.rs:27-30)
-#pragma unroll
-                        for (int q = 0; q < 8; q++)
-                            if (mok[q] && cokv[j]) { st_mn = fminf(f[q], st_mn); st_mx = fmaxf(f[q], st_mx); }
-                    }
-#pragma unroll
-                    for (int q = 0; q < 8; q++) {
-                        const float x = f[q];
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), rsC, (int)voff[q], (int)((unsigned)acc_row(h8 * 8 + q) * rs4), 0);
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 8; q++) {
-                        const unsigned x = v[q];
-                        __builtin_amdgcn_raw_buffer_store_b32(x, rsC, (int)voff[q], (int)((unsigned)acc_row(h8 * 8 + q) * rs4), 0);
-                    }
-                }
+            for (int r = 0; r < 16; r++) {
+                const unsigned x = v[r];
+                __builtin_amdgcn_raw_buffer_store_b32(x, rsC, (int)((mok[r] && cok) ? basev[j] + half_off : OOB),
+                                                      (int)((unsigned)(mb_u + i * 32 + acc_row(r)) * rs4), 0);
             }
         }
     }
