@@ -202,7 +202,7 @@ int32_t rten_hip_conv2d_int8_prepack(rten_hip_ctx *ctx, const rten_hip_conv2d_in
 /* DynamicQuantizeLinear fused with the activation staging of the ConvInteger that consumes it (the reference runs
  * DynamicQuantizeLinear -> ConvInteger back to back in ort-quantized graphs, src/ops/quantize.rs:352-436 ->
  * src/ops/conv.rs:421-476): same scale / zero point / u8 codes bit for bit, but the codes are written once, directly
- * in the layout the int8 kernel gathers from (zero-point-padded NHWC, signed domain) instead of as an NCHW u8 tensor.
+ * in the layout the int8 kernel gathers from (zero-point-padded, channel-blocked [N][C/16][H+pads][W+pads][16], signed domain; opaque to the caller) instead of as an NCHW u8 tensor.
  * `desc` is the consumer's descriptor (x_signed must be 0: DynamicQuantizeLinear produces u8); staged_bytes returns 0
  * when the staged kernel does not cover the geometry.  `mul_by` / `product` fold the Mul(x_scale, w_scale) node that
  * follows in ort-quantized graphs (one f32 multiply, same bits). */
@@ -316,7 +316,7 @@ int32_t rten_hip_set_gemm_split(rten_hip_ctx *ctx, int32_t mode, int32_t groups)
  * bit 1 = split-K workgroups walk tiles fastest and K groups slowest, so that each XCD's private L2 holds one K
  * slice of both operands. */
 int32_t rten_hip_set_gemm_order(rten_hip_ctx *ctx, int32_t order);
-/* int8 kernels: 0 = automatic (operands staged k-contiguous / padded NHWC + 16-byte LDS-DMA MFMA kernel whenever it
+/* int8 kernels: 0 = automatic (operands staged chunk-major / padded channel-blocked + 16-byte LDS-DMA MFMA kernel whenever it
  * covers the call), 1 = generic byte-gather kernel only.  Both produce the reference's bits. */
 int32_t rten_hip_set_int8_path(rten_hip_ctx *ctx, int32_t mode);
 /* attention: 0 = automatic (one fused kernel for head size 64 and key length <= 128: QK^T, mask, softmax and PV without

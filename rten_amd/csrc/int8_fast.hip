@@ -7,15 +7,20 @@
 // Integer sums are exact in any order, so -- unlike the f32 path -- the K dimension may be re-ordered.  That is
 // what makes the int8 path fast on this machine:
 //   * Both MFMA operands want 16 CONSECUTIVE k bytes per lane.  Operands are therefore staged once per call as
-//     "k-contiguous signed rows": weights as [rows][Kp] (conv: k = (ky, kx, c), channels padded to 16), with their
-//     row sums; conv activations as a zero-point-PADDED NHWC image [N][H+pads][W+pads][Cp], so that the im2col
-//     gather of one (tap, 16-channel) chunk is one aligned 16-byte load per pixel and needs no bounds tests at all
-//     (the spatial border holds the reference's padding value for the selected pad mode).
+//     CHUNK-MAJOR signed bytes [K/16][rows][16 B]: weights with k = (ky, kx, c) (channels padded to 16) plus their row
+//     sums; conv activations as a zero-point-PADDED channel-blocked image [N][Cp/16][H+pads][W+pads][16 B], so that
+//     the im2col gather of one (tap, 16-channel) chunk is one aligned 16-byte load per pixel and needs no bounds tests
+//     at all (the spatial border holds the reference's padding value for the selected pad mode).
+//     Chunk-major (rather than k-contiguous rows) because the 64 lanes of one tile-DMA instruction then read ONE
+//     1 KiB run (GEMM) or a few row-long runs (conv) instead of 64 pieces a row pitch apart: with a power-of-two
+//     pitch those 64 pieces fall on 2-4 of the 16 L2 channels (measured: +8 % end to end on ResNet-50 int8).
 //     u8 operands move to the signed domain (x ^ 0x80) during staging; (x - zp) is invariant under that shift.
 //   * Main loop: tiles go L2 -> LDS with `buffer_load_dwordx4 ... lds` (1 KiB per wave instruction), chunk-major
 //     LDS image [4 chunks][rows][16 B] (the DMA's lane-linear destination), so an MFMA operand fetch is one
 //     conflict-free ds_read_b128.  Three LDS stages, counted vmcnt waits, one barrier per 64-byte k-tile.
 //     Per-lane offsets are loop invariant; the k advance (conv: the (ky, kx, c) chunk walk) is scalar.
+//     What bounds it (tools/probes/lds_fill_rate.hip, ablation in DESIGN.md section 7): the tile DMA of a workgroup,
+//     not the MFMAs -- hence the tile / tile-order rules in dispatch_fast.
 //   * Zero-point algebra of the reference (simd_generic.rs:676-746): C = dot - b_zp*rowsum(A) - a_zp*colsum(B)
 //     + K*a_zp*b_zp with weight sums from the staging pass; the activation-side sums are only accumulated
 //     (v_dot4 on the operand fragments) when the weight zero point can be non-zero.
@@ -30,7 +35,6 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr int KT = 64;          // k bytes per tile (4 chunks of 16)
-constexpr int NSTAGE = 3; // measured: 2 stages equal, 4 and 6 slower (occupancy matters more than prefetch depth on these short-K shapes)
 constexpr unsigned OOB = 0x80000000u;
 
 struct FastArgs {
@@ -48,7 +52,7 @@ struct FastArgs {
     int a_signed, b_signed, a_zp_len, b_zp_len, scale_len, relu, need_csum;
     int scale_per_row; // conv: scale[m] per output channel instead of scale[0] / scale[n]
     unsigned *stats;   // optional: min/max of the f32 outputs, accumulated for the DynamicQuantizeLinear that consumes them
-    int tiles_m, tiles_n;
+    int tiles_m, tiles_n, n_fastest;
     // conv geometry (padded image)
     int conv, OW, sy, sx, Hp, Wp, Cp, KH, KW, dy, dx;
 };
@@ -69,14 +73,13 @@ __device__ __forceinline__ constexpr int acc_row(int r) { return (r & 3) + 8 * (
 // staging kernels
 // ---------------------------------------------------------------------------------------------------------
 
-// rows of a strided u8/i8 matrix -> k-contiguous signed rows [rows][Kp] (+ row sums).  With khw > 1 the source k
-// index is (c, tap) (OIHW weights) and the destination k index is (tap, c) with channels padded to Cp.
+// rows of a strided u8/i8 matrix -> chunk-major signed operand [Kp/16][rows][16 B] (+ row sums).  With khw > 1 the
+// source k index is (c, tap) (OIHW weights) and the destination k index is (tap, c) with channels padded to Cp.
 __global__ __launch_bounds__(256) void i8_pack_rows_kernel(const uint8_t *__restrict__ src, long long row_stride, long long k_stride, int K,
-                                                          int C, int khw, int Cp, int Kp, unsigned flip, uint8_t *__restrict__ dst,
+                                                          int C, int khw, int Cp, int Kp, int rows, unsigned flip, uint8_t *__restrict__ dst,
                                                           int *__restrict__ sums) {
     const int r = blockIdx.x;
     const uint8_t *s = src + (long long)r * row_stride;
-    uint8_t *d = dst + (long long)r * Kp;
     int sum = 0;
     for (int kq = threadIdx.x * 4; kq < Kp; kq += 1024) {
         unsigned w = 0;
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(256) void i8_pack_rows_kernel(const uint8_t *__rest
             const unsigned v = ok ? ((unsigned)s[(long long)(ks < K ? ks : 0) * k_stride] ^ flip) & 0xffu : 0u;
             w |= v << (8 * b);
         }
-        *reinterpret_cast<unsigned *>(d + kq) = w;
+        *reinterpret_cast<unsigned *>(dst + ((long long)(kq >> 4) * rows + r) * 16 + (kq & 15)) = w;
         sum = __builtin_amdgcn_sdot4((int)w, 0x01010101, sum, false);
     }
     __shared__ int red[4];
@@ -100,13 +103,16 @@ __global__ __launch_bounds__(256) void i8_pack_rows_kernel(const uint8_t *__rest
     if (threadIdx.x == 0) sums[r] = red[0] + red[1] + red[2] + red[3];
 }
 
-// Staging of conv activations: NCHW -> padded NHWC signed bytes [N][Hp][Wp][Cp]; border = pad value of the selected
-// mode, padded channels 0.  A workgroup handles 64 consecutive PADDED pixel positions of one image (so small feature
-// maps still fill the lanes) x 64 channels at a time: coalesced reads along the source's pixel axis, 16-byte writes
-// along the channel axis through an LDS transpose.  `Load` maps a source element to its signed-domain byte.
-template <typename T, typename Load>
+// Staging of conv activations: NCHW -> padded channel-blocked signed bytes [N][Cp/16][Hp][Wp][16 B]; border = pad
+// value of the selected mode, padded channels 0.  A workgroup handles 64 consecutive PADDED pixel positions of one
+// image (so small feature maps still fill the lanes) x 64 channels: coalesced reads along the source's pixel axis,
+// and -- through an LDS transpose -- one 16-byte piece per (pixel, 16-channel block), consecutive lanes writing
+// consecutive pixels (1 KiB runs).  `prep()` runs AFTER the tile's loads are in flight (so e.g. the statistics reduce
+// of the fused quantizer hides behind them) and returns the mapping: `.fill` = signed-domain border byte,
+// `.byte(v)` = source element -> signed-domain byte.
+template <typename T, typename Prep>
 __device__ __forceinline__ void stage_nhwc_tile(const T *__restrict__ x, uint8_t *__restrict__ xp, int C, int H, int W, int Hp, int Wp, int Cp, int pt, int pl,
-                                                unsigned fill, Load load) {
+                                                Prep prep) {
     __shared__ uint8_t tile[64][64 + 16];
     const int t = threadIdx.x;
     const int pp0 = blockIdx.x * 64, n = blockIdx.y;
@@ -127,6 +133,8 @@ __device__ __forceinline__ void stage_nhwc_tile(const T *__restrict__ x, uint8_t
             const int c = c0 + pass * 16 + (t >> 6) * 4 + b;
             raw[pass * 4 + b] = x[(in && c < C) ? src0 + (long long)c * H * W : 0];
         }
+    const auto map = prep();
+    const unsigned fill = map.fill;
 #pragma unroll
     for (int pass = 0; pass < 4; pass++) {
         const int cl = pass * 16 + (t >> 6) * 4;
@@ -134,51 +142,66 @@ __device__ __forceinline__ void stage_nhwc_tile(const T *__restrict__ x, uint8_t
 #pragma unroll
         for (int b = 0; b < 4; b++) {
             const int c = c0 + cl + b;
-            const unsigned v = (in && c < C) ? load(raw[pass * 4 + b]) & 0xffu : (c < C ? fill : 0u);
+            const unsigned v = (in && c < C) ? map.byte(raw[pass * 4 + b]) & 0xffu : (c < C ? fill : 0u);
             w |= v << (8 * b);
         }
         *reinterpret_cast<unsigned *>(&tile[pl_][cl]) = w;
     }
     __syncthreads();
-    const int px = t >> 2, ch = t & 3;
+    const int px = t & 63, ch = t >> 6;
     if (pp0 + px < npix && c0 + ch * 16 < Cp)
-        *reinterpret_cast<uint4 *>(xp + ((long long)n * npix + pp0 + px) * Cp + c0 + ch * 16) = *reinterpret_cast<const uint4 *>(&tile[px][ch * 16]);
+        *reinterpret_cast<uint4 *>(xp + (((long long)n * (Cp / 16) + (c0 / 16 + ch)) * npix + pp0 + px) * 16) = *reinterpret_cast<const uint4 *>(&tile[px][ch * 16]);
 }
+
+struct FlipMap {
+    unsigned fill, flip;
+    __device__ __forceinline__ unsigned byte(uint8_t b) const { return ((unsigned)b ^ flip) & 0xffu; }
+};
+struct QuantMap {
+    unsigned fill;
+    float inv_scale;
+    int zp;
+    __device__ __forceinline__ unsigned byte(float f) const { return dql::quant_u8(f, inv_scale, zp) ^ 0x80u; }
+};
 
 __global__ __launch_bounds__(256) void i8_nhwc_pad_kernel(const uint8_t *__restrict__ x, uint8_t *__restrict__ xp, int C, int H, int W, int Hp,
                                                          int Wp, int Cp, int pt, int pl, unsigned flip, const uint8_t *__restrict__ x_zp,
                                                          int x_signed, int pad_mode) {
-    int pad_s = 0;
-    if (pad_mode == RTEN_HIP_PAD_ZERO_POINT) pad_s = zp_signed(x_zp, 0, x_signed);
-    else if (pad_mode == RTEN_HIP_PAD_RAW0_U8) pad_s = -128;
-    stage_nhwc_tile(x, xp, C, H, W, Hp, Wp, Cp, pt, pl, (unsigned)pad_s & 0xffu, [flip](uint8_t b) { return ((unsigned)b ^ flip) & 0xffu; });
+    stage_nhwc_tile(x, xp, C, H, W, Hp, Wp, Cp, pt, pl, [&]() {
+        int pad_s = 0;
+        if (pad_mode == RTEN_HIP_PAD_ZERO_POINT) pad_s = zp_signed(x_zp, 0, x_signed);
+        else if (pad_mode == RTEN_HIP_PAD_RAW0_U8) pad_s = -128;
+        return FlipMap{(unsigned)pad_s & 0xffu, flip};
+    });
 }
 
 // DynamicQuantizeLinear's quantize sweep fused with the staging above: f32 NCHW -> u8 codes (bit-identical to
-// quantize.hip: same scale / zero-point algebra, same to_int_round + saturate) written as padded NHWC signed bytes.
+// quantize.hip: same scale / zero-point algebra, same to_int_round + saturate) written as padded channel-blocked
+// signed bytes.  The min/max fold runs while the tile's loads are in flight.
 __global__ __launch_bounds__(256) void i8_quantize_stage_kernel(const float *__restrict__ x, const float *__restrict__ ws, int nparts, uint8_t *__restrict__ xp,
                                                                int C, int H, int W, int Hp, int Wp, int Cp, int pt, int pl, int pad_mode,
                                                                float *scale_out, uint8_t *zp_out, const float *mul_by, float *product_out) {
-    float x_min, x_max;
-    if (nparts < 0) dql::block_minmax_slots(reinterpret_cast<const unsigned *>(ws), x_min, x_max); // producer-accumulated statistics
-    else dql::block_minmax(ws, nparts, x_min, x_max);
-    const dql::QParams q = dql::dql_params(x_min, x_max);
-    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
-        *scale_out = q.scale;
-        *zp_out = (uint8_t)q.zp;
-        if (mul_by) *product_out = q.scale * mul_by[0]; // the Mul(x_scale, w_scale) node that follows in ort-quantized graphs
-    }
-    int pad_s = 0; // signed-domain padding value
-    if (pad_mode == RTEN_HIP_PAD_ZERO_POINT) pad_s = q.zp - 128;
-    else if (pad_mode == RTEN_HIP_PAD_RAW0_U8) pad_s = -128;
-    stage_nhwc_tile(x, xp, C, H, W, Hp, Wp, Cp, pt, pl, (unsigned)pad_s & 0xffu,
-                    [q](float f) { return dql::quant_u8(f, q.inv_scale, q.zp) ^ 0x80u; });
+    stage_nhwc_tile(x, xp, C, H, W, Hp, Wp, Cp, pt, pl, [&]() {
+        float x_min, x_max;
+        if (nparts < 0) dql::block_minmax_slots(reinterpret_cast<const unsigned *>(ws), x_min, x_max); // producer-accumulated statistics
+        else dql::block_minmax(ws, nparts, x_min, x_max);
+        const dql::QParams q = dql::dql_params(x_min, x_max);
+        if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+            *scale_out = q.scale;
+            *zp_out = (uint8_t)q.zp;
+            if (mul_by) *product_out = q.scale * mul_by[0]; // the Mul(x_scale, w_scale) node that follows in ort-quantized graphs
+        }
+        int pad_s = 0; // signed-domain padding value
+        if (pad_mode == RTEN_HIP_PAD_ZERO_POINT) pad_s = q.zp - 128;
+        else if (pad_mode == RTEN_HIP_PAD_RAW0_U8) pad_s = -128;
+        return QuantMap{(unsigned)pad_s & 0xffu, q.inv_scale, q.zp};
+    });
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // main kernel
 // ---------------------------------------------------------------------------------------------------------
-template <int BM, int BN>
+template <int BM, int BN, int NSTAGE>
 __global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p) {
     constexpr int WM = 2, WN = 2;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -197,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p)
         const int xcd = id & 7, q = nt >> 3, r = nt & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
     }
-    const int bm = tile % p.tiles_m, bn = tile / p.tiles_m;
+    const int bm = p.n_fastest ? tile / p.tiles_n : tile % p.tiles_m, bn = p.n_fastest ? tile % p.tiles_n : tile / p.tiles_m;
     const int m0 = bm * BM, n0 = bn * BN;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)p.A, 0, (int)p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void *)p.B, 0, (int)p.b_bytes, 0x00020000);
@@ -207,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p)
 #pragma unroll
     for (int j = 0; j < RA; j++) {
         const int m = m0 + j * 64 + lane;
-        a_voff[j] = m < p.M ? (unsigned)m * (unsigned)p.Kp : OOB;
+        a_voff[j] = m < p.M ? (unsigned)m * 16u : OOB;
     }
 #pragma unroll
     for (int j = 0; j < RB; j++) {
@@ -216,9 +239,9 @@ __global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p)
             if (p.conv) {
                 const int nb = n / p.Pn, np = n - nb * p.Pn;
                 const int oy = np / p.OW, ox = np - oy * p.OW;
-                b_voff[j] = (unsigned)(((nb * p.Hp + oy * p.sy) * p.Wp + ox * p.sx) * p.Cp);
+                b_voff[j] = (unsigned)(((nb * (p.Cp / 16) * p.Hp + oy * p.sy) * p.Wp + ox * p.sx) * 16);
             } else {
-                b_voff[j] = (unsigned)n * (unsigned)p.Kp;
+                b_voff[j] = (unsigned)n * 16u;
             }
         } else {
             b_voff[j] = OOB;
@@ -239,12 +262,12 @@ __global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p)
         uint8_t *As = smem + stage * STAGE + wave * BM * 16;
         uint8_t *Bs = smem + stage * STAGE + BM * KT + wave * BN * 16;
         const bool live = ch_idx < nchunks;
-        const unsigned a_soff = live ? (unsigned)ch_idx * 16u : 0u;
-        unsigned b_soff = a_soff;
+        const unsigned a_soff = live ? (unsigned)ch_idx * 16u * (unsigned)p.M : 0u;
+        unsigned b_soff = live ? (unsigned)ch_idx * 16u * (unsigned)p.N : 0u;
         bool b_live = live;
         if (p.conv) {
             b_live = live && ch_ky < p.KH;
-            b_soff = b_live ? (unsigned)(((ch_ky * p.dy) * p.Wp + ch_kx * p.dx) * p.Cp + ch_c * 16) : 0u;
+            b_soff = b_live ? (unsigned)(((ch_c * p.Hp + ch_ky * p.dy) * p.Wp + ch_kx * p.dx) * 16) : 0u;
         }
 #pragma unroll
         for (int j = 0; j < RA; j++)
@@ -345,6 +368,8 @@ __global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p)
     const int nk = (p.Kp + KT - 1) / KT;
 #pragma unroll
     for (int i = 0; i < NSTAGE - 1; i++) issue_tile(i);
+    // (A two-fragment-set software pipeline of the LDS reads under the MFMAs was measured and is slower: these
+    // launches are bound by the miss latency of the tile DMA, not by the read -> MFMA chain.)
     int stage = 0;
     for (int kt = 0; kt < nk; kt++) {
         wait_vmcnt<PER_TILE *(NSTAGE - 2)>();
@@ -455,8 +480,9 @@ __global__ __launch_bounds__(256) void i8_pack_rows_t_kernel(const uint8_t *__re
         tile[rl][kl] = (uint8_t)v;
     }
     __syncthreads();
-    // write: thread -> (row, 16-byte group); k0 + 64 <= Kp always (Kp is a multiple of 64)
-    const int rl = t >> 2, g = t & 3;
+    // write: thread -> (row, 16-byte group), consecutive lanes on consecutive rows of one chunk plane; k0 + 64 <= Kp
+    // always (Kp is a multiple of 64)
+    const int rl = t & 63, g = t >> 6;
     const int r = r0 + rl;
     int sum = 0;
     if (r < rows) {
@@ -467,31 +493,34 @@ __global__ __launch_bounds__(256) void i8_pack_rows_t_kernel(const uint8_t *__re
                    ((unsigned)tile[rl][g * 16 + q * 4 + 3] << 24);
             sum = __builtin_amdgcn_sdot4((int)w[q], 0x01010101, sum, false);
         }
-        *reinterpret_cast<uint4 *>(dst + (long long)r * Kp + k0 + g * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+        *reinterpret_cast<uint4 *>(dst + ((long long)(k0 / 16 + g) * rows + r) * 16) = make_uint4(w[0], w[1], w[2], w[3]);
     }
-    sum += __shfl_xor(sum, 1, 64);
-    sum += __shfl_xor(sum, 2, 64);
-    if (g == 0 && r < rows) atomicAdd(&sums[r], sum);
+    if (r < rows) atomicAdd(&sums[r], sum);
 }
 
 inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-template <int BM, int BN>
+template <int BM, int BN, int NST>
 void launch_fast(rten_hip_ctx *ctx, FastArgs &a, const char *name, double ops, double bytes) {
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.N + BN - 1) / BN;
     ProfScope ps(ctx, name, ops, bytes);
-    hipLaunchKernelGGL((igemm_i8_fast_kernel<BM, BN>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL((igemm_i8_fast_kernel<BM, BN, NST>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), 0, ctx->stream, a);
 }
 
 int32_t dispatch_fast(rten_hip_ctx *ctx, FastArgs &a, double ops, double bytes) {
-    // tile choice: largest tile that still gives every CU work
+    // tile choice: the largest tile that still gives every CU a workgroup (the tile DMA of a workgroup tops out far
+    // below what the MFMAs could consume, so an idle CU costs more than the extra operand re-reads of a smaller tile)
     const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     const long long t12864 = (long long)((a.M + 127) / 128) * ((a.N + 63) / 64);
-    if (a.M > 64 && t128 >= ctx->num_cus) launch_fast<128, 128>(ctx, a, "igemm_i8_fast_kernel<128,128>", ops, bytes);
-    else if (a.M > 64 && t12864 >= ctx->num_cus / 2) launch_fast<128, 64>(ctx, a, "igemm_i8_fast_kernel<128,64>", ops, bytes);
-    else if (a.M > 64) launch_fast<128, 64>(ctx, a, "igemm_i8_fast_kernel<128,64>", ops, bytes);
-    else launch_fast<64, 128>(ctx, a, "igemm_i8_fast_kernel<64,128>", ops, bytes);
+    const int tile = a.M <= 64 ? 2 : (t128 >= ctx->num_cus ? 0 : (t12864 >= ctx->num_cus ? 1 : 3));
+    // tile order: consecutive workgroup ids (one XCD's share) walk the axis of the SMALLER operand, so that the larger
+    // one is fetched into as few of the eight L2s as possible
+    a.n_fastest = (double)a.a_bytes > (double)a.b_bytes ? 1 : 0;
+    if (tile == 0) launch_fast<128, 128, 3>(ctx, a, "igemm_i8_fast_kernel<128,128>", ops, bytes);
+    else if (tile == 1) launch_fast<128, 64, 3>(ctx, a, "igemm_i8_fast_kernel<128,64>", ops, bytes);
+    else if (tile == 2) launch_fast<64, 128, 3>(ctx, a, "igemm_i8_fast_kernel<64,128>", ops, bytes);
+    else launch_fast<64, 64, 3>(ctx, a, "igemm_i8_fast_kernel<64,64>", ops, bytes);
     RTEN_LAUNCH_CHECK(ctx, "igemm_i8_fast_kernel launch");
     return RTEN_HIP_OK;
 }
@@ -512,7 +541,7 @@ int32_t rten_i8_fast_gemm(rten_hip_ctx *ctx, const rten_hip_gemm_int8_desc *d, c
     auto pack = [&](const void *src, long long row_stride, long long k_stride, int rows, unsigned flip, char *dst, char *sums) {
         if (k_stride == 1) {
             hipLaunchKernelGGL(i8_pack_rows_kernel, dim3((unsigned)rows), dim3(256), 0, ctx->stream, (const uint8_t *)src, row_stride, k_stride, d->k, d->k, 1,
-                               Kp, Kp, flip, (uint8_t *)dst, (int *)sums);
+                               Kp, Kp, rows, flip, (uint8_t *)dst, (int *)sums);
         } else {
             hipMemsetAsync(sums, 0, (size_t)rows * 4, ctx->stream);
             hipLaunchKernelGGL(i8_pack_rows_t_kernel, dim3((unsigned)((rows + 63) / 64), (unsigned)(Kp / 64)), dim3(256), 0, ctx->stream, (const uint8_t *)src,
@@ -571,7 +600,7 @@ RTEN_EXPORT int32_t rten_hip_conv2d_int8_prepack(rten_hip_ctx *ctx, const rten_h
     if (!g.ok) return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "conv_int8 prepack: geometry not covered by the staged kernel (packed_bytes == 0)");
     const rten_hip_conv2d_desc *d = &di->conv;
     hipLaunchKernelGGL(i8_pack_rows_kernel, dim3((unsigned)d->o), dim3(256), 0, ctx->stream, (const uint8_t *)w, (long long)g.Kreal, 1ll, g.Kreal, d->c, g.taps,
-                       g.Cp, g.Kp, di->w_signed ? 0u : 0x80u, (uint8_t *)packed, (int *)((char *)packed + up256((size_t)d->o * g.Kp)));
+                       g.Cp, g.Kp, d->o, di->w_signed ? 0u : 0x80u, (uint8_t *)packed, (int *)((char *)packed + up256((size_t)d->o * g.Kp)));
     RTEN_LAUNCH_CHECK(ctx, "i8_pack_rows_kernel launch");
     return RTEN_HIP_OK;
 }
@@ -654,7 +683,7 @@ int32_t rten_i8_fast_conv(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di
         Ap = (const uint8_t *)(sc + offA);
         rsum = (const int *)(sc + offA + up256((size_t)d->o * cg.Kp));
         hipLaunchKernelGGL(i8_pack_rows_kernel, dim3((unsigned)d->o), dim3(256), 0, ctx->stream, (const uint8_t *)w, (long long)cg.Kreal, 1ll, cg.Kreal, d->c,
-                           cg.taps, cg.Cp, cg.Kp, di->w_signed ? 0u : 0x80u, (uint8_t *)Ap, (int *)rsum);
+                           cg.taps, cg.Cp, cg.Kp, d->o, di->w_signed ? 0u : 0x80u, (uint8_t *)Ap, (int *)rsum);
     }
     if (!di->x_staged)
         hipLaunchKernelGGL(i8_nhwc_pad_kernel, dim3((unsigned)((cg.Hp * cg.Wp + 63) / 64), (unsigned)d->n, (unsigned)((cg.Cp + 63) / 64)), dim3(256), 0, ctx->stream, (const uint8_t *)x,
