@@ -68,7 +68,12 @@ class Bert:
         w = self.weights
         up = lambda a: DeviceTensor.from_numpy(ctx, a)
         self.d = {k: up(w[k]) for k in ("word", "pos", "type", "emb_ln_g", "emb_ln_b")}
-        self.dl = [{k: up(v) for k, v in lw.items()} for lw in w["layers"]]
+        self.dl = [{k: up(v) for k, v in lw.items() if k not in ("wq", "wk", "wv", "bq", "bk", "bv")} for lw in w["layers"]]
+        # Q, K and V projections share their input: one GEMM against [Wq | Wk | Wv] (N = 3H gives 576 tiles instead of
+        # 3 x 192 on 256 CUs).  Every output element is the same k-ordered dot product, so the result is bit-identical.
+        for dlw, lw in zip(self.dl, w["layers"]):
+            dlw["wqkv"] = up(np.ascontiguousarray(np.concatenate([lw["wq"], lw["wk"], lw["wv"]], axis=1)))
+            dlw["bqkv"] = up(np.concatenate([lw["bq"], lw["bk"], lw["bv"]]))
         T, H = batch * seq, cfg.hidden
         f32 = np.float32
         self.ids = DeviceTensor(ctx, (T,), np.int32)
@@ -76,11 +81,13 @@ class Bert:
         self.mask = DeviceTensor(ctx, (batch, 1, 1, seq), f32)
         self.x = DeviceTensor(ctx, (T, H), f32)
         self.tmp = DeviceTensor(ctx, (T, H), f32)
-        self.q, self.k, self.v, self.att = (DeviceTensor(ctx, (T, H), f32) for _ in range(4))
+        self.qkv = DeviceTensor(ctx, (T, 3 * H), f32)  # [Q | K | V] rows; the attention kernel reads the three column blocks in place
+        self.att = DeviceTensor(ctx, (T, H), f32)
+        self.q_vp, self.k_vp, self.v_vp = (C.c_void_p(self.qkv.ptr + i * H * 4) for i in range(3))
         self.h = DeviceTensor(ctx, (T, cfg.ffn), f32)
         dh = H // cfg.heads
         scale = float(np.float32(1.0) / np.sqrt(np.float32(dh)))
-        self.sdpa_desc = L.SdpaDesc(batch, cfg.heads, seq, seq, dh, dh, seq * H, dh, H, seq * H, dh, H, seq * H, dh, H,
+        self.sdpa_desc = L.SdpaDesc(batch, cfg.heads, seq, seq, dh, dh, seq * 3 * H, dh, 3 * H, seq * 3 * H, dh, 3 * H, seq * 3 * H, dh, 3 * H,
                                     seq * H, dh, H, seq, 0, scale, 0)
 
     def set_inputs(self, input_ids, attention_mask, token_type_ids):
@@ -102,8 +109,8 @@ class Bert:
         picks kernels per ISA at start-up, rten-gemm/src/lib.rs:534-547).  Returns {(n, k): [(variant, ms), ...]}."""
         ctx, cfg, H = self.ctx, self.cfg, self.cfg.hidden
         lw = self.dl[0]
-        shapes = {(H, H): (self.x, lw["wq"], lw["bq"], self.q, L.ACT_NONE), (cfg.ffn, H): (self.x, lw["w1"], lw["b1"], self.h, L.ACT_GELU),
-                  (H, cfg.ffn): (self.h, lw["w2"], lw["b2"], self.tmp, L.ACT_NONE)}
+        shapes = {(3 * H, H): (self.x, lw["wqkv"], lw["bqkv"], self.qkv, L.ACT_NONE), (H, H): (self.att, lw["wo"], lw["bo"], self.tmp, L.ACT_NONE),
+                  (cfg.ffn, H): (self.x, lw["w1"], lw["b1"], self.h, L.ACT_GELU), (H, cfg.ffn): (self.h, lw["w2"], lw["b2"], self.tmp, L.ACT_NONE)}
         table = {}
         for (n, k), (x, w, b, out, act) in shapes.items():
             row = []
@@ -132,10 +139,8 @@ class Bert:
         ctx.call("rten_hip_add_f32", T * H, self.x.vp, d["pos"].vp, self.S * H, self.x.vp)
         ctx.call("rten_hip_layer_norm_f32", T, H, self.x.vp, d["emb_ln_g"].vp, d["emb_ln_b"].vp, 1.0, 0.0, cfg.eps, self.x.vp)
         for lw in self.dl:
-            self._linear(self.x, lw["wq"], lw["bq"], self.q, H, H)
-            self._linear(self.x, lw["wk"], lw["bk"], self.k, H, H)
-            self._linear(self.x, lw["wv"], lw["bv"], self.v, H, H)
-            ctx.call("rten_hip_sdpa_f32", C.byref(self.sdpa_desc), self.q.vp, self.k.vp, self.v.vp, self.mask.vp, self.att.vp)
+            self._linear(self.x, lw["wqkv"], lw["bqkv"], self.qkv, 3 * H, H)
+            ctx.call("rten_hip_sdpa_f32", C.byref(self.sdpa_desc), self.q_vp, self.k_vp, self.v_vp, self.mask.vp, self.att.vp)
             self._linear(self.att, lw["wo"], lw["bo"], self.tmp, H, H)
             # Add(residual) -> LayerNormalization as one kernel
             ctx.call("rten_hip_add_layer_norm_f32", T, H, self.tmp.vp, self.x.vp, lw["ln1_g"].vp, lw["ln1_b"].vp, 1.0, 0.0, cfg.eps, self.x.vp)
