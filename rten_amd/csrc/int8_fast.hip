@@ -104,14 +104,80 @@ __global__ __launch_bounds__(256) void i8_pack_rows_kernel(const uint8_t *__rest
 }
 
 // Staging of conv activations: NCHW -> padded channel-blocked signed bytes [N][Cp/16][Hp][Wp][16 B]; border = pad
-// value of the selected mode, padded channels 0.  A workgroup handles 64 consecutive PADDED pixel positions of one
-// image (so small feature maps still fill the lanes) x 64 channels: coalesced reads along the source's pixel axis,
-// and -- through an LDS transpose -- one 16-byte piece per (pixel, 16-channel block), consecutive lanes writing
-// consecutive pixels (1 KiB runs).  `prep()` runs AFTER the tile's loads are in flight (so e.g. the statistics reduce
-// of the fused quantizer hides behind them) and returns the mapping: `.fill` = signed-domain border byte,
-// `.byte(v)` = source element -> signed-domain byte.
+// value of the selected mode, padded channels 0.  A workgroup takes 256 consecutive SOURCE pixels of one image x one
+// 16-channel block: a thread loads 4 consecutive pixels (one 16-byte load when the plane size allows) of 4 consecutive
+// channels, packs the 4 channel bytes of each pixel into a dword and parks them in LDS ([channel quad][pixel], one
+// conflict-free ds_write_b128); the workgroup then writes the run of PADDED positions that its pixels span -- border
+// pieces included -- as consecutive 16-byte pieces (1 KiB per wave instruction).  `prep()` runs AFTER the loads are in
+// flight (so e.g. the statistics fold of the fused quantizer hides behind them) and returns the mapping: `.fill` =
+// signed-domain border byte, `.byte(v)` = source element -> signed-domain byte.
+template <typename T> struct Vec4;
+template <> struct Vec4<float> { typedef float4 type; };
+template <> struct Vec4<uint8_t> { typedef uchar4 type; };
+
+template <typename T, bool VEC, typename Prep>
+__device__ __forceinline__ void stage_blocked_tile(const T *__restrict__ x, uint8_t *__restrict__ xp, int C, int H, int W, int Hp, int Wp, int Cp, int pt, int pl,
+                                                   Prep prep) {
+    __shared__ __attribute__((aligned(16))) unsigned tile[4][256];
+    const int t = threadIdx.x;
+    const int HW = H * W, npix = Hp * Wp;
+    const int p0 = blockIdx.x * 256, n = blockIdx.y, cb = blockIdx.z;
+    const int px = (t & 63) * 4, cq = (t >> 6) * 4;
+    T raw[4][4]; // [channel][pixel]
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int c = cb * 16 + cq + j;
+        const long long base = ((long long)n * C + (c < C ? c : 0)) * HW + p0 + px;
+        if constexpr (VEC) { // HW % 4 == 0: the 4 pixels are all inside or all outside, and the address is 4-element aligned
+            const typename Vec4<T>::type v = *reinterpret_cast<const typename Vec4<T>::type *>(x + ((c < C && p0 + px < HW) ? base : 0));
+            raw[j][0] = v.x; raw[j][1] = v.y; raw[j][2] = v.z; raw[j][3] = v.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) raw[j][i] = x[(c < C && p0 + px + i < HW) ? base + i : 0];
+        }
+    }
+    const auto map = prep();
+    unsigned w[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        w[i] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned v = (cb * 16 + cq + j < C) ? map.byte(raw[j][i]) & 0xffu : 0u;
+            w[i] |= v << (8 * j);
+        }
+    }
+    *reinterpret_cast<uint4 *>(&tile[t >> 6][px]) = make_uint4(w[0], w[1], w[2], w[3]);
+    __syncthreads();
+    // border piece of this channel block: pad byte on real channels, 0 on the padding channels
+    unsigned fw[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        fw[q] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) fw[q] |= (cb * 16 + q * 4 + j < C ? map.fill : 0u) << (8 * j);
+    }
+    auto padded = [&](int sp) { const int y = sp / W; return (y + pt) * Wp + (sp - y * W) + pl; };
+    const int s_end = p0 + 256 < HW ? p0 + 256 : HW;
+    const int begin = p0 == 0 ? 0 : padded(p0);
+    const int end = s_end == HW ? npix : padded(s_end);
+    uint8_t *dst = xp + ((long long)n * (Cp / 16) + cb) * npix * 16;
+    for (int pp = begin + t; pp < end; pp += 256) {
+        const int yp = pp / Wp, xq = pp - yp * Wp;
+        const int y = yp - pt, xs = xq - pl;
+        uint4 v = make_uint4(fw[0], fw[1], fw[2], fw[3]);
+        if ((unsigned)y < (unsigned)H && (unsigned)xs < (unsigned)W) {
+            const int sl = y * W + xs - p0; // in [0, 256): the padded run [begin, end) covers exactly this workgroup's pixels
+            v = make_uint4(tile[0][sl], tile[1][sl], tile[2][sl], tile[3][sl]);
+        }
+        *reinterpret_cast<uint4 *>(dst + (long long)pp * 16) = v;
+    }
+}
+
+// Small feature maps (fewer than 128 pixels per plane, e.g. 7x7): 64 consecutive PADDED positions x 64 channels per
+// workgroup, one pixel per lane, so the lanes stay busy where the 256-pixel tile above would idle.
 template <typename T, typename Prep>
-__device__ __forceinline__ void stage_nhwc_tile(const T *__restrict__ x, uint8_t *__restrict__ xp, int C, int H, int W, int Hp, int Wp, int Cp, int pt, int pl,
+__device__ __forceinline__ void stage_blocked_tile_small(const T *__restrict__ x, uint8_t *__restrict__ xp, int C, int H, int W, int Hp, int Wp, int Cp, int pt, int pl,
                                                 Prep prep) {
     __shared__ uint8_t tile[64][64 + 16];
     const int t = threadIdx.x;
@@ -164,24 +230,28 @@ struct QuantMap {
     __device__ __forceinline__ unsigned byte(float f) const { return dql::quant_u8(f, inv_scale, zp) ^ 0x80u; }
 };
 
+template <int KIND> // 0 = small maps, 1 = 256-pixel tiles with scalar loads, 2 = with 4-pixel vector loads
 __global__ __launch_bounds__(256) void i8_nhwc_pad_kernel(const uint8_t *__restrict__ x, uint8_t *__restrict__ xp, int C, int H, int W, int Hp,
                                                          int Wp, int Cp, int pt, int pl, unsigned flip, const uint8_t *__restrict__ x_zp,
                                                          int x_signed, int pad_mode) {
-    stage_nhwc_tile(x, xp, C, H, W, Hp, Wp, Cp, pt, pl, [&]() {
+    auto prep = [&]() {
         int pad_s = 0;
         if (pad_mode == RTEN_HIP_PAD_ZERO_POINT) pad_s = zp_signed(x_zp, 0, x_signed);
         else if (pad_mode == RTEN_HIP_PAD_RAW0_U8) pad_s = -128;
         return FlipMap{(unsigned)pad_s & 0xffu, flip};
-    });
+    };
+    if constexpr (KIND == 0) stage_blocked_tile_small(x, xp, C, H, W, Hp, Wp, Cp, pt, pl, prep);
+    else stage_blocked_tile<uint8_t, KIND == 2>(x, xp, C, H, W, Hp, Wp, Cp, pt, pl, prep);
 }
 
 // DynamicQuantizeLinear's quantize sweep fused with the staging above: f32 NCHW -> u8 codes (bit-identical to
 // quantize.hip: same scale / zero-point algebra, same to_int_round + saturate) written as padded channel-blocked
 // signed bytes.  The min/max fold runs while the tile's loads are in flight.
+template <int KIND>
 __global__ __launch_bounds__(256) void i8_quantize_stage_kernel(const float *__restrict__ x, const float *__restrict__ ws, int nparts, uint8_t *__restrict__ xp,
                                                                int C, int H, int W, int Hp, int Wp, int Cp, int pt, int pl, int pad_mode,
                                                                float *scale_out, uint8_t *zp_out, const float *mul_by, float *product_out) {
-    stage_nhwc_tile(x, xp, C, H, W, Hp, Wp, Cp, pt, pl, [&]() {
+    auto prep = [&]() {
         float x_min, x_max;
         if (nparts < 0) dql::block_minmax_slots(reinterpret_cast<const unsigned *>(ws), x_min, x_max); // producer-accumulated statistics
         else dql::block_minmax(ws, nparts, x_min, x_max);
@@ -195,7 +265,9 @@ __global__ __launch_bounds__(256) void i8_quantize_stage_kernel(const float *__r
         if (pad_mode == RTEN_HIP_PAD_ZERO_POINT) pad_s = q.zp - 128;
         else if (pad_mode == RTEN_HIP_PAD_RAW0_U8) pad_s = -128;
         return QuantMap{(unsigned)pad_s & 0xffu, q.inv_scale, q.zp};
-    });
+    };
+    if constexpr (KIND == 0) stage_blocked_tile_small(x, xp, C, H, W, Hp, Wp, Cp, pt, pl, prep);
+    else stage_blocked_tile<float, KIND == 2>(x, xp, C, H, W, Hp, Wp, Cp, pt, pl, prep);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -587,6 +659,20 @@ ConvGeom conv_geom(const rten_hip_conv2d_int8_desc *di) {
 }
 } // namespace
 
+namespace {
+void launch_quantize_stage(rten_hip_ctx *ctx, const rten_hip_conv2d_desc *d, const ConvGeom &g, const float *x, const float *ws, int nparts, void *staged,
+                           int pad_mode, float *scale, uint8_t *zero_point, const float *mul_by, float *product) {
+    const dim3 grid((unsigned)((d->h * d->w + 255) / 256), (unsigned)d->n, (unsigned)(g.Cp / 16));
+    const dim3 grid_small((unsigned)((g.Hp * g.Wp + 63) / 64), (unsigned)d->n, (unsigned)((g.Cp + 63) / 64));
+    const bool vec = (d->h * d->w) % 4 == 0 && ((uintptr_t)x & 15) == 0;
+#define QS_ARGS x, ws, nparts, (uint8_t *)staged, d->c, d->h, d->w, g.Hp, g.Wp, g.Cp, d->pads[0], d->pads[1], pad_mode, scale, zero_point, mul_by, product
+    if (d->h * d->w < 128) hipLaunchKernelGGL(i8_quantize_stage_kernel<0>, grid_small, dim3(256), 0, ctx->stream, QS_ARGS);
+    else if (vec) hipLaunchKernelGGL(i8_quantize_stage_kernel<2>, grid, dim3(256), 0, ctx->stream, QS_ARGS);
+    else hipLaunchKernelGGL(i8_quantize_stage_kernel<1>, grid, dim3(256), 0, ctx->stream, QS_ARGS);
+#undef QS_ARGS
+}
+} // namespace
+
 RTEN_EXPORT size_t rten_hip_conv2d_int8_packed_bytes(const rten_hip_conv2d_int8_desc *di) {
     if (!di) return 0;
     const ConvGeom g = conv_geom(di);
@@ -623,9 +709,7 @@ RTEN_EXPORT int32_t rten_hip_dynamic_quantize_linear_staged(rten_hip_ctx *ctx, c
     int nparts = 0;
     const float *ws = rten_dql_minmax(ctx, n, x, &nparts);
     if (!ws) return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "dql: scratch allocation failed");
-    hipLaunchKernelGGL(i8_quantize_stage_kernel, dim3((unsigned)((g.Hp * g.Wp + 63) / 64), (unsigned)d->n, (unsigned)((g.Cp + 63) / 64)), dim3(256), 0, ctx->stream,
-                       x, ws, nparts, (uint8_t *)staged, d->c, d->h, d->w, g.Hp, g.Wp, g.Cp, d->pads[0], d->pads[1], di->pad_mode, scale, zero_point, mul_by,
-                       product);
+    launch_quantize_stage(ctx, d, g, x, ws, nparts, staged, di->pad_mode, scale, zero_point, mul_by, product);
     RTEN_LAUNCH_CHECK(ctx, "i8_quantize_stage_kernel launch");
     return RTEN_HIP_OK;
 }
@@ -656,9 +740,7 @@ RTEN_EXPORT int32_t rten_hip_dynamic_quantize_linear_staged_stats(rten_hip_ctx *
     if (!g.ok || di->x_signed) return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "quantize_staged: geometry not covered by the staged kernel (staged_bytes == 0)");
     const rten_hip_conv2d_desc *d = &di->conv;
     ProfScope ps(ctx, "dynamic_quantize_linear_staged_stats", 0.0, 4.0 * d->n * d->c * (double)d->h * d->w + (double)g.img);
-    hipLaunchKernelGGL(i8_quantize_stage_kernel, dim3((unsigned)((g.Hp * g.Wp + 63) / 64), (unsigned)d->n, (unsigned)((g.Cp + 63) / 64)), dim3(256), 0, ctx->stream,
-                       x, (const float *)stats, -1, (uint8_t *)staged, d->c, d->h, d->w, g.Hp, g.Wp, g.Cp, d->pads[0], d->pads[1], di->pad_mode, scale, zero_point,
-                       mul_by, product);
+    launch_quantize_stage(ctx, d, g, x, (const float *)stats, -1, staged, di->pad_mode, scale, zero_point, mul_by, product);
     RTEN_LAUNCH_CHECK(ctx, "i8_quantize_stage_kernel launch");
     return RTEN_HIP_OK;
 }
@@ -686,9 +768,16 @@ int32_t rten_i8_fast_conv(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di
                            cg.taps, cg.Cp, cg.Kp, d->o, di->w_signed ? 0u : 0x80u, (uint8_t *)Ap, (int *)rsum);
     }
     if (!di->x_staged)
-        hipLaunchKernelGGL(i8_nhwc_pad_kernel, dim3((unsigned)((cg.Hp * cg.Wp + 63) / 64), (unsigned)d->n, (unsigned)((cg.Cp + 63) / 64)), dim3(256), 0, ctx->stream, (const uint8_t *)x,
-                           (uint8_t *)(sc + offB), d->c, d->h, d->w, cg.Hp, cg.Wp, cg.Cp, d->pads[0], d->pads[1], di->x_signed ? 0u : 0x80u,
-                           (const uint8_t *)x_zp, di->x_signed, di->pad_mode);
+    {
+        const dim3 grid((unsigned)((d->h * d->w + 255) / 256), (unsigned)d->n, (unsigned)(cg.Cp / 16));
+        const dim3 grid_small((unsigned)((cg.Hp * cg.Wp + 63) / 64), (unsigned)d->n, (unsigned)((cg.Cp + 63) / 64));
+        const bool vec = (d->h * d->w) % 4 == 0 && ((uintptr_t)x & 3) == 0;
+#define PAD_ARGS (const uint8_t *)x, (uint8_t *)(sc + offB), d->c, d->h, d->w, cg.Hp, cg.Wp, cg.Cp, d->pads[0], d->pads[1], di->x_signed ? 0u : 0x80u, (const uint8_t *)x_zp, di->x_signed, di->pad_mode
+        if (d->h * d->w < 128) hipLaunchKernelGGL(i8_nhwc_pad_kernel<0>, grid_small, dim3(256), 0, ctx->stream, PAD_ARGS);
+        else if (vec) hipLaunchKernelGGL(i8_nhwc_pad_kernel<2>, grid, dim3(256), 0, ctx->stream, PAD_ARGS);
+        else hipLaunchKernelGGL(i8_nhwc_pad_kernel<1>, grid, dim3(256), 0, ctx->stream, PAD_ARGS);
+#undef PAD_ARGS
+    }
     RTEN_LAUNCH_CHECK(ctx, "int8 staging launch");
     FastArgs g = {};
     g.A = Ap; g.B = di->x_staged ? (const uint8_t *)x : (const uint8_t *)(sc + offB);

@@ -29,6 +29,7 @@ class ResNet50Int8(ResNet50):
     def __init__(self, ctx, batch, weights=None, pad_mode=L.PAD_RAW0_I8, **kw):
         super().__init__(ctx, batch, weights, **kw)
         self.pad_mode = pad_mode
+        self._staged_key = None
         self.producer_stats = True   # conv epilogues accumulate the min/max the next DynamicQuantizeLinear needs
         sb = ctx.lib.rten_hip_minmax_stats_bytes()
         self.stats_arena = DeviceTensor(ctx, (sb * len(self.specs),), np.uint8)  # one statistics block per conv output
@@ -82,12 +83,18 @@ class ResNet50Int8(ResNet50):
         # DynamicQuantizeLinear, writing the codes straight into the consumer's staged layout, and the Mul(x_scale, w_scale)
         # that feeds the conv's cast_scale.  When the producing conv left min/max statistics, the first sweep is skipped.
         st = self.stats.get(l["src"]) if self.producer_stats else None
-        if st is not None:
+        geom = (l["src"], d.conv.c, d.conv.h, d.conv.w, tuple(d.conv.pads))
+        if self._staged_key == geom:
+            # same tensor, same staged layout as the previous conv (a stage's downsample and first 1x1 conv): the graph has ONE
+            # DynamicQuantizeLinear for it (ort-quantize reuses a quantized input), only the Mul(x_scale, w_scale) differs
+            ctx.call("rten_hip_mul_f32", 1, self.xs.vp, self.ws[name].vp, 1, self.sc.vp)
+        elif st is not None:
             ctx.call("rten_hip_dynamic_quantize_linear_staged_stats", C.byref(d), src.vp, st, self.staged.vp, self.xs.vp, self.xz.vp,
                      self.ws[name].vp, self.sc.vp)
         else:
             ctx.call("rten_hip_dynamic_quantize_linear_staged", C.byref(d), src.vp, self.staged.vp, self.xs.vp, self.xz.vp,
                      self.ws[name].vp, self.sc.vp)
+        self._staged_key = geom
         flags = (L.CONV_RELU if l["relu"] else 0) | (L.CONV_RESIDUAL if l["res"] else 0)
         args = (C.byref(d), self.staged.vp, self.wq[name].vp, self.xz.vp, None, self.sc.vp, self.bq[name].vp,
                 self._act(l["res"]).vp if l["res"] else None, flags, self._act(l["dst"]).vp)
@@ -98,6 +105,7 @@ class ResNet50Int8(ResNet50):
 
     def forward(self):
         ctx = self.ctx
+        self._staged_key = None
         if self.producer_stats:
             ctx.call("rten_hip_minmax_stats_reset", self.stats_arena.vp, len(self.specs))  # one launch for every layer's block
         self._conv(self.specs[0])
