@@ -126,8 +126,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # RTEN_DIST_BACKEND=gloo lets the rank != 0 path (arena received by broadcast) be exercised with several ranks on ONE
+        # GPU (RCCL refuses two ranks per device); the driver's multi-GPU runs use the default, nccl (= RCCL over xGMI).
+        backend = os.environ.get("RTEN_DIST_BACKEND", "nccl")
+        if backend != "nccl":
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(local_rank)
 
