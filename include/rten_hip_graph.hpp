@@ -1,0 +1,735 @@
+// rten_hip_graph.hpp -- ONNX loader + device-resident graph executor above rten_hip_ops.hpp (the
+// "residency-aware executor glue" either side of the hot-path operators).
+//
+// What it mirrors in the reference, and where it stops:
+//   * onnx::parse        rten-onnx/src/onnx.rs (hand-rolled protobuf reader, same subset: ModelProto / GraphProto /
+//                        NodeProto / AttributeProto / TensorProto / ValueInfoProto), src/model/onnx_loader.rs
+//                        (int64 initializers are narrowed to int32 at load, onnx_loader.rs:332-339).
+//   * Graph::compile     Graph::prepack_weights (src/graph.rs:488-562: constant conv weights are staged once) and the
+//                        fusion passes that touch this backend's operators (src/optimize/fusions.rs):
+//                        Conv (+ Add residual) (+ Relu); ConvInteger -> Cast -> Mul(scale) (= ConvIntegerToFloat,
+//                        fusions.rs:1012-1058) (+ Add bias [1,O,1,1]) (+ Add residual) (+ Relu); MatMulInteger -> Cast -> Mul
+//                        (= MatMulIntegerToFloat); Reshape / Flatten / Squeeze / Unsqueeze / Identity as views.
+//   * Graph::run         Graph::run_plan (src/graph.rs:1139-1231): operators run sequentially in plan order, values are
+//                        reference counted and their buffers go back to the pool when the last consumer has run
+//                        (buffer_pool.rs); here every value stays in HBM between operators -- only graph inputs and
+//                        outputs cross PCIe.
+// Scope of this first version: the CNN-classifier graphs of BASELINE configs 0-2 (ResNet-50 f32 and its
+// dynamically-quantized form).  An operator outside the registry is a load-time error naming the node, never a CPU
+// fallback.  Control flow, sequences, symbolic shape inference and the transformer-graph layout ops are not built.
+#pragma once
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <fstream>
+#include <set>
+
+#include "rten_hip_ops.hpp"
+
+namespace rten_hip {
+
+// ======================================================================================================== ONNX reader
+namespace onnx {
+
+enum DataType { FLOAT = 1, UINT8 = 2, INT8 = 3, INT32 = 6, INT64 = 7, BOOL = 9 };
+
+struct TensorProto {
+    std::string name;
+    std::vector<int64_t> dims;
+    int data_type = 0;
+    std::string raw;                 // raw_data, or the typed fields re-encoded little-endian
+    int64_t len() const { int64_t n = 1; for (int64_t d : dims) n *= d; return n; }
+};
+struct Attr {
+    std::string name;
+    int type = 0; // AttributeProto.AttributeType
+    float f = 0.f;
+    int64_t i = 0;
+    std::string s;
+    std::vector<float> floats;
+    std::vector<int64_t> ints;
+    TensorProto t;
+};
+struct Node {
+    std::string op_type, name, domain;
+    std::vector<std::string> inputs, outputs;
+    std::vector<Attr> attrs;
+    const Attr *attr(const std::string &n) const {
+        for (auto &a : attrs) if (a.name == n) return &a;
+        return nullptr;
+    }
+    int64_t get_int(const std::string &n, int64_t dflt) const { const Attr *a = attr(n); return a ? a->i : dflt; }
+    float get_float(const std::string &n, float dflt) const { const Attr *a = attr(n); return a ? a->f : dflt; }
+    std::vector<int> get_ints(const std::string &n, std::vector<int> dflt) const {
+        const Attr *a = attr(n);
+        if (!a) return dflt;
+        return std::vector<int>(a->ints.begin(), a->ints.end());
+    }
+};
+struct ValueInfo {
+    std::string name;
+    int elem_type = 0;
+    std::vector<int64_t> dims; // -1: symbolic
+    std::vector<std::string> dim_params;
+};
+struct Model {
+    int64_t ir_version = 0, opset = 0;
+    std::string producer, graph_name;
+    std::vector<Node> nodes;
+    std::vector<TensorProto> initializers;
+    std::vector<ValueInfo> inputs, outputs;
+};
+
+struct ParseError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+// protobuf wire format: (field << 3 | wire type) varint keys; wire 0 varint, 1 fixed64, 2 length-delimited, 5 fixed32
+class Reader {
+  public:
+    Reader(const uint8_t *p, size_t n) : p_(p), end_(p + n) {}
+    bool done() const { return p_ >= end_; }
+    uint64_t varint() {
+        uint64_t v = 0;
+        for (int shift = 0; shift < 70; shift += 7) {
+            if (p_ >= end_) throw ParseError("onnx: truncated varint");
+            const uint8_t b = *p_++;
+            v |= (uint64_t)(b & 0x7f) << shift;
+            if (!(b & 0x80)) return v;
+        }
+        throw ParseError("onnx: varint too long");
+    }
+    void key(int &field, int &wire) { const uint64_t k = varint(); field = (int)(k >> 3); wire = (int)(k & 7); }
+    Reader sub() {
+        const uint64_t n = varint();
+        if (n > (uint64_t)(end_ - p_)) throw ParseError("onnx: length-delimited field overruns its message");
+        Reader r(p_, (size_t)n);
+        p_ += n;
+        return r;
+    }
+    std::string str() { Reader r = sub(); return std::string((const char *)r.p_, (size_t)(r.end_ - r.p_)); }
+    uint32_t fixed32() { if (end_ - p_ < 4) throw ParseError("onnx: truncated fixed32"); uint32_t v; std::memcpy(&v, p_, 4); p_ += 4; return v; }
+    uint64_t fixed64() { if (end_ - p_ < 8) throw ParseError("onnx: truncated fixed64"); uint64_t v; std::memcpy(&v, p_, 8); p_ += 8; return v; }
+    void skip(int wire) {
+        if (wire == 0) varint();
+        else if (wire == 1) fixed64();
+        else if (wire == 2) sub();
+        else if (wire == 5) fixed32();
+        else throw ParseError("onnx: unsupported wire type");
+    }
+    // repeated scalar: packed (wire 2) or one element (wire 0 / 5)
+    template <typename F> void repeated(int wire, int scalar_wire, F f) {
+        if (wire == 2) { Reader r = sub(); while (!r.done()) f(r); }
+        else if (wire == scalar_wire) f(*this);
+        else throw ParseError("onnx: unexpected wire type in a repeated scalar");
+    }
+
+  private:
+    const uint8_t *p_, *end_;
+};
+
+inline TensorProto parse_tensor(Reader r) {
+    TensorProto t;
+    std::vector<float> fdata;
+    std::vector<int64_t> i32data, i64data;
+    bool has_raw = false;
+    while (!r.done()) {
+        int f, w;
+        r.key(f, w);
+        if (f == 1) r.repeated(w, 0, [&](Reader &q) { t.dims.push_back((int64_t)q.varint()); });
+        else if (f == 2 && w == 0) t.data_type = (int)r.varint();
+        else if (f == 4) r.repeated(w, 5, [&](Reader &q) { const uint32_t b = q.fixed32(); float v; std::memcpy(&v, &b, 4); fdata.push_back(v); });
+        else if (f == 5) r.repeated(w, 0, [&](Reader &q) { i32data.push_back((int64_t)q.varint()); });
+        else if (f == 7) r.repeated(w, 0, [&](Reader &q) { i64data.push_back((int64_t)q.varint()); });
+        else if (f == 8 && w == 2) t.name = r.str();
+        else if (f == 9 && w == 2) { t.raw = r.str(); has_raw = true; }
+        else if (f == 13 || f == 14) throw ParseError("onnx: external tensor data is not supported (" + t.name + ")");
+        else r.skip(w);
+    }
+    if (!has_raw) { // typed fields -> little-endian bytes of the declared type
+        auto put = [&](const void *p, size_t n) { t.raw.append((const char *)p, n); };
+        if (t.data_type == FLOAT) for (float v : fdata) put(&v, 4);
+        else if (t.data_type == INT64) for (int64_t v : i64data) put(&v, 8);
+        else if (t.data_type == INT32) for (int64_t v : i32data) { const int32_t x = (int32_t)v; put(&x, 4); }
+        else if (t.data_type == UINT8 || t.data_type == INT8 || t.data_type == BOOL) for (int64_t v : i32data) { const uint8_t x = (uint8_t)v; put(&x, 1); }
+    }
+    return t;
+}
+
+inline Attr parse_attr(Reader r) {
+    Attr a;
+    while (!r.done()) {
+        int f, w;
+        r.key(f, w);
+        if (f == 1 && w == 2) a.name = r.str();
+        else if (f == 2 && w == 5) { const uint32_t b = r.fixed32(); std::memcpy(&a.f, &b, 4); }
+        else if (f == 3 && w == 0) a.i = (int64_t)r.varint();
+        else if (f == 4 && w == 2) a.s = r.str();
+        else if (f == 5 && w == 2) a.t = parse_tensor(r.sub());
+        else if (f == 7) r.repeated(w, 5, [&](Reader &q) { const uint32_t b = q.fixed32(); float v; std::memcpy(&v, &b, 4); a.floats.push_back(v); });
+        else if (f == 8) r.repeated(w, 0, [&](Reader &q) { a.ints.push_back((int64_t)q.varint()); });
+        else if (f == 20 && w == 0) a.type = (int)r.varint();
+        else r.skip(w);
+    }
+    return a;
+}
+
+inline Node parse_node(Reader r) {
+    Node n;
+    while (!r.done()) {
+        int f, w;
+        r.key(f, w);
+        if (f == 1 && w == 2) n.inputs.push_back(r.str());
+        else if (f == 2 && w == 2) n.outputs.push_back(r.str());
+        else if (f == 3 && w == 2) n.name = r.str();
+        else if (f == 4 && w == 2) n.op_type = r.str();
+        else if (f == 5 && w == 2) n.attrs.push_back(parse_attr(r.sub()));
+        else if (f == 7 && w == 2) n.domain = r.str();
+        else r.skip(w);
+    }
+    return n;
+}
+
+inline ValueInfo parse_value_info(Reader r) {
+    ValueInfo v;
+    while (!r.done()) {
+        int f, w;
+        r.key(f, w);
+        if (f == 1 && w == 2) v.name = r.str();
+        else if (f == 2 && w == 2) { // TypeProto
+            Reader tp = r.sub();
+            while (!tp.done()) {
+                int f2, w2;
+                tp.key(f2, w2);
+                if (f2 != 1 || w2 != 2) { tp.skip(w2); continue; } // tensor_type only
+                Reader tt = tp.sub();
+                while (!tt.done()) {
+                    int f3, w3;
+                    tt.key(f3, w3);
+                    if (f3 == 1 && w3 == 0) v.elem_type = (int)tt.varint();
+                    else if (f3 == 2 && w3 == 2) { // TensorShapeProto
+                        Reader sh = tt.sub();
+                        while (!sh.done()) {
+                            int f4, w4;
+                            sh.key(f4, w4);
+                            if (f4 != 1 || w4 != 2) { sh.skip(w4); continue; }
+                            Reader dm = sh.sub();
+                            int64_t val = -1;
+                            std::string param;
+                            while (!dm.done()) {
+                                int f5, w5;
+                                dm.key(f5, w5);
+                                if (f5 == 1 && w5 == 0) val = (int64_t)dm.varint();
+                                else if (f5 == 2 && w5 == 2) param = dm.str();
+                                else dm.skip(w5);
+                            }
+                            v.dims.push_back(val);
+                            v.dim_params.push_back(param);
+                        }
+                    } else tt.skip(w3);
+                }
+            }
+        } else r.skip(w);
+    }
+    return v;
+}
+
+inline Model parse(const uint8_t *data, size_t n) {
+    Model m;
+    Reader r(data, n);
+    bool have_graph = false;
+    while (!r.done()) {
+        int f, w;
+        r.key(f, w);
+        if (f == 1 && w == 0) m.ir_version = (int64_t)r.varint();
+        else if (f == 2 && w == 2) m.producer = r.str();
+        else if (f == 8 && w == 2) { // OperatorSetIdProto
+            Reader o = r.sub();
+            std::string domain;
+            int64_t version = 0;
+            while (!o.done()) {
+                int f2, w2;
+                o.key(f2, w2);
+                if (f2 == 1 && w2 == 2) domain = o.str();
+                else if (f2 == 2 && w2 == 0) version = (int64_t)o.varint();
+                else o.skip(w2);
+            }
+            if (domain.empty() || domain == "ai.onnx") m.opset = version;
+        } else if (f == 7 && w == 2) {
+            have_graph = true;
+            Reader g = r.sub();
+            while (!g.done()) {
+                int f2, w2;
+                g.key(f2, w2);
+                if (f2 == 1 && w2 == 2) m.nodes.push_back(parse_node(g.sub()));
+                else if (f2 == 2 && w2 == 2) m.graph_name = g.str();
+                else if (f2 == 5 && w2 == 2) m.initializers.push_back(parse_tensor(g.sub()));
+                else if (f2 == 11 && w2 == 2) m.inputs.push_back(parse_value_info(g.sub()));
+                else if (f2 == 12 && w2 == 2) m.outputs.push_back(parse_value_info(g.sub()));
+                else g.skip(w2);
+            }
+        } else r.skip(w);
+    }
+    if (!have_graph) throw ParseError("onnx: model has no graph");
+    // graph inputs that are initializers are constants, not runtime inputs (IR < 4 models list both)
+    std::set<std::string> init_names;
+    for (auto &t : m.initializers) init_names.insert(t.name);
+    m.inputs.erase(std::remove_if(m.inputs.begin(), m.inputs.end(), [&](const ValueInfo &v) { return init_names.count(v.name) != 0; }), m.inputs.end());
+    return m;
+}
+
+inline Model load(const std::string &path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw ParseError("onnx: cannot open " + path);
+    std::string buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    return parse((const uint8_t *)buf.data(), buf.size());
+}
+
+} // namespace onnx
+
+// ======================================================================================================== executor
+struct GraphError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+class Graph {
+  public:
+    struct Options {
+        bool fuse = true;    // the fusion passes listed at the top of this file
+        bool prepack = true; // stage constant conv weights once (Graph::prepack_weights)
+    };
+    struct Timing { std::string node, op; double ms; };
+
+    Graph(Context &ctx, const onnx::Model &m, Options opt) : ctx_(ctx), opt_(opt) { compile(m); }
+    Graph(Context &ctx, const onnx::Model &m) : Graph(ctx, m, Options()) {}
+
+    const std::vector<onnx::ValueInfo> &inputs() const { return inputs_; }
+    const std::vector<onnx::ValueInfo> &outputs() const { return outputs_; }
+    size_t num_steps() const { return steps_.size(); }
+    size_t num_fused_away() const { return fused_away_; }
+    std::vector<std::string> step_names() const {
+        std::vector<std::string> v;
+        for (auto &s : steps_) v.push_back(s.kind_name + ":" + s.name);
+        return v;
+    }
+
+    // Runs the plan.  `feeds` are device tensors named like the graph inputs; the returned tensors are the graph outputs
+    // in declaration order, still on the device.  With `timings`, every step is followed by a sync and timed on the host
+    // (RTEN_TIMING's per-operator table, src/timing.rs) -- a profiling aid, it serialises the stream.
+    std::vector<Tensor> run(const std::vector<std::pair<std::string, const Tensor *>> &feeds, std::vector<Timing> *timings = nullptr) {
+        std::vector<const Tensor *> val(names_.size(), nullptr);
+        std::vector<std::unique_ptr<Tensor>> owned(names_.size());
+        std::vector<int> pending(uses_);
+        for (auto &kv : consts_) val[(size_t)kv.first] = &kv.second;
+        for (auto &fd : feeds) {
+            auto it = ids_.find(fd.first);
+            if (it == ids_.end()) throw GraphError("run: no graph input named " + fd.first);
+            val[(size_t)it->second] = fd.second;
+        }
+        for (auto &in : inputs_) if (!val[(size_t)ids_.at(in.name)]) throw GraphError("run: missing input " + in.name);
+        for (auto &st : steps_) {
+            InputList in;
+            for (int id : st.in) {
+                if (id >= 0 && !val[(size_t)id]) throw GraphError("run: value " + names_[(size_t)id] + " needed by " + st.name + " was never produced");
+                in.push_back(id < 0 ? nullptr : val[(size_t)id]);
+            }
+            const auto t0 = std::chrono::steady_clock::now();
+            OutputList out;
+            try {
+                out = st.run(ctx_, in);
+            } catch (const OpError &e) { // name the node, like the reference's RunError::OperatorError { name, error }
+                throw OpError(e.kind, "operator " + st.kind_name + " \"" + st.name + "\": " + e.msg);
+            }
+            if (timings) {
+                ctx_.sync();
+                timings->push_back({st.name, st.kind_name, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()});
+            }
+            if (out.size() < st.out.size()) throw GraphError("run: " + st.name + " produced fewer outputs than the graph names");
+            for (size_t i = 0; i < st.out.size(); i++) {
+                if (st.out[i] < 0) continue;
+                owned[(size_t)st.out[i]].reset(new Tensor(std::move(out[i])));
+                val[(size_t)st.out[i]] = owned[(size_t)st.out[i]].get();
+            }
+            // a view keeps its base alive: the base's count was raised by one at compile time for exactly this reason
+            for (int id : st.release_after) {
+                if (--pending[(size_t)id] == 0) { owned[(size_t)id].reset(); }
+            }
+        }
+        std::vector<Tensor> result;
+        for (auto &o : outputs_) {
+            const int id = ids_.at(o.name);
+            if (!owned[(size_t)id]) throw GraphError("run: output " + o.name + " is not produced by an operator");
+            if (view_values_.count(id)) { // a view's storage belongs to a value that dies with this run: hand out a copy
+                const Tensor &v = *owned[(size_t)id];
+                Tensor copy(ctx_, v.shape(), v.dtype());
+                if (v.bytes()) ctx_.check(rten_hip_memcpy_d2d(ctx_.raw(), copy.ptr(), v.ptr(), v.bytes()));
+                result.push_back(std::move(copy));
+            } else {
+                result.push_back(std::move(*owned[(size_t)id]));
+            }
+        }
+        return result;
+    }
+
+  private:
+    struct Step {
+        std::string name, kind_name;
+        std::vector<int> in, out, release_after;
+        std::function<OutputList(Context &, const InputList &)> run;
+        bool view = false;
+        size_t pos = 0; // index of the LAST graph node folded into this step: the step runs where that node stood
+    };
+
+    Context &ctx_;
+    Options opt_;
+    std::vector<std::string> names_;
+    std::map<std::string, int> ids_;
+    std::map<int, Tensor> consts_;
+    std::vector<std::unique_ptr<Tensor>> packed_; // prepacked conv weights
+    std::vector<Step> steps_;
+    std::vector<int> uses_;
+    std::vector<onnx::ValueInfo> inputs_, outputs_;
+    size_t fused_away_ = 0;
+    std::set<int> view_values_;
+
+    int id_of(const std::string &n) {
+        if (n.empty()) return -1; // omitted optional input
+        auto it = ids_.find(n);
+        if (it != ids_.end()) return it->second;
+        const int id = (int)names_.size();
+        names_.push_back(n);
+        ids_[n] = id;
+        return id;
+    }
+
+    static DType dtype_of(int onnx_type, const std::string &what) {
+        switch (onnx_type) {
+        case onnx::FLOAT: return DType::F32;
+        case onnx::INT32: case onnx::INT64: return DType::I32; // int64 is narrowed to int32 at load (onnx_loader.rs:332-339)
+        case onnx::UINT8: case onnx::BOOL: return DType::U8;
+        case onnx::INT8: return DType::I8;
+        default: throw GraphError("unsupported tensor element type " + std::to_string(onnx_type) + " (" + what + ")");
+        }
+    }
+
+    Tensor upload(const onnx::TensorProto &t) {
+        const DType dt = dtype_of(t.data_type, t.name);
+        const int64_t n = t.len();
+        const size_t esz = t.data_type == onnx::INT64 ? 8 : dtype_size(dt);
+        if ((size_t)n * esz != t.raw.size()) throw GraphError("initializer " + t.name + ": data size does not match its dims");
+        if (t.data_type == onnx::INT64) {
+            std::vector<int32_t> narrow((size_t)n);
+            for (int64_t i = 0; i < n; i++) {
+                int64_t v;
+                std::memcpy(&v, t.raw.data() + 8 * i, 8);
+                narrow[(size_t)i] = (int32_t)std::max<int64_t>(INT32_MIN, std::min<int64_t>(INT32_MAX, v)); // saturating, like the loader
+            }
+            return Tensor::from_host<int32_t>(ctx_, t.dims, narrow.data());
+        }
+        Tensor d(ctx_, t.dims, dt);
+        if (d.bytes()) ctx_.check(rten_hip_memcpy_h2d(ctx_.raw(), d.ptr(), t.raw.data(), d.bytes()));
+        return d;
+    }
+
+    static Padding padding_of(const onnx::Node &n, const char *op) {
+        const onnx::Attr *ap = n.attr("auto_pad");
+        if (ap && !ap->s.empty() && ap->s != "NOTSET") {
+            if (ap->s == "SAME_UPPER") return Padding::Same();
+            if (ap->s == "VALID") return Padding::Fixed({0, 0, 0, 0});
+            throw GraphError(std::string(op) + " " + n.name + ": auto_pad " + ap->s + " is not supported");
+        }
+        std::vector<int> p = n.get_ints("pads", {0, 0, 0, 0});
+        if (p.size() != 4) throw GraphError(std::string(op) + " " + n.name + ": only 2-D spatial operators are supported");
+        return Padding::Fixed({p[0], p[1], p[2], p[3]}); // ONNX [top, left, bottom, right] == the reference's order
+    }
+    static Conv conv_attrs(const onnx::Node &n) {
+        Conv c;
+        c.groups = (int)n.get_int("group", 1);
+        c.dilations = n.get_ints("dilations", {1, 1});
+        c.strides = n.get_ints("strides", {1, 1});
+        c.padding = padding_of(n, "Conv");
+        return c;
+    }
+
+    // ---- compile: constants, fusion, steps, liveness
+    void compile(const onnx::Model &m) {
+        inputs_ = m.inputs;
+        outputs_ = m.outputs;
+        for (auto &t : m.initializers) consts_.emplace(id_of(t.name), upload(t));
+        for (auto &in : m.inputs) id_of(in.name);
+
+        const size_t N = m.nodes.size();
+        // consumers of every value (graph outputs count as a use: they must not be fused away)
+        std::map<std::string, std::vector<size_t>> users;
+        std::map<std::string, size_t> producer;
+        for (size_t i = 0; i < N; i++) {
+            for (auto &s : m.nodes[i].inputs) if (!s.empty()) users[s].push_back(i);
+            for (auto &s : m.nodes[i].outputs) if (!s.empty()) producer[s] = i;
+        }
+        std::set<std::string> graph_outs;
+        for (auto &o : m.outputs) graph_outs.insert(o.name);
+        std::vector<bool> dead(N, false);
+        const std::vector<bool> *dead_ptr = &dead;
+        auto sole_user = [&](const std::string &v, const char *op) -> long {
+            if (graph_outs.count(v)) return -1;
+            auto it = users.find(v);
+            if (it == users.end() || it->second.size() != 1 || dead_ptr->at(it->second[0])) return -1;
+            return m.nodes[it->second[0]].op_type == op ? (long)it->second[0] : -1;
+        };
+        auto is_const = [&](const std::string &v) { auto it = ids_.find(v); return it != ids_.end() && consts_.count(it->second) != 0; };
+        // A fused step runs at the position of the LAST node it absorbs (st.pos), where -- the node list being
+        // topologically sorted -- every operand of every absorbed node is already available.  An Add of two operator
+        // outputs is claimed by the LATER producer only (its other operand exists before that producer runs), so two
+        // convolutions feeding one Add (projection shortcut + main branch) do not both absorb it.
+        auto ready_before = [&](const std::string &v, size_t at) {
+            auto it = producer.find(v);
+            return it == producer.end() || it->second < at;
+        };
+        auto other_input = [&](const onnx::Node &n, const std::string &v) { return n.inputs[0] == v ? n.inputs[1] : n.inputs[0]; };
+
+        for (size_t i = 0; i < N; i++) {
+            if (dead[i]) continue;
+            const onnx::Node &n = m.nodes[i];
+            if (!n.domain.empty() && n.domain != "ai.onnx") throw GraphError("node " + n.name + ": operator domain " + n.domain + " is not supported");
+            Step st;
+            st.name = n.name.empty() ? n.outputs.at(0) : n.name;
+            st.kind_name = n.op_type;
+            st.pos = i;
+            for (auto &s : n.inputs) st.in.push_back(id_of(s));
+            std::string out_name = n.outputs.at(0);
+
+            if (n.op_type == "Conv") {
+                auto op = std::make_shared<Conv>(conv_attrs(n));
+                std::string residual;
+                if (opt_.fuse) {
+                    long a = sole_user(out_name, "Add");
+                    if (a >= 0 && m.nodes[(size_t)a].inputs.size() == 2) {
+                        const std::string other = other_input(m.nodes[(size_t)a], out_name);
+                        if (other != out_name && ready_before(other, i)) { residual = other; dead[(size_t)a] = true; out_name = m.nodes[(size_t)a].outputs[0]; fused_away_++; st.pos = (size_t)a; }
+                    }
+                    long r = sole_user(out_name, "Relu");
+                    if (r >= 0) { op->fuse_relu = true; dead[(size_t)r] = true; out_name = m.nodes[(size_t)r].outputs[0]; fused_away_++; st.pos = (size_t)r; }
+                }
+                while (st.in.size() < 3) st.in.push_back(-1);
+                st.in.push_back(residual.empty() ? -1 : id_of(residual));
+                const Tensor *packed = nullptr;
+                if (opt_.prepack && is_const(n.inputs.at(1)) && op->groups == 1) {
+                    const Tensor &w = consts_.at(ids_.at(n.inputs[1]));
+                    if (w.ndim() == 4) {
+                        packed_.emplace_back(new Tensor(op->prepack(ctx_, w)));
+                        packed = packed_.back().get();
+                    }
+                }
+                st.kind_name = std::string("Conv") + (residual.empty() ? "" : "+Add") + (op->fuse_relu ? "+Relu" : "");
+                st.run = [op, packed](Context &c, const InputList &in) { return op->run_packed(c, in, packed); };
+            } else if (n.op_type == "ConvInteger") {
+                auto op = std::make_shared<ConvInteger>();
+                op->conv = conv_attrs(n);
+                std::string scale, bias, residual;
+                bool relu = false;
+                long cast = opt_.fuse ? sole_user(out_name, "Cast") : -1;
+                long mul = cast >= 0 && m.nodes[(size_t)cast].get_int("to", 0) == onnx::FLOAT ? sole_user(m.nodes[(size_t)cast].outputs[0], "Mul") : -1;
+                if (mul >= 0) {
+                    // ConvIntegerToFloat: the Mul's other operand must be a single scale available before the conv runs
+                    const std::string sc = other_input(m.nodes[(size_t)mul], m.nodes[(size_t)cast].outputs[0]);
+                    {
+                        scale = sc;
+                        dead[(size_t)cast] = dead[(size_t)mul] = true;
+                        fused_away_ += 2;
+                        out_name = m.nodes[(size_t)mul].outputs[0];
+                        st.pos = (size_t)mul;
+                        long add = sole_user(out_name, "Add");
+                        if (add >= 0) { // Add(bias constant [1, O, 1, 1])
+                            const std::string b = other_input(m.nodes[(size_t)add], out_name);
+                            if (is_const(b)) {
+                                const Tensor &bt = consts_.at(ids_.at(b));
+                                if (bt.ndim() == 4 && bt.size(0) == 1 && bt.size(2) == 1 && bt.size(3) == 1) {
+                                    bias = b; dead[(size_t)add] = true; fused_away_++; out_name = m.nodes[(size_t)add].outputs[0]; st.pos = (size_t)add;
+                                }
+                            }
+                        }
+                        long add2 = bias.empty() ? -1 : sole_user(out_name, "Add");
+                        if (add2 >= 0) {
+                            const std::string other = other_input(m.nodes[(size_t)add2], out_name);
+                            if (other != out_name && ready_before(other, i)) { residual = other; dead[(size_t)add2] = true; fused_away_++; out_name = m.nodes[(size_t)add2].outputs[0]; st.pos = (size_t)add2; }
+                        }
+                        long r = sole_user(out_name, "Relu");
+                        if (r >= 0) { relu = true; dead[(size_t)r] = true; fused_away_++; out_name = m.nodes[(size_t)r].outputs[0]; st.pos = (size_t)r; }
+                    }
+                }
+                while (st.in.size() < 4) st.in.push_back(-1);
+                st.in.push_back(scale.empty() ? -1 : id_of(scale));
+                st.in.push_back(bias.empty() ? -1 : id_of(bias));
+                st.in.push_back(residual.empty() ? -1 : id_of(residual));
+                if (!scale.empty()) st.kind_name = std::string("ConvIntegerToFloat") + (bias.empty() ? "" : "+bias") + (residual.empty() ? "" : "+Add") + (relu ? "+Relu" : "");
+                st.run = [op, relu](Context &c, const InputList &in) {
+                    const Tensor *scale = in[4];
+                    if (scale && scale->len() != 1) throw OpError(OpError::InvalidValue, "scale should be a scalar");
+                    return op->run_fused(c, InputList(in.begin(), in.begin() + 4), scale, in[5], in[6], relu);
+                };
+            } else if (n.op_type == "MatMulInteger") {
+                auto op = std::make_shared<MatMulInteger>();
+                std::string scale;
+                long cast = opt_.fuse ? sole_user(out_name, "Cast") : -1;
+                long mul = cast >= 0 && m.nodes[(size_t)cast].get_int("to", 0) == onnx::FLOAT ? sole_user(m.nodes[(size_t)cast].outputs[0], "Mul") : -1;
+                if (mul >= 0) {
+                    const std::string sc = other_input(m.nodes[(size_t)mul], m.nodes[(size_t)cast].outputs[0]);
+                    scale = sc; dead[(size_t)cast] = dead[(size_t)mul] = true; fused_away_ += 2; out_name = m.nodes[(size_t)mul].outputs[0]; st.pos = (size_t)mul;
+                }
+                while (st.in.size() < 4) st.in.push_back(-1);
+                st.in.push_back(scale.empty() ? -1 : id_of(scale));
+                if (!scale.empty()) st.kind_name = "MatMulIntegerToFloat";
+                st.run = [op](Context &c, const InputList &in) { return op->run_scaled(c, InputList(in.begin(), in.begin() + 4), in[4]); };
+            } else if (n.op_type == "Gemm") {
+                auto op = std::make_shared<Gemm>();
+                op->alpha = n.get_float("alpha", 1.f); op->beta = n.get_float("beta", 1.f);
+                op->transpose_a = n.get_int("transA", 0) != 0; op->transpose_b = n.get_int("transB", 0) != 0;
+                st.run = [op](Context &c, const InputList &in) { return op->run(c, in); };
+            } else if (n.op_type == "MatMul") {
+                auto op = std::make_shared<MatMul>();
+                st.run = [op](Context &c, const InputList &in) { return op->run(c, in); };
+            } else if (n.op_type == "MaxPool" || n.op_type == "AveragePool") {
+                std::vector<int> k = n.get_ints("kernel_shape", {});
+                if (k.size() != 2) throw GraphError(n.op_type + " " + st.name + ": kernel_shape must have 2 values");
+                const std::vector<int> strides = n.get_ints("strides", {1, 1});
+                const Padding pad = padding_of(n, n.op_type.c_str());
+                const bool ceil = n.get_int("ceil_mode", 0) != 0;
+                if (n.outputs.size() > 1 && !n.outputs[1].empty()) throw GraphError("MaxPool " + st.name + ": the Indices output is not supported");
+                if (n.op_type == "MaxPool") {
+                    auto op = std::make_shared<MaxPool>();
+                    op->kernel_size = k; op->strides = strides; op->padding = pad; op->ceil_mode = ceil;
+                    st.run = [op](Context &c, const InputList &in) { return op->run(c, in); };
+                } else {
+                    auto op = std::make_shared<AveragePool>();
+                    op->kernel_size = k; op->strides = strides; op->padding = pad; op->ceil_mode = ceil;
+                    op->count_include_pad = n.get_int("count_include_pad", 0) != 0;
+                    st.run = [op](Context &c, const InputList &in) { return op->run(c, in); };
+                }
+            } else if (n.op_type == "Cast") {
+                auto op = std::make_shared<Cast>();
+                op->to = dtype_of((int)n.get_int("to", onnx::FLOAT), st.name);
+                st.run = [op](Context &c, const InputList &in) { return op->run(c, in); };
+            } else if (n.op_type == "Softmax") {
+                auto op = std::make_shared<Softmax>();
+                op->axis = (int)n.get_int("axis", -1);
+                st.run = [op](Context &c, const InputList &in) { return op->run(c, in); };
+            } else if (n.op_type == "Flatten" || n.op_type == "Reshape" || n.op_type == "Squeeze" || n.op_type == "Unsqueeze" || n.op_type == "Identity" ||
+                       n.op_type == "Dropout") {
+                make_view_step(st, n, m);
+            } else {
+                static const OpRegistry reg = OpRegistry::with_all_ops();
+                if (!reg.contains(n.op_type))
+                    throw GraphError("node " + st.name + ": operator " + n.op_type + " is not available on the HIP backend (no CPU fallback)");
+                std::shared_ptr<Operator> op(reg.create(n.op_type).release());
+                st.run = [op](Context &c, const InputList &in) { return op->run(c, in); };
+            }
+            st.out.push_back(id_of(out_name));
+            for (size_t k = 1; k < n.outputs.size(); k++) st.out.push_back(n.outputs[k].empty() ? -1 : id_of(n.outputs[k]));
+            steps_.push_back(std::move(st));
+        }
+        for (auto &o : m.outputs)
+            if (!ids_.count(o.name)) throw GraphError("graph output " + o.name + " is not produced by any node");
+        std::stable_sort(steps_.begin(), steps_.end(), [](const Step &a, const Step &b) { return a.pos < b.pos; });
+        for (auto &st : steps_) if (st.view && st.out[0] >= 0) view_values_.insert(st.out[0]);
+        plan_liveness();
+    }
+
+    // Shape-only operators: the output aliases the input's buffer (src/ops/layout.rs reshapes in place when it can).
+    void make_view_step(Step &st, const onnx::Node &n, const onnx::Model &m) {
+        (void)m;
+        const std::string kind = n.op_type;
+        const int axis = (int)n.get_int("axis", 1);
+        std::vector<int64_t> spec; // Reshape target / (Un)Squeeze axes from a constant input (opset >= 13) or the attribute
+        bool have_spec = false;
+        if (n.inputs.size() > 1 && !n.inputs[1].empty()) {
+            auto it = ids_.find(n.inputs[1]);
+            if (it == ids_.end() || !consts_.count(it->second)) throw GraphError(kind + " " + st.name + ": the shape / axes input must be a constant");
+            const Tensor &t = consts_.at(it->second);
+            for (int32_t v : t.to_host<int32_t>()) spec.push_back(v);
+            have_spec = true;
+            st.in.resize(1);
+        } else if (const onnx::Attr *a = n.attr("axes")) { spec = a->ints; have_spec = true; }
+        else if (const onnx::Attr *a2 = n.attr("shape")) { spec = a2->ints; have_spec = true; }
+        const bool allowzero = n.get_int("allowzero", 0) != 0;
+        st.kind_name = kind + "(view)";
+        st.run = [kind, axis, spec, have_spec, allowzero](Context &, const InputList &in) {
+            const Tensor &x = require(in, 0);
+            std::vector<int64_t> s = x.shape();
+            const int nd = (int)s.size();
+            if (kind == "Flatten") {
+                const int a = axis < 0 ? axis + nd : axis;
+                if (a < 0 || a > nd) throw OpError(OpError::InvalidValue, "Axis is invalid");
+                s = {detail::prod(x.shape(), 0, (size_t)a), detail::prod(x.shape(), (size_t)a, (size_t)nd)};
+            } else if (kind == "Reshape") {
+                if (!have_spec) throw OpError(OpError::MissingInputs, "");
+                s.assign(spec.begin(), spec.end());
+                int64_t known = 1;
+                int infer = -1;
+                for (size_t i = 0; i < s.size(); i++) {
+                    if (s[i] == 0 && !allowzero) { if (i >= (size_t)nd) throw OpError(OpError::InvalidValue, "Input and output element counts do not match"); s[i] = x.size((int)i); }
+                    if (s[i] == -1) { if (infer >= 0) throw OpError(OpError::InvalidValue, "Multiple dimensions in new shape set to -1"); infer = (int)i; }
+                    else known *= s[i];
+                }
+                if (infer >= 0) {
+                    if (known == 0 || x.len() % known != 0) throw OpError(OpError::InvalidValue, "Input length must be a multiple of specified dimensions");
+                    s[(size_t)infer] = x.len() / known;
+                }
+                if (detail::prod(s, 0, s.size()) != x.len()) throw OpError(OpError::InvalidValue, "Input and output element counts do not match");
+            } else if (kind == "Squeeze") {
+                std::vector<int64_t> o;
+                for (int i = 0; i < nd; i++) {
+                    bool drop = have_spec ? false : s[(size_t)i] == 1;
+                    for (int64_t a : spec) if ((a < 0 ? a + nd : a) == i) drop = true;
+                    if (drop && s[(size_t)i] != 1) throw OpError(OpError::InvalidValue, "Can only remove dimensions of size 1");
+                    if (!drop) o.push_back(s[(size_t)i]);
+                }
+                s = o;
+            } else if (kind == "Unsqueeze") {
+                if (!have_spec) throw OpError(OpError::MissingInputs, "");
+                const int out_nd = nd + (int)spec.size();
+                std::vector<int64_t> o((size_t)out_nd, 0);
+                for (int64_t a : spec) {
+                    const int64_t p = a < 0 ? a + out_nd : a;
+                    if (p < 0 || p >= out_nd || o[(size_t)p] == 1) throw OpError(OpError::InvalidValue, "Axes must be unique and in range");
+                    o[(size_t)p] = 1;
+                }
+                int src = 0;
+                for (auto &d : o) if (d == 0) d = s[(size_t)src++];
+                s = o;
+            }
+            OutputList out;
+            out.push_back(Tensor::view_of(x, s));
+            return out;
+        };
+        st.view = true;
+    }
+
+    // Reference counts per value (Graph::run_plan's temp value refcounts): a value's buffer returns to the pool after its
+    // last consumer; a view adds one use to its base that is released together with the view itself.
+    void plan_liveness() {
+        uses_.assign(names_.size(), 0);
+        std::vector<int> base_of(names_.size(), -1);
+        for (auto &o : outputs_) uses_[(size_t)ids_.at(o.name)] += 1 << 20; // never released
+        for (auto &st : steps_) {
+            for (int id : st.in) if (id >= 0) uses_[(size_t)id]++;
+            if (st.view && st.in[0] >= 0 && st.out[0] >= 0) {
+                int base = st.in[0];
+                while (base_of[(size_t)base] >= 0) base = base_of[(size_t)base];
+                base_of[(size_t)st.out[0]] = base;
+                uses_[(size_t)base]++; // held by the view
+            }
+        }
+        std::vector<int> left(uses_);
+        for (auto &st : steps_) {
+            for (int id : st.in) {
+                if (id < 0 || consts_.count(id)) continue;
+                st.release_after.push_back(id);
+                if (--left[(size_t)id] == 0 && base_of[(size_t)id] >= 0) { // the view died: drop its hold on the base
+                    st.release_after.push_back(base_of[(size_t)id]);
+                    left[(size_t)base_of[(size_t)id]]--;
+                }
+            }
+            // outputs nobody reads (e.g. unused secondary outputs) die immediately
+            for (int id : st.out) if (id >= 0 && uses_[(size_t)id] == 0) { uses_[(size_t)id] = 1; st.release_after.push_back(id); }
+        }
+    }
+};
+
+} // namespace rten_hip

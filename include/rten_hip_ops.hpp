@@ -49,11 +49,42 @@ class Context {
         if (rc == RTEN_HIP_ERR_NO_DEVICE) throw OpError(OpError::BackendUnavailable, "no usable gfx950 (MI355X) device: the HIP backend has no CPU fallback");
         if (rc != RTEN_HIP_OK) throw OpError(OpError::Hip, "rten_hip_init failed");
     }
-    ~Context() { if (h_) rten_hip_destroy(h_); }
+    ~Context() { if (h_) { trim_pool(); if (one_) rten_hip_free(h_, one_); rten_hip_destroy(h_); } }
     Context(const Context &) = delete;
     Context &operator=(const Context &) = delete;
     rten_hip_ctx *raw() const { return h_; }
     void sync() { check(rten_hip_sync(h_)); }
+
+    // Device buffer pool (src/buffer_pool.rs: operators take output buffers from the pool, the executor returns dead values
+    // to it).  Off by default; a graph executor turns it on so that steady-state runs allocate nothing.  Buffers are handed
+    // out by exact byte size; the stream orders reuse (one stream per context).
+    void enable_pool(bool on = true) { pool_on_ = on; if (!on) trim_pool(); }
+    void *alloc(size_t bytes) {
+        if (pool_on_) {
+            auto it = pool_.find(bytes);
+            if (it != pool_.end() && !it->second.empty()) { void *p = it->second.back(); it->second.pop_back(); return p; }
+        }
+        void *p = nullptr;
+        check(rten_hip_malloc(h_, bytes, &p));
+        return p;
+    }
+    void release(void *p, size_t bytes) {
+        if (!p) return;
+        if (pool_on_) pool_[bytes].push_back(p);
+        else rten_hip_free(h_, p);
+    }
+    void trim_pool() {
+        for (auto &kv : pool_) for (void *p : kv.second) rten_hip_free(h_, p);
+        pool_.clear();
+    }
+    const float *one() { // device-resident 1.0f (x * 1.0f is exact: Cast as cast_scale)
+        if (!one_) {
+            const float v = 1.0f;
+            check(rten_hip_malloc(h_, 4, &one_));
+            check(rten_hip_memcpy_h2d(h_, one_, &v, 4));
+        }
+        return (const float *)one_;
+    }
     // maps ABI status codes onto OpError variants (include/rten_hip.h, "status codes")
     void check(int32_t rc) const {
         if (rc == RTEN_HIP_OK) return;
@@ -68,6 +99,9 @@ class Context {
 
   private:
     rten_hip_ctx *h_ = nullptr;
+    bool pool_on_ = false;
+    void *one_ = nullptr;
+    std::map<size_t, std::vector<void *>> pool_;
 };
 
 // ---- device tensor (the backend's `Value`: contiguous, row-major, device resident)
@@ -78,8 +112,15 @@ class Tensor {
   public:
     Tensor() = default;
     Tensor(Context &ctx, std::vector<int64_t> shape, DType dt) : ctx_(&ctx), shape_(std::move(shape)), dtype_(dt) {
-        const size_t n = bytes();
-        ctx.check(rten_hip_malloc(ctx.raw(), n ? n : 4, &ptr_));
+        cap_ = bytes() ? bytes() : 4;
+        ptr_ = ctx.alloc(cap_);
+    }
+    // Non-owning alias of `base`'s storage with another shape (Reshape / Flatten / Squeeze as views, src/ops/layout.rs):
+    // the caller keeps `base` alive for as long as the view is used.
+    static Tensor view_of(const Tensor &base, std::vector<int64_t> shape) {
+        Tensor t;
+        t.ctx_ = base.ctx_; t.ptr_ = base.ptr_; t.shape_ = std::move(shape); t.dtype_ = base.dtype_; t.owns_ = false;
+        return t;
     }
     template <typename T>
     static Tensor from_host(Context &ctx, std::vector<int64_t> shape, const T *data) {
@@ -90,7 +131,7 @@ class Tensor {
     ~Tensor() { release(); }
     Tensor(Tensor &&o) noexcept { *this = std::move(o); }
     Tensor &operator=(Tensor &&o) noexcept {
-        if (this != &o) { release(); ctx_ = o.ctx_; ptr_ = o.ptr_; shape_ = std::move(o.shape_); dtype_ = o.dtype_; o.ptr_ = nullptr; }
+        if (this != &o) { release(); ctx_ = o.ctx_; ptr_ = o.ptr_; shape_ = std::move(o.shape_); dtype_ = o.dtype_; cap_ = o.cap_; owns_ = o.owns_; o.ptr_ = nullptr; }
         return *this;
     }
     Tensor(const Tensor &) = delete;
@@ -118,9 +159,11 @@ class Tensor {
     }
 
   private:
-    void release() { if (ptr_ && ctx_) rten_hip_free(ctx_->raw(), ptr_); ptr_ = nullptr; }
+    void release() { if (ptr_ && ctx_ && owns_) ctx_->release(ptr_, cap_); ptr_ = nullptr; }
     Context *ctx_ = nullptr;
     void *ptr_ = nullptr;
+    size_t cap_ = 0;
+    bool owns_ = true;
     std::vector<int64_t> shape_;
     DType dtype_ = DType::F32;
 };
@@ -515,8 +558,9 @@ struct BinaryOp : Operator { // binary_elementwise.rs:476-495; device path: equa
             const int64_t bd = b.size(b.ndim() - 1 - i), ad = a.size(a.ndim() - 1 - i);
             if (bd != ad && !(bd == 1 && detail::prod(b.shape(), 0, (size_t)(b.ndim() - 1 - i)) == 1)) ok = false;
         }
-        if (!ok) throw OpError(OpError::IncompatibleInputShapes, "Cannot broadcast inputs to same shape");
-        Tensor y(ctx, a.shape(), DType::F32);
+        const bool both_single = n == 1 && bl == 1; // [] op [1], [1,1] op []: the result takes the higher rank
+        if (!ok && !both_single) throw OpError(OpError::IncompatibleInputShapes, "Cannot broadcast inputs to same shape");
+        Tensor y(ctx, both_single && b.ndim() > a.ndim() ? b.shape() : a.shape(), DType::F32);
         if (n) ctx.check(FN(ctx.raw(), n, (const float *)a.ptr(), (const float *)b.ptr(), bl, (float *)y.ptr()));
         OutputList out;
         out.push_back(std::move(y));
@@ -599,6 +643,25 @@ struct DynamicQuantizeLinear : Operator { // src/ops/quantize.rs:352-436: output
     }
 };
 
+// Cast (src/ops/convert.rs): the device path covers what the quantized graphs need, int32 -> float32 (exact conversion with
+// round-to-nearest-even above 2^24, the same instruction cast_scale uses) and identity casts.
+struct Cast : Operator {
+    DType to = DType::F32;
+    const char *name() const override { return "Cast"; }
+    int max_inputs() const override { return 1; }
+    OutputList run(Context &ctx, const InputList &in) const override {
+        const Tensor &x = require(in, 0);
+        OutputList out;
+        if (x.dtype() == DType::I32 && to == DType::F32) {
+            Tensor y(ctx, x.shape(), DType::F32);
+            if (x.len()) ctx.check(rten_hip_cast_scale(ctx.raw(), x.len(), (const int32_t *)x.ptr(), ctx.one(), 1, (float *)y.ptr()));
+            out.push_back(std::move(y));
+            return out;
+        }
+        throw OpError(OpError::UnsupportedValue, "Cast: only int32 -> float32 on the device path");
+    }
+};
+
 // ------------------------------------------------------------------------------------------------ registry (src/op_registry.rs:25-72)
 class OpRegistry {
   public:
@@ -635,6 +698,7 @@ class OpRegistry {
         r.register_op<AveragePool>("AveragePool");
         r.register_op<GlobalAveragePool>("GlobalAveragePool");
         r.register_op<DynamicQuantizeLinear>("DynamicQuantizeLinear");
+        r.register_op<Cast>("Cast");
         return r;
     }
 
