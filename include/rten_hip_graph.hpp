@@ -313,7 +313,40 @@ class Graph {
     // Runs the plan.  `feeds` are device tensors named like the graph inputs; the returned tensors are the graph outputs
     // in declaration order, still on the device.  With `timings`, every step is followed by a sync and timed on the host
     // (RTEN_TIMING's per-operator table, src/timing.rs) -- a profiling aid, it serialises the stream.
-    std::vector<Tensor> run(const std::vector<std::pair<std::string, const Tensor *>> &feeds, std::vector<Timing> *timings = nullptr) {
+    using Feeds = std::vector<std::pair<std::string, const Tensor *>>;
+
+    // Load-time plan selection: one pass over the graph in which every f32 convolution step times its candidate launch
+    // plans on its real operands (tile variant x exact split-K plan x tile order, the candidate set of
+    // rten_amd/models/resnet50.py::candidate_plans) and keeps the fastest.  Returns the number of tuned steps.
+    size_t autotune(const Feeds &feeds, int reps = 3) {
+        tune_reps_ = reps;
+        tuned_ = 0;
+        run(feeds);
+        ctx_.sync();
+        tune_reps_ = 0;
+        return tuned_;
+    }
+
+    // hipGraph capture of one run (launch-bound at small batch: ~60 operators of 5-50 us).  The feeds and the returned
+    // outputs keep their device addresses: write new inputs into the same feed tensors, call replay(), read the outputs.
+    // While a capture is alive the context's buffer pool must not serve anyone else (the graph's intermediates live there).
+    const std::vector<Tensor> &capture(const Feeds &feeds) {
+        run(feeds); // warm: every buffer size is in the pool, scratch is grown, code objects are loaded
+        ctx_.sync();
+        ctx_.check(rten_hip_graph_begin(ctx_.raw()));
+        captured_outputs_ = run(feeds);
+        ctx_.check(rten_hip_graph_end(ctx_.raw(), &graph_));
+        return captured_outputs_;
+    }
+    void replay() {
+        if (!graph_) throw GraphError("replay: no captured graph");
+        ctx_.check(rten_hip_graph_launch(ctx_.raw(), graph_));
+    }
+    ~Graph() { if (graph_) rten_hip_graph_destroy(ctx_.raw(), graph_); }
+    Graph(const Graph &) = delete;
+    Graph &operator=(const Graph &) = delete;
+
+    std::vector<Tensor> run(const Feeds &feeds, std::vector<Timing> *timings = nullptr) {
         std::vector<const Tensor *> val(names_.size(), nullptr);
         std::vector<std::unique_ptr<Tensor>> owned(names_.size());
         std::vector<int> pending(uses_);
@@ -332,6 +365,7 @@ class Graph {
             }
             const auto t0 = std::chrono::steady_clock::now();
             OutputList out;
+            if (tune_reps_ > 0 && st.conv) tune_step(st, in);
             try {
                 out = st.run(ctx_, in);
             } catch (const OpError &e) { // name the node, like the reference's RunError::OperatorError { name, error }
@@ -374,6 +408,7 @@ class Graph {
         std::vector<int> in, out, release_after;
         std::function<OutputList(Context &, const InputList &)> run;
         bool view = false;
+        std::shared_ptr<Conv> conv; // f32 convolution steps: the launch plan is tunable
         size_t pos = 0; // index of the LAST graph node folded into this step: the step runs where that node stood
     };
 
@@ -388,6 +423,52 @@ class Graph {
     std::vector<onnx::ValueInfo> inputs_, outputs_;
     size_t fused_away_ = 0;
     std::set<int> view_values_;
+    int tune_reps_ = 0;
+    size_t tuned_ = 0;
+    uint64_t graph_ = 0;
+    std::vector<Tensor> captured_outputs_;
+
+    void tune_step(Step &st, const InputList &in) {
+        const Tensor &w = require(in, 1);
+        const int64_t k = w.len() / std::max<int64_t>(w.size(0), 1); // per-group depth C/g * kh * kw
+        const int nblk = (int)((k + 255) / 256);
+        std::vector<GemmPlan> plans;
+        const int nvar = rten_hip_num_gemm_variants();
+        for (int v = 0; v < nvar; v++) for (int o = 0; o < 2; o++) plans.push_back(GemmPlan{true, v, 0, 1, o});
+        if (nblk > 1) {
+            static const int split_variants[] = {0, 1, 2, 3, 4, 5, 6, 7, 12, 13, 14, 15};
+            for (int v : split_variants) {
+                if (v >= nvar) continue;
+                std::set<int> group_counts;
+                for (int g : {2, 3, 4, 6, nblk}) if (g >= 2 && g <= nblk) group_counts.insert(g);
+                for (int g : group_counts) {
+                    plans.push_back(GemmPlan{true, v, 1, g, 0});
+                    for (int o : {0, 2, 3}) plans.push_back(GemmPlan{true, v, 2, g, o});
+                }
+            }
+        }
+        GemmPlan best;
+        float best_ms = 1e30f;
+        for (const GemmPlan &p : plans) {
+            st.conv->plan = p;
+            try {
+                st.run(ctx_, in); // warm (also grows the split-K slab scratch before any capture)
+                float ms = 1e30f;
+                for (int round = 0; round < 2; round++) { // best of two short runs
+                    ctx_.check(rten_hip_timer_start(ctx_.raw(), 2));
+                    for (int r = 0; r < tune_reps_; r++) st.run(ctx_, in);
+                    ctx_.check(rten_hip_timer_stop(ctx_.raw(), 2));
+                    float t = 0;
+                    ctx_.check(rten_hip_timer_elapsed_ms(ctx_.raw(), 2, &t));
+                    ms = std::min(ms, t / (float)tune_reps_);
+                }
+                if (ms < best_ms) { best_ms = ms; best = p; }
+            } catch (const OpError &) { // a plan the kernel family does not offer for this shape
+            }
+        }
+        st.conv->plan = best;
+        tuned_++;
+    }
 
     int id_of(const std::string &n) {
         if (n.empty()) return -1; // omitted optional input
@@ -518,6 +599,7 @@ class Graph {
                     }
                 }
                 st.kind_name = std::string("Conv") + (residual.empty() ? "" : "+Add") + (op->fuse_relu ? "+Relu" : "");
+                st.conv = op;
                 st.run = [op, packed](Context &c, const InputList &in) { return op->run_packed(c, in, packed); };
             } else if (n.op_type == "ConvInteger") {
                 auto op = std::make_shared<ConvInteger>();

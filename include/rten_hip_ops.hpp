@@ -213,8 +213,36 @@ inline OutputSize calc_output_size_and_padding(int h, int w, int kh, int kw, con
     return OutputSize{out[0], out[1], {opads[0], opads[1], opads[2], opads[3]}};
 }
 
+// Launch plan of the f32 GEMM / implicit-GEMM conv kernels: tile variant, exact split-K mode and group count, tile
+// order (rten_hip_set_gemm_variant_override / _split / _order).  Unset = the backend's automatic choice.  An executor
+// picks one per layer by measurement at load time, as the reference picks its kernel per ISA (rten-gemm/src/lib.rs:534-547).
+struct GemmPlan {
+    bool set = false;
+    int variant = -1, mode = 3, groups = 1, order = 0;
+};
+class PlanScope { // applies a plan around one call and restores the automatic plan afterwards
+  public:
+    PlanScope(Context &ctx, const GemmPlan &p) : ctx_(ctx), on_(p.set) {
+        if (!on_) return;
+        ctx.check(rten_hip_set_gemm_variant_override(ctx.raw(), p.variant));
+        ctx.check(rten_hip_set_gemm_split(ctx.raw(), p.mode, p.groups));
+        ctx.check(rten_hip_set_gemm_order(ctx.raw(), p.order));
+    }
+    ~PlanScope() {
+        if (!on_) return;
+        rten_hip_set_gemm_variant_override(ctx_.raw(), -1);
+        rten_hip_set_gemm_split(ctx_.raw(), 3, 1);
+        rten_hip_set_gemm_order(ctx_.raw(), 0);
+    }
+
+  private:
+    Context &ctx_;
+    bool on_;
+};
+
 // ------------------------------------------------------------------------------------------------ Conv
 struct Conv : Operator {
+    GemmPlan plan;
     int groups = 1;
     std::vector<int> dilations{1, 1};
     Padding padding;
@@ -268,6 +296,7 @@ struct Conv : Operator {
         if (bias && bias->size(0) != d.o) throw OpError(OpError::IncompatibleInputShapes, "bias.size(0) != out_channels");
         Tensor y(ctx, {d.n, d.o, d.out_h, d.out_w}, DType::F32);
         const uint32_t flags = (fuse_relu ? RTEN_HIP_CONV_RELU : 0u) | (residual ? RTEN_HIP_CONV_RESIDUAL : 0u);
+        PlanScope scope(ctx, plan);
         ctx.check(rten_hip_conv2d_f32(ctx.raw(), &d, (const float *)x.ptr(), (const float *)(packed_weight ? packed_weight->ptr() : w.ptr()),
                                       packed_weight ? 1 : 0, (const float *)vp(bias), (const float *)vp(residual), flags, (float *)y.ptr()));
         OutputList out;

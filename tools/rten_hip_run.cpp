@@ -9,6 +9,8 @@
 //     --dump name=path       write an output tensor as raw bytes
 //     --no-fuse              run the graph node by node (no fusion passes)
 //     -t, --timing           per-operator table (each operator followed by a sync)
+//     --tune                 time the candidate launch plans of every f32 convolution at load and keep the fastest
+//     --graph                capture one run into a hipGraph and replay it for the timed runs
 //     --parse-only           print the model summary and exit (needs no GPU)
 //
 // There is no CPU fallback: without an MI355X the tool reports BackendUnavailable and exits 2.
@@ -31,7 +33,7 @@ static const char *type_str(int t) {
 int main(int argc, char **argv) {
     std::string path;
     int iters = 1;
-    bool fuse = true, timing = false, parse_only = false;
+    bool fuse = true, timing = false, parse_only = false, tune = false, use_graph = false;
     std::map<std::string, int64_t> sizes;
     std::map<std::string, std::string> input_files, dumps;
     auto kv = [](const std::string &a, std::string &k, std::string &v) {
@@ -50,6 +52,8 @@ int main(int argc, char **argv) {
         else if (a == "--no-fuse") fuse = false;
         else if (a == "-t" || a == "--timing") timing = true;
         else if (a == "--parse-only") parse_only = true;
+        else if (a == "--tune") tune = true;
+        else if (a == "--graph") use_graph = true;
         else if (!a.empty() && a[0] != '-') path = a;
         else { std::fprintf(stderr, "unknown or incomplete option %s\n", a.c_str()); return 1; }
     }
@@ -117,12 +121,25 @@ int main(int argc, char **argv) {
         }
 
         // warm-up (first run allocates the pool), then timed runs
-        std::vector<Tensor> outs = g.run(feeds);
+        if (tune) {
+            const auto t0 = std::chrono::steady_clock::now();
+            const size_t n = g.autotune(feeds);
+            std::printf("  Tuned the launch plan of %zu convolution steps in %.2fs\n", n, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        }
+        std::vector<Tensor> outs;
+        const std::vector<Tensor> *result = &outs;
+        if (use_graph) {
+            result = &g.capture(feeds);
+            std::printf("  Captured the plan into a hipGraph\n");
+        } else {
+            outs = g.run(feeds);
+        }
         ctx.sync();
         std::vector<double> ms;
         for (int i = 0; i < iters; i++) {
             const auto t0 = std::chrono::steady_clock::now();
-            outs = g.run(feeds);
+            if (use_graph) g.replay();
+            else outs = g.run(feeds);
             ctx.sync();
             ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
             std::printf("  #%d - %.3fms\n", i + 1, ms.back());
@@ -136,6 +153,7 @@ int main(int argc, char **argv) {
         }
         if (timing) {
             std::vector<Graph::Timing> tm;
+            if (use_graph) throw GraphError("--timing and --graph exclude each other");
             outs = g.run(feeds, &tm);
             std::map<std::string, std::pair<int, double>> by_op;
             double total = 0;
@@ -143,13 +161,14 @@ int main(int argc, char **argv) {
             std::printf("  Operator timing (each operator followed by a sync; total %.3fms):\n", total);
             for (auto &kvp : by_op) std::printf("    %-40s x%-4d %8.3fms %5.1f%%\n", kvp.first.c_str(), kvp.second.first, kvp.second.second, 100.0 * kvp.second.second / total);
         }
-        for (size_t i = 0; i < outs.size(); i++) {
+        const std::vector<Tensor> &outs_ref = *result;
+        for (size_t i = 0; i < outs_ref.size(); i++) {
             const std::string &name = g.outputs()[i].name;
-            std::printf("  Output \"%s\" resolved shape %s\n", name.c_str(), shape_str(outs[i].shape()).c_str());
+            std::printf("  Output \"%s\" resolved shape %s\n", name.c_str(), shape_str(outs_ref[i].shape()).c_str());
             auto d = dumps.find(name);
             if (d != dumps.end()) {
-                std::vector<uint8_t> host(outs[i].bytes());
-                if (outs[i].bytes()) ctx.check(rten_hip_memcpy_d2h(ctx.raw(), host.data(), outs[i].ptr(), outs[i].bytes()));
+                std::vector<uint8_t> host(outs_ref[i].bytes());
+                if (outs_ref[i].bytes()) ctx.check(rten_hip_memcpy_d2h(ctx.raw(), host.data(), outs_ref[i].ptr(), outs_ref[i].bytes()));
                 std::ofstream fo(d->second, std::ios::binary);
                 fo.write((const char *)host.data(), (std::streamsize)host.size());
             }
