@@ -304,6 +304,8 @@ class Graph {
     const std::vector<onnx::ValueInfo> &outputs() const { return outputs_; }
     size_t num_steps() const { return steps_.size(); }
     size_t num_fused_away() const { return fused_away_; }
+    size_t num_staged_quantizers() const { return staged_dql_; }
+    size_t num_stats_blocks() const { return stats_blocks_; }
     std::vector<std::string> step_names() const {
         std::vector<std::string> v;
         for (auto &s : steps_) v.push_back(s.kind_name + ":" + s.name);
@@ -357,6 +359,7 @@ class Graph {
             val[(size_t)it->second] = fd.second;
         }
         for (auto &in : inputs_) if (!val[(size_t)ids_.at(in.name)]) throw GraphError("run: missing input " + in.name);
+        if (stats_blocks_) ctx_.check(rten_hip_minmax_stats_reset(ctx_.raw(), stats_arena_->ptr(), (int32_t)stats_blocks_)); // one launch for every block
         for (auto &st : steps_) {
             InputList in;
             for (int id : st.in) {
@@ -403,12 +406,20 @@ class Graph {
     }
 
   private:
+    struct I8Conv {
+        std::shared_ptr<ConvInteger> op;
+        ConvInteger::Staging sg;
+        bool to_float = false;
+    };
     struct Step {
         std::string name, kind_name;
         std::vector<int> in, out, release_after;
         std::function<OutputList(Context &, const InputList &)> run;
         bool view = false;
         std::shared_ptr<Conv> conv; // f32 convolution steps: the launch plan is tunable
+        std::shared_ptr<I8Conv> i8; // int8 convolution steps: staged-pipeline options are decided after all steps exist
+        std::shared_ptr<DynamicQuantizeLinearStaged> dql_staged;
+        bool removed = false;
         size_t pos = 0; // index of the LAST graph node folded into this step: the step runs where that node stood
     };
 
@@ -425,6 +436,82 @@ class Graph {
     std::set<int> view_values_;
     int tune_reps_ = 0;
     size_t tuned_ = 0;
+    size_t stats_blocks_ = 0, staged_dql_ = 0;
+    std::unique_ptr<Tensor> stats_arena_;
+
+    // The staged int8 pipeline at graph level.  A DynamicQuantizeLinear whose codes feed only int8
+    // convolutions of one padding geometry writes them straight into the kernel's staged layout; if its input is the f32
+    // output of a fused ConvIntegerToFloat step, that step's epilogue accumulates the min/max the quantizer needs
+    // (one statistics block per such tensor, all reset by one launch at the start of a run).
+    void plan_int8_staging() {
+        std::map<int, size_t> producer;
+        std::map<int, std::vector<size_t>> consumers;
+        for (size_t i = 0; i < steps_.size(); i++) {
+            for (int id : steps_[i].out) if (id >= 0) producer[id] = i;
+            for (int id : steps_[i].in) if (id >= 0) consumers[id].push_back(i);
+        }
+        struct Pending { size_t dql; size_t producer; };
+        std::vector<Pending> want_stats;
+        for (size_t i = 0; i < steps_.size(); i++) {
+            Step &dq = steps_[i];
+            if (dq.kind_name != "DynamicQuantizeLinear" || dq.out.size() < 3 || dq.out[0] < 0 || dq.i8) continue;
+            bool graph_out = false;
+            for (auto &o : outputs_) if (ids_.at(o.name) == dq.out[0]) graph_out = true;
+            const auto &users = consumers[dq.out[0]];
+            if (graph_out || users.empty()) continue;
+            bool ok = true;
+            const Step *first = nullptr;
+            for (size_t u : users) {
+                const Step &cs = steps_[u];
+                if (!cs.i8 || cs.in[0] != dq.out[0] || cs.in[2] != dq.out[2] || !consts_.count(cs.in[1]) || cs.i8->op->conv.padding.same ||
+                    cs.i8->op->conv.groups != 1) { ok = false; break; }
+                if (std::count(cs.in.begin(), cs.in.end(), dq.out[0]) != 1) { ok = false; break; }
+                if (!first) first = &cs;
+                else if (cs.i8->op->conv.padding.fixed != first->i8->op->conv.padding.fixed || cs.i8->op->pad_mode != first->i8->op->pad_mode) { ok = false; break; }
+            }
+            if (!ok || !first) continue;
+            auto op = std::make_shared<DynamicQuantizeLinearStaged>();
+            op->consumer = *first->i8->op;
+            op->kernel = consts_.at(first->in[1]).shape();
+            for (size_t u : users) steps_[u].i8->sg.x_staged = true;
+            dq.kind_name = "DynamicQuantizeLinear(staged)";
+            dq.run = [op](Context &c, const InputList &in) { return op->run(c, in); };
+            dq.dql_staged = op;
+            staged_dql_++;
+            // fold ONE following Mul(y_scale, constant scalar) into the quantizer (same f32 multiply): its product becomes a 4th output
+            for (size_t u : consumers[dq.out[1]]) {
+                Step &mu = steps_[u];
+                if (mu.kind_name != "Mul" || mu.in.size() != 2 || mu.removed) continue;
+                const int other = mu.in[0] == dq.out[1] ? mu.in[1] : mu.in[0];
+                if (other == dq.out[1] || !consts_.count(other) || consts_.at(other).len() != 1 || consts_.at(other).dtype() != DType::F32) continue;
+                bool is_out = false;
+                for (auto &o : outputs_) if (ids_.at(o.name) == mu.out[0]) is_out = true;
+                if (is_out) continue;
+                op->mul_by = &consts_.at(other);
+                dq.out.push_back(mu.out[0]);
+                mu.removed = true;
+                fused_away_++;
+                break;
+            }
+            auto p = producer.find(dq.in[0]);
+            if (p != producer.end() && steps_[p->second].i8 && steps_[p->second].i8->to_float && steps_[p->second].out[0] == dq.in[0])
+                want_stats.push_back({i, p->second});
+        }
+        // (indices into steps_ stay valid until here; drop the absorbed Mul steps last)
+        struct Eraser { std::vector<Step> &v; ~Eraser() { v.erase(std::remove_if(v.begin(), v.end(), [](const Step &s) { return s.removed; }), v.end()); } } eraser{steps_};
+        if (want_stats.empty()) return;
+        const size_t sb = rten_hip_minmax_stats_bytes();
+        std::map<size_t, size_t> block_of; // producer step -> block
+        for (auto &w : want_stats) if (!block_of.count(w.producer)) { const size_t b = block_of.size(); block_of[w.producer] = b; }
+        stats_blocks_ = block_of.size();
+        stats_arena_.reset(new Tensor(ctx_, {(int64_t)(sb * stats_blocks_)}, DType::U8));
+        for (auto &w : want_stats) {
+            void *blk = (char *)stats_arena_->ptr() + sb * block_of[w.producer];
+            steps_[w.producer].i8->sg.stats_out = blk;
+            steps_[w.dql].dql_staged->stats_in = blk;
+            steps_[w.dql].kind_name = "DynamicQuantizeLinear(staged, producer statistics)";
+        }
+    }
     uint64_t graph_ = 0;
     std::vector<Tensor> captured_outputs_;
 
@@ -641,10 +728,21 @@ class Graph {
                 st.in.push_back(bias.empty() ? -1 : id_of(bias));
                 st.in.push_back(residual.empty() ? -1 : id_of(residual));
                 if (!scale.empty()) st.kind_name = std::string("ConvIntegerToFloat") + (bias.empty() ? "" : "+bias") + (residual.empty() ? "" : "+Add") + (relu ? "+Relu" : "");
-                st.run = [op, relu](Context &c, const InputList &in) {
+                auto state = std::make_shared<I8Conv>();
+                state->op = op;
+                state->to_float = !scale.empty();
+                if (opt_.prepack && is_const(n.inputs.at(1)) && op->conv.groups == 1) {
+                    const Tensor &w = consts_.at(ids_.at(n.inputs[1]));
+                    if (w.ndim() == 4) {
+                        packed_.emplace_back(new Tensor(op->prepack(ctx_, w)));
+                        state->sg.packed_weight = packed_.back().get();
+                    }
+                }
+                st.i8 = state;
+                st.run = [state, relu](Context &c, const InputList &in) {
                     const Tensor *scale = in[4];
                     if (scale && scale->len() != 1) throw OpError(OpError::InvalidValue, "scale should be a scalar");
-                    return op->run_fused(c, InputList(in.begin(), in.begin() + 4), scale, in[5], in[6], relu);
+                    return state->op->run_staged(c, InputList(in.begin(), in.begin() + 4), scale, in[5], in[6], relu, state->sg);
                 };
             } else if (n.op_type == "MatMulInteger") {
                 auto op = std::make_shared<MatMulInteger>();
@@ -710,6 +808,7 @@ class Graph {
             if (!ids_.count(o.name)) throw GraphError("graph output " + o.name + " is not produced by any node");
         std::stable_sort(steps_.begin(), steps_.end(), [](const Step &a, const Step &b) { return a.pos < b.pos; });
         for (auto &st : steps_) if (st.view && st.out[0] >= 0) view_values_.insert(st.out[0]);
+        if (opt_.fuse) plan_int8_staging();
         plan_liveness();
     }
 

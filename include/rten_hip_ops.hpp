@@ -14,6 +14,7 @@
 // Validation runs on the host before any launch; arithmetic is done by librten_hip.so on device-resident tensors.  There
 // is no CPU fallback: without a gfx950 device `Context` throws.  Header only; C++17.
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <functional>
@@ -113,6 +114,12 @@ class Tensor {
     Tensor() = default;
     Tensor(Context &ctx, std::vector<int64_t> shape, DType dt) : ctx_(&ctx), shape_(std::move(shape)), dtype_(dt) {
         cap_ = bytes() ? bytes() : 4;
+        ptr_ = ctx.alloc(cap_);
+    }
+    // Shape plus an explicit byte capacity (>= bytes()): opaque device layouts that are larger than the logical tensor,
+    // e.g. the int8 kernel's zero-point-padded staged image of an [N, C, H, W] activation.
+    Tensor(Context &ctx, std::vector<int64_t> shape, DType dt, size_t capacity) : ctx_(&ctx), shape_(std::move(shape)), dtype_(dt) {
+        cap_ = std::max<size_t>(std::max(capacity, bytes()), 4);
         ptr_ = ctx.alloc(cap_);
     }
     // Non-owning alias of `base`'s storage with another shape (Reshape / Flatten / Squeeze as views, src/ops/layout.rs):
@@ -330,14 +337,51 @@ struct ConvInteger : Operator {
         return di;
     }
     OutputList run(Context &ctx, const InputList &in) const override { return run_fused(ctx, in, nullptr, nullptr, nullptr, false); }
+
+    // PrepackedInput analogue for constant weights (rten_hip_conv2d_int8_prepack); an empty tensor (len 0) when the staged
+    // kernel does not cover the geometry -- pass the plain weights then.
+    Tensor prepack(Context &ctx, const Tensor &w) const {
+        rten_hip_conv2d_int8_desc di{};
+        di.conv.n = 1; di.conv.c = (int)w.size(1) * conv.groups; di.conv.o = (int)w.size(0); di.conv.kh = (int)w.size(2); di.conv.kw = (int)w.size(3);
+        di.conv.h = di.conv.kh; di.conv.w = di.conv.kw; di.conv.out_h = di.conv.out_w = 1;
+        di.conv.stride_h = di.conv.stride_w = di.conv.dil_h = di.conv.dil_w = 1; di.conv.groups = conv.groups;
+        di.w_signed = w.dtype() == DType::I8;
+        const size_t nbytes = rten_hip_conv2d_int8_packed_bytes(&di);
+        if (!nbytes) return Tensor(ctx, {0}, DType::U8);
+        Tensor packed(ctx, {(int64_t)nbytes}, DType::U8);
+        ctx.check(rten_hip_conv2d_int8_prepack(ctx.raw(), &di, w.ptr(), packed.ptr()));
+        return packed;
+    }
+
+    // Options of the staged pipeline: prepacked weights, `x` already in the kernel's staged layout
+    // (written by DynamicQuantizeLinearStaged below; its logical shape is still [N, C, H, W]), and a statistics block in
+    // which the epilogue accumulates min/max of the f32 outputs for the DynamicQuantizeLinear that consumes them.
+    struct Staging {
+        const Tensor *packed_weight = nullptr;
+        bool x_staged = false;
+        void *stats_out = nullptr;
+    };
+
     // scale != null: ConvIntegerToFloat epilogue (cast_scale, then the following Add(bias) / Add(residual) / Relu)
     OutputList run_fused(Context &ctx, const InputList &in, const Tensor *scale, const Tensor *bias, const Tensor *residual, bool relu) const {
+        return run_staged(ctx, in, scale, bias, residual, relu, Staging());
+    }
+    OutputList run_staged(Context &ctx, const InputList &in, const Tensor *scale, const Tensor *bias, const Tensor *residual, bool relu,
+                          const Staging &sg) const {
         const Tensor &x = require(in, 0), &w = require(in, 1);
         const Tensor *x_zp = get(in, 2), *w_zp = get(in, 3);
-        const rten_hip_conv2d_int8_desc di = desc(x, w, x_zp, w_zp);
+        rten_hip_conv2d_int8_desc di = desc(x, w, x_zp, w_zp);
+        const bool packed = sg.packed_weight && sg.packed_weight->len() > 0;
+        di.weights_packed = packed ? 1 : 0;
+        di.x_staged = sg.x_staged ? 1 : 0;
         Tensor y(ctx, {di.conv.n, di.conv.o, di.conv.out_h, di.conv.out_w}, scale ? DType::F32 : DType::I32);
         const uint32_t flags = (relu ? RTEN_HIP_CONV_RELU : 0u) | (residual ? RTEN_HIP_CONV_RESIDUAL : 0u);
-        ctx.check(rten_hip_conv2d_int8(ctx.raw(), &di, x.ptr(), w.ptr(), vp(x_zp), vp(w_zp), (const float *)vp(scale), (const float *)vp(bias),
+        const void *wp = packed ? sg.packed_weight->ptr() : w.ptr();
+        if (sg.stats_out && scale)
+            ctx.check(rten_hip_conv2d_int8_stats(ctx.raw(), &di, x.ptr(), wp, vp(x_zp), vp(w_zp), (const float *)vp(scale), (const float *)vp(bias),
+                                                 (const float *)vp(residual), flags, y.ptr(), sg.stats_out));
+        else
+        ctx.check(rten_hip_conv2d_int8(ctx.raw(), &di, x.ptr(), wp, vp(x_zp), vp(w_zp), (const float *)vp(scale), (const float *)vp(bias),
                                        (const float *)vp(residual), flags, y.ptr()));
         OutputList out;
         out.push_back(std::move(y));
@@ -668,6 +712,42 @@ struct DynamicQuantizeLinear : Operator { // src/ops/quantize.rs:352-436: output
         out.push_back(std::move(y));
         out.push_back(std::move(s));
         out.push_back(std::move(z));
+        return out;
+    }
+};
+
+// DynamicQuantizeLinear whose u8 output is only consumed by int8 convolutions of one staging geometry: the codes are
+// written once, directly in the kernel's staged layout (bit-identical values), and -- when the producer of `x` left
+// min/max statistics -- without the extra sweep over x.  Outputs: staged image (logical shape of x), y_scale, y_zero_point.
+struct DynamicQuantizeLinearStaged : Operator {
+    ConvInteger consumer;        // geometry attributes of (one of) the consuming convolutions
+    std::vector<int64_t> kernel; // [O, C/g, kh, kw] of that consumer
+    const void *stats_in = nullptr;
+    const Tensor *mul_by = nullptr; // optional: the Mul(y_scale, w_scale) that follows in ort-quantized graphs -> 4th output
+    const char *name() const override { return "DynamicQuantizeLinear"; }
+    int max_inputs() const override { return 1; }
+    OutputList run(Context &ctx, const InputList &in) const override {
+        const Tensor &x = want(require(in, 0), DType::F32, "float32");
+        rten_hip_conv2d_int8_desc di{};
+        di.conv = consumer.conv.geometry(x.shape(), kernel);
+        di.x_signed = 0; di.w_signed = 1; di.pad_mode = consumer.pad_mode;
+        const size_t nbytes = rten_hip_conv2d_int8_staged_bytes(&di);
+        if (!nbytes) throw OpError(OpError::UnsupportedValue, "quantize_staged: geometry not covered by the staged kernel");
+        Tensor y(ctx, x.shape(), DType::U8, nbytes), s(ctx, {}, DType::F32), z(ctx, {}, DType::U8);
+        Tensor prod(ctx, mul_by ? mul_by->shape() : std::vector<int64_t>{}, DType::F32);
+        const float *mb = mul_by ? (const float *)mul_by->ptr() : nullptr;
+        if (mul_by && mul_by->len() != 1) throw OpError(OpError::InvalidValue, "scale should be a scalar");
+        if (stats_in)
+            ctx.check(rten_hip_dynamic_quantize_linear_staged_stats(ctx.raw(), &di, (const float *)x.ptr(), stats_in, y.ptr(), (float *)s.ptr(), (uint8_t *)z.ptr(), mb,
+                                                                    mb ? (float *)prod.ptr() : nullptr));
+        else
+            ctx.check(rten_hip_dynamic_quantize_linear_staged(ctx.raw(), &di, (const float *)x.ptr(), y.ptr(), (float *)s.ptr(), (uint8_t *)z.ptr(), mb,
+                                                              mb ? (float *)prod.ptr() : nullptr));
+        OutputList out;
+        out.push_back(std::move(y));
+        out.push_back(std::move(s));
+        out.push_back(std::move(z));
+        if (mul_by) out.push_back(std::move(prod));
         return out;
     }
 };

@@ -83,6 +83,9 @@ int main(int argc, char **argv) {
         opt.fuse = fuse;
         Graph g(ctx, m, opt);
         std::printf("Plan: %zu steps (%zu nodes folded into fused steps)\n", g.num_steps(), g.num_fused_away());
+        if (g.num_staged_quantizers())
+            std::printf("  int8: %zu DynamicQuantizeLinear write the staged layout directly; %zu producer statistics blocks\n", g.num_staged_quantizers(),
+                        g.num_stats_blocks());
 
         // inputs
         std::vector<Tensor> feeds_store;
