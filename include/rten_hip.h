@@ -264,6 +264,15 @@ int32_t rten_hip_erf_f32(rten_hip_ctx *ctx, int64_t n, const float *x, float *y)
 /* y[i] = a[i] + b[i % b_len] (b_len == n: same shape; b_len < n: trailing-dims broadcast) */
 int32_t rten_hip_add_f32(rten_hip_ctx *ctx, int64_t n, const float *a, const float *b, int64_t b_len, float *y);
 int32_t rten_hip_mul_f32(rten_hip_ctx *ctx, int64_t n, const float *a, const float *b, int64_t b_len, float *y);
+int32_t rten_hip_sub_f32(rten_hip_ctx *ctx, int64_t n, const float *a, const float *b, int64_t b_len, float *y);
+int32_t rten_hip_div_f32(rten_hip_ctx *ctx, int64_t n, const float *a, const float *b, int64_t b_len, float *y);
+/* General numpy broadcasting (binary_elementwise.rs:58-170): op 0 add, 1 mul, 2 sub, 3 div; out_shape[ndim] (ndim <= 6);
+ * a_strides / b_strides in elements of the operands as expanded to out_shape, 0 on broadcast axes. */
+int32_t rten_hip_binary_broadcast_f32(rten_hip_ctx *ctx, int32_t op, int32_t ndim, const int64_t *out_shape, const int64_t *a_strides,
+                                      const int64_t *b_strides, const float *a, const float *b, float *y);
+/* Transpose (src/ops/layout.rs:669+) of 4-byte elements: y.shape[d] = x_shape[perm[d]], ndim <= 6; an invalid perm is
+ * "Permutation is invalid" like the reference. */
+int32_t rten_hip_transpose_b32(rten_hip_ctx *ctx, int32_t ndim, const int64_t *x_shape, const int32_t *perm, const void *x, void *y);
 /* y[(i / inner) ...] += bias[c]: per-channel bias add for NCHW tensors ([1,O,1,1] constant Add) */
 int32_t rten_hip_add_channel_bias_f32(rten_hip_ctx *ctx, int32_t n, int32_t c, int64_t inner, const float *x,
                                       const float *bias, float *y);

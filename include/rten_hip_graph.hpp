@@ -763,8 +763,78 @@ class Graph {
                 op->transpose_a = n.get_int("transA", 0) != 0; op->transpose_b = n.get_int("transB", 0) != 0;
                 st.run = [op](Context &c, const InputList &in) { return op->run(c, in); };
             } else if (n.op_type == "MatMul") {
-                auto op = std::make_shared<MatMul>();
+                // MatMul (+ Mul / Div by a constant scalar = alpha, MatMulScale fusion) (+ Add of a constant 1-D bias,
+                // MatMulAddFusion) (+ Gelu / Relu as the GEMM epilogue): FusedMatMul (src/ops/matmul.rs:455-510)
+                auto op = std::make_shared<FusedMatMul>();
+                std::string bias;
+                auto const_scalar = [&](const std::string &v, float &out) {
+                    if (!is_const(v)) return false;
+                    const Tensor &t = consts_.at(ids_.at(v));
+                    if (t.len() != 1 || t.dtype() != DType::F32) return false;
+                    out = t.to_host<float>()[0];
+                    return true;
+                };
+                if (opt_.fuse) {
+                    for (const char *sop : {"Div", "Mul"}) {
+                        long d = sole_user(out_name, sop);
+                        float c = 0.f;
+                        if (d >= 0 && m.nodes[(size_t)d].inputs[0] == out_name && const_scalar(m.nodes[(size_t)d].inputs[1], c) && op->alpha == 1.f) {
+                            op->alpha = std::string(sop) == "Div" ? 1.0f / c : c;
+                            dead[(size_t)d] = true; fused_away_++; out_name = m.nodes[(size_t)d].outputs[0]; st.pos = (size_t)d;
+                        }
+                    }
+                    long a = op->alpha == 1.f ? sole_user(out_name, "Add") : -1;
+                    if (a >= 0) {
+                        const std::string other = other_input(m.nodes[(size_t)a], out_name);
+                        if (is_const(other) && consts_.at(ids_.at(other)).ndim() == 1 && consts_.at(ids_.at(other)).dtype() == DType::F32) {
+                            bias = other; dead[(size_t)a] = true; fused_away_++; out_name = m.nodes[(size_t)a].outputs[0]; st.pos = (size_t)a;
+                            long g = sole_user(out_name, "Gelu");
+                            if (g >= 0 && !m.nodes[(size_t)g].attr("approximate")) { op->act = RTEN_HIP_ACT_GELU; dead[(size_t)g] = true; fused_away_++; out_name = m.nodes[(size_t)g].outputs[0]; st.pos = (size_t)g; }
+                            long r = g < 0 ? sole_user(out_name, "Relu") : -1;
+                            if (r >= 0) { op->act = RTEN_HIP_ACT_RELU; dead[(size_t)r] = true; fused_away_++; out_name = m.nodes[(size_t)r].outputs[0]; st.pos = (size_t)r; }
+                        }
+                    }
+                }
+                st.in.resize(2);
+                st.in.push_back(bias.empty() ? -1 : id_of(bias));
+                st.kind_name = std::string(op->alpha != 1.f || !bias.empty() ? "FusedMatMul" : "MatMul") + (op->act == RTEN_HIP_ACT_GELU ? "+Gelu" : op->act == RTEN_HIP_ACT_RELU ? "+Relu" : "");
+                st.run = [op](Context &c, const InputList &in) {
+                    const Tensor *bias = in[2];
+                    if (bias && bias->len() != require(in, 1).size(require(in, 1).ndim() - 1)) throw OpError(OpError::IncompatibleInputShapes, "Cannot broadcast bias to output shape");
+                    return op->run(c, in);
+                };
+            } else if (n.op_type == "Add" && opt_.fuse && sole_user(out_name, "Softmax") >= 0 &&
+                       m.nodes[(size_t)sole_user(out_name, "Softmax")].get_int("axis", -1) == -1) {
+                // Add -> Softmax(last axis) = AddSoftmax (src/ops/attention.rs:94-156)
+                const long sm = sole_user(out_name, "Softmax");
+                dead[(size_t)sm] = true; fused_away_++; out_name = m.nodes[(size_t)sm].outputs[0]; st.pos = (size_t)sm;
+                st.kind_name = "AddSoftmax";
+                st.run = [](Context &c, const InputList &in) {
+                    const Tensor &a = require(in, 0), &b = require(in, 1);
+                    AddSoftmax fused;
+                    try {
+                        return a.len() >= b.len() ? fused.run(c, {&a, &b}) : fused.run(c, {&b, &a});
+                    } catch (const OpError &e) { // a broadcast the fused kernel does not cover: Add, then Softmax
+                        if (e.kind != OpError::IncompatibleInputShapes) throw;
+                        OutputList sum = Add().run(c, in);
+                        return Softmax().run(c, {&sum[0]});
+                    }
+                };
+            } else if (n.op_type == "Transpose") {
+                auto op = std::make_shared<Transpose>();
+                op->perm = n.get_ints("perm", {});
                 st.run = [op](Context &c, const InputList &in) { return op->run(c, in); };
+            } else if (n.op_type == "Gather") {
+                auto op = std::make_shared<Gather>();
+                op->axis = (int)n.get_int("axis", 0);
+                st.run = [op](Context &c, const InputList &in) { return op->run(c, in); };
+            } else if (n.op_type == "LayerNormalization") {
+                auto op = std::make_shared<LayerNormalization>();
+                op->axis = (int)n.get_int("axis", -1);
+                op->epsilon = n.get_float("epsilon", 1e-5f);
+                st.run = [op](Context &c, const InputList &in) { return op->run(c, in); };
+            } else if (n.op_type == "Gelu" && n.attr("approximate") && n.attr("approximate")->s != "none") {
+                throw GraphError("Gelu " + st.name + ": approximate=\"" + n.attr("approximate")->s + "\" is not supported");
             } else if (n.op_type == "MaxPool" || n.op_type == "AveragePool") {
                 std::vector<int> k = n.get_ints("kernel_shape", {});
                 if (k.size() != 2) throw GraphError(n.op_type + " " + st.name + ": kernel_shape must have 2 values");

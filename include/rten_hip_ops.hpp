@@ -617,8 +617,8 @@ struct Relu : UnaryOp<rten_hip_relu_f32> { Relu() : UnaryOp("Relu") {} };
 struct Gelu : UnaryOp<rten_hip_gelu_f32> { Gelu() : UnaryOp("Gelu") {} };
 struct Erf : UnaryOp<rten_hip_erf_f32> { Erf() : UnaryOp("Erf") {} };
 
-template <int32_t (*FN)(rten_hip_ctx *, int64_t, const float *, const float *, int64_t, float *)>
-struct BinaryOp : Operator { // binary_elementwise.rs:476-495; device path: equal shapes or `b` broadcast over leading dims
+template <int32_t (*FN)(rten_hip_ctx *, int64_t, const float *, const float *, int64_t, float *), int OPCODE>
+struct BinaryOp : Operator { // binary_elementwise.rs:58-170,476-495: numpy broadcasting
     const char *nm;
     explicit BinaryOp(const char *n) : nm(n) {}
     const char *name() const override { return nm; }
@@ -626,22 +626,116 @@ struct BinaryOp : Operator { // binary_elementwise.rs:476-495; device path: equa
     OutputList run(Context &ctx, const InputList &in) const override {
         const Tensor &a = want(require(in, 0), DType::F32, "float32"), &b = want(require(in, 1), DType::F32, "float32");
         const int64_t n = a.len(), bl = b.len();
-        bool ok = bl > 0 && n % bl == 0 && b.ndim() <= a.ndim();
-        for (int i = 0; ok && i < b.ndim(); i++) {
+        // fast path: equal shapes, or `b` broadcast over the leading dims of `a` (flat kernels, 16 B per lane)
+        bool fast = bl > 0 && n % bl == 0 && b.ndim() <= a.ndim();
+        for (int i = 0; fast && i < b.ndim(); i++) {
             const int64_t bd = b.size(b.ndim() - 1 - i), ad = a.size(a.ndim() - 1 - i);
-            if (bd != ad && !(bd == 1 && detail::prod(b.shape(), 0, (size_t)(b.ndim() - 1 - i)) == 1)) ok = false;
+            if (bd != ad && !(bd == 1 && detail::prod(b.shape(), 0, (size_t)(b.ndim() - 1 - i)) == 1)) fast = false;
         }
-        const bool both_single = n == 1 && bl == 1; // [] op [1], [1,1] op []: the result takes the higher rank
-        if (!ok && !both_single) throw OpError(OpError::IncompatibleInputShapes, "Cannot broadcast inputs to same shape");
-        Tensor y(ctx, both_single && b.ndim() > a.ndim() ? b.shape() : a.shape(), DType::F32);
-        if (n) ctx.check(FN(ctx.raw(), n, (const float *)a.ptr(), (const float *)b.ptr(), bl, (float *)y.ptr()));
+        OutputList out;
+        if (fast) {
+            Tensor y(ctx, a.shape(), DType::F32);
+            if (n) ctx.check(FN(ctx.raw(), n, (const float *)a.ptr(), (const float *)b.ptr(), bl, (float *)y.ptr()));
+            out.push_back(std::move(y));
+            return out;
+        }
+        // general case: align the shapes on the right, stride 0 on every axis of extent 1
+        const int nd = std::max(a.ndim(), b.ndim());
+        if (nd > 6) throw OpError(OpError::UnsupportedValue, "broadcasting over more than 6 dims is not supported by the device path");
+        std::vector<int64_t> oshape((size_t)nd), as((size_t)nd, 0), bs((size_t)nd, 0);
+        int64_t sa = 1, sb = 1;
+        for (int i = nd - 1; i >= 0; i--) {
+            const int ia = i - (nd - a.ndim()), ib = i - (nd - b.ndim());
+            const int64_t da = ia >= 0 ? a.size(ia) : 1, db = ib >= 0 ? b.size(ib) : 1;
+            if (da != db && da != 1 && db != 1) throw OpError(OpError::IncompatibleInputShapes, "Cannot broadcast inputs to same shape");
+            oshape[(size_t)i] = std::max(da, db) == 1 ? 1 : (da == 1 ? db : da);
+            if (da == 0 || db == 0) oshape[(size_t)i] = 0;
+            as[(size_t)i] = da == 1 ? 0 : sa;
+            bs[(size_t)i] = db == 1 ? 0 : sb;
+            sa *= da; sb *= db;
+        }
+        Tensor y(ctx, oshape, DType::F32);
+        if (y.len()) ctx.check(rten_hip_binary_broadcast_f32(ctx.raw(), OPCODE, nd, oshape.data(), as.data(), bs.data(), (const float *)a.ptr(), (const float *)b.ptr(), (float *)y.ptr()));
+        out.push_back(std::move(y));
+        return out;
+    }
+};
+struct Add : BinaryOp<rten_hip_add_f32, 0> { Add() : BinaryOp("Add") {} };
+struct Mul : BinaryOp<rten_hip_mul_f32, 1> { Mul() : BinaryOp("Mul") {} };
+struct Sub : BinaryOp<rten_hip_sub_f32, 2> { Sub() : BinaryOp("Sub") {} };
+struct Div : BinaryOp<rten_hip_div_f32, 3> { Div() : BinaryOp("Div") {} };
+
+// ------------------------------------------------------------------------------------------------ layout (src/ops/layout.rs, gather.rs)
+struct Transpose : Operator { // layout.rs:669+: perm absent = reverse the axes
+    std::vector<int> perm;
+    const char *name() const override { return "Transpose"; }
+    int max_inputs() const override { return 1; }
+    OutputList run(Context &ctx, const InputList &in) const override {
+        const Tensor &x = require(in, 0);
+        if (dtype_size(x.dtype()) != 4) throw OpError(OpError::UnsupportedType, "");
+        const int nd = x.ndim();
+        std::vector<int32_t> p(perm.begin(), perm.end());
+        if (p.empty()) for (int i = nd - 1; i >= 0; i--) p.push_back(i);
+        if ((int)p.size() != nd) throw OpError(OpError::InvalidValue, "Permutation is invalid");
+        std::vector<int64_t> oshape;
+        for (int i = 0; i < nd; i++) {
+            if (p[(size_t)i] < 0) p[(size_t)i] += nd;
+            if (p[(size_t)i] < 0 || p[(size_t)i] >= nd) throw OpError(OpError::InvalidValue, "Permutation is invalid");
+            oshape.push_back(x.size(p[(size_t)i]));
+        }
+        Tensor y(ctx, oshape, x.dtype());
+        ctx.check(rten_hip_transpose_b32(ctx.raw(), nd, x.shape().data(), p.data(), x.ptr(), y.ptr()));
         OutputList out;
         out.push_back(std::move(y));
         return out;
     }
 };
-struct Add : BinaryOp<rten_hip_add_f32> { Add() : BinaryOp("Add") {} };
-struct Mul : BinaryOp<rten_hip_mul_f32> { Mul() : BinaryOp("Mul") {} };
+
+// Gather along axis 0 of a float table with int32 indices (gather.rs: the embedding-lookup form).  Out-of-range indices
+// are clamped on the device (the reference reports "Entry in indices is out of range").
+struct Gather : Operator {
+    int axis = 0;
+    const char *name() const override { return "Gather"; }
+    int max_inputs() const override { return 2; }
+    OutputList run(Context &ctx, const InputList &in) const override {
+        const Tensor &table = want(require(in, 0), DType::F32, "float32");
+        const Tensor &ids = want(require(in, 1), DType::I32, "int32");
+        if (table.ndim() < 1) throw OpError(OpError::InvalidValue, "Input must have >= 1 dims");
+        if (resolve_axis(axis, table.ndim()) != 0) throw OpError(OpError::UnsupportedValue, "Gather: only axis 0 on the device path");
+        const int64_t row_len = detail::prod(table.shape(), 1, table.shape().size());
+        std::vector<int64_t> oshape = ids.shape();
+        oshape.insert(oshape.end(), table.shape().begin() + 1, table.shape().end());
+        Tensor y(ctx, oshape, DType::F32);
+        if (y.len()) ctx.check(rten_hip_gather_rows_f32(ctx.raw(), ids.len(), (int32_t)row_len, (int32_t)table.size(0), (const float *)table.ptr(), (const int32_t *)ids.ptr(), (float *)y.ptr()));
+        OutputList out;
+        out.push_back(std::move(y));
+        return out;
+    }
+};
+
+// AddSoftmax (src/ops/attention.rs:94-156): softmax(x + m) over the last axis in one pass; m has x's shape, or is an
+// attention mask [B, 1, 1, T] against x = [B, H, S, T], or a single row [T].
+struct AddSoftmax : Operator {
+    bool flush_nans_to_zero = false;
+    const char *name() const override { return "AddSoftmax"; }
+    int max_inputs() const override { return 2; }
+    OutputList run(Context &ctx, const InputList &in) const override {
+        const Tensor &x = want(require(in, 0), DType::F32, "float32"), &m = want(require(in, 1), DType::F32, "float32");
+        if (x.ndim() < 1) throw OpError(OpError::InvalidValue, "Input must have >= 1 dims");
+        const int64_t cols = x.size(x.ndim() - 1), rows = cols ? x.len() / cols : 0;
+        int64_t add_div, add_mod;
+        if (m.shape() == x.shape()) { add_div = 1; add_mod = rows ? rows : 1; }
+        else if (m.len() == cols && m.size(m.ndim() - 1) == cols) { add_div = rows ? rows : 1; add_mod = 1; }
+        else if (x.ndim() == 4 && m.ndim() == 4 && m.size(0) == x.size(0) && m.size(1) == 1 && m.size(2) == 1 && m.size(3) == cols) {
+            add_div = x.size(1) * x.size(2); add_mod = x.size(0);
+        } else throw OpError(OpError::IncompatibleInputShapes, "Cannot broadcast inputs to same shape");
+        Tensor y(ctx, x.shape(), DType::F32);
+        if (x.len()) ctx.check(rten_hip_softmax_f32(ctx.raw(), rows, (int)cols, (const float *)x.ptr(), (const float *)m.ptr(), add_div, add_mod, flush_nans_to_zero ? 1 : 0, (float *)y.ptr()));
+        OutputList out;
+        out.push_back(std::move(y));
+        return out;
+    }
+};
 
 // ------------------------------------------------------------------------------------------------ pooling
 struct PoolBase : Operator {
@@ -767,6 +861,12 @@ struct Cast : Operator {
             out.push_back(std::move(y));
             return out;
         }
+        if (x.dtype() == to) { // identity cast: a copy
+            Tensor y(ctx, x.shape(), to);
+            if (x.bytes()) ctx.check(rten_hip_memcpy_d2d(ctx.raw(), y.ptr(), x.ptr(), x.bytes()));
+            out.push_back(std::move(y));
+            return out;
+        }
         throw OpError(OpError::UnsupportedValue, "Cast: only int32 -> float32 on the device path");
     }
 };
@@ -803,6 +903,11 @@ class OpRegistry {
         r.register_op<Erf>("Erf");
         r.register_op<Add>("Add");
         r.register_op<Mul>("Mul");
+        r.register_op<Sub>("Sub");
+        r.register_op<Div>("Div");
+        r.register_op<Transpose>("Transpose");
+        r.register_op<Gather>("Gather");
+        r.register_op<AddSoftmax>("AddSoftmax");
         r.register_op<MaxPool>("MaxPool");
         r.register_op<AveragePool>("AveragePool");
         r.register_op<GlobalAveragePool>("GlobalAveragePool");

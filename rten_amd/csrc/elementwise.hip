@@ -52,7 +52,15 @@ __global__ __launch_bounds__(EW_THREADS) void unary_kernel(int64_t n, const floa
     }
 }
 
-enum BinaryOp { B_ADD, B_MUL };
+enum BinaryOp { B_ADD, B_MUL, B_SUB, B_DIV };
+
+template <int OP>
+__device__ __forceinline__ float binary(float a, float b) {
+    if constexpr (OP == B_ADD) return a + b;
+    else if constexpr (OP == B_MUL) return a * b;
+    else if constexpr (OP == B_SUB) return a - b;
+    else return a / b;
+}
 
 template <int OP>
 __global__ __launch_bounds__(EW_THREADS) void binary_kernel(int64_t n, const float *__restrict__ a,
@@ -67,14 +75,14 @@ __global__ __launch_bounds__(EW_THREADS) void binary_kernel(int64_t n, const flo
             f32x4 vb = reinterpret_cast<const f32x4 *>(b)[i];
             f32x4 r;
 #pragma unroll
-            for (int k = 0; k < 4; k++) r[k] = OP == B_ADD ? va[k] + vb[k] : va[k] * vb[k];
+            for (int k = 0; k < 4; k++) r[k] = binary<OP>(va[k], vb[k]);
             reinterpret_cast<f32x4 *>(y)[i] = r;
         }
-        for (int64_t i = (n4 << 2) + tid; i < n; i += stride) y[i] = OP == B_ADD ? a[i] + b[i] : a[i] * b[i];
+        for (int64_t i = (n4 << 2) + tid; i < n; i += stride) y[i] = binary<OP>(a[i], b[i]);
     } else {
         for (int64_t i = tid; i < n; i += stride) {
             const float bv = b[b_len == n ? i : i % b_len];
-            y[i] = OP == B_ADD ? a[i] + bv : a[i] * bv;
+            y[i] = binary<OP>(a[i], bv);
         }
     }
 }
@@ -132,6 +140,44 @@ __global__ __launch_bounds__(EW_THREADS) void gather_rows_kernel(int64_t n_ids, 
     }
 }
 
+// General numpy-style broadcasting (binary_elementwise.rs:58-170: operands expanded with stride 0 on broadcast axes) and
+// Transpose / permute (src/ops/layout.rs:669+): one output element per thread-iteration, index decomposed over <= 6 axes.
+struct NdArgs {
+    int ndim;
+    int64_t n;
+    int32_t shape[6];
+    int64_t a_stride[6], b_stride[6];
+};
+
+template <int OP>
+__global__ __launch_bounds__(EW_THREADS) void binary_bcast_kernel(const NdArgs p, const float *__restrict__ a, const float *__restrict__ b,
+                                                                  float *__restrict__ y) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += stride) {
+        int64_t r = i, ao = 0, bo = 0;
+        for (int d = p.ndim - 1; d >= 0; d--) {
+            const int64_t q = r / p.shape[d], c = r - q * p.shape[d];
+            ao += c * p.a_stride[d];
+            bo += c * p.b_stride[d];
+            r = q;
+        }
+        y[i] = binary<OP>(a[ao], b[bo]);
+    }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void permute_kernel(const NdArgs p, const uint32_t *__restrict__ x, uint32_t *__restrict__ y) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += stride) {
+        int64_t r = i, xo = 0;
+        for (int d = p.ndim - 1; d >= 0; d--) {
+            const int64_t q = r / p.shape[d], c = r - q * p.shape[d];
+            xo += c * p.a_stride[d]; // stride of output axis d in the input
+            r = q;
+        }
+        y[i] = x[xo];
+    }
+}
+
 inline bool al16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 
 template <int OP>
@@ -181,6 +227,65 @@ RTEN_EXPORT int32_t rten_hip_add_f32(rten_hip_ctx *ctx, int64_t n, const float *
 RTEN_EXPORT int32_t rten_hip_mul_f32(rten_hip_ctx *ctx, int64_t n, const float *a, const float *b, int64_t b_len,
                                      float *y) {
     return run_binary<B_MUL>(ctx, n, a, b, b_len, y, "mul_f32");
+}
+RTEN_EXPORT int32_t rten_hip_sub_f32(rten_hip_ctx *ctx, int64_t n, const float *a, const float *b, int64_t b_len,
+                                     float *y) {
+    return run_binary<B_SUB>(ctx, n, a, b, b_len, y, "sub_f32");
+}
+RTEN_EXPORT int32_t rten_hip_div_f32(rten_hip_ctx *ctx, int64_t n, const float *a, const float *b, int64_t b_len,
+                                     float *y) {
+    return run_binary<B_DIV>(ctx, n, a, b, b_len, y, "div_f32");
+}
+
+// op: 0 add, 1 mul, 2 sub, 3 div.  out_shape[ndim]; a_strides / b_strides in elements, 0 on broadcast axes.
+RTEN_EXPORT int32_t rten_hip_binary_broadcast_f32(rten_hip_ctx *ctx, int32_t op, int32_t ndim, const int64_t *out_shape, const int64_t *a_strides,
+                                                  const int64_t *b_strides, const float *a, const float *b, float *y) {
+    RTEN_CHECK_CTX(ctx);
+    if (op < 0 || op > 3 || ndim < 0 || ndim > 6 || (ndim && (!out_shape || !a_strides || !b_strides)))
+        return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "binary_broadcast: op in 0..3, at most 6 dims");
+    NdArgs p = {};
+    p.ndim = ndim;
+    p.n = 1;
+    for (int d = 0; d < ndim; d++) {
+        if (out_shape[d] < 0 || out_shape[d] > 0x7fffffff) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "binary_broadcast: bad dimension");
+        p.shape[d] = (int32_t)out_shape[d]; p.a_stride[d] = a_strides[d]; p.b_stride[d] = b_strides[d];
+        p.n *= out_shape[d];
+    }
+    if (p.n == 0) return RTEN_HIP_OK;
+    if (!a || !b || !y) return RTEN_HIP_ERR_INVALID_VALUE;
+    ProfScope ps(ctx, "binary_broadcast_f32", 0.0, 12.0 * p.n);
+    const dim3 grid(ew_blocks(p.n)), block(EW_THREADS);
+    if (op == 0) hipLaunchKernelGGL((binary_bcast_kernel<B_ADD>), grid, block, 0, ctx->stream, p, a, b, y);
+    else if (op == 1) hipLaunchKernelGGL((binary_bcast_kernel<B_MUL>), grid, block, 0, ctx->stream, p, a, b, y);
+    else if (op == 2) hipLaunchKernelGGL((binary_bcast_kernel<B_SUB>), grid, block, 0, ctx->stream, p, a, b, y);
+    else hipLaunchKernelGGL((binary_bcast_kernel<B_DIV>), grid, block, 0, ctx->stream, p, a, b, y);
+    RTEN_LAUNCH_CHECK(ctx, "binary_broadcast_f32");
+    return RTEN_HIP_OK;
+}
+
+// y = transpose(x, perm) for 4-byte elements (f32 / i32): y.shape[d] = x_shape[perm[d]].
+RTEN_EXPORT int32_t rten_hip_transpose_b32(rten_hip_ctx *ctx, int32_t ndim, const int64_t *x_shape, const int32_t *perm, const void *x, void *y) {
+    RTEN_CHECK_CTX(ctx);
+    if (ndim < 0 || ndim > 6 || (ndim && (!x_shape || !perm))) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "transpose: at most 6 dims");
+    int64_t xstride[6], acc = 1;
+    unsigned seen = 0;
+    for (int d = ndim - 1; d >= 0; d--) { xstride[d] = acc; acc *= x_shape[d]; }
+    NdArgs p = {};
+    p.ndim = ndim;
+    p.n = acc;
+    for (int d = 0; d < ndim; d++) {
+        if (perm[d] < 0 || perm[d] >= ndim || (seen >> perm[d]) & 1u) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "Permutation is invalid");
+        seen |= 1u << perm[d];
+        if (x_shape[perm[d]] < 0 || x_shape[perm[d]] > 0x7fffffff) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "transpose: bad dimension");
+        p.shape[d] = (int32_t)x_shape[perm[d]];
+        p.a_stride[d] = xstride[perm[d]];
+    }
+    if (p.n == 0) return RTEN_HIP_OK;
+    if (!x || !y) return RTEN_HIP_ERR_INVALID_VALUE;
+    ProfScope ps(ctx, "transpose_b32", 0.0, 8.0 * p.n);
+    hipLaunchKernelGGL(permute_kernel, dim3(ew_blocks(p.n)), dim3(EW_THREADS), 0, ctx->stream, p, (const uint32_t *)x, (uint32_t *)y);
+    RTEN_LAUNCH_CHECK(ctx, "transpose_b32");
+    return RTEN_HIP_OK;
 }
 
 RTEN_EXPORT int32_t rten_hip_add_channel_bias_f32(rten_hip_ctx *ctx, int32_t n, int32_t c, int64_t inner,

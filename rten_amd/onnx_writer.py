@@ -210,3 +210,70 @@ def small_cnn_f32(seed: int = 7):
              node("Flatten", ["g"], ["f"], name="flatten", axis=1),
              node("Gemm", ["f", "fc.w", "fc.b"], ["y"], name="fc", transB=1)]
     return model(nodes, [value_info("x", FLOAT, ["batch", 3, 16, 16])], [value_info("y", FLOAT, ["batch", 5])], inits, name="small_cnn"), w
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# BERT encoder (BASELINE configs[3]) in the shape an exporter gives it: separate Q / K / V projections, Reshape /
+# Transpose around the attention MatMuls, Div by sqrt(d), Add(mask) -> Softmax, LayerNormalization (opset 17), Gelu
+# ----------------------------------------------------------------------------------------------------------------
+
+def bert_encoder(cfg, weights, seq: int, batch="batch") -> bytes:
+    """inputs: input_ids, token_type_ids, attention_mask -- int64 [batch, seq]; output: last_hidden_state [batch, seq, hidden]."""
+    H, nh = cfg.hidden, cfg.heads
+    dh = H // nh
+    w = weights
+    nodes, inits = [], []
+
+    def const(name, arr):
+        inits.append(tensor(name, arr))
+        return name
+
+    const("word", w["word"]); const("type", w["type"]); const("pos", np.ascontiguousarray(w["pos"][:seq]))
+    const("emb_ln_g", w["emb_ln_g"]); const("emb_ln_b", w["emb_ln_b"])
+    const("one", np.array(1.0, np.float32)); const("f32_min", np.array(np.finfo(np.float32).min, np.float32))
+    const("sqrt_dh", np.array(np.sqrt(np.float32(dh)), np.float32))
+    const("mask_axes", np.array([1, 2], np.int64))
+    const("split_heads", np.array([0, 0, nh, dh], np.int64)); const("merge_heads", np.array([0, 0, H], np.int64))
+    # embeddings
+    nodes.append(node("Gather", ["word", "input_ids"], ["emb.word"], name="emb.word", axis=0))
+    nodes.append(node("Gather", ["type", "token_type_ids"], ["emb.type"], name="emb.type", axis=0))
+    nodes.append(node("Add", ["emb.word", "emb.type"], ["emb.wt"], name="emb.add_type"))
+    nodes.append(node("Add", ["emb.wt", "pos"], ["emb.sum"], name="emb.add_pos"))
+    nodes.append(node("LayerNormalization", ["emb.sum", "emb_ln_g", "emb_ln_b"], ["x0"], name="emb.ln", axis=-1, epsilon=float(cfg.eps)))
+    # additive attention mask: (1 - mask) * finfo(f32).min as [B, 1, 1, S]
+    nodes.append(node("Unsqueeze", ["attention_mask", "mask_axes"], ["mask.4d"], name="mask.unsqueeze"))
+    nodes.append(node("Cast", ["mask.4d"], ["mask.f"], name="mask.cast", to=FLOAT))
+    nodes.append(node("Sub", ["one", "mask.f"], ["mask.inv"], name="mask.sub"))
+    nodes.append(node("Mul", ["mask.inv", "f32_min"], ["mask.bias"], name="mask.mul"))
+    x = "x0"
+    for i, lw in enumerate(w["layers"]):
+        p = f"l{i}."
+        for k in ("wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo", "ln1_g", "ln1_b", "w1", "b1", "w2", "b2", "ln2_g", "ln2_b"):
+            const(p + k, lw[k])
+        for t in ("q", "k", "v"):
+            nodes.append(node("MatMul", [x, p + "w" + t], [p + t + ".mm"], name=p + t + ".matmul"))
+            nodes.append(node("Add", [p + t + ".mm", p + "b" + t], [p + t + ".lin"], name=p + t + ".bias"))
+            nodes.append(node("Reshape", [p + t + ".lin", "split_heads"], [p + t + ".4d"], name=p + t + ".reshape"))
+            nodes.append(node("Transpose", [p + t + ".4d"], [p + t], name=p + t + ".transpose", perm=[0, 2, 3, 1] if t == "k" else [0, 2, 1, 3]))
+        nodes.append(node("MatMul", [p + "q", p + "k"], [p + "scores.raw"], name=p + "qk"))
+        nodes.append(node("Div", [p + "scores.raw", "sqrt_dh"], [p + "scores"], name=p + "scale"))
+        nodes.append(node("Add", [p + "scores", "mask.bias"], [p + "scores.masked"], name=p + "mask"))
+        nodes.append(node("Softmax", [p + "scores.masked"], [p + "probs"], name=p + "softmax", axis=-1))
+        nodes.append(node("MatMul", [p + "probs", p + "v"], [p + "ctx.h"], name=p + "pv"))
+        nodes.append(node("Transpose", [p + "ctx.h"], [p + "ctx.t"], name=p + "ctx.transpose", perm=[0, 2, 1, 3]))
+        nodes.append(node("Reshape", [p + "ctx.t", "merge_heads"], [p + "ctx"], name=p + "ctx.reshape"))
+        nodes.append(node("MatMul", [p + "ctx", p + "wo"], [p + "o.mm"], name=p + "o.matmul"))
+        nodes.append(node("Add", [p + "o.mm", p + "bo"], [p + "o.lin"], name=p + "o.bias"))
+        nodes.append(node("Add", [p + "o.lin", x], [p + "res1"], name=p + "res1"))
+        nodes.append(node("LayerNormalization", [p + "res1", p + "ln1_g", p + "ln1_b"], [p + "x1"], name=p + "ln1", axis=-1, epsilon=float(cfg.eps)))
+        nodes.append(node("MatMul", [p + "x1", p + "w1"], [p + "h.mm"], name=p + "ffn1.matmul"))
+        nodes.append(node("Add", [p + "h.mm", p + "b1"], [p + "h.lin"], name=p + "ffn1.bias"))
+        nodes.append(node("Gelu", [p + "h.lin"], [p + "h"], name=p + "gelu"))
+        nodes.append(node("MatMul", [p + "h", p + "w2"], [p + "f.mm"], name=p + "ffn2.matmul"))
+        nodes.append(node("Add", [p + "f.mm", p + "b2"], [p + "f.lin"], name=p + "ffn2.bias"))
+        nodes.append(node("Add", [p + "f.lin", p + "x1"], [p + "res2"], name=p + "res2"))
+        out = "last_hidden_state" if i == len(w["layers"]) - 1 else p + "x2"
+        nodes.append(node("LayerNormalization", [p + "res2", p + "ln2_g", p + "ln2_b"], [out], name=p + "ln2", axis=-1, epsilon=float(cfg.eps)))
+        x = out
+    ins = [value_info(n, INT64, [batch, seq]) for n in ("input_ids", "token_type_ids", "attention_mask")]
+    return model(nodes, ins, [value_info("last_hidden_state", FLOAT, [batch, seq, H])], inits, opset=20, name="bert_encoder")

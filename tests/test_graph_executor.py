@@ -169,3 +169,37 @@ def test_resnet50_int8_onnx_graph_bit_exact(tmp_path):
     got, log = _run_model(tmp_path, ow.resnet50_int8(w), x, "logits")
     assert "ConvInteger x53" in log
     assert np.array_equal(got.view(np.int32), want.ravel().view(np.int32))
+
+
+@pytest.mark.gpu
+def test_bert_encoder_onnx_graph_bit_exact(tmp_path):
+    """Transformer graph as an exporter writes it (separate Q/K/V MatMul + Add, Reshape / Transpose around the attention
+    MatMuls, Div by sqrt(d), Add(mask) -> Softmax, LayerNormalization, Gelu): bit-identical to the oracle's encoder."""
+    from oracle import models as om
+    from rten_amd import onnx_writer as ow
+    from rten_amd.models import bert
+    cfg = bert.BertConfig(hidden=64, heads=4, layers=2, ffn=128, vocab=100, max_pos=32, type_vocab=2)
+    w = bert.make_weights(cfg)
+    B, S = 3, 16
+    rng = np.random.default_rng(5)
+    ids = rng.integers(0, cfg.vocab, (B, S)).astype(np.int32)
+    tts = rng.integers(0, 2, (B, S)).astype(np.int32)
+    mask = np.ones((B, S), np.int32)
+    mask[1, 11:] = 0
+    mask[2, 5:] = 0
+    want = om.bert_forward(cfg, w, ids, mask, tts)
+    p = tmp_path / "bert.onnx"
+    p.write_bytes(ow.bert_encoder(cfg, w, S))
+    files = {}
+    for name, arr in (("input_ids", ids), ("token_type_ids", tts), ("attention_mask", mask)):
+        files[name] = tmp_path / (name + ".bin")
+        arr.tofile(files[name])
+    yout = tmp_path / "y.bin"
+    for extra in ((), ("--no-fuse",), ("--graph", "-n", "2")):
+        args = ["-s", f"batch={B}", "--dump", f"last_hidden_state={yout}", *extra]
+        for name, f in files.items():
+            args += ["--input", f"{name}={f}"]
+        r = run_cli(*args, str(p))
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        got = np.fromfile(yout, np.float32)
+        assert np.array_equal(got.view(np.int32), want.ravel().view(np.int32)), extra
