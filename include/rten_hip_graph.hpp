@@ -652,7 +652,154 @@ class Graph {
         };
         auto other_input = [&](const onnx::Node &n, const std::string &v) { return n.inputs[0] == v ? n.inputs[1] : n.inputs[0]; };
 
+        // ---- attention pre-pass (TransposeFusion + MatMulScale + AddSoftmax of the reference, taken one step further):
+        //   q_lin -> Reshape[0,0,h,d] -> Transpose(0,2,1,3) -+
+        //   k_lin -> Reshape[0,0,h,d] -> Transpose(0,2,3,1) -+> MatMul -> (Div | Mul scalar) -> Add(mask) -> Softmax(-1) -+
+        //   v_lin -> Reshape[0,0,h,d] -> Transpose(0,2,1,3) ------------------------------------------------------------+> MatMul -> Transpose(0,2,1,3) -> Reshape[0,0,H]
+        // becomes one MultiHeadSdpa step over the [B, S, H] projections; if the three projections are MatMul(x, W) + Add(b)
+        // of one input with constant weights, they become one GEMM against [Wq | Wk | Wv] whose column blocks the
+        // attention kernel reads in place (bit-identical: every output element is the same k-ordered dot product).
+        struct Attn { std::string q, k, v, mask, out, x; int heads = 0; float scale = 1.f; bool merged = false; int wqkv = -1, bqkv = -1; int64_t hidden = 0; };
+        std::map<size_t, Attn> attn_at;
+        if (opt_.fuse) {
+            auto single_use = [&](const std::string &v) { auto it = users.find(v); return !graph_outs.count(v) && it != users.end() && it->second.size() == 1; };
+            auto made_by = [&](const std::string &v, const char *op) -> long {
+                auto it = producer.find(v);
+                return it != producer.end() && !dead[it->second] && m.nodes[it->second].op_type == op && single_use(v) ? (long)it->second : -1;
+            };
+            auto const_i32 = [&](const std::string &v, std::vector<int32_t> &out) {
+                if (!is_const(v)) return false;
+                const Tensor &t = consts_.at(ids_.at(v));
+                if (t.dtype() != DType::I32) return false;
+                out = t.to_host<int32_t>();
+                return true;
+            };
+            // value -> (Reshape[0,0,h,d] node, Transpose node) feeding it with the given perm; returns the projection's name
+            auto split_heads = [&](const std::string &v, std::vector<int> perm, int &heads, std::vector<size_t> &nodes) -> std::string {
+                const long t = made_by(v, "Transpose");
+                if (t < 0 || m.nodes[(size_t)t].get_ints("perm", {}) != perm) return "";
+                const long r = made_by(m.nodes[(size_t)t].inputs[0], "Reshape");
+                std::vector<int32_t> shp;
+                if (r < 0 || m.nodes[(size_t)r].inputs.size() < 2 || !const_i32(m.nodes[(size_t)r].inputs[1], shp) || shp.size() != 4 || shp[0] != 0 || shp[1] != 0 || shp[2] <= 0) return "";
+                if (heads && heads != shp[2]) return "";
+                heads = shp[2];
+                nodes.push_back((size_t)t); nodes.push_back((size_t)r);
+                return m.nodes[(size_t)r].inputs[0];
+            };
+            for (size_t i = 0; i < N; i++) {
+                const onnx::Node &mm = m.nodes[i];
+                if (dead[i] || mm.op_type != "MatMul" || mm.inputs.size() != 2) continue;
+                Attn at;
+                std::vector<size_t> nodes{i};
+                at.q = split_heads(mm.inputs[0], {0, 2, 1, 3}, at.heads, nodes);
+                at.k = at.q.empty() ? "" : split_heads(mm.inputs[1], {0, 2, 3, 1}, at.heads, nodes);
+                if (at.k.empty()) continue;
+                std::string cur = mm.outputs[0];
+                for (const char *sop : {"Div", "Mul"}) {
+                    const long d = sole_user(cur, sop);
+                    if (d < 0 || m.nodes[(size_t)d].inputs[0] != cur || !is_const(m.nodes[(size_t)d].inputs[1])) continue;
+                    const Tensor &c = consts_.at(ids_.at(m.nodes[(size_t)d].inputs[1]));
+                    if (c.len() != 1 || c.dtype() != DType::F32 || at.scale != 1.f) continue;
+                    const float cv = c.to_host<float>()[0];
+                    at.scale = std::string(sop) == "Div" ? 1.0f / cv : cv;
+                    nodes.push_back((size_t)d);
+                    cur = m.nodes[(size_t)d].outputs[0];
+                }
+                const long add = sole_user(cur, "Add");
+                if (add >= 0) { at.mask = other_input(m.nodes[(size_t)add], cur); nodes.push_back((size_t)add); cur = m.nodes[(size_t)add].outputs[0]; }
+                const long sm = sole_user(cur, "Softmax");
+                if (sm < 0 || m.nodes[(size_t)sm].get_int("axis", -1) != -1) continue;
+                nodes.push_back((size_t)sm);
+                cur = m.nodes[(size_t)sm].outputs[0];
+                const long pv = sole_user(cur, "MatMul");
+                if (pv < 0 || m.nodes[(size_t)pv].inputs[0] != cur) continue;
+                nodes.push_back((size_t)pv);
+                at.v = split_heads(m.nodes[(size_t)pv].inputs[1], {0, 2, 1, 3}, at.heads, nodes);
+                if (at.v.empty()) continue;
+                const long tr = sole_user(m.nodes[(size_t)pv].outputs[0], "Transpose");
+                if (tr < 0 || m.nodes[(size_t)tr].get_ints("perm", {}) != std::vector<int>{0, 2, 1, 3}) continue;
+                const long rs = sole_user(m.nodes[(size_t)tr].outputs[0], "Reshape");
+                std::vector<int32_t> shp;
+                if (rs < 0 || m.nodes[(size_t)rs].inputs.size() < 2 || !const_i32(m.nodes[(size_t)rs].inputs[1], shp) || shp.size() != 3 || shp[0] != 0 || shp[1] != 0) continue;
+                nodes.push_back((size_t)tr); nodes.push_back((size_t)rs);
+                at.out = m.nodes[(size_t)rs].outputs[0];
+                if (!at.mask.empty() && producer.count(at.mask) && producer[at.mask] > i) continue; // mask must exist before the scores
+                // optional: one GEMM for the three projections
+                struct Lin { long mm = -1, add = -1; std::string x, w, b; };
+                auto linear = [&](const std::string &v) {
+                    Lin l;
+                    const long a = made_by(v, "Add");
+                    if (a < 0) return l;
+                    for (int side = 0; side < 2; side++) {
+                        const std::string &mmv = m.nodes[(size_t)a].inputs[(size_t)side], &bv = m.nodes[(size_t)a].inputs[(size_t)(1 - side)];
+                        const long mmi = made_by(mmv, "MatMul");
+                        if (mmi < 0 || !is_const(bv) || !is_const(m.nodes[(size_t)mmi].inputs[1])) continue;
+                        const Tensor &w = consts_.at(ids_.at(m.nodes[(size_t)mmi].inputs[1])), &b = consts_.at(ids_.at(bv));
+                        if (w.ndim() != 2 || b.ndim() != 1 || b.len() != w.size(1) || w.dtype() != DType::F32 || b.dtype() != DType::F32) continue;
+                        l.mm = mmi; l.add = a; l.x = m.nodes[(size_t)mmi].inputs[0]; l.w = m.nodes[(size_t)mmi].inputs[1]; l.b = bv;
+                        return l;
+                    }
+                    return l;
+                };
+                const Lin lq = linear(at.q), lk = linear(at.k), lv = linear(at.v);
+                if (lq.mm >= 0 && lk.mm >= 0 && lv.mm >= 0 && lq.x == lk.x && lq.x == lv.x) {
+                    const Tensor &wq = consts_.at(ids_.at(lq.w)), &wk = consts_.at(ids_.at(lk.w)), &wv = consts_.at(ids_.at(lv.w));
+                    if (wq.shape() == wk.shape() && wq.shape() == wv.shape()) {
+                        const int64_t K = wq.size(0), Nn = wq.size(1);
+                        const std::vector<float> hq = wq.to_host<float>(), hk = wk.to_host<float>(), hv = wv.to_host<float>();
+                        std::vector<float> wcat((size_t)(K * 3 * Nn)), bcat;
+                        for (int64_t r = 0; r < K; r++) {
+                            std::copy(hq.begin() + r * Nn, hq.begin() + (r + 1) * Nn, wcat.begin() + r * 3 * Nn);
+                            std::copy(hk.begin() + r * Nn, hk.begin() + (r + 1) * Nn, wcat.begin() + r * 3 * Nn + Nn);
+                            std::copy(hv.begin() + r * Nn, hv.begin() + (r + 1) * Nn, wcat.begin() + r * 3 * Nn + 2 * Nn);
+                        }
+                        for (const std::string *bn : {&lq.b, &lk.b, &lv.b}) { const std::vector<float> hb = consts_.at(ids_.at(*bn)).to_host<float>(); bcat.insert(bcat.end(), hb.begin(), hb.end()); }
+                        at.wqkv = id_of("__qkv_w." + std::to_string(i));
+                        at.bqkv = id_of("__qkv_b." + std::to_string(i));
+                        consts_.emplace(at.wqkv, Tensor::from_host<float>(ctx_, {K, 3 * Nn}, wcat.data()));
+                        consts_.emplace(at.bqkv, Tensor::from_host<float>(ctx_, {3 * Nn}, bcat.data()));
+                        at.merged = true; at.x = lq.x; at.hidden = Nn;
+                        for (long d : {lq.mm, lq.add, lk.mm, lk.add, lv.mm, lv.add}) nodes.push_back((size_t)d);
+                    }
+                }
+                for (size_t d : nodes) dead[d] = true;
+                fused_away_ += nodes.size() - (at.merged ? 2 : 1);
+                attn_at[(size_t)rs] = at;
+            }
+        }
+
         for (size_t i = 0; i < N; i++) {
+            auto af = attn_at.find(i);
+            if (af != attn_at.end()) {
+                const Attn &at = af->second;
+                auto op = std::make_shared<MultiHeadSdpa>();
+                op->heads = at.heads; op->scale = at.scale; op->flush_nans_to_zero = false;
+                Step st;
+                st.pos = i;
+                st.name = at.out;
+                st.kind_name = at.merged ? "MultiHeadSdpa(QKV column blocks)" : "MultiHeadSdpa";
+                if (at.merged) {
+                    auto lin = std::make_shared<FusedMatMul>();
+                    Step pj;
+                    pj.pos = i;
+                    pj.name = at.out + ".qkv";
+                    pj.kind_name = "FusedMatMul(QKV)";
+                    pj.in = {id_of(at.x), at.wqkv, at.bqkv};
+                    pj.out = {id_of("__qkv." + at.out)};
+                    pj.run = [lin](Context &c, const InputList &in) { return lin->run(c, in); };
+                    steps_.push_back(std::move(pj));
+                    const int qkv = id_of("__qkv." + at.out);
+                    op->q_rs = op->k_rs = op->v_rs = 3 * at.hidden; op->width = at.hidden;
+                    op->q_off = 0; op->k_off = at.hidden; op->v_off = 2 * at.hidden;
+                    st.in = {qkv, qkv, qkv, at.mask.empty() ? -1 : id_of(at.mask)};
+                } else {
+                    st.in = {id_of(at.q), id_of(at.k), id_of(at.v), at.mask.empty() ? -1 : id_of(at.mask)};
+                }
+                st.out = {id_of(at.out)};
+                st.run = [op](Context &c, const InputList &in) { return op->run(c, in); };
+                steps_.push_back(std::move(st));
+                continue;
+            }
             if (dead[i]) continue;
             const onnx::Node &n = m.nodes[i];
             if (!n.domain.empty() && n.domain != "ai.onnx") throw GraphError("node " + n.name + ": operator domain " + n.domain + " is not supported");
@@ -802,6 +949,25 @@ class Graph {
                     const Tensor *bias = in[2];
                     if (bias && bias->len() != require(in, 1).size(require(in, 1).ndim() - 1)) throw OpError(OpError::IncompatibleInputShapes, "Cannot broadcast bias to output shape");
                     return op->run(c, in);
+                };
+            } else if (n.op_type == "Add" && opt_.fuse && sole_user(out_name, "LayerNormalization") >= 0 &&
+                       m.nodes[(size_t)sole_user(out_name, "LayerNormalization")].get_int("axis", -1) == -1 &&
+                       m.nodes[(size_t)sole_user(out_name, "LayerNormalization")].inputs[0] == out_name) {
+                // Add(residual) -> LayerNormalization(last axis) as one kernel
+                const long ln = sole_user(out_name, "LayerNormalization");
+                const onnx::Node &lnn = m.nodes[(size_t)ln];
+                auto fused = std::make_shared<AddLayerNormalization>();
+                fused->epsilon = lnn.get_float("epsilon", 1e-5f);
+                auto plain = std::make_shared<LayerNormalization>();
+                plain->epsilon = fused->epsilon;
+                dead[(size_t)ln] = true; fused_away_++; out_name = lnn.outputs[0]; st.pos = (size_t)ln;
+                st.in.push_back(id_of(lnn.inputs.at(1)));
+                st.in.push_back(lnn.inputs.size() > 2 ? id_of(lnn.inputs[2]) : -1);
+                st.kind_name = "Add+LayerNormalization";
+                st.run = [fused, plain](Context &c, const InputList &in) {
+                    if (require(in, 0).shape() == require(in, 1).shape()) return fused->run(c, in);
+                    OutputList sum = Add().run(c, {in[0], in[1]}); // broadcasting Add: separate kernels
+                    return plain->run(c, {&sum[0], in[2], in[3]});
                 };
             } else if (n.op_type == "Add" && opt_.fuse && sole_user(out_name, "Softmax") >= 0 &&
                        m.nodes[(size_t)sole_user(out_name, "Softmax")].get_int("axis", -1) == -1) {

@@ -737,6 +737,75 @@ struct AddSoftmax : Operator {
     }
 };
 
+// Multi-head scaled dot-product attention over projection outputs laid out [B, S, heads * d] (head = column block): the
+// Reshape / Transpose nodes around QK^T -> softmax -> PV become stride arithmetic (TransposeFusion's analogue,
+// src/optimize/fusions.rs:1066; the core is sdpa_multi_head, src/ops/attention.rs:589-626).  Inputs q, k, v (+ additive mask
+// [B,1,1,T] or [B,1,S,T]); q / k / v may be column blocks of one wider buffer: pass `row_stride` / `col_offset` views via
+// the *_rs, *_off fields (elements).
+struct MultiHeadSdpa : Operator {
+    int heads = 1;
+    float scale = 1.f;
+    bool flush_nans_to_zero = false; // the FusedMatMul -> AddSoftmax -> MatMul graph does not flush; sdpa_head does (attention.rs:551)
+    int64_t q_rs = 0, k_rs = 0, v_rs = 0;    // row strides (0: the tensor's own last dim)
+    int64_t q_off = 0, k_off = 0, v_off = 0; // column offsets into the rows
+    int64_t width = 0;                       // heads * d when q / k / v are column blocks of wider rows (0: last dim)
+    const char *name() const override { return "MultiHeadSdpa"; }
+    int max_inputs() const override { return 4; }
+    OutputList run(Context &ctx, const InputList &in) const override {
+        const Tensor &q = want(require(in, 0), DType::F32, "float32"), &k = want(require(in, 1), DType::F32, "float32"), &v = want(require(in, 2), DType::F32, "float32");
+        const Tensor *mask = get(in, 3);
+        if (q.ndim() != 3 || k.ndim() != 3 || v.ndim() != 3) throw OpError(OpError::InvalidValue, "expected [batch, seq, hidden] projections");
+        const int64_t B = q.size(0), S = q.size(1), T = k.size(1);
+        const int64_t Hd = width ? width : q.size(2);
+        if (heads <= 0 || Hd % heads != 0) throw OpError(OpError::InvalidValue, "hidden size is not divisible by the number of heads");
+        if (k.size(0) != B || v.size(0) != B || v.size(1) != T) throw OpError(OpError::IncompatibleInputShapes, "q / k / v batch or sequence sizes do not match");
+        const int64_t d = Hd / heads;
+        rten_hip_sdpa_desc sd{};
+        sd.batch = (int)B; sd.heads = heads; sd.s = (int)S; sd.t = (int)T; sd.d = (int)d; sd.dv = (int)d;
+        sd.q_rs = q_rs ? q_rs : q.size(2); sd.k_rs = k_rs ? k_rs : k.size(2); sd.v_rs = v_rs ? v_rs : v.size(2);
+        sd.q_bs = S * sd.q_rs; sd.k_bs = T * sd.k_rs; sd.v_bs = T * sd.v_rs;
+        sd.q_hs = sd.k_hs = sd.v_hs = d;
+        sd.o_rs = Hd; sd.o_bs = S * Hd; sd.o_hs = d;
+        sd.scale = scale; sd.flush_nan_to_zero = flush_nans_to_zero ? 1 : 0;
+        if (mask) {
+            if (mask->ndim() == 4 && mask->size(0) == B && mask->size(1) == 1 && mask->size(3) == T && (mask->size(2) == 1 || mask->size(2) == S)) {
+                sd.mask_row_stride = mask->size(2) == 1 ? 0 : T;
+                sd.mask_batch_stride = mask->size(2) == 1 ? T : S * T;
+            } else throw OpError(OpError::IncompatibleInputShapes, "attention mask must be [B, 1, 1, T] or [B, 1, S, T]");
+        }
+        Tensor y(ctx, {B, S, Hd}, DType::F32);
+        if (y.len())
+            ctx.check(rten_hip_sdpa_f32(ctx.raw(), &sd, (const float *)q.ptr() + q_off, (const float *)k.ptr() + k_off, (const float *)v.ptr() + v_off,
+                                        (const float *)vp(mask), (float *)y.ptr()));
+        OutputList out;
+        out.push_back(std::move(y));
+        return out;
+    }
+};
+
+// Add(residual) -> LayerNormalization as one kernel (the sum is formed in registers in the reference's order: x + r).
+struct AddLayerNormalization : Operator {
+    float epsilon = 1e-5f;
+    const char *name() const override { return "AddLayerNormalization"; }
+    int max_inputs() const override { return 4; }
+    OutputList run(Context &ctx, const InputList &in) const override {
+        const Tensor &x = want(require(in, 0), DType::F32, "float32"), &r = want(require(in, 1), DType::F32, "float32");
+        const Tensor &scale = want(require(in, 2), DType::F32, "float32");
+        const Tensor *bias = get(in, 3);
+        if (x.shape() != r.shape()) throw OpError(OpError::IncompatibleInputShapes, "Cannot broadcast inputs to same shape");
+        const int64_t cols = x.ndim() ? x.size(x.ndim() - 1) : 1, rows = cols ? x.len() / cols : 0;
+        if (scale.len() != cols) throw OpError(OpError::IncompatibleInputShapes, "Cannot broadcast scale to input shape");
+        if (bias && bias->len() != cols) throw OpError(OpError::IncompatibleInputShapes, "Cannot broadcast bias to input shape");
+        Tensor y(ctx, x.shape(), DType::F32);
+        if (x.len())
+            ctx.check(rten_hip_add_layer_norm_f32(ctx.raw(), rows, (int)cols, (const float *)x.ptr(), (const float *)r.ptr(), (const float *)scale.ptr(), (const float *)vp(bias), 1.f,
+                                                  0.f, epsilon, (float *)y.ptr()));
+        OutputList out;
+        out.push_back(std::move(y));
+        return out;
+    }
+};
+
 // ------------------------------------------------------------------------------------------------ pooling
 struct PoolBase : Operator {
     std::vector<int> kernel_size{1, 1}, strides{1, 1};

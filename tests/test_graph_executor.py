@@ -172,6 +172,35 @@ def test_resnet50_int8_onnx_graph_bit_exact(tmp_path):
 
 
 @pytest.mark.gpu
+def test_bert_base_layer_onnx_graph_bit_exact(tmp_path):
+    """One BERT-base layer (hidden 768, 12 heads x 64, 128 tokens): the attention pattern runs as the fused single-kernel
+    sdpa over the column blocks of one QKV GEMM."""
+    from oracle import models as om
+    from rten_amd import onnx_writer as ow
+    from rten_amd.models import bert
+    cfg = bert.BertConfig(layers=1, vocab=1000, max_pos=128)
+    w = bert.make_weights(cfg)
+    B, S = 2, 128
+    rng = np.random.default_rng(9)
+    ids = rng.integers(0, cfg.vocab, (B, S)).astype(np.int32)
+    tts = np.zeros((B, S), np.int32)
+    mask = np.ones((B, S), np.int32)
+    mask[1, 100:] = 0
+    want = om.bert_forward(cfg, w, ids, mask, tts)
+    p = tmp_path / "bert.onnx"
+    p.write_bytes(ow.bert_encoder(cfg, w, S))
+    args = ["-s", f"batch={B}", "--dump", f"last_hidden_state={tmp_path / 'y.bin'}", "-t"]
+    for name, arr in (("input_ids", ids), ("token_type_ids", tts), ("attention_mask", mask)):
+        arr.tofile(tmp_path / (name + ".bin"))
+        args += ["--input", f"{name}={tmp_path / (name + '.bin')}"]
+    r = run_cli(*args, str(p))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "MultiHeadSdpa(QKV column blocks)" in r.stdout and "FusedMatMul+Gelu" in r.stdout and "Add+LayerNormalization" in r.stdout
+    got = np.fromfile(tmp_path / "y.bin", np.float32)
+    assert np.array_equal(got.view(np.int32), want.ravel().view(np.int32))
+
+
+@pytest.mark.gpu
 def test_bert_encoder_onnx_graph_bit_exact(tmp_path):
     """Transformer graph as an exporter writes it (separate Q/K/V MatMul + Add, Reshape / Transpose around the attention
     MatMuls, Div by sqrt(d), Add(mask) -> Softmax, LayerNormalization, Gelu): bit-identical to the oracle's encoder."""
