@@ -706,3 +706,48 @@ def test_bert_encoder_bit_exact(ctx):
         net.graph = None
         net.autotune(reps=1)  # per-shape tile variants leave the bits unchanged
         bits_equal(net.forward().numpy(), want)
+
+
+def test_layout_and_broadcast_ops_bit_exact(ctx):
+    """Transpose / general broadcasting / Sub / Div (src/ops/layout.rs, binary_elementwise.rs): pure data movement and
+    single IEEE operations, so numpy is the exact reference."""
+    rng = ref.XorShiftRng(21)
+    i64 = lambda v: (C.c_int64 * len(v))(*v)
+    x = (rng.f32(3 * 4 * 5 * 7) - 0.5).reshape(3, 4, 5, 7)
+    xd = dev(ctx, x)
+    for perm in ((0, 2, 1, 3), (0, 2, 3, 1), (3, 2, 1, 0), (0, 1, 2, 3), (1, 0, 3, 2)):
+        want = np.ascontiguousarray(x.transpose(perm))
+        out = DeviceTensor(ctx, want.shape, np.float32)
+        ctx.call("rten_hip_transpose_b32", 4, i64(x.shape), (C.c_int32 * 4)(*perm), xd.vp, out.vp)
+        bits_equal(out.numpy(), want)
+    with pytest.raises(L.HipError, match="Permutation is invalid"):
+        ctx.call("rten_hip_transpose_b32", 4, i64(x.shape), (C.c_int32 * 4)(0, 1, 1, 3), xd.vp, xd.vp)
+    # flat forms: equal shapes and trailing-dims broadcast
+    y = (rng.f32(x.size) - 0.5).reshape(x.shape) + 2.0
+    yd, out = dev(ctx, y), DeviceTensor(ctx, x.shape, np.float32)
+    for name, fn in (("rten_hip_sub_f32", np.subtract), ("rten_hip_div_f32", np.divide)):
+        ctx.call(name, x.size, xd.vp, yd.vp, y.size, out.vp)
+        bits_equal(out.numpy(), fn(x, y))
+        row = dev(ctx, y[0, 0, 0])
+        ctx.call(name, x.size, xd.vp, row.vp, 7, out.vp)
+        bits_equal(out.numpy(), fn(x, y[0, 0, 0]))
+    # general broadcasting: scalar on the left, [B,1,1,T] masks, middle-axis broadcast
+    cases = [(np.float32(1.0).reshape(()), x), (x, (rng.f32(3 * 7) - 0.5).reshape(3, 1, 1, 7)), ((rng.f32(4 * 5) + 1).reshape(4, 5, 1), x),
+             ((rng.f32(5) + 1).reshape(5, 1), (rng.f32(3 * 7)).reshape(3, 1, 1, 7))]
+    for a, b in cases:
+        a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+        oshape = np.broadcast_shapes(a.shape, b.shape)
+        nd = len(oshape)
+
+        def strides(t):
+            s, acc, shp = [0] * nd, 1, (1,) * (nd - t.ndim) + t.shape
+            for i in range(nd - 1, -1, -1):
+                s[i] = 0 if shp[i] == 1 else acc
+                acc *= shp[i]
+            return s
+        ad, bd = dev(ctx, a.reshape(-1) if a.ndim else a.reshape(1)), dev(ctx, b.reshape(-1) if b.ndim else b.reshape(1))
+        out = DeviceTensor(ctx, oshape, np.float32)
+        for op, fn in enumerate((np.add, np.multiply, np.subtract, np.divide)):
+            ctx.call("rten_hip_binary_broadcast_f32", op, nd, i64(oshape), i64(strides(a)), i64(strides(b)), ad.vp, bd.vp, out.vp)
+            with np.errstate(all="ignore"):
+                bits_equal(out.numpy(), fn(a, b).astype(np.float32))
