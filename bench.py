@@ -257,7 +257,7 @@ def main():
 
     if rank == 0 and roof:
         # HBM bytes per launch of the dominant kernel from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, collected separately by
-        # tools_gpu_traffic.sh over the same tuned plan -- counters cannot be collected inside the timed run)
+        # tools/gpu/traffic.sh over the same tuned plan -- counters cannot be collected inside the timed run)
         import glob
         for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*", "hbm_traffic_per_kernel.json")), reverse=True):
             t = json.load(open(path)).get("kernels", {}).get(roof["kernel"].replace(" ", ""))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes (separate runs per counter set; kernel-trace only, no sys/hip traces) over isolated layers.
-# Usage: tools_gpu_pmc.sh <tag> <layers> <variants|-> [plan.json]
+# Usage: tools/gpu/pmc.sh <tag> <layers> <variants|-> [plan.json]
 TAG=${1:-pmc}
 LAYERS=${2:-s0b0c2,s0b0c3,s2b1c1,s2b1c2,s3b1c2}
 VARS=${3:-0,3}

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Shorter GPU session: GPU parity tests + bench with the per-layer table (no rocprof).
-# Usage: gpurun --timeout 1500 -- 'bash tools_gpu_quick.sh <tag> [pytest -k expr]'
+# Usage: gpurun --timeout 1500 -- 'bash tools/gpu/quick.sh <tag> [pytest -k expr]'
 TAG=${1:-q}
 KEXPR=${2:-}
 mkdir -p gpurun_out

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session: smoke, GPU parity tests, bench (with per-layer table), rocprof kernel stats.
-# Usage: gpurun --timeout 2400 -- 'bash tools_gpu_round.sh [tag]'
+# Usage: gpurun --timeout 2400 -- 'bash tools/gpu/round.sh [tag]'
 TAG=${1:-r01}
 R=$(pwd)
 mkdir -p gpurun_out

@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM traffic per kernel of the bench workload: two PMC passes (FETCH_SIZE, WRITE_SIZE) over an eager replay of a tuned plan.
-# Usage: tools_gpu_traffic.sh <tag> <plan.json (tracked path)>
+# Usage: tools/gpu/traffic.sh <tag> <plan.json (tracked path)>
 TAG=${1:-traffic}
 PLAN=${2:-profiles/r02/plan.json}
 R=$(pwd)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise tools_gpu_pmc.sh output: the LAST `reps` dispatches of every igemm kernel per probed layer.
+"""Summarise tools/gpu/pmc.sh output: the LAST `reps` dispatches of every igemm kernel per probed layer.
 usage: pmc_summary.py gpurun_out/<tag> [reps=3]   (reads <tag>_sq1, _sq2, _fetch, _write)"""
 import csv, sys, collections, re
 tag = sys.argv[1]; reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
