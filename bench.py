@@ -103,6 +103,26 @@ def cpu_op_baselines():
     return out
 
 
+def secondary_configs():
+    """The other single-GPU configs of BASELINE.json, measured by their own harnesses in child processes after the headline
+    run (same backend, same box): reported for the record, never part of `value`.  A failure is recorded, not raised."""
+    import subprocess
+    root = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+    for key, script in (("resnet50_int8_b32", "bench_resnet50_int8.py"), ("bert_base_f32_b32_s128", "bench_bert.py")):
+        try:
+            p = subprocess.run([sys.executable, os.path.join(root, "tools", script)], capture_output=True, text=True, timeout=420, cwd=root)
+            line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+            j = json.loads(line)
+            res[key] = {k: j[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype") if k in j}
+            if key.startswith("bert") and "roofline" in j:
+                res[key]["gemm_family_tflops"] = j["roofline"].get("achieved")
+                res[key]["gemm_family_frac_of_f32_mfma_peak"] = j["roofline"].get("frac")
+        except Exception as e:  # noqa: BLE001
+            res[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,6 +134,7 @@ def main():
     ap.add_argument("--layer-table", action="store_true", help="print the per-layer autotune table to stderr")
     ap.add_argument("--save-plan", default=None, help="write the autotuned per-layer plans (variant, split mode, groups) as JSON")
     ap.add_argument("--load-plan", default=None, help="use per-layer plans from a JSON file instead of autotuning (profiling runs)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of BASELINE configs[2] (int8 ResNet-50) and configs[3] (BERT-base) reported under \"secondary\"")
     ap.add_argument("--concurrent", action="store_true", help="run the projection shortcuts on a second stream (parallel graph branches)")
     args = ap.parse_args()
 
@@ -285,6 +306,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(net.specs, weights)
         else:
             out["cpu_baseline"] = None
+        if n_gpus == 1 and world == 1 and not args.no_secondary:
+            out["secondary"] = secondary_configs()
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${TAG}_smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/${TAG}_smoke.log
 timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest_gpu.log
 timeout 900 python bench.py --layer-table --save-plan gpurun_out/${TAG}_plan.json > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$?" >> gpurun_out/${TAG}_bench.err
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_prof -o ${TAG} -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --load-plan $R/gpurun_out/${TAG}_plan.json > $R/gpurun_out/${TAG}_prof_bench.json 2> $R/gpurun_out/${TAG}_prof.err; echo "rocprof rc=$?" >> $R/gpurun_out/${TAG}_prof.err
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_prof -o ${TAG} -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --load-plan $R/gpurun_out/${TAG}_plan.json > $R/gpurun_out/${TAG}_prof_bench.json 2> $R/gpurun_out/${TAG}_prof.err; echo "rocprof rc=$?" >> $R/gpurun_out/${TAG}_prof.err
 cd $R
 (rocprofv3 -L 2>/dev/null | grep -E "^\s*(Name|Counter_Name|gpu|  *[A-Z_0-9]+)" | head -400) > gpurun_out/${TAG}_counters.txt 2>&1
 find gpurun_out/${TAG}_prof -name "*stats*" | head; du -sh gpurun_out

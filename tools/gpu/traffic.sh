@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/${TAG}_$c -o t -- python $R/bench.py --load-plan $R/$PLAN --no-graph --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/${TAG}_$c.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/${TAG}_$c -o t -- python $R/bench.py --load-plan $R/$PLAN --no-graph --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $R/gpurun_out/${TAG}_$c.log 2>&1
   echo "$c rc=$?"
 done
 cd $R
