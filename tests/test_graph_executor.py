@@ -18,7 +18,7 @@ def build_cli():
     from rten_amd import lib as L
     L.load()  # raises if librten_hip.so is missing
     src = os.path.join(ROOT, "tools", "rten_hip_run.cpp")
-    deps = [src] + [os.path.join(ROOT, "include", h) for h in ("rten_hip_graph.hpp", "rten_hip_ops.hpp", "rten_hip.h")]
+    deps = [src] + [os.path.join(ROOT, "include", h) for h in ("rten_hip_graph.hpp", "rten_hip_ops.hpp", "rten_hip_safetensors.hpp", "rten_hip.h")]
     os.makedirs(os.path.dirname(BIN), exist_ok=True)
     if not os.path.exists(BIN) or os.path.getmtime(BIN) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), src, "-o", BIN,
@@ -232,3 +232,50 @@ def test_bert_encoder_onnx_graph_bit_exact(tmp_path):
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
         got = np.fromfile(yout, np.float32)
         assert np.array_equal(got.view(np.int32), want.ravel().view(np.int32)), extra
+
+
+def test_safetensors_reader_writer_roundtrip(tmp_path):
+    """The golden-exchange format of `rten-cli --inputs / --check-outputs`: files written by the safetensors package are read
+    by the C++ reader, re-written by the C++ writer, and load back identically."""
+    from safetensors.numpy import load_file, save_file
+    rng = np.random.default_rng(2)
+    tensors = {"x": rng.random((2, 3, 4), dtype=np.float32), "ids": rng.integers(-5, 5, (2, 7)).astype(np.int64), "q": rng.integers(0, 255, (5,)).astype(np.uint8),
+               "scalar": np.array(3.5, np.float32)}
+    src, dst = tmp_path / "a.safetensors", tmp_path / "b.safetensors"
+    save_file(tensors, str(src), metadata={"note": "golden \"inputs\""})
+    out = run_cli("--safetensors-info", str(src), "--save-outputs", str(dst))
+    assert out.returncode == 0, out.stderr
+    assert "x: F32 [2, 3, 4]" in out.stdout and "ids: I64 [2, 7]" in out.stdout and "scalar: F32 []" in out.stdout
+    back = load_file(str(dst))
+    assert set(back) == set(tensors)
+    for k, v in tensors.items():
+        assert back[k].dtype == v.dtype and back[k].shape == v.shape and np.array_equal(back[k], v)
+    bad = tmp_path / "bad.safetensors"
+    bad.write_bytes(src.read_bytes()[:40])
+    assert run_cli("--safetensors-info", str(bad)).returncode == 1
+
+
+@pytest.mark.gpu
+def test_cli_safetensors_inputs_and_check_outputs(tmp_path):
+    """`rten_hip_run -i inputs.safetensors --check-outputs expected.safetensors` (the rten-cli golden workflow)."""
+    from oracle import ref
+    from rten_amd import onnx_writer as ow
+    from safetensors.numpy import load_file, save_file
+    m, w = ow.small_cnn_f32()
+    x = np.random.default_rng(3).random((3, 3, 16, 16), dtype=np.float32) - 0.5
+    a = ref.conv2d_f32(x, w["c1"][0], w["c1"][1], pads=(1, 1, 1, 1), strides=(2, 2), relu=True)
+    p = ref.max_pool(a, (2, 2), (2, 2))
+    s = ref.conv2d_f32(p, w["c2"][0], w["c2"][1], residual=p, relu=True)
+    g = ref.global_average_pool(s).reshape(3, -1)
+    want = ref.gemm_f32(g, w["fc"][0].T, c=np.broadcast_to(w["fc"][1], (3, 5)).astype(np.float32), alpha=1.0, beta=1.0)
+    model, fin, fexp, fout = tmp_path / "m.onnx", tmp_path / "in.safetensors", tmp_path / "exp.safetensors", tmp_path / "out.safetensors"
+    model.write_bytes(m)
+    save_file({"x": x}, str(fin))
+    save_file({"y": want}, str(fexp))
+    r = run_cli("-i", str(fin), "--check-outputs", str(fexp), "--max-diff", "0", "--save-outputs", str(fout), str(model))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert 'Output "y" vs expected: max diff 0.000000 (0 of 15 elements differ in their bits)' in r.stdout
+    assert np.array_equal(load_file(str(fout))["y"], want)
+    save_file({"y": want + np.float32(0.01)}, str(fexp))
+    r = run_cli("-i", str(fin), "--check-outputs", str(fexp), "--max-diff", "1e-6", str(model))
+    assert r.returncode == 3 and "max diff 0.01" in r.stdout
