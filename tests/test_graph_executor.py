@@ -167,8 +167,12 @@ def test_resnet50_int8_onnx_graph_bit_exact(tmp_path):
     x = np.random.default_rng(1234).random((2, 3, 224, 224), dtype=np.float32)
     want = om.resnet50_int8_forward(resnet50.conv_specs(), om.quantize_weights_int8(w), x)
     got, log = _run_model(tmp_path, ow.resnet50_int8(w), x, "logits")
-    assert "ConvInteger x53" in log
+    assert "ConvInteger x53" in log and "49 DynamicQuantizeLinear write the staged layout directly" in log
     assert np.array_equal(got.view(np.int32), want.ravel().view(np.int32))
+    # node by node (ConvInteger, Cast, Mul, Add([1,O,1,1] broadcast), Add, Relu as separate kernels): the same arithmetic
+    got2, log2 = _run_model(tmp_path, ow.resnet50_int8(w), x, "logits", "--no-fuse")
+    assert "Plan: 388 steps (0 nodes folded" in log2
+    assert np.array_equal(got2.view(np.int32), want.ravel().view(np.int32))
 
 
 @pytest.mark.gpu
