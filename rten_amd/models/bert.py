@@ -97,16 +97,19 @@ class Bert:
 
     def _linear(self, x, w, b, out, n, k, act=L.ACT_NONE):
         d = L.gemm_desc(self.B * self.S, n, k, k, 1, n, 1, n, bias_kind=L.BIAS_PER_COL, act=act)
-        v = self.variants.get((n, k))
-        if v is not None:
+        plan = self.variants.get((n, k))
+        if plan is not None:
+            v, order = plan if isinstance(plan, (tuple, list)) else (plan, 0)
             self.ctx.set_gemm_variant(v)
+            self.ctx.call("rten_hip_set_gemm_order", order)
         self.ctx.call("rten_hip_gemm_f32", C.byref(d), x.vp, w.vp, b.vp, out.vp)
-        if v is not None:
+        if plan is not None:
             self.ctx.set_gemm_variant(-1)
+            self.ctx.call("rten_hip_set_gemm_order", 0)
 
     def autotune(self, reps=3):
-        """Pick the fastest GEMM tile variant per distinct projection shape by measurement (load-time, like the reference
-        picks kernels per ISA at start-up, rten-gemm/src/lib.rs:534-547).  Returns {(n, k): [(variant, ms), ...]}."""
+        """Pick the fastest (GEMM tile variant, tile order) per distinct projection shape by measurement (load-time, like the
+        reference picks kernels per ISA at start-up, rten-gemm/src/lib.rs:534-547).  Returns {(n, k): [((variant, order), ms), ...]}."""
         ctx, cfg, H = self.ctx, self.cfg, self.cfg.hidden
         lw = self.dl[0]
         shapes = {(3 * H, H): (self.x, lw["wqkv"], lw["bqkv"], self.qkv, L.ACT_NONE), (H, H): (self.att, lw["wo"], lw["bo"], self.tmp, L.ACT_NONE),
@@ -114,7 +117,9 @@ class Bert:
         table = {}
         for (n, k), (x, w, b, out, act) in shapes.items():
             row = []
-            for v in (0, 1, 2, 3, 12, 13, 14, 15):  # LDS-DMA pipeline, three / four stages (row-major A)
+            # LDS-DMA pipeline, three / four stages (row-major A) x tile order (m fastest / n fastest within an XCD's share:
+            # which operand stays L2-resident)
+            for v in [(v, o) for v in (0, 1, 2, 3, 12, 13, 14, 15) for o in (0, 1)]:
                 self.variants[(n, k)] = v
                 self._linear(x, w, b, out, n, k, act)
                 ms = 1e30
