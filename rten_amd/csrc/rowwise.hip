@@ -14,6 +14,8 @@
 // masked tail, and the 16 lane totals are added sequentially.  Results are therefore bit-identical to
 // the reference running on an AVX-512 host (and to oracle lanes=16); hosts with another SIMD width
 // differ by reduction-order rounding only (tolerance in DESIGN.md).
+#include <type_traits>
+
 #include "internal.h"
 #include "vecmath.h"
 
@@ -54,57 +56,145 @@ __device__ __forceinline__ float simd16_reduce(Get get, int n, float off, int la
 // Softmax: max (f32::MIN start), e = ReducedRangeExp(x - max), sum in single-accumulator 16-lane order
 // (softmax.rs:194-228), y = e * (1 / sum), optional NaN -> 0.
 // ------------------------------------------------------------------------------------------------
-template <int CH>
+// One wave per row, R consecutive rows per wave: short rows (128 columns = 2 elements per lane) are latency-bound on the
+// load -> max -> exp -> sum -> scale chain, so a wave keeps R independent chains in flight (all loads first).
+template <int CH, int R>
 __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void softmax_kernel(int64_t rows, int cols, const float *__restrict__ x,
                                                                       const float *__restrict__ addend, int64_t add_div,
                                                                       int64_t add_mod, int flush_nan,
                                                                       float *__restrict__ y) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const float *xr = x + row * cols;
-    const float *ar = addend ? addend + ((row / add_div) % add_mod) * cols : nullptr;
-    float v[CH];
-    float mx = -3.40282347e+38f; // f32::MIN (softmax.rs:181)
+    const int64_t row0 = ((int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6)) * R;
+    if (row0 >= rows) return;
+    float v[R][CH];
+    float mx[R];
 #pragma unroll
-    for (int c = 0; c < CH; c++) {
-        const int i = c * 64 + lane;
-        float t = -3.40282347e+38f;
-        if (i < cols) {
-            t = xr[i];
-            if (ar) t = t + ar[i]; // `*qk += m` (attention.rs:59-61)
-            mx = fmaxf(mx, t);
+    for (int r = 0; r < R; r++) {
+        const int64_t row = row0 + r < rows ? row0 + r : rows - 1; // clamped: the tail rows of the last wave recompute the last row
+        const float *xr = x + row * cols;
+        const float *ar = addend ? addend + ((row / add_div) % add_mod) * cols : nullptr;
+        mx[r] = -3.40282347e+38f; // f32::MIN (softmax.rs:181)
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const int i = c * 64 + lane;
+            float t = -3.40282347e+38f;
+            if (i < cols) {
+                t = xr[i];
+                if (ar) t = t + ar[i]; // `*qk += m` (attention.rs:59-61)
+                mx[r] = fmaxf(mx[r], t);
+            }
+            v[r][c] = t;
         }
-        v[c] = t;
     }
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    for (int o = 32; o >= 1; o >>= 1)
+#pragma unroll
+        for (int r = 0; r < R; r++) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], o, 64));
     // exp + 16-lane ordered sum: lane l < 16 adds e[64c + l], e[64c + l + 16], e[64c + l + 32], e[64c + l + 48]
-    float a = 0.f;
+    float a[R];
     const int l = lane & 15;
 #pragma unroll
-    for (int c = 0; c < CH; c++) {
-        const int i = c * 64 + lane;
-        const float e = i < cols ? vm::exp_reduced(v[c] - mx) : 0.f;
-        v[c] = e;
+    for (int r = 0; r < R; r++) {
+        a[r] = 0.f;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float eq = lane_bcast(e, l + 16 * q);
-            if (c * 64 + l + 16 * q < cols) a = a + eq;
+        for (int c = 0; c < CH; c++) {
+            const int i = c * 64 + lane;
+            const float e = i < cols ? vm::exp_reduced(v[r][c] - mx[r]) : 0.f;
+            v[r][c] = e;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float eq = lane_bcast(e, l + 16 * q);
+                if (c * 64 + l + 16 * q < cols) a[r] = a[r] + eq;
+            }
         }
     }
-    float s = 0.f;
+    float inv[R];
 #pragma unroll
-    for (int k = 0; k < 16; k++) s = s + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), k));
+    for (int r = 0; r < R; r++) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) s = s + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a[r]), k));
+        inv[r] = 1.0f / s;
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        if (row0 + r >= rows) break;
+        float *yr = y + (row0 + r) * cols;
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const int i = c * 64 + lane;
+            if (i < cols) {
+                float o = v[r][c] * inv[r];
+                if (flush_nan && !(o == o)) o = 0.f;
+                yr[i] = o;
+            }
+        }
+    }
+}
+
+// Short rows (<= 256 columns): FOUR rows per wave, one per 16-lane DPP row.  Lane l of a row owns elements l, l + 16,
+// l + 32, ... -- exactly the elements the reference's 16-lane accumulator lane l adds, in the order it adds them
+// (softmax.rs:194-228), so the partial sums need no cross-lane traffic at all; the row maximum is 4 DPP steps, and the final
+// in-order sum of the 16 partials is a 15-step DPP shift-and-add chain (lane 15 ends with ((a0 + a1) + a2) + ... + a15) shared
+// by the four rows.  The wave-per-row kernel above spends ~30 LDS-crossbar / readlane operations per row on the same thing.
+template <int EPL>
+__global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void softmax_rows16_kernel(int64_t rows, int cols, const float *__restrict__ x,
+                                                                             const float *__restrict__ addend, int64_t add_div,
+                                                                             int64_t add_mod, int flush_nan,
+                                                                             float *__restrict__ y) {
+    const int lane = threadIdx.x & 63, l = lane & 15;
+    const int64_t row = ((int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const bool live = row < rows;
+    const int64_t rr = live ? row : rows - 1;
+    const float *xr = x + rr * cols;
+    const float *ar = addend ? addend + ((rr / add_div) % add_mod) * cols : nullptr;
+    float v[EPL];
+    float mx = -3.40282347e+38f; // f32::MIN (softmax.rs:181)
+#pragma unroll
+    for (int j = 0; j < EPL; j++) {
+        const int i = l + 16 * j;
+        v[j] = xr[i < cols ? i : 0];
+    }
+    if (ar) {
+#pragma unroll
+        for (int j = 0; j < EPL; j++) {
+            const int i = l + 16 * j;
+            v[j] = v[j] + ar[i < cols ? i : 0]; // `*qk += m` (attention.rs:59-61)
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < EPL; j++) {
+        if (l + 16 * j >= cols) v[j] = -3.40282347e+38f;
+        mx = fmaxf(mx, v[j]);
+    }
+    // max over the 16 lanes of the row: quad xor 1, quad xor 2, row rotate 4, row rotate 8
+    auto dpp = [](float f, auto ctrl) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(f), decltype(ctrl)::value, 0xf, 0xf, true)); };
+    mx = fmaxf(mx, dpp(mx, std::integral_constant<int, 0xB1>()));
+    mx = fmaxf(mx, dpp(mx, std::integral_constant<int, 0x4E>()));
+    mx = fmaxf(mx, dpp(mx, std::integral_constant<int, 0x124>()));
+    mx = fmaxf(mx, dpp(mx, std::integral_constant<int, 0x128>()));
+    float a = 0.f;
+#pragma unroll
+    for (int j = 0; j < EPL; j++) {
+        const float e = l + 16 * j < cols ? vm::exp_reduced(v[j] - mx) : 0.f;
+        v[j] = e;
+        if (l + 16 * j < cols) a = a + e;
+    }
+    // s = ((0 + a0) + a1) + ... + a15 in lane 15: shift right by one lane within the row (lane 0 receives 0), add own partial
+    float acc = a;
+#pragma unroll
+    for (int k = 1; k < 16; k++) acc = dpp(acc, std::integral_constant<int, 0x111>()) + a;
+    const float s = __int_as_float(__builtin_amdgcn_ds_bpermute((lane | 15) << 2, __float_as_int(acc)));
     const float inv = 1.0f / s;
+    if (!live) return;
     float *yr = y + row * cols;
 #pragma unroll
-    for (int c = 0; c < CH; c++) {
-        const int i = c * 64 + lane;
+    for (int j = 0; j < EPL; j++) {
+        const int i = l + 16 * j;
         if (i < cols) {
-            float r = v[c] * inv;
-            if (flush_nan && !(r == r)) r = 0.f;
-            yr[i] = r;
+            float o = v[j] * inv;
+            if (flush_nan && !(o == o)) o = 0.f;
+            yr[i] = o;
         }
     }
 }
@@ -302,18 +392,22 @@ RTEN_EXPORT int32_t rten_hip_softmax_f32(rten_hip_ctx *ctx, int64_t rows, int32_
     if (addend && (add_div <= 0 || add_mod <= 0))
         return rten_set_error(ctx, RTEN_HIP_ERR_INCOMPATIBLE_SHAPES, "Cannot broadcast inputs");
     if (!addend) { add_div = 1; add_mod = 1; }
-    const dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(64 * ROWS_PER_BLOCK);
+    const dim3 block(64 * ROWS_PER_BLOCK);
+    auto grid_for = [&](int r) { return dim3((unsigned)((rows + (int64_t)ROWS_PER_BLOCK * r - 1) / ((int64_t)ROWS_PER_BLOCK * r))); };
+    const dim3 grid = grid_for(1);
     ProfScope ps(ctx, "softmax_f32", 0.0, 8.0 * rows * cols);
-#define SM_LAUNCH(CH) hipLaunchKernelGGL((softmax_kernel<CH>), grid, block, 0, ctx->stream, rows, cols, x, addend, add_div, add_mod, flush_nan_to_zero, y)
-    if (cols <= 64) SM_LAUNCH(1);
-    else if (cols <= 128) SM_LAUNCH(2);
-    else if (cols <= 256) SM_LAUNCH(4);
-    else if (cols <= 512) SM_LAUNCH(8);
-    else if (cols <= 1024) SM_LAUNCH(16);
+#define SM_LAUNCH(CH, R) hipLaunchKernelGGL((softmax_kernel<CH, R>), grid_for(R), block, 0, ctx->stream, rows, cols, x, addend, add_div, add_mod, flush_nan_to_zero, y)
+#define SM16_LAUNCH(EPL) hipLaunchKernelGGL((softmax_rows16_kernel<EPL>), grid_for(4), block, 0, ctx->stream, rows, cols, x, addend, add_div, add_mod, flush_nan_to_zero, y)
+    if (cols <= 64) SM16_LAUNCH(4);
+    else if (cols <= 128) SM16_LAUNCH(8);
+    else if (cols <= 256) SM16_LAUNCH(16);
+    else if (cols <= 512) SM_LAUNCH(8, 1);
+    else if (cols <= 1024) SM_LAUNCH(16, 1);
     else
         hipLaunchKernelGGL(softmax_long_kernel, grid, block, 0, ctx->stream, rows, cols, x, addend, add_div, add_mod,
                            flush_nan_to_zero, y);
 #undef SM_LAUNCH
+#undef SM16_LAUNCH
     RTEN_LAUNCH_CHECK(ctx, "softmax_kernel");
     return RTEN_HIP_OK;
 }

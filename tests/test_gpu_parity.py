@@ -440,7 +440,7 @@ def test_dql_staged_conv_bit_exact(ctx, pm):
 
 
 # ------------------------------------------------------------------------------------------ row-wise / element-wise / pooling
-@pytest.mark.parametrize("cols", [1, 3, 6, 16, 17, 64, 100, 128, 129, 384, 768, 1000, 1024, 1500, 3000])
+@pytest.mark.parametrize("cols", [1, 3, 6, 16, 17, 64, 100, 128, 129, 200, 256, 257, 384, 768, 1000, 1024, 1500, 3000])
 def test_softmax_bit_exact_avx512_order(ctx, cols):
     rng = ref.XorShiftRng(cols)
     x = (rng.f32(37 * cols).reshape(37, cols) - 0.5) * 8
