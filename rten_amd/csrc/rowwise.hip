@@ -358,26 +358,32 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void global_avg_pool_kernel(in
     const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float *xr = x + row * inner;
-    float s;
-    if (inner <= 64) {
-        // ResNet's 7x7 map: one load per lane, then the 16-lane partial sums of simd16_reduce built from lane
-        // broadcasts in the same order (chunk q adds element q*16 + l to partial l, masked past the end).
-        const float v = xr[lane < inner ? lane : 0];
-        const int l = lane & 15;
-        float a = 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float e = lane_bcast(v, q * 16 + l);
-            if (q * 16 + l < inner) a = a + e;
-        }
-        s = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; k++) s = s + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), k));
-    } else {
-        auto get = [&](int i) -> float { return xr[i]; };
-        s = simd16_reduce<0>(get, inner, 0.f, lane);
-    }
+    auto get = [&](int i) -> float { return xr[i]; };
+    const float s = simd16_reduce<0>(get, inner, 0.f, lane);
     if (lane == 0) y[row] = s / (float)inner;
+}
+
+// Planes of at most 64 elements (ResNet's 7x7): four planes per wave, one per 16-lane DPP row.  Lane l owns elements l,
+// l + 16, l + 32, l + 48 -- the ones the reference's accumulator lane l adds, in its order -- and the in-order sum of the
+// 16 partials is the DPP shift-and-add chain of softmax_rows16_kernel.
+__global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void global_avg_pool_rows16_kernel(int64_t rows, int inner,
+                                                                                     const float *__restrict__ x,
+                                                                                     float *__restrict__ y) {
+    const int lane = threadIdx.x & 63, l = lane & 15;
+    const int64_t row = ((int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const int64_t rr = row < rows ? row : rows - 1;
+    const float *xr = x + rr * inner;
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) v[q] = xr[l + 16 * q < inner ? l + 16 * q : 0];
+    float a = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (l + 16 * q < inner) a = a + v[q];
+    float acc = a;
+#pragma unroll
+    for (int k = 1; k < 16; k++) acc = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x111, 0xf, 0xf, true)) + a;
+    if (l == 15 && row < rows) y[row] = acc / (float)inner;
 }
 
 } // namespace
@@ -455,7 +461,10 @@ RTEN_EXPORT int32_t rten_hip_global_average_pool_f32(rten_hip_ctx *ctx, int64_t 
     if (!x || !y) return RTEN_HIP_ERR_INVALID_VALUE;
     const dim3 grid((unsigned)((nc + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(64 * ROWS_PER_BLOCK);
     ProfScope ps(ctx, "global_average_pool_f32", 0.0, 4.0 * nc * (inner + 1));
-    hipLaunchKernelGGL(global_avg_pool_kernel, grid, block, 0, ctx->stream, nc, inner, x, y);
+    if (inner <= 64)
+        hipLaunchKernelGGL(global_avg_pool_rows16_kernel, dim3((unsigned)((nc + 4 * ROWS_PER_BLOCK - 1) / (4 * ROWS_PER_BLOCK))), block, 0, ctx->stream, nc, inner, x, y);
+    else
+        hipLaunchKernelGGL(global_avg_pool_kernel, grid, block, 0, ctx->stream, nc, inner, x, y);
     RTEN_LAUNCH_CHECK(ctx, "global_avg_pool_kernel");
     return RTEN_HIP_OK;
 }
