@@ -126,8 +126,8 @@ def secondary_configs():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")

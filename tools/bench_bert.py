@@ -8,8 +8,8 @@ from rten_amd import lib as L  # noqa: E402
 from rten_amd.models import bert  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--steps", type=int, default=10)
-ap.add_argument("--warmup", type=int, default=3)
+ap.add_argument("--steps", type=int, default=30)
+ap.add_argument("--warmup", type=int, default=10)
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--seq", type=int, default=128)
 args = ap.parse_args()

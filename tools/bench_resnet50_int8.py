@@ -8,8 +8,8 @@ from rten_amd import lib as L  # noqa: E402
 from rten_amd.models import resnet50, resnet50_int8  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--steps", type=int, default=20)
-ap.add_argument("--warmup", type=int, default=5)
+ap.add_argument("--steps", type=int, default=50)
+ap.add_argument("--warmup", type=int, default=20)
 ap.add_argument("--batch", type=int, default=32)
 args = ap.parse_args()
 ctx = L.Context(0)
