@@ -161,8 +161,8 @@ def main():
         torch.cuda.set_device(local_rank)
 
     from rten_amd import lib
-    from rten_amd.models import resnet50
-    from rten_amd.parallel import broadcast_weight_arena
+    from rten_amd.workloads import resnet50
+    from rten_amd.sharding import broadcast_weight_arena
 
     ctx = lib.Context(local_rank)  # no CPU fallback: raises if the HIP extension / MI355X is missing
     weights = resnet50.make_weights()

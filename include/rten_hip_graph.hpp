@@ -319,7 +319,7 @@ class Graph {
 
     // Load-time plan selection: one pass over the graph in which every f32 convolution step times its candidate launch
     // plans on its real operands (tile variant x exact split-K plan x tile order, the candidate set of
-    // rten_amd/models/resnet50.py::candidate_plans) and keeps the fastest.  Returns the number of tuned steps.
+    // rten_amd/workloads/resnet50.py::candidate_plans) and keeps the fastest.  Returns the number of tuned steps.
     size_t autotune(const Feeds &feeds, int reps = 3) {
         tune_reps_ = reps;
         tuned_ = 0;

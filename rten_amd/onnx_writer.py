@@ -108,7 +108,7 @@ def model(nodes, inputs, outputs, initializers, opset: int = 17, name: str = "gr
 # ----------------------------------------------------------------------------------------------------------------
 
 def resnet50_f32(weights, batch="batch", image: int = 224) -> bytes:
-    from .models.resnet50 import conv_specs
+    from .workloads.resnet50 import conv_specs
     nodes, inits = [], []
     for l in conv_specs():
         w, b = weights[l["name"]]
@@ -146,7 +146,7 @@ def resnet50_int8(weights, batch="batch", image: int = 224) -> bytes:
         DynamicQuantizeLinear(x) -> ConvInteger(xq, wq, x_zp, w_zp) -> Cast(FLOAT) -> Mul(Mul(x_scale, w_scale)) -> Add(bias [1,O,1,1])
     one DynamicQuantizeLinear per distinct input tensor (the quantiser caches quantised inputs), bias as a separate Add
     (SURVEY 8d config 3), the classifier as MatMulInteger."""
-    from .models.resnet50 import conv_specs
+    from .workloads.resnet50 import conv_specs
     nodes, inits, quantized = [], [], set()
 
     def dql(src):

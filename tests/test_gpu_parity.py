@@ -593,7 +593,7 @@ def test_sdpa_head64_shapes_bit_exact(ctx, path):
 # ------------------------------------------------------------------------------------------ end to end
 def test_resnet50_end_to_end_bit_exact_and_graph_replay(ctx):
     from oracle import models as omodels
-    from rten_amd.models import resnet50
+    from rten_amd.workloads import resnet50
     w = resnet50.make_weights()
     net = resnet50.ResNet50(ctx, batch=2, weights=w)
     net.upload_weights()
@@ -631,7 +631,7 @@ def test_resnet50_end_to_end_bit_exact_and_graph_replay(ctx):
 def test_resnet50_int8_end_to_end_bit_exact(ctx):
     # BASELINE configs[2]: dynamically quantized ResNet-50 (DynamicQuantizeLinear -> ConvIntegerToFloat chain per conv)
     from oracle import models as omodels
-    from rten_amd.models import resnet50, resnet50_int8
+    from rten_amd.workloads import resnet50, resnet50_int8
     w = resnet50.make_weights()
     net = resnet50_int8.ResNet50Int8(ctx, batch=2, weights=w)
     net.upload_weights()
@@ -670,7 +670,7 @@ def test_resnet50_int8_end_to_end_bit_exact(ctx):
 def test_resnet50_batch32_batch_independence(ctx):
     # BASELINE config 2 at full size: every image of a batch-32 run equals the oracle's batch-1 run of that image
     from oracle import models as omodels
-    from rten_amd.models import resnet50
+    from rten_amd.workloads import resnet50
     w = resnet50.make_weights()
     net = resnet50.ResNet50(ctx, batch=32, weights=w)
     net.upload_weights()
@@ -686,7 +686,7 @@ def test_resnet50_batch32_batch_independence(ctx):
 def test_bert_encoder_bit_exact(ctx):
     # BASELINE config 4 topology (reduced width/depth so the oracle finishes in seconds) + one full-width layer
     from oracle import models as omodels
-    from rten_amd.models import bert
+    from rten_amd.workloads import bert
     for cfg, B, S in ((bert.BertConfig(hidden=128, heads=4, layers=2, ffn=256, vocab=1000, max_pos=64), 3, 40),
                       (bert.BertConfig(hidden=768, heads=12, layers=1, ffn=3072, vocab=2000, max_pos=128), 2, 128)):
         w = bert.make_weights(cfg)

@@ -80,7 +80,7 @@ def test_writer_emits_wellformed_protobuf():
 
 def test_cpp_loader_parses_written_models(tmp_path):
     from rten_amd import onnx_writer as ow
-    from rten_amd.models import resnet50
+    from rten_amd.workloads import resnet50
     m, _ = ow.small_cnn_f32()
     p = tmp_path / "small.onnx"
     p.write_bytes(m)
@@ -145,7 +145,7 @@ def test_small_cnn_graph_bit_exact(tmp_path):
 def test_resnet50_f32_onnx_graph_bit_exact(tmp_path):
     from oracle import models as om
     from rten_amd import onnx_writer as ow
-    from rten_amd.models import resnet50
+    from rten_amd.workloads import resnet50
     w = resnet50.make_weights()
     x = np.random.default_rng(1234).random((2, 3, 224, 224), dtype=np.float32)
     want = om.resnet50_forward(resnet50.conv_specs(), w, x)
@@ -162,7 +162,7 @@ def test_resnet50_f32_onnx_graph_bit_exact(tmp_path):
 def test_resnet50_int8_onnx_graph_bit_exact(tmp_path):
     from oracle import models as om
     from rten_amd import onnx_writer as ow
-    from rten_amd.models import resnet50
+    from rten_amd.workloads import resnet50
     w = resnet50.make_weights()
     x = np.random.default_rng(1234).random((2, 3, 224, 224), dtype=np.float32)
     want = om.resnet50_int8_forward(resnet50.conv_specs(), om.quantize_weights_int8(w), x)
@@ -181,7 +181,7 @@ def test_bert_base_layer_onnx_graph_bit_exact(tmp_path):
     sdpa over the column blocks of one QKV GEMM."""
     from oracle import models as om
     from rten_amd import onnx_writer as ow
-    from rten_amd.models import bert
+    from rten_amd.workloads import bert
     cfg = bert.BertConfig(layers=1, vocab=1000, max_pos=128)
     w = bert.make_weights(cfg)
     B, S = 2, 128
@@ -210,7 +210,7 @@ def test_bert_encoder_onnx_graph_bit_exact(tmp_path):
     MatMuls, Div by sqrt(d), Add(mask) -> Softmax, LayerNormalization, Gelu): bit-identical to the oracle's encoder."""
     from oracle import models as om
     from rten_amd import onnx_writer as ow
-    from rten_amd.models import bert
+    from rten_amd.workloads import bert
     cfg = bert.BertConfig(hidden=64, heads=4, layers=2, ffn=128, vocab=100, max_pos=32, type_vocab=2)
     w = bert.make_weights(cfg)
     B, S = 3, 16

@@ -112,7 +112,7 @@ def test_registry_covers_hot_path_ops():
 
 
 def test_resnet50_graph_shape_accounting():
-    from rten_amd.models import resnet50
+    from rten_amd.workloads import resnet50
     specs = resnet50.conv_specs()
     assert len(specs) == 53
     assert abs(resnet50.conv_flops_per_image() / 1e9 - 8.174) < 0.01

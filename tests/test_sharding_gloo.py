@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from rten_amd.parallel import broadcast_weight_arena, gather_outputs, shard_range
+from rten_amd.sharding import broadcast_weight_arena, gather_outputs, shard_range
 
 
 def test_shard_range_partitions_batch():

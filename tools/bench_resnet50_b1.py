@@ -4,7 +4,7 @@ import argparse, json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rten_amd import lib as L  # noqa: E402
-from rten_amd.models import resnet50  # noqa: E402
+from rten_amd.workloads import resnet50  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=200)

@@ -17,8 +17,8 @@ import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rten_amd import lib  # noqa: E402
-from rten_amd.models import resnet50  # noqa: E402
-from rten_amd.parallel import broadcast_weight_arena  # noqa: E402
+from rten_amd.workloads import resnet50  # noqa: E402
+from rten_amd.sharding import broadcast_weight_arena  # noqa: E402
 
 
 def main():

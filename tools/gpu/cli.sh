@@ -5,7 +5,7 @@ python - <<PY
 import sys
 sys.path.insert(0, ".")
 from rten_amd import onnx_writer as ow
-from rten_amd.models import bert, resnet50
+from rten_amd.workloads import bert, resnet50
 W = resnet50.make_weights()
 open("/tmp/resnet50.onnx", "wb").write(ow.resnet50_f32(W))
 open("/tmp/resnet50_int8.onnx", "wb").write(ow.resnet50_int8(W))

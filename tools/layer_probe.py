@@ -11,7 +11,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rten_amd import lib  # noqa: E402
-from rten_amd.models import resnet50  # noqa: E402
+from rten_amd.workloads import resnet50  # noqa: E402
 
 
 def main():
