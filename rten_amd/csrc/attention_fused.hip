@@ -15,7 +15,7 @@
 // a whole softmax row in registers -- the max and the 16 ordered partial sums are plain in-lane register arithmetic
 // (key index t = 32j + acc_row(r) + 4*half, hence t mod 16 is fixed per register), and the left-to-right fold of the 16
 // partials crosses between the two half-waves four times.  The probabilities never leave registers either: cross-half
-// moves (ds_bpermute) re-pair them into the MFMA A operand (k = t, even t in lanes 0-31, odd t in lanes
+// swaps (v_permlane32_swap, one per register pair) re-pair them into the MFMA A operand (k = t, even t in lanes 0-31, odd t in lanes
 // 32-63) for PV.  Q and K are staged in LDS as [d-quad][row][4] (16-byte global loads); V replaces K after phase 1.
 // 64 KB of LDS and < 128 VGPRs: two workgroups per CU.
 #include "internal.h"
@@ -168,13 +168,15 @@ __global__ __launch_bounds__(256, 2) void sdpa_fused_kernel(const SdpaArgs p) {
         for (int g = 0; g < 4; g++)
 #pragma unroll
             for (int c = 0; c < 4; c += 2) {
+                // v_permlane32_swap(a, b): a' = {a.lo, b.lo}, b' = {a.hi, b.hi} (tools/probes/permlane32_swap.hip) -- exactly
+                // the re-pairing wanted, one VALU instruction per register pair (operands copied to scalars first: a bit_cast
+                // applied directly to an ext-vector element reads element 0 under this compiler)
                 const float r0 = sc[j][4 * g + c], r1 = sc[j][4 * g + c + 1];
-                // cross-half moves by ds_bpermute (v_permlane32_swap has the right lane semantics --
-                // tools/probes/permlane32_swap.hip -- but miscompares inside this kernel; kept on the conservative path)
-                const float r1_from_lo = __shfl_xor(r1, 32, 64); // in half 1: half 0's r1
-                const float r0_from_hi = __shfl_xor(r0, 32, 64); // in half 0: half 1's r0
-                sc[j][4 * g + c] = half ? r1_from_lo : r0;       // keys (8g+c | 8g+c+1)
-                sc[j][4 * g + c + 1] = half ? r1 : r0_from_hi;   // keys (8g+4+c | 8g+4+c+1)
+                const unsigned u0 = __float_as_uint(r0), u1 = __float_as_uint(r1);
+                const auto sw = __builtin_amdgcn_permlane32_swap(u0, u1, false, false);
+                const unsigned n0 = sw[0], n1 = sw[1];
+                sc[j][4 * g + c] = __uint_as_float(n0);       // keys (8g+c | 8g+c+1)
+                sc[j][4 * g + c + 1] = __uint_as_float(n1);   // keys (8g+4+c | 8g+4+c+1)
             }
     __syncthreads(); // V is in LDS
 
