@@ -12,7 +12,9 @@ collective is the one-time RCCL broadcast of the prepacked weight arena from ran
 Rank 0 prints ONE JSON line: metric/value (whole-job inferences/s), roofline of the dominant kernel
 (measured live with HIP events on the backend's stream in an instrumented pass over the same K steps),
 and cpu_baseline (the CPU oracle -- a port of the reference algorithm -- timed on this host's cores on a
-bounded sample; N=1 only).
+bounded sample; N=1 only).  At N=1 the line also carries `secondary`: the int8 ResNet-50 (configs[2]) and BERT-base (configs[3])
+harnesses run in child processes after the headline measurement.  Defaults: K = 50, W = 20 (the chip needs about 20 ms of
+load to settle its clocks; a run with the driver's own K / W is timed exactly as given).
 """
 import argparse
 import json
