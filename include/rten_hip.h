@@ -319,9 +319,7 @@ int32_t rten_hip_num_gemm_variants(void);
  * boundaries, rten-gemm/src/lib.rs:630-633, and the per-block partial sums are added in block order by a fixup
  * kernel).  mode 0 = off, 1 = split only the tiles beyond the last full round of compute units, 2 = split every
  * tile, 3 = automatic (default: split every tile when the launch would have fewer workgroups than half the compute
- * units), 4 = split every tile and fold in the producer kernel itself: the last workgroup to arrive at a tile (ticket on a
- * device-scope counter, release / acquire fences) replays the same ordered fold, so there is no fixup launch;
- * groups = K groups per split tile (modes 1, 2, 4).  A tuning knob like the variant override: sticky. */
+ * units); groups = K groups per split tile (modes 1, 2).  A tuning knob like the variant override: sticky. */
 int32_t rten_hip_set_gemm_split(rten_hip_ctx *ctx, int32_t mode, int32_t groups);
 /* Workgroup -> tile order (tuning knob, sticky, default 0): bit 0 = tiles walk n fastest instead of m fastest;
  * bit 1 = split-K workgroups walk tiles fastest and K groups slowest, so that each XCD's private L2 holds one K

@@ -106,10 +106,6 @@ RTEN_EXPORT int32_t rten_hip_init(int32_t device_id, void *external_stream, rten
     ctx->device = device_id;
     ctx->num_cus = prop.multiProcessorCount;
     if (const char *dbg = getenv("RTEN_HIP_DEBUG")) ctx->debug = atoi(dbg);
-    if (hipMalloc((void **)&ctx->split_counters, rten_hip_ctx::kSplitCounters * sizeof(int)) == hipSuccess)
-        hipMemset(ctx->split_counters, 0, rten_hip_ctx::kSplitCounters * sizeof(int));
-    else
-        ctx->split_counters = nullptr;
     if (external_stream) {
         ctx->stream = (hipStream_t)external_stream;
     } else {
@@ -138,7 +134,6 @@ RTEN_EXPORT int32_t rten_hip_destroy(rten_hip_ctx *ctx) {
         for (hipEvent_t e : t)
             if (e) hipEventDestroy(e);
     if (ctx->scratch) hipFree(ctx->scratch);
-    if (ctx->split_counters) hipFree(ctx->split_counters);
     for (auto &kv : ctx->luts) hipFree(kv.second);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -88,7 +88,6 @@ struct GemmArgs {
     // the fixup kernel replays the unsplit fold over the slots in block order -> bit-identical to the unsplit chain.
     float *slab;
     int split_t1, split_s, split_g, split_slots, split_ntail;
-    int *counters; // != nullptr: split-K producers fold in-kernel -- the last workgroup to arrive at a tile replays the fixup
     int order; // bit 0: tiles walk n fastest (default m fastest); bit 1: split workgroups walk tiles fastest, K groups slowest
 };
 
@@ -591,10 +590,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_kernel(const GemmArgs p
 
 
 // =====================================================================================================
-// (defined below, next to igemm_f32_fixup_kernel)
-template <int BM, int BN>
-__device__ __forceinline__ void fixup_quadrant(const GemmArgs &p, int lane, int wq, int ti, int z);
-
 // LDS-DMA variant (conv paths: A = prepacked [K][M] weights, B = dense two-level or im2col gather).
 //
 // Tiles go HBM/L2 -> LDS directly (`buffer_load_dword[x4] ... offen lds`): no staging VGPRs, no ds_write
@@ -909,27 +904,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
     }
     wait_vmcnt<0>(); // drain the two look-ahead tiles before the LDS goes away
 
-    if constexpr (SPLIT) {
-        // Split mode 4: no separate fixup launch.  Every producer publishes its slab slots (release), takes a ticket on the
-        // tile's arrival counter, and the workgroup that draws the last ticket (acquire) replays the ordered fold for the
-        // whole tile -- each of its four waves one quadrant, exactly the fixup kernel's lane <-> element mapping -- and
-        // leaves the counter at zero for the next launch.  The fold order is fixed by the slot index, not by arrival, so
-        // the result is the same bits whichever workgroup finishes last.
-        if (p.counters) {
-            __threadfence();
-            __syncthreads();
-            int *cnt = p.counters + (long long)z * p.split_ntail + (tile - p.split_t1);
-            int *tk = reinterpret_cast<int *>(smem); // the stage buffers are idle: every wave passed the barrier above after its last LDS read
-            if (t == 0) *tk = atomicAdd(cnt, 1);
-            __syncthreads();
-            if (*tk == p.split_s - 1) {
-                __threadfence();
-                fixup_quadrant<BM, BN>(p, lane, wave, tile - p.split_t1, z);
-                if (t == 0) atomicExch(cnt, 0);
-            }
-        }
-    }
-
     if constexpr (!SPLIT) {
         if (MIXED && grp >= 0) return;
         if (!(ABLATE(p) & 4)) {
@@ -949,13 +923,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
 // mapping as the GEMM kernels.  Replays the unsplit kernel's fold over the parked per-block accumulators in
 // depth-block order (first block: beta*C + bias; later blocks: separate adds), then the shared epilogue (residual,
 // activation, store).  Slots are fetched U at a time so several loads are in flight per lane.
-// One wave's share of the fixup: quadrant `wq` of split tile `ti` (batch item z).
 template <int BM, int BN>
-__device__ __forceinline__ void fixup_quadrant(const GemmArgs &p, int lane, int wq, int ti, int z) {
+__global__ __launch_bounds__(64) void igemm_f32_fixup_kernel(const GemmArgs p) {
     constexpr int WM = 2, WN = 2;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int U = TM * TN >= 4 ? 1 : 4 / (TM * TN); // slots per batch: 64 floats per lane in flight
+    const int lane = threadIdx.x, wq = blockIdx.x & 3, ti = blockIdx.x >> 2;
     const int l31 = lane & 31, half = lane >> 5;
+    const int z = blockIdx.y;
     const int tile = p.split_t1 + ti;
     const int bm = (p.order & 1) ? tile / p.tiles_n : tile % p.tiles_m, bn = (p.order & 1) ? tile % p.tiles_n : tile / p.tiles_m;
     const int m0 = bm * BM, n0 = bn * BN;
@@ -993,11 +968,6 @@ __device__ __forceinline__ void fixup_quadrant(const GemmArgs &p, int lane, int 
         fold_next<TM, TN>(p, acc[0], tot);
     }
     store_out<TM, TN>(p, tot, mb, nb0, c_zoff);
-}
-
-template <int BM, int BN>
-__global__ __launch_bounds__(64) void igemm_f32_fixup_kernel(const GemmArgs p) {
-    fixup_quadrant<BM, BN>(p, threadIdx.x, blockIdx.x & 3, blockIdx.x >> 2, blockIdx.y);
 }
 
 template <int BM, int BN, int BL, bool MULTI_KC>
@@ -1302,9 +1272,6 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
         split_mode = (multi && wgs * 2 <= ctx->num_cus) ? 2 : 0;
         split_req = (int)(ctx->num_cus / (wgs > 0 ? wgs : 1));
     }
-    const bool fold_in_kernel = split_mode == 4;
-    if (fold_in_kernel) split_mode = 2;
-    a.counters = nullptr;
     if (multi && pipe != 2 && split_mode > 0 && split_req > 1) {
         const int s_req = split_req < nblk ? split_req : nblk;
         const int G = (nblk + s_req - 1) / s_req;
@@ -1317,9 +1284,6 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
             char *sc = (char *)rten_scratch(ctx, need);
             if (!sc) return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "split-K slab allocation failed (or attempted during graph capture)");
             a.slab = (float *)(sc + 4096);
-            // in-kernel fold: DMA pipelines only (the register-staged kernel keeps the fixup launch), one counter per split tile
-            if (fold_in_kernel && kDma && (pipe == 1 || pipe == 3) && ctx->split_counters && (long long)Z * ntail <= rten_hip_ctx::kSplitCounters)
-                a.counters = ctx->split_counters;
         } else {
             t1 = T;
         }
@@ -1383,7 +1347,6 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
         if (!mixed) {
             const int32_t rc = launch(2, (unsigned)(ntail * S), flops * ntail / T, bytes * ntail / T);
             if (rc) return rc;
-            if (a.counters) return RTEN_HIP_OK; // folded by the last-arriving producer of every tile
         }
         snprintf(kname, sizeof kname, "igemm_f32_fixup_kernel<%d,%d>", BM, BN);
         ProfScope ps(ctx, kname, 0.0, 8.0 * Z * ntail * nblk * BM * BN);
@@ -1458,7 +1421,7 @@ RTEN_EXPORT int32_t rten_hip_set_gemm_variant_override(rten_hip_ctx *ctx, int32_
 // would exist); `groups` = K groups per split tile (modes 1, 2).
 RTEN_EXPORT int32_t rten_hip_set_gemm_split(rten_hip_ctx *ctx, int32_t mode, int32_t groups) {
     RTEN_CHECK_CTX(ctx);
-    if (mode < 0 || mode > 4 || groups < 0) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "set_gemm_split: bad mode/groups");
+    if (mode < 0 || mode > 3 || groups < 0) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "set_gemm_split: bad mode/groups");
     ctx->split_mode = mode;
     ctx->split_s = groups;
     return RTEN_HIP_OK;

@@ -45,9 +45,7 @@ struct rten_hip_ctx {
     int sdpa_path = 0;  // 0 automatic (fused attention kernel when it covers the shape), 1 composed path only
     int int8_path = 0;  // 0 automatic (fast staging path when it covers the call), 1 generic kernel only
     int tile_order = 0; // workgroup -> tile order bits (rten_hip_set_gemm_order)
-    int split_mode = 3, split_s = 1; // exact split-K plan: 0 off, 1 tail tiles, 2 all tiles, 3 automatic, 4 all tiles + in-kernel fold (gemm_f32.hip)
-    int *split_counters = nullptr;   // one arrival counter per split tile (mode 4); zero between launches (the last arriver resets its own)
-    static constexpr int kSplitCounters = 16384;
+    int split_mode = 3, split_s = 1; // exact split-K plan: 0 off, 1 tail tiles, 2 all tiles, 3 automatic (gemm_f32.hip)
     int debug = 0; // RTEN_HIP_DEBUG ablation bits (tuning only)
 };
 

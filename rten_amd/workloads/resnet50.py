@@ -248,9 +248,6 @@ class ResNet50:
                     plans.append((v, 1, groups, 0))
                     for o in (0, 2, 3):
                         plans.append((v, 2, groups, o))
-                    # (split mode 4 -- the ordered fold inside the last-arriving producer, no fixup launch -- is 25-70 % slower than
-                    # producer + fixup on every layer, batch 1 and 32: the per-workgroup release / acquire fences cost more than a
-                    # launch; tools/probe_inkernel_fold.py.  It stays available but is not a candidate.)
         return plans
 
     def autotune(self, reps=3):

@@ -119,7 +119,7 @@ def test_gemm_f32_split_k_bit_exact(ctx):
             at, bt = np.ascontiguousarray(a.T).T, np.ascontiguousarray(b.T).T
             want = ref.gemm_f32(a, b)
             want2 = ref.gelu(ref.gemm_f32(a, b, c=c, alpha=0.5, beta=2.0, bias=bc, bias_kind=ref.BIAS_PER_COL))
-            for mode, groups in ((3, 1), (2, 2), (2, 3), (2, 64), (1, 4), (4, 2), (4, 3), (4, 64)):
+            for mode, groups in ((3, 1), (2, 2), (2, 3), (2, 64), (1, 4)):
                 ctx.call("rten_hip_set_gemm_split", mode, groups)
                 for aa, bb in ((a, b), (at, b), (a, bt), (at, bt)):
                     bits_equal(gpu_gemm(ctx, aa, bb), want)
@@ -265,7 +265,7 @@ def test_conv_f32_split_k_bit_exact(ctx, shape):
     nblk = (Cc * k * k + 255) // 256
     try:
         for v in range(4):
-            for mode in (1, 2, 4):
+            for mode in (1, 2):
                 for groups in sorted({2, 3, nblk}):
                     ctx.call("rten_hip_set_gemm_split", mode, groups)
                     for order in ((0, 1, 2, 3) if v == 3 else (0, 3)):  # workgroup -> tile orders
@@ -289,7 +289,7 @@ def test_conv_f32_grouped_split_k_bit_exact(ctx):
     want = ref.conv2d_f32(x, w, b, pads=(1, 1, 1, 1), groups=2, relu=True)
     try:
         for v in (3, 7, 1):
-            for mode, groups in ((0, 1), (2, 2), (2, 3), (1, 3), (4, 2), (4, 3)):
+            for mode, groups in ((0, 1), (2, 2), (2, 3), (1, 3)):
                 ctx.call("rten_hip_set_gemm_split", mode, groups)
                 bits_equal(gpu_conv(ctx, x, w, b, (1, 1, 1, 1), (1, 1), (1, 1), 2, relu=True, variant=v), want)
     finally:
