@@ -23,6 +23,7 @@ def build_binary():
     if not os.path.exists(BIN) or os.path.getmtime(BIN) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), src, "-o", BIN,
                                "-L" + os.path.join(ROOT, "rten_amd"), "-lrten_hip", "-L" + os.path.join(ROOT, "oracle", "_build"), "-lrten_oracle",
+                               "-Wl,-rpath,$ORIGIN/../../../rten_amd", "-Wl,-rpath,$ORIGIN/../../../oracle/_build",
                                "-Wl,-rpath," + os.path.join(ROOT, "rten_amd"), "-Wl,-rpath," + os.path.join(ROOT, "oracle", "_build"),
                                "-Wl,-rpath,/opt/rocm/lib"])
     return BIN

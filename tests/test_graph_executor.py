@@ -22,7 +22,8 @@ def build_cli():
     os.makedirs(os.path.dirname(BIN), exist_ok=True)
     if not os.path.exists(BIN) or os.path.getmtime(BIN) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), src, "-o", BIN,
-                               "-L" + os.path.join(ROOT, "rten_amd"), "-lrten_hip", "-Wl,-rpath," + os.path.join(ROOT, "rten_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+                               "-L" + os.path.join(ROOT, "rten_amd"), "-lrten_hip", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + os.path.join(ROOT, "rten_amd"),
+                               "-Wl,-rpath,/opt/rocm/lib"])  # $ORIGIN/.. = rten_amd/: the binary finds the library wherever the tree is mounted
     return BIN
 
 
