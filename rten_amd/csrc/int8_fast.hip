@@ -273,7 +273,9 @@ __global__ __launch_bounds__(256) void i8_quantize_stage_kernel(const float *__r
 // ---------------------------------------------------------------------------------------------------------
 // main kernel
 // ---------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int NSTAGE>
+// RES: the epilogue adds a residual tile (prefetched into 16 * TM * TN registers); a separate instantiation so that the
+// launches without one keep the smaller register footprint (one more workgroup per CU on the 128 x 128 tile).
+template <int BM, int BN, int NSTAGE, bool RES>
 __global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p) {
     constexpr int WM = 2, WN = 2;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p)
     // stage buffers are free), per-column constants and the residual tile straight into registers.  They are older
     // than every LDS-DMA load, so the counted vmcnt waits of the main loop cover them.
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void *)p.C, 0, 0x7ffffffc, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void *)(p.res ? (const void *)p.res : (const void *)p.C), 0, 0x7ffffffc, 0x00020000);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void *)(p.res ? (const void *)p.res : (const void *)p.C), 0, 0x7ffffffc, 0x00020000);
     const unsigned rs4 = (unsigned)p.c_rs << 2;
     const int mb = m0 + wm0 + 4 * half;
     int rc_rsum = 0, rc_az = 0;
@@ -423,8 +425,8 @@ __global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p)
     // half (rows +4) folded into the vector offset
     const unsigned half_off = (unsigned)(4 * half) * rs4;
     const int mb_u = m0 + (wave / WN) * (BM / WM);
-    float rr[TM][TN][16];
-    if (p.res) {
+    [[maybe_unused]] float rr[RES ? TM : 1][RES ? TN : 1][16];
+    if constexpr (RES) {
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -499,7 +501,7 @@ __global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p)
 #pragma unroll
                     for (int r = 0; r < 16; r++) f[r] = f[r] + bv[r];
                 }
-                if (p.res) {
+                if constexpr (RES) {
 #pragma unroll
                     for (int r = 0; r < 16; r++) f[r] = f[r] + rr[i][j][r];
                 }
@@ -577,7 +579,8 @@ void launch_fast(rten_hip_ctx *ctx, FastArgs &a, const char *name, double ops, d
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.N + BN - 1) / BN;
     ProfScope ps(ctx, name, ops, bytes);
-    hipLaunchKernelGGL((igemm_i8_fast_kernel<BM, BN, NST>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), 0, ctx->stream, a);
+    if (a.res && a.scale) hipLaunchKernelGGL((igemm_i8_fast_kernel<BM, BN, NST, true>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((igemm_i8_fast_kernel<BM, BN, NST, false>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), 0, ctx->stream, a);
 }
 
 int32_t dispatch_fast(rten_hip_ctx *ctx, FastArgs &a, double ops, double bytes) {
