@@ -284,17 +284,60 @@ RTO_API void rto_gemm_f32_batched(int64_t batch, int64_t M, int64_t N, int64_t K
  * NCHW input, OIHW kernel (I = C/groups), NCHW output.  Per image and group:
  * out[O_g, OH*OW] = W_g[O_g, C_g*kh*kw] . im2col(x)[C_g*kh*kw, OH*OW] with bias per out channel
  * (BiasVector::Column).  The pointwise fast path (conv.rs:250-267) is the same GEMM with the
- * image viewed as a [C, H*W] matrix, so a single restatement covers both.  The depthwise path
- * (conv/depthwise.rs) is out of scope (not in the configs) -- depthwise shapes
- * run through the generic path here, which is what the reference's own tests compare against
- * (reference_conv, conv.rs:629-747).
+ * image viewed as a [C, H*W] matrix, so a single restatement covers both.  Depthwise convolutions
+ * (groups == C == O) take the reference's own path, rto_depthwise_conv2d_f32 below, as conv.rs:269-284
+ * dispatches them: its arithmetic differs from the GEMM's (separate multiply and add, no FMA; the
+ * accumulator starts at the bias; padded taps are skipped).
  * Fused extras (not in the reference Conv op; restated as the op sequence the reference graph
  * runs): residual Add (binary_elementwise.rs:476-495) then Relu (unary_elementwise.rs:611-613).
  * ---------------------------------------------------------------------------------- */
+/* Depthwise convolution -- src/ops/conv/depthwise.rs:95-146 (GenericDepthwiseConvKernel<f32>::compute_row) and
+ * :215-262 (channel loop).  One input channel per output channel.  Per output element:
+ *     acc = bias[c] (or 0);  for k_y in 0..kh: skip rows outside the image;
+ *                            for k_x in 0..kw: if the tap's input column is inside the image: acc += x * w
+ * with `x * w` rounded to f32 before the add (Rust does not contract `a += b * c` into an FMA), taps visited in
+ * (k_y, k_x) order, padding taps not visited at all.  (The reference walks whole output rows per tap; the per-element
+ * sequence of operations is the one written here.) */
+static void rto_depthwise_conv2d_f32(int64_t N, int64_t C, int64_t H, int64_t W, int64_t kh, int64_t kw, const int64_t pads[4],
+                                     const int64_t strides[2], const int64_t dil[2], const float *X, const float *Wt, const float *bias,
+                                     const float *residual, int relu, float *Y, int64_t OH, int64_t OW) {
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int64_t n = 0; n < N; n++)
+        for (int64_t c = 0; c < C; c++) {
+            const float *xc = X + (n * C + c) * H * W;
+            const float *wc = Wt + c * kh * kw;
+            float *yc = Y + (n * C + c) * OH * OW;
+            const float *rc = residual ? residual + (n * C + c) * OH * OW : NULL;
+            for (int64_t oy = 0; oy < OH; oy++)
+                for (int64_t ox = 0; ox < OW; ox++) {
+                    float acc = bias ? bias[c] : 0.0f;
+                    for (int64_t ky = 0; ky < kh; ky++) {
+                        const int64_t iy = oy * strides[0] + ky * dil[0] - pads[0];
+                        if (iy < 0 || iy >= H) continue;
+                        for (int64_t kx = 0; kx < kw; kx++) {
+                            const int64_t ix = ox * strides[1] + kx * dil[1] - pads[1];
+                            if (ix < 0 || ix >= W) continue;
+                            const float prod = xc[iy * W + ix] * wc[ky * kw + kx];
+                            acc = acc + prod;
+                        }
+                    }
+                    if (rc) acc = acc + rc[oy * OW + ox];
+                    if (relu) acc = fmaxf(acc, 0.f); /* f32::max: NaN -> 0 */
+                    yc[oy * OW + ox] = acc;
+                }
+        }
+}
+
 RTO_API int rto_conv2d_f32(int64_t N, int64_t C, int64_t H, int64_t W, int64_t O, int64_t kh, int64_t kw,
                            const int64_t pads[4], const int64_t strides[2], const int64_t dil[2],
                            int64_t groups, const float *X, const float *Wt, const float *bias,
                            const float *residual, int relu, float *Y, int64_t OH, int64_t OW) {
+    const int pointwise = kh == 1 && kw == 1 && groups == 1 && strides[0] == 1 && strides[1] == 1 && dil[0] == 1 && dil[1] == 1 &&
+                          pads[0] == 0 && pads[1] == 0 && pads[2] == 0 && pads[3] == 0;
+    if (!pointwise && C == O && groups == C) { /* conv.rs:269-284 */
+        rto_depthwise_conv2d_f32(N, C, H, W, kh, kw, pads, strides, dil, X, Wt, bias, residual, relu, Y, OH, OW);
+        return 0;
+    }
     const int64_t Cg = C / groups, Og = O / groups, Kg = Cg * kh * kw, P = OH * OW;
 #pragma omp parallel for collapse(2) schedule(dynamic)
     for (int64_t n = 0; n < N; n++) {
@@ -373,6 +416,12 @@ RTO_API int rto_conv2d_int8(int64_t N, int64_t C, int64_t H, int64_t W, int64_t 
                             int32_t x_zp, const void *w_zp, int64_t w_zp_len, int pad_mode, int32_t *Y,
                             int64_t OH, int64_t OW) {
     const int64_t Cg = C / groups, Og = O / groups, P = OH * OW;
+    {   /* depthwise geometries run conv/depthwise.rs:148-190 (conv.rs:269-284), which skips padded taps: they contribute 0 on
+         * every platform, whatever the im2col quirk selected by pad_mode would do on the GEMM path */
+        const int pointwise = kh == 1 && kw == 1 && groups == 1 && strides[0] == 1 && strides[1] == 1 && dil[0] == 1 && dil[1] == 1 &&
+                              pads[0] == 0 && pads[1] == 0 && pads[2] == 0 && pads[3] == 0;
+        if (!pointwise && C == O && groups == C) pad_mode = 0;
+    }
     int32_t pad_val;
     if (pad_mode == 0) pad_val = x_zp;
     else if (pad_mode == 1) pad_val = x_signed ? 0 : 128;

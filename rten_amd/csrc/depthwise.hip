@@ -1,0 +1,77 @@
+// Depthwise convolution (groups == C == O), f32: the reference routes these to its own kernel (src/ops/conv.rs:269-284 ->
+// src/ops/conv/depthwise.rs:95-146, 215-262), whose arithmetic is NOT the GEMM's: the accumulator starts at the bias, every
+// in-bounds tap contributes one rounded multiply followed by one add (Rust does not contract `acc += x * w` into an FMA),
+// taps are visited in (k_y, k_x) order and padding taps are not visited at all.  One thread per output element replays
+// exactly that sequence, so the result is bit-identical to the reference's; the generic grouped-GEMM path would differ in the
+// last bits (FMA chain from zero, bias afterwards).  HBM-bound: every input element is read kh*kw/stride^2 times through L1 / L2.
+#include "internal.h"
+#include "vecmath.h"
+
+namespace {
+
+template <int KH, int KW> // > 0: compile-time window with all taps' loads issued first; 0: runtime window
+__global__ __launch_bounds__(256) void depthwise_conv2d_f32_kernel(const rten_hip_conv2d_desc d, const float *__restrict__ x, const float *__restrict__ w,
+                                                                   int w_stride, const float *__restrict__ bias, const float *__restrict__ residual,
+                                                                   int relu, float *__restrict__ y) {
+    const int plane = d.out_h * d.out_w;
+    const int o = blockIdx.y * 256 + threadIdx.x;
+    if (o >= plane) return;
+    const int nc = blockIdx.x, c = nc % d.c;
+    const int oy = o / d.out_w, ox = o - oy * d.out_w;
+    const float *xc = x + (long long)nc * d.h * d.w;
+    const int kh = KH > 0 ? KH : d.kh, kw = KW > 0 ? KW : d.kw;
+    const float *wc = w + (long long)c * kh * kw * w_stride;
+    const int y0 = oy * d.stride_h - d.pads[0], x0 = ox * d.stride_w - d.pads[1];
+    float acc = bias ? bias[c] : 0.0f;
+    if constexpr (KH > 0) {
+        float xv[KH * KW], wv[KH * KW];
+        bool ok[KH * KW];
+#pragma unroll
+        for (int ky = 0; ky < KH; ky++)
+#pragma unroll
+            for (int kx = 0; kx < KW; kx++) {
+                const int iy = y0 + ky * d.dil_h, ix = x0 + kx * d.dil_w;
+                const bool in = (unsigned)iy < (unsigned)d.h && (unsigned)ix < (unsigned)d.w;
+                ok[ky * KW + kx] = in;
+                xv[ky * KW + kx] = xc[in ? iy * d.w + ix : 0];
+                wv[ky * KW + kx] = wc[(ky * KW + kx) * w_stride];
+            }
+#pragma unroll
+        for (int t = 0; t < KH * KW; t++)
+            if (ok[t]) acc = __fadd_rn(acc, __fmul_rn(xv[t], wv[t]));
+    } else {
+        for (int ky = 0; ky < kh; ky++) {
+            const int iy = y0 + ky * d.dil_h;
+            if ((unsigned)iy >= (unsigned)d.h) continue;
+            for (int kx = 0; kx < kw; kx++) {
+                const int ix = x0 + kx * d.dil_w;
+                if ((unsigned)ix >= (unsigned)d.w) continue;
+                acc = __fadd_rn(acc, __fmul_rn(xc[iy * d.w + ix], wc[(ky * kw + kx) * w_stride]));
+            }
+        }
+    }
+    const long long oi = (long long)nc * plane + o;
+    if (residual) acc = acc + residual[oi]; // the Add node that follows (binary_elementwise.rs:476-495)
+    if (relu) acc = vm::relu(acc);
+    y[oi] = acc;
+}
+
+} // namespace
+
+// Called by rten_hip_conv2d_f32 for groups == C == O geometries (weights OIHW [C,1,kh,kw], or the prepacked form whose
+// per-group K x 4 block holds the taps at stride 4).
+int32_t rten_depthwise_conv2d_f32(rten_hip_ctx *ctx, const rten_hip_conv2d_desc *d, const float *x, const float *w, int32_t weights_packed, const float *bias,
+                                  const float *residual, uint32_t flags, float *y) {
+    const long long planes = (long long)d->n * d->c, plane = (long long)d->out_h * d->out_w;
+    if (planes > 0x7fffffffLL || plane > 65535LL * 256 || (long long)d->h * d->w > 0x7fffffffLL)
+        return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "depthwise conv: plane too large");
+    const dim3 grid((unsigned)planes, (unsigned)((plane + 255) / 256));
+    const int ws = weights_packed ? 4 : 1, relu = (flags & RTEN_HIP_CONV_RELU) ? 1 : 0;
+    const float *res = (flags & RTEN_HIP_CONV_RESIDUAL) ? residual : nullptr;
+    ProfScope ps(ctx, "depthwise_conv2d_f32", 2.0 * planes * plane * d->kh * d->kw, 4.0 * (planes * (double)d->h * d->w + planes * (double)plane));
+    if (d->kh == 3 && d->kw == 3) hipLaunchKernelGGL((depthwise_conv2d_f32_kernel<3, 3>), grid, dim3(256), 0, ctx->stream, *d, x, w, ws, bias, res, relu, y);
+    else if (d->kh == 5 && d->kw == 5) hipLaunchKernelGGL((depthwise_conv2d_f32_kernel<5, 5>), grid, dim3(256), 0, ctx->stream, *d, x, w, ws, bias, res, relu, y);
+    else hipLaunchKernelGGL((depthwise_conv2d_f32_kernel<0, 0>), grid, dim3(256), 0, ctx->stream, *d, x, w, ws, bias, res, relu, y);
+    RTEN_LAUNCH_CHECK(ctx, "depthwise_conv2d_f32_kernel launch");
+    return RTEN_HIP_OK;
+}

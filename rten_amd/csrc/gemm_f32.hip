@@ -1533,6 +1533,10 @@ const i32x2 *get_im2col_lut(rten_hip_ctx *ctx, int Cg, int kh, int kw, int dy, i
 }
 } // namespace
 
+// depthwise.hip
+int32_t rten_depthwise_conv2d_f32(rten_hip_ctx *ctx, const rten_hip_conv2d_desc *d, const float *x, const float *w, int32_t weights_packed, const float *bias,
+                                  const float *residual, uint32_t flags, float *y);
+
 RTEN_EXPORT size_t rten_hip_conv2d_f32_packed_bytes(const rten_hip_conv2d_desc *d) {
     if (!d || d->groups <= 0) return 0;
     const int Og = d->o / d->groups, Og4 = (Og + 3) & ~3;
@@ -1566,6 +1570,11 @@ RTEN_EXPORT int32_t rten_hip_conv2d_f32(rten_hip_ctx *ctx, const rten_hip_conv2d
     if ((flags & RTEN_HIP_CONV_RESIDUAL) && !residual)
         return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "conv: residual flag without residual tensor");
     if (d->n == 0 || d->out_h == 0 || d->out_w == 0) return RTEN_HIP_OK;
+    {   // dispatch order of conv_impl (conv.rs:248-284): the pointwise GEMM first (groups == 1 only), then depthwise
+        const bool pw = d->kh == 1 && d->kw == 1 && d->groups == 1 && d->stride_h == 1 && d->stride_w == 1 && d->dil_h == 1 && d->dil_w == 1 &&
+                        d->pads[0] == 0 && d->pads[1] == 0 && d->pads[2] == 0 && d->pads[3] == 0;
+        if (!pw && d->c == d->o && d->groups == d->c) return rten_depthwise_conv2d_f32(ctx, d, x, w, weights_packed, bias, residual, flags, y);
+    }
     const int Cg = d->c / d->groups, Og = d->o / d->groups, Og4 = (Og + 3) & ~3;
     const int K = Cg * d->kh * d->kw;
     const int P = d->out_h * d->out_w;

@@ -364,7 +364,7 @@ int32_t conv2d_int8_impl(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di,
     g.sy = d->stride_h; g.sx = d->stride_w; g.dy = d->dil_h; g.dx = d->dil_w;
     g.pt = d->pads[0]; g.pl = d->pads[1];
     g.magic_khw = magic_for((unsigned)g.KHW); g.magic_kw = magic_for((unsigned)g.KW);
-    g.pad_mode = di->pad_mode;
+    g.pad_mode = rten_effective_pad_mode(di);
     return launch_i8(ctx, g, d->groups);
 }
 } // namespace

@@ -712,7 +712,7 @@ RTEN_EXPORT int32_t rten_hip_dynamic_quantize_linear_staged(rten_hip_ctx *ctx, c
     int nparts = 0;
     const float *ws = rten_dql_minmax(ctx, n, x, &nparts);
     if (!ws) return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "dql: scratch allocation failed");
-    launch_quantize_stage(ctx, d, g, x, ws, nparts, staged, di->pad_mode, scale, zero_point, mul_by, product);
+    launch_quantize_stage(ctx, d, g, x, ws, nparts, staged, rten_effective_pad_mode(di), scale, zero_point, mul_by, product);
     RTEN_LAUNCH_CHECK(ctx, "i8_quantize_stage_kernel launch");
     return RTEN_HIP_OK;
 }
@@ -743,7 +743,7 @@ RTEN_EXPORT int32_t rten_hip_dynamic_quantize_linear_staged_stats(rten_hip_ctx *
     if (!g.ok || di->x_signed) return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "quantize_staged: geometry not covered by the staged kernel (staged_bytes == 0)");
     const rten_hip_conv2d_desc *d = &di->conv;
     ProfScope ps(ctx, "dynamic_quantize_linear_staged_stats", 0.0, 4.0 * d->n * d->c * (double)d->h * d->w + (double)g.img);
-    launch_quantize_stage(ctx, d, g, x, (const float *)stats, -1, staged, di->pad_mode, scale, zero_point, mul_by, product);
+    launch_quantize_stage(ctx, d, g, x, (const float *)stats, -1, staged, rten_effective_pad_mode(di), scale, zero_point, mul_by, product);
     RTEN_LAUNCH_CHECK(ctx, "i8_quantize_stage_kernel launch");
     return RTEN_HIP_OK;
 }
@@ -775,7 +775,7 @@ int32_t rten_i8_fast_conv(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di
         const dim3 grid((unsigned)((d->h * d->w + 255) / 256), (unsigned)d->n, (unsigned)(cg.Cp / 16));
         const dim3 grid_small((unsigned)((cg.Hp * cg.Wp + 63) / 64), (unsigned)d->n, (unsigned)((cg.Cp + 63) / 64));
         const bool vec = (d->h * d->w) % 4 == 0 && ((uintptr_t)x & 3) == 0;
-#define PAD_ARGS (const uint8_t *)x, (uint8_t *)(sc + offB), d->c, d->h, d->w, cg.Hp, cg.Wp, cg.Cp, d->pads[0], d->pads[1], di->x_signed ? 0u : 0x80u, (const uint8_t *)x_zp, di->x_signed, di->pad_mode
+#define PAD_ARGS (const uint8_t *)x, (uint8_t *)(sc + offB), d->c, d->h, d->w, cg.Hp, cg.Wp, cg.Cp, d->pads[0], d->pads[1], di->x_signed ? 0u : 0x80u, (const uint8_t *)x_zp, di->x_signed, rten_effective_pad_mode(di)
         if (d->h * d->w < 128) hipLaunchKernelGGL(i8_nhwc_pad_kernel<0>, grid_small, dim3(256), 0, ctx->stream, PAD_ARGS);
         else if (vec) hipLaunchKernelGGL(i8_nhwc_pad_kernel<2>, grid, dim3(256), 0, ctx->stream, PAD_ARGS);
         else hipLaunchKernelGGL(i8_nhwc_pad_kernel<1>, grid, dim3(256), 0, ctx->stream, PAD_ARGS);

@@ -49,6 +49,16 @@ struct rten_hip_ctx {
     int debug = 0; // RTEN_HIP_DEBUG ablation bits (tuning only)
 };
 
+// Padding value semantics of an integer convolution.  Depthwise geometries (groups == C == O, not the groups == 1 pointwise
+// case) run the reference's depthwise kernel (conv.rs:269-284 -> conv/depthwise.rs:148-190), which skips padded taps -- they
+// contribute 0 whatever the platform's im2col quirk is -- so the requested pad mode is overridden for them.
+inline int rten_effective_pad_mode(const rten_hip_conv2d_int8_desc *di) {
+    const rten_hip_conv2d_desc &d = di->conv;
+    const bool pw = d.kh == 1 && d.kw == 1 && d.groups == 1 && d.stride_h == 1 && d.stride_w == 1 && d.dil_h == 1 && d.dil_w == 1 && d.pads[0] == 0 &&
+                    d.pads[1] == 0 && d.pads[2] == 0 && d.pads[3] == 0;
+    return (!pw && d.c == d.o && d.groups == d.c) ? RTEN_HIP_PAD_ZERO_POINT : di->pad_mode;
+}
+
 int32_t rten_set_error(rten_hip_ctx *ctx, int32_t code, const char *fmt, ...);
 int32_t rten_check_hip(rten_hip_ctx *ctx, hipError_t e, const char *what);
 void *rten_scratch(rten_hip_ctx *ctx, size_t bytes);

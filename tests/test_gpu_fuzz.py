@@ -154,3 +154,55 @@ def test_matmul_integer_random(ctx, seed):
                 bits_equal(got, want)
         finally:
             ctx.call("rten_hip_set_int8_path", 0)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_depthwise_conv_f32_random_geometry(ctx, seed):
+    """groups == C == O: the reference's depthwise kernel (conv/depthwise.rs) -- bias-first accumulator, separate multiply and add,
+    padded taps skipped -- replayed per output element; window sizes with and without the unrolled instantiations."""
+    rng = np.random.default_rng(6000 + seed)
+    for _ in range(14):
+        C_ = int(rng.integers(1, 40))
+        kh, kw = [(3, 3), (5, 5), (2, 2), (1, 3), (3, 1), (1, 1), (7, 7)][int(rng.integers(0, 7))]
+        strides = (int(rng.integers(1, 3)), int(rng.integers(1, 3)))
+        dil = (int(rng.choice([1, 1, 2])), int(rng.choice([1, 1, 2])))
+        pads = tuple(int(v) for v in rng.integers(0, 4, 4))
+        H, W = int(rng.integers(1, 24)), int(rng.integers(1, 24))
+        if H + pads[0] + pads[2] < dil[0] * (kh - 1) + 1 or W + pads[1] + pads[3] < dil[1] * (kw - 1) + 1:
+            continue
+        if (kh, kw) == (1, 1) and strides == (1, 1) and pads == (0, 0, 0, 0) and C_ == 1:
+            continue  # that one is the pointwise GEMM (groups == 1)
+        N = int(rng.integers(1, 4))
+        x = rng.random((N, C_, H, W), dtype=np.float32) - 0.5
+        w = rng.random((C_, 1, kh, kw), dtype=np.float32) - 0.5
+        bias = (rng.random(C_, dtype=np.float32) - 0.5) if rng.random() < 0.7 else None
+        relu = bool(rng.random() < 0.5)
+        want = ref.conv2d_f32(x, w, bias, pads=pads, strides=strides, dilations=dil, groups=C_)
+        res = (rng.random(want.shape, dtype=np.float32) - 0.5) if rng.random() < 0.4 else None
+        want = ref.conv2d_f32(x, w, bias, pads=pads, strides=strides, dilations=dil, groups=C_, residual=res, relu=relu)
+        got = gpu_conv(ctx, x, w, bias, pads, strides, dil, C_, residual=res, relu=relu, prepack=bool(rng.random() < 0.5))
+        try:
+            bits_equal(got, want)
+        except AssertionError as e:
+            raise AssertionError(f"depthwise N={N} C={C_} H={H} W={W} k={kh}x{kw} pads={pads} strides={strides} dil={dil}: {e}") from None
+
+
+def test_depthwise_conv_integer_ignores_the_padding_quirk(ctx):
+    """Integer depthwise geometries skip padded taps in the reference (conv/depthwise.rs:148-190): the platform's im2col pad
+    quirk (pad_mode) must not show, on either int8 path."""
+    rng = np.random.default_rng(7000)
+    for path in (0, 1):
+        ctx.call("rten_hip_set_int8_path", path)
+        try:
+            for (C_, H, W, k, pads, strides) in ((6, 9, 8, 3, (1, 1, 1, 1), (1, 1)), (16, 7, 7, 3, (1, 0, 2, 1), (2, 2)), (3, 12, 5, 5, (2, 2, 2, 2), (1, 1))):
+                x = rng.integers(0, 256, (2, C_, H, W)).astype(np.uint8)
+                w = rng.integers(-64, 65, (C_, 1, k, k)).astype(np.int8)
+                x_zp = np.array(rng.integers(1, 255), np.uint8)
+                want = ref.conv2d_int8(x, w, x_zp=int(x_zp), pads=pads, strides=strides, groups=C_, pad_mode=L.PAD_ZERO_POINT)
+                for pm in (L.PAD_ZERO_POINT, L.PAD_RAW0_I8, L.PAD_RAW0_U8):
+                    assert np.array_equal(ref.conv2d_int8(x, w, x_zp=int(x_zp), pads=pads, strides=strides, groups=C_, pad_mode=pm), want)
+                    op = ops.ConvInteger(groups=C_, padding=list(pads), strides=strides, pad_mode=pm)
+                    got = op.run(ctx, [dev(ctx, x), dev(ctx, w), dev(ctx, x_zp), None])[0].numpy()
+                    bits_equal(got, want)
+        finally:
+            ctx.call("rten_hip_set_int8_path", 0)

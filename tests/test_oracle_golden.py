@@ -45,6 +45,41 @@ def test_conv_literals():
     assert (oh, ow, pads) == (3, 3, [1, 1, 1, 1])
 
 
+def test_conv_depthwise_literal_and_operation_order():
+    """Depthwise convolutions take the reference's own path (conv.rs:269-284 -> conv/depthwise.rs): the literal of
+    test_conv_depthwise (conv.rs:990-1031), and the operation sequence itself -- accumulator starts at the bias, one rounded
+    multiply and one add per in-bounds tap in (k_y, k_x) order, padded taps skipped -- against a scalar numpy loop."""
+    g = G["conv_depthwise"]
+    x = np.array(g["input"], np.float32).reshape(g["input_shape"])
+    k = np.array(g["kernel"], np.float32).reshape(g["kernel_shape"])
+    b = np.array(g["bias"], np.float32)
+    want = np.array(g["expected_without_bias"], np.float32) + b
+    eq_1e4(ref.conv2d_f32(x, k, b, groups=3).ravel(), want)
+    rng = ref.XorShiftRng(77)
+    for (C, H, W, kh, kw, pads, strides, dil) in ((5, 9, 7, 3, 3, (1, 1, 1, 1), (1, 1), (1, 1)), (3, 8, 8, 3, 3, (0, 0, 1, 1), (2, 2), (1, 1)),
+                                                  (4, 10, 6, 5, 3, (2, 1, 2, 1), (1, 2), (2, 1)), (2, 6, 6, 1, 1, (0, 0, 0, 0), (2, 2), (1, 1))):
+        x = rng.f32(2 * C * H * W).reshape(2, C, H, W) - 0.5
+        w = rng.f32(C * kh * kw).reshape(C, 1, kh, kw) - 0.5
+        bias = rng.f32(C) - 0.5
+        got = ref.conv2d_f32(x, w, bias, pads=pads, strides=strides, dilations=dil, groups=C)
+        want = np.empty_like(got)
+        for n in range(2):
+            for c in range(C):
+                for oy in range(got.shape[2]):
+                    for ox in range(got.shape[3]):
+                        acc = np.float32(bias[c])
+                        for ky in range(kh):
+                            iy = oy * strides[0] + ky * dil[0] - pads[0]
+                            if not 0 <= iy < H:
+                                continue
+                            for kx in range(kw):
+                                ix = ox * strides[1] + kx * dil[1] - pads[1]
+                                if 0 <= ix < W:
+                                    acc = np.float32(acc + np.float32(x[n, c, iy, ix] * w[c, 0, ky, kx]))
+                        want[n, c, oy, ox] = acc
+        assert np.array_equal(got.view(np.int32), want.view(np.int32))
+
+
 def test_layer_norm_literals():
     for c in G["layer_norm"]["cases"]:
         x = np.array(c["input"], np.float32)
