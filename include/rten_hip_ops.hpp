@@ -565,7 +565,27 @@ struct Softmax : Operator { // src/ops/norm.rs:825-840 (last-axis lanes contiguo
     OutputList run(Context &ctx, const InputList &in) const override {
         const Tensor &x = want(require(in, 0), DType::F32, "float32");
         const int a = resolve_axis(axis, x.ndim());
-        if (a != x.ndim() - 1) throw OpError(OpError::UnsupportedValue, "Softmax: only the last axis on the device path");
+        if (a != x.ndim() - 1) {
+            // normalize_lanes (src/ops/norm.rs:705-754): move the axis last, make contiguous, apply, move it back
+            const int nd = x.ndim();
+            if (nd > 6) throw OpError(OpError::UnsupportedValue, "Softmax over a non-last axis of more than 6 dims is not supported by the device path");
+            std::vector<int32_t> fwd, back((size_t)nd);
+            for (int i = 0; i < nd; i++) if (i != a) fwd.push_back(i);
+            fwd.push_back(a);
+            for (int i = 0; i < nd; i++) back[(size_t)fwd[(size_t)i]] = i;
+            std::vector<int64_t> tshape;
+            for (int i = 0; i < nd; i++) tshape.push_back(x.size(fwd[(size_t)i]));
+            Tensor t(ctx, tshape, DType::F32), u(ctx, tshape, DType::F32), y(ctx, x.shape(), DType::F32);
+            if (x.len()) {
+                const int64_t cols = x.size(a), rows = x.len() / cols;
+                ctx.check(rten_hip_transpose_b32(ctx.raw(), nd, x.shape().data(), fwd.data(), x.ptr(), t.ptr()));
+                ctx.check(rten_hip_softmax_f32(ctx.raw(), rows, (int)cols, (const float *)t.ptr(), nullptr, 1, 1, 0, (float *)u.ptr()));
+                ctx.check(rten_hip_transpose_b32(ctx.raw(), nd, tshape.data(), back.data(), u.ptr(), y.ptr()));
+            }
+            OutputList out;
+            out.push_back(std::move(y));
+            return out;
+        }
         const int64_t cols = x.size(a), rows = cols ? x.len() / cols : 0;
         Tensor y(ctx, x.shape(), DType::F32);
         if (x.len()) ctx.check(rten_hip_softmax_f32(ctx.raw(), rows, (int)cols, (const float *)x.ptr(), nullptr, 1, 1, 0, (float *)y.ptr()));

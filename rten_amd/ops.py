@@ -441,7 +441,7 @@ def _resolve_axis(ndim, axis):
 
 
 class Softmax(Operator):
-    """src/ops/norm.rs:842-900 (last axis on device; other axes need a host-side transpose)."""
+    """src/ops/norm.rs:842-900; any axis (a non-last axis is moved last and back, like normalize_lanes)."""
 
     def __init__(self, axis=-1, flush_nans_to_zero=False):
         self.axis = axis
@@ -452,12 +452,28 @@ class Softmax(Operator):
 
     def run(self, ctx, inputs):
         x = _want(_require(inputs, 0), np.float32)
-        ax = _resolve_axis(len(x.shape), self.axis)
-        if ax != len(x.shape) - 1:
-            raise UnsupportedValue("device softmax runs along the last axis")
+        nd = len(x.shape)
+        ax = _resolve_axis(nd, self.axis)
+        flush = 1 if self.flush_nans_to_zero else 0
+        if ax != nd - 1:
+            # normalize_lanes (src/ops/norm.rs:705-754): move the axis last, make contiguous, apply, move it back
+            if nd > 6:
+                raise UnsupportedValue("Softmax over a non-last axis of more than 6 dims is not supported by the device path")
+            fwd = [i for i in range(nd) if i != ax] + [ax]
+            back = [fwd.index(i) for i in range(nd)]
+            tshape = [x.shape[i] for i in fwd]
+            t, u, y = DeviceTensor(ctx, tshape, np.float32), DeviceTensor(ctx, tshape, np.float32), DeviceTensor(ctx, x.shape, np.float32)
+            if x.size:
+                cols = x.shape[ax]
+                i64 = lambda v: (C.c_int64 * len(v))(*v)
+                i32 = lambda v: (C.c_int32 * len(v))(*v)
+                ctx.call("rten_hip_transpose_b32", nd, i64(list(x.shape)), i32(fwd), x.vp, t.vp)
+                ctx.call("rten_hip_softmax_f32", x.size // cols, cols, t.vp, None, 1, 1, flush, u.vp)
+                ctx.call("rten_hip_transpose_b32", nd, i64(tshape), i32(back), u.vp, y.vp)
+            return [y]
         y = DeviceTensor(ctx, x.shape, np.float32)
         cols = x.shape[-1]
-        ctx.call("rten_hip_softmax_f32", x.size // max(cols, 1), cols, x.vp, None, 1, 1, 1 if self.flush_nans_to_zero else 0, y.vp)
+        ctx.call("rten_hip_softmax_f32", x.size // max(cols, 1), cols, x.vp, None, 1, 1, flush, y.vp)
         return [y]
 
 

@@ -449,6 +449,16 @@ def test_softmax_bit_exact_avx512_order(ctx, cols):
     np.testing.assert_allclose(got, ref.softmax(x, lanes=4), rtol=1e-6, atol=0)
 
 
+def test_softmax_other_axes(ctx):
+    # normalize_lanes (norm.rs:705-754): the axis is moved last, the lanes processed, and moved back
+    rng = ref.XorShiftRng(31)
+    x = (rng.f32(3 * 5 * 7 * 4).reshape(3, 5, 7, 4) - 0.5) * 6
+    for axis in (0, 1, 2, -2, -4, 3):
+        got = ops.Softmax(axis=axis).run(ctx, [dev(ctx, x)])[0].numpy()
+        want = np.moveaxis(ref.softmax(np.ascontiguousarray(np.moveaxis(x, axis, -1)), lanes=16), -1, axis)
+        bits_equal(got, want)
+
+
 def test_add_softmax_bert_mask(ctx):
     rng = ref.XorShiftRng(2)
     qk = (rng.f32(2 * 12 * 128 * 128).reshape(2, 12, 128, 128) - 0.5) * 4
