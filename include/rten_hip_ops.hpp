@@ -261,10 +261,6 @@ struct Conv : Operator {
 
     // shape checks in the reference's order with its messages (src/ops/conv.rs:136-214)
     rten_hip_conv2d_desc geometry(const std::vector<int64_t> &xs, const std::vector<int64_t> &ws) const {
-        if (xs.size() == 3) {
-            if (ws.size() != 3) throw OpError(OpError::InvalidValue, "kernel must have 3 dims (OCW)");
-            throw OpError(OpError::UnsupportedValue, "1D convolution: expand to 2D on the host before calling the backend");
-        }
         if (xs.size() != 4) throw OpError(OpError::InvalidValue, "input must have 4 dims (NCHW)");
         if (ws.size() != 4) throw OpError(OpError::InvalidValue, "kernel must have 4 dims (OCHW)");
         if (strides.size() != 2) throw OpError(OpError::InvalidValue, "expected 2 stride values");
@@ -299,6 +295,24 @@ struct Conv : Operator {
         const Tensor &x = want(require(in, 0), DType::F32, "float32");
         const Tensor &w = want(require(in, 1), DType::F32, "float32");
         const Tensor *bias = get(in, 2), *residual = get(in, 3);
+        if (x.ndim() == 3) { // 1-D convolution: expand to 2-D, remove the extra axis from the result (conv.rs:142-182; views only)
+            if (w.ndim() != 3) throw OpError(OpError::InvalidValue, "kernel must have 3 dims (OCW)");
+            Conv op2 = *this;
+            if (!padding.same) {
+                if (padding.fixed.size() != 2) throw OpError(OpError::InvalidValue, "expected 2 pad values");
+                op2.padding = Padding::Fixed({0, padding.fixed[0], 0, padding.fixed[1]});
+            }
+            if (strides.size() != 1) throw OpError(OpError::InvalidValue, "expected 1 stride value");
+            if (dilations.size() != 1) throw OpError(OpError::InvalidValue, "expected 1 dilation value");
+            op2.strides = {1, strides[0]};
+            op2.dilations = {1, dilations[0]};
+            const Tensor x2 = Tensor::view_of(x, {x.size(0), x.size(1), 1, x.size(2)}), w2 = Tensor::view_of(w, {w.size(0), w.size(1), 1, w.size(2)});
+            Tensor r2;
+            if (residual) r2 = Tensor::view_of(*residual, {residual->size(0), residual->size(1), 1, residual->size(2)});
+            OutputList out = op2.run_packed(ctx, {&x2, &w2, bias, residual ? &r2 : nullptr}, packed_weight);
+            out[0].reshape({out[0].size(0), out[0].size(1), out[0].size(3)});
+            return out;
+        }
         const rten_hip_conv2d_desc d = geometry(x.shape(), w.shape());
         if (bias && bias->size(0) != d.o) throw OpError(OpError::IncompatibleInputShapes, "bias.size(0) != out_channels");
         Tensor y(ctx, {d.n, d.o, d.out_h, d.out_w}, DType::F32);

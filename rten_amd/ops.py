@@ -128,10 +128,6 @@ class Conv(Operator):
         return [1]
 
     def _geometry(self, ctx, xs, ws):
-        if len(xs) == 3:  # 1D conv -> 2D (conv.rs:142-182)
-            if len(ws) != 3:
-                raise InvalidValue("kernel must have 3 dims (OCW)")
-            raise UnsupportedValue("1D convolution: expand to 2D on the host before calling the backend")
         if len(xs) != 4:
             raise InvalidValue("input must have 4 dims (NCHW)")
         if len(ws) != 4:
@@ -166,11 +162,34 @@ class Conv(Operator):
         ctx.call("rten_hip_conv2d_f32_prepack", C.byref(desc), weight.vp, packed.vp)
         return packed
 
+    def _as_2d(self, x, w):
+        """1-D convolution: expand to 2-D and remove the extra axis from the result (conv.rs:142-182; views, no copies)."""
+        if len(w.shape) != 3:
+            raise InvalidValue("kernel must have 3 dims (OCW)")
+        if not isinstance(self.padding, str):
+            if len(self.padding) != 2:
+                raise InvalidValue("expected 2 pad values")
+            pad2 = [0, self.padding[0], 0, self.padding[1]]
+        else:
+            pad2 = "same"
+        if len(self.strides) != 1:
+            raise InvalidValue("expected 1 stride value")
+        if len(self.dilations) != 1:
+            raise InvalidValue("expected 1 dilation value")
+        op = Conv(self.groups, [1, self.dilations[0]], pad2, [1, self.strides[0]], self.fuse_relu)
+        n, c, wd = x.shape
+        return op, x.view((n, c, 1, wd)), w.view((w.shape[0], w.shape[1], 1, w.shape[2]))
+
     def run(self, ctx, inputs, packed_weight: DeviceTensor | None = None, out: DeviceTensor | None = None):
         x = _want(_require(inputs, 0), np.float32)
         w = _want(_require(inputs, 1), np.float32)
         bias = _get(inputs, 2)
         residual = _get(inputs, 3)
+        if len(x.shape) == 3:
+            op, x2, w2 = self._as_2d(x, w)
+            res2 = residual.view((residual.shape[0], residual.shape[1], 1, residual.shape[2])) if residual is not None else None
+            y = op.run(ctx, [x2, w2, bias, res2], packed_weight=packed_weight)[0]
+            return [y.view((y.shape[0], y.shape[1], y.shape[3]))]
         d = self._geometry(ctx, x.shape, w.shape)
         if bias is not None and bias.shape[0] != d.o:
             raise IncompatibleInputShapes("bias.size(0) != out_channels")

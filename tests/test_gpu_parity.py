@@ -218,6 +218,21 @@ def test_conv_f32_bit_exact(ctx, case):
                ref.conv2d_f32(x, w, None, pads=pads, strides=strides, dilations=dil, groups=groups, relu=True))
 
 
+def test_conv_1d_expands_to_2d(ctx):
+    # conv.rs:142-182: [N, C, W] x [O, C/g, kw] runs as the 2-D convolution with H = kh = 1
+    rng = ref.XorShiftRng(8)
+    x = rng.f32(2 * 8 * 20).reshape(2, 8, 20) - 0.5
+    w = rng.f32(5 * 8 * 3).reshape(5, 8, 3) - 0.5
+    b = rng.f32(5) - 0.5
+    got = ops.Conv(padding=[1, 2], strides=[2], dilations=[1]).run(ctx, [dev(ctx, x), dev(ctx, w), dev(ctx, b)])[0].numpy()
+    want = ref.conv2d_f32(x[:, :, None, :], w[:, :, None, :], b, pads=(0, 1, 0, 2), strides=(1, 2))[:, :, 0, :]
+    bits_equal(got, want)
+    with pytest.raises(ops.OpError, match="expected 1 stride value"):
+        ops.Conv(padding=[1, 2], strides=[1, 1], dilations=[1]).run(ctx, [dev(ctx, x), dev(ctx, w)])
+    with pytest.raises(ops.OpError, match="kernel must have 3 dims"):
+        ops.Conv(padding=[0, 0], strides=[1], dilations=[1]).run(ctx, [dev(ctx, x), dev(ctx, w[:, :, None, :])])
+
+
 def test_conv_f32_reference_literals(ctx):
     import json, os
     g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_literals.json")))["conv"]

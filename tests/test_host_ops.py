@@ -38,7 +38,8 @@ def raises(fn, err):
 
 def test_conv_errors(fctx):
     # conv.rs:1182-1268
-    raises(lambda: ops.Conv(groups=1).run(fctx, [T((1, 2, 3)), T((1, 2, 3, 3))]), ops.UnsupportedValue("1D convolution: expand to 2D on the host before calling the backend")) if False else None
+    raises(lambda: ops.Conv(groups=1).run(fctx, [T((1, 2, 3)), T((1, 2, 3, 3))]), ops.InvalidValue("kernel must have 3 dims (OCW)"))  # 1-D input
+    raises(lambda: ops.Conv(padding=[0, 0], strides=[1, 1], dilations=[1]).run(fctx, [T((1, 2, 9)), T((1, 2, 3))]), ops.InvalidValue("expected 1 stride value"))
     raises(lambda: ops.Conv().run(fctx, [T((1, 2, 3, 3, 3)), T((1, 2, 3, 3))]), ops.InvalidValue("input must have 4 dims (NCHW)"))
     raises(lambda: ops.Conv().run(fctx, [T((1, 2, 5, 5)), T((1, 2, 3))]), ops.InvalidValue("kernel must have 4 dims (OCHW)"))
     raises(lambda: ops.Conv(groups=0).run(fctx, [T((1, 2, 5, 5)), T((1, 2, 3, 3))]), ops.InvalidValue("Group count must be > 0"))
