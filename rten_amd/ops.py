@@ -659,7 +659,11 @@ class Erf(_Unary):
 
 
 class _Binary(Operator):
+    """binary_elementwise.rs:58-170,476-495: numpy broadcasting.  Equal shapes and trailing-dims / per-channel broadcasts take
+    the flat 16-byte kernels; anything else goes through the general stride-0 kernel (rten_hip_binary_broadcast_f32)."""
     fn = ""
+    opcode = 0
+    commutative = True
 
     def max_inputs(self):
         return 2
@@ -667,36 +671,81 @@ class _Binary(Operator):
     def run(self, ctx, inputs, in_place=False):
         a = _want(_require(inputs, 0), np.float32)
         b = _want(_require(inputs, 1), np.float32)
-        if b.size > a.size:  # commutative: largest input is the in-place candidate (graph.rs:977-990)
+        if self.commutative and b.size > a.size:  # largest input is the in-place candidate (graph.rs:977-990)
             a, b = b, a
         bshape = _broadcast_shapes(a.shape, b.shape)
         if bshape is None:
             raise IncompatibleInputShapes("Cannot broadcast inputs")
-        if bshape != tuple(a.shape):
-            raise UnsupportedValue("device path needs one input to have the output shape")
-        y = a if in_place else DeviceTensor(ctx, a.shape, np.float32)
-        bsh = (1,) * (len(a.shape) - len(b.shape)) + tuple(b.shape)
-        # trailing-dims broadcast (b == a's trailing block) or per-channel [1,C,1,1]
-        k = 0
-        while k < len(bsh) and bsh[k] == 1:
-            k += 1
-        if tuple(bsh[k:]) == tuple(a.shape[k:]):
-            ctx.call(self.fn, a.size, a.vp, b.vp, b.size, y.vp)
-        elif self.fn == "rten_hip_add_f32" and len(a.shape) >= 2 and bsh[1] == a.shape[1] and b.size == a.shape[1]:
-            inner = a.size // (a.shape[0] * a.shape[1])
-            ctx.call("rten_hip_add_channel_bias_f32", a.shape[0], a.shape[1], inner, a.vp, b.vp, y.vp)
-        else:
-            raise UnsupportedValue("unsupported broadcast pattern on the device path")
+        if bshape == tuple(a.shape):
+            bsh = (1,) * (len(a.shape) - len(b.shape)) + tuple(b.shape)
+            k = 0
+            while k < len(bsh) and bsh[k] == 1:
+                k += 1
+            if tuple(bsh[k:]) == tuple(a.shape[k:]):  # trailing-dims broadcast (b == a's trailing block)
+                y = a if in_place else DeviceTensor(ctx, a.shape, np.float32)
+                ctx.call(self.fn, a.size, a.vp, b.vp, b.size, y.vp)
+                return [y]
+            if self.fn == "rten_hip_add_f32" and len(a.shape) >= 2 and bsh[1] == a.shape[1] and b.size == a.shape[1]:  # [1,C,1,1]
+                y = a if in_place else DeviceTensor(ctx, a.shape, np.float32)
+                inner = a.size // (a.shape[0] * a.shape[1])
+                ctx.call("rten_hip_add_channel_bias_f32", a.shape[0], a.shape[1], inner, a.vp, b.vp, y.vp)
+                return [y]
+        nd = len(bshape)
+        if nd > 6:
+            raise UnsupportedValue("broadcasting over more than 6 dims is not supported by the device path")
+
+        def strides(shape):
+            sh, st, acc = (1,) * (nd - len(shape)) + tuple(shape), [0] * nd, 1
+            for i in range(nd - 1, -1, -1):
+                st[i] = 0 if sh[i] == 1 else acc
+                acc *= sh[i]
+            return st
+        y = DeviceTensor(ctx, bshape, np.float32)
+        i64 = lambda v: (C.c_int64 * max(len(v), 1))(*v)
+        if y.size:
+            ctx.call("rten_hip_binary_broadcast_f32", self.opcode, nd, i64(list(bshape)), i64(strides(a.shape)), i64(strides(b.shape)), a.vp, b.vp, y.vp)
         return [y]
 
 
 class Add(_Binary):
     """src/ops/binary_elementwise.rs:476-495"""
-    fn = "rten_hip_add_f32"
+    fn, opcode = "rten_hip_add_f32", 0
 
 
 class Mul(_Binary):
-    fn = "rten_hip_mul_f32"
+    fn, opcode = "rten_hip_mul_f32", 1
+
+
+class Sub(_Binary):
+    fn, opcode, commutative = "rten_hip_sub_f32", 2, False
+
+
+class Div(_Binary):
+    fn, opcode, commutative = "rten_hip_div_f32", 3, False
+
+
+class Transpose(Operator):
+    """src/ops/layout.rs:669+: perm None = reverse the axes; 4-byte element types."""
+
+    def __init__(self, perm=None):
+        self.perm = perm
+
+    def max_inputs(self):
+        return 1
+
+    def run(self, ctx, inputs):
+        x = _require(inputs, 0)
+        if x.dtype.itemsize != 4:
+            raise UnsupportedType
+        nd = len(x.shape)
+        perm = list(range(nd - 1, -1, -1)) if self.perm is None else [p + nd if p < 0 else p for p in self.perm]
+        if sorted(perm) != list(range(nd)):
+            raise InvalidValue("Permutation is invalid")
+        y = DeviceTensor(ctx, [x.shape[p] for p in perm], x.dtype)
+        if nd > 6:
+            raise UnsupportedValue("transpose of more than 6 dims is not supported by the device path")
+        ctx.call("rten_hip_transpose_b32", nd, (C.c_int64 * max(nd, 1))(*x.shape), (C.c_int32 * max(nd, 1))(*perm), x.vp, y.vp)
+        return [y]
 
 
 # ------------------------------------------------------------------------------------------ pooling
@@ -857,7 +906,7 @@ class OpRegistry:
     def with_all_ops(cls):
         r = cls()
         for op in (Conv, ConvInteger, ConvIntegerToFloat, MatMul, FusedMatMul, Gemm, MatMulInteger, MatMulIntegerToFloat,
-                   Softmax, AddSoftmax, LayerNormalization, BatchNormalization, Relu, Gelu, Erf, Add, Mul, MaxPool,
+                   Softmax, AddSoftmax, LayerNormalization, BatchNormalization, Relu, Gelu, Erf, Add, Mul, Sub, Div, Transpose, MaxPool,
                    AveragePool, GlobalAveragePool, Flatten, DynamicQuantizeLinear, Attention, Gather):
             r.register_op(op)
         return r

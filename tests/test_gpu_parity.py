@@ -733,6 +733,25 @@ def test_bert_encoder_bit_exact(ctx):
         bits_equal(net.forward().numpy(), want)
 
 
+def test_binary_ops_numpy_broadcasting(ctx):
+    # binary_elementwise.rs:58-170: every numpy broadcast form, through the operator layer
+    rng = ref.XorShiftRng(5)
+    x = rng.f32(2 * 3 * 4 * 5).reshape(2, 3, 4, 5) - 0.5
+    others = [rng.f32(5) + 1, (rng.f32(3) + 1).reshape(3, 1, 1), (rng.f32(2 * 5) + 1).reshape(2, 1, 1, 5), np.float32(1.5).reshape(()), (rng.f32(4) + 1).reshape(4, 1),
+              rng.f32(2 * 3 * 4 * 5).reshape(2, 3, 4, 5) + 1]
+    for o in others:
+        o = np.asarray(o, np.float32)
+        for op, fn in ((ops.Add, np.add), (ops.Mul, np.multiply), (ops.Sub, np.subtract), (ops.Div, np.divide)):
+            bits_equal(op().run(ctx, [dev(ctx, x), dev(ctx, o)])[0].numpy(), fn(x, o))
+            bits_equal(op().run(ctx, [dev(ctx, o), dev(ctx, x)])[0].numpy(), fn(o, x))
+    a, b = rng.f32(3).reshape(3, 1), rng.f32(4).reshape(1, 4)
+    bits_equal(ops.Sub().run(ctx, [dev(ctx, a), dev(ctx, b)])[0].numpy(), a - b)  # neither input has the output shape
+    with pytest.raises(ops.OpError, match="Cannot broadcast"):
+        ops.Add().run(ctx, [dev(ctx, rng.f32(6).reshape(2, 3)), dev(ctx, rng.f32(8).reshape(2, 4))])
+    for perm in (None, (0, 2, 1, 3), (3, 0, 1, 2), (-1, 1, 2, 0)):
+        bits_equal(ops.Transpose(perm).run(ctx, [dev(ctx, x)])[0].numpy(), np.transpose(x, perm))
+
+
 def test_layout_and_broadcast_ops_bit_exact(ctx):
     """Transpose / general broadcasting / Sub / Div (src/ops/layout.rs, binary_elementwise.rs): pure data movement and
     single IEEE operations, so numpy is the exact reference."""
