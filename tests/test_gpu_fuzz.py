@@ -206,3 +206,32 @@ def test_depthwise_conv_integer_ignores_the_padding_quirk(ctx):
                     bits_equal(got, want)
         finally:
             ctx.call("rten_hip_set_int8_path", 0)
+
+
+@pytest.mark.parametrize("seed", range(2))
+def test_pooling_random_geometry(ctx, seed):
+    rng = np.random.default_rng(8000 + seed)
+    done = 0
+    while done < 25:
+        k = (int(rng.integers(1, 5)), int(rng.integers(1, 5)))
+        s = (int(rng.integers(1, 4)), int(rng.integers(1, 4)))
+        p = tuple(int(v) for v in rng.integers(0, 3, 4))
+        if p[0] >= k[0] or p[2] >= k[0] or p[1] >= k[1] or p[3] >= k[1]:
+            continue  # a window must not lie entirely in the padding
+        N, C_, H, W = int(rng.integers(1, 3)), int(rng.integers(1, 7)), int(rng.integers(1, 26)), int(rng.integers(1, 26))
+        if H + p[0] + p[2] < k[0] or W + p[1] + p[3] < k[1]:
+            continue
+        ceil = bool(rng.random() < 0.3)
+        x = rng.random((N, C_, H, W), dtype=np.float32) - 0.5
+        try:
+            want_max = ref.max_pool(x, k, s, p, ceil)
+        except Exception:
+            continue  # geometry the reference rejects
+        bits_equal(ops.MaxPool(k, padding=list(p), strides=s, ceil_mode=ceil).run(ctx, [dev(ctx, x)])[0].numpy(), want_max)
+        for cip in (False, True):
+            bits_equal(ops.AveragePool(k, padding=list(p), strides=s, ceil_mode=ceil, count_include_pad=cip).run(ctx, [dev(ctx, x)])[0].numpy(),
+                       ref.average_pool(x, k, s, p, cip, ceil))
+        done += 1
+    for (nc, inner) in ((1, 1), (7, 49), (130, 64), (5, 65), (3, 1000), (260, 13)):
+        xg = rng.random((nc, 1, inner, 1), dtype=np.float32).reshape(1, nc, inner, 1) - 0.5
+        bits_equal(ops.GlobalAveragePool().run(ctx, [dev(ctx, xg)])[0].numpy(), ref.global_average_pool(xg, lanes=16))
