@@ -284,3 +284,34 @@ def test_cli_safetensors_inputs_and_check_outputs(tmp_path):
     save_file({"y": want + np.float32(0.01)}, str(fexp))
     r = run_cli("-i", str(fin), "--check-outputs", str(fexp), "--max-diff", "1e-6", str(model))
     assert r.returncode == 3 and "max diff 0.01" in r.stdout
+
+
+@pytest.mark.gpu
+def test_graph_load_errors_and_attribute_forms(tmp_path):
+    """An operator outside the registry is a load-time error that names the node (never a CPU fallback); auto_pad = SAME_UPPER,
+    AveragePool attributes, Squeeze / Unsqueeze / Reshape views and a graph output that is a view."""
+    from oracle import ref
+    from rten_amd import onnx_writer as ow
+    rng = np.random.default_rng(11)
+    w = (rng.random((4, 3, 3, 3), dtype=np.float32) - 0.5)
+    bad = ow.model([ow.node("Conv", ["x", "w"], ["a"], name="c0", kernel_shape=[3, 3]), ow.node("FooBar", ["a"], ["y"], name="mystery_node")],
+                   [ow.value_info("x", ow.FLOAT, [1, 3, 8, 8])], [ow.value_info("y", ow.FLOAT, [1, 4, 6, 6])], [ow.tensor("w", w)])
+    p = tmp_path / "bad.onnx"
+    p.write_bytes(bad)
+    r = run_cli(str(p))
+    assert r.returncode == 1 and "mystery_node" in r.stderr and "FooBar" in r.stderr and "no CPU fallback" in r.stderr
+
+    x = rng.random((2, 3, 9, 7), dtype=np.float32) - 0.5
+    b = rng.random(4, dtype=np.float32) - 0.5
+    nodes = [ow.node("Conv", ["x", "w", "b"], ["a"], name="conv_same", kernel_shape=[3, 3], auto_pad="SAME_UPPER", strides=[2, 2]),
+             ow.node("AveragePool", ["a"], ["p"], name="avg", kernel_shape=[2, 2], strides=[1, 1], pads=[0, 0, 1, 1], count_include_pad=1),
+             ow.node("Unsqueeze", ["p", "ax0"], ["p5"], name="unsq"),
+             ow.node("Squeeze", ["p5", "ax0"], ["p4"], name="sq"),
+             ow.node("Reshape", ["p4", "shape"], ["y"], name="reshape")]
+    m = ow.model(nodes, [ow.value_info("x", ow.FLOAT, ["batch", 3, 9, 7])], [ow.value_info("y", ow.FLOAT, ["batch", -1])],
+                 [ow.tensor("w", w), ow.tensor("b", b), ow.tensor("ax0", np.array([0], np.int64)), ow.tensor("shape", np.array([0, -1], np.int64))])
+    oh, ow_, pads = ref.calc_output_size_and_padding((9, 7), (3, 3), (2, 2), "same")
+    a = ref.conv2d_f32(x, w, b, pads=tuple(pads), strides=(2, 2))
+    want = ref.average_pool(a, (2, 2), (1, 1), (0, 0, 1, 1), True, False).reshape(2, -1)
+    got, log = _run_model(tmp_path, m, x, "y")
+    assert np.array_equal(got.view(np.int32), want.ravel().view(np.int32))
