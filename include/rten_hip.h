@@ -277,6 +277,14 @@ int32_t rten_hip_transpose_b32(rten_hip_ctx *ctx, int32_t ndim, const int64_t *x
 int32_t rten_hip_add_channel_bias_f32(rten_hip_ctx *ctx, int32_t n, int32_t c, int64_t inner, const float *x,
                                       const float *bias, float *y);
 
+/* ---- ConvTranspose: src/ops/conv_transpose.rs:226-412 (GEMM into a column matrix + col2im), :144-224 (output size) ----
+ * desc: n, c, h, w = input; o = output channels over all groups; kernel [c, o / groups, kh, kw]; pads / out_h / out_w as
+ * resolved by rten_hip_conv_transpose_output_size (same = Padding::Same; the same error strings through *msg). */
+int32_t rten_hip_conv_transpose_output_size(int32_t in_h, int32_t in_w, int32_t kh, int32_t kw, int32_t stride_h, int32_t stride_w, int32_t same,
+                                            const int32_t pads[4], int32_t dil_h, int32_t dil_w, int32_t out_pad_h, int32_t out_pad_w, int32_t out_hw[2],
+                                            int32_t out_pads[4], const char **msg);
+int32_t rten_hip_conv_transpose2d_f32(rten_hip_ctx *ctx, const rten_hip_conv2d_desc *desc, const float *x, const float *w, const float *bias, float *y);
+
 /* ---- pooling: src/ops/pooling.rs:174-389,392-417,516-521,581-600 ---- */
 typedef struct {
     int32_t n, c, h, w;

@@ -835,6 +835,15 @@ class Graph {
                 st.kind_name = std::string("Conv") + (residual.empty() ? "" : "+Add") + (op->fuse_relu ? "+Relu" : "");
                 st.conv = op;
                 st.run = [op, packed](Context &c, const InputList &in) { return op->run_packed(c, in, packed); };
+            } else if (n.op_type == "ConvTranspose") {
+                auto op = std::make_shared<ConvTranspose>();
+                op->groups = (int)n.get_int("group", 1);
+                op->strides = n.get_ints("strides", {1, 1});
+                op->dilations = n.get_ints("dilations", {1, 1});
+                op->output_padding = n.get_ints("output_padding", {});
+                op->padding = padding_of(n, "ConvTranspose");
+                if (n.attr("output_shape")) throw GraphError("ConvTranspose " + st.name + ": the output_shape attribute is not supported");
+                st.run = [op](Context &c, const InputList &in) { return op->run(c, in); };
             } else if (n.op_type == "ConvInteger") {
                 auto op = std::make_shared<ConvInteger>();
                 op->conv = conv_attrs(n);

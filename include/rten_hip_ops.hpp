@@ -326,6 +326,63 @@ struct Conv : Operator {
     }
 };
 
+// ------------------------------------------------------------------------------------------------ ConvTranspose
+struct ConvTranspose : Operator { // src/ops/conv_transpose.rs:414-458; kernel layout [C, O/g, kh, kw]
+    Padding padding;
+    int groups = 1;
+    std::vector<int> strides{1, 1}, dilations{1, 1}, output_padding; // output_padding empty = zeros
+    const char *name() const override { return "ConvTranspose"; }
+    int max_inputs() const override { return 3; }
+    OutputList run(Context &ctx, const InputList &in) const override {
+        const Tensor &x = want(require(in, 0), DType::F32, "float32"), &w = want(require(in, 1), DType::F32, "float32");
+        const Tensor *bias = get(in, 2);
+        if (x.ndim() == 3) { // 1-D: expand to 2-D, remove the extra axis from the result (conv_transpose.rs:237-291)
+            if (w.ndim() != 3) throw OpError(OpError::InvalidValue, "kernel must have 3 dims (OCW)");
+            ConvTranspose op2 = *this;
+            if (!padding.same) {
+                if (padding.fixed.size() != 2) throw OpError(OpError::InvalidValue, "expected 2 pad values");
+                op2.padding = Padding::Fixed({0, padding.fixed[0], 0, padding.fixed[1]});
+            }
+            if (strides.size() != 1) throw OpError(OpError::InvalidValue, "expected 1 stride value");
+            if (dilations.size() != 1) throw OpError(OpError::InvalidValue, "expected 1 dilation value");
+            if (!output_padding.empty() && output_padding.size() != 1) throw OpError(OpError::InvalidValue, "expected 1 output_padding value");
+            op2.strides = {1, strides[0]};
+            op2.dilations = {1, dilations[0]};
+            if (!output_padding.empty()) op2.output_padding = {0, output_padding[0]};
+            const Tensor x2 = Tensor::view_of(x, {x.size(0), x.size(1), 1, x.size(2)}), w2 = Tensor::view_of(w, {w.size(0), w.size(1), 1, w.size(2)});
+            OutputList out = op2.run(ctx, {&x2, &w2, bias});
+            out[0].reshape({out[0].size(0), out[0].size(1), out[0].size(3)});
+            return out;
+        }
+        if (groups == 0) throw OpError(OpError::InvalidValue, "Group count must be > 0");
+        if (x.ndim() != 4) throw OpError(OpError::InvalidValue, "input must have 4 dims (NCHW)");
+        if (w.ndim() != 4) throw OpError(OpError::InvalidValue, "kernel must have 4 dims (COHW)");
+        const int64_t o = w.size(1) * groups;
+        if (bias && bias->size(0) != o) throw OpError(OpError::IncompatibleInputShapes, "bias.size(0) != out_channels");
+        if (x.size(1) != w.size(0)) throw OpError(OpError::IncompatibleInputShapes, "Input channels does not match kernel input channels");
+        if (w.size(0) % groups != 0) throw OpError(OpError::InvalidValue, "Input channel count not divisible by groups");
+        if (strides.size() != 2) throw OpError(OpError::InvalidValue, "expected 2 stride values");
+        if (dilations.size() != 2) throw OpError(OpError::InvalidValue, "expected 2 dilation values");
+        if (!output_padding.empty() && output_padding.size() != 2) throw OpError(OpError::InvalidValue, "expected 2 output_padding values");
+        if (!padding.same && padding.fixed.size() != 4) throw OpError(OpError::InvalidValue, "Wrong number of pad values");
+        int32_t pads[4] = {0, 0, 0, 0}, out_hw[2], out_pads[4];
+        if (!padding.same) for (int i = 0; i < 4; i++) pads[i] = padding.fixed[(size_t)i];
+        const char *msg = nullptr;
+        if (rten_hip_conv_transpose_output_size((int)x.size(2), (int)x.size(3), (int)w.size(2), (int)w.size(3), strides[0], strides[1], padding.same ? 1 : 0, pads, dilations[0],
+                                                dilations[1], output_padding.empty() ? 0 : output_padding[0], output_padding.empty() ? 0 : output_padding[1], out_hw, out_pads, &msg))
+            throw OpError(OpError::InvalidValue, msg ? msg : "");
+        rten_hip_conv2d_desc d{};
+        d.n = (int)x.size(0); d.c = (int)x.size(1); d.h = (int)x.size(2); d.w = (int)x.size(3); d.o = (int)o; d.kh = (int)w.size(2); d.kw = (int)w.size(3);
+        for (int i = 0; i < 4; i++) d.pads[i] = out_pads[i];
+        d.stride_h = strides[0]; d.stride_w = strides[1]; d.dil_h = dilations[0]; d.dil_w = dilations[1]; d.groups = groups; d.out_h = out_hw[0]; d.out_w = out_hw[1];
+        Tensor y(ctx, {d.n, d.o, d.out_h, d.out_w}, DType::F32);
+        ctx.check(rten_hip_conv_transpose2d_f32(ctx.raw(), &d, (const float *)x.ptr(), (const float *)w.ptr(), (const float *)vp(bias), (float *)y.ptr()));
+        OutputList out;
+        out.push_back(std::move(y));
+        return out;
+    }
+};
+
 // zero_point_to_vec (src/ops/matmul.rs:513-531)
 inline int zero_point_len(const Tensor *zp, int64_t expected) {
     if (!zp) return 0;
@@ -993,6 +1050,7 @@ class OpRegistry {
     static OpRegistry with_all_ops() { // every hot-path operator this backend overrides
         OpRegistry r;
         r.register_op<Conv>("Conv");
+        r.register_op<ConvTranspose>("ConvTranspose");
         r.register_op<ConvInteger>("ConvInteger");
         r.register_op<ConvIntegerToFloat>("ConvIntegerToFloat");
         r.register_op<MatMul>("MatMul");

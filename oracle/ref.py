@@ -172,6 +172,46 @@ def _is_signed(a):
     return 1 if a.dtype == np.int8 else 0
 
 
+def conv_transpose_output_size_and_padding(in_hw, k_hw, padding, strides, dilations=(1, 1), output_padding=(0, 0)):
+    """src/ops/conv_transpose.rs:144-224.  padding: "same" or [top, left, bottom, right].  Returns (oh, ow, pads)."""
+    if 0 in strides:
+        raise ValueError("Strides must be > 0")
+    if 0 in dilations:
+        raise ValueError("Dilations must be > 0")
+    if 0 in k_hw:
+        raise ValueError("Kernel size must be > 0")
+    if 0 in in_hw:
+        raise ValueError("Input width and height must be > 0")
+    ke = [(k - 1) * d + 1 for k, d in zip(k_hw, dilations)]
+    full = [(i - 1) * s + k + op for i, s, k, op in zip(in_hw, strides, ke, output_padding)]
+    if isinstance(padding, str):
+        out = [i * s for i, s in zip(in_hw, strides)]
+        pad = [f - o for f, o in zip(full, out)]
+        if min(pad) < 0:
+            raise ValueError("Input is too small")
+        return out[0], out[1], [pad[0] // 2, pad[1] // 2, -(-pad[0] // 2), -(-pad[1] // 2)]
+    if len(padding) != 4:
+        raise ValueError("Wrong number of pad values")
+    oh, ow = full[0] - padding[0] - padding[2], full[1] - padding[1] - padding[3]
+    if oh < 0 or ow < 0:
+        raise ValueError("Input is too small")
+    return oh, ow, list(padding)
+
+
+def conv_transpose2d_f32(x, w, bias=None, padding=(0, 0, 0, 0), strides=(1, 1), dilations=(1, 1), groups=1, output_padding=(0, 0)):
+    """src/ops/conv_transpose.rs:226-412.  x [N,C,H,W], w [C, O/g, kh, kw]."""
+    x, w = _f32(x), _f32(w)
+    N, Cc, H, W = x.shape
+    _, Og, kh, kw = w.shape
+    oh, ow, pads = conv_transpose_output_size_and_padding((H, W), (kh, kw), padding, strides, dilations, output_padding)
+    y = np.empty((N, Og * groups, oh, ow), np.float32)
+    bias = None if bias is None else _f32(bias)
+    rc = lib().rto_conv_transpose2d_f32(i64(N), i64(Cc), i64(H), i64(W), i64(Og), i64(kh), i64(kw), (i64 * 4)(*pads), (i64 * 2)(*strides),
+                                        (i64 * 2)(*dilations), i64(groups), _p(x), _p(w), _p(bias), _p(y), i64(oh), i64(ow))
+    assert rc == 0
+    return y
+
+
 def gemm_int8(a, b, a_zp=None, b_zp=None, c=None):
     """sum_k (A - a_zp[m]) (B - b_zp[n]) -> i32 (rten-gemm/src/kernels/generic.rs:274-366)."""
     M, K = a.shape

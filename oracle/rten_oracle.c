@@ -374,6 +374,47 @@ RTO_API int rto_conv2d_f32(int64_t N, int64_t C, int64_t H, int64_t W, int64_t O
  * (x - zp) unchanged, so the oracle works on widened integers directly.
  * a_signed / b_signed select how the raw bytes are interpreted.
  * ---------------------------------------------------------------------------------- */
+/* ------------------------------------------------------------------------------------
+ * ConvTranspose -- src/ops/conv_transpose.rs:226-412 (conv_transpose), :80-142 (col2im).
+ * X [N, C, H, W], kernel [C, O/g, kh, kw] ("COHW"), Y [N, O, OH, OW].  Per group and image:
+ *   columns[O_g*kh*kw, H*W] = kernel_mat^T [O_g*kh*kw, C_g] . input_mat [C_g, H*W]      (GemmExecutor::gemm_uninit: alpha 1, beta 0)
+ *   out channel o: every element starts at bias[o] (or 0); then for k_y, k_x in order every column image
+ *   columns[o, k_y, k_x] is accumulated at out[y*stride + k_y*dil - pad_top, x*stride + k_x*dil - pad_left].
+ * An output element receives at most one addend per (k_y, k_x), so its value is bias, then the addends in (k_y, k_x) order.
+ * ---------------------------------------------------------------------------------- */
+RTO_API int rto_conv_transpose2d_f32(int64_t N, int64_t C, int64_t H, int64_t W, int64_t Og, int64_t kh, int64_t kw, const int64_t pads[4],
+                                     const int64_t strides[2], const int64_t dil[2], int64_t groups, const float *X, const float *Wt,
+                                     const float *bias, float *Y, int64_t OH, int64_t OW) {
+    const int64_t Cg = C / groups, M = Og * kh * kw, P = H * W, O = Og * groups;
+    float *cols = (float *)aligned_alloc(64, (size_t)((M * P * sizeof(float) + 63) / 64 * 64 + 64));
+    if (!cols) return -1;
+    for (int64_t g = 0; g < groups; g++)
+        for (int64_t n = 0; n < N; n++) {
+            /* A[m][k] = kernel[(g*Cg + k)][m]: row stride 1, column stride M (the transposed kernel matrix) */
+            rto_gemm_f32(M, P, Cg, Wt + g * Cg * M, 1, M, X + (n * C + g * Cg) * P, P, 1, cols, P, 1.0f, 0.0f, NULL, 0);
+            for (int64_t o = 0; o < Og; o++) {
+                float *out = Y + (n * O + g * Og + o) * OH * OW;
+                const float b = bias ? bias[g * Og + o] : 0.0f;
+                for (int64_t i = 0; i < OH * OW; i++) out[i] = b;
+                for (int64_t ky = 0; ky < kh; ky++)
+                    for (int64_t kx = 0; kx < kw; kx++) {
+                        const float *img = cols + ((o * kh + ky) * kw + kx) * P;
+                        for (int64_t y = 0; y < H; y++) {
+                            const int64_t oy = y * strides[0] + ky * dil[0] - pads[0];
+                            if (oy < 0 || oy >= OH) continue;
+                            for (int64_t x = 0; x < W; x++) {
+                                const int64_t ox = x * strides[1] + kx * dil[1] - pads[1];
+                                if (ox < 0 || ox >= OW) continue;
+                                out[oy * OW + ox] = out[oy * OW + ox] + img[y * W + x];
+                            }
+                        }
+                    }
+            }
+        }
+    free(cols);
+    return 0;
+}
+
 static inline int32_t ld8(const void *p, int64_t i, int is_signed) {
     return is_signed ? (int32_t)((const int8_t *)p)[i] : (int32_t)((const uint8_t *)p)[i];
 }

@@ -41,6 +41,21 @@ void *rten_scratch(rten_hip_ctx *ctx, size_t bytes) {
     return ctx->scratch;
 }
 
+void *rten_aux_scratch(rten_hip_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->aux_bytes) return ctx->aux;
+    if (ctx->capturing) return nullptr;
+    if (ctx->aux) {
+        hipStreamSynchronize(ctx->stream);
+        hipFree(ctx->aux);
+        ctx->aux = nullptr;
+        ctx->aux_bytes = 0;
+    }
+    const size_t want = bytes + bytes / 4;
+    if (hipMalloc(&ctx->aux, want) != hipSuccess) return nullptr;
+    ctx->aux_bytes = want;
+    return ctx->aux;
+}
+
 static hipEvent_t get_event(rten_hip_ctx *ctx) {
     if (!ctx->event_pool.empty()) {
         hipEvent_t e = ctx->event_pool.back();
@@ -134,6 +149,7 @@ RTEN_EXPORT int32_t rten_hip_destroy(rten_hip_ctx *ctx) {
         for (hipEvent_t e : t)
             if (e) hipEventDestroy(e);
     if (ctx->scratch) hipFree(ctx->scratch);
+    if (ctx->aux) hipFree(ctx->aux);
     for (auto &kv : ctx->luts) hipFree(kv.second);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;

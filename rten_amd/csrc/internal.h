@@ -38,6 +38,8 @@ struct rten_hip_ctx {
     // scratch (grown on demand, never during capture)
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
+    void *aux = nullptr; // second grow-only buffer for operators that call the GEMM (which owns `scratch`) on an intermediate of their own
+    size_t aux_bytes = 0;
     std::map<std::string, void *> luts; // im2col lookup tables, keyed by conv geometry (gemm_f32.hip)
     int gemm_variant_override = -1;
     int pipeline = 1; // conv paths: 0 register-staged, 1 LDS-DMA, 2 LDS-DMA + wave specialisation
@@ -62,6 +64,7 @@ inline int rten_effective_pad_mode(const rten_hip_conv2d_int8_desc *di) {
 int32_t rten_set_error(rten_hip_ctx *ctx, int32_t code, const char *fmt, ...);
 int32_t rten_check_hip(rten_hip_ctx *ctx, hipError_t e, const char *what);
 void *rten_scratch(rten_hip_ctx *ctx, size_t bytes);
+void *rten_aux_scratch(rten_hip_ctx *ctx, size_t bytes);
 
 // Profiling bracket around one kernel launch.
 struct ProfScope {

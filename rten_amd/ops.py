@@ -201,6 +201,78 @@ class Conv(Operator):
         return [y]
 
 
+class ConvTranspose(Operator):
+    """src/ops/conv_transpose.rs:414-458 (op), :226-412 (conv_transpose).  inputs: X [N,C,H,W] (or [N,C,W]), W [C, O/g, kh, kw], bias [O]?"""
+
+    def __init__(self, padding=(0, 0, 0, 0), groups=1, strides=(1, 1), dilations=(1, 1), output_padding=None):
+        self.padding = padding
+        self.groups = groups
+        self.strides = list(strides)
+        self.dilations = list(dilations)
+        self.output_padding = None if output_padding is None else list(output_padding)
+
+    def max_inputs(self):
+        return 3
+
+    def run(self, ctx, inputs):
+        x = _want(_require(inputs, 0), np.float32)
+        w = _want(_require(inputs, 1), np.float32)
+        bias = _get(inputs, 2)
+        if len(x.shape) == 3:  # 1-D: expand to 2-D, remove the extra axis from the result (conv_transpose.rs:237-291)
+            if len(w.shape) != 3:
+                raise InvalidValue("kernel must have 3 dims (OCW)")
+            if not isinstance(self.padding, str):
+                if len(self.padding) != 2:
+                    raise InvalidValue("expected 2 pad values")
+                pad2 = [0, self.padding[0], 0, self.padding[1]]
+            else:
+                pad2 = self.padding
+            if len(self.strides) != 1:
+                raise InvalidValue("expected 1 stride value")
+            if len(self.dilations) != 1:
+                raise InvalidValue("expected 1 dilation value")
+            if self.output_padding is not None and len(self.output_padding) != 1:
+                raise InvalidValue("expected 1 output_padding value")
+            op = ConvTranspose(pad2, self.groups, [1, self.strides[0]], [1, self.dilations[0]], [0, self.output_padding[0]] if self.output_padding else None)
+            y = op.run(ctx, [x.view((x.shape[0], x.shape[1], 1, x.shape[2])), w.view((w.shape[0], w.shape[1], 1, w.shape[2])), bias])[0]
+            return [y.view((y.shape[0], y.shape[1], y.shape[3]))]
+        if self.groups == 0:
+            raise InvalidValue("Group count must be > 0")
+        if len(x.shape) != 4:
+            raise InvalidValue("input must have 4 dims (NCHW)")
+        if len(w.shape) != 4:
+            raise InvalidValue("kernel must have 4 dims (COHW)")
+        n, c, h, wd = x.shape
+        kc, og, kh, kw = w.shape
+        o = og * self.groups
+        if bias is not None and bias.shape[0] != o:
+            raise IncompatibleInputShapes("bias.size(0) != out_channels")
+        if c != kc:
+            raise IncompatibleInputShapes("Input channels does not match kernel input channels")
+        if kc % self.groups != 0:
+            raise InvalidValue("Input channel count not divisible by groups")
+        if len(self.strides) != 2:
+            raise InvalidValue("expected 2 stride values")
+        if len(self.dilations) != 2:
+            raise InvalidValue("expected 2 dilation values")
+        if self.output_padding is not None and len(self.output_padding) != 2:
+            raise InvalidValue("expected 2 output_padding values")
+        op_h, op_w = self.output_padding or (0, 0)
+        same = isinstance(self.padding, str)
+        if not same and len(self.padding) != 4:
+            raise InvalidValue("Wrong number of pad values")
+        pads = (C.c_int32 * 4)(*([0, 0, 0, 0] if same else [int(p) for p in self.padding]))
+        out_hw, out_pads, msg = (C.c_int32 * 2)(), (C.c_int32 * 4)(), C.c_char_p()
+        rc = ctx.lib.rten_hip_conv_transpose_output_size(h, wd, kh, kw, self.strides[0], self.strides[1], 1 if same else 0, pads, self.dilations[0], self.dilations[1],
+                                                         op_h, op_w, out_hw, out_pads, C.byref(msg))
+        if rc:
+            raise InvalidValue(msg.value.decode() if msg.value else "")
+        d = L.Conv2dDesc(n, c, h, wd, o, kh, kw, out_pads, self.strides[0], self.strides[1], self.dilations[0], self.dilations[1], self.groups, out_hw[0], out_hw[1])
+        y = DeviceTensor(ctx, (n, o, out_hw[0], out_hw[1]), np.float32)
+        ctx.call("rten_hip_conv_transpose2d_f32", C.byref(d), x.vp, w.vp, _vp(bias), y.vp)
+        return [y]
+
+
 class ConvInteger(Operator):
     """src/ops/conv.rs:478-526.  inputs: X u8|i8, W i8|u8, x_zero_point (scalar)?, w_zero_point (scalar|[O])?"""
 
@@ -905,7 +977,7 @@ class OpRegistry:
     @classmethod
     def with_all_ops(cls):
         r = cls()
-        for op in (Conv, ConvInteger, ConvIntegerToFloat, MatMul, FusedMatMul, Gemm, MatMulInteger, MatMulIntegerToFloat,
+        for op in (Conv, ConvTranspose, ConvInteger, ConvIntegerToFloat, MatMul, FusedMatMul, Gemm, MatMulInteger, MatMulIntegerToFloat,
                    Softmax, AddSoftmax, LayerNormalization, BatchNormalization, Relu, Gelu, Erf, Add, Mul, Sub, Div, Transpose, MaxPool,
                    AveragePool, GlobalAveragePool, Flatten, DynamicQuantizeLinear, Attention, Gather):
             r.register_op(op)

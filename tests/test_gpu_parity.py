@@ -233,6 +233,35 @@ def test_conv_1d_expands_to_2d(ctx):
         ops.Conv(padding=[0, 0], strides=[1], dilations=[1]).run(ctx, [dev(ctx, x), dev(ctx, w[:, :, None, :])])
 
 
+def test_conv_transpose(ctx):
+    # literals of test_conv_transpose / _padding / _1d (conv_transpose.rs:603-760) and bit-exact sweeps of the cases the
+    # reference's own tests run (groups, dilations, output_padding, uneven padding, empty input ranges)
+    x = np.array([1.0, 2.0, 3.0, 4.0], np.float32).reshape(1, 1, 2, 2)
+    k = np.array([0.1, 0.2, 0.3, 0.4], np.float32).reshape(1, 1, 2, 2)
+    got = ops.ConvTranspose(strides=[2, 2]).run(ctx, [dev(ctx, x), dev(ctx, k)])[0].numpy()
+    np.testing.assert_allclose(got.ravel(), [0.1, 0.2, 0.2, 0.4, 0.3, 0.4, 0.6, 0.8, 0.3, 0.6, 0.4, 0.8, 0.9, 1.2, 1.2, 1.6], rtol=1e-6)
+    got = ops.ConvTranspose(strides=[2, 2]).run(ctx, [dev(ctx, x), dev(ctx, k), dev(ctx, np.array([1.234], np.float32))])[0].numpy()
+    np.testing.assert_allclose(got.ravel(), np.array([0.1, 0.2, 0.2, 0.4, 0.3, 0.4, 0.6, 0.8, 0.3, 0.6, 0.4, 0.8, 0.9, 1.2, 1.2, 1.6]) + 1.234, rtol=1e-6)
+    np.testing.assert_allclose(ops.ConvTranspose(padding=[1, 1, 1, 1], strides=[2, 2]).run(ctx, [dev(ctx, x), dev(ctx, k)])[0].numpy().ravel(), [0.4, 0.6, 0.6, 0.4], rtol=1e-6)
+    assert ops.ConvTranspose(padding="same", strides=[2, 2]).run(ctx, [dev(ctx, x), dev(ctx, k)])[0].shape == (1, 1, 4, 4)
+    got = ops.ConvTranspose(padding=[0, 0], strides=[2], dilations=[1]).run(ctx, [dev(ctx, x.reshape(1, 1, 4)[:, :, :2].copy()), dev(ctx, k.reshape(1, 1, 4)[:, :, :2].copy())])[0].numpy()
+    np.testing.assert_allclose(got.ravel(), [0.1, 0.2, 0.2, 0.4], rtol=1e-6)
+    rng = np.random.default_rng(12)
+    for (N, Cc, H, W, og, kh, kw, pads, strides, dil, groups, opad) in ((2, 6, 5, 7, 4, 3, 2, (1, 0, 2, 1), (2, 3), (1, 2), 2, (1, 0)), (1, 4, 8, 8, 3, 4, 4, (1, 1, 1, 1), (2, 2), (1, 1), 1, (0, 0)),
+                                                                          (3, 3, 1, 9, 5, 1, 3, (0, 2, 0, 2), (1, 1), (1, 1), 3, (0, 0)), (1, 300, 6, 6, 8, 2, 2, (0, 0, 0, 0), (2, 2), (1, 1), 1, (1, 1)),
+                                                                          (1, 2, 3, 3, 2, 3, 3, (2, 2, 2, 2), (3, 3), (1, 1), 1, (0, 0))):
+        x = rng.random((N, Cc, H, W), dtype=np.float32) - 0.5
+        w = rng.random((Cc, og, kh, kw), dtype=np.float32) - 0.5
+        b = rng.random(og * groups, dtype=np.float32) - 0.5
+        op = ops.ConvTranspose(padding=list(pads), groups=groups, strides=list(strides), dilations=list(dil), output_padding=list(opad))
+        bits_equal(op.run(ctx, [dev(ctx, x), dev(ctx, w), dev(ctx, b)])[0].numpy(), ref.conv_transpose2d_f32(x, w, b, pads, strides, dil, groups, opad))
+        bits_equal(op.run(ctx, [dev(ctx, x), dev(ctx, w)])[0].numpy(), ref.conv_transpose2d_f32(x, w, None, pads, strides, dil, groups, opad))
+    with pytest.raises(ops.OpError, match="Input channels does not match kernel input channels"):
+        ops.ConvTranspose().run(ctx, [dev(ctx, x), dev(ctx, rng.random((5, 2, 3, 3), dtype=np.float32))])
+    with pytest.raises(ops.OpError, match="Input is too small"):
+        ops.ConvTranspose(padding=[9, 9, 9, 9]).run(ctx, [dev(ctx, x), dev(ctx, w)])
+
+
 def test_conv_f32_reference_literals(ctx):
     import json, os
     g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_literals.json")))["conv"]

@@ -315,3 +315,19 @@ def test_graph_load_errors_and_attribute_forms(tmp_path):
     want = ref.average_pool(a, (2, 2), (1, 1), (0, 0, 1, 1), True, False).reshape(2, -1)
     got, log = _run_model(tmp_path, m, x, "y")
     assert np.array_equal(got.view(np.int32), want.ravel().view(np.int32))
+
+
+@pytest.mark.gpu
+def test_conv_transpose_node_in_a_graph(tmp_path):
+    from oracle import ref
+    from rten_amd import onnx_writer as ow
+    rng = np.random.default_rng(13)
+    x = rng.random((2, 4, 6, 5), dtype=np.float32) - 0.5
+    w = rng.random((4, 3, 3, 3), dtype=np.float32) - 0.5
+    b = rng.random(6, dtype=np.float32) - 0.5
+    nodes = [ow.node("ConvTranspose", ["x", "w", "b"], ["u"], name="up", kernel_shape=[3, 3], strides=[2, 2], pads=[1, 1, 1, 1], group=2, output_padding=[1, 1]),
+             ow.node("Relu", ["u"], ["y"], name="relu")]
+    m = ow.model(nodes, [ow.value_info("x", ow.FLOAT, ["batch", 4, 6, 5])], [ow.value_info("y", ow.FLOAT, ["batch", 6, 12, 10])], [ow.tensor("w", w), ow.tensor("b", b)])
+    want = ref.relu(ref.conv_transpose2d_f32(x, w, b, (1, 1, 1, 1), (2, 2), (1, 1), 2, (1, 1)))
+    got, _ = _run_model(tmp_path, m, x, "y")
+    assert np.array_equal(got.view(np.int32), want.ravel().view(np.int32))

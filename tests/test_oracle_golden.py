@@ -80,6 +80,27 @@ def test_conv_depthwise_literal_and_operation_order():
         assert np.array_equal(got.view(np.int32), want.view(np.int32))
 
 
+def test_conv_transpose_literals():
+    """conv_transpose.rs:603-760 (test_conv_transpose, _padding, _1d) + output-size cases + torch as an independent restatement."""
+    x = np.array([1.0, 2.0, 3.0, 4.0], np.float32).reshape(1, 1, 2, 2)
+    k = np.array([0.1, 0.2, 0.3, 0.4], np.float32).reshape(1, 1, 2, 2)
+    eq_1e4(ref.conv_transpose2d_f32(x, k, strides=(2, 2)).ravel(), [0.1, 0.2, 0.2, 0.4, 0.3, 0.4, 0.6, 0.8, 0.3, 0.6, 0.4, 0.8, 0.9, 1.2, 1.2, 1.6])
+    eq_1e4(ref.conv_transpose2d_f32(x, k, padding=(1, 1, 1, 1), strides=(2, 2)).ravel(), [0.4, 0.6, 0.6, 0.4])
+    assert ref.conv_transpose2d_f32(x, k, padding="same", strides=(2, 2)).shape == (1, 1, 4, 4)
+    eq_1e4(ref.conv_transpose2d_f32(x[:, :, :1, :], k[:, :, :1, :], strides=(1, 2)).ravel(), [0.1, 0.2, 0.2, 0.4])  # the 1-D case as 2-D
+    assert ref.conv_transpose_output_size_and_padding((5, 5), (3, 3), "same", (2, 2)) == (10, 10, [0, 0, 1, 1])
+    with pytest.raises(ValueError, match="Input is too small"):
+        ref.conv_transpose_output_size_and_padding((1, 1), (1, 1), [2, 2, 2, 2], (1, 1))
+    import torch
+    rng = np.random.default_rng(0)
+    x = rng.random((2, 6, 5, 7), dtype=np.float32) - 0.5
+    w = rng.random((6, 4, 3, 2), dtype=np.float32) - 0.5
+    b = rng.random(8, dtype=np.float32)
+    got = ref.conv_transpose2d_f32(x, w, b, padding=(1, 0, 2, 1), strides=(2, 3), dilations=(1, 2), groups=2, output_padding=(1, 0))
+    want = torch.nn.functional.conv_transpose2d(torch.tensor(x), torch.tensor(w), torch.tensor(b), stride=(2, 3), dilation=(1, 2), groups=2, output_padding=(1, 0)).numpy()
+    np.testing.assert_allclose(got, want[:, :, 1:want.shape[2] - 2, 0:want.shape[3] - 1], rtol=1e-5, atol=1e-6)
+
+
 def test_layer_norm_literals():
     for c in G["layer_norm"]["cases"]:
         x = np.array(c["input"], np.float32)
