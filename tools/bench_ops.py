@@ -105,6 +105,18 @@ def main():
     hbm("MaxPool 3x3/2", "32x64x112x112", (lambda: ctx.call("rten_hip_max_pool2d_f32", C.byref(pd), x.vp, y.vp)), 4.0 * (n_in + n_out))
     hbm("GlobalAveragePool", "32x2048x7x7", (lambda: ctx.call("rten_hip_global_average_pool_f32", 32 * 2048, 49, x.vp, y.vp)), 4.0 * 32 * 2048 * 50)
 
+    # depthwise 3x3 (MobileNet-style: 32 x 144 x 56 x 56) and a 2x upsampling ConvTranspose (32 x 64 x 28 x 28 -> 32 x 32 x 56 x 56, 4x4 / 2)
+    cdw = 144
+    xdw, wdw, bdw = dev(rng.standard_normal((32, cdw, 56, 56), dtype=np.float32)), dev(rng.standard_normal((cdw, 1, 3, 3), dtype=np.float32)), dev(np.zeros(cdw, np.float32))
+    ydw = empty((32, cdw, 56, 56))
+    ddw = L.Conv2dDesc(32, cdw, 56, 56, cdw, 3, 3, (C.c_int32 * 4)(1, 1, 1, 1), 1, 1, 1, 1, cdw, 56, 56)
+    hbm("Conv depthwise 3x3", f"32x{cdw}x56x56", (lambda: ctx.call("rten_hip_conv2d_f32", C.byref(ddw), xdw.vp, wdw.vp, 0, bdw.vp, None, 0, ydw.vp)), 8.0 * 32 * cdw * 56 * 56)
+    xct, wct, bct = dev(rng.standard_normal((32, 64, 28, 28), dtype=np.float32)), dev(rng.standard_normal((64, 32, 4, 4), dtype=np.float32)), dev(np.zeros(32, np.float32))
+    yct = empty((32, 32, 56, 56))
+    dct = L.Conv2dDesc(32, 64, 28, 28, 32, 4, 4, (C.c_int32 * 4)(1, 1, 1, 1), 2, 2, 1, 1, 1, 56, 56)
+    mfma("ConvTranspose 4x4/2", "32x64x28x28 -> 32", (lambda: ctx.call("rten_hip_conv_transpose2d_f32", C.byref(dct), xct.vp, wct.vp, bct.vp, yct.vp)),
+         2.0 * 32 * 64 * 28 * 28 * 32 * 16, F32_PEAK_TF, "TFLOP/s")
+
     # ---- f32 GEMM on BERT-base shapes (batch 32 x 128 tokens)
     for (m, k, n, act, name) in ((4096, 768, 768, 0, "MatMul proj"), (4096, 768, 3072, L.ACT_GELU, "MatMul FFN1 + Gelu"), (4096, 3072, 768, 0, "MatMul FFN2")):
         a, w, bias, out = dev(rng.standard_normal((m, k), dtype=np.float32)), dev(rng.standard_normal((k, n), dtype=np.float32)), dev(np.zeros(n, np.float32)), empty((m, n))
