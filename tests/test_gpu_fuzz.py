@@ -156,7 +156,7 @@ def test_matmul_integer_random(ctx, seed):
             ctx.call("rten_hip_set_int8_path", 0)
 
 
-@pytest.mark.parametrize("seed", range(3))
+@pytest.mark.parametrize("seed", range(5))
 def test_depthwise_conv_f32_random_geometry(ctx, seed):
     """groups == C == O: the reference's depthwise kernel (conv/depthwise.rs) -- bias-first accumulator, separate multiply and add,
     padded taps skipped -- replayed per output element; window sizes with and without the unrolled instantiations."""
@@ -168,6 +168,13 @@ def test_depthwise_conv_f32_random_geometry(ctx, seed):
         dil = (int(rng.choice([1, 1, 2])), int(rng.choice([1, 1, 2])))
         pads = tuple(int(v) for v in rng.integers(0, 4, 4))
         H, W = int(rng.integers(1, 24)), int(rng.integers(1, 24))
+        if rng.random() < 0.4:  # steer some cases onto the four-outputs-per-thread 3x3 kernel (out_w % 4 == 0, dilation 1, stride_w 1 or 2)
+            kh, kw, dil = 3, 3, (1, 1)
+            strides = (int(rng.integers(1, 3)), int(rng.integers(1, 3)))
+            ow = 4 * int(rng.integers(1, 7))
+            W = (ow - 1) * strides[1] + 3 - pads[1] - pads[3]
+            if W < 1:
+                continue
         if H + pads[0] + pads[2] < dil[0] * (kh - 1) + 1 or W + pads[1] + pads[3] < dil[1] * (kw - 1) + 1:
             continue
         if (kh, kw) == (1, 1) and strides == (1, 1) and pads == (0, 0, 0, 0) and C_ == 1:
