@@ -56,6 +56,53 @@ __global__ __launch_bounds__(256) void depthwise_conv2d_f32_kernel(const rten_hi
     y[oi] = acc;
 }
 
+// 3 x 3 window, dilation 1, stride_h SH: four VERTICALLY adjacent outputs per thread (lanes still walk x, so every load and store
+// stays coalesced).  The ((4-1)*SH + 3) x 3 input patch is loaded once and each output replays its own (k_y, k_x)-ordered
+// sequence from registers: the arithmetic per output element is unchanged, the kernel issues half the loads and a quarter of
+// the workgroups.
+template <int SH>
+__global__ __launch_bounds__(256) void depthwise3x3_y4_kernel(const rten_hip_conv2d_desc d, const float *__restrict__ x, const float *__restrict__ w, int w_stride,
+                                                             const float *__restrict__ bias, const float *__restrict__ residual, int relu, float *__restrict__ y) {
+    constexpr int NROW = 3 * SH + 3;
+    const int hq = (d.out_h + 3) >> 2, items = hq * d.out_w;
+    const int q = blockIdx.y * 256 + threadIdx.x;
+    if (q >= items) return;
+    const int nc = blockIdx.x, c = nc % d.c;
+    const int yq = q / d.out_w, ox = q - yq * d.out_w, oy0 = yq * 4;
+    const float *xc = x + (long long)nc * d.h * d.w;
+    const float *wc = w + (long long)c * 9 * w_stride;
+    const int y0 = oy0 * SH - d.pads[0], x0 = ox * d.stride_w - d.pads[1];
+    float xv[NROW][3], wv[9];
+    bool rok[NROW], cok[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; kx++) cok[kx] = (unsigned)(x0 + kx) < (unsigned)d.w;
+#pragma unroll
+    for (int r = 0; r < NROW; r++) {
+        const int iy = y0 + r;
+        rok[r] = (unsigned)iy < (unsigned)d.h;
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) xv[r][kx] = xc[(rok[r] && cok[kx]) ? iy * d.w + x0 + kx : 0];
+    }
+#pragma unroll
+    for (int t = 0; t < 9; t++) wv[t] = wc[t * w_stride];
+    const float b = bias ? bias[c] : 0.0f;
+    const long long o0 = (long long)nc * d.out_h * d.out_w + ox;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (oy0 + j >= d.out_h) break;
+        float acc = b;
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++)
+                if (rok[j * SH + ky] && cok[kx]) acc = __fadd_rn(acc, __fmul_rn(xv[j * SH + ky][kx], wv[ky * 3 + kx]));
+        const long long oi = o0 + (long long)(oy0 + j) * d.out_w;
+        if (residual) acc = acc + residual[oi];
+        if (relu) acc = vm::relu(acc);
+        y[oi] = acc;
+    }
+}
+
 } // namespace
 
 // Called by rten_hip_conv2d_f32 for groups == C == O geometries (weights OIHW [C,1,kh,kw], or the prepacked form whose
@@ -69,7 +116,13 @@ int32_t rten_depthwise_conv2d_f32(rten_hip_ctx *ctx, const rten_hip_conv2d_desc 
     const int ws = weights_packed ? 4 : 1, relu = (flags & RTEN_HIP_CONV_RELU) ? 1 : 0;
     const float *res = (flags & RTEN_HIP_CONV_RESIDUAL) ? residual : nullptr;
     ProfScope ps(ctx, "depthwise_conv2d_f32", 2.0 * planes * plane * d->kh * d->kw, 4.0 * (planes * (double)d->h * d->w + planes * (double)plane));
-    if (d->kh == 3 && d->kw == 3) hipLaunchKernelGGL((depthwise_conv2d_f32_kernel<3, 3>), grid, dim3(256), 0, ctx->stream, *d, x, w, ws, bias, res, relu, y);
+    const bool y4 = d->kh == 3 && d->kw == 3 && d->dil_h == 1 && d->dil_w == 1 && (d->stride_h == 1 || d->stride_h == 2) && d->out_h >= 4;
+    if (y4) {
+        const long long items = (long long)((d->out_h + 3) / 4) * d->out_w;
+        const dim3 grid4((unsigned)planes, (unsigned)((items + 255) / 256));
+        if (d->stride_h == 1) hipLaunchKernelGGL((depthwise3x3_y4_kernel<1>), grid4, dim3(256), 0, ctx->stream, *d, x, w, ws, bias, res, relu, y);
+        else hipLaunchKernelGGL((depthwise3x3_y4_kernel<2>), grid4, dim3(256), 0, ctx->stream, *d, x, w, ws, bias, res, relu, y);
+    } else if (d->kh == 3 && d->kw == 3) hipLaunchKernelGGL((depthwise_conv2d_f32_kernel<3, 3>), grid, dim3(256), 0, ctx->stream, *d, x, w, ws, bias, res, relu, y);
     else if (d->kh == 5 && d->kw == 5) hipLaunchKernelGGL((depthwise_conv2d_f32_kernel<5, 5>), grid, dim3(256), 0, ctx->stream, *d, x, w, ws, bias, res, relu, y);
     else hipLaunchKernelGGL((depthwise_conv2d_f32_kernel<0, 0>), grid, dim3(256), 0, ctx->stream, *d, x, w, ws, bias, res, relu, y);
     RTEN_LAUNCH_CHECK(ctx, "depthwise_conv2d_f32_kernel launch");
