@@ -59,6 +59,47 @@ __global__ __launch_bounds__(256) void pool2d_kernel(const rten_hip_pool2d_desc 
     y[(long long)blockIdx.x * plane + o] = acc;
 }
 
+// 3 x 3 window, stride_h SH: four vertically adjacent outputs per thread (lanes walk x: coalesced).  The patch of (4-1)*SH + 3
+// rows x 3 columns is loaded once; every output folds its own window in (ky, kx) order from registers.
+template <bool IS_MAX, int SH>
+__global__ __launch_bounds__(256) void pool3x3_y4_kernel(const rten_hip_pool2d_desc d, const float *__restrict__ x, float *__restrict__ y) {
+    constexpr int NROW = 3 * SH + 3;
+    const int hq = (d.out_h + 3) >> 2, items = hq * d.out_w;
+    const int q = blockIdx.y * 256 + threadIdx.x;
+    if (q >= items) return;
+    const int yq = q / d.out_w, ox = q - yq * d.out_w, oy0 = yq * 4;
+    const float *in = x + (long long)blockIdx.x * d.h * d.w;
+    const int y0 = oy0 * SH - d.pads[0], x0 = ox * d.stride_w - d.pads[1];
+    float xv[NROW][3];
+    bool rok[NROW], cok[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; kx++) cok[kx] = (unsigned)(x0 + kx) < (unsigned)d.w;
+#pragma unroll
+    for (int r = 0; r < NROW; r++) {
+        const int iy = y0 + r;
+        rok[r] = (unsigned)iy < (unsigned)d.h;
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) xv[r][kx] = in[(rok[r] && cok[kx]) ? iy * d.w + x0 + kx : 0];
+    }
+    float *out = y + (long long)blockIdx.x * d.out_h * d.out_w + ox;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (oy0 + j >= d.out_h) break;
+        float acc = IS_MAX ? -__builtin_inff() : 0.f;
+        int cnt = 0;
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++)
+                if (rok[j * SH + ky] && cok[kx]) {
+                    acc = IS_MAX ? fmaxf(acc, xv[j * SH + ky][kx]) : acc + xv[j * SH + ky][kx];
+                    cnt++;
+                }
+        if (!IS_MAX) acc = d.count_include_pad ? acc / 9.0f : acc / (float)cnt;
+        out[(long long)(oy0 + j) * d.out_w] = acc;
+    }
+}
+
 template <bool IS_MAX>
 int32_t run_pool(rten_hip_ctx *ctx, const rten_hip_pool2d_desc *d, const float *x, float *y, const char *name) {
     RTEN_CHECK_CTX(ctx);
@@ -74,7 +115,12 @@ int32_t run_pool(rten_hip_ctx *ctx, const rten_hip_pool2d_desc *d, const float *
         return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "pool: plane too large");
     const dim3 grid((unsigned)planes, (unsigned)((plane_out + 255) / 256));
     ProfScope ps(ctx, name, 0.0, 4.0 * ((double)d->n * d->c * d->h * d->w + (double)total));
-    if (d->kh == 3 && d->kw == 3) hipLaunchKernelGGL((pool2d_kernel<IS_MAX, 3, 3>), grid, dim3(256), 0, ctx->stream, *d, x, y);
+    if (d->kh == 3 && d->kw == 3 && (d->stride_h == 1 || d->stride_h == 2) && d->out_h >= 4) {
+        const long long items = (long long)((d->out_h + 3) / 4) * d->out_w;
+        const dim3 grid4((unsigned)planes, (unsigned)((items + 255) / 256));
+        if (d->stride_h == 1) hipLaunchKernelGGL((pool3x3_y4_kernel<IS_MAX, 1>), grid4, dim3(256), 0, ctx->stream, *d, x, y);
+        else hipLaunchKernelGGL((pool3x3_y4_kernel<IS_MAX, 2>), grid4, dim3(256), 0, ctx->stream, *d, x, y);
+    } else if (d->kh == 3 && d->kw == 3) hipLaunchKernelGGL((pool2d_kernel<IS_MAX, 3, 3>), grid, dim3(256), 0, ctx->stream, *d, x, y);
     else if (d->kh == 2 && d->kw == 2) hipLaunchKernelGGL((pool2d_kernel<IS_MAX, 2, 2>), grid, dim3(256), 0, ctx->stream, *d, x, y);
     else hipLaunchKernelGGL((pool2d_kernel<IS_MAX, 0, 0>), grid, dim3(256), 0, ctx->stream, *d, x, y);
     RTEN_LAUNCH_CHECK(ctx, name);
