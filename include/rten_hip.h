@@ -285,6 +285,14 @@ int32_t rten_hip_conv_transpose_output_size(int32_t in_h, int32_t in_w, int32_t 
                                             int32_t out_pads[4], const char **msg);
 int32_t rten_hip_conv_transpose2d_f32(rten_hip_ctx *ctx, const rten_hip_conv2d_desc *desc, const float *x, const float *w, const float *bias, float *y);
 
+/* ---- MatMulNBits (com.microsoft contrib op): src/ops/matmul/contrib.rs:21-106, rten-gemm/src/block_quant.rs:61-141 (vector x
+ * matrix), rten-gemm/src/packing.rs:229-318 (dequantise-while-packing for the ordinary GEMM) ----
+ * a [batch][rows][k] f32; b_quant [n][k / block_size][block_size / 2] packed 4-bit (even element low nibble), zero point 8;
+ * scales [n][k / block_size]; y [batch][rows][n].  block_size: power of two >= 16 ("Unsupported K block size" otherwise).
+ * rows == 1 reproduces the reference's 64-slot accumulation order, rows > 1 its f32 GEMM on the dequantised matrix. */
+int32_t rten_hip_matmul_nbits_f32(rten_hip_ctx *ctx, int64_t batch, int32_t rows, int32_t k, int32_t n, int32_t block_size, const float *a,
+                                  const uint8_t *b_quant, const float *scales, float *y);
+
 /* ---- pooling: src/ops/pooling.rs:174-389,392-417,516-521,581-600 ---- */
 typedef struct {
     int32_t n, c, h, w;

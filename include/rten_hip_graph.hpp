@@ -802,7 +802,9 @@ class Graph {
             }
             if (dead[i]) continue;
             const onnx::Node &n = m.nodes[i];
-            if (!n.domain.empty() && n.domain != "ai.onnx") throw GraphError("node " + n.name + ": operator domain " + n.domain + " is not supported");
+            // contrib operators this backend carries live in com.microsoft (onnx_registry.rs registers them under that domain)
+            const bool contrib = n.domain == "com.microsoft" && n.op_type == "MatMulNBits";
+            if (!n.domain.empty() && n.domain != "ai.onnx" && !contrib) throw GraphError("node " + n.name + ": operator domain " + n.domain + " is not supported");
             Step st;
             st.name = n.name.empty() ? n.outputs.at(0) : n.name;
             st.kind_name = n.op_type;
@@ -843,6 +845,12 @@ class Graph {
                 op->output_padding = n.get_ints("output_padding", {});
                 op->padding = padding_of(n, "ConvTranspose");
                 if (n.attr("output_shape")) throw GraphError("ConvTranspose " + st.name + ": the output_shape attribute is not supported");
+                st.run = [op](Context &c, const InputList &in) { return op->run(c, in); };
+            } else if (n.op_type == "MatMulNBits") { // com.microsoft contrib op (onnx_registry reads bits / block_size / accuracy_level)
+                auto op = std::make_shared<MatMulNBits>();
+                op->bits = (int)n.get_int("bits", 4);
+                op->block_size = n.get_int("block_size", 32);
+                op->accuracy_level = (int)n.get_int("accuracy_level", 0);
                 st.run = [op](Context &c, const InputList &in) { return op->run(c, in); };
             } else if (n.op_type == "ConvInteger") {
                 auto op = std::make_shared<ConvInteger>();

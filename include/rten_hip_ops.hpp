@@ -622,6 +622,51 @@ struct MatMulInteger : Operator { // src/ops/matmul.rs:582-647; scale != null: M
     }
 };
 
+struct MatMulNBits : Operator { // src/ops/matmul/contrib.rs:119-196; the reference op has no K / N fields (they come from the shapes)
+    int bits = 4;
+    int64_t block_size = 32;
+    int accuracy_level = 0; // AccuracyLevel::Int8 (4) is an opt-in approximation the reference may decline (contrib.rs:102-108): always Float here
+    const char *name() const override { return "MatMulNBits"; }
+    int max_inputs() const override { return 3; }
+    OutputList run(Context &ctx, const InputList &in) const override {
+        const Tensor &lhs = want(require(in, 0), DType::F32, "float32");
+        const Tensor &rhs = require(in, 1);
+        if (rhs.dtype() != DType::U8) throw OpError(OpError::InputCastFailed, "input 1: expected uint8");
+        if (rhs.ndim() != 3) throw OpError(OpError::InputCastFailed, "input 1: expected 3 dims");
+        const Tensor &scales = want(require(in, 2), DType::F32, "float32");
+        const int64_t n = rhs.size(0);
+        int64_t k_blocks;
+        if (scales.ndim() == 2) {
+            k_blocks = scales.size(1);
+        } else if (scales.ndim() == 1) { // earlier versions of the spec used 1-D scales (contrib.rs:152-164)
+            const int64_t k = lhs.ndim() >= 1 ? lhs.size(lhs.ndim() - 1) : 1;
+            k_blocks = block_size > 0 ? k / block_size : 0;
+            if (scales.len() != n * k_blocks) throw OpError(OpError::InvalidValue, "Expected 1D `scales` size to match columns * block_size");
+        } else {
+            throw OpError(OpError::InvalidValue, "Expected `scales` to have one or two dims");
+        }
+        if (in.size() > 3) throw OpError(OpError::UnsupportedValue, "zero_points, g_idx and bias inputs are unsupported");
+        if (lhs.ndim() < 2) throw OpError(OpError::InvalidValue, "A input must have at least 2 dims");
+        if (bits != 4 && bits != 8) throw OpError(OpError::UnsupportedValue, "Unsupported bits-per-element"); // BlockQuantizedMatrix::new (block_quant.rs:690-708)
+        const int64_t elems_per_block = rhs.size(2) * (8 / bits);
+        if (elems_per_block < 16 || (elems_per_block & (elems_per_block - 1))) throw OpError(OpError::UnsupportedValue, "Unsupported K block size");
+        const int64_t rows = lhs.size(lhs.ndim() - 2), k = lhs.size(lhs.ndim() - 1);
+        if (k != rhs.size(1) * elems_per_block) throw OpError(OpError::IncompatibleInputShapes, "Columns of first matrix does not match rows of second matrix");
+        if (bits != 4) throw OpError(OpError::UnsupportedValue, "MatMulNBits: only 4-bit elements (GemmError::QuantBitsNotSupported, block_quant.rs:77-79)");
+        if (scales.ndim() == 2 && (scales.size(0) != n || k_blocks != rhs.size(1))) throw OpError(OpError::IncompatibleInputShapes, "scales shape does not match the quantised matrix");
+        std::vector<int64_t> out_shape(lhs.shape().begin(), lhs.shape().end() - 1);
+        out_shape.push_back(n);
+        int64_t batch = 1;
+        for (int i = 0; i + 2 < lhs.ndim(); i++) batch *= lhs.size(i);
+        Tensor y(ctx, out_shape, DType::F32);
+        ctx.check(rten_hip_matmul_nbits_f32(ctx.raw(), batch, (int)rows, (int)k, (int)n, (int)elems_per_block, (const float *)lhs.ptr(), (const uint8_t *)rhs.ptr(),
+                                            (const float *)scales.ptr(), (float *)y.ptr()));
+        OutputList out;
+        out.push_back(std::move(y));
+        return out;
+    }
+};
+
 // ------------------------------------------------------------------------------------------------ row-wise / element-wise
 inline int resolve_axis(int axis, int ndim) { // resolve_axis (src/ops/mod.rs): same message
     const int a = axis < 0 ? axis + ndim : axis;
@@ -1057,6 +1102,7 @@ class OpRegistry {
         r.register_op<FusedMatMul>("FusedMatMul");
         r.register_op<Gemm>("Gemm");
         r.register_op<MatMulInteger>("MatMulInteger");
+        r.register_op<MatMulNBits>("MatMulNBits");
         r.register_op<Softmax>("Softmax");
         r.register_op<LayerNormalization>("LayerNormalization");
         r.register_op<Relu>("Relu");

@@ -198,6 +198,50 @@ def conv_transpose_output_size_and_padding(in_hw, k_hw, padding, strides, dilati
     return oh, ow, list(padding)
 
 
+def matmul_nbits_f32(lhs, quant, scales):
+    """MatMulNBits (src/ops/matmul/contrib.rs:21-106, rten-gemm/src/block_quant.rs).  lhs [..., rows, K] f32, quant [N, K/bs, bs/2] u8,
+    scales [N, K/bs] f32.  rows == 1 follows the AVX-512 vector path, rows > 1 the f32 GEMM on the dequantised matrix."""
+    lhs = _f32(lhs)
+    quant = np.ascontiguousarray(quant, np.uint8)
+    scales = _f32(scales).reshape(quant.shape[0], quant.shape[1])
+    N, kb, half = quant.shape
+    bs = half * 2
+    rows, K = lhs.shape[-2], lhs.shape[-1]
+    assert K == kb * bs
+    batch = int(np.prod(lhs.shape[:-2], dtype=np.int64))
+    y = np.empty(lhs.shape[:-1] + (N,), np.float32)
+    rc = lib().rto_matmul_nbits_f32(i64(batch), i64(rows), i64(K), i64(N), i64(bs), _p(lhs), _p(quant), _p(scales), _p(y))
+    assert rc == 0
+    return y
+
+
+def dequantize_4bit(quant, scales):
+    """[K, N] f32 matrix a block-quantised RHS stands for (packing.rs:300-312)."""
+    quant = np.ascontiguousarray(quant, np.uint8)
+    N, kb, half = quant.shape
+    scales = _f32(scales).reshape(N, kb)
+    out = np.empty((kb * half * 2, N), np.float32)
+    lib().rto_dequantize_4bit(i64(N), i64(kb * half * 2), i64(half * 2), _p(quant), _p(scales), _p(out))
+    return out
+
+
+def quantize_4bit_blocks(w, block_size):
+    """Symmetric 4-bit block quantisation of a [K, N] f32 matrix into the MatMulNBits layout (zero point 8), the way ONNX Runtime's
+    MatMul4BitsQuantizer does for is_symmetric=True: scale = -absmax_signed / 8 per block, q = clip(round(w / scale) + 8, 0, 15).
+    Test / tooling helper -- not a reference restatement."""
+    w = _f32(w)
+    K, N = w.shape
+    assert K % block_size == 0
+    blocks = w.T.reshape(N, K // block_size, block_size)
+    idx = np.abs(blocks).argmax(axis=2)
+    peak = np.take_along_axis(blocks, idx[..., None], axis=2)[..., 0]
+    scales = (peak / np.float32(-8.0)).astype(np.float32)
+    inv = np.where(scales != 0, np.float32(1.0) / np.where(scales != 0, scales, 1), 0).astype(np.float32)
+    q = np.clip(np.rint(blocks * inv[..., None]) + 8, 0, 15).astype(np.uint8)
+    packed = (q[..., 0::2] | (q[..., 1::2] << 4)).astype(np.uint8)
+    return packed, scales
+
+
 def conv_transpose2d_f32(x, w, bias=None, padding=(0, 0, 0, 0), strides=(1, 1), dilations=(1, 1), groups=1, output_padding=(0, 0)):
     """src/ops/conv_transpose.rs:226-412.  x [N,C,H,W], w [C, O/g, kh, kw]."""
     x, w = _f32(x), _f32(w)

@@ -280,6 +280,81 @@ RTO_API void rto_gemm_f32_batched(int64_t batch, int64_t M, int64_t N, int64_t K
 }
 
 /* ------------------------------------------------------------------------------------
+ * MatMulNBits (4-bit block-quantised RHS) -- src/ops/matmul/contrib.rs:21-106, rten-gemm/src/block_quant.rs.
+ * quant is [N][K/bs][bs/2] bytes, element 2j of a block in the low nibble of byte j, element 2j+1 in the high
+ * nibble; scales is [N][K/bs]; the zero point is fixed at 8 (block_quant.rs:802-805).  Dequantised value
+ * = (float)(q - 8) * scale, one rounded multiply (packing.rs:300-312, block_quant.rs:243-262).
+ *  - rows > 1 (contrib.rs:86-100): the dequantised matrix goes through the ordinary f32 GEMM
+ *    (packing.rs:229-318 feeds the same micro-kernel), depth blocks kc = max(min(256, K), bs) (lib.rs:630-633,
+ *    894-905).  The oracle GEMM blocks at min(256, K): identical for bs <= 256, the range ONNX Runtime emits.
+ *  - rows == 1, ComputeMode::Float (block_quant.rs:166-389, AVX-512 instantiation): 128-element vblocks, eight
+ *    16-lane groups per vblock, group i accumulating into acc[i % 4] with one FMA per element, so lane slot
+ *    s = k % 64 owns k = s, s + 64, ...; then (acc0 + acc1) + (acc2 + acc3) lane-wise, a horizontal sum
+ *    (_mm512_reduce_add_ps: halves folded 16 -> 8 -> 4 -> 2 -> 1, lane l + lane l + width/2), and a scalar tail over
+ *    the K % 128 remainder: tail += a0 * lo + a1 * hi per byte with separately rounded products (:351-377).
+ *    ComputeMode::Int8 (accuracy_level 4) is an opt-in approximation the reference itself may decline
+ *    (contrib.rs:102-108); this backend always computes at Float accuracy.
+ */
+RTO_API void rto_dequantize_4bit(int64_t N, int64_t K, int64_t bs, const uint8_t *quant, const float *scales, float *b /* [K][N] */) {
+    const int64_t kb = K / bs;
+    for (int64_t n = 0; n < N; n++)
+        for (int64_t k = 0; k < K; k++) {
+            const uint8_t byte = quant[(n * kb + k / bs) * (bs / 2) + (k % bs) / 2];
+            const int q = (k & 1) ? (byte >> 4) : (byte & 0x0F);
+            b[k * N + n] = (float)(q - 8) * scales[n * kb + k / bs];
+        }
+}
+
+static float vec_dot_4bit(int64_t K, int64_t bs, const float *a, const uint8_t *col, const float *col_scales) {
+    float acc[64];
+    for (int s = 0; s < 64; s++) acc[s] = 0.f;
+    const int64_t kv = K - K % 128;
+    for (int64_t k = 0; k < kv; k++) {
+        const uint8_t byte = col[k / 2];
+        const int q = (k & 1) ? (byte >> 4) : (byte & 0x0F);
+        const float w = (float)(q - 8) * col_scales[k / bs];
+        acc[k % 64] = fmaf(a[k], w, acc[k % 64]);
+    }
+    float v[16];
+    for (int l = 0; l < 16; l++) v[l] = (acc[l] + acc[16 + l]) + (acc[32 + l] + acc[48 + l]);
+    for (int w = 8; w >= 1; w >>= 1)
+        for (int l = 0; l < w; l++) v[l] = v[l] + v[l + w];
+    float out = v[0];
+    if (kv < K) {
+        float tail = 0.f;
+        for (int64_t k = kv; k < K; k += 2) {
+            const uint8_t byte = col[k / 2];
+            const float s = col_scales[k / bs];
+            const float lo = (float)((int)(byte & 0x0F) - 8) * s, hi = (float)((int)(byte >> 4) - 8) * s;
+            volatile float p0 = a[k] * lo, p1 = a[k + 1] * hi; /* separately rounded products, no contraction */
+            tail = tail + (p0 + p1);
+        }
+        out = out + tail;
+    }
+    return out;
+}
+
+/* lhs is [batch][rows][K]; out [batch][rows][N].  Returns 0 or an RTO_E_* code (contrib.rs:29-61). */
+RTO_API int rto_matmul_nbits_f32(int64_t batch, int64_t rows, int64_t K, int64_t N, int64_t bs, const float *lhs,
+                                 const uint8_t *quant, const float *scales, float *out) {
+    if (bs < 16 || (bs & (bs - 1)) || K % bs) return 1;
+    const int64_t kb = K / bs;
+    if (K == 0) { memset(out, 0, (size_t)(batch * rows * N) * sizeof(float)); return 0; }
+    if (rows == 1) {
+#pragma omp parallel for schedule(static)
+        for (int64_t n = 0; n < N; n++)
+            for (int64_t b = 0; b < batch; b++)
+                out[b * N + n] = vec_dot_4bit(K, bs, lhs + b * K, quant + n * kb * (bs / 2), scales + n * kb);
+        return 0;
+    }
+    float *bm = (float *)malloc((size_t)K * N * sizeof(float));
+    rto_dequantize_4bit(N, K, bs, quant, scales, bm);
+    rto_gemm_f32(batch * rows, N, K, lhs, K, 1, bm, N, 1, out, N, 1.f, 0.f, NULL, 0);
+    free(bm);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------
  * f32 Conv -- src/ops/conv.rs:124-365 (conv_impl), :33-87 (pointwise), conv/im2col.rs:11-128.
  * NCHW input, OIHW kernel (I = C/groups), NCHW output.  Per image and group:
  * out[O_g, OH*OW] = W_g[O_g, C_g*kh*kw] . im2col(x)[C_g*kh*kw, OH*OW] with bias per out channel

@@ -524,6 +524,55 @@ class MatMulIntegerToFloat(Operator):
         return self.matmul.run(ctx, inputs[:4], scale=scale)
 
 
+class MatMulNBits(Operator):
+    """com.microsoft MatMulNBits, src/ops/matmul/contrib.rs:119-196 (op), :21-106 (matmul_nbits).
+    inputs: A f32 [..., M, K]; B u8 [N, K/bs, bs/2] (4-bit, even element in the low nibble, zero point 8); scales f32 [N, K/bs] or 1-D.
+    accuracy_level 4 (AccuracyLevel::Int8) is an opt-in approximation the reference may decline (contrib.rs:102-108): always Float here."""
+
+    def __init__(self, bits=4, block_size=32, accuracy_level=0):
+        self.bits = bits
+        self.block_size = block_size
+        self.accuracy_level = accuracy_level
+
+    def max_inputs(self):
+        return 3
+
+    def run(self, ctx, inputs):
+        lhs = _want(_require(inputs, 0), np.float32)
+        rhs = _want(_require(inputs, 1), np.uint8)
+        if len(rhs.shape) != 3:
+            raise OpError("InputCastFailed", "expected tensor with 3 dims")
+        scales = _want(_require(inputs, 2), np.float32)
+        n = rhs.shape[0]
+        if len(scales.shape) == 1:  # earlier versions of the spec used 1-D scales (contrib.rs:152-164)
+            k = lhs.shape[-1] if len(lhs.shape) >= 1 else 1
+            k_blocks = k // self.block_size if self.block_size else 0
+            if scales.size != n * k_blocks:
+                raise InvalidValue("Expected 1D `scales` size to match columns * block_size")
+        elif len(scales.shape) != 2:
+            raise InvalidValue("Expected `scales` to have one or two dims")
+        if len(inputs) > 3:
+            raise UnsupportedValue("zero_points, g_idx and bias inputs are unsupported")
+        if len(lhs.shape) < 2:
+            raise InvalidValue("A input must have at least 2 dims")
+        if self.bits not in (4, 8):  # BlockQuantizedMatrix::new (block_quant.rs:690-708)
+            raise UnsupportedValue("Unsupported bits-per-element")
+        bs = rhs.shape[2] * (8 // self.bits)
+        if bs < 16 or bs & (bs - 1):
+            raise UnsupportedValue("Unsupported K block size")
+        rows, k = lhs.shape[-2], lhs.shape[-1]
+        if k != rhs.shape[1] * bs:
+            raise IncompatibleInputShapes("Columns of first matrix does not match rows of second matrix")
+        if self.bits != 4:
+            raise UnsupportedValue("MatMulNBits: only 4-bit elements (GemmError::QuantBitsNotSupported, block_quant.rs:77-79)")
+        if len(scales.shape) == 2 and tuple(scales.shape) != (n, rhs.shape[1]):
+            raise IncompatibleInputShapes("scales shape does not match the quantised matrix")
+        batch = int(np.prod(lhs.shape[:-2], dtype=np.int64))
+        y = DeviceTensor(ctx, list(lhs.shape[:-1]) + [n], np.float32)
+        ctx.call("rten_hip_matmul_nbits_f32", batch, rows, k, n, bs, lhs.vp, rhs.vp, scales.vp, y.vp)
+        return [y]
+
+
 # ------------------------------------------------------------------------------------------ norm / softmax
 def _resolve_axis(ndim, axis):
     if axis < -ndim or axis >= ndim:
@@ -977,7 +1026,7 @@ class OpRegistry:
     @classmethod
     def with_all_ops(cls):
         r = cls()
-        for op in (Conv, ConvTranspose, ConvInteger, ConvIntegerToFloat, MatMul, FusedMatMul, Gemm, MatMulInteger, MatMulIntegerToFloat,
+        for op in (Conv, ConvTranspose, ConvInteger, ConvIntegerToFloat, MatMul, FusedMatMul, Gemm, MatMulInteger, MatMulIntegerToFloat, MatMulNBits,
                    Softmax, AddSoftmax, LayerNormalization, BatchNormalization, Relu, Gelu, Erf, Add, Mul, Sub, Div, Transpose, MaxPool,
                    AveragePool, GlobalAveragePool, Flatten, DynamicQuantizeLinear, Attention, Gather):
             r.register_op(op)

@@ -262,6 +262,67 @@ def test_conv_transpose(ctx):
         ops.ConvTranspose(padding=[9, 9, 9, 9]).run(ctx, [dev(ctx, x), dev(ctx, w)])
 
 
+def test_matmul_nbits(ctx):
+    # the reference's seeded cases (block_quant.rs:940-1072) plus wider sweeps of both paths, bit-exact against the oracle
+    def case(n_rows, n_cols, n_blocks, bs, batch=(), seed=1234):
+        rng = ref.XorShiftRng(seed)
+        lead = int(np.prod(batch, dtype=np.int64))
+        lhs = (rng.f32(lead * n_rows * n_blocks * bs) - np.float32(0.5)).reshape(*batch, n_rows, n_blocks * bs)
+        quant = rng.u8(n_cols * n_blocks * (bs // 2)).reshape(n_cols, n_blocks, bs // 2)
+        scales = rng.f32(n_cols * n_blocks).reshape(n_cols, n_blocks)
+        return lhs, quant, scales
+
+    cases = [(1, 3, max(128 // bs, 1), bs, ()) for bs in (16, 32, 64, 128, 256)]
+    cases += [(1, 1, 128 // 16 + 1, 16, ()),     # one vector step + a scalar tail
+              (1, 37, 24, 32, ()),               # K = 768: six 128-element steps, ragged column count
+              (1, 9, 7, 16, (3,)),               # batch of vectors, K = 112: tail only
+              (1, 16, 3, 64, (2, 2)),            # K = 192: one step + 64-element tail
+              (1, 5, 70, 128, ()),               # K = 8960: crosses the 8192-element LDS chunk
+              (1, 8, 33, 256, ()),               # K = 8448
+              (1, 8192, 10, 32, ()), (1, 16384 + 5, 3, 128, ()), (1, 4100, 9, 16, (2,)),  # wide matrices: the 4- and 8-slots-per-lane launches
+              (4, 21, 6, 32, ()), (7, 130, 3, 128, (2,)), (33, 64, 2, 16, ())]  # rows > 1: the f32 GEMM on the expanded weights
+    for n_rows, n_cols, n_blocks, bs, batch in cases:
+        lhs, quant, scales = case(n_rows, n_cols, n_blocks, bs, batch)
+        got = ops.MatMulNBits(4, bs).run(ctx, [dev(ctx, lhs), dev(ctx, quant), dev(ctx, scales)])[0].numpy()
+        bits_equal(got, ref.matmul_nbits_f32(lhs, quant, scales))
+    # 1-D scales (contrib.rs:152-164) and K == 0
+    lhs, quant, scales = case(1, 4, 2, 32)
+    got = ops.MatMulNBits(4, 32).run(ctx, [dev(ctx, lhs), dev(ctx, quant), dev(ctx, scales.reshape(-1))])[0].numpy()
+    bits_equal(got, ref.matmul_nbits_f32(lhs, quant, scales))
+    z = ops.MatMulNBits(4, 32).run(ctx, [dev(ctx, np.zeros((2, 1, 0), np.float32)), dev(ctx, np.zeros((3, 0, 16), np.uint8)), dev(ctx, np.zeros((3, 0), np.float32))])[0]
+    assert z.shape == (2, 1, 3) and not z.numpy().any()
+    # error behaviour of the op (contrib.rs:29-61, 141-178)
+    with pytest.raises(ops.OpError, match="A input must have at least 2 dims"):
+        ops.MatMulNBits(4, 32).run(ctx, [dev(ctx, lhs.reshape(-1)), dev(ctx, quant), dev(ctx, scales)])
+    with pytest.raises(ops.OpError, match="Columns of first matrix does not match rows of second matrix"):
+        ops.MatMulNBits(4, 32).run(ctx, [dev(ctx, lhs[:, :32].copy()), dev(ctx, quant), dev(ctx, scales)])
+    with pytest.raises(ops.OpError, match="Unsupported K block size"):
+        ops.MatMulNBits(4, 8).run(ctx, [dev(ctx, lhs), dev(ctx, quant.reshape(4, 8, 4).copy()), dev(ctx, np.zeros((4, 8), np.float32))])
+    with pytest.raises(ops.OpError, match="Unsupported bits-per-element"):
+        ops.MatMulNBits(2, 32).run(ctx, [dev(ctx, lhs), dev(ctx, quant), dev(ctx, scales)])
+    with pytest.raises(ops.OpError, match="Expected `scales` to have one or two dims"):
+        ops.MatMulNBits(4, 32).run(ctx, [dev(ctx, lhs), dev(ctx, quant), dev(ctx, scales.reshape(1, 4, 2))])
+    with pytest.raises(ops.OpError, match="zero_points, g_idx and bias inputs are unsupported"):
+        ops.MatMulNBits(4, 32).run(ctx, [dev(ctx, lhs), dev(ctx, quant), dev(ctx, scales), dev(ctx, np.zeros(4, np.uint8))])
+
+
+def test_matmul_nbits_decoder_sized(ctx):
+    # an LLM-decoder-sized projection (K = N = 4096, block 32) quantised from real-valued weights: vector path bit-exact against the
+    # oracle and close to the f64 product with the dequantised matrix; the 16-row prefill path within the f32 GEMM tolerance
+    rng = np.random.default_rng(21)
+    w = (rng.standard_normal((4096, 1024)) * 0.02).astype(np.float32)
+    quant, scales = ref.quantize_4bit_blocks(w, 32)
+    deq = ref.dequantize_4bit(quant, scales).astype(np.float64)
+    x = rng.standard_normal((1, 4096)).astype(np.float32)
+    got = ops.MatMulNBits(4, 32).run(ctx, [dev(ctx, x), dev(ctx, quant), dev(ctx, scales)])[0].numpy()
+    bits_equal(got, ref.matmul_nbits_f32(x, quant, scales))
+    want = x.astype(np.float64) @ deq
+    assert np.max(np.abs(got - want)) <= 1e-4 * np.max(np.abs(want)) + 1e-5
+    xs = rng.standard_normal((16, 4096)).astype(np.float32)
+    got = ops.MatMulNBits(4, 32).run(ctx, [dev(ctx, xs), dev(ctx, quant), dev(ctx, scales)])[0].numpy()
+    bits_equal(got, ref.matmul_nbits_f32(xs, quant, scales))
+
+
 def test_conv_f32_reference_literals(ctx):
     import json, os
     g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_literals.json")))["conv"]

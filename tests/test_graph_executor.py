@@ -331,3 +331,25 @@ def test_conv_transpose_node_in_a_graph(tmp_path):
     want = ref.relu(ref.conv_transpose2d_f32(x, w, b, (1, 1, 1, 1), (2, 2), (1, 1), 2, (1, 1)))
     got, _ = _run_model(tmp_path, m, x, "y")
     assert np.array_equal(got.view(np.int32), want.ravel().view(np.int32))
+
+
+@pytest.mark.gpu
+def test_matmul_nbits_node_in_a_graph(tmp_path):
+    # com.microsoft MatMulNBits as ONNX Runtime's 4-bit quantiser emits it: B and scales are initialisers, K / N / bits / block_size attributes
+    from oracle import ref
+    from rten_amd import onnx_writer as ow
+    rng = np.random.default_rng(17)
+    w = (rng.standard_normal((64, 24)) * 0.1).astype(np.float32)
+    quant, scales = ref.quantize_4bit_blocks(w, 16)
+    nodes = [ow.node("MatMulNBits", ["x", "wq", "ws"], ["h"], name="proj", domain="com.microsoft", K=64, N=24, bits=4, block_size=16, accuracy_level=0),
+             ow.node("Relu", ["h"], ["y"], name="relu")]
+    m = ow.model(nodes, [ow.value_info("x", ow.FLOAT, ["batch", 5, 64])], [ow.value_info("y", ow.FLOAT, ["batch", 5, 24])], [ow.tensor("wq", quant), ow.tensor("ws", scales)])
+    x = rng.standard_normal((2, 5, 64)).astype(np.float32)
+    got, _ = _run_model(tmp_path, m, x, "y")
+    want = ref.relu(ref.matmul_nbits_f32(x, quant, scales))
+    assert np.array_equal(got.view(np.int32), want.ravel().view(np.int32))
+    x1 = rng.standard_normal((3, 1, 64)).astype(np.float32)  # rows == 1: the vector path
+    m1 = ow.model(nodes, [ow.value_info("x", ow.FLOAT, ["batch", 1, 64])], [ow.value_info("y", ow.FLOAT, ["batch", 1, 24])], [ow.tensor("wq", quant), ow.tensor("ws", scales)])
+    got, _ = _run_model(tmp_path, m1, x1, "y")
+    want = ref.relu(ref.matmul_nbits_f32(x1, quant, scales))
+    assert np.array_equal(got.view(np.int32), want.ravel().view(np.int32))

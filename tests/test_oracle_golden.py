@@ -344,3 +344,70 @@ def test_sdpa_vs_torch():
     got = ref.sdpa(q, k, v, mask=mask)
     want = torch.nn.functional.scaled_dot_product_attention(torch.tensor(q), torch.tensor(k), torch.tensor(v), attn_mask=torch.tensor(mask)).numpy()
     np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)
+
+
+# ---- MatMulNBits: the reference pins its optimised paths structurally (rten-gemm/src/block_quant.rs:940-1072): same seeded
+# inputs, optimised result == naive f32 loop under expect_equal.  Restated here for the oracle's two paths.
+def _naive_block_quant_gemm(lhs, quant, scales):
+    """reference_gemm_f32_with_block_quantized_rhs (block_quant.rs:820-849): acc += lhs * ((q - 8) as f32 * scale), k ascending, in f32."""
+    m, k = lhs.shape
+    n, kb, half = quant.shape
+    bs = half * 2
+    out = np.zeros((m, n), np.float32)
+    for row in range(m):
+        for col in range(n):
+            acc = np.float32(0)
+            for ki in range(k):
+                byte = int(quant[col, ki // bs, (ki % bs) // 2])
+                elem = (byte & 0x0F) if ki % 2 == 0 else (byte >> 4)
+                deq = np.float32(elem - 8) * scales[col, ki // bs]
+                acc = np.float32(acc + np.float32(lhs[row, ki] * deq))
+            out[row, col] = acc
+    return out
+
+
+def _block_quant_case(n_rows, n_cols, n_blocks, block_size):
+    rng = ref.XorShiftRng(1234)
+    lhs = rng.f32(n_rows * n_blocks * block_size).reshape(n_rows, n_blocks * block_size)
+    quant = rng.u8(n_cols * n_blocks * (block_size // 2)).reshape(n_cols, n_blocks, block_size // 2)
+    scales = rng.f32(n_cols * n_blocks).reshape(n_cols, n_blocks)
+    return lhs, quant, scales
+
+
+@pytest.mark.parametrize("block_size", [16, 32, 64, 128, 256])
+def test_matmul_nbits_vector_cases(block_size):
+    # block_quant.rs:957-966: one row, three columns, max(128 / bs, 1) blocks
+    lhs, quant, scales = _block_quant_case(1, 3, max(128 // block_size, 1), block_size)
+    got = ref.matmul_nbits_f32(lhs[None], quant, scales)[0]
+    want = _naive_block_quant_gemm(lhs, quant, scales)
+    assert np.all(np.abs(got - want) <= 1e-8 + 1e-5 * np.abs(want)), (got, want)  # expect_equal (test_util.rs:47-93)
+
+
+def test_matmul_nbits_vector_main_and_tail():
+    # block_quant.rs:968-979: block 16, 128 / 16 + 1 blocks: one vector step plus a 16-element scalar tail
+    lhs, quant, scales = _block_quant_case(1, 1, 128 // 16 + 1, 16)
+    got = ref.matmul_nbits_f32(lhs[None], quant, scales)[0]
+    want = _naive_block_quant_gemm(lhs, quant, scales)
+    assert np.all(np.abs(got - want) <= 1e-8 + 1e-5 * np.abs(want))
+
+
+def test_matmul_nbits_empty_k_and_matrix_path():
+    out = ref.matmul_nbits_f32(np.zeros((1, 1, 0), np.float32), np.zeros((1, 0, 16), np.uint8), np.zeros((1, 0), np.float32))
+    assert out.shape == (1, 1, 1) and out[0, 0, 0] == 0.0  # block_quant.rs:82-86
+    # rows > 1 (contrib.rs:86-100, test_matmul_nbits :270-330): the f32 GEMM on the dequantised matrix
+    lhs, quant, scales = _block_quant_case(5, 7, 4, 32)
+    got = ref.matmul_nbits_f32(lhs, quant, scales)
+    want = _naive_block_quant_gemm(lhs, quant, scales)
+    assert np.all(np.abs(got - want) <= 1e-8 + 1e-5 * np.abs(want))
+    deq = ref.dequantize_4bit(quant, scales)
+    np.testing.assert_array_equal(got, ref.gemm_f32(lhs, deq))
+
+
+def test_quantize_4bit_blocks_round_trip():
+    rng = np.random.default_rng(5)
+    w = rng.standard_normal((128, 24)).astype(np.float32)
+    packed, scales = ref.quantize_4bit_blocks(w, 32)
+    assert packed.shape == (24, 4, 16) and scales.shape == (24, 4)
+    deq = ref.dequantize_4bit(packed, scales)
+    step = np.repeat(np.abs(scales), 32, axis=1).T  # [K, N]: one quantisation step per element (the +7 side clips, so allow a full step)
+    assert np.all(np.abs(deq - w) <= step * 1.0001 + 1e-6)

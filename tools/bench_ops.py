@@ -117,6 +117,19 @@ def main():
     mfma("ConvTranspose 4x4/2", "32x64x28x28 -> 32", (lambda: ctx.call("rten_hip_conv_transpose2d_f32", C.byref(dct), xct.vp, wct.vp, bct.vp, yct.vp)),
          2.0 * 32 * 64 * 28 * 28 * 32 * 16, F32_PEAK_TF, "TFLOP/s")
 
+    # ---- MatMulNBits on LLM-decoder projections (4-bit blocks of 32): decode (1 row, bound by streaming the packed weights) on a
+    # 4096 x 4096 attention projection and a 4096 x 14336 FFN up-projection, and a 128-row prefill
+    for (kq, nq, rows_list) in ((4096, 4096, (1, 128)), (4096, 14336, (1,))):
+        bsq = 32
+        wq, wsc = dev(rng.integers(0, 256, (nq, kq // bsq, bsq // 2)).astype(np.uint8)), dev(rng.random((nq, kq // bsq), dtype=np.float32) * 0.01)
+        for rows_q in rows_list:
+            xq, yq = dev(rng.standard_normal((rows_q, kq), dtype=np.float32)), empty((rows_q, nq))
+            fn = (lambda xq=xq, yq=yq, rows_q=rows_q, kq=kq, nq=nq, wq=wq, wsc=wsc: ctx.call("rten_hip_matmul_nbits_f32", 1, rows_q, kq, nq, bsq, xq.vp, wq.vp, wsc.vp, yq.vp))
+            if rows_q == 1:
+                hbm("MatMulNBits decode", f"1x{kq}x{nq} q4/{bsq}", fn, nq * kq / 2 + 4.0 * (nq * kq // bsq + kq + nq))
+            else:
+                mfma("MatMulNBits prefill", f"{rows_q}x{kq}x{nq} q4/{bsq}", fn, 2.0 * rows_q * kq * nq, F32_PEAK_TF, "TFLOP/s")
+
     # ---- f32 GEMM on BERT-base shapes (batch 32 x 128 tokens)
     for (m, k, n, act, name) in ((4096, 768, 768, 0, "MatMul proj"), (4096, 768, 3072, L.ACT_GELU, "MatMul FFN1 + Gelu"), (4096, 3072, 768, 0, "MatMul FFN2")):
         a, w, bias, out = dev(rng.standard_normal((m, k), dtype=np.float32)), dev(rng.standard_normal((k, n), dtype=np.float32)), dev(np.zeros(n, np.float32)), empty((m, n))
