@@ -273,6 +273,17 @@ int32_t rten_hip_binary_broadcast_f32(rten_hip_ctx *ctx, int32_t op, int32_t ndi
 /* Transpose (src/ops/layout.rs:669+) of 4-byte elements: y.shape[d] = x_shape[perm[d]], ndim <= 6; an invalid perm is
  * "Permutation is invalid" like the reference. */
 int32_t rten_hip_transpose_b32(rten_hip_ctx *ctx, int32_t ndim, const int64_t *x_shape, const int32_t *perm, const void *x, void *y);
+/* y (contiguous, shape[ndim], ndim <= 6) = x read through x_strides (elements; 0 = broadcast axis, a sum of strides = a
+ * diagonal): TensorView::to_tensor / to_contiguous / expand_to of the permuted, diagonal and expanded views that Einsum
+ * builds (src/ops/einsum.rs:124-162,255-257,320-329,534-535). */
+int32_t rten_hip_copy_strided_b32(rten_hip_ctx *ctx, int32_t ndim, const int64_t *shape, const int64_t *x_strides, const void *x, void *y);
+/* ReduceSum of a strided view (reduce_sum, src/ops/reduce.rs:414-520,1101-1124; vecmath::Sum, rten-vecmath/src/sum.rs:12-34):
+ * y[r] (r = row-major index over the kept dims outer_shape[n_outer]) = sum of the slice spanned by the reduced dims
+ * inner_shape[n_inner] walked in row-major order -- the order the reference packs a non-contiguous slice in -- added in the
+ * AVX-512 16-lane order (bit-identical to the reference on the GPU box's host).  An empty slice sums to 0.  <= 6 + 6 dims. */
+int32_t rten_hip_reduce_sum_strided_f32(rten_hip_ctx *ctx, int32_t n_outer, const int64_t *outer_shape, const int64_t *outer_strides,
+                                        int32_t n_inner, const int64_t *inner_shape, const int64_t *inner_strides,
+                                        const float *x, float *y);
 /* y[(i / inner) ...] += bias[c]: per-channel bias add for NCHW tensors ([1,O,1,1] constant Add) */
 int32_t rten_hip_add_channel_bias_f32(rten_hip_ctx *ctx, int32_t n, int32_t c, int64_t inner, const float *x,
                                       const float *bias, float *y);

@@ -288,6 +288,29 @@ RTEN_EXPORT int32_t rten_hip_transpose_b32(rten_hip_ctx *ctx, int32_t ndim, cons
     return RTEN_HIP_OK;
 }
 
+// y (contiguous, `shape`) = x viewed through `x_strides` (elements; 0 = broadcast axis, a sum of strides = a diagonal).
+// The device form of TensorView::to_tensor / to_contiguous / expand_to on the views Einsum builds
+// (src/ops/einsum.rs:124-162,255-257,320-329,534-535; src/ops/layout.rs expand_to).
+RTEN_EXPORT int32_t rten_hip_copy_strided_b32(rten_hip_ctx *ctx, int32_t ndim, const int64_t *shape, const int64_t *x_strides, const void *x, void *y) {
+    RTEN_CHECK_CTX(ctx);
+    if (ndim < 0 || ndim > 6 || (ndim && (!shape || !x_strides))) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "copy_strided: at most 6 dims");
+    NdArgs p = {};
+    p.ndim = ndim;
+    p.n = 1;
+    for (int d = 0; d < ndim; d++) {
+        if (shape[d] < 0 || shape[d] > 0x7fffffff || x_strides[d] < 0) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "copy_strided: bad dimension");
+        p.shape[d] = (int32_t)shape[d];
+        p.a_stride[d] = x_strides[d];
+        p.n *= shape[d];
+    }
+    if (p.n == 0) return RTEN_HIP_OK;
+    if (!x || !y) return RTEN_HIP_ERR_INVALID_VALUE;
+    ProfScope ps(ctx, "copy_strided_b32", 0.0, 8.0 * p.n);
+    hipLaunchKernelGGL(permute_kernel, dim3(ew_blocks(p.n)), dim3(EW_THREADS), 0, ctx->stream, p, (const uint32_t *)x, (uint32_t *)y);
+    RTEN_LAUNCH_CHECK(ctx, "copy_strided_b32");
+    return RTEN_HIP_OK;
+}
+
 RTEN_EXPORT int32_t rten_hip_add_channel_bias_f32(rten_hip_ctx *ctx, int32_t n, int32_t c, int64_t inner,
                                                   const float *x, const float *bias, float *y) {
     RTEN_CHECK_CTX(ctx);

@@ -386,6 +386,71 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void global_avg_pool_rows16_ke
     if (l == 15 && row < rows) y[row] = acc / (float)inner;
 }
 
+// ReduceSum over a strided view (src/ops/reduce.rs:414-520,1101-1124): output element r = vecmath::Sum of the reduced
+// slice, whose elements are the reduced axes walked in row-major order -- the order in which the reference packs a
+// non-contiguous slice before calling the kernel (reduce.rs:470-505).  The view is read in place through its strides
+// (stride 0 = broadcast axis, summed strides = a diagonal): nothing is packed.
+struct ReduceArgs {
+    int n_outer, n_inner;
+    int64_t rows;
+    int inner;
+    int32_t oshape[6], ishape[6];
+    int64_t ostride[6], istride[6];
+};
+
+__device__ __forceinline__ int64_t reduce_row_base(const ReduceArgs &p, int64_t row) {
+    int64_t r = row, off = 0;
+    for (int d = p.n_outer - 1; d >= 0; d--) {
+        const int64_t q = r / p.oshape[d];
+        off += (r - q * p.oshape[d]) * p.ostride[d];
+        r = q;
+    }
+    return off;
+}
+
+__device__ __forceinline__ int64_t reduce_elem_off(const ReduceArgs &p, int i) {
+    if (p.n_inner == 1) return (int64_t)i * p.istride[0];
+    int r = i;
+    int64_t off = 0;
+    for (int d = p.n_inner - 1; d >= 0; d--) {
+        const int q = r / p.ishape[d];
+        off += (int64_t)(r - q * p.ishape[d]) * p.istride[d];
+        r = q;
+    }
+    return off;
+}
+
+__global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void reduce_sum_kernel(const ReduceArgs p, const float *__restrict__ x,
+                                                                         float *__restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const float *xr = x + reduce_row_base(p, row);
+    auto get = [&](int i) -> float { return xr[reduce_elem_off(p, i)]; };
+    const float s = simd16_reduce<0>(get, p.inner, 0.f, lane);
+    if (lane == 0) y[row] = s;
+}
+
+// Slices of at most 64 elements: four output elements per wave, one per 16-lane DPP row (global_avg_pool_rows16_kernel's scheme).
+__global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void reduce_sum_rows16_kernel(const ReduceArgs p, const float *__restrict__ x,
+                                                                                float *__restrict__ y) {
+    const int lane = threadIdx.x & 63, l = lane & 15;
+    const int64_t row = ((int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const int64_t rr = row < p.rows ? row : p.rows - 1;
+    const float *xr = x + reduce_row_base(p, rr);
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) v[q] = xr[reduce_elem_off(p, l + 16 * q < p.inner ? l + 16 * q : 0)];
+    float a = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (l + 16 * q < p.inner) a = a + v[q];
+    float acc = a;
+#pragma unroll
+    for (int k = 1; k < 16; k++) acc = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x111, 0xf, 0xf, true)) + a;
+    if (l == 15 && row < p.rows) y[row] = acc;
+}
+
 } // namespace
 
 RTEN_EXPORT int32_t rten_hip_softmax_f32(rten_hip_ctx *ctx, int64_t rows, int32_t cols, const float *x,
@@ -466,5 +531,49 @@ RTEN_EXPORT int32_t rten_hip_global_average_pool_f32(rten_hip_ctx *ctx, int64_t 
     else
         hipLaunchKernelGGL(global_avg_pool_kernel, grid, block, 0, ctx->stream, nc, inner, x, y);
     RTEN_LAUNCH_CHECK(ctx, "global_avg_pool_kernel");
+    return RTEN_HIP_OK;
+}
+
+RTEN_EXPORT int32_t rten_hip_reduce_sum_strided_f32(rten_hip_ctx *ctx, int32_t n_outer, const int64_t *outer_shape, const int64_t *outer_strides,
+                                                    int32_t n_inner, const int64_t *inner_shape, const int64_t *inner_strides,
+                                                    const float *x, float *y) {
+    RTEN_CHECK_CTX(ctx);
+    if (n_outer < 0 || n_outer > 6 || n_inner < 0 || n_inner > 6 || (n_outer && (!outer_shape || !outer_strides)) ||
+        (n_inner && (!inner_shape || !inner_strides)))
+        return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "reduce_sum: at most 6 kept and 6 reduced dims");
+    ReduceArgs p = {};
+    p.n_outer = n_outer;
+    p.n_inner = n_inner > 0 ? n_inner : 1;
+    p.rows = 1;
+    int64_t inner = 1;
+    for (int d = 0; d < n_outer; d++) {
+        if (outer_shape[d] < 0 || outer_shape[d] > 0x7fffffff || outer_strides[d] < 0) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "reduce_sum: bad dimension");
+        p.oshape[d] = (int32_t)outer_shape[d];
+        p.ostride[d] = outer_strides[d];
+        p.rows *= outer_shape[d];
+    }
+    p.ishape[0] = 1;
+    for (int d = 0; d < n_inner; d++) {
+        if (inner_shape[d] < 0 || inner_strides[d] < 0) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "reduce_sum: bad dimension");
+        inner *= inner_shape[d];
+        if (inner > 0x7fffffff) return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "reduce_sum: reduced slice longer than 2^31 - 1");
+        p.ishape[d] = (int32_t)inner_shape[d];
+        p.istride[d] = inner_strides[d];
+    }
+    p.inner = (int)inner;
+    if (p.rows == 0) return RTEN_HIP_OK;
+    if (!y) return RTEN_HIP_ERR_INVALID_VALUE;
+    if (inner == 0) { // the sum of an empty slice is the kernel's identity (reduce.rs:446-452)
+        RTEN_HIP_TRY(ctx, hipMemsetAsync(y, 0, sizeof(float) * (size_t)p.rows, ctx->stream));
+        return RTEN_HIP_OK;
+    }
+    if (!x) return RTEN_HIP_ERR_INVALID_VALUE;
+    const dim3 block(64 * ROWS_PER_BLOCK);
+    ProfScope ps(ctx, "reduce_sum_f32", 0.0, 4.0 * p.rows * (inner + 1));
+    if (inner <= 64)
+        hipLaunchKernelGGL(reduce_sum_rows16_kernel, dim3((unsigned)((p.rows + 4 * ROWS_PER_BLOCK - 1) / (4 * ROWS_PER_BLOCK))), block, 0, ctx->stream, p, x, y);
+    else
+        hipLaunchKernelGGL(reduce_sum_kernel, dim3((unsigned)((p.rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block, 0, ctx->stream, p, x, y);
+    RTEN_LAUNCH_CHECK(ctx, "reduce_sum_kernel");
     return RTEN_HIP_OK;
 }

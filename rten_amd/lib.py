@@ -142,6 +142,8 @@ PROTOTYPES = {
     "rten_hip_div_f32": (_I32, [_VP, _I64, _VP, _VP, _I64, _VP]),
     "rten_hip_binary_broadcast_f32": (_I32, [_VP, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP]),
     "rten_hip_transpose_b32": (_I32, [_VP, _I32, _VP, _VP, _VP, _VP]),
+    "rten_hip_copy_strided_b32": (_I32, [_VP, _I32, _VP, _VP, _VP, _VP]),
+    "rten_hip_reduce_sum_strided_f32": (_I32, [_VP, _I32, _VP, _VP, _I32, _VP, _VP, _VP, _VP]),
     "rten_hip_conv_transpose_output_size": (_I32, [_I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP, _I32, _I32, _I32, _I32, _VP, _VP, _VP]),
     "rten_hip_conv_transpose2d_f32": (_I32, [_VP, _VP, _VP, _VP, _VP, _VP]),
     "rten_hip_matmul_nbits_f32": (_I32, [_VP, _I64, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP]),

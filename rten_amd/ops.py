@@ -1017,6 +1017,50 @@ class Gather(Operator):
         return [out]
 
 
+class ReduceSum(Operator):
+    """src/ops/reduce.rs:1126-1165 (f32): axes attribute or second input already resolved by the caller into `axes`;
+    the slice of every output element is summed in place through the view's strides, 16-lane vecmath::Sum order."""
+
+    def __init__(self, axes=None, keep_dims=True, noop_with_empty_axes=False):
+        self.axes, self.keep_dims, self.noop_with_empty_axes = axes, keep_dims, noop_with_empty_axes
+
+    def max_inputs(self):
+        return 2
+
+    def run(self, ctx, inputs):
+        from . import einsum as E
+        x = _want(_require(inputs, 0), np.float32)
+        nd = len(x.shape)
+        if not self.axes and self.noop_with_empty_axes:
+            return [E.materialize(ctx, E.View(x))]
+        axes = []
+        for a in (self.axes if self.axes else range(nd)):
+            if a < -nd or a >= nd:
+                raise InvalidValue("Axis is invalid")
+            axes.append(a + nd if a < 0 else a)
+        axes = sorted(set(axes))  # resolve_axes sorts and dedups (src/ops/mod.rs:259-271)
+        y = E.reduce_sum(ctx, E.View(x), axes) if nd else E.materialize(ctx, E.View(x))
+        if self.keep_dims:
+            y = y.reshape([1 if d in axes else x.shape[d] for d in range(nd)])
+        return [y]
+
+
+class Einsum(Operator):
+    """src/ops/einsum.rs:21-108: any number of f32 inputs, `equation` attribute.  The planner and the strided lowering
+    are in rten_amd/einsum.py."""
+
+    def __init__(self, equation: str):
+        self.equation = equation
+
+    def max_inputs(self):
+        return None
+
+    def run(self, ctx, inputs):
+        from . import einsum as E
+        xs = [_want(_require(inputs, i), np.float32) for i in range(len(inputs))]
+        return [E.einsum(ctx, xs, self.equation)]
+
+
 class OpRegistry:
     """Mirror of OpRegistry (src/op_registry.rs:25-72): op_type -> operator class for the hot path."""
 
@@ -1028,7 +1072,7 @@ class OpRegistry:
         r = cls()
         for op in (Conv, ConvTranspose, ConvInteger, ConvIntegerToFloat, MatMul, FusedMatMul, Gemm, MatMulInteger, MatMulIntegerToFloat, MatMulNBits,
                    Softmax, AddSoftmax, LayerNormalization, BatchNormalization, Relu, Gelu, Erf, Add, Mul, Sub, Div, Transpose, MaxPool,
-                   AveragePool, GlobalAveragePool, Flatten, DynamicQuantizeLinear, Attention, Gather):
+                   AveragePool, GlobalAveragePool, Flatten, DynamicQuantizeLinear, Attention, Gather, ReduceSum, Einsum):
             r.register_op(op)
         return r
 
