@@ -1039,6 +1039,23 @@ class Graph {
                 auto op = std::make_shared<Cast>();
                 op->to = dtype_of((int)n.get_int("to", onnx::FLOAT), st.name);
                 st.run = [op](Context &c, const InputList &in) { return op->run(c, in); };
+            } else if (n.op_type == "Einsum") {
+                auto op = std::make_shared<Einsum>();
+                if (!n.attr("equation")) throw GraphError("Einsum " + st.name + ": the equation attribute is missing");
+                op->equation = n.attr("equation")->s;
+                st.run = [op](Context &c, const InputList &in) { return op->run(c, in); };
+            } else if (n.op_type == "ReduceSum") {
+                auto op = std::make_shared<ReduceSum>();
+                op->keep_dims = n.get_int("keepdims", 1) != 0;
+                op->noop_with_empty_axes = n.get_int("noop_with_empty_axes", 0) != 0;
+                op->axes = n.get_ints("axes", {});
+                if (n.inputs.size() > 1 && !n.inputs[1].empty()) { // opset >= 13: axes as a (constant) input
+                    auto it = ids_.find(n.inputs[1]);
+                    if (it == ids_.end() || !consts_.count(it->second)) throw GraphError("ReduceSum " + st.name + ": the axes input must be a constant");
+                    for (int32_t v : consts_.at(it->second).to_host<int32_t>()) op->axes.push_back(v);
+                    st.in.resize(1);
+                }
+                st.run = [op](Context &c, const InputList &in) { return op->run(c, in); };
             } else if (n.op_type == "Softmax") {
                 auto op = std::make_shared<Softmax>();
                 op->axis = (int)n.get_int("axis", -1);

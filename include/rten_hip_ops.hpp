@@ -11,6 +11,7 @@
 //   * Gelu, Erf, Relu, Add, Mul                    src/ops/unary_elementwise.rs, binary_elementwise.rs:476-495
 //   * MaxPool, AveragePool, GlobalAveragePool      src/ops/pooling.rs:174-521
 //   * DynamicQuantizeLinear                        src/ops/quantize.rs:352-436
+//   * Einsum, ReduceSum                            src/ops/einsum.rs:21-692, src/ops/reduce.rs:414-520,1126-1165
 // Validation runs on the host before any launch; arithmetic is done by librten_hip.so on device-resident tensors.  There
 // is no CPU fallback: without a gfx950 device `Context` throws.  Header only; C++17.
 #pragma once
@@ -1076,6 +1077,449 @@ struct Cast : Operator {
     }
 };
 
+// ------------------------------------------------------------------------------------------------ Einsum / ReduceSum
+// src/ops/einsum.rs:21-692, rten-shape-inference/src/einsum_parser.rs:68-275, src/ops/reduce.rs:414-520,1101-1165.
+// The reference walks a path of two-term steps over permuted TensorViews and copies where a kernel wants contiguous data.
+// Here a view is (device pointer, shape, element strides) and the kernels read THROUGH the strides: permutes, inserted axes,
+// diagonals and 1 -> n expansion are stride arithmetic; ReduceSum runs in place on the strided view; a product is ONE
+// rten_hip_gemm_f32 launch (M / K / N are strides, batch labels become the descriptor's two batch levels once neighbouring
+// axes with compatible strides are merged); only the final permutation into the output order is a copy.  The order of the
+// arithmetic is the reference's (same path, same M / N / batch labels, lone labels summed first, [A, M, K] x [K, N] folded
+// into one GEMM), so results are bit-identical except for a GEMM with one row (ISA-dependent gemv path).
+namespace einsum_detail {
+using Shape = std::vector<int64_t>;
+constexpr char INS_M = '<', INS_N = '>', MERGED_K = '*'; // einsum.rs:366-380
+constexpr int MAX_DIMS = 10;                             // einsum_parser.rs:241-245
+
+inline bool has(const std::string &s, char c) { return s.find(c) != std::string::npos; }
+inline std::string dedup(const std::string &s) {
+    std::string o;
+    for (char c : s) if (!has(o, c)) o.push_back(c);
+    return o;
+}
+inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\f'; }
+inline std::string strip_ws(const std::string &s) {
+    std::string o;
+    for (char c : s) if (!is_ws(c)) o.push_back(c);
+    return o;
+}
+inline bool valid_term(const std::string &t) { // is_valid_term, einsum_parser.rs:231-237
+    const size_t e = t.find("...");
+    std::string letters = t;
+    if (e != std::string::npos) {
+        if (t.find("...", e + 3) != std::string::npos) return false;
+        letters = t.substr(0, e) + t.substr(e + 3);
+    }
+    for (char c : letters) if (!((c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'))) return false;
+    return true;
+}
+
+// EinsumExpr::parse, einsum_parser.rs:68-103
+inline void parse_equation(const std::string &equation, std::vector<std::string> &terms, std::string &out) {
+    const size_t arrow = equation.find("->");
+    const std::string lhs = equation.substr(0, arrow);
+    terms.clear();
+    size_t b = 0;
+    for (;;) {
+        const size_t c = lhs.find(',', b);
+        terms.push_back(strip_ws(lhs.substr(b, c == std::string::npos ? c : c - b)));
+        if (c == std::string::npos) break;
+        b = c + 1;
+    }
+    for (auto &t : terms) if (!valid_term(t)) throw OpError(OpError::InvalidValue, "Input term is invalid");
+    if (arrow != std::string::npos) out = strip_ws(equation.substr(arrow + 2));
+    else { // default_output, :191-228: "..." then the letters used exactly once, in ASCII order
+        int count[128] = {0};
+        bool dots = false;
+        for (auto &t : terms) { dots = dots || t.find("...") != std::string::npos; for (char c : t) if (c != '.') count[(int)c]++; }
+        out = dots ? "..." : "";
+        for (int c = 0; c < 128; c++) if (count[c] == 1) out.push_back((char)c);
+    }
+    if (!valid_term(out)) throw OpError(OpError::InvalidValue, "Output term is invalid");
+    for (size_t i = 0; i < out.size(); i++)
+        if (out[i] != '.' && out.find(out[i], i + 1) != std::string::npos) throw OpError(OpError::InvalidValue, "Einsum output term contains repeated labels");
+    for (char c : out) {
+        if (c == '.') continue;
+        bool found = false;
+        for (auto &t : terms) found = found || has(t, c);
+        if (!found) throw OpError(OpError::InvalidValue, "Einsum output term contains a label not present in any input term");
+    }
+}
+
+// EinsumExpr::validate_inputs (einsum_parser.rs:109-165) with the error mapping of einsum.rs:69-86
+inline int broadcast_ndim(const std::vector<std::string> &terms, const std::vector<int> &ndims) {
+    if (ndims.size() != terms.size()) throw OpError(OpError::InvalidValue, "Number of terms in Einsum equation does not match input tensor count");
+    int b = -1;
+    for (size_t i = 0; i < terms.size(); i++) {
+        const bool dots = terms[i].find("...") != std::string::npos;
+        const int named = (int)terms[i].size() - (dots ? 3 : 0), nd = ndims[i];
+        if (dots ? nd < named : nd != named) throw OpError(OpError::InvalidValue, "Einsum term dimension count does not match input tensor");
+        if (nd > MAX_DIMS) throw OpError(OpError::UnsupportedValue, "Einsum input or term has too many dimensions");
+        if (dots) {
+            if (b >= 0 && b != nd - named) throw OpError(OpError::InvalidValue, "Number of broadcast dims does not match across inputs");
+            b = nd - named;
+        }
+    }
+    return b < 0 ? 0 : b;
+}
+
+inline std::string expand_ellipsis(const std::string &t, int n) { // einsum_parser.rs:254-265
+    const size_t e = t.find("...");
+    if (e == std::string::npos) return t;
+    std::string digits;
+    for (int i = 0; i < n; i++) digits.push_back((char)('0' + i));
+    return t.substr(0, e) + digits + t.substr(e + 3);
+}
+
+struct Step { // EinsumStep, einsum.rs:558-564; a source is an input index or -1 for the previous step's result
+    std::string lhs;
+    int lhs_src = 0;
+    bool binary = false;
+    std::string rhs;
+    int rhs_src = 0;
+    std::string out;
+};
+
+// einsum_path, einsum.rs:605-692
+inline std::vector<Step> plan_path(std::vector<std::string> terms, std::string out, int bdims) {
+    out = expand_ellipsis(out, bdims);
+    for (auto &t : terms) t = expand_ellipsis(t, bdims);
+    std::vector<Step> steps;
+    if (terms.size() <= 2) {
+        Step s;
+        s.lhs = terms[0]; s.binary = terms.size() == 2; s.out = out;
+        if (s.binary) { s.rhs = terms[1]; s.rhs_src = 1; }
+        steps.push_back(s);
+        return steps;
+    }
+    std::map<char, int> pending; // reduced label -> terms that still have to consume it
+    for (auto &t : terms) for (char c : dedup(t)) if (!has(out, c)) pending[c]++;
+    auto consume = [&](const std::string &t) { for (char c : dedup(t)) if (pending.count(c)) pending[c]--; };
+    auto keep = [&](const std::string &a, const std::string &b) {
+        std::string o;
+        for (char c : dedup(a + b)) if (has(out, c) || (pending.count(c) && pending[c] > 0)) o.push_back(c);
+        return o;
+    };
+    consume(terms[0]);
+    consume(terms[1]);
+    std::string cur = keep(terms[0], terms[1]);
+    Step first;
+    first.lhs = terms[0]; first.binary = true; first.rhs = terms[1]; first.rhs_src = 1; first.out = cur;
+    steps.push_back(first);
+    for (size_t i = 2; i < terms.size(); i++) {
+        consume(terms[i]);
+        const std::string nxt = i + 1 == terms.size() ? out : keep(cur, terms[i]);
+        Step s;
+        s.lhs = cur; s.lhs_src = -1; s.binary = true; s.rhs = terms[i]; s.rhs_src = (int)i; s.out = nxt;
+        steps.push_back(s);
+        cur = nxt;
+    }
+    return steps;
+}
+
+struct View {
+    const float *p = nullptr;
+    Shape shape, strides;
+    static View of(const Tensor &t) {
+        View v;
+        v.p = (const float *)t.ptr();
+        v.shape = t.shape();
+        v.strides.assign(v.shape.size(), 0);
+        int64_t acc = 1;
+        for (int d = (int)v.shape.size() - 1; d >= 0; d--) { v.strides[(size_t)d] = acc; acc *= v.shape[(size_t)d]; }
+        return v;
+    }
+    int nd() const { return (int)shape.size(); }
+    int64_t len() const { return detail::prod(shape, 0, shape.size()); }
+    View relabel(const std::string &have, const std::string &want) const { // permute_and_insert_axes, einsum.rs:414-442
+        View v;
+        v.p = p;
+        for (char c : want) {
+            const size_t i = have.find(c);
+            v.shape.push_back(i == std::string::npos ? 1 : shape[i]);
+            v.strides.push_back(i == std::string::npos ? 0 : strides[i]);
+        }
+        return v;
+    }
+    View expanded(const Shape &to) const {
+        View v = *this;
+        for (size_t i = 0; i < to.size(); i++) if (shape[i] == 1 && to[i] != 1) v.strides[i] = 0;
+        v.shape = to;
+        return v;
+    }
+};
+
+// drops 1-sized axes and merges neighbours (outer, inner) with outer stride == inner stride * inner size in every operand
+inline void merge_axes(const Shape &shape, const std::vector<Shape> &strides, Shape &mshape, std::vector<Shape> &mstrides) {
+    mshape.clear();
+    mstrides.assign(strides.size(), Shape());
+    for (size_t i = 0; i < shape.size(); i++) {
+        if (shape[i] == 1) continue;
+        bool merge = !mshape.empty();
+        for (size_t k = 0; merge && k < strides.size(); k++) merge = mstrides[k].back() == strides[k][i] * shape[i];
+        if (merge) { mshape.back() *= shape[i]; for (size_t k = 0; k < strides.size(); k++) mstrides[k].back() = strides[k][i]; }
+        else { mshape.push_back(shape[i]); for (size_t k = 0; k < strides.size(); k++) mstrides[k].push_back(strides[k][i]); }
+    }
+}
+inline Shape broadcast(const Shape &a, const Shape &b, const char *msg) {
+    Shape o(a.size());
+    for (size_t i = 0; i < a.size(); i++) {
+        if (a[i] != b[i] && a[i] != 1 && b[i] != 1) throw OpError(OpError::IncompatibleInputShapes, msg);
+        o[i] = a[i] == 1 ? b[i] : a[i];
+    }
+    return o;
+}
+
+inline Tensor materialize(Context &ctx, const View &v) { // to_tensor / to_contiguous / expand_to
+    Tensor y(ctx, v.shape, DType::F32);
+    if (y.len()) {
+        Shape ms; std::vector<Shape> mst;
+        merge_axes(v.shape, {v.strides}, ms, mst);
+        if (ms.size() > 6) throw OpError(OpError::UnsupportedValue, "Einsum view with more than 6 non-mergeable dims is not supported by the device path");
+        ctx.check(rten_hip_copy_strided_b32(ctx.raw(), (int)ms.size(), ms.data(), mst[0].data(), v.p, y.ptr()));
+    }
+    return y;
+}
+
+// reduce_sum(view, axes, keep_dims = false): axes sorted and unique
+inline Tensor reduce_sum(Context &ctx, const View &v, const std::vector<int> &axes) {
+    Shape ks, kst, rs, rst;
+    for (int d = 0; d < v.nd(); d++) {
+        const bool red = std::find(axes.begin(), axes.end(), d) != axes.end();
+        (red ? rs : ks).push_back(v.shape[(size_t)d]);
+        (red ? rst : kst).push_back(v.strides[(size_t)d]);
+    }
+    Tensor y(ctx, ks, DType::F32);
+    if (y.len()) {
+        Shape mo, mi; std::vector<Shape> mos, mis;
+        merge_axes(ks, {kst}, mo, mos);
+        merge_axes(rs, {rst}, mi, mis);
+        if (mo.size() > 6 || mi.size() > 6) throw OpError(OpError::UnsupportedValue, "Einsum reduction over more than 6 non-mergeable dims is not supported by the device path");
+        ctx.check(rten_hip_reduce_sum_strided_f32(ctx.raw(), (int)mo.size(), mo.data(), mos[0].data(), (int)mi.size(), mi.data(), mis[0].data(), v.p, (float *)y.ptr()));
+    }
+    return y;
+}
+
+inline Tensor mul(Context &ctx, const View &a, const View &b) { // mul() with numpy broadcasting on views of equal rank
+    const Shape shape = broadcast(a.shape, b.shape, "Cannot broadcast inputs");
+    Tensor y(ctx, shape, DType::F32);
+    if (y.len()) {
+        Shape ms; std::vector<Shape> mst;
+        merge_axes(shape, {a.expanded(shape).strides, b.expanded(shape).strides}, ms, mst);
+        if (ms.size() > 6) throw OpError(OpError::UnsupportedValue, "broadcasting over more than 6 dims is not supported by the device path");
+        ctx.check(rten_hip_binary_broadcast_f32(ctx.raw(), 1, (int)ms.size(), ms.data(), mst[0].data(), mst[1].data(), a.p, b.p, (float *)y.ptr()));
+    }
+    return y;
+}
+
+// matmul() of [batch.., M, K] x [batch.., K, N] views of equal rank, src/ops/matmul.rs:208-385
+inline Tensor matmul(Context &ctx, View a, View b) {
+    const int nd = a.nd();
+    const int64_t m = a.shape[(size_t)nd - 2], k = a.shape[(size_t)nd - 1], n = b.shape[(size_t)nd - 1];
+    if (k != b.shape[(size_t)nd - 2]) throw OpError(OpError::IncompatibleInputShapes, "Columns of first matrix does not match rows of second matrix");
+    const Shape apre(a.shape.begin(), a.shape.end() - 2), bpre(b.shape.begin(), b.shape.end() - 2);
+    const Shape pre = broadcast(apre, bpre, "Cannot broadcast shapes");
+    Shape oshape = pre;
+    oshape.push_back(m);
+    oshape.push_back(n);
+    Tensor y(ctx, oshape, DType::F32);
+    if (y.len() == 0) return y;
+    if (k == 0) { ctx.check(rten_hip_memset(ctx.raw(), y.ptr(), 0, y.bytes())); return y; }
+    std::vector<Tensor> keep; // re-laid operands stay alive until the launch is enqueued
+    auto relay = [&](View &v) { keep.push_back(materialize(ctx, v)); v = View::of(keep.back()); };
+    auto gemm_axis_is_broadcast = [&](const View &v) {
+        for (int d = nd - 2; d < nd; d++) if (v.strides[(size_t)d] == 0 && v.shape[(size_t)d] > 1) return true;
+        return false;
+    };
+    if (gemm_axis_is_broadcast(a)) relay(a); // expand_dim, einsum.rs:210-223
+    if (gemm_axis_is_broadcast(b)) relay(b);
+    rten_hip_gemm_desc d;
+    std::memset(&d, 0, sizeof d);
+    d.n = (int32_t)n; d.k = (int32_t)k; d.ldc = n; d.alpha = 1.0f; d.batch = 1;
+    const int64_t na = detail::prod(apre, 0, apre.size()), nb = detail::prod(bpre, 0, bpre.size());
+    Shape ms; std::vector<Shape> mst;
+    if (na > 1 && nb == 1) { // [A, M, K] x [K, N] as one GEMM of A * M rows (matmul.rs:266-297)
+        auto rows = [&] { merge_axes(Shape(a.shape.begin(), a.shape.end() - 1), {Shape(a.strides.begin(), a.strides.end() - 1)}, ms, mst); };
+        rows();
+        if (ms.size() > 1) { relay(a); rows(); }
+        d.m = (int32_t)(na * m);
+        d.a_rs = ms.empty() ? 0 : mst[0][0]; d.a_cs = a.strides[(size_t)nd - 1];
+        d.b_rs = b.strides[(size_t)nd - 2]; d.b_cs = b.strides[(size_t)nd - 1];
+        ctx.check(rten_hip_gemm_f32(ctx.raw(), &d, a.p, b.p, nullptr, (float *)y.ptr()));
+        return y;
+    }
+    Shape ea_shape = pre, eb_shape = pre;
+    ea_shape.push_back(m); ea_shape.push_back(k);
+    eb_shape.push_back(k); eb_shape.push_back(n);
+    View ea = a.expanded(ea_shape), eb = b.expanded(eb_shape);
+    auto batch_strides = [&](const View &v) { return Shape(v.strides.begin(), v.strides.end() - 2); };
+    merge_axes(pre, {batch_strides(ea), batch_strides(eb)}, ms, mst);
+    if (ms.size() > 2) { // more batch levels than the descriptor has: re-lay the operand(s) that do not merge by themselves
+        auto needs_relay = [&](const View &v) {
+            Shape s1; std::vector<Shape> st1;
+            merge_axes(pre, {batch_strides(v)}, s1, st1);
+            return s1.size() > 1 || (!st1[0].empty() && st1[0][0] == 0);
+        };
+        if (needs_relay(ea)) relay(ea);
+        if (needs_relay(eb)) relay(eb);
+        merge_axes(pre, {batch_strides(ea), batch_strides(eb)}, ms, mst);
+    }
+    d.m = (int32_t)m;
+    d.a_rs = ea.strides[(size_t)nd - 2]; d.a_cs = ea.strides[(size_t)nd - 1];
+    d.b_rs = eb.strides[(size_t)nd - 2]; d.b_cs = eb.strides[(size_t)nd - 1];
+    d.batch = (int32_t)detail::prod(ms, 0, ms.size());
+    if (ms.size() == 2) {
+        d.a_bs = mst[0][0]; d.b_bs = mst[1][0]; d.c_bs = ms[1] * m * n;
+        d.batch_inner = (int32_t)ms[1]; d.a_bsi = mst[0][1]; d.b_bsi = mst[1][1]; d.c_bsi = m * n;
+    } else if (ms.size() == 1) {
+        d.a_bs = mst[0][0]; d.b_bs = mst[1][0]; d.c_bs = m * n;
+    }
+    ctx.check(rten_hip_gemm_f32(ctx.raw(), &d, ea.p, eb.p, nullptr, (float *)y.ptr()));
+    return y;
+}
+
+inline View diagonals(std::string &term, const View &v) { // take_diagonals, einsum.rs:124-162
+    const std::string labels = dedup(term);
+    View o;
+    o.p = v.p;
+    for (char c : labels) {
+        int64_t size = -1, stride = 0;
+        for (size_t i = 0; i < term.size(); i++) {
+            if (term[i] != c) continue;
+            if (size >= 0 && v.shape[i] != size) throw OpError(OpError::InvalidValue, "Dimension sizes for repeated labels in term do not match");
+            size = v.shape[i];
+            stride += v.strides[i];
+        }
+        o.shape.push_back(size);
+        o.strides.push_back(stride);
+    }
+    term = labels;
+    return o;
+}
+
+inline int64_t bsize(int64_t a, int64_t b) { // broadcast_size, einsum.rs:197-205
+    if (a == b || b == 1) return a;
+    if (a == 1) return b;
+    throw OpError(OpError::IncompatibleInputShapes, "Einsum label has different sizes in different terms");
+}
+
+// einsum_matmul, einsum.rs:449-537
+inline Tensor contract(Context &ctx, const View &x, const View &y, const std::string &tx, const std::string &ty, const std::string &out, char kl) {
+    char nl = INS_N, ml = INS_M;
+    for (size_t i = ty.size(); i-- > 0;) if (!has(tx, ty[i])) { nl = ty[i]; break; }
+    for (size_t i = tx.size(); i-- > 0;) if (!has(ty, tx[i])) { ml = tx[i]; break; }
+    std::string batch;
+    for (char c : dedup(tx + ty)) if (c != kl && c != ml && c != nl) batch.push_back(c);
+    View xv = x.relabel(tx, batch + ml + kl), yv = y.relabel(ty, batch + kl + nl);
+    const int64_t ks = bsize(xv.shape.back(), yv.shape[yv.shape.size() - 2]);
+    Shape xs = xv.shape, ys = yv.shape;
+    xs.back() = ks;
+    ys[ys.size() - 2] = ks;
+    Tensor r = matmul(ctx, xv.expanded(xs), yv.expanded(ys));
+    const std::string full = batch + ml + nl;
+    std::string order;
+    Shape shape;
+    for (size_t i = 0; i < full.size(); i++) if (full[i] != INS_M && full[i] != INS_N) { order.push_back(full[i]); shape.push_back(r.size((int)i)); }
+    r.reshape(shape);
+    if (order == out) return r;
+    return materialize(ctx, View::of(r).relabel(order, out));
+}
+
+// einsum_step, einsum.rs:238-364
+inline Tensor run_step(Context &ctx, const Step &s, View x, const View *yin) {
+    std::string tx = s.lhs, ty = s.rhs;
+    const std::string &out = s.out;
+    x = diagonals(tx, x);
+    auto reduced = [&](const std::string &labels) { std::string r; for (char c : labels) if (!has(out, c)) r.push_back(c); return r; };
+    auto trailing = [&](size_t from, size_t count) { std::vector<int> a; for (size_t i = 0; i < count; i++) a.push_back((int)(from + i)); return a; };
+    if (!s.binary) {
+        const std::string red = reduced(tx);
+        const View xv = x.relabel(tx, out + red);
+        return red.empty() ? materialize(ctx, xv) : reduce_sum(ctx, xv, trailing(out.size(), red.size()));
+    }
+    View y = diagonals(ty, *yin);
+    std::vector<Tensor> keep;
+    auto drop_lone = [&](View &v, std::string &term, const std::string &other) { // sum_lone_dims, einsum.rs:168-190
+        std::vector<int> lone;
+        std::string kept;
+        for (size_t i = 0; i < term.size(); i++) {
+            if (has(other, term[i]) || has(out, term[i])) kept.push_back(term[i]);
+            else lone.push_back((int)i);
+        }
+        if (!lone.empty()) { keep.push_back(reduce_sum(ctx, v, lone)); v = View::of(keep.back()); }
+        term = kept;
+    };
+    drop_lone(x, tx, ty);
+    drop_lone(y, ty, tx);
+    const std::string red = reduced(dedup(tx + ty));
+    if (red.size() == 1) return contract(ctx, x, y, tx, ty, out, red[0]);
+    const View xv = x.relabel(tx, out + red), yv = y.relabel(ty, out + red);
+    if (red.empty()) return mul(ctx, xv, yv);
+    Shape xs = xv.shape, ys = yv.shape; // several reduced labels: re-laid side by side and merged into one K (einsum.rs:310-344)
+    int64_t ksz = 1;
+    for (size_t i = out.size(); i < xs.size(); i++) { xs[i] = ys[i] = bsize(xs[i], ys[i]); ksz *= xs[i]; }
+    Tensor xc = materialize(ctx, xv.expanded(xs)), yc = materialize(ctx, yv.expanded(ys));
+    xs.resize(out.size()); xs.push_back(ksz);
+    ys.resize(out.size()); ys.push_back(ksz);
+    xc.reshape(xs);
+    yc.reshape(ys);
+    return contract(ctx, View::of(xc), View::of(yc), out + MERGED_K, out + MERGED_K, out, MERGED_K);
+}
+} // namespace einsum_detail
+
+struct ReduceSum : Operator { // src/ops/reduce.rs:1126-1165 (f32); axes as the attribute (or the resolved second input)
+    std::vector<int> axes;
+    bool keep_dims = true, noop_with_empty_axes = false;
+    const char *name() const override { return "ReduceSum"; }
+    int max_inputs() const override { return 2; }
+    OutputList run(Context &ctx, const InputList &in) const override {
+        namespace E = einsum_detail;
+        const Tensor &x = want(require(in, 0), DType::F32, "float32");
+        const int nd = x.ndim();
+        OutputList out;
+        if ((axes.empty() && noop_with_empty_axes) || nd == 0) { out.push_back(E::materialize(ctx, E::View::of(x))); return out; }
+        std::vector<int> ax;
+        if (axes.empty()) for (int d = 0; d < nd; d++) ax.push_back(d);
+        for (int a : axes) ax.push_back(resolve_axis(a, nd));
+        std::sort(ax.begin(), ax.end());
+        ax.erase(std::unique(ax.begin(), ax.end()), ax.end()); // resolve_axes, src/ops/mod.rs:259-271
+        Tensor y = E::reduce_sum(ctx, E::View::of(x), ax);
+        if (keep_dims) {
+            std::vector<int64_t> s = x.shape();
+            for (int a : ax) s[(size_t)a] = 1;
+            y.reshape(s);
+        }
+        out.push_back(std::move(y));
+        return out;
+    }
+};
+
+struct Einsum : Operator { // src/ops/einsum.rs:21-108
+    std::string equation;
+    const char *name() const override { return "Einsum"; }
+    int max_inputs() const override { return -1; }
+    OutputList run(Context &ctx, const InputList &in) const override {
+        namespace E = einsum_detail;
+        std::vector<int> ndims;
+        for (size_t i = 0; i < in.size(); i++) ndims.push_back(want(require(in, i), DType::F32, "float32").ndim());
+        std::vector<std::string> terms;
+        std::string out;
+        E::parse_equation(equation, terms, out);
+        const int bdims = E::broadcast_ndim(terms, ndims);
+        Tensor result;
+        for (const E::Step &s : E::plan_path(terms, out, bdims)) {
+            const E::View x = s.lhs_src < 0 ? E::View::of(result) : E::View::of(*in[(size_t)s.lhs_src]);
+            E::View y;
+            if (s.binary) y = s.rhs_src < 0 ? E::View::of(result) : E::View::of(*in[(size_t)s.rhs_src]);
+            Tensor next = E::run_step(ctx, s, x, s.binary ? &y : nullptr);
+            result = std::move(next); // the previous result is released only after the step that read it was enqueued
+        }
+        OutputList o;
+        o.push_back(std::move(result));
+        return o;
+    }
+};
+
 // ------------------------------------------------------------------------------------------------ registry (src/op_registry.rs:25-72)
 class OpRegistry {
   public:
@@ -1120,6 +1564,8 @@ class OpRegistry {
         r.register_op<GlobalAveragePool>("GlobalAveragePool");
         r.register_op<DynamicQuantizeLinear>("DynamicQuantizeLinear");
         r.register_op<Cast>("Cast");
+        r.register_op<ReduceSum>("ReduceSum");
+        r.register_op<Einsum>("Einsum");
         return r;
     }
 

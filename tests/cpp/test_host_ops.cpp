@@ -29,6 +29,7 @@ void rto_layer_norm(int64_t rows, int64_t cols, const float *x, const float *gam
 void rto_pool2d(int64_t N, int64_t C, int64_t H, int64_t W, int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t pt, int64_t pl, int64_t OH, int64_t OW,
                 const float *x, float *y, int is_max, int count_include_pad);
 void rto_global_avg_pool(int64_t NC, int64_t inner, const float *x, float *y, int lanes);
+float rto_simd_sum(const float *x, int64_t n, int lanes);
 }
 
 using namespace rten_hip;
@@ -78,9 +79,44 @@ static void host_only_tests() {
     const rten_hip_conv2d_desc ds = same.geometry({1, 4, 9, 9}, {4, 4, 3, 3});
     CHECK(ds.out_h == 5 && ds.out_w == 5, "conv same padding output size");
     const OpRegistry reg = OpRegistry::with_all_ops();
-    CHECK(reg.contains("Conv") && reg.contains("MatMulInteger") && !reg.contains("Einsum"), "registry contents");
+    CHECK(reg.contains("Conv") && reg.contains("MatMulInteger") && reg.contains("Einsum") && !reg.contains("Where"), "registry contents");
     CHECK(std::string(reg.create("LayerNormalization")->name()) == "LayerNormalization", "registry create");
-    expect_error(OpError::UnsupportedValue, "operator not registered: Einsum", [&] { reg.create("Einsum"); }, "registry missing op");
+    expect_error(OpError::UnsupportedValue, "operator not registered: Where", [&] { reg.create("Where"); }, "registry missing op");
+}
+
+
+// Einsum: parser, validation and path tables of the reference (einsum_parser.rs:277-557, einsum.rs:971-1293,1313-1498)
+static void einsum_host_tests() {
+    namespace E = rten_hip::einsum_detail;
+    auto parsed = [](const char *eq) { std::vector<std::string> t; std::string o; E::parse_equation(eq, t, o); std::string j; for (auto &x : t) j += x + ","; return j + "->" + o; };
+    CHECK(parsed(" i j , j k -> i k ") == "ij,jk,->ik", "einsum parse whitespace");
+    CHECK(parsed("ij,jk") == "ij,jk,->ik", "einsum implicit output");
+    CHECK(parsed("aBc") == "aBc,->Bac", "einsum implicit output ASCII order");
+    CHECK(parsed("...ij") == "...ij,->...ij", "einsum implicit ellipsis");
+    CHECK(parsed("") == ",->" && parsed("->") == ",->", "einsum empty equation");
+    expect_error(OpError::InvalidValue, "Input term is invalid", [&] { parsed("i1j"); }, "einsum digit label");
+    expect_error(OpError::InvalidValue, "Input term is invalid", [&] { parsed("i...j..."); }, "einsum two ellipses");
+    expect_error(OpError::InvalidValue, "Output term is invalid", [&] { parsed("ij,jk->i.k"); }, "einsum bad output");
+    expect_error(OpError::InvalidValue, "Einsum output term contains repeated labels", [&] { parsed("ij->ii"); }, "einsum repeated output");
+    expect_error(OpError::InvalidValue, "Einsum output term contains a label not present in any input term", [&] { parsed("ij,jk->IK"); }, "einsum unknown label");
+    auto bnd = [](const char *eq, std::vector<int> nd) { std::vector<std::string> t; std::string o; E::parse_equation(eq, t, o); return E::broadcast_ndim(t, nd); };
+    CHECK(bnd("i...j->j...i", {5}) == 3 && bnd("ij,jk", {2, 2}) == 0, "einsum broadcast dims");
+    expect_error(OpError::InvalidValue, "Number of terms in Einsum equation does not match input tensor count", [&] { bnd("ij,jk->ik", {2}); }, "einsum input count");
+    expect_error(OpError::InvalidValue, "Einsum term dimension count does not match input tensor", [&] { bnd("ij", {1}); }, "einsum rank");
+    expect_error(OpError::UnsupportedValue, "Einsum input or term has too many dimensions", [&] { bnd("...", {11}); }, "einsum too many dims");
+    expect_error(OpError::InvalidValue, "Number of broadcast dims does not match across inputs", [&] { bnd("...,...->...", {1, 2}); }, "einsum broadcast mismatch");
+    auto path = [](const char *eq, int b) {
+        std::vector<std::string> t; std::string o; E::parse_equation(eq, t, o);
+        std::string j;
+        for (auto &s : E::plan_path(t, o, b)) j += s.lhs + "@" + std::to_string(s.lhs_src) + (s.binary ? "," + s.rhs + "@" + std::to_string(s.rhs_src) : "") + "->" + s.out + ";";
+        return j;
+    };
+    CHECK(path("ab,bc,cd,de->ea", 0) == "ab@0,bc@1->ac;ac@-1,cd@2->ad;ad@-1,de@3->ea;", "einsum path chain");
+    CHECK(path("ab,cd,ef", 0) == "ab@0,cd@1->abcd;abcd@-1,ef@2->abcdef;", "einsum path outer");
+    CHECK(path("ii,j,i->", 0) == "ii@0,j@1->i;i@-1,i@2->;", "einsum path repeated label kept");
+    CHECK(path("ii,i,j->", 0) == "ii@0,i@1->;@-1,j@2->;", "einsum path repeated label dropped");
+    CHECK(path("i...j->j...i", 3) == "i012j@0->j012i;", "einsum path ellipsis");
+    CHECK(path("...i,...j,...k->...ijk", 2) == "01i@0,01j@1->01ij;01ij@-1,01k@2->01ijk;", "einsum path ellipsis chain");
 }
 
 static void device_tests() {
@@ -196,6 +232,47 @@ static void device_tests() {
         rto_global_avg_pool(N * C, H * W, x.data(), gw.data(), 16);
         CHECK(same_bits(GlobalAveragePool().run(ctx, {&tx})[0].to_host<float>(), gw), "GlobalAveragePool bits");
     }
+    { // Einsum / ReduceSum through strides, against compositions of the oracle's GEMM and ordered sum
+        const int64_t B = 2, S = 17, T = 19, H = 3, D = 8;
+        auto q = randf(31, B * S * H * D), kk = randf(32, B * T * H * D);
+        Tensor tq = Tensor::from_host(ctx, {B, S, H, D}, q.data()), tk = Tensor::from_host(ctx, {B, T, H, D}, kk.data());
+        Einsum scores;
+        scores.equation = "bqhd,bkhd->bhqk"; // un-transposed [B, S, H, D] heads: one strided two-level batched GEMM
+        OutputList y = scores.run(ctx, {&tq, &tk});
+        CHECK(y[0].shape() == (std::vector<int64_t>{B, H, S, T}), "Einsum attention-scores shape");
+        std::vector<float> want((size_t)(B * H * S * T));
+        for (int64_t b = 0; b < B; b++)
+            for (int64_t h = 0; h < H; h++)
+                rto_gemm_f32(S, T, D, q.data() + b * S * H * D + h * D, H * D, 1, kk.data() + b * T * H * D + h * D, 1, H * D, want.data() + (b * H + h) * S * T, T, 1.0f,
+                             0.0f, nullptr, 0);
+        CHECK(same_bits(y[0].to_host<float>(), want), "Einsum bqhd,bkhd->bhqk bits");
+        const int64_t M = 70, K = 513, N = 45;
+        auto a = randf(33, M * K), bb = randf(34, N * K);
+        Tensor ta = Tensor::from_host(ctx, {M, K}, a.data()), tb = Tensor::from_host(ctx, {N, K}, bb.data());
+        Einsum abt;
+        abt.equation = "ik,jk->ji"; // transposed RHS as strides, transposed output as the one copy
+        std::vector<float> c((size_t)(M * N)), ct((size_t)(M * N));
+        rto_gemm_f32(M, N, K, a.data(), K, 1, bb.data(), 1, K, c.data(), N, 1.0f, 0.0f, nullptr, 0);
+        for (int64_t i = 0; i < M; i++) for (int64_t j = 0; j < N; j++) ct[(size_t)(j * M + i)] = c[(size_t)(i * N + j)];
+        CHECK(same_bits(abt.run(ctx, {&ta, &tb})[0].to_host<float>(), ct), "Einsum ik,jk->ji bits");
+        Einsum colsum;
+        colsum.equation = "ij->j"; // reduction over the strided axis, in place
+        std::vector<float> cs((size_t)K), col((size_t)M);
+        for (int64_t j = 0; j < K; j++) { for (int64_t i = 0; i < M; i++) col[(size_t)i] = a[(size_t)(i * K + j)]; cs[(size_t)j] = rto_simd_sum(col.data(), M, 16); }
+        CHECK(same_bits(colsum.run(ctx, {&ta})[0].to_host<float>(), cs), "Einsum ij->j bits");
+        ReduceSum rs;
+        rs.axes = {-1};
+        rs.keep_dims = false;
+        std::vector<float> rsum((size_t)M);
+        for (int64_t i = 0; i < M; i++) rsum[(size_t)i] = rto_simd_sum(a.data() + i * K, K, 16);
+        CHECK(same_bits(rs.run(ctx, {&ta})[0].to_host<float>(), rsum), "ReduceSum bits");
+        Einsum diag;
+        diag.equation = "ii->i";
+        expect_error(OpError::InvalidValue, "Dimension sizes for repeated labels in term do not match", [&] { diag.run(ctx, {&ta}); }, "einsum diagonal sizes");
+        Einsum mism;
+        mism.equation = "ij,jk->ik";
+        expect_error(OpError::IncompatibleInputShapes, "Einsum label has different sizes in different terms", [&] { mism.run(ctx, {&ta, &tb}); }, "einsum label sizes");
+    }
     ctx.sync();
 }
 
@@ -203,6 +280,7 @@ int main(int argc, char **argv) {
     const bool host_only = argc > 1 && std::strcmp(argv[1], "--host-only") == 0;
     try {
         host_only_tests();
+        einsum_host_tests();
         if (!host_only) device_tests();
     } catch (const OpError &e) {
         std::printf("FAIL unexpected OpError: %s\n", e.what());

@@ -353,3 +353,45 @@ def test_matmul_nbits_node_in_a_graph(tmp_path):
     got, _ = _run_model(tmp_path, m1, x1, "y")
     want = ref.relu(ref.matmul_nbits_f32(x1, quant, scales))
     assert np.array_equal(got.view(np.int32), want.ravel().view(np.int32))
+
+
+def _einsum_attention_model(wk, wv, S, H, D):
+    """x [batch, S, H*D] -> Reshape [batch, S, H, D] = q; K / V = Einsum projections of x with per-head weights;
+    scores = Einsum(bqhd,bkhd->bhqk) -> Softmax -> Einsum(bhqk,bkhd->bqhd) -> ReduceSum over heads."""
+    from rten_amd import onnx_writer as ow
+    nodes = [ow.node("Reshape", ["x", "shape4"], ["q"]),
+             ow.node("Einsum", ["x", "wk"], ["k"], equation="bsc,chd->bshd"),
+             ow.node("Einsum", ["x", "wv"], ["v"], equation="bsc,chd->bshd"),
+             ow.node("Einsum", ["q", "k"], ["scores"], equation="bqhd,bkhd->bhqk"),
+             ow.node("Softmax", ["scores"], ["probs"], axis=-1),
+             ow.node("Einsum", ["probs", "v"], ["ctx"], equation="bhqk,bkhd->bqhd"),
+             ow.node("ReduceSum", ["ctx", "axes"], ["y"], keepdims=0)]
+    inits = [ow.tensor("shape4", np.array([0, S, H, D], np.int64)), ow.tensor("wk", wk), ow.tensor("wv", wv), ow.tensor("axes", np.array([2], np.int64))]
+    return ow.model(nodes, [ow.value_info("x", 1, ["batch", S, H * D])], [ow.value_info("y", 1, ["batch", S, D])], inits)
+
+
+def test_cpp_loader_parses_einsum_graph(tmp_path):
+    rng = np.random.default_rng(2)
+    p = tmp_path / "einsum.onnx"
+    p.write_bytes(_einsum_attention_model(rng.standard_normal((24, 3, 8)).astype(np.float32), rng.standard_normal((24, 3, 8)).astype(np.float32), 10, 3, 8))
+    out = run_cli("--parse-only", str(p))
+    assert out.returncode == 0 and "Einsum x4" in out.stdout and "ReduceSum x1" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_einsum_attention_graph_bit_exact(tmp_path):
+    """Einsum / ReduceSum nodes from an ONNX file through the C++ executor (include/rten_hip_graph.hpp) against the oracle's
+    restatement of the reference's Einsum (oracle/einsum.py) and softmax."""
+    from oracle import einsum as OE
+    from oracle import ref
+    rng = np.random.default_rng(2)
+    B, S, H, D = 3, 10, 3, 8
+    wk = (rng.standard_normal((H * D, H, D)) * 0.2).astype(np.float32)
+    wv = (rng.standard_normal((H * D, H, D)) * 0.2).astype(np.float32)
+    x = rng.standard_normal((B, S, H * D)).astype(np.float32)
+    q = x.reshape(B, S, H, D)
+    k, v = OE.einsum("bsc,chd->bshd", x, wk), OE.einsum("bsc,chd->bshd", x, wv)
+    probs = ref.softmax(OE.einsum("bqhd,bkhd->bhqk", q, k))
+    want = OE.reduce_sum(OE.einsum("bhqk,bkhd->bqhd", probs, v), [2])
+    got, log = _run_model(tmp_path, _einsum_attention_model(wk, wv, S, H, D), x, "y")
+    assert np.array_equal(got.view(np.int32), want.ravel().view(np.int32)), np.abs(got - want.ravel()).max()
