@@ -194,9 +194,41 @@ class Context:
             raise HipError(rc, "rten_hip_init failed")
         self.h = h
         self.device = device
+        self._pool_on = False
+        self._pool = {}  # byte size -> free device pointers
+
+    # Device buffer pool (src/buffer_pool.rs; the C++ layer's Context::enable_pool): off by default.  When on, freed tensors
+    # go to a free list keyed by exact size and are handed out again without hipMalloc / hipFree (neither of which is
+    # asynchronous); the context's single stream orders the reuse.
+    def enable_pool(self, on: bool = True):
+        self._pool_on = on
+        if not on:
+            self.trim_pool()
+
+    def alloc(self, nbytes: int) -> int:
+        nbytes = max(int(nbytes), 16)
+        free = self._pool.get(nbytes) if self._pool_on else None
+        if free:
+            return free.pop()
+        p = C.c_void_p()
+        self.call("rten_hip_malloc", C.c_size_t(nbytes), C.byref(p))
+        return p.value
+
+    def release(self, ptr: int, nbytes: int):
+        if self._pool_on:
+            self._pool.setdefault(max(int(nbytes), 16), []).append(ptr)
+        else:
+            self.call("rten_hip_free", C.c_void_p(ptr))
+
+    def trim_pool(self):
+        for free in self._pool.values():
+            for p in free:
+                self.call("rten_hip_free", C.c_void_p(p))
+        self._pool = {}
 
     def close(self):
         if getattr(self, "h", None):
+            self.trim_pool()
             self.lib.rten_hip_destroy(self.h)
             self.h = None
 

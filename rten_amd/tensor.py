@@ -22,9 +22,12 @@ class DeviceTensor:
         self._owned = ptr is None
         self._keepalive = keepalive
         if ptr is None:
-            p = C.c_void_p()
-            ctx.call("rten_hip_malloc", C.c_size_t(max(self.nbytes, 16)), C.byref(p))
-            self.ptr = p.value
+            if hasattr(ctx, "alloc"):  # Context: pooled when enable_pool() is on
+                self.ptr = ctx.alloc(self.nbytes)
+            else:
+                p = C.c_void_p()
+                ctx.call("rten_hip_malloc", C.c_size_t(max(self.nbytes, 16)), C.byref(p))
+                self.ptr = p.value
         else:
             self.ptr = int(ptr)
 
@@ -76,7 +79,10 @@ class DeviceTensor:
 
     def free(self):
         if self._owned and self.ptr and self.ctx.h:
-            self.ctx.call("rten_hip_free", C.c_void_p(self.ptr))
+            if hasattr(self.ctx, "release"):
+                self.ctx.release(self.ptr, self.nbytes)
+            else:
+                self.ctx.call("rten_hip_free", C.c_void_p(self.ptr))
         self.ptr = 0
 
     def __del__(self):

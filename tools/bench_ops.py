@@ -130,6 +130,24 @@ def main():
             else:
                 mfma("MatMulNBits prefill", f"{rows_q}x{kq}x{nq} q4/{bsq}", fn, 2.0 * rows_q * kq * nq, F32_PEAK_TF, "TFLOP/s")
 
+    # ---- ReduceSum through strides and Einsum (src/ops/reduce.rs, src/ops/einsum.rs): a contiguous last-axis sum, a column sum over
+    # the strided axis (nothing packed), and the two attention products written as Einsum on un-transposed [B, S, H, D]
+    # projections (one strided two-level batched GEMM each; the second also pays the output permutation copy)
+    from rten_amd import ops as _ops
+    ctx.enable_pool(True)  # operator-level rows: outputs and intermediates come from the buffer pool, as under a graph executor
+    xr = dev(rng.standard_normal((32 * 12 * 128, 128), dtype=np.float32))
+    rs_last, rs_first = _ops.ReduceSum(axes=[1], keep_dims=False), _ops.ReduceSum(axes=[0], keep_dims=False)
+    hbm("ReduceSum last axis", "49152x128", (lambda: rs_last.run(ctx, [xr])), 4.0 * (49152 * 128 + 49152))
+    xc = dev(rng.standard_normal((4096, 3072), dtype=np.float32))
+    hbm("ReduceSum strided axis", "4096x3072 -> 3072", (lambda: rs_first.run(ctx, [xc])), 4.0 * (4096 * 3072 + 3072))
+    Be, Se, He, De = 32, 128, 12, 64
+    qe, ke, ve = (dev(rng.standard_normal((Be, Se, He, De), dtype=np.float32)) for _ in range(3))
+    pe = dev(rng.standard_normal((Be, He, Se, Se), dtype=np.float32))
+    es, ec = _ops.Einsum("bqhd,bkhd->bhqk"), _ops.Einsum("bhqk,bkhd->bqhd")
+    mfma("Einsum bqhd,bkhd->bhqk", f"{Be}x{Se}x{He}x{De}", (lambda: es.run(ctx, [qe, ke])), 2.0 * Be * He * Se * Se * De, F32_PEAK_TF, "TFLOP/s")
+    mfma("Einsum bhqk,bkhd->bqhd", f"{Be}x{He}x{Se}x{Se}", (lambda: ec.run(ctx, [pe, ve])), 2.0 * Be * He * Se * Se * De, F32_PEAK_TF, "TFLOP/s")
+    ctx.enable_pool(False)
+
     # ---- f32 GEMM on BERT-base shapes (batch 32 x 128 tokens)
     for (m, k, n, act, name) in ((4096, 768, 768, 0, "MatMul proj"), (4096, 768, 3072, L.ACT_GELU, "MatMul FFN1 + Gelu"), (4096, 3072, 768, 0, "MatMul FFN2")):
         a, w, bias, out = dev(rng.standard_normal((m, k), dtype=np.float32)), dev(rng.standard_normal((k, n), dtype=np.float32)), dev(np.zeros(n, np.float32)), empty((m, n))
