@@ -431,24 +431,67 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void reduce_sum_kernel(const R
     if (lane == 0) y[row] = s;
 }
 
-// Slices of at most 64 elements: four output elements per wave, one per 16-lane DPP row (global_avg_pool_rows16_kernel's scheme).
+// Slices of at most 16 * EPL elements: four output elements per wave, one per 16-lane DPP row (global_avg_pool_rows16_kernel's
+// scheme).  Lane l owns elements l + 16 q -- the ones the reference's accumulator lane l adds: the first 4 * (n / 64) of them
+// go round-robin into the four unrolled accumulators, which fold left to right; the rest (whole vectors, masked tail) are
+// added to the folded value one by one (rten-simd/src/iter.rs:97-120).
+template <int EPL>
 __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void reduce_sum_rows16_kernel(const ReduceArgs p, const float *__restrict__ x,
                                                                                 float *__restrict__ y) {
     const int lane = threadIdx.x & 63, l = lane & 15;
     const int64_t row = ((int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6)) * 4 + (lane >> 4);
     const int64_t rr = row < p.rows ? row : p.rows - 1;
     const float *xr = x + reduce_row_base(p, rr);
-    float v[4];
+    float v[EPL];
 #pragma unroll
-    for (int q = 0; q < 4; q++) v[q] = xr[reduce_elem_off(p, l + 16 * q < p.inner ? l + 16 * q : 0)];
-    float a = 0.f;
+    for (int q = 0; q < EPL; q++) v[q] = xr[reduce_elem_off(p, l + 16 * q < p.inner ? l + 16 * q : 0)];
+    const int unrolled = (p.inner >> 6) * 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < 4; q++)
-        if (l + 16 * q < p.inner) a = a + v[q];
-    float acc = a;
+    for (int q = 0; q < EPL; q++)
+        if (q < unrolled) acc[q & 3] = acc[q & 3] + v[q];
+    float a = ((acc[0] + acc[1]) + acc[2]) + acc[3];
 #pragma unroll
-    for (int k = 1; k < 16; k++) acc = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x111, 0xf, 0xf, true)) + a;
-    if (l == 15 && row < p.rows) y[row] = acc;
+    for (int q = 0; q < EPL; q++)
+        if (q >= unrolled && l + 16 * q < p.inner) a = a + v[q];
+    float s = a;
+#pragma unroll
+    for (int k = 1; k < 16; k++) s = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x111, 0xf, 0xf, true)) + a;
+    if (l == 15 && row < p.rows) y[row] = s;
+}
+
+// Reduced axes strided, innermost kept axis contiguous (a column sum): a wave-per-row walk would touch 64 cache lines per
+// load.  Here a 1024-thread workgroup owns 16 adjacent output elements j; wave w is the reference's accumulator lane l = w and
+// its lanes are (u = unrolled accumulator, j): every load instruction reads four 64-byte runs.  Each thread's chain is the
+// reference's acc[u][l]; the fold over u is three lane shuffles, the in-order sum over l goes through LDS.
+__global__ __launch_bounds__(1024) void reduce_sum_cols_kernel(const ReduceArgs p, const float *__restrict__ x, float *__restrict__ y) {
+    __shared__ float part[16][16];
+    const int lane = threadIdx.x & 63, l = threadIdx.x >> 6, u = lane >> 4, j = lane & 15;
+    const int last = p.oshape[p.n_outer - 1];
+    const int groups = (last + 15) >> 4;
+    const int64_t prefix = blockIdx.x / groups;
+    const int j0 = (int)(blockIdx.x - prefix * groups) * 16;
+    const int jj = j0 + j < last ? j0 + j : last - 1;
+    const int64_t row = prefix * last + jj;
+    const float *xr = x + reduce_row_base(p, row);
+    const int n = p.inner, full4 = n >> 6;
+    float acc = 0.f;
+    for (int c = 0; c < full4; c++) acc = acc + xr[reduce_elem_off(p, c * 64 + u * 16 + l)];
+    float a = lane_bcast(acc, j);
+    a = a + lane_bcast(acc, j + 16);
+    a = a + lane_bcast(acc, j + 32);
+    a = a + lane_bcast(acc, j + 48);
+    int i0 = full4 * 64;
+    for (; i0 + 16 <= n; i0 += 16) a = a + xr[reduce_elem_off(p, i0 + l)];
+    if (i0 + l < n) a = a + xr[reduce_elem_off(p, i0 + l)];
+    if (u == 0) part[l][j] = a;
+    __syncthreads();
+    if (threadIdx.x < 16 && j0 + (int)threadIdx.x < last) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) s = s + part[k][threadIdx.x];
+        y[prefix * last + j0 + threadIdx.x] = s;
+    }
 }
 
 } // namespace
@@ -570,8 +613,13 @@ RTEN_EXPORT int32_t rten_hip_reduce_sum_strided_f32(rten_hip_ctx *ctx, int32_t n
     if (!x) return RTEN_HIP_ERR_INVALID_VALUE;
     const dim3 block(64 * ROWS_PER_BLOCK);
     ProfScope ps(ctx, "reduce_sum_f32", 0.0, 4.0 * p.rows * (inner + 1));
-    if (inner <= 64)
-        hipLaunchKernelGGL(reduce_sum_rows16_kernel, dim3((unsigned)((p.rows + 4 * ROWS_PER_BLOCK - 1) / (4 * ROWS_PER_BLOCK))), block, 0, ctx->stream, p, x, y);
+    const dim3 grid16((unsigned)((p.rows + 4 * ROWS_PER_BLOCK - 1) / (4 * ROWS_PER_BLOCK)));
+    const int64_t last = n_outer ? p.oshape[n_outer - 1] : 1;
+    if (inner > 64 && n_outer && p.ostride[n_outer - 1] == 1 && last >= 16 && p.istride[p.n_inner - 1] > 1)
+        hipLaunchKernelGGL(reduce_sum_cols_kernel, dim3((unsigned)(p.rows / last * ((last + 15) / 16))), dim3(1024), 0, ctx->stream, p, x, y);
+    else if (inner <= 64) hipLaunchKernelGGL(reduce_sum_rows16_kernel<4>, grid16, block, 0, ctx->stream, p, x, y);
+    else if (inner <= 128) hipLaunchKernelGGL(reduce_sum_rows16_kernel<8>, grid16, block, 0, ctx->stream, p, x, y);
+    else if (inner <= 256) hipLaunchKernelGGL(reduce_sum_rows16_kernel<16>, grid16, block, 0, ctx->stream, p, x, y);
     else
         hipLaunchKernelGGL(reduce_sum_kernel, dim3((unsigned)((p.rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block, 0, ctx->stream, p, x, y);
     RTEN_LAUNCH_CHECK(ctx, "reduce_sum_kernel");

@@ -348,7 +348,13 @@ def test_gpu_reduce_sum_strided_matches_oracle(ctx):
     """ReduceSum through strides (kept / reduced axes interleaved, diagonal, broadcast, slices of 1..3000 elements, empty)."""
     rng = np.random.default_rng(11)
     for shape, axes in (((4, 70, 3, 5), [1]), ((4, 70, 3, 5), [0, 3]), ((4, 70, 3, 5), [0, 1, 2, 3]), ((3000, 7), [0]), ((7, 3000), [1]),
-                        ((129, 64), [1]), ((129, 65), [1]), ((5, 1, 9), [1]), ((6, 0, 4), [1]), ((2, 3, 4, 5, 6, 7), [1, 3, 5])):
+                        ((129, 64), [1]), ((129, 65), [1]), ((5, 1, 9), [1]), ((6, 0, 4), [1]), ((2, 3, 4, 5, 6, 7), [1, 3, 5]),
+                        # every branch of the 16-lane order on the four-rows-per-wave path (1..256 elements) and just above it
+                        *[((37, n), [1]) for n in (1, 15, 16, 17, 63, 64, 65, 79, 80, 127, 128, 129, 191, 192, 193, 255, 256, 257, 300)],
+                        # column sums (coalesced kernel): whole and ragged groups of 16 columns, chunk / vector / tail boundaries,
+                        # a kept prefix axis, two reduced axes of which the inner one is strided
+                        *[((n, c), [0]) for n in (65, 128, 143, 144, 150, 1000) for c in (16, 17, 100)],
+                        ((3, 200, 40), [1]), ((70, 3, 33), [0, 1]), ((9, 70, 5, 20), [1]), ((4096, 384), [0])):
         x = rng.standard_normal(shape).astype(np.float32)
         got = ops.ReduceSum(axes=axes, keep_dims=False).run(ctx, [DeviceTensor.from_numpy(ctx, x)])[0].numpy()
         want = OE.reduce_sum(x, axes, False)
