@@ -1083,7 +1083,8 @@ struct Cast : Operator {
 // Here a view is (device pointer, shape, element strides) and the kernels read THROUGH the strides: permutes, inserted axes,
 // diagonals and 1 -> n expansion are stride arithmetic; ReduceSum runs in place on the strided view; a product is ONE
 // rten_hip_gemm_f32 launch (M / K / N are strides, batch labels become the descriptor's two batch levels once neighbouring
-// axes with compatible strides are merged); only the final permutation into the output order is a copy.  The order of the
+// axes with compatible strides are merged); the final permutation into the output order goes into the GEMM's C strides when it
+// keeps N innermost and is a copy otherwise.  The order of the
 // arithmetic is the reference's (same path, same M / N / batch labels, lone labels summed first, [A, M, K] x [K, N] folded
 // into one GEMM), so results are bit-identical except for a GEMM with one row (ISA-dependent gemv path).
 namespace einsum_detail {
@@ -1313,18 +1314,17 @@ inline Tensor mul(Context &ctx, const View &a, const View &b) { // mul() with nu
 }
 
 // matmul() of [batch.., M, K] x [batch.., K, N] views of equal rank, src/ops/matmul.rs:208-385
-inline Tensor matmul(Context &ctx, View a, View b) {
+// `into`: [batch.., M, N] view (N contiguous) of the caller's output tensor; the GEMM then writes the permuted output directly
+// through ldc and the C batch strides.  Returns false when those strides do not fit the descriptor's two batch levels.
+inline bool matmul_into(Context &ctx, View a, View b, const View &cv) {
     const int nd = a.nd();
     const int64_t m = a.shape[(size_t)nd - 2], k = a.shape[(size_t)nd - 1], n = b.shape[(size_t)nd - 1];
     if (k != b.shape[(size_t)nd - 2]) throw OpError(OpError::IncompatibleInputShapes, "Columns of first matrix does not match rows of second matrix");
     const Shape apre(a.shape.begin(), a.shape.end() - 2), bpre(b.shape.begin(), b.shape.end() - 2);
     const Shape pre = broadcast(apre, bpre, "Cannot broadcast shapes");
-    Shape oshape = pre;
-    oshape.push_back(m);
-    oshape.push_back(n);
-    Tensor y(ctx, oshape, DType::F32);
-    if (y.len() == 0) return y;
-    if (k == 0) { ctx.check(rten_hip_memset(ctx.raw(), y.ptr(), 0, y.bytes())); return y; }
+    float *const c = const_cast<float *>(cv.p);
+    if (cv.len() == 0) return true;
+    if (k == 0) { ctx.check(rten_hip_memset(ctx.raw(), c, 0, (size_t)cv.len() * 4)); return true; } // the output tensor is exactly this view's elements
     std::vector<Tensor> keep; // re-laid operands stay alive until the launch is enqueued
     auto relay = [&](View &v) { keep.push_back(materialize(ctx, v)); v = View::of(keep.back()); };
     auto gemm_axis_is_broadcast = [&](const View &v) {
@@ -1335,25 +1335,30 @@ inline Tensor matmul(Context &ctx, View a, View b) {
     if (gemm_axis_is_broadcast(b)) relay(b);
     rten_hip_gemm_desc d;
     std::memset(&d, 0, sizeof d);
-    d.n = (int32_t)n; d.k = (int32_t)k; d.ldc = n; d.alpha = 1.0f; d.batch = 1;
+    d.n = (int32_t)n; d.k = (int32_t)k; d.ldc = std::max(cv.strides[(size_t)nd - 2], n); d.alpha = 1.0f; d.batch = 1;
     const int64_t na = detail::prod(apre, 0, apre.size()), nb = detail::prod(bpre, 0, bpre.size());
     Shape ms; std::vector<Shape> mst;
-    if (na > 1 && nb == 1) { // [A, M, K] x [K, N] as one GEMM of A * M rows (matmul.rs:266-297)
+    Shape crows_shape = pre, crows, crows_strides(cv.strides.begin(), cv.strides.end() - 1);
+    crows_shape.push_back(m);
+    std::vector<Shape> crows_st;
+    merge_axes(crows_shape, {crows_strides}, crows, crows_st);
+    if (na > 1 && nb == 1 && crows.size() <= 1) { // [A, M, K] x [K, N] as one GEMM of A * M rows (matmul.rs:266-297)
         auto rows = [&] { merge_axes(Shape(a.shape.begin(), a.shape.end() - 1), {Shape(a.strides.begin(), a.strides.end() - 1)}, ms, mst); };
         rows();
         if (ms.size() > 1) { relay(a); rows(); }
         d.m = (int32_t)(na * m);
         d.a_rs = ms.empty() ? 0 : mst[0][0]; d.a_cs = a.strides[(size_t)nd - 1];
         d.b_rs = b.strides[(size_t)nd - 2]; d.b_cs = b.strides[(size_t)nd - 1];
-        ctx.check(rten_hip_gemm_f32(ctx.raw(), &d, a.p, b.p, nullptr, (float *)y.ptr()));
-        return y;
+        d.ldc = crows.empty() ? n : std::max(crows_st[0][0], n);
+        ctx.check(rten_hip_gemm_f32(ctx.raw(), &d, a.p, b.p, nullptr, c));
+        return true;
     }
     Shape ea_shape = pre, eb_shape = pre;
     ea_shape.push_back(m); ea_shape.push_back(k);
     eb_shape.push_back(k); eb_shape.push_back(n);
     View ea = a.expanded(ea_shape), eb = b.expanded(eb_shape);
     auto batch_strides = [&](const View &v) { return Shape(v.strides.begin(), v.strides.end() - 2); };
-    merge_axes(pre, {batch_strides(ea), batch_strides(eb)}, ms, mst);
+    merge_axes(pre, {batch_strides(ea), batch_strides(eb), batch_strides(cv)}, ms, mst);
     if (ms.size() > 2) { // more batch levels than the descriptor has: re-lay the operand(s) that do not merge by themselves
         auto needs_relay = [&](const View &v) {
             Shape s1; std::vector<Shape> st1;
@@ -1362,19 +1367,29 @@ inline Tensor matmul(Context &ctx, View a, View b) {
         };
         if (needs_relay(ea)) relay(ea);
         if (needs_relay(eb)) relay(eb);
-        merge_axes(pre, {batch_strides(ea), batch_strides(eb)}, ms, mst);
+        merge_axes(pre, {batch_strides(ea), batch_strides(eb), batch_strides(cv)}, ms, mst);
+        if (ms.size() > 2) return false; // only a permuted C can still refuse to merge: the caller multiplies, then copies
     }
     d.m = (int32_t)m;
     d.a_rs = ea.strides[(size_t)nd - 2]; d.a_cs = ea.strides[(size_t)nd - 1];
     d.b_rs = eb.strides[(size_t)nd - 2]; d.b_cs = eb.strides[(size_t)nd - 1];
     d.batch = (int32_t)detail::prod(ms, 0, ms.size());
     if (ms.size() == 2) {
-        d.a_bs = mst[0][0]; d.b_bs = mst[1][0]; d.c_bs = ms[1] * m * n;
-        d.batch_inner = (int32_t)ms[1]; d.a_bsi = mst[0][1]; d.b_bsi = mst[1][1]; d.c_bsi = m * n;
+        d.a_bs = mst[0][0]; d.b_bs = mst[1][0]; d.c_bs = mst[2][0];
+        d.batch_inner = (int32_t)ms[1]; d.a_bsi = mst[0][1]; d.b_bsi = mst[1][1]; d.c_bsi = mst[2][1];
     } else if (ms.size() == 1) {
-        d.a_bs = mst[0][0]; d.b_bs = mst[1][0]; d.c_bs = m * n;
+        d.a_bs = mst[0][0]; d.b_bs = mst[1][0]; d.c_bs = mst[2][0];
     }
-    ctx.check(rten_hip_gemm_f32(ctx.raw(), &d, ea.p, eb.p, nullptr, (float *)y.ptr()));
+    ctx.check(rten_hip_gemm_f32(ctx.raw(), &d, ea.p, eb.p, nullptr, c));
+    return true;
+}
+inline Tensor matmul(Context &ctx, const View &a, const View &b) {
+    const int nd = a.nd();
+    Shape oshape = broadcast(Shape(a.shape.begin(), a.shape.end() - 2), Shape(b.shape.begin(), b.shape.end() - 2), "Cannot broadcast shapes");
+    oshape.push_back(a.shape[(size_t)nd - 2]);
+    oshape.push_back(b.shape[(size_t)nd - 1]);
+    Tensor y(ctx, oshape, DType::F32);
+    matmul_into(ctx, a, b, View::of(y)); // a contiguous C always fits
     return y;
 }
 
@@ -1415,11 +1430,22 @@ inline Tensor contract(Context &ctx, const View &x, const View &y, const std::st
     Shape xs = xv.shape, ys = yv.shape;
     xs.back() = ks;
     ys[ys.size() - 2] = ks;
-    Tensor r = matmul(ctx, xv.expanded(xs), yv.expanded(ys));
     const std::string full = batch + ml + nl;
     std::string order;
+    for (char c : full) if (c != INS_M && c != INS_N) order.push_back(c);
+    if (order != out && (nl == INS_N || out.back() == nl)) {
+        // the output permutation keeps N innermost: the GEMM writes the permuted tensor directly (C strides), no copy
+        Shape fshape;
+        for (char c : out) {
+            const size_t i = full.find(c);
+            fshape.push_back(i + 2 == full.size() ? xs[xs.size() - 2] : i + 1 == full.size() ? ys.back() : (xs[i] == 1 ? ys[i] : xs[i]));
+        }
+        Tensor final(ctx, fshape, DType::F32);
+        if (matmul_into(ctx, xv.expanded(xs), yv.expanded(ys), View::of(final).relabel(out, full))) return final;
+    }
+    Tensor r = matmul(ctx, xv.expanded(xs), yv.expanded(ys));
     Shape shape;
-    for (size_t i = 0; i < full.size(); i++) if (full[i] != INS_M && full[i] != INS_N) { order.push_back(full[i]); shape.push_back(r.size((int)i)); }
+    for (size_t i = 0; i < full.size(); i++) if (full[i] != INS_M && full[i] != INS_N) shape.push_back(r.size((int)i));
     r.reshape(shape);
     if (order == out) return r;
     return materialize(ctx, View::of(r).relabel(order, out));

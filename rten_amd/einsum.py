@@ -11,7 +11,8 @@ Mul or a (batched) MatMul on permuted TensorViews, copying views where its kerne
     levels after adjacent axes with compatible strides are merged (a copy happens only when more than two levels remain,
     when a GEMM axis is a broadcast, or where the reference's own algorithm needs the data re-laid -- the multi-label K
     merge, einsum.rs:310-344);
-  * only the final permutation into the output order is a copy (`rten_hip_copy_strided_b32`, einsum.rs:531-536).
+  * the final permutation into the output order (einsum.rs:531-536) is folded into the GEMM's C strides (ldc + the two C
+    batch strides) whenever it keeps N innermost; otherwise it is the one copy (`rten_hip_copy_strided_b32`).
 
 What is computed, in which order, is the reference's: the same path (einsum.rs:605-692), the same choice of M / N / batch
 labels (:473-492), sums of lone labels before the product (:273-276), `[A, M, K] x [K, N]` folded into one GEMM
@@ -233,9 +234,13 @@ def mul(ctx, a: View, b: View) -> DeviceTensor:
     return out
 
 
-def matmul(ctx, a: View, b: View) -> DeviceTensor:
+def matmul(ctx, a: View, b: View, into: View | None = None) -> DeviceTensor:
     """matmul() of [batch.., M, K] x [batch.., K, N] views of equal rank (src/ops/matmul.rs:208-385): numpy batch
-    broadcasting; `[A, M, K] x [K, N]` is one GEMM of A*M rows (:266-297)."""
+    broadcasting; `[A, M, K] x [K, N]` is one GEMM of A*M rows (:266-297).
+
+    `into`: a view of the caller's output tensor with this product's [batch.., M, N] axes (N contiguous): the GEMM then
+    writes its rows straight into the permuted output through ldc and the C batch strides.  Returns None when those
+    strides do not fit the descriptor's two batch levels (the caller falls back to product + copy)."""
     m, k, n = a.shape[-2], a.shape[-1], b.shape[-1]
     if k != b.shape[-2]:
         raise _err("IncompatibleInputShapes", "Columns of first matrix does not match rows of second matrix")
@@ -243,12 +248,17 @@ def matmul(ctx, a: View, b: View) -> DeviceTensor:
         pre = list(np.broadcast_shapes(tuple(a.shape[:-2]), tuple(b.shape[:-2])))
     except ValueError:
         raise _err("IncompatibleInputShapes", "Cannot broadcast shapes")
-    out = DeviceTensor(ctx, pre + [m, n], np.float32)
+    if into is None:
+        out = DeviceTensor(ctx, pre + [m, n], np.float32)
+        cv = View(out)
+    else:
+        out, cv = into.t, into
     if out.size == 0:
         return out
     if k == 0:
         ctx.call("rten_hip_memset", out.vp, 0, C.c_size_t(out.nbytes))
         return out
+    ldc = max(cv.strides[-2], n)  # a single row never uses it
     # a GEMM axis that is a broadcast (stride 0 with size > 1) is re-laid, as expand_dim does (einsum.rs:210-223)
     if any(s == 0 and sz > 1 for s, sz in zip(a.strides[-2:], a.shape[-2:])):
         a = View(materialize(ctx, a))
@@ -256,31 +266,34 @@ def matmul(ctx, a: View, b: View) -> DeviceTensor:
         b = View(materialize(ctx, b))
     na = int(np.prod(a.shape[:-2], dtype=np.int64))
     nb = int(np.prod(b.shape[:-2], dtype=np.int64))
-    if na > 1 and nb == 1:
+    if na > 1 and nb == 1 and len(_merge_axes(pre + [m], cv.strides[:-1])[0]) <= 1:
         # rows of all A matrices form one [A*M, K] matrix when the (batch.., M) axes merge into one stride; else re-lay A
         rsh, (rst,) = _merge_axes(a.shape[:-1], a.strides[:-1])
         if len(rsh) > 1:
             a = View(materialize(ctx, a))
             rsh, (rst,) = _merge_axes(a.shape[:-1], a.strides[:-1])
-        d = L.gemm_desc(na * m, n, k, rst[0] if rst else 0, a.strides[-1], b.strides[-2], b.strides[-1], n)
+        crows = _merge_axes(pre + [m], cv.strides[:-1])[1][0]
+        d = L.gemm_desc(na * m, n, k, rst[0] if rst else 0, a.strides[-1], b.strides[-2], b.strides[-1], max(crows[0], n) if crows else n)
         ctx.call("rten_hip_gemm_f32", C.byref(d), a.t.vp, b.t.vp, None, out.vp)
         return out
     ea, eb = a.expanded(pre + [m, k]), b.expanded(pre + [k, n])
-    bsh, (sa, sb) = _merge_axes(pre, ea.strides[:-2], eb.strides[:-2])
+    bsh, (sa, sb, sc) = _merge_axes(pre, ea.strides[:-2], eb.strides[:-2], cv.strides[:-2])
     if len(bsh) > 2:  # more batch levels than the descriptor has: re-lay the operand(s) that do not merge
         if len(_merge_axes(pre, ea.strides[:-2])[0]) > 1 or any(s == 0 for s in sa):
             ea = View(materialize(ctx, ea))
         if len(_merge_axes(pre, eb.strides[:-2])[0]) > 1 or any(s == 0 for s in sb):
             eb = View(materialize(ctx, eb))
-        bsh, (sa, sb) = _merge_axes(pre, ea.strides[:-2], eb.strides[:-2])
-        assert len(bsh) <= 2
+        bsh, (sa, sb, sc) = _merge_axes(pre, ea.strides[:-2], eb.strides[:-2], cv.strides[:-2])
+        if len(bsh) > 2:
+            assert into is not None  # a contiguous C always merges with re-laid operands
+            return None
     batch = int(np.prod(bsh, dtype=np.int64)) if bsh else 1
     if len(bsh) == 2:
-        d = L.gemm_desc(m, n, k, ea.strides[-2], ea.strides[-1], eb.strides[-2], eb.strides[-1], n, batch, sa[0], sb[0],
-                        bsh[1] * m * n, batch_inner=bsh[1], a_bsi=sa[1], b_bsi=sb[1], c_bsi=m * n)
+        d = L.gemm_desc(m, n, k, ea.strides[-2], ea.strides[-1], eb.strides[-2], eb.strides[-1], ldc, batch, sa[0], sb[0],
+                        sc[0], batch_inner=bsh[1], a_bsi=sa[1], b_bsi=sb[1], c_bsi=sc[1])
     else:
-        d = L.gemm_desc(m, n, k, ea.strides[-2], ea.strides[-1], eb.strides[-2], eb.strides[-1], n, batch,
-                        sa[0] if sa else 0, sb[0] if sb else 0, m * n)
+        d = L.gemm_desc(m, n, k, ea.strides[-2], ea.strides[-1], eb.strides[-2], eb.strides[-1], ldc, batch,
+                        sa[0] if sa else 0, sb[0] if sb else 0, sc[0] if sc else 0)
     ctx.call("rten_hip_gemm_f32", C.byref(d), ea.t.vp, eb.t.vp, None, out.vp)
     return out
 
@@ -323,10 +336,17 @@ def _contract(ctx, x: View, y: View, tx: str, ty: str, out: str, kl: str) -> Dev
     ks = _bsize(xv.shape[-1], yv.shape[-2])
     xv = xv.expanded(xv.shape[:-1] + [ks])
     yv = yv.expanded(yv.shape[:-2] + [ks, yv.shape[-1]])
+    full = batch + ml + nl
+    order = "".join(c for c in full if c not in (INS_M, INS_N))
+    if order != out and (nl == INS_N or out[-1] == nl):
+        # the output permutation keeps N innermost: the GEMM writes the permuted tensor directly (C strides), no copy
+        size = {c: max(sx, sy) if min(sx, sy) == 1 else sx for c, sx, sy in zip(batch, xv.shape, yv.shape)}
+        size[ml], size[nl] = xv.shape[-2], yv.shape[-1]
+        final = DeviceTensor(ctx, [size[c] for c in out], np.float32)
+        if matmul(ctx, xv, yv, into=View(final).relabel(out, full)) is not None:
+            return final
     r = matmul(ctx, xv, yv)
-    order = batch + (ml if ml != INS_M else "") + (nl if nl != INS_N else "")
-    shape = [s for s, c in zip(r.shape, batch + ml + nl) if c not in (INS_M, INS_N)]
-    r = r.reshape(shape)
+    r = r.reshape([s for s, c in zip(r.shape, full) if c not in (INS_M, INS_N)])
     return r if order == out else materialize(ctx, View(r).relabel(order, out))
 
 

@@ -246,6 +246,20 @@ static void device_tests() {
                 rto_gemm_f32(S, T, D, q.data() + b * S * H * D + h * D, H * D, 1, kk.data() + b * T * H * D + h * D, 1, H * D, want.data() + (b * H + h) * S * T, T, 1.0f,
                              0.0f, nullptr, 0);
         CHECK(same_bits(y[0].to_host<float>(), want), "Einsum bqhd,bkhd->bhqk bits");
+        { // second attention product with the permuted output [B, S, H, D] written through the GEMM's C strides (no copy)
+            auto vv = randf(35, B * T * H * D);
+            Tensor tv = Tensor::from_host(ctx, {B, T, H, D}, vv.data());
+            Einsum pv;
+            pv.equation = "bhqk,bkhd->bqhd";
+            OutputList o = pv.run(ctx, {&y[0], &tv});
+            CHECK(o[0].shape() == (std::vector<int64_t>{B, S, H, D}), "Einsum attention-context shape");
+            std::vector<float> wo((size_t)(B * S * H * D));
+            for (int64_t b = 0; b < B; b++)
+                for (int64_t h = 0; h < H; h++)
+                    rto_gemm_f32(S, D, T, want.data() + (b * H + h) * S * T, T, 1, vv.data() + b * T * H * D + h * D, H * D, 1, wo.data() + b * S * H * D + h * D, H * D,
+                                 1.0f, 0.0f, nullptr, 0);
+            CHECK(same_bits(o[0].to_host<float>(), wo), "Einsum bhqk,bkhd->bqhd bits");
+        }
         const int64_t M = 70, K = 513, N = 45;
         auto a = randf(33, M * K), bb = randf(34, N * K);
         Tensor ta = Tensor::from_host(ctx, {M, K}, a.data()), tb = Tensor::from_host(ctx, {N, K}, bb.data());

@@ -122,6 +122,10 @@ RANDOM_CASES = [
     ("...ij,...jk->...ik", [(2, 3, 4, 5), (2, 3, 5, 6)]), ("i...,i...->...", [(7, 3, 4), (7, 3, 4)]), ("ab,cd->acbd", [(3, 4), (5, 6)]),
     ("bhwc,hkc->bhwk", [(2, 5, 6, 16), (5, 7, 16)]), ("ij,jk->ik", [(1, 300), (300, 5)]), ("abij,jk->abik", [(2, 3, 1, 40), (40, 5)]),
     ("ij,ij->j", [(1, 5), (300, 5)]), ("aij,ajk->aik", [(1, 4, 5), (3, 5, 6)]),
+    # output permutations that keep N innermost go through the GEMM's C strides (no copy)
+    ("bhqk,bkhd->bqhd", [(2, 3, 17, 19), (2, 19, 3, 8)]), ("mc,hck->mhk", [(5, 6), (4, 6, 7)]), ("abij,abjk->baik", [(2, 3, 4, 5), (2, 3, 5, 6)]),
+    ("abcij,abcjk->cbaik", [(2, 3, 2, 5, 7), (2, 3, 2, 7, 4)]), ("ij,jk,kl->il", [(4, 5), (5, 6), (6, 7)]), ("bsc,chd->bshd", [(3, 10, 24), (24, 3, 8)]),
+    ("ak,bk->ba", [(5, 9), (7, 9)]), ("abk,ck->cab", [(2, 3, 9), (4, 9)]),
 ]
 
 
@@ -223,7 +227,7 @@ class SimDevice:
             self._view(self._addr(y), shape, _row_major(shape))[...] = self._view(self._addr(x), shape, list(sa)[:nd]) * self._view(self._addr(z), shape, list(sb)[:nd])
         elif name == "rten_hip_gemm_f32":
             d = a[0]._obj
-            assert a[3] is None and d.alpha == 1.0 and d.beta == 0.0 and d.ldc == d.n and d.k > 0
+            assert a[3] is None and d.alpha == 1.0 and d.beta == 0.0 and d.ldc >= d.n and d.k > 0
             assert min(d.a_rs, d.a_cs, d.b_rs, d.b_cs) >= 0
             assert not (d.a_rs == 0 and d.m > 1) and not (d.a_cs == 0 and d.k > 1) and not (d.b_rs == 0 and d.k > 1) and not (d.b_cs == 0 and d.n > 1)
             inner = d.batch_inner if d.batch_inner > 1 else 1
@@ -231,7 +235,7 @@ class SimDevice:
                 zo, zi = divmod(z, inner)
                 A = self._view(self._addr(a[1]) + 4 * (zo * d.a_bs + zi * d.a_bsi), [d.m, d.k], [d.a_rs, d.a_cs])
                 B = self._view(self._addr(a[2]) + 4 * (zo * d.b_bs + zi * d.b_bsi), [d.k, d.n], [d.b_rs, d.b_cs])
-                self._view(self._addr(a[4]) + 4 * (zo * d.c_bs + zi * d.c_bsi), [d.m, d.n], [d.n, 1])[...] = ref.gemm_f32(A, B)
+                self._view(self._addr(a[4]) + 4 * (zo * d.c_bs + zi * d.c_bsi), [d.m, d.n], [d.ldc, 1])[...] = ref.gemm_f32(A, B)
         else:
             raise AssertionError(f"unexpected device call {name}")
 
@@ -278,7 +282,9 @@ def test_planner_lowering_is_strided_not_copied():
         return [n for n, _ in sim.launches]
     assert launches("bqhd,bkhd->bhqk", [(2, 17, 3, 8), (2, 19, 3, 8)]) == ["rten_hip_gemm_f32"]  # [B,S,H,D] heads: two batch levels
     assert launches("ji,kj->ik", [(3, 2), (4, 3)]) == ["rten_hip_gemm_f32"]
-    assert launches("ij,jk->ki", [(2, 3), (3, 4)]) == ["rten_hip_gemm_f32", "rten_hip_copy_strided_b32"]
+    assert launches("ij,jk->ki", [(2, 3), (3, 4)]) == ["rten_hip_gemm_f32", "rten_hip_copy_strided_b32"]  # N not innermost
+    assert launches("bhqk,bkhd->bqhd", [(2, 3, 17, 19), (2, 19, 3, 8)]) == ["rten_hip_gemm_f32"]  # permuted output through C strides
+    assert launches("mc,hck->mhk", [(5, 6), (4, 6, 7)]) == ["rten_hip_gemm_f32"]
     assert launches("iij->j", [(6, 6, 40)]) == ["rten_hip_reduce_sum_strided_f32"]  # diagonal + reduction in place
     assert launches("ij,ik->ik", [(2, 3), (2, 4)]) == ["rten_hip_reduce_sum_strided_f32", "rten_hip_binary_broadcast_f32"]
 
