@@ -102,6 +102,15 @@ def cpu_op_baselines():
     for (o_, c_, hw, k_, p_, name) in ((64, 64, 56, 3, 1, "s0 3x3"), (256, 256, 14, 3, 1, "s2 3x3"), (256, 64, 56, 1, 0, "s0 1x1 expand")):
         xq, wq = rng.integers(0, 255, (2, c_, hw, hw)).astype(np.uint8), rng.integers(-127, 127, (o_, c_, k_, k_)).astype(np.int8)
         put(f"ConvInteger {name}", t(lambda: ref.conv2d_int8(xq, wq, x_zp=128, pads=(p_,) * 4), 2), 16, f"2x{c_}x{hw}x{hw}")
+    from oracle import einsum as oe
+    rs = x[:4096 * 128].reshape(4096, 128)
+    put("ReduceSum last axis", t(lambda: oe.reduce_sum(rs, [1])), 12, "4096x128")
+    rc = x[:512 * 3072].reshape(512, 3072)
+    put("ReduceSum strided axis", t(lambda: oe.reduce_sum(rc, [0])), 8, "512x3072 -> 3072")
+    qe, ke = (rng.standard_normal((2, 128, 12, 64), dtype=np.float32) for _ in range(2))
+    pe = rng.standard_normal((2, 12, 128, 128), dtype=np.float32)
+    put("Einsum bqhd,bkhd->bhqk", t(lambda: oe.einsum("bqhd,bkhd->bhqk", qe, ke), 2), 16, "2x128x12x64")
+    put("Einsum bhqk,bkhd->bqhd", t(lambda: oe.einsum("bhqk,bkhd->bqhd", pe, ke), 2), 16, "2x12x128x128")
     return out
 
 
