@@ -321,6 +321,7 @@ def main():
             out["secondary"] = secondary_configs()
         print(json.dumps(out))
     if dist is not None:
+        dist.barrier()  # rank 0's instrumented pass / JSON line happen before any rank tears the group down
         dist.destroy_process_group()
 
 

@@ -395,3 +395,52 @@ def test_einsum_attention_graph_bit_exact(tmp_path):
     want = OE.reduce_sum(OE.einsum("bhqk,bkhd->bqhd", probs, v), [2])
     got, log = _run_model(tmp_path, _einsum_attention_model(wk, wv, S, H, D), x, "y")
     assert np.array_equal(got.view(np.int32), want.ravel().view(np.int32)), np.abs(got - want.ravel()).max()
+
+
+def test_cpp_loader_parses_pytorch_exported_graph(tmp_path):
+    """Real exporter output (PyTorch's TorchScript ONNX exporter driven without the `onnx` package, tools/torch_export.py):
+    BatchNorm folded into Conv by the exporter, Gemm with transB, GlobalAveragePool + Flatten, dynamic batch axis."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import torch
+    import torch_export as te
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c, self.b, self.f = torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.BatchNorm2d(8), torch.nn.Linear(8, 4)
+
+        def forward(self, x):
+            y = torch.relu(self.b(self.c(x)))
+            return self.f(torch.flatten(torch.nn.functional.adaptive_avg_pool2d(y, 1), 1))
+    p = tmp_path / "torch_small.onnx"
+    p.write_bytes(te.export_bytes(Net(), (torch.zeros(2, 3, 8, 8),), ["x"], ["y"], {"x": {0: "batch"}}))
+    out = run_cli("--parse-only", str(p))
+    assert out.returncode == 0, out.stderr
+    assert "producer pytorch" in out.stdout and "Conv x1" in out.stdout and "Gemm x1" in out.stdout and "BatchNormalization" not in out.stdout
+    assert "input  x: f32 [batch, 3, 8, 8]" in out.stdout
+
+
+@pytest.mark.gpu
+def test_pytorch_exported_resnet50_bit_exact(tmp_path):
+    """ResNet-50 v1.5 written by PyTorch's exporter (122 nodes: Conv x53, Relu x49, Add x16, MaxPool, GlobalAveragePool, Flatten,
+    Gemm) from a torch.nn module holding the harness's weights: the C++ loader / executor must give the oracle's logits bit for
+    bit, fused and unfused, and agree with torch's own CPU forward to f32 accumulation-order tolerance."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import torch
+    import torch_export as te
+    from oracle import models as om
+    from rten_amd.workloads import resnet50
+    w = resnet50.make_weights()
+    x = np.random.default_rng(1234).random((2, 3, 224, 224), dtype=np.float32)
+    want = om.resnet50_forward(resnet50.conv_specs(), w, x)
+    model = te.resnet50_onnx(w)
+    got, log = _run_model(tmp_path, model, x, "logits")
+    assert "folded into fused steps" in log
+    assert np.array_equal(got.view(np.int32), want.ravel().view(np.int32)), np.abs(got - want.ravel()).max()
+    got2, _ = _run_model(tmp_path, model, x, "logits", "--no-fuse")
+    assert np.array_equal(got2.view(np.int32), want.ravel().view(np.int32))
+    with torch.no_grad():
+        ref_t = te.resnet50_module(w)(torch.from_numpy(x)).numpy()
+    np.testing.assert_allclose(got.reshape(ref_t.shape), ref_t, rtol=2e-3, atol=2e-3)
