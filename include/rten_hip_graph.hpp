@@ -616,8 +616,154 @@ class Graph {
         return c;
     }
 
+    // ---- canonicalisation of exporter idioms, on the ONNX node list (the reference does these in its graph optimiser, so its
+    //      numerics are the FUSED operators' numerics -- they are applied whether or not the backend's own epilogue fusions are on):
+    //   * Constant nodes become initializers (`Constant` -> constant node, rten-onnx loader);
+    //   * x * (Erf(x / sqrt(2) | x * (1 / sqrt(2))) + 1) * 0.5                              -> Gelu               (GeluFusion, optimize/fusions.rs:407-430)
+    //   * (x - ReduceMean(x)) / Sqrt(eps + ReduceMean(Pow(x - ReduceMean(x), 2))) * scale [+ bias], means over the last axis
+    //                                                                                      -> LayerNormalization (fusions.rs:674-747)
+    //     (PyTorch's exporter writes nn.LayerNorm and nn.GELU this way).
+    static onnx::Model canonicalize(const onnx::Model &src) {
+        onnx::Model m = src;
+        for (auto &n : m.nodes)
+            if (n.op_type == "Constant" && n.outputs.size() == 1) {
+                const onnx::Attr *v = n.attr("value");
+                if (!v) throw GraphError("Constant " + n.name + ": only the tensor `value` form is supported");
+                onnx::TensorProto t = v->t;
+                t.name = n.outputs[0];
+                m.initializers.push_back(std::move(t));
+                n.op_type.clear(); // removed below
+            }
+        std::map<std::string, size_t> producer, uses;
+        std::map<std::string, const onnx::TensorProto *> inits;
+        auto index = [&] {
+            producer.clear(); uses.clear(); inits.clear();
+            for (size_t i = 0; i < m.nodes.size(); i++) {
+                if (m.nodes[i].op_type.empty()) continue;
+                for (auto &o : m.nodes[i].outputs) if (!o.empty()) producer[o] = i;
+                for (auto &in : m.nodes[i].inputs) if (!in.empty()) uses[in]++;
+            }
+            for (auto &o : m.outputs) uses[o.name] += 2; // a graph output is never an interior value of a pattern
+            for (auto &t : m.initializers) inits[t.name] = &t;
+        };
+        index();
+        auto scalar = [&](const std::string &v, float &out) {
+            auto it = inits.find(v);
+            if (it == inits.end() || it->second->data_type != onnx::FLOAT || it->second->len() != 1 || it->second->raw.size() != 4) return false;
+            std::memcpy(&out, it->second->raw.data(), 4);
+            return true;
+        };
+        auto is_init = [&](const std::string &v) { return inits.count(v) != 0; };
+        auto node_of = [&](const std::string &v, const char *op, bool interior = true) -> onnx::Node * { // producer of v if it is `op` (and v has one use)
+            auto it = producer.find(v);
+            if (it == producer.end() || m.nodes[it->second].op_type != op) return nullptr;
+            if (interior && uses[v] != 1) return nullptr;
+            return &m.nodes[it->second];
+        };
+        // binary node with one operand equal to a scalar constant c (|c - want| tiny); returns the other operand
+        auto with_scalar = [&](onnx::Node *n, float want, bool commutative, std::string &other) {
+            if (!n || n->inputs.size() != 2) return false;
+            for (int k = 0; k < (commutative ? 2 : 1); k++) {
+                float c;
+                const std::string &cs = n->inputs[(size_t)(commutative ? k : 1)], &os = n->inputs[(size_t)(commutative ? 1 - k : 0)];
+                if (scalar(cs, c) && std::fabs(c - want) <= 1e-6f * std::fabs(want)) { other = os; return true; }
+            }
+            return false;
+        };
+        auto last_axis_mean = [&](onnx::Node *n) {
+            if (!n || n->inputs.empty() || n->get_int("keepdims", 1) != 1) return false;
+            std::vector<int> axes = n->get_ints("axes", {});
+            if (axes.empty() && n->inputs.size() > 1 && is_init(n->inputs[1])) { // opset >= 18: axes as a constant input (ReduceMeanAxesFusion)
+                const onnx::TensorProto *t = inits[n->inputs[1]];
+                if (t->data_type == onnx::INT64 && t->len() == 1 && t->raw.size() == 8) { int64_t a; std::memcpy(&a, t->raw.data(), 8); axes = {(int)a}; }
+            }
+            return axes.size() == 1 && axes[0] == -1;
+        };
+        const float sqrt2 = std::sqrt(2.0f);
+        for (size_t i = 0; i < m.nodes.size(); i++) {
+            onnx::Node &last = m.nodes[i];
+            if (last.op_type == "Mul") { // ---- Gelu
+                std::string a, xin, e_plus_1, erf_out, xs, x2;
+                if (!with_scalar(&last, 0.5f, true, a)) continue;
+                onnx::Node *mul = node_of(a, "Mul");
+                if (!mul || mul->inputs.size() != 2) continue;
+                onnx::Node *add = nullptr;
+                for (int k = 0; k < 2 && !add; k++) { add = node_of(mul->inputs[(size_t)k], "Add"); if (add) { e_plus_1 = mul->inputs[(size_t)k]; xin = mul->inputs[(size_t)(1 - k)]; } }
+                if (!add || !with_scalar(add, 1.0f, true, erf_out)) continue;
+                onnx::Node *erf = node_of(erf_out, "Erf");
+                if (!erf || erf->inputs.size() != 1) continue;
+                onnx::Node *scale = node_of(erf->inputs[0], "Div");
+                bool ok = scale && with_scalar(scale, sqrt2, false, x2);
+                if (!ok) { scale = node_of(erf->inputs[0], "Mul"); ok = scale && with_scalar(scale, 1.0f / sqrt2, true, x2); }
+                if (!ok || x2 != xin) continue;
+                onnx::Node g;
+                g.op_type = "Gelu"; g.name = last.name.empty() ? "gelu" : last.name; g.inputs = {xin}; g.outputs = last.outputs;
+                scale->op_type.clear(); erf->op_type.clear(); add->op_type.clear(); mul->op_type.clear();
+                last = g;
+                index();
+            } else if (last.op_type == "Add" || last.op_type == "Mul") {
+                continue;
+            }
+        }
+        for (size_t i = 0; i < m.nodes.size(); i++) { // ---- LayerNormalization: anchored at the scaling Mul
+            onnx::Node &mulnode = m.nodes[i];
+            if (mulnode.op_type != "Mul" || mulnode.inputs.size() != 2) continue;
+            onnx::Node *div = nullptr;
+            std::string scale_name;
+            for (int k = 0; k < 2 && !div; k++)
+                if (is_init(mulnode.inputs[(size_t)(1 - k)])) { div = node_of(mulnode.inputs[(size_t)k], "Div"); scale_name = mulnode.inputs[(size_t)(1 - k)]; }
+            if (!div || div->inputs.size() != 2) continue;
+            onnx::Node *sqrt_n = node_of(div->inputs[1], "Sqrt");
+            auto cit = producer.find(div->inputs[0]);
+            if (!sqrt_n || cit == producer.end() || m.nodes[cit->second].op_type != "Sub" || uses[div->inputs[0]] != 2) continue;
+            onnx::Node *center = &m.nodes[cit->second];
+            onnx::Node *addeps = node_of(sqrt_n->inputs[0], "Add");
+            if (!addeps || addeps->inputs.size() != 2) continue;
+            float eps = 0.f;
+            onnx::Node *mean2 = nullptr;
+            for (int k = 0; k < 2 && !mean2; k++) if (scalar(addeps->inputs[(size_t)k], eps)) mean2 = node_of(addeps->inputs[(size_t)(1 - k)], "ReduceMean");
+            if (!mean2 || !last_axis_mean(mean2)) continue;
+            onnx::Node *pow = node_of(mean2->inputs[0], "Pow");
+            std::string powed;
+            if (!pow || !with_scalar(pow, 2.0f, false, powed) || powed != div->inputs[0]) continue;
+            onnx::Node *mean1 = node_of(center->inputs[1], "ReduceMean");
+            if (!mean1 || !last_axis_mean(mean1) || mean1->inputs[0] != center->inputs[0]) continue;
+            const std::string x = center->inputs[0];
+            onnx::Node ln;
+            ln.op_type = "LayerNormalization";
+            ln.inputs = {x, scale_name};
+            onnx::Node *tail = &mulnode; // optional "+ bias" (a constant): the fused node then takes the Add's place
+            if (uses[mulnode.outputs[0]] == 1)
+                for (size_t j = i + 1; j < m.nodes.size(); j++) {
+                    onnx::Node &c = m.nodes[j];
+                    if (c.op_type != "Add" || c.inputs.size() != 2) continue;
+                    const int k = c.inputs[0] == mulnode.outputs[0] ? 0 : (c.inputs[1] == mulnode.outputs[0] ? 1 : -1);
+                    if (k < 0) continue;
+                    if (is_init(c.inputs[(size_t)(1 - k)])) { ln.inputs.push_back(c.inputs[(size_t)(1 - k)]); tail = &c; }
+                    break;
+                }
+            ln.name = tail->name.empty() ? "layer_norm" : tail->name;
+            ln.outputs = tail->outputs;
+            onnx::Attr axis, epsilon;
+            axis.name = "axis"; axis.type = 2; axis.i = -1;
+            epsilon.name = "epsilon"; epsilon.type = 1; epsilon.f = eps;
+            ln.attrs = {axis, epsilon};
+            mean1->op_type.clear(); center->op_type.clear(); pow->op_type.clear(); mean2->op_type.clear(); addeps->op_type.clear(); sqrt_n->op_type.clear();
+            div->op_type.clear();
+            if (tail != &mulnode) mulnode.op_type.clear();
+            *tail = ln;
+            index();
+        }
+        std::vector<onnx::Node> kept;
+        for (auto &n : m.nodes) if (!n.op_type.empty()) kept.push_back(std::move(n));
+        m.nodes = std::move(kept);
+        return m;
+    }
+
     // ---- compile: constants, fusion, steps, liveness
-    void compile(const onnx::Model &m) {
+    void compile(const onnx::Model &m_in) {
+        const onnx::Model m_canonical = canonicalize(m_in);
+        const onnx::Model &m = m_canonical;
         inputs_ = m.inputs;
         outputs_ = m.outputs;
         for (auto &t : m.initializers) consts_.emplace(id_of(t.name), upload(t));

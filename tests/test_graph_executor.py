@@ -444,3 +444,44 @@ def test_pytorch_exported_resnet50_bit_exact(tmp_path):
     with torch.no_grad():
         ref_t = te.resnet50_module(w)(torch.from_numpy(x)).numpy()
     np.testing.assert_allclose(got.reshape(ref_t.shape), ref_t, rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.gpu
+def test_pytorch_exported_transformer_encoder_bit_exact(tmp_path):
+    """A BERT-style encoder written by PyTorch's exporter: LayerNorm and GELU arrive decomposed (ReduceMean / Sub / Pow / Sqrt /
+    Div, Div / Erf / Add / Mul), scalars as Constant nodes, Linear as MatMul + Add.  The executor applies the reference's
+    LayerNormalizationFusion / GeluFusion (optimize/fusions.rs:407-430,674-747) on load, so the result is the oracle's encoder
+    (the reference's post-fusion operator order) bit for bit, and agrees with torch's own CPU forward to f32 tolerance."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import torch
+    import torch_export as te
+    from oracle import models as om
+    from rten_amd.workloads import bert
+    cfg = bert.BertConfig(hidden=64, heads=4, layers=2, ffn=128, vocab=100, max_pos=32, type_vocab=2)
+    w = bert.make_weights(cfg)
+    B, S = 3, 16
+    rng = np.random.default_rng(5)
+    ids = rng.integers(0, cfg.vocab, (B, S)).astype(np.int32)
+    tts = rng.integers(0, 2, (B, S)).astype(np.int32)
+    mask = np.ones((B, S), np.int32)
+    mask[1, 11:] = 0
+    mask[2, 5:] = 0
+    want = om.bert_forward(cfg, w, ids, mask, tts)
+    p = tmp_path / "encoder_torch.onnx"
+    p.write_bytes(te.encoder_onnx(cfg, w, B, S))
+    parsed = run_cli("--parse-only", str(p))
+    assert "ReduceMean x10" in parsed.stdout and "Erf x2" in parsed.stdout and "Constant x" in parsed.stdout, parsed.stdout
+    yout = tmp_path / "y.bin"
+    for extra in ((), ("--no-fuse",)):
+        args = ["--dump", f"last_hidden_state={yout}", *extra]
+        for name, arr in (("input_ids", ids), ("token_type_ids", tts), ("attention_mask", mask)):
+            arr.tofile(tmp_path / (name + ".bin"))
+            args += ["--input", f"{name}={tmp_path / (name + '.bin')}"]
+        r = run_cli(*args, str(p))
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        got = np.fromfile(yout, np.float32)
+        assert np.array_equal(got.view(np.int32), want.ravel().view(np.int32)), (extra, np.abs(got - want.ravel()).max())
+    with torch.no_grad():
+        t = te.encoder_module(cfg, w, S)(torch.from_numpy(ids.astype(np.int64)), torch.from_numpy(mask.astype(np.int64)), torch.from_numpy(tts.astype(np.int64))).numpy()
+    np.testing.assert_allclose(got.reshape(t.shape), t, rtol=1e-4, atol=1e-4)

@@ -86,6 +86,73 @@ def resnet50_onnx(weights, image: int = 224) -> bytes:
     return export_bytes(resnet50_module(weights), (torch.zeros(2, 3, image, image),), ["x"], ["logits"], {"x": {0: "batch"}, "logits": {0: "batch"}})
 
 
+def encoder_module(cfg, w, seq):
+    """A BERT encoder in plain torch.nn (Embedding, Linear, LayerNorm, GELU, matmul / softmax attention with an additive
+    mask) holding rten_amd.workloads.bert.make_weights(cfg): the operator order of oracle.models.bert_forward.  PyTorch's
+    exporter writes nn.LayerNorm as ReduceMean / Sub / Pow / Sqrt / Div / Mul / Add and nn.GELU as Div / Erf / Add / Mul / Mul,
+    Linear as MatMul + Add, scalars as Constant nodes."""
+    import math
+    import torch
+    import torch.nn as nn
+
+    def lin(wm, b):
+        l = nn.Linear(wm.shape[0], wm.shape[1])
+        l.weight.data, l.bias.data = torch.from_numpy(np.ascontiguousarray(wm.T)), torch.from_numpy(b.copy())
+        return l
+
+    def ln(g, b):
+        l = nn.LayerNorm(g.shape[0], eps=cfg.eps)
+        l.weight.data, l.bias.data = torch.from_numpy(g.copy()), torch.from_numpy(b.copy())
+        return l
+
+    def emb(t):
+        e = nn.Embedding(*t.shape)
+        e.weight.data = torch.from_numpy(t.copy())
+        return e
+
+    class Layer(nn.Module):
+        def __init__(self, lw):
+            super().__init__()
+            self.q, self.k, self.v, self.o = lin(lw["wq"], lw["bq"]), lin(lw["wk"], lw["bk"]), lin(lw["wv"], lw["bv"]), lin(lw["wo"], lw["bo"])
+            self.ln1, self.ln2 = ln(lw["ln1_g"], lw["ln1_b"]), ln(lw["ln2_g"], lw["ln2_b"])
+            self.f1, self.f2, self.act = lin(lw["w1"], lw["b1"]), lin(lw["w2"], lw["b2"]), nn.GELU()
+
+        def forward(self, x, mask):
+            B, S, H = x.shape
+            d = H // cfg.heads
+
+            def heads(t):
+                return t.view(B, S, cfg.heads, d).permute(0, 2, 1, 3)
+            scores = torch.matmul(heads(self.q(x)), heads(self.k(x)).transpose(-1, -2)) / math.sqrt(d) + mask
+            ctx = torch.matmul(torch.softmax(scores, -1), heads(self.v(x))).permute(0, 2, 1, 3).reshape(B, S, H)
+            x = self.ln1(self.o(ctx) + x)
+            return self.ln2(self.f2(self.act(self.f1(x))) + x)
+
+    class Encoder(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.word, self.ttype, self.pos = emb(w["word"]), emb(w["type"]), emb(w["pos"])
+            self.ln = ln(w["emb_ln_g"], w["emb_ln_b"])
+            self.layers = nn.ModuleList([Layer(lw) for lw in w["layers"]])
+            self.register_buffer("position_ids", torch.arange(seq).unsqueeze(0))
+
+        def forward(self, input_ids, attention_mask, token_type_ids):
+            x = self.ln((self.word(input_ids) + self.ttype(token_type_ids)) + self.pos(self.position_ids))
+            mask = (1.0 - attention_mask[:, None, None, :].to(torch.float32)) * torch.finfo(torch.float32).min
+            for l in self.layers:
+                x = l(x, mask)
+            return x
+
+    return Encoder().eval()
+
+
+def encoder_onnx(cfg, w, batch, seq) -> bytes:
+    import torch
+    ids = torch.zeros(batch, seq, dtype=torch.int64)
+    return export_bytes(encoder_module(cfg, w, seq), (ids, torch.ones_like(ids), torch.zeros_like(ids)),
+                        ["input_ids", "attention_mask", "token_type_ids"], ["last_hidden_state"])
+
+
 def bert_module(layers=2, hidden=768, heads=12, ffn=3072, vocab=30522, seed=0):
     import torch
     from transformers import BertConfig, BertModel
