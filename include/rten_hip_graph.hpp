@@ -805,7 +805,9 @@ class Graph {
         // becomes one MultiHeadSdpa step over the [B, S, H] projections; if the three projections are MatMul(x, W) + Add(b)
         // of one input with constant weights, they become one GEMM against [Wq | Wk | Wv] whose column blocks the
         // attention kernel reads in place (bit-identical: every output element is the same k-ordered dot product).
-        struct Attn { std::string q, k, v, mask, out, x; int heads = 0; float scale = 1.f; bool merged = false; int wqkv = -1, bqkv = -1; int64_t hidden = 0; };
+        // lead0 / lead1: leading dims when the Reshapes spell them out ([B, S, h, d], as PyTorch's exporter writes a static-shape
+        // `view`) instead of copying them ([0, 0, h, d]); checked against the projections at run time (0 = copied)
+        struct Attn { std::string q, k, v, mask, out, x; int heads = 0; float scale = 1.f; bool merged = false; int wqkv = -1, bqkv = -1; int64_t hidden = 0; int lead0 = 0, lead1 = 0; };
         std::map<size_t, Attn> attn_at;
         if (opt_.fuse) {
             auto single_use = [&](const std::string &v) { auto it = users.find(v); return !graph_outs.count(v) && it != users.end() && it->second.size() == 1; };
@@ -821,12 +823,18 @@ class Graph {
                 return true;
             };
             // value -> (Reshape[0,0,h,d] node, Transpose node) feeding it with the given perm; returns the projection's name
-            auto split_heads = [&](const std::string &v, std::vector<int> perm, int &heads, std::vector<size_t> &nodes) -> std::string {
+            auto leading_ok = [](const std::vector<int32_t> &shp, Attn &at, bool first) { // [0, 0, ..] or one explicit [B, S, ..] throughout
+                if ((shp[0] == 0) != (shp[1] == 0) || shp[0] < 0 || shp[1] < 0) return false;
+                if (first) { at.lead0 = shp[0]; at.lead1 = shp[1]; return true; }
+                return at.lead0 == shp[0] && at.lead1 == shp[1];
+            };
+            auto split_heads = [&](const std::string &v, std::vector<int> perm, Attn &at, bool first, std::vector<size_t> &nodes) -> std::string {
+                int &heads = at.heads;
                 const long t = made_by(v, "Transpose");
                 if (t < 0 || m.nodes[(size_t)t].get_ints("perm", {}) != perm) return "";
                 const long r = made_by(m.nodes[(size_t)t].inputs[0], "Reshape");
                 std::vector<int32_t> shp;
-                if (r < 0 || m.nodes[(size_t)r].inputs.size() < 2 || !const_i32(m.nodes[(size_t)r].inputs[1], shp) || shp.size() != 4 || shp[0] != 0 || shp[1] != 0 || shp[2] <= 0) return "";
+                if (r < 0 || m.nodes[(size_t)r].inputs.size() < 2 || !const_i32(m.nodes[(size_t)r].inputs[1], shp) || shp.size() != 4 || shp[2] <= 0 || !leading_ok(shp, at, first)) return "";
                 if (heads && heads != shp[2]) return "";
                 heads = shp[2];
                 nodes.push_back((size_t)t); nodes.push_back((size_t)r);
@@ -837,8 +845,8 @@ class Graph {
                 if (dead[i] || mm.op_type != "MatMul" || mm.inputs.size() != 2) continue;
                 Attn at;
                 std::vector<size_t> nodes{i};
-                at.q = split_heads(mm.inputs[0], {0, 2, 1, 3}, at.heads, nodes);
-                at.k = at.q.empty() ? "" : split_heads(mm.inputs[1], {0, 2, 3, 1}, at.heads, nodes);
+                at.q = split_heads(mm.inputs[0], {0, 2, 1, 3}, at, true, nodes);
+                at.k = at.q.empty() ? "" : split_heads(mm.inputs[1], {0, 2, 3, 1}, at, false, nodes);
                 if (at.k.empty()) continue;
                 std::string cur = mm.outputs[0];
                 for (const char *sop : {"Div", "Mul"}) {
@@ -860,13 +868,13 @@ class Graph {
                 const long pv = sole_user(cur, "MatMul");
                 if (pv < 0 || m.nodes[(size_t)pv].inputs[0] != cur) continue;
                 nodes.push_back((size_t)pv);
-                at.v = split_heads(m.nodes[(size_t)pv].inputs[1], {0, 2, 1, 3}, at.heads, nodes);
+                at.v = split_heads(m.nodes[(size_t)pv].inputs[1], {0, 2, 1, 3}, at, false, nodes);
                 if (at.v.empty()) continue;
                 const long tr = sole_user(m.nodes[(size_t)pv].outputs[0], "Transpose");
                 if (tr < 0 || m.nodes[(size_t)tr].get_ints("perm", {}) != std::vector<int>{0, 2, 1, 3}) continue;
                 const long rs = sole_user(m.nodes[(size_t)tr].outputs[0], "Reshape");
                 std::vector<int32_t> shp;
-                if (rs < 0 || m.nodes[(size_t)rs].inputs.size() < 2 || !const_i32(m.nodes[(size_t)rs].inputs[1], shp) || shp.size() != 3 || shp[0] != 0 || shp[1] != 0) continue;
+                if (rs < 0 || m.nodes[(size_t)rs].inputs.size() < 2 || !const_i32(m.nodes[(size_t)rs].inputs[1], shp) || shp.size() != 3 || !leading_ok(shp, at, false)) continue;
                 nodes.push_back((size_t)tr); nodes.push_back((size_t)rs);
                 at.out = m.nodes[(size_t)rs].outputs[0];
                 if (!at.mask.empty() && producer.count(at.mask) && producer[at.mask] > i) continue; // mask must exist before the scores
@@ -942,7 +950,12 @@ class Graph {
                     st.in = {id_of(at.q), id_of(at.k), id_of(at.v), at.mask.empty() ? -1 : id_of(at.mask)};
                 }
                 st.out = {id_of(at.out)};
-                st.run = [op](Context &c, const InputList &in) { return op->run(c, in); };
+                const int lead0 = at.lead0, lead1 = at.lead1;
+                st.run = [op, lead0, lead1](Context &c, const InputList &in) {
+                    if (lead0 && (require(in, 0).ndim() != 3 || require(in, 0).size(0) != lead0 || require(in, 0).size(1) != lead1))
+                        throw OpError(OpError::InvalidValue, "fused attention: the graph's Reshape spells out leading dims that differ from the projection's");
+                    return op->run(c, in);
+                };
                 steps_.push_back(std::move(st));
                 continue;
             }
