@@ -862,7 +862,8 @@ class Graph {
                 const long add = sole_user(cur, "Add");
                 if (add >= 0) { at.mask = other_input(m.nodes[(size_t)add], cur); nodes.push_back((size_t)add); cur = m.nodes[(size_t)add].outputs[0]; }
                 const long sm = sole_user(cur, "Softmax");
-                if (sm < 0 || m.nodes[(size_t)sm].get_int("axis", -1) != -1) continue;
+                const int64_t sm_axis = sm < 0 ? 0 : m.nodes[(size_t)sm].get_int("axis", -1);
+                if (sm < 0 || (sm_axis != -1 && sm_axis != 3)) continue; // the scores are 4-D here: PyTorch's exporter writes the last axis as 3
                 nodes.push_back((size_t)sm);
                 cur = m.nodes[(size_t)sm].outputs[0];
                 const long pv = sole_user(cur, "MatMul");
