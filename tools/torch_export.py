@@ -8,7 +8,9 @@ Flatten / Shape idioms as PyTorch emits them -- next to the graphs `rten_amd/onn
 
 Test and tooling infrastructure only: nothing under rten_amd/ imports this.
     python tools/torch_export.py resnet50 /tmp/resnet50_torch.onnx     # BASELINE topology, the harness's synthetic weights
-    python tools/torch_export.py bert /tmp/bert_torch.onnx             # transformers.BertModel, random init, 2 layers
+    python tools/torch_export.py encoder /tmp/bert_base_torch.onnx     # BERT-base sized encoder in plain torch.nn, batch 32 x 128
+    python tools/torch_export.py bert /tmp/bert_torch.onnx             # transformers.BertModel, random init, 2 layers (its mask
+                                                                       # subgraph needs NonZero / Where / Expand: not loadable yet)
 """
 from __future__ import annotations
 
@@ -174,6 +176,10 @@ if __name__ == "__main__":
     if kind == "resnet50":
         from rten_amd.workloads import resnet50 as R
         data = resnet50_onnx(R.make_weights())
+    elif kind == "encoder":  # BERT-base sized (BASELINE configs[3]): 12 layers, hidden 768, 12 heads, batch 32 x 128 tokens
+        from rten_amd.workloads import bert as Bw
+        cfg = Bw.BertConfig()
+        data = encoder_onnx(cfg, Bw.make_weights(cfg), 32, 128)
     else:
         data = bert_onnx(bert_module())
     open(path, "wb").write(data)
