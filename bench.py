@@ -120,12 +120,13 @@ def secondary_configs():
     import subprocess
     root = os.path.dirname(os.path.abspath(__file__))
     res = {}
-    for key, script in (("resnet50_int8_b32", "bench_resnet50_int8.py"), ("bert_base_f32_b32_s128", "bench_bert.py")):
+    for key, script in (("resnet50_int8_b32", "bench_resnet50_int8.py"), ("bert_base_f32_b32_s128", "bench_bert.py"),
+                        ("resnet50_f32_b1_latency", "bench_resnet50_b1.py")):
         try:
             p = subprocess.run([sys.executable, os.path.join(root, "tools", script)], capture_output=True, text=True, timeout=420, cwd=root)
             line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
             j = json.loads(line)
-            res[key] = {k: j[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype") if k in j}
+            res[key] = {k: j[k] for k in ("metric", "value", "unit", "ms_per_step", "p50_latency_ms", "ms_per_step_back_to_back", "dtype") if k in j}
             if key.startswith("bert") and "roofline" in j:
                 res[key]["gemm_family_tflops"] = j["roofline"].get("achieved")
                 res[key]["gemm_family_frac_of_f32_mfma_peak"] = j["roofline"].get("frac")
