@@ -299,6 +299,8 @@ class Graph {
 
     Graph(Context &ctx, const onnx::Model &m, Options opt) : ctx_(ctx), opt_(opt) { compile(m); }
     Graph(Context &ctx, const onnx::Model &m) : Graph(ctx, m, Options()) {}
+    // the node list after the load-time canonicalisation of exporter idioms (Constant nodes, GeluFusion, LayerNormalizationFusion): needs no device
+    static onnx::Model canonical_form(const onnx::Model &m) { return canonicalize(m); }
 
     const std::vector<onnx::ValueInfo> &inputs() const { return inputs_; }
     const std::vector<onnx::ValueInfo> &outputs() const { return outputs_; }

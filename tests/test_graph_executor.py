@@ -421,6 +421,27 @@ def test_cpp_loader_parses_pytorch_exported_graph(tmp_path):
     assert "input  x: f32 [batch, 3, 8, 8]" in out.stdout
 
 
+def test_canonicalisation_of_pytorch_exported_encoder(tmp_path):
+    """The load-time canonicalisation (no device needed): PyTorch writes nn.LayerNorm as 9 nodes and nn.GELU as 5, scalars as
+    Constant nodes; the reference's LayerNormalizationFusion / GeluFusion patterns turn them back into single operators."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import torch_export as te
+    from rten_amd.workloads import bert
+    cfg = bert.BertConfig(hidden=64, heads=4, layers=2, ffn=128, vocab=100, max_pos=32, type_vocab=2)
+    p = tmp_path / "encoder_torch.onnx"
+    p.write_bytes(te.encoder_onnx(cfg, bert.make_weights(cfg), 3, 16))
+    out = run_cli("--parse-only", str(p))
+    assert out.returncode == 0, out.stderr
+    raw, canon = [l for l in out.stdout.splitlines() if "operators:" in l][0], [l for l in out.stdout.splitlines() if "canonical form" in l][0]
+    assert "ReduceMean x10" in raw and "Pow x5" in raw and "Sqrt x5" in raw and "Erf x2" in raw and "Constant x" in raw
+    assert "LayerNormalization x5" in canon and "Gelu x2" in canon
+    for gone in ("ReduceMean", "Pow", "Sqrt", "Erf", "Constant"):
+        assert gone not in canon.split("nodes:")[1], canon
+    # MatMul x16 (8 per layer), Softmax x2 and the mask arithmetic are untouched
+    assert "MatMul x16" in canon and "Softmax x2" in canon
+
+
 @pytest.mark.gpu
 def test_pytorch_exported_resnet50_bit_exact(tmp_path):
     """ResNet-50 v1.5 written by PyTorch's exporter (122 nodes: Conv x53, Relu x49, Add x16, MaxPool, GlobalAveragePool, Flatten,

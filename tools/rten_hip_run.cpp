@@ -105,6 +105,16 @@ int main(int argc, char **argv) {
             std::printf("  input  %s: %s %s]\n", in.name.c_str(), type_str(in.elem_type), dims.c_str());
         }
         for (auto &o : m.outputs) std::printf("  output %s: %s\n", o.name.c_str(), type_str(o.elem_type));
+        {
+            const onnx::Model c = Graph::canonical_form(m);
+            if (c.nodes.size() != m.nodes.size()) {
+                std::map<std::string, int> chist;
+                for (auto &n : c.nodes) chist[n.op_type]++;
+                std::printf("  canonical form (Constant nodes, Gelu / LayerNormalization patterns): %zu nodes:", c.nodes.size());
+                for (auto &h : chist) std::printf(" %s x%d", h.first.c_str(), h.second);
+                std::printf("\n");
+            }
+        }
         if (parse_only) return 0;
 
         Context ctx(0);
