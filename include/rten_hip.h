@@ -284,6 +284,10 @@ int32_t rten_hip_copy_strided_b32(rten_hip_ctx *ctx, int32_t ndim, const int64_t
 int32_t rten_hip_reduce_sum_strided_f32(rten_hip_ctx *ctx, int32_t n_outer, const int64_t *outer_shape, const int64_t *outer_strides,
                                         int32_t n_inner, const int64_t *inner_shape, const int64_t *inner_strides,
                                         const float *x, float *y);
+/* ReduceMean (reduce_mean, src/ops/reduce.rs:523-541): the same sum divided by the slice length as f32; an empty slice gives NaN. */
+int32_t rten_hip_reduce_mean_strided_f32(rten_hip_ctx *ctx, int32_t n_outer, const int64_t *outer_shape, const int64_t *outer_strides,
+                                         int32_t n_inner, const int64_t *inner_shape, const int64_t *inner_strides,
+                                         const float *x, float *y);
 /* y[(i / inner) ...] += bias[c]: per-channel bias add for NCHW tensors ([1,O,1,1] constant Add) */
 int32_t rten_hip_add_channel_bias_f32(rten_hip_ctx *ctx, int32_t n, int32_t c, int64_t inner, const float *x,
                                       const float *bias, float *y);

@@ -1206,14 +1206,15 @@ class Graph {
                 if (!n.attr("equation")) throw GraphError("Einsum " + st.name + ": the equation attribute is missing");
                 op->equation = n.attr("equation")->s;
                 st.run = [op](Context &c, const InputList &in) { return op->run(c, in); };
-            } else if (n.op_type == "ReduceSum") {
+            } else if (n.op_type == "ReduceSum" || n.op_type == "ReduceMean") {
                 auto op = std::make_shared<ReduceSum>();
+                op->mean = n.op_type == "ReduceMean";
                 op->keep_dims = n.get_int("keepdims", 1) != 0;
                 op->noop_with_empty_axes = n.get_int("noop_with_empty_axes", 0) != 0;
                 op->axes = n.get_ints("axes", {});
                 if (n.inputs.size() > 1 && !n.inputs[1].empty()) { // opset >= 13: axes as a (constant) input
                     auto it = ids_.find(n.inputs[1]);
-                    if (it == ids_.end() || !consts_.count(it->second)) throw GraphError("ReduceSum " + st.name + ": the axes input must be a constant");
+                    if (it == ids_.end() || !consts_.count(it->second)) throw GraphError(n.op_type + " " + st.name + ": the axes input must be a constant");
                     for (int32_t v : consts_.at(it->second).to_host<int32_t>()) op->axes.push_back(v);
                     st.in.resize(1);
                 }

@@ -1283,7 +1283,7 @@ inline Tensor materialize(Context &ctx, const View &v) { // to_tensor / to_conti
 }
 
 // reduce_sum(view, axes, keep_dims = false): axes sorted and unique
-inline Tensor reduce_sum(Context &ctx, const View &v, const std::vector<int> &axes) {
+inline Tensor reduce_sum(Context &ctx, const View &v, const std::vector<int> &axes, bool mean = false) {
     Shape ks, kst, rs, rst;
     for (int d = 0; d < v.nd(); d++) {
         const bool red = std::find(axes.begin(), axes.end(), d) != axes.end();
@@ -1296,7 +1296,7 @@ inline Tensor reduce_sum(Context &ctx, const View &v, const std::vector<int> &ax
         merge_axes(ks, {kst}, mo, mos);
         merge_axes(rs, {rst}, mi, mis);
         if (mo.size() > 6 || mi.size() > 6) throw OpError(OpError::UnsupportedValue, "Einsum reduction over more than 6 non-mergeable dims is not supported by the device path");
-        ctx.check(rten_hip_reduce_sum_strided_f32(ctx.raw(), (int)mo.size(), mo.data(), mos[0].data(), (int)mi.size(), mi.data(), mis[0].data(), v.p, (float *)y.ptr()));
+        ctx.check((mean ? rten_hip_reduce_mean_strided_f32 : rten_hip_reduce_sum_strided_f32)(ctx.raw(), (int)mo.size(), mo.data(), mos[0].data(), (int)mi.size(), mi.data(), mis[0].data(), v.p, (float *)y.ptr()));
     }
     return y;
 }
@@ -1495,8 +1495,8 @@ inline Tensor run_step(Context &ctx, const Step &s, View x, const View *yin) {
 
 struct ReduceSum : Operator { // src/ops/reduce.rs:1126-1165 (f32); axes as the attribute (or the resolved second input)
     std::vector<int> axes;
-    bool keep_dims = true, noop_with_empty_axes = false;
-    const char *name() const override { return "ReduceSum"; }
+    bool keep_dims = true, noop_with_empty_axes = false, mean = false;
+    const char *name() const override { return mean ? "ReduceMean" : "ReduceSum"; }
     int max_inputs() const override { return 2; }
     OutputList run(Context &ctx, const InputList &in) const override {
         namespace E = einsum_detail;
@@ -1509,7 +1509,7 @@ struct ReduceSum : Operator { // src/ops/reduce.rs:1126-1165 (f32); axes as the 
         for (int a : axes) ax.push_back(resolve_axis(a, nd));
         std::sort(ax.begin(), ax.end());
         ax.erase(std::unique(ax.begin(), ax.end()), ax.end()); // resolve_axes, src/ops/mod.rs:259-271
-        Tensor y = E::reduce_sum(ctx, E::View::of(x), ax);
+        Tensor y = E::reduce_sum(ctx, E::View::of(x), ax, mean);
         if (keep_dims) {
             std::vector<int64_t> s = x.shape();
             for (int a : ax) s[(size_t)a] = 1;
@@ -1518,6 +1518,10 @@ struct ReduceSum : Operator { // src/ops/reduce.rs:1126-1165 (f32); axes as the 
         out.push_back(std::move(y));
         return out;
     }
+};
+
+struct ReduceMean : ReduceSum { // src/ops/reduce.rs:523-580: Sum / len per slice
+    ReduceMean() { mean = true; }
 };
 
 struct Einsum : Operator { // src/ops/einsum.rs:21-108
@@ -1591,6 +1595,7 @@ class OpRegistry {
         r.register_op<DynamicQuantizeLinear>("DynamicQuantizeLinear");
         r.register_op<Cast>("Cast");
         r.register_op<ReduceSum>("ReduceSum");
+        r.register_op<ReduceMean>("ReduceMean");
         r.register_op<Einsum>("Einsum");
         return r;
     }

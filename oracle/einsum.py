@@ -156,6 +156,18 @@ def reduce_sum(x, axes, keep_dims=False, lanes=ref.LANES):
     return out.reshape(kshape)
 
 
+def reduce_mean(x, axes, keep_dims=False, lanes=ref.LANES):
+    """reduce_mean, reduce.rs:523-541: Sum(slice) / slice.len() as f32 per output element (an empty slice: 0 / 0 = NaN)."""
+    x = np.asarray(x, np.float32)
+    s = reduce_sum(x, axes, keep_dims, lanes)
+    if x.ndim == 0:
+        return s
+    ax = sorted({a + x.ndim if a < 0 else a for a in axes}) if axes else list(range(x.ndim))
+    n = np.float32(int(np.prod([x.shape[a] for a in ax], dtype=np.int64)))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return (s / n).astype(np.float32)
+
+
 def _matmul(a, b):
     """matmul(), src/ops/matmul.rs:208-385 on views (ref.matmul_f32 folds [A,M,K]x[K,N] into one GEMM like :266-297)."""
     pa, pb = a.shape[:-2], b.shape[:-2]

@@ -394,6 +394,7 @@ struct ReduceArgs {
     int n_outer, n_inner;
     int64_t rows;
     int inner;
+    float divisor; // 0: ReduceSum; slice length: ReduceMean = Sum / len (reduce.rs:532-537)
     int32_t oshape[6], ishape[6];
     int64_t ostride[6], istride[6];
 };
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void reduce_sum_kernel(const R
     const float *xr = x + reduce_row_base(p, row);
     auto get = [&](int i) -> float { return xr[reduce_elem_off(p, i)]; };
     const float s = simd16_reduce<0>(get, p.inner, 0.f, lane);
-    if (lane == 0) y[row] = s;
+    if (lane == 0) y[row] = p.divisor != 0.f ? s / p.divisor : s;
 }
 
 // Slices of at most 16 * EPL elements: four output elements per wave, one per 16-lane DPP row (global_avg_pool_rows16_kernel's
@@ -457,7 +458,7 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void reduce_sum_rows16_kernel(
     float s = a;
 #pragma unroll
     for (int k = 1; k < 16; k++) s = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x111, 0xf, 0xf, true)) + a;
-    if (l == 15 && row < p.rows) y[row] = s;
+    if (l == 15 && row < p.rows) y[row] = p.divisor != 0.f ? s / p.divisor : s;
 }
 
 // Reduced axes strided, innermost kept axis contiguous (a column sum): a wave-per-row walk would touch 64 cache lines per
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(1024) void reduce_sum_cols_kernel(const ReduceArgs 
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; k++) s = s + part[k][threadIdx.x];
-        y[prefix * last + j0 + threadIdx.x] = s;
+        y[prefix * last + j0 + threadIdx.x] = p.divisor != 0.f ? s / p.divisor : s;
     }
 }
 
@@ -577,9 +578,8 @@ RTEN_EXPORT int32_t rten_hip_global_average_pool_f32(rten_hip_ctx *ctx, int64_t 
     return RTEN_HIP_OK;
 }
 
-RTEN_EXPORT int32_t rten_hip_reduce_sum_strided_f32(rten_hip_ctx *ctx, int32_t n_outer, const int64_t *outer_shape, const int64_t *outer_strides,
-                                                    int32_t n_inner, const int64_t *inner_shape, const int64_t *inner_strides,
-                                                    const float *x, float *y) {
+static int32_t reduce_strided(rten_hip_ctx *ctx, bool mean, int32_t n_outer, const int64_t *outer_shape, const int64_t *outer_strides,
+                              int32_t n_inner, const int64_t *inner_shape, const int64_t *inner_strides, const float *x, float *y) {
     RTEN_CHECK_CTX(ctx);
     if (n_outer < 0 || n_outer > 6 || n_inner < 0 || n_inner > 6 || (n_outer && (!outer_shape || !outer_strides)) ||
         (n_inner && (!inner_shape || !inner_strides)))
@@ -604,10 +604,11 @@ RTEN_EXPORT int32_t rten_hip_reduce_sum_strided_f32(rten_hip_ctx *ctx, int32_t n
         p.istride[d] = inner_strides[d];
     }
     p.inner = (int)inner;
+    p.divisor = mean ? (float)inner : 0.f;
     if (p.rows == 0) return RTEN_HIP_OK;
     if (!y) return RTEN_HIP_ERR_INVALID_VALUE;
-    if (inner == 0) { // the sum of an empty slice is the kernel's identity (reduce.rs:446-452)
-        RTEN_HIP_TRY(ctx, hipMemsetAsync(y, 0, sizeof(float) * (size_t)p.rows, ctx->stream));
+    if (inner == 0) { // an empty slice gives the kernel's value for it (reduce.rs:446-452): Sum 0, Mean 0 / 0 = NaN
+        RTEN_HIP_TRY(ctx, hipMemsetAsync(y, mean ? 0xff : 0, sizeof(float) * (size_t)p.rows, ctx->stream));
         return RTEN_HIP_OK;
     }
     if (!x) return RTEN_HIP_ERR_INVALID_VALUE;
@@ -624,4 +625,16 @@ RTEN_EXPORT int32_t rten_hip_reduce_sum_strided_f32(rten_hip_ctx *ctx, int32_t n
         hipLaunchKernelGGL(reduce_sum_kernel, dim3((unsigned)((p.rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block, 0, ctx->stream, p, x, y);
     RTEN_LAUNCH_CHECK(ctx, "reduce_sum_kernel");
     return RTEN_HIP_OK;
+}
+
+RTEN_EXPORT int32_t rten_hip_reduce_sum_strided_f32(rten_hip_ctx *ctx, int32_t n_outer, const int64_t *outer_shape, const int64_t *outer_strides,
+                                                    int32_t n_inner, const int64_t *inner_shape, const int64_t *inner_strides,
+                                                    const float *x, float *y) {
+    return reduce_strided(ctx, false, n_outer, outer_shape, outer_strides, n_inner, inner_shape, inner_strides, x, y);
+}
+
+RTEN_EXPORT int32_t rten_hip_reduce_mean_strided_f32(rten_hip_ctx *ctx, int32_t n_outer, const int64_t *outer_shape, const int64_t *outer_strides,
+                                                     int32_t n_inner, const int64_t *inner_shape, const int64_t *inner_strides,
+                                                     const float *x, float *y) {
+    return reduce_strided(ctx, true, n_outer, outer_shape, outer_strides, n_inner, inner_shape, inner_strides, x, y);
 }

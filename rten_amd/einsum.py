@@ -204,7 +204,7 @@ def materialize(ctx, v: View, shape=None) -> DeviceTensor:
     return out
 
 
-def reduce_sum(ctx, v: View, axes) -> DeviceTensor:
+def reduce_sum(ctx, v: View, axes, mean: bool = False) -> DeviceTensor:
     """reduce_sum(view, axes, keep_dims = false), reduce.rs:414-520: kept axes in order; each output element sums its slice
     over the reduced axes in row-major order (the order the reference packs it in), 16-lane vecmath::Sum order."""
     axes = sorted(axes)
@@ -215,7 +215,7 @@ def reduce_sum(ctx, v: View, axes) -> DeviceTensor:
         ish, (ist,) = _merge_axes([v.shape[d] for d in axes], [v.strides[d] for d in axes])
         if len(osh) > 6 or len(ish) > 6:
             raise _err("UnsupportedValue", "Einsum reduction over more than 6 non-mergeable dims is not supported by the device path")
-        ctx.call("rten_hip_reduce_sum_strided_f32", len(osh), _i64(osh), _i64(ost), len(ish), _i64(ish), _i64(ist), v.t.vp, out.vp)
+        ctx.call("rten_hip_reduce_mean_strided_f32" if mean else "rten_hip_reduce_sum_strided_f32", len(osh), _i64(osh), _i64(ost), len(ish), _i64(ish), _i64(ist), v.t.vp, out.vp)
     return out
 
 

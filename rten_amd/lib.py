@@ -144,6 +144,7 @@ PROTOTYPES = {
     "rten_hip_transpose_b32": (_I32, [_VP, _I32, _VP, _VP, _VP, _VP]),
     "rten_hip_copy_strided_b32": (_I32, [_VP, _I32, _VP, _VP, _VP, _VP]),
     "rten_hip_reduce_sum_strided_f32": (_I32, [_VP, _I32, _VP, _VP, _I32, _VP, _VP, _VP, _VP]),
+    "rten_hip_reduce_mean_strided_f32": (_I32, [_VP, _I32, _VP, _VP, _I32, _VP, _VP, _VP, _VP]),
     "rten_hip_conv_transpose_output_size": (_I32, [_I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP, _I32, _I32, _I32, _I32, _VP, _VP, _VP]),
     "rten_hip_conv_transpose2d_f32": (_I32, [_VP, _VP, _VP, _VP, _VP, _VP]),
     "rten_hip_matmul_nbits_f32": (_I32, [_VP, _I64, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP]),

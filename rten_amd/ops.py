@@ -1020,6 +1020,7 @@ class Gather(Operator):
 class ReduceSum(Operator):
     """src/ops/reduce.rs:1126-1165 (f32): axes attribute or second input already resolved by the caller into `axes`;
     the slice of every output element is summed in place through the view's strides, 16-lane vecmath::Sum order."""
+    mean = False
 
     def __init__(self, axes=None, keep_dims=True, noop_with_empty_axes=False):
         self.axes, self.keep_dims, self.noop_with_empty_axes = axes, keep_dims, noop_with_empty_axes
@@ -1039,10 +1040,15 @@ class ReduceSum(Operator):
                 raise InvalidValue("Axis is invalid")
             axes.append(a + nd if a < 0 else a)
         axes = sorted(set(axes))  # resolve_axes sorts and dedups (src/ops/mod.rs:259-271)
-        y = E.reduce_sum(ctx, E.View(x), axes) if nd else E.materialize(ctx, E.View(x))
+        y = E.reduce_sum(ctx, E.View(x), axes, mean=self.mean) if nd else E.materialize(ctx, E.View(x))  # rank 0: Sum = Mean = x (slice of one)
         if self.keep_dims:
             y = y.reshape([1 if d in axes else x.shape[d] for d in range(nd)])
         return [y]
+
+
+class ReduceMean(ReduceSum):
+    """src/ops/reduce.rs:523-580: vecmath::Sum(slice) / len(slice) as f32 (an empty slice gives NaN)."""
+    mean = True
 
 
 class Einsum(Operator):
@@ -1072,7 +1078,7 @@ class OpRegistry:
         r = cls()
         for op in (Conv, ConvTranspose, ConvInteger, ConvIntegerToFloat, MatMul, FusedMatMul, Gemm, MatMulInteger, MatMulIntegerToFloat, MatMulNBits,
                    Softmax, AddSoftmax, LayerNormalization, BatchNormalization, Relu, Gelu, Erf, Add, Mul, Sub, Div, Transpose, MaxPool,
-                   AveragePool, GlobalAveragePool, Flatten, DynamicQuantizeLinear, Attention, Gather, ReduceSum, Einsum):
+                   AveragePool, GlobalAveragePool, Flatten, DynamicQuantizeLinear, Attention, Gather, ReduceSum, ReduceMean, Einsum):
             r.register_op(op)
         return r
 

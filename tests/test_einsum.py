@@ -213,13 +213,14 @@ class SimDevice:
             nd, shape, st, x, y = a
             assert nd <= 6
             self._view(self._addr(y), list(shape)[:nd], _row_major(list(shape)[:nd]))[...] = self._view(self._addr(x), list(shape)[:nd], list(st)[:nd])
-        elif name == "rten_hip_reduce_sum_strided_f32":
+        elif name in ("rten_hip_reduce_sum_strided_f32", "rten_hip_reduce_mean_strided_f32"):
             no, osh, ost, ni, ish, ist, x, y = a
             assert no <= 6 and ni <= 6
             osh, ost, ish, ist = list(osh)[:no], list(ost)[:no], list(ish)[:ni], list(ist)[:ni]
             v = self._view(self._addr(x), osh + ish, ost + ist)
             out = self._view(self._addr(y), osh, _row_major(osh))
-            out[...] = OE.reduce_sum(v, list(range(no, no + ni))) if ni else v
+            red = OE.reduce_mean if "mean" in name else OE.reduce_sum
+            out[...] = red(v, list(range(no, no + ni))) if ni else v
         elif name == "rten_hip_binary_broadcast_f32":
             op, nd, shape, sa, sb, x, z, y = a
             assert op == 1 and nd <= 6
@@ -315,9 +316,16 @@ def test_reduce_sum_operator_on_simulated_device():
         got = ops.ReduceSum(axes=axes, keep_dims=keep).run(sim, [DeviceTensor.from_numpy(sim, x)])[0].numpy()
         want = OE.reduce_sum(x, axes, keep)
         assert got.shape == want.shape and np.array_equal(got, want)
+        got = ops.ReduceMean(axes=axes, keep_dims=keep).run(sim, [DeviceTensor.from_numpy(sim, x)])[0].numpy()
+        want = OE.reduce_mean(x, axes, keep)
+        assert got.shape == want.shape and np.array_equal(got, want)
+        np.testing.assert_allclose(got, x.astype(np.float64).mean(axis=tuple(sorted({a % 4 for a in axes})) if axes else None, keepdims=keep), rtol=1e-5, atol=1e-6)
     with pytest.raises(ops.OpError) as e:
         ops.ReduceSum(axes=[4]).run(SimDevice(), [DeviceTensor.from_numpy(SimDevice(), x)])
     assert e.value == ops.InvalidValue("Axis is invalid")
+    # reduce.rs:1868-1872 (test_reduce_mean literals): mean over the last axis / all axes of [[1,2,3],[4,5,6]]... exact small integers
+    lit = np.arange(1, 10, dtype=np.float32).reshape(3, 3)
+    assert OE.reduce_mean(lit, [-1]).tolist() == [2.0, 5.0, 8.0] and OE.reduce_mean(lit, None).tolist() == 5.0
 
 
 # ------------------------------------------------------------------------------------------------ GPU parity
@@ -365,6 +373,9 @@ def test_gpu_reduce_sum_strided_matches_oracle(ctx):
         got = ops.ReduceSum(axes=axes, keep_dims=False).run(ctx, [DeviceTensor.from_numpy(ctx, x)])[0].numpy()
         want = OE.reduce_sum(x, axes, False)
         assert got.shape == want.shape and np.array_equal(got, want), (shape, axes)
+        gm = ops.ReduceMean(axes=axes, keep_dims=True).run(ctx, [DeviceTensor.from_numpy(ctx, x)])[0].numpy()
+        wm = OE.reduce_mean(x, axes, True)
+        assert gm.shape == wm.shape and np.array_equal(gm, wm, equal_nan=True), (shape, axes)
 
 
 @pytest.mark.gpu
