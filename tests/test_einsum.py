@@ -395,3 +395,61 @@ def test_gpu_einsum_at_bert_attention_size(ctx):
         want_s = OE.einsum("qd,kd->qk", q[b, :, h], k[b, :, h])
         assert np.array_equal(sn[b, h], want_s)
         assert np.array_equal(o[b, :, h], OE.einsum("qk,kd->qd", want_s, v[b, :, h]))
+
+
+# ------------------------------------------------------------------------------------------------ seeded random equations
+def _random_equation(rng):
+    """2-3 operands over labels a..f with sizes 1..6: random ranks, repeated labels (diagonals), labels summed in one or several
+    terms, random output subset in random order; `broadcast` variants shrink one occurrence of a label to size 1."""
+    labels = "abcdef"
+    size = {c: int(rng.integers(1, 7)) for c in labels}
+    terms = []
+    for _ in range(int(rng.integers(1, 4))):
+        r = int(rng.integers(0, 5))
+        t = "".join(rng.choice(list(labels), r, replace=True)) if rng.random() < 0.25 else "".join(rng.choice(list(labels), min(r, 6), replace=False))
+        terms.append(t)
+    used = sorted(set("".join(terms)))
+    out = "".join(rng.permutation([c for c in used if rng.random() < 0.5])) if used else ""
+    shapes = [[size[c] for c in t] for t in terms]
+    broadcast = False
+    if rng.random() < 0.2 and len(terms) > 1:
+        for ti, t in enumerate(terms):  # a label that also occurs in another term, once in this one: make it 1 here
+            cands = [i for i, c in enumerate(t) if t.count(c) == 1 and any(c in o for j, o in enumerate(terms) if j != ti)]
+            if cands:
+                shapes[ti][int(rng.choice(cands))] = 1
+                broadcast = True
+                break
+    return ",".join(terms) + "->" + out, shapes, broadcast
+
+
+RANDOM_EQUATIONS = [_random_equation(np.random.default_rng(1000 + i)) for i in range(160)]
+
+
+@pytest.mark.parametrize("case", range(len(RANDOM_EQUATIONS)))
+def test_random_equations_oracle_and_planner(case):
+    """oracle vs numpy.einsum in f64 (the oracle's semantics beyond the reference's table) and planner-on-simulated-device vs
+    oracle bit for bit."""
+    eq, shapes, broadcast = RANDOM_EQUATIONS[case]
+    xs = _random_operands(shapes, 5000 + case)
+    want = OE.einsum(eq, *xs)
+    if not broadcast:  # numpy's einsum has its own broadcasting rules for 1-sized axes: compare only label-consistent cases
+        f = np.einsum(eq, *[x.astype(np.float64) for x in xs])
+        assert want.shape == f.shape
+        np.testing.assert_allclose(want, f, rtol=1e-4, atol=1e-4)
+    sim = SimDevice()
+    got = ops.Einsum(eq).run(sim, [DeviceTensor.from_numpy(sim, x) for x in xs])[0]
+    assert tuple(got.shape) == want.shape and np.array_equal(got.numpy(), want), eq
+
+
+@pytest.mark.gpu
+def test_gpu_random_equations_match_oracle(ctx):
+    bad = []
+    for eq, shapes, _ in RANDOM_EQUATIONS:
+        xs = _random_operands(shapes, 7000 + len(eq))
+        spy = _GemvSpy(ctx)
+        got = ops.Einsum(eq).run(spy, [DeviceTensor.from_numpy(ctx, x) for x in xs])[0].numpy()
+        want = OE.einsum(eq, *xs)
+        ok = got.shape == want.shape and (np.allclose(got, want, rtol=1e-5, atol=1e-6) if spy.gemv else np.array_equal(got, want))
+        if not ok:
+            bad.append(eq)
+    assert not bad, bad
