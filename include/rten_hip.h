@@ -16,8 +16,16 @@
  *    the ABI reports RTEN_HIP_ERR_INVALID_VALUE for arguments it cannot execute and
  *    RTEN_HIP_ERR_HIP for runtime failures, with text in rten_hip_last_error().
  *  - All work is enqueued on the context's HIP stream and is asynchronous w.r.t. the host;
- *    rten_hip_sync() (or a D2H copy) makes results visible.  A context is not thread-safe: use one
- *    context per host thread (Graph::run_plan executes operators sequentially, src/graph.rs:880).
+ *    rten_hip_sync() (or a D2H copy) makes results visible.
+ *  - Thread safety (Model::run(&self) may be entered by several host threads at once, src/model.rs:308-550,
+ *    call site src/graph.rs:782): a context MAY be shared.  Every entry point that takes a context locks the
+ *    context's internal (recursive) mutex for the duration of the call, binds the context's device to the
+ *    calling thread, and enqueues all launches of one operator back to back, so concurrent callers
+ *    interleave at operator granularity on the one stream and the shared scratch / staging buffers are
+ *    reused in stream order.  rten_hip_last_error() is per calling thread.  A hipGraph capture
+ *    (rten_hip_graph_begin .. rten_hip_graph_end) holds the lock: other threads' calls on that context
+ *    block until the capture ends.  Tuning knobs (set_gemm_variant_override, set_gemm_split, ...) are
+ *    per context, not per thread: callers that tune concurrently use one context per thread.
  *  - Numerics: integer paths are bit-exact w.r.t. the reference.  f32 GEMM/conv reproduce the
  *    reference's accumulation order exactly (k-ordered FMA chains in depth blocks of 256,
  *    rten-gemm/src/lib.rs:630-633 + kernels/simd_generic.rs:326-414), element-wise kernels
@@ -37,7 +45,7 @@
 extern "C" {
 #endif
 
-#define RTEN_HIP_ABI_VERSION 1
+#define RTEN_HIP_ABI_VERSION 2
 
 /* ---- status codes (map onto OpError variants, src/operator.rs:116-144) ---- */
 #define RTEN_HIP_OK 0
@@ -141,12 +149,34 @@ typedef struct {
     int32_t m, n, k;
     int64_t a_rs, a_cs, b_rs, b_cs, ldc;
     int32_t a_signed, b_signed;
-    int32_t a_zp_len, b_zp_len; /* 0 (none), 1 (scalar) or m / n */
+    /* a_zp_len: 0 (none), 1 (scalar) or a period p that divides m: row r uses a_zp[r % p].  p == m is the plain
+     * per-row form; p < m is the zero-point cycling of a batched LHS collapsed to [A*M, K] (matmul.rs:266-280).
+     * b_zp_len: 0, 1 or n. */
+    int32_t a_zp_len, b_zp_len;
     int32_t scale_len;          /* 0 (i32 output), 1 or n */
+    /* batched_gemm_uninit over a broadcast prefix (matmul.rs:302-372): `batch` products, operand z at
+     * base + z * {a,b,c}_bs elements; a stride of 0 broadcasts that operand.  batch <= 1: one product.  Every
+     * product uses the same zero points / scale. */
+    int32_t batch;
+    int64_t a_bs, b_bs, c_bs;
+    /* != 0: `b` is a buffer written by rten_hip_gemm_int8_prepack for this (k, n, b_signed); b_rs / b_cs / b_bs
+     * are ignored (a prepacked RHS is a single matrix, as in the reference: packed_b is only used when
+     * num_b_matrices == 1, matmul.rs:318-327). */
+    int32_t b_prepacked;
 } rten_hip_gemm_int8_desc;
 
 int32_t rten_hip_gemm_int8(rten_hip_ctx *ctx, const rten_hip_gemm_int8_desc *desc, const void *a, const void *b,
                            const void *a_zp, const void *b_zp, const float *scale, void *c);
+
+/* Load-time staging of a constant MatMulInteger / MatMulIntegerToFloat RHS: PackedBMatrix via
+ * Operator::prepack -> matmul_prepack_b (src/ops/matmul.rs:696-705,812-840), Graph::prepack_weights
+ * (src/graph.rs:488-562), rten-gemm/src/prepack.rs:19-120, packing/int8.rs:80-249 (the packed image carries the
+ * column sums the zero-point epilogue needs).  B [k, n] is read through element strides and written as
+ * chunk-major signed bytes [k/16][n][16] followed by int32 column sums; consumed by rten_hip_gemm_int8 with
+ * desc.b_prepacked != 0.  packed_bytes returns 0 for shapes the staged kernel does not cover. */
+size_t rten_hip_gemm_int8_packed_bytes(int32_t k, int32_t n);
+int32_t rten_hip_gemm_int8_prepack(rten_hip_ctx *ctx, int32_t k, int32_t n, const void *b, int64_t b_rs, int64_t b_cs,
+                                   int32_t b_signed, void *packed);
 
 /* ---- Conv (f32): Conv::run -> conv_impl, src/ops/conv.rs:124-365,384-400 ----
  * X [n,c,h,w], W [o, c/groups, kh, kw], bias [o] or NULL, Y [n,o,oh,ow]; pads are the FIXED pads
@@ -341,6 +371,23 @@ int32_t rten_hip_sdpa_f32(rten_hip_ctx *ctx, const rten_hip_sdpa_desc *desc, con
 /* ---- Gather of rows (embedding lookup; src/ops/gather.rs Gather axis 0): out[i,:] = table[ids[i],:] ---- */
 int32_t rten_hip_gather_rows_f32(rten_hip_ctx *ctx, int64_t n_ids, int32_t row_len, int32_t table_rows,
                                  const float *table, const int32_t *ids, float *out);
+
+/* ---- multi-GPU: one process per GPU, batches sharded with no data-path collective; the only
+ *      collective is the one-time broadcast of the prepacked weight arena over xGMI.  The reference has no
+ *      analogue (single-process CPU executor); a Rust host calls these next to Model::load.  librccl is
+ *      loaded on first use (dlopen), so single-GPU users never map it.
+ *      Rank 0 obtains a 128-byte id and hands it to the other ranks by any host-side channel (file, env, socket);
+ *      every rank then calls comm_init_rank with its own context (device).  broadcast runs on the context's
+ *      stream: stream-ordered with the kernels that consume the weights. */
+#define RTEN_HIP_COMM_ID_BYTES 128
+typedef struct rten_hip_comm rten_hip_comm;
+int32_t rten_hip_comm_get_unique_id(rten_hip_ctx *ctx, uint8_t id[RTEN_HIP_COMM_ID_BYTES]);
+int32_t rten_hip_comm_init_rank(rten_hip_ctx *ctx, const uint8_t id[RTEN_HIP_COMM_ID_BYTES], int32_t world_size, int32_t rank,
+                                rten_hip_comm **out_comm);
+/* In-place broadcast of `bytes` bytes at device pointer `buf` from rank `root` to every rank. */
+int32_t rten_hip_broadcast(rten_hip_ctx *ctx, rten_hip_comm *comm, void *buf, size_t bytes, int32_t root);
+int32_t rten_hip_comm_world_size(rten_hip_comm *comm, int32_t *world_size, int32_t *rank);
+int32_t rten_hip_comm_destroy(rten_hip_ctx *ctx, rten_hip_comm *comm);
 
 /* ---- tuning: per-shape kernel-variant selection by measurement at load time ----
  * variant < 0 restores the built-in heuristic.  Used by the harness's autotuner. */

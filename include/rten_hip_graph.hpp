@@ -337,8 +337,18 @@ class Graph {
     const std::vector<Tensor> &capture(const Feeds &feeds) {
         run(feeds); // warm: every buffer size is in the pool, scratch is grown, code objects are loaded
         ctx_.sync();
+        if (graph_) { // re-capture: the previous executable graph is released first
+            ctx_.check(rten_hip_graph_destroy(ctx_.raw(), graph_));
+            graph_ = 0;
+        }
         ctx_.check(rten_hip_graph_begin(ctx_.raw()));
-        captured_outputs_ = run(feeds);
+        try {
+            captured_outputs_ = run(feeds);
+        } catch (...) { // leave the stream (and the context's lock) out of capture mode before the error propagates
+            uint64_t dead = 0;
+            if (rten_hip_graph_end(ctx_.raw(), &dead) == RTEN_HIP_OK && dead) rten_hip_graph_destroy(ctx_.raw(), dead);
+            throw;
+        }
         ctx_.check(rten_hip_graph_end(ctx_.raw(), &graph_));
         return captured_outputs_;
     }
@@ -392,16 +402,21 @@ class Graph {
             }
         }
         std::vector<Tensor> result;
+        std::set<int> moved;
         for (auto &o : outputs_) {
             const int id = ids_.at(o.name);
-            if (!owned[(size_t)id]) throw GraphError("run: output " + o.name + " is not produced by an operator");
-            if (view_values_.count(id)) { // a view's storage belongs to a value that dies with this run: hand out a copy
-                const Tensor &v = *owned[(size_t)id];
+            if (!val[(size_t)id]) throw GraphError("run: output " + o.name + " is not produced by an operator");
+            // a graph output that is a graph input or an initializer (not owned by this run), one that is listed twice, and a
+            // view (its storage belongs to a value that dies with this run) are handed out as copies
+            if (!owned[(size_t)id] || moved.count(id) || view_values_.count(id)) {
+                const Tensor &v = moved.count(id) ? result[(size_t)std::distance(outputs_.begin(), std::find_if(outputs_.begin(), outputs_.end(), [&](const onnx::ValueInfo &x) { return x.name == o.name; }))]
+                                                  : *val[(size_t)id];
                 Tensor copy(ctx_, v.shape(), v.dtype());
                 if (v.bytes()) ctx_.check(rten_hip_memcpy_d2d(ctx_.raw(), copy.ptr(), v.ptr(), v.bytes()));
                 result.push_back(std::move(copy));
             } else {
                 result.push_back(std::move(*owned[(size_t)id]));
+                moved.insert(id);
             }
         }
         return result;
@@ -809,7 +824,7 @@ class Graph {
         // attention kernel reads in place (bit-identical: every output element is the same k-ordered dot product).
         // lead0 / lead1: leading dims when the Reshapes spell them out ([B, S, h, d], as PyTorch's exporter writes a static-shape
         // `view`) instead of copying them ([0, 0, h, d]); checked against the projections at run time (0 = copied)
-        struct Attn { std::string q, k, v, mask, out, x; int heads = 0; float scale = 1.f; bool merged = false; int wqkv = -1, bqkv = -1; int64_t hidden = 0; int lead0 = 0, lead1 = 0; };
+        struct Attn { std::string q, k, v, mask, out, x; int heads = 0; float scale = 1.f; bool merged = false; int wqkv = -1, bqkv = -1; int64_t hidden = 0; int lead0 = 0, lead1 = 0; int head_dim = 0; };
         std::map<size_t, Attn> attn_at;
         if (opt_.fuse) {
             auto single_use = [&](const std::string &v) { auto it = users.find(v); return !graph_outs.count(v) && it != users.end() && it->second.size() == 1; };
@@ -838,7 +853,10 @@ class Graph {
                 std::vector<int32_t> shp;
                 if (r < 0 || m.nodes[(size_t)r].inputs.size() < 2 || !const_i32(m.nodes[(size_t)r].inputs[1], shp) || shp.size() != 4 || shp[2] <= 0 || !leading_ok(shp, at, first)) return "";
                 if (heads && heads != shp[2]) return "";
+                // one head size for q, k and v (the kernel's d == dv); -1 ("the rest") is accepted only if all three say so
+                if (heads && at.head_dim != shp[3]) return "";
                 heads = shp[2];
+                at.head_dim = shp[3];
                 nodes.push_back((size_t)t); nodes.push_back((size_t)r);
                 return m.nodes[(size_t)r].inputs[0];
             };
@@ -881,6 +899,10 @@ class Graph {
                 nodes.push_back((size_t)tr); nodes.push_back((size_t)rs);
                 at.out = m.nodes[(size_t)rs].outputs[0];
                 if (!at.mask.empty() && producer.count(at.mask) && producer[at.mask] > i) continue; // mask must exist before the scores
+                if (!at.mask.empty() && is_const(at.mask)) { // a constant mask with a head axis is outside the kernel's forms: leave the graph unfused
+                    const Tensor &mk = consts_.at(ids_.at(at.mask));
+                    if (mk.dtype() != DType::F32 || mk.ndim() > 4 || (mk.ndim() == 4 && mk.size(1) != 1) || (mk.ndim() == 3 && mk.size(0) != 1)) continue;
+                }
                 // optional: one GEMM for the three projections
                 struct Lin { long mm = -1, add = -1; std::string x, w, b; };
                 auto linear = [&](const std::string &v) {
@@ -998,7 +1020,29 @@ class Graph {
                 }
                 st.kind_name = std::string("Conv") + (residual.empty() ? "" : "+Add") + (op->fuse_relu ? "+Relu" : "");
                 st.conv = op;
-                st.run = [op, packed](Context &c, const InputList &in) { return op->run_packed(c, in, packed); };
+                // The Add's other operand is used as the kernel's residual only when it has exactly the conv's output shape
+                // (the kernel indexes it with the output's strides).  Its shape is a run-time fact (no shape inference here), and
+                // it may be a constant or any broadcasting operand -- e.g. the exporter's explicit bias Add([1,O,1,1]) -- so a
+                // mismatch runs the operators as the graph spells them: Conv, broadcasting Add, Relu.  (The constant is NOT
+                // routed to the conv's bias input: the GEMM adds a bias after the first depth block, the graph adds it last.)
+                st.run = [op, packed](Context &c, const InputList &in) {
+                    const Tensor *res = in.size() > 3 ? in[3] : nullptr;
+                    if (res) {
+                        const Tensor &x = require(in, 0), &w = require(in, 1);
+                        bool same = res->dtype() == DType::F32 && x.ndim() == 4 && w.ndim() == 4; // 1-D convs with an Add: always unfused
+                        if (same) {
+                            const rten_hip_conv2d_desc d = op->geometry(x.shape(), w.shape());
+                            same = res->shape() == std::vector<int64_t>{d.n, d.o, d.out_h, d.out_w};
+                        }
+                        if (!same) {
+                            Conv plain = *op; plain.fuse_relu = false;
+                            OutputList y = plain.run_packed(c, {in[0], in[1], in.size() > 2 ? in[2] : nullptr}, packed);
+                            OutputList sum = Add().run(c, {&y[0], res});
+                            return op->fuse_relu ? Relu().run(c, {&sum[0]}) : std::move(sum);
+                        }
+                    }
+                    return op->run_packed(c, in, packed);
+                };
             } else if (n.op_type == "ConvTranspose") {
                 auto op = std::make_shared<ConvTranspose>();
                 op->groups = (int)n.get_int("group", 1);
@@ -1065,10 +1109,39 @@ class Graph {
                     }
                 }
                 st.i8 = state;
+                // ConvIntegerToFloatFusion (fusions.rs:1012-1058) fuses only a scale of shape [] or [1] and leaves every other graph
+                // as ConvInteger -> Cast -> Mul.  Shapes are run-time facts here, so the step decides per run: a scalar f32 scale
+                // (or a per-output-channel [1,O,1,1] / [O,1,1] one, which the kernel applies exactly as Cast -> Mul would) with a
+                // bias of O channels and a residual of the output's shape takes the fused kernel; anything else runs the
+                // operators as the graph spells them.
                 st.run = [state, relu](Context &c, const InputList &in) {
-                    const Tensor *scale = in[4];
-                    if (scale && scale->len() != 1) throw OpError(OpError::InvalidValue, "scale should be a scalar");
-                    return state->op->run_staged(c, InputList(in.begin(), in.begin() + 4), scale, in[5], in[6], relu, state->sg);
+                    const Tensor *scale = in[4], *bias = in[5], *residual = in[6];
+                    if (!scale) return state->op->run_staged(c, InputList(in.begin(), in.begin() + 4), nullptr, nullptr, nullptr, false, state->sg);
+                    const Tensor &x = require(in, 0), &w = require(in, 1);
+                    bool fused = scale->dtype() == DType::F32 && x.ndim() == 4 && w.ndim() == 4;
+                    int64_t o = fused ? w.size(0) : 0;
+                    bool per_channel = false;
+                    if (fused && scale->len() != 1) {
+                        const auto &sh = scale->shape();
+                        per_channel = scale->len() == o && ((sh.size() == 4 && sh[0] == 1 && sh[1] == o) || (sh.size() == 3 && sh[0] == o));
+                        fused = per_channel;
+                    }
+                    if (fused && bias) fused = bias->dtype() == DType::F32 && bias->len() == o && bias->ndim() == 4 && bias->size(1) == o;
+                    if (fused && residual) {
+                        const rten_hip_conv2d_desc d = state->op->conv.geometry(x.shape(), w.shape());
+                        fused = residual->dtype() == DType::F32 && residual->shape() == std::vector<int64_t>{d.n, d.o, d.out_h, d.out_w};
+                    }
+                    if (fused) return state->op->run_staged(c, InputList(in.begin(), in.begin() + 4), scale, bias, residual, relu, state->sg, per_channel);
+                    ConvInteger::Staging sg = state->sg;
+                    sg.stats_out = nullptr; // statistics are accumulated by the float epilogue only
+                    OutputList acc = state->op->run_staged(c, InputList(in.begin(), in.begin() + 4), nullptr, nullptr, nullptr, false, sg);
+                    Cast cast; cast.to = DType::F32;
+                    OutputList f = cast.run(c, {&acc[0]});
+                    OutputList y = Mul().run(c, {&f[0], scale});
+                    if (bias) y = Add().run(c, {&y[0], bias});
+                    if (residual) y = Add().run(c, {&y[0], residual});
+                    if (relu) y = Relu().run(c, {&y[0]});
+                    return y;
                 };
             } else if (n.op_type == "MatMulInteger") {
                 auto op = std::make_shared<MatMulInteger>();
@@ -1082,7 +1155,30 @@ class Graph {
                 while (st.in.size() < 4) st.in.push_back(-1);
                 st.in.push_back(scale.empty() ? -1 : id_of(scale));
                 if (!scale.empty()) st.kind_name = "MatMulIntegerToFloat";
-                st.run = [op](Context &c, const InputList &in) { return op->run_scaled(c, InputList(in.begin(), in.begin() + 4), in[4]); };
+                // Graph::prepack_weights (src/graph.rs:488-562): a constant RHS is staged once at load (PackedBMatrix)
+                const Tensor *packed = nullptr;
+                if (opt_.prepack && is_const(n.inputs.at(1))) {
+                    const Tensor &w = consts_.at(ids_.at(n.inputs.at(1)));
+                    Tensor pk = op->prepack(ctx_, w);
+                    if (pk.len()) { packed_.emplace_back(new Tensor(std::move(pk))); packed = packed_.back().get(); }
+                }
+                // MatMulIntegerToFloatFusion (fusions.rs:960-1009) needs a scale of rank <= 1; the operator then needs length 1 or N.
+                // Decided per run (shapes are run-time facts); otherwise MatMulInteger -> Cast -> Mul as the graph spells it.
+                st.run = [op, packed](Context &c, const InputList &in) {
+                    const Tensor *scale = in[4];
+                    if (scale) {
+                        const Tensor &b = require(in, 1);
+                        const int64_t ncols = b.ndim() > 1 ? b.size(b.ndim() - 1) : 1;
+                        const bool ok = scale->dtype() == DType::F32 && scale->ndim() <= 1 && (scale->len() == 1 || scale->len() == ncols);
+                        if (!ok) {
+                            OutputList acc = op->run_scaled(c, InputList(in.begin(), in.begin() + 4), nullptr, packed);
+                            Cast cast; cast.to = DType::F32;
+                            OutputList f = cast.run(c, {&acc[0]});
+                            return Mul().run(c, {&f[0], scale});
+                        }
+                    }
+                    return op->run_scaled(c, InputList(in.begin(), in.begin() + 4), scale, packed);
+                };
             } else if (n.op_type == "Gemm") {
                 auto op = std::make_shared<Gemm>();
                 op->alpha = n.get_float("alpha", 1.f); op->beta = n.get_float("beta", 1.f);

@@ -21,6 +21,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <numeric>
 #include <stdexcept>
 #include <string>
@@ -43,7 +44,8 @@ struct OpError : std::runtime_error {
     }
 };
 
-// ---- Context: RAII over rten_hip_ctx.  One per host thread (Graph::run_plan runs operators sequentially).
+// ---- Context: RAII over rten_hip_ctx.  May be shared by host threads (rten_hip.h, "Thread safety"): the C ABI locks the
+// context per call and the buffer pool below has its own mutex.
 class Context {
   public:
     explicit Context(int device = 0, void *stream = nullptr) {
@@ -63,6 +65,7 @@ class Context {
     void enable_pool(bool on = true) { pool_on_ = on; if (!on) trim_pool(); }
     void *alloc(size_t bytes) {
         if (pool_on_) {
+            std::lock_guard<std::mutex> lk(pool_mu_);
             auto it = pool_.find(bytes);
             if (it != pool_.end() && !it->second.empty()) { void *p = it->second.back(); it->second.pop_back(); return p; }
         }
@@ -72,10 +75,11 @@ class Context {
     }
     void release(void *p, size_t bytes) {
         if (!p) return;
-        if (pool_on_) pool_[bytes].push_back(p);
+        if (pool_on_) { std::lock_guard<std::mutex> lk(pool_mu_); pool_[bytes].push_back(p); }
         else rten_hip_free(h_, p);
     }
     void trim_pool() {
+        std::lock_guard<std::mutex> lk(pool_mu_);
         for (auto &kv : pool_) for (void *p : kv.second) rten_hip_free(h_, p);
         pool_.clear();
     }
@@ -104,6 +108,7 @@ class Context {
     bool pool_on_ = false;
     void *one_ = nullptr;
     std::map<size_t, std::vector<void *>> pool_;
+    std::mutex pool_mu_; // the pool is shared by concurrent Model::run callers (the C ABI context locks itself)
 };
 
 // ---- device tensor (the backend's `Value`: contiguous, row-major, device resident)
@@ -386,10 +391,14 @@ struct ConvTranspose : Operator { // src/ops/conv_transpose.rs:414-458; kernel l
 
 // zero_point_to_vec (src/ops/matmul.rs:513-531)
 inline int zero_point_len(const Tensor *zp, int64_t expected) {
+    // zero_point_to_vec, src/ops/matmul.rs:513-531
     if (!zp) return 0;
-    if (zp->ndim() == 0 || zp->len() == 1) return 1;
-    if (zp->ndim() == 1 && zp->len() == expected) return (int)expected;
-    throw OpError(OpError::InvalidValue, "Zero point has incorrect size");
+    if (zp->ndim() == 0) return 1;
+    if (zp->ndim() == 1) {
+        if (zp->len() != expected) throw OpError(OpError::InvalidValue, "Zero point has incorrect size");
+        return (int)expected;
+    }
+    throw OpError(OpError::UnsupportedValue, "Only scalar or vector zero points are supported");
 }
 
 struct ConvInteger : Operator {
@@ -438,14 +447,20 @@ struct ConvInteger : Operator {
     OutputList run_fused(Context &ctx, const InputList &in, const Tensor *scale, const Tensor *bias, const Tensor *residual, bool relu) const {
         return run_staged(ctx, in, scale, bias, residual, relu, Staging());
     }
+    // per_channel_scale: `scale` holds one value per output channel ([1,O,1,1] / [O,1,1], the Cast -> Mul form of per-channel weights)
     OutputList run_staged(Context &ctx, const InputList &in, const Tensor *scale, const Tensor *bias, const Tensor *residual, bool relu,
-                          const Staging &sg) const {
+                          const Staging &sg, bool per_channel_scale = false) const {
         const Tensor &x = require(in, 0), &w = require(in, 1);
         const Tensor *x_zp = get(in, 2), *w_zp = get(in, 3);
         rten_hip_conv2d_int8_desc di = desc(x, w, x_zp, w_zp);
         const bool packed = sg.packed_weight && sg.packed_weight->len() > 0;
         di.weights_packed = packed ? 1 : 0;
         di.x_staged = sg.x_staged ? 1 : 0;
+        if (scale && per_channel_scale) {
+            if (scale->len() != di.conv.o) throw OpError(OpError::IncompatibleInputShapes, "per-channel scale length does not match output channels");
+            di.scale_len = di.conv.o;
+        }
+        if (bias && bias->len() != di.conv.o) throw OpError(OpError::IncompatibleInputShapes, "bias length does not match output channels");
         Tensor y(ctx, {di.conv.n, di.conv.o, di.conv.out_h, di.conv.out_w}, scale ? DType::F32 : DType::I32);
         const uint32_t flags = (relu ? RTEN_HIP_CONV_RELU : 0u) | (residual ? RTEN_HIP_CONV_RESIDUAL : 0u);
         const void *wp = packed ? sg.packed_weight->ptr() : w.ptr();
@@ -595,29 +610,89 @@ struct Gemm : Operator { // src/ops/matmul.rs:106-156: c = alpha * (a b) + beta 
     }
 };
 
-struct MatMulInteger : Operator { // src/ops/matmul.rs:582-647; scale != null: MatMulIntegerToFloat (:789-794)
+struct MatMulInteger : Operator { // src/ops/matmul.rs:582-700 (matmul_integer -> matmul_impl :208-385); scale != null: MatMulIntegerToFloat (:789-794)
     const char *name() const override { return "MatMulInteger"; }
     int max_inputs() const override { return 4; }
     OutputList run(Context &ctx, const InputList &in) const override { return run_scaled(ctx, in, nullptr); }
-    OutputList run_scaled(Context &ctx, const InputList &in, const Tensor *scale) const {
+
+    // Operator::prepack for input 1 (matmul.rs:696-705 -> matmul_prepack_b; Graph::prepack_weights, src/graph.rs:488-562): a
+    // constant 2-D RHS staged once as the int8 kernel's chunk-major image + column sums.  Returns an empty tensor when the
+    // staged kernel does not cover the shape (the op then runs unpacked).
+    Tensor prepack(Context &ctx, const Tensor &b) const {
+        if ((b.dtype() != DType::U8 && b.dtype() != DType::I8) || b.ndim() != 2) return Tensor();
+        const size_t bytes = rten_hip_gemm_int8_packed_bytes((int32_t)b.size(0), (int32_t)b.size(1));
+        if (!bytes) return Tensor();
+        Tensor packed(ctx, {(int64_t)bytes}, DType::U8);
+        ctx.check(rten_hip_gemm_int8_prepack(ctx.raw(), (int32_t)b.size(0), (int32_t)b.size(1), b.ptr(), b.size(1), 1, b.dtype() == DType::I8, packed.ptr()));
+        return packed;
+    }
+
+    // All of matmul_impl's forms: vector operands (numpy.matmul rules), `[A.., M, K] x [K, N]` collapsed to one product with
+    // the row zero points cycled (:259-296), batched / broadcast prefixes (batched_gemm_uninit, :302-372).
+    OutputList run_scaled(Context &ctx, const InputList &in, const Tensor *scale, const Tensor *packed_b = nullptr) const {
         const Tensor &a = require(in, 0), &b = require(in, 1);
         auto is8 = [](DType t) { return t == DType::U8 || t == DType::I8; };
         if (!is8(a.dtype()) || !is8(b.dtype())) throw OpError(OpError::UnsupportedType, "");
-        if (a.ndim() != 2 || b.ndim() != 2) throw OpError(OpError::UnsupportedValue, "MatMulInteger: only 2-D operands on the device path");
-        const int64_t m = a.size(0), k = a.size(1), n = b.size(1);
-        if (k != b.size(0)) throw OpError(OpError::IncompatibleInputShapes, "Columns of first matrix does not match rows of second matrix");
         const Tensor *a_zp = get(in, 2), *b_zp = get(in, 3);
-        rten_hip_gemm_int8_desc d{};
-        d.m = (int)m; d.n = (int)n; d.k = (int)k; d.a_rs = k; d.a_cs = 1; d.b_rs = n; d.b_cs = 1; d.ldc = n;
-        d.a_signed = a.dtype() == DType::I8; d.b_signed = b.dtype() == DType::I8;
-        d.a_zp_len = zero_point_len(a_zp, m); d.b_zp_len = zero_point_len(b_zp, n);
+        const int64_t a_rows = a.ndim() > 1 ? a.size(a.ndim() - 2) : 1, b_cols = b.ndim() > 1 ? b.size(b.ndim() - 1) : 1;
+        const int azl = zero_point_len(a_zp, a_rows), bzl = zero_point_len(b_zp, b_cols);
+        if (a.ndim() < 1 || b.ndim() < 1) throw OpError(OpError::InvalidValue, "Inputs must have >= 1 dimensions");
+        std::vector<int64_t> ash = a.shape(), bsh = b.shape();
+        const bool a_vec = ash.size() == 1, b_vec = bsh.size() == 1;
+        if (a_vec) ash.insert(ash.begin(), 1);
+        if (b_vec) bsh.push_back(1);
+        const int64_t m = ash[ash.size() - 2], k = ash.back(), kb = bsh[bsh.size() - 2], n = bsh.back();
+        if (k != kb) throw OpError(OpError::IncompatibleInputShapes, "Columns of first matrix does not match rows of second matrix");
+        std::vector<int64_t> ap(ash.begin(), ash.end() - 2), bp(bsh.begin(), bsh.end() - 2);
+        const size_t np = std::max(ap.size(), bp.size());
+        ap.insert(ap.begin(), np - ap.size(), 1);
+        bp.insert(bp.begin(), np - bp.size(), 1);
+        std::vector<int64_t> op(np);
+        for (size_t i = 0; i < np; i++) {
+            if (ap[i] != bp[i] && ap[i] != 1 && bp[i] != 1) throw OpError(OpError::IncompatibleInputShapes, "Cannot broadcast shapes");
+            op[i] = (ap[i] == 0 || bp[i] == 0) ? 0 : std::max(ap[i], bp[i]);
+        }
+        int sl = 0;
         if (scale) {
             if (scale->len() != 1 && scale->len() != n) throw OpError(OpError::IncompatibleInputShapes, "Scale length does not match tensor columns");
-            d.scale_len = (int)scale->len();
+            sl = (int)scale->len();
         }
-        Tensor y(ctx, {m, n}, scale ? DType::F32 : DType::I32);
-        ctx.check(rten_hip_gemm_int8(ctx.raw(), &d, a.ptr(), b.ptr(), vp(a_zp), vp(b_zp), (const float *)vp(scale), y.ptr()));
+        std::vector<int64_t> out_shape = op;
+        if (!a_vec) out_shape.push_back(m);
+        if (!b_vec) out_shape.push_back(n);
+        Tensor y(ctx, out_shape, scale ? DType::F32 : DType::I32);
         OutputList out;
+        if (y.len() == 0) { out.push_back(std::move(y)); return out; }
+        auto prod = [](const std::vector<int64_t> &v) { int64_t p = 1; for (int64_t x : v) p *= x; return p; };
+        const int64_t num_a = prod(ap), num_b = prod(bp), nb = prod(op);
+        const bool packed = packed_b && packed_b->len() && num_b == 1;
+        auto call = [&](int64_t mm, int batch, int64_t a_bs, int64_t b_bs, int64_t c_bs, int64_t a_off, int64_t b_off, int64_t c_off) {
+            rten_hip_gemm_int8_desc d{};
+            d.m = (int)mm; d.n = (int)n; d.k = (int)k; d.a_rs = k; d.a_cs = 1; d.b_rs = n; d.b_cs = 1; d.ldc = n;
+            d.a_signed = a.dtype() == DType::I8; d.b_signed = b.dtype() == DType::I8;
+            d.a_zp_len = azl; d.b_zp_len = bzl; d.scale_len = sl;
+            d.batch = batch; d.a_bs = a_bs; d.b_bs = b_bs; d.c_bs = c_bs; d.b_prepacked = packed ? 1 : 0;
+            ctx.check(rten_hip_gemm_int8(ctx.raw(), &d, (const uint8_t *)a.ptr() + a_off, packed ? packed_b->ptr() : (const void *)((const uint8_t *)b.ptr() + b_off), vp(a_zp), vp(b_zp),
+                                         (const float *)vp(scale), (uint8_t *)y.ptr() + c_off * 4));
+        };
+        if (num_b == 1) { // one [A*M, K] x [K, N] product; row r uses a_zp[r % M]
+            call(num_a * m, 1, 0, 0, 0, 0, 0, 0);
+        } else if ((num_a == 1 || ap == op) && bp == op) {
+            call(m, (int)nb, num_a == 1 ? 0 : m * k, k * n, m * n, 0, 0, 0);
+        } else { // general broadcast: one product per output matrix
+            std::vector<int64_t> as(np), bs(np), idx(np, 0);
+            for (size_t i = 0; i < np; i++) {
+                int64_t sa = 1, sb = 1;
+                for (size_t j = i + 1; j < np; j++) { sa *= ap[j]; sb *= bp[j]; }
+                as[i] = ap[i] == 1 ? 0 : sa; bs[i] = bp[i] == 1 ? 0 : sb;
+            }
+            for (int64_t z = 0; z < nb; z++) {
+                int64_t ia = 0, ib = 0;
+                for (size_t i = 0; i < np; i++) { ia += idx[i] * as[i]; ib += idx[i] * bs[i]; }
+                call(m, 1, 0, 0, 0, ia * m * k, ib * k * n, z * m * n);
+                for (size_t i = np; i-- > 0;) { if (++idx[i] < op[i]) break; idx[i] = 0; }
+            }
+        }
         out.push_back(std::move(y));
         return out;
     }
@@ -896,6 +971,7 @@ struct MultiHeadSdpa : Operator {
         const int64_t Hd = width ? width : q.size(2);
         if (heads <= 0 || Hd % heads != 0) throw OpError(OpError::InvalidValue, "hidden size is not divisible by the number of heads");
         if (k.size(0) != B || v.size(0) != B || v.size(1) != T) throw OpError(OpError::IncompatibleInputShapes, "q / k / v batch or sequence sizes do not match");
+        if (!width && (k.size(2) != Hd || v.size(2) != Hd)) throw OpError(OpError::IncompatibleInputShapes, "q / k / v hidden sizes do not match");
         const int64_t d = Hd / heads;
         rten_hip_sdpa_desc sd{};
         sd.batch = (int)B; sd.heads = heads; sd.s = (int)S; sd.t = (int)T; sd.d = (int)d; sd.dv = (int)d;
@@ -904,11 +980,33 @@ struct MultiHeadSdpa : Operator {
         sd.q_hs = sd.k_hs = sd.v_hs = d;
         sd.o_rs = Hd; sd.o_bs = S * Hd; sd.o_hs = d;
         sd.scale = scale; sd.flush_nan_to_zero = flush_nans_to_zero ? 1 : 0;
+        Tensor expanded; // a mask that broadcasts to [B, 1, S, T] in another form (e.g. a causal [1, 1, S, T] or [S, T]) is expanded first
         if (mask) {
+            want(*mask, DType::F32, "float32");
             if (mask->ndim() == 4 && mask->size(0) == B && mask->size(1) == 1 && mask->size(3) == T && (mask->size(2) == 1 || mask->size(2) == S)) {
                 sd.mask_row_stride = mask->size(2) == 1 ? 0 : T;
                 sd.mask_batch_stride = mask->size(2) == 1 ? T : S * T;
-            } else throw OpError(OpError::IncompatibleInputShapes, "attention mask must be [B, 1, 1, T] or [B, 1, S, T]");
+            } else {
+                // numpy broadcasting of the Add(scores [B, H, S, T], mask): every form without a head axis is the same addend for
+                // all heads, so the expanded copy gives the unfused graph's bits
+                const int nd = mask->ndim();
+                if (nd > 4) throw OpError(OpError::IncompatibleInputShapes, "Cannot broadcast inputs to same shape");
+                int64_t ms[4] = {1, 1, 1, 1};
+                for (int i = 0; i < nd; i++) ms[4 - nd + i] = mask->size(i);
+                const int64_t want_shape[4] = {B, 1, S, T};
+                if (ms[1] != 1) throw OpError(OpError::UnsupportedValue, "fused attention: a mask with a head axis is not supported (run the graph unfused)");
+                int64_t strides[4], acc = 1;
+                for (int i = 3; i >= 0; i--) {
+                    if (ms[i] != 1 && ms[i] != want_shape[i]) throw OpError(OpError::IncompatibleInputShapes, "Cannot broadcast inputs to same shape");
+                    strides[i] = ms[i] == 1 ? 0 : acc;
+                    acc *= ms[i];
+                }
+                expanded = Tensor(ctx, {B, 1, S, T}, DType::F32);
+                if (expanded.len()) ctx.check(rten_hip_copy_strided_b32(ctx.raw(), 4, want_shape, strides, mask->ptr(), expanded.ptr()));
+                mask = &expanded;
+                sd.mask_row_stride = T;
+                sd.mask_batch_stride = S * T;
+            }
         }
         Tensor y(ctx, {B, S, Hd}, DType::F32);
         if (y.len())

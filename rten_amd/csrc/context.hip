@@ -5,15 +5,18 @@
 
 #include "internal.h"
 
+// Error text is per calling host thread (several Model::run threads may share a context): a thread always reads the
+// message of ITS last failing call, and the returned pointer stays valid until that thread's next failing call.
+static thread_local std::string tls_last_error;
+
 int32_t rten_set_error(rten_hip_ctx *ctx, int32_t code, const char *fmt, ...) {
-    if (ctx) {
-        char buf[512];
-        va_list ap;
-        va_start(ap, fmt);
-        vsnprintf(buf, sizeof buf, fmt, ap);
-        va_end(ap);
-        ctx->last_error = buf;
-    }
+    (void)ctx;
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    tls_last_error = buf;
     return code;
 }
 
@@ -156,7 +159,7 @@ RTEN_EXPORT int32_t rten_hip_destroy(rten_hip_ctx *ctx) {
     return RTEN_HIP_OK;
 }
 
-RTEN_EXPORT const char *rten_hip_last_error(rten_hip_ctx *ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+RTEN_EXPORT const char *rten_hip_last_error(rten_hip_ctx *ctx) { return ctx ? tls_last_error.c_str() : "null context"; }
 
 RTEN_EXPORT int32_t rten_hip_sync(rten_hip_ctx *ctx) {
     RTEN_CHECK_CTX(ctx);
@@ -253,6 +256,10 @@ RTEN_EXPORT int32_t rten_hip_graph_begin(rten_hip_ctx *ctx) {
     if (ctx->capturing) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "graph capture already active");
     RTEN_HIP_TRY(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
     ctx->capturing = true;
+    // the capturing thread keeps the context until rten_hip_graph_end: launches of other host threads must not be
+    // recorded into this graph (they block on the mutex instead)
+    ctx->mu.lock();
+    ctx->capture_locks++;
     return RTEN_HIP_OK;
 }
 
@@ -260,6 +267,7 @@ RTEN_EXPORT int32_t rten_hip_graph_end(rten_hip_ctx *ctx, uint64_t *out_graph) {
     RTEN_CHECK_CTX(ctx);
     if (!ctx->capturing || !out_graph) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "no active capture");
     ctx->capturing = false;
+    if (ctx->capture_locks > 0) { ctx->capture_locks--; ctx->mu.unlock(); } // the guard of this call still holds it
     hipGraph_t graph = nullptr;
     RTEN_HIP_TRY(ctx, hipStreamEndCapture(ctx->stream, &graph));
     hipGraphExec_t exec = nullptr;
@@ -274,10 +282,13 @@ RTEN_EXPORT int32_t rten_hip_graph_end(rten_hip_ctx *ctx, uint64_t *out_graph) {
 // after everything enqueued on `signaler` so far.  During graph capture this is how a second context joins (and
 // later re-joins) the capturing context's graph, giving parallel branches.
 RTEN_EXPORT int32_t rten_hip_stream_wait(rten_hip_ctx *waiter, rten_hip_ctx *signaler) {
-    RTEN_CHECK_CTX(waiter);
+    if (!waiter) return RTEN_HIP_ERR_INVALID_VALUE;
     if (!signaler || signaler->device != waiter->device)
         return rten_set_error(waiter, RTEN_HIP_ERR_INVALID_VALUE, "stream_wait: contexts must share a device");
     if (waiter == signaler) return RTEN_HIP_OK;
+    std::unique_lock<std::recursive_mutex> lk_w(waiter->mu, std::defer_lock), lk_s(signaler->mu, std::defer_lock);
+    std::lock(lk_w, lk_s); // both contexts' capture flags are touched below
+    rten_bind_device(waiter);
     if (waiter->sync_events.size() < 64) {
         hipEvent_t e = nullptr;
         RTEN_HIP_TRY(waiter, hipEventCreateWithFlags(&e, hipEventDisableTiming));

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_i8_kernel(const I8Args p) {
         const int ml = wm0 + (r & 3) + 8 * (r >> 2) + 4 * half;
         const int m = m0 + ml;
         if (m >= p.M) continue;
-        const unsigned az = (unsigned)zp_signed(p.a_zp, z * p.a_zp_bs + (p.a_zp_len == 1 ? 0 : m), p.a_signed);
+        const unsigned az = (unsigned)zp_signed(p.a_zp, z * p.a_zp_bs + (p.a_zp_len > 1 ? m % p.a_zp_len : 0), p.a_signed); // period < M: cycled zero points (matmul.rs:266-280)
         const unsigned v = (unsigned)acc[r] - bz * (unsigned)rsum[ml] - az * cs + (unsigned)p.K * az * bz;
         const long long off = ccol + (long long)m * p.c_rs;
         if (p.scale) {
@@ -261,21 +261,14 @@ int32_t launch_i8(rten_hip_ctx *ctx, I8Args &a, int Z) {
 
 } // namespace
 
-RTEN_EXPORT int32_t rten_hip_gemm_int8(rten_hip_ctx *ctx, const rten_hip_gemm_int8_desc *d, const void *a,
-                                       const void *b, const void *a_zp, const void *b_zp, const float *scale,
-                                       void *c) {
-    RTEN_CHECK_CTX(ctx);
-    if (!d) return RTEN_HIP_ERR_INVALID_VALUE;
-    if (d->m < 0 || d->n < 0 || d->k < 0) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "gemm_int8: negative dimension");
-    if (d->m == 0 || d->n == 0) return RTEN_HIP_OK;
-    if (!c || (d->k > 0 && (!a || !b))) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "gemm_int8: NULL operand");
-    if ((d->a_zp_len != 0 && d->a_zp_len != 1 && d->a_zp_len != d->m) || (d->b_zp_len != 0 && d->b_zp_len != 1 && d->b_zp_len != d->n))
-        return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "Zero point has incorrect size"); // matmul.rs:523
-    if (d->scale_len != 0 && d->scale_len != 1 && d->scale_len != d->n)
-        return rten_set_error(ctx, RTEN_HIP_ERR_INCOMPATIBLE_SHAPES, "Scale length does not match tensor columns");
-    if (ctx->int8_path == 0 && d->k > 0) {
+namespace {
+// One product of the (possibly batched) call.
+int32_t gemm_int8_one(rten_hip_ctx *ctx, const rten_hip_gemm_int8_desc *d, const void *a, const void *b, const void *a_zp, const void *b_zp,
+                      const float *scale, void *c) {
+    if ((ctx->int8_path == 0 || d->b_prepacked) && d->k > 0) {
         const int32_t rc = rten_i8_fast_gemm(ctx, d, a, b, a_zp, b_zp, scale, c);
         if (rc != RTEN_HIP_ERR_UNSUPPORTED) return rc;
+        if (d->b_prepacked) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "gemm_int8: prepacked RHS for a shape the staged kernel does not cover (packed_bytes == 0)");
     }
     I8Args g = {};
     g.A = (const uint8_t *)a; g.B = (const uint8_t *)b; g.C = c;
@@ -288,6 +281,36 @@ RTEN_EXPORT int32_t rten_hip_gemm_int8(rten_hip_ctx *ctx, const rten_hip_gemm_in
     g.a_signed = d->a_signed; g.b_signed = d->b_signed;
     g.a_zp_len = d->a_zp_len; g.b_zp_len = d->b_zp_len; g.scale_len = d->scale_len;
     return launch_i8(ctx, g, 1);
+}
+} // namespace
+
+RTEN_EXPORT int32_t rten_hip_gemm_int8(rten_hip_ctx *ctx, const rten_hip_gemm_int8_desc *d, const void *a,
+                                       const void *b, const void *a_zp, const void *b_zp, const float *scale,
+                                       void *c) {
+    RTEN_CHECK_CTX(ctx);
+    if (!d) return RTEN_HIP_ERR_INVALID_VALUE;
+    if (d->m < 0 || d->n < 0 || d->k < 0 || d->batch < 0) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "gemm_int8: negative dimension");
+    const int batch = d->batch <= 1 ? 1 : d->batch;
+    if (d->m == 0 || d->n == 0) return RTEN_HIP_OK;
+    if (!c || (d->k > 0 && (!a || !b))) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "gemm_int8: NULL operand");
+    // a_zp: scalar, per row, or a period dividing m (cycled zero points of a collapsed batched LHS, matmul.rs:266-280)
+    if ((d->a_zp_len < 0 || (d->a_zp_len > 1 && d->m % d->a_zp_len != 0)) || (d->b_zp_len != 0 && d->b_zp_len != 1 && d->b_zp_len != d->n))
+        return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "Zero point has incorrect size"); // matmul.rs:523
+    if ((d->a_zp_len && !a_zp) || (d->b_zp_len && !b_zp)) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "gemm_int8: zero point length set but pointer is NULL");
+    if (d->scale_len != 0 && d->scale_len != 1 && d->scale_len != d->n)
+        return rten_set_error(ctx, RTEN_HIP_ERR_INCOMPATIBLE_SHAPES, "Scale length does not match tensor columns");
+    if (d->scale_len && !scale) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "gemm_int8: scale_len set but scale is NULL");
+    if (d->b_prepacked && batch > 1 && d->b_bs != 0)
+        return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "gemm_int8: a prepacked RHS is a single matrix (b_bs must be 0)");
+    // batched_gemm_uninit (matmul.rs:302-372): independent products over the broadcast prefix, same quantization
+    // parameters for each; the staging buffers are reused in stream order.
+    const size_t csz = d->scale_len ? sizeof(float) : sizeof(int32_t);
+    for (int z = 0; z < batch; z++) {
+        const int32_t rc = gemm_int8_one(ctx, d, (const uint8_t *)a + (long long)z * d->a_bs, d->b_prepacked ? b : (const void *)((const uint8_t *)b + (long long)z * d->b_bs), a_zp, b_zp,
+                                         scale, (uint8_t *)c + (size_t)z * (size_t)d->c_bs * csz);
+        if (rc) return rc;
+    }
+    return RTEN_HIP_OK;
 }
 
 namespace {

@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p)
     if (t < BM) {
         const int m = m0 + t < p.M ? m0 + t : 0;
         rc_rsum = p.rsum[m];
-        rc_az = zp_signed(p.a_zp, p.a_zp_len == 1 ? 0 : m, p.a_signed);
+        rc_az = zp_signed(p.a_zp, p.a_zp_len > 1 ? m % p.a_zp_len : 0, p.a_signed); // GEMM: period < M cycles the zero points (matmul.rs:266-280)
         rc_bias = p.bias ? p.bias[m] : 0.f;
         rc_srow = (p.scale && p.scale_per_row) ? p.scale[m] : 0.f;
     }
@@ -602,33 +602,62 @@ int32_t dispatch_fast(rten_hip_ctx *ctx, FastArgs &a, double ops, double bytes) 
 
 } // namespace
 
+namespace {
+inline int gemm_kp(int k) { return (k + KT - 1) / KT * KT; }
+inline bool gemm_b_covered(int k, int n) { return k > 0 && n > 0 && (long long)n * gemm_kp(k) < (1ll << 31); }
+
+// rows of a strided u8 / i8 matrix -> chunk-major signed operand + row sums (both packers; see the kernels)
+void pack_rows(rten_hip_ctx *ctx, const void *src, long long row_stride, long long k_stride, int rows, int k, int Kp, unsigned flip, char *dst, char *sums) {
+    if (k_stride == 1) {
+        hipLaunchKernelGGL(i8_pack_rows_kernel, dim3((unsigned)rows), dim3(256), 0, ctx->stream, (const uint8_t *)src, row_stride, k_stride, k, k, 1, Kp, Kp, rows, flip,
+                           (uint8_t *)dst, (int *)sums);
+    } else {
+        hipMemsetAsync(sums, 0, (size_t)rows * 4, ctx->stream);
+        hipLaunchKernelGGL(i8_pack_rows_t_kernel, dim3((unsigned)((rows + 63) / 64), (unsigned)(Kp / 64)), dim3(256), 0, ctx->stream, (const uint8_t *)src, row_stride, k_stride,
+                           rows, k, Kp, flip, (uint8_t *)dst, (int *)sums);
+    }
+}
+} // namespace
+
+// Load-time staging of a constant MatMulInteger RHS (PackedBMatrix, rten-gemm/src/prepack.rs:19-120; packing/int8.rs:80-249
+// keeps the column sums inside the packed image, as here).  Layout: [Kp/16][n][16] signed bytes, then int32[n] column sums.
+RTEN_EXPORT size_t rten_hip_gemm_int8_packed_bytes(int32_t k, int32_t n) {
+    if (!gemm_b_covered(k, n)) return 0;
+    return up256((size_t)n * gemm_kp(k)) + up256((size_t)n * 4);
+}
+
+RTEN_EXPORT int32_t rten_hip_gemm_int8_prepack(rten_hip_ctx *ctx, int32_t k, int32_t n, const void *b, int64_t b_rs, int64_t b_cs, int32_t b_signed, void *packed) {
+    RTEN_CHECK_CTX(ctx);
+    if (!b || !packed) return RTEN_HIP_ERR_INVALID_VALUE;
+    if (!gemm_b_covered(k, n)) return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "gemm_int8 prepack: shape not covered by the staged kernel (packed_bytes == 0)");
+    if (b_rs < 0 || b_cs < 0) return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "gemm_int8 prepack: negative strides are not supported");
+    const int Kp = gemm_kp(k);
+    pack_rows(ctx, b, b_cs, b_rs, n, k, Kp, b_signed ? 0u : 0x80u, (char *)packed, (char *)packed + up256((size_t)n * Kp));
+    RTEN_LAUNCH_CHECK(ctx, "i8_pack_rows_kernel launch");
+    return RTEN_HIP_OK;
+}
+
 // Entry points used by int8.hip: return RTEN_HIP_ERR_UNSUPPORTED when the fast path does not cover the call
 // (the caller then falls back to the generic kernel).
 int32_t rten_i8_fast_gemm(rten_hip_ctx *ctx, const rten_hip_gemm_int8_desc *d, const void *a, const void *b, const void *a_zp,
                           const void *b_zp, const float *scale, void *c) {
-    const int Kp = (d->k + KT - 1) / KT * KT;
-    if (d->k <= 0 || (long long)d->m * Kp >= (1ll << 31) || (long long)d->n * Kp >= (1ll << 31) || (long long)d->m * d->ldc >= (1ll << 29))
+    const int Kp = gemm_kp(d->k);
+    if (d->k <= 0 || (long long)d->m * Kp >= (1ll << 31) || !gemm_b_covered(d->k, d->n) || (long long)d->m * d->ldc >= (1ll << 29))
         return RTEN_HIP_ERR_UNSUPPORTED;
+    // per call: the activation side (A) is staged; B too unless the caller prepacked it at load (MatMulInteger weights)
+    const size_t b_img = up256((size_t)d->n * Kp);
     const size_t offA = 4096, offRs = offA + up256((size_t)d->m * Kp), offB = offRs + up256((size_t)d->m * 4),
-                 offCs = offB + up256((size_t)d->n * Kp), total = offCs + up256((size_t)d->n * 4);
+                 offCs = offB + (d->b_prepacked ? 0 : b_img), total = offCs + (d->b_prepacked ? 0 : up256((size_t)d->n * 4));
     char *sc = (char *)rten_scratch(ctx, total);
     if (!sc) return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "int8 staging allocation failed (or attempted during graph capture)");
-    auto pack = [&](const void *src, long long row_stride, long long k_stride, int rows, unsigned flip, char *dst, char *sums) {
-        if (k_stride == 1) {
-            hipLaunchKernelGGL(i8_pack_rows_kernel, dim3((unsigned)rows), dim3(256), 0, ctx->stream, (const uint8_t *)src, row_stride, k_stride, d->k, d->k, 1,
-                               Kp, Kp, rows, flip, (uint8_t *)dst, (int *)sums);
-        } else {
-            hipMemsetAsync(sums, 0, (size_t)rows * 4, ctx->stream);
-            hipLaunchKernelGGL(i8_pack_rows_t_kernel, dim3((unsigned)((rows + 63) / 64), (unsigned)(Kp / 64)), dim3(256), 0, ctx->stream, (const uint8_t *)src,
-                               row_stride, k_stride, rows, d->k, Kp, flip, (uint8_t *)dst, (int *)sums);
-        }
-    };
-    pack(a, d->a_rs, d->a_cs, d->m, d->a_signed ? 0u : 0x80u, sc + offA, sc + offRs);
-    pack(b, d->b_cs, d->b_rs, d->n, d->b_signed ? 0u : 0x80u, sc + offB, sc + offCs);
+    pack_rows(ctx, a, d->a_rs, d->a_cs, d->m, d->k, Kp, d->a_signed ? 0u : 0x80u, sc + offA, sc + offRs);
+    if (!d->b_prepacked) pack_rows(ctx, b, d->b_cs, d->b_rs, d->n, d->k, Kp, d->b_signed ? 0u : 0x80u, sc + offB, sc + offCs);
     RTEN_LAUNCH_CHECK(ctx, "i8_pack_rows_kernel launch");
     FastArgs g = {};
-    g.A = (const uint8_t *)(sc + offA); g.B = (const uint8_t *)(sc + offB);
-    g.rsum = (const int *)(sc + offRs); g.csum = (const int *)(sc + offCs);
+    g.A = (const uint8_t *)(sc + offA);
+    g.B = d->b_prepacked ? (const uint8_t *)b : (const uint8_t *)(sc + offB);
+    g.rsum = (const int *)(sc + offRs);
+    g.csum = d->b_prepacked ? (const int *)((const char *)b + b_img) : (const int *)(sc + offCs);
     g.C = c;
     g.a_zp = d->a_zp_len ? (const uint8_t *)a_zp : nullptr;
     g.b_zp = d->b_zp_len ? (const uint8_t *)b_zp : nullptr;

@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -22,10 +23,13 @@ struct ProfEntry {
 };
 
 struct rten_hip_ctx {
+    // Serialises host-side entry into the context (rten_hip.h, "Thread safety"): every exported function takes it for
+    // the duration of the call; recursive because entry points call each other (conv -> gemm, graph capture holds it).
+    std::recursive_mutex mu;
+    int capture_locks = 0; // times rten_hip_graph_begin locked `mu` on behalf of the capturing thread
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    std::string last_error;
     hipEvent_t timers[64][2] = {};
     bool capturing = false;
     rten_hip_ctx *capture_origin = nullptr;  // set on contexts that joined another context's capture (stream_wait)
@@ -76,10 +80,18 @@ struct ProfScope {
     ~ProfScope();
 };
 
-#define RTEN_CHECK_CTX(ctx)                 \
-    do {                                    \
-        if (!(ctx)) return RTEN_HIP_ERR_INVALID_VALUE; \
-    } while (0)
+// Binds the context's device to the calling host thread (the current device is per thread in HIP: a second
+// Model::run thread starts on device 0).
+inline void rten_bind_device(const rten_hip_ctx *ctx) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != ctx->device) hipSetDevice(ctx->device);
+}
+
+// First statement of every entry point that takes a context: NULL check, lock for the whole call, device binding.
+#define RTEN_CHECK_CTX(ctx)                                                  \
+    if (!(ctx)) return RTEN_HIP_ERR_INVALID_VALUE;                           \
+    std::lock_guard<std::recursive_mutex> rten_ctx_guard_((ctx)->mu);        \
+    rten_bind_device(ctx)
 
 #define RTEN_HIP_TRY(ctx, expr)                                  \
     do {                                                         \

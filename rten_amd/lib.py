@@ -63,7 +63,9 @@ class GemmInt8Desc(C.Structure):
     _fields_ = [("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32),
                 ("a_rs", C.c_int64), ("a_cs", C.c_int64), ("b_rs", C.c_int64), ("b_cs", C.c_int64),
                 ("ldc", C.c_int64), ("a_signed", C.c_int32), ("b_signed", C.c_int32),
-                ("a_zp_len", C.c_int32), ("b_zp_len", C.c_int32), ("scale_len", C.c_int32)]
+                ("a_zp_len", C.c_int32), ("b_zp_len", C.c_int32), ("scale_len", C.c_int32),
+                ("batch", C.c_int32), ("a_bs", C.c_int64), ("b_bs", C.c_int64), ("c_bs", C.c_int64),
+                ("b_prepacked", C.c_int32)]
 
 
 class Conv2dDesc(C.Structure):
@@ -115,6 +117,13 @@ PROTOTYPES = {
                                                                  C.POINTER(_I32), C.POINTER(C.c_char_p)]),
     "rten_hip_gemm_f32": (_I32, [_VP, C.POINTER(GemmDesc), _VP, _VP, _VP, _VP]),
     "rten_hip_gemm_int8": (_I32, [_VP, C.POINTER(GemmInt8Desc), _VP, _VP, _VP, _VP, _VP, _VP]),
+    "rten_hip_gemm_int8_packed_bytes": (_SZ, [_I32, _I32]),
+    "rten_hip_gemm_int8_prepack": (_I32, [_VP, _I32, _I32, _VP, _I64, _I64, _I32, _VP]),
+    "rten_hip_comm_get_unique_id": (_I32, [_VP, _VP]),
+    "rten_hip_comm_init_rank": (_I32, [_VP, _VP, _I32, _I32, C.POINTER(_VP)]),
+    "rten_hip_broadcast": (_I32, [_VP, _VP, _VP, _SZ, _I32]),
+    "rten_hip_comm_world_size": (_I32, [_VP, C.POINTER(_I32), C.POINTER(_I32)]),
+    "rten_hip_comm_destroy": (_I32, [_VP, _VP]),
     "rten_hip_conv2d_f32_packed_bytes": (_SZ, [C.POINTER(Conv2dDesc)]),
     "rten_hip_conv2d_f32_prepack": (_I32, [_VP, C.POINTER(Conv2dDesc), _VP, _VP]),
     "rten_hip_conv2d_f32": (_I32, [_VP, C.POINTER(Conv2dDesc), _VP, _VP, _I32, _VP, _VP, _U32, _VP]),
@@ -298,3 +307,41 @@ class Context:
 
     def set_gemm_variant(self, v: int):
         self.call("rten_hip_set_gemm_variant_override", v)
+
+
+class Comm:
+    """RAII wrapper of rten_hip_comm (RCCL behind the C ABI): the weight-arena broadcast of a batch-sharded deployment.
+    `unique_id()` on rank 0, hand the 128 bytes to the other ranks by any host channel, then `Comm(ctx, id, world, rank)`."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id(ctx: Context) -> bytes:
+        buf = (C.c_uint8 * Comm.ID_BYTES)()
+        ctx.call("rten_hip_comm_get_unique_id", buf)
+        return bytes(buf)
+
+    def __init__(self, ctx: Context, uid: bytes, world_size: int, rank: int):
+        if len(uid) != Comm.ID_BYTES:
+            raise ValueError("communicator id must be 128 bytes")
+        self.ctx = ctx
+        h = C.c_void_p()
+        buf = (C.c_uint8 * Comm.ID_BYTES).from_buffer_copy(uid)
+        ctx.call("rten_hip_comm_init_rank", buf, world_size, rank, C.byref(h))
+        self.h = h
+        self.world_size, self.rank = world_size, rank
+
+    def broadcast(self, dptr: int, nbytes: int, root: int = 0):
+        """In-place broadcast of a device buffer on the context's stream."""
+        self.ctx.call("rten_hip_broadcast", self.h, C.c_void_p(dptr), C.c_size_t(nbytes), root)
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
+            self.ctx.call("rten_hip_comm_destroy", self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -468,33 +468,71 @@ def _zp_len(zp, expected, what):
     raise UnsupportedValue("Only scalar or vector zero points are supported")
 
 
+def _broadcast_prefix(a_prefix, b_prefix):
+    """broadcast_shapes (rten-tensor) of two batch prefixes; None when they do not broadcast."""
+    n = max(len(a_prefix), len(b_prefix))
+    ap = [1] * (n - len(a_prefix)) + list(a_prefix)
+    bp = [1] * (n - len(b_prefix)) + list(b_prefix)
+    out = []
+    for x, y in zip(ap, bp):
+        if x != y and x != 1 and y != 1:
+            return None
+        out.append(max(x, y) if min(x, y) != 0 else 0)
+    return out, ap, bp
+
+
 class MatMulInteger(Operator):
-    """src/ops/matmul.rs:649-700.  inputs: A u8|i8 [M,K], B i8|u8 [K,N], a_zero_point?, b_zero_point?"""
+    """src/ops/matmul.rs:582-700 (matmul_integer -> matmul_impl :208-385).  inputs: A u8|i8 [..., M, K], B i8|u8 [..., K, N],
+    a_zero_point? (scalar or [M]), b_zero_point? (scalar or [N]).  All of matmul_impl's forms: vector operands, the
+    `[A.., M, K] x [K, N]` collapse with the row zero points cycled (:266-280), and batched / broadcast prefixes
+    (batched_gemm_uninit, :302-372).  `packed_b`: the RHS staged at load by `prepack` (Operator::prepack, :696-705)."""
 
     def max_inputs(self):
         return 4
 
-    def run(self, ctx, inputs, scale=None):
+    def prepack_inputs(self):
+        return [1]
+
+    def prepack(self, ctx, b):
+        """Stage a constant 2-D RHS once (PackedBMatrix).  Returns None when the staged kernel does not cover the shape."""
+        if b.dtype not in (np.uint8, np.int8) or len(b.shape) != 2:
+            return None
+        k, n = b.shape
+        nbytes = ctx.lib.rten_hip_gemm_int8_packed_bytes(k, n)
+        if not nbytes:
+            return None
+        packed = DeviceTensor(ctx, [nbytes], np.uint8)
+        ctx.call("rten_hip_gemm_int8_prepack", k, n, b.vp, n, 1, 1 if b.dtype == np.int8 else 0, packed.vp)
+        packed.packed_for = (k, n, b.dtype)
+        return packed
+
+    def run(self, ctx, inputs, scale=None, packed_b=None):
         a = _require(inputs, 0)
         b = _require(inputs, 1)
         if a.dtype not in (np.uint8, np.int8) or b.dtype not in (np.uint8, np.int8):
             raise UnsupportedType
         a_zp, b_zp = _get(inputs, 2), _get(inputs, 3)
         ash, bsh = list(a.shape), list(b.shape)
+        a_rows = ash[-2] if len(ash) > 1 else 1  # matmul_integer, matmul.rs:598-607
+        b_cols = bsh[-1] if len(bsh) > 1 else 1
+        azl = _zp_len(a_zp, a_rows, "a")
+        bzl = _zp_len(b_zp, b_cols, "b")
         if len(ash) < 1 or len(bsh) < 1:
             raise InvalidValue("Inputs must have >= 1 dimensions")
-        if len(bsh) != 2:
-            raise UnsupportedValue("batched RHS is not supported by the device int8 path")
-        rows = ash[-2] if len(ash) > 1 else 1
-        k = ash[-1]
-        kb, n = bsh
-        azl = _zp_len(a_zp, rows, "a")
-        bzl = _zp_len(b_zp, n, "b")
+        a_is_vec, b_is_vec = len(ash) == 1, len(bsh) == 1  # numpy.matmul rules (matmul.rs:232-240)
+        if a_is_vec:
+            ash = [1] + ash
+        if b_is_vec:
+            bsh = bsh + [1]
+        m, k = ash[-2], ash[-1]
+        kb, n = bsh[-2], bsh[-1]
         if k != kb:
             raise IncompatibleInputShapes("Columns of first matrix does not match rows of second matrix")
-        m_total = int(np.prod(ash[:-1], dtype=np.int64)) if len(ash) > 1 else 1
-        if azl > 1 and m_total != rows:
-            raise UnsupportedValue("per-row zero point with batched LHS is not supported by the device path")
+        bc = _broadcast_prefix(ash[:-2], bsh[:-2])
+        if bc is None:
+            raise IncompatibleInputShapes("Cannot broadcast shapes")
+        out_prefix, ap, bp = bc
+        out_shape = out_prefix + [m, n]
         sl = 0
         if scale is not None:
             if len(scale.shape) > 1:
@@ -502,11 +540,43 @@ class MatMulInteger(Operator):
             sl = 1 if scale.size == 1 else scale.size
             if sl > 1 and sl != n:
                 raise IncompatibleInputShapes("Scale length does not match tensor columns")
-        out_shape = (ash[:-1] if len(ash) > 1 else []) + [n]
-        y = DeviceTensor(ctx, out_shape, np.float32 if scale is not None else np.int32)
-        d = L.GemmInt8Desc(m_total, n, k, k, 1, n, 1, n, 1 if a.dtype == np.int8 else 0, 1 if b.dtype == np.int8 else 0,
-                           azl, bzl, sl)
-        ctx.call("rten_hip_gemm_int8", C.byref(d), a.vp, b.vp, _vp(a_zp), _vp(b_zp), _vp(scale), y.vp)
+        final_shape = list(out_shape)
+        if a_is_vec:
+            del final_shape[-2]
+        if b_is_vec:
+            del final_shape[-1]
+        y = DeviceTensor(ctx, final_shape, np.float32 if scale is not None else np.int32)
+        if y.size == 0:
+            return [y]
+        num_a = int(np.prod(ash[:-2], dtype=np.int64))
+        num_b = int(np.prod(bsh[:-2], dtype=np.int64))
+        a_s, b_s = 1 if a.dtype == np.int8 else 0, 1 if b.dtype == np.int8 else 0
+        use_packed = packed_b is not None and num_b == 1 and getattr(packed_b, "packed_for", None) == (k, n, b.dtype)
+        bptr = packed_b.vp if use_packed else b.vp
+
+        def call(mm, a_zp_len, batch, a_bs, b_bs, c_bs, a_off=0, b_off=0, c_off=0):
+            d = L.GemmInt8Desc(mm, n, k, k, 1, n, 1, n, a_s, b_s, a_zp_len, bzl, sl, batch, a_bs, b_bs, c_bs, 1 if use_packed else 0)
+            itm = y.dtype.itemsize
+            ctx.call("rten_hip_gemm_int8", C.byref(d), C.c_void_p(a.ptr + a_off), bptr if use_packed else C.c_void_p(b.ptr + b_off),
+                     _vp(a_zp), _vp(b_zp), _vp(scale), C.c_void_p(y.ptr + c_off * itm))
+
+        if num_b == 1:
+            # [A.., M, K] x [K, N] as one [A*M, K] x [K, N] product; row r uses a_zp[r % M] (matmul.rs:259-296)
+            call(num_a * m, azl, 1, 0, 0, 0)
+            return [y]
+        # batched products over the broadcast prefix (matmul.rs:302-372)
+        nb = int(np.prod(out_prefix, dtype=np.int64))
+        if num_a == 1 or ap == out_prefix:
+            a_mat = 0 if num_a == 1 else m * k
+            if num_b == 1 or bp == out_prefix:
+                call(m, azl, nb, a_mat, 0 if num_b == 1 else k * n, m * n)
+                return [y]
+        # general broadcast: one product per output matrix
+        a_str = np.array([0 if d == 1 else int(np.prod(ap[i + 1:], dtype=np.int64)) for i, d in enumerate(ap)], np.int64)
+        b_str = np.array([0 if d == 1 else int(np.prod(bp[i + 1:], dtype=np.int64)) for i, d in enumerate(bp)], np.int64)
+        for z, idx in enumerate(np.ndindex(*out_prefix)):
+            ia, ib = int(np.dot(idx, a_str)), int(np.dot(idx, b_str))
+            call(m, azl, 1, 0, 0, 0, a_off=ia * m * k, b_off=ib * k * n, c_off=z * m * n)
         return [y]
 
 
@@ -519,9 +589,15 @@ class MatMulIntegerToFloat(Operator):
     def max_inputs(self):
         return 5
 
-    def run(self, ctx, inputs):
+    def prepack_inputs(self):
+        return [1]
+
+    def prepack(self, ctx, b):
+        return self.matmul.prepack(ctx, b)
+
+    def run(self, ctx, inputs, packed_b=None):
         scale = _want(_require(inputs, 4), np.float32)
-        return self.matmul.run(ctx, inputs[:4], scale=scale)
+        return self.matmul.run(ctx, inputs[:4], scale=scale, packed_b=packed_b)
 
 
 class MatMulNBits(Operator):

@@ -159,6 +159,7 @@ int main(int argc, char **argv) {
             if (gv != given.end()) {
                 const safetensors::Entry &e = gv->second;
                 if (e.dtype == "I64" && esz == 4 && !is_f32) { // int64 inputs are narrowed to int32, as the reference does at load
+                    if (e.data.size() != (size_t)n * 8) throw GraphError("input " + in.name + ": Safetensors entry holds " + std::to_string(e.data.size()) + " bytes, the model input needs " + std::to_string(n * 8));
                     for (int64_t i = 0; i < n; i++) { int64_t v; std::memcpy(&v, e.data.data() + 8 * i, 8); const int32_t x = (int32_t)v; std::memcpy(host.data() + 4 * i, &x, 4); }
                 } else if (e.data.size() == host.size() && ((is_f32 && e.dtype == "F32") || (!is_f32 && e.dtype != "F32"))) {
                     std::memcpy(host.data(), e.data.data(), host.size());
@@ -260,15 +261,19 @@ int main(int argc, char **argv) {
                 if (got.dtype != ex->second.dtype) { std::printf("  Output \"%s\" dtype %s does not match expected %s\n", name.c_str(), got.dtype.c_str(), ex->second.dtype.c_str()); check_failed = true; continue; }
                 if (got.dtype != "F32") { std::fprintf(stderr, "  Unable to compare outputs. Unsupported tensor types.\n"); continue; }
                 float max_diff = 0.f;
-                size_t bit_diffs = 0;
+                size_t bit_diffs = 0, nan_diffs = 0; // a NaN on one side only (or NaNs that differ in their bits) is sticky: it fails the gate
                 const float *a = (const float *)got.data.data(), *b = (const float *)ex->second.data.data();
                 for (int64_t k = 0; k < got.len(); k++) {
+                    const bool same_bits = std::memcmp(a + k, b + k, 4) == 0;
+                    bit_diffs += !same_bits;
+                    if (same_bits) continue; // identical bits (NaNs included) are equal
                     const float d = std::fabs(a[k] - b[k]);
-                    if (!(d <= max_diff)) max_diff = d; // NaN differences propagate
-                    bit_diffs += std::memcmp(a + k, b + k, 4) != 0;
+                    if (std::isnan(d)) nan_diffs++;
+                    else max_diff = std::max(max_diff, d);
                 }
-                std::printf("  Output \"%s\" vs expected: max diff %.6f (%zu of %lld elements differ in their bits)\n", name.c_str(), max_diff, bit_diffs, (long long)got.len());
-                if (max_diff_allowed >= 0 && !(max_diff <= max_diff_allowed)) check_failed = true;
+                std::printf("  Output \"%s\" vs expected: max diff %.6f (%zu of %lld elements differ in their bits%s)\n", name.c_str(), max_diff, bit_diffs, (long long)got.len(),
+                            nan_diffs ? (", " + std::to_string(nan_diffs) + " NaN mismatches").c_str() : "");
+                if (max_diff_allowed >= 0 && (nan_diffs || !(max_diff <= max_diff_allowed))) check_failed = true;
             }
         }
         return check_failed && max_diff_allowed >= 0 ? 3 : 0;
