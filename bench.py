@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- ResNet-50 f32, batch 32 per GPU, on the HIP backend (BASELINE.json configs[1]).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config f32|int8]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+`--gpus N` always means N ranks, one per GPU: without a launcher the script spawns them itself (torch.distributed.run);
+under a launcher it refuses to run when WORLD_SIZE != N.  `--config int8` runs the dynamically quantized graph
+(BASELINE configs[2]; with --gpus 8: configs[4]) with its own roofline / cpu_baseline objects.
 
 A step = one forward pass of ResNet-50 (53 convs + maxpool + global-avg-pool + fc) over one batch of
 32 synthetic 224x224 images that is already resident in HBM.  One process per GPU; batches are
@@ -29,6 +33,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 F32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X v_mfma_f32_32x32x2_f32 peak (MI355X_MICROARCH.md)
+I8_MATRIX_PEAK_TOPS = 5033.0    # dense i8 MFMA: 2x the bf16 rate (MI355X_MICROARCH.md, "Matrix cores")
+HBM_PEAK_GBS = 8000.0           # HBM3E spec (6.29 TB/s measured with a float4 copy)
 BATCH_PER_GPU = 32
 
 
@@ -114,18 +120,74 @@ def cpu_op_baselines():
     return out
 
 
+def cpu_baseline_int8(specs, weights, budget_s=12.0):
+    """cpu_baseline leg of --config int8: the CPU oracle's dynamically quantized ResNet-50 (port of the reference algorithm:
+    DynamicQuantizeLinear -> ConvInteger -> cast_scale -> Add [-> Add] [-> Relu] per conv) on a bounded sample."""
+    from oracle import models as omodels
+    from oracle import ref
+    threads = ref.num_threads()
+    q = omodels.quantize_weights_int8(weights)
+    x = ref.XorShiftRng(7).f32(2 * 3 * 224 * 224).reshape(2, 3, 224, 224)
+    t0 = time.perf_counter()
+    omodels.resnet50_int8_forward(specs, q, x)
+    t_first = time.perf_counter() - t0
+    reps = int(max(1, min(16, budget_s / max(t_first, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        omodels.resnet50_int8_forward(specs, q, x)
+    dt = time.perf_counter() - t0
+    imgs = 2 * reps
+    return {"value": round(imgs / dt, 3), "unit": "inferences/s", "cores": threads, "kind": "port",
+            "sample": f"{imgs} images (batch 2 x {reps} forward passes) of the same dynamically quantized ResNet-50 graph through oracle/rten_oracle.c "
+                      f"({threads} OpenMP threads, {dt:.1f} s)"}
+
+
+def int8_algorithmic_bytes(net):
+    """HBM bytes one forward pass of the dynamically quantized graph must move, per DESIGN.md section 7 / SURVEY 8(d): every
+    conv output is an f32 tensor of the graph (4 B write), its consumer's DynamicQuantizeLinear reads it (4 B; one
+    quantization per distinct tensor) and writes u8 codes (1 B), every conv reads those codes once (1 B) plus its weights,
+    a residual Add reads 4 B.  The min/max sweep of DynamicQuantizeLinear is NOT counted (the producer's epilogue
+    accumulates it), nor are the staged image's padding bytes: this is the floor, not what the kernels happen to move."""
+    total, quantized = 0.0, set()
+    for l in net.specs:
+        d = net.descs[l["name"]]
+        in_elems = d.n * d.c * d.h * d.w
+        out_elems = d.n * d.o * d.out_h * d.out_w
+        if l["src"] not in quantized:
+            quantized.add(l["src"])
+            total += 5.0 * in_elems          # quantize: f32 read + u8 write
+        total += 1.0 * in_elems              # conv reads the codes
+        total += d.o * d.c * d.kh * d.kw     # i8 weights
+        total += 4.0 * out_elems             # f32 output
+        if l["res"]:
+            total += 4.0 * out_elems         # residual read
+    p = net.pool_desc
+    total += 4.0 * p.n * p.c * (p.h * p.w + p.out_h * p.out_w)      # MaxPool
+    last = net.shapes[net.specs[-1]["dst"]]
+    total += 4.0 * last[0] * last[1] * (last[2] * last[3] + 1)      # GlobalAveragePool
+    total += 2048.0 * net.num_classes + 8.0 * last[0] * net.num_classes + 9.0 * last[0] * 2048  # classifier
+    return total
+
+
 def secondary_configs():
-    """The other single-GPU configs of BASELINE.json, measured by their own harnesses in child processes after the headline
-    run (same backend, same box): reported for the record, never part of `value`.  A failure is recorded, not raised."""
+    """The other single-GPU configs of BASELINE.json, measured in child processes after the headline run (same backend, same
+    box): reported for the record, never part of `value`.  The int8 ResNet-50 (configs[2], named in BASELINE's metric) is a
+    full bench line of its own -- `python bench.py --config int8` -- with its roofline and cpu_baseline objects."""
     import subprocess
     root = os.path.dirname(os.path.abspath(__file__))
     res = {}
-    for key, script in (("resnet50_int8_b32", "bench_resnet50_int8.py"), ("bert_base_f32_b32_s128", "bench_bert.py"),
-                        ("resnet50_f32_b1_latency", "bench_resnet50_b1.py")):
+    jobs = (("resnet50_int8_b32", [os.path.join(root, "bench.py"), "--config", "int8", "--no-secondary"]),
+            ("bert_base_f32_b32_s128", [os.path.join(root, "tools", "bench_bert.py")]),
+            ("resnet50_f32_b1_latency", [os.path.join(root, "tools", "bench_resnet50_b1.py")]))
+    for key, cmd in jobs:
         try:
-            p = subprocess.run([sys.executable, os.path.join(root, "tools", script)], capture_output=True, text=True, timeout=420, cwd=root)
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+            p = subprocess.run([sys.executable] + cmd, capture_output=True, text=True, timeout=420, cwd=root, env=env)
             line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
             j = json.loads(line)
+            if key == "resnet50_int8_b32":
+                res[key] = {k: j[k] for k in ("metric", "value", "unit", "ms_per_step", "p50_latency_ms", "dtype", "config", "roofline", "cpu_baseline") if k in j}
+                continue
             res[key] = {k: j[k] for k in ("metric", "value", "unit", "ms_per_step", "p50_latency_ms", "ms_per_step_back_to_back", "dtype") if k in j}
             if key.startswith("bert") and "roofline" in j:
                 res[key]["gemm_family_tflops"] = j["roofline"].get("achieved")
@@ -135,11 +197,28 @@ def secondary_configs():
     return res
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` started without a launcher: re-exec under torch.distributed.run, one rank per GPU (the
+    form the driver uses itself), and hand back its exit code.  Rank 0's JSON line goes to our stdout unchanged."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", choices=("f32", "int8"), default="f32",
+                    help="f32: ResNet-50 f32 batch 32 per GPU (BASELINE configs[1], the headline); int8: the dynamically quantized graph "
+                         "(configs[2]; with --gpus 8 = configs[4], 8 x 32 images, weights RCCL-broadcast)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -150,12 +229,25 @@ def main():
     ap.add_argument("--concurrent", action="store_true", help="run the projection shortcuts on a second stream (parallel graph branches)")
     args = ap.parse_args()
 
+    # ---- launch contract: N ranks, one per GPU.  Under a launcher (the driver's torch.distributed.run) WORLD_SIZE must
+    # equal --gpus; without one, --gpus N > 1 spawns the ranks itself.  A single process never reports N GPUs.
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        return 2
+    under_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if not under_launcher and args.gpus > 1:
+        return spawn_ranks(args.gpus, sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to report a number for GPUs that are not running",
+              file=sys.stderr)
+        return 2
     n_gpus = args.gpus
     dist = None
     import torch
+    backend = "none"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -173,27 +265,45 @@ def main():
         torch.cuda.set_device(local_rank)
 
     from rten_amd import lib
-    from rten_amd.workloads import resnet50
+    from rten_amd.workloads import resnet50, resnet50_int8
     from rten_amd.sharding import broadcast_weight_arena
 
     ctx = lib.Context(local_rank)  # no CPU fallback: raises if the HIP extension / MI355X is missing
     weights = resnet50.make_weights()
-    # weight arena lives in a torch allocation so RCCL can broadcast it
-    net = None
-    arena_t = None
+    int8 = args.config == "int8"
+
+    def build(**kw):
+        if int8:
+            return resnet50_int8.ResNet50Int8(ctx, BATCH_PER_GPU, weights, **kw)
+        return resnet50.ResNet50(ctx, BATCH_PER_GPU, weights, **kw)
+
+    comm_world = 1
     if world > 1:
-        tmp = resnet50.ResNet50(ctx, BATCH_PER_GPU, weights)
-        nbytes = tmp.arena_bytes
-        del tmp
+        # The weight arena (prepacked conv weights + biases + classifier; f32: 102 MB) is staged ONCE, by rank 0, and broadcast:
+        # through the backend's own communicator (rten_hip_comm_* = RCCL behind the C ABI, what a Rust host would call) on
+        # the context's stream.  Under RTEN_DIST_BACKEND=gloo (several ranks on one GPU) torch.distributed carries it.
+        probe = build()
+        nbytes = probe.i8_arena_bytes if int8 else probe.arena_bytes
+        del probe
         arena_t = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{local_rank}")
-        net = resnet50.ResNet50(ctx, BATCH_PER_GPU, weights, arena_ptr=arena_t.data_ptr(), arena_keepalive=arena_t)
+        net = build(i8_arena_ptr=arena_t.data_ptr(), i8_arena_keepalive=arena_t) if int8 else build(arena_ptr=arena_t.data_ptr(), arena_keepalive=arena_t)
         if rank == 0:
             net.upload_weights()
         ctx.sync()
-        broadcast_weight_arena(arena_t, src=0)  # RCCL over xGMI, once
+        if backend == "nccl":
+            uid = [lib.Comm.unique_id(ctx) if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            comm = lib.Comm(ctx, uid[0], world, rank)
+            comm.broadcast(arena_t.data_ptr(), nbytes, root=0)  # RCCL over xGMI, once
+            ctx.sync()
+            comm_world = comm.world_size
+            comm.close()
+        else:
+            broadcast_weight_arena(arena_t, src=0)
+            comm_world = dist.get_world_size()
         torch.cuda.synchronize()
     else:
-        net = resnet50.ResNet50(ctx, BATCH_PER_GPU, weights)
+        net = build()
         net.upload_weights()
 
     # each rank gets its own (independent) synthetic batch, resident in HBM before timing starts
@@ -210,7 +320,7 @@ def main():
         table = net.autotune(reps=3)
         if args.save_plan and rank == 0:
             json.dump({k: list(v) for k, v in net.variants.items()}, open(args.save_plan, "w"))
-        if args.layer_table and rank == 0:
+        if args.layer_table and rank == 0 and table:
             for l in net.specs:
                 d = net.descs[l["name"]]
                 fl = 2.0 * d.o * d.c * d.kh * d.kw * d.out_h * d.out_w * d.n
@@ -241,8 +351,14 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
+    per_rank_ms = [round(elapsed / args.steps * 1e3, 4)]
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dev = f"cuda:{local_rank}" if backend == "nccl" else "cpu"
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        allt = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allt, mine)
+        per_rank_ms = [round(float(t.item()) / args.steps * 1e3, 4) for t in allt]
+        t = mine.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -254,6 +370,17 @@ def main():
         ctx.sync()
         lat.append((time.perf_counter() - t1) * 1e3)
     p50 = float(np.median(lat))
+
+    # ---- PCIe-inclusive rate (the reference's Model::run takes host tensors): the same K steps with the batch uploaded
+    #      from host memory and the logits downloaded every step.  Reported beside `value`, never as `value`.
+    pcie_ms = None
+    if rank == 0:
+        t1 = time.perf_counter()
+        for _ in range(min(args.steps, 20)):
+            net.x.upload(x)
+            net.run()
+            net.logits.numpy()
+        pcie_ms = (time.perf_counter() - t1) / min(args.steps, 20) * 1e3
 
     # ---- roofline of the dominant kernel: instrumented eager pass over the same K steps (HIP events per launch
     #      on the backend's stream).  Kept out of the timed region so `value` is not perturbed.
@@ -269,62 +396,109 @@ def main():
         ctx.profile(False)
         net.graph, net.concurrent = saved_graph, saved_conc
         rep = ctx.profile_report()
-        conv = [r for r in rep if r["kernel"].startswith("igemm_f32")]
         tot_ms = sum(r["ms"] for r in rep)
-        if conv:
-            dom = max(conv, key=lambda r: r["ms"])
-            fam_ms = sum(r["ms"] for r in conv)
-            fam_fl = sum(r["flops"] for r in conv)
-            roof = {"bound": "mfma", "kernel": dom["kernel"],
-                    "achieved": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12, 3), "peak": F32_MATRIX_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12 / F32_MATRIX_PEAK_TFLOPS, 4),
-                    "traffic": None, "traffic_source": None,
-                    "avg_launch_us": round(dom["ms"] * 1e3 / max(dom["launches"], 1), 2), "launches": dom["launches"],
-                    "flops_per_launch": dom["flops"] / max(dom["launches"], 1),
-                    "kernel_share_of_step": round(dom["ms"] / max(tot_ms, 1e-9), 4),
-                    "igemm_family": {"achieved": round(fam_fl / (fam_ms * 1e-3) / 1e12, 3),
-                                     "frac": round(fam_fl / (fam_ms * 1e-3) / 1e12 / F32_MATRIX_PEAK_TFLOPS, 4),
-                                     "share_of_step": round(fam_ms / max(tot_ms, 1e-9), 4),
-                                     "variants": {r["kernel"]: {"launches": r["launches"], "ms": round(r["ms"], 4),
-                                                                "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2)} for r in conv}}}
+        if int8:
+            conv = [r for r in rep if r["kernel"].startswith("igemm_i8")]
+            if conv:
+                dom = max(conv, key=lambda r: r["ms"])
+                fam_ms, fam_ops = sum(r["ms"] for r in conv), sum(r["flops"] for r in conv)
+                alg = int8_algorithmic_bytes(net)
+                step_ms = elapsed / args.steps * 1e3
+                gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+                roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
+                        "avg_launch_us": round(dom["ms"] * 1e3 / max(dom["launches"], 1), 2), "launches": dom["launches"],
+                        "bytes_per_launch": dom["bytes"] / max(dom["launches"], 1),
+                        "kernel_share_of_step": round(dom["ms"] / max(tot_ms, 1e-9), 4),
+                        "mfma": {"achieved": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12, 2), "peak": I8_MATRIX_PEAK_TOPS, "unit": "TOP/s",
+                                 "frac": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12 / I8_MATRIX_PEAK_TOPS, 4)},
+                        "step": {"algorithmic_bytes": alg, "achieved": round(alg / (step_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(alg / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "note": "whole forward pass against the graph's HBM floor (DESIGN.md section 7)"},
+                        "igemm_i8_family": {"achieved": round(fam_ops / (fam_ms * 1e-3) / 1e12, 2), "unit": "TOP/s",
+                                            "frac_of_i8_mfma_peak": round(fam_ops / (fam_ms * 1e-3) / 1e12 / I8_MATRIX_PEAK_TOPS, 4),
+                                            "share_of_step": round(fam_ms / max(tot_ms, 1e-9), 4),
+                                            "variants": {r["kernel"]: {"launches": r["launches"], "ms": round(r["ms"], 4),
+                                                                       "tops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2),
+                                                                       "gbs": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)} for r in conv}},
+                        "other_kernels": {r["kernel"]: {"launches": r["launches"], "ms": round(r["ms"], 4), "gbs": round(r["bytes"] / max(r["ms"] * 1e-3, 1e-12) / 1e9, 1)}
+                                          for r in rep if not r["kernel"].startswith("igemm_i8")}}
+        else:
+            conv = [r for r in rep if r["kernel"].startswith("igemm_f32")]
+            if conv:
+                dom = max(conv, key=lambda r: r["ms"])
+                fam_ms = sum(r["ms"] for r in conv)
+                fam_fl = sum(r["flops"] for r in conv)
+                roof = {"bound": "mfma", "kernel": dom["kernel"],
+                        "achieved": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12, 3), "peak": F32_MATRIX_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12 / F32_MATRIX_PEAK_TFLOPS, 4),
+                        "traffic": None, "traffic_source": None,
+                        "avg_launch_us": round(dom["ms"] * 1e3 / max(dom["launches"], 1), 2), "launches": dom["launches"],
+                        "flops_per_launch": dom["flops"] / max(dom["launches"], 1),
+                        "kernel_share_of_step": round(dom["ms"] / max(tot_ms, 1e-9), 4),
+                        "igemm_family": {"achieved": round(fam_fl / (fam_ms * 1e-3) / 1e12, 3),
+                                         "frac": round(fam_fl / (fam_ms * 1e-3) / 1e12 / F32_MATRIX_PEAK_TFLOPS, 4),
+                                         "share_of_step": round(fam_ms / max(tot_ms, 1e-9), 4),
+                                         "variants": {r["kernel"]: {"launches": r["launches"], "ms": round(r["ms"], 4),
+                                                                    "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2)} for r in conv}}}
 
     if rank == 0 and roof:
-        # HBM bytes per launch of the dominant kernel from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, collected separately by
-        # tools/gpu/traffic.sh over the same tuned plan -- counters cannot be collected inside the timed run)
+        # HBM bytes per launch of the dominant kernel from a SEPARATE PMC pass (FETCH_SIZE x2 + WRITE_SIZE, tools/gpu/traffic.sh:
+        # counters cannot be collected inside the timed run).  The figure belongs to the plan that pass ran under, named in
+        # `traffic_source` / `traffic_note`; it is null when no committed pass covers this kernel instantiation.
         import glob
-        for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*", "hbm_traffic_per_kernel.json")), reverse=True):
+        fname = "int8_hbm_traffic_per_kernel.json" if int8 else "hbm_traffic_per_kernel.json"
+        for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*", fname)), reverse=True):
             t = json.load(open(path)).get("kernels", {}).get(roof["kernel"].replace(" ", ""))
             if t:
                 roof["traffic"] = t["hbm_read_bytes_per_launch"] + t["hbm_write_bytes_per_launch"]
                 roof["traffic_source"] = os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))
+                roof["traffic_note"] = "measured in a separate rocprofv3 --pmc pass over that profile's tuned plan, not in this run (autotune draws differ)"
                 break
     if rank == 0:
         global_batch = BATCH_PER_GPU * n_gpus
         value = global_batch * args.steps / elapsed
+        if int8:
+            metric = "inferences/sec, ResNet-50 int8 (dynamically quantized) batch 32 per GPU"
+            workload = ("ResNet-50 v1.5 dynamically quantized int8 inference (DynamicQuantizeLinear -> ConvIntegerToFloat per conv, 7-bit per-tensor weights as "
+                        "tools/ort-quantize.py writes them), 224x224, batch 32 per GPU (BASELINE configs[2]; x8 GPUs = configs[4]); synthetic He-normal "
+                        "BN-folded weights (seed 1234), inputs U[0,1) resident in HBM")
+            flop = "gop_per_image"
+        else:
+            metric = "inferences/sec, ResNet-50 f32 batch 32 per GPU"
+            workload = ("ResNet-50 v1.5 f32 inference, 224x224, batch 32 per GPU (BASELINE configs[1]); "
+                        "synthetic He-normal BN-folded weights (seed 1234), inputs U[0,1) resident in HBM")
+            flop = "gflop_per_image"
         out = {
-            "metric": "inferences/sec, ResNet-50 f32 batch 32 per GPU",
+            "metric": metric,
             "value": round(value, 2), "unit": "inferences/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "p50_latency_ms": round(p50, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "ResNet-50 v1.5 f32 inference, 224x224, batch 32 per GPU (BASELINE configs[1]); "
-                                   "synthetic He-normal BN-folded weights (seed 1234), inputs U[0,1) resident in HBM",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 x i8 -> i32 (f32 between layers)" if int8 else "f32", "data": "synthetic",
+            "config": {"workload": workload,
                        "global_batch": global_batch, "parallelism": f"batch-shard x{n_gpus} (weights RCCL-broadcast once)" if n_gpus > 1 else "single GPU",
                        "launch": "eager" if args.no_graph else "hipGraph replay", "autotuned_tiles": bool(net.variants), "shortcut_branch": "second stream" if net.concurrent else "main stream",
-                       "gflop_per_image": round((resnet50.conv_flops_per_image() + 2 * 2048 * 1000) / 1e9, 3),
+                       flop: round((resnet50.conv_flops_per_image() + 2 * 2048 * 1000) / 1e9, 3),
                        "device": ctx.device_info()},
+            "ranks": {"world_size": world, "dist_backend": backend, "weight_broadcast_world": comm_world, "ms_per_step_per_rank": per_rank_ms},
+            "pcie_inclusive": {"ms_per_step": round(pcie_ms, 4), "inferences_per_s": round(BATCH_PER_GPU / (pcie_ms * 1e-3), 1),
+                               "note": "rank 0: batch uploaded from pageable host memory and logits downloaded every step (19.3 MB in, 128 KB out); not `value`"} if pcie_ms else None,
             "roofline": roof,
         }
+        if int8:
+            out["config"]["int8_pad_mode"] = ("RAW0_I8 -- ASSUMPTION: padded taps of an integer convolution hold raw 0 after the u8->i8 shift, the x86 reference's im2col behaviour "
+                                              "(rten-gemm/src/im2col.rs:340-358, SURVEY App. C.1); unpinned by a reference-held vector; ZERO_POINT / RAW0_U8 are the other modes of the ABI")
         if n_gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(net.specs, weights)
+            out["cpu_baseline"] = cpu_baseline_int8(net.specs, weights) if int8 else cpu_baseline(net.specs, weights)
         else:
             out["cpu_baseline"] = None
-        if n_gpus == 1 and world == 1 and not args.no_secondary:
+        if n_gpus == 1 and world == 1 and not args.no_secondary and not int8:
             out["secondary"] = secondary_configs()
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()  # rank 0's instrumented pass / JSON line happen before any rank tears the group down
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

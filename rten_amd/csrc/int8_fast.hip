@@ -831,5 +831,7 @@ int32_t rten_i8_fast_conv(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di
     g.need_csum = (di->w_zp_len != 0 || !di->w_signed) ? 1 : 0; // weight zero point may be non-zero in the signed domain
     g.conv = 1; g.OW = d->out_w; g.sy = d->stride_h; g.sx = d->stride_w; g.Hp = cg.Hp; g.Wp = cg.Wp; g.Cp = cg.Cp;
     g.KH = d->kh; g.KW = d->kw; g.dy = d->dil_h; g.dx = d->dil_w;
-    return dispatch_fast(ctx, g, 2.0 * d->o * (double)g.N * cg.Kreal, (double)d->o * cg.Kreal + (double)d->n * d->c * d->h * d->w + 4.0 * d->o * g.N);
+    // algorithmic bytes: i8 weights + u8 activations (once) + f32 output (+ f32 residual when the epilogue adds one)
+    return dispatch_fast(ctx, g, 2.0 * d->o * (double)g.N * cg.Kreal,
+                         (double)d->o * cg.Kreal + (double)d->n * d->c * d->h * d->w + 4.0 * d->o * g.N + (g.res ? 4.0 * d->o * g.N : 0.0));
 }

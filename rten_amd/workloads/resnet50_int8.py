@@ -26,7 +26,7 @@ def quantize_weights(weights):
 
 
 class ResNet50Int8(ResNet50):
-    def __init__(self, ctx, batch, weights=None, pad_mode=L.PAD_RAW0_I8, **kw):
+    def __init__(self, ctx, batch, weights=None, pad_mode=L.PAD_RAW0_I8, i8_arena_ptr=None, i8_arena_keepalive=None, **kw):
         super().__init__(ctx, batch, weights, **kw)
         self.pad_mode = pad_mode
         self._staged_key = None
@@ -48,28 +48,51 @@ class ResNet50Int8(ResNet50):
             staged_max = max(staged_max, ctx.lib.rten_hip_conv2d_int8_staged_bytes(C.byref(self.idesc[l["name"]])))
         self.staged = DeviceTensor(ctx, (max(staged_max, 256),), np.uint8)  # quantized activations in the int8 kernel's layout
         self.fc_tmp = DeviceTensor(ctx, (batch, self.num_classes), np.float32)
-        self.fc_idesc = L.GemmInt8Desc(batch, self.num_classes, 2048, 2048, 1, 1, 2048, self.num_classes, 0, 1, 1, 0, 1)
+        # classifier RHS [K = 2048, N = 1000] staged once (rten_hip_gemm_int8_prepack: PackedBMatrix, Graph::prepack_weights)
+        self.fc_packed_bytes = ctx.lib.rten_hip_gemm_int8_packed_bytes(2048, self.num_classes)
+        self.fc_idesc = L.GemmInt8Desc(batch, self.num_classes, 2048, 2048, 1, 1, 2048, self.num_classes, 0, 1, 1, 0, 1,
+                                       1, 0, 0, 0, 1 if self.fc_packed_bytes else 0)
+        # int8 weight arena: per layer [staged weights + row sums | w_scale f32 | bias f32], then the classifier; ONE allocation so
+        # that rank 0 of a batch-sharded job stages it once and RCCL broadcasts it (bench.py --config int8)
+        offs, total = {}, 0
+        for l in self.specs:
+            nb = ctx.lib.rten_hip_conv2d_int8_packed_bytes(C.byref(self.idesc[l["name"]]))
+            if nb == 0:
+                raise RuntimeError("int8 conv geometry not covered by the staged kernel: " + l["name"])
+            offs[l["name"]] = (total, total + nb, total + nb + 256)
+            total = (total + nb + 256 + l["cout"] * 4 + 255) & ~255
+        fc_nb = self.fc_packed_bytes or 2048 * self.num_classes
+        offs["fc"] = (total, total + fc_nb, total + fc_nb + 256)
+        total = (total + fc_nb + 256 + self.num_classes * 4 + 255) & ~255
+        self.i8_off, self.i8_arena_bytes = offs, total
+        self.i8_arena = DeviceTensor(ctx, (total,), np.uint8, ptr=i8_arena_ptr, keepalive=i8_arena_keepalive)
+        for name, (a, b, c) in offs.items():
+            o = self.num_classes if name == "fc" else next(l["cout"] for l in self.specs if l["name"] == name)
+            self.wq[name] = DeviceTensor(ctx, (b - a,), np.uint8, ptr=self.i8_arena.ptr + a, keepalive=self.i8_arena)
+            self.ws[name] = DeviceTensor(ctx, (1,), np.float32, ptr=self.i8_arena.ptr + b, keepalive=self.i8_arena)
+            self.bq[name] = DeviceTensor(ctx, (o,), np.float32, ptr=self.i8_arena.ptr + c, keepalive=self.i8_arena)
 
     def upload_weights(self):
+        """Stage every weight into the int8 arena (rank 0 of a multi-GPU job; the others receive the broadcast)."""
         ctx = self.ctx
         for l in self.specs:
             wq, ws, b = self.q[l["name"]]
-            d = self.idesc[l["name"]]
-            nbytes = ctx.lib.rten_hip_conv2d_int8_packed_bytes(C.byref(d))
-            if nbytes == 0:
-                raise RuntimeError("int8 conv geometry not covered by the staged kernel: " + l["name"])
             raw = DeviceTensor.from_numpy(ctx, wq)
-            packed = DeviceTensor(ctx, (nbytes,), np.uint8)
-            ctx.call("rten_hip_conv2d_int8_prepack", C.byref(d), raw.vp, packed.vp)
+            ctx.call("rten_hip_conv2d_int8_prepack", C.byref(self.idesc[l["name"]]), raw.vp, self.wq[l["name"]].vp)
             ctx.sync()
             raw.free()
-            self.wq[l["name"]] = packed
-            self.ws[l["name"]] = DeviceTensor.from_numpy(ctx, np.array([ws], np.float32))
-            self.bq[l["name"]] = DeviceTensor.from_numpy(ctx, b)
-        wq, ws, b = self.q["fc"]
-        self.wq["fc"] = DeviceTensor.from_numpy(ctx, wq)  # [1000, 2048]: B[k, n] = wq[n, k] via strides
-        self.ws["fc"] = DeviceTensor.from_numpy(ctx, np.array([ws], np.float32))
-        self.bq["fc"] = DeviceTensor.from_numpy(ctx, b)
+            self.ws[l["name"]].upload(np.array([ws], np.float32))
+            self.bq[l["name"]].upload(b)
+        wq, ws, b = self.q["fc"]  # [1000, 2048]: B[k, n] = wq[n, k] via strides
+        if self.fc_packed_bytes:
+            raw = DeviceTensor.from_numpy(ctx, wq)
+            ctx.call("rten_hip_gemm_int8_prepack", 2048, self.num_classes, raw.vp, 1, 2048, 1, self.wq["fc"].vp)
+            ctx.sync()
+            raw.free()
+        else:
+            self.wq["fc"].upload(wq.reshape(-1).view(np.uint8))
+        self.ws["fc"].upload(np.array([ws], np.float32))
+        self.bq["fc"].upload(b)
 
     def _quantize(self, src, n):
         ctx = self.ctx

@@ -1,0 +1,74 @@
+"""bench.py's launch contract (no GPU needed): `--gpus N` means N ranks.  Under a launcher whose WORLD_SIZE differs the script
+must fail loudly instead of printing N x the single-GPU rate; without a launcher it must start the ranks itself."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env_extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
+
+
+def test_gpus_2_without_matching_ranks_fails_loudly():
+    p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
+    assert p.returncode != 0
+    assert "WORLD_SIZE=1" in p.stderr and "--gpus 2" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]  # and no JSON line
+
+
+def test_world_size_larger_than_gpus_fails_too():
+    p = _run(["--gpus", "1"], {"RANK": "1", "LOCAL_RANK": "1", "WORLD_SIZE": "2"})
+    assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr
+
+
+def test_gpus_n_without_launcher_spawns_n_ranks(monkeypatch):
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd, *a, **kw):
+        seen["cmd"] = cmd
+        return 0
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1", "--config", "int8"])
+    assert bench.main() == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    tail = cmd[cmd.index(BENCH) + 1:]
+    assert tail == ["--gpus", "4", "--steps", "3", "--warmup", "1", "--config", "int8"]
+
+
+def test_int8_algorithmic_bytes_formula():
+    """The HBM floor of the dynamically quantized graph (roofline.step of --config int8) from the layer list alone."""
+    sys.path.insert(0, ROOT)
+    import ctypes as C
+    import bench
+    from rten_amd import lib as L
+    from rten_amd.workloads import resnet50
+
+    class Net:  # shapes only: no device
+        specs = resnet50.conv_specs()
+        num_classes = 1000
+    shapes = {"x": (32, 3, 224, 224)}
+    Net.descs = {}
+    for l in Net.specs:
+        n, c, h, w = shapes[l["src"]]
+        oh = (h + 2 * l["pad"] - l["k"]) // l["stride"] + 1
+        Net.descs[l["name"]] = L.Conv2dDesc(n, c, h, w, l["cout"], l["k"], l["k"], (C.c_int32 * 4)(*([l["pad"]] * 4)), l["stride"], l["stride"], 1, 1, 1, oh, oh)
+        shapes[l["dst"]] = (n, l["cout"], oh, oh)
+        if l["dst"] == "stem":
+            shapes["pool"] = (n, l["cout"], (oh + 2 - 3) // 2 + 1, (oh + 2 - 3) // 2 + 1)
+    Net.shapes = shapes
+    Net.pool_desc = L.Pool2dDesc(32, 64, 112, 112, 3, 3, 2, 2, (C.c_int32 * 4)(1, 1, 1, 1), 56, 56, 0)
+    total = bench.int8_algorithmic_bytes(Net)
+    assert 3.5e9 < total < 5.0e9  # about 4.3 GB per 32-image batch
