@@ -397,7 +397,10 @@ int32_t rten_hip_num_gemm_variants(void);
  * boundaries, rten-gemm/src/lib.rs:630-633, and the per-block partial sums are added in block order by a fixup
  * kernel).  mode 0 = off, 1 = split only the tiles beyond the last full round of compute units, 2 = split every
  * tile, 3 = automatic (default: split every tile when the launch would have fewer workgroups than half the compute
- * units); groups = K groups per split tile (modes 1, 2).  A tuning knob like the variant override: sticky. */
+ * units); groups = K groups per split tile (modes 1, 2).  Mode 4 (no K split): a convolution whose tile count is not a
+ * multiple of the compute units runs its whole rounds with the selected tile shape and the remaining columns as thin
+ * 16 x 64 tiles on v_mfma_f32_16x16x4_f32 (a quarter of the per-SIMD work, so the partial last round costs a quarter of
+ * a round); other calls ignore it.  A tuning knob like the variant override: sticky. */
 int32_t rten_hip_set_gemm_split(rten_hip_ctx *ctx, int32_t mode, int32_t groups);
 /* Workgroup -> tile order (tuning knob, sticky, default 0): bit 0 = tiles walk n fastest instead of m fastest;
  * bit 1 = split-K workgroups walk tiles fastest and K groups slowest, so that each XCD's private L2 holds one K

@@ -539,8 +539,10 @@ class Graph {
         std::vector<GemmPlan> plans;
         const int nvar = rten_hip_num_gemm_variants();
         for (int v = 0; v < nvar; v++) for (int o = 0; o < 2; o++) plans.push_back(GemmPlan{true, v, 0, 1, o});
+        // thin-tile tail (split mode 4) on the LDS-DMA pipelines: whole rounds with the variant's tile + 16x64 tiles on 16x16x4 MFMAs
+        for (int v = 0; v < nvar; v++) if (v < 4 || v >= 12) for (int o = 0; o < 2; o++) plans.push_back(GemmPlan{true, v, 4, 1, o});
         if (nblk > 1) {
-            static const int split_variants[] = {0, 1, 2, 3, 4, 5, 6, 7, 12, 13, 14, 15};
+            static const int split_variants[] = {0, 1, 2, 3, 4, 5, 6, 7, 12, 13, 14, 15, 16, 17, 18, 19};
             for (int v : split_variants) {
                 if (v >= nvar) continue;
                 std::set<int> group_counts;

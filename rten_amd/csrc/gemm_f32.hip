@@ -89,6 +89,7 @@ struct GemmArgs {
     float *slab;
     int split_t1, split_s, split_g, split_slots, split_ntail;
     int order; // bit 0: tiles walk n fastest (default m fastest); bit 1: split workgroups walk tiles fastest, K groups slowest
+    int n_lo;  // thin-tile kernel: first column of its share (the whole-round tiles of the same call cover [0, n_lo))
 };
 
 
@@ -616,7 +617,11 @@ __device__ __forceinline__ void wait_vmcnt() {
 // (no fold, no epilogue: igemm_f32_fixup_kernel finishes the tile).
 // AL: A_M4 = k-major A ([K][M], prepacked conv weights, transposed GEMM operands); A_K4 = row-major A ([M][K], the
 // plain MatMul layout): one DMA instruction then moves 64 rows x one k-quad and the LDS image is [k-quad][m][4].
-template <int BM, int BN, int AL, int BL, int MODE, int NST = 3>
+// MFK: 0 = operand fragments double buffered across k-pairs with the next pair's ds_reads behind the current MFMA group (iglp_opt);
+//      1 = all of the k-tile's fragments first, then the MFMAs back to back with nothing between them: with one 32x32 block per
+//          wave (64x64 tiles) consecutive MFMAs hit the SAME accumulator, and any instruction issued between two such MFMAs
+//          costs ~43 cycles on top of its own slot (MI355X_MICROARCH.md, per-instruction constants).
+template <int BM, int BN, int AL, int BL, int MODE, int NST = 3, int MFK = 0>
 __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmArgs p) {
     // MODE 3 ("mixed"): one launch holds the whole tiles [0, split_t1) (fold + epilogue, as MODE 1) AND the split-K
     // producers of the tail tiles (as MODE 2), so the tail's small workgroups fill the last round next to the whole
@@ -817,6 +822,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
         const float *As = smem + stage * STAGE + (AL == A_M4 ? wm0 + l31 + half * BM : (wm0 + l31) * 4 + half);
         auto a_idx = [](int kk, int i) { return AL == A_M4 ? 2 * kk * BM + i * 32 : (kk >> 1) * BM * 4 + ((2 * kk) & 3) + i * 128; };
         const float *Bs = smem + stage * STAGE + BK * BM + wn0 + l31;
+        if constexpr (MFK == 1) {
+            float afa[BK / 2][TM], bfa[BK / 2][TN];
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; kk++) {
+#pragma unroll
+                for (int i = 0; i < TM; i++) afa[kk][i] = As[a_idx(kk, i)];
+#pragma unroll
+                for (int j = 0; j < TN; j++) bfa[kk][j] = Bs[(2 * kk + half) * BN + j * 32];
+            }
+            __builtin_amdgcn_sched_barrier(0); // every ds_read of the tile is issued before the first MFMA
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; kk++)
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(afa[kk][i], bfa[kk][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            return;
+        }
         float af[2][TM], bf[2][TN]; // operand fragments, double buffered across k-pairs
 #pragma unroll
         for (int i = 0; i < TM; i++) af[0][i] = As[a_idx(0, i)];
@@ -968,6 +993,366 @@ __global__ __launch_bounds__(64) void igemm_f32_fixup_kernel(const GemmArgs p) {
         fold_next<TM, TN>(p, acc[0], tot);
     }
     store_out<TM, TN>(p, tot, mb, nb0, c_zoff);
+}
+
+// =====================================================================================================
+// LDS-DMA kernel on v_mfma_f32_16x16x4_f32: the same tile DMA, LDS image and depth-block fold as igemm_f32_dma_kernel, but a
+// wave's (BM/2) x (BN/2) share is a grid of 16x16 accumulator blocks.  With 64x64 tiles the 32x32x2 form leaves every wave ONE
+// accumulator, i.e. a chain of dependent MFMAs: whatever the wave issues between two of them (the next operands' ds_reads) costs
+// ~43 cycles beyond its own slot, and the dependent latency itself is the whole 64-cycle issue time.  Four independent 16x16
+// accumulators (40-cycle dependent latency, revisited every 128 cycles) take both stalls away at the same LDS traffic per flop.
+// v_mfma_f32_16x16x4_f32 is a k-ordered fmaf chain (tools/probes/mfma_16x16x4_order.hip): same bits.  MODE 0 / 1 (no split-K form).
+// Accumulator element r of block (i, j): row wm0 + 16 i + 4 * (lane / 16) + r, column wn0 + 16 j + lane % 16.
+// =====================================================================================================
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int TM2, int TN2>
+__device__ __forceinline__ void fold_first16(const GemmArgs &p, int z, f32x4v (&acc)[TM2][TN2], f32x4v (&out)[TM2][TN2], int mb, int nb0, long long c_zoff) {
+    const __amdgpu_buffer_rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc((void *)((p.bias ? p.bias : p.C) + (long long)z * p.bias_bs), 0, 0x7ffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void *)(p.C + c_zoff), 0, 0x7ffffffc, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < TM2; i++) {
+        const int mrow = mb + i * 16;
+        float brow[4];
+        if (p.bias_kind == RTEN_HIP_BIAS_PER_ROW) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) brow[r] = buf_load1(rsBias, mrow + r < p.M ? (unsigned)(mrow + r) << 2 : OOB, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < TN2; j++) {
+            const int n = nb0 + j * 16;
+            const bool cok = n < p.N;
+            f32x4v v = acc[i][j];
+            if (p.beta == 0.f) {
+                if (p.alpha != 1.f) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) v[r] = v[r] * p.alpha;
+                }
+            } else {
+                const int nn = cok ? n : 0;
+                const int nb = nn / p.Pn, np = nn - nb * p.Pn;
+                const unsigned col = (unsigned)((long long)nb * p.c_ns + np);
+                float cin[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int m = mrow + r;
+                    cin[r] = buf_load1(rsC, (m < p.M && cok) ? (col + (unsigned)m * (unsigned)p.c_rs) << 2 : OOB, 0);
+                }
+                if (p.beta == 1.f && p.alpha == 1.f) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) v[r] = cin[r] + v[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) v[r] = vm::fma(v[r], p.alpha, cin[r] * p.beta);
+                }
+            }
+            if (p.bias_kind == RTEN_HIP_BIAS_PER_ROW) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = v[r] + brow[r];
+            } else if (p.bias_kind == RTEN_HIP_BIAS_PER_COL) {
+                const float bcol = buf_load1(rsBias, cok ? (unsigned)n << 2 : OOB, 0);
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = v[r] + bcol;
+            }
+            out[i][j] = v;
+        }
+    }
+}
+
+template <int TM2, int TN2>
+__device__ __forceinline__ void fold_next16(const GemmArgs &p, f32x4v (&acc)[TM2][TN2], f32x4v (&tot)[TM2][TN2]) {
+#pragma unroll
+    for (int i = 0; i < TM2; i++)
+#pragma unroll
+        for (int j = 0; j < TN2; j++) {
+            if (p.alpha == 1.f) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) tot[i][j][r] = tot[i][j][r] + acc[i][j][r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; r++) tot[i][j][r] = vm::fma(acc[i][j][r], p.alpha, tot[i][j][r]);
+            }
+        }
+}
+
+template <int TM2, int TN2>
+__device__ __forceinline__ void store_out16(const GemmArgs &p, f32x4v (&val)[TM2][TN2], int mb, int nb0, long long c_zoff) {
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void *)(p.C + c_zoff), 0, 0x7ffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void *)((p.res ? p.res : p.C) + c_zoff), 0, 0x7ffffffc, 0x00020000);
+    const bool has_res = p.res != nullptr;
+    const unsigned rs4 = (unsigned)p.c_rs << 2;
+#pragma unroll
+    for (int j = 0; j < TN2; j++) {
+        const int n = nb0 + j * 16;
+        const bool cok = n < p.N;
+        const int nn = cok ? n : 0;
+        const int nb = nn / p.Pn, np = nn - nb * p.Pn;
+        const unsigned col = (unsigned)((long long)nb * p.c_ns + np);
+        unsigned voff[TM2][4];
+        float rr[TM2][4];
+#pragma unroll
+        for (int i = 0; i < TM2; i++) {
+            const int mrow = mb + i * 16;
+            const unsigned base = cok ? (col + (unsigned)mrow * (unsigned)p.c_rs) << 2 : OOB;
+#pragma unroll
+            for (int r = 0; r < 4; r++) voff[i][r] = mrow + r < p.M ? base : OOB;
+            if (has_res) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) rr[i][r] = buf_load1(rsR, voff[i][r], (unsigned)r * rs4);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM2; i++) {
+            f32x4v v = val[i][j];
+            if (has_res) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = v[r] + rr[i][r];
+            }
+            if (p.act == RTEN_HIP_ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = vm::relu(v[r]);
+            } else if (p.act == RTEN_HIP_ACT_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = vm::gelu(v[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float x = v[r];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), rsC, (int)voff[i][r], (int)((unsigned)r * rs4), 0);
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int AL, int BL, int MODE>
+__global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma16_kernel(const GemmArgs p) {
+    constexpr bool MULTI_KC = MODE == 1;
+    static_assert(MODE == 0 || MODE == 1, "the 16x16x4 kernel has no split-K form");
+    static_assert(AL == A_M4 || AL == A_K4, "DMA kernel: A is k-major or row-major with 16-byte rows");
+    static_assert(BL == B_N4 || BL == B_IM2COL || BL == B_IM2COL_TAPS, "DMA kernel covers the conv operand layouts");
+    constexpr int WM = 2, WN = 2;
+    constexpr int TM2 = BM / WM / 16, TN2 = BN / WN / 16;
+    constexpr int STAGE = BK * (BM + BN);
+    constexpr int NA = BK * BM / 256 / 4;
+    constexpr int NBV = BK * BN / 256 / 4;
+    constexpr int NBG = BK * BN / 64 / 4;
+    constexpr int PER_TILE = NA + (BL == B_N4 ? NBV : NBG);
+    constexpr int NSTAGE = 3;
+    __shared__ __attribute__((aligned(16))) float smem[NSTAGE * STAGE];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l15 = lane & 15, quad = lane >> 4;
+    const int z = blockIdx.y;
+
+    int tile;
+    {
+        const int id = blockIdx.x;
+        const int nt = (int)gridDim.x;
+        const int xcd = id & 7, q = nt >> 3, r = nt & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    }
+    const int bm = (p.order & 1) ? tile / p.tiles_n : tile % p.tiles_m, bn = (p.order & 1) ? tile % p.tiles_n : tile / p.tiles_m;
+    const int m0 = bm * BM, n0 = bn * BN;
+
+    int zo = z, zi = 0;
+    if (p.batch_inner > 1) { zo = z / p.batch_inner; zi = z - zo * p.batch_inner; }
+    const float *Ab = p.A + (long long)zo * p.a_bs + (long long)zi * p.a_bsi;
+    const float *Bb = p.B + (long long)zo * p.b_bs + (long long)zi * p.b_bsi;
+    const long long c_zoff = (long long)zo * p.c_bs + (long long)zi * p.c_bsi;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)Ab, 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void *)Bb, 0, (int)p.b_bytes, 0x00020000);
+    const int nk = (p.K + BK - 1) / BK;
+
+    unsigned a_voff[NA];
+    [[maybe_unused]] int a_kq[NA];
+#pragma unroll
+    for (int j = 0; j < NA; j++) {
+        if constexpr (AL == A_M4) {
+            const int f = (wave * NA + j) * 256 + lane * 4;
+            const int k = f / BM, m = m0 + f % BM;
+            a_voff[j] = m < (int)p.a_cs ? (unsigned)(((long long)k * p.a_cs + m) * 4) : OOB;
+        } else {
+            const int q = wave * NA + j, kq = q / (BM / 64), m = m0 + (q % (BM / 64)) * 64 + lane;
+            a_kq[j] = kq * 4;
+            a_voff[j] = m < p.M ? (unsigned)(((long long)m * p.a_rs + kq * 4) * 4) : OOB;
+        }
+    }
+    const unsigned a_kstep = AL == A_M4 ? (unsigned)(BK * p.a_cs * 4) : (unsigned)(BK * 4);
+
+    [[maybe_unused]] unsigned b_voff[BL == B_N4 ? NBV : 1];
+    [[maybe_unused]] int b_krow[BL == B_N4 ? NBV : 1];
+    [[maybe_unused]] unsigned b_kstep = 0;
+    constexpr bool IM2COL = BL == B_IM2COL || BL == B_IM2COL_TAPS, TAPS = BL == B_IM2COL_TAPS;
+    constexpr int NCOL = IM2COL && BN == 128 ? 2 : 1;
+    [[maybe_unused]] int im_iy0[NCOL], im_ix0[NCOL], im_pix[NCOL];
+    [[maybe_unused]] unsigned im_inv[NCOL];
+    if constexpr (BL == B_N4) {
+#pragma unroll
+        for (int j = 0; j < NBV; j++) {
+            const int f = (wave * NBV + j) * 256 + lane * 4;
+            const int k = f / BN, n = n0 + f % BN;
+            const int nn = n < p.N ? n : 0;
+            const int nb = nn / p.Pn, np = nn - nb * p.Pn;
+            b_krow[j] = k;
+            b_voff[j] = n < p.N ? (unsigned)(((long long)k * p.b_rs + (long long)nb * p.b_ns + np) * 4) : OOB;
+        }
+        b_kstep = (unsigned)(BK * p.b_rs * 4);
+    } else {
+#pragma unroll
+        for (int c = 0; c < BN / 64; c++) {
+            const int n = n0 + c * 64 + lane;
+            const bool ok = n < p.N;
+            const int nn = ok ? n : 0;
+            const int nb = nn / p.Pn, np = nn - nb * p.Pn;
+            const int oy = np / p.OW, ox = np - oy * p.OW;
+            im_iy0[c] = ok ? oy * p.sy - p.pt : -0x40000000;
+            im_ix0[c] = ox * p.sx - p.pl;
+            im_pix[c] = (int)((long long)nb * p.b_ns) + (oy * p.sy - p.pt) * p.W + im_ix0[c];
+            if constexpr (TAPS) {
+                unsigned colbad = 0;
+                for (int kx = 0; kx < p.KW; kx++) colbad |= ((unsigned)(im_ix0[c] + kx * p.dx) >= (unsigned)p.W ? 1u : 0u) << kx;
+                const unsigned allbad = (1u << p.KW) - 1u;
+                unsigned inv = 0x80000000u;
+                for (int ky = 0; ky < p.KH; ky++)
+                    inv |= ((unsigned)(im_iy0[c] + ky * p.dy) >= (unsigned)p.H ? allbad : colbad) << (ky * p.KW);
+                im_inv[c] = inv;
+            }
+        }
+    }
+
+    typedef const __attribute__((address_space(4))) i32x2 *lut_ptr_t;
+    constexpr int LROWS = BK / 4;
+    [[maybe_unused]] i32x2 lutE[LROWS];
+    [[maybe_unused]] auto fetch_lut = [&](int kt) {
+        if constexpr (IM2COL) {
+            const int krow0 = kt * BK + wave * LROWS;
+            const lut_ptr_t lc = (lut_ptr_t)(unsigned long long)p.lut;
+#pragma unroll
+            for (int j = 0; j < LROWS; j++) lutE[j] = lc[krow0 + j];
+        }
+    };
+
+    typedef __attribute__((address_space(3))) void *lds_ptr_t;
+    auto issue_tile = [&](int kt, int stage) {
+        float *As = smem + stage * STAGE;
+        float *Bs = As + BK * BM;
+        const int kts = kt < nk ? kt : (nk > 0 ? nk - 1 : 0);
+        const bool past = kt >= nk;
+        const unsigned a_soff = (unsigned)kts * a_kstep;
+#pragma unroll
+        for (int j = 0; j < NA; j++) {
+            bool dead = past;
+            if constexpr (AL == A_K4) dead = a_kq[j] >= p.K - kt * BK;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(As + (wave * NA + j) * 256), 16, (int)(dead ? OOB : a_voff[j]), (int)a_soff, 0, 0);
+        }
+        if constexpr (BL == B_N4) {
+            const int kleft = p.K - kt * BK;
+            const unsigned b_soff = (unsigned)kts * b_kstep;
+#pragma unroll
+            for (int j = 0; j < NBV; j++)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(Bs + (wave * NBV + j) * 256), 16, (int)(b_krow[j] < kleft ? b_voff[j] : OOB), (int)b_soff, 0, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NBG; j++) {
+                constexpr int CPR = BN / 64;
+                const int r = j / CPR, c = j % CPR;
+                const i32x2 e = lutE[r];
+                unsigned voff;
+                if constexpr (TAPS) {
+                    voff = ((im_inv[c] << e[1]) & 0x80000000u) | ((unsigned)(im_pix[c] + e[0]) << 2);
+                } else {
+                    const int iy = im_iy0[c] + (e[1] & 0xffff);
+                    const int ix = im_ix0[c] + (e[1] >> 16);
+                    const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+                    voff = ok ? (unsigned)(im_pix[c] + e[0]) << 2 : OOB;
+                }
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(Bs + (wave * LROWS + r) * BN + c * 64), 4, (int)voff, 0, 0, 0);
+            }
+        }
+    };
+
+    const int wq = t >> 6;
+    const int wm0 = (wq / WN) * (BM / WM), wn0 = (wq % WN) * (BN / WN);
+    f32x4v acc[TM2][TN2];
+    [[maybe_unused]] f32x4v tot[TM2][TN2];
+#pragma unroll
+    for (int i = 0; i < TM2; i++)
+#pragma unroll
+        for (int j = 0; j < TN2; j++) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    [[maybe_unused]] auto flush = [&](bool first) {
+        int mb = m0 + wm0 + 4 * quad, nb0 = n0 + wn0 + l15;
+        asm volatile("" : "+v"(mb), "+v"(nb0));
+        if (first) fold_first16<TM2, TN2>(p, z, acc, tot, mb, nb0, c_zoff);
+        else fold_next16<TM2, TN2>(p, acc, tot);
+#pragma unroll
+        for (int i = 0; i < TM2; i++)
+#pragma unroll
+            for (int j = 0; j < TN2; j++) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    };
+
+    auto compute_tile = [&](int stage) {
+        // k-step ks covers rows 4 ks .. 4 ks + 3 of the tile; lane -> k = 4 ks + quad.  k-major image As[k][m]; row-major image [k/4][m][4]
+        const float *As = smem + stage * STAGE + (AL == A_M4 ? wm0 + l15 + quad * BM : (wm0 + l15) * 4 + quad);
+        auto a_idx = [](int ks, int i) { return AL == A_M4 ? 4 * ks * BM + i * 16 : ks * BM * 4 + i * 64; };
+        const float *Bs = smem + stage * STAGE + BK * BM + wn0 + l15 + quad * BN;
+        float af[2][TM2], bf[2][TN2];
+#pragma unroll
+        for (int i = 0; i < TM2; i++) af[0][i] = As[a_idx(0, i)];
+#pragma unroll
+        for (int j = 0; j < TN2; j++) bf[0][j] = Bs[j * 16];
+#pragma unroll
+        for (int ks = 0; ks < BK / 4; ks++) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks + 1 < BK / 4) {
+#pragma unroll
+                for (int i = 0; i < TM2; i++) af[nxt][i] = As[a_idx(ks + 1, i)];
+#pragma unroll
+                for (int j = 0; j < TN2; j++) bf[nxt][j] = Bs[4 * (ks + 1) * BN + j * 16];
+            }
+#pragma unroll
+            for (int i = 0; i < TM2; i++)
+#pragma unroll
+                for (int j = 0; j < TN2; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_iglp_opt(0);
+    };
+
+    const int nblk = MULTI_KC ? (nk + KC_TILES - 1) / KC_TILES : 1;
+    fetch_lut(0);
+#pragma unroll
+    for (int i = 0; i < NSTAGE - 1; i++) {
+        issue_tile(i, i);
+        fetch_lut(i + 1);
+    }
+    int stage = 0;
+    for (int blk = 0; blk < nblk; blk++) {
+        const int kt_end = MULTI_KC ? ((blk + 1) * KC_TILES < nk ? (blk + 1) * KC_TILES : nk) : nk;
+        for (int kt = blk * KC_TILES; kt < kt_end; kt++) {
+            wait_vmcnt<PER_TILE *(NSTAGE - 2)>();
+            __builtin_amdgcn_s_barrier();
+            const int stp = stage == 0 ? NSTAGE - 1 : stage - 1;
+            issue_tile(kt + NSTAGE - 1, stp);
+            fetch_lut(kt + NSTAGE);
+            compute_tile(stage);
+            stage = stage == NSTAGE - 1 ? 0 : stage + 1;
+        }
+        if constexpr (MULTI_KC) {
+            if (blk + 1 < nblk) flush(blk == 0);
+        }
+    }
+    wait_vmcnt<0>();
+
+    const int mb = m0 + wm0 + 4 * quad, nb0 = n0 + wn0 + l15;
+    if constexpr (MULTI_KC) {
+        fold_next16<TM2, TN2>(p, acc, tot);
+        store_out16<TM2, TN2>(p, tot, mb, nb0, c_zoff);
+    } else {
+        fold_first16<TM2, TN2>(p, z, acc, acc, mb, nb0, c_zoff);
+        store_out16<TM2, TN2>(p, acc, mb, nb0, c_zoff);
+    }
 }
 
 template <int BM, int BN, int BL, bool MULTI_KC>
@@ -1221,6 +1606,251 @@ __global__ __launch_bounds__(2 * NTHREADS, 2) void igemm_f32_ws_kernel(const Gem
     }
 }
 
+// =====================================================================================================
+// Thin-tile tail kernel: 16 (m) x 64 (n) tiles on v_mfma_f32_16x16x4_f32.
+//
+// The f32 matrix pipe makes a 32x32 accumulator block x full K a long indivisible unit on one SIMD, and ResNet's column
+// counts (batch x 49 x 2^k) leave a fraction of a round of 64x64 tiles over: the chip then idles 12-25 % of the layer's
+// time behind a few straggler tiles.  A launch plan with `split_mode == 4` gives the whole rounds to the 64x64 kernel
+// (columns [0, n_lo)) and the remaining columns to this kernel, whose waves own 16x16 blocks -- a quarter of the work per
+// SIMD, so the tail costs a quarter of a round and every CU takes part.
+// v_mfma_f32_16x16x4_f32 is a k-ordered fmaf chain like the 32x32x2 form (tools/probes/mfma_16x16x4_order.hip), so an
+// output element sees the same chain: depth blocks of 256 folded with separate adds, bias after the first block --
+// bit-identical to the big tiles and to the reference.
+// Tile DMA as in the kernel above (A k-major [K][M4] -> LDS [32][32] with rows >= 16 zero filled, B dense or im2col
+// gather -> LDS [32][64]), three stages, k-tiles of 32.  alpha == 1, beta == 0 (convolution) only.
+// =====================================================================================================
+typedef float f32x4acc __attribute__((ext_vector_type(4)));
+constexpr int TBK = 32;               // k-tile depth of the thin kernel
+constexpr int TKC_TILES = 256 / TBK;  // k-tiles per reference depth block
+
+template <int BL, bool MULTI_KC>
+__global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_thin_kernel(const GemmArgs p) {
+    static_assert(BL == B_N4 || BL == B_IM2COL || BL == B_IM2COL_TAPS, "thin kernel covers the conv operand layouts");
+    constexpr int BM = 16, BN = 64, LDA = 32;        // LDS A image is 32 wide (one dwordx4 DMA instruction per wave), 16 used
+    constexpr int STAGE = TBK * (LDA + BN);          // floats per stage
+    constexpr int NBV = TBK * BN / 256 / 4;          // dwordx4 per wave per tile (dense B) = 2
+    constexpr int NBG = TBK * BN / 64 / 4;           // dword gathers per wave per tile (im2col B) = 8
+    constexpr int PER_TILE = 1 + (BL == B_N4 ? NBV : NBG);
+    constexpr int NSTAGE = 3;
+    constexpr bool IM2COL = BL == B_IM2COL || BL == B_IM2COL_TAPS, TAPS = BL == B_IM2COL_TAPS;
+    __shared__ __attribute__((aligned(16))) float smem[NSTAGE * STAGE];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l15 = lane & 15, quad = lane >> 4;
+    const int z = blockIdx.y;
+    const int tile = blockIdx.x;
+    const int bm = tile % p.tiles_m, bn = tile / p.tiles_m; // m fastest: the workgroups of one column strip share the B panel in L2
+    const int m0 = bm * BM, n0 = p.n_lo + bn * BN;
+
+    int zo = z, zi = 0;
+    if (p.batch_inner > 1) { zo = z / p.batch_inner; zi = z - zo * p.batch_inner; }
+    const float *Ab = p.A + (long long)zo * p.a_bs + (long long)zi * p.a_bsi;
+    const float *Bb = p.B + (long long)zo * p.b_bs + (long long)zi * p.b_bsi;
+    const long long c_zoff = (long long)zo * p.c_bs + (long long)zi * p.c_bsi;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)Ab, 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void *)Bb, 0, (int)p.b_bytes, 0x00020000);
+    const int nk = (p.K + TBK - 1) / TBK;
+
+    // A: wave w moves rows [8w, 8w+8) of the k-tile: lane -> (row 8w + lane/8, columns (lane%8)*4 ..+3 of the 32-wide LDS image)
+    unsigned a_voff;
+    {
+        const int k = wave * 8 + (lane >> 3), ml = (lane & 7) * 4, m = m0 + ml;
+        a_voff = (ml < BM && m < (int)p.a_cs) ? (unsigned)(((long long)k * p.a_cs + m) * 4) : OOB;
+    }
+    const unsigned a_kstep = (unsigned)(TBK * p.a_cs * 4);
+
+    [[maybe_unused]] unsigned b_voff[BL == B_N4 ? NBV : 1];
+    [[maybe_unused]] int b_krow[BL == B_N4 ? NBV : 1];
+    [[maybe_unused]] unsigned b_kstep = 0;
+    [[maybe_unused]] int im_iy0 = 0, im_ix0 = 0, im_pix = 0;
+    [[maybe_unused]] unsigned im_inv = 0;
+    if constexpr (BL == B_N4) {
+#pragma unroll
+        for (int j = 0; j < NBV; j++) {
+            const int f = (wave * NBV + j) * 256 + lane * 4;
+            const int k = f / BN, n = n0 + f % BN;
+            const int nn = n < p.N ? n : 0;
+            const int nb = nn / p.Pn, np = nn - nb * p.Pn;
+            b_krow[j] = k;
+            b_voff[j] = n < p.N ? (unsigned)(((long long)k * p.b_rs + (long long)nb * p.b_ns + np) * 4) : OOB;
+        }
+        b_kstep = (unsigned)(TBK * p.b_rs * 4);
+    } else {
+        const int n = n0 + lane; // gather instruction = one k row x 64 columns: a lane sees one column
+        const bool ok = n < p.N;
+        const int nn = ok ? n : 0;
+        const int nb = nn / p.Pn, np = nn - nb * p.Pn;
+        const int oy = np / p.OW, ox = np - oy * p.OW;
+        im_iy0 = ok ? oy * p.sy - p.pt : -0x40000000;
+        im_ix0 = ox * p.sx - p.pl;
+        im_pix = (int)((long long)nb * p.b_ns) + (oy * p.sy - p.pt) * p.W + im_ix0;
+        if constexpr (TAPS) {
+            unsigned colbad = 0;
+            for (int kx = 0; kx < p.KW; kx++) colbad |= ((unsigned)(im_ix0 + kx * p.dx) >= (unsigned)p.W ? 1u : 0u) << kx;
+            const unsigned allbad = (1u << p.KW) - 1u;
+            unsigned inv = 0x80000000u;
+            for (int ky = 0; ky < p.KH; ky++) inv |= ((unsigned)(im_iy0 + ky * p.dy) >= (unsigned)p.H ? allbad : colbad) << (ky * p.KW);
+            im_inv = inv;
+        }
+    }
+
+    typedef const __attribute__((address_space(4))) i32x2 *lut_ptr_t;
+    constexpr int LROWS = TBK / 4; // rows of a k-tile gathered by one wave
+    [[maybe_unused]] i32x2 lutE[LROWS];
+    [[maybe_unused]] auto fetch_lut = [&](int kt) {
+        if constexpr (IM2COL) {
+            const int krow0 = kt * TBK + wave * LROWS;
+            const lut_ptr_t lc = (lut_ptr_t)(unsigned long long)p.lut;
+#pragma unroll
+            for (int j = 0; j < LROWS; j++) lutE[j] = lc[krow0 + j];
+        }
+    };
+
+    typedef __attribute__((address_space(3))) void *lds_ptr_t;
+    auto issue_tile = [&](int kt, int stage) {
+        float *As = smem + stage * STAGE;
+        float *Bs = As + TBK * LDA;
+        const int kts = kt < nk ? kt : (nk > 0 ? nk - 1 : 0); // keep the scalar offset inside the buffer
+        const bool past = kt >= nk;
+        // rows >= K lie past the end of the [K][M4] buffer: the hardware range check zero-fills them
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(As + wave * 256), 16, (int)(past ? OOB : a_voff), (int)((unsigned)kts * a_kstep), 0, 0);
+        if constexpr (BL == B_N4) {
+            const int kleft = p.K - kt * TBK;
+            const unsigned b_soff = (unsigned)kts * b_kstep;
+#pragma unroll
+            for (int j = 0; j < NBV; j++)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(Bs + (wave * NBV + j) * 256), 16, (int)(b_krow[j] < kleft ? b_voff[j] : OOB), (int)b_soff, 0, 0);
+        } else {
+#pragma unroll
+            for (int r = 0; r < NBG; r++) {
+                const i32x2 e = lutE[r];
+                unsigned voff;
+                if constexpr (TAPS) {
+                    voff = ((im_inv << e[1]) & 0x80000000u) | ((unsigned)(im_pix + e[0]) << 2);
+                } else {
+                    const int iy = im_iy0 + (e[1] & 0xffff);
+                    const int ix = im_ix0 + (e[1] >> 16);
+                    const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+                    voff = ok ? (unsigned)(im_pix + e[0]) << 2 : OOB;
+                }
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(Bs + (wave * LROWS + r) * BN), 4, (int)voff, 0, 0, 0);
+            }
+        }
+    };
+
+    const int wq = t >> 6;       // per-lane copy of the wave id for address math
+    const int wn0 = wq * 16;     // the four waves own 16-column strips of the 64-column tile
+    f32x4acc acc = {0.f, 0.f, 0.f, 0.f};
+    [[maybe_unused]] f32x4acc tot = {0.f, 0.f, 0.f, 0.f};
+
+    auto compute_tile = [&](int stage) {
+        // fragments of k-step kk (4 rows of the tile): A[m = l15][k = 4 kk + quad], B[k = 4 kk + quad][n = wn0 + l15]
+        const float *As = smem + stage * STAGE + quad * LDA + l15;
+        const float *Bs = smem + stage * STAGE + TBK * LDA + quad * BN + wn0 + l15;
+        float af[TBK / 4], bf[TBK / 4];
+#pragma unroll
+        for (int kk = 0; kk < TBK / 4; kk++) {
+            af[kk] = As[kk * 4 * LDA];
+            bf[kk] = Bs[kk * 4 * BN];
+        }
+#pragma unroll
+        for (int kk = 0; kk < TBK / 4; kk++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk], bf[kk], acc, 0, 0, 0);
+    };
+
+    // element r of the accumulator: row m0 + 4 * quad + r, column n0 + wn0 + l15
+    const __amdgpu_buffer_rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc((void *)((p.bias ? p.bias : p.C) + (long long)z * p.bias_bs), 0, 0x7ffffffc, 0x00020000);
+    auto first_block = [&](f32x4acc a) { // alpha == 1, beta == 0: out = acc, then the bias (rten-gemm/src/lib.rs:1008-1013,1221-1255)
+        f32x4acc v = a;
+        if (p.bias_kind == RTEN_HIP_BIAS_PER_ROW) {
+            float b4[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int m = m0 + 4 * quad + r;
+                b4[r] = buf_load1(rsBias, m < p.M ? (unsigned)m << 2 : OOB, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[r] = v[r] + b4[r];
+        }
+        return v;
+    };
+
+    const int nblk = MULTI_KC ? (nk + TKC_TILES - 1) / TKC_TILES : 1;
+    fetch_lut(0);
+#pragma unroll
+    for (int i = 0; i < NSTAGE - 1; i++) {
+        issue_tile(i, i);
+        fetch_lut(i + 1);
+    }
+    int stage = 0;
+    for (int blk = 0; blk < nblk; blk++) {
+        const int kt_end = MULTI_KC ? ((blk + 1) * TKC_TILES < nk ? (blk + 1) * TKC_TILES : nk) : nk;
+        for (int kt = blk * TKC_TILES; kt < kt_end; kt++) {
+            wait_vmcnt<PER_TILE *(NSTAGE - 2)>();
+            __builtin_amdgcn_s_barrier();
+            const int stp = stage == 0 ? NSTAGE - 1 : stage - 1;
+            issue_tile(kt + NSTAGE - 1, stp);
+            fetch_lut(kt + NSTAGE);
+            compute_tile(stage);
+            stage = stage == NSTAGE - 1 ? 0 : stage + 1;
+        }
+        if constexpr (MULTI_KC) {
+            if (blk + 1 < nblk) {
+                if (blk == 0) tot = first_block(acc);
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) tot[r] = tot[r] + acc[r];
+                }
+                acc = f32x4acc{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
+    wait_vmcnt<0>(); // drain the look-ahead tiles before the LDS goes away
+
+    f32x4acc v;
+    if constexpr (MULTI_KC) { // launched only for K > 256: at least two depth blocks
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = tot[r] + acc[r];
+    } else {
+        v = first_block(acc);
+    }
+    // residual Add, activation, NCHW / row-major store
+    const int n = n0 + wn0 + l15;
+    const bool cok = n < p.N;
+    const int nn = cok ? n : 0;
+    const int nb = nn / p.Pn, np = nn - nb * p.Pn;
+    const unsigned col = (unsigned)((long long)nb * p.c_ns + np);
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void *)(p.C + c_zoff), 0, 0x7ffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void *)((p.res ? p.res : p.C) + c_zoff), 0, 0x7ffffffc, 0x00020000);
+    unsigned voff[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int m = m0 + 4 * quad + r;
+        voff[r] = (cok && m < p.M) ? (col + (unsigned)m * (unsigned)p.c_rs) << 2 : OOB;
+    }
+    if (p.res != nullptr) {
+        float rr[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) rr[r] = buf_load1(rsR, voff[r], 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = v[r] + rr[r];
+    }
+    if (p.act == RTEN_HIP_ACT_RELU) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = vm::relu(v[r]);
+    } else if (p.act == RTEN_HIP_ACT_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = vm::gelu(v[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const float x = v[r];
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), rsC, (int)voff[r], 0, 0);
+    }
+}
+
 // im2col lookup table: entry k -> {c*HW + ky*dy*W + kx*dx, (ky*dy) | (kx*dx) << 16}; rows >= K get an
 // offset pair that fails every bounds test.  taps != 0 (B_IM2COL_TAPS): the second word is 31 - (ky*KW + kx), the
 // left shift that moves the tap's padding bit of the per-lane mask to bit 31; rows >= K use shift 0 (bit 31 is
@@ -1272,7 +1902,7 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
         split_mode = (multi && wgs * 2 <= ctx->num_cus) ? 2 : 0;
         split_req = (int)(ctx->num_cus / (wgs > 0 ? wgs : 1));
     }
-    if (multi && pipe != 2 && split_mode > 0 && split_req > 1) {
+    if (multi && pipe != 2 && pipe != 5 && split_mode > 0 && split_mode < 4 && split_req > 1) { // (the wave-specialised and 16x16x4 kernels have no split-K form)
         const int s_req = split_req < nblk ? split_req : nblk;
         const int G = (nblk + s_req - 1) / s_req;
         S = (nblk + G - 1) / G;
@@ -1309,6 +1939,23 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
                 RTEN_LAUNCH_CHECK(ctx, "igemm_f32_dma_kernel launch");
                 return RTEN_HIP_OK;
             }
+            if (pipe == 4) { // fragments first, MFMAs back to back (see MFK)
+                snprintf(kname, sizeof kname, "igemm_f32_dma_kernel<%d,%d,%d,%d,%d,3,1>", BM, BN, AL, BL, mode);
+                ProfScope ps(ctx, kname, fl, by);
+                if (mode == 2) hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, AL, BL, 2, 3, 1>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+                else if (mode == 1) hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, AL, BL, 1, 3, 1>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+                else hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, AL, BL, 0, 3, 1>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+                RTEN_LAUNCH_CHECK(ctx, "igemm_f32_dma_kernel launch");
+                return RTEN_HIP_OK;
+            }
+            if (pipe == 5) { // 16x16x4 MFMAs: four independent accumulators per 32x32 of a wave's share
+                snprintf(kname, sizeof kname, "igemm_f32_dma16_kernel<%d,%d,%d,%d,%d>", BM, BN, AL, BL, mode);
+                ProfScope ps(ctx, kname, fl, by);
+                if (mode == 1) hipLaunchKernelGGL((igemm_f32_dma16_kernel<BM, BN, AL, BL, 1>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+                else hipLaunchKernelGGL((igemm_f32_dma16_kernel<BM, BN, AL, BL, 0>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+                RTEN_LAUNCH_CHECK(ctx, "igemm_f32_dma16_kernel launch");
+                return RTEN_HIP_OK;
+            }
             if (pipe == 3) { // four LDS stages: three k-tiles in flight behind the one being multiplied
                 snprintf(kname, sizeof kname, "igemm_f32_dma_kernel<%d,%d,%d,%d,%d,4>", BM, BN, AL, BL, mode);
                 ProfScope ps(ctx, kname, fl, by);
@@ -1329,6 +1976,36 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
         }
         return RTEN_HIP_OK;
     };
+
+    // Thin-tile tail plan (split mode 4; convolution form alpha = 1, beta = 0, one group): the whole rounds of num_cus tiles go
+    // to this tile shape over columns [0, n_big), the remaining columns to the 16x64 kernel on 16x16x4 MFMAs, whose quarter-size
+    // per-SIMD blocks finish the tail in a quarter of a round (see igemm_f32_thin_kernel).  Same bits as any other plan.
+    if constexpr (kDma && AL == A_M4) {
+        if (ctx->split_mode == 4 && Z == 1 && a.batch_inner <= 1 && a.alpha == 1.f && a.beta == 0.f && a.bias_kind != RTEN_HIP_BIAS_PER_COL) {
+            const long long rounds = T / ctx->num_cus;
+            const long long big_cols = rounds * ctx->num_cus / a.tiles_m; // column tiles that fit into the whole rounds
+            const long long big_tiles = big_cols * a.tiles_m;
+            if (rounds >= 1 && big_cols >= 1 && big_cols * BN < a.N) {
+                const int n_big = (int)(big_cols * BN);
+                GemmArgs th = a;
+                th.n_lo = n_big;
+                th.tiles_m = (a.M + 15) / 16;
+                const int thin_tiles_n = (a.N - n_big + 63) / 64;
+                a.N = n_big; // the whole tiles stop at n_big; output addressing is unchanged
+                a.tiles_n = n_big / BN;
+                const double frac_big = (double)n_big / th.N;
+                const int32_t rc = launch(multi ? 1 : 0, (unsigned)big_tiles, flops * frac_big, bytes * frac_big);
+                if (rc) return rc;
+                snprintf(kname, sizeof kname, "igemm_f32_thin_kernel<%d,%s>", BL, multi ? "true" : "false");
+                ProfScope ps(ctx, kname, flops * (1.0 - frac_big), bytes * (1.0 - frac_big));
+                const dim3 grid((unsigned)(th.tiles_m * thin_tiles_n), 1u);
+                if (multi) hipLaunchKernelGGL((igemm_f32_thin_kernel<BL, true>), grid, dim3(NTHREADS), 0, ctx->stream, th);
+                else hipLaunchKernelGGL((igemm_f32_thin_kernel<BL, false>), grid, dim3(NTHREADS), 0, ctx->stream, th);
+                RTEN_LAUNCH_CHECK(ctx, "igemm_f32_thin_kernel launch");
+                return RTEN_HIP_OK;
+            }
+        }
+    }
 
     bool mixed = false;
     if constexpr (kDma && BM * BN < 128 * 128) mixed = pipe == 1 && ntail > 0 && t1 > 0;
@@ -1367,7 +2044,7 @@ int32_t launch_variant(rten_hip_ctx *ctx, GemmArgs &a, int Z, int cfg) {
 }
 
 int pick_cfg(rten_hip_ctx *ctx, int M, long long N, int Z) {
-    if (ctx->gemm_variant_override >= 0 && ctx->gemm_variant_override < 16) return ctx->gemm_variant_override & 3;
+    if (ctx->gemm_variant_override >= 0 && ctx->gemm_variant_override < 24) return ctx->gemm_variant_override & 3;
     int best = 3;
     double best_cost = 1e300;
     for (int c = 0; c < 4; c++) {
@@ -1407,21 +2084,23 @@ constexpr long long kMaxBufBytes = 0x7fffffffll; // buffer offsets are 32-bit; t
 // variants 4..7: the same tile shapes with the register-staged pipeline; variants 8..11: LDS-DMA with
 // wave specialisation (4 MFMA waves + 4 loader waves); variants 12..15: LDS-DMA with four LDS stages.  Non-conv
 // operand layouts always use the register-staged kernel.
-RTEN_EXPORT int32_t rten_hip_num_gemm_variants(void) { return 16; }
+// Variants 16..19: LDS-DMA, fragments-first MFMA issue; variants 20..23: LDS-DMA on 16x16x4 MFMAs.
+RTEN_EXPORT int32_t rten_hip_num_gemm_variants(void) { return 24; }
 
 RTEN_EXPORT int32_t rten_hip_set_gemm_variant_override(rten_hip_ctx *ctx, int32_t variant) {
     RTEN_CHECK_CTX(ctx);
     ctx->gemm_variant_override = variant;
-    ctx->pipeline = (variant >= 12 && variant < 16) ? 3 : (variant >= 8 && variant < 12) ? 2 : ((variant >= 4 && variant < 8) ? 0 : 1);
+    ctx->pipeline = (variant >= 20 && variant < 24) ? 5 : (variant >= 16 && variant < 20) ? 4 : (variant >= 12 && variant < 16) ? 3 : (variant >= 8 && variant < 12) ? 2 : ((variant >= 4 && variant < 8) ? 0 : 1);
     return RTEN_HIP_OK;
 }
 
 // Exact split-K plan: mode 0 = off, 1 = split only the tiles past the last full round of num_cus workgroups (tail
 // balancing), 2 = split every tile, 3 = automatic (default: split every tile when fewer than num_cus/2 workgroups
-// would exist); `groups` = K groups per split tile (modes 1, 2).
+// would exist); `groups` = K groups per split tile (modes 1, 2).  Mode 4 is not a K split: whole rounds of tiles plus a tail of
+// thin 16x64 tiles on 16x16x4 MFMAs (convolutions; other calls run their plain plan).
 RTEN_EXPORT int32_t rten_hip_set_gemm_split(rten_hip_ctx *ctx, int32_t mode, int32_t groups) {
     RTEN_CHECK_CTX(ctx);
-    if (mode < 0 || mode > 3 || groups < 0) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "set_gemm_split: bad mode/groups");
+    if (mode < 0 || mode > 4 || groups < 0) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "set_gemm_split: bad mode/groups");
     ctx->split_mode = mode;
     ctx->split_s = groups;
     return RTEN_HIP_OK;

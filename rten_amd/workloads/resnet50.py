@@ -242,8 +242,11 @@ class ResNet50:
         plans = [(v, 0, 1, o) for v in range(nvar) for o in (0, 1)]
         d = self.descs[l["name"]]
         nblk = (d.c // d.groups * d.kh * d.kw + 255) // 256
+        dma = [v for v in range(nvar) if not 4 <= v < 12]  # LDS-DMA pipelines (3 / 4 stages, fragments-first, 16x16x4 MFMAs)
+        # thin-tile tail (mode 4): whole rounds with this tile shape + the remaining columns as 16x64 tiles on 16x16x4 MFMAs
+        plans += [(v, 4, 1, o) for v in dma for o in (0, 1)]
         if nblk > 1:
-            for v in (0, 1, 2, 3, 4, 5, 6, 7, 12, 13, 14, 15):  # LDS-DMA (3/4 stages) and register-staged pipelines; the wave-specialised kernel has no split form
+            for v in [v for v in range(nvar) if not (8 <= v < 12 or v >= 20)]:  # the wave-specialised and 16x16x4 kernels have no split form
                 for groups in sorted({2, 3, 4, 6, nblk} & set(range(2, nblk + 1))):
                     plans.append((v, 1, groups, 0))
                     for o in (0, 2, 3):

@@ -214,6 +214,35 @@ static void device_tests() {
         rto_gemm_int8(M, Nn, K, a.data(), 0, K, 1, bm.data(), 1, Nn, 1, mwant.data(), Nn, azp.data(), 1, nullptr, 0, 0);
         Tensor ta = Tensor::from_host(ctx, {M, K}, a.data()), tbm = Tensor::from_host(ctx, {K, Nn}, bm.data()), tz = Tensor::from_host(ctx, {}, azp.data());
         CHECK(MatMulInteger().run(ctx, {&ta, &tbm, &tz})[0].to_host<int32_t>() == mwant, "MatMulInteger bits");
+        // Operator::prepack (matmul.rs:696-705): the staged RHS gives the same bits
+        const MatMulInteger mmi;
+        const Tensor packed = mmi.prepack(ctx, tbm);
+        CHECK(packed.len() == (int64_t)rten_hip_gemm_int8_packed_bytes((int32_t)K, (int32_t)Nn) && packed.len() > 0, "MatMulInteger prepack size");
+        CHECK(mmi.run_scaled(ctx, {&ta, &tbm, &tz}, nullptr, &packed)[0].to_host<int32_t>() == mwant, "MatMulInteger prepacked bits");
+        // [A, M, K] x [K, N] collapses to one product and the row zero points cycle with period M (matmul.rs:259-296);
+        // a batched RHS runs as batched_gemm_uninit (:302-372)
+        const int64_t A3 = 3, M3 = 11;
+        std::vector<uint8_t> a3((size_t)(A3 * M3 * K)), azv((size_t)M3);
+        rto_rng_u8(&st, A3 * M3 * K, a3.data());
+        rto_rng_u8(&st, M3, azv.data());
+        std::vector<int8_t> b3((size_t)(A3 * K * Nn)), bzv((size_t)Nn);
+        rto_rng_i8_reduced(&st, A3 * K * Nn, b3.data());
+        rto_rng_i8_reduced(&st, Nn, bzv.data());
+        std::vector<int32_t> want1((size_t)(A3 * M3 * Nn)), want2(want1.size());
+        for (int64_t z = 0; z < A3; z++) {
+            rto_gemm_int8(M3, Nn, K, a3.data() + z * M3 * K, 0, K, 1, bm.data(), 1, Nn, 1, want1.data() + z * M3 * Nn, Nn, azv.data(), M3, bzv.data(), Nn, 0);
+            rto_gemm_int8(M3, Nn, K, a3.data() + z * M3 * K, 0, K, 1, b3.data() + z * K * Nn, 1, Nn, 1, want2.data() + z * M3 * Nn, Nn, azv.data(), M3, bzv.data(), Nn, 0);
+        }
+        Tensor ta3 = Tensor::from_host(ctx, {A3, M3, K}, a3.data()), tb3 = Tensor::from_host(ctx, {A3, K, Nn}, b3.data()), taz = Tensor::from_host(ctx, {M3}, azv.data()),
+               tbz = Tensor::from_host(ctx, {Nn}, bzv.data());
+        OutputList y1 = mmi.run(ctx, {&ta3, &tbm, &taz, &tbz});
+        CHECK((y1[0].shape() == std::vector<int64_t>{A3, M3, Nn}) && y1[0].to_host<int32_t>() == want1, "MatMulInteger [A,M,K]x[K,N] with cycled zero points");
+        CHECK(mmi.run_scaled(ctx, {&ta3, &tbm, &taz, &tbz}, nullptr, &packed)[0].to_host<int32_t>() == want1, "MatMulInteger collapsed + prepacked");
+        CHECK(mmi.run(ctx, {&ta3, &tb3, &taz, &tbz})[0].to_host<int32_t>() == want2, "MatMulInteger batched RHS");
+        Tensor tbad = Tensor::from_host(ctx, {2, K, Nn}, b3.data());
+        expect_error(OpError::IncompatibleInputShapes, "Cannot broadcast shapes", [&] { mmi.run(ctx, {&ta3, &tbad}); }, "MatMulInteger broadcast error");
+        Tensor tzbad = Tensor::from_host(ctx, {A3}, azv.data());
+        expect_error(OpError::InvalidValue, "Zero point has incorrect size", [&] { mmi.run(ctx, {&ta3, &tbm, &tzbad}); }, "MatMulInteger zero point size");
     }
     { // MaxPool, GlobalAveragePool
         const int64_t N = 2, C = 5, H = 12, W = 10;

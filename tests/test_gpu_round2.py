@@ -200,7 +200,7 @@ def test_matmul_integer_prepacked_rhs(ctx):
     # a prepacked RHS cannot be batched
     d.batch, d.b_bs = 2, 5
     with pytest.raises(L.HipError, match="single matrix"):
-        ctx.call("rten_hip_gemm_int8", C.byref(d), dev(ctx, a).vp, packed.vp, None, None, None, y.vp)
+        ctx.call("rten_hip_gemm_int8", C.byref(d), dev(ctx, a).vp, packed.vp, dev(ctx, np.array(7, np.uint8)).vp, None, None, y.vp)
 
 
 # ------------------------------------------------------------------------------------------ the boundary
@@ -338,3 +338,45 @@ def test_graph_conv_integer_per_channel_and_odd_scales(tmp_path):
         for extra in ((), ("--no-fuse",)):
             got, _ = _run_model(tmp_path, m, x, "y", *extra)
             assert np.array_equal(got.view(np.int32), want.ravel().view(np.int32)), (sshape, extra)
+
+
+# ------------------------------------------------------------------------------------------ f32 conv launch plans (round 2)
+def test_conv_f32_thin_tail_and_16x16_plans_bit_exact(ctx):
+    """The thin-tile tail plan (split mode 4: whole rounds of 256 tiles + 16x64 tiles on v_mfma_f32_16x16x4_f32), the
+    fragments-first variants (16..19) and the 16x16x4 variants (20..23) on geometries that leave a partial round: bits of the
+    oracle's k-ordered chain, for 1x1 (dense) and 3x3 (gather) layers, K below and above one depth block, with the fused
+    bias / residual / Relu epilogue."""
+    from tests.test_gpu_parity import gpu_conv
+    rng = ref.XorShiftRng(4242)
+    cases = [  # N, C, H, W, O, k, pad, stride  -> tiles of 64x64 = ceil(O/64) * ceil(N*OH*OW/64)
+        (9, 64, 56, 56, 64, 1, 0, 1),     # 441 tiles: one whole round + 185
+        (6, 40, 57, 57, 64, 3, 1, 1),     # K = 360 (two depth blocks), ragged width, 305 tiles
+        (8, 300, 29, 29, 130, 1, 0, 1),   # M tail (130 rows = 3 row tiles: the whole rounds hold 85 column tiles), K = 300
+        (12, 70, 60, 60, 128, 3, 1, 2),   # strided 3x3, K = 630 (three depth blocks), 338 tiles
+    ]
+    for (N, C_, H, W, O, k, pad, stride) in cases:
+        x = rng.f32(N * C_ * H * W).reshape(N, C_, H, W) - 0.5
+        w = (rng.f32(O * C_ * k * k).reshape(O, C_, k, k) - 0.5) * 0.2
+        b = rng.f32(O) - 0.5
+        oh = (H + 2 * pad - k) // stride + 1
+        res = rng.f32(N * O * oh * oh).reshape(N, O, oh, oh) - 0.5
+        want = ref.conv2d_f32(x, w, b, pads=(pad,) * 4, strides=(stride,) * 2, residual=res, relu=True)
+        for variant in (3, 2, 1, 0, 15, 19, 16, 23, 22, 21, 20):
+            for mode in (0, 4):
+                ctx.call("rten_hip_set_gemm_split", mode, 1)
+                try:
+                    got = gpu_conv(ctx, x, w, b, (pad,) * 4, (stride,) * 2, residual=res, relu=True, prepack=True, variant=variant)
+                finally:
+                    ctx.call("rten_hip_set_gemm_split", 3, 1)
+                try:
+                    bits_equal(got, want)
+                except AssertionError as e:
+                    raise AssertionError(f"conv N={N} C={C_} {H}x{W} O={O} k={k} variant={variant} split mode={mode}: {e}") from None
+    # the 16x16x4 GEMM path (row-major A, BERT projection form) incl. alpha / beta / per-column bias
+    M, K, Nn = 200, 300, 136
+    a, bm_ = rng.f32(M * K).reshape(M, K) - 0.5, rng.f32(K * Nn).reshape(K, Nn) - 0.5
+    c0, bias = rng.f32(M * Nn).reshape(M, Nn) - 0.5, rng.f32(Nn) - 0.5
+    from tests.test_gpu_parity import gpu_gemm
+    for variant in (20, 21, 22, 23, 16, 19):
+        bits_equal(gpu_gemm(ctx, a, bm_, c=c0.copy(), alpha=0.5, beta=0.75, bias=bias, bias_kind=L.BIAS_PER_COL, variant=variant),
+                   ref.gemm_f32(a, bm_, c=c0, alpha=0.5, beta=0.75, bias=bias, bias_kind=L.BIAS_PER_COL))
