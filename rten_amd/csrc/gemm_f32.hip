@@ -1355,6 +1355,335 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma16_kernel(const Gemm
     }
 }
 
+// =====================================================================================================
+// Persistent LDS-DMA kernel: a workgroup walks a LIST of tiles and its tile DMA runs two k-tiles ahead ACROSS tile boundaries.
+//
+// Why: a pure MFMA stream sustains 154.7 TFLOP/s on this chip (tools/probes/mfma_sustained.hip: 2381 MHz under load), yet the
+// one-tile-per-workgroup kernels above reach 80-105 on ResNet's layers.  Their tiles are short (K = 64 ... 576: 7 us of matrix
+// work) and every workgroup starts with ~2 us of load latency and ends with an epilogue that waits on its residual loads and
+// stores; all resident workgroups of a CU begin together and stay in lockstep, so those phases do not overlap anybody's MFMAs,
+// and the partial last round costs a whole tile latency.  Here a CU's resident workgroups live for the whole launch:
+//   * the loader (same DMA instructions, same LDS ring) keeps its own (tile, k-tile) position and simply continues into the next
+//     tile of the list, recomputing its per-lane source offsets when it crosses -- the first k-tiles of tile i+1 land while tile
+//     i's last MFMAs and epilogue run: no load bubble between tiles;
+//   * the launch-time prologue (kernarg loads, LUT warm-up, first DMA latency) is paid once per workgroup, not once per tile;
+//   * the grid is num_cus x R workgroups (R = split `groups` of plan mode 5), tiles are dealt round-robin inside each XCD's
+//     contiguous chunk (same L2 locality as the remapped ids above).
+// Numerics: per output element exactly the chain of the other kernels (k-ordered MFMA chain per depth block of 256, blocks
+// folded with separate adds, bias after the first block): bit-identical.  MF16 selects v_mfma_f32_16x16x4_f32 blocks.
+// =====================================================================================================
+template <int BM, int BN, int AL, int BL, bool MF16>
+__global__ __launch_bounds__(NTHREADS, (BM * BN >= 128 * 128) ? 1 : 2) void igemm_f32_pers_kernel(const GemmArgs p) {
+    static_assert(AL == A_M4 || AL == A_K4, "DMA kernel: A is k-major or row-major with 16-byte rows");
+    static_assert(BL == B_N4 || BL == B_IM2COL || BL == B_IM2COL_TAPS, "DMA kernel covers the conv operand layouts");
+    constexpr int WM = 2, WN = 2;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;    // 32x32 blocks per wave
+    constexpr int TM2 = BM / WM / 16, TN2 = BN / WN / 16;  // 16x16 blocks per wave
+    constexpr int STAGE = BK * (BM + BN);
+    constexpr int NA = BK * BM / 256 / 4;
+    constexpr int NBV = BK * BN / 256 / 4;
+    constexpr int NBG = BK * BN / 64 / 4;
+    constexpr int PER_TILE = NA + (BL == B_N4 ? NBV : NBG);
+    constexpr int NSTAGE = 3;
+    constexpr bool IM2COL = BL == B_IM2COL || BL == B_IM2COL_TAPS, TAPS = BL == B_IM2COL_TAPS;
+    constexpr int NCOL = IM2COL && BN == 128 ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) float smem[NSTAGE * STAGE];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int z = blockIdx.y;
+
+    // ---- this workgroup's tile list: XCD x = id & 7 owns the contiguous chunk [lo, lo + cnt) of the launch's tiles (as the
+    // remapped ids of the one-tile kernels), its workgroups j = id >> 3 take tiles lo + j, lo + j + gx, ...
+    const int T = p.tiles_m * p.tiles_n;
+    int t_next, t_end, t_step;
+    {
+        const int id = blockIdx.x, G = (int)gridDim.x;
+        const int xcd = id & 7, q = T >> 3, r = T & 7;
+        const int lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        const int cnt = q + (xcd < r ? 1 : 0);
+        t_step = (G - xcd + 7) >> 3; // workgroups on this XCD
+        t_next = lo + (id >> 3);
+        t_end = lo + cnt;
+    }
+    if (t_next >= t_end) return; // more workgroups than tiles on this XCD (uniform per workgroup: no barrier is skipped by part of it)
+
+    int zo = z, zi = 0;
+    if (p.batch_inner > 1) { zo = z / p.batch_inner; zi = z - zo * p.batch_inner; }
+    const float *Ab = p.A + (long long)zo * p.a_bs + (long long)zi * p.a_bsi;
+    const float *Bb = p.B + (long long)zo * p.b_bs + (long long)zi * p.b_bsi;
+    const long long c_zoff = (long long)zo * p.c_bs + (long long)zi * p.c_bsi;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)Ab, 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void *)Bb, 0, (int)p.b_bytes, 0x00020000);
+    const int nk = (p.K + BK - 1) / BK;
+    const unsigned a_kstep = AL == A_M4 ? (unsigned)(BK * p.a_cs * 4) : (unsigned)(BK * 4);
+    const unsigned b_kstep = BL == B_N4 ? (unsigned)(BK * p.b_rs * 4) : 0u;
+
+    // ---- loader state: position (l_tile, l_kt) in this workgroup's stream of k-tiles and the per-lane source offsets of l_tile
+    int l_tile = t_next, l_kt = 0;
+    bool l_dead = false; // past the last tile of the list: the ring keeps turning on zero-fill loads
+    unsigned a_voff[NA];
+    [[maybe_unused]] int a_kq[NA];
+    [[maybe_unused]] unsigned b_voff[BL == B_N4 ? NBV : 1];
+    [[maybe_unused]] int b_krow[BL == B_N4 ? NBV : 1];
+    [[maybe_unused]] int im_iy0[NCOL], im_ix0[NCOL], im_pix[NCOL];
+    [[maybe_unused]] unsigned im_inv[NCOL];
+    auto tile_origin = [&](int tile, int &m0, int &n0) {
+        const int bm = (p.order & 1) ? tile / p.tiles_n : tile % p.tiles_m, bn = (p.order & 1) ? tile % p.tiles_n : tile / p.tiles_m;
+        m0 = bm * BM;
+        n0 = bn * BN;
+    };
+    auto setup_loader = [&](int tile) {
+        int m0, n0;
+        tile_origin(tile, m0, n0);
+#pragma unroll
+        for (int j = 0; j < NA; j++) {
+            if constexpr (AL == A_M4) {
+                const int f = (wave * NA + j) * 256 + lane * 4;
+                const int k = f / BM, m = m0 + f % BM;
+                a_voff[j] = m < (int)p.a_cs ? (unsigned)(((long long)k * p.a_cs + m) * 4) : OOB;
+            } else {
+                const int q = wave * NA + j, kq = q / (BM / 64), m = m0 + (q % (BM / 64)) * 64 + lane;
+                a_kq[j] = kq * 4;
+                a_voff[j] = m < p.M ? (unsigned)(((long long)m * p.a_rs + kq * 4) * 4) : OOB;
+            }
+        }
+        if constexpr (BL == B_N4) {
+#pragma unroll
+            for (int j = 0; j < NBV; j++) {
+                const int f = (wave * NBV + j) * 256 + lane * 4;
+                const int k = f / BN, n = n0 + f % BN;
+                const int nn = n < p.N ? n : 0;
+                const int nb = nn / p.Pn, np = nn - nb * p.Pn;
+                b_krow[j] = k;
+                b_voff[j] = n < p.N ? (unsigned)(((long long)k * p.b_rs + (long long)nb * p.b_ns + np) * 4) : OOB;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < BN / 64; c++) {
+                const int n = n0 + c * 64 + lane;
+                const bool ok = n < p.N;
+                const int nn = ok ? n : 0;
+                const int nb = nn / p.Pn, np = nn - nb * p.Pn;
+                const int oy = np / p.OW, ox = np - oy * p.OW;
+                im_iy0[c] = ok ? oy * p.sy - p.pt : -0x40000000;
+                im_ix0[c] = ox * p.sx - p.pl;
+                im_pix[c] = (int)((long long)nb * p.b_ns) + (oy * p.sy - p.pt) * p.W + im_ix0[c];
+                if constexpr (TAPS) {
+                    unsigned colbad = 0;
+                    for (int kx = 0; kx < p.KW; kx++) colbad |= ((unsigned)(im_ix0[c] + kx * p.dx) >= (unsigned)p.W ? 1u : 0u) << kx;
+                    const unsigned allbad = (1u << p.KW) - 1u;
+                    unsigned inv = 0x80000000u;
+                    for (int ky = 0; ky < p.KH; ky++)
+                        inv |= ((unsigned)(im_iy0[c] + ky * p.dy) >= (unsigned)p.H ? allbad : colbad) << (ky * p.KW);
+                    im_inv[c] = inv;
+                }
+            }
+        }
+    };
+
+    typedef const __attribute__((address_space(4))) i32x2 *lut_ptr_t;
+    constexpr int LROWS = BK / 4;
+    [[maybe_unused]] i32x2 lutE[LROWS];
+    [[maybe_unused]] auto fetch_lut = [&](int kt) { // LUT rows of the k-tile the loader issues NEXT (one table per conv geometry: tile independent)
+        if constexpr (IM2COL) {
+            const int krow0 = kt * BK + wave * LROWS;
+            const lut_ptr_t lc = (lut_ptr_t)(unsigned long long)p.lut;
+#pragma unroll
+            for (int j = 0; j < LROWS; j++) lutE[j] = lc[krow0 + j];
+        }
+    };
+
+    typedef __attribute__((address_space(3))) void *lds_ptr_t;
+    auto issue_tile = [&](int stage) { // DMA of (l_tile, l_kt) into `stage`, then advance the loader
+        float *As = smem + stage * STAGE;
+        float *Bs = As + BK * BM;
+        const int kt = l_kt;
+        const unsigned a_soff = (unsigned)kt * a_kstep;
+#pragma unroll
+        for (int j = 0; j < NA; j++) {
+            bool dead = l_dead;
+            if constexpr (AL == A_K4) dead = dead || a_kq[j] >= p.K - kt * BK;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(As + (wave * NA + j) * 256), 16, (int)(dead ? OOB : a_voff[j]), (int)(l_dead ? 0u : a_soff), 0, 0);
+        }
+        if constexpr (BL == B_N4) {
+            const int kleft = p.K - kt * BK;
+            const unsigned b_soff = (unsigned)kt * b_kstep;
+#pragma unroll
+            for (int j = 0; j < NBV; j++)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(Bs + (wave * NBV + j) * 256), 16,
+                                                         (int)((!l_dead && b_krow[j] < kleft) ? b_voff[j] : OOB), (int)(l_dead ? 0u : b_soff), 0, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NBG; j++) {
+                constexpr int CPR = BN / 64;
+                const int r = j / CPR, c = j % CPR;
+                const i32x2 e = lutE[r];
+                unsigned voff;
+                if constexpr (TAPS) {
+                    voff = ((im_inv[c] << e[1]) & 0x80000000u) | ((unsigned)(im_pix[c] + e[0]) << 2);
+                } else {
+                    const int iy = im_iy0[c] + (e[1] & 0xffff);
+                    const int ix = im_ix0[c] + (e[1] >> 16);
+                    const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+                    voff = ok ? (unsigned)(im_pix[c] + e[0]) << 2 : OOB;
+                }
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(Bs + (wave * LROWS + r) * BN + c * 64), 4, (int)(l_dead ? OOB : voff), 0, 0, 0);
+            }
+        }
+        // advance: next k-tile of this tile, or the first k-tile of the next tile of the list (new per-lane offsets)
+        if (!l_dead) {
+            if (++l_kt == nk) {
+                l_kt = 0;
+                l_tile += t_step;
+                if (l_tile < t_end) setup_loader(l_tile);
+                else l_dead = true;
+            }
+        }
+        fetch_lut(l_kt);
+    };
+
+    // ---- accumulators
+    const int wq = t >> 6;
+    const int wm0 = (wq / WN) * (BM / WM), wn0 = (wq % WN) * (BN / WN);
+    const int l31 = lane & 31, half = lane >> 5, l15 = lane & 15, quad = lane >> 4;
+    f32x16 acc[MF16 ? 1 : TM][MF16 ? 1 : TN], tot[MF16 ? 1 : TM][MF16 ? 1 : TN];
+    f32x4v acc4[MF16 ? TM2 : 1][MF16 ? TN2 : 1], tot4[MF16 ? TM2 : 1][MF16 ? TN2 : 1];
+    auto zero_acc = [&]() {
+        if constexpr (MF16) {
+#pragma unroll
+            for (int i = 0; i < TM2; i++)
+#pragma unroll
+                for (int j = 0; j < TN2; j++) acc4[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+        }
+    };
+
+    auto compute_tile = [&](int stage) {
+        if constexpr (MF16) {
+            const float *As = smem + stage * STAGE + (AL == A_M4 ? wm0 + l15 + quad * BM : (wm0 + l15) * 4 + quad);
+            auto a_idx = [](int ks, int i) { return AL == A_M4 ? 4 * ks * BM + i * 16 : ks * BM * 4 + i * 64; };
+            const float *Bs = smem + stage * STAGE + BK * BM + wn0 + l15 + quad * BN;
+            float af[2][TM2], bf[2][TN2];
+#pragma unroll
+            for (int i = 0; i < TM2; i++) af[0][i] = As[a_idx(0, i)];
+#pragma unroll
+            for (int j = 0; j < TN2; j++) bf[0][j] = Bs[j * 16];
+#pragma unroll
+            for (int ks = 0; ks < BK / 4; ks++) {
+                const int cur = ks & 1, nxt = cur ^ 1;
+                if (ks + 1 < BK / 4) {
+#pragma unroll
+                    for (int i = 0; i < TM2; i++) af[nxt][i] = As[a_idx(ks + 1, i)];
+#pragma unroll
+                    for (int j = 0; j < TN2; j++) bf[nxt][j] = Bs[4 * (ks + 1) * BN + j * 16];
+                }
+#pragma unroll
+                for (int i = 0; i < TM2; i++)
+#pragma unroll
+                    for (int j = 0; j < TN2; j++) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][i], bf[cur][j], acc4[i][j], 0, 0, 0);
+            }
+        } else {
+            const float *As = smem + stage * STAGE + (AL == A_M4 ? wm0 + l31 + half * BM : (wm0 + l31) * 4 + half);
+            auto a_idx = [](int kk, int i) { return AL == A_M4 ? 2 * kk * BM + i * 32 : (kk >> 1) * BM * 4 + ((2 * kk) & 3) + i * 128; };
+            const float *Bs = smem + stage * STAGE + BK * BM + wn0 + l31;
+            float af[2][TM], bf[2][TN];
+#pragma unroll
+            for (int i = 0; i < TM; i++) af[0][i] = As[a_idx(0, i)];
+#pragma unroll
+            for (int j = 0; j < TN; j++) bf[0][j] = Bs[half * BN + j * 32];
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; kk++) {
+                const int cur = kk & 1, nxt = cur ^ 1;
+                if (kk + 1 < BK / 2) {
+#pragma unroll
+                    for (int i = 0; i < TM; i++) af[nxt][i] = As[a_idx(kk + 1, i)];
+#pragma unroll
+                    for (int j = 0; j < TN; j++) bf[nxt][j] = Bs[(2 * (kk + 1) + half) * BN + j * 32];
+                }
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_iglp_opt(0);
+    };
+
+    // fold of a finished depth block into `tot` / epilogue of a finished tile (the helpers of the one-tile kernels)
+    auto flush = [&](bool first, int m0, int n0) {
+        if constexpr (MF16) {
+            int mb = m0 + wm0 + 4 * quad, nb0 = n0 + wn0 + l15;
+            asm volatile("" : "+v"(mb), "+v"(nb0));
+            if (first) fold_first16<TM2, TN2>(p, z, acc4, tot4, mb, nb0, c_zoff);
+            else fold_next16<TM2, TN2>(p, acc4, tot4);
+        } else {
+            int mb = m0 + wm0 + 4 * half, nb0 = n0 + wn0 + l31;
+            asm volatile("" : "+v"(mb), "+v"(nb0));
+            if (first) fold_first<TM, TN>(p, z, acc, tot, mb, nb0, c_zoff);
+            else fold_next<TM, TN>(p, acc, tot);
+        }
+        zero_acc();
+    };
+    auto finish = [&](bool single_block, int m0, int n0) {
+        if constexpr (MF16) {
+            int mb = m0 + wm0 + 4 * quad, nb0 = n0 + wn0 + l15;
+            asm volatile("" : "+v"(mb), "+v"(nb0));
+            if (single_block) {
+                fold_first16<TM2, TN2>(p, z, acc4, acc4, mb, nb0, c_zoff);
+                store_out16<TM2, TN2>(p, acc4, mb, nb0, c_zoff);
+            } else {
+                fold_next16<TM2, TN2>(p, acc4, tot4);
+                store_out16<TM2, TN2>(p, tot4, mb, nb0, c_zoff);
+            }
+        } else {
+            int mb = m0 + wm0 + 4 * half, nb0 = n0 + wn0 + l31;
+            asm volatile("" : "+v"(mb), "+v"(nb0));
+            if (single_block) {
+                fold_first<TM, TN>(p, z, acc, acc, mb, nb0, c_zoff);
+                store_out<TM, TN>(p, acc, mb, nb0, c_zoff);
+            } else {
+                fold_next<TM, TN>(p, acc, tot);
+                store_out<TM, TN>(p, tot, mb, nb0, c_zoff);
+            }
+        }
+        zero_acc();
+    };
+
+    // ---- the ring: NSTAGE - 1 k-tiles in flight before the first MFMA, then one barrier per k-tile for the whole list
+    setup_loader(l_tile);
+    fetch_lut(0);
+#pragma unroll
+    for (int i = 0; i < NSTAGE - 1; i++) issue_tile(i);
+    zero_acc();
+    int stage = 0;
+    const bool single_block = nk <= KC_TILES;
+    for (int c_tile = t_next; c_tile < t_end; c_tile += t_step) {
+        int m0, n0;
+        tile_origin(c_tile, m0, n0);
+        for (int kt = 0; kt < nk; kt++) {
+            // this wave's DMA for this k-tile has landed (younger loads: one more k-tile; stores of the previous tile's epilogue
+            // can only make the count conservative: loads retire in order among themselves)
+            wait_vmcnt<PER_TILE *(NSTAGE - 2)>();
+            __builtin_amdgcn_s_barrier(); // ... and everyone else's; all waves are done reading the stage refilled next
+            const int stp = stage == 0 ? NSTAGE - 1 : stage - 1;
+            issue_tile(stp);
+            compute_tile(stage);
+            stage = stage == NSTAGE - 1 ? 0 : stage + 1;
+            if (!single_block && kt + 1 < nk && (kt + 1) % KC_TILES == 0) flush(kt + 1 == KC_TILES, m0, n0);
+        }
+        finish(single_block, m0, n0);
+    }
+    wait_vmcnt<0>(); // the zero-fill look-ahead loads must land before the LDS goes away
+}
+
 template <int BM, int BN, int BL, bool MULTI_KC>
 __global__ __launch_bounds__(2 * NTHREADS, 2) void igemm_f32_ws_kernel(const GemmArgs p) {
     static_assert(BL == B_N4 || BL == B_IM2COL || BL == B_IM2COL_TAPS, "DMA kernel covers the conv operand layouts");
@@ -1977,6 +2306,23 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
         return RTEN_HIP_OK;
     };
 
+    // Persistent plan (split mode 5, groups = resident workgroups per compute unit): one launch of num_cus x groups workgroups
+    // that walk the tile list with the tile DMA running across tile boundaries (igemm_f32_pers_kernel).
+    if constexpr (kDma) {
+        if (ctx->split_mode == 5 && (pipe == 1 || pipe == 5) && T > 1) {
+            int per_cu = ctx->split_s < 1 ? 1 : (ctx->split_s > 4 ? 4 : ctx->split_s);
+            long long G = (long long)ctx->num_cus * per_cu;
+            if (G > T) G = T;
+            snprintf(kname, sizeof kname, "igemm_f32_pers_kernel<%d,%d,%d,%d,%s>", BM, BN, AL, BL, pipe == 5 ? "true" : "false");
+            ProfScope ps(ctx, kname, flops, bytes);
+            const dim3 grid((unsigned)G, (unsigned)Z);
+            if (pipe == 5) hipLaunchKernelGGL((igemm_f32_pers_kernel<BM, BN, AL, BL, true>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+            else hipLaunchKernelGGL((igemm_f32_pers_kernel<BM, BN, AL, BL, false>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+            RTEN_LAUNCH_CHECK(ctx, "igemm_f32_pers_kernel launch");
+            return RTEN_HIP_OK;
+        }
+    }
+
     // Thin-tile tail plan (split mode 4; convolution form alpha = 1, beta = 0, one group): the whole rounds of num_cus tiles go
     // to this tile shape over columns [0, n_big), the remaining columns to the 16x64 kernel on 16x16x4 MFMAs, whose quarter-size
     // per-SIMD blocks finish the tail in a quarter of a round (see igemm_f32_thin_kernel).  Same bits as any other plan.
@@ -2100,7 +2446,7 @@ RTEN_EXPORT int32_t rten_hip_set_gemm_variant_override(rten_hip_ctx *ctx, int32_
 // thin 16x64 tiles on 16x16x4 MFMAs (convolutions; other calls run their plain plan).
 RTEN_EXPORT int32_t rten_hip_set_gemm_split(rten_hip_ctx *ctx, int32_t mode, int32_t groups) {
     RTEN_CHECK_CTX(ctx);
-    if (mode < 0 || mode > 4 || groups < 0) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "set_gemm_split: bad mode/groups");
+    if (mode < 0 || mode > 5 || groups < 0) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "set_gemm_split: bad mode/groups");
     ctx->split_mode = mode;
     ctx->split_s = groups;
     return RTEN_HIP_OK;

@@ -342,7 +342,7 @@ def test_graph_conv_integer_per_channel_and_odd_scales(tmp_path):
 
 # ------------------------------------------------------------------------------------------ f32 conv launch plans (round 2)
 def test_conv_f32_thin_tail_and_16x16_plans_bit_exact(ctx):
-    """The thin-tile tail plan (split mode 4: whole rounds of 256 tiles + 16x64 tiles on v_mfma_f32_16x16x4_f32), the
+    """The persistent plan (split mode 5: num_cus x groups workgroups walking tile lists), the thin-tile tail plan (split mode 4: whole rounds of 256 tiles + 16x64 tiles on v_mfma_f32_16x16x4_f32), the
     fragments-first variants (16..19) and the 16x16x4 variants (20..23) on geometries that leave a partial round: bits of the
     oracle's k-ordered chain, for 1x1 (dense) and 3x3 (gather) layers, K below and above one depth block, with the fused
     bias / residual / Relu epilogue."""
@@ -361,9 +361,10 @@ def test_conv_f32_thin_tail_and_16x16_plans_bit_exact(ctx):
         oh = (H + 2 * pad - k) // stride + 1
         res = rng.f32(N * O * oh * oh).reshape(N, O, oh, oh) - 0.5
         want = ref.conv2d_f32(x, w, b, pads=(pad,) * 4, strides=(stride,) * 2, residual=res, relu=True)
-        for variant in (3, 2, 1, 0, 15, 19, 16, 23, 22, 21, 20):
-            for mode in (0, 4):
-                ctx.call("rten_hip_set_gemm_split", mode, 1)
+        for variant, mode, groups in [(v, m, 1) for v in (3, 2, 1, 0, 15, 19, 16, 23, 22, 21, 20) for m in (0, 4)] + \
+                                     [(v, 5, r) for v in (3, 2, 1, 0, 23, 22, 21, 20) for r in (1, 2, 3)]:
+            if True:
+                ctx.call("rten_hip_set_gemm_split", mode, groups)
                 try:
                     got = gpu_conv(ctx, x, w, b, (pad,) * 4, (stride,) * 2, residual=res, relu=True, prepack=True, variant=variant)
                 finally:
@@ -371,12 +372,18 @@ def test_conv_f32_thin_tail_and_16x16_plans_bit_exact(ctx):
                 try:
                     bits_equal(got, want)
                 except AssertionError as e:
-                    raise AssertionError(f"conv N={N} C={C_} {H}x{W} O={O} k={k} variant={variant} split mode={mode}: {e}") from None
+                    raise AssertionError(f"conv N={N} C={C_} {H}x{W} O={O} k={k} variant={variant} split mode={mode} groups={groups}: {e}") from None
     # the 16x16x4 GEMM path (row-major A, BERT projection form) incl. alpha / beta / per-column bias
     M, K, Nn = 200, 300, 136
     a, bm_ = rng.f32(M * K).reshape(M, K) - 0.5, rng.f32(K * Nn).reshape(K, Nn) - 0.5
     c0, bias = rng.f32(M * Nn).reshape(M, Nn) - 0.5, rng.f32(Nn) - 0.5
     from tests.test_gpu_parity import gpu_gemm
+    want = ref.gemm_f32(a, bm_, c=c0, alpha=0.5, beta=0.75, bias=bias, bias_kind=L.BIAS_PER_COL)
     for variant in (20, 21, 22, 23, 16, 19):
-        bits_equal(gpu_gemm(ctx, a, bm_, c=c0.copy(), alpha=0.5, beta=0.75, bias=bias, bias_kind=L.BIAS_PER_COL, variant=variant),
-                   ref.gemm_f32(a, bm_, c=c0, alpha=0.5, beta=0.75, bias=bias, bias_kind=L.BIAS_PER_COL))
+        bits_equal(gpu_gemm(ctx, a, bm_, c=c0.copy(), alpha=0.5, beta=0.75, bias=bias, bias_kind=L.BIAS_PER_COL, variant=variant), want)
+    for variant in (0, 3, 20, 23):  # persistent plan on the plain GEMM form (row-major A), fewer tiles than workgroups
+        ctx.call("rten_hip_set_gemm_split", 5, 2)
+        try:
+            bits_equal(gpu_gemm(ctx, a, bm_, c=c0.copy(), alpha=0.5, beta=0.75, bias=bias, bias_kind=L.BIAS_PER_COL, variant=variant), want)
+        finally:
+            ctx.call("rten_hip_set_gemm_split", 3, 1)
