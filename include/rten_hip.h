@@ -401,8 +401,9 @@ int32_t rten_hip_num_gemm_variants(void);
  * multiple of the compute units runs its whole rounds with the selected tile shape and the remaining columns as thin
  * 16 x 64 tiles on v_mfma_f32_16x16x4_f32 (a quarter of the per-SIMD work, so the partial last round costs a quarter of
  * a round); other calls ignore it.  Mode 5: persistent launch of (compute units x groups) workgroups, each walking a list of
- * tiles with its tile DMA running across tile boundaries (LDS-DMA variants 0..3 and 20..23; others ignore it).  A tuning knob
- * like the variant override: sticky. */
+ * tiles with its tile DMA running across tile boundaries (LDS-DMA variants 0..3 and 20..23; others ignore it).  Mode 6: the
+ * lean form of mode 5 for convolutions with 64 x 64 tiles and K a multiple of 32 (k-tiles of 32, no selects or table waits in
+ * the loop); other calls ignore it.  A tuning knob like the variant override: sticky. */
 int32_t rten_hip_set_gemm_split(rten_hip_ctx *ctx, int32_t mode, int32_t groups);
 /* Workgroup -> tile order (tuning knob, sticky, default 0): bit 0 = tiles walk n fastest instead of m fastest;
  * bit 1 = split-K workgroups walk tiles fastest and K groups slowest, so that each XCD's private L2 holds one K

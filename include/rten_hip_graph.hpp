@@ -543,6 +543,8 @@ class Graph {
         for (int v = 0; v < nvar; v++) if (v < 4 || v >= 12) for (int o = 0; o < 2; o++) plans.push_back(GemmPlan{true, v, 4, 1, o});
         // persistent plan (split mode 5, groups = workgroups per compute unit): tile list per workgroup, DMA across tile boundaries
         for (int v : {0, 1, 2, 3, 20, 21, 22, 23}) if (v < nvar) for (int r = 1; r <= 4; r++) for (int o = 0; o < 2; o++) plans.push_back(GemmPlan{true, v, 5, r, o});
+        // lean persistent kernel (split mode 6: 64x64 tiles, K a multiple of 32)
+        for (int r = 1; r <= 3; r++) for (int o = 0; o < 2; o++) plans.push_back(GemmPlan{true, 3, 6, r, o});
         if (nblk > 1) {
             static const int split_variants[] = {0, 1, 2, 3, 4, 5, 6, 7, 12, 13, 14, 15, 16, 17, 18, 19};
             for (int v : split_variants) {

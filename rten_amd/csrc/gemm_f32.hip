@@ -1372,7 +1372,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma16_kernel(const Gemm
 // Numerics: per output element exactly the chain of the other kernels (k-ordered MFMA chain per depth block of 256, blocks
 // folded with separate adds, bias after the first block): bit-identical.  MF16 selects v_mfma_f32_16x16x4_f32 blocks.
 // =====================================================================================================
-template <int BM, int BN, int AL, int BL, bool MF16>
+template <int BM, int BN, int AL, int BL, bool MF16, int MFK = 0>
 __global__ __launch_bounds__(NTHREADS, (BM * BN >= 128 * 128) ? 1 : 2) void igemm_f32_pers_kernel(const GemmArgs p) {
     static_assert(AL == A_M4 || AL == A_K4, "DMA kernel: A is k-major or row-major with 16-byte rows");
     static_assert(BL == B_N4 || BL == B_IM2COL || BL == B_IM2COL_TAPS, "DMA kernel covers the conv operand layouts");
@@ -1594,6 +1594,25 @@ __global__ __launch_bounds__(NTHREADS, (BM * BN >= 128 * 128) ? 1 : 2) void igem
             const float *As = smem + stage * STAGE + (AL == A_M4 ? wm0 + l31 + half * BM : (wm0 + l31) * 4 + half);
             auto a_idx = [](int kk, int i) { return AL == A_M4 ? 2 * kk * BM + i * 32 : (kk >> 1) * BM * 4 + ((2 * kk) & 3) + i * 128; };
             const float *Bs = smem + stage * STAGE + BK * BM + wn0 + l31;
+            if constexpr (MFK == 1) { // every fragment of the k-tile first, then the MFMAs with nothing between them
+                float afa[BK / 2][TM], bfa[BK / 2][TN];
+#pragma unroll
+                for (int kk = 0; kk < BK / 2; kk++) {
+#pragma unroll
+                    for (int i = 0; i < TM; i++) afa[kk][i] = As[a_idx(kk, i)];
+#pragma unroll
+                    for (int j = 0; j < TN; j++) bfa[kk][j] = Bs[(2 * kk + half) * BN + j * 32];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kk = 0; kk < BK / 2; kk++)
+#pragma unroll
+                    for (int i = 0; i < TM; i++)
+#pragma unroll
+                        for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(afa[kk][i], bfa[kk][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                return;
+            }
             float af[2][TM], bf[2][TN];
 #pragma unroll
             for (int i = 0; i < TM; i++) af[0][i] = As[a_idx(0, i)];
@@ -1665,23 +1684,269 @@ __global__ __launch_bounds__(NTHREADS, (BM * BN >= 128 * 128) ? 1 : 2) void igem
     zero_acc();
     int stage = 0;
     const bool single_block = nk <= KC_TILES;
+#ifdef RTEN_TRACE
+    unsigned long long tr_seg[5] = {0, 0, 0, 0, 0}, tr_n = 0, tr_prev = __builtin_readcyclecounter();
+#define RTEN_STAMP(i) { const unsigned long long now_ = __builtin_readcyclecounter(); tr_seg[i] += now_ - tr_prev; tr_prev = now_; }
+#else
+#define RTEN_STAMP(i)
+#endif
     for (int c_tile = t_next; c_tile < t_end; c_tile += t_step) {
         int m0, n0;
         tile_origin(c_tile, m0, n0);
         for (int kt = 0; kt < nk; kt++) {
+            RTEN_STAMP(4)
             // this wave's DMA for this k-tile has landed (younger loads: one more k-tile; stores of the previous tile's epilogue
             // can only make the count conservative: loads retire in order among themselves)
-            wait_vmcnt<PER_TILE *(NSTAGE - 2)>();
-            __builtin_amdgcn_s_barrier(); // ... and everyone else's; all waves are done reading the stage refilled next
+            if (!(ABLATE(p) & 32)) wait_vmcnt<PER_TILE *(NSTAGE - 2)>();
+            RTEN_STAMP(0)
+            if (!(ABLATE(p) & 8)) __builtin_amdgcn_s_barrier(); // ... and everyone else's; all waves are done reading the stage refilled next
+            RTEN_STAMP(1)
             const int stp = stage == 0 ? NSTAGE - 1 : stage - 1;
-            issue_tile(stp);
-            compute_tile(stage);
+            if (!(ABLATE(p) & 1)) issue_tile(stp);
+            RTEN_STAMP(2)
+            if (ABLATE(p) & 16) { // ablation: the k-tile's MFMAs on register operands (no ds_read)
+                if constexpr (!MF16) {
+                    float fa = (float)kt, fb = (float)lane;
+#pragma unroll
+                    for (int kk = 0; kk < BK / 2; kk++)
+#pragma unroll
+                        for (int i = 0; i < TM; i++)
+#pragma unroll
+                            for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[i][j], 0, 0, 0);
+                }
+            } else if (!(ABLATE(p) & 2)) compute_tile(stage);
+            RTEN_STAMP(3)
+#ifdef RTEN_TRACE
+            tr_n++;
+#endif
             stage = stage == NSTAGE - 1 ? 0 : stage + 1;
             if (!single_block && kt + 1 < nk && (kt + 1) % KC_TILES == 0) flush(kt + 1 == KC_TILES, m0, n0);
         }
         finish(single_block, m0, n0);
     }
     wait_vmcnt<0>(); // the zero-fill look-ahead loads must land before the LDS goes away
+#ifdef RTEN_TRACE
+    if (blockIdx.x == 8 && blockIdx.y == 0 && lane == 0 && (wave == 0 || wave == 3))
+        printf("[trace] wave %d: %llu k-tiles; cycles per k-tile: vmcnt wait %.0f, barrier %.0f, DMA issue + loader advance %.0f, fragments + MFMA issue %.0f, loop / fold / epilogue %.0f\n",
+               wave, tr_n, (double)tr_seg[0] / tr_n, (double)tr_seg[1] / tr_n, (double)tr_seg[2] / tr_n, (double)tr_seg[3] / tr_n, (double)tr_seg[4] / tr_n);
+#endif
+#undef RTEN_STAMP
+}
+
+// =====================================================================================================
+// Lean persistent kernel: 64x64 tiles, k-tiles of 32, prepacked (k-major) weights, dense or tap-masked im2col B.
+//
+// tools/probes/kloop.hip builds the k-loop of the kernels above piece by piece: 8 dependent MFMAs + their 16 LDS fragment reads
+// + one barrier + the tile DMA cost a wave 666 cycles per k-tile (512 = matrix pipe) when NOTHING else is in the loop -- 120-130
+// TFLOP/s with one or two workgroups per compute unit -- while the general kernels spend 1400: per-DMA selects for k-tails and
+// dead tiles, LUT loads whose lgkmcnt(0) wait lands in the MFMA phase, depth-block / split / ablation branches, spilled scalars.
+// This kernel is the probe's loop made real for the shapes that carry ResNet-50 (K a multiple of 32, alpha = 1, beta = 0):
+//   * persistent workgroups walking an XCD-chunked tile list, DMA two k-tiles ahead across tile boundaries (as the kernel above);
+//   * per k-tile and wave: 2 + 2 dwordx4 DMA (dense) or 2 + 8 dword gathers, 32 fragment reads, 16 MFMAs, ONE barrier; DMA source
+//     offsets are plain per-tile registers (no selects: rows past K do not exist, rows past M / columns past N are out-of-range
+//     offsets fixed at tile setup), the LUT rows of the k-tile after next are fetched by one s_load_dwordx16 AFTER the MFMAs are
+//     issued, the tile-crossing bookkeeping sits in a cold branch;
+//   * depth blocks of 256 = 8 k-tiles: the fold is one compare per k-tile.
+// Numerics are those of every other kernel in this file (same chain per element): bit-identical.
+// =====================================================================================================
+constexpr int LBK = 32; // k-tile depth of the lean kernel
+
+template <int BL, int NSTAGE = 3>
+__global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_lean_kernel(const GemmArgs p) {
+    static_assert(BL == B_N4 || BL == B_IM2COL_TAPS, "lean kernel: dense or tap-masked im2col B");
+    constexpr int BM = 64, BN = 64;
+    constexpr int STAGE = LBK * (BM + BN); // floats
+    constexpr int NBG = LBK * BN / 64 / 4; // gather rows per wave per k-tile = 8
+    constexpr int PER_TILE = 2 + (BL == B_N4 ? 2 : NBG);
+    constexpr bool TAPS = BL == B_IM2COL_TAPS;
+    __shared__ __attribute__((aligned(16))) float smem[NSTAGE * STAGE];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wq = t >> 6;
+    const int wm0 = (wq >> 1) * 32, wn0 = (wq & 1) * 32;
+
+    const int T = p.tiles_m * p.tiles_n;
+    int t_next, t_end, t_step;
+    {
+        const int id = blockIdx.x, G = (int)gridDim.x;
+        const int xcd = id & 7, q = T >> 3, r = T & 7;
+        const int lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        t_step = (G - xcd + 7) >> 3;
+        t_next = lo + (id >> 3);
+        t_end = lo + q + (xcd < r ? 1 : 0);
+    }
+    if (t_next >= t_end) return;
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)p.A, 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void *)p.B, 0, (int)p.b_bytes, 0x00020000);
+    const int nk = p.K / LBK;
+    const unsigned a_kstep = (unsigned)(LBK * p.a_cs * 4);
+    const unsigned b_kstep = BL == B_N4 ? (unsigned)(LBK * p.b_rs * 4) : 0u;
+
+    // ---- loader: (l_tile, l_kt) and the per-lane source offsets of l_tile (out-of-range lanes carry OOB: no select in the loop)
+    int l_tile = t_next, l_kt = 0;
+    unsigned a_voff[2], b_voff[2];
+    [[maybe_unused]] int im_pix = 0;
+    [[maybe_unused]] unsigned im_inv = 0;
+    auto tile_origin = [&](int tile, int &m0, int &n0) __attribute__((always_inline)) {
+        const int bm = (p.order & 1) ? tile / p.tiles_n : tile % p.tiles_m, bn = (p.order & 1) ? tile % p.tiles_n : tile / p.tiles_m;
+        m0 = bm * BM;
+        n0 = bn * BN;
+    };
+    auto setup_loader = [&](int tile) __attribute__((always_inline)) {
+        int m0, n0;
+        tile_origin(tile, m0, n0);
+#pragma unroll
+        for (int j = 0; j < 2; j++) { // DMA instruction q = 2 * wave + j moves k rows 4q .. 4q+3: lane -> row 4q + lane / 16, columns (lane % 16) * 4 ..
+            const int q = wave * 2 + j, k = q * 4 + (lane >> 4), c = (lane & 15) * 4;
+            const int m = m0 + c;
+            a_voff[j] = m < (int)p.a_cs ? (unsigned)(((long long)k * p.a_cs + m) * 4) : OOB;
+            if constexpr (BL == B_N4) {
+                const int n = n0 + c;
+                const int nn = n < p.N ? n : 0;
+                const int nb = nn / p.Pn, np = nn - nb * p.Pn;
+                b_voff[j] = n < p.N ? (unsigned)(((long long)k * p.b_rs + (long long)nb * p.b_ns + np) * 4) : OOB;
+            }
+        }
+        if constexpr (TAPS) {
+            const int n = n0 + lane; // gather instruction = one k row x 64 columns
+            const bool ok = n < p.N;
+            const int nn = ok ? n : 0;
+            const int nb = nn / p.Pn, np = nn - nb * p.Pn;
+            const int oy = np / p.OW, ox = np - oy * p.OW;
+            const int iy0 = ok ? oy * p.sy - p.pt : -0x40000000, ix0 = ox * p.sx - p.pl;
+            im_pix = (int)((long long)nb * p.b_ns) + (oy * p.sy - p.pt) * p.W + ix0;
+            unsigned colbad = 0;
+            for (int kx = 0; kx < p.KW; kx++) colbad |= ((unsigned)(ix0 + kx * p.dx) >= (unsigned)p.W ? 1u : 0u) << kx;
+            const unsigned allbad = (1u << p.KW) - 1u;
+            unsigned inv = 0x80000000u;
+            for (int ky = 0; ky < p.KH; ky++) inv |= ((unsigned)(iy0 + ky * p.dy) >= (unsigned)p.H ? allbad : colbad) << (ky * p.KW);
+            im_inv = inv;
+        }
+    };
+
+    typedef const __attribute__((address_space(4))) i32x2 *lut_ptr_t;
+    [[maybe_unused]] i32x2 lutE[NBG];
+    [[maybe_unused]] auto fetch_lut = [&](int kt) __attribute__((always_inline)) { // LUT rows (8 consecutive entries = one s_load_dwordx16) of the k-tile the loader issues next
+        if constexpr (TAPS) {
+            const lut_ptr_t lc = (lut_ptr_t)(unsigned long long)p.lut + (kt * LBK + wave * NBG);
+#pragma unroll
+            for (int j = 0; j < NBG; j++) lutE[j] = lc[j];
+        }
+    };
+
+    typedef __attribute__((address_space(3))) void *lds_ptr_t;
+    auto issue_tile = [&](int stage) __attribute__((always_inline)) {
+        float *As = smem + stage * STAGE, *Bs = As + LBK * BM;
+        const unsigned a_soff = (unsigned)l_kt * a_kstep;
+#pragma unroll
+        for (int j = 0; j < 2; j++) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(As + (wave * 2 + j) * 256), 16, (int)a_voff[j], (int)a_soff, 0, 0);
+        if constexpr (BL == B_N4) {
+            const unsigned b_soff = (unsigned)l_kt * b_kstep;
+#pragma unroll
+            for (int j = 0; j < 2; j++) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(Bs + (wave * 2 + j) * 256), 16, (int)b_voff[j], (int)b_soff, 0, 0);
+        } else {
+#pragma unroll
+            for (int r = 0; r < NBG; r++) {
+                const i32x2 e = lutE[r];
+                const unsigned voff = ((im_inv << e[1]) & 0x80000000u) | ((unsigned)(im_pix + e[0]) << 2);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(Bs + (wave * NBG + r) * BN), 4, (int)voff, 0, 0, 0);
+            }
+        }
+    };
+    auto advance_loader = [&]() __attribute__((always_inline)) { // next k-tile; crossing into the next tile of the list (or off its end: zero-fill loads) is the cold path
+        if (__builtin_expect(++l_kt == nk, 0)) {
+            l_kt = 0;
+            l_tile += t_step;
+            if (l_tile < t_end) {
+                setup_loader(l_tile);
+            } else {
+                a_voff[0] = a_voff[1] = b_voff[0] = b_voff[1] = OOB;
+                if constexpr (TAPS) im_inv = 0xffffffffu; // every tap reads out of range
+            }
+        }
+    };
+
+    f32x16 acc[1][1], tot[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[0][0][r] = 0.f;
+
+    auto compute_tile = [&](int stage) __attribute__((always_inline)) {
+        const float *As = smem + stage * STAGE + wm0 + l31 + half * BM;
+        const float *Bs = smem + stage * STAGE + LBK * BM + wn0 + l31 + half * BN;
+        float af[2], bf[2];
+        af[0] = As[0];
+        bf[0] = Bs[0];
+#pragma unroll
+        for (int kk = 0; kk < LBK / 2; kk++) {
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < LBK / 2) {
+                af[nxt] = As[2 * (kk + 1) * BM];
+                bf[nxt] = Bs[2 * (kk + 1) * BN];
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur], bf[cur], acc[0][0], 0, 0, 0);
+        }
+        __builtin_amdgcn_iglp_opt(0);
+    };
+
+    setup_loader(l_tile);
+    fetch_lut(0);
+#pragma unroll
+    for (int i = 0; i < NSTAGE - 1; i++) {
+        issue_tile(i);
+        advance_loader();
+        fetch_lut(l_kt);
+    }
+    // De-phase the workgroups that share a compute unit: they run identical tile lists and would otherwise reach their
+    // epilogues (and tile-crossing setup) together, leaving the matrix pipe idle for both.  Workgroup ids are dealt round-robin
+    // over the compute units, so id / num_cus is the residency slot; slot s waits s / slots of a tile's matrix time once.
+    if (p.debug & 0x100) {
+        const int slots = (int)gridDim.x / p.split_slots, slot = slots > 1 ? (int)blockIdx.x / p.split_slots : 0; // split_slots = num_cus here
+        if (slot > 0) {
+            const int ticks = nk * 16 * 64 * slot / slots / 64; // s_sleep unit = 64 cycles
+            for (int i = 0; i < ticks; i += 8) __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    int stage = 0;
+    const bool single_block = nk <= 256 / LBK;
+    for (int c_tile = t_next; c_tile < t_end; c_tile += t_step) {
+        int m0, n0;
+        tile_origin(c_tile, m0, n0);
+        for (int kt = 0; kt < nk; kt++) {
+            wait_vmcnt<PER_TILE *(NSTAGE - 2)>(); // this wave's DMA for this k-tile has landed (NSTAGE - 2 younger k-tiles stay in flight)
+            __builtin_amdgcn_s_barrier();
+            issue_tile(stage == 0 ? NSTAGE - 1 : stage - 1);
+            compute_tile(stage);
+            advance_loader();
+            fetch_lut(l_kt); // consumed by the NEXT iteration's issue: the scalar load's latency runs under this k-tile's MFMAs
+            stage = stage == NSTAGE - 1 ? 0 : stage + 1;
+            if (__builtin_expect(((kt + 1) & 7) == 0 && kt + 1 < nk, 0)) { // depth-block boundary (256 = 8 k-tiles)
+                int mb = m0 + wm0 + 4 * half, nb0 = n0 + wn0 + l31;
+                asm volatile("" : "+v"(mb), "+v"(nb0));
+                if (kt + 1 == 8) fold_first<1, 1>(p, 0, acc, tot, mb, nb0, 0);
+                else fold_next<1, 1>(p, acc, tot);
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[0][0][r] = 0.f;
+            }
+        }
+        {
+            int mb = m0 + wm0 + 4 * half, nb0 = n0 + wn0 + l31;
+            asm volatile("" : "+v"(mb), "+v"(nb0));
+            if (single_block) {
+                fold_first<1, 1>(p, 0, acc, acc, mb, nb0, 0);
+                store_out<1, 1>(p, acc, mb, nb0, 0);
+            } else {
+                fold_next<1, 1>(p, acc, tot);
+                store_out<1, 1>(p, tot, mb, nb0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[0][0][r] = 0.f;
+        }
+    }
+    wait_vmcnt<0>();
 }
 
 template <int BM, int BN, int BL, bool MULTI_KC>
@@ -2306,18 +2571,59 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
         return RTEN_HIP_OK;
     };
 
+    // Lean persistent plan (split mode 6, groups = resident workgroups per compute unit): igemm_f32_lean_kernel, 64x64 tiles, for
+    // the convolution form (prepacked weights, one group, alpha = 1 / beta = 0) with K a multiple of 32; other calls ignore it.
+    if constexpr (AL == A_M4 && (BL == B_N4 || BL == B_IM2COL_TAPS) && BM == 64 && BN == 64) {
+        if (ctx->split_mode == 6 && Z == 1 && a.batch_inner <= 1 && a.alpha == 1.f && a.beta == 0.f && a.bias_kind != RTEN_HIP_BIAS_PER_COL &&
+            a.K % LBK == 0 && a.K >= LBK && T > 1 && a.a_bs == (long long)a.K * a.a_cs) {
+            // groups = workgroups per compute unit + 10 * (LDS stages - 3): 1..3 (three stages), 11, 12 (four), 21, 22 (five)
+            const int nst = 3 + (ctx->split_s / 10 > 2 ? 2 : ctx->split_s / 10);
+            int per_cu = ctx->split_s % 10;
+            const int max_cu = 160 * 1024 / (nst * LBK * 128 * 4);
+            per_cu = per_cu < 1 ? 1 : (per_cu > max_cu ? max_cu : per_cu);
+            long long G = (long long)ctx->num_cus * per_cu;
+            if (G > T) G = T;
+            a.split_slots = ctx->num_cus; // (unused by this kernel's arithmetic: carries num_cus for the de-phasing delay)
+            a.debug = (ctx->tile_order & 2) ? 0x100 : 0; // order bit 1 = de-phase co-resident workgroups (tuning knob)
+            snprintf(kname, sizeof kname, "igemm_f32_lean_kernel<%d,%d>", BL, nst);
+            ProfScope ps(ctx, kname, flops, bytes);
+            auto go = [&](auto kern, int kStatic) {
+                int dyn = (160 * 1024 / per_cu - kStatic - 256) & ~1023; // exactly per_cu workgroups fit a compute unit (see mode 5)
+                if (dyn < 0) dyn = 0;
+                if (kStatic + dyn > 64 * 1024 || kStatic > 48 * 1024) hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+                hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(NTHREADS), (size_t)dyn, ctx->stream, a);
+            };
+            if (nst == 5) go(igemm_f32_lean_kernel<BL, 5>, 5 * LBK * 128 * 4);
+            else if (nst == 4) go(igemm_f32_lean_kernel<BL, 4>, 4 * LBK * 128 * 4);
+            else go(igemm_f32_lean_kernel<BL, 3>, 3 * LBK * 128 * 4);
+            RTEN_LAUNCH_CHECK(ctx, "igemm_f32_lean_kernel launch");
+            return RTEN_HIP_OK;
+        }
+    }
+
     // Persistent plan (split mode 5, groups = resident workgroups per compute unit): one launch of num_cus x groups workgroups
     // that walk the tile list with the tile DMA running across tile boundaries (igemm_f32_pers_kernel).
     if constexpr (kDma) {
-        if (ctx->split_mode == 5 && (pipe == 1 || pipe == 5) && T > 1) {
+        if (ctx->split_mode == 5 && (pipe == 1 || pipe == 4 || pipe == 5) && T > 1) {
             int per_cu = ctx->split_s < 1 ? 1 : (ctx->split_s > 4 ? 4 : ctx->split_s);
             long long G = (long long)ctx->num_cus * per_cu;
             if (G > T) G = T;
-            snprintf(kname, sizeof kname, "igemm_f32_pers_kernel<%d,%d,%d,%d,%s>", BM, BN, AL, BL, pipe == 5 ? "true" : "false");
+            snprintf(kname, sizeof kname, "igemm_f32_pers_kernel<%d,%d,%d,%d,%s,%d>", BM, BN, AL, BL, pipe == 5 ? "true" : "false", pipe == 4 ? 1 : 0);
             ProfScope ps(ctx, kname, flops, bytes);
             const dim3 grid((unsigned)G, (unsigned)Z);
-            if (pipe == 5) hipLaunchKernelGGL((igemm_f32_pers_kernel<BM, BN, AL, BL, true>), grid, dim3(NTHREADS), 0, ctx->stream, a);
-            else hipLaunchKernelGGL((igemm_f32_pers_kernel<BM, BN, AL, BL, false>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+            // The dispatcher places workgroups wherever a slot is free: a grid of num_cus x R workgroups only lands R per compute
+            // unit if no compute unit can take more.  Pad the LDS request (dynamic bytes the kernel never touches) so that exactly
+            // `per_cu` workgroups fit into a compute unit's 160 KiB.
+            constexpr int kStatic = 3 * BK * (BM + BN) * 4;
+            int dyn = (160 * 1024 / per_cu - kStatic - 256) & ~1023;
+            if (dyn < 0) dyn = 0;
+            auto go = [&](auto kern) {
+                if (kStatic + dyn > 64 * 1024) hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+                hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), (size_t)dyn, ctx->stream, a);
+            };
+            if (pipe == 5) go(igemm_f32_pers_kernel<BM, BN, AL, BL, true>);
+            else if (pipe == 4) go(igemm_f32_pers_kernel<BM, BN, AL, BL, false, 1>);
+            else go(igemm_f32_pers_kernel<BM, BN, AL, BL, false>);
             RTEN_LAUNCH_CHECK(ctx, "igemm_f32_pers_kernel launch");
             return RTEN_HIP_OK;
         }
@@ -2446,7 +2752,7 @@ RTEN_EXPORT int32_t rten_hip_set_gemm_variant_override(rten_hip_ctx *ctx, int32_
 // thin 16x64 tiles on 16x16x4 MFMAs (convolutions; other calls run their plain plan).
 RTEN_EXPORT int32_t rten_hip_set_gemm_split(rten_hip_ctx *ctx, int32_t mode, int32_t groups) {
     RTEN_CHECK_CTX(ctx);
-    if (mode < 0 || mode > 5 || groups < 0) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "set_gemm_split: bad mode/groups");
+    if (mode < 0 || mode > 6 || groups < 0) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "set_gemm_split: bad mode/groups");
     ctx->split_mode = mode;
     ctx->split_s = groups;
     return RTEN_HIP_OK;

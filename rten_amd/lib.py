@@ -11,7 +11,7 @@ import json
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "librten_hip.so")
+SO_PATH = os.environ.get("RTEN_HIP_LIBRARY") or os.path.join(_HERE, "librten_hip.so")  # (override: instrumented tuning builds)
 
 OK = 0
 ERR_INVALID_VALUE, ERR_INCOMPATIBLE_SHAPES, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE = 1, 2, 3, 4, 5

@@ -247,6 +247,8 @@ class ResNet50:
         plans += [(v, 4, 1, o) for v in dma for o in (0, 1)]
         # persistent plan (mode 5): num_cus x groups workgroups walk the tile list, tile DMA runs across tile boundaries
         plans += [(v, 5, r, o) for v in (0, 1, 2, 3, 20, 21, 22, 23) if v < nvar for r in (1, 2, 3, 4) for o in (0, 1)]
+        # lean persistent kernel (mode 6; 64x64 tiles, K % 32 == 0): groups = workgroups per compute unit
+        plans += [(3, 6, r, o) for r in (1, 2, 3) for o in (0, 1)]
         if nblk > 1:
             for v in [v for v in range(nvar) if not (8 <= v < 12 or v >= 20)]:  # the wave-specialised and 16x16x4 kernels have no split form
                 for groups in sorted({2, 3, 4, 6, nblk} & set(range(2, nblk + 1))):

@@ -39,7 +39,7 @@ def test_conv_f32_random_geometry(ctx, seed):
         want = ref.conv2d_f32(x, w, bias, pads=pads, strides=strides, dilations=dil, groups=groups, residual=res, relu=relu)
         nvar = ctx.lib.rten_hip_num_gemm_variants()
         variant = None if rng.random() < 0.3 else int(rng.integers(0, nvar))
-        mode, g, order = int(rng.integers(0, 6)), int(rng.integers(1, 5)), int(rng.integers(0, 4))  # mode 4 = thin-tile tail plan, 5 = persistent
+        mode, g, order = int(rng.integers(0, 7)), int(rng.integers(1, 5)), int(rng.integers(0, 4))  # mode 4 = thin-tile tail plan, 5 / 6 = persistent
         ctx.call("rten_hip_set_gemm_split", mode, g)
         ctx.call("rten_hip_set_gemm_order", order)
         try:
@@ -69,7 +69,7 @@ def test_conv_f32_random_deep_k(ctx, seed):
         bias = rng.random(O, dtype=np.float32) - 0.5
         want = ref.conv2d_f32(x, w, bias, pads=(p, p, p, p), relu=True)
         nblk = (C_ * k * k + 255) // 256
-        for mode in (0, 1, 2, 3, 4, 5):
+        for mode in (0, 1, 2, 3, 4, 5, 6):
             g = int(rng.integers(1, nblk + 2))
             ctx.call("rten_hip_set_gemm_split", mode, g)
             try:

@@ -353,6 +353,9 @@ def test_conv_f32_thin_tail_and_16x16_plans_bit_exact(ctx):
         (6, 40, 57, 57, 64, 3, 1, 1),     # K = 360 (two depth blocks), ragged width, 305 tiles
         (8, 300, 29, 29, 130, 1, 0, 1),   # M tail (130 rows = 3 row tiles: the whole rounds hold 85 column tiles), K = 300
         (12, 70, 60, 60, 128, 3, 1, 2),   # strided 3x3, K = 630 (three depth blocks), 338 tiles
+        (10, 96, 55, 55, 100, 1, 0, 1),   # K = 96 (lean kernel: K % 32 == 0, one depth block), M tail, 948 tiles
+        (7, 64, 41, 41, 72, 3, 1, 1),     # K = 576 (lean kernel, three depth blocks), gather with ragged rows, 368 tiles
+        (9, 320, 30, 30, 64, 1, 0, 2),    # 1x1 stride 2 (tap-masked gather with one tap), K = 320
     ]
     for (N, C_, H, W, O, k, pad, stride) in cases:
         x = rng.f32(N * C_ * H * W).reshape(N, C_, H, W) - 0.5
@@ -362,7 +365,7 @@ def test_conv_f32_thin_tail_and_16x16_plans_bit_exact(ctx):
         res = rng.f32(N * O * oh * oh).reshape(N, O, oh, oh) - 0.5
         want = ref.conv2d_f32(x, w, b, pads=(pad,) * 4, strides=(stride,) * 2, residual=res, relu=True)
         for variant, mode, groups in [(v, m, 1) for v in (3, 2, 1, 0, 15, 19, 16, 23, 22, 21, 20) for m in (0, 4)] + \
-                                     [(v, 5, r) for v in (3, 2, 1, 0, 23, 22, 21, 20) for r in (1, 2, 3)]:
+                                     [(v, 5, r) for v in (3, 2, 1, 0, 23, 22, 21, 20) for r in (1, 2, 3)] + [(3, 6, r) for r in (1, 2, 3)]:
             if True:
                 ctx.call("rten_hip_set_gemm_split", mode, groups)
                 try:

@@ -1,0 +1,145 @@
+// Probe: what does one k-tile of the f32 implicit-GEMM loop cost a wave, piece by piece?
+//
+// A 64x64 tile / 4 waves / BK = 16 k-loop (8 dependent v_mfma_f32_32x32x2_f32 per wave per k-tile = 512 matrix-pipe cycles) is
+// built up in steps and timed per k-tile with s_memtime, for 1..3 workgroups per compute unit:
+//   A  MFMAs on register operands only
+//   B  + operand fragments from LDS (16 ds_read_b32 per k-tile, next k-pair's reads behind the current MFMA, as the kernels do)
+//   C  + s_barrier per k-tile
+//   D  + tile DMA: 2 buffer_load_dwordx4 ... lds per wave per k-tile (dense 1x1 layer), counted vmcnt wait, 3 LDS stages
+//   E  as D with 1 dwordx4 + 4 dword gathers per wave per k-tile (3x3 layer)
+//   F  as D, but all fragments first and the 8 MFMAs back to back
+// hipcc --offload-arch=gfx950 -O3 -o /tmp/kloop kloop.hip && /tmp/kloop
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int BK = 16, BM = 64, BN = 64, NSTAGE = 3, STAGE = BK * (BM + BN);
+constexpr unsigned OOB = 0x80000000u;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int MODE>
+__global__ __launch_bounds__(256) void kloop(const float *src, float *sink, unsigned long long *clocks, int iters, unsigned src_bytes) {
+    __shared__ __attribute__((aligned(16))) float smem[NSTAGE * STAGE];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wq = t >> 6, wm0 = (wq >> 1) * 32, wn0 = (wq & 1) * 32;
+    for (int i = t; i < NSTAGE * STAGE; i += 256) smem[i] = (float)((i * 2654435761u) >> 20) * 1e-4f;
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, (int)src_bytes, 0x00020000);
+    typedef __attribute__((address_space(3))) void *lds_ptr_t;
+    const unsigned voff = (unsigned)((blockIdx.x * 4096u + wave * 1024u + lane * 16u) % (src_bytes - 65536u));
+    auto issue = [&](int kt, int stage) {
+        float *As = smem + stage * STAGE, *Bs = As + BK * BM;
+        const unsigned soff = (unsigned)(kt & 63) * 1024u;
+        if constexpr (MODE == 3 || MODE == 5) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(As + wave * 256), 16, (int)voff, (int)soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(Bs + wave * 256), 16, (int)(voff + 4096u), (int)soff, 0, 0);
+        } else if constexpr (MODE == 4) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(As + wave * 256), 16, (int)voff, (int)soff, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(Bs + (wave * 4 + r) * BN), 4, (int)(voff / 4 + 8192u * r + 4 * lane), (int)soff, 0, 0);
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    constexpr int PER_TILE = MODE == 4 ? 5 : 2;
+    if constexpr (MODE >= 3) {
+        issue(0, 0);
+        issue(1, 1);
+    }
+    int stage = 0;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int kt = 0; kt < iters; kt++) {
+        if constexpr (MODE >= 3) wait_vmcnt<PER_TILE>();
+        if constexpr (MODE >= 2) __builtin_amdgcn_s_barrier();
+        if constexpr (MODE >= 3) issue(kt + 2, stage == 0 ? NSTAGE - 1 : stage - 1);
+        if constexpr (MODE == 0) {
+            const float fa = (float)kt, fb = (float)lane;
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; kk++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc, 0, 0, 0);
+        } else if constexpr (MODE == 5) {
+            const float *As = smem + stage * STAGE + wm0 + l31 + half * BM, *Bs = smem + stage * STAGE + BK * BM + wn0 + l31;
+            float af[BK / 2], bf[BK / 2];
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; kk++) { af[kk] = As[2 * kk * BM]; bf[kk] = Bs[(2 * kk + half) * BN]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; kk++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], bf[kk], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            const float *As = smem + stage * STAGE + wm0 + l31 + half * BM, *Bs = smem + stage * STAGE + BK * BM + wn0 + l31;
+            float af[2], bf[2];
+            af[0] = As[0];
+            bf[0] = Bs[half * BN];
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; kk++) {
+                const int cur = kk & 1, nxt = cur ^ 1;
+                if (kk + 1 < BK / 2) { af[nxt] = As[2 * (kk + 1) * BM]; bf[nxt] = Bs[(2 * (kk + 1) + half) * BN]; }
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur], bf[cur], acc, 0, 0, 0);
+            }
+            __builtin_amdgcn_iglp_opt(0);
+        }
+        stage = stage == NSTAGE - 1 ? 0 : stage + 1;
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if constexpr (MODE >= 3) wait_vmcnt<0>();
+    if (lane == 0 && wave == 0) clocks[blockIdx.x] = t1 - t0;
+    float keep = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) keep += acc[r];
+    if (keep == 12345.678f) sink[0] = keep;
+}
+
+template <int MODE>
+void run(const char *name, const float *src, float *sink, unsigned long long *clocks, int cus, unsigned src_bytes) {
+    const int iters = 4000;
+    for (int per_cu = 1; per_cu <= 3; per_cu++) {
+        const int grid = cus * per_cu;
+        // pad the LDS request so that exactly per_cu workgroups fit a compute unit
+        int dyn = (160 * 1024 / per_cu - NSTAGE * STAGE * 4 - 256) & ~1023;
+        if (NSTAGE * STAGE * 4 + dyn > 64 * 1024) hipFuncSetAttribute((const void *)kloop<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        hipLaunchKernelGGL((kloop<MODE>), dim3(grid), dim3(256), (size_t)dyn, 0, src, sink, clocks, iters, src_bytes);
+        hipDeviceSynchronize();
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL((kloop<MODE>), dim3(grid), dim3(256), (size_t)dyn, 0, src, sink, clocks, iters, src_bytes);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        std::vector<unsigned long long> h((size_t)grid);
+        hipMemcpy(h.data(), clocks, h.size() * 8, hipMemcpyDeviceToHost);
+        double cyc = 0;
+        for (auto c : h) cyc += (double)c;
+        const double flops = (double)grid * 4 * iters * 8.0 * 2.0 * 32 * 32 * 2;
+        printf("%-46s %d WG/CU: %7.1f cycles per k-tile per wave (512 = matrix pipe alone)  %6.1f TFLOP/s\n", name, per_cu, cyc / grid / iters, flops / (ms * 1e-3) / 1e12);
+    }
+}
+
+int main() {
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, 0);
+    const int cus = prop.multiProcessorCount;
+    const unsigned src_bytes = 64u << 20;
+    float *src, *sink;
+    unsigned long long *clocks;
+    hipMalloc(&src, src_bytes);
+    hipMemset(src, 0x3c, src_bytes);
+    hipMalloc(&sink, 16);
+    hipMalloc(&clocks, (size_t)cus * 4 * 8);
+    run<0>("A  MFMA on register operands", src, sink, clocks, cus, src_bytes);
+    run<1>("B  + fragments from LDS (interleaved)", src, sink, clocks, cus, src_bytes);
+    run<2>("C  + s_barrier per k-tile", src, sink, clocks, cus, src_bytes);
+    run<3>("D  + tile DMA, 2 dwordx4 per wave (dense)", src, sink, clocks, cus, src_bytes);
+    run<4>("E  + tile DMA, 1 dwordx4 + 4 dword (gather)", src, sink, clocks, cus, src_bytes);
+    run<5>("F  as D, fragments first, MFMAs back to back", src, sink, clocks, cus, src_bytes);
+    return 0;
+}
