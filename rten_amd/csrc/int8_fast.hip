@@ -275,14 +275,21 @@ __global__ __launch_bounds__(256) void i8_quantize_stage_kernel(const float *__r
 // ---------------------------------------------------------------------------------------------------------
 // RES: the epilogue adds a residual tile (prefetched into 16 * TM * TN registers); a separate instantiation so that the
 // launches without one keep the smaller register footprint (one more workgroup per CU on the 128 x 128 tile).
-template <int BM, int BN, int NSTAGE, bool RES>
+// KTK = k bytes per tile (a multiple of 64): one barrier, one counted wait and one trip round the loop per KTK / 32 MFMA steps.
+// The i8 matrix pipe retires a 32x32x32 step in 32 cycles -- sixteen times the f32 rate -- so with 64-byte k-tiles a wave's two
+// MFMAs (64 cycles) sat behind ~600 cycles of barrier / wait / DMA issue / loop overhead (tools/probes/kloop.hip prices that
+// overhead for the f32 loop); the long-K launches of stages 2-3 therefore take 256-byte k-tiles.  All LDS is ONE dynamic array.
+extern __shared__ __attribute__((aligned(16))) uint8_t i8_smem[];
+
+template <int BM, int BN, int NSTAGE, bool RES, int KTK = 64>
 __global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p) {
     constexpr int WM = 2, WN = 2;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int RA = BM / 64, RB = BN / 64;      // DMA instructions per chunk (64 rows each)
-    constexpr int PER_TILE = RA + RB;              // per wave: wave w moves chunk w of the tile
-    constexpr int STAGE = (BM + BN) * KT;          // bytes
-    __shared__ __attribute__((aligned(16))) uint8_t smem[NSTAGE * STAGE];
+    constexpr int CPW = KTK / 64;                  // chunks per wave per tile: wave w moves chunks w, w + 4, ... of the tile
+    constexpr int PER_TILE = (RA + RB) * CPW;
+    constexpr int STAGE = (BM + BN) * KTK;         // bytes
+    uint8_t *const smem = i8_smem;
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -333,26 +340,29 @@ __global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p)
     }
     typedef __attribute__((address_space(3))) void *lds_ptr_t;
     auto issue_tile = [&](int stage) {
-        uint8_t *As = smem + stage * STAGE + wave * BM * 16;
-        uint8_t *Bs = smem + stage * STAGE + BM * KT + wave * BN * 16;
-        const bool live = ch_idx < nchunks;
-        const unsigned a_soff = live ? (unsigned)ch_idx * 16u * (unsigned)p.M : 0u;
-        unsigned b_soff = live ? (unsigned)ch_idx * 16u * (unsigned)p.N : 0u;
-        bool b_live = live;
-        if (p.conv) {
-            b_live = live && ch_ky < p.KH;
-            b_soff = b_live ? (unsigned)(((ch_c * p.Hp + ch_ky * p.dy) * p.Wp + ch_kx * p.dx) * 16) : 0u;
-        }
 #pragma unroll
-        for (int j = 0; j < RA; j++)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(As + j * 1024), 16, (int)(live ? a_voff[j] : OOB), (int)a_soff, 0, 0);
+        for (int q = 0; q < CPW; q++) { // LDS chunk slot wave + 4 q of the tile <- this wave's next chunk (its walk is every 4th chunk)
+            uint8_t *As = smem + stage * STAGE + (wave + 4 * q) * BM * 16;
+            uint8_t *Bs = smem + stage * STAGE + BM * KTK + (wave + 4 * q) * BN * 16;
+            const bool live = ch_idx < nchunks;
+            const unsigned a_soff = live ? (unsigned)ch_idx * 16u * (unsigned)p.M : 0u;
+            unsigned b_soff = live ? (unsigned)ch_idx * 16u * (unsigned)p.N : 0u;
+            bool b_live = live;
+            if (p.conv) {
+                b_live = live && ch_ky < p.KH;
+                b_soff = b_live ? (unsigned)(((ch_c * p.Hp + ch_ky * p.dy) * p.Wp + ch_kx * p.dx) * 16) : 0u;
+            }
 #pragma unroll
-        for (int j = 0; j < RB; j++)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(Bs + j * 1024), 16, (int)(b_live ? b_voff[j] : OOB), (int)b_soff, 0, 0);
-        ch_idx += 4;
-        if (p.conv) {
-            ch_c += 4;
-            while (ch_c >= cpc) { ch_c -= cpc; if (++ch_kx == p.KW) { ch_kx = 0; ch_ky++; } }
+            for (int j = 0; j < RA; j++)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(As + j * 1024), 16, (int)(live ? a_voff[j] : OOB), (int)a_soff, 0, 0);
+#pragma unroll
+            for (int j = 0; j < RB; j++)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(Bs + j * 1024), 16, (int)(b_live ? b_voff[j] : OOB), (int)b_soff, 0, 0);
+            ch_idx += 4;
+            if (p.conv) {
+                ch_c += 4;
+                while (ch_c >= cpc) { ch_c -= cpc; if (++ch_kx == p.KW) { ch_kx = 0; ch_ky++; } }
+            }
         }
     };
 
@@ -370,9 +380,9 @@ __global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p)
 
     auto compute_tile = [&](int stage) {
         const uint8_t *As = smem + stage * STAGE + (wm0 + l31) * 16;
-        const uint8_t *Bs = smem + stage * STAGE + BM * KT + (wn0 + l31) * 16;
+        const uint8_t *Bs = smem + stage * STAGE + BM * KTK + (wn0 + l31) * 16;
 #pragma unroll
-        for (int s = 0; s < 2; s++) {
+        for (int s = 0; s < KTK / 32; s++) {
             i32x4 af[TM], bf[TN];
 #pragma unroll
             for (int i = 0; i < TM; i++) af[i] = *reinterpret_cast<const i32x4 *>(As + ((2 * s + half) * BM + i * 32) * 16);
@@ -439,7 +449,7 @@ __global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p)
                 }
     }
 
-    const int nk = (p.Kp + KT - 1) / KT;
+    const int nk = (p.Kp + KTK - 1) / KTK;
 #pragma unroll
     for (int i = 0; i < NSTAGE - 1; i++) issue_tile(i);
     // (A two-fragment-set software pipeline of the LDS reads under the MFMAs was measured and is slower: these
@@ -574,13 +584,19 @@ __global__ __launch_bounds__(256) void i8_pack_rows_t_kernel(const uint8_t *__re
 
 inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-template <int BM, int BN, int NST>
+template <int BM, int BN, int NST, int KTK = 64>
 void launch_fast(rten_hip_ctx *ctx, FastArgs &a, const char *name, double ops, double bytes) {
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.N + BN - 1) / BN;
     ProfScope ps(ctx, name, ops, bytes);
-    if (a.res && a.scale) hipLaunchKernelGGL((igemm_i8_fast_kernel<BM, BN, NST, true>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), 0, ctx->stream, a);
-    else hipLaunchKernelGGL((igemm_i8_fast_kernel<BM, BN, NST, false>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), 0, ctx->stream, a);
+    constexpr size_t lds = (size_t)NST * (BM + BN) * KTK;
+    static_assert(lds <= 160 * 1024, "int8 tile ring exceeds the LDS of a compute unit");
+    auto go = [&](auto kern) {
+        if (lds > 64 * 1024) hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), lds, ctx->stream, a);
+    };
+    if (a.res && a.scale) go(igemm_i8_fast_kernel<BM, BN, NST, true, KTK>);
+    else go(igemm_i8_fast_kernel<BM, BN, NST, false, KTK>);
 }
 
 int32_t dispatch_fast(rten_hip_ctx *ctx, FastArgs &a, double ops, double bytes) {
@@ -592,10 +608,21 @@ int32_t dispatch_fast(rten_hip_ctx *ctx, FastArgs &a, double ops, double bytes) 
     // tile order: consecutive workgroup ids (one XCD's share) walk the axis of the SMALLER operand, so that the larger
     // one is fetched into as few of the eight L2s as possible
     a.n_fastest = (double)a.a_bytes > (double)a.b_bytes ? 1 : 0;
-    if (tile == 0) launch_fast<128, 128, 3>(ctx, a, "igemm_i8_fast_kernel<128,128>", ops, bytes);
-    else if (tile == 1) launch_fast<128, 64, 3>(ctx, a, "igemm_i8_fast_kernel<128,64>", ops, bytes);
-    else if (tile == 2) launch_fast<64, 128, 3>(ctx, a, "igemm_i8_fast_kernel<64,128>", ops, bytes);
-    else launch_fast<64, 64, 3>(ctx, a, "igemm_i8_fast_kernel<64,64>", ops, bytes);
+    // k-tile depth: 64 bytes per trip; RTEN_HIP_DEBUG bit 0x200 selects 256-byte (128 for the 128x128 tile) trips for K >= 512.
+    const bool deep = a.Kp >= 512 && (ctx->debug & 0x200); // measured (profiles/r05): slower -- the long-K launches are bound by L2 -> LDS DMA parallelism across workgroups, and the 96 KiB ring leaves one workgroup per CU
+    if (tile == 0) {
+        if (deep) launch_fast<128, 128, 3, 128>(ctx, a, "igemm_i8_fast_kernel<128,128,k128>", ops, bytes);
+        else launch_fast<128, 128, 3>(ctx, a, "igemm_i8_fast_kernel<128,128>", ops, bytes);
+    } else if (tile == 1) {
+        if (deep) launch_fast<128, 64, 3, 256>(ctx, a, "igemm_i8_fast_kernel<128,64,k256>", ops, bytes);
+        else launch_fast<128, 64, 3>(ctx, a, "igemm_i8_fast_kernel<128,64>", ops, bytes);
+    } else if (tile == 2) {
+        if (deep) launch_fast<64, 128, 3, 256>(ctx, a, "igemm_i8_fast_kernel<64,128,k256>", ops, bytes);
+        else launch_fast<64, 128, 3>(ctx, a, "igemm_i8_fast_kernel<64,128>", ops, bytes);
+    } else {
+        if (deep) launch_fast<64, 64, 3, 256>(ctx, a, "igemm_i8_fast_kernel<64,64,k256>", ops, bytes);
+        else launch_fast<64, 64, 3>(ctx, a, "igemm_i8_fast_kernel<64,64>", ops, bytes);
+    }
     RTEN_LAUNCH_CHECK(ctx, "igemm_i8_fast_kernel launch");
     return RTEN_HIP_OK;
 }
