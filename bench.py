@@ -58,6 +58,44 @@ def cpu_baseline(specs, weights, budget_s=12.0):
                       f"({threads} OpenMP threads, {dt:.1f} s)"}
 
 
+def torch_cpu_reference(specs, weights, budget_s=8.0, int8=False):
+    """A COMPETENT CPU number beside the oracle's: the same ResNet-50 graph through PyTorch's CPU kernels (oneDNN) on this
+    host's cores.  It is NOT the reference (RTen's own CPU path cannot be built here: no Rust toolchain) and not the parity
+    checker -- only context for `cpu_baseline.value`, which times a plain restatement of the reference's algorithm."""
+    try:
+        import torch
+        import torch.nn.functional as F
+        torch.set_grad_enabled(False)
+        tw = {k: (torch.from_numpy(w), torch.from_numpy(b)) for k, (w, b) in weights.items()}
+        x = torch.rand(32, 3, 224, 224)
+
+        def fwd(x):
+            acts = {"x": x}
+            for i, l in enumerate(specs):
+                w, b = tw[l["name"]]
+                y = F.conv2d(acts[l["src"]], w, b, stride=l["stride"], padding=l["pad"])
+                if l["res"]:
+                    y = y + acts[l["res"]]
+                if l["relu"]:
+                    y = F.relu(y)
+                acts[l["dst"]] = y
+                if i == 0:
+                    acts["pool"] = F.max_pool2d(y, 3, 2, 1)
+            g = acts[specs[-1]["dst"]].mean((2, 3))
+            return F.linear(g, tw["fc"][0], tw["fc"][1])
+        fwd(x)
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < budget_s and reps < 20:
+            fwd(x)
+            reps += 1
+        dt = time.perf_counter() - t0
+        return {"value": round(32 * reps / dt, 1), "unit": "inferences/s", "cores": torch.get_num_threads(), "kind": "pytorch-cpu (oneDNN), f32; not the reference",
+                "sample": f"{32 * reps} images (batch 32 x {reps} forward passes, {dt:.1f} s)"}
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"[:200]}
+
+
 def cpu_op_baselines():
     """cpu_baseline leg for the per-kernel table (tools/bench_ops.py --cpu-baseline): the CPU oracle timed on a bounded
     sample of each kernel's shape, scaled linearly to the full shape.  Returns {op: {"us": ..., "sample": ...}}."""
@@ -489,6 +527,8 @@ def main():
                                               "(rten-gemm/src/im2col.rs:340-358, SURVEY App. C.1); unpinned by a reference-held vector; ZERO_POINT / RAW0_U8 are the other modes of the ABI")
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_int8(net.specs, weights) if int8 else cpu_baseline(net.specs, weights)
+            if not int8:
+                out["cpu_baseline"]["other_cpu_implementation"] = torch_cpu_reference(net.specs, weights)
         else:
             out["cpu_baseline"] = None
         if n_gpus == 1 and world == 1 and not args.no_secondary and not int8:

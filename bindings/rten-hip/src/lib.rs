@@ -1,0 +1,174 @@
+//! rten-hip: the reference's `Operator` interface (src/operator.rs:486-613) implemented over librten_hip.so.
+//!
+//! NOT COMPILED in the build image (no Rust toolchain there); the `extern "C"` layer it calls, `rten-hip-sys`, is generated
+//! from include/rten_hip.h and checked against it by tests/test_abi.py.  What is tested in this repository is the same layer
+//! written in C++ (include/rten_hip_ops.hpp) and Python (rten_amd/ops.py).
+//!
+//! Design constraint: the reference's surface stays IDENTICAL.  No new `Value` variant, no new accessor on `OpRunContext`, no
+//! change to `PrepackedInput`:
+//!   * every operator here wraps the reference's own operator struct (`inner`) and delegates `name`, `max_inputs`,
+//!     `output_types`, `as_infer_shapes` to it -- attributes, shape inference and the planner see the operators they know;
+//!   * `run` takes the reference's host `ValueView`s and returns host `Value`s allocated from `ctx.pool()`;
+//!   * constant inputs (weights) are staged on the device ONCE: `PrepackedInput` is a closed enum of rten-gemm types, so the
+//!     cache lives in the backend, keyed by the constant's host address and length (graph constants do not move while the
+//!     model is alive -- `Graph` owns them, src/graph.rs:488-562);
+//!   * activations cross PCIe per operator in this drop-in form.  The residency-aware executor of SURVEY 8(f) rank 1 (values
+//!     stay in HBM between operators) needs a `Value::Device` variant, i.e. a change to the reference; it is built and measured
+//!     in this repository as include/rten_hip_graph.hpp and is the "next" step of the Rust integration, not part of it.
+//!   * one `HipContext` may be shared by every thread that calls `Model::run(&self)`: the C ABI locks per call.
+//!
+//! Registration (what a user writes):
+//! ```ignore
+//! let mut reg = OpRegistry::with_all_ops();                 // src/op_registry.rs
+//! rten_hip::register(&mut reg, HipContext::new(0)?);        // same op names, HIP-backed
+//! let model = ModelOptions::with_ops(reg).load_file("resnet50.onnx")?;
+//! let out = model.run_one(input.view().into(), None)?;      // unchanged call site
+//! ```
+mod ops;
+
+use std::collections::HashMap;
+use std::ffi::{c_void, CStr};
+use std::ptr;
+use std::sync::{Arc, Mutex};
+
+use rten::ops::OpError;
+use rten_hip_sys as sys;
+
+pub use ops::register;
+
+/// RAII over `rten_hip_ctx`.  `Send + Sync`: the C ABI serialises entry per call (rten_hip.h, "Thread safety").
+pub struct HipContext {
+    raw: *mut sys::rten_hip_ctx,
+    /// device copies of graph constants: (host address, bytes, layout tag) -> device buffer
+    weights: Mutex<HashMap<(usize, usize, u32), DeviceBuffer>>,
+}
+unsafe impl Send for HipContext {}
+unsafe impl Sync for HipContext {}
+
+#[derive(Debug)]
+pub enum HipInitError {
+    /// no gfx950 device / library unusable: the backend has no CPU fallback
+    NoDevice,
+    Hip(String),
+}
+
+impl HipContext {
+    pub fn new(device: i32) -> Result<Arc<HipContext>, HipInitError> {
+        let mut raw = ptr::null_mut();
+        match unsafe { sys::rten_hip_init(device, ptr::null_mut(), &mut raw) } {
+            sys::RTEN_HIP_OK => Ok(Arc::new(HipContext { raw, weights: Mutex::new(HashMap::new()) })),
+            sys::RTEN_HIP_ERR_NO_DEVICE => Err(HipInitError::NoDevice),
+            _ => Err(HipInitError::Hip("rten_hip_init failed".into())),
+        }
+    }
+
+    pub fn raw(&self) -> *mut sys::rten_hip_ctx {
+        self.raw
+    }
+
+    /// Status code -> the reference's `OpError` (include/rten_hip.h, "status codes").  A HIP runtime failure is not an
+    /// operator error and never turns into a silent CPU fallback.
+    pub fn check(&self, status: i32) -> Result<(), OpError> {
+        let msg = || -> &'static str {
+            // OpError carries &'static str: the ABI's validation messages are static strings of the library
+            let p = unsafe { sys::rten_hip_last_error(self.raw) };
+            Box::leak(unsafe { CStr::from_ptr(p) }.to_string_lossy().into_owned().into_boxed_str())
+        };
+        match status {
+            sys::RTEN_HIP_OK => Ok(()),
+            sys::RTEN_HIP_ERR_INVALID_VALUE => Err(OpError::InvalidValue(msg())),
+            sys::RTEN_HIP_ERR_INCOMPATIBLE_SHAPES => Err(OpError::IncompatibleInputShapes(msg())),
+            sys::RTEN_HIP_ERR_UNSUPPORTED => Err(OpError::UnsupportedValue(msg())),
+            _ => panic!("HIP failure in librten_hip.so: {}", msg()),
+        }
+    }
+
+    pub fn alloc(self: &Arc<Self>, bytes: usize) -> Result<DeviceBuffer, OpError> {
+        let mut p: *mut c_void = ptr::null_mut();
+        self.check(unsafe { sys::rten_hip_malloc(self.raw, bytes, &mut p) })?;
+        Ok(DeviceBuffer { ptr: p, bytes, ctx: self.clone() })
+    }
+
+    /// Host slice -> fresh device buffer (activations of the drop-in form).
+    pub fn upload<T: Copy>(self: &Arc<Self>, host: &[T]) -> Result<DeviceBuffer, OpError> {
+        let buf = self.alloc(std::mem::size_of_val(host))?;
+        self.check(unsafe { sys::rten_hip_memcpy_h2d(self.raw, buf.ptr, host.as_ptr() as *const c_void, buf.bytes) })?;
+        Ok(buf)
+    }
+
+    pub fn download<T: Copy>(&self, buf: &DeviceBuffer, host: &mut [T]) -> Result<(), OpError> {
+        debug_assert!(std::mem::size_of_val(host) <= buf.bytes);
+        self.check(unsafe { sys::rten_hip_memcpy_d2h(self.raw, host.as_mut_ptr() as *mut c_void, buf.ptr, std::mem::size_of_val(host)) })
+    }
+
+    /// Device copy of a graph constant, created on first use -- uploaded, then handed to `stage`, which returns either the
+    /// upload itself (`|_, raw| Ok(raw)`) or a re-laid copy (rten_hip_conv2d_f32_prepack, rten_hip_gemm_int8_prepack) -- and
+    /// kept for the life of the context: the backend's analogue of `Graph::prepack_weights` + `WeightCache`.
+    pub fn constant<T: Copy>(
+        self: &Arc<Self>,
+        host: &[T],
+        layout: u32,
+        stage: impl FnOnce(&Arc<Self>, DeviceBuffer) -> Result<DeviceBuffer, OpError>,
+    ) -> Result<*const c_void, OpError> {
+        let key = (host.as_ptr() as usize, std::mem::size_of_val(host), layout);
+        let mut cache = self.weights.lock().unwrap();
+        if let Some(b) = cache.get(&key) {
+            return Ok(b.ptr as *const c_void);
+        }
+        let raw = self.upload(host)?;
+        let staged = stage(self, &raw)?;
+        let p = staged.ptr as *const c_void;
+        cache.insert(key, staged);
+        Ok(p)
+    }
+}
+
+impl Drop for HipContext {
+    fn drop(&mut self) {
+        self.weights.lock().unwrap().clear(); // buffers free themselves through the context: before it goes away
+        unsafe { sys::rten_hip_destroy(self.raw) };
+    }
+}
+
+/// Device allocation freed through its context.
+pub struct DeviceBuffer {
+    pub ptr: *mut c_void,
+    pub bytes: usize,
+    ctx: Arc<HipContext>,
+}
+unsafe impl Send for DeviceBuffer {}
+
+impl Drop for DeviceBuffer {
+    fn drop(&mut self) {
+        unsafe { sys::rten_hip_free(self.ctx.raw, self.ptr) };
+    }
+}
+
+/// Weight broadcast of a batch-sharded deployment: one process per GPU, rank 0 stages the weight arena, the
+/// other ranks receive it over xGMI.  `id` travels from rank 0 to the others by any host channel.
+pub struct Communicator {
+    raw: *mut sys::rten_hip_comm,
+    ctx: Arc<HipContext>,
+}
+
+impl Communicator {
+    pub fn unique_id(ctx: &HipContext) -> Result<[u8; 128], OpError> {
+        let mut id = [0u8; 128];
+        ctx.check(unsafe { sys::rten_hip_comm_get_unique_id(ctx.raw, id.as_mut_ptr()) })?;
+        Ok(id)
+    }
+    pub fn new(ctx: Arc<HipContext>, id: &[u8; 128], world_size: i32, rank: i32) -> Result<Self, OpError> {
+        let mut raw = ptr::null_mut();
+        ctx.check(unsafe { sys::rten_hip_comm_init_rank(ctx.raw, id.as_ptr(), world_size, rank, &mut raw) })?;
+        Ok(Communicator { raw, ctx })
+    }
+    pub fn broadcast(&self, buf: &DeviceBuffer, root: i32) -> Result<(), OpError> {
+        self.ctx.check(unsafe { sys::rten_hip_broadcast(self.ctx.raw, self.raw, buf.ptr, buf.bytes, root) })
+    }
+}
+
+impl Drop for Communicator {
+    fn drop(&mut self) {
+        unsafe { sys::rten_hip_comm_destroy(self.ctx.raw, self.raw) };
+    }
+}

@@ -390,3 +390,25 @@ def test_conv_f32_thin_tail_and_16x16_plans_bit_exact(ctx):
             bits_equal(gpu_gemm(ctx, a, bm_, c=c0.copy(), alpha=0.5, beta=0.75, bias=bias, bias_kind=L.BIAS_PER_COL, variant=variant), want)
         finally:
             ctx.call("rten_hip_set_gemm_split", 3, 1)
+
+
+def test_golden_package_for_the_real_reference(tmp_path):
+    """tools/make_rten_golden.py: the files a maintainer feeds to `rten --check-outputs` -- the expected outputs written by the HIP
+    backend are the oracle's, bit for bit, and the package checks against itself with rten_hip_run (same flags as rten-cli)."""
+    import subprocess
+    import sys
+    from safetensors.numpy import load_file
+    from tests.test_graph_executor import ROOT, build_cli
+    import os
+    outs = {}
+    for source in ("hip", "oracle"):
+        d = tmp_path / source
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_rten_golden.py"), "--out", str(d), "--batch", "1", "--source", source,
+                            "--models", "resnet50_int8"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        outs[source] = load_file(str(d / "resnet50_int8.expected.safetensors"))["logits"]
+    bits_equal(outs["hip"], outs["oracle"])
+    d = tmp_path / "oracle"
+    r = subprocess.run([build_cli(), "-s", "batch=1", "-i", str(d / "resnet50_int8.inputs.safetensors"), "--check-outputs",
+                        str(d / "resnet50_int8.expected.safetensors"), "--max-diff", "0", str(d / "resnet50_int8.onnx")], capture_output=True, text=True)
+    assert r.returncode == 0 and "max diff 0" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
