@@ -78,8 +78,9 @@ def conv_flops_per_image():
 class ResNet50:
     """Device-resident ResNet-50 forward for a fixed batch size (static plan, optional hipGraph)."""
 
-    def __init__(self, ctx, batch, weights=None, image=224, num_classes=1000, arena_ptr=None, arena_keepalive=None):
+    def __init__(self, ctx, batch, weights=None, image=224, num_classes=1000, arena_ptr=None, arena_keepalive=None, x_view=None, logits_view=None):
         self.ctx, self.batch, self.image, self.num_classes = ctx, batch, image, num_classes
+        self._x_view, self._logits_view = x_view, logits_view  # (ptr, keepalive): this net works on a slice of a larger batch
         self.weights = weights if weights is not None else make_weights(num_classes=num_classes)
         self.specs = conv_specs()
         self.graph = None
@@ -135,7 +136,8 @@ class ResNet50:
                 last_use[nm] = i
         last_use[ops[-1][1]] = len(ops)  # final activation is read by GlobalAveragePool
         free, self.bufs = [], {}
-        self.x = DeviceTensor(ctx, shapes["x"], np.float32)
+        xv = self._x_view or (None, None)
+        self.x = DeviceTensor(ctx, shapes["x"], np.float32, ptr=xv[0], keepalive=xv[1])
         for i, (ins, out) in enumerate(ops):
             need = int(np.prod(shapes[out])) * 4
             best = None
@@ -153,7 +155,8 @@ class ResNet50:
                 if nm != "x" and last_use[nm] == i:
                     free.append(self._raw[nm])
         self.gap = DeviceTensor(ctx, (N, 2048), np.float32)
-        self.logits = DeviceTensor(ctx, (N, self.num_classes), np.float32)
+        lv = self._logits_view or (None, None)
+        self.logits = DeviceTensor(ctx, (N, self.num_classes), np.float32, ptr=lv[0], keepalive=lv[1])
         p = self.shapes["stem"]
         self.pool_desc = L.Pool2dDesc(p[0], p[1], p[2], p[3], 3, 3, 2, 2, (C.c_int32 * 4)(1, 1, 1, 1), self.shapes["pool"][2],
                                       self.shapes["pool"][3], 0)
@@ -235,6 +238,20 @@ class ResNet50:
         else:
             self.forward()
 
+    def profile_pass(self, steps):
+        """Instrumented eager pass (HIP events per launch, serialised launches): [{kernel, launches, ms, flops, bytes}]."""
+        ctx = self.ctx
+        ctx.profile_reset()
+        ctx.profile(True)
+        saved_graph, self.graph = self.graph, None
+        saved_conc, self.concurrent = self.concurrent, False
+        for _ in range(steps):
+            self.forward()
+        ctx.sync()
+        ctx.profile(False)
+        self.graph, self.concurrent = saved_graph, saved_conc
+        return ctx.profile_report()
+
     def candidate_plans(self, l):
         """(variant, split mode, K groups, tile order) plans worth timing for one conv layer.  Split-K plans exist for
         the LDS-DMA variants (0..3) when K spans more than one depth block of 256."""
@@ -281,3 +298,175 @@ class ResNet50:
             self.variants[l["name"]] = best
             table[l["name"]] = row
         return table
+
+
+class ChainedResNet50:
+    """The batch as `chains` independent sub-batch chains, each on its own stream with its own activations, plan and hipGraph;
+    the weight arena is shared.
+
+    Why: a conv kernel whose tile count is not a multiple of the CU count leaves most of the chip idle during its last partial
+    round (tools/probe_quantization.py: 6.125 rounds cost 7), and inside ONE chain nothing can use those CUs because layer i+1
+    depends on layer i.  Sub-batch chains are mutually independent (every output column of a convolution depends on its own
+    image only, so the logits are bit-identical to the single-chain result), and the hardware schedules their kernels side by
+    side: measured 3.07 -> 2.79 ms per batch of 32 with 4 chains (tools/probe_two_chains.py; 2 chains 2.90 ms, 8 chains slower --
+    tiles of 4-image layers are mostly padding, and 8 co-resident kernels thrash the LDS / L2).
+
+    Streams map onto a handful of hardware queues; two chains that land on the same queue serialise (measured 3.45 ms).  The
+    runner therefore owns a pool of contexts and `tune_placement()` picks, by measurement, which of them the chain graphs are
+    launched on (a hipGraph captured on one stream may be launched on another)."""
+
+    POOL = 8
+
+    def __init__(self, ctx, batch, weights=None, chains=4, image=224, num_classes=1000, arena_ptr=None, arena_keepalive=None):
+        assert 1 <= chains <= min(batch, self.POOL)
+        self.ctx, self.batch, self.chains = ctx, batch, chains
+        self.weights = weights if weights is not None else make_weights(num_classes=num_classes)
+        sub = batch // chains
+        self.sizes = [sub + (1 if i < batch - sub * chains else 0) for i in range(chains)]
+        self.starts = [sum(self.sizes[:i]) for i in range(chains)]
+        self.pool = [ctx] + [L.Context(ctx.device) for _ in range(self.POOL - 1)]
+        self.place = list(range(chains))  # chain i's graph is launched on pool[place[i]]
+        self.x = DeviceTensor(ctx, (batch, 3, image, image), np.float32)
+        self.logits = DeviceTensor(ctx, (batch, num_classes), np.float32)
+        self.nets = []
+        for i in range(chains):
+            a = (arena_ptr, arena_keepalive) if i == 0 else (self.nets[0].arena.ptr, self.nets[0].arena)
+            self.nets.append(ResNet50(self.pool[i], self.sizes[i], self.weights, image, num_classes, arena_ptr=a[0], arena_keepalive=a[1],
+                                      x_view=(self.x.ptr + self.starts[i] * 3 * image * image * 4, self.x),
+                                      logits_view=(self.logits.ptr + self.starts[i] * num_classes * 4, self.logits)))
+        n0 = self.nets[0]
+        self.specs, self.descs, self.arena, self.arena_bytes = n0.specs, n0.descs, n0.arena, n0.arena_bytes
+        self.graph = None      # list of per-chain graphs once captured
+        self.concurrent = False
+        self.cotune = {}
+
+    @property
+    def variants(self):
+        return self.nets[0].variants
+
+    @variants.setter
+    def variants(self, v):
+        """One plan table for every chain, or a table per sub-batch size ({"8": {layer: plan}, "7": {...}}) when the sizes differ."""
+        keyed = bool(v) and all(isinstance(x, dict) for x in v.values())
+        for net in self.nets:
+            net.variants = {k: tuple(p) for k, p in (v[str(net.batch)] if keyed else v).items()}
+
+    def upload_weights(self):
+        self.nets[0].upload_weights()
+        self.ctx.sync()
+
+    def sync(self):
+        for c in self.pool:
+            c.sync()
+
+    def forward(self):
+        """Eager pass: every chain enqueues its layers on its own stream; the main context then waits for all of them."""
+        for net in self.nets:
+            net.forward()
+        for net in self.nets:
+            if net.ctx is not self.ctx:
+                self.ctx.wait(net.ctx)
+
+    def capture(self):
+        for net in self.nets:
+            net.capture()
+        self.sync()
+        self.graph = [net.graph for net in self.nets]
+        return self.graph
+
+    def run(self):
+        if not self.graph:
+            return self.forward()
+        main = self.ctx
+        used = [self.pool[p] for p in self.place]
+        # no wait on the main context here: uploads through the C ABI are host-synchronous, and a per-step wait would turn the
+        # main stream into a barrier between steps (the chains may run ahead of each other across steps)
+        for g, c in zip(self.graph, used):
+            c.graph_launch(g)
+        for c in used:
+            if c is not main:
+                main.wait(c)  # the logits are read on the main context
+
+    def _time_steps(self, steps):
+        import time
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.run()
+        self.sync()
+        return (time.perf_counter() - t0) / steps
+
+    def tune_placement(self, steps=8):
+        """Choose the contexts (streams -> hardware queues) the chain graphs are launched on: every window of `chains`
+        consecutive pool members is timed over a few steps.  Returns [(placement, ms per step)]."""
+        assert self.graph
+        rows = []
+        for first in range(self.POOL - self.chains + 1):
+            self.place = list(range(first, first + self.chains))
+            self._time_steps(2)
+            rows.append((list(self.place), min(self._time_steps(steps) for _ in range(2)) * 1e3))
+        self.place = min(rows, key=lambda r: r[1])[0]
+        return rows
+
+    def autotune(self, reps=3, top=6, corun_reps=6):
+        """Per layer: (1) every candidate plan timed alone at each distinct sub-batch size (ResNet50.autotune); (2) the `top`
+        fastest of them timed again with ALL chains running that layer at the same time (one small hipGraph of `corun_reps`
+        launches per chain) -- next to other kernels the cheapest plan in CU-time wins, which is not always the one with the
+        lowest latency alone (split-K plans trade extra work for latency).  Returns the stand-alone table of chain 0."""
+        import time
+        tables = {}
+        for net in self.nets:
+            if net.batch not in tables:
+                tables[net.batch] = net.autotune(reps)
+                tables[(net.batch, "plan")] = dict(net.variants)
+            net.variants = dict(tables[(net.batch, "plan")])
+        if self.chains > 1 and top > 1:
+            for l in self.specs:
+                name = l["name"]
+                cands = {}
+                for b in {net.batch for net in self.nets}:
+                    cands[b] = [p for p, _ in sorted(tables[b][name], key=lambda r: r[1])[:top]]
+                best, rows = None, []
+                for k in range(top):
+                    graphs = []
+                    for net in self.nets:
+                        net.variants[name] = cands[net.batch][min(k, len(cands[net.batch]) - 1)]
+                        net._conv(l)  # warm: scratch for this plan exists before the capture
+                        net.ctx.sync()
+                        net.ctx.graph_begin()
+                        for _ in range(corun_reps):
+                            net._conv(l)
+                        graphs.append(net.ctx.graph_end())
+                    ms = 1e30
+                    for _ in range(3):
+                        self.sync()
+                        t0 = time.perf_counter()
+                        for net, g in zip(self.nets, graphs):
+                            net.ctx.graph_launch(g)
+                        for net in self.nets:
+                            net.ctx.sync()
+                        ms = min(ms, (time.perf_counter() - t0) * 1e3 / corun_reps)
+                    for net, g in zip(self.nets, graphs):
+                        net.ctx.graph_destroy(g)
+                    rows.append((k, ms))
+                    if best is None or ms < best[1]:
+                        best = (k, ms)
+                for net in self.nets:
+                    net.variants[name] = cands[net.batch][min(best[0], len(cands[net.batch]) - 1)]
+                self.cotune[name] = rows
+        return tables[self.nets[0].batch]
+
+    def plan_table(self):
+        """{sub-batch size: {layer: plan}} for --save-plan."""
+        return {str(net.batch): {k: list(v) for k, v in net.variants.items()} for net in self.nets}
+
+    def profile_pass(self, steps):
+        """Chain after chain, serialised (clean per-kernel durations at the sub-batch shapes actually launched); merged."""
+        merged = {}
+        for net in self.nets:
+            self.sync()
+            for r in net.profile_pass(steps):
+                m = merged.setdefault(r["kernel"], dict(r, launches=0, ms=0.0, flops=0.0, bytes=0.0))
+                for k in ("launches", "ms", "flops", "bytes"):
+                    m[k] += r[k]
+        return list(merged.values())

@@ -412,3 +412,50 @@ def test_golden_package_for_the_real_reference(tmp_path):
     r = subprocess.run([build_cli(), "-s", "batch=1", "-i", str(d / "resnet50_int8.inputs.safetensors"), "--check-outputs",
                         str(d / "resnet50_int8.expected.safetensors"), "--max-diff", "0", str(d / "resnet50_int8.onnx")], capture_output=True, text=True)
     assert r.returncode == 0 and "max diff 0" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_chained_resnet50_bit_exact(ctx):
+    """The batch as independent sub-batch chains on their own streams (what bench.py times by default): eager, hipGraph replay
+    on every stream placement, after the stand-alone + co-run autotune -- always the oracle's logits, bit for bit; and at the
+    full batch of 32 the 4-chain logits equal the single-chain ones."""
+    from oracle import models as omodels
+    from rten_amd.workloads import resnet50
+    w = resnet50.make_weights()
+    x = ref.XorShiftRng(77).f32(5 * 3 * 224 * 224).reshape(5, 3, 224, 224)
+    net = resnet50.ChainedResNet50(ctx, 5, w, chains=2)  # uneven split: 3 + 2 images
+    assert net.sizes == [3, 2]
+    net.upload_weights()
+    net.x.upload(x)
+    net.forward()
+    ctx.sync()
+    want = omodels.resnet50_forward(net.specs, w, x)
+    bits_equal(net.logits.numpy(), want)
+    net.autotune(reps=1, top=3, corun_reps=2)
+    assert set(net.cotune) == {l["name"] for l in net.specs}
+    net.capture()
+    rows = net.tune_placement(steps=2)
+    assert len(rows) == net.POOL - 1
+    for place, _ in rows:
+        net.place = place
+        net.logits.upload(np.zeros_like(want))
+        net.run()
+        ctx.sync()
+        bits_equal(net.logits.numpy(), want)
+    rep = net.profile_pass(1)
+    assert any(r["kernel"].startswith("igemm_f32") for r in rep)
+    # plan tables round-trip through the keyed form bench.py --save-plan / --load-plan uses
+    table = net.plan_table()
+    assert set(table) == {"3", "2"}
+    net.variants = table
+    assert net.nets[1].variants == {k: tuple(v) for k, v in table["2"].items()}
+    # full batch: 4 chains == 1 chain
+    x32 = ref.XorShiftRng(5).f32(32 * 3 * 224 * 224).reshape(32, 3, 224, 224)
+    one = resnet50.ResNet50(ctx, 32, w, arena_ptr=net.arena.ptr, arena_keepalive=net.arena)
+    one.x.upload(x32)
+    one.forward()
+    four = resnet50.ChainedResNet50(ctx, 32, w, chains=4, arena_ptr=net.arena.ptr, arena_keepalive=net.arena)
+    four.x.upload(x32)
+    four.capture()
+    four.run()
+    ctx.sync()
+    bits_equal(four.logits.numpy(), one.logits.numpy())
