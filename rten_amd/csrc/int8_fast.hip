@@ -55,6 +55,7 @@ struct FastArgs {
     int tiles_m, tiles_n, n_fastest;
     // conv geometry (padded image)
     int conv, OW, sy, sx, Hp, Wp, Cp, KH, KW, dy, dx;
+    int debug; // RTEN_HIP_DEBUG ablation bits (timing experiments only; results are wrong): 0x1000 one k-tile, 0x2000 no stores, 0x4000 no statistics atomics
 };
 
 __device__ __forceinline__ int zp_signed(const uint8_t *zp, int idx, int is_signed) {
@@ -281,19 +282,27 @@ __global__ __launch_bounds__(256) void i8_quantize_stage_kernel(const float *__r
 // overhead for the f32 loop); the long-K launches of stages 2-3 therefore take 256-byte k-tiles.  All LDS is ONE dynamic array.
 extern __shared__ __attribute__((aligned(16))) uint8_t i8_smem[];
 
-template <int BM, int BN, int NSTAGE, bool RES, int KTK = 64>
-__global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p) {
+// KG = k-groups: the workgroup has KG x 4 waves; group g takes k-tiles g, g + KG, ... into accumulators of its own, and the
+// groups' partial sums are added through LDS before the (group 0) epilogue -- exact, integer addition is order-free.  An
+// under-filled launch (stage 3-4 of ResNet-50 at batch 32: ~200 tiles of 64 x 64 for 256 CUs) otherwise runs ONE wave per
+// SIMD, and every latency of its k-loop (barrier, DMA issue, LDS fragment reads, dependent MFMAs: ~550 cycles per 64-byte
+// k-tile, independent of where the operands come from -- profiles/r05/int8_kloop_ablation.txt) is exposed 72 times in a row.
+template <int BM, int BN, int NSTAGE, bool RES, int KTK = 64, int KG = 1>
+__global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kernel(const FastArgs p) {
     constexpr int WM = 2, WN = 2;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int RA = BM / 64, RB = BN / 64;      // DMA instructions per chunk (64 rows each)
     constexpr int CPW = KTK / 64;                  // chunks per wave per tile: wave w moves chunks w, w + 4, ... of the tile
     constexpr int PER_TILE = (RA + RB) * CPW;
-    constexpr int STAGE = (BM + BN) * KTK;         // bytes
+    constexpr int SUB = (BM + BN) * KTK;           // bytes of one k-tile
+    constexpr int STAGE = SUB * KG;                // a stage holds one k-tile per group
     uint8_t *const smem = i8_smem;
 
     const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wq = t >> 6;
+    const int wave_all = __builtin_amdgcn_readfirstlane(t >> 6); // 0 .. 4 KG - 1
+    const int kg = wave_all >> 2;                                // k-group of this wave
+    const int wave = wave_all & 3;                               // wave within the group: its chunk slot and its quadrant of the tile
+    const int wq = wave;
     const int l31 = lane & 31, half = lane >> 5;
     int tile;
     {
@@ -329,39 +338,62 @@ __global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p)
         }
     }
 
-    // this wave's chunk walk: chunk index wave, wave + 4, ...  (conv: (ky, kx, c16) odometer, no divisions)
+    // ---- this wave's chunk walk: chunk index wave, wave + 4, ... of the K axis (16-byte chunks).
+    // The B-side scalar offset of a chunk -- conv: its (ky, kx, c16) position on the padded image -- comes from a table that the
+    // workgroup builds in LDS before the loop (one division pair per chunk, once), and everything the loop derives from the
+    // walk is kept in scalar registers: the previous form carried an odometer in vector registers and paid ~100 VALU + SALU
+    // instructions per k-tile, waterfall loops around the DMA included, for two 32-cycle MFMAs (counters: profiles/r05).
     const int nchunks = p.Kp / 16;
-    const int cpc = p.conv ? p.Cp / 16 : 1; // chunks per tap
-    int ch_idx = wave;                      // chunk index of the next tile to issue
-    int ch_c = 0, ch_kx = 0, ch_ky = 0;
-    if (p.conv) {
-        ch_c = wave;
-        while (ch_c >= cpc) { ch_c -= cpc; if (++ch_kx == p.KW) { ch_kx = 0; ch_ky++; } }
+    const int nkt = (p.Kp + KTK - 1) / KTK;
+    const int nit = (p.debug & 0x1000) ? 1 : (nkt + KG - 1) / KG;   // loop trips: KG k-tiles per trip
+    const int tchunks = ((nkt + KG - 1) / KG + NSTAGE) * KG * (KTK / 16); // chunks the walk can name (>= nchunks; the tail is dead)
+    int *const btab = reinterpret_cast<int *>(smem + NSTAGE * STAGE);
+    {
+        const int cpc = p.conv ? p.Cp / 16 : 1; // chunks per tap
+        for (int c = t; c < tchunks; c += 256 * KG) {
+            int off = -1; // dead chunk: K padding
+            if (c < nchunks) {
+                if (p.conv) {
+                    const int tap = c / cpc, cc = c - tap * cpc, ky = tap / p.KW, kx = tap - ky * p.KW;
+                    if (ky < p.KH) off = ((cc * p.Hp + ky * p.dy) * p.Wp + kx * p.dx) * 16;
+                } else {
+                    off = c * 16 * p.N;
+                }
+            }
+            btab[c] = off;
+        }
     }
+    __syncthreads();
+    int ch_idx = __builtin_amdgcn_readfirstlane(wave_all); // chunk index of the next piece to issue: wave_all, wave_all + 4 KG, ...
+    // the table entries of this wave's next 64 pieces ride in one vector register (lane i = i-th piece from here) and are picked
+    // with v_readlane: no LDS round trip on the issue path.  Refilled every 64 pieces.
+    auto bo_fill = [&](int first) {
+        const int c = first + 4 * KG * lane;
+        return c < tchunks ? btab[c] : -1;
+    };
+    int bo_vec = bo_fill(ch_idx);
+    int bo_pos = 0;
+    const unsigned a_step = 16u * (unsigned)p.M;
     typedef __attribute__((address_space(3))) void *lds_ptr_t;
     auto issue_tile = [&](int stage) {
 #pragma unroll
         for (int q = 0; q < CPW; q++) { // LDS chunk slot wave + 4 q of the tile <- this wave's next chunk (its walk is every 4th chunk)
-            uint8_t *As = smem + stage * STAGE + (wave + 4 * q) * BM * 16;
-            uint8_t *Bs = smem + stage * STAGE + BM * KTK + (wave + 4 * q) * BN * 16;
-            const bool live = ch_idx < nchunks;
-            const unsigned a_soff = live ? (unsigned)ch_idx * 16u * (unsigned)p.M : 0u;
-            unsigned b_soff = live ? (unsigned)ch_idx * 16u * (unsigned)p.N : 0u;
-            bool b_live = live;
-            if (p.conv) {
-                b_live = live && ch_ky < p.KH;
-                b_soff = b_live ? (unsigned)(((ch_c * p.Hp + ch_ky * p.dy) * p.Wp + ch_kx * p.dx) * 16) : 0u;
-            }
+            uint8_t *As = smem + stage * STAGE + kg * SUB + (wave + 4 * q) * BM * 16;
+            uint8_t *Bs = smem + stage * STAGE + kg * SUB + BM * KTK + (wave + 4 * q) * BN * 16;
+            const int bo = __builtin_amdgcn_readlane(bo_vec, bo_pos);
+            const bool a_live = ch_idx < nchunks, b_live = bo >= 0;
+            const unsigned a_soff = (a_live && !(p.debug & 0x10000)) ? (unsigned)ch_idx * a_step : 0u; // (ablation: every piece = piece 0)
+            const unsigned b_soff = (b_live && !(p.debug & 0x20000)) ? (unsigned)bo : 0u;
 #pragma unroll
             for (int j = 0; j < RA; j++)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(As + j * 1024), 16, (int)(live ? a_voff[j] : OOB), (int)a_soff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(As + j * 1024), 16, (int)(a_live ? a_voff[j] : OOB), (int)a_soff, 0, 0);
 #pragma unroll
             for (int j = 0; j < RB; j++)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(Bs + j * 1024), 16, (int)(b_live ? b_voff[j] : OOB), (int)b_soff, 0, 0);
-            ch_idx += 4;
-            if (p.conv) {
-                ch_c += 4;
-                while (ch_c >= cpc) { ch_c -= cpc; if (++ch_kx == p.KW) { ch_kx = 0; ch_ky++; } }
+            ch_idx += 4 * (CPW == 1 ? KG : 1);
+            if (++bo_pos == 64) {
+                bo_vec = bo_fill(ch_idx);
+                bo_pos = 0;
             }
         }
     };
@@ -379,25 +411,33 @@ __global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p)
     for (int j = 0; j < TN; j++) cs[j] = 0;
 
     auto compute_tile = [&](int stage) {
-        const uint8_t *As = smem + stage * STAGE + (wm0 + l31) * 16;
-        const uint8_t *Bs = smem + stage * STAGE + BM * KTK + (wn0 + l31) * 16;
+        const uint8_t *As = smem + stage * STAGE + kg * SUB + (wm0 + l31) * 16;
+        const uint8_t *Bs = smem + stage * STAGE + kg * SUB + BM * KTK + (wn0 + l31) * 16;
+        constexpr int NS = KTK / 32; // MFMA k-steps per tile; all fragment reads of a 64-byte tile are issued before its first MFMA
+        i32x4 af[NS < 2 ? NS : 2][TM], bf[NS < 2 ? NS : 2][TN];
 #pragma unroll
-        for (int s = 0; s < KTK / 32; s++) {
-            i32x4 af[TM], bf[TN];
+        for (int s0 = 0; s0 < NS; s0 += 2) {
 #pragma unroll
-            for (int i = 0; i < TM; i++) af[i] = *reinterpret_cast<const i32x4 *>(As + ((2 * s + half) * BM + i * 32) * 16);
+            for (int u = 0; u < 2 && s0 + u < NS; u++) {
+                const int s = s0 + u;
 #pragma unroll
-            for (int j = 0; j < TN; j++) bf[j] = *reinterpret_cast<const i32x4 *>(Bs + ((2 * s + half) * BN + j * 32) * 16);
-            if (p.need_csum) {
+                for (int i = 0; i < TM; i++) af[u][i] = *reinterpret_cast<const i32x4 *>(As + ((2 * s + half) * BM + i * 32) * 16);
 #pragma unroll
-                for (int j = 0; j < TN; j++)
-#pragma unroll
-                    for (int q = 0; q < 4; q++) cs[j] = __builtin_amdgcn_sdot4(bf[j][q], 0x01010101, cs[j], false);
+                for (int j = 0; j < TN; j++) bf[u][j] = *reinterpret_cast<const i32x4 *>(Bs + ((2 * s + half) * BN + j * 32) * 16);
             }
 #pragma unroll
-            for (int i = 0; i < TM; i++)
+            for (int u = 0; u < 2 && s0 + u < NS; u++) {
+                if (p.need_csum) {
 #pragma unroll
-                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; j++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) cs[j] = __builtin_amdgcn_sdot4(bf[u][j][q], 0x01010101, cs[j], false);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[u][i], bf[u][j], acc[i][j], 0, 0, 0);
+            }
         }
     };
 
@@ -411,7 +451,7 @@ __global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p)
     const int mb = m0 + wm0 + 4 * half;
     int rc_rsum = 0, rc_az = 0;
     float rc_bias = 0.f, rc_srow = 0.f;
-    if (t < BM) {
+    if (t < BM) { // (threads of k-group 0)
         const int m = m0 + t < p.M ? m0 + t : 0;
         rc_rsum = p.rsum[m];
         rc_az = zp_signed(p.a_zp, p.a_zp_len > 1 ? m % p.a_zp_len : 0, p.a_signed); // GEMM: period < M cycles the zero points (matmul.rs:266-280)
@@ -437,25 +477,25 @@ __global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p)
     const int mb_u = m0 + (wave / WN) * (BM / WM);
     [[maybe_unused]] float rr[RES ? TM : 1][RES ? TN : 1][16];
     if constexpr (RES) {
+        if (KG == 1 || kg == 0) {
 #pragma unroll
-        for (int i = 0; i < TM; i++)
+            for (int i = 0; i < TM; i++)
 #pragma unroll
-            for (int j = 0; j < TN; j++)
+                for (int j = 0; j < TN; j++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int m = mb + i * 32 + acc_row(r);
-                    const unsigned vo = (m < p.M && basev[j] != OOB) ? basev[j] + half_off : OOB;
-                    rr[i][j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)vo, (int)((unsigned)(mb_u + i * 32 + acc_row(r)) * rs4), 0));
-                }
+                    for (int r = 0; r < 16; r++) {
+                        const int m = mb + i * 32 + acc_row(r);
+                        const unsigned vo = (m < p.M && basev[j] != OOB) ? basev[j] + half_off : OOB;
+                        rr[i][j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)vo, (int)((unsigned)(mb_u + i * 32 + acc_row(r)) * rs4), 0));
+                    }
+        }
     }
 
-    const int nk = (p.Kp + KTK - 1) / KTK;
 #pragma unroll
     for (int i = 0; i < NSTAGE - 1; i++) issue_tile(i);
-    // (A two-fragment-set software pipeline of the LDS reads under the MFMAs was measured and is slower: these
-    // launches are bound by the miss latency of the tile DMA, not by the read -> MFMA chain.)
+    // (A two-fragment-set software pipeline of the LDS reads under the MFMAs was measured and is slower.)
     int stage = 0;
-    for (int kt = 0; kt < nk; kt++) {
+    for (int it = 0; it < nit; it++) {
         wait_vmcnt<PER_TILE *(NSTAGE - 2)>();
         __builtin_amdgcn_s_barrier();
         const int stp = stage == 0 ? NSTAGE - 1 : stage - 1;
@@ -464,7 +504,40 @@ __global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p)
         stage = stage == NSTAGE - 1 ? 0 : stage + 1;
     }
     wait_vmcnt<0>();
-    __syncthreads(); // every wave is done with the stage buffers: park the row constants there
+    __syncthreads(); // every wave is done with the stage buffers
+    if constexpr (KG > 1) {
+        // partial sums of k-groups 1 .. KG-1 -> LDS ([group][register][thread of the group]: 1 KiB per wave store), added by group 0
+        int *red = reinterpret_cast<int *>(smem);
+        constexpr int RW = TM * TN * 16 + TN; // words per thread: accumulators + column-sum partials
+        const int tg = t & 255;
+        if (kg > 0) {
+            int *dst = red + (kg - 1) * RW * 256 + tg;
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) dst[((i * TN + j) * 16 + r) * 256] = acc[i][j][r];
+#pragma unroll
+            for (int j = 0; j < TN; j++) dst[(TM * TN * 16 + j) * 256] = cs[j];
+        }
+        __syncthreads();
+        if (kg == 0) {
+#pragma unroll
+            for (int g = 1; g < KG; g++) {
+                const int *src = red + (g - 1) * RW * 256 + tg;
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) acc[i][j][r] += src[((i * TN + j) * 16 + r) * 256];
+#pragma unroll
+                for (int j = 0; j < TN; j++) cs[j] += src[(TM * TN * 16 + j) * 256];
+            }
+        }
+        __syncthreads(); // the row constants are parked over the same bytes next
+    }
     int *rowc = reinterpret_cast<int *>(smem); // [4][BM]: row sum, a_zp, bias, per-row scale
     if (t < BM) {
         rowc[t] = rc_rsum;
@@ -477,6 +550,7 @@ __global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p)
 #pragma unroll
         for (int j = 0; j < TN; j++) csv[j] = (unsigned)(cs[j] + __shfl_xor(cs[j], 32, 64)); // the two k halves of the column
     }
+    if (KG > 1 && kg != 0) return; // the epilogue belongs to k-group 0 (no barrier follows)
 
     // ---- epilogue: zero-point algebra, optional cast_scale / bias / residual / relu, store.  16 accumulator
     // registers (one 32 x 32 block) are finished at a time; all of a block's stores are issued back to back.
@@ -530,7 +604,7 @@ __global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const unsigned x = v[r];
-                __builtin_amdgcn_raw_buffer_store_b32(x, rsC, (int)((mok[r] && cok) ? basev[j] + half_off : OOB),
+                __builtin_amdgcn_raw_buffer_store_b32(x, rsC, (int)((mok[r] && cok && !(p.debug & 0x2000)) ? basev[j] + half_off : OOB),
                                                       (int)((unsigned)(mb_u + i * 32 + acc_row(r)) * rs4), 0);
             }
         }
@@ -538,7 +612,7 @@ __global__ __launch_bounds__(256, 2) void igemm_i8_fast_kernel(const FastArgs p)
     if (p.stats) {
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) { st_mn = fminf(st_mn, __shfl_xor(st_mn, o, 64)); st_mx = fmaxf(st_mx, __shfl_xor(st_mx, o, 64)); }
-        if (lane == 0) {
+        if (lane == 0 && !(p.debug & 0x4000)) {
             const unsigned slot = (blockIdx.x * 4u + (unsigned)wq) % (unsigned)dql::kStatSlots;
             atomicMin(&p.stats[slot], dql::f2ord(st_mn));
             atomicMax(&p.stats[dql::kStatSlots + slot], dql::f2ord(st_mx));
@@ -584,19 +658,23 @@ __global__ __launch_bounds__(256) void i8_pack_rows_t_kernel(const uint8_t *__re
 
 inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-template <int BM, int BN, int NST, int KTK = 64>
+template <int BM, int BN, int NST, int KTK = 64, int KG = 1>
 void launch_fast(rten_hip_ctx *ctx, FastArgs &a, const char *name, double ops, double bytes) {
+    static_assert(KTK == 64 || KG == 1, "k-groups walk 64-byte k-tiles");
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.N + BN - 1) / BN;
+    a.debug = ctx->debug;
     ProfScope ps(ctx, name, ops, bytes);
-    constexpr size_t lds = (size_t)NST * (BM + BN) * KTK;
-    static_assert(lds <= 160 * 1024, "int8 tile ring exceeds the LDS of a compute unit");
+    constexpr size_t ring = (size_t)NST * KG * (BM + BN) * KTK;
+    static_assert(ring <= 128 * 1024, "int8 tile ring exceeds the LDS of a compute unit");
+    const int nkt = (a.Kp + KTK - 1) / KTK;
+    const size_t lds = ring + (size_t)((nkt + KG - 1) / KG + NST) * KG * (KTK / 16) * 4; // + the chunk -> B offset table
     auto go = [&](auto kern) {
         if (lds > 64 * 1024) hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), lds, ctx->stream, a);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256 * KG), lds, ctx->stream, a);
     };
-    if (a.res && a.scale) go(igemm_i8_fast_kernel<BM, BN, NST, true, KTK>);
-    else go(igemm_i8_fast_kernel<BM, BN, NST, false, KTK>);
+    if (a.res && a.scale) go(igemm_i8_fast_kernel<BM, BN, NST, true, KTK, KG>);
+    else go(igemm_i8_fast_kernel<BM, BN, NST, false, KTK, KG>);
 }
 
 int32_t dispatch_fast(rten_hip_ctx *ctx, FastArgs &a, double ops, double bytes) {
@@ -608,19 +686,22 @@ int32_t dispatch_fast(rten_hip_ctx *ctx, FastArgs &a, double ops, double bytes) 
     // tile order: consecutive workgroup ids (one XCD's share) walk the axis of the SMALLER operand, so that the larger
     // one is fetched into as few of the eight L2s as possible
     a.n_fastest = (double)a.a_bytes > (double)a.b_bytes ? 1 : 0;
-    // k-tile depth: 64 bytes per trip; RTEN_HIP_DEBUG bit 0x200 selects 256-byte (128 for the 128x128 tile) trips for K >= 512.
-    const bool deep = a.Kp >= 512 && (ctx->debug & 0x200); // measured (profiles/r05): slower -- the long-K launches are bound by L2 -> LDS DMA parallelism across workgroups, and the 96 KiB ring leaves one workgroup per CU
+    // (256-byte k-tiles were measured and are slower: profiles/r05/int8_notes.md)
     if (tile == 0) {
-        if (deep) launch_fast<128, 128, 3, 128>(ctx, a, "igemm_i8_fast_kernel<128,128,k128>", ops, bytes);
-        else launch_fast<128, 128, 3>(ctx, a, "igemm_i8_fast_kernel<128,128>", ops, bytes);
+        launch_fast<128, 128, 3>(ctx, a, "igemm_i8_fast_kernel<128,128>", ops, bytes);
     } else if (tile == 1) {
-        if (deep) launch_fast<128, 64, 3, 256>(ctx, a, "igemm_i8_fast_kernel<128,64,k256>", ops, bytes);
-        else launch_fast<128, 64, 3>(ctx, a, "igemm_i8_fast_kernel<128,64>", ops, bytes);
+        launch_fast<128, 64, 3>(ctx, a, "igemm_i8_fast_kernel<128,64>", ops, bytes);
     } else if (tile == 2) {
-        if (deep) launch_fast<64, 128, 3, 256>(ctx, a, "igemm_i8_fast_kernel<64,128,k256>", ops, bytes);
-        else launch_fast<64, 128, 3>(ctx, a, "igemm_i8_fast_kernel<64,128>", ops, bytes);
+        launch_fast<64, 128, 3>(ctx, a, "igemm_i8_fast_kernel<64,128>", ops, bytes);
     } else {
-        if (deep) launch_fast<64, 64, 3, 256>(ctx, a, "igemm_i8_fast_kernel<64,64,k256>", ops, bytes);
+        // under-filled launches (fewer than ~2 workgroups per CU) split K over 2 or 4 k-groups inside the workgroup: more waves
+        // per SIMD to hide the k-loop's latencies behind each other (RTEN_HIP_DEBUG bit 0x800 turns this off)
+        const long long t64 = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64);
+        const int nkt = (a.Kp + 63) / 64;
+        // measured (profiles/r05/int8_per_layer.txt): 4 groups pay off below ~1.25 workgroups per CU with K >= 1024 bytes (stage-4 3x3:
+        // 20.8 -> 14.8 us); 2 groups on the 1.5-workgroup launches of stage 3 do not (10.3 -> 11.5 us) and are not used
+        const int kgs = (ctx->debug & 0x800) ? 1 : (t64 * 4 <= 5 * ctx->num_cus && nkt >= 16 ? 4 : 1);
+        if (kgs == 4) launch_fast<64, 64, 3, 64, 4>(ctx, a, "igemm_i8_fast_kernel<64,64,kg4>", ops, bytes);
         else launch_fast<64, 64, 3>(ctx, a, "igemm_i8_fast_kernel<64,64>", ops, bytes);
     }
     RTEN_LAUNCH_CHECK(ctx, "igemm_i8_fast_kernel launch");
@@ -631,7 +712,7 @@ int32_t dispatch_fast(rten_hip_ctx *ctx, FastArgs &a, double ops, double bytes) 
 
 namespace {
 inline int gemm_kp(int k) { return (k + KT - 1) / KT * KT; }
-inline bool gemm_b_covered(int k, int n) { return k > 0 && n > 0 && (long long)n * gemm_kp(k) < (1ll << 31); }
+inline bool gemm_b_covered(int k, int n) { return k > 0 && n > 0 && k <= (1 << 18) && (long long)n * gemm_kp(k) < (1ll << 31); } // K bound: the kernel's chunk table lives in LDS
 
 // rows of a strided u8 / i8 matrix -> chunk-major signed operand + row sums (both packers; see the kernels)
 void pack_rows(rten_hip_ctx *ctx, const void *src, long long row_stride, long long k_stride, int rows, int k, int Kp, unsigned flip, char *dst, char *sums) {
@@ -710,7 +791,7 @@ ConvGeom conv_geom(const rten_hip_conv2d_int8_desc *di) {
     g.Kp = (g.taps * g.Cp + KT - 1) / KT * KT;
     g.P = d->out_h * d->out_w;
     g.img = (size_t)d->n * g.Hp * g.Wp * g.Cp;
-    g.ok = d->groups == 1 && d->c > 0 && d->o > 0 &&
+    g.ok = d->groups == 1 && d->c > 0 && d->o > 0 && g.Kp <= (1 << 18) && // (the kernel's chunk -> offset table lives in LDS)
            // the chunk walk addresses taps on the padded image: the window must fit (true for valid conv geometry)
            (d->out_h - 1) * d->stride_h + (d->kh - 1) * d->dil_h < g.Hp && (d->out_w - 1) * d->stride_w + (d->kw - 1) * d->dil_w < g.Wp &&
            g.img < (1ull << 31) && (size_t)d->o * g.Kp < (1ull << 31) && (long long)d->n * d->o * g.P < (1ll << 29);

@@ -1,0 +1,10 @@
+#!/bin/bash
+tag=${1:-r2y}
+mkdir -p gpurun_out
+timeout 600 python bench.py --config int8 --steps 50 --warmup 20 --no-cpu-baseline > gpurun_out/${tag}_bench_int8.json 2> gpurun_out/${tag}_bench_int8.err
+echo "rc=$?"
+python - <<PY
+import json
+d=json.loads(open("gpurun_out/${tag}_bench_int8.json").read().strip().splitlines()[-1])
+print(d["value"], d["ms_per_step"], d["roofline"]["kernel"], d["roofline"]["frac"], d["roofline"]["step"])
+PY

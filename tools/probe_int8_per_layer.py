@@ -31,8 +31,11 @@ def timed(fn):
 
 tq = tc = 0.0
 print(f"{'layer':9s} {'O':>4s} {'C':>4s} k s {'HxW':>7s} | {'quant us':>8s} {'GB/s':>6s} | {'conv us':>8s} {'GB/s':>6s} {'TOP/s':>6s}  tiles(128x128)")
+ONLY = os.environ.get("LAYERS")
 for l in net.specs:
     name = l["name"]
+    if ONLY and name not in ONLY.split(","):
+        continue
     d = net.idesc[name]
     cv = d.conv
     src = net._act(l["src"])
