@@ -133,6 +133,12 @@ RTEN_EXPORT int32_t rten_hip_init(int32_t device_id, void *external_stream, rten
         }
         ctx->own_stream = true;
     }
+    // arrival counters of the split-K producers (gemm_f32.hip, split_finish): zero now, left zero by every launch
+    if (hipMalloc((void **)&ctx->split_counters, rten_hip_ctx::kSplitCounters * sizeof(unsigned)) != hipSuccess ||
+        hipMemset(ctx->split_counters, 0, rten_hip_ctx::kSplitCounters * sizeof(unsigned)) != hipSuccess) {
+        if (ctx->split_counters) hipFree(ctx->split_counters);
+        ctx->split_counters = nullptr; // the fixup-kernel path needs none
+    }
     *out_ctx = ctx;
     return RTEN_HIP_OK;
 }
@@ -153,6 +159,7 @@ RTEN_EXPORT int32_t rten_hip_destroy(rten_hip_ctx *ctx) {
             if (e) hipEventDestroy(e);
     if (ctx->scratch) hipFree(ctx->scratch);
     if (ctx->aux) hipFree(ctx->aux);
+    if (ctx->split_counters) hipFree(ctx->split_counters);
     for (auto &kv : ctx->luts) hipFree(kv.second);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;

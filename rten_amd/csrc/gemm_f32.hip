@@ -87,6 +87,7 @@ struct GemmArgs {
     // split_s groups of split_g blocks; each block's raw accumulator is parked in slab slot `blk` of its tile and
     // the fixup kernel replays the unsplit fold over the slots in block order -> bit-identical to the unsplit chain.
     float *slab;
+    unsigned *split_counters; // arrival counters, one per split tile (zero between launches); NULL: the fixup kernel folds
     int split_t1, split_s, split_g, split_slots, split_ntail;
     int order; // bit 0: tiles walk n fastest (default m fastest); bit 1: split workgroups walk tiles fastest, K groups slowest
     int n_lo;  // thin-tile kernel: first column of its share (the whole-round tiles of the same call cover [0, n_lo))
@@ -98,6 +99,17 @@ __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned vo
 }
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+// Coherent (sc0 sc1) accesses: the store writes through to memory, the load bypasses this XCD's L2.  Used for the split-K slab
+// when the tile is folded in the same launch by a workgroup that may sit on another XCD (split_finish): the eight L2s are not
+// coherent with each other inside a kernel, and fencing instead (L2 write-back + invalidate per workgroup) throws away the
+// weights and activations every other workgroup has cached -- measured: the whole forward pass 2.8 -> 3.6 ms.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void coherent_store4(__amdgpu_buffer_rsrc_t r, unsigned off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)off, 0, 17);
+}
+__device__ __forceinline__ f32x4 coherent_load4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 17));
 }
 
 
@@ -226,6 +238,65 @@ __device__ __forceinline__ void store_out(const GemmArgs &p, f32x16 (&val)[TM][T
             }
         }
     }
+}
+
+
+// Split-K, last arrival folds: a producer workgroup that has parked its depth blocks in the slab announces itself on the
+// tile's counter; the workgroup that finds all the others already there replays the unsplit fold over the slots in
+// depth-block order (exactly what igemm_f32_fixup_kernel does: first block beta * C + bias, later blocks separate adds, then
+// the shared epilogue) and clears the counter for the next launch.  Which workgroup arrives last varies from run to run;
+// the order of the additions does not.  Visibility across the eight XCDs' L2s: the slab is written with write-through stores and
+// read back with L2-bypassing loads (coherent_store4 / coherent_load4); a wave's stores are acknowledged (vmcnt 0) before its
+// workgroup arrives on the counter, an agent-scope atomic.  No cache-wide fence.
+// Saves the fixup launch (ResNet-50 batch 1: 34 of 90 launches) and its dependency gap.  `flag` = one LDS word.
+template <int BM, int BN, int TM, int TN>
+__device__ __forceinline__ void split_finish(const GemmArgs &p, int z, int tile, int wq, int lane, int m0, int n0, long long c_zoff, int *flag) {
+    constexpr int WM = 2, WN = 2;
+    const int ti = tile - p.split_t1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's write-through slab stores have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(p.split_counters + (long long)z * p.split_ntail + ti, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = old == (unsigned)p.split_s - 1u;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm0 = (wq / WN) * (BM / WM), wn0 = (wq % WN) * (BN / WN);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(p.slab + ((long long)z * p.split_ntail + ti) * p.split_slots * (long long)(BM * BN)), 0, (int)((unsigned)p.split_slots * (BM * BN) * 4u), 0x00020000);
+    const unsigned loff = (unsigned)(wq * (TM * TN * 16 * 64) + lane * 4) * 4u;
+    constexpr int U = TM * TN >= 2 ? 1 : 2; // slots fetched per batch: kept small, the fold shares the producer kernel's register budget (occupancy): their loads are all in flight before the first fold
+    f32x16 acc[U][TM][TN], tot[TM][TN];
+    auto load_raw = [&](f32x16 (&v)[TM][TN], int slot) {
+        const unsigned b = loff + (unsigned)slot * (BM * BN) * 4u;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const f32x4 o = coherent_load4(rs, b + (unsigned)(((i * TN + j) * 4 + q) * 256) * 4u);
+                    v[i][j][4 * q] = o[0]; v[i][j][4 * q + 1] = o[1]; v[i][j][4 * q + 2] = o[2]; v[i][j][4 * q + 3] = o[3];
+                }
+    };
+    const int mb = m0 + wm0 + 4 * half, nb0 = n0 + wn0 + l31;
+    // slot index past the end: the buffer's range check returns zeros and the value is never folded
+#pragma unroll
+    for (int u = 0; u < U; u++) load_raw(acc[u], u);
+    fold_first<TM, TN>(p, z, acc[0], tot, mb, nb0, c_zoff);
+#pragma unroll
+    for (int u = 1; u < U; u++)
+        if (u < p.split_slots) fold_next<TM, TN>(p, acc[u], tot);
+    for (int s = U; s < p.split_slots; s += U) {
+#pragma unroll
+        for (int u = 0; u < U; u++) load_raw(acc[u], s + u);
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (s + u < p.split_slots) fold_next<TM, TN>(p, acc[u], tot);
+    }
+    store_out<TM, TN>(p, tot, mb, nb0, c_zoff);
+    if (threadIdx.x == 0) p.split_counters[(long long)z * p.split_ntail + ti] = 0u;
 }
 
 // MODE: 0 = one depth block, 1 = several depth blocks folded in registers, 2 = split-K producer (see the LDS-DMA kernel).
@@ -527,6 +598,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_kernel(const GemmArgs p
         int loff = wave * (TM * TN * 16 * 64) + lane * 4;
         asm volatile("" : "+v"(loff));
         float *base = p.slab + (((long long)z * p.split_ntail + (tile - p.split_t1)) * p.split_slots + slot) * (long long)(BM * BN) + loff;
+        if (p.split_counters) { // folded in this launch, possibly on another XCD: write through (see coherent_store4)
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(base - loff), 0, BM * BN * 4, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        f32x4 o = {v[i][j][4 * q], v[i][j][4 * q + 1], v[i][j][4 * q + 2], v[i][j][4 * q + 3]};
+                        coherent_store4(rs, (unsigned)(loff + ((i * TN + j) * 4 + q) * 256) * 4u, o);
+                    }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -586,6 +670,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_kernel(const GemmArgs p
                 store_out<TM, TN>(p, acc, mb, nb0, c_zoff);
             }
         }
+    } else if (p.split_counters) {
+        split_finish<BM, BN, TM, TN>(p, z, tile, wave, lane, m0, n0, c_zoff, reinterpret_cast<int *>(smem));
     }
 }
 
@@ -870,6 +956,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
         int loff = wq * (TM * TN * 16 * 64) + lane * 4;
         asm volatile("" : "+v"(loff)); // keep the address math at the use (not hoisted across the K loop)
         float *base = p.slab + (((long long)z * p.split_ntail + (tile - p.split_t1)) * p.split_slots + slot) * (long long)(BM * BN) + loff;
+        if (p.split_counters) { // folded in this launch, possibly on another XCD: write through (see coherent_store4)
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(base - loff), 0, BM * BN * 4, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        f32x4 o = {v[i][j][4 * q], v[i][j][4 * q + 1], v[i][j][4 * q + 2], v[i][j][4 * q + 3]};
+                        coherent_store4(rs, (unsigned)(loff + ((i * TN + j) * 4 + q) * 256) * 4u, o);
+                    }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -929,8 +1028,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
     }
     wait_vmcnt<0>(); // drain the two look-ahead tiles before the LDS goes away
 
+    if (SPLIT || (MIXED && grp >= 0)) {
+        if (p.split_counters) split_finish<BM, BN, TM, TN>(p, z, tile, wq, lane, m0, n0, c_zoff, reinterpret_cast<int *>(smem));
+        return;
+    }
     if constexpr (!SPLIT) {
-        if (MIXED && grp >= 0) return;
         if (!(ABLATE(p) & 4)) {
             const int mb = m0 + wm0 + 4 * half, nb0 = n0 + wn0 + l31;
             if constexpr (MULTI_KC) { // launched only for K > 256: at least two depth blocks
@@ -2508,6 +2610,8 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
             char *sc = (char *)rten_scratch(ctx, need);
             if (!sc) return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "split-K slab allocation failed (or attempted during graph capture)");
             a.slab = (float *)(sc + 4096);
+            // the last-arriving producer folds the tile in the same launch (split_finish); RTEN_HIP_DEBUG bit 0x80000 keeps the fixup kernel
+            a.split_counters = (!(ctx->debug & 0x80000) && (long long)Z * ntail <= rten_hip_ctx::kSplitCounters) ? ctx->split_counters : nullptr;
         } else {
             t1 = T;
         }
@@ -2677,10 +2781,12 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
             const int32_t rc = launch(2, (unsigned)(ntail * S), flops * ntail / T, bytes * ntail / T);
             if (rc) return rc;
         }
-        snprintf(kname, sizeof kname, "igemm_f32_fixup_kernel<%d,%d>", BM, BN);
-        ProfScope ps(ctx, kname, 0.0, 8.0 * Z * ntail * nblk * BM * BN);
-        hipLaunchKernelGGL((igemm_f32_fixup_kernel<BM, BN>), dim3((unsigned)ntail * 4u, (unsigned)Z), dim3(64), 0, ctx->stream, a);
-        RTEN_LAUNCH_CHECK(ctx, "igemm_f32_fixup_kernel launch");
+        if (!a.split_counters) {
+            snprintf(kname, sizeof kname, "igemm_f32_fixup_kernel<%d,%d>", BM, BN);
+            ProfScope ps(ctx, kname, 0.0, 8.0 * Z * ntail * nblk * BM * BN);
+            hipLaunchKernelGGL((igemm_f32_fixup_kernel<BM, BN>), dim3((unsigned)ntail * 4u, (unsigned)Z), dim3(64), 0, ctx->stream, a);
+            RTEN_LAUNCH_CHECK(ctx, "igemm_f32_fixup_kernel launch");
+        }
     }
     return RTEN_HIP_OK;
 }

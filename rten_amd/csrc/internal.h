@@ -52,6 +52,8 @@ struct rten_hip_ctx {
     int int8_path = 0;  // 0 automatic (fast staging path when it covers the call), 1 generic kernel only
     int tile_order = 0; // workgroup -> tile order bits (rten_hip_set_gemm_order)
     int split_mode = 3, split_s = 1; // exact split-K plan: 0 off, 1 tail tiles, 2 all tiles, 3 automatic (gemm_f32.hip)
+    static constexpr long long kSplitCounters = 1 << 16;
+    unsigned *split_counters = nullptr; // arrival counters of the split-K producers (zero between launches), allocated with the context
     int debug = 0; // RTEN_HIP_DEBUG ablation bits (tuning only)
 };
 

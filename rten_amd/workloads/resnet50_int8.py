@@ -47,6 +47,12 @@ class ResNet50Int8(ResNet50):
             self.idesc[l["name"]] = L.Conv2dInt8Desc(d, 0, 1, 0, pad_mode, 1, 1)
             staged_max = max(staged_max, ctx.lib.rten_hip_conv2d_int8_staged_bytes(C.byref(self.idesc[l["name"]])))
         self.staged = DeviceTensor(ctx, (max(staged_max, 256),), np.uint8)  # quantized activations in the int8 kernel's layout
+        # second (codes, x_scale, x_zero_point) set + cast_scale slot: with `concurrent` a projection shortcut runs on a second stream
+        # next to c1 -> c2 and keeps reading ITS quantized input while the main stream quantizes the next tensors
+        self.qsets = [(self.staged, self.xs, self.xz),
+                      (DeviceTensor(ctx, (max(staged_max, 256),), np.uint8), DeviceTensor(ctx, (1,), np.float32), DeviceTensor(ctx, (1,), np.uint8))]
+        self.sc_side = DeviceTensor(ctx, (1,), np.float32)
+        self._cur, self._side_reads = 0, None
         self.fc_tmp = DeviceTensor(ctx, (batch, self.num_classes), np.float32)
         # classifier RHS [K = 2048, N = 1000] staged once (rten_hip_gemm_int8_prepack: PackedBMatrix, Graph::prepack_weights)
         self.fc_packed_bytes = ctx.lib.rten_hip_gemm_int8_packed_bytes(2048, self.num_classes)
@@ -103,6 +109,8 @@ class ResNet50Int8(ResNet50):
         name = l["name"]
         src = self._act(l["src"])
         d = self.idesc[name]
+        on_side = self.concurrent and name.endswith("ds")
+        sc = self.sc_side if on_side else self.sc
         # DynamicQuantizeLinear, writing the codes straight into the consumer's staged layout, and the Mul(x_scale, w_scale)
         # that feeds the conv's cast_scale.  When the producing conv left min/max statistics, the first sweep is skipped.
         st = self.stats.get(l["src"]) if self.producer_stats else None
@@ -110,25 +118,44 @@ class ResNet50Int8(ResNet50):
         if self._staged_key == geom:
             # same tensor, same staged layout as the previous conv (a stage's downsample and first 1x1 conv): the graph has ONE
             # DynamicQuantizeLinear for it (ort-quantize reuses a quantized input), only the Mul(x_scale, w_scale) differs
-            ctx.call("rten_hip_mul_f32", 1, self.xs.vp, self.ws[name].vp, 1, self.sc.vp)
-        elif st is not None:
-            ctx.call("rten_hip_dynamic_quantize_linear_staged_stats", C.byref(d), src.vp, st, self.staged.vp, self.xs.vp, self.xz.vp,
-                     self.ws[name].vp, self.sc.vp)
+            staged, xs, xz = self.qsets[self._cur]
+            ctx.call("rten_hip_mul_f32", 1, xs.vp, self.ws[name].vp, 1, sc.vp)
         else:
-            ctx.call("rten_hip_dynamic_quantize_linear_staged", C.byref(d), src.vp, self.staged.vp, self.xs.vp, self.xz.vp,
-                     self.ws[name].vp, self.sc.vp)
+            nxt = (1 - self._cur) if self.concurrent else 0
+            if self._side_reads == nxt:  # the shortcut conv on the side stream still reads this set: join before overwriting it
+                ctx.wait(self.side)
+                self._side_reads = None
+            self._cur = nxt
+            staged, xs, xz = self.qsets[nxt]
+            if st is not None:
+                ctx.call("rten_hip_dynamic_quantize_linear_staged_stats", C.byref(d), src.vp, st, staged.vp, xs.vp, xz.vp, self.ws[name].vp, sc.vp)
+            else:
+                ctx.call("rten_hip_dynamic_quantize_linear_staged", C.byref(d), src.vp, staged.vp, xs.vp, xz.vp, self.ws[name].vp, sc.vp)
         self._staged_key = geom
         flags = (L.CONV_RELU if l["relu"] else 0) | (L.CONV_RESIDUAL if l["res"] else 0)
-        args = (C.byref(d), self.staged.vp, self.wq[name].vp, self.xz.vp, None, self.sc.vp, self.bq[name].vp,
+        args = (C.byref(d), staged.vp, self.wq[name].vp, xz.vp, None, sc.vp, self.bq[name].vp,
                 self._act(l["res"]).vp if l["res"] else None, flags, self._act(l["dst"]).vp)
+        run_on = ctx
+        if on_side:
+            self.side.wait(ctx)  # the quantized input and its scale are ready
+            run_on = self.side
+            self._side_reads = self._cur
+            self._pending.add(l["dst"])
+        elif l["res"] in self._pending:
+            ctx.wait(self.side)  # the shortcut's output (this conv's residual) is ready
+            self._pending.discard(l["res"])
+            self._side_reads = None
         if self.producer_stats:
-            ctx.call("rten_hip_conv2d_int8_stats", *args, self.stats[l["dst"]])
+            run_on.call("rten_hip_conv2d_int8_stats", *args, self.stats[l["dst"]])
         else:
-            ctx.call("rten_hip_conv2d_int8", *args)
+            run_on.call("rten_hip_conv2d_int8", *args)
 
     def forward(self):
         ctx = self.ctx
         self._staged_key = None
+        self._cur, self._side_reads, self._pending = 0, None, set()
+        if self.concurrent and self.side is None:
+            self.side = L.Context(ctx.device)
         if self.producer_stats:
             ctx.call("rten_hip_minmax_stats_reset", self.stats_arena.vp, len(self.specs))  # one launch for every layer's block
         self._conv(self.specs[0])

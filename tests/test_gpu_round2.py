@@ -459,3 +459,61 @@ def test_chained_resnet50_bit_exact(ctx):
     four.run()
     ctx.sync()
     bits_equal(four.logits.numpy(), one.logits.numpy())
+
+
+def test_resnet50_int8_shortcuts_on_second_stream(ctx):
+    """int8 ResNet-50 with the projection shortcuts on a second stream (double-buffered quantized input, own cast_scale slot):
+    eager and as parallel hipGraph branches, bit-identical to the oracle."""
+    from oracle import models as omodels
+    from rten_amd.workloads import resnet50, resnet50_int8
+    w = resnet50.make_weights()
+    x = ref.XorShiftRng(4242).f32(3 * 3 * 224 * 224).reshape(3, 3, 224, 224)
+    net = resnet50_int8.ResNet50Int8(ctx, batch=3, weights=w)
+    net.upload_weights()
+    net.x.upload(x)
+    want = omodels.resnet50_int8_forward(net.specs, omodels.quantize_weights_int8(w), x)
+    net.concurrent = True
+    for _ in range(3):  # repeated: a missing join shows up as a race between passes
+        net.logits.upload(np.zeros_like(want))
+        net.forward()
+        ctx.sync()
+        bits_equal(net.logits.numpy(), want)
+    net.capture()
+    for _ in range(3):
+        net.logits.upload(np.zeros_like(want))
+        net.run()
+        ctx.sync()
+        bits_equal(net.logits.numpy(), want)
+
+
+def test_split_k_last_arrival_fold_is_deterministic(ctx):
+    """Split-K producers fold their tile in the same launch: whichever workgroup arrives last replays the ordered fold.  The
+    arrival order varies from launch to launch, the bits must not: 300 launches of a stage-3 3x3 conv (K = 2304, every tile cut
+    into 9 / 3 / 2 K groups) and of the batch-1 classifier GEMM, each compared with the oracle's unsplit chain."""
+    from tests.test_gpu_parity import gpu_gemm
+    rng = ref.XorShiftRng(2024)
+    x = rng.f32(2 * 256 * 14 * 14).reshape(2, 256, 14, 14) - 0.5
+    w = (rng.f32(256 * 256 * 9).reshape(256, 256, 3, 3) - 0.5) * 0.05
+    b = rng.f32(256) - 0.5
+    res = rng.f32(2 * 256 * 14 * 14).reshape(2, 256, 14, 14) - 0.5
+    want = ref.conv2d_f32(x, w, b, pads=(1, 1, 1, 1), residual=res, relu=True)
+    op = ops.Conv(padding=[1, 1, 1, 1], fuse_relu=True)
+    xd, wd, bd, rd = (DeviceTensor.from_numpy(ctx, a) for a in (x, w, b, res))
+    packed = op.prepack(ctx, wd, op._geometry(ctx, x.shape, w.shape))
+    a1 = rng.f32(2048).reshape(1, 2048) - 0.5
+    b1 = rng.f32(2048 * 1000).reshape(2048, 1000) - 0.5
+    want1 = None
+    try:
+        for mode, groups in ((2, 9), (2, 3), (2, 2), (1, 4), (3, 1)):
+            ctx.call("rten_hip_set_gemm_split", mode, groups)
+            for it in range(60):
+                y = op.run(ctx, [xd, wd, bd, rd], packed_weight=packed)[0]
+                if it % 10 == 9 or it == 0:
+                    bits_equal(y.numpy(), want)
+                y.free()
+            got1 = gpu_gemm(ctx, a1, b1)
+            if want1 is None:
+                want1 = got1
+            bits_equal(got1, want1)  # same bits under every split plan (M == 1 parity itself is by tolerance)
+    finally:
+        ctx.call("rten_hip_set_gemm_split", 3, 1)
