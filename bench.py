@@ -275,6 +275,12 @@ def main():
     if args.gpus < 1:
         print("bench.py: --gpus must be >= 1", file=sys.stderr)
         return 2
+    if args.config == "int8" and args.chains not in (None, 1):
+        print("bench.py: --config int8 runs as one chain (DynamicQuantizeLinear takes min / max over the whole batch: sub-batches would change the codes)", file=sys.stderr)
+        return 2
+    if args.chains is not None and not 1 <= args.chains <= 8:
+        print("bench.py: --chains must be 1..8", file=sys.stderr)
+        return 2
     under_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ
     if not under_launcher and args.gpus > 1:
         return spawn_ranks(args.gpus, sys.argv[1:])
@@ -314,9 +320,6 @@ def main():
     int8 = args.config == "int8"
 
     chains = 1 if int8 else (4 if args.chains is None else args.chains)
-    if int8 and args.chains not in (None, 1):
-        print("bench.py: --config int8 runs as one chain (DynamicQuantizeLinear takes min / max over the whole batch)", file=sys.stderr)
-        return 2
 
     def build(**kw):
         if int8:
@@ -499,9 +502,14 @@ def main():
         import glob
         fname = "int8_hbm_traffic_per_kernel.json" if int8 else "hbm_traffic_per_kernel.json"
         for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*", fname)), reverse=True):
-            t = json.load(open(path)).get("kernels", {}).get(roof["kernel"].replace(" ", ""))
+            ks = json.load(open(path)).get("kernels", {})
+            name = roof["kernel"].replace(" ", "")
+            # the profiler prints every template argument (defaults included): match on the prefix the backend's own label gives
+            cands = [k for k in ks if k == name or k.startswith(name[:-1] + ",")]
+            t = ks[max(cands, key=lambda k: ks[k].get("launches", 0))] if cands else None
             if t:
                 roof["traffic"] = t["hbm_read_bytes_per_launch"] + t["hbm_write_bytes_per_launch"]
+                roof["traffic_kernel"] = max(cands, key=lambda k: ks[k].get("launches", 0))
                 roof["traffic_source"] = os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))
                 roof["traffic_note"] = "measured in a separate rocprofv3 --pmc pass over that profile's tuned plan, not in this run (autotune draws differ)"
                 break

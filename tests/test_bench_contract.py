@@ -26,6 +26,15 @@ def test_world_size_larger_than_gpus_fails_too():
     assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr
 
 
+def test_int8_cannot_be_split_into_chains():
+    """Sub-batch chains are an f32-only schedule: the int8 graph's quantizers reduce over the whole batch."""
+    p = _run(["--config", "int8", "--chains", "2"], {})
+    assert p.returncode == 2 and "one chain" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+    p = _run(["--chains", "9"], {})
+    assert p.returncode == 2
+
+
 def test_gpus_n_without_launcher_spawns_n_ranks(monkeypatch):
     sys.path.insert(0, ROOT)
     import importlib
