@@ -16,3 +16,24 @@ def test_two_ranks_one_gpu_identical_logits():
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "identical_logits=True" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", ["f32", "int8"])
+def test_bench_two_ranks_prints_one_line(config):
+    """`python bench.py --gpus 2` (the form the driver uses on a multi-GPU node), here with both ranks on the one GPU over gloo: the
+    script spawns the ranks itself, rank 1 receives the weight arena only by broadcast, rank 0 prints ONE line that says 2 GPUs,
+    carries both ranks' step times and, for f32, the 4-chain schedule."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(RTEN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT="29561" if config == "f32" else "29563")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--config", config], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 64 and j["scaling"] == "weak"
+    assert j["ranks"]["world_size"] == 2 and len(j["ranks"]["ms_per_step_per_rank"]) == 2 and j["ranks"]["weight_broadcast_world"] == 2
+    assert j["cpu_baseline"] is None and j["roofline"]["frac"] > 0
+    assert j["config"]["batch_chains"]["chains"] == (4 if config == "f32" else 1)
