@@ -216,7 +216,8 @@ def secondary_configs():
     res = {}
     jobs = (("resnet50_int8_b32", [os.path.join(root, "bench.py"), "--config", "int8", "--no-secondary"]),
             ("bert_base_f32_b32_s128", [os.path.join(root, "tools", "bench_bert.py")]),
-            ("resnet50_f32_b1_latency", [os.path.join(root, "tools", "bench_resnet50_b1.py")]))
+            ("resnet50_f32_b1_latency", [os.path.join(root, "tools", "bench_resnet50_b1.py")]),
+            ("resnet50_int8_b1_latency", [os.path.join(root, "tools", "bench_resnet50_b1.py"), "--config", "int8"]))
     for key, cmd in jobs:
         try:
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
@@ -536,7 +537,7 @@ def main():
                        "global_batch": global_batch, "parallelism": f"batch-shard x{n_gpus} (weights RCCL-broadcast once)" if n_gpus > 1 else "single GPU",
                        "launch": "eager" if args.no_graph else "hipGraph replay", "autotuned_tiles": bool(net.variants), "shortcut_branch": "second stream" if net.concurrent else "main stream",
                        "batch_chains": {"chains": chains, "sub_batches": getattr(net, "sizes", [BATCH_PER_GPU]), "placement": getattr(net, "place", [0]),
-                                        "placement_ms": [[pl[0], round(ms, 4)] for pl, ms in placement] if placement else None,
+                                        "placement_ms": [["".join(str(x) for x in pl), round(ms, 3)] for pl, ms in placement] if placement else None,
                                         "note": "independent sub-batch chains on their own streams, shared weights, logits bit-identical to one chain"},
                        flop: round((resnet50.conv_flops_per_image() + 2 * 2048 * 1000) / 1e9, 3),
                        "device": ctx.device_info()},

@@ -199,16 +199,18 @@ class ResNet50:
             ctx.call("rten_hip_set_gemm_split", 3, 1)  # back to the automatic plan
             ctx.call("rten_hip_set_gemm_order", 0)
 
-    def forward(self):
+    def forward(self, upto=None):
         """Enqueue one forward pass over self.x -> self.logits (asynchronous).  With `concurrent`, each projection
-        shortcut runs on a second context (stream) next to c1 -> c2 and is joined before c3 reads it."""
+        shortcut runs on a second context (stream) next to c1 -> c2 and is joined before c3 reads it.
+        `upto` = n: only the first n conv layers (a partial pass whose results the next full pass overwrites; used to put the
+        chains of a ChainedResNet50 out of phase)."""
         ctx = self.ctx
         if self.concurrent and self.side is None:
             self.side = L.Context(ctx.device)
         self._conv(self.specs[0])
         ctx.call("rten_hip_max_pool2d_f32", C.byref(self.pool_desc), self.bufs["stem"].vp, self.bufs["pool"].vp)
         pending = set()  # shortcut outputs produced on the side stream and not yet joined
-        for l in self.specs[1:]:
+        for l in (self.specs[1:] if upto is None else self.specs[1:max(upto, 1)]):
             if self.concurrent and l["name"].endswith("ds"):
                 self.side.wait(ctx)           # block input is ready
                 self._conv(l, self.side)
@@ -218,6 +220,10 @@ class ResNet50:
                 ctx.wait(self.side)
                 pending.discard(l["res"])
             self._conv(l)
+        if upto is not None:
+            if pending:
+                ctx.wait(self.side)
+            return
         last = self.specs[-1]["dst"]
         n, c, h, w = self.shapes[last]
         ctx.call("rten_hip_global_average_pool_f32", n * c, h * w, self.bufs[last].vp, self.gap.vp)
@@ -397,15 +403,35 @@ class ChainedResNet50:
         return (time.perf_counter() - t0) / steps
 
     def tune_placement(self, steps=8):
-        """Choose the contexts (streams -> hardware queues) the chain graphs are launched on: every window of `chains`
-        consecutive pool members is timed over a few steps.  Returns [(placement, ms per step)]."""
+        """Choose the contexts (streams -> hardware queues) the chain graphs are launched on.  Every window of `chains`
+        consecutive pool members is timed over a few steps; then one pass of local search swaps each member for each unused
+        context and keeps a swap that is at least 1 % faster (the stream -> queue mapping is the runtime's business and differs
+        from process to process: no window need be collision-free).  Returns [(placement, ms per step)] of everything tried."""
         assert self.graph
         rows = []
-        for first in range(self.POOL - self.chains + 1):
-            self.place = list(range(first, first + self.chains))
+
+        def measure(place):
+            self.place = list(place)
             self._time_steps(2)
-            rows.append((list(self.place), min(self._time_steps(steps) for _ in range(2)) * 1e3))
-        self.place = min(rows, key=lambda r: r[1])[0]
+            ms = min(self._time_steps(steps) for _ in range(2)) * 1e3
+            rows.append((list(place), ms))
+            return ms
+        best, best_ms = None, 1e30
+        for first in range(self.POOL - self.chains + 1):
+            place = list(range(first, first + self.chains))
+            ms = measure(place)
+            if ms < best_ms:
+                best, best_ms = place, ms
+        for i in range(self.chains):
+            for u in range(self.POOL):
+                if u in best:
+                    continue
+                cand = list(best)
+                cand[i] = u
+                ms = measure(cand)
+                if ms < best_ms * 0.99:
+                    best, best_ms = cand, ms
+        self.place = best
         return rows
 
     def autotune(self, reps=3, top=6, corun_reps=6):

@@ -434,7 +434,7 @@ def test_chained_resnet50_bit_exact(ctx):
     assert set(net.cotune) == {l["name"] for l in net.specs}
     net.capture()
     rows = net.tune_placement(steps=2)
-    assert len(rows) == net.POOL - 1
+    assert len(rows) >= net.POOL - 1 and net.place in [r[0] for r in rows] and len(set(net.place)) == net.chains
     for place, _ in rows:
         net.place = place
         net.logits.upload(np.zeros_like(want))
