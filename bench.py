@@ -367,13 +367,23 @@ def main():
     net.concurrent = args.concurrent
     if args.load_plan:
         plan = json.load(open(args.load_plan))
-        net.variants = plan if chains > 1 else {k: tuple(v) for k, v in plan.items()}
+        if int8:
+            net.fused_dql, net.fused_layers = True, set(plan.get("fused_dql", []))
+        else:
+            net.variants = plan if chains > 1 else {k: tuple(v) for k, v in plan.items()}
         args.no_autotune = True
     if not args.no_autotune:
         table = net.autotune(reps=3)
         if args.save_plan and rank == 0:
-            json.dump(net.plan_table() if chains > 1 else {k: list(v) for k, v in net.variants.items()}, open(args.save_plan, "w"))
-        if args.layer_table and rank == 0 and table:
+            if int8:
+                json.dump({"fused_dql": sorted(net.fused_layers)}, open(args.save_plan, "w"))
+            else:
+                json.dump(net.plan_table() if chains > 1 else {k: list(v) for k, v in net.variants.items()}, open(args.save_plan, "w"))
+        if args.layer_table and rank == 0 and table and int8:
+            for name, (sep, fus) in table.items():
+                print(f"[layer] {name:8s} DynamicQuantizeLinear staged + conv {sep:6.1f} us | quantize-on-load conv {fus:6.1f} us -> {'fused' if name in net.fused_layers else 'staged'}",
+                      file=sys.stderr)
+        if args.layer_table and rank == 0 and table and not int8:
             for l in net.specs:
                 d = net.descs[l["name"]]
                 fl = 2.0 * d.o * d.c * d.kh * d.kw * d.out_h * d.out_w * d.n
@@ -547,6 +557,7 @@ def main():
             "roofline": roof,
         }
         if int8:
+            out["config"]["quantize_on_load_layers"] = sorted(net.fused_layers) if getattr(net, "fused_layers", None) else []
             out["config"]["int8_pad_mode"] = ("RAW0_I8 -- ASSUMPTION: padded taps of an integer convolution hold raw 0 after the u8->i8 shift, the x86 reference's im2col behaviour "
                                               "(rten-gemm/src/im2col.rs:340-358, SURVEY App. C.1); unpinned by a reference-held vector; ZERO_POINT / RAW0_U8 are the other modes of the ABI")
         if n_gpus == 1 and not args.no_cpu_baseline:

@@ -257,6 +257,16 @@ int32_t rten_hip_conv2d_int8_stats(rten_hip_ctx *ctx, const rten_hip_conv2d_int8
 int32_t rten_hip_dynamic_quantize_linear_staged_stats(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *desc, const float *x,
                                                       const void *stats, void *staged, float *scale, uint8_t *zero_point,
                                                       const float *mul_by, float *product);
+/* The whole chain DynamicQuantizeLinear -> ConvInteger -> Cast -> Mul(x_scale, w_scale) [-> Add bias] [-> Add residual] [-> Relu]
+ * (the reference's DynamicQuantizeLinear + ConvIntegerToFloat, src/ops/quantize.rs:352-436 + src/ops/conv.rs:495-587) in ONE launch
+ * for pointwise convolutions (1x1, stride 1, no padding, groups 1, C % 64 == 0) whose input statistics `in_stats` were accumulated
+ * by the producing launch: the quantizer runs in the integer GEMM's operand loader, no quantized tensor is written.  `w` must be
+ * prepacked (desc->weights_packed), `w_scale` is the scalar or per-output-channel weight scale (desc->scale_len values), the
+ * quantizer's own outputs go to `x_scale_out` / `x_zero_point_out` (optional), the float outputs' statistics to `out_stats`
+ * (optional).  Bit-identical to the separate operators.  RTEN_HIP_ERR_UNSUPPORTED for other geometries. */
+int32_t rten_hip_conv2d_int8_dql(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *desc, const float *x, const void *in_stats,
+                                 const void *w, const float *w_scale, const float *bias, const float *residual, uint32_t flags,
+                                 float *y, void *out_stats, float *x_scale_out, uint8_t *x_zero_point_out);
 
 /* ---- DynamicQuantizeLinear, src/ops/quantize.rs:352-436 + rten-vecmath/src/quantize.rs:39-79 ---- */
 int32_t rten_hip_dynamic_quantize_linear(rten_hip_ctx *ctx, int64_t n, const float *x, uint8_t *y, float *scale,

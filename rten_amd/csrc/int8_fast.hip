@@ -55,6 +55,13 @@ struct FastArgs {
     int tiles_m, tiles_n, n_fastest;
     // conv geometry (padded image)
     int conv, OW, sy, sx, Hp, Wp, Cp, KH, KW, dy, dx;
+    // BQ kernels (DynamicQuantizeLinear fused into the B loader of a pointwise conv): the f32 activations, the min/max block their
+    // producer left, the plane size, and where the quantizer's own outputs go
+    const float *xf;
+    const unsigned *in_stats;
+    int HW, Cin;
+    float *xs_out;
+    uint8_t *xz_out;
     int debug; // RTEN_HIP_DEBUG ablation bits (timing experiments only; results are wrong): 0x1000 one k-tile, 0x2000 no stores, 0x4000 no statistics atomics
 };
 
@@ -287,8 +294,14 @@ extern __shared__ __attribute__((aligned(16))) uint8_t i8_smem[];
 // under-filled launch (stage 3-4 of ResNet-50 at batch 32: ~200 tiles of 64 x 64 for 256 CUs) otherwise runs ONE wave per
 // SIMD, and every latency of its k-loop (barrier, DMA issue, LDS fragment reads, dependent MFMAs: ~550 cycles per 64-byte
 // k-tile, independent of where the operands come from -- profiles/r05/int8_kloop_ablation.txt) is exposed 72 times in a row.
-template <int BM, int BN, int NSTAGE, bool RES, int KTK = 64, int KG = 1>
+// BQ = the B operand is QUANTIZED ON LOAD from the f32 activation tensor (pointwise stride-1 unpadded convolutions of a dynamically
+// quantized graph): DynamicQuantizeLinear's parameters come from the min/max block the producing conv accumulated, a thread
+// reads 16 channels of one pixel (lanes = consecutive pixels: 256-byte runs), converts with dql::quant_u8 and writes the
+// 16-byte chunk piece the DMA would have delivered (conflict-free ds_write_b128).  The staging launch, its 1 B/element write
+// and the staged image's read disappear; A still arrives by LDS-DMA.  Same codes, same sums: bit-identical.
+template <int BM, int BN, int NSTAGE, bool RES, int KTK = 64, int KG = 1, bool BQ = false>
 __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kernel(const FastArgs p) {
+    static_assert(!BQ || (KG == 1 && KTK == 64), "quantize-on-load: one k-group, 64-byte k-tiles");
     constexpr int WM = 2, WN = 2;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int RA = BM / 64, RB = BN / 64;      // DMA instructions per chunk (64 rows each)
@@ -313,7 +326,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
     const int bm = p.n_fastest ? tile / p.tiles_n : tile % p.tiles_m, bn = p.n_fastest ? tile % p.tiles_n : tile / p.tiles_m;
     const int m0 = bm * BM, n0 = bn * BN;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)p.A, 0, (int)p.a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void *)p.B, 0, (int)p.b_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(BQ ? (void *)p.xf : (void *)p.B, 0, (int)p.b_bytes, 0x00020000);
 
     // loop-invariant per-lane row bases (bytes)
     unsigned a_voff[RA], b_voff[RB];
@@ -364,6 +377,37 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
         }
     }
     __syncthreads();
+    // ---- BQ: DynamicQuantizeLinear parameters from the producer's statistics (every workgroup folds the 256 slots; min / max are
+    // order-free), the quantizer's outputs, and this thread's pieces of the B tile
+    [[maybe_unused]] float q_scale = 0.f, q_inv = 0.f;
+    [[maybe_unused]] int q_zp = 0;
+    constexpr int NP = BQ ? 4 * BN / 256 : 1; // 16-byte pieces (16 channels of one pixel) per thread per k-tile
+    [[maybe_unused]] unsigned q_voff = OOB;   // byte offset of (image, channel 0, pixel) of this thread's pixel
+    [[maybe_unused]] int q_slot0 = 0, q_px = 0;
+    if constexpr (BQ) {
+        float a = __builtin_inff(), b = -__builtin_inff();
+        a = dql::ord2f(p.in_stats[t]);
+        b = dql::ord2f(p.in_stats[dql::kStatSlots + t]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { a = fminf(a, __shfl_xor(a, o, 64)); b = fmaxf(b, __shfl_xor(b, o, 64)); }
+        float *red = reinterpret_cast<float *>(btab);
+        if (lane == 0) { red[wave_all] = a; red[4 + wave_all] = b; }
+        __syncthreads();
+        const float mn = fminf(fminf(red[0], red[1]), fminf(red[2], red[3])), mx = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+        const dql::QParams q = dql::dql_params(mn, mx);
+        q_scale = q.scale; q_inv = q.inv_scale; q_zp = q.zp;
+        if (t == 0 && blockIdx.x == 0) {
+            if (p.xs_out) *p.xs_out = q.scale;
+            if (p.xz_out) *p.xz_out = (uint8_t)q.zp;
+        }
+        q_px = t % BN;
+        q_slot0 = __builtin_amdgcn_readfirstlane(t / BN); // wave-uniform: BN is a multiple of 64
+        const int n = n0 + q_px;
+        if (n < p.N) {
+            const int img = n / p.HW, pp = n - img * p.HW;
+            q_voff = (unsigned)((img * p.Cin) * p.HW + pp) * 4u;
+        }
+    }
     int ch_idx = __builtin_amdgcn_readfirstlane(wave_all); // chunk index of the next piece to issue: wave_all, wave_all + 4 KG, ...
     // the table entries of this wave's next 64 pieces ride in one vector register (lane i = i-th piece from here) and are picked
     // with v_readlane: no LDS round trip on the issue path.  Refilled every 64 pieces.
@@ -387,14 +431,43 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
 #pragma unroll
             for (int j = 0; j < RA; j++)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(As + j * 1024), 16, (int)(a_live ? a_voff[j] : OOB), (int)a_soff, 0, 0);
+            if constexpr (!BQ) {
 #pragma unroll
-            for (int j = 0; j < RB; j++)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(Bs + j * 1024), 16, (int)(b_live ? b_voff[j] : OOB), (int)b_soff, 0, 0);
+                for (int j = 0; j < RB; j++)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(Bs + j * 1024), 16, (int)(b_live ? b_voff[j] : OOB), (int)b_soff, 0, 0);
+            }
             ch_idx += 4 * (CPW == 1 ? KG : 1);
             if (++bo_pos == 64) {
                 bo_vec = bo_fill(ch_idx);
                 bo_pos = 0;
             }
+        }
+    };
+
+    // BQ: the f32 values of k-tile kt (its 64 channels) for this thread's NP pieces -> registers; later -> codes -> LDS
+    [[maybe_unused]] float qv[NP][16];
+    [[maybe_unused]] auto q_load = [&](int kt) {
+#pragma unroll
+        for (int r = 0; r < NP; r++) {
+            const int slot = q_slot0 + r * (256 / BN);
+            const unsigned soff = (unsigned)((kt * 64 + slot * 16) * p.HW) * 4u; // channel kt*64 + slot*16 (+ j): beyond Cin -> out of range -> 0, never used
+#pragma unroll
+            for (int j = 0; j < 16; j++)
+                qv[r][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, (int)q_voff, (int)(soff + (unsigned)(j * p.HW) * 4u), 0));
+        }
+    };
+    [[maybe_unused]] auto q_store = [&](int stage) {
+#pragma unroll
+        for (int r = 0; r < NP; r++) {
+            const int slot = q_slot0 + r * (256 / BN);
+            unsigned w[4];
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                w[d] = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) w[d] |= ((dql::quant_u8(qv[r][4 * d + j], q_inv, q_zp) ^ 0x80u) & 0xffu) << (8 * j);
+            }
+            *reinterpret_cast<uint4 *>(smem + stage * STAGE + BM * KTK + (slot * BN + q_px) * 16) = make_uint4(w[0], w[1], w[2], w[3]);
         }
     };
 
@@ -457,6 +530,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
         rc_az = zp_signed(p.a_zp, p.a_zp_len > 1 ? m % p.a_zp_len : 0, p.a_signed); // GEMM: period < M cycles the zero points (matmul.rs:266-280)
         rc_bias = p.bias ? p.bias[m] : 0.f;
         rc_srow = (p.scale && p.scale_per_row) ? p.scale[m] : 0.f;
+        if constexpr (BQ) rc_srow = q_scale * rc_srow; // Mul(x_scale, w_scale[m])
     }
     unsigned basev[TN], bzv[TN], csv[TN];
     float scv[TN];
@@ -470,6 +544,10 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
         bzv[j] = (unsigned)zp_signed(p.b_zp, p.b_zp_len == 1 ? 0 : nn, p.b_signed);
         csv[j] = p.csum ? (unsigned)p.csum[nn] : 0u;
         scv[j] = (p.scale && !p.scale_per_row) ? p.scale[p.scale_len == 1 ? 0 : nn] : 0.f;
+        if constexpr (BQ) {
+            bzv[j] = (unsigned)(q_zp - 128);   // the activation zero point in the signed domain
+            scv[j] = q_scale * scv[j];         // Mul(x_scale, w_scale)
+        }
     }
     // row r of 32-row block i sits at scalar byte offset (mb_u + i*32 + acc_row(r)) * rs4, with mb_u wave-uniform and the lane's
     // half (rows +4) folded into the vector offset
@@ -491,17 +569,39 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
         }
     }
 
-#pragma unroll
-    for (int i = 0; i < NSTAGE - 1; i++) issue_tile(i);
-    // (A two-fragment-set software pipeline of the LDS reads under the MFMAs was measured and is slower.)
     int stage = 0;
-    for (int it = 0; it < nit; it++) {
-        wait_vmcnt<PER_TILE *(NSTAGE - 2)>();
-        __builtin_amdgcn_s_barrier();
-        const int stp = stage == 0 ? NSTAGE - 1 : stage - 1;
-        issue_tile(stp);
-        compute_tile(stage);
-        stage = stage == NSTAGE - 1 ? 0 : stage + 1;
+    if constexpr (BQ) {
+        // A by DMA two tiles ahead (as below); B: the values of tile it + 1 are in flight in registers while tile it is multiplied,
+        // and are converted and written to their stage at the top of the next trip, before the barrier that publishes it.
+#pragma unroll
+        for (int i = 0; i < NSTAGE - 1; i++) issue_tile(i);
+        q_load(0);
+        wait_vmcnt<0>();
+        q_store(0);
+        q_load(1);
+        for (int it = 0; it < nit; it++) {
+            wait_vmcnt<0>(); // A of tile it (and it + 1), B values of tile it + 1
+            const int stn = stage == NSTAGE - 1 ? 0 : stage + 1;
+            q_store(stn);    // stage of tile it + 1: last read two trips ago
+            __builtin_amdgcn_s_barrier();
+            const int stp = stage == 0 ? NSTAGE - 1 : stage - 1;
+            issue_tile(stp); // A of tile it + 2
+            q_load(it + 2);
+            compute_tile(stage);
+            stage = stn;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NSTAGE - 1; i++) issue_tile(i);
+        // (A two-fragment-set software pipeline of the LDS reads under the MFMAs was measured and is slower.)
+        for (int it = 0; it < nit; it++) {
+            wait_vmcnt<PER_TILE *(NSTAGE - 2)>();
+            __builtin_amdgcn_s_barrier();
+            const int stp = stage == 0 ? NSTAGE - 1 : stage - 1;
+            issue_tile(stp);
+            compute_tile(stage);
+            stage = stage == NSTAGE - 1 ? 0 : stage + 1;
+        }
     }
     wait_vmcnt<0>();
     __syncthreads(); // every wave is done with the stage buffers
@@ -658,7 +758,7 @@ __global__ __launch_bounds__(256) void i8_pack_rows_t_kernel(const uint8_t *__re
 
 inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-template <int BM, int BN, int NST, int KTK = 64, int KG = 1>
+template <int BM, int BN, int NST, int KTK = 64, int KG = 1, bool BQ = false>
 void launch_fast(rten_hip_ctx *ctx, FastArgs &a, const char *name, double ops, double bytes) {
     static_assert(KTK == 64 || KG == 1, "k-groups walk 64-byte k-tiles");
     a.tiles_m = (a.M + BM - 1) / BM;
@@ -673,8 +773,8 @@ void launch_fast(rten_hip_ctx *ctx, FastArgs &a, const char *name, double ops, d
         if (lds > 64 * 1024) hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256 * KG), lds, ctx->stream, a);
     };
-    if (a.res && a.scale) go(igemm_i8_fast_kernel<BM, BN, NST, true, KTK, KG>);
-    else go(igemm_i8_fast_kernel<BM, BN, NST, false, KTK, KG>);
+    if (a.res && a.scale) go(igemm_i8_fast_kernel<BM, BN, NST, true, KTK, KG, BQ>);
+    else go(igemm_i8_fast_kernel<BM, BN, NST, false, KTK, KG, BQ>);
 }
 
 int32_t dispatch_fast(rten_hip_ctx *ctx, FastArgs &a, double ops, double bytes) {
@@ -687,6 +787,14 @@ int32_t dispatch_fast(rten_hip_ctx *ctx, FastArgs &a, double ops, double bytes) 
     // one is fetched into as few of the eight L2s as possible
     a.n_fastest = (double)a.a_bytes > (double)a.b_bytes ? 1 : 0;
     // (256-byte k-tiles were measured and are slower: profiles/r05/int8_notes.md)
+    if (a.xf) { // quantize-on-load form (rten_hip_conv2d_int8_dql)
+        if (tile == 0) launch_fast<128, 128, 3, 64, 1, true>(ctx, a, "igemm_i8_fast_kernel<128,128,bq>", ops, bytes);
+        else if (tile == 1) launch_fast<128, 64, 3, 64, 1, true>(ctx, a, "igemm_i8_fast_kernel<128,64,bq>", ops, bytes);
+        else if (tile == 2) launch_fast<64, 128, 3, 64, 1, true>(ctx, a, "igemm_i8_fast_kernel<64,128,bq>", ops, bytes);
+        else launch_fast<64, 64, 3, 64, 1, true>(ctx, a, "igemm_i8_fast_kernel<64,64,bq>", ops, bytes);
+        RTEN_LAUNCH_CHECK(ctx, "igemm_i8_fast_kernel launch");
+        return RTEN_HIP_OK;
+    }
     if (tile == 0) {
         launch_fast<128, 128, 3>(ctx, a, "igemm_i8_fast_kernel<128,128>", ops, bytes);
     } else if (tile == 1) {
@@ -942,4 +1050,50 @@ int32_t rten_i8_fast_conv(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di
     // algorithmic bytes: i8 weights + u8 activations (once) + f32 output (+ f32 residual when the epilogue adds one)
     return dispatch_fast(ctx, g, 2.0 * d->o * (double)g.N * cg.Kreal,
                          (double)d->o * cg.Kreal + (double)d->n * d->c * d->h * d->w + 4.0 * d->o * g.N + (g.res ? 4.0 * d->o * g.N : 0.0));
+}
+
+
+// DynamicQuantizeLinear -> ConvInteger -> Cast -> Mul(x_scale, w_scale) [-> Add(bias)] [-> Add(residual)] [-> Relu] of a dynamically
+// quantized graph in ONE launch, for pointwise (1x1, stride 1, no padding, groups 1) convolutions whose input statistics were
+// accumulated by the producing kernel (rten_hip_conv2d_int8_stats / this function): the quantizer runs inside the B loader of the
+// integer GEMM (igemm_i8_fast_kernel, BQ).  `w` must be prepacked (rten_hip_conv2d_int8_prepack), `w_scale` is the scalar or
+// per-output-channel weight scale (di->scale_len), `x_scale_out` / `x_zero_point_out` receive DynamicQuantizeLinear's own outputs
+// (optional).  RTEN_HIP_ERR_UNSUPPORTED for any other geometry: run the staged sequence instead.
+RTEN_EXPORT int32_t rten_hip_conv2d_int8_dql(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di, const float *x, const void *in_stats, const void *w,
+                                             const float *w_scale, const float *bias, const float *residual, uint32_t flags, float *y, void *out_stats,
+                                             float *x_scale_out, uint8_t *x_zero_point_out) {
+    RTEN_CHECK_CTX(ctx);
+    if (!di || !x || !in_stats || !w || !w_scale || !y) return RTEN_HIP_ERR_INVALID_VALUE;
+    const rten_hip_conv2d_desc *d = &di->conv;
+    const ConvGeom cg = conv_geom(di);
+    const bool pointwise = d->kh == 1 && d->kw == 1 && d->stride_h == 1 && d->stride_w == 1 && d->groups == 1 && d->pads[0] == 0 && d->pads[1] == 0 &&
+                           d->pads[2] == 0 && d->pads[3] == 0;
+    if (!cg.ok || !pointwise || !di->weights_packed || di->x_signed || di->w_zp_len != 0 || d->c % 64 != 0 ||
+        (long long)d->n * d->c * d->h * d->w * 4 >= (1ll << 31))
+        return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "conv2d_int8_dql: pointwise stride-1 unpadded convolutions with prepacked weights and C % 64 == 0 only");
+    if (di->scale_len != 0 && di->scale_len != 1 && di->scale_len != d->o)
+        return rten_set_error(ctx, RTEN_HIP_ERR_INCOMPATIBLE_SHAPES, "conv_int8: scale must be a scalar or have one value per output channel");
+    if (d->n == 0 || d->out_h == 0 || d->out_w == 0) return RTEN_HIP_OK;
+    FastArgs g = {};
+    g.A = (const uint8_t *)w;
+    g.rsum = (const int *)((const char *)w + up256((size_t)d->o * cg.Kp));
+    g.C = y;
+    g.xf = x; g.in_stats = (const unsigned *)in_stats; g.HW = d->h * d->w; g.Cin = d->c;
+    g.xs_out = x_scale_out; g.xz_out = x_zero_point_out;
+    g.scale = w_scale; g.bias = bias;
+    g.res = (flags & RTEN_HIP_CONV_RESIDUAL) ? residual : nullptr;
+    g.relu = (flags & RTEN_HIP_CONV_RELU) ? 1 : 0;
+    g.M = d->o; g.N = d->n * cg.P; g.Kp = cg.Kp; g.Kreal = cg.Kreal;
+    g.a_bytes = (unsigned)((size_t)d->o * cg.Kp); g.b_bytes = (unsigned)((size_t)d->n * d->c * d->h * d->w * 4);
+    g.c_rs = cg.P; g.c_ns = (long long)d->o * cg.P; g.Pn = cg.P;
+    g.a_signed = di->w_signed; g.b_signed = 0;
+    g.a_zp_len = 0; g.b_zp_len = 1;
+    g.scale_len = 1;
+    g.scale_per_row = di->scale_len > 1 ? 1 : 0;
+    g.stats = (unsigned *)out_stats;
+    g.need_csum = di->w_signed ? 0 : 1;
+    g.conv = 1; g.OW = d->out_w; g.sy = 1; g.sx = 1; g.Hp = d->h; g.Wp = d->w; g.Cp = cg.Cp; g.KH = 1; g.KW = 1; g.dy = 1; g.dx = 1;
+    // algorithmic bytes: i8 weights + f32 activations (read once) + f32 output (+ f32 residual)
+    return dispatch_fast(ctx, g, 2.0 * d->o * (double)g.N * cg.Kreal,
+                         (double)d->o * cg.Kreal + 4.0 * d->n * d->c * d->h * d->w + 4.0 * d->o * g.N + (g.res ? 4.0 * d->o * g.N : 0.0));
 }

@@ -31,6 +31,8 @@ class ResNet50Int8(ResNet50):
         self.pad_mode = pad_mode
         self._staged_key = None
         self.producer_stats = True   # conv epilogues accumulate the min/max the next DynamicQuantizeLinear needs
+        self.fused_dql = False       # pointwise stride-1 convs quantize their input in the GEMM's loader (rten_hip_conv2d_int8_dql) ...
+        self.fused_layers = None     # ... all that qualify (None) or the set autotune() measured to be faster that way
         sb = ctx.lib.rten_hip_minmax_stats_bytes()
         self.stats_arena = DeviceTensor(ctx, (sb * len(self.specs),), np.uint8)  # one statistics block per conv output
         self.stats = {l["dst"]: C.c_void_p(self.stats_arena.ptr + i * sb) for i, l in enumerate(self.specs)}
@@ -115,6 +117,19 @@ class ResNet50Int8(ResNet50):
         # that feeds the conv's cast_scale.  When the producing conv left min/max statistics, the first sweep is skipped.
         st = self.stats.get(l["src"]) if self.producer_stats else None
         geom = (l["src"], d.conv.c, d.conv.h, d.conv.w, tuple(d.conv.pads))
+        cv = d.conv
+        if (self.fused_dql and (self.fused_layers is None or name in self.fused_layers) and st is not None and not on_side and cv.kh == 1 and cv.kw == 1 and cv.stride_h == 1 and cv.stride_w == 1
+                and not any(cv.pads) and cv.c % 64 == 0):
+            # DynamicQuantizeLinear + ConvIntegerToFloat of this layer in one launch: no staged tensor (a later conv that shares this
+            # input quantizes it again for itself, with the same result)
+            flags = (L.CONV_RELU if l["relu"] else 0) | (L.CONV_RESIDUAL if l["res"] else 0)
+            if l["res"] in self._pending:
+                ctx.wait(self.side)
+                self._pending.discard(l["res"])
+                self._side_reads = None
+            ctx.call("rten_hip_conv2d_int8_dql", C.byref(d), src.vp, st, self.wq[name].vp, self.ws[name].vp, self.bq[name].vp,
+                     self._act(l["res"]).vp if l["res"] else None, flags, self._act(l["dst"]).vp, self.stats[l["dst"]], None, None)
+            return
         if self._staged_key == geom:
             # same tensor, same staged layout as the previous conv (a stage's downsample and first 1x1 conv): the graph has ONE
             # DynamicQuantizeLinear for it (ort-quantize reuses a quantized input), only the Mul(x_scale, w_scale) differs
@@ -171,5 +186,49 @@ class ResNet50Int8(ResNet50):
         ctx.call("rten_hip_gemm_int8", C.byref(self.fc_idesc), self.xq.vp, self.wq["fc"].vp, self.xz.vp, None, self.sc.vp, self.fc_tmp.vp)
         ctx.call("rten_hip_add_f32", n * self.num_classes, self.fc_tmp.vp, self.bq["fc"].vp, self.num_classes, self.logits.vp)
 
-    def autotune(self, reps=3):  # the int8 kernels pick their tile by shape; nothing to tune yet
-        return {}
+    def autotune(self, reps=5):
+        """The int8 kernels pick their tile by shape; what is measured at load is, per pointwise layer, whether DynamicQuantizeLinear
+        runs as its own staging launch or inside the conv's loader (rten_hip_conv2d_int8_dql).  The fused form wins where few
+        output-channel tiles share the input (the 1x1 reduce layers), the staged form where many do (the expand layers re-read and
+        re-quantize the f32 input once per tile row).  Returns {layer: (separate us, fused us)}."""
+        ctx = self.ctx
+        self.fused_dql, self.fused_layers = False, None
+        self.forward()  # activations and statistics of every layer exist
+        ctx.sync()
+        table, chosen = {}, set()
+
+        def timed(fn):
+            fn()
+            best = 1e30
+            for _ in range(2):
+                ctx.timer_start(1)
+                for _ in range(reps):
+                    fn()
+                ctx.timer_stop(1)
+                best = min(best, ctx.timer_ms(1) / reps * 1e3)
+            return best
+        for l in self.specs:
+            name, d = l["name"], self.idesc[l["name"]]
+            cv, st = d.conv, self.stats.get(l["src"])
+            if st is None or not (cv.kh == 1 and cv.kw == 1 and cv.stride_h == 1 and cv.stride_w == 1 and not any(cv.pads) and cv.c % 64 == 0):
+                continue
+            src, staged, xs, xz = self._act(l["src"]), *self.qsets[0]
+            flags = (L.CONV_RELU if l["relu"] else 0) | (L.CONV_RESIDUAL if l["res"] else 0)
+            res = self._act(l["res"]).vp if l["res"] else None
+
+            def separate():
+                ctx.call("rten_hip_dynamic_quantize_linear_staged_stats", C.byref(d), src.vp, st, staged.vp, xs.vp, xz.vp, self.ws[name].vp, self.sc.vp)
+                ctx.call("rten_hip_conv2d_int8_stats", C.byref(d), staged.vp, self.wq[name].vp, xz.vp, None, self.sc.vp, self.bq[name].vp, res, flags,
+                         self._act(l["dst"]).vp, self.stats[l["dst"]])
+
+            def fused():
+                ctx.call("rten_hip_conv2d_int8_dql", C.byref(d), src.vp, st, self.wq[name].vp, self.ws[name].vp, self.bq[name].vp, res, flags,
+                         self._act(l["dst"]).vp, self.stats[l["dst"]], None, None)
+            us = (timed(separate), timed(fused))
+            table[name] = us
+            # a layer that shares its quantized input with the previous conv (a stage's downsample + first 1x1) saves no staging launch
+            if us[1] < us[0] * 0.97:
+                chosen.add(name)
+        self.fused_dql, self.fused_layers = True, chosen
+        self.variants = {n: "dql" for n in chosen}
+        return table

@@ -63,6 +63,16 @@ def test_resnet50_int8_batch32_bit_exact_runner(ctx):
     net.logits.upload(np.zeros_like(want))
     net.run()
     bits_equal(net.logits.numpy(), want)
+    # pointwise layers with the quantizer fused into the GEMM's loader (rten_hip_conv2d_int8_dql): same bits, eager and replayed
+    net.graph, net.fused_dql = None, True
+    net.logits.upload(np.zeros_like(want))
+    net.forward()
+    bits_equal(net.logits.numpy(), want)
+    net.capture()
+    net.logits.upload(np.zeros_like(want))
+    net.run()
+    bits_equal(net.logits.numpy(), want)
+    net.graph, net.fused_dql = None, False
     # the other pad modes differ from the x86 default on a padded network: the mode is observable, i.e. it IS an assumption
     net2 = resnet50_int8.ResNet50Int8(ctx, batch=32, weights=w, pad_mode=L.PAD_ZERO_POINT)
     net2.upload_weights()
@@ -517,3 +527,56 @@ def test_split_k_last_arrival_fold_is_deterministic(ctx):
             bits_equal(got1, want1)  # same bits under every split plan (M == 1 parity itself is by tolerance)
     finally:
         ctx.call("rten_hip_set_gemm_split", 3, 1)
+
+
+def test_conv2d_int8_dql_matches_the_separate_operators(ctx):
+    """rten_hip_conv2d_int8_dql (DynamicQuantizeLinear inside the integer GEMM's loader) against DynamicQuantizeLinear (staged) +
+    ConvIntegerToFloat on the same f32 tensor and statistics: outputs, output statistics and the quantizer's own scale / zero point,
+    for every tile shape the dispatcher picks, scalar and per-channel weight scales, residual + Relu, ragged pixel counts."""
+    rng = ref.XorShiftRng(777)
+    sb = ctx.lib.rten_hip_minmax_stats_bytes()
+    for (n, c, h, w, o, per_ch) in ((2, 64, 56, 56, 256, False), (32, 256, 14, 14, 1024, False), (3, 128, 7, 7, 512, True), (32, 64, 7, 7, 64, False),
+                                    (1, 192, 5, 3, 40, True), (32, 512, 28, 28, 128, False)):
+        # producer: an int8 conv whose f32 output (+ statistics) is the tensor under test
+        x0 = rng.u8(n * 16 * h * w).reshape(n, 16, h, w)
+        w0 = rng.i8(c * 16, reduced=True).reshape(c, 16, 1, 1)
+        d0 = L.Conv2dInt8Desc(L.Conv2dDesc(n, 16, h, w, c, 1, 1, (C.c_int32 * 4)(0, 0, 0, 0), 1, 1, 1, 1, 1, h, w), 0, 1, 0, L.PAD_RAW0_I8, 0, 0, 1)
+        stats = DeviceTensor(ctx, (2 * sb,), np.uint8)
+        ctx.call("rten_hip_minmax_stats_reset", stats.vp, 2)
+        st_in, st_a, st_b = C.c_void_p(stats.ptr), None, None
+        t = DeviceTensor(ctx, (n, c, h, w), np.float32)
+        zp0, sc0 = DeviceTensor.from_numpy(ctx, np.array([7], np.uint8)), DeviceTensor.from_numpy(ctx, np.array([0.013], np.float32))
+        ctx.call("rten_hip_conv2d_int8_stats", C.byref(d0), DeviceTensor.from_numpy(ctx, x0).vp, DeviceTensor.from_numpy(ctx, w0).vp, zp0.vp, None, sc0.vp, None, None, 0,
+                 t.vp, st_in)
+        # consumer weights
+        wq = rng.i8(o * c, reduced=True).reshape(o, c, 1, 1)
+        ws = (rng.f32(o if per_ch else 1) * 0.01 + 0.001).astype(np.float32)
+        bias = rng.f32(o) - 0.5
+        res = rng.f32(n * o * h * w).reshape(n, o, h, w) - 0.5
+        d = L.Conv2dInt8Desc(L.Conv2dDesc(n, c, h, w, o, 1, 1, (C.c_int32 * 4)(0, 0, 0, 0), 1, 1, 1, 1, 1, h, w), 0, 1, 0, L.PAD_RAW0_I8, 1, 1, o if per_ch else 1)
+        packed = DeviceTensor(ctx, (ctx.lib.rten_hip_conv2d_int8_packed_bytes(C.byref(d)),), np.uint8)
+        ctx.call("rten_hip_conv2d_int8_prepack", C.byref(d), DeviceTensor.from_numpy(ctx, wq).vp, packed.vp)
+        wsd, bd, rd = DeviceTensor.from_numpy(ctx, ws), DeviceTensor.from_numpy(ctx, bias), DeviceTensor.from_numpy(ctx, res)
+        outs = []
+        for fused in (False, True):
+            y = DeviceTensor(ctx, (n, o, h, w), np.float32)
+            ost = DeviceTensor(ctx, (sb,), np.uint8)
+            ctx.call("rten_hip_minmax_stats_reset", ost.vp, 1)
+            xs, xz = DeviceTensor(ctx, (1,), np.float32), DeviceTensor(ctx, (1,), np.uint8)
+            flags = L.CONV_RELU | L.CONV_RESIDUAL
+            if fused:
+                ctx.call("rten_hip_conv2d_int8_dql", C.byref(d), t.vp, st_in, packed.vp, wsd.vp, bd.vp, rd.vp, flags, y.vp, ost.vp, xs.vp, xz.vp)
+            else:
+                staged = DeviceTensor(ctx, (ctx.lib.rten_hip_conv2d_int8_staged_bytes(C.byref(d)),), np.uint8)
+                sc = DeviceTensor(ctx, (o if per_ch else 1,), np.float32)
+                ctx.call("rten_hip_dynamic_quantize_linear_staged_stats", C.byref(d), t.vp, st_in, staged.vp, xs.vp, xz.vp, None, None)
+                ctx.call("rten_hip_mul_f32", o if per_ch else 1, wsd.vp, xs.vp, 1, sc.vp)
+                ctx.call("rten_hip_conv2d_int8_stats", C.byref(d), staged.vp, packed.vp, xz.vp, None, sc.vp, bd.vp, rd.vp, flags, y.vp, ost.vp)
+            ctx.sync()
+            outs.append((y.numpy(), ost.numpy(), xs.numpy(), xz.numpy()))
+        bits_equal(outs[0][0], outs[1][0])
+        assert np.array_equal(outs[0][2].view(np.uint32), outs[1][2].view(np.uint32)) and np.array_equal(outs[0][3], outs[1][3])
+        # statistics blocks hold the same min / max (which slot a workgroup hits may differ)
+        k = sb // 8
+        a0, a1 = outs[0][1].view(np.uint32), outs[1][1].view(np.uint32)
+        assert a0[:k].min() == a1[:k].min() and a0[k:].max() == a1[k:].max()

@@ -29,7 +29,7 @@ def timed(fn):
     return ctx.timer_ms(1) / REPS * 1e3
 
 
-tq = tc = 0.0
+tq = tc = tf = tsep = 0.0
 print(f"{'layer':9s} {'O':>4s} {'C':>4s} k s {'HxW':>7s} | {'quant us':>8s} {'GB/s':>6s} | {'conv us':>8s} {'GB/s':>6s} {'TOP/s':>6s}  tiles(128x128)")
 ONLY = os.environ.get("LAYERS")
 for l in net.specs:
@@ -58,5 +58,12 @@ for l in net.specs:
     tiles = ((cv.o + 127) // 128) * ((cv.n * cv.out_h * cv.out_w + 127) // 128)
     tq += us_q
     tc += us_c
-    print(f"{name:9s} {cv.o:4d} {cv.c:4d} {cv.kh} {cv.stride_h} {cv.h:3d}x{cv.w:<3d} | {us_q:8.1f} {qb / us_q / 1e3:6.0f} | {us_c:8.1f} {cb / us_c / 1e3:6.0f} {ops / us_c / 1e6:6.0f}  {tiles}")
-print(f"sum: quantize {tq / 1e3:.3f} ms, conv {tc / 1e3:.3f} ms")
+    fused = ""
+    if st is not None and cv.kh == 1 and cv.stride_h == 1 and not any(cv.pads) and cv.c % 64 == 0:
+        us_f = timed(lambda: ctx.call("rten_hip_conv2d_int8_dql", C.byref(d), src.vp, st, net.wq[name].vp, net.ws[name].vp, net.bq[name].vp,
+                                      net._act(l["res"]).vp if l["res"] else None, flags, net._act(l["dst"]).vp, net.stats[l["dst"]], None, None))
+        tf += us_f
+        tsep += us_q + us_c
+        fused = f" | fused quantize+conv {us_f:6.1f} us (separate {us_q + us_c:6.1f})"
+    print(f"{name:9s} {cv.o:4d} {cv.c:4d} {cv.kh} {cv.stride_h} {cv.h:3d}x{cv.w:<3d} | {us_q:8.1f} {qb / us_q / 1e3:6.0f} | {us_c:8.1f} {cb / us_c / 1e3:6.0f} {ops / us_c / 1e6:6.0f}  {tiles}{fused}")
+print(f"sum: quantize {tq / 1e3:.3f} ms, conv {tc / 1e3:.3f} ms; pointwise layers fused {tf / 1e3:.3f} ms vs separate {tsep / 1e3:.3f} ms")
