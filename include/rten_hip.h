@@ -139,6 +139,14 @@ typedef struct {
 
 int32_t rten_hip_gemm_f32(rten_hip_ctx *ctx, const rten_hip_gemm_desc *desc, const float *a, const float *b,
                           const float *bias, float *c);
+/* One-row products (m == 1, per batch element): the reference takes its vector-matrix kernels when A has one row and B is not
+ * prepacked (rten-gemm/src/lib.rs:668-747, 876-891; kernels/simd_generic.rs:14-197), and their accumulation order is not the
+ * blocked GEMM's (depth blocks of 8 or 512, 16-lane partial sums for transposed B, unfused scalar loops for the columns left over
+ * in a column block).  `on` (default 1): rten_hip_gemm_f32 reproduces that order bit for bit; 0: m == 1 takes the blocked order, i.e.
+ * the reference with prepacked weights (ModelOptions::prepack_weights).  The reference's column blocks are
+ * max(128, ceil(n / threads)) wide, so WHICH columns are "left over" depends on its thread count: `reference_threads` states it
+ * (0 = at least n / 128 threads, every block 128 columns). */
+int32_t rten_hip_set_gemv_order(rten_hip_ctx *ctx, int32_t on, int32_t reference_threads);
 
 /* ---- int8 GEMM: GemmExecutor<u8,i8,i32>, kernels/generic.rs:274-366; front-ends
  *      matmul_integer / MatMulIntegerToFloat, src/ops/matmul.rs:582-647,789-794 ----

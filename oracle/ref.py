@@ -128,6 +128,17 @@ def gemm_f32(a, b, c=None, alpha=1.0, beta=0.0, bias=None, bias_kind=BIAS_NONE):
     return out
 
 
+def set_gemv_threads(t: int):
+    """Thread count the reference's gemv path is assumed to run with (column blocks of max(128, ceil(N / t)) columns); 0 = enough
+    threads for 128-column blocks everywhere (the default)."""
+    lib().rto_set_gemv_threads(i64(t))
+
+
+def set_gemv_enabled(on: bool):
+    """False: M == 1 products take the blocked GEMM order too (the reference with prepacked weights)."""
+    lib().rto_set_gemv_enabled(C.c_int(1 if on else 0))
+
+
 def matmul_f32(a, b, alpha=1.0, bias=None):
     """numpy.matmul-style batched product following src/ops/matmul.rs:208-385 (bias = per column)."""
     a = _f32(a)

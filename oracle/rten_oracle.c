@@ -143,9 +143,8 @@ RTO_API int rto_calc_output_size_and_padding(int64_t in_h, int64_t in_w, int64_t
  * beta, later blocks beta = 1 (lib.rs:1008-1013 `effective_beta`).  The bias is added after
  * the first depth block only (lib.rs:1221-1255).  Every output element is an independent
  * chain, so the result does not depend on MR/NR, thread count or ISA (all f32 kernels use
- * fused mul_add).  The M == 1 gemv fast path (lib.rs:876-891, simd_generic.rs:14-197) uses
- * ISA-dependent orders and is NOT restated; M == 1 goes through the same blocked order and
- * parity for it is by tolerance only.
+ * fused mul_add).  The M == 1 gemv fast path (lib.rs:876-891, simd_generic.rs:14-197) is restated
+ * separately below (rto_gemm_f32 takes it like gemm_impl does; the convolution's GEMM never does).
  *
  * B is "virtual": element (k, n) comes from a callback so that dense, transposed and im2col
  * inputs share the code (the reference does the same via packing, lib.rs:958-1003).
@@ -259,9 +258,136 @@ static void gemm_f32_core(int64_t M, int64_t N, int64_t K, const float *A, int64
     free(apack);
 }
 
+/* ------------------------------------------------------------------------------------
+ * M == 1: the reference's vector-matrix path -- rten-gemm/src/lib.rs:668-747 (gemv: column blocks, depth blocks, bias),
+ * :876-891 (taken when A has one row and B is NOT prepacked; ModelOptions::prepack_weights defaults to false, src/model.rs:694),
+ * kernels/simd_generic.rs:14-197 (the three kernels).  AVX-512 instantiation (x86_64.rs:452-470: 16 lanes, NR_REGS = 2), like
+ * the reductions elsewhere in this file.  Unlike the blocked GEMM this is NOT one k-ordered chain per output:
+ *  - B with unit column stride (row-major [K][N]): depth blocks of 8 (lib.rs:698); per block a fused-multiply-add chain from 0
+ *    per column, scaled by alpha, folded into the output with the block's beta (caller's beta, then 1) by store / add / fma;
+ *    columns are processed 32 at a time and the columns left over at the end of a column block run a scalar loop with SEPARATE
+ *    multiply and add and `beta * out + acc * alpha` (simd_generic.rs:90-103);
+ *  - B with unit row stride (transposed operands, e.g. Gemm transB): depth blocks of 512; 8 columns at a time, each with 16 lane
+ *    accumulators over 16-element depth tiles, summed by _mm512_reduce_add_ps (lane l + lane l + 8, + 4, + 2, + 1), then a scalar
+ *    fma tail over depth % 16, then `alpha * acc (+ beta * out)`; the < 8 columns left over in a column block run the scalar fma
+ *    chain of the fallback kernel;
+ *  - neither stride 1: depth blocks of 8, scalar fma chain per column, `acc *= alpha`, `acc + beta * out`.
+ * The bias is added after the last depth block.  Column blocks have max(128, ceil(N / threads)) columns (lib.rs:697), so WHICH
+ * columns are "left over" depends on the reference's thread count: `rto_set_gemv_threads(t)`; the default 0 stands for "at least
+ * N / 128 threads" (every block 128 columns wide), the case on the many-core hosts this project measures on.
+ * ---------------------------------------------------------------------------------- */
+static int64_t g_gemv_threads = 0;
+static int g_gemv_enabled = 1;
+RTO_API void rto_set_gemv_threads(int64_t t) { g_gemv_threads = t; }
+RTO_API void rto_set_gemv_enabled(int on) { g_gemv_enabled = on; } /* 0: B is "prepacked": M == 1 takes the blocked path too */
+
+static void gemv_fallback(int64_t ncols, int64_t depth, const float *a, const float *b, int64_t rs, int64_t cs, float *out,
+                          float alpha, float beta) { /* simd_generic.rs:179-197 */
+    for (int64_t c = 0; c < ncols; c++) {
+        float acc = 0.f;
+        for (int64_t k = 0; k < depth; k++) acc = fma32(a[k], b[k * rs + c * cs], acc);
+        acc = acc * alpha;
+        if (beta == 0.f) out[c] = acc;
+        else {
+            volatile float t = beta * out[c]; /* separately rounded product */
+            out[c] = acc + t;
+        }
+    }
+}
+
+static void gemv_transposed(int64_t ncols, int64_t depth, const float *a, const float *b, int64_t cs, float *out, float alpha,
+                            float beta) { /* simd_generic.rs:107-174; b has unit row stride */
+    const int64_t full = ncols / 8 * 8, dt = depth / 16 * 16;
+    for (int64_t c = 0; c < full; c++) {
+        const float *col = b + c * cs;
+        float lanes[16];
+        for (int l = 0; l < 16; l++) lanes[l] = 0.f;
+        for (int64_t d = 0; d < dt; d += 16)
+            for (int l = 0; l < 16; l++) lanes[l] = fma32(a[d + l], col[d + l], lanes[l]);
+        for (int w = 8; w >= 1; w >>= 1)
+            for (int l = 0; l < w; l++) lanes[l] = lanes[l] + lanes[l + w];
+        float acc = lanes[0];
+        for (int64_t k = dt; k < depth; k++) acc = fma32(a[k], col[k], acc);
+        volatile float pa = alpha * acc;
+        if (beta == 0.f) out[c] = pa;
+        else {
+            volatile float pb = beta * out[c];
+            out[c] = pa + pb;
+        }
+    }
+    if (full < ncols) gemv_fallback(ncols - full, depth, a, b + full * cs, 1, cs, out + full, alpha, beta);
+}
+
+static void gemv_rowmajor(int64_t ncols, int64_t depth, const float *a, const float *b, int64_t rs, float *out, float alpha,
+                          float beta) { /* simd_generic.rs:28-104; b has unit column stride */
+    const int64_t full = ncols / 32 * 32;
+    for (int64_t c = 0; c < full; c++) {
+        float acc = 0.f;
+        for (int64_t k = 0; k < depth; k++) acc = fma32(a[k], b[k * rs + c], acc);
+        if (alpha != 1.f) acc = acc * alpha;
+        if (beta == 0.f) out[c] = acc;
+        else if (beta == 1.f) out[c] = out[c] + acc;
+        else out[c] = fma32(out[c], beta, acc);
+    }
+    for (int64_t c = full; c < ncols; c++) {
+        float acc = 0.f;
+        for (int64_t k = 0; k < depth; k++) {
+            volatile float pr = a[k] * b[k * rs + c]; /* `acc += ax * b`: no fused multiply-add in Rust */
+            acc = acc + pr;
+        }
+        const float tmp = beta == 0.f ? 0.f : out[c];
+        volatile float p0 = beta * tmp, p1 = acc * alpha;
+        out[c] = p0 + p1;
+    }
+}
+
+static void gemv_f32(int64_t N, int64_t K, const float *A, int64_t a_cs, const float *B, int64_t b_rs, int64_t b_cs, float *out,
+                     float alpha, float beta, const float *bias, int bias_kind) {
+    float *a = (float *)malloc((size_t)(K > 0 ? K : 1) * sizeof(float)); /* a.to_contiguous() */
+    for (int64_t k = 0; k < K; k++) a[k] = A[k * a_cs];
+    int64_t cb = 128;
+    if (g_gemv_threads > 0) {
+        cb = (N + g_gemv_threads - 1) / g_gemv_threads;
+        if (cb < 128) cb = 128;
+    }
+    const int64_t kb = b_rs == 1 ? 512 : 8;
+    for (int64_t c0 = 0; c0 < N; c0 += cb) {
+        const int64_t nc = N - c0 < cb ? N - c0 : cb;
+        float eff_beta = beta;
+        for (int64_t k0 = 0; k0 < K; k0 += kb) {
+            const int64_t depth = K - k0 < kb ? K - k0 : kb;
+            const float *bb = B + k0 * b_rs + c0 * b_cs;
+            if (b_rs == 1) gemv_transposed(nc, depth, a + k0, bb, b_cs, out + c0, alpha, eff_beta);
+            else if (b_cs != 1) gemv_fallback(nc, depth, a + k0, bb, b_rs, b_cs, out + c0, alpha, eff_beta);
+            else gemv_rowmajor(nc, depth, a + k0, bb, b_rs, out + c0, alpha, eff_beta);
+            eff_beta = 1.f;
+        }
+        for (int64_t c = 0; c < nc; c++) {
+            if (bias_kind == 1) out[c0 + c] = out[c0 + c] + bias[0];       /* BiasVector::Column: one row */
+            else if (bias_kind == 2) out[c0 + c] = out[c0 + c] + bias[c0 + c];
+        }
+    }
+    free(a);
+}
+
+/* the blocked order whatever M is: the products INSIDE attention, ConvTranspose and MatMulNBits (rows > 1).  (With one query row /
+ * one output row the reference's matmul would take its gemv kernels there as well; neither this oracle nor the backend follow it
+ * into those operators -- DESIGN.md section 9.) */
+static void gemm_f32_blocked(int64_t M, int64_t N, int64_t K, const float *A, int64_t a_rs, int64_t a_cs, const float *B, int64_t b_rs,
+                             int64_t b_cs, float *C, int64_t ldc, float alpha, float beta, const float *bias, int bias_kind) {
+    bsrc_f32 bs;
+    memset(&bs, 0, sizeof bs);
+    bs.b = B; bs.rs = b_rs; bs.cs = b_cs;
+    gemm_f32_core(M, N, K, A, a_rs, a_cs, &bs, C, ldc, alpha, beta, bias, bias_kind);
+}
+
 RTO_API void rto_gemm_f32(int64_t M, int64_t N, int64_t K, const float *A, int64_t a_rs, int64_t a_cs,
                           const float *B, int64_t b_rs, int64_t b_cs, float *C, int64_t ldc,
                           float alpha, float beta, const float *bias, int bias_kind) {
+    if (M == 1 && N > 0 && K > 0 && g_gemv_enabled) { /* lib.rs:876-891 (after the K == 0 case, :843-873) */
+        gemv_f32(N, K, A, a_cs, B, b_rs, b_cs, C, alpha, beta, bias, bias_kind);
+        return;
+    }
     bsrc_f32 bs;
     memset(&bs, 0, sizeof bs);
     bs.b = B; bs.rs = b_rs; bs.cs = b_cs;
@@ -349,7 +475,7 @@ RTO_API int rto_matmul_nbits_f32(int64_t batch, int64_t rows, int64_t K, int64_t
     }
     float *bm = (float *)malloc((size_t)K * N * sizeof(float));
     rto_dequantize_4bit(N, K, bs, quant, scales, bm);
-    rto_gemm_f32(batch * rows, N, K, lhs, K, 1, bm, N, 1, out, N, 1.f, 0.f, NULL, 0);
+    gemm_f32_blocked(batch * rows, N, K, lhs, K, 1, bm, N, 1, out, N, 1.f, 0.f, NULL, 0);
     free(bm);
     return 0;
 }
@@ -466,7 +592,7 @@ RTO_API int rto_conv_transpose2d_f32(int64_t N, int64_t C, int64_t H, int64_t W,
     for (int64_t g = 0; g < groups; g++)
         for (int64_t n = 0; n < N; n++) {
             /* A[m][k] = kernel[(g*Cg + k)][m]: row stride 1, column stride M (the transposed kernel matrix) */
-            rto_gemm_f32(M, P, Cg, Wt + g * Cg * M, 1, M, X + (n * C + g * Cg) * P, P, 1, cols, P, 1.0f, 0.0f, NULL, 0);
+            gemm_f32_blocked(M, P, Cg, Wt + g * Cg * M, 1, M, X + (n * C + g * Cg) * P, P, 1, cols, P, 1.0f, 0.0f, NULL, 0);
             for (int64_t o = 0; o < Og; o++) {
                 float *out = Y + (n * O + g * Og + o) * OH * OW;
                 const float b = bias ? bias[g * Og + o] : 0.0f;
@@ -902,10 +1028,10 @@ RTO_API void rto_sdpa_head(int64_t S, int64_t T, int64_t D, int64_t Dv, const fl
                            const float *v, const float *mask, int64_t mask_rs, float scale, float *out,
                            int lanes, int flush_nan) {
     float *scores = (float *)malloc((size_t)S * T * sizeof(float));
-    rto_gemm_f32(S, T, D, q, D, 1, k, 1, D, scores, T, scale, 0.f, NULL, 0);
+    gemm_f32_blocked(S, T, D, q, D, 1, k, 1, D, scores, T, scale, 0.f, NULL, 0);
     for (int64_t s = 0; s < S; s++)
         rto_softmax_row(T, scores + s * T, mask ? mask + s * mask_rs : NULL, scores + s * T, flush_nan, lanes);
-    rto_gemm_f32(S, Dv, T, scores, T, 1, v, Dv, 1, out, Dv, 1.f, 0.f, NULL, 0);
+    gemm_f32_blocked(S, Dv, T, scores, T, 1, v, Dv, 1, out, Dv, 1.f, 0.f, NULL, 0);
     free(scores);
 }
 

@@ -51,7 +51,7 @@ RTEN_EXPORT int32_t rten_hip_sdpa_f32(rten_hip_ctx *ctx, const rten_hip_sdpa_des
     g.a_bs = d->q_bs; g.a_bsi = d->q_hs; g.b_bs = d->k_bs; g.b_bsi = d->k_hs;
     g.c_bs = (int64_t)d->heads * d->s * d->t; g.c_bsi = (int64_t)d->s * d->t;
     g.alpha = d->scale; g.beta = 0.f;
-    int32_t rc = rten_hip_gemm_f32(ctx, &g, q, k, nullptr, scores);
+    int32_t rc = rten_gemm_f32_blocked(ctx, &g, q, k, nullptr, scores);
     if (rc) return rc;
     // row softmax with NaN flush (attention.rs:546-552); score row r = ((b*H + h)*S + qi)
     if (d->t > 0) {
@@ -75,5 +75,5 @@ RTEN_EXPORT int32_t rten_hip_sdpa_f32(rten_hip_ctx *ctx, const rten_hip_sdpa_des
     g.a_bs = (int64_t)d->heads * d->s * d->t; g.a_bsi = (int64_t)d->s * d->t;
     g.b_bs = d->v_bs; g.b_bsi = d->v_hs; g.c_bs = d->o_bs; g.c_bsi = d->o_hs;
     g.alpha = 1.f; g.beta = 0.f;
-    return rten_hip_gemm_f32(ctx, &g, scores, v, nullptr, out);
+    return rten_gemm_f32_blocked(ctx, &g, scores, v, nullptr, out);
 }

@@ -90,7 +90,7 @@ RTEN_EXPORT int32_t rten_hip_conv_transpose2d_f32(rten_hip_ctx *ctx, const rten_
         gd.b_rs = P; gd.b_cs = 1; gd.ldc = P;
         gd.batch = d->n; gd.a_bs = 0; gd.b_bs = (long long)d->c * P; gd.c_bs = M * P;
         gd.alpha = 1.f; gd.beta = 0.f;
-        const int32_t rc = rten_hip_gemm_f32(ctx, &gd, w + (long long)g * Cg * M, x + (long long)g * Cg * P, nullptr, cols);
+        const int32_t rc = rten_gemm_f32_blocked(ctx, &gd, w + (long long)g * Cg * M, x + (long long)g * Cg * P, nullptr, cols);
         if (rc) return rc;
         ProfScope ps(ctx, "col2im_f32", 0.0, 4.0 * ((double)d->n * M * P + (double)d->n * Og * plane));
         hipLaunchKernelGGL(col2im_kernel, dim3((unsigned)(d->n * Og), (unsigned)((plane + 255) / 256)), dim3(256), 0, ctx->stream, *d, Og, g * Og, cols, bias, y);

@@ -2873,9 +2873,31 @@ RTEN_EXPORT int32_t rten_hip_set_gemm_order(rten_hip_ctx *ctx, int32_t order) {
     return RTEN_HIP_OK;
 }
 
+namespace {
+int32_t gemm_f32_entry(rten_hip_ctx *ctx, const rten_hip_gemm_desc *d, const float *a, const float *b, const float *bias, float *c, bool allow_gemv);
+}
+
 RTEN_EXPORT int32_t rten_hip_gemm_f32(rten_hip_ctx *ctx, const rten_hip_gemm_desc *d, const float *a, const float *b,
                                       const float *bias, float *c) {
     RTEN_CHECK_CTX(ctx);
+    return gemm_f32_entry(ctx, d, a, b, bias, c, ctx->gemv_order != 0);
+}
+
+int32_t rten_gemm_f32_blocked(rten_hip_ctx *ctx, const rten_hip_gemm_desc *d, const float *a, const float *b, const float *bias, float *c) {
+    RTEN_CHECK_CTX(ctx);
+    return gemm_f32_entry(ctx, d, a, b, bias, c, false);
+}
+
+RTEN_EXPORT int32_t rten_hip_set_gemv_order(rten_hip_ctx *ctx, int32_t on, int32_t reference_threads) {
+    RTEN_CHECK_CTX(ctx);
+    if (reference_threads < 0) return RTEN_HIP_ERR_INVALID_VALUE;
+    ctx->gemv_order = on ? 1 : 0;
+    ctx->gemv_threads = reference_threads;
+    return RTEN_HIP_OK;
+}
+
+namespace {
+int32_t gemm_f32_entry(rten_hip_ctx *ctx, const rten_hip_gemm_desc *d, const float *a, const float *b, const float *bias, float *c, bool allow_gemv) {
     if (!d) return RTEN_HIP_ERR_INVALID_VALUE;
     if (d->m < 0 || d->n < 0 || d->k < 0 || d->batch < 0)
         return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "gemm: negative dimension");
@@ -2886,6 +2908,8 @@ RTEN_EXPORT int32_t rten_hip_gemm_f32(rten_hip_ctx *ctx, const rten_hip_gemm_des
     if (d->ldc < d->n) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "gemm: ldc < n");
     if (d->a_rs < 0 || d->a_cs < 0 || d->b_rs < 0 || d->b_cs < 0)
         return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "gemm: negative strides are not supported");
+    // one row, B not prepacked: the reference takes its gemv kernels, whose accumulation order is not the blocked one (lib.rs:876-891)
+    if (allow_gemv && d->m == 1 && d->k > 0) return rten_gemv_f32(ctx, d, a, b, bias, c);
 
     GemmArgs g = {};
     g.A = a ? a : c; g.B = b ? b : c; g.C = c; g.bias = bias; g.res = nullptr;
@@ -2917,6 +2941,7 @@ RTEN_EXPORT int32_t rten_hip_gemm_f32(rten_hip_ctx *ctx, const rten_hip_gemm_des
     }
     return dispatch(ctx, g, d->batch, al, bl);
 }
+} // namespace
 
 // ---- conv weight staging: W[g][m][k] (OIHW) -> packed[g][k][Og4], zero padded (Og4 = round_up(O/g, 4))
 namespace {

@@ -52,6 +52,8 @@ struct rten_hip_ctx {
     int int8_path = 0;  // 0 automatic (fast staging path when it covers the call), 1 generic kernel only
     int tile_order = 0; // workgroup -> tile order bits (rten_hip_set_gemm_order)
     int split_mode = 3, split_s = 1; // exact split-K plan: 0 off, 1 tail tiles, 2 all tiles, 3 automatic (gemm_f32.hip)
+    int gemv_order = 1;          // m == 1 products of rten_hip_gemm_f32 follow the reference's gemv kernels (gemv_f32.hip); 0: the blocked order
+    long long gemv_threads = 0;  // reference thread count assumed for its column blocks (0: at least n / 128)
     static constexpr long long kSplitCounters = 1 << 16;
     unsigned *split_counters = nullptr; // arrival counters of the split-K producers (zero between launches), allocated with the context
     int debug = 0; // RTEN_HIP_DEBUG ablation bits (tuning only)
@@ -70,6 +72,10 @@ inline int rten_effective_pad_mode(const rten_hip_conv2d_int8_desc *di) {
 int32_t rten_set_error(rten_hip_ctx *ctx, int32_t code, const char *fmt, ...);
 int32_t rten_check_hip(rten_hip_ctx *ctx, hipError_t e, const char *what);
 void *rten_scratch(rten_hip_ctx *ctx, size_t bytes);
+// gemv_f32.hip: the m == 1 product in the reference's gemv order (called by rten_hip_gemm_f32)
+int32_t rten_gemv_f32(rten_hip_ctx *ctx, const rten_hip_gemm_desc *d, const float *a, const float *b, const float *bias, float *c);
+// gemm_f32.hip: rten_hip_gemm_f32 without the gemv dispatch (operators whose reference form is not a gemm_impl call on unpacked operands)
+int32_t rten_gemm_f32_blocked(rten_hip_ctx *ctx, const rten_hip_gemm_desc *d, const float *a, const float *b, const float *bias, float *c);
 void *rten_aux_scratch(rten_hip_ctx *ctx, size_t bytes);
 
 // Profiling bracket around one kernel launch.

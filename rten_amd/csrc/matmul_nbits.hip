@@ -216,5 +216,5 @@ RTEN_EXPORT int32_t rten_hip_matmul_nbits_f32(rten_hip_ctx *ctx, int64_t batch, 
     gd.b_rs = 1; gd.b_cs = k; // the expanded weights are [n][k]
     gd.ldc = n; gd.batch = 1;
     gd.alpha = 1.f; gd.beta = 0.f;
-    return rten_hip_gemm_f32(ctx, &gd, a, bm, nullptr, y);
+    return rten_gemm_f32_blocked(ctx, &gd, a, bm, nullptr, y);
 }

@@ -116,6 +116,7 @@ PROTOTYPES = {
     "rten_hip_calc_output_size_and_padding": (_I32, [_I32] * 7 + [C.POINTER(_I32), _I32, _I32, _I32, C.POINTER(_I32),
                                                                  C.POINTER(_I32), C.POINTER(C.c_char_p)]),
     "rten_hip_gemm_f32": (_I32, [_VP, C.POINTER(GemmDesc), _VP, _VP, _VP, _VP]),
+    "rten_hip_set_gemv_order": (_I32, [_VP, _I32, _I32]),
     "rten_hip_gemm_int8": (_I32, [_VP, C.POINTER(GemmInt8Desc), _VP, _VP, _VP, _VP, _VP, _VP]),
     "rten_hip_gemm_int8_packed_bytes": (_SZ, [_I32, _I32]),
     "rten_hip_gemm_int8_prepack": (_I32, [_VP, _I32, _I32, _VP, _I64, _I64, _I32, _VP]),

@@ -160,7 +160,13 @@ class ResNet50:
         p = self.shapes["stem"]
         self.pool_desc = L.Pool2dDesc(p[0], p[1], p[2], p[3], 3, 3, 2, 2, (C.c_int32 * 4)(1, 1, 1, 1), self.shapes["pool"][2],
                                       self.shapes["pool"][3], 0)
-        self.fc_desc = L.gemm_desc(N, self.num_classes, 2048, 2048, 1, 1, 2048, self.num_classes, bias_kind=L.BIAS_PER_COL)
+        # Gemm(transB = 1, C = bias): the reference expands C into the output and runs gemm with beta = 1 (matmul.rs:63-82).  With
+        # several rows that equals a per-column bias after the first depth block (what the fused form below does); a ONE-row product
+        # takes the reference's gemv kernels, where the bias enters with the first depth block and not at the end, so batch 1 runs
+        # the operator's own form: logits <- bias, then gemm(beta = 1).
+        self.fc_gemm_form = N == 1
+        self.fc_desc = (L.gemm_desc(N, self.num_classes, 2048, 2048, 1, 1, 2048, self.num_classes, beta=1.0) if self.fc_gemm_form else
+                        L.gemm_desc(N, self.num_classes, 2048, 2048, 1, 1, 2048, self.num_classes, bias_kind=L.BIAS_PER_COL))
 
     def _wptr(self, name, which):
         a, b = self.w_off[name]
@@ -227,7 +233,11 @@ class ResNet50:
         last = self.specs[-1]["dst"]
         n, c, h, w = self.shapes[last]
         ctx.call("rten_hip_global_average_pool_f32", n * c, h * w, self.bufs[last].vp, self.gap.vp)
-        ctx.call("rten_hip_gemm_f32", C.byref(self.fc_desc), self.gap.vp, self._wptr("fc", 0), self._wptr("fc", 1), self.logits.vp)
+        if self.fc_gemm_form:
+            ctx.call("rten_hip_memcpy_d2d", self.logits.vp, self._wptr("fc", 1), C.c_size_t(self.num_classes * 4))
+            ctx.call("rten_hip_gemm_f32", C.byref(self.fc_desc), self.gap.vp, self._wptr("fc", 0), None, self.logits.vp)
+        else:
+            ctx.call("rten_hip_gemm_f32", C.byref(self.fc_desc), self.gap.vp, self._wptr("fc", 0), self._wptr("fc", 1), self.logits.vp)
 
     def capture(self):
         """Capture the forward pass into a hipGraph (one host call per inference afterwards)."""

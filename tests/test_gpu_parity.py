@@ -130,14 +130,76 @@ def test_gemm_f32_split_k_bit_exact(ctx):
         ctx.call("rten_hip_set_gemm_split", 3, 1)
 
 
-def test_gemm_f32_gemv_tolerance(ctx):
-    # M == 1: the reference takes its ISA-dependent gemv path; parity by tolerance (rtol 1e-5 of sum|a||b|)
+def test_gemm_f32_one_row_follows_the_reference_gemv_order(ctx):
+    """M == 1: the reference takes its gemv kernels (rten-gemm/src/lib.rs:876-891, simd_generic.rs:14-197) whose order is not the
+    blocked GEMM's; rten_hip_gemm_f32 follows them bit for bit (row-major / transposed / strided B, alpha / beta / bias / activation,
+    left-over columns of a column block, the stated reference thread count), and with the order switched off (prepacked weights in
+    the reference) a one-row product is a row of the blocked result."""
     rng = ref.XorShiftRng(11)
-    a = rng.f32(2048).reshape(1, 2048) - 0.5
-    b = rng.f32(2048 * 1000).reshape(2048, 1000) - 0.5
-    got = gpu_gemm(ctx, a, b)
-    want = a.astype(np.float64) @ b.astype(np.float64)
-    assert np.abs(got - want).max() <= 1e-5 * (np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64)).max()
+    for (k, n) in ((1, 1), (7, 5), (8, 32), (20, 45), (530, 40), (2048, 1000), (33, 300), (600, 137)):
+        a = rng.f32(k).reshape(1, k) - 0.5
+        b = rng.f32(k * n).reshape(k, n) - 0.5
+        bt = np.ascontiguousarray(b.T).T  # unit ROW stride: the transposed kernel
+        c = rng.f32(n).reshape(1, n) - 0.5
+        bias = rng.f32(n) - 0.5
+        for bb in (b, bt):
+            bits_equal(gpu_gemm(ctx, a, bb), ref.gemm_f32(a, bb))
+            bits_equal(gpu_gemm(ctx, a, bb, c=c, alpha=0.5, beta=2.0, bias=bias, bias_kind=L.BIAS_PER_COL),
+                       ref.gemm_f32(a, bb, c=c, alpha=0.5, beta=2.0, bias=bias, bias_kind=ref.BIAS_PER_COL))
+            bits_equal(gpu_gemm(ctx, a, bb, c=c, alpha=1.0, beta=1.0), ref.gemm_f32(a, bb, c=c, alpha=1.0, beta=1.0))
+            bits_equal(gpu_gemm(ctx, a, bb, bias=bias, bias_kind=L.BIAS_PER_COL, act=L.ACT_GELU), ref.gelu(ref.gemm_f32(a, bb, bias=bias, bias_kind=ref.BIAS_PER_COL)))
+            bits_equal(gpu_gemm(ctx, a, bb, alpha=0.25), ref.gemm_f32(a, bb, alpha=0.25))
+        # against the truth, by tolerance (what round 1 could claim)
+        want = a.astype(np.float64) @ b.astype(np.float64)
+        assert np.abs(gpu_gemm(ctx, a, b) - want).max() <= 1e-5 * max((np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64)).max(), 1e-30)
+    # neither stride is 1: the fallback kernel (a strided view staged as a wider matrix on the device)
+    k, n = 37, 50
+    wide = rng.f32(2 * k * 3 * n).reshape(2 * k, 3 * n) - 0.5
+    bs = wide[::2, ::3]
+    a = rng.f32(k).reshape(1, k) - 0.5
+    wd, ad = dev(ctx, wide), dev(ctx, a)
+    cd = dev(ctx, np.full((1, n), np.nan, np.float32))
+    d = L.gemm_desc(1, n, k, k, 1, 2 * 3 * n, 3, n)
+    ctx.call("rten_hip_gemm_f32", C.byref(d), ad.vp, wd.vp, None, cd.vp)
+    bits_equal(cd.numpy(), ref.gemm_f32(a, bs))
+    # the reference's thread count is part of the order (which columns are left over in a column block) ...
+    k, n = 300, 1000
+    a = rng.f32(k).reshape(1, k) - 0.5
+    b = rng.f32(k * n).reshape(k, n) - 0.5
+    try:
+        for threads in (4, 3, 1):
+            ctx.call("rten_hip_set_gemv_order", 1, threads)
+            ref.set_gemv_threads(threads)
+            for bb in (b, np.ascontiguousarray(b.T).T):
+                bits_equal(gpu_gemm(ctx, a, bb), ref.gemm_f32(a, bb))
+        # ... and switched off, a one-row product is the blocked GEMM's row
+        ctx.call("rten_hip_set_gemv_order", 0, 0)
+        bits_equal(gpu_gemm(ctx, a, b), ref.gemm_f32(np.concatenate([a, a]), b)[:1])
+    finally:
+        ctx.call("rten_hip_set_gemv_order", 1, 0)
+        ref.set_gemv_threads(0)
+    # batched one-row products (one gemv per batch element, matmul.rs:299-385)
+    qa = rng.f32(3 * 1 * 40).reshape(3, 1, 40) - 0.5
+    qb = rng.f32(3 * 40 * 24).reshape(3, 40, 24) - 0.5
+    got = ops.MatMul().run(ctx, [DeviceTensor.from_numpy(ctx, qa), DeviceTensor.from_numpy(ctx, qb)])[0].numpy()
+    bits_equal(got, ref.matmul_f32(qa, qb))
+
+
+def test_resnet50_batch1_logits_bit_exact(ctx):
+    """BASELINE configs[0] (batch 1): the classifier is a one-row Gemm(transB), i.e. the reference's transposed gemv kernel."""
+    from oracle import models as omodels
+    from rten_amd.workloads import resnet50
+    w = resnet50.make_weights()
+    net = resnet50.ResNet50(ctx, batch=1, weights=w)
+    net.upload_weights()
+    x = ref.XorShiftRng(8).f32(3 * 224 * 224).reshape(1, 3, 224, 224)
+    net.x.upload(x)
+    net.forward()
+    bits_equal(net.logits.numpy(), omodels.resnet50_forward(net.specs, w, x))
+    net.capture()
+    net.logits.upload(np.zeros((1, 1000), np.float32))
+    net.run()
+    bits_equal(net.logits.numpy(), omodels.resnet50_forward(net.specs, w, x))
 
 
 def test_matmul_ops_broadcast_and_batched(ctx):

@@ -422,3 +422,106 @@ def test_real_reference_check_recorded():
     import re
     diffs = [float(d) for d in re.findall(r"max diff ([0-9.eE+-]+)", open(path).read())]
     assert len(diffs) >= 3 and all(d == 0.0 for d in diffs), diffs
+
+
+def _fma(a, b, c):
+    """f32 fused multiply-add through 80-bit intermediates (product exact; a double rounding would need a 64-bit tie)."""
+    return np.float32(np.longdouble(a) * np.longdouble(b) + np.longdouble(c))
+
+
+def _gemv_emulation(a, b, out0, alpha, beta, bias, threads=0):
+    """The reference's vector-matrix product written a second time, straight from rten-gemm/src/lib.rs:668-747 and
+    kernels/simd_generic.rs:14-197 (AVX-512: 16 lanes, 32-column tiles), with numpy scalars."""
+    f = np.float32
+    K, N = b.shape
+    rs, cs = b.strides[0] // 4, b.strides[1] // 4
+    out = None if out0 is None else out0.astype(np.float32).copy()
+    res = np.zeros(N, np.float32)
+    cb = 128 if threads == 0 else max(128, -(-N // threads))
+    kb = 512 if rs == 1 else 8
+    for c0 in range(0, N, cb):
+        nc = min(cb, N - c0)
+        for c in range(nc):
+            col = c0 + c
+            eff_beta = f(beta)
+            o = f(0) if out is None else out[col]
+            for k0 in range(0, K, kb):
+                depth = min(kb, K - k0)
+                ak, bk = a[k0:k0 + depth], b[k0:k0 + depth, col]
+                if rs == 1 and c < nc // 8 * 8:
+                    lanes = [f(0)] * 16
+                    dt = depth // 16 * 16
+                    for d in range(0, dt, 16):
+                        for l in range(16):
+                            lanes[l] = _fma(ak[d + l], bk[d + l], lanes[l])
+                    w = 8
+                    while w >= 1:
+                        for l in range(w):
+                            lanes[l] = f(lanes[l] + lanes[l + w])
+                        w //= 2
+                    acc = lanes[0]
+                    for k in range(dt, depth):
+                        acc = _fma(ak[k], bk[k], acc)
+                    o = f(f(alpha) * acc) if eff_beta == 0 else f(f(f(alpha) * acc) + f(eff_beta * o))
+                elif rs == 1 or cs != 1:
+                    acc = f(0)
+                    for k in range(depth):
+                        acc = _fma(ak[k], bk[k], acc)
+                    acc = f(acc * f(alpha))
+                    o = acc if eff_beta == 0 else f(acc + f(eff_beta * o))
+                elif c < nc // 32 * 32:
+                    acc = f(0)
+                    for k in range(depth):
+                        acc = _fma(ak[k], bk[k], acc)
+                    if alpha != 1.0:
+                        acc = f(acc * f(alpha))
+                    o = acc if eff_beta == 0 else (f(o + acc) if eff_beta == 1 else _fma(o, eff_beta, acc))
+                else:
+                    acc = f(0)
+                    for k in range(depth):
+                        acc = f(acc + f(ak[k] * bk[k]))
+                    tmp = f(0) if eff_beta == 0 else o
+                    o = f(f(eff_beta * tmp) + f(acc * f(alpha)))
+                eff_beta = f(1)
+            if bias is not None:
+                o = f(o + (bias[col] if len(bias) > 1 else bias[0]))
+            res[col] = o
+    return res
+
+
+@pytest.mark.parametrize("layout", ["rowmajor", "transposed", "strided"])
+def test_gemv_path_restated_twice(layout):
+    """M == 1 takes the reference's gemv kernels (not the blocked GEMM order): the C restatement against a second, scalar one."""
+    rng = ref.XorShiftRng(31)
+    for (K, N) in ((1, 1), (7, 5), (8, 32), (20, 45), (530, 40), (2048, 137), (33, 300)):
+        a = rng.f32(K) - 0.5
+        if layout == "rowmajor":
+            b = rng.f32(K * N).reshape(K, N) - 0.5
+        elif layout == "transposed":
+            b = (rng.f32(K * N).reshape(N, K) - 0.5).T
+        else:
+            b = (rng.f32(K * N * 6).reshape(K * 2, N * 3) - 0.5)[::2, ::3]
+        c = rng.f32(N) - 0.5
+        bias = rng.f32(N) - 0.5
+        for alpha, beta, use_bias in ((1.0, 0.0, False), (1.0, 1.0, True), (0.5, 2.0, True), (0.25, 0.0, False)):
+            got = ref.gemm_f32(a.reshape(1, K), b, c=c.reshape(1, N) if beta != 0 else None, alpha=alpha, beta=beta,
+                               bias=bias if use_bias else None, bias_kind=ref.BIAS_PER_COL if use_bias else ref.BIAS_NONE)
+            want = _gemv_emulation(a, b, c if beta != 0 else None, alpha, beta, bias if use_bias else None)
+            assert np.array_equal(got.ravel().view(np.uint32), want.view(np.uint32)), (layout, K, N, alpha, beta)
+    # the thread-count assumption is observable: left-over columns of a 250-column block take the scalar kernel
+    a = rng.f32(300) - 0.5
+    b = rng.f32(300 * 1000).reshape(300, 1000) - 0.5
+    base = ref.gemm_f32(a.reshape(1, -1), b)
+    try:
+        ref.set_gemv_threads(4)
+        other = ref.gemm_f32(a.reshape(1, -1), b)
+        assert np.array_equal(other.ravel().view(np.uint32), _gemv_emulation(a, b, None, 1.0, 0.0, None, threads=4).view(np.uint32))
+        assert not np.array_equal(other, base) and np.allclose(other, base, rtol=1e-4, atol=1e-5)
+        ref.set_gemv_enabled(False)  # "prepacked B": the blocked order, one fma chain per 256-deep block
+        blocked = ref.gemm_f32(a.reshape(1, -1), b)
+        two = ref.gemm_f32(np.stack([a, a]), b)
+        assert np.array_equal(blocked.ravel().view(np.uint32), two[0].view(np.uint32))
+    finally:
+        ref.set_gemv_threads(0)
+        ref.set_gemv_enabled(True)
+    assert np.array_equal(ref.gemm_f32(np.stack([a, a]), b)[1].view(np.uint32), blocked.ravel().view(np.uint32))
