@@ -62,7 +62,6 @@ struct FastArgs {
     int HW, Cin;
     float *xs_out;
     uint8_t *xz_out;
-    int debug; // RTEN_HIP_DEBUG ablation bits (timing experiments only; results are wrong): 0x1000 one k-tile, 0x2000 no stores, 0x4000 no statistics atomics
 };
 
 __device__ __forceinline__ int zp_signed(const uint8_t *zp, int idx, int is_signed) {
@@ -358,7 +357,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
     // instructions per k-tile, waterfall loops around the DMA included, for two 32-cycle MFMAs (counters: profiles/r05).
     const int nchunks = p.Kp / 16;
     const int nkt = (p.Kp + KTK - 1) / KTK;
-    const int nit = (p.debug & 0x1000) ? 1 : (nkt + KG - 1) / KG;   // loop trips: KG k-tiles per trip
+    const int nit = (nkt + KG - 1) / KG;   // loop trips: KG k-tiles per trip
     const int tchunks = ((nkt + KG - 1) / KG + NSTAGE) * KG * (KTK / 16); // chunks the walk can name (>= nchunks; the tail is dead)
     int *const btab = reinterpret_cast<int *>(smem + NSTAGE * STAGE);
     {
@@ -426,8 +425,8 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
             uint8_t *Bs = smem + stage * STAGE + kg * SUB + BM * KTK + (wave + 4 * q) * BN * 16;
             const int bo = __builtin_amdgcn_readlane(bo_vec, bo_pos);
             const bool a_live = ch_idx < nchunks, b_live = bo >= 0;
-            const unsigned a_soff = (a_live && !(p.debug & 0x10000)) ? (unsigned)ch_idx * a_step : 0u; // (ablation: every piece = piece 0)
-            const unsigned b_soff = (b_live && !(p.debug & 0x20000)) ? (unsigned)bo : 0u;
+            const unsigned a_soff = a_live ? (unsigned)ch_idx * a_step : 0u;
+            const unsigned b_soff = b_live ? (unsigned)bo : 0u;
 #pragma unroll
             for (int j = 0; j < RA; j++)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(As + j * 1024), 16, (int)(a_live ? a_voff[j] : OOB), (int)a_soff, 0, 0);
@@ -704,7 +703,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const unsigned x = v[r];
-                __builtin_amdgcn_raw_buffer_store_b32(x, rsC, (int)((mok[r] && cok && !(p.debug & 0x2000)) ? basev[j] + half_off : OOB),
+                __builtin_amdgcn_raw_buffer_store_b32(x, rsC, (int)((mok[r] && cok) ? basev[j] + half_off : OOB),
                                                       (int)((unsigned)(mb_u + i * 32 + acc_row(r)) * rs4), 0);
             }
         }
@@ -712,7 +711,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
     if (p.stats) {
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) { st_mn = fminf(st_mn, __shfl_xor(st_mn, o, 64)); st_mx = fmaxf(st_mx, __shfl_xor(st_mx, o, 64)); }
-        if (lane == 0 && !(p.debug & 0x4000)) {
+        if (lane == 0) {
             const unsigned slot = (blockIdx.x * 4u + (unsigned)wq) % (unsigned)dql::kStatSlots;
             atomicMin(&p.stats[slot], dql::f2ord(st_mn));
             atomicMax(&p.stats[dql::kStatSlots + slot], dql::f2ord(st_mx));
@@ -763,7 +762,6 @@ void launch_fast(rten_hip_ctx *ctx, FastArgs &a, const char *name, double ops, d
     static_assert(KTK == 64 || KG == 1, "k-groups walk 64-byte k-tiles");
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.N + BN - 1) / BN;
-    a.debug = ctx->debug;
     ProfScope ps(ctx, name, ops, bytes);
     constexpr size_t ring = (size_t)NST * KG * (BM + BN) * KTK;
     static_assert(ring <= 128 * 1024, "int8 tile ring exceeds the LDS of a compute unit");
