@@ -1,9 +1,8 @@
 #!/bin/bash
+# per-layer table of the int8 ResNet-50 pipeline (staging kernel, conv kernel, and the quantize-on-load form where it applies):
+#   gpurun --timeout 600 -- 'bash tools/gpu/r2_i8layers.sh <tag>'       RTEN_HIP_DEBUG=2048 in the environment turns the k-groups off
 tag=${1:-r2y}
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_round2.py -x -q -k "int8 or integer or Integer or quant" 2>&1 | tail -3
-for dbg in 0 2048; do
-  echo "=== RTEN_HIP_DEBUG=$dbg"
-  RTEN_HIP_DEBUG=$dbg timeout 300 python tools/probe_int8_per_layer.py 2>&1
-done > gpurun_out/${tag}_int8_kg.txt 2>&1
-grep -c . gpurun_out/${tag}_int8_kg.txt
+timeout 300 python tools/probe_int8_per_layer.py > gpurun_out/${tag}_int8_per_layer.txt 2>&1
+echo rc=$?
+cat gpurun_out/${tag}_int8_per_layer.txt
