@@ -66,6 +66,14 @@ impl HipContext {
         self.raw
     }
 
+    /// How one-row matrix products are accumulated (rten_hip.h, `rten_hip_set_gemv_order`).  The reference takes its
+    /// vector-matrix kernels when the LHS has one row and the RHS is not prepacked (rten-gemm/src/lib.rs:876-891); a model
+    /// loaded with `ModelOptions::prepack_weights(true)` passes `prepacked = true` here once, any other model may pass the
+    /// size of its thread pool (`threads`; 0 = at least n / 128), which decides the reference's column blocks.
+    pub fn set_gemv_order(&self, prepacked: bool, threads: u32) -> Result<(), OpError> {
+        self.check(unsafe { sys::rten_hip_set_gemv_order(self.raw, if prepacked { 0 } else { 1 }, threads as i32) })
+    }
+
     /// Status code -> the reference's `OpError` (include/rten_hip.h, "status codes").  A HIP runtime failure is not an
     /// operator error and never turns into a silent CPU fallback.
     pub fn check(&self, status: i32) -> Result<(), OpError> {

@@ -316,6 +316,15 @@ class ResNet50:
         return table
 
 
+def split_batch(batch, chains):
+    """Sub-batch sizes and first-image indices of `chains` chains over a batch: sizes differ by at most one image, larger first."""
+    if not 1 <= chains <= batch:
+        raise ValueError(f"cannot run a batch of {batch} as {chains} chains")
+    sub = batch // chains
+    sizes = [sub + (1 if i < batch - sub * chains else 0) for i in range(chains)]
+    return sizes, [sum(sizes[:i]) for i in range(chains)]
+
+
 class ChainedResNet50:
     """The batch as `chains` independent sub-batch chains, each on its own stream with its own activations, plan and hipGraph;
     the weight arena is shared.
@@ -337,9 +346,7 @@ class ChainedResNet50:
         assert 1 <= chains <= min(batch, self.POOL)
         self.ctx, self.batch, self.chains = ctx, batch, chains
         self.weights = weights if weights is not None else make_weights(num_classes=num_classes)
-        sub = batch // chains
-        self.sizes = [sub + (1 if i < batch - sub * chains else 0) for i in range(chains)]
-        self.starts = [sum(self.sizes[:i]) for i in range(chains)]
+        self.sizes, self.starts = split_batch(batch, chains)
         self.pool = [ctx] + [L.Context(ctx.device) for _ in range(self.POOL - 1)]
         self.place = list(range(chains))  # chain i's graph is launched on pool[place[i]]
         self.x = DeviceTensor(ctx, (batch, 3, image, image), np.float32)

@@ -81,3 +81,17 @@ def test_int8_algorithmic_bytes_formula():
     Net.pool_desc = L.Pool2dDesc(32, 64, 112, 112, 3, 3, 2, 2, (C.c_int32 * 4)(1, 1, 1, 1), 56, 56, 0)
     total = bench.int8_algorithmic_bytes(Net)
     assert 3.5e9 < total < 5.0e9  # about 4.3 GB per 32-image batch
+
+
+def test_split_batch_covers_the_batch_once():
+    sys.path.insert(0, ROOT)
+    import pytest
+    from rten_amd.workloads.resnet50 import split_batch
+    for batch in (1, 5, 32, 33):
+        for chains in range(1, min(batch, 8) + 1):
+            sizes, starts = split_batch(batch, chains)
+            assert sum(sizes) == batch and max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+            assert starts == [sum(sizes[:i]) for i in range(chains)] and starts[0] == 0
+    assert split_batch(32, 4) == ([8, 8, 8, 8], [0, 8, 16, 24]) and split_batch(5, 2) == ([3, 2], [0, 3])
+    with pytest.raises(ValueError):
+        split_batch(3, 4)
