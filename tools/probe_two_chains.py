@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--config", default="f32")
     ap.add_argument("--one-graph", action="store_true", help="capture all chains into ONE hipGraph (fork / join on the first chain's stream)")
+    ap.add_argument("--sizes", default=None, help="explicit sub-batch sizes, e.g. 10,8,8,6 (overrides --chains)")
     ap.add_argument("--stagger", action="store_true", help="put the chains out of phase: chain i first runs the first i/chains of the layers once")
     ap.add_argument("--no-split", action="store_true", help="tune without split-K plans (less total work when chains overlap)")
     args = ap.parse_args()
@@ -32,9 +33,12 @@ def main():
     weights = resnet50.make_weights()
     x = np.random.default_rng(1234).random((args.batch, 3, 224, 224), dtype=np.float32)
     ref_logits = None
-    for chains in [int(c) for c in args.chains.split(",")]:
+    for chains in ([len(args.sizes.split(","))] if args.sizes else [int(c) for c in args.chains.split(",")]):
         sub = args.batch // chains
         sizes = [sub + (1 if i < args.batch - sub * chains else 0) for i in range(chains)]  # uneven split when chains does not divide the batch
+        if args.sizes:
+            sizes = [int(x) for x in args.sizes.split(",")]
+            assert sum(sizes) == args.batch
         starts = [sum(sizes[:i]) for i in range(chains)]
         ctxs = [lib.Context(0) for _ in range(chains)]
         nets = []
