@@ -139,6 +139,14 @@ RTEN_EXPORT int32_t rten_hip_init(int32_t device_id, void *external_stream, rten
         if (ctx->split_counters) hipFree(ctx->split_counters);
         ctx->split_counters = nullptr; // the fixup-kernel path needs none
     }
+    // the memset ran on the null stream and the context's stream does not synchronise with it (hipStreamNonBlocking): the counters
+    // must be zero before the first producer can arrive on them
+    if (hipDeviceSynchronize() != hipSuccess) {
+        if (ctx->split_counters) hipFree(ctx->split_counters);
+        if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return RTEN_HIP_ERR_HIP;
+    }
     *out_ctx = ctx;
     return RTEN_HIP_OK;
 }
