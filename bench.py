@@ -260,6 +260,7 @@ def main():
                          "(configs[2]; with --gpus 8 = configs[4], 8 x 32 images, weights RCCL-broadcast)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-autotune", action="store_true")
+    ap.add_argument("--no-qout", action="store_true", help="int8: do not quantize single-consumer conv outputs in the producing launch (rten_hip_conv2d_int8_qout)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layer-table", action="store_true", help="print the per-layer autotune table to stderr")
     ap.add_argument("--save-plan", default=None, help="write the autotuned per-layer plans (variant, split mode, groups) as JSON")
@@ -394,6 +395,8 @@ def main():
                 print(f"[layer] {l['name']:8s} O={d.o:4d} C={d.c:4d} k={d.kh} s={d.stride_h} {d.h:3d}->{d.out_h:3d} us: {nosplit}"
                       + " | split " + " ".join(f"v{p[0]}m{p[1]}g{p[2]}o{p[3]}={ms*1e3:6.1f}" for ms, p in split)
                       + f"  best={net.variants[l['name']]} {fl / (best_ms * 1e-3) / 1e12:6.1f} TF/s", file=sys.stderr)
+    if int8:
+        net.fused_qout = not args.no_qout
     placement = None
     if not args.no_graph:
         net.capture()

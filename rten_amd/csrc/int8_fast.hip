@@ -31,6 +31,7 @@
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -62,6 +63,16 @@ struct FastArgs {
     int HW, Cin;
     float *xs_out;
     uint8_t *xz_out;
+    // QO kernels (the DynamicQuantizeLinear that CONSUMES this convolution's output runs in its epilogue, behind a grid-wide min / max):
+    // the barrier block, the consumer's staged image and its geometry, the quantizer's own outputs
+    unsigned *sync;
+    uint8_t *q_out;
+    float *q_scale_out;
+    uint8_t *q_zp_out;
+    const float *q_mul_by;
+    float *q_product;
+    int q_cb, q_Hp, q_Wp, q_pt, q_pl, q_H, q_W, q_pad_mode;
+    unsigned q_bytes;
 };
 
 __device__ __forceinline__ int zp_signed(const uint8_t *zp, int idx, int is_signed) {
@@ -298,9 +309,19 @@ extern __shared__ __attribute__((aligned(16))) uint8_t i8_smem[];
 // reads 16 channels of one pixel (lanes = consecutive pixels: 256-byte runs), converts with dql::quant_u8 and writes the
 // 16-byte chunk piece the DMA would have delivered (conflict-free ds_write_b128).  The staging launch, its 1 B/element write
 // and the staged image's read disappear; A still arrives by LDS-DMA.  Same codes, same sums: bit-identical.
-template <int BM, int BN, int NSTAGE, bool RES, int KTK = 64, int KG = 1, bool BQ = false>
+// QO = the output is QUANTIZED IN THE EPILOGUE for the one convolution that consumes it (DynamicQuantizeLinear -> ConvInteger of the
+// next layer, src/ops/quantize.rs:352-436): the finished f32 values stay in the accumulator registers, every workgroup publishes its
+// min / max (the ordered-uint slots of the producer-statistics scheme) and arrives on a grid-wide counter barrier; behind it each
+// workgroup folds the slots -- min / max are order free, so these are the statistics of the two-sweep operator -- derives the same
+// scale / zero point, converts with the same dql::quant_u8 and writes the codes straight into the consumer's staged image
+// (channel-blocked, padded; border pieces included).  The f32 tensor is written only if somebody else needs it (p.C != NULL).
+// Every workgroup of the grid must be resident at once (the host checks the occupancy before it launches this form).
+constexpr unsigned kSyncWords = 256;      // barrier block: arrival counters at words 0, 16, ..., 112; departures at 128; time-out flag at 144
+constexpr unsigned kSyncSpinLimit = 1u << 18;
+template <int BM, int BN, int NSTAGE, bool RES, int KTK = 64, int KG = 1, bool BQ = false, bool QO = false>
 __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kernel(const FastArgs p) {
     static_assert(!BQ || (KG == 1 && KTK == 64), "quantize-on-load: one k-group, 64-byte k-tiles");
+    static_assert(!(BQ && QO), "quantize-on-load and quantized output are separate instantiations");
     constexpr int WM = 2, WN = 2;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int RA = BM / 64, RB = BN / 64;      // DMA instructions per chunk (64 rows each)
@@ -649,12 +670,14 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
 #pragma unroll
         for (int j = 0; j < TN; j++) csv[j] = (unsigned)(cs[j] + __shfl_xor(cs[j], 32, 64)); // the two k halves of the column
     }
-    if (KG > 1 && kg != 0) return; // the epilogue belongs to k-group 0 (no barrier follows)
+    const bool epi = KG == 1 || kg == 0; // the epilogue belongs to k-group 0
+    if (!QO && !epi) return;             // (no barrier follows)
 
     // ---- epilogue: zero-point algebra, optional cast_scale / bias / residual / relu, store.  16 accumulator
     // registers (one 32 x 32 block) are finished at a time; all of a block's stores are issued back to back.
     float st_mn = __builtin_inff(), st_mx = -__builtin_inff(); // output statistics for the consuming DynamicQuantizeLinear
     const int ml0 = wm0 + 4 * half;
+    if (epi) {
 #pragma unroll
     for (int i = 0; i < TM; i++) {
         unsigned rsv[16], azv[16];
@@ -700,13 +723,132 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
 #pragma unroll
                 for (int r = 0; r < 16; r++) v[r] = __builtin_bit_cast(unsigned, f[r]);
             }
+            if constexpr (QO) { // the finished values wait in the accumulator registers for the grid-wide statistics
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const unsigned x = v[r];
-                __builtin_amdgcn_raw_buffer_store_b32(x, rsC, (int)((mok[r] && cok) ? basev[j] + half_off : OOB),
-                                                      (int)((unsigned)(mb_u + i * 32 + acc_row(r)) * rs4), 0);
+                for (int r = 0; r < 16; r++) acc[i][j][r] = (int)v[r];
+            }
+            if (!QO || p.C) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const unsigned x = v[r];
+                    __builtin_amdgcn_raw_buffer_store_b32(x, rsC, (int)((mok[r] && cok) ? basev[j] + half_off : OOB),
+                                                          (int)((unsigned)(mb_u + i * 32 + acc_row(r)) * rs4), 0);
+                }
             }
         }
+    }
+    } // epi
+    if constexpr (QO) {
+        // ---- (1) publish this workgroup's min / max, arrive, wait for the whole grid
+        if (epi) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) { st_mn = fminf(st_mn, __shfl_xor(st_mn, o, 64)); st_mx = fmaxf(st_mx, __shfl_xor(st_mx, o, 64)); }
+            if (lane == 0) { // returning forms: their completion is what the wait below covers
+                const unsigned slot = (blockIdx.x * 4u + (unsigned)wq) % (unsigned)dql::kStatSlots;
+                const unsigned o1 = __hip_atomic_fetch_min(&p.stats[slot], dql::f2ord(st_mn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned o2 = __hip_atomic_fetch_max(&p.stats[dql::kStatSlots + slot], dql::f2ord(st_mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("" ::"v"(o1), "v"(o2));
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every wave: its statistics are in place before the workgroup arrives
+        __syncthreads();
+        const unsigned G = gridDim.x;
+        if (t == 0) __hip_atomic_fetch_add(p.sync + (blockIdx.x & 7u) * 16u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wave_all == 0) { // one wave polls: lanes 0..7 read the eight arrival counters (relaxed agent-scope loads), bounded
+            unsigned spins = 0;
+            for (;;) {
+                unsigned v = lane < 8 ? __hip_atomic_load(p.sync + lane * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+                if ((unsigned)__builtin_amdgcn_readfirstlane((int)v) >= G) break;
+                if (++spins >= kSyncSpinLimit) { // not every workgroup is resident (or a previous launch timed out): give up, loudly
+                    if (lane == 0) __hip_atomic_store(p.sync + 144, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        __syncthreads();
+        if (t == 0) { // the last workgroup through the barrier leaves the block zeroed for the next launch
+            const unsigned old = __hip_atomic_fetch_add(p.sync + 128, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == G - 1u) {
+#pragma unroll
+                for (int c = 0; c < 8; c++) __hip_atomic_store(p.sync + c * 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.sync + 128, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        // ---- (2) the statistics of the whole tensor -> DynamicQuantizeLinear's parameters (quantize.rs:397-419)
+        float ga = __builtin_inff(), gb = -__builtin_inff();
+        if (t < dql::kStatSlots) {
+            ga = dql::ord2f(__hip_atomic_load(p.stats + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            gb = dql::ord2f(__hip_atomic_load(p.stats + dql::kStatSlots + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { ga = fminf(ga, __shfl_xor(ga, o, 64)); gb = fmaxf(gb, __shfl_xor(gb, o, 64)); }
+        float *const gred = reinterpret_cast<float *>(smem + 8192); // (the row constants at the start of the stage buffers are dead by now)
+        if (lane == 0 && wave_all < 4) { gred[wave_all] = ga; gred[4 + wave_all] = gb; }
+        __syncthreads();
+        if (!epi) return;
+        const float g_mn = fminf(fminf(gred[0], gred[1]), fminf(gred[2], gred[3])), g_mx = fmaxf(fmaxf(gred[4], gred[5]), fmaxf(gred[6], gred[7]));
+        const dql::QParams q = dql::dql_params(g_mn, g_mx);
+        if (t == 0 && blockIdx.x == 0) {
+            *p.q_scale_out = q.scale;
+            *p.q_zp_out = (uint8_t)q.zp;
+            if (p.q_mul_by) *p.q_product = q.scale * p.q_mul_by[0]; // the Mul(x_scale, w_scale) node of the consumer
+        }
+        // ---- (3) codes -> the consumer's staged image [N][C/16][Hp][Wp][16 B] (signed domain).  A lane holds, per 32-row block, four
+        // dwords of four consecutive channels each: rows 0-3, 8-11, 16-19, 24-27 (+4 in the upper half of the wave); two
+        // v_permlane32_swap give the lower half the sixteen channels 0-15 of its pixel and the upper half channels 16-31.
+        const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void *)p.q_out, 0, (int)p.q_bytes, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int n = n0 + wn0 + j * 32 + l31;
+            const bool cok = n < p.N;
+            const int nn = cok ? n : 0;
+            const int nb = nn / p.Pn, np = nn - nb * p.Pn;
+            const int oy = np / p.q_W, ox = np - oy * p.q_W;
+            const unsigned pix = (unsigned)((oy + p.q_pt) * p.q_Wp + ox + p.q_pl);
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                unsigned d[4];
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    d[g] = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; b++)
+                        d[g] |= ((dql::quant_u8(__builtin_bit_cast(float, acc[i][j][4 * g + b]), q.inv_scale, q.zp) ^ 0x80u) & 0xffu) << (8 * b);
+                }
+                const auto s02 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false); // {lower: own d0 | upper: partner's d2}, {partner's d0 | own d2}
+                const auto s13 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
+                const unsigned w0 = s02[0], w1 = s02[1], w2 = s13[0], w3 = s13[1];
+                const int chunk = (m0 + wm0 + i * 32) / 16 + half;
+                const unsigned off = (chunk * 16 < p.M && cok) ? ((unsigned)((nb * p.q_cb + chunk) * (p.q_Hp * p.q_Wp)) + pix) * 16u : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{w0, w1, w2, w3}, rsQ, (int)off, 0, 0);
+            }
+        }
+        // border pieces of the consumer's padding (value of its pad mode), dealt over the whole grid
+        const int nbp = p.q_Hp * p.q_Wp - p.q_H * p.q_W;
+        if (nbp > 0) {
+            int pad_s = 0;
+            if (p.q_pad_mode == RTEN_HIP_PAD_ZERO_POINT) pad_s = q.zp - 128;
+            else if (p.q_pad_mode == RTEN_HIP_PAD_RAW0_U8) pad_s = -128;
+            const unsigned fb = ((unsigned)pad_s & 0xffu) * 0x01010101u;
+            const int planes = (p.N / p.Pn) * p.q_cb, total = planes * nbp;
+            const int top = p.q_pt * p.q_Wp, side = p.q_Wp - p.q_W;
+            for (int idx = (int)blockIdx.x * 256 + t; idx < total; idx += (int)G * 256) {
+                const int plane = idx / nbp, b = idx - plane * nbp;
+                int pos;
+                if (b < top) pos = b;
+                else {
+                    const int b1 = b - top;
+                    if (side > 0 && b1 < p.q_H * side) {
+                        const int row = b1 / side, wi = b1 - row * side;
+                        pos = (p.q_pt + row) * p.q_Wp + (wi < p.q_pl ? wi : p.q_W + wi);
+                    } else pos = (p.q_pt + p.q_H) * p.q_Wp + (b1 - p.q_H * side);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{fb, fb, fb, fb}, rsQ, (int)(((unsigned)(plane * (p.q_Hp * p.q_Wp)) + (unsigned)pos) * 16u), 0, 0);
+            }
+        }
+        return;
     }
     if (p.stats) {
 #pragma unroll
@@ -757,22 +899,44 @@ __global__ __launch_bounds__(256) void i8_pack_rows_t_kernel(const uint8_t *__re
 
 inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-template <int BM, int BN, int NST, int KTK = 64, int KG = 1, bool BQ = false>
-void launch_fast(rten_hip_ctx *ctx, FastArgs &a, const char *name, double ops, double bytes) {
+// Workgroups of `kern` (threads, dynamic LDS) the whole device holds at once (the occupancy query is cached per kernel and LDS size).
+int resident_capacity(rten_hip_ctx *ctx, const void *kern, int threads, size_t lds) {
+    static std::mutex mu;
+    static std::map<std::pair<const void *, size_t>, int> cache;
+    std::lock_guard<std::mutex> g(mu);
+    const auto key = std::make_pair(kern, lds);
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, lds) != hipSuccess) nb = 0;
+        it = cache.emplace(key, nb < 8 ? nb : 8).first;
+    }
+    return it->second * ctx->num_cus;
+}
+
+// Returns false (nothing launched) when QO is requested and the grid cannot be resident all at once.
+template <int BM, int BN, int NST, int KTK = 64, int KG = 1, bool BQ = false, bool QO = false>
+bool launch_fast(rten_hip_ctx *ctx, FastArgs &a, const char *name, double ops, double bytes) {
     static_assert(KTK == 64 || KG == 1, "k-groups walk 64-byte k-tiles");
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.N + BN - 1) / BN;
-    ProfScope ps(ctx, name, ops, bytes);
     constexpr size_t ring = (size_t)NST * KG * (BM + BN) * KTK;
     static_assert(ring <= 128 * 1024, "int8 tile ring exceeds the LDS of a compute unit");
     const int nkt = (a.Kp + KTK - 1) / KTK;
     const size_t lds = ring + (size_t)((nkt + KG - 1) / KG + NST) * KG * (KTK / 16) * 4; // + the chunk -> B offset table
+    bool launched = true;
     auto go = [&](auto kern) {
         if (lds > 64 * 1024) hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (QO && (long long)a.tiles_m * a.tiles_n > resident_capacity(ctx, (const void *)kern, 256 * KG, lds)) {
+            launched = false;
+            return;
+        }
+        ProfScope ps(ctx, name, ops, bytes);
         hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256 * KG), lds, ctx->stream, a);
     };
-    if (a.res && a.scale) go(igemm_i8_fast_kernel<BM, BN, NST, true, KTK, KG, BQ>);
-    else go(igemm_i8_fast_kernel<BM, BN, NST, false, KTK, KG, BQ>);
+    if (a.res && a.scale) go(igemm_i8_fast_kernel<BM, BN, NST, true, KTK, KG, BQ, QO>);
+    else go(igemm_i8_fast_kernel<BM, BN, NST, false, KTK, KG, BQ, QO>);
+    return launched;
 }
 
 int32_t dispatch_fast(rten_hip_ctx *ctx, FastArgs &a, double ops, double bytes) {
@@ -785,6 +949,23 @@ int32_t dispatch_fast(rten_hip_ctx *ctx, FastArgs &a, double ops, double bytes) 
     // one is fetched into as few of the eight L2s as possible
     a.n_fastest = (double)a.a_bytes > (double)a.b_bytes ? 1 : 0;
     // (256-byte k-tiles were measured and are slower: profiles/r05/int8_notes.md)
+    if (a.q_out) { // quantized-output form (rten_hip_conv2d_int8_qout): the same tile choice, or the next larger one that fits the chip at once
+        const long long t64 = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64);
+        const int nkt = (a.Kp + 63) / 64;
+        const bool kg4 = !(ctx->debug & 0x800) && t64 * 4 <= 5 * ctx->num_cus && nkt >= 16;
+        bool ok = false;
+        if (tile == 0) ok = launch_fast<128, 128, 3, 64, 1, false, true>(ctx, a, "igemm_i8_fast_kernel<128,128,qo>", ops, bytes);
+        else if (tile == 1) ok = launch_fast<128, 64, 3, 64, 1, false, true>(ctx, a, "igemm_i8_fast_kernel<128,64,qo>", ops, bytes) ||
+                                 launch_fast<128, 128, 3, 64, 1, false, true>(ctx, a, "igemm_i8_fast_kernel<128,128,qo>", ops, bytes);
+        else if (tile == 2) ok = launch_fast<64, 128, 3, 64, 1, false, true>(ctx, a, "igemm_i8_fast_kernel<64,128,qo>", ops, bytes) ||
+                                 launch_fast<64, 256, 3, 64, 1, false, true>(ctx, a, "igemm_i8_fast_kernel<64,256,qo>", ops, bytes);
+        else if (kg4) ok = launch_fast<64, 64, 3, 64, 4, false, true>(ctx, a, "igemm_i8_fast_kernel<64,64,kg4,qo>", ops, bytes);
+        else ok = launch_fast<64, 64, 3, 64, 1, false, true>(ctx, a, "igemm_i8_fast_kernel<64,64,qo>", ops, bytes) ||
+                  launch_fast<128, 64, 3, 64, 1, false, true>(ctx, a, "igemm_i8_fast_kernel<128,64,qo>", ops, bytes);
+        if (!ok) return RTEN_HIP_ERR_UNSUPPORTED; // more workgroups than the device holds at once: run the two-launch sequence
+        RTEN_LAUNCH_CHECK(ctx, "igemm_i8_fast_kernel launch");
+        return RTEN_HIP_OK;
+    }
     if (a.xf) { // quantize-on-load form (rten_hip_conv2d_int8_dql)
         if (tile == 0) launch_fast<128, 128, 3, 64, 1, true>(ctx, a, "igemm_i8_fast_kernel<128,128,bq>", ops, bytes);
         else if (tile == 1) launch_fast<128, 64, 3, 64, 1, true>(ctx, a, "igemm_i8_fast_kernel<128,64,bq>", ops, bytes);
@@ -991,8 +1172,27 @@ RTEN_EXPORT int32_t rten_hip_dynamic_quantize_linear_staged_stats(rten_hip_ctx *
     return RTEN_HIP_OK;
 }
 
+namespace {
+struct QOutArgs { // the consumer side of rten_hip_conv2d_int8_qout
+    const rten_hip_conv2d_int8_desc *next;
+    void *sync, *staged;
+    float *scale;
+    uint8_t *zp;
+    const float *mul_by;
+    float *product;
+};
+int32_t i8_fast_conv_impl(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di, const void *x, const void *w, const void *x_zp, const void *w_zp,
+                          const float *scale, const float *bias, const float *residual, uint32_t flags, void *y, void *stats, const QOutArgs *qo);
+} // namespace
+
 int32_t rten_i8_fast_conv(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di, const void *x, const void *w, const void *x_zp,
                           const void *w_zp, const float *scale, const float *bias, const float *residual, uint32_t flags, void *y, void *stats) {
+    return i8_fast_conv_impl(ctx, di, x, w, x_zp, w_zp, scale, bias, residual, flags, y, stats, nullptr);
+}
+
+namespace {
+int32_t i8_fast_conv_impl(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di, const void *x, const void *w, const void *x_zp, const void *w_zp,
+                          const float *scale, const float *bias, const float *residual, uint32_t flags, void *y, void *stats, const QOutArgs *qo) {
     const rten_hip_conv2d_desc *d = &di->conv;
     const ConvGeom cg = conv_geom(di);
     if (!cg.ok)
@@ -1045,9 +1245,61 @@ int32_t rten_i8_fast_conv(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di
     g.need_csum = (di->w_zp_len != 0 || !di->w_signed) ? 1 : 0; // weight zero point may be non-zero in the signed domain
     g.conv = 1; g.OW = d->out_w; g.sy = d->stride_h; g.sx = d->stride_w; g.Hp = cg.Hp; g.Wp = cg.Wp; g.Cp = cg.Cp;
     g.KH = d->kh; g.KW = d->kw; g.dy = d->dil_h; g.dx = d->dil_w;
-    // algorithmic bytes: i8 weights + u8 activations (once) + f32 output (+ f32 residual when the epilogue adds one)
+    double out_bytes = 4.0 * d->o * g.N;
+    if (qo) {
+        const ConvGeom ng = conv_geom(qo->next);
+        g.sync = (unsigned *)qo->sync;
+        g.q_out = (uint8_t *)qo->staged;
+        g.q_scale_out = qo->scale; g.q_zp_out = qo->zp; g.q_mul_by = qo->mul_by; g.q_product = qo->product;
+        g.q_cb = ng.Cp / 16; g.q_Hp = ng.Hp; g.q_Wp = ng.Wp; g.q_pt = qo->next->conv.pads[0]; g.q_pl = qo->next->conv.pads[1];
+        g.q_H = d->out_h; g.q_W = d->out_w; g.q_pad_mode = rten_effective_pad_mode(qo->next);
+        g.q_bytes = (unsigned)ng.img;
+        out_bytes = (y ? out_bytes : 0.0) + (double)ng.img;
+    }
+    // algorithmic bytes: i8 weights + u8 activations (once) + f32 output (+ f32 residual when the epilogue adds one); quantized-output form:
+    // the consumer's staged u8 image instead of (or, when y is wanted too, besides) the f32 output
     return dispatch_fast(ctx, g, 2.0 * d->o * (double)g.N * cg.Kreal,
-                         (double)d->o * cg.Kreal + (double)d->n * d->c * d->h * d->w + 4.0 * d->o * g.N + (g.res ? 4.0 * d->o * g.N : 0.0));
+                         (double)d->o * cg.Kreal + (double)d->n * d->c * d->h * d->w + out_bytes + (g.res ? 4.0 * d->o * g.N : 0.0));
+}
+} // namespace
+
+// ConvIntegerToFloat [+ bias] [+ residual] [+ Relu] AND the DynamicQuantizeLinear of the one convolution that consumes its output, in ONE
+// launch (igemm_i8_fast_kernel, QO): see rten_hip.h.  RTEN_HIP_ERR_UNSUPPORTED when the geometry is not covered or the launch's
+// workgroups cannot all be resident at once -- run rten_hip_conv2d_int8_stats + rten_hip_dynamic_quantize_linear_staged_stats then.
+RTEN_EXPORT size_t rten_hip_grid_sync_bytes(void) { return kSyncWords * sizeof(unsigned); }
+
+RTEN_EXPORT int32_t rten_hip_conv2d_int8_qout(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di, const void *x, const void *w, const void *x_zp,
+                                              const void *w_zp, const float *scale, const float *bias, const float *residual, uint32_t flags, float *y,
+                                              void *stats, void *sync, const rten_hip_conv2d_int8_desc *next, void *next_staged, float *next_scale,
+                                              uint8_t *next_zero_point, const float *mul_by, float *product) {
+    RTEN_CHECK_CTX(ctx);
+    if (!di || !x || !w || !scale || !stats || !sync || !next || !next_staged || !next_scale || !next_zero_point || (mul_by && !product))
+        return RTEN_HIP_ERR_INVALID_VALUE;
+    const rten_hip_conv2d_desc *d = &di->conv, *nd = &next->conv;
+    if (di->scale_len != 0 && di->scale_len != 1 && di->scale_len != d->o)
+        return rten_set_error(ctx, RTEN_HIP_ERR_INCOMPATIBLE_SHAPES, "conv_int8: scale must be a scalar or have one value per output channel");
+    if (di->w_zp_len != 0 && di->w_zp_len != 1 && di->w_zp_len != d->o) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "Zero point has incorrect size");
+    if (nd->n != d->n || nd->c != d->o || nd->h != d->out_h || nd->w != d->out_w)
+        return rten_set_error(ctx, RTEN_HIP_ERR_INCOMPATIBLE_SHAPES, "conv2d_int8_qout: the consumer's input is not this convolution's output");
+    const ConvGeom cg = conv_geom(di), ng = conv_geom(next);
+    if (!cg.ok || !ng.ok || next->x_signed || !di->weights_packed || !di->x_staged || d->o % 16 != 0)
+        return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "conv2d_int8_qout: staged operands, O % 16 == 0 and a consumer covered by the staged kernel only");
+    if (d->n == 0 || d->out_h == 0 || d->out_w == 0) return RTEN_HIP_OK;
+    const QOutArgs qo = {next, sync, next_staged, next_scale, next_zero_point, mul_by, product};
+    return i8_fast_conv_impl(ctx, di, x, w, x_zp, w_zp, scale, bias, residual, flags, y, stats, &qo);
+}
+
+// Time-out flags of `count` consecutive barrier blocks (non-zero: a quantized-output launch gave up waiting for its grid and its results are void).
+RTEN_EXPORT int32_t rten_hip_grid_sync_timeouts(rten_hip_ctx *ctx, const void *sync, int32_t count, int32_t *timeouts) {
+    RTEN_CHECK_CTX(ctx);
+    if (!sync || count < 1 || !timeouts) return RTEN_HIP_ERR_INVALID_VALUE;
+    std::vector<unsigned> host((size_t)count * kSyncWords);
+    RTEN_HIP_TRY(ctx, hipMemcpyAsync(host.data(), sync, host.size() * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    RTEN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    int n = 0;
+    for (int i = 0; i < count; i++) n += host[(size_t)i * kSyncWords + 144] != 0;
+    *timeouts = n;
+    return RTEN_HIP_OK;
 }
 
 

@@ -33,6 +33,21 @@ class ResNet50Int8(ResNet50):
         self.producer_stats = True   # conv epilogues accumulate the min/max the next DynamicQuantizeLinear needs
         self.fused_dql = False       # pointwise stride-1 convs quantize their input in the GEMM's loader (rten_hip_conv2d_int8_dql) ...
         self.fused_layers = None     # ... all that qualify (None) or the set autotune() measured to be faster that way
+        # Quantized-output launches (rten_hip_conv2d_int8_qout): a conv whose output is read by exactly ONE other conv (and by nothing
+        # else: not a residual, not the network output) quantizes it for that consumer in its own epilogue, behind a grid-wide min / max;
+        # the f32 tensor is never written.  In a bottleneck block these are the c1 -> c2 and c2 -> c3 edges (32 of the 53 layers).
+        self.fused_qout = False
+        readers = {}
+        for m in self.specs:
+            readers.setdefault(m["src"], []).append(m)
+        residuals = {m["res"] for m in self.specs if m["res"]}
+        self.qout_next = {m["name"]: readers[m["dst"]][0] for m in self.specs
+                          if len(readers.get(m["dst"], [])) == 1 and m["dst"] not in residuals and m["dst"] != "stem"}
+        self._qout_off = set()       # layers whose launch cannot be resident at once on this device (found at the first attempt)
+        gb = ctx.lib.rten_hip_grid_sync_bytes()
+        self.sync_arena = DeviceTensor(ctx, (gb * len(self.specs),), np.uint8)  # zeroed once; every launch leaves its block zero
+        ctx.call("rten_hip_memset", self.sync_arena.vp, 0, C.c_size_t(gb * len(self.specs)))
+        self.syncs = {l["name"]: C.c_void_p(self.sync_arena.ptr + i * gb) for i, l in enumerate(self.specs)}
         sb = ctx.lib.rten_hip_minmax_stats_bytes()
         self.stats_arena = DeviceTensor(ctx, (sb * len(self.specs),), np.uint8)  # one statistics block per conv output
         self.stats = {l["dst"]: C.c_void_p(self.stats_arena.ptr + i * sb) for i, l in enumerate(self.specs)}
@@ -54,6 +69,7 @@ class ResNet50Int8(ResNet50):
         self.qsets = [(self.staged, self.xs, self.xz),
                       (DeviceTensor(ctx, (max(staged_max, 256),), np.uint8), DeviceTensor(ctx, (1,), np.float32), DeviceTensor(ctx, (1,), np.uint8))]
         self.sc_side = DeviceTensor(ctx, (1,), np.float32)
+        self.scs = [self.sc, DeviceTensor(ctx, (1,), np.float32)]  # Mul(x_scale, w_scale) per quantized-input set (quantized-output launches)
         self._cur, self._side_reads = 0, None
         self.fc_tmp = DeviceTensor(ctx, (batch, self.num_classes), np.float32)
         # classifier RHS [K = 2048, N = 1000] staged once (rten_hip_gemm_int8_prepack: PackedBMatrix, Graph::prepack_weights)
@@ -106,7 +122,59 @@ class ResNet50Int8(ResNet50):
         ctx = self.ctx
         ctx.call("rten_hip_dynamic_quantize_linear", n, src.vp, self.xq.vp, self.xs.vp, self.xz.vp)
 
+    def _conv_q(self, l):
+        """One conv layer with quantized-output launches enabled (single stream).  The two (codes, x_scale, x_zero_point, scale
+        product) sets alternate: a launch reads its quantized input from one set and, when its output has a single consumer, writes
+        that consumer's quantized input into the other."""
+        ctx, name = self.ctx, l["name"]
+        d, cv = self.idesc[name], self.idesc[name].conv
+        geom = (l["src"], cv.c, cv.h, cv.w, tuple(cv.pads))
+        if self._prestaged == name:      # the producing conv quantized this input in its epilogue, scale product included
+            pass
+        elif self._staged_key == geom:   # same tensor, same staged layout as the previous conv: only the Mul(x_scale, w_scale) differs
+            ctx.call("rten_hip_mul_f32", 1, self.qsets[self._cur][1].vp, self.ws[name].vp, 1, self.scs[self._cur].vp)
+        else:
+            self._cur = 1 - self._cur
+            staged, xs, xz = self.qsets[self._cur]
+            st = self.stats.get(l["src"]) if self.producer_stats else None
+            if st is not None:
+                ctx.call("rten_hip_dynamic_quantize_linear_staged_stats", C.byref(d), self._act(l["src"]).vp, st, staged.vp, xs.vp, xz.vp, self.ws[name].vp,
+                         self.scs[self._cur].vp)
+            else:
+                ctx.call("rten_hip_dynamic_quantize_linear_staged", C.byref(d), self._act(l["src"]).vp, staged.vp, xs.vp, xz.vp, self.ws[name].vp,
+                         self.scs[self._cur].vp)
+        self._staged_key, self._prestaged = geom, None
+        (staged, xs, xz), sc = self.qsets[self._cur], self.scs[self._cur]
+        flags = (L.CONV_RELU if l["relu"] else 0) | (L.CONV_RESIDUAL if l["res"] else 0)
+        res = self._act(l["res"]).vp if l["res"] else None
+        nxt = self.qout_next.get(name)
+        if nxt is not None and name not in self._qout_off:
+            other = 1 - self._cur
+            (ostaged, oxs, oxz), osc = self.qsets[other], self.scs[other]
+            rc = ctx.lib.rten_hip_conv2d_int8_qout(ctx.h, C.byref(d), staged.vp, self.wq[name].vp, xz.vp, None, sc.vp, self.bq[name].vp, res, flags, None,
+                                                   self.stats[l["dst"]], self.syncs[name], C.byref(self.idesc[nxt["name"]]), ostaged.vp, oxs.vp, oxz.vp,
+                                                   self.ws[nxt["name"]].vp, osc.vp)
+            if rc == L.OK:
+                self._cur, self._prestaged = other, nxt["name"]
+                return
+            if rc != L.ERR_UNSUPPORTED:
+                ctx.check(rc)
+            self._qout_off.add(name)  # more workgroups than the device holds at once: the two-launch sequence, from now on
+        args = (C.byref(d), staged.vp, self.wq[name].vp, xz.vp, None, sc.vp, self.bq[name].vp, res, flags, self._act(l["dst"]).vp)
+        if self.producer_stats:
+            ctx.call("rten_hip_conv2d_int8_stats", *args, self.stats[l["dst"]])
+        else:
+            ctx.call("rten_hip_conv2d_int8", *args)
+
+    def qout_timeouts(self):
+        """Number of quantized-output launches that gave up waiting for their grid (0 unless the residency assumption broke)."""
+        n = C.c_int32(0)
+        self.ctx.call("rten_hip_grid_sync_timeouts", self.sync_arena.vp, len(self.specs), C.byref(n))
+        return n.value
+
     def _conv(self, l, ctx=None):
+        if self.fused_qout and not self.concurrent:
+            return self._conv_q(l)
         ctx = self.ctx
         name = l["name"]
         src = self._act(l["src"])
@@ -168,7 +236,7 @@ class ResNet50Int8(ResNet50):
     def forward(self):
         ctx = self.ctx
         self._staged_key = None
-        self._cur, self._side_reads, self._pending = 0, None, set()
+        self._cur, self._side_reads, self._pending, self._prestaged = 0, None, set(), None
         if self.concurrent and self.side is None:
             self.side = L.Context(ctx.device)
         if self.producer_stats:

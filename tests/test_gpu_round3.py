@@ -1,0 +1,166 @@
+"""Round-3 parity tests (all through the C ABI, on the GPU).
+
+  * rten_hip_conv2d_int8_qout: ConvIntegerToFloat with the DynamicQuantizeLinear of its single consumer in the epilogue (one launch,
+    grid-wide min / max behind an arrival barrier) against the two operators run separately -- staged codes byte for byte (border
+    pieces included), scale, zero point, scale product, optional f32 output -- and int8 ResNet-50 at batch 32 with those launches on.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import ref
+from rten_amd import lib as L
+from rten_amd.tensor import DeviceTensor
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(ctx, a):
+    return DeviceTensor.from_numpy(ctx, a)
+
+
+def bits_equal(a, b):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if a.dtype == np.float32:
+        same = (a == b) | (np.isnan(a) & np.isnan(b))
+        if not same.all():
+            idx = tuple(np.argwhere(~same)[0])
+            raise AssertionError(f"{(~same).sum()} of {a.size} elements differ; first at {idx}: {a[idx]!r} vs {b[idx]!r}")
+    else:
+        assert np.array_equal(a, b), f"{(a != b).sum()} of {a.size} elements differ"
+
+
+def _conv_desc(n, c, h, w, o, k, stride, pad, pad_mode=L.PAD_RAW0_I8, packed=1, staged=1, scale_len=1):
+    oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    return L.Conv2dInt8Desc(L.Conv2dDesc(n, c, h, w, o, k, k, (C.c_int32 * 4)(pad, pad, pad, pad), stride, stride, 1, 1, 1, oh, ow), 0, 1, 0, pad_mode,
+                            packed, staged, scale_len), oh, ow
+
+
+QOUT_CASES = [
+    # n, c, h, w | producer o, k, stride, pad | consumer o2, k2, stride2, pad2 | consumer pad mode, per-channel scale, residual + f32 output
+    (4, 64, 56, 56, 64, 1, 1, 0, 64, 3, 1, 1, L.PAD_RAW0_I8, False, False),      # c1 -> c2 of stage 0
+    (3, 64, 28, 28, 64, 3, 1, 1, 256, 1, 1, 0, L.PAD_RAW0_I8, False, False),     # c2 -> c3
+    (32, 256, 14, 14, 128, 1, 1, 0, 128, 3, 2, 1, L.PAD_ZERO_POINT, False, False),  # stride-2 consumer, dynamic border value
+    (8, 128, 28, 28, 128, 3, 2, 1, 512, 1, 1, 0, L.PAD_RAW0_I8, False, True),    # stride-2 producer, residual, f32 output kept as well
+    (32, 2048, 7, 7, 512, 1, 1, 0, 512, 3, 1, 1, L.PAD_RAW0_U8, False, False),   # under-filled launch: four k-groups per workgroup
+    (1, 48, 9, 5, 80, 3, 1, 1, 32, 3, 1, 1, L.PAD_ZERO_POINT, True, True),       # ragged everything, per-channel scale
+    (32, 64, 56, 56, 64, 3, 1, 1, 256, 1, 1, 0, L.PAD_RAW0_I8, False, False),    # BASELINE size: 784 tiles of 64 x 128, all resident
+    (2, 16, 6, 6, 16, 1, 1, 0, 16, 1, 1, 0, L.PAD_RAW0_I8, False, False),        # one workgroup
+]
+
+
+@pytest.mark.parametrize("case", QOUT_CASES, ids=[f"case{i}" for i in range(len(QOUT_CASES))])
+def test_conv2d_int8_qout_matches_the_separate_operators(ctx, case):
+    n, c, h, w, o, k, stride, pad, o2, k2, stride2, pad2, pad_mode2, per_ch, with_res = case
+    rng = ref.XorShiftRng(4321 + n * 7 + c)
+    lib = ctx.lib
+    sb, gb = lib.rten_hip_minmax_stats_bytes(), lib.rten_hip_grid_sync_bytes()
+    d, oh, ow = _conv_desc(n, c, h, w, o, k, stride, pad, scale_len=o if per_ch else 1)
+    d2, _, _ = _conv_desc(n, o, oh, ow, o2, k2, stride2, pad2, pad_mode=pad_mode2)
+    # the producer's own quantized input (staged) and prepacked weights
+    xf = (rng.f32(n * c * h * w).reshape(n, c, h, w) - 0.3).astype(np.float32)
+    staged_in = DeviceTensor(ctx, (lib.rten_hip_conv2d_int8_staged_bytes(C.byref(d)),), np.uint8)
+    xs, xz, sc = DeviceTensor(ctx, (1,), np.float32), DeviceTensor(ctx, (1,), np.uint8), DeviceTensor(ctx, (o if per_ch else 1,), np.float32)
+    ws = dev(ctx, (rng.f32(o if per_ch else 1) * 0.01 + 0.002).astype(np.float32))
+    ctx.call("rten_hip_dynamic_quantize_linear_staged", C.byref(d), dev(ctx, xf).vp, staged_in.vp, xs.vp, xz.vp, None, None)
+    ctx.call("rten_hip_mul_f32", o if per_ch else 1, ws.vp, xs.vp, 1, sc.vp)
+    wq = rng.i8(o * c * k * k, reduced=True).reshape(o, c, k, k)
+    packed = DeviceTensor(ctx, (lib.rten_hip_conv2d_int8_packed_bytes(C.byref(d)),), np.uint8)
+    ctx.call("rten_hip_conv2d_int8_prepack", C.byref(d), dev(ctx, wq).vp, packed.vp)
+    bias = dev(ctx, rng.f32(o) - 0.5)
+    res = dev(ctx, rng.f32(n * o * oh * ow).reshape(n, o, oh, ow) - 0.5) if with_res else None
+    flags = L.CONV_RELU | (L.CONV_RESIDUAL if with_res else 0)
+    ws2 = dev(ctx, np.array([0.0173], np.float32))
+    nb = lib.rten_hip_conv2d_int8_staged_bytes(C.byref(d2))
+    assert nb > 0
+
+    # (a) the two operators: ConvIntegerToFloat (+ producer statistics), then DynamicQuantizeLinear into the consumer's staged layout
+    y_a = DeviceTensor(ctx, (n, o, oh, ow), np.float32)
+    st_a = DeviceTensor(ctx, (sb,), np.uint8)
+    ctx.call("rten_hip_minmax_stats_reset", st_a.vp, 1)
+    ctx.call("rten_hip_conv2d_int8_stats", C.byref(d), staged_in.vp, packed.vp, xz.vp, None, sc.vp, bias.vp, res.vp if res else None, flags, y_a.vp, st_a.vp)
+    staged_a = dev(ctx, np.full(nb, 0xEE, np.uint8))
+    xs_a, xz_a, pr_a = DeviceTensor(ctx, (1,), np.float32), DeviceTensor(ctx, (1,), np.uint8), DeviceTensor(ctx, (1,), np.float32)
+    ctx.call("rten_hip_dynamic_quantize_linear_staged_stats", C.byref(d2), y_a.vp, st_a.vp, staged_a.vp, xs_a.vp, xz_a.vp, ws2.vp, pr_a.vp)
+    ctx.sync()
+
+    # (b) one launch; twice in a row (the barrier block must come back zeroed), with and without the f32 output
+    sync = dev(ctx, np.zeros(gb, np.uint8))
+    for rep, want_y in enumerate((with_res, False, True)):
+        st_b = DeviceTensor(ctx, (sb,), np.uint8)
+        ctx.call("rten_hip_minmax_stats_reset", st_b.vp, 1)
+        staged_b = dev(ctx, np.full(nb, 0xEE, np.uint8))
+        y_b = dev(ctx, np.zeros((n, o, oh, ow), np.float32))
+        xs_b, xz_b, pr_b = DeviceTensor(ctx, (1,), np.float32), DeviceTensor(ctx, (1,), np.uint8), DeviceTensor(ctx, (1,), np.float32)
+        ctx.call("rten_hip_conv2d_int8_qout", C.byref(d), staged_in.vp, packed.vp, xz.vp, None, sc.vp, bias.vp, res.vp if res else None, flags,
+                 y_b.vp if want_y else None, st_b.vp, sync.vp, C.byref(d2), staged_b.vp, xs_b.vp, xz_b.vp, ws2.vp, pr_b.vp)
+        ctx.sync()
+        to = C.c_int32(-1)
+        ctx.call("rten_hip_grid_sync_timeouts", sync.vp, 1, C.byref(to))
+        assert to.value == 0, "the launch gave up waiting for its grid"
+        assert not sync.numpy().any(), "barrier block not left zeroed"
+        assert np.array_equal(xs_a.numpy().view(np.uint32), xs_b.numpy().view(np.uint32)) and np.array_equal(xz_a.numpy(), xz_b.numpy())
+        assert np.array_equal(pr_a.numpy().view(np.uint32), pr_b.numpy().view(np.uint32))
+        a, b = staged_a.numpy(), staged_b.numpy()
+        assert np.array_equal(a, b), f"rep {rep}: {(a != b).sum()} of {a.size} staged bytes differ (first at {np.argwhere(a != b)[0]})"
+        if want_y:
+            bits_equal(y_b.numpy(), y_a.numpy())
+        else:
+            assert not y_b.numpy().any()
+
+
+def test_conv2d_int8_qout_refuses_a_grid_that_cannot_be_resident(ctx):
+    """A launch with more workgroups than the device holds at once must be refused (UNSUPPORTED), never attempted."""
+    lib = ctx.lib
+    n, c, h, w, o = 64, 64, 112, 112, 256  # 256 x 802816 outputs: 12544 tiles of 128 x 128
+    d, oh, ow = _conv_desc(n, c, h, w, o, 1, 1, 0)
+    d2, _, _ = _conv_desc(n, o, oh, ow, 64, 1, 1, 0)
+    sb, gb = lib.rten_hip_minmax_stats_bytes(), lib.rten_hip_grid_sync_bytes()
+    staged_in = DeviceTensor(ctx, (lib.rten_hip_conv2d_int8_staged_bytes(C.byref(d)),), np.uint8)
+    packed = DeviceTensor(ctx, (lib.rten_hip_conv2d_int8_packed_bytes(C.byref(d)),), np.uint8)
+    staged_out = DeviceTensor(ctx, (lib.rten_hip_conv2d_int8_staged_bytes(C.byref(d2)),), np.uint8)
+    st, sync = DeviceTensor(ctx, (sb,), np.uint8), dev(ctx, np.zeros(gb, np.uint8))
+    one = dev(ctx, np.ones(1, np.float32))
+    z = dev(ctx, np.zeros(1, np.uint8))
+    rc = lib.rten_hip_conv2d_int8_qout(ctx.h, C.byref(d), staged_in.vp, packed.vp, z.vp, None, one.vp, None, None, 0, None, st.vp, sync.vp, C.byref(d2), staged_out.vp,
+                                       one.vp, z.vp, None, None)
+    assert rc == L.ERR_UNSUPPORTED
+    ctx.sync()
+
+
+def test_resnet50_int8_batch32_quantized_output_launches(ctx):
+    """BASELINE configs[2] with the c1 -> c2 -> c3 edges of every bottleneck block quantized in the producing conv's epilogue: logits
+    bit-identical to the oracle, eager and as a replayed hipGraph, and to the runner with the feature off."""
+    from oracle import models as omodels
+    from rten_amd.workloads import resnet50, resnet50_int8
+    w = resnet50.make_weights()
+    net = resnet50_int8.ResNet50Int8(ctx, batch=32, weights=w)
+    net.upload_weights()
+    x = np.random.default_rng(1234).random((32, 3, 224, 224), dtype=np.float32)
+    net.x.upload(x)
+    want = omodels.resnet50_int8_forward(net.specs, omodels.quantize_weights_int8(w), x)
+    net.fused_qout = True
+    net.forward()
+    bits_equal(net.logits.numpy(), want)
+    assert net.qout_timeouts() == 0
+    assert len(net.qout_next) == 32 and len(net._qout_off) <= 2, sorted(net._qout_off)  # (s1b0c1: 784 tiles of 128 x 128 do not fit at once)
+    net.capture()
+    for _ in range(3):
+        net.logits.upload(np.zeros_like(want))
+        net.run()
+        bits_equal(net.logits.numpy(), want)
+    assert net.qout_timeouts() == 0
+    net.graph, net.fused_qout = None, False
+    net.logits.upload(np.zeros_like(want))
+    net.forward()
+    bits_equal(net.logits.numpy(), want)
+    # the other pad mode goes through the in-kernel border fill with the dynamic zero point
+    net2 = resnet50_int8.ResNet50Int8(ctx, batch=32, weights=w, pad_mode=L.PAD_ZERO_POINT)
+    net2.upload_weights()
+    net2.x.upload(x)
+    net2.fused_qout = True
+    net2.forward()
+    bits_equal(net2.logits.numpy(), omodels.resnet50_int8_forward(net.specs, omodels.quantize_weights_int8(w), x, pad_mode=ref.PAD_ZERO_POINT))
+    assert net2.qout_timeouts() == 0

@@ -29,7 +29,7 @@ def timed(fn):
     return ctx.timer_ms(1) / REPS * 1e3
 
 
-tq = tc = tf = tsep = 0.0
+tq = tc = tf = tsep = tqo = tqo_sep = 0.0
 print(f"{'layer':9s} {'O':>4s} {'C':>4s} k s {'HxW':>7s} | {'quant us':>8s} {'GB/s':>6s} | {'conv us':>8s} {'GB/s':>6s} {'TOP/s':>6s}  tiles(128x128)")
 ONLY = os.environ.get("LAYERS")
 for l in net.specs:
@@ -65,5 +65,22 @@ for l in net.specs:
         tf += us_f
         tsep += us_q + us_c
         fused = f" | fused quantize+conv {us_f:6.1f} us (separate {us_q + us_c:6.1f})"
+    nxt = net.qout_next.get(name)
+    if nxt is not None:  # quantized-output launch (conv + the consumer's DynamicQuantizeLinear in one launch) vs the two launches
+        nd = net.idesc[nxt["name"]]
+        ost, oxs, oxz = net.qsets[1]
+        qo = lambda: ctx.lib.rten_hip_conv2d_int8_qout(ctx.h, C.byref(d), net.staged.vp, net.wq[name].vp, net.xz.vp, None, net.sc.vp, net.bq[name].vp,
+                                                       net._act(l["res"]).vp if l["res"] else None, flags, None, net.stats[l["dst"]], net.syncs[name], C.byref(nd),
+                                                       ost.vp, oxs.vp, oxz.vp, net.ws[nxt["name"]].vp, net.scs[1].vp)
+        if qo() == 0:
+            us_qo = timed(qo)
+            us_nq = timed(lambda: ctx.call("rten_hip_dynamic_quantize_linear_staged_stats", C.byref(nd), net._act(l["dst"]).vp, net.stats[l["dst"]], ost.vp, oxs.vp,
+                                           oxz.vp, net.ws[nxt["name"]].vp, net.scs[1].vp))
+            tqo += us_qo
+            tqo_sep += us_c + us_nq
+            fused += f" | qout {us_qo:6.1f} us (conv + consumer's quantize {us_c + us_nq:6.1f})"
+        else:
+            fused += " | qout: grid not resident at once"
     print(f"{name:9s} {cv.o:4d} {cv.c:4d} {cv.kh} {cv.stride_h} {cv.h:3d}x{cv.w:<3d} | {us_q:8.1f} {qb / us_q / 1e3:6.0f} | {us_c:8.1f} {cb / us_c / 1e3:6.0f} {ops / us_c / 1e6:6.0f}  {tiles}{fused}")
-print(f"sum: quantize {tq / 1e3:.3f} ms, conv {tc / 1e3:.3f} ms; pointwise layers fused {tf / 1e3:.3f} ms vs separate {tsep / 1e3:.3f} ms")
+print(f"sum: quantize {tq / 1e3:.3f} ms, conv {tc / 1e3:.3f} ms; pointwise layers fused {tf / 1e3:.3f} ms vs separate {tsep / 1e3:.3f} ms; "
+      f"quantized-output launches {tqo / 1e3:.3f} ms vs conv + consumer's quantize {tqo_sep / 1e3:.3f} ms; time-outs {net.qout_timeouts()}")
