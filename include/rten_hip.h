@@ -279,17 +279,19 @@ int32_t rten_hip_conv2d_int8_dql(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_d
 /* ConvIntegerToFloat [-> Add bias] [-> Add residual] [-> Relu] AND the DynamicQuantizeLinear of the ONE convolution that consumes its
  * output (the c1 -> c2 -> c3 edges of a bottleneck block in an ort-quantized CNN; the reference runs ConvIntegerToFloat,
  * src/ops/conv.rs:495-587, then DynamicQuantizeLinear, src/ops/quantize.rs:352-436, as two operators with an f32 tensor between them)
- * in ONE launch: the finished f32 values stay in registers, every workgroup publishes its min / max into `stats` and crosses one
- * grid-wide arrival barrier (`sync`), then quantizes its own values with the same scale / zero-point algebra and writes the u8 codes
+ * in ONE launch: the finished f32 values stay in registers, every workgroup publishes its min / max as one 8-byte granule of the
+ * exchange block `sync` and sweeps everybody else's (a grid-wide all-gather: the only cross-workgroup step), then quantizes its own
+ * values with the same scale / zero-point algebra and writes the u8 codes
  * directly as the staged image of `next` (the consumer's descriptor; what rten_hip_dynamic_quantize_linear_staged would have written,
  * byte for byte, border pieces included).  `y` may be NULL: the f32 tensor is then never materialised (4 B written + 4 B read per
  * element less).  `next_scale` / `next_zero_point` receive DynamicQuantizeLinear's outputs, `product` = scale * mul_by[0] (optional).
  * `x` must be staged and `w` prepacked (desc->x_staged, desc->weights_packed); `stats` as for rten_hip_conv2d_int8_stats (reset
- * before the call); `sync` is a device buffer of rten_hip_grid_sync_bytes(), zeroed ONCE when allocated -- every launch leaves it
- * zero.  The launch needs all its workgroups resident at once and nothing else running on the device's compute units:
+ * before the call; it receives the output's statistics as there); `sync` is a device buffer of rten_hip_grid_sync_bytes(), initialised
+ * ONCE with rten_hip_grid_sync_reset when allocated -- every launch leaves it in that state.  The launch needs all its workgroups resident at once and nothing else running on the device's compute units:
  * RTEN_HIP_ERR_UNSUPPORTED when the grid does not fit (or the geometry is not covered) -> run the two-launch sequence.  A launch that
  * nevertheless waits longer than ~0.5 s for its grid gives up and sets the block's time-out flag (rten_hip_grid_sync_timeouts). */
 size_t rten_hip_grid_sync_bytes(void);
+int32_t rten_hip_grid_sync_reset(rten_hip_ctx *ctx, void *sync, int32_t count /* consecutive blocks */);
 int32_t rten_hip_conv2d_int8_qout(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *desc, const void *x, const void *w,
                                   const void *x_zp, const void *w_zp, const float *scale, const float *bias, const float *residual,
                                   uint32_t flags, float *y /* optional */, void *stats, void *sync,

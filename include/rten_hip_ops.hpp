@@ -592,7 +592,10 @@ struct Gemm : Operator { // src/ops/matmul.rs:106-156: c = alpha * (a b) + beta 
             ctx.check(rten_hip_memcpy_d2d(ctx.raw(), y.ptr(), c->ptr(), y.bytes()));
             d.beta = beta;
             ctx.check(rten_hip_gemm_f32(ctx.raw(), &d, (const float *)a.ptr(), (const float *)b.ptr(), nullptr, (float *)y.ptr()));
-        } else if (c && beta == 1.f && alpha == 1.f) { // row vector, c + ab: the per-column bias epilogue adds in the same place
+        } else if (c && beta == 1.f && alpha == 1.f && m != 1) {
+            // row vector, c + ab, several rows: the per-column bias epilogue adds in the same place (after the first depth block).  A ONE-row
+            // product takes the reference's gemv kernels (rten-gemm/src/lib.rs:668-747,876-891), where the expanded C enters with the
+            // FIRST depth block -- ((c + acc0) + acc1) ... -- not after the last: that case runs the general form below.
             d.beta = 0.f; d.bias_kind = bias_kind;
             ctx.check(rten_hip_gemm_f32(ctx.raw(), &d, (const float *)a.ptr(), (const float *)b.ptr(), (const float *)c->ptr(), (float *)y.ptr()));
         } else if (c) { // general case: output = expand(c), then gemm(alpha, beta) (matmul.rs:63-82)

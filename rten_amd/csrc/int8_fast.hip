@@ -316,8 +316,11 @@ extern __shared__ __attribute__((aligned(16))) uint8_t i8_smem[];
 // scale / zero point, converts with the same dql::quant_u8 and writes the codes straight into the consumer's staged image
 // (channel-blocked, padded; border pieces included).  The f32 tensor is written only if somebody else needs it (p.C != NULL).
 // Every workgroup of the grid must be resident at once (the host checks the occupancy before it launches this form).
-constexpr unsigned kSyncWords = 256;      // barrier block: arrival counters at words 0, 16, ..., 112; departures at 128; time-out flag at 144
-constexpr unsigned kSyncSpinLimit = 1u << 18;
+constexpr unsigned kSyncCtlWords = 16;    // exchange block: word 0 = departures, word 8 = time-out flag, then kSyncGranules 8-byte {min, max} granules
+constexpr unsigned kSyncGranules = 2048;  // >= the workgroups the device holds at once (8 per compute unit x 256)
+constexpr unsigned kSyncWords = kSyncCtlWords + 2 * kSyncGranules;
+constexpr unsigned long long kGranuleReset = 0x00000000ffffffffull; // {min = 0xffffffff, max = 0}: what a reset leaves, never a real pair
+constexpr unsigned kSyncSpinLimit = 1u << 17;
 template <int BM, int BN, int NSTAGE, bool RES, int KTK = 64, int KG = 1, bool BQ = false, bool QO = false>
 __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kernel(const FastArgs p) {
     static_assert(!BQ || (KG == 1 && KTK == 64), "quantize-on-load: one k-group, 64-byte k-tiles");
@@ -739,56 +742,63 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
     }
     } // epi
     if constexpr (QO) {
-        // ---- (1) publish this workgroup's min / max, arrive, wait for the whole grid
+        // ---- (1) all-gather of the workgroups' min / max.  One hop: every workgroup publishes ONE 8-byte granule {min, max} (ordered-uint
+        // images; the pair a reset leaves there, {0xffffffff, 0}, cannot be a real one, so the data is its own flag) with a write-through
+        // store and then sweeps all G granules with relaxed agent-scope loads until none is the reset pair.  No counters, no fences, no
+        // read-modify-write on the critical path (the first version -- eight arrival counters polled by every workgroup plus the slot
+        // atomics -- cost 6 / 9 / 22 us at 200 / 392 / 784 workgroups: profiles/r06/int8_qout_per_layer.txt).
+        unsigned long long *const gran = reinterpret_cast<unsigned long long *>(p.sync + kSyncCtlWords);
+        const unsigned G = gridDim.x;
+        float *const gred = reinterpret_cast<float *>(smem + 8192); // (the row constants at the start of the stage buffers are dead by now)
         if (epi) {
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) { st_mn = fminf(st_mn, __shfl_xor(st_mn, o, 64)); st_mx = fmaxf(st_mx, __shfl_xor(st_mx, o, 64)); }
-            if (lane == 0) { // returning forms: their completion is what the wait below covers
+            if (lane == 0) {
+                gred[wq] = st_mn; gred[4 + wq] = st_mx;
+                // the statistics block as rten_hip_conv2d_int8_stats leaves it (for a second reader of the f32 output); nobody waits for these
                 const unsigned slot = (blockIdx.x * 4u + (unsigned)wq) % (unsigned)dql::kStatSlots;
-                const unsigned o1 = __hip_atomic_fetch_min(&p.stats[slot], dql::f2ord(st_mn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned o2 = __hip_atomic_fetch_max(&p.stats[dql::kStatSlots + slot], dql::f2ord(st_mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("" ::"v"(o1), "v"(o2));
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every wave: its statistics are in place before the workgroup arrives
-        __syncthreads();
-        const unsigned G = gridDim.x;
-        if (t == 0) __hip_atomic_fetch_add(p.sync + (blockIdx.x & 7u) * 16u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (wave_all == 0) { // one wave polls: lanes 0..7 read the eight arrival counters (relaxed agent-scope loads), bounded
-            unsigned spins = 0;
-            for (;;) {
-                unsigned v = lane < 8 ? __hip_atomic_load(p.sync + lane * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
-                if ((unsigned)__builtin_amdgcn_readfirstlane((int)v) >= G) break;
-                if (++spins >= kSyncSpinLimit) { // not every workgroup is resident (or a previous launch timed out): give up, loudly
-                    if (lane == 0) __hip_atomic_store(p.sync + 144, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(8);
+                atomicMin(&p.stats[slot], dql::f2ord(st_mn));
+                atomicMax(&p.stats[dql::kStatSlots + slot], dql::f2ord(st_mx));
             }
         }
         __syncthreads();
-        if (t == 0) { // the last workgroup through the barrier leaves the block zeroed for the next launch
-            const unsigned old = __hip_atomic_fetch_add(p.sync + 128, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old == G - 1u) {
-#pragma unroll
-                for (int c = 0; c < 8; c++) __hip_atomic_store(p.sync + c * 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(p.sync + 128, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == 0) {
+            const float mn = fminf(fminf(gred[0], gred[1]), fminf(gred[2], gred[3])), mx = fmaxf(fmaxf(gred[4], gred[5]), fmaxf(gred[6], gred[7]));
+            __hip_atomic_store(gran + blockIdx.x, ((unsigned long long)dql::f2ord(mx) << 32) | dql::f2ord(mn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        float ga = __builtin_inff(), gb = -__builtin_inff();
+        for (unsigned spins = 0;;) {
+            bool ok = true;
+            ga = __builtin_inff(); gb = -__builtin_inff();
+            for (unsigned g = (unsigned)t; g < G; g += 256u * KG) {
+                const unsigned long long v = __hip_atomic_load(gran + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = ok && v != kGranuleReset;
+                ga = fminf(ga, dql::ord2f((unsigned)v)); gb = fmaxf(gb, dql::ord2f((unsigned)(v >> 32)));
             }
+            if (__syncthreads_and(ok)) break;
+            if (++spins >= kSyncSpinLimit) { // not every workgroup is resident (or a previous launch timed out): give up, loudly
+                if (t == 0) __hip_atomic_store(p.sync + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if (t == 0) { // the last workgroup out resets the granules for the next launch (everybody has finished sweeping by then)
+            const unsigned old = __hip_atomic_fetch_add(p.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gred[8] = old == G - 1u ? 1.f : 0.f;
         }
         // ---- (2) the statistics of the whole tensor -> DynamicQuantizeLinear's parameters (quantize.rs:397-419)
-        float ga = __builtin_inff(), gb = -__builtin_inff();
-        if (t < dql::kStatSlots) {
-            ga = dql::ord2f(__hip_atomic_load(p.stats + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            gb = dql::ord2f(__hip_atomic_load(p.stats + dql::kStatSlots + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) { ga = fminf(ga, __shfl_xor(ga, o, 64)); gb = fmaxf(gb, __shfl_xor(gb, o, 64)); }
-        float *const gred = reinterpret_cast<float *>(smem + 8192); // (the row constants at the start of the stage buffers are dead by now)
-        if (lane == 0 && wave_all < 4) { gred[wave_all] = ga; gred[4 + wave_all] = gb; }
+        if (lane == 0) { gred[16 + wave_all] = ga; gred[32 + wave_all] = gb; }
         __syncthreads();
+        if (gred[8] != 0.f) {
+            for (unsigned g = (unsigned)t; g < G; g += 256u * KG) __hip_atomic_store(gran + g, kGranuleReset, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == 0) __hip_atomic_store(p.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (!epi) return;
-        const float g_mn = fminf(fminf(gred[0], gred[1]), fminf(gred[2], gred[3])), g_mx = fmaxf(fmaxf(gred[4], gred[5]), fmaxf(gred[6], gred[7]));
+        float g_mn = gred[16], g_mx = gred[32];
+#pragma unroll
+        for (int wv = 1; wv < 4 * KG; wv++) { g_mn = fminf(g_mn, gred[16 + wv]); g_mx = fmaxf(g_mx, gred[32 + wv]); }
         const dql::QParams q = dql::dql_params(g_mn, g_mx);
         if (t == 0 && blockIdx.x == 0) {
             *p.q_scale_out = q.scale;
@@ -927,7 +937,7 @@ bool launch_fast(rten_hip_ctx *ctx, FastArgs &a, const char *name, double ops, d
     bool launched = true;
     auto go = [&](auto kern) {
         if (lds > 64 * 1024) hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (QO && (long long)a.tiles_m * a.tiles_n > resident_capacity(ctx, (const void *)kern, 256 * KG, lds)) {
+        if (QO && ((long long)a.tiles_m * a.tiles_n > resident_capacity(ctx, (const void *)kern, 256 * KG, lds) || (long long)a.tiles_m * a.tiles_n > (long long)kSyncGranules)) {
             launched = false;
             return;
         }
@@ -1289,6 +1299,25 @@ RTEN_EXPORT int32_t rten_hip_conv2d_int8_qout(rten_hip_ctx *ctx, const rten_hip_
     return i8_fast_conv_impl(ctx, di, x, w, x_zp, w_zp, scale, bias, residual, flags, y, stats, &qo);
 }
 
+namespace {
+__global__ void grid_sync_reset_kernel(unsigned *sync, int count) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; // one thread per word
+    if (i >= (long long)count * kSyncWords) return;
+    const unsigned w = (unsigned)(i % kSyncWords);
+    sync[i] = (w >= kSyncCtlWords && ((w - kSyncCtlWords) & 1u) == 0u) ? 0xffffffffu : 0u; // granule = {lo = 0xffffffff, hi = 0}
+}
+} // namespace
+
+// Initialises `count` consecutive exchange blocks (once, when they are allocated; every launch leaves its block in this state).
+RTEN_EXPORT int32_t rten_hip_grid_sync_reset(rten_hip_ctx *ctx, void *sync, int32_t count) {
+    RTEN_CHECK_CTX(ctx);
+    if (!sync || count < 1) return RTEN_HIP_ERR_INVALID_VALUE;
+    const long long n = (long long)count * kSyncWords;
+    hipLaunchKernelGGL(grid_sync_reset_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (unsigned *)sync, count);
+    RTEN_LAUNCH_CHECK(ctx, "grid_sync_reset_kernel launch");
+    return RTEN_HIP_OK;
+}
+
 // Time-out flags of `count` consecutive barrier blocks (non-zero: a quantized-output launch gave up waiting for its grid and its results are void).
 RTEN_EXPORT int32_t rten_hip_grid_sync_timeouts(rten_hip_ctx *ctx, const void *sync, int32_t count, int32_t *timeouts) {
     RTEN_CHECK_CTX(ctx);
@@ -1297,7 +1326,7 @@ RTEN_EXPORT int32_t rten_hip_grid_sync_timeouts(rten_hip_ctx *ctx, const void *s
     RTEN_HIP_TRY(ctx, hipMemcpyAsync(host.data(), sync, host.size() * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
     RTEN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     int n = 0;
-    for (int i = 0; i < count; i++) n += host[(size_t)i * kSyncWords + 144] != 0;
+    for (int i = 0; i < count; i++) n += host[(size_t)i * kSyncWords + 8] != 0;
     *timeouts = n;
     return RTEN_HIP_OK;
 }

@@ -139,6 +139,7 @@ PROTOTYPES = {
     "rten_hip_grid_sync_bytes": (_SZ, []),
     "rten_hip_conv2d_int8_qout": (_I32, [_VP, C.POINTER(Conv2dInt8Desc), _VP, _VP, _VP, _VP, _VP, _VP, _VP, _U32, _VP, _VP, _VP,
                                           C.POINTER(Conv2dInt8Desc), _VP, _VP, _VP, _VP, _VP]),
+    "rten_hip_grid_sync_reset": (_I32, [_VP, _VP, _I32]),
     "rten_hip_grid_sync_timeouts": (_I32, [_VP, _VP, _I32, C.POINTER(_I32)]),
     "rten_hip_dynamic_quantize_linear_staged_stats": (_I32, [_VP, C.POINTER(Conv2dInt8Desc), _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "rten_hip_dynamic_quantize_linear_staged": (_I32, [_VP, C.POINTER(Conv2dInt8Desc), _VP, _VP, _VP, _VP, _VP, _VP]),

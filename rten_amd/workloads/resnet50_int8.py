@@ -45,8 +45,8 @@ class ResNet50Int8(ResNet50):
                           if len(readers.get(m["dst"], [])) == 1 and m["dst"] not in residuals and m["dst"] != "stem"}
         self._qout_off = set()       # layers whose launch cannot be resident at once on this device (found at the first attempt)
         gb = ctx.lib.rten_hip_grid_sync_bytes()
-        self.sync_arena = DeviceTensor(ctx, (gb * len(self.specs),), np.uint8)  # zeroed once; every launch leaves its block zero
-        ctx.call("rten_hip_memset", self.sync_arena.vp, 0, C.c_size_t(gb * len(self.specs)))
+        self.sync_arena = DeviceTensor(ctx, (gb * len(self.specs),), np.uint8)  # initialised once; every launch leaves its block as it found it
+        ctx.call("rten_hip_grid_sync_reset", self.sync_arena.vp, len(self.specs))
         self.syncs = {l["name"]: C.c_void_p(self.sync_arena.ptr + i * gb) for i, l in enumerate(self.specs)}
         sb = ctx.lib.rten_hip_minmax_stats_bytes()
         self.stats_arena = DeviceTensor(ctx, (sb * len(self.specs),), np.uint8)  # one statistics block per conv output

@@ -161,6 +161,22 @@ static void device_tests() {
         Tensor t3 = Tensor::from_host(ctx, {K + 1, Nn}, b.data());
         expect_error(OpError::IncompatibleInputShapes, "Columns of first matrix does not match rows of second matrix", [&] { MatMul().run(ctx, {&ta, &t3}); }, "matmul shapes");
     }
+    { // Gemm with ONE row and a row-vector C: the reference's gemv kernels, where C enters with the first depth block (matmul.rs:63-82,
+      // rten-gemm/src/lib.rs:668-747) -- the batch-1 classifier of ResNet-50 -- with and without transB
+        const int64_t K = 1100, Nn = 1000;
+        auto a = randf(31, K), b = randf(32, K * Nn), bias = randf(33, Nn);
+        std::vector<float> bt((size_t)(K * Nn));
+        for (int64_t i = 0; i < K; i++) for (int64_t j = 0; j < Nn; j++) bt[(size_t)(j * K + i)] = b[(size_t)(i * Nn + j)];
+        Tensor ta = Tensor::from_host(ctx, {1, K}, a.data()), tb = Tensor::from_host(ctx, {K, Nn}, b.data()), tbt = Tensor::from_host(ctx, {Nn, K}, bt.data()),
+               tbias = Tensor::from_host(ctx, {Nn}, bias.data());
+        std::vector<float> want(bias), want_t(bias);
+        rto_gemm_f32(1, Nn, K, a.data(), K, 1, b.data(), Nn, 1, want.data(), Nn, 1.f, 1.f, nullptr, 0);
+        rto_gemm_f32(1, Nn, K, a.data(), K, 1, bt.data(), 1, K, want_t.data(), Nn, 1.f, 1.f, nullptr, 0);
+        Gemm g;
+        CHECK(same_bits(g.run(ctx, {&ta, &tb, &tbias})[0].to_host<float>(), want), "Gemm one row bits");
+        g.transpose_b = true;
+        CHECK(same_bits(g.run(ctx, {&ta, &tbt, &tbias})[0].to_host<float>(), want_t), "Gemm one row transB bits");
+    }
     { // Softmax, LayerNormalization, Gelu
         const int64_t R = 37, Cc = 100;
         auto x = randf(8, R * Cc), g = randf(9, Cc), b = randf(10, Cc);

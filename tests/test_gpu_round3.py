@@ -87,7 +87,10 @@ def test_conv2d_int8_qout_matches_the_separate_operators(ctx, case):
     ctx.sync()
 
     # (b) one launch; twice in a row (the barrier block must come back zeroed), with and without the f32 output
-    sync = dev(ctx, np.zeros(gb, np.uint8))
+    sync = DeviceTensor(ctx, (gb,), np.uint8)
+    ctx.call("rten_hip_grid_sync_reset", sync.vp, 1)
+    ctx.sync()
+    sync0 = sync.numpy()
     for rep, want_y in enumerate((with_res, False, True)):
         st_b = DeviceTensor(ctx, (sb,), np.uint8)
         ctx.call("rten_hip_minmax_stats_reset", st_b.vp, 1)
@@ -100,7 +103,7 @@ def test_conv2d_int8_qout_matches_the_separate_operators(ctx, case):
         to = C.c_int32(-1)
         ctx.call("rten_hip_grid_sync_timeouts", sync.vp, 1, C.byref(to))
         assert to.value == 0, "the launch gave up waiting for its grid"
-        assert not sync.numpy().any(), "barrier block not left zeroed"
+        assert np.array_equal(sync.numpy(), sync0), "exchange block not left as it was found"
         assert np.array_equal(xs_a.numpy().view(np.uint32), xs_b.numpy().view(np.uint32)) and np.array_equal(xz_a.numpy(), xz_b.numpy())
         assert np.array_equal(pr_a.numpy().view(np.uint32), pr_b.numpy().view(np.uint32))
         a, b = staged_a.numpy(), staged_b.numpy()
@@ -121,7 +124,8 @@ def test_conv2d_int8_qout_refuses_a_grid_that_cannot_be_resident(ctx):
     staged_in = DeviceTensor(ctx, (lib.rten_hip_conv2d_int8_staged_bytes(C.byref(d)),), np.uint8)
     packed = DeviceTensor(ctx, (lib.rten_hip_conv2d_int8_packed_bytes(C.byref(d)),), np.uint8)
     staged_out = DeviceTensor(ctx, (lib.rten_hip_conv2d_int8_staged_bytes(C.byref(d2)),), np.uint8)
-    st, sync = DeviceTensor(ctx, (sb,), np.uint8), dev(ctx, np.zeros(gb, np.uint8))
+    st, sync = DeviceTensor(ctx, (sb,), np.uint8), DeviceTensor(ctx, (gb,), np.uint8)
+    ctx.call("rten_hip_grid_sync_reset", sync.vp, 1)
     one = dev(ctx, np.ones(1, np.float32))
     z = dev(ctx, np.zeros(1, np.uint8))
     rc = lib.rten_hip_conv2d_int8_qout(ctx.h, C.byref(d), staged_in.vp, packed.vp, z.vp, None, one.vp, None, None, 0, None, st.vp, sync.vp, C.byref(d2), staged_out.vp,

@@ -4,7 +4,7 @@
 TAG=${1:-r3a}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_round3.py -m gpu -q -x --tb=short -p no:cacheprovider > gpurun_out/${TAG}_pytest_r3.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest_r3.log
+timeout 900 python -m pytest tests/test_gpu_round3.py -m gpu -q -x -s --tb=short -p no:cacheprovider > gpurun_out/${TAG}_pytest_r3.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest_r3.log
 timeout 300 python tools/probe_int8_per_layer.py > gpurun_out/${TAG}_int8_per_layer.txt 2>&1
 timeout 400 python bench.py --config int8 --no-secondary --no-cpu-baseline --no-qout > gpurun_out/${TAG}_bench_int8_noqout.json 2> gpurun_out/${TAG}_bench_int8_noqout.err
 timeout 400 python bench.py --config int8 --no-secondary --no-cpu-baseline > gpurun_out/${TAG}_bench_int8.json 2> gpurun_out/${TAG}_bench_int8.err
