@@ -26,6 +26,11 @@ import os
 import sys
 import time
 
+# Every stream of the process gets a hardware queue of its own (the runtime's default maps streams onto 4 queues, and two of the f32
+# runner's sub-batch chains on one queue serialise: 3.45 vs 2.79 ms per step, profiles/r05/chains_probe.txt).  Must be set before the HIP
+# runtime starts, i.e. before torch / librten_hip.so are loaded; with it no stream-placement search is needed.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -259,7 +264,10 @@ def main():
                     help="f32: ResNet-50 f32 batch 32 per GPU (BASELINE configs[1], the headline); int8: the dynamically quantized graph "
                          "(configs[2]; with --gpus 8 = configs[4], 8 x 32 images, weights RCCL-broadcast)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
-    ap.add_argument("--no-autotune", action="store_true")
+    ap.add_argument("--no-autotune", action="store_true", help="neither load a plan nor tune: the backend's built-in launch plans")
+    ap.add_argument("--autotune", action="store_true", help="tune the per-layer launch plans in this run (rank 0 tunes, the plan is broadcast) even if a "
+                                                              "committed plan for this configuration exists under profiles/plans/")
+    ap.add_argument("--tune-placement", action="store_true", help="f32 chains: own 8 streams and search which of them to launch on (not needed with GPU_MAX_HW_QUEUES=8)")
     ap.add_argument("--no-qout", action="store_true", help="int8: do not quantize single-consumer conv outputs in the producing launch (rten_hip_conv2d_int8_qout)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layer-table", action="store_true", help="print the per-layer autotune table to stderr")
@@ -327,7 +335,7 @@ def main():
         if int8:
             return resnet50_int8.ResNet50Int8(ctx, BATCH_PER_GPU, weights, **kw)
         if chains > 1:
-            return resnet50.ChainedResNet50(ctx, BATCH_PER_GPU, weights, chains=chains, **kw)
+            return resnet50.ChainedResNet50(ctx, BATCH_PER_GPU, weights, chains=chains, pool=None if args.tune_placement else chains, **kw)
         return resnet50.ResNet50(ctx, BATCH_PER_GPU, weights, **kw)
 
     comm_world = 1
@@ -335,9 +343,7 @@ def main():
         # The weight arena (prepacked conv weights + biases + classifier; f32: 102 MB) is staged ONCE, by rank 0, and broadcast:
         # through the backend's own communicator (rten_hip_comm_* = RCCL behind the C ABI, what a Rust host would call) on
         # the context's stream.  Under RTEN_DIST_BACKEND=gloo (several ranks on one GPU) torch.distributed carries it.
-        probe = build()
-        nbytes = probe.i8_arena_bytes if int8 else probe.arena_bytes
-        del probe
+        nbytes = resnet50_int8.i8_arena_layout(ctx.lib, BATCH_PER_GPU)[1] if int8 else resnet50.arena_bytes(ctx.lib, BATCH_PER_GPU)  # host arithmetic: nothing is built twice
         arena_t = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{local_rank}")
         net = build(i8_arena_ptr=arena_t.data_ptr(), i8_arena_keepalive=arena_t) if int8 else build(arena_ptr=arena_t.data_ptr(), arena_keepalive=arena_t)
         if rank == 0:
@@ -366,24 +372,52 @@ def main():
 
     table = None
     net.concurrent = args.concurrent
-    if args.load_plan:
-        plan = json.load(open(args.load_plan))
+
+    # ---- the per-layer launch plan.  Default: the plan committed for this configuration (tuned once on an MI355X, profiles/plans/): every
+    # rank of every run launches the same kernels, the committed rocprofv3 / PMC passes describe exactly the plan that is timed, and no
+    # start-up time goes into tuning.  --autotune (or no committed plan): rank 0 tunes and the plan is broadcast -- ranks never tune on their own.
+    def export_plan():
+        if int8:
+            return {"fused_dql": sorted(net.fused_layers or []), "qout": sorted(set(net.qout_next) - net._qout_off)}
+        return net.plan_table() if chains > 1 else {k: list(v) for k, v in net.variants.items()}
+
+    def apply_plan(plan):
         if int8:
             net.fused_dql, net.fused_layers = True, set(plan.get("fused_dql", []))
+            if "qout" in plan:
+                net._qout_off = set(net.qout_next) - set(plan["qout"])
         else:
             net.variants = plan if chains > 1 else {k: tuple(v) for k, v in plan.items()}
-        args.no_autotune = True
-    if not args.no_autotune:
-        table = net.autotune(reps=3)
+
+    plan, plan_source = None, "backend defaults (no plan)"
+    default_plan = os.path.join(ROOT, "profiles", "plans", "int8.json" if int8 else f"f32_{chains}chain{'s' if chains > 1 else ''}.json")
+    if int8:
+        net.fused_qout = not args.no_qout
+    if args.load_plan:
+        plan, plan_source = json.load(open(args.load_plan)), os.path.relpath(os.path.abspath(args.load_plan), ROOT)
+    elif not args.autotune and not args.no_autotune and os.path.exists(default_plan):
+        plan, plan_source = json.load(open(default_plan)), os.path.relpath(default_plan, ROOT)
+    elif not args.no_autotune:
+        qtab = None
+        if rank == 0:
+            table = net.autotune(reps=3)
+            if int8 and net.fused_qout:
+                qtab = net.autotune_qout()
+            plan = export_plan()
+        if dist is not None:
+            box = [plan]
+            dist.broadcast_object_list(box, src=0)
+            plan = box[0]
+        plan_source = "tuned in this run by rank 0" + (" and broadcast" if world > 1 else "")
         if args.save_plan and rank == 0:
-            if int8:
-                json.dump({"fused_dql": sorted(net.fused_layers)}, open(args.save_plan, "w"))
-            else:
-                json.dump(net.plan_table() if chains > 1 else {k: list(v) for k, v in net.variants.items()}, open(args.save_plan, "w"))
+            json.dump(plan, open(args.save_plan, "w"))
         if args.layer_table and rank == 0 and table and int8:
             for name, (sep, fus) in table.items():
                 print(f"[layer] {name:8s} DynamicQuantizeLinear staged + conv {sep:6.1f} us | quantize-on-load conv {fus:6.1f} us -> {'fused' if name in net.fused_layers else 'staged'}",
                       file=sys.stderr)
+            for name, (us2, us1) in (qtab or {}).items():
+                print(f"[layer] {name:8s} conv + consumer's quantize {us2:6.1f} us | one quantized-output launch "
+                      + (f"{us1:6.1f} us" if us1 is not None else "  (grid not resident at once)") + f" -> {'one' if name not in net._qout_off else 'two'}", file=sys.stderr)
         if args.layer_table and rank == 0 and table and not int8:
             for l in net.specs:
                 d = net.descs[l["name"]]
@@ -395,12 +429,14 @@ def main():
                 print(f"[layer] {l['name']:8s} O={d.o:4d} C={d.c:4d} k={d.kh} s={d.stride_h} {d.h:3d}->{d.out_h:3d} us: {nosplit}"
                       + " | split " + " ".join(f"v{p[0]}m{p[1]}g{p[2]}o{p[3]}={ms*1e3:6.1f}" for ms, p in split)
                       + f"  best={net.variants[l['name']]} {fl / (best_ms * 1e-3) / 1e12:6.1f} TF/s", file=sys.stderr)
-    if int8:
-        net.fused_qout = not args.no_qout
+    if plan is not None:
+        apply_plan(plan)
+    import hashlib
+    plan_sha = hashlib.sha256(json.dumps(plan, sort_keys=True).encode()).hexdigest()[:16] if plan is not None else None
     placement = None
     if not args.no_graph:
         net.capture()
-        if chains > 1:
+        if chains > 1 and args.tune_placement:
             placement = net.tune_placement()  # which streams (hardware queues) the chain graphs are launched on
 
     def barrier():
@@ -430,6 +466,16 @@ def main():
         t = mine.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- what every rank computed, and under which plan: rank r's logits are those of ITS 32 inputs (seed 1234 + r) -- the parity
+    #      definition of a sharded run (each shard == an independent reference run on that shard) -- and every rank ran the
+    #      same launch plan.  tests/test_gpu_multirank.py checks both against the oracle.
+    logits_sha = hashlib.sha256(np.ascontiguousarray(net.logits.numpy()).tobytes()).hexdigest()[:16]
+    shard_report = [(rank, logits_sha, plan_sha)]
+    if dist is not None:
+        box = [None] * world
+        dist.all_gather_object(box, shard_report[0])
+        shard_report = sorted(box)
 
     # ---- p50 latency per batch (separate pass, host-timed per step)
     lat = []
@@ -489,25 +535,29 @@ def main():
                 dom = max(conv, key=lambda r: r["ms"])
                 fam_ms = sum(r["ms"] for r in conv)
                 fam_fl = sum(r["flops"] for r in conv)
+                step_ms = elapsed / args.steps * 1e3
+                step_tf = fam_fl / args.steps / (step_ms * 1e-3) / 1e12
+                dom_tf = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+                # `achieved` / `frac` describe the TIMED state: the conv FLOPs of one batch over the timed step (hipGraph replay, all
+                # chains overlapping, every other kernel and every gap included).  The per-kernel figures of the serialised
+                # instrumented pass (HIP events per launch, one chain after the other) are detail: `dominant_kernel`, `igemm_family`.
                 roof = {"bound": "mfma", "kernel": dom["kernel"],
-                        "achieved": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12, 3), "peak": F32_MATRIX_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12 / F32_MATRIX_PEAK_TFLOPS, 4),
+                        "achieved": round(step_tf, 3), "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(step_tf / F32_MATRIX_PEAK_TFLOPS, 4),
+                        "what": "2*M*N*K of every convolution / classifier launch of one batch, divided by the TIMED step (all kernels and gaps included; "
+                                "the chains overlap in the timed region, so this -- not a serialised per-kernel figure -- is the state the value was measured in)",
                         "traffic": None, "traffic_source": None,
-                        "avg_launch_us": round(dom["ms"] * 1e3 / max(dom["launches"], 1), 2), "launches": dom["launches"],
-                        "flops_per_launch": dom["flops"] / max(dom["launches"], 1),
-                        "kernel_share_of_step": round(dom["ms"] / max(tot_ms, 1e-9), 4),
+                        "dominant_kernel": {"kernel": dom["kernel"], "achieved": round(dom_tf, 3), "frac": round(dom_tf / F32_MATRIX_PEAK_TFLOPS, 4),
+                                            "avg_launch_us": round(dom["ms"] * 1e3 / max(dom["launches"], 1), 2), "launches": dom["launches"],
+                                            "flops_per_launch": dom["flops"] / max(dom["launches"], 1),
+                                            "share_of_serialised_pass": round(dom["ms"] / max(tot_ms, 1e-9), 4),
+                                            "note": "stand-alone, serialised launches (HIP events per launch on the backend's stream)"
+                                                    + (f" at the sub-batch shapes the chains launch ({net.sizes} images): such a kernel under-fills the chip on its "
+                                                       f"own, which is what overlapping {chains} chains is for" if chains > 1 else "")},
                         "igemm_family": {"achieved": round(fam_fl / (fam_ms * 1e-3) / 1e12, 3),
                                          "frac": round(fam_fl / (fam_ms * 1e-3) / 1e12 / F32_MATRIX_PEAK_TFLOPS, 4),
                                          "share_of_step": round(fam_ms / max(tot_ms, 1e-9), 4),
                                          "variants": {r["kernel"]: {"launches": r["launches"], "ms": round(r["ms"], 4),
                                                                     "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2)} for r in conv}}}
-                step_ms = elapsed / args.steps * 1e3
-                step_tf = fam_fl / args.steps / (step_ms * 1e-3) / 1e12
-                roof["step"] = {"achieved": round(step_tf, 3), "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(step_tf / F32_MATRIX_PEAK_TFLOPS, 4),
-                                "note": "conv FLOPs of one batch / the TIMED step (hipGraph replay, all chains overlapping, every other kernel included)"}
-                if chains > 1:
-                    roof["note"] = (f"kernel durations are from the serialised instrumented pass, chain after chain, at the sub-batch shapes the chains launch "
-                                    f"({net.sizes} images); in the timed region the {chains} chains overlap, which is what `step` measures")
 
     if rank == 0 and roof:
         # HBM bytes per launch of the dominant kernel from a SEPARATE PMC pass (FETCH_SIZE x2 + WRITE_SIZE, tools/gpu/traffic.sh:
@@ -515,18 +565,26 @@ def main():
         # `traffic_source` / `traffic_note`; it is null when no committed pass covers this kernel instantiation.
         import glob
         fname = "int8_hbm_traffic_per_kernel.json" if int8 else "hbm_traffic_per_kernel.json"
-        for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*", fname)), reverse=True):
-            ks = json.load(open(path)).get("kernels", {})
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", fname)), reverse=True):
+            prof = json.load(open(path))
+            ks = prof.get("kernels", {})
             name = roof["kernel"].replace(" ", "")
             # the profiler prints every template argument (defaults included): match on the prefix the backend's own label gives
             cands = [k for k in ks if k == name or k.startswith(name[:-1] + ",")]
-            t = ks[max(cands, key=lambda k: ks[k].get("launches", 0))] if cands else None
-            if t:
-                roof["traffic"] = t["hbm_read_bytes_per_launch"] + t["hbm_write_bytes_per_launch"]
-                roof["traffic_kernel"] = max(cands, key=lambda k: ks[k].get("launches", 0))
-                roof["traffic_source"] = os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))
-                roof["traffic_note"] = "measured in a separate rocprofv3 --pmc pass over that profile's tuned plan, not in this run (autotune draws differ)"
-                break
+            if not cands:
+                continue
+            best = max(cands, key=lambda k: ks[k].get("launches", 0))
+            t = ks[best]
+            total = t["hbm_read_bytes_per_launch"] + t["hbm_write_bytes_per_launch"]
+            same_plan = plan_sha is not None and prof.get("plan_sha16") == plan_sha
+            roof["traffic"] = total if same_plan else None  # a figure measured under another launch plan is not this run's traffic
+            roof["traffic_kernel"] = best
+            roof["traffic_source"] = os.path.relpath(path, ROOT)
+            roof["traffic_plan_sha16"] = prof.get("plan_sha16")
+            roof["traffic_note"] = ("HBM bytes per launch of the dominant kernel (FETCH_SIZE x 2 + WRITE_SIZE) from a separate rocprofv3 --pmc pass over the SAME launch plan "
+                                    "(plan_sha16 matches; counters cannot be collected inside the timed run)" if same_plan else
+                                    f"null: the committed PMC pass ran another launch plan (its figure for this kernel: {total} B per launch)")
+            break
     if rank == 0:
         global_batch = BATCH_PER_GPU * n_gpus
         value = global_batch * args.steps / elapsed
@@ -548,13 +606,17 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 x i8 -> i32 (f32 between layers)" if int8 else "f32", "data": "synthetic",
             "config": {"workload": workload,
                        "global_batch": global_batch, "parallelism": f"batch-shard x{n_gpus} (weights RCCL-broadcast once)" if n_gpus > 1 else "single GPU",
-                       "launch": "eager" if args.no_graph else "hipGraph replay", "autotuned_tiles": bool(net.variants), "shortcut_branch": "second stream" if net.concurrent else "main stream",
+                       "launch": "eager" if args.no_graph else "hipGraph replay", "autotuned_tiles": bool(net.variants),
+                       "launch_plan": {"source": plan_source, "sha16": plan_sha, "identical_on_all_ranks": True},
+                       "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "shortcut_branch": "second stream" if net.concurrent else "main stream",
                        "batch_chains": {"chains": chains, "sub_batches": getattr(net, "sizes", [BATCH_PER_GPU]), "placement": getattr(net, "place", [0]),
                                         "placement_ms": [["".join(str(x) for x in pl), round(ms, 3)] for pl, ms in placement] if placement else None,
                                         "note": "independent sub-batch chains on their own streams, shared weights, logits bit-identical to one chain"},
                        flop: round((resnet50.conv_flops_per_image() + 2 * 2048 * 1000) / 1e9, 3),
                        "device": ctx.device_info()},
-            "ranks": {"world_size": world, "dist_backend": backend, "weight_broadcast_world": comm_world, "ms_per_step_per_rank": per_rank_ms},
+            "ranks": {"world_size": world, "dist_backend": backend, "weight_broadcast_world": comm_world, "ms_per_step_per_rank": per_rank_ms,
+                      "logits_sha16_per_rank": [r[1] for r in shard_report], "plan_sha16_per_rank": [r[2] for r in shard_report],
+                      "input_seed_per_rank": [1234 + r[0] for r in shard_report]},
             "pcie_inclusive": {"ms_per_step": round(pcie_ms, 4), "inferences_per_s": round(BATCH_PER_GPU / (pcie_ms * 1e-3), 1),
                                "note": "rank 0: batch uploaded from pageable host memory and logits downloaded every step (19.3 MB in, 128 KB out); not `value`"} if pcie_ms else None,
             "roofline": roof,

@@ -32,8 +32,11 @@
  *    (Gelu/Erf/Relu/Add/cast_scale/DQL) are operation-for-operation restatements; reductions
  *    (softmax sum, LayerNorm mean/variance, GlobalAveragePool) reproduce the reference's 16-lane
  *    (AVX-512) partial-sum order bit for bit and differ from its other ISA widths only by
- *    summation-order rounding.  The M == 1 gemv fast path (ISA-dependent in the reference) is
- *    held to rtol 1e-5.
+ *    summation-order rounding.  One-row products (M == 1) of rten_hip_gemm_f32 follow the reference's
+ *    vector-matrix kernels (rten-gemm/src/lib.rs:668-747,876-891; kernels/simd_generic.rs:14-197) bit for bit
+ *    under the thread-count assumption stated by rten_hip_set_gemv_order (the reference's own result depends on
+ *    its thread count there).  One-row products INSIDE composite operators (sdpa, ConvTranspose, MatMulNBits
+ *    with rows > 1) keep the blocked order: out of contract for the gemv order.
  */
 #ifndef RTEN_HIP_H
 #define RTEN_HIP_H
@@ -85,6 +88,9 @@ int32_t rten_hip_timer_elapsed_ms(rten_hip_ctx *ctx, int32_t slot, float *out_ms
 /* hipGraph capture of a launch sequence (the executor's per-run plan, src/graph.rs:880-1286). */
 int32_t rten_hip_graph_begin(rten_hip_ctx *ctx);
 int32_t rten_hip_graph_end(rten_hip_ctx *ctx, uint64_t *out_graph);
+/* Abandons an active capture (an operator failed while capturing): ends it, drops what was recorded, releases the capture lock.
+ * graph_begin / graph_end / graph_abort must be called by the same host thread; graph_end ends the capture on every path. */
+int32_t rten_hip_graph_abort(rten_hip_ctx *ctx);
 int32_t rten_hip_graph_launch(rten_hip_ctx *ctx, uint64_t graph);
 int32_t rten_hip_graph_destroy(rten_hip_ctx *ctx, uint64_t graph);
 

@@ -109,6 +109,7 @@ static void prof_resolve(rten_hip_ctx *ctx) {
 
 RTEN_EXPORT int32_t rten_hip_abi_version(void) { return RTEN_HIP_ABI_VERSION; }
 
+
 RTEN_EXPORT int32_t rten_hip_init(int32_t device_id, void *external_stream, rten_hip_ctx **out_ctx) {
     if (!out_ctx) return RTEN_HIP_ERR_INVALID_VALUE;
     *out_ctx = nullptr;
@@ -133,19 +134,13 @@ RTEN_EXPORT int32_t rten_hip_init(int32_t device_id, void *external_stream, rten
         }
         ctx->own_stream = true;
     }
-    // arrival counters of the split-K producers (gemm_f32.hip, split_finish): zero now, left zero by every launch
+    // arrival counters of the split-K producers (gemm_f32.hip, split_finish): zeroed ON THE CONTEXT'S STREAM -- stream order puts the
+    // memset before any producer that can arrive on them -- and left zero by every launch.  (No null-stream memset + device-wide
+    // synchronise: creating a context must not stall the other contexts' work, nor break a capture active on this thread.)
     if (hipMalloc((void **)&ctx->split_counters, rten_hip_ctx::kSplitCounters * sizeof(unsigned)) != hipSuccess ||
-        hipMemset(ctx->split_counters, 0, rten_hip_ctx::kSplitCounters * sizeof(unsigned)) != hipSuccess) {
+        hipMemsetAsync(ctx->split_counters, 0, rten_hip_ctx::kSplitCounters * sizeof(unsigned), ctx->stream) != hipSuccess) {
         if (ctx->split_counters) hipFree(ctx->split_counters);
         ctx->split_counters = nullptr; // the fixup-kernel path needs none
-    }
-    // the memset ran on the null stream and the context's stream does not synchronise with it (hipStreamNonBlocking): the counters
-    // must be zero before the first producer can arrive on them
-    if (hipDeviceSynchronize() != hipSuccess) {
-        if (ctx->split_counters) hipFree(ctx->split_counters);
-        if (ctx->own_stream) hipStreamDestroy(ctx->stream);
-        delete ctx;
-        return RTEN_HIP_ERR_HIP;
     }
     *out_ctx = ctx;
     return RTEN_HIP_OK;
@@ -154,6 +149,7 @@ RTEN_EXPORT int32_t rten_hip_init(int32_t device_id, void *external_stream, rten
 RTEN_EXPORT int32_t rten_hip_destroy(rten_hip_ctx *ctx) {
     if (!ctx) return RTEN_HIP_OK;
     hipSetDevice(ctx->device);
+    if (ctx->capturing && ctx->capture_locks > 0) rten_hip_graph_abort(ctx); // a capture nobody ended: never delete a locked mutex
     hipStreamSynchronize(ctx->stream);
     for (auto &kv : ctx->prof)
         for (auto &p : kv.second.pending) {
@@ -278,18 +274,41 @@ RTEN_EXPORT int32_t rten_hip_graph_begin(rten_hip_ctx *ctx) {
     return RTEN_HIP_OK;
 }
 
+// Ends the capture on EVERY path (argument errors and instantiation failures included): the capture lock taken by graph_begin is
+// released and the stream leaves capture mode, so a failed capture cannot leave the context locked for its other threads.
+// Must be called by the thread that called rten_hip_graph_begin (the lock is owned by it).
 RTEN_EXPORT int32_t rten_hip_graph_end(rten_hip_ctx *ctx, uint64_t *out_graph) {
     RTEN_CHECK_CTX(ctx);
-    if (!ctx->capturing || !out_graph) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "no active capture");
+    if (!ctx->capturing) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "no active capture");
     ctx->capturing = false;
     if (ctx->capture_locks > 0) { ctx->capture_locks--; ctx->mu.unlock(); } // the guard of this call still holds it
     hipGraph_t graph = nullptr;
-    RTEN_HIP_TRY(ctx, hipStreamEndCapture(ctx->stream, &graph));
+    const hipError_t ec = hipStreamEndCapture(ctx->stream, &graph);
+    if (ec != hipSuccess) return rten_check_hip(ctx, ec, "hipStreamEndCapture");
+    if (!out_graph) {
+        if (graph) hipGraphDestroy(graph);
+        return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "graph_end: out_graph is NULL (the capture was ended and dropped)");
+    }
     hipGraphExec_t exec = nullptr;
     hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     hipGraphDestroy(graph);
     if (e != hipSuccess) return rten_check_hip(ctx, e, "hipGraphInstantiate");
     *out_graph = (uint64_t)(uintptr_t)exec;
+    return RTEN_HIP_OK;
+}
+
+// Abandons an active capture (an operator failed while capturing and the caller gives up): ends it, drops the recorded graph,
+// releases the capture lock.  No-op without an active capture.  Same-thread rule as rten_hip_graph_end.
+RTEN_EXPORT int32_t rten_hip_graph_abort(rten_hip_ctx *ctx) {
+    RTEN_CHECK_CTX(ctx);
+    if (!ctx->capturing) return RTEN_HIP_OK;
+    ctx->capturing = false;
+    if (ctx->capture_locks > 0) { ctx->capture_locks--; ctx->mu.unlock(); }
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(ctx->stream, &graph); // an invalidated capture reports an error here: it is over either way
+    if (graph) hipGraphDestroy(graph);
+    (void)e;
+    (void)hipGetLastError();
     return RTEN_HIP_OK;
 }
 

@@ -108,6 +108,7 @@ PROTOTYPES = {
     "rten_hip_timer_elapsed_ms": (_I32, [_VP, _I32, C.POINTER(_F32)]),
     "rten_hip_graph_begin": (_I32, [_VP]),
     "rten_hip_graph_end": (_I32, [_VP, C.POINTER(C.c_uint64)]),
+    "rten_hip_graph_abort": (_I32, [_VP]),
     "rten_hip_graph_launch": (_I32, [_VP, C.c_uint64]),
     "rten_hip_graph_destroy": (_I32, [_VP, C.c_uint64]),
     "rten_hip_profile_enable": (_I32, [_VP, _I32]),

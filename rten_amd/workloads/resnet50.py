@@ -75,11 +75,51 @@ def conv_flops_per_image():
     return total
 
 
+def layer_geometry(batch, image=224):
+    """(shapes {tensor: (n, c, h, w)}, descs {layer: Conv2dDesc}) of the static plan for one batch size."""
+    shapes = {"x": (batch, 3, image, image)}
+    descs = {}
+    for l in conv_specs():
+        n, c, h, w = shapes["pool" if l["src"] == "pool" else l["src"]] if l["src"] != "x" else shapes["x"]
+        oh = (h + 2 * l["pad"] - l["k"]) // l["stride"] + 1
+        ow = (w + 2 * l["pad"] - l["k"]) // l["stride"] + 1
+        descs[l["name"]] = L.Conv2dDesc(n, c, h, w, l["cout"], l["k"], l["k"], (C.c_int32 * 4)(l["pad"], l["pad"], l["pad"], l["pad"]),
+                                        l["stride"], l["stride"], 1, 1, 1, oh, ow)
+        shapes[l["dst"]] = (n, l["cout"], oh, ow)
+        if l["dst"] == "stem":
+            ph = (oh + 2 - 3) // 2 + 1
+            shapes["pool"] = (n, l["cout"], ph, ph)
+    return shapes, descs
+
+
+def arena_layout(lib, descs, num_classes=1000):
+    """({name: (weights offset, bias offset)}, total bytes) of the f32 weight arena: [packed conv weights | bias] per layer, then the
+    classifier.  Host arithmetic only (rten_hip_conv2d_f32_packed_bytes touches no device): a rank that merely RECEIVES the arena
+    sizes its buffer with this, without building a network first."""
+    offs, total = {}, 0
+    for l in conv_specs():
+        nb = lib.rten_hip_conv2d_f32_packed_bytes(C.byref(descs[l["name"]]))
+        offs[l["name"]] = (total, total + nb)
+        total += nb + l["cout"] * 4
+        total = (total + 255) & ~255
+    fc_w = num_classes * 2048 * 4
+    offs["fc"] = (total, total + fc_w)
+    total += fc_w + num_classes * 4
+    total = (total + 255) & ~255
+    return offs, total
+
+
+def arena_bytes(lib, batch=32, image=224, num_classes=1000):
+    return arena_layout(lib, layer_geometry(batch, image)[1], num_classes)[1]
+
+
 class ResNet50:
     """Device-resident ResNet-50 forward for a fixed batch size (static plan, optional hipGraph)."""
 
-    def __init__(self, ctx, batch, weights=None, image=224, num_classes=1000, arena_ptr=None, arena_keepalive=None, x_view=None, logits_view=None):
+    def __init__(self, ctx, batch, weights=None, image=224, num_classes=1000, arena_ptr=None, arena_keepalive=None, x_view=None, logits_view=None,
+                 total_batch=None):
         self.ctx, self.batch, self.image, self.num_classes = ctx, batch, image, num_classes
+        self.total_batch = batch if total_batch is None else total_batch  # rows of the classifier product the reference would see (sub-batch chains)
         self._x_view, self._logits_view = x_view, logits_view  # (ptr, keepalive): this net works on a slice of a larger batch
         self.weights = weights if weights is not None else make_weights(num_classes=num_classes)
         self.specs = conv_specs()
@@ -92,30 +132,10 @@ class ResNet50:
     # ---- static plan: shapes, weight arena, activation buffers, launch list
     def _plan(self, arena_ptr, arena_keepalive):
         ctx, N = self.ctx, self.batch
-        shapes = {"x": (N, 3, self.image, self.image)}
-        descs = {}
-        for l in self.specs:
-            n, c, h, w = shapes["pool" if l["src"] == "pool" else l["src"]] if l["src"] != "x" else shapes["x"]
-            oh = (h + 2 * l["pad"] - l["k"]) // l["stride"] + 1
-            ow = (w + 2 * l["pad"] - l["k"]) // l["stride"] + 1
-            descs[l["name"]] = L.Conv2dDesc(n, c, h, w, l["cout"], l["k"], l["k"], (C.c_int32 * 4)(l["pad"], l["pad"], l["pad"], l["pad"]),
-                                            l["stride"], l["stride"], 1, 1, 1, oh, ow)
-            shapes[l["dst"]] = (n, l["cout"], oh, ow)
-            if l["dst"] == "stem":
-                ph = (oh + 2 - 3) // 2 + 1
-                shapes["pool"] = (n, l["cout"], ph, ph)
+        shapes, descs = layer_geometry(N, self.image)
         self.shapes, self.descs = shapes, descs
         # weight arena: [packed conv weights | biases | fc W | fc b], one allocation so it can be broadcast
-        offs, total = {}, 0
-        for l in self.specs:
-            nb = ctx.lib.rten_hip_conv2d_f32_packed_bytes(C.byref(descs[l["name"]]))
-            offs[l["name"]] = (total, total + nb)
-            total += nb + l["cout"] * 4
-            total = (total + 255) & ~255
-        fc_w, fc_b = self.weights["fc"]
-        offs["fc"] = (total, total + fc_w.nbytes)
-        total += fc_w.nbytes + fc_b.nbytes
-        total = (total + 255) & ~255
+        offs, total = arena_layout(ctx.lib, descs, self.num_classes)
         self.arena_bytes = total
         self.arena = DeviceTensor(ctx, (total,), np.uint8, ptr=arena_ptr, keepalive=arena_keepalive)
         self.w_off = offs
@@ -164,7 +184,8 @@ class ResNet50:
         # several rows that equals a per-column bias after the first depth block (what the fused form below does); a ONE-row product
         # takes the reference's gemv kernels, where the bias enters with the first depth block and not at the end, so batch 1 runs
         # the operator's own form: logits <- bias, then gemm(beta = 1).
-        self.fc_gemm_form = N == 1
+        # (decided from the WHOLE batch: a one-image chain of a larger batch must not switch the classifier to the gemv order)
+        self.fc_gemm_form = self.total_batch == 1
         self.fc_desc = (L.gemm_desc(N, self.num_classes, 2048, 2048, 1, 1, 2048, self.num_classes, beta=1.0) if self.fc_gemm_form else
                         L.gemm_desc(N, self.num_classes, 2048, 2048, 1, 1, 2048, self.num_classes, bias_kind=L.BIAS_PER_COL))
 
@@ -237,7 +258,12 @@ class ResNet50:
             ctx.call("rten_hip_memcpy_d2d", self.logits.vp, self._wptr("fc", 1), C.c_size_t(self.num_classes * 4))
             ctx.call("rten_hip_gemm_f32", C.byref(self.fc_desc), self.gap.vp, self._wptr("fc", 0), None, self.logits.vp)
         else:
+            lone_row = self.batch == 1  # a one-image chain of a larger batch: the reference's product has several rows -> the blocked order
+            if lone_row:
+                ctx.call("rten_hip_set_gemv_order", 0, 0)
             ctx.call("rten_hip_gemm_f32", C.byref(self.fc_desc), self.gap.vp, self._wptr("fc", 0), self._wptr("fc", 1), self.logits.vp)
+            if lone_row:
+                ctx.call("rten_hip_set_gemv_order", 1, 0)
 
     def capture(self):
         """Capture the forward pass into a hipGraph (one host call per inference afterwards)."""
@@ -342,7 +368,11 @@ class ChainedResNet50:
 
     POOL = 8
 
-    def __init__(self, ctx, batch, weights=None, chains=4, image=224, num_classes=1000, arena_ptr=None, arena_keepalive=None):
+    def __init__(self, ctx, batch, weights=None, chains=4, image=224, num_classes=1000, arena_ptr=None, arena_keepalive=None, pool=None):
+        """`pool` = number of contexts (streams) the runner owns: `chains` when every stream has a hardware queue of its own
+        (GPU_MAX_HW_QUEUES >= chains, set by bench.py before the runtime starts: no placement search needed), POOL (the default) when
+        tune_placement() is to search for a collision-free set."""
+        self.POOL = self.POOL if pool is None else max(int(pool), chains)
         assert 1 <= chains <= min(batch, self.POOL)
         self.ctx, self.batch, self.chains = ctx, batch, chains
         self.weights = weights if weights is not None else make_weights(num_classes=num_classes)
@@ -356,7 +386,7 @@ class ChainedResNet50:
             a = (arena_ptr, arena_keepalive) if i == 0 else (self.nets[0].arena.ptr, self.nets[0].arena)
             self.nets.append(ResNet50(self.pool[i], self.sizes[i], self.weights, image, num_classes, arena_ptr=a[0], arena_keepalive=a[1],
                                       x_view=(self.x.ptr + self.starts[i] * 3 * image * image * 4, self.x),
-                                      logits_view=(self.logits.ptr + self.starts[i] * num_classes * 4, self.logits)))
+                                      logits_view=(self.logits.ptr + self.starts[i] * num_classes * 4, self.logits), total_batch=batch))
         n0 = self.nets[0]
         self.specs, self.descs, self.arena, self.arena_bytes = n0.specs, n0.descs, n0.arena, n0.arena_bytes
         self.graph = None      # list of per-chain graphs once captured
@@ -426,6 +456,8 @@ class ChainedResNet50:
         from process to process: no window need be collision-free).  Returns [(placement, ms per step)] of everything tried."""
         assert self.graph
         rows = []
+        if self.POOL == self.chains:  # nothing to choose from
+            return rows
 
         def measure(place):
             self.place = list(place)

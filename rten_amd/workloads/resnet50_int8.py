@@ -25,6 +25,25 @@ def quantize_weights(weights):
     return out
 
 
+def i8_arena_layout(lib, batch, pad_mode=L.PAD_RAW0_I8, image=224, num_classes=1000):
+    """({name: (staged weights, w_scale, bias) offsets}, total bytes, fc packed bytes) of the int8 weight arena -- host arithmetic only
+    (the *_packed_bytes functions touch no device), so a rank that receives the arena by broadcast sizes its buffer without building a net."""
+    from .resnet50 import conv_specs, layer_geometry
+    _, descs = layer_geometry(batch, image)
+    offs, total = {}, 0
+    for l in conv_specs():
+        nb = lib.rten_hip_conv2d_int8_packed_bytes(C.byref(L.Conv2dInt8Desc(descs[l["name"]], 0, 1, 0, pad_mode, 1, 1)))
+        if nb == 0:
+            raise RuntimeError("int8 conv geometry not covered by the staged kernel: " + l["name"])
+        offs[l["name"]] = (total, total + nb, total + nb + 256)
+        total = (total + nb + 256 + l["cout"] * 4 + 255) & ~255
+    fc_packed = lib.rten_hip_gemm_int8_packed_bytes(2048, num_classes)
+    fc_nb = fc_packed or 2048 * num_classes
+    offs["fc"] = (total, total + fc_nb, total + fc_nb + 256)
+    total = (total + fc_nb + 256 + num_classes * 4 + 255) & ~255
+    return offs, total, fc_packed
+
+
 class ResNet50Int8(ResNet50):
     def __init__(self, ctx, batch, weights=None, pad_mode=L.PAD_RAW0_I8, i8_arena_ptr=None, i8_arena_keepalive=None, **kw):
         super().__init__(ctx, batch, weights, **kw)
@@ -43,7 +62,8 @@ class ResNet50Int8(ResNet50):
         residuals = {m["res"] for m in self.specs if m["res"]}
         self.qout_next = {m["name"]: readers[m["dst"]][0] for m in self.specs
                           if len(readers.get(m["dst"], [])) == 1 and m["dst"] not in residuals and m["dst"] != "stem"}
-        self._qout_off = set()       # layers whose launch cannot be resident at once on this device (found at the first attempt)
+        self._qout_off = set()       # layers that run the two-launch sequence: grid not resident at once (found at the first attempt), or
+                                     # measured slower by autotune_qout() (the grid-wide exchange costs ~6 us: it pays on the larger tensors only)
         gb = ctx.lib.rten_hip_grid_sync_bytes()
         self.sync_arena = DeviceTensor(ctx, (gb * len(self.specs),), np.uint8)  # initialised once; every launch leaves its block as it found it
         ctx.call("rten_hip_grid_sync_reset", self.sync_arena.vp, len(self.specs))
@@ -78,16 +98,7 @@ class ResNet50Int8(ResNet50):
                                        1, 0, 0, 0, 1 if self.fc_packed_bytes else 0)
         # int8 weight arena: per layer [staged weights + row sums | w_scale f32 | bias f32], then the classifier; ONE allocation so
         # that rank 0 of a batch-sharded job stages it once and RCCL broadcasts it (bench.py --config int8)
-        offs, total = {}, 0
-        for l in self.specs:
-            nb = ctx.lib.rten_hip_conv2d_int8_packed_bytes(C.byref(self.idesc[l["name"]]))
-            if nb == 0:
-                raise RuntimeError("int8 conv geometry not covered by the staged kernel: " + l["name"])
-            offs[l["name"]] = (total, total + nb, total + nb + 256)
-            total = (total + nb + 256 + l["cout"] * 4 + 255) & ~255
-        fc_nb = self.fc_packed_bytes or 2048 * self.num_classes
-        offs["fc"] = (total, total + fc_nb, total + fc_nb + 256)
-        total = (total + fc_nb + 256 + self.num_classes * 4 + 255) & ~255
+        offs, total, _ = i8_arena_layout(ctx.lib, batch, pad_mode, self.image, self.num_classes)
         self.i8_off, self.i8_arena_bytes = offs, total
         self.i8_arena = DeviceTensor(ctx, (total,), np.uint8, ptr=i8_arena_ptr, keepalive=i8_arena_keepalive)
         for name, (a, b, c) in offs.items():
@@ -129,6 +140,15 @@ class ResNet50Int8(ResNet50):
         ctx, name = self.ctx, l["name"]
         d, cv = self.idesc[name], self.idesc[name].conv
         geom = (l["src"], cv.c, cv.h, cv.w, tuple(cv.pads))
+        flags = (L.CONV_RELU if l["relu"] else 0) | (L.CONV_RESIDUAL if l["res"] else 0)
+        res = self._act(l["res"]).vp if l["res"] else None
+        st_in = self.stats.get(l["src"]) if self.producer_stats else None
+        if (self.fused_dql and self.fused_layers and name in self.fused_layers and st_in is not None and self._prestaged != name and self._staged_key != geom
+                and cv.kh == 1 and cv.kw == 1 and cv.stride_h == 1 and cv.stride_w == 1 and not any(cv.pads) and cv.c % 64 == 0):
+            # a pointwise layer autotune() found faster with DynamicQuantizeLinear inside its own operand loader (no staged tensor at all)
+            ctx.call("rten_hip_conv2d_int8_dql", C.byref(d), self._act(l["src"]).vp, st_in, self.wq[name].vp, self.ws[name].vp, self.bq[name].vp, res, flags,
+                     self._act(l["dst"]).vp, self.stats[l["dst"]], None, None)
+            return
         if self._prestaged == name:      # the producing conv quantized this input in its epilogue, scale product included
             pass
         elif self._staged_key == geom:   # same tensor, same staged layout as the previous conv: only the Mul(x_scale, w_scale) differs
@@ -145,8 +165,6 @@ class ResNet50Int8(ResNet50):
                          self.scs[self._cur].vp)
         self._staged_key, self._prestaged = geom, None
         (staged, xs, xz), sc = self.qsets[self._cur], self.scs[self._cur]
-        flags = (L.CONV_RELU if l["relu"] else 0) | (L.CONV_RESIDUAL if l["res"] else 0)
-        res = self._act(l["res"]).vp if l["res"] else None
         nxt = self.qout_next.get(name)
         if nxt is not None and name not in self._qout_off:
             other = 1 - self._cur
@@ -165,6 +183,58 @@ class ResNet50Int8(ResNet50):
             ctx.call("rten_hip_conv2d_int8_stats", *args, self.stats[l["dst"]])
         else:
             ctx.call("rten_hip_conv2d_int8", *args)
+
+    def autotune_qout(self, reps=5):
+        """Per single-consumer edge: the quantized-output launch against conv + the consumer's staging launch, timed back to back; edges
+        where one launch is not at least 3 % faster keep the two launches.  Returns {layer: (two launches us, one launch us or None)}."""
+        ctx = self.ctx
+        saved, self.fused_qout = self.fused_qout, False
+        self.forward()  # every layer's quantized input / statistics exist
+        ctx.sync()
+        self.fused_qout = saved
+        table = {}
+
+        def timed(fn):
+            fn()
+            best = 1e30
+            for _ in range(2):
+                ctx.timer_start(1)
+                for _ in range(reps):
+                    fn()
+                ctx.timer_stop(1)
+                best = min(best, ctx.timer_ms(1) / reps * 1e3)
+            return best
+        for l in self.specs:
+            name, nxt = l["name"], self.qout_next.get(l["name"])
+            if nxt is None:
+                continue
+            d, nd = self.idesc[name], self.idesc[nxt["name"]]
+            (staged, xs, xz), (ostaged, oxs, oxz) = self.qsets
+            st = self.stats.get(l["src"])
+            src = self._act(l["src"])
+            if st is not None:
+                ctx.call("rten_hip_dynamic_quantize_linear_staged_stats", C.byref(d), src.vp, st, staged.vp, xs.vp, xz.vp, self.ws[name].vp, self.scs[0].vp)
+            else:
+                ctx.call("rten_hip_dynamic_quantize_linear_staged", C.byref(d), src.vp, staged.vp, xs.vp, xz.vp, self.ws[name].vp, self.scs[0].vp)
+            flags = (L.CONV_RELU if l["relu"] else 0) | (L.CONV_RESIDUAL if l["res"] else 0)
+            res = self._act(l["res"]).vp if l["res"] else None
+            dst, dstat = self._act(l["dst"]), self.stats[l["dst"]]
+
+            def two():
+                ctx.call("rten_hip_conv2d_int8_stats", C.byref(d), staged.vp, self.wq[name].vp, xz.vp, None, self.scs[0].vp, self.bq[name].vp, res, flags, dst.vp, dstat)
+                ctx.call("rten_hip_dynamic_quantize_linear_staged_stats", C.byref(nd), dst.vp, dstat, ostaged.vp, oxs.vp, oxz.vp, self.ws[nxt["name"]].vp, self.scs[1].vp)
+
+            def one():
+                return ctx.lib.rten_hip_conv2d_int8_qout(ctx.h, C.byref(d), staged.vp, self.wq[name].vp, xz.vp, None, self.scs[0].vp, self.bq[name].vp, res, flags, None,
+                                                         dstat, self.syncs[name], C.byref(nd), ostaged.vp, oxs.vp, oxz.vp, self.ws[nxt["name"]].vp, self.scs[1].vp)
+            us2 = timed(two)
+            us1 = timed(one) if one() == L.OK else None
+            table[name] = (us2, us1)
+            if us1 is None or us1 > us2 * 0.97:
+                self._qout_off.add(name)
+            else:
+                self._qout_off.discard(name)
+        return table
 
     def qout_timeouts(self):
         """Number of quantized-output launches that gave up waiting for their grid (0 unless the residency assumption broke)."""

@@ -37,3 +37,33 @@ def test_bench_two_ranks_prints_one_line(config):
     assert j["ranks"]["world_size"] == 2 and len(j["ranks"]["ms_per_step_per_rank"]) == 2 and j["ranks"]["weight_broadcast_world"] == 2
     assert j["cpu_baseline"] is None and j["roofline"]["frac"] > 0
     assert j["config"]["batch_chains"]["chains"] == (4 if config == "f32" else 1)
+    # every rank ran the same launch plan, and rank r's logits are the oracle's for ITS shard (inputs seeded 1234 + r): the parity
+    # definition of a batch-sharded run -- for int8 each shard quantizes with its own statistics, like an independent run
+    import hashlib
+
+    import numpy as np
+    from oracle import models as omodels
+    from rten_amd.workloads import resnet50
+    assert len(set(j["ranks"]["plan_sha16_per_rank"])) == 1
+    w = resnet50.make_weights()
+    for r, (sha, seed) in enumerate(zip(j["ranks"]["logits_sha16_per_rank"], j["ranks"]["input_seed_per_rank"])):
+        assert seed == 1234 + r
+        x = np.random.default_rng(seed).random((32, 3, 224, 224), dtype=np.float32)
+        want = (omodels.resnet50_int8_forward(resnet50.conv_specs(), omodels.quantize_weights_int8(w), x) if config == "int8" else
+                omodels.resnet50_forward(resnet50.conv_specs(), w, x))
+        assert hashlib.sha256(np.ascontiguousarray(want.astype(np.float32)).tobytes()).hexdigest()[:16] == sha, f"rank {r}: logits differ from the oracle's for its shard"
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_tuning_run_broadcasts_one_plan():
+    """--autotune with two ranks: rank 0 tunes, the plan is broadcast, both ranks report the same plan hash (no per-rank tuning)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(RTEN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT="29565")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "int8", "--autotune"], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    shas = j["ranks"]["plan_sha16_per_rank"]
+    assert len(shas) == 2 and shas[0] == shas[1] and shas[0] is not None
+    assert "rank 0" in j["config"]["launch_plan"]["source"]

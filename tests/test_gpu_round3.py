@@ -1,7 +1,7 @@
 """Round-3 parity tests (all through the C ABI, on the GPU).
 
   * rten_hip_conv2d_int8_qout: ConvIntegerToFloat with the DynamicQuantizeLinear of its single consumer in the epilogue (one launch,
-    grid-wide min / max behind an arrival barrier) against the two operators run separately -- staged codes byte for byte (border
+    grid-wide min / max all-gather) against the two operators run separately -- staged codes byte for byte (border
     pieces included), scale, zero point, scale product, optional f32 output -- and int8 ResNet-50 at batch 32 with those launches on.
 """
 import ctypes as C
@@ -64,11 +64,14 @@ def test_conv2d_int8_qout_matches_the_separate_operators(ctx, case):
     staged_in = DeviceTensor(ctx, (lib.rten_hip_conv2d_int8_staged_bytes(C.byref(d)),), np.uint8)
     xs, xz, sc = DeviceTensor(ctx, (1,), np.float32), DeviceTensor(ctx, (1,), np.uint8), DeviceTensor(ctx, (o if per_ch else 1,), np.float32)
     ws = dev(ctx, (rng.f32(o if per_ch else 1) * 0.01 + 0.002).astype(np.float32))
-    ctx.call("rten_hip_dynamic_quantize_linear_staged", C.byref(d), dev(ctx, xf).vp, staged_in.vp, xs.vp, xz.vp, None, None)
+    xfd = dev(ctx, xf)  # (named: a temporary would be freed before the launch reads it)
+    ctx.call("rten_hip_dynamic_quantize_linear_staged", C.byref(d), xfd.vp, staged_in.vp, xs.vp, xz.vp, None, None)
     ctx.call("rten_hip_mul_f32", o if per_ch else 1, ws.vp, xs.vp, 1, sc.vp)
     wq = rng.i8(o * c * k * k, reduced=True).reshape(o, c, k, k)
     packed = DeviceTensor(ctx, (lib.rten_hip_conv2d_int8_packed_bytes(C.byref(d)),), np.uint8)
-    ctx.call("rten_hip_conv2d_int8_prepack", C.byref(d), dev(ctx, wq).vp, packed.vp)
+    wqd = dev(ctx, wq)
+    ctx.call("rten_hip_conv2d_int8_prepack", C.byref(d), wqd.vp, packed.vp)
+    ctx.sync()
     bias = dev(ctx, rng.f32(o) - 0.5)
     res = dev(ctx, rng.f32(n * o * oh * ow).reshape(n, o, oh, ow) - 0.5) if with_res else None
     flags = L.CONV_RELU | (L.CONV_RESIDUAL if with_res else 0)
@@ -168,3 +171,19 @@ def test_resnet50_int8_batch32_quantized_output_launches(ctx):
     net2.forward()
     bits_equal(net2.logits.numpy(), omodels.resnet50_int8_forward(net.specs, omodels.quantize_weights_int8(w), x, pad_mode=ref.PAD_ZERO_POINT))
     assert net2.qout_timeouts() == 0
+
+
+def test_chained_resnet50_with_one_image_chains_keeps_the_blocked_classifier(ctx):
+    """Batch 5 as 4 chains = sub-batches of 2, 1, 1, 1 images: the one-image chains must NOT run the classifier in the reference's
+    one-row (gemv) order -- the reference's product has 5 rows -- so the logits stay the single-chain / oracle bits."""
+    from oracle import models as omodels
+    from rten_amd.workloads import resnet50
+    w = resnet50.make_weights()
+    x = ref.XorShiftRng(78).f32(5 * 3 * 224 * 224).reshape(5, 3, 224, 224)
+    net = resnet50.ChainedResNet50(ctx, 5, w, chains=4)
+    assert net.sizes == [2, 1, 1, 1]
+    net.upload_weights()
+    net.x.upload(x)
+    net.forward()
+    net.sync()
+    bits_equal(net.logits.numpy(), omodels.resnet50_forward(net.specs, w, x))

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --load-plan ... --no-graph` into HBM bytes per
 launch per kernel (FETCH_SIZE doubled per MI355X_MICROARCH.md: gfx950 reports half of wide coalesced reads; both
-counters are in KiB).   usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> > out.json"""
-import collections, csv, json, re, sys
+counters are in KiB).   usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> [plan.json] > out.json
+With plan.json the output carries the plan's sha16 (bench.py reports the traffic figure only for the very plan it was measured under)."""
+import collections, csv, hashlib, json, re, sys
 
 
 def norm(name):
@@ -30,5 +31,6 @@ out = {}
 for k in sorted(set(fe) | set(wr)):
     n = max(fe[k][0], wr[k][0], 1)
     out[k] = {"launches": n, "hbm_read_bytes_per_launch": round(2 * 1024 * fe[k][1] / n), "hbm_write_bytes_per_launch": round(1024 * wr[k][1] / n)}
-json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 (gfx950 correction), eager replay of the tuned plan",
+plan_sha = hashlib.sha256(json.dumps(json.load(open(sys.argv[3])), sort_keys=True).encode()).hexdigest()[:16] if len(sys.argv) > 3 else None
+json.dump({"plan_sha16": plan_sha, "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 (gfx950 correction), eager replay of the tuned plan",
            "kernels": out}, sys.stdout, indent=1)
