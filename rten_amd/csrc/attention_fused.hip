@@ -208,12 +208,208 @@ __global__ __launch_bounds__(256, 2) void sdpa_fused_kernel(const SdpaArgs p) {
         }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// General form: head size HD in {32, 64, 128}, up to 128 * NCH <= 512 keys.  Same mapping and the same operation sequence per output
+// element as the kernel above (sdpa_head, src/ops/attention.rs:518-562: scores = gemm(alpha = scale), += mask, softmax with the
+// reference's ordered partial sums, out = gemm), with the key axis walked in chunks of 128 through ONE LDS buffer: K chunk c feeds
+// score blocks 4c .. 4c+3 (all NJ = 4 NCH blocks of a query row stay in the registers of one lane pair -- the reference's softmax
+// is three passes over the whole row, not an online one, so nothing may be rescaled), V chunk c then takes K's place for PV.
+// PV over more than 256 keys crosses the reference's depth-block boundary (kc = 256, rten-gemm/src/lib.rs:630-633): keys 0-255 and
+// 256-511 are separate MFMA chains from zero, combined with one separate add (lib.rs:1008-1013), as everywhere else in this backend.
+// 128 KB of LDS at HD = 128 and up to ~400 VGPRs: one workgroup per CU.
+extern __shared__ __attribute__((aligned(16))) float sdpa_smem[];
+template <int HD, int NCH>
+__global__ __launch_bounds__(256, 1) void sdpa_fused_general_kernel(const SdpaArgs p) {
+    constexpr int NJ = 4 * NCH, DQ = HD / 4, NO = HD / 32;
+    float *const Qs = sdpa_smem, *const Ks = sdpa_smem + DQ * SQ * 4, *const Vs = Ks; // Qs [DQ][SQ][4] | Ks [DQ][128][4] -> Vs [128][HD]
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int st = blockIdx.x % p.s_tiles, bh = blockIdx.x / p.s_tiles;
+    const int b = bh / p.heads, h = bh - b * p.heads;
+    const int s0 = st * SQ;
+    const float *qb = p.q + (long long)b * p.q_bs + (long long)h * p.q_hs;
+    const float *kb = p.k + (long long)b * p.k_bs + (long long)h * p.k_hs;
+    const float *vb = p.v + (long long)b * p.v_bs + (long long)h * p.v_hs;
+    float *ob = p.out + (long long)b * p.o_bs + (long long)h * p.o_hs;
+
+#pragma unroll
+    for (int i = 0; i < SQ * DQ / 256; i++) {
+        const int f = i * 256 + t, row = f / DQ, dq = f % DQ;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (s0 + row < p.s) v = *reinterpret_cast<const f32x4 *>(qb + (long long)(s0 + row) * p.q_rs + dq * 4);
+        *reinterpret_cast<f32x4 *>(Qs + (dq * SQ + row) * 4) = v;
+    }
+
+    // ---- phase 1: S^T[t][s] for this wave's 32 query columns, key chunk by key chunk (k = d ascending: one depth block)
+    f32x16 sc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) sc[j][r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        if (c > 0) __syncthreads(); // everybody is done with the previous K chunk
+#pragma unroll
+        for (int i = 0; i < TT * DQ / 256; i++) {
+            const int f = i * 256 + t, row = f / DQ, dq = f % DQ;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (c * TT + row < p.t) v = *reinterpret_cast<const f32x4 *>(kb + (long long)(c * TT + row) * p.k_rs + dq * 4);
+            *reinterpret_cast<f32x4 *>(Ks + (dq * TT + row) * 4) = v;
+        }
+        __syncthreads();
+        const float *Ak = Ks + l31 * 4 + half;
+        const float *Bq = Qs + (wave * 32 + l31) * 4 + half;
+#pragma unroll 4
+        for (int kk = 0; kk < HD / 2; kk++) {
+            const float bq = Bq[(kk >> 1) * SQ * 4 + ((2 * kk) & 3)];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float ak = Ak[(kk >> 1) * TT * 4 + ((2 * kk) & 3) + j * 32 * 4];
+                sc[4 * c + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ak, bq, sc[4 * c + j], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- phase 2: softmax of query row s0 + 32 wave + l31 (this lane and lane ^ 32); sc[j][r] is key 32j + acc_row(r) + 4 half
+    const int srow = s0 + wave * 32 + l31;
+    const float *mrow = nullptr;
+    if (p.mask) mrow = p.mask + (long long)b * p.mask_bs + (long long)(srow < p.s ? srow : 0) * p.mask_rs;
+    float mx = -3.40282347e+38f; // f32::MIN (softmax.rs:181)
+#pragma unroll
+    for (int j = 0; j < NJ; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int tk = 32 * j + acc_row(r) + 4 * half;
+            float v = sc[j][r] * p.scale;
+            if (mrow && tk < p.t) v = v + mrow[tk];
+            sc[j][r] = v;
+            if (tk < p.t) mx = fmaxf(mx, v);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float lo[4] = {0.f, 0.f, 0.f, 0.f}, hi[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NJ; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int tk = 32 * j + acc_row(r) + 4 * half;
+            sc[j][r] = tk < p.t ? vm::exp_reduced(sc[j][r] - mx) : 0.f;
+        }
+#pragma unroll
+    for (int j = 0; j < NJ; j++)
+#pragma unroll
+        for (int g = 0; g < 2; g++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                lo[c] = lo[c] + sc[j][8 * g + c];
+                hi[c] = hi[c] + sc[j][8 * g + 4 + c];
+            }
+    auto add4 = [](float x, const float (&a)[4]) { return (((x + a[0]) + a[1]) + a[2]) + a[3]; };
+    float run = add4(0.f, lo);
+    run = add4(__shfl_xor(run, 32, 64), lo);
+    run = add4(__shfl_xor(run, 32, 64), hi);
+    run = add4(__shfl_xor(run, 32, 64), hi);
+    const float other = __shfl_xor(run, 32, 64);
+    const float ssum = half ? run : other;
+    const float inv = 1.0f / ssum;
+#pragma unroll
+    for (int j = 0; j < NJ; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int tk = 32 * j + acc_row(r) + 4 * half;
+            float pr = sc[j][r] * inv;
+            if (p.flush_nan && !(pr == pr)) pr = 0.f;
+            sc[j][r] = tk < p.t ? pr : 0.f;
+        }
+#pragma unroll
+    for (int j = 0; j < NJ; j++)
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+#pragma unroll
+            for (int c = 0; c < 4; c += 2) {
+                const float r0 = sc[j][4 * g + c], r1 = sc[j][4 * g + c + 1];
+                const unsigned u0 = __float_as_uint(r0), u1 = __float_as_uint(r1);
+                const auto sw = __builtin_amdgcn_permlane32_swap(u0, u1, false, false);
+                const unsigned n0 = sw[0], n1 = sw[1];
+                sc[j][4 * g + c] = __uint_as_float(n0);
+                sc[j][4 * g + c + 1] = __uint_as_float(n1);
+            }
+
+    // ---- phase 3: out[s][dv] = sum_t P[s][t] V[t][dv], t ascending, V chunk by V chunk; depth blocks of 256 keys folded with separate adds
+    f32x16 oc[NO], tot[NCH > 2 ? NO : 1];
+#pragma unroll
+    for (int jn = 0; jn < NO; jn++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) oc[jn][r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        __syncthreads(); // K chunk / previous V chunk no longer read
+#pragma unroll
+        for (int i = 0; i < TT * DQ / 256; i++) {
+            const int f = i * 256 + t, row = f / DQ, dq = f % DQ;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (c * TT + row < p.t) v = *reinterpret_cast<const f32x4 *>(vb + (long long)(c * TT + row) * p.v_rs + dq * 4);
+            *reinterpret_cast<f32x4 *>(Vs + row * HD + dq * 4) = v;
+        }
+        __syncthreads();
+        if constexpr (NCH > 2) {
+            if (c == 2) { // keys 0..255 were the first depth block: park it, start the second chain from zero
+#pragma unroll
+                for (int jn = 0; jn < NO; jn++) {
+                    tot[jn] = oc[jn];
+#pragma unroll
+                    for (int r = 0; r < 16; r++) oc[jn][r] = 0.f;
+                }
+            }
+        }
+        const float *Bv = Vs + half * HD + l31;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int kl = 0; kl < 16; kl++) {
+                const int t0 = 2 * kl, g = t0 >> 3, off = t0 & 7;
+                const float a = sc[4 * c + j][off < 4 ? 4 * g + off : 4 * g + (off - 4) + 1];
+#pragma unroll
+                for (int jn = 0; jn < NO; jn++) oc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bv[(32 * j + t0) * HD + jn * 32], oc[jn], 0, 0, 0);
+            }
+    }
+    if constexpr (NCH > 2) {
+        if (p.t > 256) { // (with <= 256 real keys the second chain only saw zero-filled rows: the reference has one depth block then)
+#pragma unroll
+            for (int jn = 0; jn < NO; jn++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) oc[jn][r] = tot[jn][r] + oc[jn][r];
+        } else {
+#pragma unroll
+            for (int jn = 0; jn < NO; jn++) oc[jn] = tot[jn];
+        }
+    }
+#pragma unroll
+    for (int jn = 0; jn < NO; jn++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = s0 + wave * 32 + acc_row(r) + 4 * half;
+            if (row < p.s) ob[(long long)row * p.o_rs + jn * 32 + l31] = oc[jn][r];
+        }
+}
+
+template <int HD, int NCH>
+void launch_general(rten_hip_ctx *ctx, const SdpaArgs &a, long long wgs) {
+    constexpr size_t lds = (size_t)(SQ + TT) * HD * sizeof(float);
+    auto kern = sdpa_fused_general_kernel<HD, NCH>;
+    if (lds > 64 * 1024) hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(256), lds, ctx->stream, a);
+}
+
 } // namespace
 
 // Returns RTEN_HIP_ERR_UNSUPPORTED when the shape is not covered (the caller falls back to the composed path).
 int32_t rten_sdpa_fused(rten_hip_ctx *ctx, const rten_hip_sdpa_desc *d, const float *q, const float *k, const float *v, const float *mask, float *out) {
     auto al16 = [](const void *p) { return ((uintptr_t)p & 15u) == 0; };
-    if (d->d != HD || d->dv != HD || d->t > TT || d->t < 1) return RTEN_HIP_ERR_UNSUPPORTED;
+    const bool fast = d->d == HD && d->dv == HD && d->t <= TT;                                             // BERT-base: head 64, <= 128 keys
+    const bool general = d->d == d->dv && (d->d == 32 || d->d == 64 || d->d == 128) && d->t <= 4 * TT;    // head 32 / 64 / 128, <= 512 keys
+    if (d->t < 1 || (!fast && !general)) return RTEN_HIP_ERR_UNSUPPORTED;
     const int64_t strides[] = {d->q_bs, d->q_hs, d->q_rs, d->k_bs, d->k_hs, d->k_rs, d->v_bs, d->v_hs, d->v_rs};
     for (int64_t s : strides)
         if (s % 4 != 0) return RTEN_HIP_ERR_UNSUPPORTED;
@@ -228,8 +424,22 @@ int32_t rten_sdpa_fused(rten_hip_ctx *ctx, const rten_hip_sdpa_desc *d, const fl
     a.s_tiles = (d->s + SQ - 1) / SQ;
     const long long wgs = (long long)d->batch * d->heads * a.s_tiles;
     const double flops = 2.0 * d->batch * d->heads * (double)d->s * d->t * (d->d + d->dv);
-    ProfScope ps(ctx, "sdpa_fused_kernel", flops, 4.0 * d->batch * d->heads * ((double)d->s * (d->d + d->dv) + (double)d->t * (d->d + d->dv)));
-    hipLaunchKernelGGL(sdpa_fused_kernel, dim3((unsigned)wgs), dim3(256), 0, ctx->stream, a);
+    const double bytes = 4.0 * d->batch * d->heads * ((double)d->s * (d->d + d->dv) + (double)d->t * (d->d + d->dv));
+    if (fast) {
+        ProfScope ps(ctx, "sdpa_fused_kernel", flops, bytes);
+        hipLaunchKernelGGL(sdpa_fused_kernel, dim3((unsigned)wgs), dim3(256), 0, ctx->stream, a);
+    } else {
+        ProfScope ps(ctx, "sdpa_fused_general_kernel", flops, bytes);
+        const int nch = (d->t + TT - 1) / TT; // 1 .. 4 chunks of 128 keys (3 runs as 4: the fourth chunk is zero-filled)
+#define RTEN_SDPA_CASE(HDV)                                                        \
+        if (nch <= 1) launch_general<HDV, 1>(ctx, a, wgs);                         \
+        else if (nch == 2) launch_general<HDV, 2>(ctx, a, wgs);                    \
+        else launch_general<HDV, 4>(ctx, a, wgs)
+        if (d->d == 32) { RTEN_SDPA_CASE(32); }
+        else if (d->d == 64) { RTEN_SDPA_CASE(64); }
+        else { RTEN_SDPA_CASE(128); }
+#undef RTEN_SDPA_CASE
+    }
     RTEN_LAUNCH_CHECK(ctx, "sdpa_fused_kernel launch");
     return RTEN_HIP_OK;
 }

@@ -824,8 +824,10 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
                 for (int g = 0; g < 4; g++) {
                     d[g] = 0;
 #pragma unroll
-                    for (int b = 0; b < 4; b++)
-                        d[g] |= ((dql::quant_u8(__builtin_bit_cast(float, acc[i][j][4 * g + b]), q.inv_scale, q.zp) ^ 0x80u) & 0xffu) << (8 * b);
+                    for (int b = 0; b < 4; b++) {
+                        const int bits = acc[i][j][4 * g + b]; // (copied to a scalar first: a bit_cast applied directly to an ext-vector element reads element 0 under this compiler)
+                        d[g] |= ((dql::quant_u8(__int_as_float(bits), q.inv_scale, q.zp) ^ 0x80u) & 0xffu) << (8 * b);
+                    }
                 }
                 const auto s02 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false); // {lower: own d0 | upper: partner's d2}, {partner's d0 | own d2}
                 const auto s13 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);

@@ -187,3 +187,45 @@ def test_chained_resnet50_with_one_image_chains_keeps_the_blocked_classifier(ctx
     net.forward()
     net.sync()
     bits_equal(net.logits.numpy(), omodels.resnet50_forward(net.specs, w, x))
+
+
+@pytest.mark.parametrize("hd", [32, 64, 128])
+def test_sdpa_fused_general_shapes_bit_exact(ctx, hd):
+    """The one-kernel attention path beyond BERT-base's shape (missing 2): head size 32 / 64 / 128, up to 512 keys walked in
+    chunks of 128, PV across the reference's depth-block boundary at 256 keys -- against the oracle's sdpa (sdpa_head,
+    src/ops/attention.rs:518-562) and against the composed GEMM / softmax / GEMM path, bit for bit; ragged lengths, both mask forms, fully
+    masked rows with and without the NaN flush."""
+    rng = ref.XorShiftRng(97 + hd)
+    scale = np.float32(1.0 / np.sqrt(hd))
+    for (B, H, S, T) in ((1, 2, 40, 200), (2, 2, 130, 256), (1, 1, 128, 257), (1, 2, 33, 300), (1, 1, 64, 512), (2, 1, 200, 384), (1, 3, 17, 129)):
+        q = rng.f32(B * H * S * hd).reshape(B, H, S, hd) - 0.5
+        k = rng.f32(B * H * T * hd).reshape(B, H, T, hd) - 0.5
+        v = rng.f32(B * H * T * hd).reshape(B, H, T, hd) - 0.5
+        m1 = np.where(rng.f32(B * T).reshape(B, 1, 1, T) > 0.3, 0.0, -np.inf).astype(np.float32)
+        m1[0, 0, 0, :] = -np.inf
+        m2 = ((rng.f32(B * S * T).reshape(B, 1, S, T) - 0.5) * 4).astype(np.float32)
+        qd, kd, vd = dev(ctx, q), dev(ctx, k), dev(ctx, v)
+        for m in (None, m1, m2):
+            md = dev(ctx, m) if m is not None else None
+            for flush in (True, False):
+                mbs, mrs = (0, 0) if m is None else ((T, 0) if m.shape[2] == 1 else (S * T, T))
+                d = L.SdpaDesc(B, H, S, T, hd, hd, H * S * hd, S * hd, hd, H * T * hd, T * hd, hd, H * T * hd, T * hd, hd, H * S * hd, S * hd, hd,
+                               mbs, mrs, float(scale), 1 if flush else 0)
+                want = ref.sdpa(q, k, v, mask=m, scale=scale, lanes=16, flush_nan=flush)
+                outs = []
+                for path in (0, 1):
+                    ctx.call("rten_hip_set_sdpa_path", path)
+                    try:
+                        out = DeviceTensor(ctx, (B, H, S, hd), np.float32)
+                        ctx.profile_reset()
+                        ctx.profile(True)
+                        ctx.call("rten_hip_sdpa_f32", C.byref(d), qd.vp, kd.vp, vd.vp, md.vp if md is not None else None, out.vp)
+                        ctx.sync()
+                        ctx.profile(False)
+                        kernels = {r["kernel"] for r in ctx.profile_report()}
+                    finally:
+                        ctx.call("rten_hip_set_sdpa_path", 0)
+                    assert ("sdpa_fused_general_kernel" in kernels) == (path == 0), kernels  # the shape really took the path under test
+                    outs.append(out.numpy())
+                bits_equal(outs[0], want)
+                bits_equal(outs[1], want)
