@@ -392,7 +392,9 @@ def main():
     plan, plan_source = None, "backend defaults (no plan)"
     default_plan = os.path.join(ROOT, "profiles", "plans", "int8.json" if int8 else f"f32_{chains}chain{'s' if chains > 1 else ''}.json")
     if int8:
-        net.fused_qout = not args.no_qout
+        # quantized-output launches need every workgroup of a launch resident at once: not when several ranks share ONE GPU (the gloo test
+        # mode) -- on a real multi-GPU node every rank has a device to itself
+        net.fused_qout = not args.no_qout and (world == 1 or backend == "nccl")
     if args.load_plan:
         plan, plan_source = json.load(open(args.load_plan)), os.path.relpath(os.path.abspath(args.load_plan), ROOT)
     elif not args.autotune and not args.no_autotune and os.path.exists(default_plan):
@@ -476,6 +478,10 @@ def main():
         box = [None] * world
         dist.all_gather_object(box, shard_report[0])
         shard_report = sorted(box)
+
+    if int8 and net.qout_timeouts():
+        print("bench.py: a quantized-output launch gave up waiting for its grid (workgroups not all resident): results are void", file=sys.stderr)
+        return 3
 
     # ---- p50 latency per batch (separate pass, host-timed per step)
     lat = []
@@ -623,6 +629,7 @@ def main():
         }
         if int8:
             out["config"]["quantize_on_load_layers"] = sorted(net.fused_layers) if getattr(net, "fused_layers", None) else []
+            out["config"]["quantized_output_launches"] = sorted(set(net.qout_next) - net._qout_off) if net.fused_qout else []
             out["config"]["int8_pad_mode"] = ("RAW0_I8 -- ASSUMPTION: padded taps of an integer convolution hold raw 0 after the u8->i8 shift, the x86 reference's im2col behaviour "
                                               "(rten-gemm/src/im2col.rs:340-358, SURVEY App. C.1); unpinned by a reference-held vector; ZERO_POINT / RAW0_U8 are the other modes of the ABI")
         if n_gpus == 1 and not args.no_cpu_baseline:

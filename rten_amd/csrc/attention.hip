@@ -39,9 +39,11 @@ RTEN_EXPORT int32_t rten_hip_sdpa_f32(rten_hip_ctx *ctx, const rten_hip_sdpa_des
         if (rc != RTEN_HIP_ERR_UNSUPPORTED) return rc;
     }
     const size_t score_bytes = (size_t)bh * d->s * (size_t)d->t * sizeof(float);
-    float *scores = (float *)rten_scratch(ctx, score_bytes + 256);
+    // (the auxiliary scratch: the GEMMs called below own `scratch` -- a PV product over more than 256 keys may park split-K slabs there,
+    // which used to overwrite the scores it was reading: wrong results for 256 < T < 512 on the composed path until round 3)
+    float *scores = (float *)rten_aux_scratch(ctx, score_bytes + 256);
     if (!scores) return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "sdpa: scratch allocation failed (warm up before capture)");
-    scores += 64; // first 256 B of the scratch are the DQL min/max words
+    scores += 64;
 
     rten_hip_gemm_desc g = {};
     // scores = scale * Q K^T   (attention.rs:533-544)

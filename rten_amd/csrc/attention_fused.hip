@@ -322,6 +322,9 @@ __global__ __launch_bounds__(256, 1) void sdpa_fused_general_kernel(const SdpaAr
             if (p.flush_nan && !(pr == pr)) pr = 0.f;
             sc[j][r] = tk < p.t ? pr : 0.f;
         }
+    // re-pair into MFMA A operands (register 4g+c: keys (8g+c | 8g+c+1) in (half 0 | half 1), register 4g+c+1: keys (8g+4+c | 8g+4+c+1)):
+    // one cross-half exchange per register pair.  (__shfl_xor rather than the v_permlane32_swap of the kernel above: with all 256 VGPRs
+    // holding the score row, the builtin's in-place pair was mis-allocated by this compiler -- two keys per chunk were dropped at HD = 128.)
 #pragma unroll
     for (int j = 0; j < NJ; j++)
 #pragma unroll
@@ -329,69 +332,73 @@ __global__ __launch_bounds__(256, 1) void sdpa_fused_general_kernel(const SdpaAr
 #pragma unroll
             for (int c = 0; c < 4; c += 2) {
                 const float r0 = sc[j][4 * g + c], r1 = sc[j][4 * g + c + 1];
-                const unsigned u0 = __float_as_uint(r0), u1 = __float_as_uint(r1);
-                const auto sw = __builtin_amdgcn_permlane32_swap(u0, u1, false, false);
-                const unsigned n0 = sw[0], n1 = sw[1];
-                sc[j][4 * g + c] = __uint_as_float(n0);
-                sc[j][4 * g + c + 1] = __uint_as_float(n1);
+                const float recv = __shfl_xor(half ? r0 : r1, 32, 64); // lower half receives the partner's r0, upper half the partner's r1
+                sc[j][4 * g + c] = half ? recv : r0;
+                sc[j][4 * g + c + 1] = half ? r1 : recv;
             }
 
     // ---- phase 3: out[s][dv] = sum_t P[s][t] V[t][dv], t ascending, V chunk by V chunk; depth blocks of 256 keys folded with separate adds
-    f32x16 oc[NO], tot[NCH > 2 ? NO : 1];
+    // (HD = 128 with 512 keys: two passes over the output width, 64 columns each -- the score row already fills the VGPR file and
+    // 2 x 64 more accumulator registers do not fit beside it; V chunks are staged again for the second pass, from L2)
+    constexpr int NPASS = (HD == 128 && NCH == 4) ? 2 : 1, NOP = NO / NPASS;
 #pragma unroll
-    for (int jn = 0; jn < NO; jn++)
+    for (int pass = 0; pass < NPASS; pass++) {
+        f32x16 oc[NOP], tot[NCH > 2 ? NOP : 1];
 #pragma unroll
-        for (int r = 0; r < 16; r++) oc[jn][r] = 0.f;
+        for (int jn = 0; jn < NOP; jn++)
 #pragma unroll
-    for (int c = 0; c < NCH; c++) {
-        __syncthreads(); // K chunk / previous V chunk no longer read
+            for (int r = 0; r < 16; r++) oc[jn][r] = 0.f;
 #pragma unroll
-        for (int i = 0; i < TT * DQ / 256; i++) {
-            const int f = i * 256 + t, row = f / DQ, dq = f % DQ;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (c * TT + row < p.t) v = *reinterpret_cast<const f32x4 *>(vb + (long long)(c * TT + row) * p.v_rs + dq * 4);
-            *reinterpret_cast<f32x4 *>(Vs + row * HD + dq * 4) = v;
-        }
-        __syncthreads();
-        if constexpr (NCH > 2) {
-            if (c == 2) { // keys 0..255 were the first depth block: park it, start the second chain from zero
+        for (int c = 0; c < NCH; c++) {
+            __syncthreads(); // K chunk / previous V chunk no longer read
 #pragma unroll
-                for (int jn = 0; jn < NO; jn++) {
-                    tot[jn] = oc[jn];
+            for (int i = 0; i < TT * DQ / 256; i++) {
+                const int f = i * 256 + t, row = f / DQ, dq = f % DQ;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (c * TT + row < p.t) v = *reinterpret_cast<const f32x4 *>(vb + (long long)(c * TT + row) * p.v_rs + dq * 4);
+                *reinterpret_cast<f32x4 *>(Vs + row * HD + dq * 4) = v;
+            }
+            __syncthreads();
+            if constexpr (NCH > 2) {
+                if (c == 2) { // keys 0..255 were the first depth block: park it, start the second chain from zero
 #pragma unroll
-                    for (int r = 0; r < 16; r++) oc[jn][r] = 0.f;
+                    for (int jn = 0; jn < NOP; jn++) {
+                        tot[jn] = oc[jn];
+#pragma unroll
+                        for (int r = 0; r < 16; r++) oc[jn][r] = 0.f;
+                    }
                 }
             }
+            const float *Bv = Vs + half * HD + pass * NOP * 32 + l31;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int kl = 0; kl < 16; kl++) {
+                    const int t0 = 2 * kl, g = t0 >> 3, off = t0 & 7;
+                    const float a = sc[4 * c + j][off < 4 ? 4 * g + off : 4 * g + (off - 4) + 1];
+#pragma unroll
+                    for (int jn = 0; jn < NOP; jn++) oc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bv[(32 * j + t0) * HD + jn * 32], oc[jn], 0, 0, 0);
+                }
         }
-        const float *Bv = Vs + half * HD + l31;
+        if constexpr (NCH > 2) {
+            if (p.t > 256) { // (with <= 256 real keys the second chain only saw zero-filled rows: the reference has one depth block then)
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+                for (int jn = 0; jn < NOP; jn++)
 #pragma unroll
-            for (int kl = 0; kl < 16; kl++) {
-                const int t0 = 2 * kl, g = t0 >> 3, off = t0 & 7;
-                const float a = sc[4 * c + j][off < 4 ? 4 * g + off : 4 * g + (off - 4) + 1];
+                    for (int r = 0; r < 16; r++) oc[jn][r] = tot[jn][r] + oc[jn][r];
+            } else {
 #pragma unroll
-                for (int jn = 0; jn < NO; jn++) oc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bv[(32 * j + t0) * HD + jn * 32], oc[jn], 0, 0, 0);
+                for (int jn = 0; jn < NOP; jn++) oc[jn] = tot[jn];
+            }
+        }
+#pragma unroll
+        for (int jn = 0; jn < NOP; jn++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = s0 + wave * 32 + acc_row(r) + 4 * half;
+                if (row < p.s) ob[(long long)row * p.o_rs + (pass * NOP + jn) * 32 + l31] = oc[jn][r];
             }
     }
-    if constexpr (NCH > 2) {
-        if (p.t > 256) { // (with <= 256 real keys the second chain only saw zero-filled rows: the reference has one depth block then)
-#pragma unroll
-            for (int jn = 0; jn < NO; jn++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) oc[jn][r] = tot[jn][r] + oc[jn][r];
-        } else {
-#pragma unroll
-            for (int jn = 0; jn < NO; jn++) oc[jn] = tot[jn];
-        }
-    }
-#pragma unroll
-    for (int jn = 0; jn < NO; jn++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int row = s0 + wave * 32 + acc_row(r) + 4 * half;
-            if (row < p.s) ob[(long long)row * p.o_rs + jn * 32 + l31] = oc[jn][r];
-        }
 }
 
 template <int HD, int NCH>

@@ -52,16 +52,23 @@ class ResNet50Int8(ResNet50):
         self.producer_stats = True   # conv epilogues accumulate the min/max the next DynamicQuantizeLinear needs
         self.fused_dql = False       # pointwise stride-1 convs quantize their input in the GEMM's loader (rten_hip_conv2d_int8_dql) ...
         self.fused_layers = None     # ... all that qualify (None) or the set autotune() measured to be faster that way
-        # Quantized-output launches (rten_hip_conv2d_int8_qout): a conv whose output is read by exactly ONE other conv (and by nothing
-        # else: not a residual, not the network output) quantizes it for that consumer in its own epilogue, behind a grid-wide min / max;
-        # the f32 tensor is never written.  In a bottleneck block these are the c1 -> c2 and c2 -> c3 edges (32 of the 53 layers).
+        # Quantized-output launches (rten_hip_conv2d_int8_qout): a conv whose output goes through ONE DynamicQuantizeLinear -- it is read by one
+        # conv, or by several that share the quantized tensor (a stage's projection shortcut and first 1x1, which ort-quantize feeds from one
+        # DynamicQuantizeLinear) -- runs that quantizer in its own epilogue, behind a grid-wide min / max.  In a bottleneck block: the c1 -> c2
+        # and c2 -> c3 edges, whose f32 tensor is then never written (32 of the 53 layers), and the c3 -> next block edges, where the f32
+        # tensor is still written for the residual Add (`qout_keeps_f32`).
         self.fused_qout = False
         readers = {}
         for m in self.specs:
             readers.setdefault(m["src"], []).append(m)
         residuals = {m["res"] for m in self.specs if m["res"]}
+
+        def one_quantizer(rs):
+            g = {(self.descs[r["name"]].c, self.descs[r["name"]].h, self.descs[r["name"]].w, tuple(self.descs[r["name"]].pads)) for r in rs}
+            return len(g) == 1
         self.qout_next = {m["name"]: readers[m["dst"]][0] for m in self.specs
-                          if len(readers.get(m["dst"], [])) == 1 and m["dst"] not in residuals and m["dst"] != "stem"}
+                          if readers.get(m["dst"]) and one_quantizer(readers[m["dst"]]) and m["dst"] != "stem"}
+        self.qout_keeps_f32 = {m["name"] for m in self.specs if m["name"] in self.qout_next and m["dst"] in residuals}
         self._qout_off = set()       # layers that run the two-launch sequence: grid not resident at once (found at the first attempt), or
                                      # measured slower by autotune_qout() (the grid-wide exchange costs ~6 us: it pays on the larger tensors only)
         gb = ctx.lib.rten_hip_grid_sync_bytes()
@@ -169,11 +176,13 @@ class ResNet50Int8(ResNet50):
         if nxt is not None and name not in self._qout_off:
             other = 1 - self._cur
             (ostaged, oxs, oxz), osc = self.qsets[other], self.scs[other]
-            rc = ctx.lib.rten_hip_conv2d_int8_qout(ctx.h, C.byref(d), staged.vp, self.wq[name].vp, xz.vp, None, sc.vp, self.bq[name].vp, res, flags, None,
+            y = self._act(l["dst"]).vp if name in self.qout_keeps_f32 else None
+            rc = ctx.lib.rten_hip_conv2d_int8_qout(ctx.h, C.byref(d), staged.vp, self.wq[name].vp, xz.vp, None, sc.vp, self.bq[name].vp, res, flags, y,
                                                    self.stats[l["dst"]], self.syncs[name], C.byref(self.idesc[nxt["name"]]), ostaged.vp, oxs.vp, oxz.vp,
                                                    self.ws[nxt["name"]].vp, osc.vp)
             if rc == L.OK:
-                self._cur, self._prestaged = other, nxt["name"]
+                nc = self.idesc[nxt["name"]].conv  # a second reader of the same tensor finds the staged codes through `_staged_key`
+                self._cur, self._prestaged, self._staged_key = other, nxt["name"], (nxt["src"], nc.c, nc.h, nc.w, tuple(nc.pads))
                 return
             if rc != L.ERR_UNSUPPORTED:
                 ctx.check(rc)
@@ -225,7 +234,8 @@ class ResNet50Int8(ResNet50):
                 ctx.call("rten_hip_dynamic_quantize_linear_staged_stats", C.byref(nd), dst.vp, dstat, ostaged.vp, oxs.vp, oxz.vp, self.ws[nxt["name"]].vp, self.scs[1].vp)
 
             def one():
-                return ctx.lib.rten_hip_conv2d_int8_qout(ctx.h, C.byref(d), staged.vp, self.wq[name].vp, xz.vp, None, self.scs[0].vp, self.bq[name].vp, res, flags, None,
+                return ctx.lib.rten_hip_conv2d_int8_qout(ctx.h, C.byref(d), staged.vp, self.wq[name].vp, xz.vp, None, self.scs[0].vp, self.bq[name].vp, res, flags,
+                                                         dst.vp if name in self.qout_keeps_f32 else None,
                                                          dstat, self.syncs[name], C.byref(nd), ostaged.vp, oxs.vp, oxz.vp, self.ws[nxt["name"]].vp, self.scs[1].vp)
             us2 = timed(two)
             us1 = timed(one) if one() == L.OK else None

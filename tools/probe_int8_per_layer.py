@@ -70,7 +70,8 @@ for l in net.specs:
         nd = net.idesc[nxt["name"]]
         ost, oxs, oxz = net.qsets[1]
         qo = lambda: ctx.lib.rten_hip_conv2d_int8_qout(ctx.h, C.byref(d), net.staged.vp, net.wq[name].vp, net.xz.vp, None, net.sc.vp, net.bq[name].vp,
-                                                       net._act(l["res"]).vp if l["res"] else None, flags, None, net.stats[l["dst"]], net.syncs[name], C.byref(nd),
+                                                       net._act(l["res"]).vp if l["res"] else None, flags, net._act(l["dst"]).vp if name in net.qout_keeps_f32 else None,
+                                                       net.stats[l["dst"]], net.syncs[name], C.byref(nd),
                                                        ost.vp, oxs.vp, oxz.vp, net.ws[nxt["name"]].vp, net.scs[1].vp)
         if qo() == 0:
             us_qo = timed(qo)
