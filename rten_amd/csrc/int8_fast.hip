@@ -956,7 +956,7 @@ int32_t dispatch_fast(rten_hip_ctx *ctx, FastArgs &a, double ops, double bytes) 
     // below what the MFMAs could consume, so an idle CU costs more than the extra operand re-reads of a smaller tile)
     const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     const long long t12864 = (long long)((a.M + 127) / 128) * ((a.N + 63) / 64);
-    int tile = a.M <= 64 ? 2 : (t128 >= ctx->num_cus ? 0 : (t12864 >= ctx->num_cus ? 1 : 3));
+    const int tile = a.M <= 64 ? 2 : (t128 >= ctx->num_cus ? 0 : (t12864 >= ctx->num_cus ? 1 : 3));
     // tile order: consecutive workgroup ids (one XCD's share) walk the axis of the SMALLER operand, so that the larger
     // one is fetched into as few of the eight L2s as possible
     a.n_fastest = (double)a.a_bytes > (double)a.b_bytes ? 1 : 0;
@@ -986,19 +986,8 @@ int32_t dispatch_fast(rten_hip_ctx *ctx, FastArgs &a, double ops, double bytes) 
         RTEN_LAUNCH_CHECK(ctx, "igemm_i8_fast_kernel launch");
         return RTEN_HIP_OK;
     }
-    // tuning switches (RTEN_HIP_DEBUG): 0x1000 = 128-byte k-tiles on the 128x64 / 64x128 / 64x64 tiles, 0x2000 = the next larger tile for the
-    // under-filled launches (64x64 -> 128x64, 128x64 -> 128x128), 0x4000 = four LDS stages
-    if ((ctx->debug & 0x2000) && tile == 3 && a.M > 64) tile = 1;
-    else if ((ctx->debug & 0x2000) && tile == 1) tile = 0;
-    if (ctx->debug & 0x1000) {
-        if (tile == 1) { launch_fast<128, 64, 3, 128>(ctx, a, "igemm_i8_fast_kernel<128,64,k128>", ops, bytes); RTEN_LAUNCH_CHECK(ctx, "igemm_i8_fast_kernel launch"); return RTEN_HIP_OK; }
-        if (tile == 2) { launch_fast<64, 128, 3, 128>(ctx, a, "igemm_i8_fast_kernel<64,128,k128>", ops, bytes); RTEN_LAUNCH_CHECK(ctx, "igemm_i8_fast_kernel launch"); return RTEN_HIP_OK; }
-        if (tile == 3) { launch_fast<64, 64, 3, 128>(ctx, a, "igemm_i8_fast_kernel<64,64,k128>", ops, bytes); RTEN_LAUNCH_CHECK(ctx, "igemm_i8_fast_kernel launch"); return RTEN_HIP_OK; }
-    }
-    if (ctx->debug & 0x4000) {
-        if (tile == 1) { launch_fast<128, 64, 4>(ctx, a, "igemm_i8_fast_kernel<128,64,s4>", ops, bytes); RTEN_LAUNCH_CHECK(ctx, "igemm_i8_fast_kernel launch"); return RTEN_HIP_OK; }
-        if (tile == 3) { launch_fast<64, 64, 4>(ctx, a, "igemm_i8_fast_kernel<64,64,s4>", ops, bytes); RTEN_LAUNCH_CHECK(ctx, "igemm_i8_fast_kernel launch"); return RTEN_HIP_OK; }
-    }
+    // (measured again in round 3 and dropped -- profiles/r06/int8_tile_experiments.txt: 128-byte k-tiles on the 128x64 / 64x128 / 64x64 tiles
+    // +5 % on the whole conv time, the next larger tile for the under-filled launches +6 %, four LDS stages +2 %; no layer gains more than 5 %)
     if (tile == 0) {
         launch_fast<128, 128, 3>(ctx, a, "igemm_i8_fast_kernel<128,128>", ops, bytes);
     } else if (tile == 1) {
