@@ -152,9 +152,10 @@ def test_resnet50_int8_batch32_quantized_output_launches(ctx):
     net.forward()
     bits_equal(net.logits.numpy(), want)
     assert net.qout_timeouts() == 0
-    # 32 c1 -> c2 -> c3 edges + 15 block outputs that feed the next block's quantizer (the last block's feeds the pooling); the launches
+    # 32 c1 -> c2 -> c3 edges + 15 block outputs that feed the next block's quantizer (the last block's feeds the pooling); 12 of those are
+    # also a residual and keep their f32 tensor (the last block of a stage is read only through the next stage's quantizer).  The launches
     # of stage 0 / 1 block outputs (1568 / 784 tiles of 128 x 128) and s1b0c1 do not fit the device at once and keep the two launches
-    assert len(net.qout_next) == 47 and len(net.qout_keeps_f32) == 15, (len(net.qout_next), len(net.qout_keeps_f32))
+    assert len(net.qout_next) == 47 and len(net.qout_keeps_f32) == 12, (len(net.qout_next), len(net.qout_keeps_f32))
     assert len(net._qout_off) <= 9, sorted(net._qout_off)
     net.capture()
     for _ in range(3):

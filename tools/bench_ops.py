@@ -95,6 +95,9 @@ def main():
     g, b = dev(np.ones(c, np.float32)), dev(np.zeros(c, np.float32))
     hbm("LayerNormalization", f"rows={r} cols={c}",
         (lambda: ctx.call("rten_hip_layer_norm_f32", r, c, x.vp, g.vp, b.vp, C.c_float(1.0), C.c_float(0.0), C.c_float(1e-12), y.vp)), 8.0 * r * c)
+    # reference point for the short row-wise launches: a device copy of the same 12.6 MB (the fraction of the HBM peak ANY 6 us launch can
+    # reach is bounded by its ramp-up and drain; LayerNormalization is to be read against this row, not against 8 TB/s)
+    hbm("copy, LayerNormalization's size (reference point)", f"{4 * r * c} B", (lambda: ctx.call("rten_hip_memcpy_d2d", y.vp, x.vp, C.c_size_t(4 * r * c))), 8.0 * r * c)
     u8 = empty((n_act,), np.uint8)
     sc, zp = empty((1,)), empty((1,), np.uint8)
     hbm("DynamicQuantizeLinear", f"n={n_act}", (lambda: ctx.call("rten_hip_dynamic_quantize_linear", n_act, x.vp, u8.vp, sc.vp, zp.vp)), 9.0 * n_act)
@@ -169,12 +172,32 @@ def main():
     mfma("sdpa (QK^T, softmax, PV)", f"b={B} h={H} s={S} d={D}", (lambda: ctx.call("rten_hip_sdpa_f32", C.byref(sd), q.vp, kk.vp, v.vp, None, o.vp)),
          4.0 * B * H * S * S * D, F32_PEAK_TF, "TFLOP/s")
 
+    # the general one-kernel form (round 3): head 128 x 512 keys (2 query tiles per head), head 64 x 384 keys, head 32 x 256 keys
+    for (B2, H2, S2, T2, D2) in ((8, 16, 256, 512, 128), (16, 12, 384, 384, 64), (32, 8, 256, 256, 32)):
+        q2, o2 = dev(rng.standard_normal((B2, H2, S2, D2), dtype=np.float32)), empty((B2, H2, S2, D2))
+        k2, v2 = dev(rng.standard_normal((B2, H2, T2, D2), dtype=np.float32)), dev(rng.standard_normal((B2, H2, T2, D2), dtype=np.float32))
+        sd2 = L.SdpaDesc(B2, H2, S2, T2, D2, D2, H2 * S2 * D2, S2 * D2, D2, H2 * T2 * D2, T2 * D2, D2, H2 * T2 * D2, T2 * D2, D2, H2 * S2 * D2, S2 * D2, D2, 0, 0,
+                         float(1.0 / np.sqrt(D2)), 0)
+        for path, label in ((0, "one kernel"), (1, "composed: GEMM, softmax, GEMM")):
+            def fn(sd2=sd2, q2=q2, k2=k2, v2=v2, o2=o2):
+                ctx.call("rten_hip_sdpa_f32", C.byref(sd2), q2.vp, k2.vp, v2.vp, None, o2.vp)
+            ctx.call("rten_hip_set_sdpa_path", path)
+            mfma(f"sdpa general ({label})", f"b={B2} h={H2} s={S2} t={T2} d={D2}", fn, 4.0 * B2 * H2 * S2 * T2 * D2, F32_PEAK_TF, "TFLOP/s")
+            ctx.call("rten_hip_set_sdpa_path", 0)
+
     # ---- int8 GEMM / conv (u8 activations x i8 weights)
     for (m, k, n) in ((4096, 768, 768), (4096, 768, 3072)):
         a = dev(rng.integers(0, 255, (m, k)).astype(np.uint8)); w = dev(rng.integers(-127, 127, (k, n)).astype(np.int8))
         az, wz, out = dev(np.array(128, np.uint8)), dev(np.zeros(n, np.int8)), empty((m, n), np.int32)
         d = L.GemmInt8Desc(m, n, k, k, 1, n, 1, n, 0, 1, 1, n, 0)
         mfma("MatMulInteger", f"{m}x{k}x{n}", (lambda: ctx.call("rten_hip_gemm_int8", C.byref(d), a.vp, w.vp, az.vp, wz.vp, None, out.vp)), 2.0 * m * k * n, I8_PEAK_TOPS, "TOP/s")
+        nb = ctx.lib.rten_hip_gemm_int8_packed_bytes(k, n)  # constant RHS staged once at load (Operator::prepack): the per-call staging of B disappears
+        if nb:
+            packed = empty((nb,), np.uint8)
+            ctx.call("rten_hip_gemm_int8_prepack", k, n, w.vp, n, 1, 1, packed.vp)
+            dp = L.GemmInt8Desc(m, n, k, k, 1, n, 1, n, 0, 1, 1, n, 0, 1, 0, 0, 0, 1)
+            mfma("MatMulInteger (prepacked RHS)", f"{m}x{k}x{n}", (lambda: ctx.call("rten_hip_gemm_int8", C.byref(dp), a.vp, packed.vp, az.vp, wz.vp, None, out.vp)),
+                 2.0 * m * k * n, I8_PEAK_TOPS, "TOP/s")
     for (o_, c_, hw, k_, s_, p_, name) in ((64, 64, 56, 3, 1, 1, "s0 3x3"), (256, 256, 14, 3, 1, 1, "s2 3x3"), (256, 64, 56, 1, 1, 0, "s0 1x1 expand")):
         xq = dev(rng.integers(0, 255, (32, c_, hw, hw)).astype(np.uint8)); wq = dev(rng.integers(-127, 127, (o_, c_, k_, k_)).astype(np.int8))
         xz, wz = dev(np.array(128, np.uint8)), dev(np.zeros(o_, np.int8))

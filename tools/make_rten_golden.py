@@ -36,6 +36,9 @@ def main():
     ap.add_argument("--source", choices=("hip", "oracle"), default=None)
     ap.add_argument("--pad-mode", choices=("raw0_i8", "zero_point", "raw0_u8"), default="raw0_i8")
     ap.add_argument("--models", default="resnet50_f32,resnet50_int8,bert_base")
+    ap.add_argument("--reference-threads", type=int, default=0,
+                    help="--source oracle, --batch 1: the reference's thread-pool size (RTEN_NUM_THREADS) its one-row gemv column blocks depend on "
+                         "(rten-gemm/src/lib.rs:697); 0 = at least N / 128 threads, the backend's default assumption")
     args = ap.parse_args()
     from safetensors.numpy import save_file
     from rten_amd import onnx_writer as ow
@@ -75,6 +78,7 @@ def main():
                 raise SystemExit(f"{name}: rten_hip_run failed\n{r.stdout[-800:]}{r.stderr[-800:]}")
         else:
             from oracle import models as om, ref
+            ref.set_gemv_threads(args.reference_threads)
             if name == "resnet50_f32":
                 y = om.resnet50_forward(specs, w, inputs["x"])
             elif name == "resnet50_int8":

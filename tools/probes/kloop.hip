@@ -124,6 +124,102 @@ void run(const char *name, const float *src, float *sink, unsigned long long *cl
     }
 }
 
+// G: the 3x3 convolution's k-loop on channels-last-by-4 activations ([N][C/4][H][W][4]): a k-UNIT is one channel quad x 9 taps = 36 k
+// (18 MFMAs per wave, 1152 matrix-pipe cycles).  Per unit a workgroup moves A = 36 x 64 f32 (9 dwordx4 DMA instructions, k-major weights)
+// and B = 9 taps x 64 pixels x 16 B (9 dwordx4 instructions, one per tap: a lane's piece is the 4 channels of ITS pixel) -- 18 instructions over
+// 4 waves (5 / 5 / 4 / 4) against the 45 of the NCHW gather loop for the same 36 k.  B fragments: 9 ds_read_b128 give a lane all 36 values of
+// its column, the k-pair of MFMA s is picked by register index (k = 9 j + tap, even k in the lower half-wave, odd k in the upper).
+constexpr int UK = 36, USTAGE = UK * BM + 9 * BN * 4;
+typedef float f32x4p __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void kloop_cl4(const float *src, float *sink, unsigned long long *clocks, int iters, unsigned src_bytes) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    float *smem = dsm;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wq = t >> 6, wm0 = (wq >> 1) * 32, wn0 = (wq & 1) * 32;
+    for (int i = t; i < NSTAGE * USTAGE; i += 256) smem[i] = (float)((i * 2654435761u) >> 20) * 1e-4f;
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, (int)src_bytes, 0x00020000);
+    typedef __attribute__((address_space(3))) void *lds_ptr_t;
+    const unsigned voff = (unsigned)((blockIdx.x * 4096u + wave * 1024u + lane * 16u) % (src_bytes - (1u << 20)));
+    const int n_dma = wave < 2 ? 5 : 4; // instructions 0..8 = A rows (4 k rows each), 9..17 = B taps
+    auto issue = [&](int u, int stage) {
+        float *As = smem + stage * USTAGE, *Bs = As + UK * BM;
+        const unsigned soff = (unsigned)(u & 63) * 4096u;
+#pragma unroll
+        for (int q = 0; q < 5; q++) {
+            const int id = wave + 4 * q; // 0 .. 19; ids >= 18 do not exist
+            if (q < 4 || wave < 2) {
+                float *dst = id < 9 ? As + id * 256 : Bs + (id - 9) * 256;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dst, 16, (int)(voff + (unsigned)id * 8192u), (int)soff, 0, 0);
+            }
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    issue(0, 0);
+    issue(1, 1);
+    int stage = 0;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int u = 0; u < iters; u++) {
+        if (n_dma == 5) wait_vmcnt<5>(); else wait_vmcnt<4>();
+        __builtin_amdgcn_s_barrier();
+        issue(u + 2, stage == 0 ? NSTAGE - 1 : stage - 1);
+        const float *As = smem + stage * USTAGE + wm0 + l31, *Bs = smem + stage * USTAGE + UK * BM + (wn0 + l31) * 4;
+        f32x4p b[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) b[tap] = *reinterpret_cast<const f32x4p *>(Bs + tap * BN * 4);
+        float af[2];
+        af[0] = As[half * BM];
+#pragma unroll
+        for (int s = 0; s < 18; s++) {
+            const int cur = s & 1, nxt = cur ^ 1;
+            if (s + 1 < 18) af[nxt] = As[(2 * (s + 1) + half) * BM];
+            const int k0 = 2 * s, k1 = 2 * s + 1; // k = 9 j + tap
+            const float bv = half ? b[k1 % 9][k1 / 9] : b[k0 % 9][k0 / 9];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur], bv, acc, 0, 0, 0);
+        }
+        stage = stage == NSTAGE - 1 ? 0 : stage + 1;
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    wait_vmcnt<0>();
+    if (lane == 0 && wave == 0) clocks[blockIdx.x] = t1 - t0;
+    float keep = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) keep += acc[r];
+    if (keep == 12345.678f) sink[0] = keep;
+}
+
+void run_cl4(const float *src, float *sink, unsigned long long *clocks, int cus, unsigned src_bytes) {
+    const int iters = 2000;
+    for (int per_cu = 1; per_cu <= 2; per_cu++) {
+        const int grid = cus * per_cu;
+        const int base = NSTAGE * USTAGE * 4;
+        int dyn = (160 * 1024 / per_cu - 256) & ~1023;
+        if (dyn < base) dyn = base;
+        hipFuncSetAttribute((const void *)kloop_cl4, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        hipLaunchKernelGGL(kloop_cl4, dim3(grid), dim3(256), (size_t)dyn, 0, src, sink, clocks, iters, src_bytes);
+        hipDeviceSynchronize();
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(kloop_cl4, dim3(grid), dim3(256), (size_t)dyn, 0, src, sink, clocks, iters, src_bytes);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        std::vector<unsigned long long> h((size_t)grid);
+        hipMemcpy(h.data(), clocks, h.size() * 8, hipMemcpyDeviceToHost);
+        double cyc = 0;
+        for (auto c : h) cyc += (double)c;
+        const double flops = (double)grid * 4 * iters * 18.0 * 2.0 * 32 * 32 * 2;
+        printf("%-46s %d WG/CU: %7.1f cycles per 36-k unit per wave (1152 = matrix pipe alone)  %6.1f TFLOP/s\n", "G  3x3 on channels-last-by-4: 36-k units", per_cu,
+               cyc / grid / iters, flops / (ms * 1e-3) / 1e12);
+    }
+}
+
 int main() {
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
@@ -135,6 +231,7 @@ int main() {
     hipMemset(src, 0x3c, src_bytes);
     hipMalloc(&sink, 16);
     hipMalloc(&clocks, (size_t)cus * 4 * 8);
+    run_cl4(src, sink, clocks, cus, src_bytes);
     run<0>("A  MFMA on register operands", src, sink, clocks, cus, src_bytes);
     run<1>("B  + fragments from LDS (interleaved)", src, sink, clocks, cus, src_bytes);
     run<2>("C  + s_barrier per k-tile", src, sink, clocks, cus, src_bytes);
