@@ -150,8 +150,10 @@ class ResNet50Int8(ResNet50):
         flags = (L.CONV_RELU if l["relu"] else 0) | (L.CONV_RESIDUAL if l["res"] else 0)
         res = self._act(l["res"]).vp if l["res"] else None
         st_in = self.stats.get(l["src"]) if self.producer_stats else None
-        if (self.fused_dql and self.fused_layers and name in self.fused_layers and st_in is not None and self._prestaged != name and self._staged_key != geom
-                and cv.kh == 1 and cv.kw == 1 and cv.stride_h == 1 and cv.stride_w == 1 and not any(cv.pads) and cv.c % 64 == 0):
+        runs_qout = name in self.qout_next and name not in self._qout_off  # (measured: where both forms apply, quantizing the OUTPUT in the epilogue is
+        #                                                                     worth more to the replayed graph than quantizing the input in the loader)
+        if (self.fused_dql and self.fused_layers and name in self.fused_layers and not runs_qout and st_in is not None and self._prestaged != name
+                and self._staged_key != geom and cv.kh == 1 and cv.kw == 1 and cv.stride_h == 1 and cv.stride_w == 1 and not any(cv.pads) and cv.c % 64 == 0):
             # a pointwise layer autotune() found faster with DynamicQuantizeLinear inside its own operand loader (no staged tensor at all)
             ctx.call("rten_hip_conv2d_int8_dql", C.byref(d), self._act(l["src"]).vp, st_in, self.wq[name].vp, self.ws[name].vp, self.bq[name].vp, res, flags,
                      self._act(l["dst"]).vp, self.stats[l["dst"]], None, None)
