@@ -10,8 +10,9 @@
 //!     `output_types`, `as_infer_shapes` to it -- attributes, shape inference and the planner see the operators they know;
 //!   * `run` takes the reference's host `ValueView`s and returns host `Value`s allocated from `ctx.pool()`;
 //!   * constant inputs (weights) are staged on the device ONCE: `PrepackedInput` is a closed enum of rten-gemm types, so the
-//!     cache lives in the backend, keyed by the constant's host address and length (graph constants do not move while the
-//!     model is alive -- `Graph` owns them, src/graph.rs:488-562);
+//!     device copy lives in the OPERATOR INSTANCE that uses it (`ConstCache`, one slot per input): an operator belongs to one
+//!     graph, so the copies die with the model that owns them, and a slot is re-staged if the constant behind it is ever a
+//!     different allocation (graph constants do not move while the model is alive -- `Graph` owns them, src/graph.rs:488-562);
 //!   * activations cross PCIe per operator in this drop-in form.  The residency-aware executor of SURVEY 8(f) rank 1 (values
 //!     stay in HBM between operators) needs a `Value::Device` variant, i.e. a change to the reference; it is built and measured
 //!     in this repository as include/rten_hip_graph.hpp and is the "next" step of the Rust integration, not part of it.
@@ -39,8 +40,6 @@ pub use ops::register;
 /// RAII over `rten_hip_ctx`.  `Send + Sync`: the C ABI serialises entry per call (rten_hip.h, "Thread safety").
 pub struct HipContext {
     raw: *mut sys::rten_hip_ctx,
-    /// device copies of graph constants: (host address, bytes, layout tag) -> device buffer
-    weights: Mutex<HashMap<(usize, usize, u32), DeviceBuffer>>,
 }
 unsafe impl Send for HipContext {}
 unsafe impl Sync for HipContext {}
@@ -56,7 +55,7 @@ impl HipContext {
     pub fn new(device: i32) -> Result<Arc<HipContext>, HipInitError> {
         let mut raw = ptr::null_mut();
         match unsafe { sys::rten_hip_init(device, ptr::null_mut(), &mut raw) } {
-            sys::RTEN_HIP_OK => Ok(Arc::new(HipContext { raw, weights: Mutex::new(HashMap::new()) })),
+            sys::RTEN_HIP_OK => Ok(Arc::new(HipContext { raw })),
             sys::RTEN_HIP_ERR_NO_DEVICE => Err(HipInitError::NoDevice),
             _ => Err(HipInitError::Hip("rten_hip_init failed".into())),
         }
@@ -108,33 +107,49 @@ impl HipContext {
         debug_assert!(std::mem::size_of_val(host) <= buf.bytes);
         self.check(unsafe { sys::rten_hip_memcpy_d2h(self.raw, host.as_mut_ptr() as *mut c_void, buf.ptr, std::mem::size_of_val(host)) })
     }
-
-    /// Device copy of a graph constant, created on first use -- uploaded, then handed to `stage`, which returns either the
-    /// upload itself (`|_, raw| Ok(raw)`) or a re-laid copy (rten_hip_conv2d_f32_prepack, rten_hip_gemm_int8_prepack) -- and
-    /// kept for the life of the context: the backend's analogue of `Graph::prepack_weights` + `WeightCache`.
-    pub fn constant<T: Copy>(
-        self: &Arc<Self>,
-        host: &[T],
-        layout: u32,
-        stage: impl FnOnce(&Arc<Self>, DeviceBuffer) -> Result<DeviceBuffer, OpError>,
-    ) -> Result<*const c_void, OpError> {
-        let key = (host.as_ptr() as usize, std::mem::size_of_val(host), layout);
-        let mut cache = self.weights.lock().unwrap();
-        if let Some(b) = cache.get(&key) {
-            return Ok(b.ptr as *const c_void);
-        }
-        let raw = self.upload(host)?;
-        let staged = stage(self, &raw)?;
-        let p = staged.ptr as *const c_void;
-        cache.insert(key, staged);
-        Ok(p)
-    }
 }
 
 impl Drop for HipContext {
     fn drop(&mut self) {
-        self.weights.lock().unwrap().clear(); // buffers free themselves through the context: before it goes away
+        // every DeviceBuffer holds an Arc of its context, so the last buffer is gone by now; the context owns none itself (no cycle)
         unsafe { sys::rten_hip_destroy(self.raw) };
+    }
+}
+
+/// Device copies of ONE operator's constant inputs (weights, biases, scales), created on first use: uploaded, then handed to `stage`,
+/// which returns either the upload itself (`|_, raw| Ok(raw)`) or a re-laid copy (rten_hip_conv2d_f32_prepack,
+/// rten_hip_gemm_int8_prepack).  The backend's analogue of `Graph::prepack_weights` + `WeightCache`, owned by the operator instance:
+/// dropped with the model, never shared between models, and a slot whose constant is no longer the allocation it was staged from
+/// (address or length changed) is staged again instead of serving stale weights.
+pub struct ConstCache {
+    slots: Mutex<HashMap<(usize, u32), (usize, usize, DeviceBuffer)>>, // (input index, layout tag) -> (host address, bytes, device copy)
+}
+
+impl ConstCache {
+    pub fn new() -> Self {
+        ConstCache { slots: Mutex::new(HashMap::new()) }
+    }
+
+    pub fn get<T: Copy>(
+        &self,
+        hip: &Arc<HipContext>,
+        input: usize,
+        host: &[T],
+        layout: u32,
+        stage: impl FnOnce(&Arc<HipContext>, DeviceBuffer) -> Result<DeviceBuffer, OpError>,
+    ) -> Result<*const c_void, OpError> {
+        let id = (host.as_ptr() as usize, std::mem::size_of_val(host));
+        let mut slots = self.slots.lock().unwrap();
+        if let Some((addr, len, buf)) = slots.get(&(input, layout)) {
+            if (*addr, *len) == id {
+                return Ok(buf.ptr as *const c_void);
+            }
+        }
+        let raw = hip.upload(host)?;
+        let staged = stage(hip, raw)?; // by value: `stage` either returns it or frees it after re-laying
+        let p = staged.ptr as *const c_void;
+        slots.insert((input, layout), (id.0, id.1, staged)); // a stale entry is dropped (and freed) here
+        Ok(p)
     }
 }
 

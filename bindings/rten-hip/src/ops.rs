@@ -13,7 +13,7 @@ use rten_hip_sys as sys;
 use rten_tensor::prelude::*;
 use rten_tensor::{NdTensorView, Tensor, TensorView};
 
-use crate::{DeviceBuffer, HipContext};
+use crate::{ConstCache, DeviceBuffer, HipContext};
 
 /// Delegation of the parts of the trait that are not `run`.
 macro_rules! delegate_to_inner {
@@ -38,7 +38,7 @@ fn download_tensor<T: Copy + Default>(hip: &HipContext, pool: &rten::BufferPool,
 }
 
 // ------------------------------------------------------------------------------------------------ Conv (src/ops/conv.rs:367-403)
-pub struct HipConv { pub inner: ops::Conv, pub hip: Arc<HipContext> }
+pub struct HipConv { pub inner: ops::Conv, pub hip: Arc<HipContext>, pub consts: ConstCache }
 
 fn conv_desc(x: &[usize], w: &[usize], op: &ops::Conv) -> Result<sys::rten_hip_conv2d_desc, OpError> {
     // checks and messages of conv_impl, src/ops/conv.rs:136-214
@@ -70,12 +70,12 @@ impl Operator for HipConv {
         let xd = hip.upload(&xs)?;
         // weights: staged once per graph constant (rten_hip_conv2d_f32_prepack), then served from the backend's cache
         let ws = contiguous(ctx.pool(), &w);
-        let wd = hip.constant(&ws, 1, |hip, raw| {
+        let wd = self.consts.get(hip, 1, &ws, 1, |hip, raw| {
             let packed = hip.alloc(unsafe { sys::rten_hip_conv2d_f32_packed_bytes(&d) })?;
             hip.check(unsafe { sys::rten_hip_conv2d_f32_prepack(hip.raw(), &d, raw.ptr as *const f32, packed.ptr as *mut f32) })?;
             Ok(packed)
         })?;
-        let bd = match &bias { Some(b) => hip.constant(b.to_contiguous().data().unwrap(), 0, |_, raw| Ok(raw))?, None => null() };
+        let bd = match &bias { Some(b) => self.consts.get(hip, 2, b.to_contiguous().data().unwrap(), 0, |_, raw| Ok(raw))?, None => null() };
         let out_shape = [d.n as usize, d.o as usize, d.out_h as usize, d.out_w as usize];
         let yd = hip.alloc(out_shape.iter().product::<usize>() * 4)?;
         hip.check(unsafe { sys::rten_hip_conv2d_f32(hip.raw(), &d, xd.ptr as *const f32, wd as *const f32, 1, bd as *const f32, null(), 0, yd.ptr as *mut f32) })?;
@@ -84,7 +84,7 @@ impl Operator for HipConv {
 }
 
 // ------------------------------------------------------------------------------------------------ MatMul (src/ops/matmul.rs:387-428)
-pub struct HipMatMul { pub inner: ops::MatMul, pub hip: Arc<HipContext> }
+pub struct HipMatMul { pub inner: ops::MatMul, pub hip: Arc<HipContext>, pub consts: ConstCache }
 
 /// numpy.matmul shape rules of matmul_impl (src/ops/matmul.rs:208-385): returns (batch, m, k, n, a_bs, b_bs, out shape)
 fn matmul_shapes(a: &[usize], b: &[usize]) -> Result<(usize, usize, usize, usize, i64, i64, Vec<usize>), OpError> {
@@ -126,7 +126,7 @@ impl Operator for HipMatMul {
 }
 
 // ------------------------------------------------------------------------------------------------ MatMulInteger (matmul.rs:582-700)
-pub struct HipMatMulInteger { pub inner: ops::MatMulInteger, pub hip: Arc<HipContext> }
+pub struct HipMatMulInteger { pub inner: ops::MatMulInteger, pub hip: Arc<HipContext>, pub consts: ConstCache }
 
 impl Operator for HipMatMulInteger {
     delegate_to_inner!();
@@ -156,7 +156,7 @@ impl Operator for HipMatMulInteger {
         let single_b = b_bs == 0;
         let bs = contiguous(ctx.pool(), &b);
         let bd = if single_b {
-            hip.constant(&bs, 2, |hip, raw| {
+            self.consts.get(hip, 1, &bs, 2, |hip, raw| {
                 let packed = hip.alloc(unsafe { sys::rten_hip_gemm_int8_packed_bytes(k as i32, n as i32) })?;
                 hip.check(unsafe { sys::rten_hip_gemm_int8_prepack(hip.raw(), k as i32, n as i32, raw.ptr, n as i64, 1, 1, packed.ptr) })?;
                 Ok(packed)
@@ -177,7 +177,7 @@ impl Operator for HipMatMulInteger {
 }
 
 // ------------------------------------------------------------------------------------------------ row-wise and element-wise operators
-pub struct HipSoftmax { pub inner: ops::Softmax, pub hip: Arc<HipContext> }
+pub struct HipSoftmax { pub inner: ops::Softmax, pub hip: Arc<HipContext>, pub consts: ConstCache }
 impl Operator for HipSoftmax {
     delegate_to_inner!();
     fn run(&self, ctx: &OpRunContext) -> Result<OutputList, OpError> {
@@ -193,7 +193,7 @@ impl Operator for HipSoftmax {
     }
 }
 
-pub struct HipLayerNormalization { pub inner: ops::LayerNormalization, pub hip: Arc<HipContext> }
+pub struct HipLayerNormalization { pub inner: ops::LayerNormalization, pub hip: Arc<HipContext>, pub consts: ConstCache }
 impl Operator for HipLayerNormalization {
     delegate_to_inner!();
     fn run(&self, ctx: &OpRunContext) -> Result<OutputList, OpError> {
@@ -205,8 +205,8 @@ impl Operator for HipLayerNormalization {
         if scale.len() != cols || bias.as_ref().map_or(false, |b| b.len() != cols) { return self.inner.run(ctx); } // broadcast forms: reference path
         let hip = &self.hip;
         let xd = hip.upload(&contiguous(ctx.pool(), &x))?;
-        let gd = hip.constant(&contiguous(ctx.pool(), &scale), 0, |_, raw| Ok(raw))?;
-        let bd = match &bias { Some(b) => hip.constant(&contiguous(ctx.pool(), b), 0, |_, raw| Ok(raw))?, None => null() };
+        let gd = self.consts.get(hip, 1, &contiguous(ctx.pool(), &scale), 0, |_, raw| Ok(raw))?;
+        let bd = match &bias { Some(b) => self.consts.get(hip, 2, &contiguous(ctx.pool(), b), 0, |_, raw| Ok(raw))?, None => null() };
         let yd = hip.alloc(x.len() * 4)?;
         hip.check(unsafe { sys::rten_hip_layer_norm_f32(hip.raw(), (x.len() / cols.max(1)) as i64, cols as i32, xd.ptr as *const f32, gd as *const f32, bd as *const f32,
                                                        1.0, 0.0, self.inner.epsilon.unwrap_or(1e-5), yd.ptr as *mut f32) })?;
@@ -216,7 +216,7 @@ impl Operator for HipLayerNormalization {
 
 macro_rules! hip_unary {
     ($name:ident, $inner:ty, $entry:ident) => {
-        pub struct $name { pub inner: $inner, pub hip: Arc<HipContext> }
+        pub struct $name { pub inner: $inner, pub hip: Arc<HipContext>, pub consts: ConstCache } // (`consts` unused here: one constructor shape for `register`)
         impl Operator for $name {
             delegate_to_inner!();
             fn run(&self, ctx: &OpRunContext) -> Result<OutputList, OpError> {
@@ -234,7 +234,7 @@ hip_unary!(HipRelu, ops::Relu, rten_hip_relu_f32);
 hip_unary!(HipGelu, ops::Gelu, rten_hip_gelu_f32);
 hip_unary!(HipErf, ops::Erf, rten_hip_erf_f32);
 
-pub struct HipGlobalAveragePool { pub inner: ops::GlobalAveragePool, pub hip: Arc<HipContext> }
+pub struct HipGlobalAveragePool { pub inner: ops::GlobalAveragePool, pub hip: Arc<HipContext>, pub consts: ConstCache }
 impl Operator for HipGlobalAveragePool {
     delegate_to_inner!();
     fn run(&self, ctx: &OpRunContext) -> Result<OutputList, OpError> {
@@ -248,7 +248,7 @@ impl Operator for HipGlobalAveragePool {
     }
 }
 
-pub struct HipDynamicQuantizeLinear { pub inner: ops::DynamicQuantizeLinear, pub hip: Arc<HipContext> }
+pub struct HipDynamicQuantizeLinear { pub inner: ops::DynamicQuantizeLinear, pub hip: Arc<HipContext>, pub consts: ConstCache }
 impl Operator for HipDynamicQuantizeLinear {
     delegate_to_inner!();
     fn run(&self, ctx: &OpRunContext) -> Result<OutputList, OpError> {
@@ -277,7 +277,7 @@ pub fn register(reg: &mut OpRegistry, hip: Arc<HipContext>) {
             ($op:ty, $hip_op:ident) => {
                 if (op.as_ref() as &dyn std::any::Any).is::<$op>() {
                     let inner = *(op as Box<dyn std::any::Any>).downcast::<$op>().unwrap();
-                    return Box::new($hip_op { inner, hip: hip.clone() });
+                    return Box::new($hip_op { inner, hip: hip.clone(), consts: ConstCache::new() });
                 }
             };
         }
