@@ -459,8 +459,9 @@ int32_t rten_hip_set_gemm_order(rten_hip_ctx *ctx, int32_t order);
 /* int8 kernels: 0 = automatic (operands staged chunk-major / padded channel-blocked + 16-byte LDS-DMA MFMA kernel whenever it
  * covers the call), 1 = generic byte-gather kernel only.  Both produce the reference's bits. */
 int32_t rten_hip_set_int8_path(rten_hip_ctx *ctx, int32_t mode);
-/* attention: 0 = automatic (one fused kernel for head size 64 and key length <= 128: QK^T, mask, softmax and PV without
- * a score tensor in memory), 1 = composed path only (batched GEMM, row softmax, batched GEMM).  Same bits either way. */
+/* attention: 0 = automatic (one fused kernel -- QK^T, mask, softmax and PV without a score tensor in memory -- for head size 32 / 64 / 128
+ * and key length <= 128, where it is the faster form), 1 = composed path only (batched GEMM, row softmax, batched GEMM), 2 = the fused
+ * kernel wherever it covers the shape (head size 32 / 64 / 128, key length <= 512).  Same bits on every path. */
 int32_t rten_hip_set_sdpa_path(rten_hip_ctx *ctx, int32_t mode);
 
 #ifdef __cplusplus

@@ -12,13 +12,15 @@
 // is bit-identical to the oracle's sdpa.
 #include "internal.h"
 
-// attention_fused.hip: single-kernel path for head size 64, key length <= 128; RTEN_HIP_ERR_UNSUPPORTED = not covered
-int32_t rten_sdpa_fused(rten_hip_ctx *ctx, const rten_hip_sdpa_desc *d, const float *q, const float *k, const float *v, const float *mask, float *out);
+// attention_fused.hip: single-kernel path (head size 32 / 64 / 128, key length <= 512; without `force` only where it is the faster form);
+// RTEN_HIP_ERR_UNSUPPORTED = not covered
+int32_t rten_sdpa_fused(rten_hip_ctx *ctx, const rten_hip_sdpa_desc *d, const float *q, const float *k, const float *v, const float *mask, float *out, bool force);
 
-// 0 = automatic (fused kernel whenever it covers the shape), 1 = composed path only (GEMM, softmax, GEMM).
+// 0 = automatic (the one-kernel form where it covers the shape and is the faster one: <= 128 keys), 1 = composed path only (GEMM, softmax,
+// GEMM), 2 = the one-kernel form wherever it covers the shape (head 32 / 64 / 128, <= 512 keys).
 RTEN_EXPORT int32_t rten_hip_set_sdpa_path(rten_hip_ctx *ctx, int32_t mode) {
     RTEN_CHECK_CTX(ctx);
-    if (mode < 0 || mode > 1) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "set_sdpa_path: mode must be 0 or 1");
+    if (mode < 0 || mode > 2) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "set_sdpa_path: mode must be 0, 1 or 2");
     ctx->sdpa_path = mode;
     return RTEN_HIP_OK;
 }
@@ -34,8 +36,8 @@ RTEN_EXPORT int32_t rten_hip_sdpa_f32(rten_hip_ctx *ctx, const rten_hip_sdpa_des
     if (mask && ((d->mask_row_stride != 0 && d->mask_row_stride != d->t) ||
                  d->mask_batch_stride != (d->mask_row_stride ? (int64_t)d->s * d->t : (int64_t)d->t)))
         return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "sdpa: mask must be [B,1,1,T] or [B,1,S,T] contiguous");
-    if (ctx->sdpa_path == 0) {
-        const int32_t rc = rten_sdpa_fused(ctx, d, q, k, v, mask, out);
+    if (ctx->sdpa_path != 1) {
+        const int32_t rc = rten_sdpa_fused(ctx, d, q, k, v, mask, out, ctx->sdpa_path == 2);
         if (rc != RTEN_HIP_ERR_UNSUPPORTED) return rc;
     }
     const size_t score_bytes = (size_t)bh * d->s * (size_t)d->t * sizeof(float);

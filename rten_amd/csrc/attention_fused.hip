@@ -412,11 +412,15 @@ void launch_general(rten_hip_ctx *ctx, const SdpaArgs &a, long long wgs) {
 } // namespace
 
 // Returns RTEN_HIP_ERR_UNSUPPORTED when the shape is not covered (the caller falls back to the composed path).
-int32_t rten_sdpa_fused(rten_hip_ctx *ctx, const rten_hip_sdpa_desc *d, const float *q, const float *k, const float *v, const float *mask, float *out) {
+int32_t rten_sdpa_fused(rten_hip_ctx *ctx, const rten_hip_sdpa_desc *d, const float *q, const float *k, const float *v, const float *mask, float *out, bool force) {
     auto al16 = [](const void *p) { return ((uintptr_t)p & 15u) == 0; };
     const bool fast = d->d == HD && d->dv == HD && d->t <= TT;                                             // BERT-base: head 64, <= 128 keys
     const bool general = d->d == d->dv && (d->d == 32 || d->d == 64 || d->d == 128) && d->t <= 4 * TT;    // head 32 / 64 / 128, <= 512 keys
-    if (d->t < 1 || (!fast && !general)) return RTEN_HIP_ERR_UNSUPPORTED;
+    // Beyond 128 keys the whole score row of a query (up to 256 registers per lane) leaves room for ONE workgroup per CU, and the composed
+    // GEMM / softmax / GEMM path is faster (profiles/r06/ops_microbench.json: 134 vs 209 us at head 128 x 512 keys, 66 vs 102 us at head 64 x
+    // 256 keys; the one-kernel form wins at <= 128 keys: 23 vs 42 us at head 32): the automatic choice keeps the one-kernel form to <= 128
+    // keys, `force` (rten_hip_set_sdpa_path(ctx, 2)) takes it wherever it is covered.
+    if (d->t < 1 || (!fast && !(general && (force || d->t <= TT)))) return RTEN_HIP_ERR_UNSUPPORTED;
     const int64_t strides[] = {d->q_bs, d->q_hs, d->q_rs, d->k_bs, d->k_hs, d->k_rs, d->v_bs, d->v_hs, d->v_rs};
     for (int64_t s : strides)
         if (s % 4 != 0) return RTEN_HIP_ERR_UNSUPPORTED;
