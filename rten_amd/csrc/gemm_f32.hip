@@ -707,11 +707,6 @@ __device__ __forceinline__ void wait_vmcnt() {
 //      1 = all of the k-tile's fragments first, then the MFMAs back to back with nothing between them: with one 32x32 block per
 //          wave (64x64 tiles) consecutive MFMAs hit the SAME accumulator, and any instruction issued between two such MFMAs
 //          costs ~43 cycles on top of its own slot (MI355X_MICROARCH.md, per-instruction constants).
-//      2 = the synchronisation point sits in the MIDDLE of a k-tile's MFMA sequence (four LDS stages): the first half of tile kt's MFMAs, then
-//          the counted wait + barrier that publishes tile kt+1 and frees the stage tile kt-1 was read from, the DMA of tile kt+3 issued between
-//          the MFMAs of the second half, and the first fragments of tile kt+1 read before tile kt ends -- no barrier, no DMA issue and no cold
-//          fragment read at the tile boundary, where the matrix pipe otherwise drains.  tools/probes/kloop.hip: 113 -> 122 TF/s on the 3x3
-//          gather loop (2 workgroups per CU), no change on the dense loop.  Same MFMA order per accumulator: same bits.
 template <int BM, int BN, int AL, int BL, int MODE, int NST = 3, int MFK = 0>
 __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmArgs p) {
     // MODE 3 ("mixed"): one launch holds the whole tiles [0, split_t1) (fold + epilogue, as MODE 1) AND the split-K
@@ -842,8 +837,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
     };
 
     typedef __attribute__((address_space(3))) void *lds_ptr_t;
-    auto issue_tile_a = [&](int kt, int stage) {
+    auto issue_tile = [&](int kt, int stage) {
         float *As = smem + stage * STAGE;
+        float *Bs = As + BK * BM;
         const int kts = kt < nk ? kt : (nk > 0 ? nk - 1 : 0); // keep the scalar offset inside the buffer
         const bool past = kt >= nk;
         const unsigned a_soff = (unsigned)kts * a_kstep;
@@ -854,10 +850,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(As + (wave * NA + j) * 256), 16,
                                                      (int)(dead ? OOB : a_voff[j]), (int)a_soff, 0, 0);
         }
-    };
-    auto issue_tile_b = [&](int kt, int stage) {
-        float *Bs = smem + stage * STAGE + BK * BM;
-        const int kts = kt < nk ? kt : (nk > 0 ? nk - 1 : 0);
         if constexpr (BL == B_N4) {
             const int kleft = p.K - kt * BK;
             const unsigned b_soff = (unsigned)kts * b_kstep;
@@ -884,10 +876,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(Bs + (wave * LROWS + r) * BN + c * 64), 4, (int)voff, 0, 0, 0);
             }
         }
-    };
-    auto issue_tile = [&](int kt, int stage) {
-        issue_tile_a(kt, stage);
-        issue_tile_b(kt, stage);
     };
 
     // ---- accumulators / epilogue helpers (same numerics as igemm_f32_kernel)
@@ -1007,61 +995,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
         fetch_lut(kt0 + i + 1);
     }
     int stage = 0;
-    // MFK == 2: fragment registers live across tiles (the last k-pair of a tile prefetches the first pair of the next one)
-    [[maybe_unused]] float xaf[2][TM], xbf[2][TN];
-    if constexpr (MFK == 2) {
-        static_assert(NSTAGE >= 4, "mid-tile barrier: the tile issued at the middle of tile kt-1 must not be needed before the middle of tile kt + 1");
-        wait_vmcnt<PER_TILE *(NSTAGE - 2)>(); // the first tile has landed ...
-        __builtin_amdgcn_s_barrier();         // ... for every wave
-        const float *As = smem + (AL == A_M4 ? wm0 + l31 + half * BM : (wm0 + l31) * 4 + half);
-        const float *Bs = smem + BK * BM + wn0 + l31;
-#pragma unroll
-        for (int i = 0; i < TM; i++) xaf[0][i] = As[AL == A_M4 ? i * 32 : i * 128];
-#pragma unroll
-        for (int j = 0; j < TN; j++) xbf[0][j] = Bs[half * BN + j * 32];
-    }
     for (int blk = blk0; blk < blk1; blk++) {
         const int kt_end = (MULTI_KC || SPLIT) ? ((blk + 1) * KC_TILES < nk ? (blk + 1) * KC_TILES : nk) : nk;
         for (int kt = blk * KC_TILES; kt < kt_end; kt++) {
-            if constexpr (MFK == 2) {
-                const int sn = stage == NSTAGE - 1 ? 0 : stage + 1, stp = stage == 0 ? NSTAGE - 1 : stage - 1;
-                const float *As = smem + stage * STAGE + (AL == A_M4 ? wm0 + l31 + half * BM : (wm0 + l31) * 4 + half);
-                const float *Bs = smem + stage * STAGE + BK * BM + wn0 + l31;
-                const float *An = smem + sn * STAGE + (AL == A_M4 ? wm0 + l31 + half * BM : (wm0 + l31) * 4 + half);
-                const float *Bn = smem + sn * STAGE + BK * BM + wn0 + l31;
-                auto a_idx = [](int kk, int i) { return AL == A_M4 ? 2 * kk * BM + i * 32 : (kk >> 1) * BM * 4 + ((2 * kk) & 3) + i * 128; };
-#pragma unroll
-                for (int kk = 0; kk < BK / 2; kk++) {
-                    const int cur = kk & 1, nxt = cur ^ 1;
-                    if (kk + 1 < BK / 2) {
-#pragma unroll
-                        for (int i = 0; i < TM; i++) xaf[nxt][i] = As[a_idx(kk + 1, i)];
-#pragma unroll
-                        for (int j = 0; j < TN; j++) xbf[nxt][j] = Bs[(2 * (kk + 1) + half) * BN + j * 32];
-                    } else { // first k-pair of tile kt + 1 (published by the barrier below; a tile past the end is zero-filled and never multiplied)
-#pragma unroll
-                        for (int i = 0; i < TM; i++) xaf[nxt][i] = An[a_idx(0, i)];
-#pragma unroll
-                        for (int j = 0; j < TN; j++) xbf[nxt][j] = Bn[half * BN + j * 32];
-                    }
-#pragma unroll
-                    for (int i = 0; i < TM; i++)
-#pragma unroll
-                        for (int j = 0; j < TN; j++)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xaf[cur][i], xbf[cur][j], acc[i][j], 0, 0, 0);
-                    if (kk == BK / 4 - 1) {
-                        wait_vmcnt<PER_TILE *(NSTAGE - 3)>(); // this wave's DMA for tile kt + 1 has landed (NSTAGE - 3 later tiles stay in flight)
-                        __builtin_amdgcn_s_barrier();         // ... and everyone else's; every wave is past tile kt - 1, whose stage is refilled next
-                        issue_tile_a(kt + NSTAGE - 1, stp);
-                    }
-                    if (kk == BK / 4 + 1) {
-                        issue_tile_b(kt + NSTAGE - 1, stp);
-                        fetch_lut(kt + NSTAGE);
-                    }
-                }
-                stage = sn;
-                continue;
-            }
             wait_vmcnt<PER_TILE *(NSTAGE - 2)>(); // this wave's DMA for tile kt has landed; NSTAGE-2 later tiles stay in flight
             if (!(ABLATE(p) & 8)) __builtin_amdgcn_s_barrier(); // ... and everyone else's; all waves are done reading the stage of tile kt-1
             const int stp = stage == 0 ? NSTAGE - 1 : stage - 1; // (kt + NSTAGE - 1) % NSTAGE: the stage tile kt-1 used
@@ -2718,15 +2654,6 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
                 RTEN_LAUNCH_CHECK(ctx, "igemm_f32_dma16_kernel launch");
                 return RTEN_HIP_OK;
             }
-            if (pipe == 6) { // four LDS stages, synchronisation point in the middle of a k-tile (see MFK)
-                snprintf(kname, sizeof kname, "igemm_f32_dma_kernel<%d,%d,%d,%d,%d,4,2>", BM, BN, AL, BL, mode);
-                ProfScope ps(ctx, kname, fl, by);
-                if (mode == 2) hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, AL, BL, 2, 4, 2>), grid, dim3(NTHREADS), 0, ctx->stream, a);
-                else if (mode == 1) hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, AL, BL, 1, 4, 2>), grid, dim3(NTHREADS), 0, ctx->stream, a);
-                else hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, AL, BL, 0, 4, 2>), grid, dim3(NTHREADS), 0, ctx->stream, a);
-                RTEN_LAUNCH_CHECK(ctx, "igemm_f32_dma_kernel launch");
-                return RTEN_HIP_OK;
-            }
             if (pipe == 3) { // four LDS stages: three k-tiles in flight behind the one being multiplied
                 snprintf(kname, sizeof kname, "igemm_f32_dma_kernel<%d,%d,%d,%d,%d,4>", BM, BN, AL, BL, mode);
                 ProfScope ps(ctx, kname, fl, by);
@@ -2875,7 +2802,7 @@ int32_t launch_variant(rten_hip_ctx *ctx, GemmArgs &a, int Z, int cfg) {
 }
 
 int pick_cfg(rten_hip_ctx *ctx, int M, long long N, int Z) {
-    if (ctx->gemm_variant_override >= 0 && ctx->gemm_variant_override < 28) return ctx->gemm_variant_override & 3;
+    if (ctx->gemm_variant_override >= 0 && ctx->gemm_variant_override < 24) return ctx->gemm_variant_override & 3;
     int best = 3;
     double best_cost = 1e300;
     for (int c = 0; c < 4; c++) {
@@ -2916,13 +2843,12 @@ constexpr long long kMaxBufBytes = 0x7fffffffll; // buffer offsets are 32-bit; t
 // wave specialisation (4 MFMA waves + 4 loader waves); variants 12..15: LDS-DMA with four LDS stages.  Non-conv
 // operand layouts always use the register-staged kernel.
 // Variants 16..19: LDS-DMA, fragments-first MFMA issue; variants 20..23: LDS-DMA on 16x16x4 MFMAs.
-// Variants 24..27: LDS-DMA, four stages, synchronisation point in the middle of a k-tile.
-RTEN_EXPORT int32_t rten_hip_num_gemm_variants(void) { return 28; }
+RTEN_EXPORT int32_t rten_hip_num_gemm_variants(void) { return 24; }
 
 RTEN_EXPORT int32_t rten_hip_set_gemm_variant_override(rten_hip_ctx *ctx, int32_t variant) {
     RTEN_CHECK_CTX(ctx);
     ctx->gemm_variant_override = variant;
-    ctx->pipeline = (variant >= 24 && variant < 28) ? 6 : (variant >= 20 && variant < 24) ? 5 : (variant >= 16 && variant < 20) ? 4 : (variant >= 12 && variant < 16) ? 3 : (variant >= 8 && variant < 12) ? 2 : ((variant >= 4 && variant < 8) ? 0 : 1);
+    ctx->pipeline = (variant >= 20 && variant < 24) ? 5 : (variant >= 16 && variant < 20) ? 4 : (variant >= 12 && variant < 16) ? 3 : (variant >= 8 && variant < 12) ? 2 : ((variant >= 4 && variant < 8) ? 0 : 1);
     return RTEN_HIP_OK;
 }
 
