@@ -593,7 +593,8 @@ def test_dql_staged_conv_bit_exact(ctx, pm):
         # per-output-channel weight scales: ConvInteger -> Cast -> Mul([1,O,1,1]) (the form the reference leaves unfused)
         wsv = (rng.f32(O) * 0.01 + 0.001).astype(np.float32)
         scv = DeviceTensor(ctx, (O,), np.float32)
-        ctx.call("rten_hip_mul_f32", O, dev(ctx, wsv).vp, xs.vp, 1, scv.vp)
+        wsd = dev(ctx, wsv)  # (named: a temporary would be freed before the launch reads it)
+        ctx.call("rten_hip_mul_f32", O, wsd.vp, xs.vp, 1, scv.vp)
         dv = L.Conv2dInt8Desc(cd, 0, 1, 0, pm, 1, 1, O)
         ctx.call("rten_hip_conv2d_int8", C.byref(dv), staged.vp, packed.vp, xz.vp, None, scv.vp, bd.vp, None, 0, out.vp)
         sv = (wsv * np.float32(s)).astype(np.float32)
@@ -601,7 +602,9 @@ def test_dql_staged_conv_bit_exact(ctx, pm):
         bits_equal(out.numpy(), want)
         ctx.call("rten_hip_set_int8_path", 1)  # generic kernel, plain operands
         dg = L.Conv2dInt8Desc(cd, 0, 1, 0, pm, 0, 0, O)
-        ctx.call("rten_hip_conv2d_int8", C.byref(dg), dev(ctx, q).vp, wd.vp, xz.vp, None, scv.vp, bd.vp, None, 0, out.vp)
+        qd = dev(ctx, q)
+        ctx.call("rten_hip_conv2d_int8", C.byref(dg), qd.vp, wd.vp, xz.vp, None, scv.vp, bd.vp, None, 0, out.vp)
+        ctx.sync()
         ctx.call("rten_hip_set_int8_path", 0)
         bits_equal(out.numpy(), want)
 

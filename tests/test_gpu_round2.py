@@ -202,15 +202,16 @@ def test_matmul_integer_prepacked_rhs(ctx):
     a = rng.integers(0, 256, (32, 2048)).astype(np.uint8)
     nb = ctx.lib.rten_hip_gemm_int8_packed_bytes(2048, 1000)
     packed = DeviceTensor(ctx, [nb], np.uint8)
-    ctx.call("rten_hip_gemm_int8_prepack", 2048, 1000, dev(ctx, wq).vp, 1, 2048, 1, packed.vp)
+    wqd, ad, zpd = dev(ctx, wq), dev(ctx, a), dev(ctx, np.array(7, np.uint8))  # (named: temporaries would be freed before the launches read them)
+    ctx.call("rten_hip_gemm_int8_prepack", 2048, 1000, wqd.vp, 1, 2048, 1, packed.vp)
     d = L.GemmInt8Desc(32, 1000, 2048, 2048, 1, 0, 0, 1000, 0, 1, 1, 0, 0, 1, 0, 0, 0, 1)
     y = DeviceTensor(ctx, [32, 1000], np.int32)
-    ctx.call("rten_hip_gemm_int8", C.byref(d), dev(ctx, a).vp, packed.vp, dev(ctx, np.array(7, np.uint8)).vp, None, None, y.vp)
+    ctx.call("rten_hip_gemm_int8", C.byref(d), ad.vp, packed.vp, zpd.vp, None, None, y.vp)
     bits_equal(y.numpy(), _mmi_ref(a, np.ascontiguousarray(wq.T), np.array(7, np.uint8), None))
     # a prepacked RHS cannot be batched
     d.batch, d.b_bs = 2, 5
     with pytest.raises(L.HipError, match="single matrix"):
-        ctx.call("rten_hip_gemm_int8", C.byref(d), dev(ctx, a).vp, packed.vp, dev(ctx, np.array(7, np.uint8)).vp, None, None, y.vp)
+        ctx.call("rten_hip_gemm_int8", C.byref(d), ad.vp, packed.vp, zpd.vp, None, None, y.vp)
 
 
 # ------------------------------------------------------------------------------------------ the boundary
@@ -546,7 +547,8 @@ def test_conv2d_int8_dql_matches_the_separate_operators(ctx):
         st_in, st_a, st_b = C.c_void_p(stats.ptr), None, None
         t = DeviceTensor(ctx, (n, c, h, w), np.float32)
         zp0, sc0 = DeviceTensor.from_numpy(ctx, np.array([7], np.uint8)), DeviceTensor.from_numpy(ctx, np.array([0.013], np.float32))
-        ctx.call("rten_hip_conv2d_int8_stats", C.byref(d0), DeviceTensor.from_numpy(ctx, x0).vp, DeviceTensor.from_numpy(ctx, w0).vp, zp0.vp, None, sc0.vp, None, None, 0,
+        x0d, w0d = DeviceTensor.from_numpy(ctx, x0), DeviceTensor.from_numpy(ctx, w0)  # (named: temporaries would be freed before the launch reads them)
+        ctx.call("rten_hip_conv2d_int8_stats", C.byref(d0), x0d.vp, w0d.vp, zp0.vp, None, sc0.vp, None, None, 0,
                  t.vp, st_in)
         # consumer weights
         wq = rng.i8(o * c, reduced=True).reshape(o, c, 1, 1)
@@ -555,7 +557,8 @@ def test_conv2d_int8_dql_matches_the_separate_operators(ctx):
         res = rng.f32(n * o * h * w).reshape(n, o, h, w) - 0.5
         d = L.Conv2dInt8Desc(L.Conv2dDesc(n, c, h, w, o, 1, 1, (C.c_int32 * 4)(0, 0, 0, 0), 1, 1, 1, 1, 1, h, w), 0, 1, 0, L.PAD_RAW0_I8, 1, 1, o if per_ch else 1)
         packed = DeviceTensor(ctx, (ctx.lib.rten_hip_conv2d_int8_packed_bytes(C.byref(d)),), np.uint8)
-        ctx.call("rten_hip_conv2d_int8_prepack", C.byref(d), DeviceTensor.from_numpy(ctx, wq).vp, packed.vp)
+        wqd = DeviceTensor.from_numpy(ctx, wq)
+        ctx.call("rten_hip_conv2d_int8_prepack", C.byref(d), wqd.vp, packed.vp)
         wsd, bd, rd = DeviceTensor.from_numpy(ctx, ws), DeviceTensor.from_numpy(ctx, bias), DeviceTensor.from_numpy(ctx, res)
         outs = []
         for fused in (False, True):
