@@ -56,7 +56,6 @@ struct FastArgs {
     int tiles_m, tiles_n, n_fastest;
     // conv geometry (padded image)
     int conv, OW, sy, sx, Hp, Wp, Cp, KH, KW, dy, dx;
-    const int *btab_g; // conv: chunk -> B-side byte offset, one table per geometry, built once and cached in the context (-1 = dead chunk)
     // BQ kernels (DynamicQuantizeLinear fused into the B loader of a pointwise conv): the f32 activations, the min/max block their
     // producer left, the plane size, and where the quantizer's own outputs go
     const float *xf;
@@ -376,17 +375,31 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
     }
 
     // ---- this wave's chunk walk: chunk index wave, wave + 4, ... of the K axis (16-byte chunks).
-    // The B-side scalar offset of a chunk -- conv: its (ky, kx, c16) position on the padded image -- comes from a per-geometry table
-    // (built once, cached in the context), and everything the loop derives from the
+    // The B-side scalar offset of a chunk -- conv: its (ky, kx, c16) position on the padded image -- comes from a table that the
+    // workgroup builds in LDS before the loop (one division pair per chunk, once), and everything the loop derives from the
     // walk is kept in scalar registers: the previous form carried an odometer in vector registers and paid ~100 VALU + SALU
     // instructions per k-tile, waterfall loops around the DMA included, for two 32-cycle MFMAs (counters: profiles/r05).
     const int nchunks = p.Kp / 16;
     const int nkt = (p.Kp + KTK - 1) / KTK;
     const int nit = (nkt + KG - 1) / KG;   // loop trips: KG k-tiles per trip
     const int tchunks = ((nkt + KG - 1) / KG + NSTAGE) * KG * (KTK / 16); // chunks the walk can name (>= nchunks; the tail is dead)
-    // (Round 3: the conv's table comes from the context's cache -- one division pair per chunk used to be paid by every workgroup of every
-    // launch, behind a barrier of its own; a GEMM's entries are plain multiples and are formed where they are used.)
-    const int *const btab = p.btab_g;
+    int *const btab = reinterpret_cast<int *>(smem + NSTAGE * STAGE);
+    {
+        const int cpc = p.conv ? p.Cp / 16 : 1; // chunks per tap
+        for (int c = t; c < tchunks; c += 256 * KG) {
+            int off = -1; // dead chunk: K padding
+            if (c < nchunks) {
+                if (p.conv) {
+                    const int tap = c / cpc, cc = c - tap * cpc, ky = tap / p.KW, kx = tap - ky * p.KW;
+                    if (ky < p.KH) off = ((cc * p.Hp + ky * p.dy) * p.Wp + kx * p.dx) * 16;
+                } else {
+                    off = c * 16 * p.N;
+                }
+            }
+            btab[c] = off;
+        }
+    }
+    __syncthreads();
     // ---- BQ: DynamicQuantizeLinear parameters from the producer's statistics (every workgroup folds the 256 slots; min / max are
     // order-free), the quantizer's outputs, and this thread's pieces of the B tile
     [[maybe_unused]] float q_scale = 0.f, q_inv = 0.f;
@@ -400,7 +413,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
         b = dql::ord2f(p.in_stats[dql::kStatSlots + t]);
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) { a = fminf(a, __shfl_xor(a, o, 64)); b = fmaxf(b, __shfl_xor(b, o, 64)); }
-        float *red = reinterpret_cast<float *>(smem + NSTAGE * STAGE); // (the bytes behind the stage ring)
+        float *red = reinterpret_cast<float *>(btab);
         if (lane == 0) { red[wave_all] = a; red[4 + wave_all] = b; }
         __syncthreads();
         const float mn = fminf(fminf(red[0], red[1]), fminf(red[2], red[3])), mx = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
@@ -423,8 +436,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
     // with v_readlane: no LDS round trip on the issue path.  Refilled every 64 pieces.
     auto bo_fill = [&](int first) {
         const int c = first + 4 * KG * lane;
-        if (p.conv) return c < tchunks ? btab[c] : -1;
-        return c < nchunks ? c * 16 * p.N : -1;
+        return c < tchunks ? btab[c] : -1;
     };
     int bo_vec = bo_fill(ch_idx);
     int bo_pos = 0;
@@ -1068,34 +1080,6 @@ int32_t rten_i8_fast_gemm(rten_hip_ctx *ctx, const rten_hip_gemm_int8_desc *d, c
 }
 
 namespace {
-// chunk c of the conv's K axis (k = (ky, kx, c16)) -> byte offset of its 16-channel piece relative to a pixel's base on the padded image
-__global__ void i8_chunk_table_kernel(int *tab, int n, int nchunks, int cpc, int KH, int KW, int Hp, int Wp, int dy, int dx) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n) return;
-    int off = -1; // dead chunk: K padding / look-ahead past the end
-    if (c < nchunks) {
-        const int tap = c / cpc, cc = c - tap * cpc, ky = tap / KW, kx = tap - ky * KW;
-        if (ky < KH) off = ((cc * Hp + ky * dy) * Wp + kx * dx) * 16;
-    }
-    tab[c] = off;
-}
-constexpr int kChunkTableSlack = 256; // entries past the last chunk that the kernels' look-ahead may name (<= (stages + 1) * k-groups * chunks per k-tile)
-const int *get_chunk_table(rten_hip_ctx *ctx, int nchunks, int cpc, int KH, int KW, int Hp, int Wp, int dy, int dx) {
-    char key[112];
-    snprintf(key, sizeof key, "i8ct.%d.%d.%d.%d.%d.%d.%d.%d", nchunks, cpc, KH, KW, Hp, Wp, dy, dx);
-    auto it = ctx->luts.find(key);
-    if (it != ctx->luts.end()) return (const int *)it->second;
-    if (ctx->capturing) return nullptr; // allocation is not capturable: warm up eagerly first
-    const int n = nchunks + kChunkTableSlack;
-    void *dptr = nullptr;
-    if (hipMalloc(&dptr, (size_t)n * sizeof(int)) != hipSuccess) return nullptr;
-    hipLaunchKernelGGL(i8_chunk_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int *)dptr, n, nchunks, cpc, KH, KW, Hp, Wp, dy, dx);
-    ctx->luts[key] = dptr;
-    return (const int *)dptr;
-}
-} // namespace
-
-namespace {
 struct ConvGeom { int Cp, Hp, Wp, taps, Kreal, Kp, P; size_t img; bool ok; };
 ConvGeom conv_geom(const rten_hip_conv2d_int8_desc *di) {
     const rten_hip_conv2d_desc *d = &di->conv;
@@ -1275,8 +1259,6 @@ int32_t i8_fast_conv_impl(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di
     g.need_csum = (di->w_zp_len != 0 || !di->w_signed) ? 1 : 0; // weight zero point may be non-zero in the signed domain
     g.conv = 1; g.OW = d->out_w; g.sy = d->stride_h; g.sx = d->stride_w; g.Hp = cg.Hp; g.Wp = cg.Wp; g.Cp = cg.Cp;
     g.KH = d->kh; g.KW = d->kw; g.dy = d->dil_h; g.dx = d->dil_w;
-    g.btab_g = get_chunk_table(ctx, cg.Kp / 16, cg.Cp / 16, d->kh, d->kw, cg.Hp, cg.Wp, d->dil_h, d->dil_w);
-    if (!g.btab_g) return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "conv_int8: chunk table allocation failed (warm up before graph capture)");
     double out_bytes = 4.0 * d->o * g.N;
     if (qo) {
         const ConvGeom ng = conv_geom(qo->next);
@@ -1394,8 +1376,6 @@ RTEN_EXPORT int32_t rten_hip_conv2d_int8_dql(rten_hip_ctx *ctx, const rten_hip_c
     g.stats = (unsigned *)out_stats;
     g.need_csum = di->w_signed ? 0 : 1;
     g.conv = 1; g.OW = d->out_w; g.sy = 1; g.sx = 1; g.Hp = d->h; g.Wp = d->w; g.Cp = cg.Cp; g.KH = 1; g.KW = 1; g.dy = 1; g.dx = 1;
-    g.btab_g = get_chunk_table(ctx, cg.Kp / 16, cg.Cp / 16, 1, 1, d->h, d->w, 1, 1);
-    if (!g.btab_g) return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "conv_int8: chunk table allocation failed (warm up before graph capture)");
     // algorithmic bytes: i8 weights + f32 activations (read once) + f32 output (+ f32 residual)
     return dispatch_fast(ctx, g, 2.0 * d->o * (double)g.N * cg.Kreal,
                          (double)d->o * cg.Kreal + 4.0 * d->n * d->c * d->h * d->w + 4.0 * d->o * g.N + (g.res ? 4.0 * d->o * g.N : 0.0));
