@@ -13,11 +13,14 @@ A step = one forward pass of ResNet-50 (53 convs + maxpool + global-avg-pool + f
 independent, so the path shards with no data-path collective (weak scaling: 32 images per GPU); the only
 collective is the one-time RCCL broadcast of the prepacked weight arena from rank 0 at load.
 
-Rank 0 prints ONE JSON line: metric/value (whole-job inferences/s), roofline of the dominant kernel
-(measured live with HIP events on the backend's stream in an instrumented pass over the same K steps),
-and cpu_baseline (the CPU oracle -- a port of the reference algorithm -- timed on this host's cores on a
+Rank 0 prints ONE JSON line: metric/value (whole-job inferences/s); `roofline` -- f32: achieved / frac = the conv FLOPs of one batch over the
+TIMED step (the state `value` was measured in: chains overlapping, every kernel and gap included), with the dominant kernel's stand-alone
+figures (HIP events per launch on the backend's stream, an instrumented pass over the same K steps) as `dominant_kernel` / `igemm_family`, and its
+HBM traffic from the committed PMC pass when that pass ran the same launch plan; int8: the dominant kernel against the HBM peak plus the whole step
+against the graph's HBM floor -- ; and cpu_baseline (the CPU oracle -- a port of the reference algorithm -- timed on this host's cores on a
 bounded sample; N=1 only).  At N=1 the line also carries `secondary`: the int8 ResNet-50 (configs[2]) and BERT-base (configs[3])
-harnesses run in child processes after the headline measurement.  Defaults: K = 50, W = 20 (the chip needs about 20 ms of
+harnesses run in child processes after the headline measurement.  The per-layer launch plan is the one committed under profiles/plans/
+(`--autotune` re-tunes: rank 0 tunes, the plan is broadcast; `config.launch_plan` names what ran).  Defaults: K = 50, W = 20 (the chip needs about 20 ms of
 load to settle its clocks; a run with the driver's own K / W is timed exactly as given).
 """
 import argparse
