@@ -73,6 +73,7 @@ struct FastArgs {
     float *q_product;
     int q_cb, q_Hp, q_Wp, q_pt, q_pl, q_H, q_W, q_pad_mode;
     unsigned q_bytes;
+    int debug_flags; // RTEN_HIP_DEBUG tuning switches seen by the kernel (bit 0: general zero-point algebra everywhere)
 };
 
 __device__ __forceinline__ int zp_signed(const uint8_t *zp, int idx, int is_signed) {
@@ -321,7 +322,7 @@ constexpr unsigned kSyncGranules = 2048;  // >= the workgroups the device holds 
 constexpr unsigned kSyncWords = kSyncCtlWords + 2 * kSyncGranules;
 constexpr unsigned long long kGranuleReset = 0x00000000ffffffffull; // {min = 0xffffffff, max = 0}: what a reset leaves, never a real pair
 constexpr unsigned kSyncSpinLimit = 1u << 17;
-template <int BM, int BN, int NSTAGE, bool RES, int KTK = 64, int KG = 1, bool BQ = false, bool QO = false>
+template <int BM, int BN, int NSTAGE, bool RES, int KTK = 64, int KG = 1, bool BQ = false, bool QO = false, bool RT = false>
 __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kernel(const FastArgs p) {
     static_assert(!BQ || (KG == 1 && KTK == 64), "quantize-on-load: one k-group, 64-byte k-tiles");
     static_assert(!(BQ && QO), "quantize-on-load and quantized output are separate instantiations");
@@ -680,6 +681,8 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
     // registers (one 32 x 32 block) are finished at a time; all of a block's stores are issued back to back.
     float st_mn = __builtin_inff(), st_mx = -__builtin_inff(); // output statistics for the consuming DynamicQuantizeLinear
     const int ml0 = wm0 + 4 * half;
+    const bool full_rows = m0 + BM <= p.M;                                                           // (workgroup-uniform)
+    constexpr bool rowterm_only = RT; // weight zero point 0, one activation zero point (the launcher checks: a_zp == NULL, signed A, b_zp_len <= 1)
     if (epi) {
 #pragma unroll
     for (int i = 0; i < TM; i++) {
@@ -691,21 +694,41 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
             const int ml = ml0 + i * 32 + acc_row(r);
             mok[r] = m0 + ml < p.M;
             rsv[r] = (unsigned)rowc[ml];
-            azv[r] = (unsigned)rowc[BM + ml];
+            azv[r] = RT ? 0u : (unsigned)rowc[BM + ml];
             bv[r] = __builtin_bit_cast(float, rowc[2 * BM + ml]);
             srow[r] = __builtin_bit_cast(float, rowc[3 * BM + ml]);
+        }
+        // The convolution form of every ort-quantized graph -- weight zero point 0 (signed weights without a zero-point input), ONE activation
+        // zero point -- needs a single correction term per ROW, bz * rowsum(A): formed once per 32-row block instead of three multiplies and
+        // three adds per element (the epilogue of these short-K launches is VALU-issue bound: tools/debug/i8_trace.py measured 2.7-5.4 us of
+        // epilogue next to a 2-7 us k-loop).  Same integers: the dropped terms are multiplied by a zero.
+        [[maybe_unused]] unsigned trow[16];
+        if constexpr (rowterm_only) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) trow[r] = bzv[0] * rsv[r];
         }
 #pragma unroll
         for (int j = 0; j < TN; j++) {
             const bool cok = basev[j] != OOB;
             unsigned v[16];
+            if constexpr (rowterm_only) {
 #pragma unroll
-            for (int r = 0; r < 16; r++)
-                v[r] = (unsigned)acc[i][j][r] - bzv[j] * rsv[r] - azv[r] * csv[j] + (unsigned)p.Kreal * azv[r] * bzv[j];
+                for (int r = 0; r < 16; r++) v[r] = (unsigned)acc[i][j][r] - trow[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    v[r] = (unsigned)acc[i][j][r] - bzv[j] * rsv[r] - azv[r] * csv[j] + (unsigned)p.Kreal * azv[r] * bzv[j];
+            }
             if (p.scale) {
                 float f[16];
+                if (p.scale_per_row) {
 #pragma unroll
-                for (int r = 0; r < 16; r++) f[r] = (float)(int)v[r] * (p.scale_per_row ? srow[r] : scv[j]); // cast_scale (matmul.rs:751,761)
+                    for (int r = 0; r < 16; r++) f[r] = (float)(int)v[r] * srow[r]; // cast_scale (matmul.rs:751,761)
+                } else {
+                    const float sj = scv[j];
+#pragma unroll
+                    for (int r = 0; r < 16; r++) f[r] = (float)(int)v[r] * sj;
+                }
                 if (p.bias) {
 #pragma unroll
                     for (int r = 0; r < 16; r++) f[r] = f[r] + bv[r];
@@ -719,9 +742,16 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
                     for (int r = 0; r < 16; r++) f[r] = vm::relu(f[r]);
                 }
                 if (p.stats) { // fminf / fmaxf drop NaNs like the reference's min/max sweep (min_max.rs:27-30)
+                    if (full_rows) { // every row of the tile exists: one column test for the block
+                        if (cok) {
 #pragma unroll
-                    for (int r = 0; r < 16; r++)
-                        if (mok[r] && cok) { st_mn = fminf(f[r], st_mn); st_mx = fmaxf(f[r], st_mx); }
+                            for (int r = 0; r < 16; r++) { st_mn = fminf(f[r], st_mn); st_mx = fmaxf(f[r], st_mx); }
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; r++)
+                            if (mok[r] && cok) { st_mn = fminf(f[r], st_mn); st_mx = fmaxf(f[r], st_mx); }
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 16; r++) v[r] = __builtin_bit_cast(unsigned, f[r]);
@@ -731,11 +761,15 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
                 for (int r = 0; r < 16; r++) acc[i][j][r] = (int)v[r];
             }
             if (!QO || p.C) {
+                const unsigned vo_col = cok ? basev[j] + half_off : OOB;
+                if (full_rows) {
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const unsigned x = v[r];
-                    __builtin_amdgcn_raw_buffer_store_b32(x, rsC, (int)((mok[r] && cok) ? basev[j] + half_off : OOB),
-                                                          (int)((unsigned)(mb_u + i * 32 + acc_row(r)) * rs4), 0);
+                    for (int r = 0; r < 16; r++)
+                        __builtin_amdgcn_raw_buffer_store_b32(v[r], rsC, (int)vo_col, (int)((unsigned)(mb_u + i * 32 + acc_row(r)) * rs4), 0);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        __builtin_amdgcn_raw_buffer_store_b32(v[r], rsC, (int)(mok[r] ? vo_col : OOB), (int)((unsigned)(mb_u + i * 32 + acc_row(r)) * rs4), 0);
                 }
             }
         }
@@ -946,8 +980,15 @@ bool launch_fast(rten_hip_ctx *ctx, FastArgs &a, const char *name, double ops, d
         ProfScope ps(ctx, name, ops, bytes);
         hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256 * KG), lds, ctx->stream, a);
     };
-    if (a.res && a.scale) go(igemm_i8_fast_kernel<BM, BN, NST, true, KTK, KG, BQ, QO>);
-    else go(igemm_i8_fast_kernel<BM, BN, NST, false, KTK, KG, BQ, QO>);
+    // RT: the single-row-term zero-point algebra of the convolution form (weight zero point 0 in the signed domain, one activation zero point)
+    const bool rt = a.conv && !(a.debug_flags & 1) && a.a_zp == nullptr && a.a_signed && a.b_zp_len <= 1 && !a.need_csum;
+    if (rt) {
+        if (a.res && a.scale) go(igemm_i8_fast_kernel<BM, BN, NST, true, KTK, KG, BQ, QO, true>);
+        else go(igemm_i8_fast_kernel<BM, BN, NST, false, KTK, KG, BQ, QO, true>);
+    } else {
+        if (a.res && a.scale) go(igemm_i8_fast_kernel<BM, BN, NST, true, KTK, KG, BQ, QO, false>);
+        else go(igemm_i8_fast_kernel<BM, BN, NST, false, KTK, KG, BQ, QO, false>);
+    }
     return launched;
 }
 
@@ -1257,6 +1298,7 @@ int32_t i8_fast_conv_impl(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di
     g.scale_per_row = (scale && di->scale_len > 1) ? 1 : 0;
     g.stats = scale ? (unsigned *)stats : nullptr;
     g.need_csum = (di->w_zp_len != 0 || !di->w_signed) ? 1 : 0; // weight zero point may be non-zero in the signed domain
+    g.debug_flags = (ctx->debug & 0x200000) ? 1 : 0;
     g.conv = 1; g.OW = d->out_w; g.sy = d->stride_h; g.sx = d->stride_w; g.Hp = cg.Hp; g.Wp = cg.Wp; g.Cp = cg.Cp;
     g.KH = d->kh; g.KW = d->kw; g.dy = d->dil_h; g.dx = d->dil_w;
     double out_bytes = 4.0 * d->o * g.N;
