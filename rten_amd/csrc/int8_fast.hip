@@ -76,25 +76,9 @@ struct FastArgs {
     int debug_flags; // RTEN_HIP_DEBUG tuning switches seen by the kernel (bit 0: general zero-point algebra everywhere)
     // exact division by the conv geometry's run-time divisors as multiply + shift (filled by launch_fast): the prologue's per-lane
     // pixel decode and the chunk table otherwise spend ~40 VALU instructions per division, on every resident wave at once
-    struct Div { unsigned mul; int shift; } d_pn, d_ow, d_cpc, d_kw, d_hw, d_qw, d_tile;
+    RtenDiv d_pn, d_ow, d_cpc, d_kw, d_hw, d_qw, d_tile;
 };
 
-// q = n / d for 0 <= n < 2^L as (n * mul) >> shift with mul = ceil(2^(L+s) / d), s = ceil(log2 d): the error term n * (mul*d - 2^(L+s)) stays
-// below 2^(L+s), so the quotient is exact on the whole range (Granlund & Montgomery, division by invariant integers)
-inline FastArgs::Div make_div(long long n_max, int d) {
-    if (d < 1) d = 1;
-    int L = 1;
-    while (((long long)1 << L) <= n_max) L++;
-    int sft = 0;
-    while (((long long)1 << sft) < d) sft++;
-    const unsigned long long two = (unsigned long long)1 << (L + sft);
-    FastArgs::Div r;
-    r.mul = (unsigned)((two + (unsigned long long)d - 1) / (unsigned long long)d);
-    r.shift = L + sft;
-    return r;
-}
-
-__device__ __forceinline__ int fast_div(int n, const FastArgs::Div &d) { return (int)(((unsigned long long)(unsigned)n * d.mul) >> d.shift); }
 
 __device__ __forceinline__ int zp_signed(const uint8_t *zp, int idx, int is_signed) {
     if (!zp) return is_signed ? 0 : -128;
@@ -367,7 +351,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
         const int xcd = id & 7, q = nt >> 3, r = nt & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
     }
-    const int tdiv = p.n_fastest ? p.tiles_n : p.tiles_m, tq = fast_div(tile, p.d_tile), tr = tile - tq * tdiv;
+    const int tdiv = p.n_fastest ? p.tiles_n : p.tiles_m, tq = rten_div(tile, p.d_tile), tr = tile - tq * tdiv;
     const int bm = p.n_fastest ? tq : tr, bn = p.n_fastest ? tr : tq;
     const int m0 = bm * BM, n0 = bn * BN;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)p.A, 0, (int)p.a_bytes, 0x00020000);
@@ -385,8 +369,8 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
         const int n = n0 + j * 64 + lane;
         if (n < p.N) {
             if (RT || p.conv) { // (RT kernels are convolutions by construction: the GEMM form is not compiled into them)
-                const int nb = fast_div(n, p.d_pn), np = n - nb * p.Pn;
-                const int oy = fast_div(np, p.d_ow), ox = np - oy * p.OW;
+                const int nb = rten_div(n, p.d_pn), np = n - nb * p.Pn;
+                const int oy = rten_div(np, p.d_ow), ox = np - oy * p.OW;
                 b_voff[j] = (unsigned)(((nb * (p.Cp / 16) * p.Hp + oy * p.sy) * p.Wp + ox * p.sx) * 16);
             } else {
                 b_voff[j] = (unsigned)n * 16u;
@@ -412,7 +396,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
             int off = -1; // dead chunk: K padding
             if (c < nchunks) {
                 if (RT || p.conv) {
-                    const int tap = fast_div(c, p.d_cpc), cc = c - tap * cpc, ky = fast_div(tap, p.d_kw), kx = tap - ky * p.KW;
+                    const int tap = rten_div(c, p.d_cpc), cc = c - tap * cpc, ky = rten_div(tap, p.d_kw), kx = tap - ky * p.KW;
                     if (ky < p.KH) off = ((cc * p.Hp + ky * p.dy) * p.Wp + kx * p.dx) * 16;
                 } else {
                     off = c * 16 * p.N;
@@ -449,7 +433,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
         q_slot0 = __builtin_amdgcn_readfirstlane(t / BN); // wave-uniform: BN is a multiple of 64
         const int n = n0 + q_px;
         if (n < p.N) {
-            const int img = fast_div(n, p.d_hw), pp = n - img * p.HW;
+            const int img = rten_div(n, p.d_hw), pp = n - img * p.HW;
             q_voff = (unsigned)((img * p.Cin) * p.HW + pp) * 4u;
         }
     }
@@ -584,7 +568,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
         const int n = n0 + wn0 + j * 32 + l31;
         const bool cok = n < p.N;
         const int nn = cok ? n : 0;
-        const int nb = fast_div(nn, p.d_pn), np = nn - nb * p.Pn;
+        const int nb = rten_div(nn, p.d_pn), np = nn - nb * p.Pn;
         basev[j] = cok ? (unsigned)((long long)nb * p.c_ns + np) << 2 : OOB; // byte offset of (row 0, column n); rows ride the scalar offset
         bzv[j] = (unsigned)zp_signed(p.b_zp, (RT || p.b_zp_len == 1) ? 0 : nn, p.b_signed);
         csv[j] = (!RT && p.csum) ? (unsigned)p.csum[nn] : 0u;
@@ -873,8 +857,8 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
             const int n = n0 + wn0 + j * 32 + l31;
             const bool cok = n < p.N;
             const int nn = cok ? n : 0;
-            const int nb = fast_div(nn, p.d_pn), np = nn - nb * p.Pn;
-            const int oy = fast_div(np, p.d_qw), ox = np - oy * p.q_W;
+            const int nb = rten_div(nn, p.d_pn), np = nn - nb * p.Pn;
+            const int oy = rten_div(np, p.d_qw), ox = np - oy * p.q_W;
             const unsigned pix = (unsigned)((oy + p.q_pt) * p.q_Wp + ox + p.q_pl);
 #pragma unroll
             for (int i = 0; i < TM; i++) {
@@ -995,15 +979,15 @@ bool launch_fast(rten_hip_ctx *ctx, FastArgs &a, const char *name, double ops, d
     static_assert(ring <= 128 * 1024, "int8 tile ring exceeds the LDS of a compute unit");
     const int nkt = (a.Kp + KTK - 1) / KTK;
     const size_t lds = ring + (size_t)((nkt + KG - 1) / KG + NST) * KG * (KTK / 16) * 4; // + the chunk -> B offset table
-    a.d_pn = make_div((long long)a.tiles_n * BN, a.Pn);
-    a.d_tile = make_div((long long)a.tiles_m * a.tiles_n, a.n_fastest ? a.tiles_n : a.tiles_m);
-    if (BQ) a.d_hw = make_div((long long)a.tiles_n * BN, a.HW);
-    if (QO) a.d_qw = make_div(a.Pn, a.q_W);
+    a.d_pn = rten_make_div((long long)a.tiles_n * BN, a.Pn);
+    a.d_tile = rten_make_div((long long)a.tiles_m * a.tiles_n, a.n_fastest ? a.tiles_n : a.tiles_m);
+    if (BQ) a.d_hw = rten_make_div((long long)a.tiles_n * BN, a.HW);
+    if (QO) a.d_qw = rten_make_div(a.Pn, a.q_W);
     if (a.conv) {
         const long long tchunks = (long long)((nkt + KG - 1) / KG + NST) * KG * (KTK / 16);
-        a.d_ow = make_div(a.Pn, a.OW);
-        a.d_cpc = make_div(tchunks, a.Cp / 16);
-        a.d_kw = make_div(tchunks, a.KW);
+        a.d_ow = rten_make_div(a.Pn, a.OW);
+        a.d_cpc = rten_make_div(tchunks, a.Cp / 16);
+        a.d_kw = rten_make_div(tchunks, a.KW);
     }
     bool launched = true;
     auto go = [&](auto kern) {

@@ -114,3 +114,24 @@ inline void rten_bind_device(const rten_hip_ctx *ctx) {
     } while (0)
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Exact division by a run-time divisor as multiply + shift.  q = n / d for 0 <= n < 2^L as (n * mul) >> shift with mul = ceil(2^(L+s) / d),
+// s = ceil(log2 d): the error term n * (mul * d - 2^(L+s)) stays below 2^(L+s), so the quotient is exact on the whole range (Granlund &
+// Montgomery, "Division by invariant integers using multiplication").  The kernels' prologues decode tile / pixel indices with run-time
+// divisors; the compiler's integer division is ~40 VALU instructions per quotient, paid by every wave of every workgroup.
+struct RtenDiv { unsigned mul; int shift; };
+inline RtenDiv rten_make_div(long long n_max, long long d) {
+    if (d < 1) d = 1;
+    if (n_max < 1) n_max = 1;
+    int L = 1;
+    while (L < 31 && ((long long)1 << L) <= n_max) L++;
+    int sft = 0;
+    while (((long long)1 << sft) < d) sft++;
+    RtenDiv r;
+    if (sft > 31) { r.mul = 0; r.shift = 0; return r; } // divisor above every n in range: quotient 0
+    const unsigned long long two = (unsigned long long)1 << (L + sft);
+    r.mul = (unsigned)((two + (unsigned long long)d - 1) / (unsigned long long)d);
+    r.shift = L + sft;
+    return r;
+}
+__device__ __forceinline__ int rten_div(int n, const RtenDiv &d) { return (int)(((unsigned long long)(unsigned)n * d.mul) >> d.shift); }
