@@ -271,6 +271,16 @@ int32_t rten_hip_conv2d_int8_stats(rten_hip_ctx *ctx, const rten_hip_conv2d_int8
 int32_t rten_hip_dynamic_quantize_linear_staged_stats(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *desc, const float *x,
                                                       const void *stats, void *staged, float *scale, uint8_t *zero_point,
                                                       const float *mul_by, float *product);
+/* One DynamicQuantizeLinear read by SEVERAL ConvInteger nodes (ort-quantize reuses a quantized input: a stage's shortcut convolution and
+ * its first 1x1 convolution read the same tensor) is followed by one scalar Mul(x_scale, w_scale_i) per consumer.  This form folds all of
+ * them into the quantizer's launch: product[i][0] = scale * mul_by[i][0] for i < count (count <= 4; `mul_by` / `product` are HOST arrays of
+ * device pointers), each a single f32 multiply -- the bits of the separate Mul nodes.  `stats` optional: non-NULL = the producer's
+ * statistics block (as rten_hip_dynamic_quantize_linear_staged_stats), NULL = the quantizer sweeps the tensor itself (as
+ * rten_hip_dynamic_quantize_linear_staged). */
+int32_t rten_hip_dynamic_quantize_linear_staged_products(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *desc, const float *x,
+                                                         const void *stats /* optional */, void *staged, float *scale,
+                                                         uint8_t *zero_point, int32_t count, const float *const *mul_by,
+                                                         float *const *product);
 /* The whole chain DynamicQuantizeLinear -> ConvInteger -> Cast -> Mul(x_scale, w_scale) [-> Add bias] [-> Add residual] [-> Relu]
  * (the reference's DynamicQuantizeLinear + ConvIntegerToFloat, src/ops/quantize.rs:352-436 + src/ops/conv.rs:495-587) in ONE launch
  * for pointwise convolutions (1x1, stride 1, no padding, groups 1, C % 64 == 0) whose input statistics `in_stats` were accumulated
@@ -394,6 +404,10 @@ typedef struct {
     int32_t count_include_pad; /* AveragePool only */
 } rten_hip_pool2d_desc;
 int32_t rten_hip_max_pool2d_f32(rten_hip_ctx *ctx, const rten_hip_pool2d_desc *desc, const float *x, float *y);
+/* MaxPool whose output is quantized next (stem -> MaxPool -> DynamicQuantizeLinear in an ort-quantized CNN): the same values, plus their
+ * min / max accumulated into `stats` (rten_hip_minmax_stats_bytes(), reset before the call) for
+ * rten_hip_dynamic_quantize_linear_staged_stats / _products / rten_hip_conv2d_int8_dql, which then skip their own sweep. */
+int32_t rten_hip_max_pool2d_f32_stats(rten_hip_ctx *ctx, const rten_hip_pool2d_desc *desc, const float *x, float *y, void *stats);
 int32_t rten_hip_average_pool2d_f32(rten_hip_ctx *ctx, const rten_hip_pool2d_desc *desc, const float *x, float *y);
 int32_t rten_hip_global_average_pool_f32(rten_hip_ctx *ctx, int64_t nc, int32_t inner, const float *x, float *y);
 

@@ -270,10 +270,19 @@ __global__ __launch_bounds__(256) void i8_nhwc_pad_kernel(const uint8_t *__restr
 // DynamicQuantizeLinear's quantize sweep fused with the staging above: f32 NCHW -> u8 codes (bit-identical to
 // quantize.hip: same scale / zero-point algebra, same to_int_round + saturate) written as padded channel-blocked
 // signed bytes.  The min/max fold runs while the tile's loads are in flight.
+// the scalar Mul(x_scale, w_scale) nodes that follow a DynamicQuantizeLinear in ort-quantized graphs (one per convolution that reads the
+// quantized tensor: a stage's shortcut and first 1x1 convolution share one): product[i] = scale * mul_by[i][0]
+constexpr int kMaxProducts = 4;
+struct ScaleProducts {
+    int count;
+    const float *mul_by[kMaxProducts];
+    float *product[kMaxProducts];
+};
+
 template <int KIND>
 __global__ __launch_bounds__(256) void i8_quantize_stage_kernel(const float *__restrict__ x, const float *__restrict__ ws, int nparts, uint8_t *__restrict__ xp,
                                                                int C, int H, int W, int Hp, int Wp, int Cp, int pt, int pl, int pad_mode,
-                                                               float *scale_out, uint8_t *zp_out, const float *mul_by, float *product_out) {
+                                                               float *scale_out, uint8_t *zp_out, const ScaleProducts sp) {
     auto prep = [&]() {
         float x_min, x_max;
         if (nparts < 0) dql::block_minmax_slots(reinterpret_cast<const unsigned *>(ws), x_min, x_max); // producer-accumulated statistics
@@ -282,7 +291,9 @@ __global__ __launch_bounds__(256) void i8_quantize_stage_kernel(const float *__r
         if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
             *scale_out = q.scale;
             *zp_out = (uint8_t)q.zp;
-            if (mul_by) *product_out = q.scale * mul_by[0]; // the Mul(x_scale, w_scale) node that follows in ort-quantized graphs
+#pragma unroll
+            for (int i = 0; i < kMaxProducts; i++)
+                if (i < sp.count) *sp.product[i] = q.scale * sp.mul_by[i][0];
         }
         int pad_s = 0; // signed-domain padding value
         if (pad_mode == RTEN_HIP_PAD_ZERO_POINT) pad_s = q.zp - 128;
@@ -1161,12 +1172,18 @@ ConvGeom conv_geom(const rten_hip_conv2d_int8_desc *di) {
 } // namespace
 
 namespace {
+ScaleProducts one_product(const float *mul_by, float *product) {
+    ScaleProducts sp = {};
+    if (mul_by) { sp.count = 1; sp.mul_by[0] = mul_by; sp.product[0] = product; }
+    return sp;
+}
+
 void launch_quantize_stage(rten_hip_ctx *ctx, const rten_hip_conv2d_desc *d, const ConvGeom &g, const float *x, const float *ws, int nparts, void *staged,
-                           int pad_mode, float *scale, uint8_t *zero_point, const float *mul_by, float *product) {
+                           int pad_mode, float *scale, uint8_t *zero_point, const ScaleProducts &sp) {
     const dim3 grid((unsigned)((d->h * d->w + 255) / 256), (unsigned)d->n, (unsigned)(g.Cp / 16));
     const dim3 grid_small((unsigned)((g.Hp * g.Wp + 63) / 64), (unsigned)d->n, (unsigned)((g.Cp + 63) / 64));
     const bool vec = (d->h * d->w) % 4 == 0 && ((uintptr_t)x & 15) == 0;
-#define QS_ARGS x, ws, nparts, (uint8_t *)staged, d->c, d->h, d->w, g.Hp, g.Wp, g.Cp, d->pads[0], d->pads[1], pad_mode, scale, zero_point, mul_by, product
+#define QS_ARGS x, ws, nparts, (uint8_t *)staged, d->c, d->h, d->w, g.Hp, g.Wp, g.Cp, d->pads[0], d->pads[1], pad_mode, scale, zero_point, sp
     if (d->h * d->w < 128) hipLaunchKernelGGL(i8_quantize_stage_kernel<0>, grid_small, dim3(256), 0, ctx->stream, QS_ARGS);
     else if (vec) hipLaunchKernelGGL(i8_quantize_stage_kernel<2>, grid, dim3(256), 0, ctx->stream, QS_ARGS);
     else hipLaunchKernelGGL(i8_quantize_stage_kernel<1>, grid, dim3(256), 0, ctx->stream, QS_ARGS);
@@ -1210,7 +1227,7 @@ RTEN_EXPORT int32_t rten_hip_dynamic_quantize_linear_staged(rten_hip_ctx *ctx, c
     int nparts = 0;
     const float *ws = rten_dql_minmax(ctx, n, x, &nparts);
     if (!ws) return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "dql: scratch allocation failed");
-    launch_quantize_stage(ctx, d, g, x, ws, nparts, staged, rten_effective_pad_mode(di), scale, zero_point, mul_by, product);
+    launch_quantize_stage(ctx, d, g, x, ws, nparts, staged, rten_effective_pad_mode(di), scale, zero_point, one_product(mul_by, product));
     RTEN_LAUNCH_CHECK(ctx, "i8_quantize_stage_kernel launch");
     return RTEN_HIP_OK;
 }
@@ -1241,7 +1258,38 @@ RTEN_EXPORT int32_t rten_hip_dynamic_quantize_linear_staged_stats(rten_hip_ctx *
     if (!g.ok || di->x_signed) return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "quantize_staged: geometry not covered by the staged kernel (staged_bytes == 0)");
     const rten_hip_conv2d_desc *d = &di->conv;
     ProfScope ps(ctx, "dynamic_quantize_linear_staged_stats", 0.0, 4.0 * d->n * d->c * (double)d->h * d->w + (double)g.img);
-    launch_quantize_stage(ctx, d, g, x, (const float *)stats, -1, staged, rten_effective_pad_mode(di), scale, zero_point, mul_by, product);
+    launch_quantize_stage(ctx, d, g, x, (const float *)stats, -1, staged, rten_effective_pad_mode(di), scale, zero_point, one_product(mul_by, product));
+    RTEN_LAUNCH_CHECK(ctx, "i8_quantize_stage_kernel launch");
+    return RTEN_HIP_OK;
+}
+
+RTEN_EXPORT int32_t rten_hip_dynamic_quantize_linear_staged_products(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di, const float *x, const void *stats,
+                                                                     void *staged, float *scale, uint8_t *zero_point, int32_t count,
+                                                                     const float *const *mul_by, float *const *product) {
+    RTEN_CHECK_CTX(ctx);
+    if (!di || !x || !staged || !scale || !zero_point || count < 0 || (count > 0 && (!mul_by || !product))) return RTEN_HIP_ERR_INVALID_VALUE;
+    if (count > kMaxProducts) return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "quantize_staged_products: at most 4 scale products per launch");
+    ScaleProducts sp = {};
+    sp.count = count;
+    for (int i = 0; i < count; i++) {
+        if (!mul_by[i] || !product[i]) return RTEN_HIP_ERR_INVALID_VALUE;
+        sp.mul_by[i] = mul_by[i];
+        sp.product[i] = product[i];
+    }
+    const ConvGeom g = conv_geom(di);
+    if (!g.ok || di->x_signed) return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "quantize_staged: geometry not covered by the staged kernel (staged_bytes == 0)");
+    const rten_hip_conv2d_desc *d = &di->conv;
+    const int64_t n = (int64_t)d->n * d->c * d->h * d->w;
+    if (stats) {
+        ProfScope ps(ctx, "dynamic_quantize_linear_staged_stats", 0.0, 4.0 * n + (double)g.img);
+        launch_quantize_stage(ctx, d, g, x, (const float *)stats, -1, staged, rten_effective_pad_mode(di), scale, zero_point, sp);
+    } else {
+        ProfScope ps(ctx, "dynamic_quantize_linear_staged", 0.0, 8.0 * n + (double)g.img);
+        int nparts = 0;
+        const float *ws = rten_dql_minmax(ctx, n, x, &nparts);
+        if (!ws) return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "dql: scratch allocation failed");
+        launch_quantize_stage(ctx, d, g, x, ws, nparts, staged, rten_effective_pad_mode(di), scale, zero_point, sp);
+    }
     RTEN_LAUNCH_CHECK(ctx, "i8_quantize_stage_kernel launch");
     return RTEN_HIP_OK;
 }

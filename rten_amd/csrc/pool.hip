@@ -6,8 +6,22 @@
 // One thread per output element, adjacent lanes -> adjacent output columns, so a wavefront reads
 // contiguous (strided by `stride_w`) runs of each input row.
 #include "internal.h"
+#include "quantize.h"
 
 namespace {
+
+// Optional producer-side statistics (rten_hip_max_pool2d_f32_stats): the min / max of the values this wave stored, folded into the
+// 256 + 256 ordered-uint slots a consuming DynamicQuantizeLinear reads instead of sweeping the tensor (fminf / fmaxf drop NaNs like
+// the reference's sweep, rten-vecmath/src/min_max.rs:27-30).  Every lane of the wave calls this; lanes without an output pass +-inf.
+__device__ __forceinline__ void wave_stats(unsigned *stats, float mn, float mx) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o, 64)); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); }
+    if ((threadIdx.x & 63) == 0 && mn <= mx) {
+        const unsigned slot = ((blockIdx.x * gridDim.y + blockIdx.y) * 4u + (threadIdx.x >> 6)) % (unsigned)dql::kStatSlots;
+        atomicMin(&stats[slot], dql::f2ord(mn));
+        atomicMax(&stats[dql::kStatSlots + slot], dql::f2ord(mx));
+    }
+}
 
 // One thread per output element; grid.x = (image, channel) plane, grid.y = 256-output slabs of the plane, so the
 // index arithmetic stays 32-bit.  With a compile-time window (KH, KW > 0) every tap's load is issued unconditionally
@@ -15,10 +29,11 @@ namespace {
 // folded in (ky, kx) order either way (the order the header comment cites).
 template <bool IS_MAX, int KH, int KW>
 __global__ __launch_bounds__(256) void pool2d_kernel(const rten_hip_pool2d_desc d, const float *__restrict__ x,
-                                                     float *__restrict__ y) {
+                                                     float *__restrict__ y, unsigned *__restrict__ stats) {
     const int plane = d.out_h * d.out_w;
     const int o = blockIdx.y * 256 + threadIdx.x;
-    if (o >= plane) return;
+    float st_mn = __builtin_inff(), st_mx = -__builtin_inff();
+    if (o < plane) {
     const int oy = o / d.out_w, ox = o - oy * d.out_w;
     const float *in = x + (long long)blockIdx.x * d.h * d.w;
     float acc = IS_MAX ? -__builtin_inff() : 0.f;
@@ -57,16 +72,21 @@ __global__ __launch_bounds__(256) void pool2d_kernel(const rten_hip_pool2d_desc 
     }
     if (!IS_MAX) acc = d.count_include_pad ? acc / (float)(d.kh * d.kw) : acc / (float)cnt;
     y[(long long)blockIdx.x * plane + o] = acc;
+    st_mn = fminf(acc, st_mn); st_mx = fmaxf(acc, st_mx);
+    }
+    if (stats) wave_stats(stats, st_mn, st_mx);
 }
 
 // 3 x 3 window, stride_h SH: four vertically adjacent outputs per thread (lanes walk x: coalesced).  The patch of (4-1)*SH + 3
 // rows x 3 columns is loaded once; every output folds its own window in (ky, kx) order from registers.
 template <bool IS_MAX, int SH>
-__global__ __launch_bounds__(256) void pool3x3_y4_kernel(const rten_hip_pool2d_desc d, const float *__restrict__ x, float *__restrict__ y) {
+__global__ __launch_bounds__(256) void pool3x3_y4_kernel(const rten_hip_pool2d_desc d, const float *__restrict__ x, float *__restrict__ y,
+                                                         unsigned *__restrict__ stats) {
     constexpr int NROW = 3 * SH + 3;
     const int hq = (d.out_h + 3) >> 2, items = hq * d.out_w;
     const int q = blockIdx.y * 256 + threadIdx.x;
-    if (q >= items) return;
+    float st_mn = __builtin_inff(), st_mx = -__builtin_inff();
+    if (q < items) {
     const int yq = q / d.out_w, ox = q - yq * d.out_w, oy0 = yq * 4;
     const float *in = x + (long long)blockIdx.x * d.h * d.w;
     const int y0 = oy0 * SH - d.pads[0], x0 = ox * d.stride_w - d.pads[1];
@@ -97,11 +117,14 @@ __global__ __launch_bounds__(256) void pool3x3_y4_kernel(const rten_hip_pool2d_d
                 }
         if (!IS_MAX) acc = d.count_include_pad ? acc / 9.0f : acc / (float)cnt;
         out[(long long)(oy0 + j) * d.out_w] = acc;
+        st_mn = fminf(acc, st_mn); st_mx = fmaxf(acc, st_mx);
     }
+    }
+    if (stats) wave_stats(stats, st_mn, st_mx);
 }
 
 template <bool IS_MAX>
-int32_t run_pool(rten_hip_ctx *ctx, const rten_hip_pool2d_desc *d, const float *x, float *y, const char *name) {
+int32_t run_pool(rten_hip_ctx *ctx, const rten_hip_pool2d_desc *d, const float *x, float *y, const char *name, unsigned *stats = nullptr) {
     RTEN_CHECK_CTX(ctx);
     if (!d) return RTEN_HIP_ERR_INVALID_VALUE;
     if (d->n < 0 || d->c < 0 || d->h <= 0 || d->w <= 0 || d->kh <= 0 || d->kw <= 0 || d->stride_h <= 0 ||
@@ -118,11 +141,11 @@ int32_t run_pool(rten_hip_ctx *ctx, const rten_hip_pool2d_desc *d, const float *
     if (d->kh == 3 && d->kw == 3 && (d->stride_h == 1 || d->stride_h == 2) && d->out_h >= 4) {
         const long long items = (long long)((d->out_h + 3) / 4) * d->out_w;
         const dim3 grid4((unsigned)planes, (unsigned)((items + 255) / 256));
-        if (d->stride_h == 1) hipLaunchKernelGGL((pool3x3_y4_kernel<IS_MAX, 1>), grid4, dim3(256), 0, ctx->stream, *d, x, y);
-        else hipLaunchKernelGGL((pool3x3_y4_kernel<IS_MAX, 2>), grid4, dim3(256), 0, ctx->stream, *d, x, y);
-    } else if (d->kh == 3 && d->kw == 3) hipLaunchKernelGGL((pool2d_kernel<IS_MAX, 3, 3>), grid, dim3(256), 0, ctx->stream, *d, x, y);
-    else if (d->kh == 2 && d->kw == 2) hipLaunchKernelGGL((pool2d_kernel<IS_MAX, 2, 2>), grid, dim3(256), 0, ctx->stream, *d, x, y);
-    else hipLaunchKernelGGL((pool2d_kernel<IS_MAX, 0, 0>), grid, dim3(256), 0, ctx->stream, *d, x, y);
+        if (d->stride_h == 1) hipLaunchKernelGGL((pool3x3_y4_kernel<IS_MAX, 1>), grid4, dim3(256), 0, ctx->stream, *d, x, y, stats);
+        else hipLaunchKernelGGL((pool3x3_y4_kernel<IS_MAX, 2>), grid4, dim3(256), 0, ctx->stream, *d, x, y, stats);
+    } else if (d->kh == 3 && d->kw == 3) hipLaunchKernelGGL((pool2d_kernel<IS_MAX, 3, 3>), grid, dim3(256), 0, ctx->stream, *d, x, y, stats);
+    else if (d->kh == 2 && d->kw == 2) hipLaunchKernelGGL((pool2d_kernel<IS_MAX, 2, 2>), grid, dim3(256), 0, ctx->stream, *d, x, y, stats);
+    else hipLaunchKernelGGL((pool2d_kernel<IS_MAX, 0, 0>), grid, dim3(256), 0, ctx->stream, *d, x, y, stats);
     RTEN_LAUNCH_CHECK(ctx, name);
     return RTEN_HIP_OK;
 }
@@ -132,6 +155,11 @@ int32_t run_pool(rten_hip_ctx *ctx, const rten_hip_pool2d_desc *d, const float *
 RTEN_EXPORT int32_t rten_hip_max_pool2d_f32(rten_hip_ctx *ctx, const rten_hip_pool2d_desc *desc, const float *x,
                                             float *y) {
     return run_pool<true>(ctx, desc, x, y, "max_pool2d_f32");
+}
+
+RTEN_EXPORT int32_t rten_hip_max_pool2d_f32_stats(rten_hip_ctx *ctx, const rten_hip_pool2d_desc *desc, const float *x, float *y, void *stats) {
+    if (!stats) return RTEN_HIP_ERR_INVALID_VALUE;
+    return run_pool<true>(ctx, desc, x, y, "max_pool2d_f32", (unsigned *)stats);
 }
 
 RTEN_EXPORT int32_t rten_hip_average_pool2d_f32(rten_hip_ctx *ctx, const rten_hip_pool2d_desc *desc, const float *x,

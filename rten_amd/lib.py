@@ -143,6 +143,7 @@ PROTOTYPES = {
     "rten_hip_grid_sync_reset": (_I32, [_VP, _VP, _I32]),
     "rten_hip_grid_sync_timeouts": (_I32, [_VP, _VP, _I32, C.POINTER(_I32)]),
     "rten_hip_dynamic_quantize_linear_staged_stats": (_I32, [_VP, C.POINTER(Conv2dInt8Desc), _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "rten_hip_dynamic_quantize_linear_staged_products": (_I32, [_VP, C.POINTER(Conv2dInt8Desc), _VP, _VP, _VP, _VP, _VP, _I32, C.POINTER(_VP), C.POINTER(_VP)]),
     "rten_hip_dynamic_quantize_linear_staged": (_I32, [_VP, C.POINTER(Conv2dInt8Desc), _VP, _VP, _VP, _VP, _VP, _VP]),
     "rten_hip_dynamic_quantize_linear": (_I32, [_VP, _I64, _VP, _VP, _VP, _VP]),
     "rten_hip_cast_scale": (_I32, [_VP, _I64, _VP, _VP, _I32, _VP]),
@@ -167,6 +168,7 @@ PROTOTYPES = {
     "rten_hip_matmul_nbits_f32": (_I32, [_VP, _I64, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP]),
     "rten_hip_add_channel_bias_f32": (_I32, [_VP, _I32, _I32, _I64, _VP, _VP, _VP]),
     "rten_hip_max_pool2d_f32": (_I32, [_VP, C.POINTER(Pool2dDesc), _VP, _VP]),
+    "rten_hip_max_pool2d_f32_stats": (_I32, [_VP, C.POINTER(Pool2dDesc), _VP, _VP, _VP]),
     "rten_hip_average_pool2d_f32": (_I32, [_VP, C.POINTER(Pool2dDesc), _VP, _VP]),
     "rten_hip_global_average_pool_f32": (_I32, [_VP, _I64, _I32, _VP, _VP]),
     "rten_hip_sdpa_f32": (_I32, [_VP, C.POINTER(SdpaDesc), _VP, _VP, _VP, _VP, _VP]),

@@ -76,8 +76,18 @@ class ResNet50Int8(ResNet50):
         ctx.call("rten_hip_grid_sync_reset", self.sync_arena.vp, len(self.specs))
         self.syncs = {l["name"]: C.c_void_p(self.sync_arena.ptr + i * gb) for i, l in enumerate(self.specs)}
         sb = ctx.lib.rten_hip_minmax_stats_bytes()
-        self.stats_arena = DeviceTensor(ctx, (sb * len(self.specs),), np.uint8)  # one statistics block per conv output
+        self.stats_arena = DeviceTensor(ctx, (sb * (len(self.specs) + 1),), np.uint8)  # one statistics block per conv output + the max-pool's
         self.stats = {l["dst"]: C.c_void_p(self.stats_arena.ptr + i * sb) for i, l in enumerate(self.specs)}
+        self.stats["pool"] = C.c_void_p(self.stats_arena.ptr + len(self.specs) * sb)  # (rten_hip_max_pool2d_f32_stats)
+        # A quantized tensor read by two convolutions in a row (a stage's shortcut and first 1x1) is followed by one Mul(x_scale, w_scale)
+        # per reader: both products come out of the quantizer's launch (rten_hip_dynamic_quantize_linear_staged_products)
+        self.fold_products = True
+
+        def geom_of(m):
+            d = self.descs[m["name"]]
+            return (m["src"], d.c, d.h, d.w, tuple(d.pads))
+        self.shared_next = {a["name"]: b["name"] for a, b in zip(self.specs, self.specs[1:]) if geom_of(a) == geom_of(b)}
+        self._sc_for = {}
         self.q = quantize_weights(self.weights)
         n_max = max(int(np.prod(s)) for s in self.shapes.values())
         self.xq = DeviceTensor(ctx, (n_max,), np.uint8)
@@ -97,6 +107,7 @@ class ResNet50Int8(ResNet50):
                       (DeviceTensor(ctx, (max(staged_max, 256),), np.uint8), DeviceTensor(ctx, (1,), np.float32), DeviceTensor(ctx, (1,), np.uint8))]
         self.sc_side = DeviceTensor(ctx, (1,), np.float32)
         self.scs = [self.sc, DeviceTensor(ctx, (1,), np.float32)]  # Mul(x_scale, w_scale) per quantized-input set (quantized-output launches)
+        self.scs2 = [DeviceTensor(ctx, (1,), np.float32), DeviceTensor(ctx, (1,), np.float32)]  # ... and the second reader's product
         self._cur, self._side_reads = 0, None
         self.fc_tmp = DeviceTensor(ctx, (batch, self.num_classes), np.float32)
         # classifier RHS [K = 2048, N = 1000] staged once (rten_hip_gemm_int8_prepack: PackedBMatrix, Graph::prepack_weights)
@@ -158,22 +169,31 @@ class ResNet50Int8(ResNet50):
             ctx.call("rten_hip_conv2d_int8_dql", C.byref(d), self._act(l["src"]).vp, st_in, self.wq[name].vp, self.ws[name].vp, self.bq[name].vp, res, flags,
                      self._act(l["dst"]).vp, self.stats[l["dst"]], None, None)
             return
+        sc_mine = self._sc_for.pop(name, None)  # this layer's Mul(x_scale, w_scale) already came out of the quantizer's launch
         if self._prestaged == name:      # the producing conv quantized this input in its epilogue, scale product included
             pass
         elif self._staged_key == geom:   # same tensor, same staged layout as the previous conv: only the Mul(x_scale, w_scale) differs
-            ctx.call("rten_hip_mul_f32", 1, self.qsets[self._cur][1].vp, self.ws[name].vp, 1, self.scs[self._cur].vp)
+            if sc_mine is None:
+                ctx.call("rten_hip_mul_f32", 1, self.qsets[self._cur][1].vp, self.ws[name].vp, 1, self.scs[self._cur].vp)
         else:
+            sc_mine = None
             self._cur = 1 - self._cur
             staged, xs, xz = self.qsets[self._cur]
             st = self.stats.get(l["src"]) if self.producer_stats else None
-            if st is not None:
+            nxt2 = self.shared_next.get(name) if self.fold_products else None
+            if nxt2 is not None:
+                muls = (C.c_void_p * 2)(self.ws[name].ptr, self.ws[nxt2].ptr)
+                outs = (C.c_void_p * 2)(self.scs[self._cur].ptr, self.scs2[self._cur].ptr)
+                ctx.call("rten_hip_dynamic_quantize_linear_staged_products", C.byref(d), self._act(l["src"]).vp, st, staged.vp, xs.vp, xz.vp, 2, muls, outs)
+                self._sc_for[nxt2] = self.scs2[self._cur]
+            elif st is not None:
                 ctx.call("rten_hip_dynamic_quantize_linear_staged_stats", C.byref(d), self._act(l["src"]).vp, st, staged.vp, xs.vp, xz.vp, self.ws[name].vp,
                          self.scs[self._cur].vp)
             else:
                 ctx.call("rten_hip_dynamic_quantize_linear_staged", C.byref(d), self._act(l["src"]).vp, staged.vp, xs.vp, xz.vp, self.ws[name].vp,
                          self.scs[self._cur].vp)
         self._staged_key, self._prestaged = geom, None
-        (staged, xs, xz), sc = self.qsets[self._cur], self.scs[self._cur]
+        (staged, xs, xz), sc = self.qsets[self._cur], (sc_mine if sc_mine is not None else self.scs[self._cur])
         nxt = self.qout_next.get(name)
         if nxt is not None and name not in self._qout_off:
             other = 1 - self._cur
@@ -319,12 +339,16 @@ class ResNet50Int8(ResNet50):
         ctx = self.ctx
         self._staged_key = None
         self._cur, self._side_reads, self._pending, self._prestaged = 0, None, set(), None
+        self._sc_for = {}
         if self.concurrent and self.side is None:
             self.side = L.Context(ctx.device)
         if self.producer_stats:
-            ctx.call("rten_hip_minmax_stats_reset", self.stats_arena.vp, len(self.specs))  # one launch for every layer's block
+            ctx.call("rten_hip_minmax_stats_reset", self.stats_arena.vp, len(self.specs) + 1)  # one launch for every layer's block (+ the pool's)
         self._conv(self.specs[0])
-        ctx.call("rten_hip_max_pool2d_f32", C.byref(self.pool_desc), self.bufs["stem"].vp, self.bufs["pool"].vp)
+        if self.producer_stats:  # the pooled tensor is quantized next: its min / max come out of the pooling launch
+            ctx.call("rten_hip_max_pool2d_f32_stats", C.byref(self.pool_desc), self.bufs["stem"].vp, self.bufs["pool"].vp, self.stats["pool"])
+        else:
+            ctx.call("rten_hip_max_pool2d_f32", C.byref(self.pool_desc), self.bufs["stem"].vp, self.bufs["pool"].vp)
         for l in self.specs[1:]:
             self._conv(l)
         last = self.specs[-1]["dst"]

@@ -234,3 +234,113 @@ def test_sdpa_fused_general_shapes_bit_exact(ctx, hd):
                     outs.append(out.numpy())
                 bits_equal(outs[0], want)
                 bits_equal(outs[1], want)
+
+
+PRODUCT_CASES = [
+    # n, c, h, w | consumer k, stride, pad | pad mode | statistics from the producer (True) or the quantizer's own sweep (False) | products
+    (32, 64, 56, 56, 1, 1, 0, L.PAD_RAW0_I8, True, 2),     # the max-pool's output, read by a stage's shortcut and first 1x1
+    (4, 256, 56, 56, 1, 2, 0, L.PAD_RAW0_I8, False, 2),    # strided shortcut + 1x1 of stage 1, own sweep
+    (2, 48, 9, 7, 3, 1, 1, L.PAD_ZERO_POINT, True, 4),     # ragged, padded, four readers
+    (3, 2048, 7, 7, 1, 1, 0, L.PAD_RAW0_U8, False, 3),     # small-map form of the staging kernel
+    (1, 16, 5, 5, 3, 1, 1, L.PAD_RAW0_I8, True, 0),        # no product at all
+]
+
+
+@pytest.mark.parametrize("case", PRODUCT_CASES, ids=[f"case{i}" for i in range(len(PRODUCT_CASES))])
+def test_quantize_staged_products_matches_the_quantizer_plus_separate_muls(ctx, case):
+    n, c, h, w, k, stride, pad, pad_mode, from_stats, count = case
+    rng = ref.XorShiftRng(977 + n + c)
+    lib = ctx.lib
+    d, _, _ = _conv_desc(n, c, h, w, 32, k, stride, pad, pad_mode=pad_mode)
+    xf = (rng.f32(n * c * h * w).reshape(n, c, h, w) * 3.0 - 0.8).astype(np.float32)
+    xfd = dev(ctx, xf)
+    nb = lib.rten_hip_conv2d_int8_staged_bytes(C.byref(d))
+    assert nb > 0
+    st = None
+    if from_stats:  # a statistics block as a producing launch leaves it: here the max-pool form over a 1x1 window (the identity)
+        st = DeviceTensor(ctx, (lib.rten_hip_minmax_stats_bytes(),), np.uint8)
+        ctx.call("rten_hip_minmax_stats_reset", st.vp, 1)
+        pd = L.Pool2dDesc(n, c, h, w, 1, 1, 1, 1, (C.c_int32 * 4)(0, 0, 0, 0), h, w, 0)
+        ycopy = DeviceTensor(ctx, (n, c, h, w), np.float32)
+        ctx.call("rten_hip_max_pool2d_f32_stats", C.byref(pd), xfd.vp, ycopy.vp, st.vp)
+        ctx.sync()
+        bits_equal(ycopy.numpy(), xf)
+    muls_np = [np.array([0.004 + 0.013 * i], np.float32) for i in range(count)]
+    muls = [dev(ctx, m) for m in muls_np]
+    # (a) the quantizer (own sweep: the operator as the reference runs it) and one Mul launch per reader
+    staged_a = dev(ctx, np.full(nb, 0xEE, np.uint8))
+    xs_a, xz_a = DeviceTensor(ctx, (1,), np.float32), DeviceTensor(ctx, (1,), np.uint8)
+    ctx.call("rten_hip_dynamic_quantize_linear_staged", C.byref(d), xfd.vp, staged_a.vp, xs_a.vp, xz_a.vp, None, None)
+    prods_a = [DeviceTensor(ctx, (1,), np.float32) for _ in range(count)]
+    for m, p in zip(muls, prods_a):
+        ctx.call("rten_hip_mul_f32", 1, xs_a.vp, m.vp, 1, p.vp)
+    # (b) one launch
+    staged_b = dev(ctx, np.full(nb, 0xEE, np.uint8))
+    xs_b, xz_b = DeviceTensor(ctx, (1,), np.float32), DeviceTensor(ctx, (1,), np.uint8)
+    prods_b = [dev(ctx, np.array([-1.0], np.float32)) for _ in range(count)]
+    mul_ptrs = (C.c_void_p * max(count, 1))(*[m.ptr for m in muls])
+    out_ptrs = (C.c_void_p * max(count, 1))(*[p.ptr for p in prods_b])
+    ctx.call("rten_hip_dynamic_quantize_linear_staged_products", C.byref(d), xfd.vp, st.vp if st is not None else None, staged_b.vp, xs_b.vp, xz_b.vp, count,
+             mul_ptrs if count else None, out_ptrs if count else None)
+    ctx.sync()
+    assert np.array_equal(xs_a.numpy().view(np.uint32), xs_b.numpy().view(np.uint32)) and np.array_equal(xz_a.numpy(), xz_b.numpy())
+    a, b = staged_a.numpy(), staged_b.numpy()
+    assert np.array_equal(a, b), f"{(a != b).sum()} of {a.size} staged bytes differ"
+    for i in range(count):
+        want = (xs_a.numpy() * muls_np[i]).astype(np.float32)  # one f32 multiply
+        assert np.array_equal(prods_a[i].numpy().view(np.uint32), want.view(np.uint32))
+        assert np.array_equal(prods_b[i].numpy().view(np.uint32), want.view(np.uint32)), f"product {i}"
+    # the oracle's DynamicQuantizeLinear on the same tensor: scale and zero point
+    _, s_ref, z_ref = ref.dynamic_quantize_linear(xf.reshape(-1))
+    assert np.float32(s_ref).view(np.uint32) == xs_b.numpy().view(np.uint32)[0] and int(z_ref) == int(xz_b.numpy()[0])
+
+
+def test_quantize_staged_products_rejects_more_than_four_and_null_entries(ctx):
+    d, _, _ = _conv_desc(1, 16, 4, 4, 16, 1, 1, 0)
+    x = dev(ctx, np.ones((1, 16, 4, 4), np.float32))
+    staged = DeviceTensor(ctx, (ctx.lib.rten_hip_conv2d_int8_staged_bytes(C.byref(d)),), np.uint8)
+    xs, xz = DeviceTensor(ctx, (1,), np.float32), DeviceTensor(ctx, (1,), np.uint8)
+    five = (C.c_void_p * 5)(*[xs.ptr] * 5)
+    rc = ctx.lib.rten_hip_dynamic_quantize_linear_staged_products(ctx.h, C.byref(d), x.vp, None, staged.vp, xs.vp, xz.vp, 5, five, five)
+    assert rc == L.ERR_UNSUPPORTED
+    two = (C.c_void_p * 2)(xs.ptr, None)
+    rc = ctx.lib.rten_hip_dynamic_quantize_linear_staged_products(ctx.h, C.byref(d), x.vp, None, staged.vp, xs.vp, xz.vp, 2, two, two)
+    assert rc == L.ERR_INVALID_VALUE
+    rc = ctx.lib.rten_hip_dynamic_quantize_linear_staged_products(ctx.h, C.byref(d), x.vp, None, staged.vp, xs.vp, xz.vp, 1, None, None)
+    assert rc == L.ERR_INVALID_VALUE
+
+
+@pytest.mark.parametrize("geom", [(32, 64, 112, 112, 3, 2, 1), (2, 5, 9, 7, 2, 2, 0), (1, 3, 13, 11, 3, 1, 1), (2, 4, 7, 5, 5, 3, 2)],
+                         ids=["resnet_stem_pool", "k2s2", "k3s1", "k5s3"])
+def test_max_pool_stats_same_values_and_the_statistics_the_quantizer_would_sweep(ctx, geom):
+    n, c, h, w, k, stride, pad = geom
+    oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    rng = ref.XorShiftRng(31 + h)
+    x = (rng.f32(n * c * h * w).reshape(n, c, h, w) * 2.0 - 1.2).astype(np.float32)
+    xd = dev(ctx, x)
+    pd = L.Pool2dDesc(n, c, h, w, k, k, stride, stride, (C.c_int32 * 4)(pad, pad, pad, pad), oh, ow, 0)
+    y_a, y_b = DeviceTensor(ctx, (n, c, oh, ow), np.float32), DeviceTensor(ctx, (n, c, oh, ow), np.float32)
+    st = DeviceTensor(ctx, (ctx.lib.rten_hip_minmax_stats_bytes(),), np.uint8)
+    ctx.call("rten_hip_minmax_stats_reset", st.vp, 1)
+    ctx.call("rten_hip_max_pool2d_f32", C.byref(pd), xd.vp, y_a.vp)
+    ctx.call("rten_hip_max_pool2d_f32_stats", C.byref(pd), xd.vp, y_b.vp, st.vp)
+    ctx.sync()
+    bits_equal(y_b.numpy(), y_a.numpy())
+    bits_equal(y_a.numpy(), ref.max_pool(x, (k, k), (stride, stride), (pad, pad, pad, pad)))
+    # the statistics, read the way their consumer reads them: DynamicQuantizeLinear into a 1x1 consumer's staged layout
+    d, _, _ = _conv_desc(n, c, oh, ow, 16, 1, 1, 0)
+    nb = ctx.lib.rten_hip_conv2d_int8_staged_bytes(C.byref(d))
+    outs = []
+    for stats in (None, st):
+        staged = dev(ctx, np.full(nb, 0xEE, np.uint8))
+        xs, xz = DeviceTensor(ctx, (1,), np.float32), DeviceTensor(ctx, (1,), np.uint8)
+        ctx.call("rten_hip_dynamic_quantize_linear_staged_products", C.byref(d), y_a.vp, stats.vp if stats is not None else None, staged.vp, xs.vp, xz.vp, 0, None, None)
+        ctx.sync()
+        outs.append((staged.numpy(), xs.numpy().view(np.uint32), xz.numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+
+
+def test_max_pool_stats_needs_a_statistics_block(ctx):
+    pd = L.Pool2dDesc(1, 1, 4, 4, 2, 2, 2, 2, (C.c_int32 * 4)(0, 0, 0, 0), 2, 2, 0)
+    x, y = dev(ctx, np.ones((1, 1, 4, 4), np.float32)), DeviceTensor(ctx, (1, 1, 2, 2), np.float32)
+    assert ctx.lib.rten_hip_max_pool2d_f32_stats(ctx.h, C.byref(pd), x.vp, y.vp, None) == L.ERR_INVALID_VALUE
