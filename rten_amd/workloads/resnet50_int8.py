@@ -8,6 +8,7 @@ the cast_scale / bias / residual / Relu epilogue.  Weights are staged once (rten
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -78,10 +79,12 @@ class ResNet50Int8(ResNet50):
         sb = ctx.lib.rten_hip_minmax_stats_bytes()
         self.stats_arena = DeviceTensor(ctx, (sb * (len(self.specs) + 1),), np.uint8)  # one statistics block per conv output + the max-pool's
         self.stats = {l["dst"]: C.c_void_p(self.stats_arena.ptr + i * sb) for i, l in enumerate(self.specs)}
-        self.stats["pool"] = C.c_void_p(self.stats_arena.ptr + len(self.specs) * sb)  # (rten_hip_max_pool2d_f32_stats)
+        no_fold = os.environ.get("RTEN_INT8_NO_FOLD") == "1"  # A/B switch: the launch sequence before these two folds
+        if not no_fold:
+            self.stats["pool"] = C.c_void_p(self.stats_arena.ptr + len(self.specs) * sb)  # (rten_hip_max_pool2d_f32_stats)
         # A quantized tensor read by two convolutions in a row (a stage's shortcut and first 1x1) is followed by one Mul(x_scale, w_scale)
         # per reader: both products come out of the quantizer's launch (rten_hip_dynamic_quantize_linear_staged_products)
-        self.fold_products = True
+        self.fold_products = not no_fold
 
         def geom_of(m):
             d = self.descs[m["name"]]
@@ -345,7 +348,7 @@ class ResNet50Int8(ResNet50):
         if self.producer_stats:
             ctx.call("rten_hip_minmax_stats_reset", self.stats_arena.vp, len(self.specs) + 1)  # one launch for every layer's block (+ the pool's)
         self._conv(self.specs[0])
-        if self.producer_stats:  # the pooled tensor is quantized next: its min / max come out of the pooling launch
+        if self.producer_stats and "pool" in self.stats:  # the pooled tensor is quantized next: its min / max come out of the pooling launch
             ctx.call("rten_hip_max_pool2d_f32_stats", C.byref(self.pool_desc), self.bufs["stem"].vp, self.bufs["pool"].vp, self.stats["pool"])
         else:
             ctx.call("rten_hip_max_pool2d_f32", C.byref(self.pool_desc), self.bufs["stem"].vp, self.bufs["pool"].vp)
