@@ -436,6 +436,7 @@ class Graph {
         std::shared_ptr<Conv> conv; // f32 convolution steps: the launch plan is tunable
         std::shared_ptr<I8Conv> i8; // int8 convolution steps: staged-pipeline options are decided after all steps exist
         std::shared_ptr<DynamicQuantizeLinearStaged> dql_staged;
+        std::shared_ptr<MaxPool> maxpool; // a max-pool whose output is quantized next can accumulate the quantizer's statistics
         bool removed = false;
         size_t pos = 0; // index of the LAST graph node folded into this step: the step runs where that node stood
     };
@@ -458,7 +459,7 @@ class Graph {
 
     // The staged int8 pipeline at graph level.  A DynamicQuantizeLinear whose codes feed only int8
     // convolutions of one padding geometry writes them straight into the kernel's staged layout; if its input is the f32
-    // output of a fused ConvIntegerToFloat step, that step's epilogue accumulates the min/max the quantizer needs
+    // output of a fused ConvIntegerToFloat step or of a MaxPool, that launch accumulates the min/max the quantizer needs
     // (one statistics block per such tensor, all reset by one launch at the start of a run).
     void plan_int8_staging() {
         std::map<int, size_t> producer;
@@ -495,8 +496,10 @@ class Graph {
             dq.run = [op](Context &c, const InputList &in) { return op->run(c, in); };
             dq.dql_staged = op;
             staged_dql_++;
-            // fold ONE following Mul(y_scale, constant scalar) into the quantizer (same f32 multiply): its product becomes a 4th output
+            // fold the following Mul(y_scale, constant scalar) nodes -- one per convolution that reads the codes -- into the quantizer (same f32
+            // multiply each): their products become outputs 4, 5, ...
             for (size_t u : consumers[dq.out[1]]) {
+                if (op->mul_by.size() >= DynamicQuantizeLinearStaged::kMaxProducts) break;
                 Step &mu = steps_[u];
                 if (mu.kind_name != "Mul" || mu.in.size() != 2 || mu.removed) continue;
                 const int other = mu.in[0] == dq.out[1] ? mu.in[1] : mu.in[0];
@@ -504,14 +507,14 @@ class Graph {
                 bool is_out = false;
                 for (auto &o : outputs_) if (ids_.at(o.name) == mu.out[0]) is_out = true;
                 if (is_out) continue;
-                op->mul_by = &consts_.at(other);
+                op->mul_by.push_back(&consts_.at(other));
                 dq.out.push_back(mu.out[0]);
                 mu.removed = true;
                 fused_away_++;
-                break;
             }
             auto p = producer.find(dq.in[0]);
-            if (p != producer.end() && steps_[p->second].i8 && steps_[p->second].i8->to_float && steps_[p->second].out[0] == dq.in[0])
+            if (p != producer.end() && steps_[p->second].out[0] == dq.in[0] &&
+                ((steps_[p->second].i8 && steps_[p->second].i8->to_float) || steps_[p->second].maxpool))
                 want_stats.push_back({i, p->second});
         }
         // (indices into steps_ stay valid until here; drop the absorbed Mul steps last)
@@ -524,7 +527,8 @@ class Graph {
         stats_arena_.reset(new Tensor(ctx_, {(int64_t)(sb * stats_blocks_)}, DType::U8));
         for (auto &w : want_stats) {
             void *blk = (char *)stats_arena_->ptr() + sb * block_of[w.producer];
-            steps_[w.producer].i8->sg.stats_out = blk;
+            if (steps_[w.producer].maxpool) steps_[w.producer].maxpool->stats_out = blk;
+            else steps_[w.producer].i8->sg.stats_out = blk;
             steps_[w.dql].dql_staged->stats_in = blk;
             steps_[w.dql].kind_name = "DynamicQuantizeLinear(staged, producer statistics)";
         }
@@ -1293,6 +1297,7 @@ class Graph {
                     auto op = std::make_shared<MaxPool>();
                     op->kernel_size = k; op->strides = strides; op->padding = pad; op->ceil_mode = ceil;
                     st.run = [op](Context &c, const InputList &in) { return op->run(c, in); };
+                    st.maxpool = op;
                 } else {
                     auto op = std::make_shared<AveragePool>();
                     op->kernel_size = k; op->strides = strides; op->padding = pad; op->ceil_mode = ceil;

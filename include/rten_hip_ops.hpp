@@ -1061,13 +1061,15 @@ struct PoolBase : Operator {
     }
 };
 struct MaxPool : PoolBase { // src/ops/pooling.rs:477-521
+    void *stats_out = nullptr; // executor-set: a DynamicQuantizeLinear reads the output next -> its min / max come out of this launch
     const char *name() const override { return "MaxPool"; }
     int max_inputs() const override { return 1; }
     OutputList run(Context &ctx, const InputList &in) const override {
         const Tensor &x = want(require(in, 0), DType::F32, "float32");
         const rten_hip_pool2d_desc d = desc(x, false);
         Tensor y(ctx, {d.n, d.c, d.out_h, d.out_w}, DType::F32);
-        ctx.check(rten_hip_max_pool2d_f32(ctx.raw(), &d, (const float *)x.ptr(), (float *)y.ptr()));
+        if (stats_out) ctx.check(rten_hip_max_pool2d_f32_stats(ctx.raw(), &d, (const float *)x.ptr(), (float *)y.ptr(), stats_out));
+        else ctx.check(rten_hip_max_pool2d_f32(ctx.raw(), &d, (const float *)x.ptr(), (float *)y.ptr()));
         OutputList out;
         out.push_back(std::move(y));
         return out;
@@ -1124,7 +1126,10 @@ struct DynamicQuantizeLinearStaged : Operator {
     ConvInteger consumer;        // geometry attributes of (one of) the consuming convolutions
     std::vector<int64_t> kernel; // [O, C/g, kh, kw] of that consumer
     const void *stats_in = nullptr;
-    const Tensor *mul_by = nullptr; // optional: the Mul(y_scale, w_scale) that follows in ort-quantized graphs -> 4th output
+    // optional: the scalar Mul(y_scale, w_scale) nodes that follow in ort-quantized graphs, one per convolution reading the codes (a stage's
+    // shortcut and first 1x1 share one quantizer) -> outputs 4, 5, ... in this order (rten_hip_dynamic_quantize_linear_staged_products)
+    std::vector<const Tensor *> mul_by;
+    static constexpr size_t kMaxProducts = 4;
     const char *name() const override { return "DynamicQuantizeLinear"; }
     int max_inputs() const override { return 1; }
     OutputList run(Context &ctx, const InputList &in) const override {
@@ -1134,21 +1139,25 @@ struct DynamicQuantizeLinearStaged : Operator {
         di.x_signed = 0; di.w_signed = 1; di.pad_mode = consumer.pad_mode;
         const size_t nbytes = rten_hip_conv2d_int8_staged_bytes(&di);
         if (!nbytes) throw OpError(OpError::UnsupportedValue, "quantize_staged: geometry not covered by the staged kernel");
+        if (mul_by.size() > kMaxProducts) throw OpError(OpError::UnsupportedValue, "quantize_staged: at most 4 scale products per launch");
         Tensor y(ctx, x.shape(), DType::U8, nbytes), s(ctx, {}, DType::F32), z(ctx, {}, DType::U8);
-        Tensor prod(ctx, mul_by ? mul_by->shape() : std::vector<int64_t>{}, DType::F32);
-        const float *mb = mul_by ? (const float *)mul_by->ptr() : nullptr;
-        if (mul_by && mul_by->len() != 1) throw OpError(OpError::InvalidValue, "scale should be a scalar");
-        if (stats_in)
-            ctx.check(rten_hip_dynamic_quantize_linear_staged_stats(ctx.raw(), &di, (const float *)x.ptr(), stats_in, y.ptr(), (float *)s.ptr(), (uint8_t *)z.ptr(), mb,
-                                                                    mb ? (float *)prod.ptr() : nullptr));
-        else
-            ctx.check(rten_hip_dynamic_quantize_linear_staged(ctx.raw(), &di, (const float *)x.ptr(), y.ptr(), (float *)s.ptr(), (uint8_t *)z.ptr(), mb,
-                                                              mb ? (float *)prod.ptr() : nullptr));
+        std::vector<Tensor> prods;
+        prods.reserve(kMaxProducts);
+        const float *mb[kMaxProducts] = {};
+        float *pr[kMaxProducts] = {};
+        for (size_t i = 0; i < mul_by.size(); i++) {
+            if (!mul_by[i] || mul_by[i]->len() != 1) throw OpError(OpError::InvalidValue, "scale should be a scalar");
+            prods.emplace_back(ctx, mul_by[i]->shape(), DType::F32);
+            mb[i] = (const float *)mul_by[i]->ptr();
+            pr[i] = (float *)prods.back().ptr();
+        }
+        ctx.check(rten_hip_dynamic_quantize_linear_staged_products(ctx.raw(), &di, (const float *)x.ptr(), stats_in, y.ptr(), (float *)s.ptr(), (uint8_t *)z.ptr(),
+                                                                   (int32_t)mul_by.size(), mul_by.empty() ? nullptr : mb, mul_by.empty() ? nullptr : pr));
         OutputList out;
         out.push_back(std::move(y));
         out.push_back(std::move(s));
         out.push_back(std::move(z));
-        if (mul_by) out.push_back(std::move(prod));
+        for (Tensor &t : prods) out.push_back(std::move(t));
         return out;
     }
 };
