@@ -84,6 +84,35 @@ __device__ __forceinline__ int zp_signed(const uint8_t *zp, int idx, int is_sign
     if (!zp) return is_signed ? 0 : -128;
     return is_signed ? (int)(int8_t)zp[idx] : (int)zp[idx] - 128;
 }
+// The same in two steps: the load (raw byte, -1 = no zero-point input) is issued in the kernel's prologue, the conversion waits until the epilogue --
+// any arithmetic on the loaded byte makes the compiler drain every outstanding load right there, a full memory round trip before the first operand tile
+// is even requested (tools/debug/i8_trace.py: ~1000 cycles per launch).
+__device__ __forceinline__ int zp_raw(const uint8_t *zp, int idx) { return zp ? (int)zp[idx] : -1; }
+__device__ __forceinline__ int zp_from_raw(int raw, int is_signed) {
+    if (raw < 0) return is_signed ? 0 : -128;
+    return is_signed ? (int)(int8_t)(uint8_t)raw : raw - 128;
+}
+
+// All cache lines of the kernel-argument segment requested at once, one wait.  The compiler fetches a large by-value argument struct piecemeal, field
+// groups where they are first used, each group a dependent scalar-cache miss (five in a row in these kernels: ~2400 cycles before the first address can be
+// formed, on every launch of a graph whose launches are each ONE wave of workgroups); behind this prefetch its loads hit the scalar cache.
+template <int BYTES>
+__device__ __forceinline__ void kernarg_prefetch() {
+    static_assert(BYTES > 0x180 && BYTES <= 0x1c0, "seven 64-byte lines, all inside the argument struct");
+    const unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned d0, d1, d2, d3, d4, d5, d6;
+    asm volatile("s_load_dword %0, %7, 0x0\n\t"
+                 "s_load_dword %1, %7, 0x40\n\t"
+                 "s_load_dword %2, %7, 0x80\n\t"
+                 "s_load_dword %3, %7, 0xc0\n\t"
+                 "s_load_dword %4, %7, 0x100\n\t"
+                 "s_load_dword %5, %7, 0x140\n\t"
+                 "s_load_dword %6, %7, 0x180\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6)
+                 : "s"(ka)
+                 : "memory");
+}
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -349,6 +378,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
     constexpr int SUB = (BM + BN) * KTK;           // bytes of one k-tile
     constexpr int STAGE = SUB * KG;                // a stage holds one k-tile per group
     uint8_t *const smem = i8_smem;
+    kernarg_prefetch<(int)sizeof(FastArgs)>();
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave_all = __builtin_amdgcn_readfirstlane(t >> 6); // 0 .. 4 KG - 1
@@ -356,6 +386,12 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
     const int wave = wave_all & 3;                               // wave within the group: its chunk slot and its quadrant of the tile
     const int wq = wave;
     const int l31 = lane & 31, half = lane >> 5;
+#ifdef RTEN_TRACE // build.sh -DRTEN_TRACE: cycle stamps at the phase boundaries, printed by one wave (tools/debug/i8_trace.py)
+    unsigned long long tr_seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_prev = __builtin_readcyclecounter();
+#define I8_STAMP(i) { const unsigned long long now_ = __builtin_readcyclecounter(); tr_seg[i] += now_ - tr_prev; tr_prev = now_; }
+#else
+#define I8_STAMP(i)
+#endif
     int tile;
     {
         const int nt = gridDim.x, id = blockIdx.x;
@@ -391,6 +427,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
         }
     }
 
+    I8_STAMP(0) // kernel arguments, tile decode, per-lane row / pixel bases
     // ---- this wave's chunk walk: chunk index wave, wave + 4, ... of the K axis (16-byte chunks).
     // The B-side scalar offset of a chunk -- conv: its (ky, kx, c16) position on the padded image -- comes from a table that the
     // workgroup builds in LDS before the loop (one division pair per chunk, once), and everything the loop derives from the
@@ -417,6 +454,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
         }
     }
     __syncthreads();
+    I8_STAMP(1) // chunk -> offset table in LDS + barrier
     // ---- BQ: DynamicQuantizeLinear parameters from the producer's statistics (every workgroup folds the 256 slots; min / max are
     // order-free), the quantizer's outputs, and this thread's pieces of the B tile
     [[maybe_unused]] float q_scale = 0.f, q_inv = 0.f;
@@ -562,17 +600,29 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
     [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void *)(p.res ? (const void *)p.res : (const void *)p.C), 0, 0x7ffffffc, 0x00020000);
     const unsigned rs4 = (unsigned)p.c_rs << 2;
     const int mb = m0 + wm0 + 4 * half;
-    int rc_rsum = 0, rc_az = 0;
+    int rc_rsum = 0, rc_az_raw = -1;
     float rc_bias = 0.f, rc_srow = 0.f;
     if (t < BM) { // (threads of k-group 0)
         const int m = m0 + t < p.M ? m0 + t : 0;
         rc_rsum = p.rsum[m];
-        if constexpr (!RT) rc_az = zp_signed(p.a_zp, p.a_zp_len > 1 ? m % p.a_zp_len : 0, p.a_signed); // GEMM: period < M cycles the zero points (matmul.rs:266-280)
+        if constexpr (!RT) rc_az_raw = zp_raw(p.a_zp, p.a_zp_len > 1 ? m % p.a_zp_len : 0); // GEMM: period < M cycles the zero points (matmul.rs:266-280)
         rc_bias = p.bias ? p.bias[m] : 0.f;
         rc_srow = (p.scale && p.scale_per_row) ? p.scale[m] : 0.f;
         if constexpr (BQ) rc_srow = q_scale * rc_srow; // Mul(x_scale, w_scale[m])
     }
     unsigned basev[TN], bzv[TN], csv[TN];
+    [[maybe_unused]] int bz_raw[TN]; // (converted after the main loop: zp_from_raw)
+    // RT: ONE activation zero point for the whole launch.  A wave-uniform byte load comes back through a vector register and v_readfirstlane, i.e. with a
+    // full drain of the vector-memory counter right here; the aligned word around the byte through the scalar cache instead is only waited for where it is used.
+    [[maybe_unused]] unsigned bz_word = 0;
+    [[maybe_unused]] int bz_shift = -1;
+    if constexpr (RT && !BQ) {
+        if (p.b_zp) {
+            const unsigned long long addr = (unsigned long long)p.b_zp;
+            bz_word = *(const __attribute__((address_space(4))) unsigned *)(addr & ~3ull);
+            bz_shift = (int)(addr & 3ull) * 8;
+        }
+    }
     float scv[TN];
 #pragma unroll
     for (int j = 0; j < TN; j++) {
@@ -581,7 +631,8 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
         const int nn = cok ? n : 0;
         const int nb = rten_div(nn, p.d_pn), np = nn - nb * p.Pn;
         basev[j] = cok ? (unsigned)((long long)nb * p.c_ns + np) << 2 : OOB; // byte offset of (row 0, column n); rows ride the scalar offset
-        bzv[j] = (unsigned)zp_signed(p.b_zp, (RT || p.b_zp_len == 1) ? 0 : nn, p.b_signed);
+        if constexpr (!RT) bz_raw[j] = zp_raw(p.b_zp, p.b_zp_len == 1 ? 0 : nn);
+        bzv[j] = 0u;
         csv[j] = (!RT && p.csum) ? (unsigned)p.csum[nn] : 0u;
         scv[j] = (p.scale && !p.scale_per_row) ? p.scale[p.scale_len == 1 ? 0 : nn] : 0.f;
         if constexpr (BQ) {
@@ -593,6 +644,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
     // half (rows +4) folded into the vector offset
     const unsigned half_off = (unsigned)(4 * half) * rs4;
     const int mb_u = m0 + (wave / WN) * (BM / WM);
+    I8_STAMP(2) // quantizer parameters (BQ), zero points / scales / row constants of this lane's columns and rows
     [[maybe_unused]] float rr[RES ? TM : 1][RES ? TN : 1][16];
     if constexpr (RES) {
         if (KG == 1 || kg == 0) {
@@ -609,6 +661,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
         }
     }
 
+    I8_STAMP(3) // residual tile requested (RES)
     int stage = 0;
     if constexpr (BQ) {
         // A by DMA two tiles ahead (as below); B: the values of tile it + 1 are in flight in registers while tile it is multiplied,
@@ -619,6 +672,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
         wait_vmcnt<0>();
         q_store(0);
         q_load(1);
+        I8_STAMP(4) // first operand tiles requested (and the first B tile converted)
         for (int it = 0; it < nit; it++) {
             wait_vmcnt<0>(); // A of tile it (and it + 1), B values of tile it + 1
             const int stn = stage == NSTAGE - 1 ? 0 : stage + 1;
@@ -634,6 +688,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
 #pragma unroll
         for (int i = 0; i < NSTAGE - 1; i++) issue_tile(i);
         // (A two-fragment-set software pipeline of the LDS reads under the MFMAs was measured and is slower.)
+        I8_STAMP(4) // first operand tiles requested
         for (int it = 0; it < nit; it++) {
             wait_vmcnt<PER_TILE *(NSTAGE - 2)>();
             __builtin_amdgcn_s_barrier();
@@ -643,6 +698,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
             stage = stage == NSTAGE - 1 ? 0 : stage + 1;
         }
     }
+    I8_STAMP(5) // k-loop
     wait_vmcnt<0>();
     __syncthreads(); // every wave is done with the stage buffers
     if constexpr (KG > 1) {
@@ -685,7 +741,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
     int *rowc = reinterpret_cast<int *>(smem); // [4][BM]: row sum, a_zp, bias, per-row scale
     if (t < BM) {
         rowc[t] = rc_rsum;
-        if constexpr (!RT) rowc[BM + t] = rc_az;
+        if constexpr (!RT) rowc[BM + t] = zp_from_raw(rc_az_raw, p.a_signed);
         rowc[2 * BM + t] = __builtin_bit_cast(int, rc_bias);
         rowc[3 * BM + t] = __builtin_bit_cast(int, rc_srow);
     }
@@ -693,6 +749,12 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
     if (!RT && !p.csum) {
 #pragma unroll
         for (int j = 0; j < TN; j++) csv[j] = (unsigned)(cs[j] + __shfl_xor(cs[j], 32, 64)); // the two k halves of the column
+    }
+    I8_STAMP(6) // drain, k-group reduction, row constants through LDS
+    if constexpr (!BQ) {
+        [[maybe_unused]] const int raw_u = bz_shift < 0 ? -1 : (int)((bz_word >> bz_shift) & 0xffu);
+#pragma unroll
+        for (int j = 0; j < TN; j++) bzv[j] = (unsigned)zp_from_raw(RT ? raw_u : bz_raw[j], p.b_signed);
     }
     const bool epi = KG == 1 || kg == 0; // the epilogue belongs to k-group 0
     if (!QO && !epi) return;             // (no barrier follows)
@@ -914,6 +976,16 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{fb, fb, fb, fb}, rsQ, (int)(((unsigned)(plane * (p.q_Hp * p.q_Wp)) + (unsigned)pos) * 16u), 0, 0);
             }
         }
+#ifdef RTEN_TRACE
+        {
+            I8_STAMP(7) // epilogue (zero-point algebra, scale, bias, residual, statistics, stores issued; QO: + the grid-wide exchange and the quantized stores)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long t_end_ = __builtin_readcyclecounter();
+            if (blockIdx.x == (gridDim.x > 8 ? 8 : 0) && t == 0)
+                printf("[i8 trace] <%d,%d,res=%d,kg=%d,bq=%d,qo=%d,rt=%d> M %d N %d Kp %d grid %u: args+decode %llu, table %llu, operands %llu, residual req %llu, first tiles %llu, k-loop %llu (%d trips), drain+rowc %llu, epilogue %llu, store drain %llu cycles\n",
+                       BM, BN, (int)RES, KG, (int)BQ, (int)QO, (int)RT, p.M, p.N, p.Kp, gridDim.x, tr_seg[0], tr_seg[1], tr_seg[2], tr_seg[3], tr_seg[4], tr_seg[5], nit, tr_seg[6], tr_seg[7], t_end_ - tr_prev);
+        }
+#endif
         return;
     }
     if (p.stats) {
@@ -925,6 +997,17 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
             atomicMax(&p.stats[dql::kStatSlots + slot], dql::f2ord(st_mx));
         }
     }
+#ifdef RTEN_TRACE
+    {
+        I8_STAMP(7) // epilogue (zero-point algebra, scale, bias, residual, statistics, stores issued; QO: + the grid-wide exchange and the quantized stores)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t_end_ = __builtin_readcyclecounter();
+        if (blockIdx.x == (gridDim.x > 8 ? 8 : 0) && t == 0)
+            printf("[i8 trace] <%d,%d,res=%d,kg=%d,bq=%d,qo=%d,rt=%d> M %d N %d Kp %d grid %u: args+decode %llu, table %llu, operands %llu, residual req %llu, first tiles %llu, k-loop %llu (%d trips), drain+rowc %llu, epilogue %llu, store drain %llu cycles\n",
+                   BM, BN, (int)RES, KG, (int)BQ, (int)QO, (int)RT, p.M, p.N, p.Kp, gridDim.x, tr_seg[0], tr_seg[1], tr_seg[2], tr_seg[3], tr_seg[4], tr_seg[5], nit, tr_seg[6], tr_seg[7], t_end_ - tr_prev);
+    }
+#endif
+#undef I8_STAMP
 }
 
 // Transposing variant of the row packer for operands whose rows are NOT k-contiguous (e.g. MatMulInteger weights

@@ -1,4 +1,10 @@
-"""One launch of selected int8 conv layers of ResNet-50 (batch 32) with the kernel's cycle stamps printed (debug build of int8_fast.hip only)."""
+"""One launch of selected int8 conv layers of ResNet-50 (batch 32) with the kernel's cycle stamps printed: the per-phase table of DESIGN.md section 7.2.
+
+Needs a library whose int8_fast.hip was compiled with -DRTEN_TRACE (the stamps are compiled out of the product build):
+    cd rten_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -DRTEN_TRACE -c int8_fast.hip -o /tmp/int8_trace.o
+    cd .. && hipcc --offload-arch=gfx950 -shared -fPIC -o _ab/trace.so $(ls _build/*.o | grep -v int8_fast.o) /tmp/int8_trace.o
+    RTEN_HIP_LIBRARY=$PWD/_ab/trace.so python tools/debug/i8_trace.py s0b0c3 s1b1c2 s2b1c1 s3b1c2      (on the GPU box: through gpurun)
+One workgroup (id 8) of every launch prints its cycle counts per phase (shader clock, s_memtime)."""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
