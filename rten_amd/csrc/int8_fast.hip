@@ -98,20 +98,31 @@ __device__ __forceinline__ int zp_from_raw(int raw, int is_signed) {
 // formed, on every launch of a graph whose launches are each ONE wave of workgroups); behind this prefetch its loads hit the scalar cache.
 template <int BYTES>
 __device__ __forceinline__ void kernarg_prefetch() {
-    static_assert(BYTES > 0x180 && BYTES <= 0x1c0, "seven 64-byte lines, all inside the argument struct");
+    constexpr int NLINES = (BYTES + 63) / 64; // every line requested lies inside the explicit arguments
+    static_assert(NLINES == 3 || NLINES == 7, "the argument blocks of this file");
     const unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
     unsigned d0, d1, d2, d3, d4, d5, d6;
-    asm volatile("s_load_dword %0, %7, 0x0\n\t"
-                 "s_load_dword %1, %7, 0x40\n\t"
-                 "s_load_dword %2, %7, 0x80\n\t"
-                 "s_load_dword %3, %7, 0xc0\n\t"
-                 "s_load_dword %4, %7, 0x100\n\t"
-                 "s_load_dword %5, %7, 0x140\n\t"
-                 "s_load_dword %6, %7, 0x180\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6)
-                 : "s"(ka)
-                 : "memory");
+    if constexpr (NLINES == 7) {
+        asm volatile("s_load_dword %0, %7, 0x0\n\t"
+                     "s_load_dword %1, %7, 0x40\n\t"
+                     "s_load_dword %2, %7, 0x80\n\t"
+                     "s_load_dword %3, %7, 0xc0\n\t"
+                     "s_load_dword %4, %7, 0x100\n\t"
+                     "s_load_dword %5, %7, 0x140\n\t"
+                     "s_load_dword %6, %7, 0x180\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6)
+                     : "s"(ka)
+                     : "memory");
+    } else {
+        asm volatile("s_load_dword %0, %3, 0x0\n\t"
+                     "s_load_dword %1, %3, 0x40\n\t"
+                     "s_load_dword %2, %3, 0x80\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&s"(d0), "=&s"(d1), "=&s"(d2)
+                     : "s"(ka)
+                     : "memory");
+    }
 }
 
 template <int N>
@@ -312,6 +323,8 @@ template <int KIND>
 __global__ __launch_bounds__(256) void i8_quantize_stage_kernel(const float *__restrict__ x, const float *__restrict__ ws, int nparts, uint8_t *__restrict__ xp,
                                                                int C, int H, int W, int Hp, int Wp, int Cp, int pt, int pl, int pad_mode,
                                                                float *scale_out, uint8_t *zp_out, const ScaleProducts sp) {
+    // explicit arguments: 0x58 bytes + ScaleProducts = 160 bytes, three lines (the tail of them is first touched AFTER the tile has arrived: on the critical path)
+    kernarg_prefetch<0x58 + (int)sizeof(ScaleProducts)>();
     auto prep = [&]() {
         float x_min, x_max;
         if (nparts < 0) dql::block_minmax_slots(reinterpret_cast<const unsigned *>(ws), x_min, x_max); // producer-accumulated statistics
@@ -378,7 +391,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
     constexpr int SUB = (BM + BN) * KTK;           // bytes of one k-tile
     constexpr int STAGE = SUB * KG;                // a stage holds one k-tile per group
     uint8_t *const smem = i8_smem;
-    kernarg_prefetch<(int)sizeof(FastArgs)>();
+    kernarg_prefetch<(int)sizeof(FastArgs)>(); // (7 lines)
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave_all = __builtin_amdgcn_readfirstlane(t >> 6); // 0 .. 4 KG - 1
