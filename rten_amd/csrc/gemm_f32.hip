@@ -302,6 +302,7 @@ __device__ __forceinline__ void split_finish(const GemmArgs &p, int z, int tile,
 // MODE: 0 = one depth block, 1 = several depth blocks folded in registers, 2 = split-K producer (see the LDS-DMA kernel).
 template <int BM, int BN, int AL, int BL, int MODE>
 __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_kernel(const GemmArgs p) {
+    kernarg_prefetch<(int)sizeof(GemmArgs)>();
     constexpr bool MULTI_KC = MODE == 1, SPLIT = MODE == 2;
     constexpr int WM = 2, WN = 2;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -709,6 +710,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 //          costs ~43 cycles on top of its own slot (MI355X_MICROARCH.md, per-instruction constants).
 template <int BM, int BN, int AL, int BL, int MODE, int NST = 3, int MFK = 0>
 __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmArgs p) {
+    kernarg_prefetch<(int)sizeof(GemmArgs)>();
     // MODE 3 ("mixed"): one launch holds the whole tiles [0, split_t1) (fold + epilogue, as MODE 1) AND the split-K
     // producers of the tail tiles (as MODE 2), so the tail's small workgroups fill the last round next to the whole
     // tiles instead of running alone afterwards.
@@ -1052,6 +1054,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
 // activation, store).  Slots are fetched U at a time so several loads are in flight per lane.
 template <int BM, int BN>
 __global__ __launch_bounds__(64) void igemm_f32_fixup_kernel(const GemmArgs p) {
+    kernarg_prefetch<(int)sizeof(GemmArgs)>();
     constexpr int WM = 2, WN = 2;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int U = TM * TN >= 4 ? 1 : 4 / (TM * TN); // slots per batch: 64 floats per lane in flight
@@ -1228,6 +1231,7 @@ __device__ __forceinline__ void store_out16(const GemmArgs &p, f32x4v (&val)[TM2
 
 template <int BM, int BN, int AL, int BL, int MODE>
 __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma16_kernel(const GemmArgs p) {
+    kernarg_prefetch<(int)sizeof(GemmArgs)>();
     constexpr bool MULTI_KC = MODE == 1;
     static_assert(MODE == 0 || MODE == 1, "the 16x16x4 kernel has no split-K form");
     static_assert(AL == A_M4 || AL == A_K4, "DMA kernel: A is k-major or row-major with 16-byte rows");
@@ -1476,6 +1480,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma16_kernel(const Gemm
 // =====================================================================================================
 template <int BM, int BN, int AL, int BL, bool MF16, int MFK = 0>
 __global__ __launch_bounds__(NTHREADS, (BM * BN >= 128 * 128) ? 1 : 2) void igemm_f32_pers_kernel(const GemmArgs p) {
+    kernarg_prefetch<(int)sizeof(GemmArgs)>();
     static_assert(AL == A_M4 || AL == A_K4, "DMA kernel: A is k-major or row-major with 16-byte rows");
     static_assert(BL == B_N4 || BL == B_IM2COL || BL == B_IM2COL_TAPS, "DMA kernel covers the conv operand layouts");
     constexpr int WM = 2, WN = 2;
@@ -1855,6 +1860,7 @@ constexpr int LBK = 32; // k-tile depth of the lean kernel
 
 template <int BL, int NSTAGE = 3>
 __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_lean_kernel(const GemmArgs p) {
+    kernarg_prefetch<(int)sizeof(GemmArgs)>();
     static_assert(BL == B_N4 || BL == B_IM2COL_TAPS, "lean kernel: dense or tap-masked im2col B");
     constexpr int BM = 64, BN = 64;
     constexpr int STAGE = LBK * (BM + BN); // floats
@@ -2053,6 +2059,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_lean_kernel(const GemmA
 
 template <int BM, int BN, int BL, bool MULTI_KC>
 __global__ __launch_bounds__(2 * NTHREADS, 2) void igemm_f32_ws_kernel(const GemmArgs p) {
+    kernarg_prefetch<(int)sizeof(GemmArgs)>();
     static_assert(BL == B_N4 || BL == B_IM2COL || BL == B_IM2COL_TAPS, "DMA kernel covers the conv operand layouts");
     constexpr int WM = 2, WN = 2;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -2322,6 +2329,7 @@ constexpr int TKC_TILES = 256 / TBK;  // k-tiles per reference depth block
 
 template <int BL, bool MULTI_KC>
 __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_thin_kernel(const GemmArgs p) {
+    kernarg_prefetch<(int)sizeof(GemmArgs)>();
     static_assert(BL == B_N4 || BL == B_IM2COL || BL == B_IM2COL_TAPS, "thin kernel covers the conv operand layouts");
     constexpr int BM = 16, BN = 64, LDA = 32;        // LDS A image is 32 wide (one dwordx4 DMA instruction per wave), 16 used
     constexpr int STAGE = TBK * (LDA + BN);          // floats per stage

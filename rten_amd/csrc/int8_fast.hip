@@ -93,37 +93,6 @@ __device__ __forceinline__ int zp_from_raw(int raw, int is_signed) {
     return is_signed ? (int)(int8_t)(uint8_t)raw : raw - 128;
 }
 
-// All cache lines of the kernel-argument segment requested at once, one wait.  The compiler fetches a large by-value argument struct piecemeal, field
-// groups where they are first used, each group a dependent scalar-cache miss (five in a row in these kernels: ~2400 cycles before the first address can be
-// formed, on every launch of a graph whose launches are each ONE wave of workgroups); behind this prefetch its loads hit the scalar cache.
-template <int BYTES>
-__device__ __forceinline__ void kernarg_prefetch() {
-    constexpr int NLINES = (BYTES + 63) / 64; // every line requested lies inside the explicit arguments
-    static_assert(NLINES == 3 || NLINES == 7, "the argument blocks of this file");
-    const unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
-    unsigned d0, d1, d2, d3, d4, d5, d6;
-    if constexpr (NLINES == 7) {
-        asm volatile("s_load_dword %0, %7, 0x0\n\t"
-                     "s_load_dword %1, %7, 0x40\n\t"
-                     "s_load_dword %2, %7, 0x80\n\t"
-                     "s_load_dword %3, %7, 0xc0\n\t"
-                     "s_load_dword %4, %7, 0x100\n\t"
-                     "s_load_dword %5, %7, 0x140\n\t"
-                     "s_load_dword %6, %7, 0x180\n\t"
-                     "s_waitcnt lgkmcnt(0)"
-                     : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6)
-                     : "s"(ka)
-                     : "memory");
-    } else {
-        asm volatile("s_load_dword %0, %3, 0x0\n\t"
-                     "s_load_dword %1, %3, 0x40\n\t"
-                     "s_load_dword %2, %3, 0x80\n\t"
-                     "s_waitcnt lgkmcnt(0)"
-                     : "=&s"(d0), "=&s"(d1), "=&s"(d2)
-                     : "s"(ka)
-                     : "memory");
-    }
-}
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {

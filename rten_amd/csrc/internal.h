@@ -135,3 +135,46 @@ inline RtenDiv rten_make_div(long long n_max, long long d) {
     return r;
 }
 __device__ __forceinline__ int rten_div(int n, const RtenDiv &d) { return (int)(((unsigned long long)(unsigned)n * d.mul) >> d.shift); }
+
+// All cache lines of the kernel-argument segment requested at once, one wait.  The compiler fetches a large by-value argument struct piecemeal, field
+// groups where they are first used, each group a dependent scalar-cache miss (five in a row in the int8 convolution kernels: ~2400 cycles before the first
+// address can be formed -- tools/debug/i8_trace.py); behind this prefetch its loads hit the scalar cache.  It matters where a launch is ONE wave of workgroups
+// (the int8 graph, batch-1 latency): nothing else hides a prologue there.  BYTES = size of the explicit arguments: every line requested lies inside them.
+template <int BYTES>
+__device__ __forceinline__ void kernarg_prefetch() {
+    constexpr int NLINES = (BYTES + 63) / 64;
+    static_assert(NLINES == 3 || NLINES == 5 || NLINES == 7, "argument blocks of 3, 5 or 7 cache lines");
+    const unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned d0, d1, d2, d3, d4, d5, d6;
+    if constexpr (NLINES == 7) {
+        asm volatile("s_load_dword %0, %7, 0x0\n\t"
+                     "s_load_dword %1, %7, 0x40\n\t"
+                     "s_load_dword %2, %7, 0x80\n\t"
+                     "s_load_dword %3, %7, 0xc0\n\t"
+                     "s_load_dword %4, %7, 0x100\n\t"
+                     "s_load_dword %5, %7, 0x140\n\t"
+                     "s_load_dword %6, %7, 0x180\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6)
+                     : "s"(ka)
+                     : "memory");
+    } else if constexpr (NLINES == 5) {
+        asm volatile("s_load_dword %0, %5, 0x0\n\t"
+                     "s_load_dword %1, %5, 0x40\n\t"
+                     "s_load_dword %2, %5, 0x80\n\t"
+                     "s_load_dword %3, %5, 0xc0\n\t"
+                     "s_load_dword %4, %5, 0x100\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4)
+                     : "s"(ka)
+                     : "memory");
+    } else {
+        asm volatile("s_load_dword %0, %3, 0x0\n\t"
+                     "s_load_dword %1, %3, 0x40\n\t"
+                     "s_load_dword %2, %3, 0x80\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&s"(d0), "=&s"(d1), "=&s"(d2)
+                     : "s"(ka)
+                     : "memory");
+    }
+}
