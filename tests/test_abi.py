@@ -88,6 +88,14 @@ def test_no_silent_cpu_fallback():
         lib.Context(0)
 
 
+def test_product_library_is_not_a_trace_or_ablation_build():
+    """The phase stamps (-DRTEN_TRACE: device printf per launch) and ablation switches are for tools/debug and tools/probes; the library that
+    travels with the tree must be the plain build."""
+    from rten_amd import lib
+    blob = open(lib.SO_PATH, "rb").read()
+    assert b"[i8 trace]" not in blob and b"[trace] wave" not in blob
+
+
 def test_product_never_imports_oracle():
     """oracle/ is test infrastructure: nothing under rten_amd/ (or bench.py's product path) may import it."""
     for dirpath, _, files in os.walk(os.path.join(ROOT, "rten_amd")):
