@@ -25,6 +25,11 @@
 //     + K*a_zp*b_zp with weight sums from the staging pass; the activation-side sums are only accumulated
 //     (v_dot4 on the operand fragments) when the weight zero point can be non-zero.
 //   * Epilogue fuses cast_scale, bias, residual Add and Relu; i32 or f32 output straight into NCHW / row-major.
+//   * A launch of this path is usually ONE wave of workgroups (a few hundred tiles for 256 CUs), so its prologue and epilogue are on the critical path one
+//     for one (tools/debug/i8_trace.py on a -DRTEN_TRACE build).  Hence: all kernel-argument lines requested at entry
+//     (kernarg_prefetch), index arithmetic by multiply-shift (rten_div), no arithmetic on a loaded value before the main loop (it would drain the
+//     vector-memory counter in front of the first operand request), the launch's single activation zero point through the scalar cache, and the
+//     single-row-term epilogue of the convolution form as a template flag (RT).
 #include "internal.h"
 #include "quantize.h"
 #include "vecmath.h"
