@@ -134,7 +134,7 @@ inline RtenDiv rten_make_div(long long n_max, long long d) {
     r.shift = L + sft;
     return r;
 }
-__device__ __forceinline__ int rten_div(int n, const RtenDiv &d) { return (int)(((unsigned long long)(unsigned)n * d.mul) >> d.shift); }
+__host__ __device__ __forceinline__ int rten_div(int n, const RtenDiv &d) { return (int)(((unsigned long long)(unsigned)n * d.mul) >> d.shift); }
 
 // All cache lines of the kernel-argument segment requested at once, one wait.  The compiler fetches a large by-value argument struct piecemeal, field
 // groups where they are first used, each group a dependent scalar-cache miss (five in a row in the int8 convolution kernels: ~2400 cycles before the first
