@@ -20,11 +20,16 @@
 //!
 //! Registration (what a user writes):
 //! ```ignore
-//! let mut reg = OpRegistry::with_all_ops();                 // src/op_registry.rs
-//! rten_hip::register(&mut reg, HipContext::new(0)?);        // same op names, HIP-backed
-//! let model = ModelOptions::with_ops(reg).load_file("resnet50.onnx")?;
-//! let out = model.run_one(input.view().into(), None)?;      // unchanged call site
+//! let hip = HipContext::new(0)?;                             // Err(NoDevice) without an MI355X: there is no CPU fallback inside the backend
+//! let mut opts = ModelOptions::with_all_ops();               // src/model.rs:679-700
+//! rten_hip::register(&mut opts, hip);                        // post-optimisation operator rewrite (ops.rs, `register`)
+//! let model = opts.load_file("resnet50.onnx")?;
+//! let out = model.run_one(input.view().into(), None)?;      // unchanged call site; rten-cli / rten-examples unchanged
 //! ```
+//! The operators are wrapped AFTER the reference's optimiser has run, so its fusion passes (which recognise operators by `Any`
+//! downcast) see the operators they know and the backend sees `ConvIntegerToFloat` / `FusedMatMul` / `AddSoftmax` / `MatMulIntegerToFloat`.
+//! Two additions to the reference, both listed in INTEGRATION.md section 2.1: `ModelOptions::set_operator_rewriter` and the accessors
+//! `ConvIntegerToFloat::conv()` / `MatMulIntegerToFloat::matmul()` for fields that are private today.
 mod ops;
 
 use std::collections::HashMap;
@@ -35,11 +40,14 @@ use std::sync::{Arc, Mutex};
 use rten::ops::OpError;
 use rten_hip_sys as sys;
 
-pub use ops::register;
+pub use ops::{accelerate, register};
 
 /// RAII over `rten_hip_ctx`.  `Send + Sync`: the C ABI serialises entry per call (rten_hip.h, "Thread safety").
 pub struct HipContext {
     raw: *mut sys::rten_hip_ctx,
+}
+impl std::fmt::Debug for HipContext { // `Operator: Debug` (src/operator.rs:486): every wrapper derives it
+    fn fmt(&self, f: &mut std::fmt::Formatter<'_>) -> std::fmt::Result { write!(f, "HipContext({:p})", self.raw) }
 }
 unsafe impl Send for HipContext {}
 unsafe impl Sync for HipContext {}
@@ -123,6 +131,10 @@ impl Drop for HipContext {
 /// (address or length changed) is staged again instead of serving stale weights.
 pub struct ConstCache {
     slots: Mutex<HashMap<(usize, u32), (usize, usize, DeviceBuffer)>>, // (input index, layout tag) -> (host address, bytes, device copy)
+}
+
+impl std::fmt::Debug for ConstCache {
+    fn fmt(&self, f: &mut std::fmt::Formatter<'_>) -> std::fmt::Result { write!(f, "ConstCache({} staged)", self.slots.lock().map(|s| s.len()).unwrap_or(0)) }
 }
 
 impl ConstCache {

@@ -57,6 +57,19 @@ constexpr int NTHREADS = 256;
 #endif
 constexpr unsigned OOB = 0x80000000u; // byte offset beyond every buffer (< 2 GiB): buffer loads return 0
 
+#ifdef RTEN_TRACE
+// -DRTEN_TRACE builds only (tools/debug/f32_trace.py): every workgroup of the LDS-DMA kernel appends one record of wall-clock stamps
+// (s_memrealtime, 100 MHz, the same counter on every XCD) at its phase boundaries, with its compute unit.  Compiled out of the product build.
+__device__ unsigned long long *g_trace_buf = nullptr; // 16 x u64 per record
+__device__ unsigned g_trace_cap = 0;
+unsigned g_trace_host_next = 0; // host: slots handed out so far (a captured launch keeps its slots for every replay)
+#define TR_DECL unsigned long long tr_t[6] = {0, 0, 0, 0, 0, 0}; unsigned tr_trips = 0;
+#define TR_STAMP(i) tr_t[i] = __builtin_amdgcn_s_memrealtime();
+#else
+#define TR_DECL
+#define TR_STAMP(i)
+#endif
+
 enum ALoad { A_M4 = 0, A_K4 = 1, A_SCALAR = 2 };
 enum BLoad { B_N4 = 0, B_K4 = 1, B_SCALAR = 2, B_IM2COL = 3, B_IM2COL_TAPS = 4 }; // TAPS: <= 31 kernel taps, per-lane validity bitmask
 
@@ -91,6 +104,9 @@ struct GemmArgs {
     int split_t1, split_s, split_g, split_slots, split_ntail;
     int order; // bit 0: tiles walk n fastest (default m fastest); bit 1: split workgroups walk tiles fastest, K groups slowest
     int n_lo;  // thin-tile kernel: first column of its share (the whole-round tiles of the same call cover [0, n_lo))
+#ifdef RTEN_TRACE
+    unsigned trace_base; // first record slot of this launch (host counter: a launch's workgroups own slots base + blockIdx)
+#endif
 };
 
 
@@ -694,6 +710,28 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_kernel(const GemmArgs p
 constexpr int nstage_for(int bm, int bn) { return 3; } // deeper rings measured slower: LDS-limited occupancy, no gain for a lone workgroup
 constexpr int MAX_NSTAGE = 6;
 
+#ifdef RTEN_TRACE
+__device__ __forceinline__ void trace_write(const GemmArgs &p, unsigned kid, int tile, int grp, unsigned trips, const unsigned long long (&t)[6]) {
+    if (threadIdx.x != 0 || g_trace_buf == nullptr) return;
+    const unsigned i = p.trace_base + blockIdx.y * gridDim.x + blockIdx.x; // no shared counter: 130k same-address atomics per step serialise (first version: 2.7 -> 11.7 ms)
+    if (i >= g_trace_cap) return;
+    unsigned long long *r = g_trace_buf + (unsigned long long)i * 16;
+    const unsigned hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    r[0] = kid | ((unsigned long long)blockIdx.x << 32);
+    r[1] = hwid | ((unsigned long long)xcc << 32);
+    for (int k = 0; k < 6; k++) r[2 + k] = t[k];
+    r[8] = (unsigned)p.M | ((unsigned long long)(unsigned)p.K << 32);
+    r[9] = (unsigned)p.N | ((unsigned long long)gridDim.x << 32);
+    r[10] = trips | ((unsigned long long)(unsigned)tile << 32);
+    r[11] = (unsigned)(grp + 1) | ((unsigned long long)(unsigned)p.split_s << 32);
+    r[12] = (unsigned long long)p.C;
+    r[13] = blockIdx.y;
+}
+#define TR_WRITE(kid, tile, grp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TR_STAMP(5) trace_write(p, kid, tile, grp, tr_trips, tr_t); }
+#else
+#define TR_WRITE(kid, tile, grp)
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -710,6 +748,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 //          costs ~43 cycles on top of its own slot (MI355X_MICROARCH.md, per-instruction constants).
 template <int BM, int BN, int AL, int BL, int MODE, int NST = 3, int MFK = 0>
 __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmArgs p) {
+    TR_DECL
+    TR_STAMP(0)
     kernarg_prefetch<(int)sizeof(GemmArgs)>();
     // MODE 3 ("mixed"): one launch holds the whole tiles [0, split_t1) (fold + epilogue, as MODE 1) AND the split-K
     // producers of the tail tiles (as MODE 2), so the tail's small workgroups fill the last round next to the whole
@@ -997,11 +1037,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
         fetch_lut(kt0 + i + 1);
     }
     int stage = 0;
+    TR_STAMP(1)
     for (int blk = blk0; blk < blk1; blk++) {
         const int kt_end = (MULTI_KC || SPLIT) ? ((blk + 1) * KC_TILES < nk ? (blk + 1) * KC_TILES : nk) : nk;
         for (int kt = blk * KC_TILES; kt < kt_end; kt++) {
             wait_vmcnt<PER_TILE *(NSTAGE - 2)>(); // this wave's DMA for tile kt has landed; NSTAGE-2 later tiles stay in flight
             if (!(ABLATE(p) & 8)) __builtin_amdgcn_s_barrier(); // ... and everyone else's; all waves are done reading the stage of tile kt-1
+#ifdef RTEN_TRACE
+            if (tr_trips == 0) TR_STAMP(2)
+            tr_trips++;
+#endif
             const int stp = stage == 0 ? NSTAGE - 1 : stage - 1; // (kt + NSTAGE - 1) % NSTAGE: the stage tile kt-1 used
             if (!(ABLATE(p) & 1)) issue_tile(kt + NSTAGE - 1, stp);
             fetch_lut(kt + NSTAGE);
@@ -1029,9 +1074,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
         }
     }
     wait_vmcnt<0>(); // drain the two look-ahead tiles before the LDS goes away
+    TR_STAMP(3)
+    [[maybe_unused]] constexpr unsigned TR_KID = BM | (BN << 8) | (MODE << 16) | (BL << 20) | (AL << 24) | (NST << 28);
 
     if (SPLIT || (MIXED && grp >= 0)) {
         if (p.split_counters) split_finish<BM, BN, TM, TN>(p, z, tile, wq, lane, m0, n0, c_zoff, reinterpret_cast<int *>(smem));
+        TR_STAMP(4)
+        TR_WRITE(TR_KID, tile, grp)
         return;
     }
     if constexpr (!SPLIT) {
@@ -1046,6 +1095,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmAr
             }
         }
     }
+    TR_STAMP(4)
+    TR_WRITE(TR_KID, tile, grp)
 }
 
 // Split-K fixup: one WAVE per quadrant of a split tile (grid = 4 x split tiles, 64 threads), same lane <-> element
@@ -2578,6 +2629,18 @@ struct TileCfg { int bm, bn; float penalty; };
 // variant ids are part of the tuning interface (rten_hip_set_gemm_variant_override)
 constexpr TileCfg kCfgs[4] = {{128, 128, 1.00f}, {128, 64, 1.04f}, {64, 128, 1.04f}, {64, 64, 1.12f}};
 
+// Occupancy cap of the LDS-DMA kernels (order bits 4-6 = workgroups per compute unit, 0 = whatever fits): dynamic LDS bytes the kernel never
+// touches, sized so that exactly `cap` workgroups fit the 160 KB of a compute unit.  Why a cap: with one 32x32 accumulator block per wave
+// every MFMA of a wave depends on its previous one, and three or more such waves on a SIMD share the matrix pipe badly (tools/debug/f32_trace.py:
+// 64x64 tiles at 3-4 workgroups per CU keep it 67 % busy inside the k-loop; tools/probes/kloop.hip row A: 150 TF/s at two waves per SIMD, 114 at three).
+inline size_t occupancy_pad(const rten_hip_ctx *ctx, int static_bytes) {
+    static const int env_cap = getenv("RTEN_HIP_OCC_CAP") ? atoi(getenv("RTEN_HIP_OCC_CAP")) : 0; // tuning only
+    const int cap = env_cap > 0 ? env_cap : (ctx->tile_order >> 4) & 7;
+    if (cap < 2) return 0; // (a cap of 1 needs more than 64 KB per workgroup: not offered)
+    const int want = 160 * 1024 / (cap + 1) + 1024; // one byte more than what cap + 1 workgroups could share
+    return want > static_bytes ? (size_t)((want - static_bytes + 255) & ~255) : 0;
+}
+
 // One launch plan for every pipeline: whole tiles [0, t1) by the folding kernel (MODE 0/1), split tiles [t1, T) by
 // the split-K producer (MODE 2) followed by the ordered fixup.  Only depth-block boundaries are legal K cuts.
 template <int BM, int BN, int AL, int BL>
@@ -2599,7 +2662,7 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
     const int T = a.tiles_m * a.tiles_n;
     int ntail = 0, t1 = T, S = 1;
     a.split_s = 1;
-    a.order = ctx->tile_order;
+    a.order = ctx->tile_order & 3;
     int split_mode = ctx->split_mode, split_req = ctx->split_s;
     if (split_mode == 3) { // auto: too few tiles to fill the chip -> cut every tile so that ~num_cus workgroups exist
         const long long wgs = (long long)T * Z;
@@ -2627,6 +2690,10 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
 
     auto launch = [&](int mode, unsigned gx, double fl, double by) -> int32_t {
         const dim3 grid(gx, (unsigned)Z);
+#ifdef RTEN_TRACE
+        a.trace_base = g_trace_host_next;
+        g_trace_host_next += gx * (unsigned)Z;
+#endif
         if constexpr (kDma) {
             if (pipe == 2) {
                 snprintf(kname, sizeof kname, "igemm_f32_ws_kernel<%d,%d,%d,%s>", BM, BN, BL, mode == 1 ? "true" : "false");
@@ -2639,9 +2706,10 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
             if (pipe == 1) {
                 snprintf(kname, sizeof kname, "igemm_f32_dma_kernel<%d,%d,%d,%d,%d,3>", BM, BN, AL, BL, mode);
                 ProfScope ps(ctx, kname, fl, by);
-                if (mode == 2) hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, AL, BL, 2>), grid, dim3(NTHREADS), 0, ctx->stream, a);
-                else if (mode == 1) hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, AL, BL, 1>), grid, dim3(NTHREADS), 0, ctx->stream, a);
-                else hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, AL, BL, 0>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+                const size_t pad = occupancy_pad(ctx, 3 * BK * (BM + BN) * 4);
+                if (mode == 2) hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, AL, BL, 2>), grid, dim3(NTHREADS), pad, ctx->stream, a);
+                else if (mode == 1) hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, AL, BL, 1>), grid, dim3(NTHREADS), pad, ctx->stream, a);
+                else hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, AL, BL, 0>), grid, dim3(NTHREADS), pad, ctx->stream, a);
                 RTEN_LAUNCH_CHECK(ctx, "igemm_f32_dma_kernel launch");
                 return RTEN_HIP_OK;
             }
@@ -2777,7 +2845,12 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
         if constexpr (kDma && BM * BN < 128 * 128) {
             snprintf(kname, sizeof kname, "igemm_f32_dma_kernel<%d,%d,%d,%d,3,3>", BM, BN, AL, BL);
             ProfScope ps(ctx, kname, flops, bytes);
-            hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, AL, BL, 3>), dim3((unsigned)(t1 + ntail * S), (unsigned)Z), dim3(NTHREADS), 0, ctx->stream, a);
+#ifdef RTEN_TRACE
+            a.trace_base = g_trace_host_next;
+            g_trace_host_next += (unsigned)(t1 + ntail * S) * (unsigned)Z;
+#endif
+            hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, AL, BL, 3>), dim3((unsigned)(t1 + ntail * S), (unsigned)Z), dim3(NTHREADS),
+                               occupancy_pad(ctx, 3 * BK * (BM + BN) * 4), ctx->stream, a);
             RTEN_LAUNCH_CHECK(ctx, "igemm_f32_dma_kernel (mixed) launch");
         }
     } else if (t1 > 0) {
@@ -2876,7 +2949,7 @@ RTEN_EXPORT int32_t rten_hip_set_gemm_split(rten_hip_ctx *ctx, int32_t mode, int
 // workgroups walk tiles fastest and K groups slowest (each XCD's L2 then holds one K slice of both operands).
 RTEN_EXPORT int32_t rten_hip_set_gemm_order(rten_hip_ctx *ctx, int32_t order) {
     RTEN_CHECK_CTX(ctx);
-    if (order < 0 || order > 3) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "set_gemm_order: order must be 0..3");
+    if (order < 0 || (order & ~0x73)) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "set_gemm_order: bits 0-1 (tile walk) and 4-6 (workgroups per compute unit) only");
     ctx->tile_order = order;
     return RTEN_HIP_OK;
 }
@@ -3100,3 +3173,19 @@ RTEN_EXPORT int32_t rten_hip_conv2d_f32(rten_hip_ctx *ctx, const rten_hip_conv2d
     g.debug = ctx->debug;
     return dispatch(ctx, g, d->groups, al, bl);
 }
+
+#ifdef RTEN_TRACE
+// Trace builds only: hand the kernels a device buffer of `cap` 128-byte records (NULL: off) / read the number of records written.
+RTEN_EXPORT int32_t rten_hip_debug_trace_set(rten_hip_ctx *ctx, void *buf, uint32_t cap) {
+    RTEN_CHECK_CTX(ctx);
+    unsigned long long *b = (unsigned long long *)buf;
+    RTEN_HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_trace_buf), &b, sizeof(b)));
+    RTEN_HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_trace_cap), &cap, sizeof(cap)));
+    return RTEN_HIP_OK;
+}
+RTEN_EXPORT int32_t rten_hip_debug_trace_count(rten_hip_ctx *ctx, uint32_t *n) { // slots handed out to launches so far
+    RTEN_CHECK_CTX(ctx);
+    *n = g_trace_host_next;
+    return RTEN_HIP_OK;
+}
+#endif

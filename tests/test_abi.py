@@ -188,3 +188,98 @@ def test_rust_repr_c_field_order_and_offsets_match_the_c_compiler():
         # the C struct has exactly these fields (a field missing on the Rust side would shift a later offset or the size)
         assert [c[f] for f, _ in fields] == offs, (name, [c[f] for f, _ in fields], offs)
         assert offs == sorted(offs)
+
+
+# ---- the safe Rust layer (bindings/rten-hip): structural checks that need no Rust toolchain ---------------------------------------------
+OPS_RS = os.path.join(ROOT, "bindings", "rten-hip", "src", "ops.rs")
+# reference operators of INTEGRATION.md section 2.3 that the drop-in wraps (one `impl Operator for Hip<Name>` each)
+RUST_OPERATORS = ["Conv", "ConvInteger", "ConvIntegerToFloat", "MatMul", "FusedMatMul", "Gemm", "MatMulInteger", "MatMulIntegerToFloat",
+                  "DynamicQuantizeLinear", "Softmax", "AddSoftmax", "LayerNormalization", "Gelu", "Erf", "Relu", "Add", "Mul",
+                  "MaxPool", "AveragePool", "GlobalAveragePool", "Attention"]
+
+
+def _ops_rs_defined_operators(text):
+    """Names with an `impl Operator for X` -- written out or produced by the hip_unary! / hip_binary! / hip_pool! macros."""
+    impls = set(re.findall(r"impl Operator for (Hip[A-Za-z]+)", text))
+    for macro in ("hip_unary", "hip_binary", "hip_pool"):
+        body = re.search(rf"macro_rules! {macro} \{{(.*?)\n\}}\n", text, flags=re.S)
+        assert body and "impl Operator for $name" in body.group(1), macro
+        impls |= set(re.findall(rf"^{macro}!\((Hip[A-Za-z]+),", text, flags=re.M))
+    return impls
+
+
+def test_rust_operator_table_is_complete():
+    """Every operator of INTEGRATION.md section 2.3 has an `impl Operator for Hip<Op>` in bindings/rten-hip/src/ops.rs, `accelerate` wraps
+    exactly those, every wrap! target is a defined struct with a `run`, and INTEGRATION.md names every one of them."""
+    text = open(OPS_RS).read()
+    impls = _ops_rs_defined_operators(text)
+    assert impls == {"Hip" + n for n in RUST_OPERATORS}, sorted(impls ^ {"Hip" + n for n in RUST_OPERATORS})
+    wraps = re.findall(r"wrap!\(ops::([A-Za-z]+), (Hip[A-Za-z]+),", text)
+    assert sorted(w[0] for w in wraps) == sorted(RUST_OPERATORS)
+    for ref_op, hip_op in wraps:
+        assert hip_op == "Hip" + ref_op and hip_op in impls
+    # struct definitions: hip_operator!(... HipX { .. }) directly or inside the three macros
+    structs = set(re.findall(r"^\s*(Hip[A-Za-z]+) \{", text, flags=re.M)) | set(re.findall(r"^hip_(?:unary|binary|pool)!\((Hip[A-Za-z]+),", text, flags=re.M))
+    assert impls <= structs, sorted(impls - structs)
+    assert "a comment where" not in text and "follow the three shapes above" not in text  # the round-3 placeholder is gone
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for n in RUST_OPERATORS:
+        assert f"`{n}`" in integ, n
+    assert "set_operator_rewriter" in integ and "set_operator_rewriter" in text
+
+
+def test_rust_ops_call_only_declared_abi_symbols_with_the_declared_arity():
+    """Every `sys::rten_hip_*` call in the safe layer names a function of the generated -sys crate and passes as many arguments as it declares;
+    every `sys::RTEN_HIP_*` constant and `sys::rten_hip_*_desc` struct exists there."""
+    sys_text = open(RS_PATH).read()
+    decl = {}
+    for m in re.finditer(r"pub fn (rten_hip_[a-z0-9_]+)\((.*?)\)(?: -> [a-z0-9_*: ]+)?;", sys_text):
+        decl[m.group(1)] = len([a for a in m.group(2).split(",") if a.strip()])
+    consts = set(re.findall(r"pub const (RTEN_HIP_[A-Z0-9_]+):", sys_text))
+    structs = set(re.findall(r"pub struct (rten_hip_[a-z0-9_]+)", sys_text))
+    for path in (OPS_RS, os.path.join(ROOT, "bindings", "rten-hip", "src", "lib.rs")):
+        text = open(path).read()
+        text = re.sub(r"//[^\n]*", "", text)
+        for m in re.finditer(r"sys::(\$entry|\$flat|rten_hip_[a-z0-9_]+|RTEN_HIP_[A-Z0-9_]+)", text):
+            name = m.group(1)
+            if name.startswith("$"):
+                continue  # macro parameter: the instantiations are checked below
+            if name.startswith("RTEN_HIP_"):
+                assert name in consts, name
+                continue
+            rest = text[m.end():]
+            if not rest.lstrip().startswith("("):
+                assert name in structs or name in decl or name in ("rten_hip_ctx", "rten_hip_comm"), name
+                continue
+            assert name in decl, f"{name} is not declared by rten-hip-sys"
+            # count top-level commas of the call
+            depth, n_args, i, seen = 0, 0, rest.index("("), False
+            for ch in rest[i:]:
+                if ch in "([{":
+                    depth += 1
+                elif ch in ")]}":
+                    depth -= 1
+                    if depth == 0:
+                        break
+                elif ch == "," and depth == 1:
+                    n_args += 1
+                elif depth >= 1 and not ch.isspace():
+                    seen = True
+            n_args = n_args + 1 if seen else 0
+            assert n_args == decl[name], (name, n_args, decl[name])
+        for entry in re.findall(r"^hip_(?:unary|binary|pool)!\(Hip[A-Za-z]+, (rten_hip_[a-z0-9_]+)", text, flags=re.M):
+            assert entry in decl, entry
+
+
+def test_rust_ops_repeat_the_reference_error_messages():
+    """The messages the reference's tests assert (conv.rs / matmul.rs / pooling.rs / attention.rs) are spelled identically in the Rust layer,
+    the C++ layer and the Python layer."""
+    rs = open(OPS_RS).read()
+    cpp = open(os.path.join(ROOT, "include", "rten_hip_ops.hpp")).read()
+    py = open(os.path.join(ROOT, "rten_amd", "ops.py")).read()
+    for msg in ["input zero point must be a scalar", "Zero point has incorrect size", "Only scalar or vector zero points are supported",
+                "scale should be a scalar", "Input channels (per group) does not match kernel input channels", "Group count must be > 0",
+                "Columns of first matrix does not match rows of second matrix", "kernel_size len does not match spatial dims",
+                "Cannot broadcast c to output shape"]:
+        assert msg in rs, msg
+        assert msg in cpp or msg in py, msg
