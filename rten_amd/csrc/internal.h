@@ -46,7 +46,8 @@ struct rten_hip_ctx {
     size_t aux_bytes = 0;
     std::map<std::string, void *> luts; // im2col lookup tables, keyed by conv geometry (gemm_f32.hip)
     int gemm_variant_override = -1;
-    int pipeline = 1; // conv paths: 0 register-staged, 1 LDS-DMA, 2 LDS-DMA + wave specialisation
+    int pipeline = 1; // conv paths: 0 register-staged, 1 LDS-DMA, 2 LDS-DMA + wave specialisation, 3 four stages, 4 fragments first, 5 16x16x4 MFMAs, 6 one wave per 64x64 tile (gemm_f32_wave.hip)
+    int wave_flavour = 0; // pipeline 6: 0 = k-tiles of 16 x 2 LDS stages, 1 = 8 x 4, 2 = 16 x 3
     int num_cus = 256;
     int sdpa_path = 0;  // 0 automatic (fused attention kernel when it covers the shape), 1 composed path only
     int int8_path = 0;  // 0 automatic (fast staging path when it covers the call), 1 generic kernel only
@@ -77,6 +78,8 @@ int32_t rten_gemv_f32(rten_hip_ctx *ctx, const rten_hip_gemm_desc *d, const floa
 // gemm_f32.hip: rten_hip_gemm_f32 without the gemv dispatch (operators whose reference form is not a gemm_impl call on unpacked operands)
 int32_t rten_gemm_f32_blocked(rten_hip_ctx *ctx, const rten_hip_gemm_desc *d, const float *a, const float *b, const float *bias, float *c);
 void *rten_aux_scratch(rten_hip_ctx *ctx, size_t bytes);
+// gemm_f32_wave.hip: one launch of the wave-tile kernels; `args` = the caller's GemmArgs (gemm_f32_common.h)
+int32_t rten_launch_gemm_f32_wave(rten_hip_ctx *ctx, const void *args, unsigned grid_x, unsigned grid_z, int bl, int mode, int flavour);
 
 // Profiling bracket around one kernel launch.
 struct ProfScope {

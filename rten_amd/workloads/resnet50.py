@@ -301,7 +301,7 @@ class ResNet50:
         plans = [(v, 0, 1, o) for v in range(nvar) for o in (0, 1)]
         d = self.descs[l["name"]]
         nblk = (d.c // d.groups * d.kh * d.kw + 255) // 256
-        dma = [v for v in range(nvar) if not 4 <= v < 12]  # LDS-DMA pipelines (3 / 4 stages, fragments-first, 16x16x4 MFMAs)
+        dma = [v for v in range(nvar) if not 4 <= v < 12]  # LDS-DMA pipelines (3 / 4 stages, fragments-first, 16x16x4 MFMAs, one wave per tile)
         # thin-tile tail (mode 4): whole rounds with this tile shape + the remaining columns as 16x64 tiles on 16x16x4 MFMAs
         plans += [(v, 4, 1, o) for v in dma for o in (0, 1)]
         # persistent plan (mode 5): num_cus x groups workgroups walk the tile list, tile DMA runs across tile boundaries
@@ -309,7 +309,7 @@ class ResNet50:
         # lean persistent kernel (mode 6; 64x64 tiles, K % 32 == 0): groups = workgroups per compute unit
         plans += [(3, 6, r, o) for r in (1, 2, 3) for o in (0, 1)]
         if nblk > 1:
-            for v in [v for v in range(nvar) if not (8 <= v < 12 or v >= 20)]:  # the wave-specialised and 16x16x4 kernels have no split form
+            for v in [v for v in range(nvar) if not (8 <= v < 12 or 20 <= v < 24)]:  # the wave-specialised and 16x16x4 kernels have no split form
                 for groups in sorted({2, 3, 4, 6, nblk} & set(range(2, nblk + 1))):
                     plans.append((v, 1, groups, 0))
                     for o in (0, 2, 3):

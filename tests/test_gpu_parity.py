@@ -409,7 +409,7 @@ def test_conv_f32_resnet_layer_shapes_all_variants(ctx, shape):
         bits_equal(gpu_conv(ctx, x, w, b, (pad,) * 4, (s, s), relu=True, variant=v), want)
     try:
         ctx.call("rten_hip_set_gemm_order", 1)  # tiles walk n fastest
-        for v in (0, 3, 7, 11):
+        for v in (0, 3, 7, 11, 24, 25):
             bits_equal(gpu_conv(ctx, x, w, b, (pad,) * 4, (s, s), relu=True, variant=v), want)
     finally:
         ctx.call("rten_hip_set_gemm_order", 0)
@@ -431,11 +431,11 @@ def test_conv_f32_split_k_bit_exact(ctx, shape):
     want = ref.conv2d_f32(x, w, b, pads=(pad,) * 4, strides=(s, s), residual=res, relu=True)
     nblk = (Cc * k * k + 255) // 256
     try:
-        for v in range(4):
+        for v in (0, 1, 2, 3, 24, 25, 26):  # 24..26: one wave per 64x64 tile (gemm_f32_wave.hip)
             for mode in (1, 2):
                 for groups in sorted({2, 3, nblk}):
                     ctx.call("rten_hip_set_gemm_split", mode, groups)
-                    for order in ((0, 1, 2, 3) if v == 3 else (0, 3)):  # workgroup -> tile orders
+                    for order in ((0, 1, 2, 3) if v in (3, 24) else (0, 3)):  # workgroup -> tile orders
                         ctx.call("rten_hip_set_gemm_order", order)
                         bits_equal(gpu_conv(ctx, x, w, b, (pad,) * 4, (s, s), residual=res, relu=True, variant=v), want)
                     ctx.call("rten_hip_set_gemm_order", 0)
@@ -455,7 +455,7 @@ def test_conv_f32_grouped_split_k_bit_exact(ctx):
     b = rng.f32(96) - 0.5
     want = ref.conv2d_f32(x, w, b, pads=(1, 1, 1, 1), groups=2, relu=True)
     try:
-        for v in (3, 7, 1):
+        for v in (3, 7, 1, 24):
             for mode, groups in ((0, 1), (2, 2), (2, 3), (1, 3)):
                 ctx.call("rten_hip_set_gemm_split", mode, groups)
                 bits_equal(gpu_conv(ctx, x, w, b, (1, 1, 1, 1), (1, 1), (1, 1), 2, relu=True, variant=v), want)

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(64) void kloop_wave(const float *src, const i32x2 *
     for (int s = 0; s < NST - 1; s++) { fetch_lut(s); issue(s, s); }
     fetch_lut(NST - 1);
     int stage = 0;
-    const unsigned long long t0 = __builtin_readcyclecounter();
+    const unsigned long long t0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int kt = 0; kt < iters; kt++) {
         wait_vmcnt<PER_TILE *(NST - 2)>(); // tile kt has landed; NST-2 younger tiles stay in flight.  No barrier: the ring is this wave's own.
         const int sp = stage == 0 ? NST - 1 : stage - 1;
@@ -124,9 +124,9 @@ __global__ __launch_bounds__(64) void kloop_wave(const float *src, const i32x2 *
         else __builtin_amdgcn_iglp_opt(0);
         stage = stage == NST - 1 ? 0 : stage + 1;
     }
-    const unsigned long long t1 = __builtin_readcyclecounter();
+    const unsigned long long t1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
     wait_vmcnt<0>();
-    if (lane == 0) clocks[blockIdx.x] = t1 - t0;
+    if (lane == 0) { clocks[blockIdx.x] = t1 - t0; clocks[gridDim.x + blockIdx.x] = r1 - r0; }
     float keep = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; i++)
@@ -157,13 +157,14 @@ void run(const char *name, const float *src, const i32x2 *lut, float *sink, unsi
         hipEventSynchronize(e1);
         float ms = 0.f;
         hipEventElapsedTime(&ms, e0, e1);
-        std::vector<unsigned long long> h((size_t)grid);
+        std::vector<unsigned long long> h((size_t)grid * 2);
         hipMemcpy(h.data(), clocks, h.size() * 8, hipMemcpyDeviceToHost);
-        double cyc = 0;
-        for (auto c : h) cyc += (double)c;
+        double cyc = 0, rt = 0;
+        for (int i = 0; i < grid; i++) { cyc += (double)h[i]; rt += (double)h[grid + i]; }
         const double flops = (double)grid * iters * (BKW / 2) * 4 * 2.0 * 32 * 32 * 2;
-        printf("%-52s %2d waves/CU: %7.1f cycles per 16 k per wave (2048 = matrix pipe alone)  %6.1f TFLOP/s\n", name, per_cu, cyc / grid / iters * 16.0 / BKW,
-               flops / (ms * 1e-3) / 1e12);
+        // s_memtime vs s_memrealtime (100 MHz): which clock do "cycles" count, and how fast does the shader clock really run under this load?
+        printf("%-52s %2d waves/CU: %7.1f s_memtime ticks per 16 k per wave (2048 = matrix pipe alone)  %6.1f TFLOP/s  | s_memtime runs at %.1f MHz; loop wall %.0f us of kernel %.0f us\n",
+               name, per_cu, cyc / grid / iters * 16.0 / BKW, flops / (ms * 1e-3) / 1e12, cyc / rt * 100.0, rt / grid / 100.0, ms * 1e3);
         fflush(stdout);
     }
 }
@@ -179,7 +180,7 @@ int main() {
     hipMalloc(&src, src_bytes);
     hipMemset(src, 0x3c, src_bytes);
     hipMalloc(&sink, 16);
-    hipMalloc(&clocks, (size_t)cus * 16 * 8);
+    hipMalloc(&clocks, (size_t)cus * 16 * 8 * 2);
     std::vector<i32x2> hl(64 * 16);
     for (size_t i = 0; i < hl.size(); i++) hl[i] = i32x2{(int)((i * 40503u) % 200000u), 31 - (int)(i % 9)};
     hipMalloc(&lut, hl.size() * sizeof(i32x2));
