@@ -240,13 +240,78 @@ def secondary_configs():
             if key == "resnet50_int8_b32":
                 res[key] = {k: j[k] for k in ("metric", "value", "unit", "ms_per_step", "p50_latency_ms", "dtype", "config", "roofline", "cpu_baseline") if k in j}
                 continue
-            res[key] = {k: j[k] for k in ("metric", "value", "unit", "ms_per_step", "p50_latency_ms", "ms_per_step_back_to_back", "dtype") if k in j}
-            if key.startswith("bert") and "roofline" in j:
-                res[key]["gemm_family_tflops"] = j["roofline"].get("achieved")
-                res[key]["gemm_family_frac_of_f32_mfma_peak"] = j["roofline"].get("frac")
+            res[key] = {k: j[k] for k in ("metric", "value", "unit", "ms_per_step", "p50_latency_ms", "ms_per_step_back_to_back", "dtype", "config", "roofline", "cpu_baseline") if k in j}
         except Exception as e:  # noqa: BLE001
             res[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
     return res
+
+
+def run_via_executor(args):
+    """`--via-executor`: the SAME workload through the product path a Rust host would use -- the C++ plan executor behind the C ABI
+    (rten_hip_model_*: ONNX bytes in, values resident in HBM, the committed launch plan, sub-batch chains, hipGraph replay) -- instead of the
+    hand-planned Python runner.  One GPU.  The line has the same fields; `config.path` says which path ran, `ranks.logits_sha16_per_rank` is
+    comparable with the runner's (same weights, same inputs -> same bits)."""
+    import hashlib
+    from rten_amd import lib, onnx_writer
+    from rten_amd.tensor import DeviceTensor
+    from rten_amd.workloads import resnet50
+    int8 = args.config == "int8"
+    ctx = lib.Context(0)
+    weights = resnet50.make_weights()
+    chains = 1 if int8 else (4 if args.chains is None else args.chains)
+    onnx_bytes = onnx_writer.resnet50_int8(weights) if int8 else onnx_writer.resnet50_f32(weights)
+    plan_path = args.load_plan or os.path.join(ROOT, "profiles", "plans", f"f32_{chains}chain{'s' if chains > 1 else ''}.json")
+    plan_text = None if (int8 or args.no_autotune or not os.path.exists(plan_path)) else open(plan_path).read()
+    model = lib.Model(ctx, onnx_bytes, plan_text, chains)
+    xptr = model.bind_input("x", (BATCH_PER_GPU, 3, 224, 224))
+    model.prepare(tune=bool(args.autotune and not plan_text))
+    x = np.random.default_rng(1234).random((BATCH_PER_GPU, 3, 224, 224), dtype=np.float32)
+    xt = DeviceTensor(ctx, x.shape, np.float32, ptr=xptr, keepalive=model)
+    xt.upload(x)
+    ctx.sync()
+    for _ in range(args.warmup):
+        model.run()
+    model.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.run()
+    model.sync()
+    elapsed = time.perf_counter() - t0
+    optr, oshape = model.output(0)
+    logits = DeviceTensor(ctx, oshape, np.float32, ptr=optr, keepalive=model).numpy()
+    lat = []
+    for _ in range(min(args.steps, 20)):
+        t1 = time.perf_counter()
+        model.run()
+        model.sync()
+        lat.append((time.perf_counter() - t1) * 1e3)
+    step_ms = elapsed / args.steps * 1e3
+    gflop = (resnet50.conv_flops_per_image() + 2 * 2048 * 1000) / 1e9
+    step_tf = gflop * BATCH_PER_GPU / step_ms
+    if int8:
+        roof = {"bound": "mfma", "achieved": round(step_tf, 2), "peak": I8_MATRIX_PEAK_TOPS, "unit": "TOP/s", "frac": round(step_tf / I8_MATRIX_PEAK_TOPS, 4), "traffic": None,
+                "what": "integer ops of one batch over the timed step (the per-kernel / HBM tables belong to `python bench.py --config int8`)"}
+    else:
+        roof = {"bound": "mfma", "achieved": round(step_tf, 3), "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(step_tf / F32_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
+                "what": "2*M*N*K of every convolution / classifier launch of one batch over the TIMED step, through the C++ executor (same definition as the runner's line)"}
+    out = {"metric": f"inferences/sec, ResNet-50 {'int8 (dynamically quantized)' if int8 else 'f32'} batch 32 per GPU", "value": round(BATCH_PER_GPU * args.steps / elapsed, 2),
+           "unit": "inferences/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_ms, 4), "p50_latency_ms": round(float(np.median(lat)), 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 x i8 -> i32 (f32 between layers)" if int8 else "f32", "data": "synthetic",
+           "config": {"workload": f"ResNet-50 v1.5 {'dynamically quantized int8' if int8 else 'f32'} inference, 224x224, batch 32 (BASELINE configs[{2 if int8 else 1}]) from an ONNX file "
+                                  "(rten_amd.onnx_writer), synthetic He-normal BN-folded weights (seed 1234), inputs U[0,1) resident in HBM",
+                      "path": "C++ plan executor behind the C ABI (rten_hip_model_load / _prepare / _run: include/rten_hip_graph.hpp + csrc/graph_abi.cpp) -- the path a Rust host binds",
+                      "global_batch": BATCH_PER_GPU, "launch": "hipGraph replay", "batch_chains": {"chains": chains},
+                      "launch_plan": {"source": os.path.relpath(plan_path, ROOT) if plan_text else ("tuned at load" if args.autotune else "backend defaults"),
+                                      "sha16": hashlib.sha256(json.dumps(json.loads(plan_text), sort_keys=True).encode()).hexdigest()[:16] if plan_text else None,
+                                      "steps_planned": model.planned_steps, "steps": model.num_steps},
+                      "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "gflop_per_image": round(gflop, 3), "device": ctx.device_info()},
+           "ranks": {"world_size": 1, "logits_sha16_per_rank": [hashlib.sha256(np.ascontiguousarray(logits).tobytes()).hexdigest()[:16]], "input_seed_per_rank": [1234]},
+           "roofline": roof}
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_int8(resnet50.conv_specs(), weights) if int8 else cpu_baseline(resnet50.conv_specs(), weights)
+    print(json.dumps(out))
+    model.close()
+    return 0
 
 
 def spawn_ranks(n, argv):
@@ -286,6 +351,9 @@ def main():
                     help="f32: run the batch as this many independent sub-batch chains on their own streams (default 4; 1 = one chain). "
                          "The int8 graph quantizes each activation over the whole batch, so it always runs as one chain")
     ap.add_argument("--concurrent", action="store_true", help="run the projection shortcuts on a second stream (parallel graph branches)")
+    ap.add_argument("--via-executor", action="store_true",
+                    help="run the workload through the C++ plan executor behind the C ABI (rten_hip_model_*: ONNX file in, committed launch plan, chains, hipGraph "
+                         "replay) -- the product path a Rust host binds -- instead of the Python runner; one GPU")
     args = ap.parse_args()
 
     # ---- launch contract: N ranks, one per GPU.  Under a launcher (the driver's torch.distributed.run) WORLD_SIZE must
@@ -299,6 +367,11 @@ def main():
     if args.chains is not None and not 1 <= args.chains <= 8:
         print("bench.py: --chains must be 1..8", file=sys.stderr)
         return 2
+    if args.via_executor:
+        if args.gpus != 1 or "WORLD_SIZE" in os.environ:
+            print("bench.py: --via-executor is a single-GPU measurement", file=sys.stderr)
+            return 2
+        return run_via_executor(args)
     under_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ
     if not under_launcher and args.gpus > 1:
         return spawn_ranks(args.gpus, sys.argv[1:])
@@ -481,15 +554,21 @@ def main():
     #      definition of a sharded run (each shard == an independent reference run on that shard) -- and every rank ran the
     #      same launch plan.  tests/test_gpu_multirank.py checks both against the oracle.
     logits_sha = hashlib.sha256(np.ascontiguousarray(net.logits.numpy()).tobytes()).hexdigest()[:16]
-    shard_report = [(rank, logits_sha, plan_sha)]
+    # the plan that actually RAN on this rank (after warm-up an int8 edge whose quantized-output launch did not fit falls back to the two-launch form):
+    # hashed per rank, compared below -- a rank that ran other kernels than rank 0 is reported, not assumed away
+    effective = export_plan() if plan is not None else None
+    effective_sha = hashlib.sha256(json.dumps(effective, sort_keys=True).encode()).hexdigest()[:16] if effective is not None else None
+    shard_report = [(rank, logits_sha, effective_sha)]
     if dist is not None:
         box = [None] * world
         dist.all_gather_object(box, shard_report[0])
         shard_report = sorted(box)
 
-    if int8 and net.qout_timeouts():
-        print("bench.py: a quantized-output launch gave up waiting for its grid (workgroups not all resident): results are void", file=sys.stderr)
-        return 3
+    def check_qout(where):
+        if int8 and net.qout_timeouts():
+            print(f"bench.py: a quantized-output launch gave up waiting for its grid (workgroups not all resident) {where}: results are void", file=sys.stderr)
+            sys.exit(3)
+    check_qout("during the timed steps")
 
     # ---- p50 latency per batch (separate pass, host-timed per step)
     lat = []
@@ -499,6 +578,7 @@ def main():
         ctx.sync()
         lat.append((time.perf_counter() - t1) * 1e3)
     p50 = float(np.median(lat))
+    check_qout("during the latency pass")
 
     # ---- PCIe-inclusive rate (the reference's Model::run takes host tensors): the same K steps with the batch uploaded
     #      from host memory and the logits downloaded every step.  Reported beside `value`, never as `value`.
@@ -511,6 +591,7 @@ def main():
             net.logits.numpy()
         pcie_ms = (time.perf_counter() - t1) / min(args.steps, 20) * 1e3
 
+    check_qout("during the PCIe-inclusive pass")
     # ---- roofline of the dominant kernel: instrumented eager pass over the same K steps (HIP events per launch
     #      on the backend's stream).  Kept out of the timed region so `value` is not perturbed.
     roof = None
@@ -624,7 +705,7 @@ def main():
             "config": {"workload": workload,
                        "global_batch": global_batch, "parallelism": f"batch-shard x{n_gpus} (weights RCCL-broadcast once)" if n_gpus > 1 else "single GPU",
                        "launch": "eager" if args.no_graph else "hipGraph replay", "autotuned_tiles": bool(net.variants),
-                       "launch_plan": {"source": plan_source, "sha16": plan_sha, "identical_on_all_ranks": True},
+                       "launch_plan": {"source": plan_source, "sha16": plan_sha, "identical_on_all_ranks": len({r[2] for r in shard_report}) == 1},
                        "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "shortcut_branch": "second stream" if net.concurrent else "main stream",
                        "batch_chains": {"chains": chains, "sub_batches": getattr(net, "sizes", [BATCH_PER_GPU]), "placement": getattr(net, "place", [0]),
                                         "placement_ms": [["".join(str(x) for x in pl), round(ms, 3)] for pl, ms in placement] if placement else None,

@@ -48,7 +48,11 @@
 extern "C" {
 #endif
 
-#define RTEN_HIP_ABI_VERSION 2
+/* v3 (round 4): + rten_hip_model_* (the plan executor behind the C ABI), rten_hip_set_gemm_order bits 4-6 (occupancy cap),
+ * GEMM variants 24-26 (one wave per tile), sticky device fault reported by rten_hip_sync / rten_hip_graph_launch.  v2 (round 3) had added
+ * rten_hip_graph_abort, rten_hip_conv2d_int8_qout, rten_hip_grid_sync_*, rten_hip_dynamic_quantize_linear_staged_products, rten_hip_max_pool2d_f32_stats and
+ * rten_hip_set_sdpa_path mode 2 WITHOUT a bump: a binding built against this header must refuse a library whose rten_hip_abi_version() differs. */
+#define RTEN_HIP_ABI_VERSION 3
 
 /* ---- status codes (map onto OpError variants, src/operator.rs:116-144) ---- */
 #define RTEN_HIP_OK 0
@@ -65,9 +69,14 @@ typedef struct rten_hip_ctx rten_hip_ctx;
 /* Create a context on `device_id`.  `external_stream` may be NULL (the context creates its own
  * stream) or a hipStream_t owned by the caller (e.g. torch's current stream). */
 int32_t rten_hip_init(int32_t device_id, void *external_stream, rten_hip_ctx **out_ctx);
+/* Destroys the context.  Same-thread rule: a context with an ACTIVE graph capture (rten_hip_graph_begin without _end / _abort) can only be destroyed
+ * by the thread that began the capture (the capture is aborted first); from any other thread the call returns RTEN_HIP_ERR_INVALID_VALUE and destroys
+ * nothing -- end or abort the capture on its own thread, then destroy (a Rust `Drop` that may run anywhere must do the same). */
 int32_t rten_hip_destroy(rten_hip_ctx *ctx);
 const char *rten_hip_last_error(rten_hip_ctx *ctx);
 int32_t rten_hip_abi_version(void);
+/* Waits for the context's stream.  Also reports the context's sticky device fault (a kernel that had to give up -- see rten_hip_conv2d_int8_qout):
+ * RTEN_HIP_ERR_HIP on every call until rten_hip_grid_sync_reset. */
 int32_t rten_hip_sync(rten_hip_ctx *ctx);
 /* Device properties used by the measurement harness. */
 int32_t rten_hip_device_info(rten_hip_ctx *ctx, char *name_buf, int32_t name_len, int32_t *compute_units,
@@ -305,7 +314,10 @@ int32_t rten_hip_conv2d_int8_dql(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_d
  * before the call; it receives the output's statistics as there); `sync` is a device buffer of rten_hip_grid_sync_bytes(), initialised
  * ONCE with rten_hip_grid_sync_reset when allocated -- every launch leaves it in that state.  The launch needs all its workgroups resident at once and nothing else running on the device's compute units:
  * RTEN_HIP_ERR_UNSUPPORTED when the grid does not fit (or the geometry is not covered) -> run the two-launch sequence.  A launch that
- * nevertheless waits longer than ~0.5 s for its grid gives up and sets the block's time-out flag (rten_hip_grid_sync_timeouts). */
+ * nevertheless waits longer than ~0.5 s for its grid (the device was shared with other work) gives up LOUDLY: it sets the block's time-out flag
+ * (rten_hip_grid_sync_timeouts), stores NaN as `next_scale` / `product` -- statistics that miss a workgroup never become plausible codes: every value
+ * downstream is NaN -- and raises the context's sticky fault: rten_hip_sync and rten_hip_graph_launch fail with RTEN_HIP_ERR_HIP from then on, until
+ * rten_hip_grid_sync_reset (which also clears the fault).  A library-level executor keeps this launch form opt-in (launch plan), never a default. */
 size_t rten_hip_grid_sync_bytes(void);
 int32_t rten_hip_grid_sync_reset(rten_hip_ctx *ctx, void *sync, int32_t count /* consecutive blocks */);
 int32_t rten_hip_conv2d_int8_qout(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *desc, const void *x, const void *w,
@@ -450,6 +462,32 @@ int32_t rten_hip_broadcast(rten_hip_ctx *ctx, rten_hip_comm *comm, void *buf, si
 int32_t rten_hip_comm_world_size(rten_hip_comm *comm, int32_t *world_size, int32_t *rank);
 int32_t rten_hip_comm_destroy(rten_hip_ctx *ctx, rten_hip_comm *comm);
 
+/* ---- the plan executor behind the C ABI (new; the host-side analogue is Model::load + Model::run, src/model.rs:235-550, for ONE resident subgraph) ----
+ * An ONNX graph (bytes of a ModelProto) compiled into a static plan whose every value stays in HBM: constants uploaded and conv weights prepacked once,
+ * the fusions of optimize/fusions.rs:1012-1058 applied, per-layer launch plan from a plan file (profiles/plans/[*].json: {step: [variant, split mode,
+ * K groups, order]}, optionally keyed by sub-batch size) or tuned at prepare time, the batch run as `chains` independent dim-0 slices on their own
+ * streams, each captured into a hipGraph.  This is what lets a Rust host keep activations on the device WITHOUT a new `Value` variant: a maximal run
+ * of accelerated nodes becomes one `Operator` that owns an rten_hip_model (precedent: SubgraphOperator, src/operator.rs:630-646).
+ * ("model", not "graph": rten_hip_graph_* above is the hipGraph capture of a context's stream.)
+ *   load -> bind_input (each input's full-batch shape; returns the device pointer the caller writes the input to) -> prepare -> { run, sync, output }*
+ * Errors: the usual status codes; rten_hip_model_last_error has the text.  Not thread-safe per model object (one caller at a time). */
+typedef struct rten_hip_model rten_hip_model;
+int32_t rten_hip_model_load(rten_hip_ctx *ctx, const void *onnx_bytes, size_t onnx_len, const char *plan_json /* optional */, int32_t chains,
+                            int32_t device_id, rten_hip_model **out_model);
+const char *rten_hip_model_last_error(const rten_hip_model *model);
+int32_t rten_hip_model_info(const rten_hip_model *model, int32_t *n_inputs, int32_t *n_outputs, int32_t *n_steps, int32_t *n_planned_steps);
+const char *rten_hip_model_input_name(const rten_hip_model *model, int32_t i);
+const char *rten_hip_model_output_name(const rten_hip_model *model, int32_t i);
+int32_t rten_hip_model_bind_input(rten_hip_model *model, int32_t i, const int64_t *shape, int32_t ndim, void **dev_ptr);
+/* tune != 0 and no plan file: every f32 convolution step times its candidate launch plans once per distinct sub-batch size. */
+int32_t rten_hip_model_prepare(rten_hip_model *model, int32_t tune);
+/* flags bit 0: the inputs were written on the caller context's stream since the last run (the chains wait for it first); bit 1: do not order the
+ * caller's stream after the chains (the caller calls rten_hip_model_sync before reading the outputs). */
+int32_t rten_hip_model_run(rten_hip_model *model, uint32_t flags);
+int32_t rten_hip_model_sync(rten_hip_model *model);
+int32_t rten_hip_model_output(rten_hip_model *model, int32_t i, const void **dev_ptr, int64_t *shape /* 8 entries */, int32_t *ndim);
+int32_t rten_hip_model_destroy(rten_hip_model *model);
+
 /* ---- tuning: per-shape kernel-variant selection by measurement at load time ----
  * variant < 0 restores the built-in heuristic.  Used by the harness's autotuner. */
 int32_t rten_hip_set_gemm_variant_override(rten_hip_ctx *ctx, int32_t variant);
@@ -468,7 +506,8 @@ int32_t rten_hip_num_gemm_variants(void);
 int32_t rten_hip_set_gemm_split(rten_hip_ctx *ctx, int32_t mode, int32_t groups);
 /* Workgroup -> tile order (tuning knob, sticky, default 0): bit 0 = tiles walk n fastest instead of m fastest;
  * bit 1 = split-K workgroups walk tiles fastest and K groups slowest, so that each XCD's private L2 holds one K
- * slice of both operands. */
+ * slice of both operands; bits 4-6 = occupancy cap of the LDS-DMA kernels (workgroups per compute unit, 2..7; 0 = whatever fits:
+ * the launch is padded with dynamic LDS it never touches). */
 int32_t rten_hip_set_gemm_order(rten_hip_ctx *ctx, int32_t order);
 /* int8 kernels: 0 = automatic (operands staged chunk-major / padded channel-blocked + 16-byte LDS-DMA MFMA kernel whenever it
  * covers the call), 1 = generic byte-gather kernel only.  Both produce the reference's bits. */

@@ -299,6 +299,10 @@ class Graph {
 
     Graph(Context &ctx, const onnx::Model &m, Options opt) : ctx_(ctx), opt_(opt) { compile(m); }
     Graph(Context &ctx, const onnx::Model &m) : Graph(ctx, m, Options()) {}
+    // A second plan over the SAME model that shares `donor`'s device constants and prepacked weights instead of uploading its own (the sub-batch
+    // chains of one model: four copies of a 100 MB weight set would also compete for the same L2 / MALL lines).  `donor` must outlive this graph
+    // and live on the same device; both must have been built with the same options.
+    Graph(Context &ctx, const onnx::Model &m, Options opt, const Graph &donor) : ctx_(ctx), opt_(opt), donor_(&donor) { compile(m); }
     // the node list after the load-time canonicalisation of exporter idioms (Constant nodes, GeluFusion, LayerNormalizationFusion): needs no device
     static onnx::Model canonical_form(const onnx::Model &m) { return canonicalize(m); }
 
@@ -331,10 +335,34 @@ class Graph {
         return tuned_;
     }
 
+    // A committed launch plan instead of timing at load ({conv step name: GemmPlan}, profiles/plans/*.json: tuned once on an MI355X so that
+    // every process -- and every rank of a sharded deployment -- launches the same kernels).  Steps the table does not name keep the
+    // backend's automatic plan.  Returns the number of steps that took an entry.
+    size_t apply_plan(const std::map<std::string, GemmPlan> &table) {
+        size_t n = 0;
+        for (auto &st : steps_) {
+            if (!st.conv) continue;
+            auto it = table.find(st.name);
+            if (it == table.end()) continue;
+            st.conv->plan = it->second;
+            n++;
+        }
+        return n;
+    }
+    std::map<std::string, GemmPlan> plans() const { // what autotune() / apply_plan() left on the convolution steps
+        std::map<std::string, GemmPlan> t;
+        for (auto &st : steps_) if (st.conv && st.conv->plan.set) t[st.name] = st.conv->plan;
+        return t;
+    }
+    bool captured() const { return graph_ != 0; }
+    const std::vector<Tensor> &captured_outputs() const { return captured_outputs_; }
+
     // hipGraph capture of one run (launch-bound at small batch: ~60 operators of 5-50 us).  The feeds and the returned
     // outputs keep their device addresses: write new inputs into the same feed tensors, call replay(), read the outputs.
     // While a capture is alive the context's buffer pool must not serve anyone else (the graph's intermediates live there).
-    const std::vector<Tensor> &capture(const Feeds &feeds) {
+    // `tail` (optional) runs at the end of the captured region, on the capturing stream, with the run's outputs: work recorded there -- e.g. the
+    // copy of a sub-batch's rows into a resident full-batch tensor -- replays with the graph.
+    const std::vector<Tensor> &capture(const Feeds &feeds, const std::function<void(const std::vector<Tensor> &)> &tail = nullptr) {
         run(feeds); // warm: every buffer size is in the pool, scratch is grown, code objects are loaded
         ctx_.sync();
         if (graph_) { // re-capture: the previous executable graph is released first
@@ -344,6 +372,7 @@ class Graph {
         ctx_.check(rten_hip_graph_begin(ctx_.raw()));
         try {
             captured_outputs_ = run(feeds);
+            if (tail) tail(captured_outputs_);
         } catch (...) { // leave the stream (and the context's lock) out of capture mode before the error propagates
             uint64_t dead = 0;
             if (rten_hip_graph_end(ctx_.raw(), &dead) == RTEN_HIP_OK && dead) rten_hip_graph_destroy(ctx_.raw(), dead);
@@ -447,6 +476,22 @@ class Graph {
     std::map<std::string, int> ids_;
     std::map<int, Tensor> consts_;
     std::vector<std::unique_ptr<Tensor>> packed_; // prepacked conv weights
+    std::map<std::string, const Tensor *> packed_of_; // step name -> its prepacked operand (what a sharing graph looks up)
+    const Graph *donor_ = nullptr;
+    // a constant of this graph: uploaded here, or a non-owning view of the donor's
+    void add_const(int id, const std::function<Tensor()> &make) {
+        if (donor_) { const Tensor &d = donor_->consts_.at(id); consts_.emplace(id, Tensor::view_of(d, d.shape())); }
+        else consts_.emplace(id, make());
+    }
+    // the prepacked operand of step `name`: packed here, or the donor's
+    const Tensor *packed_for(const std::string &name, const std::function<Tensor()> &pack) {
+        if (donor_) { auto it = donor_->packed_of_.find(name); return it == donor_->packed_of_.end() ? nullptr : it->second; }
+        Tensor pk = pack();
+        if (!pk.len()) return nullptr;
+        packed_.emplace_back(new Tensor(std::move(pk)));
+        packed_of_[name] = packed_.back().get();
+        return packed_.back().get();
+    }
     std::vector<Step> steps_;
     std::vector<int> uses_;
     std::vector<onnx::ValueInfo> inputs_, outputs_;
@@ -793,7 +838,7 @@ class Graph {
         const onnx::Model &m = m_canonical;
         inputs_ = m.inputs;
         outputs_ = m.outputs;
-        for (auto &t : m.initializers) consts_.emplace(id_of(t.name), upload(t));
+        for (auto &t : m.initializers) add_const(id_of(t.name), [&] { return upload(t); });
         for (auto &in : m.inputs) id_of(in.name);
 
         const size_t N = m.nodes.size();
@@ -945,8 +990,8 @@ class Graph {
                         for (const std::string *bn : {&lq.b, &lk.b, &lv.b}) { const std::vector<float> hb = consts_.at(ids_.at(*bn)).to_host<float>(); bcat.insert(bcat.end(), hb.begin(), hb.end()); }
                         at.wqkv = id_of("__qkv_w." + std::to_string(i));
                         at.bqkv = id_of("__qkv_b." + std::to_string(i));
-                        consts_.emplace(at.wqkv, Tensor::from_host<float>(ctx_, {K, 3 * Nn}, wcat.data()));
-                        consts_.emplace(at.bqkv, Tensor::from_host<float>(ctx_, {3 * Nn}, bcat.data()));
+                        add_const(at.wqkv, [&] { return Tensor::from_host<float>(ctx_, {K, 3 * Nn}, wcat.data()); });
+                        add_const(at.bqkv, [&] { return Tensor::from_host<float>(ctx_, {3 * Nn}, bcat.data()); });
                         at.merged = true; at.x = lq.x; at.hidden = Nn;
                         for (long d : {lq.mm, lq.add, lk.mm, lk.add, lv.mm, lv.add}) nodes.push_back((size_t)d);
                     }
@@ -1023,10 +1068,7 @@ class Graph {
                 const Tensor *packed = nullptr;
                 if (opt_.prepack && is_const(n.inputs.at(1)) && op->groups == 1) {
                     const Tensor &w = consts_.at(ids_.at(n.inputs[1]));
-                    if (w.ndim() == 4) {
-                        packed_.emplace_back(new Tensor(op->prepack(ctx_, w)));
-                        packed = packed_.back().get();
-                    }
+                    if (w.ndim() == 4) packed = packed_for(n.name.empty() ? n.outputs.at(0) : n.name, [&] { return op->prepack(ctx_, w); });
                 }
                 st.kind_name = std::string("Conv") + (residual.empty() ? "" : "+Add") + (op->fuse_relu ? "+Relu" : "");
                 st.conv = op;
@@ -1113,10 +1155,7 @@ class Graph {
                 state->to_float = !scale.empty();
                 if (opt_.prepack && is_const(n.inputs.at(1)) && op->conv.groups == 1) {
                     const Tensor &w = consts_.at(ids_.at(n.inputs[1]));
-                    if (w.ndim() == 4) {
-                        packed_.emplace_back(new Tensor(op->prepack(ctx_, w)));
-                        state->sg.packed_weight = packed_.back().get();
-                    }
+                    if (w.ndim() == 4) state->sg.packed_weight = packed_for(n.name.empty() ? n.outputs.at(0) : n.name, [&] { return op->prepack(ctx_, w); });
                 }
                 st.i8 = state;
                 // ConvIntegerToFloatFusion (fusions.rs:1012-1058) fuses only a scale of shape [] or [1] and leaves every other graph
@@ -1169,8 +1208,7 @@ class Graph {
                 const Tensor *packed = nullptr;
                 if (opt_.prepack && is_const(n.inputs.at(1))) {
                     const Tensor &w = consts_.at(ids_.at(n.inputs.at(1)));
-                    Tensor pk = op->prepack(ctx_, w);
-                    if (pk.len()) { packed_.emplace_back(new Tensor(std::move(pk))); packed = packed_.back().get(); }
+                    packed = packed_for(n.name.empty() ? n.outputs.at(0) : n.name, [&] { return op->prepack(ctx_, w); });
                 }
                 // MatMulIntegerToFloatFusion (fusions.rs:960-1009) needs a scale of rank <= 1; the operator then needs length 1 or N.
                 // Decided per run (shapes are run-time facts); otherwise MatMulInteger -> Cast -> Mul as the graph spells it.

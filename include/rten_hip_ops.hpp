@@ -53,7 +53,12 @@ class Context {
         if (rc == RTEN_HIP_ERR_NO_DEVICE) throw OpError(OpError::BackendUnavailable, "no usable gfx950 (MI355X) device: the HIP backend has no CPU fallback");
         if (rc != RTEN_HIP_OK) throw OpError(OpError::Hip, "rten_hip_init failed");
     }
-    ~Context() { if (h_) { trim_pool(); if (one_) rten_hip_free(h_, one_); rten_hip_destroy(h_); } }
+    // Borrows a context created elsewhere (a C-ABI caller's): same stream, same lock; never destroyed here.
+    struct Borrow {};
+    Context(rten_hip_ctx *borrowed, Borrow) : h_(borrowed), owned_(false) {
+        if (!borrowed) throw OpError(OpError::InvalidValue, "null context");
+    }
+    ~Context() { if (h_) { trim_pool(); if (one_) rten_hip_free(h_, one_); if (owned_) rten_hip_destroy(h_); } }
     Context(const Context &) = delete;
     Context &operator=(const Context &) = delete;
     rten_hip_ctx *raw() const { return h_; }
@@ -105,6 +110,7 @@ class Context {
 
   private:
     rten_hip_ctx *h_ = nullptr;
+    bool owned_ = true;
     bool pool_on_ = false;
     void *one_ = nullptr;
     std::map<size_t, std::vector<void *>> pool_;
@@ -133,6 +139,12 @@ class Tensor {
     static Tensor view_of(const Tensor &base, std::vector<int64_t> shape) {
         Tensor t;
         t.ctx_ = base.ctx_; t.ptr_ = base.ptr_; t.shape_ = std::move(shape); t.dtype_ = base.dtype_; t.owns_ = false;
+        return t;
+    }
+    // Non-owning alias of `bytes_off` bytes into `base` (a sub-batch slice of a resident full-batch buffer).
+    static Tensor view_at(const Tensor &base, size_t bytes_off, std::vector<int64_t> shape) {
+        Tensor t = view_of(base, std::move(shape));
+        t.ptr_ = (char *)base.ptr_ + bytes_off;
         return t;
     }
     template <typename T>

@@ -137,11 +137,35 @@ RTEN_EXPORT int32_t rten_hip_init(int32_t device_id, void *external_stream, rten
     // arrival counters of the split-K producers (gemm_f32.hip, split_finish): zeroed ON THE CONTEXT'S STREAM -- stream order puts the
     // memset before any producer that can arrive on them -- and left zero by every launch.  (No null-stream memset + device-wide
     // synchronise: creating a context must not stall the other contexts' work, nor break a capture active on this thread.)
-    if (hipMalloc((void **)&ctx->split_counters, rten_hip_ctx::kSplitCounters * sizeof(unsigned)) != hipSuccess ||
-        hipMemsetAsync(ctx->split_counters, 0, rten_hip_ctx::kSplitCounters * sizeof(unsigned), ctx->stream) != hipSuccess) {
-        if (ctx->split_counters) hipFree(ctx->split_counters);
+    // A caller-provided stream that is CAPTURING would record that memset into the caller's graph instead of executing it (hipMalloc memory
+    // is not zeroed: eager split-K launches would then find garbage counters): such a stream gets a blocking memset on the null stream with
+    // this thread's capture mode relaxed for the duration.
+    if (hipMalloc((void **)&ctx->split_counters, rten_hip_ctx::kSplitCounters * sizeof(unsigned)) == hipSuccess) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        const bool capturing = external_stream && hipStreamIsCapturing(ctx->stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+        hipError_t e;
+        if (capturing) {
+            hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+            (void)hipThreadExchangeStreamCaptureMode(&mode);
+            e = hipMemset(ctx->split_counters, 0, rten_hip_ctx::kSplitCounters * sizeof(unsigned));
+            (void)hipThreadExchangeStreamCaptureMode(&mode);
+        } else {
+            e = hipMemsetAsync(ctx->split_counters, 0, rten_hip_ctx::kSplitCounters * sizeof(unsigned), ctx->stream);
+        }
+        if (e != hipSuccess) { hipFree(ctx->split_counters); ctx->split_counters = nullptr; }
+    } else {
         ctx->split_counters = nullptr; // the fixup-kernel path needs none
     }
+    (void)hipGetLastError();
+    // sticky fault word: pinned, mapped; the device writes it only when a kernel gives up
+    unsigned *fh = nullptr;
+    if (hipHostMalloc((void **)&fh, 64, hipHostMallocMapped) == hipSuccess) {
+        *fh = 0u;
+        void *fd = nullptr;
+        if (hipHostGetDevicePointer(&fd, fh, 0) == hipSuccess) { ctx->fault_host = fh; ctx->fault_dev = (unsigned *)fd; }
+        else hipHostFree(fh);
+    }
+    (void)hipGetLastError();
     *out_ctx = ctx;
     return RTEN_HIP_OK;
 }
@@ -149,8 +173,19 @@ RTEN_EXPORT int32_t rten_hip_init(int32_t device_id, void *external_stream, rten
 RTEN_EXPORT int32_t rten_hip_destroy(rten_hip_ctx *ctx) {
     if (!ctx) return RTEN_HIP_OK;
     hipSetDevice(ctx->device);
-    if (ctx->capturing && ctx->capture_locks > 0) rten_hip_graph_abort(ctx); // a capture nobody ended: never delete a locked mutex
+    // A capture nobody ended: the capture lock belongs to the thread that called rten_hip_graph_begin.  On that thread the capture is
+    // aborted here (never delete a locked mutex); from any other thread -- a Rust `Drop` may run anywhere -- taking the lock would block
+    // forever and releasing it would be undefined behaviour, so the context is refused (and leaked by a caller that ignores the status)
+    // rather than deadlocked: end or abort the capture on its own thread first.
+    if (ctx->capturing && ctx->capture_locks > 0) {
+        if (ctx->capture_thread != std::this_thread::get_id()) {
+            fprintf(stderr, "rten_hip_destroy: context %p is capturing on another thread; not destroyed\n", (void *)ctx);
+            return RTEN_HIP_ERR_INVALID_VALUE;
+        }
+        rten_hip_graph_abort(ctx);
+    }
     hipStreamSynchronize(ctx->stream);
+    if (ctx->fault_host) hipHostFree((void *)ctx->fault_host);
     for (auto &kv : ctx->prof)
         for (auto &p : kv.second.pending) {
             hipEventDestroy(p.first);
@@ -172,10 +207,18 @@ RTEN_EXPORT int32_t rten_hip_destroy(rten_hip_ctx *ctx) {
 
 RTEN_EXPORT const char *rten_hip_last_error(rten_hip_ctx *ctx) { return ctx ? tls_last_error.c_str() : "null context"; }
 
+int32_t rten_check_fault(rten_hip_ctx *ctx) {
+    if (ctx->fault_host && *ctx->fault_host)
+        return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "a quantized-output launch gave up waiting for its grid (workgroups not all resident: the device was shared "
+                                                      "with other work): every result since is void (NaN scale written); rten_hip_grid_sync_reset clears the fault (code %u)",
+                              (unsigned)*ctx->fault_host);
+    return RTEN_HIP_OK;
+}
+
 RTEN_EXPORT int32_t rten_hip_sync(rten_hip_ctx *ctx) {
     RTEN_CHECK_CTX(ctx);
     RTEN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return RTEN_HIP_OK;
+    return rten_check_fault(ctx); // sticky: a kernel that gave up is reported by every sync until the fault is reset
 }
 
 RTEN_EXPORT int32_t rten_hip_device_info(rten_hip_ctx *ctx, char *name_buf, int32_t name_len, int32_t *compute_units,
@@ -267,6 +310,7 @@ RTEN_EXPORT int32_t rten_hip_graph_begin(rten_hip_ctx *ctx) {
     if (ctx->capturing) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "graph capture already active");
     RTEN_HIP_TRY(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
     ctx->capturing = true;
+    ctx->capture_thread = std::this_thread::get_id();
     // the capturing thread keeps the context until rten_hip_graph_end: launches of other host threads must not be
     // recorded into this graph (they block on the mutex instead)
     ctx->mu.lock();
@@ -340,6 +384,7 @@ RTEN_EXPORT int32_t rten_hip_stream_wait(rten_hip_ctx *waiter, rten_hip_ctx *sig
 RTEN_EXPORT int32_t rten_hip_graph_launch(rten_hip_ctx *ctx, uint64_t graph) {
     RTEN_CHECK_CTX(ctx);
     if (!graph) return RTEN_HIP_ERR_INVALID_VALUE;
+    if (const int32_t rc = rten_check_fault(ctx)) return rc;
     RTEN_HIP_TRY(ctx, hipGraphLaunch((hipGraphExec_t)(uintptr_t)graph, ctx->stream));
     return RTEN_HIP_OK;
 }

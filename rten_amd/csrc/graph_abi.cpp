@@ -1,0 +1,343 @@
+// The plan executor (include/rten_hip_graph.hpp: ONNX in, every value resident in HBM, fused steps, committed launch plan, hipGraph replay,
+// independent sub-batch chains) behind the C ABI: rten_hip_model_load / _bind / _prepare / _run / _output / _destroy.
+//
+// Why it is in the library: a Rust host cannot keep values on the device between operators without a `Value::Device` variant (a change to the
+// reference's `Value`, src/value.rs:487).  It CAN wrap a maximal run of accelerated nodes as ONE `Operator` that owns a graph -- the reference's own
+// `SubgraphOperator` (src/operator.rs:630-646) is the precedent -- and for that it needs the executor through `extern "C"`, not a C++ header
+// (`HipSubgraph`).  `bench.py --via-executor` times exactly this path, so the measured path is the product path.
+//
+// What a graph object owns: `chains` contexts (one stream each, GPU_MAX_HW_QUEUES permitting one hardware queue each), one compiled
+// rten_hip::Graph per chain (constants uploaded and prepacked per chain), the resident full-batch input / output buffers (a chain works on its
+// dim-0 slice in place) and one captured hipGraph per chain.
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/rten_hip_graph.hpp"
+
+#define RTEN_EXPORT extern "C" __attribute__((visibility("default")))
+
+using namespace rten_hip;
+
+namespace {
+
+// ---- the launch-plan files of profiles/plans/ are JSON objects of {step name: [variant, split mode, K groups, tile order]}, optionally one level
+// deeper keyed by sub-batch size ({"8": {...}}).  A reader for exactly that subset (objects, arrays, strings, integers).
+struct PlanJson {
+    const char *p, *e;
+    std::string err;
+    void ws() { while (p < e && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) p++; }
+    bool lit(char c) { ws(); if (p < e && *p == c) { p++; return true; } return false; }
+    bool str(std::string &out) {
+        ws();
+        if (p >= e || *p != '"') return false;
+        p++;
+        out.clear();
+        while (p < e && *p != '"') { if (*p == '\\' && p + 1 < e) p++; out.push_back(*p++); }
+        if (p >= e) return false;
+        p++;
+        return true;
+    }
+    bool integer(long long &v) {
+        ws();
+        const char *s = p;
+        if (p < e && (*p == '-' || *p == '+')) p++;
+        while (p < e && *p >= '0' && *p <= '9') p++;
+        if (p == s) return false;
+        v = std::strtoll(std::string(s, p).c_str(), nullptr, 10);
+        return true;
+    }
+    // {name: [ints]} -> table; nested objects are returned under their key
+    bool object(std::map<std::string, std::vector<long long>> &leaves, std::map<std::string, std::map<std::string, std::vector<long long>>> &nested) {
+        if (!lit('{')) return false;
+        if (lit('}')) return true;
+        do {
+            std::string key;
+            if (!str(key) || !lit(':')) return false;
+            ws();
+            if (p < e && *p == '{') {
+                std::map<std::string, std::map<std::string, std::vector<long long>>> deeper;
+                if (!object(nested[key], deeper)) return false;
+            } else if (p < e && *p == '[') {
+                p++;
+                std::vector<long long> v;
+                if (!lit(']')) {
+                    do {
+                        long long x;
+                        std::string sname;
+                        ws();
+                        if (p < e && *p == '"') { if (!str(sname)) return false; v.push_back(0); } // (lists of names: the int8 plan's edge lists; skipped here)
+                        else if (!integer(x)) return false;
+                        else v.push_back(x);
+                    } while (lit(','));
+                    if (!lit(']')) return false;
+                }
+                leaves[key] = v;
+            } else {
+                return false;
+            }
+        } while (lit(','));
+        return lit('}');
+    }
+};
+
+std::map<std::string, GemmPlan> plan_table(const std::map<std::string, std::vector<long long>> &leaves) {
+    std::map<std::string, GemmPlan> t;
+    for (auto &kv : leaves) {
+        if (kv.second.size() < 3) continue;
+        GemmPlan g;
+        g.set = true;
+        g.variant = (int)kv.second[0];
+        g.mode = (int)kv.second[1];
+        g.groups = (int)kv.second[2];
+        g.order = kv.second.size() > 3 ? (int)kv.second[3] : 0;
+        t[kv.first] = g;
+    }
+    return t;
+}
+
+DType elem_dtype(int32_t onnx_type) {
+    switch (onnx_type) {
+    case onnx::FLOAT: return DType::F32;
+    case onnx::INT32: case onnx::INT64: return DType::I32;
+    case onnx::UINT8: return DType::U8;
+    default: return DType::I8;
+    }
+}
+
+} // namespace
+
+struct rten_hip_model {
+    rten_hip_ctx *caller = nullptr; // the caller's context: its stream is ordered before / after a run, errors are reported on it
+    int chains = 1;
+    std::vector<std::unique_ptr<Context>> ctxs;
+    std::vector<std::unique_ptr<Graph>> graphs;
+    std::vector<onnx::ValueInfo> inputs, outputs;
+    std::map<std::string, std::vector<long long>> plan_flat;
+    std::map<std::string, std::map<std::string, std::vector<long long>>> plan_by_batch;
+    bool have_plan = false;
+    // bound state
+    std::vector<std::unique_ptr<Tensor>> full_in, full_out; // resident full-batch buffers (owned by ctxs[0])
+    std::vector<std::vector<Tensor>> chain_in;              // [chain][input]: dim-0 slices of full_in
+    std::vector<std::vector<int64_t>> out_shape;
+    std::vector<int64_t> sub, start;                        // sub-batch sizes / first rows
+    size_t planned_steps = 0, tuned_steps = 0;
+    bool prepared = false;
+    std::string last_error;
+};
+
+namespace {
+int32_t fail(rten_hip_model *g, int32_t code, const std::string &msg) {
+    if (g) g->last_error = msg;
+    return code;
+}
+int32_t code_of(const OpError &e) {
+    switch (e.kind) {
+    case OpError::InvalidValue: return RTEN_HIP_ERR_INVALID_VALUE;
+    case OpError::IncompatibleInputShapes: return RTEN_HIP_ERR_INCOMPATIBLE_SHAPES;
+    case OpError::UnsupportedValue: case OpError::UnsupportedType: return RTEN_HIP_ERR_UNSUPPORTED;
+    case OpError::BackendUnavailable: return RTEN_HIP_ERR_NO_DEVICE;
+    default: return RTEN_HIP_ERR_HIP;
+    }
+}
+} // namespace
+
+// Parses `onnx` (the bytes of an ONNX ModelProto), compiles it `chains` times (constants uploaded, conv weights prepacked, fusions applied) and
+// records the launch plan.  `plan_json`: NULL (the backend's automatic plans, or rten_hip_model_prepare(tune = 1)) or the text of a plan file.
+RTEN_EXPORT int32_t rten_hip_model_load(rten_hip_ctx *ctx, const void *onnx_bytes, size_t onnx_len, const char *plan_json, int32_t chains, int32_t device_id,
+                                        rten_hip_model **out_graph) {
+    if (!out_graph) return RTEN_HIP_ERR_INVALID_VALUE;
+    *out_graph = nullptr;
+    if (!ctx || !onnx_bytes || !onnx_len || chains < 1 || chains > 16) return RTEN_HIP_ERR_INVALID_VALUE;
+    std::unique_ptr<rten_hip_model> g(new rten_hip_model());
+    g->caller = ctx;
+    g->chains = chains;
+    try {
+        const onnx::Model m = onnx::parse((const uint8_t *)onnx_bytes, onnx_len);
+        if (plan_json && *plan_json) {
+            PlanJson pj{plan_json, plan_json + std::strlen(plan_json), {}};
+            if (!pj.object(g->plan_flat, g->plan_by_batch)) { delete g.release(); return RTEN_HIP_ERR_INVALID_VALUE; }
+            g->have_plan = true;
+        }
+        for (int c = 0; c < chains; c++) {
+            // chain 0 runs on the CALLER's context (its stream): a model with N chains owns N - 1 streams.  One stream more than chains costs real
+            // time on this runtime -- streams map onto hardware queues, and a fifth active stream collides with one of the four chains
+            // (measured: 3.80 ms with an idle caller stream + 4 chain streams, 2.7 ms with 4 streams in all; profiles/r07/executor_vs_runner.txt)
+            if (c == 0) g->ctxs.emplace_back(new Context(ctx, Context::Borrow()));
+            else g->ctxs.emplace_back(new Context(device_id));
+            g->ctxs.back()->enable_pool(true);
+            // chains 1.. share chain 0's device constants and prepacked weights (one copy of the weight set per model, as in the Python runner's arena)
+            if (c == 0) g->graphs.emplace_back(new Graph(*g->ctxs.back(), m));
+            else g->graphs.emplace_back(new Graph(*g->ctxs.back(), m, Graph::Options(), *g->graphs[0]));
+        }
+        g->inputs = g->graphs[0]->inputs();
+        g->outputs = g->graphs[0]->outputs();
+    } catch (const onnx::ParseError &e) {
+        return RTEN_HIP_ERR_INVALID_VALUE;
+    } catch (const OpError &e) {
+        return code_of(e);
+    } catch (const std::exception &e) {
+        return RTEN_HIP_ERR_INVALID_VALUE;
+    }
+    *out_graph = g.release();
+    return RTEN_HIP_OK;
+}
+
+RTEN_EXPORT const char *rten_hip_model_last_error(const rten_hip_model *g) { return g ? g->last_error.c_str() : "null graph"; }
+
+// Counts and names: n_inputs / n_outputs / plan steps (how many convolution steps took an entry of the plan file, after _prepare) / total steps.
+RTEN_EXPORT int32_t rten_hip_model_info(const rten_hip_model *g, int32_t *n_inputs, int32_t *n_outputs, int32_t *n_steps, int32_t *n_planned_steps) {
+    if (!g) return RTEN_HIP_ERR_INVALID_VALUE;
+    if (n_inputs) *n_inputs = (int32_t)g->inputs.size();
+    if (n_outputs) *n_outputs = (int32_t)g->outputs.size();
+    if (n_steps) *n_steps = (int32_t)g->graphs[0]->num_steps();
+    if (n_planned_steps) *n_planned_steps = (int32_t)(g->planned_steps + g->tuned_steps);
+    return RTEN_HIP_OK;
+}
+RTEN_EXPORT const char *rten_hip_model_input_name(const rten_hip_model *g, int32_t i) { return (g && i >= 0 && (size_t)i < g->inputs.size()) ? g->inputs[(size_t)i].name.c_str() : nullptr; }
+RTEN_EXPORT const char *rten_hip_model_output_name(const rten_hip_model *g, int32_t i) { return (g && i >= 0 && (size_t)i < g->outputs.size()) ? g->outputs[(size_t)i].name.c_str() : nullptr; }
+
+// Declares input `i`'s FULL-batch shape (dim 0 = batch, split over the chains) and allocates its resident buffer; `*dev_ptr` is where the caller
+// writes the input (device memory, valid until _destroy).
+RTEN_EXPORT int32_t rten_hip_model_bind_input(rten_hip_model *g, int32_t i, const int64_t *shape, int32_t ndim, void **dev_ptr) {
+    if (!g || i < 0 || (size_t)i >= g->inputs.size() || !shape || ndim < 1 || ndim > 8) return RTEN_HIP_ERR_INVALID_VALUE;
+    if (g->prepared) return fail(g, RTEN_HIP_ERR_INVALID_VALUE, "bind_input after prepare");
+    try {
+        const int64_t batch = shape[0];
+        if (batch < g->chains) return fail(g, RTEN_HIP_ERR_INVALID_VALUE, "fewer rows than chains");
+        if (g->sub.empty()) {
+            const int64_t q = batch / g->chains, r = batch % g->chains;
+            int64_t at = 0;
+            for (int c = 0; c < g->chains; c++) { g->sub.push_back(q + (c < r ? 1 : 0)); g->start.push_back(at); at += g->sub.back(); }
+        } else if (g->sub.size() && g->start.back() + g->sub.back() != batch) {
+            return fail(g, RTEN_HIP_ERR_INCOMPATIBLE_SHAPES, "every input must have the same dim 0 (the batch the chains split)");
+        }
+        if (g->full_in.size() < g->inputs.size()) { g->full_in.resize(g->inputs.size()); g->chain_in.resize((size_t)g->chains); for (auto &v : g->chain_in) v.resize(g->inputs.size()); }
+        std::vector<int64_t> full(shape, shape + ndim);
+        const DType dt = elem_dtype(g->inputs[(size_t)i].elem_type);
+        g->full_in[(size_t)i].reset(new Tensor(*g->ctxs[0], full, dt));
+        int64_t row = 1;
+        for (int d = 1; d < ndim; d++) row *= shape[d];
+        for (int c = 0; c < g->chains; c++) {
+            std::vector<int64_t> s = full;
+            s[0] = g->sub[(size_t)c];
+            g->chain_in[(size_t)c][(size_t)i] = Tensor::view_at(*g->full_in[(size_t)i], (size_t)(g->start[(size_t)c] * row) * dtype_size(dt), s);
+        }
+        if (dev_ptr) *dev_ptr = g->full_in[(size_t)i]->ptr();
+    } catch (const OpError &e) {
+        return fail(g, code_of(e), e.msg);
+    }
+    return RTEN_HIP_OK;
+}
+
+// Applies the launch plan (or, with tune != 0 and no plan file, times the candidates once per distinct sub-batch size), runs every chain once
+// (buffer pool and scratch reach their steady state) and captures each chain into a hipGraph.
+RTEN_EXPORT int32_t rten_hip_model_prepare(rten_hip_model *g, int32_t tune) {
+    if (!g) return RTEN_HIP_ERR_INVALID_VALUE;
+    if (g->full_in.size() != g->inputs.size()) return fail(g, RTEN_HIP_ERR_INVALID_VALUE, "prepare: bind every input first");
+    for (auto &t : g->full_in) if (!t) return fail(g, RTEN_HIP_ERR_INVALID_VALUE, "prepare: bind every input first");
+    try {
+        std::map<int64_t, std::map<std::string, GemmPlan>> tuned; // per sub-batch size
+        g->full_out.clear();
+        g->out_shape.clear();
+        for (int c = 0; c < g->chains; c++) {
+            Graph &gr = *g->graphs[(size_t)c];
+            Context &cx = *g->ctxs[(size_t)c];
+            Graph::Feeds feeds;
+            for (size_t i = 0; i < g->inputs.size(); i++) feeds.emplace_back(g->inputs[i].name, &g->chain_in[(size_t)c][i]);
+            const int64_t b = g->sub[(size_t)c];
+            if (g->have_plan) {
+                auto it = g->plan_by_batch.find(std::to_string(b));
+                const size_t n = gr.apply_plan(plan_table(it != g->plan_by_batch.end() ? it->second : g->plan_flat));
+                if (c == 0) g->planned_steps = n;
+            } else if (tune) {
+                if (!tuned.count(b)) { const size_t n = gr.autotune(feeds); tuned[b] = gr.plans(); if (c == 0) g->tuned_steps = n; }
+                else gr.apply_plan(tuned[b]);
+            }
+            if (c == 0) { // resident full-batch outputs, shaped from chain 0's (un-captured) first run
+                const std::vector<Tensor> probe = gr.run(feeds);
+                for (size_t o = 0; o < probe.size(); o++) {
+                    std::vector<int64_t> s = probe[o].shape();
+                    if (s.empty()) return fail(g, RTEN_HIP_ERR_UNSUPPORTED, "a scalar graph output cannot be split over chains");
+                    s[0] = g->start.back() + g->sub.back();
+                    g->out_shape.push_back(s);
+                    g->full_out.emplace_back(new Tensor(*g->ctxs[0], s, probe[o].dtype()));
+                }
+                cx.sync();
+            }
+            // a chain's rows go into the resident full-batch outputs INSIDE its captured graph (logits-sized copies): a run is then `chains` graph
+            // launches and nothing else
+            gr.capture(feeds, [&](const std::vector<Tensor> &outs) {
+                if (getenv("RTEN_MODEL_NO_GATHER")) return; // (diagnostic: timing without the output copies; the outputs are then not assembled)
+                for (size_t o = 0; o < outs.size(); o++) {
+                    int64_t row = 1;
+                    for (size_t d = 1; d < g->out_shape[o].size(); d++) row *= g->out_shape[o][d];
+                    const size_t off = (size_t)(g->start[(size_t)c] * row) * dtype_size(outs[o].dtype());
+                    if (outs[o].bytes()) cx.check(rten_hip_memcpy_d2d(cx.raw(), (char *)g->full_out[o]->ptr() + off, outs[o].ptr(), outs[o].bytes()));
+                }
+            });
+        }
+        for (auto &c : g->ctxs) c->sync();
+        g->prepared = true;
+    } catch (const OpError &e) {
+        return fail(g, code_of(e), e.msg);
+    } catch (const std::exception &e) {
+        return fail(g, RTEN_HIP_ERR_INVALID_VALUE, e.what());
+    }
+    return RTEN_HIP_OK;
+}
+
+// One inference over the bound inputs.  flags bit 0: the inputs were written on the CALLER's stream since the last run (the chains then wait for
+// that stream first; leave it clear when the inputs are already resident and visible).  On return the caller's stream is ordered after every chain,
+// unless bit 1 is set (the caller synchronises the model itself before reading: back-to-back runs then never touch the caller's stream).
+RTEN_EXPORT int32_t rten_hip_model_run(rten_hip_model *g, uint32_t flags) {
+    if (!g || !g->prepared) return RTEN_HIP_ERR_INVALID_VALUE;
+    try {
+        for (int c = 0; c < g->chains; c++) {
+            Context &cx = *g->ctxs[(size_t)c];
+            if ((flags & 1u) && c > 0) cx.check(rten_hip_stream_wait(cx.raw(), g->caller));
+            g->graphs[(size_t)c]->replay();
+        }
+        if (!(flags & 2u)) // bit 1: the caller will rten_hip_model_sync before it reads the outputs: no per-run event wait on its stream
+            for (int c = 1; c < g->chains; c++) // (chain 0 IS the caller's stream)
+                if (rten_hip_stream_wait(g->caller, g->ctxs[(size_t)c]->raw()) != RTEN_HIP_OK) return fail(g, RTEN_HIP_ERR_HIP, "stream_wait failed");
+    } catch (const OpError &e) {
+        return fail(g, code_of(e), e.msg);
+    } catch (const std::exception &e) {
+        return fail(g, RTEN_HIP_ERR_INVALID_VALUE, e.what());
+    }
+    return RTEN_HIP_OK;
+}
+
+// Waits for every chain (and reports a sticky device fault of any of them).
+RTEN_EXPORT int32_t rten_hip_model_sync(rten_hip_model *g) {
+    if (!g) return RTEN_HIP_ERR_INVALID_VALUE;
+    for (auto &c : g->ctxs) {
+        const int32_t rc = rten_hip_sync(c->raw());
+        if (rc) return fail(g, rc, rten_hip_last_error(c->raw()));
+    }
+    return RTEN_HIP_OK;
+}
+
+// Output `i` after a run: device pointer of the resident full-batch tensor, its shape (up to 8 dims) and rank.
+RTEN_EXPORT int32_t rten_hip_model_output(rten_hip_model *g, int32_t i, const void **dev_ptr, int64_t *shape, int32_t *ndim) {
+    if (!g || !g->prepared || i < 0 || (size_t)i >= g->full_out.size()) return RTEN_HIP_ERR_INVALID_VALUE;
+    if (dev_ptr) *dev_ptr = g->full_out[(size_t)i]->ptr();
+    if (ndim) *ndim = (int32_t)g->out_shape[(size_t)i].size();
+    if (shape) for (size_t d = 0; d < g->out_shape[(size_t)i].size() && d < 8; d++) shape[d] = g->out_shape[(size_t)i][d];
+    return RTEN_HIP_OK;
+}
+
+RTEN_EXPORT int32_t rten_hip_model_destroy(rten_hip_model *g) {
+    if (!g) return RTEN_HIP_OK;
+    for (auto &c : g->ctxs) rten_hip_sync(c->raw());
+    g->chain_in.clear();
+    g->full_in.clear();
+    g->full_out.clear();
+    while (!g->graphs.empty()) g->graphs.pop_back(); // sharers before the donor (chain 0), graphs before their contexts
+    g->ctxs.clear();
+    delete g;
+    return RTEN_HIP_OK;
+}

@@ -71,6 +71,7 @@ struct FastArgs {
     // QO kernels (the DynamicQuantizeLinear that CONSUMES this convolution's output runs in its epilogue, behind a grid-wide min / max):
     // the barrier block, the consumer's staged image and its geometry, the quantizer's own outputs
     unsigned *sync;
+    unsigned *fault; // the context's sticky fault word (host-mapped): written only when a grid-wide wait gives up
     uint8_t *q_out;
     float *q_scale_out;
     uint8_t *q_zp_out;
@@ -879,8 +880,15 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
                 ga = fminf(ga, dql::ord2f((unsigned)v)); gb = fmaxf(gb, dql::ord2f((unsigned)(v >> 32)));
             }
             if (__syncthreads_and(ok)) break;
-            if (++spins >= kSyncSpinLimit) { // not every workgroup is resident (or a previous launch timed out): give up, loudly
-                if (t == 0) __hip_atomic_store(p.sync + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (++spins >= kSyncSpinLimit) { // not every workgroup is resident (or a previous launch timed out): give up, LOUDLY --
+                // the block's time-out flag, the context's sticky fault word (the next rten_hip_sync / graph_launch fails) and a NaN scale for the
+                // consumer (below): statistics that miss a workgroup must never turn into plausible codes
+                if (t == 0) {
+                    __hip_atomic_store(p.sync + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (p.fault) __hip_atomic_store(p.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    *p.q_scale_out = __builtin_nanf("");
+                    if (p.q_mul_by) *p.q_product = __builtin_nanf("");
+                }
                 break;
             }
             __builtin_amdgcn_s_sleep(4);
@@ -904,9 +912,11 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
         for (int wv = 1; wv < 4 * KG; wv++) { g_mn = fminf(g_mn, gred[16 + wv]); g_mx = fmaxf(g_mx, gred[32 + wv]); }
         const dql::QParams q = dql::dql_params(g_mn, g_mx);
         if (t == 0 && blockIdx.x == 0) {
-            *p.q_scale_out = q.scale;
+            // (a workgroup that timed out -- before or after this store -- leaves NaN here: whoever gives up first has set the flag)
+            const bool void_run = __hip_atomic_load(p.sync + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+            *p.q_scale_out = void_run ? __builtin_nanf("") : q.scale;
             *p.q_zp_out = (uint8_t)q.zp;
-            if (p.q_mul_by) *p.q_product = q.scale * p.q_mul_by[0]; // the Mul(x_scale, w_scale) node of the consumer
+            if (p.q_mul_by) *p.q_product = void_run ? __builtin_nanf("") : q.scale * p.q_mul_by[0]; // the Mul(x_scale, w_scale) node of the consumer
         }
         // ---- (3) codes -> the consumer's staged image [N][C/16][Hp][Wp][16 B] (signed domain).  A lane holds, per 32-row block, four
         // dwords of four consecutive channels each: rows 0-3, 8-11, 16-19, 24-27 (+4 in the upper half of the wave); two
@@ -1442,6 +1452,7 @@ int32_t i8_fast_conv_impl(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di
     if (qo) {
         const ConvGeom ng = conv_geom(qo->next);
         g.sync = (unsigned *)qo->sync;
+        g.fault = ctx->fault_dev;
         g.q_out = (uint8_t *)qo->staged;
         g.q_scale_out = qo->scale; g.q_zp_out = qo->zp; g.q_mul_by = qo->mul_by; g.q_product = qo->product;
         g.q_cb = ng.Cp / 16; g.q_Hp = ng.Hp; g.q_Wp = ng.Wp; g.q_pt = qo->next->conv.pads[0]; g.q_pl = qo->next->conv.pads[1];
@@ -1498,6 +1509,10 @@ RTEN_EXPORT int32_t rten_hip_grid_sync_reset(rten_hip_ctx *ctx, void *sync, int3
     const long long n = (long long)count * kSyncWords;
     hipLaunchKernelGGL(grid_sync_reset_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (unsigned *)sync, count);
     RTEN_LAUNCH_CHECK(ctx, "grid_sync_reset_kernel launch");
+    if (ctx->fault_host) { // the caller starts over: the context's sticky fault goes with the blocks' flags (after what is in flight has drained)
+        RTEN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        *ctx->fault_host = 0u;
+    }
     return RTEN_HIP_OK;
 }
 

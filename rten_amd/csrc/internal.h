@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -27,6 +28,7 @@ struct rten_hip_ctx {
     // the duration of the call; recursive because entry points call each other (conv -> gemm, graph capture holds it).
     std::recursive_mutex mu;
     int capture_locks = 0; // times rten_hip_graph_begin locked `mu` on behalf of the capturing thread
+    std::thread::id capture_thread; // the thread that owns those locks (only it may end / abort the capture)
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -57,6 +59,11 @@ struct rten_hip_ctx {
     long long gemv_threads = 0;  // reference thread count assumed for its column blocks (0: at least n / 128)
     static constexpr long long kSplitCounters = 1 << 16;
     unsigned *split_counters = nullptr; // arrival counters of the split-K producers (zero between launches), allocated with the context
+    // Sticky device-fault word (pinned host memory mapped into the device): a kernel that has to give up -- today: a quantized-output launch whose
+    // grid-wide exchange timed out because its workgroups were not all resident (int8_fast.hip) -- stores a non-zero code here; the next
+    // rten_hip_sync / rten_hip_graph_launch on the context fails with it until rten_hip_grid_sync_reset clears it.  Reading it costs the host nothing.
+    volatile unsigned *fault_host = nullptr;
+    unsigned *fault_dev = nullptr;
     int debug = 0; // RTEN_HIP_DEBUG ablation bits (tuning only)
 };
 
@@ -73,6 +80,8 @@ inline int rten_effective_pad_mode(const rten_hip_conv2d_int8_desc *di) {
 int32_t rten_set_error(rten_hip_ctx *ctx, int32_t code, const char *fmt, ...);
 int32_t rten_check_hip(rten_hip_ctx *ctx, hipError_t e, const char *what);
 void *rten_scratch(rten_hip_ctx *ctx, size_t bytes);
+// non-zero: the context's sticky device fault as an error (see rten_hip_ctx::fault_host)
+int32_t rten_check_fault(rten_hip_ctx *ctx);
 // gemv_f32.hip: the m == 1 product in the reference's gemv order (called by rten_hip_gemm_f32)
 int32_t rten_gemv_f32(rten_hip_ctx *ctx, const rten_hip_gemm_desc *d, const float *a, const float *b, const float *bias, float *c);
 // gemm_f32.hip: rten_hip_gemm_f32 without the gemv dispatch (operators whose reference form is not a gemm_impl call on unpacked operands)

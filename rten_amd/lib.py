@@ -180,6 +180,18 @@ PROTOTYPES = {
     "rten_hip_set_gemm_order": (_I32, [_VP, _I32]),
     "rten_hip_set_int8_path": (_I32, [_VP, _I32]),
     "rten_hip_set_sdpa_path": (_I32, [_VP, _I32]),
+    # the plan executor behind the C ABI (csrc/graph_abi.cpp)
+    "rten_hip_model_load": (_I32, [_VP, _VP, _SZ, C.c_char_p, _I32, _I32, C.POINTER(_VP)]),
+    "rten_hip_model_last_error": (C.c_char_p, [_VP]),
+    "rten_hip_model_info": (_I32, [_VP, C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32)]),
+    "rten_hip_model_input_name": (C.c_char_p, [_VP, _I32]),
+    "rten_hip_model_output_name": (C.c_char_p, [_VP, _I32]),
+    "rten_hip_model_bind_input": (_I32, [_VP, _I32, C.POINTER(_I64), _I32, C.POINTER(_VP)]),
+    "rten_hip_model_prepare": (_I32, [_VP, _I32]),
+    "rten_hip_model_run": (_I32, [_VP, _U32]),
+    "rten_hip_model_sync": (_I32, [_VP]),
+    "rten_hip_model_output": (_I32, [_VP, _I32, C.POINTER(_VP), C.POINTER(_I64), C.POINTER(_I32)]),
+    "rten_hip_model_destroy": (_I32, [_VP]),
 }
 
 _lib = None
@@ -349,6 +361,69 @@ class Comm:
         if getattr(self, "h", None) and getattr(self.ctx, "h", None):
             self.ctx.call("rten_hip_comm_destroy", self.h)
         self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Model:
+    """RAII wrapper of rten_hip_model: the C++ plan executor (include/rten_hip_graph.hpp) behind the C ABI -- ONNX bytes in, every value resident in
+    HBM, committed launch plan, `chains` independent sub-batch chains, hipGraph replay.  What a Rust `HipSubgraph` operator would own
+    (INTEGRATION.md 2.5); `bench.py --via-executor` times it."""
+
+    def __init__(self, ctx: Context, onnx_bytes: bytes, plan_json: str | None = None, chains: int = 1):
+        self.ctx, self.lib = ctx, ctx.lib
+        h = C.c_void_p()
+        self._onnx = onnx_bytes
+        rc = self.lib.rten_hip_model_load(ctx.h, onnx_bytes, len(onnx_bytes), plan_json.encode() if plan_json else None, chains, ctx.device, C.byref(h))
+        if rc != OK:
+            raise HipError(rc, "rten_hip_model_load failed (ONNX parse / unsupported operator / bad plan file)")
+        self.h = h
+        ni, no, ns, npl = _I32(), _I32(), _I32(), _I32()
+        self._check(self.lib.rten_hip_model_info(h, C.byref(ni), C.byref(no), C.byref(ns), C.byref(npl)))
+        self.inputs = [self.lib.rten_hip_model_input_name(h, i).decode() for i in range(ni.value)]
+        self.outputs = [self.lib.rten_hip_model_output_name(h, i).decode() for i in range(no.value)]
+        self.num_steps = ns.value
+        self.input_ptrs = {}
+
+    def _check(self, rc):
+        if rc != OK:
+            raise HipError(rc, self.lib.rten_hip_model_last_error(self.h).decode(errors="replace"))
+
+    def bind_input(self, name: str, shape) -> int:
+        """Declare an input's full-batch shape; returns the device pointer to write the input to."""
+        p = C.c_void_p()
+        sh = (C.c_int64 * len(shape))(*shape)
+        self._check(self.lib.rten_hip_model_bind_input(self.h, self.inputs.index(name), sh, len(shape), C.byref(p)))
+        self.input_ptrs[name] = p.value
+        return p.value
+
+    def prepare(self, tune: bool = False):
+        self._check(self.lib.rten_hip_model_prepare(self.h, 1 if tune else 0))
+        ni, no, ns, npl = _I32(), _I32(), _I32(), _I32()
+        self._check(self.lib.rten_hip_model_info(self.h, C.byref(ni), C.byref(no), C.byref(ns), C.byref(npl)))
+        self.planned_steps = npl.value
+
+    def run(self, inputs_written_on_caller_stream: bool = False):
+        self._check(self.lib.rten_hip_model_run(self.h, 1 if inputs_written_on_caller_stream else 0))
+
+    def sync(self):
+        self._check(self.lib.rten_hip_model_sync(self.h))
+
+    def output(self, i: int = 0):
+        """(device pointer, shape) of output i after a run."""
+        p, nd = C.c_void_p(), _I32()
+        sh = (C.c_int64 * 8)()
+        self._check(self.lib.rten_hip_model_output(self.h, i, C.byref(p), sh, C.byref(nd)))
+        return p.value, tuple(sh[: nd.value])
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rten_hip_model_destroy(self.h)
+            self.h = None
 
     def __del__(self):
         try:

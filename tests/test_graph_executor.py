@@ -508,3 +508,63 @@ def test_pytorch_exported_transformer_encoder_bit_exact(tmp_path):
     with torch.no_grad():
         t = te.encoder_module(cfg, w, S)(torch.from_numpy(ids.astype(np.int64)), torch.from_numpy(mask.astype(np.int64)), torch.from_numpy(tts.astype(np.int64))).numpy()
     np.testing.assert_allclose(got.reshape(t.shape), t, rtol=1e-4, atol=1e-4)
+
+
+# ---- the same executor behind the C ABI (rten_hip_model_*: csrc/graph_abi.cpp): what a Rust `HipSubgraph` operator binds, and what
+#      `bench.py --via-executor` times
+def test_model_abi_is_declared_bound_and_refuses_bad_arguments_without_a_gpu():
+    import ctypes as C
+    from rten_amd import lib as L
+    so = L.load()
+    for name in ("load", "last_error", "info", "input_name", "output_name", "bind_input", "prepare", "run", "sync", "output", "destroy"):
+        assert hasattr(so, "rten_hip_model_" + name)
+    out = C.c_void_p()
+    assert so.rten_hip_model_load(None, b"x", 1, None, 1, 0, C.byref(out)) == L.ERR_INVALID_VALUE and not out.value  # no context
+    assert so.rten_hip_model_run(None, 0) == L.ERR_INVALID_VALUE
+    assert so.rten_hip_model_destroy(None) == L.OK
+    assert so.rten_hip_model_last_error(None) == b"null graph"
+
+
+@pytest.mark.gpu
+def test_model_abi_chains_and_plan_file_give_the_oracle_bits():
+    """ResNet-50 f32 (batch 5 -> chains of 2 + 2 + 1 images, and one chain) through rten_hip_model_*: ONNX bytes in, a launch plan file applied by
+    step name, hipGraph replay, outputs assembled on the device -- bit-identical to the CPU oracle, run after run."""
+    import ctypes as C
+    import json
+    from oracle import models as om
+    from rten_amd import lib as L, onnx_writer as ow
+    from rten_amd.tensor import DeviceTensor
+    from rten_amd.workloads import resnet50
+    w = resnet50.make_weights()
+    x = np.random.default_rng(99).random((5, 3, 224, 224), dtype=np.float32)
+    want = om.resnet50_forward(resnet50.conv_specs(), w, x)
+    ctx = L.Context(0)
+    onnx_bytes = ow.resnet50_f32(w)
+    flat = {l["name"]: [3, 0, 1, 0] for l in resnet50.conv_specs()}
+    flat["s1b1c2"] = [24, 2, 2, 0]   # a wave-tile split-K plan
+    flat["s2b1c2"] = [1, 1, 3, 0]
+    keyed = {"2": flat, "1": {k: [3, 0, 1, 1] for k in flat}}
+    for chains, plan in ((3, keyed), (1, flat), (2, None)):
+        m = L.Model(ctx, onnx_bytes, json.dumps(plan) if plan else None, chains)
+        assert m.inputs == ["x"] and m.outputs == ["logits"] and m.num_steps == 57
+        xp = m.bind_input("x", x.shape)
+        m.prepare()
+        assert m.planned_steps == (53 if plan else 0)
+        xt = DeviceTensor(ctx, x.shape, np.float32, ptr=xp, keepalive=m)
+        for rep in range(2):
+            xt.upload(x if rep == 0 else x[::-1].copy())
+            m.run(inputs_written_on_caller_stream=True)
+            m.sync()
+            optr, oshape = m.output(0)
+            assert oshape == (5, 1000)
+            got = DeviceTensor(ctx, oshape, np.float32, ptr=optr, keepalive=m).numpy()
+            ref_out = want if rep == 0 else want[::-1]
+            assert np.array_equal(got.view(np.int32), ref_out.view(np.int32)), (chains, rep)
+        m.close()
+    # a plan file that is not JSON, and a batch smaller than the chain count
+    with pytest.raises(L.HipError):
+        L.Model(ctx, onnx_bytes, "{not json", 1)
+    m = L.Model(ctx, onnx_bytes, None, 4)
+    with pytest.raises(L.HipError):
+        m.bind_input("x", (2, 3, 224, 224))
+    m.close()
