@@ -444,8 +444,12 @@ constexpr int MAX_NSTAGE = 6;
 //      1 = all of the k-tile's fragments first, then the MFMAs back to back with nothing between them: with one 32x32 block per
 //          wave (64x64 tiles) consecutive MFMAs hit the SAME accumulator, and any instruction issued between two such MFMAs
 //          costs ~43 cycles on top of its own slot (MI355X_MICROARCH.md, per-instruction constants).
+// Waves per SIMD the compiler must leave room for: 64x64 tiles are LDS-limited to 6 (three stages) / 10 (two stages) workgroups per compute unit,
+// so their register budget is set to match (80 VGPRs: the MODE 1 / 2 forms sat at 81-85, i.e. at 5) -- more resident workgroups is what these
+// kernels respond to (tools/debug/f32_trace.py with RTEN_HIP_OCC_CAP: 2 -> 3 -> 6 workgroups per CU = 3.72 -> 3.20 -> 2.95 ms per step).
+constexpr int dma_min_waves(int bm, int bn, int mode) { return bm * bn == 64 * 64 ? (mode == 3 ? 4 : 6) : 2; }
 template <int BM, int BN, int AL, int BL, int MODE, int NST = 3, int MFK = 0>
-__global__ __launch_bounds__(NTHREADS, 2) void igemm_f32_dma_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(NTHREADS, dma_min_waves(BM, BN, MODE)) void igemm_f32_dma_kernel(const GemmArgs p) {
     TR_DECL
     TR_STAMP(0)
     kernarg_prefetch<(int)sizeof(GemmArgs)>();
@@ -2353,6 +2357,7 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
     int pipe = kDma ? ctx->pipeline : 0;
     if (AL == A_K4 && pipe == 2) pipe = 1; // the wave-specialised kernel only takes k-major A
     if (pipe == 6 && !(AL == A_M4 && BM == 64 && BN == 64)) pipe = 1; // the wave-tile kernels: prepacked weights, 64x64 tiles
+    if (pipe == 7 && !(BM == 64 && BN == 64)) pipe = 1;                // the two-stage ring exists for 64x64 tiles
     if constexpr (BL == B_IM2COL_TAPS) {
         if (pipe == 0) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "internal: tap-mask im2col needs an LDS-DMA pipeline");
     }
@@ -2432,6 +2437,17 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
                 else hipLaunchKernelGGL((igemm_f32_dma16_kernel<BM, BN, AL, BL, 0>), grid, dim3(NTHREADS), 0, ctx->stream, a);
                 RTEN_LAUNCH_CHECK(ctx, "igemm_f32_dma16_kernel launch");
                 return RTEN_HIP_OK;
+            }
+            if constexpr (BM == 64 && BN == 64) {
+                if (pipe == 7) { // TWO LDS stages (16 KB per workgroup): up to 7 workgroups per compute unit instead of 6 -- the other workgroups are the prefetch depth
+                    snprintf(kname, sizeof kname, "igemm_f32_dma_kernel<%d,%d,%d,%d,%d,2>", BM, BN, AL, BL, mode);
+                    ProfScope ps(ctx, kname, fl, by);
+                    if (mode == 2) hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, AL, BL, 2, 2>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+                    else if (mode == 1) hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, AL, BL, 1, 2>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+                    else hipLaunchKernelGGL((igemm_f32_dma_kernel<BM, BN, AL, BL, 0, 2>), grid, dim3(NTHREADS), 0, ctx->stream, a);
+                    RTEN_LAUNCH_CHECK(ctx, "igemm_f32_dma_kernel launch");
+                    return RTEN_HIP_OK;
+                }
             }
             if (pipe == 3) { // four LDS stages: three k-tiles in flight behind the one being multiplied
                 snprintf(kname, sizeof kname, "igemm_f32_dma_kernel<%d,%d,%d,%d,%d,4>", BM, BN, AL, BL, mode);
@@ -2583,7 +2599,7 @@ int32_t launch_variant(rten_hip_ctx *ctx, GemmArgs &a, int Z, int cfg) {
 }
 
 int pick_cfg(rten_hip_ctx *ctx, int M, long long N, int Z) {
-    if (ctx->gemm_variant_override >= 24 && ctx->gemm_variant_override < 28) return 3; // wave-tile kernels: 64x64
+    if (ctx->gemm_variant_override >= 24 && ctx->gemm_variant_override < 28) return 3; // wave-tile kernels (24..26) and the two-stage ring (27): 64x64
     if (ctx->gemm_variant_override >= 0 && ctx->gemm_variant_override < 24) return ctx->gemm_variant_override & 3;
     int best = 3;
     double best_cost = 1e300;
@@ -2625,14 +2641,14 @@ constexpr long long kMaxBufBytes = 0x7fffffffll; // buffer offsets are 32-bit; t
 // wave specialisation (4 MFMA waves + 4 loader waves); variants 12..15: LDS-DMA with four LDS stages.  Non-conv
 // operand layouts always use the register-staged kernel.
 // Variants 16..19: LDS-DMA, fragments-first MFMA issue; variants 20..23: LDS-DMA on 16x16x4 MFMAs.
-// Variants 24..26: one wave per 64x64 tile (gemm_f32_wave.hip), k-tiles x LDS stages = 16 x 2, 8 x 4, 16 x 3 (27: reserved, = 24).
-RTEN_EXPORT int32_t rten_hip_num_gemm_variants(void) { return 27; }
+// Variants 24..26: one wave per 64x64 tile (gemm_f32_wave.hip), k-tiles x LDS stages = 16 x 2, 8 x 4, 16 x 3; 27: 64x64 LDS-DMA with TWO stages.
+RTEN_EXPORT int32_t rten_hip_num_gemm_variants(void) { return 28; }
 
 RTEN_EXPORT int32_t rten_hip_set_gemm_variant_override(rten_hip_ctx *ctx, int32_t variant) {
     RTEN_CHECK_CTX(ctx);
     ctx->gemm_variant_override = variant;
     ctx->wave_flavour = (variant >= 24 && variant < 27) ? variant - 24 : 0;
-    ctx->pipeline = (variant >= 24 && variant < 28) ? 6 : (variant >= 20 && variant < 24) ? 5 : (variant >= 16 && variant < 20) ? 4 : (variant >= 12 && variant < 16) ? 3 : (variant >= 8 && variant < 12) ? 2 : ((variant >= 4 && variant < 8) ? 0 : 1);
+    ctx->pipeline = variant == 27 ? 7 : (variant >= 24 && variant < 27) ? 6 : (variant >= 20 && variant < 24) ? 5 : (variant >= 16 && variant < 20) ? 4 : (variant >= 12 && variant < 16) ? 3 : (variant >= 8 && variant < 12) ? 2 : ((variant >= 4 && variant < 8) ? 0 : 1);
     return RTEN_HIP_OK;
 }
 
