@@ -470,6 +470,8 @@ int32_t rten_hip_comm_destroy(rten_hip_ctx *ctx, rten_hip_comm *comm);
  * of accelerated nodes becomes one `Operator` that owns an rten_hip_model (precedent: SubgraphOperator, src/operator.rs:630-646).
  * ("model", not "graph": rten_hip_graph_* above is the hipGraph capture of a context's stream.)
  *   load -> bind_input (each input's full-batch shape; returns the device pointer the caller writes the input to) -> prepare -> { run, sync, output }*
+ * Chain 0 runs on `ctx` itself (a model with N chains owns N - 1 streams of its own: one stream more than chains costs real time on this runtime), so
+ * `ctx` must outlive the model: destroy models before their context.
  * Errors: the usual status codes; rten_hip_model_last_error has the text.  Not thread-safe per model object (one caller at a time). */
 typedef struct rten_hip_model rten_hip_model;
 int32_t rten_hip_model_load(rten_hip_ctx *ctx, const void *onnx_bytes, size_t onnx_len, const char *plan_json /* optional */, int32_t chains,

@@ -256,6 +256,12 @@ RTEN_EXPORT int32_t rten_hip_model_prepare(rten_hip_model *g, int32_t tune) {
                 if (!tuned.count(b)) { const size_t n = gr.autotune(feeds); tuned[b] = gr.plans(); if (c == 0) g->tuned_steps = n; }
                 else gr.apply_plan(tuned[b]);
             }
+            // A one-image chain of a larger batch: the reference's products have several rows (the whole batch), so the chain's one-row products must
+            // NOT take the reference's vector-matrix (gemv) order -- the decision is made on the host while the launches are recorded, hence around
+            // the probe run and the capture only (the context's setting is restored: chain 0 runs on the caller's context).
+            const bool lone_row = b == 1 && g->start.back() + g->sub.back() > 1;
+            if (lone_row) cx.check(rten_hip_set_gemv_order(cx.raw(), 0, 0));
+            struct Restore { Context &c; bool on; ~Restore() { if (on) rten_hip_set_gemv_order(c.raw(), 1, 0); } } restore{cx, lone_row};
             if (c == 0) { // resident full-batch outputs, shaped from chain 0's (un-captured) first run
                 const std::vector<Tensor> probe = gr.run(feeds);
                 for (size_t o = 0; o < probe.size(); o++) {

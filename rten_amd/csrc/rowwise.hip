@@ -269,12 +269,29 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void layer_norm_kernel(int64_t
     const float *ar = addend ? addend + row * cols : nullptr;
     float *yr = y + row * cols;
     [[maybe_unused]] float v[CH > 0 ? CH : 1];
+    // per-column scale / bias of the register-resident form: requested HERE, together with the row itself -- they depend on nothing, and
+    // behind the two ordered reductions their L2 round trip (~1 us) would be the tail of every wave (round 4: 6.1 -> see ops_microbench.json)
+    [[maybe_unused]] float gv[CH > 0 ? CH : 1], bv[CH > 0 ? CH : 1];
     if constexpr (CH > 0) {
+        float xa[CH], aa[CH];
 #pragma unroll
-        for (int c = 0; c < CH; c++) {
-            const int i = c * 64 + lane;
-            v[c] = i < cols ? (ar ? xr[i] + ar[i] : xr[i]) : 0.f;
+        for (int c = 0; c < CH; c++) { const int i = c * 64 + lane; xa[c] = i < cols ? xr[i] : 0.f; }
+        if (ar) {
+#pragma unroll
+            for (int c = 0; c < CH; c++) { const int i = c * 64 + lane; aa[c] = i < cols ? ar[i] : 0.f; }
         }
+#pragma unroll
+        for (int c = 0; c < CH; c++) { gv[c] = 1.0f; bv[c] = 0.f; }
+        if (gamma) {
+#pragma unroll
+            for (int c = 0; c < CH; c++) { const int i = c * 64 + lane; gv[c] = gamma[i < cols ? i : 0]; }
+        }
+        if (beta) {
+#pragma unroll
+            for (int c = 0; c < CH; c++) { const int i = c * 64 + lane; bv[c] = beta[i < cols ? i : 0]; }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; c++) v[c] = ar ? xa[c] + aa[c] : xa[c]; // (0 + 0 for the masked tail: never used)
     }
     // element fetch by index for the ordered reduction: register-resident rows are indexed through
     // their owning lane (i % 64 == this lane for the unrolled part; the <64-element remainder needs a
@@ -317,19 +334,7 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void layer_norm_kernel(int64_t
         return vm::fma(xv - mean, gv * ssr, bv + beta_scalar);
     };
     if constexpr (CH > 0) {
-        // per-column scale / bias: all loads of the row's columns issued back to back (uniform `mode` tests hoisted out
-        // of the element loop -- a test per element serialises every load behind a waitcnt)
-        float gv[CH], bv[CH];
-#pragma unroll
-        for (int c = 0; c < CH; c++) { gv[c] = 1.0f; bv[c] = 0.f; }
-        if (gamma) {
-#pragma unroll
-            for (int c = 0; c < CH; c++) { const int i = c * 64 + lane; gv[c] = gamma[i < cols ? i : 0]; }
-        }
-        if (beta) {
-#pragma unroll
-            for (int c = 0; c < CH; c++) { const int i = c * 64 + lane; bv[c] = beta[i < cols ? i : 0]; }
-        }
+        // (uniform `mode` tests hoisted out of the element loop -- a test per element serialises every load behind a waitcnt)
         if (mode == 0) {
 #pragma unroll
             for (int c = 0; c < CH; c++) v[c] = vm::fma(v[c] - mean, ssr, beta_scalar);
@@ -476,8 +481,18 @@ __global__ __launch_bounds__(1024) void reduce_sum_cols_kernel(const ReduceArgs 
     const int64_t row = prefix * last + jj;
     const float *xr = x + reduce_row_base(p, row);
     const int n = p.inner, full4 = n >> 6;
+    // The chain of adds is the reference's (one accumulator, elements in order); the LOADS are independent, so eight are requested before the
+    // first add -- a load per add made this kernel one memory round trip per element (31.5 us for 4096 x 3072 -> 3072: round 3).
     float acc = 0.f;
-    for (int c = 0; c < full4; c++) acc = acc + xr[reduce_elem_off(p, c * 64 + u * 16 + l)];
+    int c = 0;
+    for (; c + 8 <= full4; c += 8) {
+        float tv[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) tv[k] = xr[reduce_elem_off(p, (c + k) * 64 + u * 16 + l)];
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc = acc + tv[k];
+    }
+    for (; c < full4; c++) acc = acc + xr[reduce_elem_off(p, c * 64 + u * 16 + l)];
     float a = lane_bcast(acc, j);
     a = a + lane_bcast(acc, j + 16);
     a = a + lane_bcast(acc, j + 32);

@@ -421,8 +421,11 @@ class Model:
         return p.value, tuple(sh[: nd.value])
 
     def close(self):
+        """Destroys the model.  Chain 0 runs on the context the model was loaded with: that context must still be alive (close models first)."""
         if getattr(self, "h", None):
-            self.lib.rten_hip_model_destroy(self.h)
+            if getattr(self.ctx, "h", None):
+                self.lib.rten_hip_model_destroy(self.h)
+            # (context already destroyed -- interpreter shutdown order: the model is leaked rather than torn down on a dead context)
             self.h = None
 
     def __del__(self):

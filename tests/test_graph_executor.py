@@ -546,25 +546,34 @@ def test_model_abi_chains_and_plan_file_give_the_oracle_bits():
     keyed = {"2": flat, "1": {k: [3, 0, 1, 1] for k in flat}}
     for chains, plan in ((3, keyed), (1, flat), (2, None)):
         m = L.Model(ctx, onnx_bytes, json.dumps(plan) if plan else None, chains)
-        assert m.inputs == ["x"] and m.outputs == ["logits"] and m.num_steps == 57
-        xp = m.bind_input("x", x.shape)
-        m.prepare()
-        assert m.planned_steps == (53 if plan else 0)
-        xt = DeviceTensor(ctx, x.shape, np.float32, ptr=xp, keepalive=m)
-        for rep in range(2):
-            xt.upload(x if rep == 0 else x[::-1].copy())
-            m.run(inputs_written_on_caller_stream=True)
-            m.sync()
-            optr, oshape = m.output(0)
-            assert oshape == (5, 1000)
-            got = DeviceTensor(ctx, oshape, np.float32, ptr=optr, keepalive=m).numpy()
-            ref_out = want if rep == 0 else want[::-1]
-            assert np.array_equal(got.view(np.int32), ref_out.view(np.int32)), (chains, rep)
-        m.close()
+        try:
+            _check_model(m, ctx, x, want, plan, chains)
+        finally:
+            m.close()  # chain 0 runs on `ctx`: a model must never outlive its context
     # a plan file that is not JSON, and a batch smaller than the chain count
     with pytest.raises(L.HipError):
         L.Model(ctx, onnx_bytes, "{not json", 1)
     m = L.Model(ctx, onnx_bytes, None, 4)
-    with pytest.raises(L.HipError):
-        m.bind_input("x", (2, 3, 224, 224))
-    m.close()
+    try:
+        with pytest.raises(L.HipError):
+            m.bind_input("x", (2, 3, 224, 224))
+    finally:
+        m.close()
+
+
+def _check_model(m, ctx, x, want, plan, chains):
+    from rten_amd.tensor import DeviceTensor
+    assert m.inputs == ["x"] and m.outputs == ["logits"] and m.num_steps == 57
+    xp = m.bind_input("x", x.shape)
+    m.prepare()
+    assert m.planned_steps == (53 if plan else 0)
+    xt = DeviceTensor(ctx, x.shape, np.float32, ptr=xp, keepalive=m)
+    for rep in range(2):
+        xt.upload(x if rep == 0 else x[::-1].copy())
+        m.run(inputs_written_on_caller_stream=True)
+        m.sync()
+        optr, oshape = m.output(0)
+        assert oshape == (5, 1000)
+        got = DeviceTensor(ctx, oshape, np.float32, ptr=optr, keepalive=m).numpy()
+        ref_out = want if rep == 0 else want[::-1]
+        assert np.array_equal(got.view(np.int32), ref_out.view(np.int32)), (chains, rep)  # (chains of 2 + 2 + 1 images: the lone image keeps the blocked order)
