@@ -40,6 +40,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# Control-flow test mode (tests/test_bench_world8.py): RTEN_BENCH_RECORDING=1 swaps the device context for one that records launches instead of
+# issuing them, keeps every tensor torch touches on the CPU and takes the gloo backend -- the script's rank / shard / plan / broadcast / aggregation
+# logic runs unchanged at any world size without a GPU.  Numbers printed in this mode mean nothing and say so (`data`: "recording").
+DRY = os.environ.get("RTEN_BENCH_RECORDING") == "1"
+
 F32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X v_mfma_f32_32x32x2_f32 peak (MI355X_MICROARCH.md)
 I8_MATRIX_PEAK_TOPS = 5033.0    # dense i8 MFMA: 2x the bf16 rate (MI355X_MICROARCH.md, "Matrix cores")
 HBM_PEAK_GBS = 8000.0           # HBM3E spec (6.29 TB/s measured with a float4 copy)
@@ -391,22 +396,28 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RTEN_DIST_BACKEND=gloo lets the rank != 0 path (arena received by broadcast) be exercised with several ranks on ONE
         # GPU (RCCL refuses two ranks per device); the driver's multi-GPU runs use the default, nccl (= RCCL over xGMI).
-        backend = os.environ.get("RTEN_DIST_BACKEND", "nccl")
+        backend = "gloo" if DRY else os.environ.get("RTEN_DIST_BACKEND", "nccl")
         if backend != "nccl":
             local_rank = local_rank % max(torch.cuda.device_count(), 1)
-        torch.cuda.set_device(local_rank)
+        if not DRY:
+            torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    else:
+    elif not DRY:
         torch.cuda.set_device(local_rank)
 
     from rten_amd import lib
     from rten_amd.workloads import resnet50, resnet50_int8
     from rten_amd.sharding import broadcast_weight_arena
 
-    ctx = lib.Context(local_rank)  # no CPU fallback: raises if the HIP extension / MI355X is missing
+    if DRY:
+        from tests.recording_ctx import RecordingCtx
+        ctx = RecordingCtx(local_rank)
+        torch.cuda.synchronize = lambda *a, **k: None  # (nothing is ever enqueued on a device in this mode)
+    else:
+        ctx = lib.Context(local_rank)  # no CPU fallback: raises if the HIP extension / MI355X is missing
     weights = resnet50.make_weights()
     int8 = args.config == "int8"
 
@@ -425,7 +436,7 @@ def main():
         # through the backend's own communicator (rten_hip_comm_* = RCCL behind the C ABI, what a Rust host would call) on
         # the context's stream.  Under RTEN_DIST_BACKEND=gloo (several ranks on one GPU) torch.distributed carries it.
         nbytes = resnet50_int8.i8_arena_layout(ctx.lib, BATCH_PER_GPU)[1] if int8 else resnet50.arena_bytes(ctx.lib, BATCH_PER_GPU)  # host arithmetic: nothing is built twice
-        arena_t = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{local_rank}")
+        arena_t = torch.empty(nbytes, dtype=torch.uint8, device="cpu" if DRY else f"cuda:{local_rank}")
         net = build(i8_arena_ptr=arena_t.data_ptr(), i8_arena_keepalive=arena_t) if int8 else build(arena_ptr=arena_t.data_ptr(), arena_keepalive=arena_t)
         if rank == 0:
             net.upload_weights()
@@ -442,6 +453,8 @@ def main():
             broadcast_weight_arena(arena_t, src=0)
             comm_world = dist.get_world_size()
         torch.cuda.synchronize()
+        if DRY and rank == 0:  # what the test checks about the one collective: the size every rank allocated, from host arithmetic alone
+            print(f"[recording] weight arena {nbytes} bytes broadcast to {comm_world} ranks", file=sys.stderr)
     else:
         net = build()
         net.upload_weights()
@@ -701,7 +714,8 @@ def main():
             "metric": metric,
             "value": round(value, 2), "unit": "inferences/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "p50_latency_ms": round(p50, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 x i8 -> i32 (f32 between layers)" if int8 else "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 x i8 -> i32 (f32 between layers)" if int8 else "f32",
+            "data": "recording (no device: control-flow test)" if DRY else "synthetic",
             "config": {"workload": workload,
                        "global_batch": global_batch, "parallelism": f"batch-shard x{n_gpus} (weights RCCL-broadcast once)" if n_gpus > 1 else "single GPU",
                        "launch": "eager" if args.no_graph else "hipGraph replay", "autotuned_tiles": bool(net.variants),
@@ -733,6 +747,12 @@ def main():
         if n_gpus == 1 and world == 1 and not args.no_secondary and not int8:
             out["secondary"] = secondary_configs()
         print(json.dumps(out))
+    if DRY:
+        import collections
+        c = collections.Counter(ctx.log)
+        print(f"[recording] rank {rank} seed {1234 + rank} shard {list(__import__('rten_amd.sharding', fromlist=['shard_range']).shard_range(BATCH_PER_GPU * world, rank, world))[:1]}"
+              f"..+{BATCH_PER_GPU} graph_launch {c['graph_launch']} qout {c['rten_hip_conv2d_int8_qout']} conv {c['rten_hip_conv2d_int8_stats']} "
+              f"dql_loader {c['rten_hip_conv2d_int8_dql']} h2d {c['rten_hip_memcpy_h2d']}", file=sys.stderr)
     if dist is not None:
         dist.barrier()  # rank 0's instrumented pass / JSON line happen before any rank tears the group down
         dist.destroy_process_group()

@@ -377,7 +377,7 @@ class ChainedResNet50:
         self.ctx, self.batch, self.chains = ctx, batch, chains
         self.weights = weights if weights is not None else make_weights(num_classes=num_classes)
         self.sizes, self.starts = split_batch(batch, chains)
-        self.pool = [ctx] + [L.Context(ctx.device) for _ in range(self.POOL - 1)]
+        self.pool = [ctx] + [type(ctx)(ctx.device) for _ in range(self.POOL - 1)]  # (same kind as the caller's: a recording context spawns recording contexts)
         self.place = list(range(chains))  # chain i's graph is launched on pool[place[i]]
         self.x = DeviceTensor(ctx, (batch, 3, image, image), np.float32)
         self.logits = DeviceTensor(ctx, (batch, num_classes), np.float32)

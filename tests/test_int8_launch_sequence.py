@@ -14,47 +14,7 @@ from rten_amd import lib as L
 from rten_amd.workloads import resnet50, resnet50_int8
 
 
-class _LibProxy:
-    """Pure host functions (sizes, layouts) go to the real library; everything that would touch a device is recorded."""
-
-    def __init__(self, real, log):
-        self._real, self._log = real, log
-
-    def __getattr__(self, name):
-        if name.endswith("_bytes"):
-            return getattr(self._real, name)
-
-        def recorded(*args):
-            self._log.append(name)
-            return L.OK
-        return recorded
-
-
-class RecordingCtx:
-    device = 0
-
-    def __init__(self):
-        self.log = []
-        self.lib = _LibProxy(L.load(), self.log)
-        self.h = C.c_void_p(0x1000)
-        self._next = 1 << 32
-
-    def alloc(self, nbytes):
-        p = self._next
-        self._next += (max(int(nbytes), 16) + 255) & ~255
-        return p
-
-    def release(self, ptr, nbytes):
-        pass
-
-    def call(self, name, *args):
-        self.log.append(name)
-
-    def check(self, rc):
-        assert rc == L.OK
-
-    def sync(self):
-        pass
+from tests.recording_ctx import RecordingCtx  # noqa: E402  (shared with the world-8 bench control-flow test)
 
 
 @pytest.fixture(scope="module")
