@@ -38,6 +38,24 @@ def _conv_desc(n, c, h, w, o, k, stride, pad, pad_mode=L.PAD_RAW0_I8, packed=1, 
                             packed, staged, scale_len), oh, ow
 
 
+def staged_image(codes_u8, zero_point, pads, pad_mode):
+    """numpy restatement of the staged int8 activation layout the fast kernels read (csrc/int8_fast.hip `ConvGeom`):
+    [N][ceil(C / 16)][H + pad_top + pad_bottom][W + pad_left + pad_right][16 B] of SIGNED bytes (u8 code ^ 0x80); the border holds the padded-tap
+    value of the pad mode -- zero point (in the signed domain), raw 0 after the u8 -> i8 shift, or raw u8 0; channels past C are 0
+    everywhere (border included).
+    With it a test can compare staged bytes against oracle.ref.dynamic_quantize_linear directly instead of against another HIP path."""
+    n, c, h, w = codes_u8.shape
+    pt, pl, pb, pr = pads
+    cb = (c + 15) // 16
+    border = {L.PAD_ZERO_POINT: (int(zero_point) - 128) & 0xFF, L.PAD_RAW0_I8: 0, L.PAD_RAW0_U8: 0x80}[pad_mode]
+    chan_fill = np.where(np.arange(cb * 16) < c, border, 0).astype(np.uint8).reshape(cb, 1, 1, 16)  # border bytes: pad value on real channels, 0 on padding channels
+    img = np.broadcast_to(chan_fill, (n, cb, h + pt + pb, w + pl + pr, 16)).copy()
+    body = np.zeros((n, cb * 16, h, w), np.uint8)
+    body[:, :c] = codes_u8 ^ 0x80
+    img[:, :, pt:pt + h, pl:pl + w, :] = body.reshape(n, cb, 16, h, w).transpose(0, 1, 3, 4, 2)
+    return img.reshape(-1)
+
+
 QOUT_CASES = [
     # n, c, h, w | producer o, k, stride, pad | consumer o2, k2, stride2, pad2 | consumer pad mode, per-channel scale, residual + f32 output
     (4, 64, 56, 56, 64, 1, 1, 0, 64, 3, 1, 1, L.PAD_RAW0_I8, False, False),      # c1 -> c2 of stage 0
@@ -89,6 +107,23 @@ def test_conv2d_int8_qout_matches_the_separate_operators(ctx, case):
     ctx.call("rten_hip_dynamic_quantize_linear_staged_stats", C.byref(d2), y_a.vp, st_a.vp, staged_a.vp, xs_a.vp, xz_a.vp, ws2.vp, pr_a.vp)
     ctx.sync()
 
+    # (a') ... and the CPU oracle on its own, so that this test does not rest on another HIP path: the producer's input codes, the convolution in
+    # the reference's operator order (ConvInteger -> Cast -> Mul -> Add(bias) -> Add(residual) -> Relu), DynamicQuantizeLinear of the result, and
+    # its codes laid out as the consumer's staged image
+    q_in, s_in, z_in = ref.dynamic_quantize_linear(xf)
+    acc = ref.conv2d_int8(q_in, wq, x_zp=int(z_in), pads=(pad,) * 4, strides=(stride,) * 2, pad_mode=L.PAD_RAW0_I8)
+    scale_vec = (ws.numpy() * np.float32(s_in)).astype(np.float32)
+    y_ref = acc.astype(np.float32) * (scale_vec[None, :, None, None] if per_ch else scale_vec[0])
+    y_ref = y_ref + bias.numpy()[None, :, None, None]
+    if with_res:
+        y_ref = y_ref + res.numpy()
+    y_ref = ref.relu(y_ref.astype(np.float32))
+    bits_equal(y_a.numpy(), y_ref)
+    q2, s2, z2 = ref.dynamic_quantize_linear(y_ref)
+    assert xs_a.numpy()[0] == s2 and xz_a.numpy()[0] == z2 and pr_a.numpy()[0] == np.float32(np.float32(s2) * ws2.numpy()[0])
+    want_img = staged_image(q2, z2, (pad2,) * 4, pad_mode2)
+    assert np.array_equal(staged_a.numpy()[: want_img.size], want_img), "two-operator staged image differs from the oracle's codes re-laid by numpy"
+
     # (b) one launch; twice in a row (the barrier block must come back zeroed), with and without the f32 output
     sync = DeviceTensor(ctx, (gb,), np.uint8)
     ctx.call("rten_hip_grid_sync_reset", sync.vp, 1)
@@ -111,6 +146,7 @@ def test_conv2d_int8_qout_matches_the_separate_operators(ctx, case):
         assert np.array_equal(pr_a.numpy().view(np.uint32), pr_b.numpy().view(np.uint32))
         a, b = staged_a.numpy(), staged_b.numpy()
         assert np.array_equal(a, b), f"rep {rep}: {(a != b).sum()} of {a.size} staged bytes differ (first at {np.argwhere(a != b)[0]})"
+        assert np.array_equal(b[: want_img.size], want_img) and xs_b.numpy()[0] == s2 and xz_b.numpy()[0] == z2  # the one-launch form against the ORACLE
         if want_y:
             bits_equal(y_b.numpy(), y_a.numpy())
         else:
@@ -291,8 +327,11 @@ def test_quantize_staged_products_matches_the_quantizer_plus_separate_muls(ctx, 
         assert np.array_equal(prods_a[i].numpy().view(np.uint32), want.view(np.uint32))
         assert np.array_equal(prods_b[i].numpy().view(np.uint32), want.view(np.uint32)), f"product {i}"
     # the oracle's DynamicQuantizeLinear on the same tensor: scale and zero point
-    _, s_ref, z_ref = ref.dynamic_quantize_linear(xf.reshape(-1))
+    q_ref, s_ref, z_ref = ref.dynamic_quantize_linear(xf)
     assert np.float32(s_ref).view(np.uint32) == xs_b.numpy().view(np.uint32)[0] and int(z_ref) == int(xz_b.numpy()[0])
+    # ... and its codes, re-laid by numpy into the consumer's staged image: the staged bytes stand on the oracle, not on another HIP path
+    want_img = staged_image(q_ref, z_ref, (pad,) * 4, pad_mode)
+    assert np.array_equal(b[: want_img.size], want_img), f"{(b[: want_img.size] != want_img).sum()} staged bytes differ from the oracle's codes"
 
 
 def test_quantize_staged_products_rejects_more_than_four_and_null_entries(ctx):
@@ -338,6 +377,10 @@ def test_max_pool_stats_same_values_and_the_statistics_the_quantizer_would_sweep
         ctx.sync()
         outs.append((staged.numpy(), xs.numpy().view(np.uint32), xz.numpy()))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+    # against the oracle alone: DynamicQuantizeLinear of the pooled tensor, codes re-laid by numpy
+    q_ref, s_ref, z_ref = ref.dynamic_quantize_linear(ref.max_pool(x, (k, k), (stride, stride), (pad, pad, pad, pad)))
+    want_img = staged_image(q_ref, z_ref, (0, 0, 0, 0), L.PAD_RAW0_I8)
+    assert np.array_equal(outs[1][0][: want_img.size], want_img) and outs[1][1][0] == np.float32(s_ref).view(np.uint32) and int(outs[1][2][0]) == int(z_ref)
 
 
 def test_max_pool_stats_needs_a_statistics_block(ctx):
