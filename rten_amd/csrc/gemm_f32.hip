@@ -2357,6 +2357,7 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
     int pipe = kDma ? ctx->pipeline : 0;
     if (AL == A_K4 && pipe == 2) pipe = 1; // the wave-specialised kernel only takes k-major A
     if (pipe == 6 && !(AL == A_M4 && BM == 64 && BN == 64)) pipe = 1; // the wave-tile kernels: prepacked weights, 64x64 tiles
+    if (pipe == 6 && ctx->wave_flavour >= 4 && BL != B_N4) pipe = 1;   // 32x32 wave tiles: dense B only
     if (pipe == 7 && !(BM == 64 && BN == 64)) pipe = 1;                // the two-stage ring exists for 64x64 tiles
     if constexpr (BL == B_IM2COL_TAPS) {
         if (pipe == 0) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "internal: tap-mask im2col needs an LDS-DMA pipeline");
@@ -2368,6 +2369,7 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
     a.split_s = 1;
     a.order = ctx->tile_order & 3;
     int split_mode = ctx->split_mode, split_req = ctx->split_s;
+    if (pipe == 6 && ctx->wave_flavour >= 4) split_mode = 0; // (no split-K form: whole tiles only)
     if (split_mode == 3) { // auto: too few tiles to fill the chip -> cut every tile so that ~num_cus workgroups exist
         const long long wgs = (long long)T * Z;
         split_mode = (multi && wgs * 2 <= ctx->num_cus) ? 2 : 0;
@@ -2599,7 +2601,7 @@ int32_t launch_variant(rten_hip_ctx *ctx, GemmArgs &a, int Z, int cfg) {
 }
 
 int pick_cfg(rten_hip_ctx *ctx, int M, long long N, int Z) {
-    if (ctx->gemm_variant_override >= 24 && ctx->gemm_variant_override < 28) return 3; // wave-tile kernels (24..26) and the two-stage ring (27): 64x64
+    if (ctx->gemm_variant_override >= 24 && ctx->gemm_variant_override < 30) return 3; // wave-tile kernels (24..26, 28..29) and the two-stage ring (27): 64x64 plans
     if (ctx->gemm_variant_override >= 0 && ctx->gemm_variant_override < 24) return ctx->gemm_variant_override & 3;
     int best = 3;
     double best_cost = 1e300;
@@ -2641,14 +2643,15 @@ constexpr long long kMaxBufBytes = 0x7fffffffll; // buffer offsets are 32-bit; t
 // wave specialisation (4 MFMA waves + 4 loader waves); variants 12..15: LDS-DMA with four LDS stages.  Non-conv
 // operand layouts always use the register-staged kernel.
 // Variants 16..19: LDS-DMA, fragments-first MFMA issue; variants 20..23: LDS-DMA on 16x16x4 MFMAs.
-// Variants 24..26: one wave per 64x64 tile (gemm_f32_wave.hip), k-tiles x LDS stages = 16 x 2, 8 x 4, 16 x 3; 27: 64x64 LDS-DMA with TWO stages.
-RTEN_EXPORT int32_t rten_hip_num_gemm_variants(void) { return 28; }
+// Variants 24..26: one wave per 64x64 tile (gemm_f32_wave.hip), k-tiles x LDS stages = 16 x 2, 8 x 4, 16 x 3; 27: 64x64 LDS-DMA with TWO stages;
+// 28..29: one wave per 32x32 tile (barrier-free form of the 64x64 / 4-wave granularity; dense B), 16 x 2 and 16 x 3.
+RTEN_EXPORT int32_t rten_hip_num_gemm_variants(void) { return 30; }
 
 RTEN_EXPORT int32_t rten_hip_set_gemm_variant_override(rten_hip_ctx *ctx, int32_t variant) {
     RTEN_CHECK_CTX(ctx);
     ctx->gemm_variant_override = variant;
-    ctx->wave_flavour = (variant >= 24 && variant < 27) ? variant - 24 : 0;
-    ctx->pipeline = variant == 27 ? 7 : (variant >= 24 && variant < 27) ? 6 : (variant >= 20 && variant < 24) ? 5 : (variant >= 16 && variant < 20) ? 4 : (variant >= 12 && variant < 16) ? 3 : (variant >= 8 && variant < 12) ? 2 : ((variant >= 4 && variant < 8) ? 0 : 1);
+    ctx->wave_flavour = (variant >= 24 && variant < 27) ? variant - 24 : (variant >= 28 && variant < 30) ? variant - 24 : 0;
+    ctx->pipeline = variant == 27 ? 7 : (variant >= 24 && variant < 30) ? 6 : (variant >= 20 && variant < 24) ? 5 : (variant >= 16 && variant < 20) ? 4 : (variant >= 12 && variant < 16) ? 3 : (variant >= 8 && variant < 12) ? 2 : ((variant >= 4 && variant < 8) ? 0 : 1);
     return RTEN_HIP_OK;
 }
 

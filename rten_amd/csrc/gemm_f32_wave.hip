@@ -24,18 +24,25 @@ namespace {
 // raw accumulators parked in the slab, last arrival folds -- split_finish).
 // BL: B_N4 (dense dwordx4), B_IM2COL_TAPS (<= 31 taps, per-lane padding mask) or B_IM2COL (general gather).
 // BKW x NST: k-tile depth x LDS stages of the wave's private ring (16 x 2 = 16 KB, 8 x 4 = 16 KB, 16 x 3 = 24 KB per wave).
-template <int BL, int MODE, int BKW, int NST>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void igemm_f32_wave_kernel(const GemmArgs p) {
+// TMW: the wave's tile is (32 TMW) x (32 TMW): 2 = 64x64 (four independent accumulator blocks), 1 = 32x32 -- ONE block per wave like the 4-wave
+// kernels' waves, i.e. their granularity (a 64x64 tile = four free-running waves), but with a private operand ring per wave and therefore NO
+// barrier: in the 4-wave kernels a wave that has finished its 8 MFMAs of a k-tile waits for its three siblings on the other SIMDs, and with 3-6
+// workgroups interleaved per SIMD those waits line up into convoys (the in-loop matrix-pipe efficiency of every 64x64 pipeline is 67-71 %,
+// whatever its MFMA shape or stage count; 128x128 tiles, four times fewer barriers per MFMA, run at ~100 %).  Price: each wave loads its own
+// A and B tiles (twice the L2 -> LDS traffic and DMA instructions per FLOP).  Dense B only.
+template <int BL, int MODE, int BKW, int NST, int TMW = 2>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TMW == 2 ? 2 : 4, TMW == 2 ? 2 : 8))) void igemm_f32_wave_kernel(const GemmArgs p) {
     TR_DECL
     TR_STAMP(0)
     kernarg_prefetch<(int)sizeof(GemmArgs)>();
     constexpr bool MULTI_KC = MODE == 1, SPLIT = MODE == 2;
     static_assert(BL == B_N4 || BL == B_IM2COL || BL == B_IM2COL_TAPS, "wave tile kernel covers the conv operand layouts");
-    constexpr int TM = 2, TN = 2, BMW = 64, BNW = 64;
+    constexpr int TM = TMW, TN = TMW, BMW = 32 * TMW, BNW = 32 * TMW;
+    static_assert(TMW == 2 || (BL == B_N4 && MODE != 2), "32x32 wave tiles: dense B, no split-K form");
     constexpr int STAGE = BKW * (BMW + BNW); // floats per stage: A [BKW][64] then B [BKW][64]
     constexpr int NA = BKW * BMW / 256;      // dwordx4 DMA instructions per k-tile (A)
     constexpr int NBV = BKW * BNW / 256;     // dwordx4 (dense B)
-    constexpr int NBG = BKW;                 // dword gathers (im2col B): one per k row, 64 columns = 64 lanes
+    constexpr int NBG = BKW;                 // dword gathers (im2col B, 64-wide tiles): one per k row, 64 columns = 64 lanes
     constexpr int PER_TILE = NA + (BL == B_N4 ? NBV : NBG);
     constexpr int KCT = 256 / BKW;           // k-tiles per reference depth block (kc = 256)
     constexpr bool IM2COL = BL == B_IM2COL || BL == B_IM2COL_TAPS, TAPS = BL == B_IM2COL_TAPS;
@@ -275,7 +282,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
     wait_vmcnt<0>(); // drain the look-ahead tiles before the LDS goes away
     TR_STAMP(3)
-    [[maybe_unused]] constexpr unsigned TR_KID = 64u | (64u << 8) | (MODE << 16) | (BL << 20) | (3u << 24) | ((unsigned)NST << 28);
+    [[maybe_unused]] constexpr unsigned TR_KID = (unsigned)BMW | ((unsigned)BNW << 8) | (MODE << 16) | (BL << 20) | (3u << 24) | ((unsigned)NST << 28);
 
     if constexpr (SPLIT) {
         if (p.split_counters) split_finish<BMW, BNW, TM, TN, 1, 1>(p, z, tile, 0, lane, m0, n0, c_zoff, reinterpret_cast<int *>(smem));
@@ -298,6 +305,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 
 template <int BL, int MODE>
 int32_t launch_flavour(rten_hip_ctx *ctx, const GemmArgs &a, dim3 grid, int flavour) {
+    if constexpr (BL == B_N4 && MODE != 2) {
+        if (flavour >= 4) { // 32x32 wave tiles: the caller's grid counts 64x64 tiles -- recount
+            GemmArgs b = a;
+            b.tiles_m = (a.M + 31) / 32;
+            b.tiles_n = (a.N + 31) / 32;
+            const dim3 g((unsigned)(b.tiles_m * b.tiles_n), grid.y);
+            TRACE_ASSIGN(b, g.x * g.y);
+            if (flavour == 5) hipLaunchKernelGGL((igemm_f32_wave_kernel<BL, MODE, 16, 3, 1>), g, dim3(64), 0, ctx->stream, b);
+            else hipLaunchKernelGGL((igemm_f32_wave_kernel<BL, MODE, 16, 2, 1>), g, dim3(64), 0, ctx->stream, b);
+            RTEN_LAUNCH_CHECK(ctx, "igemm_f32_wave_kernel (32x32) launch");
+            return RTEN_HIP_OK;
+        }
+    }
     switch (flavour) {
     case 1: hipLaunchKernelGGL((igemm_f32_wave_kernel<BL, MODE, 8, 4>), grid, dim3(64), 0, ctx->stream, a); break;
     case 2: hipLaunchKernelGGL((igemm_f32_wave_kernel<BL, MODE, 16, 3>), grid, dim3(64), 0, ctx->stream, a); break;

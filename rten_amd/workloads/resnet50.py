@@ -309,7 +309,7 @@ class ResNet50:
         # lean persistent kernel (mode 6; 64x64 tiles, K % 32 == 0): groups = workgroups per compute unit
         plans += [(3, 6, r, o) for r in (1, 2, 3) for o in (0, 1)]
         if nblk > 1:
-            for v in [v for v in range(nvar) if not (8 <= v < 12 or 20 <= v < 24)]:  # the wave-specialised and 16x16x4 kernels have no split form
+            for v in [v for v in range(nvar) if not (8 <= v < 12 or 20 <= v < 24 or v >= 28)]:  # the wave-specialised and 16x16x4 kernels have no split form
                 for groups in sorted({2, 3, 4, 6, nblk} & set(range(2, nblk + 1))):
                     plans.append((v, 1, groups, 0))
                     for o in (0, 2, 3):
