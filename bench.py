@@ -265,8 +265,9 @@ def run_via_executor(args):
     weights = resnet50.make_weights()
     chains = 1 if int8 else (4 if args.chains is None else args.chains)
     onnx_bytes = onnx_writer.resnet50_int8(weights) if int8 else onnx_writer.resnet50_f32(weights)
-    plan_path = args.load_plan or os.path.join(ROOT, "profiles", "plans", f"f32_{chains}chain{'s' if chains > 1 else ''}.json")
-    plan_text = None if (int8 or args.no_autotune or not os.path.exists(plan_path)) else open(plan_path).read()
+    plan_path = args.load_plan or os.path.join(ROOT, "profiles", "plans", "int8.json" if int8 else f"f32_{chains}chain{'s' if chains > 1 else ''}.json")
+    # (the int8 plan is the list of edges that take the quantized-output launch: opt-in, as in the runner's line)
+    plan_text = None if (args.no_autotune or not os.path.exists(plan_path)) else open(plan_path).read()
     model = lib.Model(ctx, onnx_bytes, plan_text, chains)
     xptr = model.bind_input("x", (BATCH_PER_GPU, 3, 224, 224))
     model.prepare(tune=bool(args.autotune and not plan_text))

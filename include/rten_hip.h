@@ -472,6 +472,9 @@ int32_t rten_hip_comm_destroy(rten_hip_ctx *ctx, rten_hip_comm *comm);
  *   load -> bind_input (each input's full-batch shape; returns the device pointer the caller writes the input to) -> prepare -> { run, sync, output }*
  * Chain 0 runs on `ctx` itself (a model with N chains owns N - 1 streams of its own: one stream more than chains costs real time on this runtime), so
  * `ctx` must outlive the model: destroy models before their context.
+ * A plan file may also carry {"qout": [ConvInteger node names]} (profiles/plans/int8.json): with chains == 1 those fused ConvIntegerToFloat steps
+ * run the DynamicQuantizeLinear of the one convolution reading their output in the same launch (rten_hip_conv2d_int8_qout above, with its opt-in and
+ * time-out contract; an edge whose launch is refused at run time runs the two operators).  rten_hip_model_info's n_planned_steps counts them.
  * Errors: the usual status codes; rten_hip_model_last_error has the text.  Not thread-safe per model object (one caller at a time). */
 typedef struct rten_hip_model rten_hip_model;
 int32_t rten_hip_model_load(rten_hip_ctx *ctx, const void *onnx_bytes, size_t onnx_len, const char *plan_json /* optional */, int32_t chains,

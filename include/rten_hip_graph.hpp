@@ -294,6 +294,10 @@ class Graph {
     struct Options {
         bool fuse = true;    // the fusion passes listed at the top of this file
         bool prepack = true; // stage constant conv weights once (Graph::prepack_weights)
+        // Opt-in, per edge (a launch plan: profiles/plans/int8.json "qout"): ConvInteger nodes, by name, whose fused ConvIntegerToFloat step also
+        // runs the DynamicQuantizeLinear of the one convolution reading its output (rten_hip_conv2d_int8_qout).  That launch needs the device to
+        // itself (all its workgroups resident at once; rten_hip.h states the time-out contract), so it is never a default.
+        std::set<std::string> qout;
     };
     struct Timing { std::string node, op; double ms; };
 
@@ -311,6 +315,7 @@ class Graph {
     size_t num_steps() const { return steps_.size(); }
     size_t num_fused_away() const { return fused_away_; }
     size_t num_staged_quantizers() const { return staged_dql_; }
+    size_t num_qout_edges() const { return qout_edges_; } // quantizers merged into their producer's launch (Options::qout)
     size_t num_stats_blocks() const { return stats_blocks_; }
     std::vector<std::string> step_names() const {
         std::vector<std::string> v;
@@ -456,6 +461,8 @@ class Graph {
         std::shared_ptr<ConvInteger> op;
         ConvInteger::Staging sg;
         bool to_float = false;
+        bool relu = false;
+        bool qout_off = false; // the one-launch form was refused once (grid not resident at once): the two-launch sequence from then on
     };
     struct Step {
         std::string name, kind_name;
@@ -499,8 +506,29 @@ class Graph {
     std::set<int> view_values_;
     int tune_reps_ = 0;
     size_t tuned_ = 0;
-    size_t stats_blocks_ = 0, staged_dql_ = 0;
-    std::unique_ptr<Tensor> stats_arena_;
+    size_t stats_blocks_ = 0, staged_dql_ = 0, qout_edges_ = 0;
+    std::unique_ptr<Tensor> stats_arena_, sync_arena_;
+
+    // what the ConvIntegerToFloat step's own lambda decides per run: does (scale, bias, residual) take the fused epilogue?
+    static bool i8_fused_form(const I8Conv &state, const InputList &in, bool &per_channel) {
+        const Tensor *scale = in[4], *bias = in[5], *residual = in[6];
+        per_channel = false;
+        if (!scale) return false;
+        const Tensor &x = require(in, 0), &w = require(in, 1);
+        bool fused = scale->dtype() == DType::F32 && x.ndim() == 4 && w.ndim() == 4;
+        const int64_t o = fused ? w.size(0) : 0;
+        if (fused && scale->len() != 1) {
+            const auto &sh = scale->shape();
+            per_channel = scale->len() == o && ((sh.size() == 4 && sh[0] == 1 && sh[1] == o) || (sh.size() == 3 && sh[0] == o));
+            fused = per_channel;
+        }
+        if (fused && bias) fused = bias->dtype() == DType::F32 && bias->len() == o && bias->ndim() == 4 && bias->size(1) == o;
+        if (fused && residual) {
+            const rten_hip_conv2d_desc d = state.op->conv.geometry(x.shape(), w.shape());
+            fused = residual->dtype() == DType::F32 && residual->shape() == std::vector<int64_t>{d.n, d.o, d.out_h, d.out_w};
+        }
+        return fused;
+    }
 
     // The staged int8 pipeline at graph level.  A DynamicQuantizeLinear whose codes feed only int8
     // convolutions of one padding geometry writes them straight into the kernel's staged layout; if its input is the f32
@@ -576,6 +604,50 @@ class Graph {
             else steps_[w.producer].i8->sg.stats_out = blk;
             steps_[w.dql].dql_staged->stats_in = blk;
             steps_[w.dql].kind_name = "DynamicQuantizeLinear(staged, producer statistics)";
+        }
+        if (opt_.qout.empty()) return;
+        // Opt-in edges: the quantizer moves INTO its producer's launch.  The merged step produces the conv's f32 tensor (only if somebody else reads
+        // it: a residual Add) and the quantizer's outputs; the quantizer's step disappears.  A launch that is refused at run time (its grid is not
+        // resident at once) runs the two operators instead, from then on.
+        std::vector<Pending> edges;
+        for (auto &w : want_stats) {
+            Step &P = steps_[w.producer], &D = steps_[w.dql];
+            if (!P.i8 || !P.i8->to_float || !opt_.qout.count(P.name) || D.dql_staged->mul_by.size() > 1 || !P.i8->sg.x_staged || !P.i8->sg.packed_weight) continue;
+            size_t quantizers = 0;
+            for (size_t u : consumers[D.in[0]]) if (steps_[u].dql_staged) quantizers++;
+            if (quantizers != 1) continue;
+            edges.push_back(w);
+        }
+        if (edges.empty()) return;
+        const size_t gb = rten_hip_grid_sync_bytes();
+        sync_arena_.reset(new Tensor(ctx_, {(int64_t)(gb * edges.size())}, DType::U8));
+        ctx_.check(rten_hip_grid_sync_reset(ctx_.raw(), sync_arena_->ptr(), (int32_t)edges.size()));
+        for (size_t e = 0; e < edges.size(); e++) {
+            Step &P = steps_[edges[e].producer], &D = steps_[edges[e].dql];
+            bool keep = consumers[D.in[0]].size() > 1;
+            for (auto &o : outputs_) if (ids_.at(o.name) == D.in[0]) keep = true;
+            void *sync = (char *)sync_arena_->ptr() + gb * e;
+            auto state = P.i8;
+            auto dql = D.dql_staged;
+            auto two_launches = P.run;
+            P.run = [state, dql, two_launches, sync, keep](Context &c, const InputList &in) {
+                OutputList out;
+                bool per_channel = false;
+                if (!state->qout_off && i8_fused_form(*state, in, per_channel)) {
+                    if (dql->run_in_producer(c, *state->op, InputList(in.begin(), in.begin() + 4), *in[4], in[5], in[6], state->relu, state->sg, per_channel, sync, keep, out))
+                        return out;
+                    state->qout_off = true;
+                }
+                out = two_launches(c, in);
+                OutputList q = dql->run(c, {&out[0]});
+                for (Tensor &t : q) out.push_back(std::move(t));
+                return out;
+            };
+            P.out.insert(P.out.end(), D.out.begin(), D.out.end());
+            P.kind_name += " + DynamicQuantizeLinear(staged) in one launch";
+            D.removed = true;
+            fused_away_++;
+            qout_edges_++;
         }
     }
     uint64_t graph_ = 0;
@@ -1163,23 +1235,12 @@ class Graph {
                 // (or a per-output-channel [1,O,1,1] / [O,1,1] one, which the kernel applies exactly as Cast -> Mul would) with a
                 // bias of O channels and a residual of the output's shape takes the fused kernel; anything else runs the
                 // operators as the graph spells them.
+                state->relu = relu;
                 st.run = [state, relu](Context &c, const InputList &in) {
                     const Tensor *scale = in[4], *bias = in[5], *residual = in[6];
                     if (!scale) return state->op->run_staged(c, InputList(in.begin(), in.begin() + 4), nullptr, nullptr, nullptr, false, state->sg);
-                    const Tensor &x = require(in, 0), &w = require(in, 1);
-                    bool fused = scale->dtype() == DType::F32 && x.ndim() == 4 && w.ndim() == 4;
-                    int64_t o = fused ? w.size(0) : 0;
                     bool per_channel = false;
-                    if (fused && scale->len() != 1) {
-                        const auto &sh = scale->shape();
-                        per_channel = scale->len() == o && ((sh.size() == 4 && sh[0] == 1 && sh[1] == o) || (sh.size() == 3 && sh[0] == o));
-                        fused = per_channel;
-                    }
-                    if (fused && bias) fused = bias->dtype() == DType::F32 && bias->len() == o && bias->ndim() == 4 && bias->size(1) == o;
-                    if (fused && residual) {
-                        const rten_hip_conv2d_desc d = state->op->conv.geometry(x.shape(), w.shape());
-                        fused = residual->dtype() == DType::F32 && residual->shape() == std::vector<int64_t>{d.n, d.o, d.out_h, d.out_w};
-                    }
+                    const bool fused = i8_fused_form(*state, in, per_channel);
                     if (fused) return state->op->run_staged(c, InputList(in.begin(), in.begin() + 4), scale, bias, residual, relu, state->sg, per_channel);
                     ConvInteger::Staging sg = state->sg;
                     sg.stats_out = nullptr; // statistics are accumulated by the float epilogue only

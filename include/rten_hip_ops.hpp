@@ -1172,6 +1172,46 @@ struct DynamicQuantizeLinearStaged : Operator {
         for (Tensor &t : prods) out.push_back(std::move(t));
         return out;
     }
+
+    // This quantizer INSIDE the launch of the ConvIntegerToFloat step `prod` that produces its input (rten_hip_conv2d_int8_qout: the f32 values never
+    // leave the registers unless `keep_f32` -- a residual Add also reads them).  `in` = prod's X (staged), W, x_zp, w_zp; `sync` = the edge's exchange
+    // block.  out = {prod's f32 output (empty unless keep_f32), codes, scale, zero point[, product]}.  Returns false when the launch form does not
+    // apply (geometry not covered, or more workgroups than the device holds at once: RTEN_HIP_ERR_UNSUPPORTED): run the two operators then.  Opt-in
+    // (launch plan) only: see the time-out contract in rten_hip.h.
+    bool run_in_producer(Context &ctx, const ConvInteger &prod, const InputList &in, const Tensor &scale, const Tensor *bias, const Tensor *residual, bool relu,
+                         const ConvInteger::Staging &sg, bool per_channel_scale, void *sync, bool keep_f32, OutputList &out) const {
+        if (mul_by.size() > 1 || !sync || !sg.stats_out || !sg.x_staged || !sg.packed_weight || !sg.packed_weight->len()) return false;
+        const Tensor &x = require(in, 0), &w = require(in, 1);
+        const Tensor *x_zp = get(in, 2), *w_zp = get(in, 3);
+        rten_hip_conv2d_int8_desc di = prod.desc(x, w, x_zp, w_zp);
+        di.weights_packed = 1;
+        di.x_staged = 1;
+        if (per_channel_scale) di.scale_len = di.conv.o;
+        const std::vector<int64_t> yshape{di.conv.n, di.conv.o, di.conv.out_h, di.conv.out_w};
+        rten_hip_conv2d_int8_desc dn{};
+        dn.conv = consumer.conv.geometry(yshape, kernel);
+        dn.x_signed = 0; dn.w_signed = 1; dn.pad_mode = consumer.pad_mode;
+        const size_t nbytes = rten_hip_conv2d_int8_staged_bytes(&dn);
+        if (!nbytes) return false;
+        if (!mul_by.empty() && (!mul_by[0] || mul_by[0]->len() != 1)) throw OpError(OpError::InvalidValue, "scale should be a scalar");
+        Tensor y(ctx, keep_f32 ? yshape : std::vector<int64_t>{0}, DType::F32);
+        Tensor q(ctx, yshape, DType::U8, nbytes), s(ctx, {}, DType::F32), z(ctx, {}, DType::U8);
+        Tensor pr(ctx, mul_by.empty() ? std::vector<int64_t>{0} : mul_by[0]->shape(), DType::F32);
+        const uint32_t flags = (relu ? RTEN_HIP_CONV_RELU : 0u) | (residual ? RTEN_HIP_CONV_RESIDUAL : 0u);
+        const int32_t rc = rten_hip_conv2d_int8_qout(ctx.raw(), &di, x.ptr(), sg.packed_weight->ptr(), vp(x_zp), vp(w_zp), (const float *)scale.ptr(),
+                                                     (const float *)vp(bias), (const float *)vp(residual), flags, keep_f32 ? (float *)y.ptr() : nullptr, sg.stats_out, sync,
+                                                     &dn, q.ptr(), (float *)s.ptr(), (uint8_t *)z.ptr(), mul_by.empty() ? nullptr : (const float *)mul_by[0]->ptr(),
+                                                     mul_by.empty() ? nullptr : (float *)pr.ptr());
+        if (rc == RTEN_HIP_ERR_UNSUPPORTED) return false;
+        ctx.check(rc);
+        out.clear();
+        out.push_back(std::move(y));
+        out.push_back(std::move(q));
+        out.push_back(std::move(s));
+        out.push_back(std::move(z));
+        if (!mul_by.empty()) out.push_back(std::move(pr));
+        return true;
+    }
 };
 
 // Cast (src/ops/convert.rs): the device path covers what the quantized graphs need, int32 -> float32 (exact conversion with

@@ -28,6 +28,7 @@ namespace {
 struct PlanJson {
     const char *p, *e;
     std::string err;
+    std::map<std::string, std::vector<std::string>> names; // lists of names, by key: the int8 plan's edge lists ({"qout": ["s0b0c1", ...]})
     void ws() { while (p < e && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) p++; }
     bool lit(char c) { ws(); if (p < e && *p == c) { p++; return true; } return false; }
     bool str(std::string &out) {
@@ -68,7 +69,7 @@ struct PlanJson {
                         long long x;
                         std::string sname;
                         ws();
-                        if (p < e && *p == '"') { if (!str(sname)) return false; v.push_back(0); } // (lists of names: the int8 plan's edge lists; skipped here)
+                        if (p < e && *p == '"') { if (!str(sname)) return false; names[key].push_back(sname); v.push_back(0); }
                         else if (!integer(x)) return false;
                         else v.push_back(x);
                     } while (lit(','));
@@ -156,10 +157,13 @@ RTEN_EXPORT int32_t rten_hip_model_load(rten_hip_ctx *ctx, const void *onnx_byte
     g->chains = chains;
     try {
         const onnx::Model m = onnx::parse((const uint8_t *)onnx_bytes, onnx_len);
+        Graph::Options opts;
         if (plan_json && *plan_json) {
             PlanJson pj{plan_json, plan_json + std::strlen(plan_json), {}};
             if (!pj.object(g->plan_flat, g->plan_by_batch)) { delete g.release(); return RTEN_HIP_ERR_INVALID_VALUE; }
             g->have_plan = true;
+            // quantized-output launches are opt-in per edge and need the device to themselves: one chain only
+            if (chains == 1 && pj.names.count("qout")) opts.qout.insert(pj.names["qout"].begin(), pj.names["qout"].end());
         }
         for (int c = 0; c < chains; c++) {
             // chain 0 runs on the CALLER's context (its stream): a model with N chains owns N - 1 streams.  One stream more than chains costs real
@@ -169,8 +173,8 @@ RTEN_EXPORT int32_t rten_hip_model_load(rten_hip_ctx *ctx, const void *onnx_byte
             else g->ctxs.emplace_back(new Context(device_id));
             g->ctxs.back()->enable_pool(true);
             // chains 1.. share chain 0's device constants and prepacked weights (one copy of the weight set per model, as in the Python runner's arena)
-            if (c == 0) g->graphs.emplace_back(new Graph(*g->ctxs.back(), m));
-            else g->graphs.emplace_back(new Graph(*g->ctxs.back(), m, Graph::Options(), *g->graphs[0]));
+            if (c == 0) g->graphs.emplace_back(new Graph(*g->ctxs.back(), m, opts));
+            else g->graphs.emplace_back(new Graph(*g->ctxs.back(), m, opts, *g->graphs[0]));
         }
         g->inputs = g->graphs[0]->inputs();
         g->outputs = g->graphs[0]->outputs();
@@ -193,7 +197,7 @@ RTEN_EXPORT int32_t rten_hip_model_info(const rten_hip_model *g, int32_t *n_inpu
     if (n_inputs) *n_inputs = (int32_t)g->inputs.size();
     if (n_outputs) *n_outputs = (int32_t)g->outputs.size();
     if (n_steps) *n_steps = (int32_t)g->graphs[0]->num_steps();
-    if (n_planned_steps) *n_planned_steps = (int32_t)(g->planned_steps + g->tuned_steps);
+    if (n_planned_steps) *n_planned_steps = (int32_t)(g->planned_steps + g->tuned_steps + g->graphs[0]->num_qout_edges());
     return RTEN_HIP_OK;
 }
 RTEN_EXPORT const char *rten_hip_model_input_name(const rten_hip_model *g, int32_t i) { return (g && i >= 0 && (size_t)i < g->inputs.size()) ? g->inputs[(size_t)i].name.c_str() : nullptr; }

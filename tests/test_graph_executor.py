@@ -577,3 +577,44 @@ def _check_model(m, ctx, x, want, plan, chains):
         got = DeviceTensor(ctx, oshape, np.float32, ptr=optr, keepalive=m).numpy()
         ref_out = want if rep == 0 else want[::-1]
         assert np.array_equal(got.view(np.int32), ref_out.view(np.int32)), (chains, rep)  # (chains of 2 + 2 + 1 images: the lone image keeps the blocked order)
+
+
+@pytest.mark.gpu
+def test_model_abi_int8_quantized_output_edges_from_the_plan_file():
+    """The dynamically quantized ResNet-50 through rten_hip_model_* with the committed int8 plan: the listed edges run the consumer's
+    DynamicQuantizeLinear inside the producing ConvIntegerToFloat launch (opt-in: without a plan file no such launch happens) -- same logits as
+    the oracle, eagerly prepared and replayed, and no launch gave up waiting for its grid."""
+    import json
+    from oracle import models as om
+    from rten_amd import lib as L, onnx_writer as ow
+    from rten_amd.tensor import DeviceTensor
+    from rten_amd.workloads import resnet50
+    w = resnet50.make_weights()
+    x = np.random.default_rng(1234).random((4, 3, 224, 224), dtype=np.float32)
+    want = om.resnet50_int8_forward(resnet50.conv_specs(), om.quantize_weights_int8(w), x)
+    plan = json.load(open(os.path.join(ROOT, "profiles", "plans", "int8.json")))
+    assert len(plan["qout"]) >= 10
+    onnx_bytes = ow.resnet50_int8(w)
+    ctx = L.Context(0)
+    # s0b0c3: a block output -- its f32 tensor is kept for the residual Add; s0b2c3: read by the next stage's shortcut AND first convolution
+    # (two scale products): not an edge
+    more = dict(plan, qout=plan["qout"] + ["s0b0c3"])
+    stage_outputs = {"s0b2c3", "s1b3c3", "s2b5c3"}
+    for text, edges in ((json.dumps(more), len([n for n in more["qout"] if n not in stage_outputs])), (None, 0), (json.dumps({"qout": ["s0b2c3", "no_such_node"]}), 0)):
+        m = L.Model(ctx, onnx_bytes, text, 1)
+        try:
+            xp = m.bind_input("x", x.shape)
+            m.prepare()
+            assert m.planned_steps == edges, (m.planned_steps, edges)
+            xt = DeviceTensor(ctx, x.shape, np.float32, ptr=xp, keepalive=m)
+            for rep in range(3):
+                xt.upload(x if rep != 1 else x[::-1].copy())
+                m.run(inputs_written_on_caller_stream=True)
+                m.sync()  # (fails on the sticky fault of a launch that timed out)
+                optr, oshape = m.output(0)
+                got = DeviceTensor(ctx, oshape, np.float32, ptr=optr, keepalive=m).numpy()
+                ref_out = want if rep != 1 else want[::-1]
+                assert np.array_equal(got.view(np.int32), ref_out.view(np.int32)), (edges, rep)
+        finally:
+            m.close()
+    ctx.close()
