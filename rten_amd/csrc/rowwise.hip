@@ -404,14 +404,27 @@ struct ReduceArgs {
     int64_t ostride[6], istride[6];
 };
 
+// (The outermost kept axis needs no division -- what is left of the row index IS its coordinate -- and a 64-bit division is ~100 instructions on this
+// machine: with one per row the last-axis kernels were division-bound, 10 us for 49152 rows of 128.  32-bit arithmetic whenever the row count allows.)
 __device__ __forceinline__ int64_t reduce_row_base(const ReduceArgs &p, int64_t row) {
-    int64_t r = row, off = 0;
-    for (int d = p.n_outer - 1; d >= 0; d--) {
+    if (p.n_outer <= 0) return 0;
+    int64_t off = 0;
+    if (p.rows <= 0x7fffffff) {
+        unsigned r = (unsigned)row;
+        for (int d = p.n_outer - 1; d > 0; d--) {
+            const unsigned q = r / (unsigned)p.oshape[d];
+            off += (int64_t)(r - q * (unsigned)p.oshape[d]) * p.ostride[d];
+            r = q;
+        }
+        return off + (int64_t)r * p.ostride[0];
+    }
+    int64_t r = row;
+    for (int d = p.n_outer - 1; d > 0; d--) {
         const int64_t q = r / p.oshape[d];
         off += (r - q * p.oshape[d]) * p.ostride[d];
         r = q;
     }
-    return off;
+    return off + r * p.ostride[0];
 }
 
 __device__ __forceinline__ int64_t reduce_elem_off(const ReduceArgs &p, int i) {
@@ -475,8 +488,16 @@ __global__ __launch_bounds__(1024) void reduce_sum_cols_kernel(const ReduceArgs 
     const int lane = threadIdx.x & 63, l = threadIdx.x >> 6, u = lane >> 4, j = lane & 15;
     const int last = p.oshape[p.n_outer - 1];
     const int groups = (last + 15) >> 4;
-    const int64_t prefix = blockIdx.x / groups;
-    const int j0 = (int)(blockIdx.x - prefix * groups) * 16;
+    // Two neighbouring column groups read the two 64-byte halves of the same 128-byte lines.  Workgroup ids go round-robin over the eight XCDs, so
+    // neighbours in id order never share an L2 and every line is fetched twice; here each XCD gets a CONTIGUOUS run of groups (ids id, id + 8, ...
+    // are dispatched to the same XCD one after the other), and the second half of a line is an L2 hit.
+    unsigned bid = blockIdx.x;
+    {
+        const unsigned nt = gridDim.x, xcd = bid & 7, qn = nt >> 3, rn = nt & 7;
+        bid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
+    }
+    const int64_t prefix = bid / groups;
+    const int j0 = (int)(bid - prefix * groups) * 16;
     const int jj = j0 + j < last ? j0 + j : last - 1;
     const int64_t row = prefix * last + jj;
     const float *xr = x + reduce_row_base(p, row);
@@ -485,6 +506,13 @@ __global__ __launch_bounds__(1024) void reduce_sum_cols_kernel(const ReduceArgs 
     // first add -- a load per add made this kernel one memory round trip per element (31.5 us for 4096 x 3072 -> 3072: round 3).
     float acc = 0.f;
     int c = 0;
+    for (; c + 16 <= full4; c += 16) {
+        float tv[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) tv[k] = xr[reduce_elem_off(p, (c + k) * 64 + u * 16 + l)];
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc = acc + tv[k];
+    }
     for (; c + 8 <= full4; c += 8) {
         float tv[8];
 #pragma unroll

@@ -365,6 +365,8 @@ def test_gpu_reduce_sum_strided_matches_oracle(ctx):
                         ((129, 64), [1]), ((129, 65), [1]), ((5, 1, 9), [1]), ((6, 0, 4), [1]), ((2, 3, 4, 5, 6, 7), [1, 3, 5]),
                         # every branch of the 16-lane order on the four-rows-per-wave path (1..256 elements) and just above it
                         *[((37, n), [1]) for n in (1, 15, 16, 17, 63, 64, 65, 79, 80, 127, 128, 129, 191, 192, 193, 255, 256, 257, 300)],
+                        # contiguous slices of 64 / 128 / 256 with ragged row counts and kept prefix axes
+                        ((1000, 256), [1]), ((3, 50, 64), [2]), ((4, 70, 128), [2]), ((2, 3, 5, 128), [3]), ((1, 128), [1]),
                         # column sums (coalesced kernel): whole and ragged groups of 16 columns, chunk / vector / tail boundaries,
                         # a kept prefix axis, two reduced axes of which the inner one is strided
                         *[((n, c), [0]) for n in (65, 128, 143, 144, 150, 1000) for c in (16, 17, 100)],

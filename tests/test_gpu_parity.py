@@ -725,6 +725,14 @@ def test_pooling_bit_exact(ctx):
         for cip in (False, True):
             bits_equal(ops.AveragePool(k, padding=list(p), strides=s, ceil_mode=ceil, count_include_pad=cip).run(ctx, [dev(ctx, x)])[0].numpy(),
                        ref.average_pool(x, k, s, p, cip, ceil))
+    # the stem pool's form (3x3, stride 2, left padding 1, even width): paired 8-byte loads + the neighbour lane's value; planes whose work items
+    # do not fill whole workgroups (the workgroup size follows the plane)
+    for shape, p in (((2, 3, 20, 22), (1, 1, 1, 1)), ((1, 2, 112, 112), (1, 1, 1, 1)), ((1, 3, 18, 140), (0, 1, 1, 0)), ((2, 2, 9, 6), (1, 1, 0, 1))):
+        xe = rng.f32(int(np.prod(shape))).reshape(shape) - 0.5
+        bits_equal(ops.MaxPool((3, 3), padding=list(p), strides=(2, 2)).run(ctx, [dev(ctx, xe)])[0].numpy(), ref.max_pool(xe, (3, 3), (2, 2), p, False))
+        for cip in (False, True):
+            bits_equal(ops.AveragePool((3, 3), padding=list(p), strides=(2, 2), count_include_pad=cip).run(ctx, [dev(ctx, xe)])[0].numpy(),
+                       ref.average_pool(xe, (3, 3), (2, 2), p, cip, False))
     for inner in ((7, 7), (1, 1), (4, 4), (9, 9), (30, 30)):
         xg = rng.f32(2 * 10 * inner[0] * inner[1]).reshape(2, 10, *inner)
         bits_equal(ops.GlobalAveragePool().run(ctx, [dev(ctx, xg)])[0].numpy(), ref.global_average_pool(xg, lanes=16))

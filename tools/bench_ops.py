@@ -149,9 +149,16 @@ def main():
         keep = fn()  # held by the closure: the graph's output buffer is not handed out again while it is replayed
         g = ctx.graph_end()
         return lambda keep=keep: ctx.graph_launch(g)
-    hbm("ReduceSum last axis", "49152x128", graphed(lambda: rs_last.run(ctx, [xr])), 4.0 * (49152 * 128 + 49152))
+    # (these two straight through the C entry, like the other single-kernel rows: the replay of a ONE-kernel hipGraph has a ~9.6 us floor of its
+    # own, which is what rounds 2-3 reported for the last-axis sum whatever its kernel did)
+    i64 = lambda *v: (C.c_int64 * len(v))(*v)
+    yr = empty((49152,))
+    hbm("ReduceSum last axis", "49152x128", (lambda: ctx.call("rten_hip_reduce_sum_strided_f32", 1, i64(49152), i64(128), 1, i64(128), i64(1), xr.vp, yr.vp)),
+        4.0 * (49152 * 128 + 49152))
     xc = dev(rng.standard_normal((4096, 3072), dtype=np.float32))
-    hbm("ReduceSum strided axis", "4096x3072 -> 3072", graphed(lambda: rs_first.run(ctx, [xc])), 4.0 * (4096 * 3072 + 3072))
+    yc = empty((3072,))
+    hbm("ReduceSum strided axis", "4096x3072 -> 3072", (lambda: ctx.call("rten_hip_reduce_sum_strided_f32", 1, i64(3072), i64(1), 1, i64(4096), i64(3072), xc.vp, yc.vp)),
+        4.0 * (4096 * 3072 + 3072))
     Be, Se, He, De = 32, 128, 12, 64
     qe, ke, ve = (dev(rng.standard_normal((Be, Se, He, De), dtype=np.float32)) for _ in range(3))
     pe = dev(rng.standard_normal((Be, He, Se, Se), dtype=np.float32))
