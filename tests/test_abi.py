@@ -283,3 +283,11 @@ def test_rust_ops_repeat_the_reference_error_messages():
                 "Cannot broadcast c to output shape"]:
         assert msg in rs, msg
         assert msg in cpp or msg in py, msg
+
+
+def test_graft_entry_build_compares_the_library_with_the_header_version():
+    # build() once asserted a literal version and would have failed the driver's build check after the ABI bump
+    import inspect
+    import __graft_entry__ as g
+    src = inspect.getsource(g.build)
+    assert "RTEN_HIP_ABI_VERSION" in src and "abi_version() == 2" not in src and "abi_version() == 3" not in src
