@@ -2359,6 +2359,8 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
     if (pipe == 6 && !(AL == A_M4 && BM == 64 && BN == 64)) pipe = 1; // the wave-tile kernels: prepacked weights, 64x64 tiles
     if (pipe == 6 && ctx->wave_flavour >= 4 && BL != B_N4) pipe = 1;   // 32x32 wave tiles: dense B only
     if (pipe == 7 && !(BM == 64 && BN == 64)) pipe = 1;                // the two-stage ring exists for 64x64 tiles
+    const bool want_patch = pipe == 8 && AL == A_M4 && BM == 64 && BN == 64 && (BL == B_IM2COL || BL == B_IM2COL_TAPS) && ctx->split_mode < 4; // (split modes 4..6 are kernels of their own)
+    if (pipe == 8 && !want_patch) pipe = 1;                            // the patch kernels: prepacked weights, 64x64 tiles, im2col B; anything else (and a launch they refuse) runs variant 3
     if constexpr (BL == B_IM2COL_TAPS) {
         if (pipe == 0) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "internal: tap-mask im2col needs an LDS-DMA pipeline");
     }
@@ -2401,6 +2403,15 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
                 snprintf(kname, sizeof kname, "igemm_f32_wave_kernel<%d,%d,%d>", BL, mode, ctx->wave_flavour);
                 ProfScope ps(ctx, kname, fl, by);
                 return rten_launch_gemm_f32_wave(ctx, &a, gx, (unsigned)Z, BL, mode, ctx->wave_flavour);
+            }
+            if constexpr (BL == B_IM2COL || BL == B_IM2COL_TAPS) {
+                if (pipe == 8) { // image patches instead of per-element gathers (gemm_f32_patch.hip): 3x3 / stride 1 / padding 1 only
+                    snprintf(kname, sizeof kname, "igemm_f32_patch_kernel<%d>", mode);
+                    ProfScope ps(ctx, kname, fl, by);
+                    const int32_t rc = rten_launch_gemm_f32_patch(ctx, &a, gx, (unsigned)Z, mode);
+                    if (rc != RTEN_HIP_ERR_UNSUPPORTED) return rc;
+                    pipe = 1; // a geometry the patch family does not cover: the three-stage LDS-DMA kernel
+                }
             }
         }
         TRACE_ASSIGN(a, gx * (unsigned)Z);
@@ -2601,7 +2612,7 @@ int32_t launch_variant(rten_hip_ctx *ctx, GemmArgs &a, int Z, int cfg) {
 }
 
 int pick_cfg(rten_hip_ctx *ctx, int M, long long N, int Z) {
-    if (ctx->gemm_variant_override >= 24 && ctx->gemm_variant_override < 30) return 3; // wave-tile kernels (24..26, 28..29) and the two-stage ring (27): 64x64 plans
+    if (ctx->gemm_variant_override >= 24 && ctx->gemm_variant_override < 31) return 3; // wave-tile kernels (24..26, 28..29), the two-stage ring (27), image patches (30): 64x64 plans
     if (ctx->gemm_variant_override >= 0 && ctx->gemm_variant_override < 24) return ctx->gemm_variant_override & 3;
     int best = 3;
     double best_cost = 1e300;
@@ -2644,14 +2655,15 @@ constexpr long long kMaxBufBytes = 0x7fffffffll; // buffer offsets are 32-bit; t
 // operand layouts always use the register-staged kernel.
 // Variants 16..19: LDS-DMA, fragments-first MFMA issue; variants 20..23: LDS-DMA on 16x16x4 MFMAs.
 // Variants 24..26: one wave per 64x64 tile (gemm_f32_wave.hip), k-tiles x LDS stages = 16 x 2, 8 x 4, 16 x 3; 27: 64x64 LDS-DMA with TWO stages;
-// 28..29: one wave per 32x32 tile (barrier-free form of the 64x64 / 4-wave granularity; dense B), 16 x 2 and 16 x 3.
-RTEN_EXPORT int32_t rten_hip_num_gemm_variants(void) { return 30; }
+// 28..29: one wave per 32x32 tile (barrier-free form of the 64x64 / 4-wave granularity; dense B), 16 x 2 and 16 x 3;
+// 30: 3x3 / stride 1 / padding 1 convolutions with B staged as image patches (gemm_f32_patch.hip); every other launch runs as variant 3.
+RTEN_EXPORT int32_t rten_hip_num_gemm_variants(void) { return 31; }
 
 RTEN_EXPORT int32_t rten_hip_set_gemm_variant_override(rten_hip_ctx *ctx, int32_t variant) {
     RTEN_CHECK_CTX(ctx);
     ctx->gemm_variant_override = variant;
     ctx->wave_flavour = (variant >= 24 && variant < 27) ? variant - 24 : (variant >= 28 && variant < 30) ? variant - 24 : 0;
-    ctx->pipeline = variant == 27 ? 7 : (variant >= 24 && variant < 30) ? 6 : (variant >= 20 && variant < 24) ? 5 : (variant >= 16 && variant < 20) ? 4 : (variant >= 12 && variant < 16) ? 3 : (variant >= 8 && variant < 12) ? 2 : ((variant >= 4 && variant < 8) ? 0 : 1);
+    ctx->pipeline = variant == 30 ? 8 : variant == 27 ? 7 : (variant >= 24 && variant < 30) ? 6 : (variant >= 20 && variant < 24) ? 5 : (variant >= 16 && variant < 20) ? 4 : (variant >= 12 && variant < 16) ? 3 : (variant >= 8 && variant < 12) ? 2 : ((variant >= 4 && variant < 8) ? 0 : 1);
     return RTEN_HIP_OK;
 }
 

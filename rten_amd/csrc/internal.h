@@ -89,6 +89,8 @@ int32_t rten_gemm_f32_blocked(rten_hip_ctx *ctx, const rten_hip_gemm_desc *d, co
 void *rten_aux_scratch(rten_hip_ctx *ctx, size_t bytes);
 // gemm_f32_wave.hip: one launch of the wave-tile kernels; `args` = the caller's GemmArgs (gemm_f32_common.h)
 int32_t rten_launch_gemm_f32_wave(rten_hip_ctx *ctx, const void *args, unsigned grid_x, unsigned grid_z, int bl, int mode, int flavour);
+// gemm_f32_patch.hip: 3x3 / stride 1 / padding 1 convolutions with B staged as image patches; RTEN_HIP_ERR_UNSUPPORTED when the launch is not covered
+int32_t rten_launch_gemm_f32_patch(rten_hip_ctx *ctx, const void *args, unsigned grid_x, unsigned grid_z, int mode);
 
 // Profiling bracket around one kernel launch.
 struct ProfScope {

@@ -431,7 +431,7 @@ def test_conv_f32_split_k_bit_exact(ctx, shape):
     want = ref.conv2d_f32(x, w, b, pads=(pad,) * 4, strides=(s, s), residual=res, relu=True)
     nblk = (Cc * k * k + 255) // 256
     try:
-        for v in (0, 1, 2, 3, 24, 25, 26):  # 24..26: one wave per 64x64 tile (gemm_f32_wave.hip)
+        for v in (0, 1, 2, 3, 24, 25, 26, 30):  # 24..26: one wave per 64x64 tile (gemm_f32_wave.hip); 30: image patches (gemm_f32_patch.hip)
             for mode in (1, 2):
                 for groups in sorted({2, 3, nblk}):
                     ctx.call("rten_hip_set_gemm_split", mode, groups)
