@@ -49,7 +49,7 @@ extern "C" {
 #endif
 
 /* v3 (round 4): + rten_hip_model_* (the plan executor behind the C ABI), rten_hip_set_gemm_order bits 4-6 (occupancy cap),
- * GEMM variants 24-26 (one wave per tile), sticky device fault reported by rten_hip_sync / rten_hip_graph_launch.  v2 (round 3) had added
+ * GEMM variants 24-30 (one wave per tile, two-stage ring, image patches), sticky device fault reported by rten_hip_sync / rten_hip_graph_launch.  v2 (round 3) had added
  * rten_hip_graph_abort, rten_hip_conv2d_int8_qout, rten_hip_grid_sync_*, rten_hip_dynamic_quantize_linear_staged_products, rten_hip_max_pool2d_f32_stats and
  * rten_hip_set_sdpa_path mode 2 WITHOUT a bump: a binding built against this header must refuse a library whose rten_hip_abi_version() differs. */
 #define RTEN_HIP_ABI_VERSION 3
