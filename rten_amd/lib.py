@@ -407,8 +407,10 @@ class Model:
         self._check(self.lib.rten_hip_model_info(self.h, C.byref(ni), C.byref(no), C.byref(ns), C.byref(npl)))
         self.planned_steps = npl.value
 
-    def run(self, inputs_written_on_caller_stream: bool = False):
-        self._check(self.lib.rten_hip_model_run(self.h, 1 if inputs_written_on_caller_stream else 0))
+    def run(self, inputs_written_on_caller_stream: bool = False, join: bool = True):
+        """`join=False`: the caller's stream is not ordered behind the chains (flags bit 1) -- back-to-back runs then let the chains free-run
+        across run boundaries; call sync() before reading the outputs."""
+        self._check(self.lib.rten_hip_model_run(self.h, (1 if inputs_written_on_caller_stream else 0) | (0 if join else 2)))
 
     def sync(self):
         self._check(self.lib.rten_hip_model_sync(self.h))

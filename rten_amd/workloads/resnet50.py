@@ -427,18 +427,24 @@ class ChainedResNet50:
         self.graph = [net.graph for net in self.nets]
         return self.graph
 
-    def run(self):
+    def run(self, join=True):
+        """One step: every chain's graph on its own stream.  `join=True` orders the main context behind all chains (the logits are read there).
+        `join=False` leaves that out: chain 0 runs ON the main context, so a per-step join makes it wait for the slowest chain before its next
+        step -- a barrier between steps.  A caller that enqueues K steps back to back (bench.py's timed region) joins once, with join()."""
         if not self.graph:
             return self.forward()
-        main = self.ctx
         used = [self.pool[p] for p in self.place]
-        # no wait on the main context here: uploads through the C ABI are host-synchronous, and a per-step wait would turn the
-        # main stream into a barrier between steps (the chains may run ahead of each other across steps)
+        # no wait on the main context BEFORE the launches: uploads through the C ABI are host-synchronous
         for g, c in zip(self.graph, used):
             c.graph_launch(g)
-        for c in used:
-            if c is not main:
-                main.wait(c)  # the logits are read on the main context
+        if join:
+            self.join()
+
+    def join(self):
+        """Order the main context behind everything enqueued on the chains so far."""
+        for c in (self.pool[p] for p in self.place):
+            if c is not self.ctx:
+                self.ctx.wait(c)
 
     def _time_steps(self, steps):
         import time
