@@ -13,9 +13,10 @@
 //!     device copy lives in the OPERATOR INSTANCE that uses it (`ConstCache`, one slot per input): an operator belongs to one
 //!     graph, so the copies die with the model that owns them, and a slot is re-staged if the constant behind it is ever a
 //!     different allocation (graph constants do not move while the model is alive -- `Graph` owns them, src/graph.rs:488-562);
-//!   * activations cross PCIe per operator in this drop-in form.  The residency-aware executor of SURVEY 8(f) rank 1 (values
-//!     stay in HBM between operators) needs a `Value::Device` variant, i.e. a change to the reference; it is built and measured
-//!     in this repository as include/rten_hip_graph.hpp and is the "next" step of the Rust integration, not part of it.
+//!   * activations cross PCIe per operator in this drop-in form.  Residency (values stay in HBM between operators, SURVEY 8(f)
+//!     rank 1) would need a `Value::Device` variant -- a change to the reference -- at operator granularity; at SUBGRAPH granularity
+//!     it needs nothing: `HipSubgraph` (subgraph.rs) is one `Operator` that owns the C++ plan executor behind the C ABI
+//!     (`rten_hip_model_*`), the path `bench.py --via-executor` measures.
 //!   * one `HipContext` may be shared by every thread that calls `Model::run(&self)`: the C ABI locks per call.
 //!
 //! Registration (what a user writes):
@@ -31,6 +32,8 @@
 //! Two additions to the reference, both listed in INTEGRATION.md section 2.1: `ModelOptions::set_operator_rewriter` and the accessors
 //! `ConvIntegerToFloat::conv()` / `MatMulIntegerToFloat::matmul()` for fields that are private today.
 mod ops;
+mod subgraph;
+pub use subgraph::HipSubgraph;
 
 use std::collections::HashMap;
 use std::ffi::{c_void, CStr};

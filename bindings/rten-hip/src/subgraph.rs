@@ -1,0 +1,128 @@
+//! `HipSubgraph`: ONE `Operator` that owns a whole device-resident subgraph.
+//!
+//! The per-operator drop-in of ops.rs moves every activation across PCIe twice.  Keeping values in HBM between operators would need a
+//! `Value::Device` variant -- a change to the reference -- unless a maximal run of accelerated nodes is handed to the backend as a single
+//! operator: the reference's own precedent for an operator that owns a graph is `SubgraphOperator` (src/operator.rs:630-646; `If` / `Loop`).
+//! The graph behind this operator is the C++ plan executor exported through the C ABI as `rten_hip_model_*` (include/rten_hip.h;
+//! rten_amd/csrc/graph_abi.cpp): ONNX bytes in, constants uploaded and prepacked once, the reference's fusions applied, a committed launch plan
+//! (profiles/plans/*.json) by step name, the batch run as `chains` independent dim-0 slices on their own streams, each a hipGraph.  `bench.py
+//! --via-executor` measures exactly this path (ResNet-50 f32 batch 32: 2.69 ms; the hand-planned runner: 2.68 ms; same logits).
+//!
+//! NOT COMPILED in the build image -- see lib.rs.  tests/test_abi.py checks that every `sys::` name used here exists in the generated -sys crate
+//! with the arity used.
+use std::ffi::{c_void, CStr, CString};
+use std::ptr;
+use std::sync::{Arc, Mutex};
+
+use rten::ops::{OpError, OpRunContext, Operator, OutputList, OutputType, OutputTypeList, OutputTypesContext};
+use rten::{DataType, ValueType};
+use rten_hip_sys as sys;
+use rten_tensor::prelude::*;
+use rten_tensor::{Tensor, TensorView};
+
+use crate::HipContext;
+
+/// One bound input: its name in the subgraph, the FULL-batch shape it was bound with and where the backend wants its bytes.
+#[derive(Debug)]
+struct BoundInput {
+    name: String,
+    shape: Vec<usize>,
+    dev: *mut c_void,
+}
+
+/// A resident subgraph as an operator.  Inputs are f32 tensors of the shapes given to `load` (a static plan: the launch plan, the buffer
+/// plan and the captured hipGraphs are per shape); outputs are f32.
+#[derive(Debug)]
+pub struct HipSubgraph {
+    model: *mut sys::rten_hip_model,
+    hip: Arc<HipContext>, // chain 0 runs on this context's stream: the context must outlive the model (rten_hip.h), which this Arc guarantees
+    inputs: Vec<BoundInput>,
+    n_outputs: usize,
+    run_lock: Mutex<()>, // the model object is not thread-safe (one caller at a time); `Model::run(&self)` may be called from several threads
+}
+unsafe impl Send for HipSubgraph {}
+unsafe impl Sync for HipSubgraph {}
+
+impl HipSubgraph {
+    /// `onnx`: the serialized `ModelProto` of the subgraph (the loader already holds the bytes).  `plan_json`: a launch-plan file
+    /// (`{step: [variant, split mode, K groups, order]}`, optionally keyed by sub-batch size; `{"qout": [...]}` opts int8 edges into the
+    /// quantized-output launch) or `None` for the backend's defaults.  `chains`: independent dim-0 slices run side by side (4 for the f32
+    /// ResNet-50 at batch 32; 1 for dynamically quantized graphs, whose DynamicQuantizeLinear statistics span the batch).
+    pub fn load(hip: Arc<HipContext>, onnx: &[u8], plan_json: Option<&str>, chains: i32, input_shapes: &[(&str, Vec<usize>)]) -> Result<Self, OpError> {
+        let plan = plan_json.map(|p| CString::new(p).map_err(|_| OpError::InvalidValue("launch plan contains a NUL byte"))).transpose()?;
+        let mut model: *mut sys::rten_hip_model = ptr::null_mut();
+        hip.check(unsafe {
+            sys::rten_hip_model_load(hip.raw(), onnx.as_ptr() as *const c_void, onnx.len(), plan.as_ref().map_or(ptr::null(), |p| p.as_ptr()), chains, 0, &mut model)
+        })?;
+        let mut this = HipSubgraph { model, hip, inputs: Vec::new(), n_outputs: 0, run_lock: Mutex::new(()) };
+        let (mut n_in, mut n_out, mut n_steps, mut n_planned) = (0i32, 0i32, 0i32, 0i32);
+        this.check(unsafe { sys::rten_hip_model_info(this.model, &mut n_in, &mut n_out, &mut n_steps, &mut n_planned) })?;
+        this.n_outputs = n_out as usize;
+        for i in 0..n_in {
+            let name = unsafe { CStr::from_ptr(sys::rten_hip_model_input_name(this.model, i)) }.to_string_lossy().into_owned();
+            let shape = input_shapes.iter().find(|(n, _)| *n == name).map(|(_, s)| s.clone()).ok_or(OpError::MissingInputs)?;
+            let dims: Vec<i64> = shape.iter().map(|&d| d as i64).collect();
+            let mut dev: *mut c_void = ptr::null_mut();
+            this.check(unsafe { sys::rten_hip_model_bind_input(this.model, i, dims.as_ptr(), dims.len() as i32, &mut dev) })?;
+            this.inputs.push(BoundInput { name, shape, dev });
+        }
+        this.check(unsafe { sys::rten_hip_model_prepare(this.model, 0) })?; // buffers planned, launch plan applied, one hipGraph per chain captured
+        Ok(this)
+    }
+
+    /// The backend's status codes as `OpError`s, with the model's own message where it has one (the text is logged: `OpError` carries
+    /// `&'static str`s).
+    fn check(&self, status: i32) -> Result<(), OpError> {
+        if status != 0 {
+            let msg = unsafe { CStr::from_ptr(sys::rten_hip_model_last_error(self.model)) }.to_string_lossy().into_owned();
+            if !msg.is_empty() { eprintln!("rten-hip: subgraph: {msg}"); }
+        }
+        self.hip.check(status)
+    }
+}
+
+impl Drop for HipSubgraph {
+    fn drop(&mut self) {
+        unsafe { sys::rten_hip_model_destroy(self.model) }; // before `hip` (a field) is released
+    }
+}
+
+impl Operator for HipSubgraph {
+    fn name(&self) -> &str { "HipSubgraph" }
+    fn max_inputs(&self) -> Option<usize> { Some(self.inputs.len()) }
+    fn max_outputs(&self) -> Option<usize> { Some(self.n_outputs) }
+    fn output_types(&self, _ctx: &OutputTypesContext) -> Option<OutputTypeList> {
+        Some((0..self.n_outputs).map(|_| OutputType::Fixed(ValueType::Tensor(DataType::Float))).collect())
+    }
+
+    fn run(&self, ctx: &OpRunContext) -> Result<OutputList, OpError> {
+        let _one_at_a_time = self.run_lock.lock().unwrap();
+        // inputs -> device, once (host-synchronous copies: no ordering flag needed for the run)
+        for (i, b) in self.inputs.iter().enumerate() {
+            let x: TensorView<f32> = ctx.inputs().require_as(i)?;
+            if x.shape() != b.shape.as_slice() {
+                eprintln!("rten-hip: subgraph input \"{}\" was bound with another shape", b.name);
+                return Err(OpError::IncompatibleInputShapes("Input shape does not match the shape the subgraph was planned for"));
+            }
+            let host = x.to_contiguous_in(ctx.pool());
+            let data = host.data().ok_or(OpError::InvalidValue("input is not contiguous"))?;
+            self.hip.check(unsafe { sys::rten_hip_memcpy_h2d(self.hip.raw(), b.dev, data.as_ptr() as *const c_void, std::mem::size_of_val(data)) })?;
+        }
+        // every chain replays its hipGraph; the caller's stream is ordered behind them (flags 0), then waited for
+        self.check(unsafe { sys::rten_hip_model_run(self.model, 0) })?;
+        self.check(unsafe { sys::rten_hip_model_sync(self.model) })?; // also reports a sticky device fault (rten_hip.h)
+        // outputs -> host, once
+        let mut out = OutputList::new();
+        for i in 0..self.n_outputs {
+            let (mut dev, mut shape, mut ndim): (*const c_void, [i64; 8], i32) = (ptr::null(), [0; 8], 0);
+            self.check(unsafe { sys::rten_hip_model_output(self.model, i as i32, &mut dev, shape.as_mut_ptr(), &mut ndim) })?;
+            let dims: Vec<usize> = shape[..ndim as usize].iter().map(|&d| d as usize).collect();
+            let len: usize = dims.iter().product();
+            let mut data: Vec<f32> = ctx.pool().alloc(len);
+            data.resize(len, 0.0);
+            self.hip.check(unsafe { sys::rten_hip_memcpy_d2h(self.hip.raw(), data.as_mut_ptr() as *mut c_void, dev, len * 4) })?;
+            out.push(Tensor::from_data(&dims, data).into());
+        }
+        Ok(out)
+    }
+}

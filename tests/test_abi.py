@@ -237,7 +237,7 @@ def test_rust_ops_call_only_declared_abi_symbols_with_the_declared_arity():
         decl[m.group(1)] = len([a for a in m.group(2).split(",") if a.strip()])
     consts = set(re.findall(r"pub const (RTEN_HIP_[A-Z0-9_]+):", sys_text))
     structs = set(re.findall(r"pub struct (rten_hip_[a-z0-9_]+)", sys_text))
-    for path in (OPS_RS, os.path.join(ROOT, "bindings", "rten-hip", "src", "lib.rs")):
+    for path in (OPS_RS, os.path.join(ROOT, "bindings", "rten-hip", "src", "lib.rs"), os.path.join(ROOT, "bindings", "rten-hip", "src", "subgraph.rs")):
         text = open(path).read()
         text = re.sub(r"//[^\n]*", "", text)
         for m in re.finditer(r"sys::(\$entry|\$flat|rten_hip_[a-z0-9_]+|RTEN_HIP_[A-Z0-9_]+)", text):
@@ -291,3 +291,23 @@ def test_graft_entry_build_compares_the_library_with_the_header_version():
     import __graft_entry__ as g
     src = inspect.getsource(g.build)
     assert "RTEN_HIP_ABI_VERSION" in src and "abi_version() == 2" not in src and "abi_version() == 3" not in src
+
+
+def test_integration_md_names_only_symbols_the_header_declares():
+    """INTEGRATION.md is what a maintainer reads: every `rten_hip_*` function it names must exist in include/rten_hip.h (section 2.5 once kept the
+    working names of the executor's entry points after they had been renamed), and the `HipSubgraph` operator it describes must exist in the crate."""
+    header = open(os.path.join(ROOT, "include", "rten_hip.h")).read()
+    declared = set(re.findall(r"\b(rten_hip_[a-z0-9_]+)\s*\(", header)) | set(re.findall(r"\b(rten_hip_[a-z0-9_]+)\b", re.sub(r"/\*.*?\*/", "", header, flags=re.S)))
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    crates = {"rten_hip_sys", "rten_hip_ops", "rten_hip_graph", "rten_hip_run", "rten_hip_safetensors", "rten_hip_h"}
+    for name in sorted(set(re.findall(r"\b(rten_hip_[a-z0-9_]+)\b", text))):
+        if name in crates or name.endswith("_hpp") or name in ("rten_hip_model_",):
+            continue
+        if name.endswith("_"):  # a family prefix written as `rten_hip_model_*`
+            assert any(d.startswith(name) for d in declared), name
+            continue
+        assert name in declared, f"INTEGRATION.md names {name}, which include/rten_hip.h does not declare"
+    sub = open(os.path.join(ROOT, "bindings", "rten-hip", "src", "subgraph.rs")).read()
+    assert "impl Operator for HipSubgraph" in sub and "pub use subgraph::HipSubgraph" in open(os.path.join(ROOT, "bindings", "rten-hip", "src", "lib.rs")).read()
+    for fn in ("load", "bind_input", "prepare", "run", "sync", "output", "destroy"):
+        assert f"sys::rten_hip_model_{fn}(" in sub, fn
