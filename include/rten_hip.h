@@ -48,11 +48,17 @@
 extern "C" {
 #endif
 
-/* v3 (round 4): + rten_hip_model_* (the plan executor behind the C ABI), rten_hip_set_gemm_order bits 4-6 (occupancy cap),
+/* v4 (round 5): + rten_hip_device_id, rten_hip_tuning_save / _restore (a library-level caller on a borrowed context puts the owner's knobs back),
+ * rten_hip_model_load_ex (device taken from the context; RTEN_HIP_MODEL_RECEIVE_WEIGHTS), rten_hip_model_load_error, rten_hip_model_weight_arena (one
+ * allocation for every constant of a model: the unit of the one-time RCCL broadcast), plan files may carry {"fused_dql": [...]}, "qout" edges may have
+ * several scale products, rten_hip_model_load validates device_id, rten_hip_grid_sync_reset refuses to run inside a capture, scratch buffers a live
+ * hipGraph replays from are retired instead of freed, rten_hip_set_gemm_order bit 3 (relaxed split-K: one partial per K group -- NOT bit-exact, tuning /
+ * measurement only).
+ * v3 (round 4): + rten_hip_model_* (the plan executor behind the C ABI), rten_hip_set_gemm_order bits 4-6 (occupancy cap),
  * GEMM variants 24-30 (one wave per tile, two-stage ring, image patches), sticky device fault reported by rten_hip_sync / rten_hip_graph_launch.  v2 (round 3) had added
  * rten_hip_graph_abort, rten_hip_conv2d_int8_qout, rten_hip_grid_sync_*, rten_hip_dynamic_quantize_linear_staged_products, rten_hip_max_pool2d_f32_stats and
  * rten_hip_set_sdpa_path mode 2 WITHOUT a bump: a binding built against this header must refuse a library whose rten_hip_abi_version() differs. */
-#define RTEN_HIP_ABI_VERSION 3
+#define RTEN_HIP_ABI_VERSION 4
 
 /* ---- status codes (map onto OpError variants, src/operator.rs:116-144) ---- */
 #define RTEN_HIP_OK 0
@@ -79,6 +85,8 @@ int32_t rten_hip_abi_version(void);
  * RTEN_HIP_ERR_HIP on every call until rten_hip_grid_sync_reset. */
 int32_t rten_hip_sync(rten_hip_ctx *ctx);
 /* Device properties used by the measurement harness. */
+/* the device the context was created on (-1: NULL context) */
+int32_t rten_hip_device_id(const rten_hip_ctx *ctx);
 int32_t rten_hip_device_info(rten_hip_ctx *ctx, char *name_buf, int32_t name_len, int32_t *compute_units,
                              int32_t *clock_mhz, int64_t *total_mem_bytes);
 
@@ -489,9 +497,28 @@ int32_t rten_hip_model_prepare(rten_hip_model *model, int32_t tune);
 /* flags bit 0: the inputs were written on the caller context's stream since the last run (the chains wait for it first); bit 1: do not order the
  * caller's stream after the chains (the caller calls rten_hip_model_sync before reading the outputs). */
 int32_t rten_hip_model_run(rten_hip_model *model, uint32_t flags);
+/* rten_hip_model_load with the device taken from `ctx` (every chain is created on the context's device) and load flags.
+ * RTEN_HIP_MODEL_RECEIVE_WEIGHTS: this process RECEIVES the weight arena -- rank != 0 of a batch-sharded job: initializers of 64 KB
+ * and more are allocated but not uploaded; the caller then fills rten_hip_model_weight_arena() by rten_hip_broadcast from the rank that loaded the
+ * model without the flag, BEFORE rten_hip_model_prepare.  The arena is one device allocation that holds every constant of the model (initializers,
+ * constants derived at load time, prepacked conv / MatMul weights); its layout depends only on the model bytes, the plan file and the chain count,
+ * so every rank computes the same one.
+ * rten_hip_model_load_error: why the calling thread's last rten_hip_model_load / _load_ex failed (parse error, operator outside the registry, bad plan
+ * file, a batch-coupled graph with chains > 1, ...): a failed load has no model object to ask. */
+#define RTEN_HIP_MODEL_RECEIVE_WEIGHTS 1u
+int32_t rten_hip_model_load_ex(rten_hip_ctx *ctx, const void *onnx_bytes, size_t onnx_len, const char *plan_json /* optional */, int32_t chains,
+                               uint32_t flags, rten_hip_model **out_model);
+const char *rten_hip_model_load_error(void);
+int32_t rten_hip_model_weight_arena(rten_hip_model *model, void **dev_ptr, size_t *bytes);
 int32_t rten_hip_model_sync(rten_hip_model *model);
 int32_t rten_hip_model_output(rten_hip_model *model, int32_t i, const void **dev_ptr, int64_t *shape /* 8 entries */, int32_t *ndim);
 int32_t rten_hip_model_destroy(rten_hip_model *model);
+
+/* ---- tuning knobs are sticky per context.  save / restore snapshot all of them (GEMM variant override, split-K plan, tile order, gemv order and its
+ * thread assumption, int8 path, attention path): code that changes knobs around its own launches on a context it does not own restores the owner's
+ * settings, not the defaults. */
+int32_t rten_hip_tuning_save(rten_hip_ctx *ctx, int32_t state[8]);
+int32_t rten_hip_tuning_restore(rten_hip_ctx *ctx, const int32_t state[8]);
 
 /* ---- tuning: per-shape kernel-variant selection by measurement at load time ----
  * variant < 0 restores the built-in heuristic.  Used by the harness's autotuner. */

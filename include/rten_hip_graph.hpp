@@ -298,6 +298,13 @@ class Graph {
         // runs the DynamicQuantizeLinear of the one convolution reading its output (rten_hip_conv2d_int8_qout).  That launch needs the device to
         // itself (all its workgroups resident at once; rten_hip.h states the time-out contract), so it is never a default.
         std::set<std::string> qout;
+        // Opt-in, per layer (profiles/plans/int8.json "fused_dql"): pointwise ConvInteger nodes, by name, whose fused ConvIntegerToFloat step runs its
+        // DynamicQuantizeLinear inside its own operand loader (rten_hip_conv2d_int8_dql) instead of reading the staged codes.
+        std::set<std::string> fused_dql;
+        // A rank that RECEIVES the weight arena (coalesce_constants() + one broadcast from the rank that loaded the file for real): initializers of
+        // 64 KB and more are allocated but not uploaded.  Everything derived from them on the device (prepacked weights) is computed on whatever the
+        // buffers hold and overwritten by the broadcast, which covers every constant buffer of the graph.
+        bool skip_large_uploads = false;
     };
     struct Timing { std::string node, op; double ms; };
 
@@ -317,6 +324,41 @@ class Graph {
     size_t num_staged_quantizers() const { return staged_dql_; }
     size_t num_qout_edges() const { return qout_edges_; } // quantizers merged into their producer's launch (Options::qout)
     size_t num_stats_blocks() const { return stats_blocks_; }
+    size_t num_dql_loader_steps() const { return dql_loader_steps_; } // convolutions that quantize in their own loader (Options::fused_dql)
+
+    // Moves every device constant of this graph -- uploaded initializers, constants derived at load (merged QKV weights), prepacked conv / MatMul
+    // weights -- into ONE allocation, in a deterministic order (value id, then prepack order): the weight arena a batch-sharded deployment
+    // broadcasts once from the rank that read the model file (RCCL over xGMI).  Two processes that load the same model with the same
+    // options get the same layout.  Must run before a sharing graph (the `donor` constructor) is built on this one and before any capture.
+    std::pair<void *, size_t> coalesce_constants() {
+        if (donor_) throw GraphError("coalesce_constants: a graph that shares a donor's constants has none of its own");
+        if (arena_) return {arena_->ptr(), (size_t)arena_->len()};
+        auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        size_t total = 0;
+        for (auto &kv : consts_) total += pad(kv.second.bytes());
+        for (auto &pk : packed_) total += pad(pk->bytes());
+        arena_.reset(new Tensor(ctx_, {(int64_t)std::max<size_t>(total, 256)}, DType::U8));
+        size_t off = 0;
+        auto move_in = [&](Tensor &t) {
+            const size_t b = t.bytes();
+            if (b) ctx_.check(rten_hip_memcpy_d2d(ctx_.raw(), (char *)arena_->ptr() + off, t.ptr(), b));
+            Tensor v = Tensor::view_at(*arena_, off, t.shape(), t.dtype());
+            ctx_.sync();       // the copy has read the old buffer before it goes back to the allocator
+            t = std::move(v);  // same Tensor object (steps hold pointers to it), new storage
+            off += pad(b);
+        };
+        for (auto &kv : consts_) move_in(kv.second);
+        for (auto &pk : packed_) move_in(*pk);
+        ctx_.trim_pool();
+        return {arena_->ptr(), (size_t)arena_->len()};
+    }
+
+    // Empty, or the first step whose result for one row of dim 0 depends on the other rows: such a graph cannot be split into sub-batch chains
+    // (DynamicQuantizeLinear takes its min / max over the whole tensor; a reduction / normalisation over axis 0 mixes rows).
+    std::string batch_coupled_step() const {
+        for (auto &st : steps_) if (st.batch_coupled) return st.kind_name + " \"" + st.name + "\"";
+        return "";
+    }
     std::vector<std::string> step_names() const {
         std::vector<std::string> v;
         for (auto &s : steps_) v.push_back(s.kind_name + ":" + s.name);
@@ -474,6 +516,7 @@ class Graph {
         std::shared_ptr<DynamicQuantizeLinearStaged> dql_staged;
         std::shared_ptr<MaxPool> maxpool; // a max-pool whose output is quantized next can accumulate the quantizer's statistics
         bool removed = false;
+        bool batch_coupled = false; // the result for one dim-0 row depends on other rows (no sub-batch chains for such a graph)
         size_t pos = 0; // index of the LAST graph node folded into this step: the step runs where that node stood
     };
 
@@ -506,8 +549,8 @@ class Graph {
     std::set<int> view_values_;
     int tune_reps_ = 0;
     size_t tuned_ = 0;
-    size_t stats_blocks_ = 0, staged_dql_ = 0, qout_edges_ = 0;
-    std::unique_ptr<Tensor> stats_arena_, sync_arena_;
+    size_t stats_blocks_ = 0, staged_dql_ = 0, qout_edges_ = 0, dql_loader_steps_ = 0;
+    std::unique_ptr<Tensor> stats_arena_, sync_arena_, arena_;
 
     // what the ConvIntegerToFloat step's own lambda decides per run: does (scale, bias, residual) take the fused epilogue?
     static bool i8_fused_form(const I8Conv &state, const InputList &in, bool &per_channel) {
@@ -612,7 +655,7 @@ class Graph {
         std::vector<Pending> edges;
         for (auto &w : want_stats) {
             Step &P = steps_[w.producer], &D = steps_[w.dql];
-            if (!P.i8 || !P.i8->to_float || !opt_.qout.count(P.name) || D.dql_staged->mul_by.size() > 1 || !P.i8->sg.x_staged || !P.i8->sg.packed_weight) continue;
+            if (!P.i8 || !P.i8->to_float || !opt_.qout.count(P.name) || !P.i8->sg.x_staged || !P.i8->sg.packed_weight) continue;
             size_t quantizers = 0;
             for (size_t u : consumers[D.in[0]]) if (steps_[u].dql_staged) quantizers++;
             if (quantizers != 1) continue;
@@ -649,6 +692,68 @@ class Graph {
             fused_away_++;
             qout_edges_++;
         }
+    }
+    // Opt-in per layer (Options::fused_dql, the runner's `fused_layers`): a pointwise ConvIntegerToFloat step whose input comes from a staged
+    // quantizer with producer statistics reads the quantizer's f32 INPUT and quantizes in its own operand loader (rten_hip_conv2d_int8_dql:
+    // DynamicQuantizeLinear + ConvIntegerToFloat of the reference, src/ops/quantize.rs:352-436 + src/ops/conv.rs:495-587, in one launch, same bits).
+    // The quantizer's step stays when another convolution still reads its codes (a stage's shortcut) and goes when none does.
+    void plan_dql_loaders() {
+        if (opt_.fused_dql.empty()) return;
+        std::map<int, size_t> producer;
+        for (size_t i = 0; i < steps_.size(); i++) for (int id : steps_[i].out) if (id >= 0) producer[id] = i;
+        for (size_t i = 0; i < steps_.size(); i++) {
+            Step &cs = steps_[i];
+            if (!cs.i8 || !cs.i8->to_float || !opt_.fused_dql.count(cs.name) || !cs.i8->sg.x_staged || !cs.i8->sg.packed_weight || !cs.i8->sg.packed_weight->len()) continue;
+            auto pit = producer.find(cs.in[0]);
+            if (pit == producer.end()) continue;
+            Step &D = steps_[pit->second];
+            if (!D.dql_staged || D.removed || !D.dql_staged->stats_in || D.out.empty() || D.out[0] != cs.in[0]) continue; // (a quantizer merged into its producer has no step)
+            // geometry the loader form covers: 1x1, stride 1, no padding, groups 1, C % 64 == 0 -- all load-time facts
+            const Tensor &w = consts_.at(cs.in[1]);
+            const Conv &cv = cs.i8->op->conv;
+            const bool unit = cv.strides == std::vector<int>{1, 1} && cv.dilations == std::vector<int>{1, 1} && !cv.padding.same && cv.padding.fixed == std::vector<int>{0, 0, 0, 0};
+            if (w.ndim() != 4 || w.size(2) != 1 || w.size(3) != 1 || !unit || cv.groups != 1 || w.size(1) % 64 != 0 || w.dtype() != DType::I8) continue;
+            if (cs.in[3] >= 0) { // a weight zero point: only the constant scalar 0 of symmetric weights
+                auto zi = consts_.find(cs.in[3]);
+                if (zi == consts_.end() || zi->second.len() != 1 || zi->second.dtype() != DType::I8 || zi->second.to_host<int8_t>()[0] != 0) continue;
+            }
+            // the conv's scale must be one of the products Mul(x_scale, w_scale) folded into the quantizer: w_scale is that Mul's constant
+            const Tensor *w_scale = nullptr;
+            for (size_t k = 0; k < D.dql_staged->mul_by.size(); k++) if (D.out.size() > 3 + k && D.out[3 + k] == cs.in[4]) w_scale = D.dql_staged->mul_by[k];
+            if (!w_scale) continue;
+            const void *stats_in = D.dql_staged->stats_in;
+            auto state = cs.i8;
+            const int f32_in = D.in[0];
+            cs.in[0] = f32_in; cs.in[2] = -1; cs.in[4] = -1;
+            cs.kind_name = "DynamicQuantizeLinear+" + cs.kind_name + " (quantize on load)";
+            cs.run = [state, w_scale, stats_in](Context &c, const InputList &in) {
+                const Tensor &x = want(require(in, 0), DType::F32, "float32"), &w = require(in, 1);
+                const Tensor *bias = in[5], *residual = in[6];
+                rten_hip_conv2d_int8_desc di{};
+                di.conv = state->op->conv.geometry(x.shape(), w.shape());
+                di.x_signed = 0; di.w_signed = 1; di.pad_mode = state->op->pad_mode; di.weights_packed = 1;
+                if (bias && bias->len() != di.conv.o) throw OpError(OpError::IncompatibleInputShapes, "bias length does not match output channels");
+                if (residual && residual->shape() != std::vector<int64_t>{di.conv.n, di.conv.o, di.conv.out_h, di.conv.out_w})
+                    throw OpError(OpError::IncompatibleInputShapes, "quantize-on-load convolution: the residual must have the output's shape");
+                Tensor y(c, {di.conv.n, di.conv.o, di.conv.out_h, di.conv.out_w}, DType::F32);
+                const uint32_t flags = (state->relu ? RTEN_HIP_CONV_RELU : 0u) | (residual ? RTEN_HIP_CONV_RESIDUAL : 0u);
+                c.check(rten_hip_conv2d_int8_dql(c.raw(), &di, (const float *)x.ptr(), stats_in, state->sg.packed_weight->ptr(), (const float *)w_scale->ptr(),
+                                                 (const float *)vp(bias), (const float *)vp(residual), flags, (float *)y.ptr(), state->sg.stats_out, nullptr, nullptr));
+                OutputList out;
+                out.push_back(std::move(y));
+                return out;
+            };
+            dql_loader_steps_++;
+            // does anybody still read the quantizer's outputs?
+            bool read = false;
+            for (auto &st : steps_) {
+                if (&st == &D || st.removed) continue;
+                for (int id : st.in) for (int o : D.out) if (id >= 0 && id == o) read = true;
+            }
+            for (auto &o : outputs_) for (int oid : D.out) if (ids_.at(o.name) == oid) read = true;
+            if (!read) { D.removed = true; fused_away_++; }
+        }
+        steps_.erase(std::remove_if(steps_.begin(), steps_.end(), [](const Step &st) { return st.removed; }), steps_.end());
     }
     uint64_t graph_ = 0;
     std::vector<Tensor> captured_outputs_;
@@ -736,7 +841,8 @@ class Graph {
             return Tensor::from_host<int32_t>(ctx_, t.dims, narrow.data());
         }
         Tensor d(ctx_, t.dims, dt);
-        if (d.bytes()) ctx_.check(rten_hip_memcpy_h2d(ctx_.raw(), d.ptr(), t.raw.data(), d.bytes()));
+        if (d.bytes() && !(opt_.skip_large_uploads && d.bytes() >= ((size_t)64 << 10)))
+            ctx_.check(rten_hip_memcpy_h2d(ctx_.raw(), d.ptr(), t.raw.data(), d.bytes()));
         return d;
     }
 
@@ -1382,6 +1488,7 @@ class Graph {
                 auto op = std::make_shared<LayerNormalization>();
                 op->axis = (int)n.get_int("axis", -1);
                 op->epsilon = n.get_float("epsilon", 1e-5f);
+                st.batch_coupled = op->axis == 0;
                 st.run = [op](Context &c, const InputList &in) { return op->run(c, in); };
             } else if (n.op_type == "Gelu" && n.attr("approximate") && n.attr("approximate")->s != "none") {
                 throw GraphError("Gelu " + st.name + ": approximate=\"" + n.attr("approximate")->s + "\" is not supported");
@@ -1424,10 +1531,12 @@ class Graph {
                     for (int32_t v : consts_.at(it->second).to_host<int32_t>()) op->axes.push_back(v);
                     st.in.resize(1);
                 }
+                st.batch_coupled = op->axes.empty() ? !op->noop_with_empty_axes : std::count(op->axes.begin(), op->axes.end(), 0) != 0; // sums over dim 0
                 st.run = [op](Context &c, const InputList &in) { return op->run(c, in); };
             } else if (n.op_type == "Softmax") {
                 auto op = std::make_shared<Softmax>();
                 op->axis = (int)n.get_int("axis", -1);
+                st.batch_coupled = op->axis == 0;
                 st.run = [op](Context &c, const InputList &in) { return op->run(c, in); };
             } else if (n.op_type == "Flatten" || n.op_type == "Reshape" || n.op_type == "Squeeze" || n.op_type == "Unsqueeze" || n.op_type == "Identity" ||
                        n.op_type == "Dropout") {
@@ -1447,7 +1556,8 @@ class Graph {
             if (!ids_.count(o.name)) throw GraphError("graph output " + o.name + " is not produced by any node");
         std::stable_sort(steps_.begin(), steps_.end(), [](const Step &a, const Step &b) { return a.pos < b.pos; });
         for (auto &st : steps_) if (st.view && st.out[0] >= 0) view_values_.insert(st.out[0]);
-        if (opt_.fuse) plan_int8_staging();
+        if (opt_.fuse) { plan_int8_staging(); plan_dql_loaders(); }
+        for (auto &st : steps_) if (st.kind_name.find("DynamicQuantizeLinear") != std::string::npos) st.batch_coupled = true; // min / max over the whole tensor
         plan_liveness();
     }
 

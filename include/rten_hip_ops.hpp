@@ -147,6 +147,11 @@ class Tensor {
         t.ptr_ = (char *)base.ptr_ + bytes_off;
         return t;
     }
+    static Tensor view_at(const Tensor &base, size_t bytes_off, std::vector<int64_t> shape, DType dt) { // ... typed: a slot of a byte arena
+        Tensor t = view_at(base, bytes_off, std::move(shape));
+        t.dtype_ = dt;
+        return t;
+    }
     template <typename T>
     static Tensor from_host(Context &ctx, std::vector<int64_t> shape, const T *data) {
         Tensor t(ctx, std::move(shape), dtype_of<T>());
@@ -249,20 +254,20 @@ class PlanScope { // applies a plan around one call and restores the automatic p
   public:
     PlanScope(Context &ctx, const GemmPlan &p) : ctx_(ctx), on_(p.set) {
         if (!on_) return;
+        ctx.check(rten_hip_tuning_save(ctx.raw(), saved_)); // (the context may be a caller's: its knobs come back as they were, not as defaults)
         ctx.check(rten_hip_set_gemm_variant_override(ctx.raw(), p.variant));
         ctx.check(rten_hip_set_gemm_split(ctx.raw(), p.mode, p.groups));
         ctx.check(rten_hip_set_gemm_order(ctx.raw(), p.order));
     }
     ~PlanScope() {
         if (!on_) return;
-        rten_hip_set_gemm_variant_override(ctx_.raw(), -1);
-        rten_hip_set_gemm_split(ctx_.raw(), 3, 1);
-        rten_hip_set_gemm_order(ctx_.raw(), 0);
+        rten_hip_tuning_restore(ctx_.raw(), saved_);
     }
 
   private:
     Context &ctx_;
     bool on_;
+    int32_t saved_[8] = {};
 };
 
 // ------------------------------------------------------------------------------------------------ Conv
@@ -1180,7 +1185,7 @@ struct DynamicQuantizeLinearStaged : Operator {
     // (launch plan) only: see the time-out contract in rten_hip.h.
     bool run_in_producer(Context &ctx, const ConvInteger &prod, const InputList &in, const Tensor &scale, const Tensor *bias, const Tensor *residual, bool relu,
                          const ConvInteger::Staging &sg, bool per_channel_scale, void *sync, bool keep_f32, OutputList &out) const {
-        if (mul_by.size() > 1 || !sync || !sg.stats_out || !sg.x_staged || !sg.packed_weight || !sg.packed_weight->len()) return false;
+        if (mul_by.size() > kMaxProducts || !sync || !sg.stats_out || !sg.x_staged || !sg.packed_weight || !sg.packed_weight->len()) return false;
         const Tensor &x = require(in, 0), &w = require(in, 1);
         const Tensor *x_zp = get(in, 2), *w_zp = get(in, 3);
         rten_hip_conv2d_int8_desc di = prod.desc(x, w, x_zp, w_zp);
@@ -1193,7 +1198,7 @@ struct DynamicQuantizeLinearStaged : Operator {
         dn.x_signed = 0; dn.w_signed = 1; dn.pad_mode = consumer.pad_mode;
         const size_t nbytes = rten_hip_conv2d_int8_staged_bytes(&dn);
         if (!nbytes) return false;
-        if (!mul_by.empty() && (!mul_by[0] || mul_by[0]->len() != 1)) throw OpError(OpError::InvalidValue, "scale should be a scalar");
+        for (const Tensor *mb : mul_by) if (!mb || mb->len() != 1) throw OpError(OpError::InvalidValue, "scale should be a scalar");
         Tensor y(ctx, keep_f32 ? yshape : std::vector<int64_t>{0}, DType::F32);
         Tensor q(ctx, yshape, DType::U8, nbytes), s(ctx, {}, DType::F32), z(ctx, {}, DType::U8);
         Tensor pr(ctx, mul_by.empty() ? std::vector<int64_t>{0} : mul_by[0]->shape(), DType::F32);
@@ -1204,12 +1209,20 @@ struct DynamicQuantizeLinearStaged : Operator {
                                                      mul_by.empty() ? nullptr : (float *)pr.ptr());
         if (rc == RTEN_HIP_ERR_UNSUPPORTED) return false;
         ctx.check(rc);
+        // a quantizer read by several convolutions (a stage's shortcut and first 1x1): the launch folds the first Mul(y_scale, w_scale); the others
+        // are the graph's own scalar Mul nodes, one tiny launch each (same f32 multiply)
+        std::vector<Tensor> more;
+        for (size_t i = 1; i < mul_by.size(); i++) {
+            more.emplace_back(ctx, mul_by[i]->shape(), DType::F32);
+            ctx.check(rten_hip_mul_f32(ctx.raw(), 1, (const float *)s.ptr(), (const float *)mul_by[i]->ptr(), 1, (float *)more.back().ptr()));
+        }
         out.clear();
         out.push_back(std::move(y));
         out.push_back(std::move(q));
         out.push_back(std::move(s));
         out.push_back(std::move(z));
         if (!mul_by.empty()) out.push_back(std::move(pr));
+        for (Tensor &t : more) out.push_back(std::move(t));
         return true;
     }
 };

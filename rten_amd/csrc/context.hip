@@ -25,17 +25,24 @@ int32_t rten_check_hip(rten_hip_ctx *ctx, hipError_t e, const char *what) {
     return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
 }
 
+// Grow-only scratch buffers and live hipGraphs.  A captured graph holds the scratch / aux pointer its launches were recorded with, so a
+// buffer that a live graph of this context may replay from is never freed by a later, larger request: while `live_graphs` > 0 the old
+// buffer is RETIRED (kept allocated, freed when the last graph of the context is destroyed, or with the context) and a new one is
+// allocated for the eager caller.  (one Arc<HipContext> shared by several HipSubgraph models and the per-op wrappers.)
+static void retire_or_free(rten_hip_ctx *ctx, void *buf) {
+    if (!buf) return;
+    if (ctx->live_graphs > 0) { ctx->retired.push_back(buf); return; }
+    hipStreamSynchronize(ctx->stream);
+    hipFree(buf);
+}
+
 void *rten_scratch(rten_hip_ctx *ctx, size_t bytes) {
     if (bytes <= ctx->scratch_bytes) return ctx->scratch;
     if (ctx->capturing) return nullptr; // cannot grow during capture
-    if (ctx->scratch) {
-        hipStreamSynchronize(ctx->stream);
-        hipFree(ctx->scratch);
-        ctx->scratch = nullptr;
-        ctx->scratch_bytes = 0;
-    }
-    // Grow rarely: a captured hipGraph holds the scratch pointer, so a later, larger request must not free the buffer a
-    // live graph replays from in the common case.  288 GB of HBM make a generous floor cheap.
+    retire_or_free(ctx, ctx->scratch);
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    // 288 GB of HBM make a generous floor cheap: growth (and therefore retirement) is rare.
     size_t want = bytes + bytes / 4;
     const size_t floor_bytes = (size_t)512 << 20;
     if (want < floor_bytes) want = floor_bytes;
@@ -47,13 +54,12 @@ void *rten_scratch(rten_hip_ctx *ctx, size_t bytes) {
 void *rten_aux_scratch(rten_hip_ctx *ctx, size_t bytes) {
     if (bytes <= ctx->aux_bytes) return ctx->aux;
     if (ctx->capturing) return nullptr;
-    if (ctx->aux) {
-        hipStreamSynchronize(ctx->stream);
-        hipFree(ctx->aux);
-        ctx->aux = nullptr;
-        ctx->aux_bytes = 0;
-    }
-    const size_t want = bytes + bytes / 4;
+    retire_or_free(ctx, ctx->aux);
+    ctx->aux = nullptr;
+    ctx->aux_bytes = 0;
+    size_t want = bytes + bytes / 4;
+    const size_t floor_bytes = (size_t)16 << 20; // a floor here too: fewer distinct buffers over a context's life
+    if (want < floor_bytes) want = floor_bytes;
     if (hipMalloc(&ctx->aux, want) != hipSuccess) return nullptr;
     ctx->aux_bytes = want;
     return ctx->aux;
@@ -198,6 +204,7 @@ RTEN_EXPORT int32_t rten_hip_destroy(rten_hip_ctx *ctx) {
             if (e) hipEventDestroy(e);
     if (ctx->scratch) hipFree(ctx->scratch);
     if (ctx->aux) hipFree(ctx->aux);
+    for (void *b : ctx->retired) hipFree(b);
     if (ctx->split_counters) hipFree(ctx->split_counters);
     for (auto &kv : ctx->luts) hipFree(kv.second);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
@@ -220,6 +227,8 @@ RTEN_EXPORT int32_t rten_hip_sync(rten_hip_ctx *ctx) {
     RTEN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return rten_check_fault(ctx); // sticky: a kernel that gave up is reported by every sync until the fault is reset
 }
+
+RTEN_EXPORT int32_t rten_hip_device_id(const rten_hip_ctx *ctx) { return ctx ? ctx->device : -1; }
 
 RTEN_EXPORT int32_t rten_hip_device_info(rten_hip_ctx *ctx, char *name_buf, int32_t name_len, int32_t *compute_units,
                                          int32_t *clock_mhz, int64_t *total_mem_bytes) {
@@ -338,6 +347,7 @@ RTEN_EXPORT int32_t rten_hip_graph_end(rten_hip_ctx *ctx, uint64_t *out_graph) {
     hipGraphDestroy(graph);
     if (e != hipSuccess) return rten_check_hip(ctx, e, "hipGraphInstantiate");
     *out_graph = (uint64_t)(uintptr_t)exec;
+    ctx->live_graphs++; // its launches hold this context's scratch / aux pointers (rten_scratch)
     return RTEN_HIP_OK;
 }
 
@@ -394,6 +404,32 @@ RTEN_EXPORT int32_t rten_hip_graph_destroy(rten_hip_ctx *ctx, uint64_t graph) {
     if (!graph) return RTEN_HIP_OK;
     RTEN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     RTEN_HIP_TRY(ctx, hipGraphExecDestroy((hipGraphExec_t)(uintptr_t)graph));
+    if (ctx->live_graphs > 0 && --ctx->live_graphs == 0) { // nothing replays from the retired scratch buffers any more
+        for (void *b : ctx->retired) hipFree(b);
+        ctx->retired.clear();
+    }
+    return RTEN_HIP_OK;
+}
+
+// Snapshot / restore of every sticky tuning knob of a context (GEMM variant override, split-K plan, tile order, gemv order + thread
+// assumption, int8 path, attention path): a library-level caller that changes knobs around its own launches -- the plan executor on a
+// BORROWED context -- puts back what the owner had set instead of the defaults.
+RTEN_EXPORT int32_t rten_hip_tuning_save(rten_hip_ctx *ctx, int32_t state[8]) {
+    RTEN_CHECK_CTX(ctx);
+    if (!state) return RTEN_HIP_ERR_INVALID_VALUE;
+    state[0] = ctx->gemm_variant_override; state[1] = ctx->split_mode; state[2] = ctx->split_s; state[3] = ctx->tile_order;
+    state[4] = ctx->gemv_order; state[5] = (int32_t)ctx->gemv_threads; state[6] = ctx->int8_path; state[7] = ctx->sdpa_path;
+    return RTEN_HIP_OK;
+}
+RTEN_EXPORT int32_t rten_hip_tuning_restore(rten_hip_ctx *ctx, const int32_t state[8]) {
+    RTEN_CHECK_CTX(ctx);
+    if (!state) return RTEN_HIP_ERR_INVALID_VALUE;
+    if (const int32_t rc = rten_hip_set_gemm_variant_override(ctx, state[0])) return rc;
+    if (const int32_t rc = rten_hip_set_gemm_split(ctx, state[1], state[2])) return rc;
+    if (const int32_t rc = rten_hip_set_gemm_order(ctx, state[3])) return rc;
+    if (const int32_t rc = rten_hip_set_gemv_order(ctx, state[4], state[5])) return rc;
+    ctx->int8_path = state[6];
+    ctx->sdpa_path = state[7];
     return RTEN_HIP_OK;
 }
 

@@ -126,10 +126,18 @@ struct rten_hip_model {
     std::vector<int64_t> sub, start;                        // sub-batch sizes / first rows
     size_t planned_steps = 0, tuned_steps = 0;
     bool prepared = false;
+    void *arena_ptr = nullptr; // chain 0's coalesced constants (owned by graphs[0])
+    size_t arena_bytes = 0;
     std::string last_error;
 };
 
 namespace {
+// text of the calling thread's last FAILED rten_hip_model_load / _load_ex (there is no model object to carry it): rten_hip_model_load_error()
+thread_local std::string tls_load_error;
+int32_t load_fail(int32_t code, const std::string &msg) {
+    tls_load_error = msg;
+    return code;
+}
 int32_t fail(rten_hip_model *g, int32_t code, const std::string &msg) {
     if (g) g->last_error = msg;
     return code;
@@ -147,23 +155,33 @@ int32_t code_of(const OpError &e) {
 
 // Parses `onnx` (the bytes of an ONNX ModelProto), compiles it `chains` times (constants uploaded, conv weights prepacked, fusions applied) and
 // records the launch plan.  `plan_json`: NULL (the backend's automatic plans, or rten_hip_model_prepare(tune = 1)) or the text of a plan file.
-RTEN_EXPORT int32_t rten_hip_model_load(rten_hip_ctx *ctx, const void *onnx_bytes, size_t onnx_len, const char *plan_json, int32_t chains, int32_t device_id,
-                                        rten_hip_model **out_graph) {
-    if (!out_graph) return RTEN_HIP_ERR_INVALID_VALUE;
+// Every chain lives on `ctx`'s device.  flags: RTEN_HIP_MODEL_RECEIVE_WEIGHTS = this process will receive the weight arena
+// (rten_hip_model_weight_arena) by broadcast from the process that loaded the file for real: large initializers are not uploaded.
+// A failed load leaves its reason in rten_hip_model_load_error() (per calling thread).
+RTEN_EXPORT int32_t rten_hip_model_load_ex(rten_hip_ctx *ctx, const void *onnx_bytes, size_t onnx_len, const char *plan_json, int32_t chains, uint32_t flags,
+                                           rten_hip_model **out_graph) {
+    if (!out_graph) return load_fail(RTEN_HIP_ERR_INVALID_VALUE, "model_load: out_model is NULL");
     *out_graph = nullptr;
-    if (!ctx || !onnx_bytes || !onnx_len || chains < 1 || chains > 16) return RTEN_HIP_ERR_INVALID_VALUE;
+    if (!ctx || !onnx_bytes || !onnx_len || chains < 1 || chains > 16 || (flags & ~(uint32_t)RTEN_HIP_MODEL_RECEIVE_WEIGHTS))
+        return load_fail(RTEN_HIP_ERR_INVALID_VALUE, "model_load: null context / empty model / chains outside 1..16 / unknown flag bits");
     std::unique_ptr<rten_hip_model> g(new rten_hip_model());
     g->caller = ctx;
     g->chains = chains;
+    const int32_t device_id = rten_hip_device_id(ctx);
     try {
         const onnx::Model m = onnx::parse((const uint8_t *)onnx_bytes, onnx_len);
         Graph::Options opts;
+        opts.skip_large_uploads = (flags & RTEN_HIP_MODEL_RECEIVE_WEIGHTS) != 0;
         if (plan_json && *plan_json) {
             PlanJson pj{plan_json, plan_json + std::strlen(plan_json), {}};
-            if (!pj.object(g->plan_flat, g->plan_by_batch)) { delete g.release(); return RTEN_HIP_ERR_INVALID_VALUE; }
+            if (!pj.object(g->plan_flat, g->plan_by_batch)) return load_fail(RTEN_HIP_ERR_INVALID_VALUE, "model_load: the plan file is not the JSON subset of profiles/plans/ (objects of integer / name arrays)");
             g->have_plan = true;
-            // quantized-output launches are opt-in per edge and need the device to themselves: one chain only
-            if (chains == 1 && pj.names.count("qout")) opts.qout.insert(pj.names["qout"].begin(), pj.names["qout"].end());
+            // quantized-output launches (and quantize-on-load layers) are opt-in per edge; the former need the device to themselves: one chain only.
+            // Asking for them with several chains is an error, not something to drop silently.
+            if ((pj.names.count("qout") && !pj.names["qout"].empty()) && chains != 1)
+                return load_fail(RTEN_HIP_ERR_INVALID_VALUE, "model_load: the plan lists quantized-output edges (\"qout\"), which need chains == 1");
+            if (pj.names.count("qout")) opts.qout.insert(pj.names["qout"].begin(), pj.names["qout"].end());
+            if (pj.names.count("fused_dql")) opts.fused_dql.insert(pj.names["fused_dql"].begin(), pj.names["fused_dql"].end());
         }
         for (int c = 0; c < chains; c++) {
             // chain 0 runs on the CALLER's context (its stream): a model with N chains owns N - 1 streams.  One stream more than chains costs real
@@ -173,19 +191,55 @@ RTEN_EXPORT int32_t rten_hip_model_load(rten_hip_ctx *ctx, const void *onnx_byte
             else g->ctxs.emplace_back(new Context(device_id));
             g->ctxs.back()->enable_pool(true);
             // chains 1.. share chain 0's device constants and prepacked weights (one copy of the weight set per model, as in the Python runner's arena)
-            if (c == 0) g->graphs.emplace_back(new Graph(*g->ctxs.back(), m, opts));
-            else g->graphs.emplace_back(new Graph(*g->ctxs.back(), m, opts, *g->graphs[0]));
+            if (c == 0) {
+                g->graphs.emplace_back(new Graph(*g->ctxs.back(), m, opts));
+                // every device constant in ONE allocation (before anybody aliases them): the arena a sharded deployment broadcasts once
+                const auto arena = g->graphs[0]->coalesce_constants();
+                g->arena_ptr = arena.first;
+                g->arena_bytes = arena.second;
+                // a graph whose rows are coupled through dim 0 cannot run as independent sub-batch chains: refused, never silently different
+                const std::string coupled = g->graphs[0]->batch_coupled_step();
+                if (chains > 1 && !coupled.empty())
+                    return load_fail(RTEN_HIP_ERR_UNSUPPORTED, "model_load: chains > 1, but " + coupled + " couples the rows of dim 0 (its result for one row depends on the others)");
+            } else {
+                g->graphs.emplace_back(new Graph(*g->ctxs.back(), m, opts, *g->graphs[0]));
+            }
         }
         g->inputs = g->graphs[0]->inputs();
         g->outputs = g->graphs[0]->outputs();
     } catch (const onnx::ParseError &e) {
-        return RTEN_HIP_ERR_INVALID_VALUE;
+        while (!g->graphs.empty()) g->graphs.pop_back();
+        return load_fail(RTEN_HIP_ERR_INVALID_VALUE, std::string("model_load: ") + e.what());
     } catch (const OpError &e) {
-        return code_of(e);
-    } catch (const std::exception &e) {
-        return RTEN_HIP_ERR_INVALID_VALUE;
+        while (!g->graphs.empty()) g->graphs.pop_back();
+        return load_fail(code_of(e), "model_load: " + OpError::kind_name(e.kind) + ": " + e.msg);
+    } catch (const std::exception &e) { // GraphError: an operator outside the registry, an attribute form that is not covered, ...
+        while (!g->graphs.empty()) g->graphs.pop_back();
+        return load_fail(RTEN_HIP_ERR_INVALID_VALUE, std::string("model_load: ") + e.what());
     }
+    tls_load_error.clear();
     *out_graph = g.release();
+    return RTEN_HIP_OK;
+}
+
+// The round-4 entry point: `device_id` must be the device `ctx` was created on (the chains are created there; a mismatch used to put chains 1..
+// on another device than chain 0 and the shared constants).
+RTEN_EXPORT int32_t rten_hip_model_load(rten_hip_ctx *ctx, const void *onnx_bytes, size_t onnx_len, const char *plan_json, int32_t chains, int32_t device_id,
+                                        rten_hip_model **out_graph) {
+    if (out_graph) *out_graph = nullptr;
+    if (ctx && device_id != rten_hip_device_id(ctx)) return load_fail(RTEN_HIP_ERR_INVALID_VALUE, "model_load: device_id is not the device of `ctx`");
+    return rten_hip_model_load_ex(ctx, onnx_bytes, onnx_len, plan_json, chains, 0u, out_graph);
+}
+
+RTEN_EXPORT const char *rten_hip_model_load_error(void) { return tls_load_error.c_str(); }
+
+// The model's weight arena: ONE device allocation holding every constant of the graph (initializers, constants derived at load, prepacked weights) in a
+// layout that depends only on the model and the load options -- what rank 0 of a batch-sharded job broadcasts once (rten_hip_broadcast: RCCL over xGMI)
+// to ranks that loaded with RTEN_HIP_MODEL_RECEIVE_WEIGHTS.  Valid until rten_hip_model_destroy.
+RTEN_EXPORT int32_t rten_hip_model_weight_arena(rten_hip_model *g, void **dev_ptr, size_t *bytes) {
+    if (!g) return RTEN_HIP_ERR_INVALID_VALUE;
+    if (dev_ptr) *dev_ptr = g->arena_ptr;
+    if (bytes) *bytes = g->arena_bytes;
     return RTEN_HIP_OK;
 }
 
@@ -197,7 +251,7 @@ RTEN_EXPORT int32_t rten_hip_model_info(const rten_hip_model *g, int32_t *n_inpu
     if (n_inputs) *n_inputs = (int32_t)g->inputs.size();
     if (n_outputs) *n_outputs = (int32_t)g->outputs.size();
     if (n_steps) *n_steps = (int32_t)g->graphs[0]->num_steps();
-    if (n_planned_steps) *n_planned_steps = (int32_t)(g->planned_steps + g->tuned_steps + g->graphs[0]->num_qout_edges());
+    if (n_planned_steps) *n_planned_steps = (int32_t)(g->planned_steps + g->tuned_steps + g->graphs[0]->num_qout_edges() + g->graphs[0]->num_dql_loader_steps());
     return RTEN_HIP_OK;
 }
 RTEN_EXPORT const char *rten_hip_model_input_name(const rten_hip_model *g, int32_t i) { return (g && i >= 0 && (size_t)i < g->inputs.size()) ? g->inputs[(size_t)i].name.c_str() : nullptr; }
@@ -254,6 +308,11 @@ RTEN_EXPORT int32_t rten_hip_model_prepare(rten_hip_model *g, int32_t tune) {
             const int64_t b = g->sub[(size_t)c];
             if (g->have_plan) {
                 auto it = g->plan_by_batch.find(std::to_string(b));
+                // a plan keyed by sub-batch size that has no entry for THIS chain's size plans nothing for it: an error, not a silent default
+                bool keyed = false;
+                for (auto &kv : g->plan_by_batch) if (!kv.first.empty() && kv.first.find_first_not_of("0123456789") == std::string::npos) keyed = true;
+                if (keyed && it == g->plan_by_batch.end() && g->plan_flat.empty())
+                    return fail(g, RTEN_HIP_ERR_INVALID_VALUE, "prepare: the plan file is keyed by sub-batch size and has no entry for a chain of " + std::to_string(b) + " rows");
                 const size_t n = gr.apply_plan(plan_table(it != g->plan_by_batch.end() ? it->second : g->plan_flat));
                 if (c == 0) g->planned_steps = n;
             } else if (tune) {
@@ -264,13 +323,22 @@ RTEN_EXPORT int32_t rten_hip_model_prepare(rten_hip_model *g, int32_t tune) {
             // NOT take the reference's vector-matrix (gemv) order -- the decision is made on the host while the launches are recorded, hence around
             // the probe run and the capture only (the context's setting is restored: chain 0 runs on the caller's context).
             const bool lone_row = b == 1 && g->start.back() + g->sub.back() > 1;
+            struct Restore { // the caller's knobs come back as they were (chain 0 IS the caller's context), not as defaults
+                Context &c; int32_t saved[8]; bool on = false;
+                explicit Restore(Context &cx_) : c(cx_) { on = rten_hip_tuning_save(c.raw(), saved) == RTEN_HIP_OK; }
+                ~Restore() { if (on) rten_hip_tuning_restore(c.raw(), saved); }
+            } restore(cx);
             if (lone_row) cx.check(rten_hip_set_gemv_order(cx.raw(), 0, 0));
-            struct Restore { Context &c; bool on; ~Restore() { if (on) rten_hip_set_gemv_order(c.raw(), 1, 0); } } restore{cx, lone_row};
             if (c == 0) { // resident full-batch outputs, shaped from chain 0's (un-captured) first run
                 const std::vector<Tensor> probe = gr.run(feeds);
                 for (size_t o = 0; o < probe.size(); o++) {
                     std::vector<int64_t> s = probe[o].shape();
                     if (s.empty()) return fail(g, RTEN_HIP_ERR_UNSUPPORTED, "a scalar graph output cannot be split over chains");
+                    // the chains' rows are assembled along dim 0: an output whose dim 0 is not the chain's sub-batch (a Reshape to [N*k, ...], a
+                    // batch-independent vector) would be copied past the end of the full-batch buffer on every replay
+                    if (s[0] != g->sub[0])
+                        return fail(g, RTEN_HIP_ERR_UNSUPPORTED, "output " + g->outputs[o].name + ": dim 0 (" + std::to_string(s[0]) + ") is not the chain's sub-batch (" +
+                                                                      std::to_string(g->sub[0]) + "): the outputs of this graph cannot be assembled from dim-0 slices");
                     s[0] = g->start.back() + g->sub.back();
                     g->out_shape.push_back(s);
                     g->full_out.emplace_back(new Tensor(*g->ctxs[0], s, probe[o].dtype()));
@@ -282,6 +350,9 @@ RTEN_EXPORT int32_t rten_hip_model_prepare(rten_hip_model *g, int32_t tune) {
             gr.capture(feeds, [&](const std::vector<Tensor> &outs) {
                 if (getenv("RTEN_MODEL_NO_GATHER")) return; // (diagnostic: timing without the output copies; the outputs are then not assembled)
                 for (size_t o = 0; o < outs.size(); o++) {
+                    if (outs[o].shape().empty() || outs[o].shape()[0] != g->sub[(size_t)c] ||
+                        !std::equal(outs[o].shape().begin() + 1, outs[o].shape().end(), g->out_shape[o].begin() + 1, g->out_shape[o].end()))
+                        throw OpError(OpError::UnsupportedValue, "output " + g->outputs[o].name + " of chain " + std::to_string(c) + " does not have the chain's rows on dim 0");
                     int64_t row = 1;
                     for (size_t d = 1; d < g->out_shape[o].size(); d++) row *= g->out_shape[o][d];
                     const size_t off = (size_t)(g->start[(size_t)c] * row) * dtype_size(outs[o].dtype());
@@ -291,6 +362,9 @@ RTEN_EXPORT int32_t rten_hip_model_prepare(rten_hip_model *g, int32_t tune) {
         }
         for (auto &c : g->ctxs) c->sync();
         g->prepared = true;
+        g->last_error.clear();
+        if (g->have_plan && g->planned_steps + g->graphs[0]->num_qout_edges() + g->graphs[0]->num_dql_loader_steps() == 0)
+            g->last_error = "warning: the plan file matched no step of this graph (every launch runs the backend's automatic plan)";
     } catch (const OpError &e) {
         return fail(g, code_of(e), e.msg);
     } catch (const std::exception &e) {

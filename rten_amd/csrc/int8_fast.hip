@@ -1506,6 +1506,9 @@ __global__ void grid_sync_reset_kernel(unsigned *sync, int count) {
 RTEN_EXPORT int32_t rten_hip_grid_sync_reset(rten_hip_ctx *ctx, void *sync, int32_t count) {
     RTEN_CHECK_CTX(ctx);
     if (!sync || count < 1) return RTEN_HIP_ERR_INVALID_VALUE;
+    // the reset ends with a stream synchronise (the sticky fault is cleared after what is in flight has drained): inside a capture that would
+    // invalidate the capture instead of resetting anything -- refused, not attempted
+    if (ctx->capturing) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "grid_sync_reset: not while a graph capture is active on this context");
     const long long n = (long long)count * kSyncWords;
     hipLaunchKernelGGL(grid_sync_reset_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (unsigned *)sync, count);
     RTEN_LAUNCH_CHECK(ctx, "grid_sync_reset_kernel launch");

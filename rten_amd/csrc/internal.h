@@ -46,6 +46,8 @@ struct rten_hip_ctx {
     size_t scratch_bytes = 0;
     void *aux = nullptr; // second grow-only buffer for operators that call the GEMM (which owns `scratch`) on an intermediate of their own
     size_t aux_bytes = 0;
+    int live_graphs = 0;          // executable graphs captured on this context and not yet destroyed (they hold scratch / aux pointers)
+    std::vector<void *> retired;  // scratch / aux buffers replaced while a graph was alive: freed with the last graph or the context
     std::map<std::string, void *> luts; // im2col lookup tables, keyed by conv geometry (gemm_f32.hip)
     int gemm_variant_override = -1;
     int pipeline = 1; // conv paths: 0 register-staged, 1 LDS-DMA, 2 LDS-DMA + wave specialisation, 3 four stages, 4 fragments first, 5 16x16x4 MFMAs, 6 one wave per 64x64 tile (gemm_f32_wave.hip)

@@ -20,6 +20,7 @@ BIAS_NONE, BIAS_PER_ROW, BIAS_PER_COL = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 CONV_RELU, CONV_RESIDUAL = 1, 2
 PAD_ZERO_POINT, PAD_RAW0_I8, PAD_RAW0_U8 = 0, 1, 2
+MODEL_RECEIVE_WEIGHTS = 1  # rten_hip_model_load_ex flag
 
 
 class BackendUnavailable(RuntimeError):
@@ -182,6 +183,12 @@ PROTOTYPES = {
     "rten_hip_set_sdpa_path": (_I32, [_VP, _I32]),
     # the plan executor behind the C ABI (csrc/graph_abi.cpp)
     "rten_hip_model_load": (_I32, [_VP, _VP, _SZ, C.c_char_p, _I32, _I32, C.POINTER(_VP)]),
+    "rten_hip_model_load_ex": (_I32, [_VP, _VP, _SZ, C.c_char_p, _I32, _U32, C.POINTER(_VP)]),
+    "rten_hip_model_load_error": (C.c_char_p, []),
+    "rten_hip_model_weight_arena": (_I32, [_VP, C.POINTER(_VP), C.POINTER(_SZ)]),
+    "rten_hip_device_id": (_I32, [_VP]),
+    "rten_hip_tuning_save": (_I32, [_VP, C.POINTER(_I32)]),
+    "rten_hip_tuning_restore": (_I32, [_VP, C.POINTER(_I32)]),
     "rten_hip_model_last_error": (C.c_char_p, [_VP]),
     "rten_hip_model_info": (_I32, [_VP, C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32)]),
     "rten_hip_model_input_name": (C.c_char_p, [_VP, _I32]),
@@ -374,13 +381,16 @@ class Model:
     HBM, committed launch plan, `chains` independent sub-batch chains, hipGraph replay.  What a Rust `HipSubgraph` operator would own
     (INTEGRATION.md 2.5); `bench.py --via-executor` times it."""
 
-    def __init__(self, ctx: Context, onnx_bytes: bytes, plan_json: str | None = None, chains: int = 1):
+    def __init__(self, ctx: Context, onnx_bytes: bytes, plan_json: str | None = None, chains: int = 1, receive_weights: bool = False):
+        """`receive_weights`: this process gets the weight arena by broadcast (rank != 0 of a sharded job): large initializers are not uploaded;
+        fill `weight_arena()` before `prepare()`."""
         self.ctx, self.lib = ctx, ctx.lib
         h = C.c_void_p()
         self._onnx = onnx_bytes
-        rc = self.lib.rten_hip_model_load(ctx.h, onnx_bytes, len(onnx_bytes), plan_json.encode() if plan_json else None, chains, ctx.device, C.byref(h))
+        rc = self.lib.rten_hip_model_load_ex(ctx.h, onnx_bytes, len(onnx_bytes), plan_json.encode() if plan_json else None, chains,
+                                             MODEL_RECEIVE_WEIGHTS if receive_weights else 0, C.byref(h))
         if rc != OK:
-            raise HipError(rc, "rten_hip_model_load failed (ONNX parse / unsupported operator / bad plan file)")
+            raise HipError(rc, self.lib.rten_hip_model_load_error().decode(errors="replace") or "rten_hip_model_load_ex failed")
         self.h = h
         ni, no, ns, npl = _I32(), _I32(), _I32(), _I32()
         self._check(self.lib.rten_hip_model_info(h, C.byref(ni), C.byref(no), C.byref(ns), C.byref(npl)))
@@ -400,6 +410,17 @@ class Model:
         self._check(self.lib.rten_hip_model_bind_input(self.h, self.inputs.index(name), sh, len(shape), C.byref(p)))
         self.input_ptrs[name] = p.value
         return p.value
+
+    def weight_arena(self):
+        """(device pointer, bytes) of the one allocation that holds every constant of the model: the unit of the one-time weight broadcast."""
+        p, n = C.c_void_p(), _SZ()
+        self._check(self.lib.rten_hip_model_weight_arena(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    @property
+    def warning(self) -> str:
+        """Text of a non-fatal condition of the last successful call (e.g. a plan file that matched no step); empty otherwise."""
+        return self.lib.rten_hip_model_last_error(self.h).decode(errors="replace")
 
     def prepare(self, tune: bool = False):
         self._check(self.lib.rten_hip_model_prepare(self.h, 1 if tune else 0))
