@@ -40,7 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# Control-flow test mode (tests/test_bench_world8.py): RTEN_BENCH_RECORDING=1 swaps the device context for one that records launches instead of
+# Control-flow test mode (tests/test_bench_world8.py): RTEN_BENCH_RECORDING=1 together with --recording-test swaps the device context for one that records launches instead of
 # issuing them, keeps every tensor torch touches on the CPU and takes the gloo backend -- the script's rank / shard / plan / broadcast / aggregation
 # logic runs unchanged at any world size without a GPU.  Numbers printed in this mode mean nothing and say so (`data`: "recording").
 DRY = os.environ.get("RTEN_BENCH_RECORDING") == "1"
@@ -251,72 +251,413 @@ def secondary_configs():
     return res
 
 
+def int8_graph_floor_bytes(batch, qout=(), num_classes=1000):
+    """int8_algorithmic_bytes() from host arithmetic alone (the executor path has no runner object): the HBM floor of the dynamically quantized graph
+    as the reference runs it -- every conv output an f32 tensor (4 B write), one DynamicQuantizeLinear per distinct tensor (4 B read + 1 B codes), every
+    conv reads its codes (1 B) and weights, a residual Add reads 4 B; max-pool, global average pool and the classifier as their operands.
+    `qout`: the floor of the launch sequence actually run -- a quantized-output launch writes its consumer's codes itself, so the quantizer's 4 B read
+    disappears, and the 4 B f32 write too unless a residual Add needs the tensor."""
+    from rten_amd.workloads import resnet50
+    shapes, descs = resnet50.layer_geometry(batch)
+    specs = resnet50.conv_specs()
+    by_dst = {l["dst"]: l["name"] for l in specs}
+    residuals = {l["res"] for l in specs if l["res"]}
+    qout = set(qout)
+    total, quantized = 0.0, set()
+    for l in specs:
+        d = descs[l["name"]]
+        in_elems, out_elems = d.n * d.c * d.h * d.w, d.n * d.o * d.out_h * d.out_w
+        if l["src"] not in quantized:
+            quantized.add(l["src"])
+            total += 1.0 * in_elems if by_dst.get(l["src"]) in qout else 5.0 * in_elems
+        total += 1.0 * in_elems + d.o * d.c * d.kh * d.kw
+        if not (l["name"] in qout and l["dst"] not in residuals):
+            total += 4.0 * out_elems
+        if l["res"]:
+            total += 4.0 * out_elems
+    n, c, h, w = shapes["stem"]
+    ph = shapes["pool"][2]
+    total += 4.0 * n * c * (h * w + ph * ph)
+    last = shapes[specs[-1]["dst"]]
+    total += 4.0 * last[0] * last[1] * (last[2] * last[3] + 1)
+    total += 2048.0 * num_classes + 8.0 * last[0] * num_classes + 9.0 * last[0] * 2048
+    return total
+
+
+def attach_traffic(roof, plan_sha, int8):
+    """HBM bytes per launch of the dominant kernel from a SEPARATE PMC pass (FETCH_SIZE x2 + WRITE_SIZE, tools/gpu/traffic.sh: counters cannot be
+    collected inside the timed run).  The figure belongs to the plan that pass ran under, named in `traffic_source` / `traffic_note`; it is null when
+    no committed pass covers this kernel instantiation under the same launch plan."""
+    import glob
+    if not roof or "kernel" not in roof:
+        return
+    fname = "int8_hbm_traffic_per_kernel.json" if int8 else "hbm_traffic_per_kernel.json"
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", fname)), reverse=True):
+        prof = json.load(open(path))
+        ks = prof.get("kernels", {})
+        name = roof["kernel"].replace(" ", "")
+        # the profiler prints every template argument (defaults included): match on the prefix the backend's own label gives
+        cands = [k for k in ks if k == name or k.startswith(name[:-1] + ",")]
+        if not cands:
+            continue
+        best = max(cands, key=lambda k: ks[k].get("launches", 0))
+        t = ks[best]
+        total = t["hbm_read_bytes_per_launch"] + t["hbm_write_bytes_per_launch"]
+        same_plan = plan_sha is not None and prof.get("plan_sha16") == plan_sha
+        roof["traffic"] = total if same_plan else None  # a figure measured under another launch plan is not this run's traffic
+        roof["traffic_kernel"] = best
+        roof["traffic_source"] = os.path.relpath(path, ROOT)
+        roof["traffic_plan_sha16"] = prof.get("plan_sha16")
+        roof["traffic_note"] = ("HBM bytes per launch of the dominant kernel (FETCH_SIZE x 2 + WRITE_SIZE) from a separate rocprofv3 --pmc pass over the SAME launch plan "
+                                "(plan_sha16 matches; counters cannot be collected inside the timed run)" if same_plan else
+                                f"null: the committed PMC pass ran another launch plan (its figure for this kernel: {total} B per launch)")
+        break
+
+
+def per_shape_table(ctx, plan_1chain, reps=8):
+    """`roofline.shapes`: every distinct convolution shape of ResNet-50 at batch 32, launched STAND-ALONE through
+    rten_hip_conv2d_f32 under the committed one-chain plan (HIP-event timers around `reps` back-to-back launches, realistic operands), with the bound
+    the shape itself allows: t_attainable = max(HBM time of its algorithmic bytes at 8 TB/s, MFMA time / tile-quantisation efficiency), where the
+    quantisation efficiency of T workgroup tiles on 256 compute units is T / (256 * ceil(T / 256)).  north_star words its target per dominant shape."""
+    from rten_amd.workloads import resnet50
+    net = resnet50.ResNet50(ctx, BATCH_PER_GPU)
+    net.upload_weights()
+    net.x.upload(np.random.default_rng(0).random(net.shapes["x"], dtype=np.float32))
+    net.forward()
+    ctx.sync()
+    tile_of = {0: (128, 128), 1: (128, 64), 2: (64, 128), 3: (64, 64)}
+    groups = {}
+    for l in net.specs:
+        d = net.descs[l["name"]]
+        key = (d.o, d.c, d.kh, d.stride_h, d.h, bool(l["res"]))
+        groups.setdefault(key, []).append(l)
+    total_fl = sum(2.0 * net.descs[l["name"]].o * net.descs[l["name"]].c * net.descs[l["name"]].kh ** 2 * net.descs[l["name"]].out_h * net.descs[l["name"]].out_w * BATCH_PER_GPU
+                   for l in net.specs)
+    rows = []
+    for key, ls in groups.items():
+        l = ls[0]
+        d = net.descs[l["name"]]
+        plan = tuple((plan_1chain or {}).get(l["name"], (3, 0, 1, 0)))
+        net.variants[l["name"]] = plan
+        net._conv(l)
+        ctx.sync()
+        best = 1e30
+        for _ in range(2):
+            ctx.timer_start(3)
+            for _ in range(reps):
+                net._conv(l)
+            ctx.timer_stop(3)
+            best = min(best, ctx.timer_ms(3) / reps)
+        M, K, N = d.o, d.c * d.kh * d.kw, d.n * d.out_h * d.out_w
+        fl = 2.0 * M * K * N
+        alg_bytes = 4.0 * (d.n * d.c * d.h * d.w + M * N * (2 if l["res"] else 1) + M * K)
+        v = plan[0]
+        bm, bn = (32, 32) if v in (28, 29) else (64, 64) if v >= 24 else tile_of[v % 4]
+        tiles = -(-M // bm) * -(-N // bn)
+        q = tiles / (256.0 * -(-tiles // 256))
+        t_mfma, t_hbm = fl / (F32_MATRIX_PEAK_TFLOPS * 1e12), alg_bytes / (HBM_PEAK_GBS * 1e9)
+        t_att = max(t_hbm, t_mfma / q)
+        rows.append({"shape": f"O{d.o} C{d.c} k{d.kh} s{d.stride_h} {d.h}x{d.w}->{d.out_h}x{d.out_w}" + (" +res" if l["res"] else ""), "layers": len(ls), "example": l["name"],
+                     "M": M, "K": K, "N": N, "plan": list(plan), "us": round(best * 1e3, 2), "tflops": round(fl / (best * 1e-3) / 1e12, 2),
+                     "frac_mfma": round(fl / (best * 1e-3) / 1e12 / F32_MATRIX_PEAK_TFLOPS, 4), "frac_hbm": round(alg_bytes / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "tiles": tiles, "tiles_per_cu": round(tiles / 256.0, 3), "quantisation_eff": round(q, 4),
+                     "attainable": {"us": round(t_att * 1e6, 2), "bound": "hbm" if t_hbm >= t_mfma / q else "mfma x tile quantisation", "frac_mfma": round(t_mfma / t_att, 4)},
+                     "frac_of_attainable": round(t_att / (best * 1e-3), 4), "share_of_conv_flops": round(fl * len(ls) / total_fl, 4)})
+    rows.sort(key=lambda r: -r["share_of_conv_flops"])
+    return rows
+
+
 def run_via_executor(args):
-    """`--via-executor`: the SAME workload through the product path a Rust host would use -- the C++ plan executor behind the C ABI
-    (rten_hip_model_*: ONNX bytes in, values resident in HBM, the committed launch plan, sub-batch chains, hipGraph replay) -- instead of the
-    hand-planned Python runner.  One GPU.  The line has the same fields; `config.path` says which path ran, `ranks.logits_sha16_per_rank` is
-    comparable with the runner's (same weights, same inputs -> same bits)."""
+    """The DEFAULT path: the workload through the product path a Rust host binds -- the C++ plan executor behind the C ABI (rten_hip_model_*: ONNX
+    bytes in, values resident in HBM, the committed launch plan, sub-batch chains, hipGraph replay).  One process per GPU; every rank loads the model,
+    rank 0 for real, the others with RTEN_HIP_MODEL_RECEIVE_WEIGHTS, and the weight arena (one allocation: every constant + prepacked weight) is
+    broadcast once from rank 0 -- by the backend's own RCCL binding (rten_hip_comm_*) under the nccl backend."""
     import hashlib
+    under_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if not under_launcher and args.gpus > 1:
+        return spawn_ranks(args.gpus, sys.argv[1:])
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to report a number for GPUs that are not running",
+              file=sys.stderr)
+        return 2
+    import torch
+    dist, backend = None, "none"
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "gloo" if DRY else os.environ.get("RTEN_DIST_BACKEND", "nccl")
+        if backend != "nccl":
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
+        if not DRY:
+            torch.cuda.set_device(local_rank)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    elif not DRY:
+        torch.cuda.set_device(local_rank)
+
     from rten_amd import lib, onnx_writer
     from rten_amd.tensor import DeviceTensor
     from rten_amd.workloads import resnet50
     int8 = args.config == "int8"
-    ctx = lib.Context(0)
+    if DRY:
+        from rten_amd.recording import RecordingCtx, RecordingModel
+        ctx, Model = RecordingCtx(local_rank), RecordingModel
+        torch.cuda.synchronize = lambda *a, **k: None  # (nothing is ever enqueued on a device in this mode)
+    else:
+        ctx, Model = lib.Context(local_rank), lib.Model  # no CPU fallback: raises if the HIP extension / MI355X is missing
     weights = resnet50.make_weights()
     chains = 1 if int8 else (4 if args.chains is None else args.chains)
     onnx_bytes = onnx_writer.resnet50_int8(weights) if int8 else onnx_writer.resnet50_f32(weights)
-    plan_path = args.load_plan or os.path.join(ROOT, "profiles", "plans", "int8.json" if int8 else f"f32_{chains}chain{'s' if chains > 1 else ''}.json")
-    # (the int8 plan is the list of edges that take the quantized-output launch: opt-in, as in the runner's line)
-    plan_text = None if (args.no_autotune or not os.path.exists(plan_path)) else open(plan_path).read()
-    model = lib.Model(ctx, onnx_bytes, plan_text, chains)
+    default_plan = os.path.join(ROOT, "profiles", "plans", "int8.json" if int8 else f"f32_{chains}chain{'s' if chains > 1 else ''}.json")
+    plan_path = args.load_plan or default_plan
+    plan_text, plan_source = None, "backend defaults (no plan)"
+    if not args.no_autotune and not args.autotune and os.path.exists(plan_path):
+        plan_text, plan_source = open(plan_path).read(), os.path.relpath(os.path.abspath(plan_path), ROOT)
+    if plan_text and int8 and (args.no_qout or (world > 1 and backend != "nccl")):
+        # quantized-output launches need every workgroup of a launch resident at once: not when several ranks share ONE GPU (the gloo test mode)
+        p = json.loads(plan_text)
+        p.pop("qout", None)
+        plan_text = json.dumps(p)
+
+    def load(text):
+        return Model(ctx, onnx_bytes, text, chains, receive_weights=(rank != 0))
+
+    # ---- the launch plan every rank runs: the committed file, or (--autotune, f32) rank 0 tunes at load and the result is broadcast
+    if args.autotune and not int8:
+        tuned = [None]
+        if rank == 0:
+            m0 = Model(ctx, onnx_bytes, None, chains)
+            m0.bind_input("x", (BATCH_PER_GPU, 3, 224, 224))
+            m0.prepare(tune=True)
+            tuned[0] = m0.plan_json()
+            m0.close()
+        if dist is not None:
+            dist.broadcast_object_list(tuned, src=0)
+        plan_text, plan_source = tuned[0], "tuned in this run by rank 0" + (" and broadcast" if world > 1 else "")
+        if args.save_plan and rank == 0:
+            open(args.save_plan, "w").write(plan_text)
+    model = load(plan_text)
+
+    # ---- the one collective: the weight arena, from the rank that loaded the model file for real
+    comm_world = 1
+    arena_ptr, arena_bytes = model.weight_arena()
+    if world > 1:
+        ctx.sync()
+        if backend == "nccl":
+            uid = [lib.Comm.unique_id(ctx) if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            comm = lib.Comm(ctx, uid[0], world, rank)
+            comm.broadcast(arena_ptr, arena_bytes, root=0)  # RCCL over xGMI, once
+            ctx.sync()
+            comm_world = comm.world_size
+            comm.close()
+        else:  # several ranks on one GPU / no GPU at all: torch.distributed (gloo) carries the bytes through the host
+            host = torch.empty(arena_bytes, dtype=torch.uint8)
+            dev = DeviceTensor(ctx, (arena_bytes,), np.uint8, ptr=arena_ptr, keepalive=model)
+            if rank == 0 and not DRY:
+                host.copy_(torch.from_numpy(dev.numpy()))
+            dist.broadcast(host, src=0)
+            if rank != 0 and not DRY:
+                dev.upload(host.numpy())
+            comm_world = dist.get_world_size()
+        if DRY and rank == 0:
+            print(f"[recording] weight arena {arena_bytes} bytes broadcast to {comm_world} ranks", file=sys.stderr)
     xptr = model.bind_input("x", (BATCH_PER_GPU, 3, 224, 224))
-    model.prepare(tune=bool(args.autotune and not plan_text))
-    x = np.random.default_rng(1234).random((BATCH_PER_GPU, 3, 224, 224), dtype=np.float32)
+    model.prepare()
+    # each rank gets its own (independent) synthetic batch, resident in HBM before timing starts
+    x = np.random.default_rng(1234 + rank).random((BATCH_PER_GPU, 3, 224, 224), dtype=np.float32)
     xt = DeviceTensor(ctx, x.shape, np.float32, ptr=xptr, keepalive=model)
     xt.upload(x)
     ctx.sync()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    # K steps back to back: the chains are joined ONCE, at the end of the region (the steps are independent batches; model.sync() covers every stream)
     for _ in range(args.warmup):
-        model.run(join=False)  # (as in the runner's line: the chains are joined once, by sync())
+        model.run(join=False)
     model.sync()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         model.run(join=False)
     model.sync()
+    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    barrier()
+    per_rank_ms = [round(elapsed / args.steps * 1e3, 4)]
+    if dist is not None:
+        devname = f"cuda:{local_rank}" if backend == "nccl" else "cpu"
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=devname)
+        allt = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allt, mine)
+        per_rank_ms = [round(float(t.item()) / args.steps * 1e3, 4) for t in allt]
+        t = mine.clone()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
     optr, oshape = model.output(0)
     logits = DeviceTensor(ctx, oshape, np.float32, ptr=optr, keepalive=model).numpy()
+    logits_sha = hashlib.sha256(np.ascontiguousarray(logits).tobytes()).hexdigest()[:16]
+    plan_sha = hashlib.sha256(json.dumps(json.loads(plan_text), sort_keys=True).encode()).hexdigest()[:16] if plan_text else None
+    shard_report = [(rank, logits_sha, plan_sha, model.planned_steps)]
+    if dist is not None:
+        box = [None] * world
+        dist.all_gather_object(box, shard_report[0])
+        shard_report = sorted(box)
+
+    # ---- per-step join (a latency figure: every step waits for all chains) beside the free-running throughput figure above
     lat = []
     for _ in range(min(args.steps, 20)):
         t1 = time.perf_counter()
         model.run()
         model.sync()
         lat.append((time.perf_counter() - t1) * 1e3)
+    p50 = float(np.median(lat))
+    t1 = time.perf_counter()
+    for _ in range(min(args.steps, 20)):
+        model.run()  # joined on the caller's stream every step, host not blocked
+    model.sync()
+    joined_ms = (time.perf_counter() - t1) / min(args.steps, 20) * 1e3
+
+    # ---- PCIe-inclusive rate (the reference's Model::run takes host tensors): batch uploaded and logits downloaded every step.  Never `value`.
+    pcie_ms = None
+    if rank == 0:
+        t1 = time.perf_counter()
+        for _ in range(min(args.steps, 20)):
+            xt.upload(x)
+            model.run(inputs_written_on_caller_stream=True)
+            model.sync()
+            DeviceTensor(ctx, oshape, np.float32, ptr=optr, keepalive=model).numpy()
+        pcie_ms = (time.perf_counter() - t1) / min(args.steps, 20) * 1e3
+
     step_ms = elapsed / args.steps * 1e3
     gflop = (resnet50.conv_flops_per_image() + 2 * 2048 * 1000) / 1e9
-    step_tf = gflop * BATCH_PER_GPU / step_ms
-    if int8:
-        roof = {"bound": "mfma", "achieved": round(step_tf, 2), "peak": I8_MATRIX_PEAK_TOPS, "unit": "TOP/s", "frac": round(step_tf / I8_MATRIX_PEAK_TOPS, 4), "traffic": None,
-                "what": "integer ops of one batch over the timed step (the per-kernel / HBM tables belong to `python bench.py --config int8`)"}
-    else:
-        roof = {"bound": "mfma", "achieved": round(step_tf, 3), "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(step_tf / F32_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
-                "what": "2*M*N*K of every convolution / classifier launch of one batch over the TIMED step, through the C++ executor (same definition as the runner's line)"}
-    out = {"metric": f"inferences/sec, ResNet-50 {'int8 (dynamically quantized)' if int8 else 'f32'} batch 32 per GPU", "value": round(BATCH_PER_GPU * args.steps / elapsed, 2),
-           "unit": "inferences/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_ms, 4), "p50_latency_ms": round(float(np.median(lat)), 4),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 x i8 -> i32 (f32 between layers)" if int8 else "f32", "data": "synthetic",
-           "config": {"workload": f"ResNet-50 v1.5 {'dynamically quantized int8' if int8 else 'f32'} inference, 224x224, batch 32 (BASELINE configs[{2 if int8 else 1}]) from an ONNX file "
-                                  "(rten_amd.onnx_writer), synthetic He-normal BN-folded weights (seed 1234), inputs U[0,1) resident in HBM",
-                      "path": "C++ plan executor behind the C ABI (rten_hip_model_load / _prepare / _run: include/rten_hip_graph.hpp + csrc/graph_abi.cpp) -- the path a Rust host binds",
-                      "global_batch": BATCH_PER_GPU, "launch": "hipGraph replay", "batch_chains": {"chains": chains},
-                      "launch_plan": {"source": os.path.relpath(plan_path, ROOT) if plan_text else ("tuned at load" if args.autotune else "backend defaults"),
-                                      "sha16": hashlib.sha256(json.dumps(json.loads(plan_text), sort_keys=True).encode()).hexdigest()[:16] if plan_text else None,
-                                      "steps_planned": model.planned_steps, "steps": model.num_steps},
-                      "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "gflop_per_image": round(gflop, 3), "device": ctx.device_info()},
-           "ranks": {"world_size": 1, "logits_sha16_per_rank": [hashlib.sha256(np.ascontiguousarray(logits).tobytes()).hexdigest()[:16]], "input_seed_per_rank": [1234]},
-           "roofline": roof}
-    if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline_int8(resnet50.conv_specs(), weights) if int8 else cpu_baseline(resnet50.conv_specs(), weights)
-    print(json.dumps(out))
+    roof = None
+    if rank == 0:
+        rep = model.profile_pass(max(1, min(args.steps, 10)))  # serialised, eager, HIP events per launch: per-kernel detail, outside the timed region
+        nrep = max(1, min(args.steps, 10))
+        tot_ms = sum(r["ms"] for r in rep)
+        if int8:
+            conv = [r for r in rep if r["kernel"].startswith("igemm_i8")]
+            qlist = json.loads(plan_text).get("qout", []) if plan_text else []
+            alg, alg_l = int8_graph_floor_bytes(BATCH_PER_GPU), int8_graph_floor_bytes(BATCH_PER_GPU, qlist)
+            step = {"algorithmic_bytes": alg, "achieved": round(alg / (step_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(alg / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "note": "whole forward pass (the TIMED step) against the HBM floor of the graph as the reference runs it (every conv output an f32 tensor; DESIGN.md section 8)",
+                    "as_launched": {"algorithmic_bytes": alg_l, "achieved": round(alg_l / (step_ms * 1e-3) / 1e9, 1), "frac": round(alg_l / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "note": "floor of the launch sequence actually run: quantized-output launches never write / re-read the f32 tensor of a single-consumer edge"},
+                    "mfma": {"achieved": round(gflop * BATCH_PER_GPU / step_ms, 2), "peak": I8_MATRIX_PEAK_TOPS, "unit": "TOP/s",
+                             "frac": round(gflop * BATCH_PER_GPU / step_ms / I8_MATRIX_PEAK_TOPS, 4)}}
+            if conv:
+                dom = max(conv, key=lambda r: r["ms"])
+                fam_ms, fam_ops = sum(r["ms"] for r in conv), sum(r["flops"] for r in conv)
+                gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+                roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                        "traffic": None, "traffic_source": None,
+                        "avg_launch_us": round(dom["ms"] * 1e3 / max(dom["launches"], 1), 2), "launches": dom["launches"], "bytes_per_launch": dom["bytes"] / max(dom["launches"], 1),
+                        "kernel_share_of_step": round(dom["ms"] / max(tot_ms, 1e-9), 4),
+                        "mfma": {"achieved": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12, 2), "peak": I8_MATRIX_PEAK_TOPS, "unit": "TOP/s",
+                                 "frac": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12 / I8_MATRIX_PEAK_TOPS, 4)},
+                        "step": step,
+                        "igemm_i8_family": {"achieved": round(fam_ops / (fam_ms * 1e-3) / 1e12, 2), "unit": "TOP/s",
+                                            "frac_of_i8_mfma_peak": round(fam_ops / (fam_ms * 1e-3) / 1e12 / I8_MATRIX_PEAK_TOPS, 4), "share_of_step": round(fam_ms / max(tot_ms, 1e-9), 4),
+                                            "variants": {r["kernel"]: {"launches": r["launches"], "ms": round(r["ms"], 4), "tops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2),
+                                                                       "gbs": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)} for r in conv}},
+                        "other_kernels": {r["kernel"]: {"launches": r["launches"], "ms": round(r["ms"], 4), "gbs": round(r["bytes"] / max(r["ms"] * 1e-3, 1e-12) / 1e9, 1)}
+                                          for r in rep if not r["kernel"].startswith("igemm_i8")}}
+                attach_traffic(roof, plan_sha, int8=True)
+            else:
+                roof = {"bound": "hbm", "achieved": step["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step["frac"], "traffic": None, "step": step}
+        else:
+            conv = [r for r in rep if r["kernel"].startswith("igemm_f32")]
+            step_tf = gflop * BATCH_PER_GPU / step_ms
+            roof = {"bound": "mfma", "achieved": round(step_tf, 3), "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(step_tf / F32_MATRIX_PEAK_TFLOPS, 4),
+                    "what": "2*M*N*K of every convolution / classifier launch of one batch, divided by the TIMED step (all kernels and gaps included; "
+                            "the chains overlap in the timed region, so this -- not a serialised per-kernel figure -- is the state the value was measured in)",
+                    "traffic": None, "traffic_source": None}
+            if conv:
+                dom = max(conv, key=lambda r: r["ms"])
+                dom_tf = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+                fam_ms, fam_fl = sum(r["ms"] for r in conv), sum(r["flops"] for r in conv)
+                roof["kernel"] = dom["kernel"]
+                roof["dominant_kernel"] = {"kernel": dom["kernel"], "achieved": round(dom_tf, 3), "frac": round(dom_tf / F32_MATRIX_PEAK_TFLOPS, 4),
+                                           "avg_launch_us": round(dom["ms"] * 1e3 / max(dom["launches"], 1), 2), "launches": dom["launches"],
+                                           "flops_per_launch": dom["flops"] / max(dom["launches"], 1), "share_of_serialised_pass": round(dom["ms"] / max(tot_ms, 1e-9), 4),
+                                           "note": "stand-alone, serialised launches (HIP events per launch on the chain's stream)"
+                                                   + (f" at the sub-batch shapes the {chains} chains launch: such a kernel under-fills the chip on its own, which is what "
+                                                      "overlapping the chains is for" if chains > 1 else "")}
+                roof["igemm_family"] = {"achieved": round(fam_fl / (fam_ms * 1e-3) / 1e12, 3), "frac": round(fam_fl / (fam_ms * 1e-3) / 1e12 / F32_MATRIX_PEAK_TFLOPS, 4),
+                                        "share_of_serialised_pass": round(fam_ms / max(tot_ms, 1e-9), 4),
+                                        "variants": {r["kernel"]: {"launches": r["launches"], "ms": round(r["ms"], 4), "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2)} for r in conv}}
+            attach_traffic(roof, plan_sha, int8=False)
+            if world == 1 and not DRY and not args.no_shapes:
+                p1 = os.path.join(ROOT, "profiles", "plans", "f32_1chain.json")
+                model.sync()
+                roof["shapes"] = per_shape_table(ctx, json.load(open(p1)) if os.path.exists(p1) else None)
+                roof["shapes_note"] = ("every distinct convolution shape at batch 32, stand-alone under profiles/plans/f32_1chain.json: us, TFLOP/s, fraction of the MFMA / HBM peak, "
+                                       "tiles per compute unit, and the bound the shape allows (max of its HBM time and its MFMA time over the tile-quantisation efficiency)")
+    if rank == 0:
+        global_batch = BATCH_PER_GPU * world
+        out = {"metric": f"inferences/sec, ResNet-50 {'int8 (dynamically quantized)' if int8 else 'f32'} batch 32 per GPU", "value": round(global_batch * args.steps / elapsed, 2),
+               "unit": "inferences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_ms, 4),
+               "ms_per_step_joined_every_step": round(joined_ms, 4), "p50_latency_ms": round(p50, 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 x i8 -> i32 (f32 between layers)" if int8 else "f32",
+               "data": "recording (no device: control-flow test)" if DRY else "synthetic",
+               "config": {"workload": f"ResNet-50 v1.5 {'dynamically quantized int8 (DynamicQuantizeLinear -> ConvIntegerToFloat per conv, 7-bit per-tensor weights as tools/ort-quantize.py writes them)' if int8 else 'f32'} "
+                                      f"inference, 224x224, batch 32 per GPU (BASELINE configs[{2 if int8 else 1}]" + ("; x8 GPUs = configs[4]" if int8 else "") + ") from ONNX bytes "
+                                      "(rten_amd.onnx_writer), synthetic He-normal BN-folded weights (seed 1234), inputs U[0,1) resident in HBM",
+                          "path": "executor",
+                          "path_note": "C++ plan executor behind the C ABI (rten_hip_model_load_ex / _prepare / _run: include/rten_hip_graph.hpp + csrc/graph_abi.cpp) -- "
+                                       "the path a Rust host binds (INTEGRATION.md 2.5); `--via-runner` times the hand-planned Python runner instead",
+                          "global_batch": global_batch, "parallelism": f"batch-shard x{world} (weight arena RCCL-broadcast once)" if world > 1 else "single GPU",
+                          "launch": "hipGraph replay",
+                          "batch_chains": {"chains": chains,
+                                           "note": "independent sub-batch chains on their own streams, shared weights, logits bit-identical to one chain; in the warm-up and the timed "
+                                                   "region the chains free-run across steps and are joined once at the end (`ms_per_step` is a THROUGHPUT figure; "
+                                                   "`ms_per_step_joined_every_step` / `p50_latency_ms` join every step)"},
+                          "launch_plan": {"source": plan_source, "sha16": plan_sha, "identical_on_all_ranks": len({r[2] for r in shard_report}) == 1,
+                                          "steps_planned": model.planned_steps, "steps": model.num_steps, "warning": model.warning or None},
+                          "weight_arena_bytes": arena_bytes, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                          ("gop_per_image" if int8 else "gflop_per_image"): round(gflop, 3), "device": ctx.device_info()},
+               "ranks": {"world_size": world, "dist_backend": backend, "weight_broadcast_world": comm_world, "ms_per_step_per_rank": per_rank_ms,
+                         "logits_sha16_per_rank": [r[1] for r in shard_report], "plan_sha16_per_rank": [r[2] for r in shard_report],
+                         "planned_steps_per_rank": [r[3] for r in shard_report], "input_seed_per_rank": [1234 + r[0] for r in shard_report]},
+               "pcie_inclusive": {"ms_per_step": round(pcie_ms, 4), "inferences_per_s": round(BATCH_PER_GPU / (pcie_ms * 1e-3), 1),
+                                  "note": "rank 0: batch uploaded from pageable host memory and logits downloaded every step (19.3 MB in, 128 KB out); not `value`"} if pcie_ms else None,
+               "roofline": roof}
+        if int8:
+            out["config"]["int8_pad_mode"] = ("RAW0_I8 -- ASSUMPTION: padded taps of an integer convolution hold raw 0 after the u8->i8 shift, the x86 reference's im2col behaviour "
+                                              "(rten-gemm/src/im2col.rs:340-358, SURVEY App. C.1); unpinned by a reference-held vector; ZERO_POINT / RAW0_U8 are the other modes of the ABI")
+            p = json.loads(plan_text) if plan_text else {}
+            out["config"]["quantized_output_launches"] = sorted(p.get("qout", []))
+            out["config"]["quantize_on_load_layers"] = sorted(p.get("fused_dql", []))
+        if world == 1 and not args.no_cpu_baseline and not DRY:
+            out["cpu_baseline"] = cpu_baseline_int8(resnet50.conv_specs(), weights) if int8 else cpu_baseline(resnet50.conv_specs(), weights)
+            if not int8:
+                out["cpu_baseline"]["other_cpu_implementation"] = torch_cpu_reference(resnet50.conv_specs(), weights)
+        else:
+            out["cpu_baseline"] = None
+        if world == 1 and not args.no_secondary and not int8 and not DRY:
+            out["secondary"] = secondary_configs()
+        print(json.dumps(out))
+    if DRY:
+        import collections
+        c = collections.Counter(ctx.log)
+        from rten_amd.sharding import shard_range
+        print(f"[recording] rank {rank} seed {1234 + rank} shard {list(shard_range(BATCH_PER_GPU * world, rank, world))[:1]}..+{BATCH_PER_GPU} graph_launch {c['graph_launch']} "
+              f"load {c['model_load']} load_receive {c['model_load_receive']} prepare {c['model_prepare']} h2d {c['rten_hip_memcpy_h2d']}", file=sys.stderr)
     model.close()
+    if dist is not None:
+        dist.barrier()  # rank 0's instrumented pass / JSON line happen before any rank tears the group down
+        dist.destroy_process_group()
     return 0
 
 
@@ -334,7 +675,7 @@ def spawn_ranks(n, argv):
     return subprocess.call(cmd)
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -357,10 +698,18 @@ def main():
                     help="f32: run the batch as this many independent sub-batch chains on their own streams (default 4; 1 = one chain). "
                          "The int8 graph quantizes each activation over the whole batch, so it always runs as one chain")
     ap.add_argument("--concurrent", action="store_true", help="run the projection shortcuts on a second stream (parallel graph branches)")
-    ap.add_argument("--via-executor", action="store_true",
-                    help="run the workload through the C++ plan executor behind the C ABI (rten_hip_model_*: ONNX file in, committed launch plan, chains, hipGraph "
-                         "replay) -- the product path a Rust host binds -- instead of the Python runner; one GPU")
-    args = ap.parse_args()
+    ap.add_argument("--via-executor", action="store_true", help="(the default since round 5; kept so that older command lines still parse)")
+    ap.add_argument("--via-runner", action="store_true",
+                    help="time the hand-planned Python runner (rten_amd/workloads/*.py over the per-operator C entry points) instead of the product path -- the C++ "
+                         "plan executor behind the C ABI (rten_hip_model_*: ONNX bytes in, committed launch plan, chains, hipGraph replay), which is the default")
+    ap.add_argument("--no-shapes", action="store_true", help="f32: skip the stand-alone per-shape table (`roofline.shapes`)")
+    ap.add_argument("--recording-test", action="store_true",
+                    help="control-flow test mode (tests/test_bench_world8.py): together with RTEN_BENCH_RECORDING=1, launches are recorded instead of issued")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
 
     # ---- launch contract: N ranks, one per GPU.  Under a launcher (the driver's torch.distributed.run) WORLD_SIZE must
     # equal --gpus; without one, --gpus N > 1 spawns the ranks itself.  A single process never reports N GPUs.
@@ -373,11 +722,19 @@ def main():
     if args.chains is not None and not 1 <= args.chains <= 8:
         print("bench.py: --chains must be 1..8", file=sys.stderr)
         return 2
-    if args.via_executor:
-        if args.gpus != 1 or "WORLD_SIZE" in os.environ:
-            print("bench.py: --via-executor is a single-GPU measurement", file=sys.stderr)
-            return 2
+    if DRY and not args.recording_test:
+        print("bench.py: RTEN_BENCH_RECORDING=1 without --recording-test: the recording mode is a control-flow test (tests/test_bench_world8.py), "
+              "never a measurement; refusing", file=sys.stderr)
+        return 2
+    # int8 --autotune: the per-edge / per-layer choices of the int8 plan (quantized-output edges, quantize-on-load layers) are measured by the Python
+    # runner, which writes the plan file the executor reads
+    if not (args.via_runner or (args.autotune and args.config == "int8")):
         return run_via_executor(args)
+    return run_via_runner(args)
+
+
+def run_via_runner(args):
+    """`--via-runner`: the hand-planned Python runner over the per-operator C entry points (rounds 1-4's headline path; A/B against the executor)."""
     under_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ
     if not under_launcher and args.gpus > 1:
         return spawn_ranks(args.gpus, sys.argv[1:])
@@ -414,7 +771,7 @@ def main():
     from rten_amd.sharding import broadcast_weight_arena
 
     if DRY:
-        from tests.recording_ctx import RecordingCtx
+        from rten_amd.recording import RecordingCtx
         ctx = RecordingCtx(local_rank)
         torch.cuda.synchronize = lambda *a, **k: None  # (nothing is ever enqueued on a device in this mode)
     else:
@@ -726,7 +1083,8 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "p50_latency_ms": round(p50, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 x i8 -> i32 (f32 between layers)" if int8 else "f32",
             "data": "recording (no device: control-flow test)" if DRY else "synthetic",
-            "config": {"workload": workload,
+            "config": {"workload": workload, "path": "runner",
+                       "path_note": "hand-planned Python runner over the per-operator C entry points (--via-runner); the default path is the C++ plan executor behind the C ABI",
                        "global_batch": global_batch, "parallelism": f"batch-shard x{n_gpus} (weights RCCL-broadcast once)" if n_gpus > 1 else "single GPU",
                        "launch": "eager" if args.no_graph else "hipGraph replay", "autotuned_tiles": bool(net.variants),
                        "launch_plan": {"source": plan_source, "sha16": plan_sha, "identical_on_all_ranks": len({r[2] for r in shard_report}) == 1},

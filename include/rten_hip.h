@@ -510,6 +510,13 @@ int32_t rten_hip_model_load_ex(rten_hip_ctx *ctx, const void *onnx_bytes, size_t
                                uint32_t flags, rten_hip_model **out_model);
 const char *rten_hip_model_load_error(void);
 int32_t rten_hip_model_weight_arena(rten_hip_model *model, void **dev_ptr, size_t *bytes);
+/* The launch plan a prepared model runs under, as plan-file text keyed by sub-batch size (what prepare(tune = 1) chose / the plan file gave): f32
+ * convolution steps AND MatMul / FusedMatMul / Gemm steps (v4: the latter take plan entries and are tuned too).  `*needed` = bytes incl. terminator. */
+int32_t rten_hip_model_plan_json(rten_hip_model *model, char *buf, size_t buf_len, size_t *needed);
+/* Measurement aid: every chain runs its plan eagerly `steps` times, one chain after the other, under the per-launch profiler (rten_hip_profile_*);
+ * result = a JSON array of one rten_hip_profile_report array per chain.  Call it with `buf` NULL / too small to learn `*needed` is NOT supported
+ * (the pass would run twice): pass a buffer of 1 MiB. */
+int32_t rten_hip_model_profile(rten_hip_model *model, int32_t steps, char *buf, size_t buf_len, size_t *needed);
 int32_t rten_hip_model_sync(rten_hip_model *model);
 int32_t rten_hip_model_output(rten_hip_model *model, int32_t i, const void **dev_ptr, int64_t *shape /* 8 entries */, int32_t *ndim);
 int32_t rten_hip_model_destroy(rten_hip_model *model);

@@ -388,17 +388,21 @@ class Graph {
     size_t apply_plan(const std::map<std::string, GemmPlan> &table) {
         size_t n = 0;
         for (auto &st : steps_) {
-            if (!st.conv) continue;
+            if (!st.conv && !st.gemm_plan) continue;
             auto it = table.find(st.name);
             if (it == table.end()) continue;
-            st.conv->plan = it->second;
+            if (st.conv) st.conv->plan = it->second;
+            else *st.gemm_plan = it->second;
             n++;
         }
         return n;
     }
     std::map<std::string, GemmPlan> plans() const { // what autotune() / apply_plan() left on the convolution steps
         std::map<std::string, GemmPlan> t;
-        for (auto &st : steps_) if (st.conv && st.conv->plan.set) t[st.name] = st.conv->plan;
+        for (auto &st : steps_) {
+            if (st.conv && st.conv->plan.set) t[st.name] = st.conv->plan;
+            if (st.gemm_plan && st.gemm_plan->set) t[st.name] = *st.gemm_plan;
+        }
         return t;
     }
     bool captured() const { return graph_ != 0; }
@@ -456,7 +460,7 @@ class Graph {
             }
             const auto t0 = std::chrono::steady_clock::now();
             OutputList out;
-            if (tune_reps_ > 0 && st.conv) tune_step(st, in);
+            if (tune_reps_ > 0 && (st.conv || st.gemm_plan)) tune_step(st, in);
             try {
                 out = st.run(ctx_, in);
             } catch (const OpError &e) { // name the node, like the reference's RunError::OperatorError { name, error }
@@ -512,6 +516,7 @@ class Graph {
         std::function<OutputList(Context &, const InputList &)> run;
         bool view = false;
         std::shared_ptr<Conv> conv; // f32 convolution steps: the launch plan is tunable
+        std::shared_ptr<GemmPlan> gemm_plan; // MatMul / FusedMatMul / Gemm steps: the same launch plan, applied around the step's GEMM
         std::shared_ptr<I8Conv> i8; // int8 convolution steps: staged-pipeline options are decided after all steps exist
         std::shared_ptr<DynamicQuantizeLinearStaged> dql_staged;
         std::shared_ptr<MaxPool> maxpool; // a max-pool whose output is quantized next can accumulate the quantizer's statistics
@@ -759,11 +764,17 @@ class Graph {
     std::vector<Tensor> captured_outputs_;
 
     void tune_step(Step &st, const InputList &in) {
+        std::vector<GemmPlan> plans;
+        const int nvar = rten_hip_num_gemm_variants();
+        auto set_plan = [&](const GemmPlan &p) { if (st.conv) st.conv->plan = p; else *st.gemm_plan = p; };
+        if (st.gemm_plan) {
+            // MatMul-family steps (row-major A): the LDS-DMA pipelines with three / four stages x tile order (m fastest / n fastest within an XCD's
+            // share: which operand stays L2-resident) -- the candidate set of rten_amd/workloads/bert.py::autotune
+            for (int v : {0, 1, 2, 3, 12, 13, 14, 15}) if (v < nvar) for (int o = 0; o < 2; o++) plans.push_back(GemmPlan{true, v, 3, 1, o});
+        } else {
         const Tensor &w = require(in, 1);
         const int64_t k = w.len() / std::max<int64_t>(w.size(0), 1); // per-group depth C/g * kh * kw
         const int nblk = (int)((k + 255) / 256);
-        std::vector<GemmPlan> plans;
-        const int nvar = rten_hip_num_gemm_variants();
         for (int v = 0; v < nvar; v++) for (int o = 0; o < 2; o++) plans.push_back(GemmPlan{true, v, 0, 1, o});
         // thin-tile tail (split mode 4) on the LDS-DMA pipelines: whole rounds with the variant's tile + 16x64 tiles on 16x16x4 MFMAs
         for (int v = 0; v < nvar; v++) if (v < 4 || v >= 12) for (int o = 0; o < 2; o++) plans.push_back(GemmPlan{true, v, 4, 1, o});
@@ -783,10 +794,11 @@ class Graph {
                 }
             }
         }
+        }
         GemmPlan best;
         float best_ms = 1e30f;
         for (const GemmPlan &p : plans) {
-            st.conv->plan = p;
+            set_plan(p);
             try {
                 st.run(ctx_, in); // warm (also grows the split-K slab scratch before any capture)
                 float ms = 1e30f;
@@ -802,7 +814,7 @@ class Graph {
             } catch (const OpError &) { // a plan the kernel family does not offer for this shape
             }
         }
-        st.conv->plan = best;
+        set_plan(best);
         tuned_++;
     }
 
@@ -1198,7 +1210,9 @@ class Graph {
                     pj.kind_name = "FusedMatMul(QKV)";
                     pj.in = {id_of(at.x), at.wqkv, at.bqkv};
                     pj.out = {id_of("__qkv." + at.out)};
-                    pj.run = [lin](Context &c, const InputList &in) { return lin->run(c, in); };
+                    auto plan = std::make_shared<GemmPlan>();
+                    pj.gemm_plan = plan;
+                    pj.run = [lin, plan](Context &c, const InputList &in) { PlanScope scope(c, *plan); return lin->run(c, in); };
                     steps_.push_back(std::move(pj));
                     const int qkv = id_of("__qkv." + at.out);
                     op->q_rs = op->k_rs = op->v_rs = 3 * at.hidden; op->width = at.hidden;
@@ -1398,7 +1412,9 @@ class Graph {
                 auto op = std::make_shared<Gemm>();
                 op->alpha = n.get_float("alpha", 1.f); op->beta = n.get_float("beta", 1.f);
                 op->transpose_a = n.get_int("transA", 0) != 0; op->transpose_b = n.get_int("transB", 0) != 0;
-                st.run = [op](Context &c, const InputList &in) { return op->run(c, in); };
+                auto plan = std::make_shared<GemmPlan>();
+                st.gemm_plan = plan;
+                st.run = [op, plan](Context &c, const InputList &in) { PlanScope scope(c, *plan); return op->run(c, in); };
             } else if (n.op_type == "MatMul") {
                 // MatMul (+ Mul / Div by a constant scalar = alpha, MatMulScale fusion) (+ Add of a constant 1-D bias,
                 // MatMulAddFusion) (+ Gelu / Relu as the GEMM epilogue): FusedMatMul (src/ops/matmul.rs:455-510)
@@ -1435,9 +1451,12 @@ class Graph {
                 st.in.resize(2);
                 st.in.push_back(bias.empty() ? -1 : id_of(bias));
                 st.kind_name = std::string(op->alpha != 1.f || !bias.empty() ? "FusedMatMul" : "MatMul") + (op->act == RTEN_HIP_ACT_GELU ? "+Gelu" : op->act == RTEN_HIP_ACT_RELU ? "+Relu" : "");
-                st.run = [op](Context &c, const InputList &in) {
+                auto plan = std::make_shared<GemmPlan>();
+                st.gemm_plan = plan;
+                st.run = [op, plan](Context &c, const InputList &in) {
                     const Tensor *bias = in[2];
                     if (bias && bias->len() != require(in, 1).size(require(in, 1).ndim() - 1)) throw OpError(OpError::IncompatibleInputShapes, "Cannot broadcast bias to output shape");
+                    PlanScope scope(c, *plan);
                     return op->run(c, in);
                 };
             } else if (n.op_type == "Add" && opt_.fuse && sole_user(out_name, "LayerNormalization") >= 0 &&

@@ -373,6 +373,77 @@ RTEN_EXPORT int32_t rten_hip_model_prepare(rten_hip_model *g, int32_t tune) {
     return RTEN_HIP_OK;
 }
 
+// The launch plan the model runs under, as the text of a plan file ({"<sub-batch>": {step: [variant, split mode, K groups, tile order]}}; what
+// rten_hip_model_prepare(tune = 1) chose, or what the plan file / the backend's defaults left on the steps): write it to profiles/plans/ and every later
+// process -- and every rank of a sharded job -- launches the same kernels without tuning.  Returns RTEN_HIP_ERR_INVALID_VALUE when `buf` is too small
+// (`*needed` = bytes including the terminator).
+RTEN_EXPORT int32_t rten_hip_model_plan_json(rten_hip_model *g, char *buf, size_t buf_len, size_t *needed) {
+    if (!g || !g->prepared) return RTEN_HIP_ERR_INVALID_VALUE;
+    std::string out = "{";
+    std::set<int64_t> seen;
+    for (int c = 0; c < g->chains; c++) {
+        const int64_t b = g->sub[(size_t)c];
+        if (!seen.insert(b).second) continue;
+        if (out.size() > 1) out += ", ";
+        out += "\"" + std::to_string(b) + "\": {";
+        bool first = true;
+        for (auto &kv : g->graphs[(size_t)c]->plans()) {
+            if (!first) out += ", ";
+            first = false;
+            out += "\"" + kv.first + "\": [" + std::to_string(kv.second.variant) + ", " + std::to_string(kv.second.mode) + ", " + std::to_string(kv.second.groups) + ", " +
+                   std::to_string(kv.second.order) + "]";
+        }
+        out += "}";
+    }
+    out += "}";
+    if (needed) *needed = out.size() + 1;
+    if (!buf || buf_len < out.size() + 1) return fail(g, RTEN_HIP_ERR_INVALID_VALUE, "plan_json: buffer too small");
+    std::memcpy(buf, out.c_str(), out.size() + 1);
+    return RTEN_HIP_OK;
+}
+
+// Instrumented pass (measurement aid; `bench.py`'s per-kernel roofline figures): every chain runs its plan EAGERLY `steps` times, chain after chain
+// (serialised launches: clean per-kernel durations at the sub-batch shapes actually launched), with the backend's per-launch HIP-event profiler on
+// (rten_hip_profile_*).  Result: a JSON array with one rten_hip_profile_report array per chain.  The captured graphs are untouched (an eager run
+// takes the same pooled buffers the replay uses, so nothing else may run on the model meanwhile).
+RTEN_EXPORT int32_t rten_hip_model_profile(rten_hip_model *g, int32_t steps, char *buf, size_t buf_len, size_t *needed) {
+    if (!g || !g->prepared || steps < 1) return RTEN_HIP_ERR_INVALID_VALUE;
+    std::string out = "[";
+    try {
+        for (auto &c : g->ctxs) c->sync();
+        for (int c = 0; c < g->chains; c++) {
+            Graph &gr = *g->graphs[(size_t)c];
+            Context &cx = *g->ctxs[(size_t)c];
+            Graph::Feeds feeds;
+            for (size_t i = 0; i < g->inputs.size(); i++) feeds.emplace_back(g->inputs[i].name, &g->chain_in[(size_t)c][i]);
+            struct Restore {
+                Context &c; int32_t saved[8]; bool on = false;
+                explicit Restore(Context &cx_) : c(cx_) { on = rten_hip_tuning_save(c.raw(), saved) == RTEN_HIP_OK; }
+                ~Restore() { if (on) rten_hip_tuning_restore(c.raw(), saved); rten_hip_profile_enable(c.raw(), 0); }
+            } restore(cx);
+            if (g->sub[(size_t)c] == 1 && g->start.back() + g->sub.back() > 1) cx.check(rten_hip_set_gemv_order(cx.raw(), 0, 0)); // as in prepare
+            cx.check(rten_hip_profile_reset(cx.raw()));
+            cx.check(rten_hip_profile_enable(cx.raw(), 1));
+            for (int s = 0; s < steps; s++) gr.run(feeds);
+            cx.sync();
+            cx.check(rten_hip_profile_enable(cx.raw(), 0));
+            std::vector<char> rep((size_t)1 << 18);
+            cx.check(rten_hip_profile_report(cx.raw(), rep.data(), (int32_t)rep.size()));
+            if (c) out += ",";
+            out += rep.data();
+        }
+    } catch (const OpError &e) {
+        return fail(g, code_of(e), e.msg);
+    } catch (const std::exception &e) {
+        return fail(g, RTEN_HIP_ERR_INVALID_VALUE, e.what());
+    }
+    out += "]";
+    if (needed) *needed = out.size() + 1;
+    if (!buf || buf_len < out.size() + 1) return fail(g, RTEN_HIP_ERR_INVALID_VALUE, "model_profile: buffer too small");
+    std::memcpy(buf, out.c_str(), out.size() + 1);
+    return RTEN_HIP_OK;
+}
+
 // One inference over the bound inputs.  flags bit 0: the inputs were written on the CALLER's stream since the last run (the chains then wait for
 // that stream first; leave it clear when the inputs are already resident and visible).  On return the caller's stream is ordered after every chain,
 // unless bit 1 is set (the caller synchronises the model itself before reading: back-to-back runs then never touch the caller's stream).

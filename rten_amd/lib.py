@@ -186,6 +186,8 @@ PROTOTYPES = {
     "rten_hip_model_load_ex": (_I32, [_VP, _VP, _SZ, C.c_char_p, _I32, _U32, C.POINTER(_VP)]),
     "rten_hip_model_load_error": (C.c_char_p, []),
     "rten_hip_model_weight_arena": (_I32, [_VP, C.POINTER(_VP), C.POINTER(_SZ)]),
+    "rten_hip_model_plan_json": (_I32, [_VP, C.c_char_p, _SZ, C.POINTER(_SZ)]),
+    "rten_hip_model_profile": (_I32, [_VP, _I32, C.c_char_p, _SZ, C.POINTER(_SZ)]),
     "rten_hip_device_id": (_I32, [_VP]),
     "rten_hip_tuning_save": (_I32, [_VP, C.POINTER(_I32)]),
     "rten_hip_tuning_restore": (_I32, [_VP, C.POINTER(_I32)]),
@@ -416,6 +418,28 @@ class Model:
         p, n = C.c_void_p(), _SZ()
         self._check(self.lib.rten_hip_model_weight_arena(self.h, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def plan_json(self) -> str:
+        """The launch plan of the prepared model as plan-file text (keyed by sub-batch size)."""
+        need = _SZ()
+        self.lib.rten_hip_model_plan_json(self.h, None, 0, C.byref(need))
+        buf = C.create_string_buffer(need.value)
+        self._check(self.lib.rten_hip_model_plan_json(self.h, buf, need.value, C.byref(need)))
+        return buf.value.decode()
+
+    def profile_pass(self, steps: int):
+        """Instrumented eager pass over every chain (serialised launches, HIP events per launch), merged by kernel:
+        [{kernel, launches, ms, flops, bytes}] -- the same rows as Context.profile_report()."""
+        import json
+        buf, need = C.create_string_buffer(1 << 20), _SZ()
+        self._check(self.lib.rten_hip_model_profile(self.h, steps, buf, len(buf), C.byref(need)))
+        merged = {}
+        for chain in json.loads(buf.value.decode()):
+            for r in chain:
+                m = merged.setdefault(r["kernel"], dict(r, launches=0, ms=0.0, flops=0.0, bytes=0.0))
+                for k in ("launches", "ms", "flops", "bytes"):
+                    m[k] += r[k]
+        return list(merged.values())
 
     @property
     def warning(self) -> str:

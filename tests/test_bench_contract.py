@@ -81,6 +81,18 @@ def test_int8_algorithmic_bytes_formula():
     Net.pool_desc = L.Pool2dDesc(32, 64, 112, 112, 3, 3, 2, 2, (C.c_int32 * 4)(1, 1, 1, 1), 56, 56, 0)
     total = bench.int8_algorithmic_bytes(Net)
     assert 3.5e9 < total < 5.0e9  # about 4.3 GB per 32-image batch
+    # the executor path of bench.py has no runner object: the same floor from host arithmetic alone, and the as-launched floor of a plan's edges
+    assert bench.int8_graph_floor_bytes(32) == total
+    import json
+    q = json.load(open(os.path.join(ROOT, "profiles", "plans", "int8.json")))["qout"]
+    assert 0.8 * total < bench.int8_graph_floor_bytes(32, q) < total
+
+
+def test_recording_mode_needs_its_flag():
+    """RTEN_BENCH_RECORDING=1 alone (an environment leak) never turns a benchmark run into a recording."""
+    p = _run(["--steps", "1", "--warmup", "0"], {"RTEN_BENCH_RECORDING": "1"})
+    assert p.returncode == 2 and "--recording-test" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
 
 
 def test_split_batch_covers_the_batch_once():

@@ -18,15 +18,50 @@ def _run(world, config, port, extra=()):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env.update(RTEN_BENCH_RECORDING="1", PYTHONPATH=ROOT + os.pathsep + env.get("PYTHONPATH", ""), OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--config", config, *extra]
+           os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--config", config, "--recording-test", *extra]
     return subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
 
 
 @pytest.mark.parametrize("config", ["int8", "f32"])
+def test_eight_rank_bench_control_flow_of_the_default_path(config):
+    """The executor path (the default): rank 0 loads the model for real, ranks 1-7 with the receive-weights flag, every rank sizes the same arena,
+    one broadcast, the committed plan on every rank, per-rank seeds, ONE aggregate line that says which path ran."""
+    r = _run(8, config, 29615 if config == "int8" else 29617)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["config"]["path"] == "executor" and j["n_gpus"] == 8 and j["config"]["global_batch"] == 256 and j["scaling"] == "weak" and j["steps"] == 3
+    assert j["data"].startswith("recording") and j["cpu_baseline"] is None and "secondary" not in j
+    rk = j["ranks"]
+    assert rk["world_size"] == 8 and rk["dist_backend"] == "gloo" and rk["weight_broadcast_world"] == 8
+    assert rk["input_seed_per_rank"] == [1234 + r_ for r_ in range(8)] and len(rk["ms_per_step_per_rank"]) == 8
+    plan_file = "int8.json" if config == "int8" else "f32_4chains.json"
+    assert j["config"]["launch_plan"]["source"] == os.path.join("profiles", "plans", plan_file)
+    assert len(set(rk["plan_sha16_per_rank"])) == 1 and j["config"]["launch_plan"]["identical_on_all_ranks"] is True
+    assert len(set(rk["planned_steps_per_rank"])) == 1
+    assert j["config"]["batch_chains"]["chains"] == (1 if config == "int8" else 4)
+    import re
+    m = re.search(r"\[recording\] weight arena (\d+) bytes broadcast to 8 ranks", r.stderr)
+    assert m and int(m.group(1)) == j["config"]["weight_arena_bytes"] > 0
+    rows = {int(m.group(1)): m for m in re.finditer(r"\[recording\] rank (\d+) seed (\d+) shard \[(\d+)\]\.\.\+32 graph_launch (\d+) load (\d+) load_receive (\d+) prepare (\d+) h2d (\d+)", r.stderr)}
+    assert sorted(rows) == list(range(8))
+    for rank, m in rows.items():
+        assert int(m.group(2)) == 1234 + rank and int(m.group(3)) == 32 * rank
+        assert (int(m.group(5)), int(m.group(6))) == ((1, 0) if rank == 0 else (0, 1))  # only rank 0 loads the weights for real
+        assert int(m.group(7)) == 1
+    if config == "int8":
+        # several ranks per device (the gloo test mode): quantized-output launches stay off, the loader-side quantizers stay in the plan
+        plan = json.load(open(os.path.join(ROOT, "profiles", "plans", "int8.json")))
+        assert j["config"]["quantized_output_launches"] == [] and sorted(j["config"]["quantize_on_load_layers"]) == sorted(plan["fused_dql"])
+
+
+@pytest.mark.parametrize("config", ["int8", "f32"])
 def test_eight_rank_bench_control_flow(config):
+    """... and the same for `--via-runner` (the Python runner: the A/B path)."""
     from rten_amd import lib as L
     from rten_amd.workloads import resnet50, resnet50_int8
-    r = _run(8, config, 29611 if config == "int8" else 29613)
+    r = _run(8, config, 29611 if config == "int8" else 29613, extra=("--via-runner",))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]  # rank 0 prints ONE line
@@ -67,5 +102,5 @@ def test_eight_rank_bench_control_flow(config):
 def test_world_size_mismatch_is_refused_in_recording_mode_too():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     env.update(RTEN_BENCH_RECORDING="1", WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", PYTHONPATH=ROOT)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--config", "int8"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=120)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--config", "int8", "--recording-test"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=120)
     assert r.returncode == 2 and "refusing to report" in r.stderr

@@ -1,0 +1,125 @@
+"""The PRODUCT path at BASELINE size: rten_hip_model_* -- ONNX bytes in, the plan files committed under
+profiles/plans/, sub-batch chains, hipGraph replay -- against the CPU oracle, bit for bit.  This is the path `python bench.py` times."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import baseline_oracle as bo
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _plan(name):
+    return open(os.path.join(ROOT, "profiles", "plans", name)).read()
+
+
+def _bits_equal(got, want, what):
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    same = got.view(np.int32) == want.view(np.int32)
+    assert same.all(), f"{what}: {(~same).sum()} of {same.size} values differ, first at {tuple(np.argwhere(~same)[0])}"
+
+
+def _run(model, ctx, feeds, reps=2):
+    from rten_amd.tensor import DeviceTensor
+    outs = []
+    for name, arr in feeds.items():
+        t = DeviceTensor(ctx, arr.shape, arr.dtype, ptr=model.input_ptrs[name], keepalive=model)
+        t.upload(arr)
+    for _ in range(reps):
+        model.run(inputs_written_on_caller_stream=True)
+        model.sync()
+        optr, oshape = model.output(0)
+        outs.append(DeviceTensor(ctx, oshape, np.float32, ptr=optr, keepalive=model).numpy())
+    return outs
+
+
+def test_resnet50_f32_batch32_four_chains_committed_plan_is_the_oracle():
+    """BASELINE configs[1] exactly as bench.py runs it: 32 images as 4 chains of 8 under profiles/plans/f32_4chains.json; also one chain under
+    f32_1chain.json.  Every image's logits are the oracle's, replay after replay."""
+    from rten_amd import lib as L, onnx_writer as ow
+    want = bo.resnet50_f32_logits()
+    x = bo.resnet_input()
+    onnx_bytes = ow.resnet50_f32(bo.resnet_weights())
+    ctx = L.Context(0)
+    try:
+        for chains, plan in ((4, "f32_4chains.json"), (1, "f32_1chain.json")):
+            m = L.Model(ctx, onnx_bytes, _plan(plan), chains)
+            try:
+                m.bind_input("x", x.shape)
+                m.prepare()
+                assert m.planned_steps == 53, m.planned_steps  # every convolution took its entry of the committed plan
+                assert m.warning == "", m.warning
+                ptr, nbytes = m.weight_arena()
+                assert ptr and nbytes > 100 << 20  # 25.5 M f32 parameters + their prepacked images, one allocation
+                for got in _run(m, ctx, {"x": x}):
+                    _bits_equal(got, want, f"f32 {chains} chain(s)")
+            finally:
+                m.close()
+    finally:
+        ctx.close()
+
+
+def test_resnet50_int8_batch32_committed_plan_is_the_oracle():
+    """BASELINE configs[2] as bench.py --config int8 runs it: one chain, profiles/plans/int8.json (quantized-output edges incl. a stage output with
+    two scale products, one quantize-on-load layer).  A batch-coupled graph refuses sub-batch chains."""
+    from rten_amd import lib as L, onnx_writer as ow
+    want = bo.resnet50_int8_logits()
+    x = bo.resnet_input()
+    onnx_bytes = ow.resnet50_int8(bo.resnet_weights())
+    plan = json.loads(_plan("int8.json"))
+    ctx = L.Context(0)
+    try:
+        with pytest.raises(L.HipError) as e:  # DynamicQuantizeLinear takes min / max over the whole batch
+            L.Model(ctx, onnx_bytes, None, 4)
+        assert "couples the rows" in str(e.value), str(e.value)
+        with pytest.raises(L.HipError) as e:
+            L.Model(ctx, onnx_bytes, _plan("int8.json"), 2)
+        assert "qout" in str(e.value), str(e.value)
+        for text in (_plan("int8.json"), None, json.dumps({"fused_dql": plan["fused_dql"]})):
+            m = L.Model(ctx, onnx_bytes, text, 1)
+            try:
+                m.bind_input("x", x.shape)
+                m.prepare()
+                if text is not None and "qout" in text:
+                    assert m.planned_steps >= len(plan["qout"]), (m.planned_steps, len(plan["qout"]))  # every listed edge + the loader layer(s)
+                elif text is None:
+                    assert m.planned_steps == 0
+                else:
+                    assert 1 <= m.planned_steps <= len(plan["fused_dql"])  # quantize-on-load layers only
+                for got in _run(m, ctx, {"x": x}, reps=3):
+                    _bits_equal(got, want, f"int8, plan {'file' if text else 'none'}")
+            finally:
+                m.close()
+    finally:
+        ctx.close()
+
+
+def test_bert_base_batch32_seq128_through_the_model_abi_is_the_oracle():
+    """BASELINE configs[3]: the 12-layer encoder from ONNX bytes (separate Q / K / V projections, Reshape / Transpose around the attention MatMuls,
+    Add(mask) -> Softmax, LayerNormalization, Gelu as an exporter writes them) through rten_hip_model_*, ragged masks, tuned launch plan."""
+    from rten_amd import lib as L, onnx_writer as ow
+    B, S = 32, 128
+    cfg, w, ids, am, tts, want = bo.bert_base_case(B, S)
+    onnx_bytes = ow.bert_encoder(cfg, w, S)
+    ctx = L.Context(0)
+    try:
+        plan_path = os.path.join(ROOT, "profiles", "plans", "bert_base_b32_s128.json")
+        texts = [None] + ([open(plan_path).read()] if os.path.exists(plan_path) else [])
+        for text in texts:
+            m = L.Model(ctx, onnx_bytes, text, 1)
+            try:
+                feeds = {"input_ids": ids.astype(np.int32), "token_type_ids": tts.astype(np.int32), "attention_mask": am.astype(np.int32)}
+                for name in m.inputs:
+                    m.bind_input(name, feeds[name].shape)
+                m.prepare()
+                if text:
+                    assert m.planned_steps >= 48, m.planned_steps  # 4 products per layer x 12 layers took their plan entry
+                for got in _run(m, ctx, feeds):
+                    _bits_equal(got.reshape(want.shape), want, "BERT-base b32 x 128")
+            finally:
+                m.close()
+    finally:
+        ctx.close()

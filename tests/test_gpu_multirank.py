@@ -42,15 +42,12 @@ def test_bench_two_ranks_prints_one_line(config):
     import hashlib
 
     import numpy as np
-    from oracle import models as omodels
-    from rten_amd.workloads import resnet50
+    from tests import baseline_oracle as bo
+    assert j["config"]["path"] == "executor"  # the default path: rank 1 loaded with the receive-weights flag and got the arena by broadcast
     assert len(set(j["ranks"]["plan_sha16_per_rank"])) == 1
-    w = resnet50.make_weights()
     for r, (sha, seed) in enumerate(zip(j["ranks"]["logits_sha16_per_rank"], j["ranks"]["input_seed_per_rank"])):
         assert seed == 1234 + r
-        x = np.random.default_rng(seed).random((32, 3, 224, 224), dtype=np.float32)
-        want = (omodels.resnet50_int8_forward(resnet50.conv_specs(), omodels.quantize_weights_int8(w), x) if config == "int8" else
-                omodels.resnet50_forward(resnet50.conv_specs(), w, x))
+        want = bo.resnet50_int8_logits(seed) if config == "int8" else bo.resnet50_f32_logits(seed)
         assert hashlib.sha256(np.ascontiguousarray(want.astype(np.float32)).tobytes()).hexdigest()[:16] == sha, f"rank {r}: logits differ from the oracle's for its shard"
 
 

@@ -43,13 +43,14 @@ def test_resnet50_int8_batch32_bit_exact_runner(ctx):
     (src/ops/quantize.rs:397-419) and the producer-side min/max fold (rten_hip_conv2d_int8_stats, 256 slots) sees 16x more
     workgroups than at batch 2, so batch 32 is its own case -- not a property of the batch-2 test."""
     from oracle import models as omodels
-    from rten_amd.workloads import resnet50, resnet50_int8
-    w = resnet50.make_weights()
+    from rten_amd.workloads import resnet50_int8
+    from tests import baseline_oracle as bo
+    w = bo.resnet_weights()
     net = resnet50_int8.ResNet50Int8(ctx, batch=32, weights=w)
     net.upload_weights()
-    x = np.random.default_rng(1234).random((32, 3, 224, 224), dtype=np.float32)  # bench.py's rank-0 batch
+    x = bo.resnet_input()  # bench.py's rank-0 batch
     net.x.upload(x)
-    want = omodels.resnet50_int8_forward(net.specs, omodels.quantize_weights_int8(w), x)
+    want = bo.resnet50_int8_logits()
     net.forward()
     bits_equal(net.logits.numpy(), want)
     # two-sweep DynamicQuantizeLinear everywhere (no producer-side statistics): same bits
@@ -83,13 +84,10 @@ def test_resnet50_int8_batch32_bit_exact_runner(ctx):
 
 
 def test_resnet50_int8_batch32_bit_exact_onnx_executor(tmp_path):
-    from oracle import models as om
     from rten_amd import onnx_writer as ow
-    from rten_amd.workloads import resnet50
+    from tests import baseline_oracle as bo
     from tests.test_graph_executor import _run_model
-    w = resnet50.make_weights()
-    x = np.random.default_rng(1234).random((32, 3, 224, 224), dtype=np.float32)
-    want = om.resnet50_int8_forward(resnet50.conv_specs(), om.quantize_weights_int8(w), x)
+    w, x, want = bo.resnet_weights(), bo.resnet_input(), bo.resnet50_int8_logits()
     got, log = _run_model(tmp_path, ow.resnet50_int8(w), x, "logits", "--graph", "-n", "2")
     assert "49 DynamicQuantizeLinear write the staged layout directly" in log and "Captured the plan into a hipGraph" in log
     assert np.array_equal(got.view(np.int32), want.ravel().view(np.int32))
@@ -99,21 +97,13 @@ def test_resnet50_int8_batch32_bit_exact_onnx_executor(tmp_path):
 
 def test_bert_base_full_size_bit_exact(ctx):
     """BASELINE configs[3] as benchmarked: 12 layers, hidden 768, 12 heads, batch 32 x 128 tokens, ragged attention masks."""
-    from oracle import models as omodels
     from rten_amd.workloads import bert
-    cfg = bert.BertConfig(hidden=768, heads=12, layers=12, ffn=3072, vocab=4000, max_pos=128)
+    from tests import baseline_oracle as bo
     B, S = 32, 128
-    w = bert.make_weights(cfg)
-    rng = np.random.default_rng(11)
-    ids = rng.integers(0, cfg.vocab, (B, S))
-    tts = rng.integers(0, 2, (B, S))
-    am = np.ones((B, S), np.float32)
-    for b in range(0, B, 3):
-        am[b, S - 1 - 5 * (b % 7):] = 0  # padded tails of different lengths
+    cfg, w, ids, am, tts, want = bo.bert_base_case(B, S)
     net = bert.Bert(ctx, cfg, B, S, w)
     net.set_inputs(ids, am, tts)
     got = net.forward().numpy()
-    want = omodels.bert_forward(cfg, w, ids, am, tts)
     bits_equal(got, want)
     net.capture()
     net.run()

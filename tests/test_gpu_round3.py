@@ -177,13 +177,14 @@ def test_resnet50_int8_batch32_quantized_output_launches(ctx):
     """BASELINE configs[2] with the c1 -> c2 -> c3 edges of every bottleneck block quantized in the producing conv's epilogue: logits
     bit-identical to the oracle, eager and as a replayed hipGraph, and to the runner with the feature off."""
     from oracle import models as omodels
-    from rten_amd.workloads import resnet50, resnet50_int8
-    w = resnet50.make_weights()
+    from rten_amd.workloads import resnet50_int8
+    from tests import baseline_oracle as bo
+    w = bo.resnet_weights()
     net = resnet50_int8.ResNet50Int8(ctx, batch=32, weights=w)
     net.upload_weights()
-    x = np.random.default_rng(1234).random((32, 3, 224, 224), dtype=np.float32)
+    x = bo.resnet_input()
     net.x.upload(x)
-    want = omodels.resnet50_int8_forward(net.specs, omodels.quantize_weights_int8(w), x)
+    want = bo.resnet50_int8_logits()
     net.fused_qout = True
     net.forward()
     bits_equal(net.logits.numpy(), want)
