@@ -545,7 +545,9 @@ int32_t rten_hip_num_gemm_variants(void);
 int32_t rten_hip_set_gemm_split(rten_hip_ctx *ctx, int32_t mode, int32_t groups);
 /* Workgroup -> tile order (tuning knob, sticky, default 0): bit 0 = tiles walk n fastest instead of m fastest;
  * bit 1 = split-K workgroups walk tiles fastest and K groups slowest, so that each XCD's private L2 holds one K
- * slice of both operands; bits 4-6 = occupancy cap of the LDS-DMA kernels (workgroups per compute unit, 2..7; 0 = whatever fits:
+ * slice of both operands; bit 3 = RELAXED split-K (LDS-DMA pipelines, split modes 1-2): a K group's depth blocks accumulate in one register block
+ * and one partial per group is folded -- NOT the reference's order (results differ in the last bits): exists to MEASURE what an order-free split would
+ * gain (profiles/r08/), never part of a committed plan; bits 4-6 = occupancy cap of the LDS-DMA kernels (workgroups per compute unit, 2..7; 0 = whatever fits:
  * the launch is padded with dynamic LDS it never touches). */
 int32_t rten_hip_set_gemm_order(rten_hip_ctx *ctx, int32_t order);
 /* int8 kernels: 0 = automatic (operands staged chunk-major / padded channel-blocked + 16-byte LDS-DMA MFMA kernel whenever it

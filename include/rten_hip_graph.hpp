@@ -509,6 +509,7 @@ class Graph {
         bool to_float = false;
         bool relu = false;
         bool qout_off = false; // the one-launch form was refused once (grid not resident at once): the two-launch sequence from then on
+        bool qout_producer = false; // this step also runs its consumer's quantizer (Options::qout): it keeps reading staged codes itself
     };
     struct Step {
         std::string name, kind_name;
@@ -676,6 +677,7 @@ class Graph {
             for (auto &o : outputs_) if (ids_.at(o.name) == D.in[0]) keep = true;
             void *sync = (char *)sync_arena_->ptr() + gb * e;
             auto state = P.i8;
+            state->qout_producer = true;
             auto dql = D.dql_staged;
             auto two_launches = P.run;
             P.run = [state, dql, two_launches, sync, keep](Context &c, const InputList &in) {
@@ -708,7 +710,7 @@ class Graph {
         for (size_t i = 0; i < steps_.size(); i++) for (int id : steps_[i].out) if (id >= 0) producer[id] = i;
         for (size_t i = 0; i < steps_.size(); i++) {
             Step &cs = steps_[i];
-            if (!cs.i8 || !cs.i8->to_float || !opt_.fused_dql.count(cs.name) || !cs.i8->sg.x_staged || !cs.i8->sg.packed_weight || !cs.i8->sg.packed_weight->len()) continue;
+            if (!cs.i8 || !cs.i8->to_float || cs.i8->qout_producer || !opt_.fused_dql.count(cs.name) || !cs.i8->sg.x_staged || !cs.i8->sg.packed_weight || !cs.i8->sg.packed_weight->len()) continue;
             auto pit = producer.find(cs.in[0]);
             if (pit == producer.end()) continue;
             Step &D = steps_[pit->second];

@@ -764,13 +764,18 @@ __global__ __launch_bounds__(NTHREADS, dma_min_waves(BM, BN, MODE)) void igemm_f
             stage = stage == NSTAGE - 1 ? 0 : stage + 1;
         }
         if (SPLIT || (MIXED && grp >= 0)) {
-            store_raw(acc, blk);
+            // order bit 3 (RELAXED split-K, measurement only, NOT the reference's order): the group's depth blocks accumulate in one register block and ONE
+            // partial per group is parked (slot = group) -- what an order-free split-K would move; the strict form parks every depth block
+            const bool relaxed = (p.order & 8) != 0;
+            if (!relaxed || blk + 1 == blk1) {
+                store_raw(acc, relaxed ? grp : blk);
 #pragma unroll
-            for (int i = 0; i < TM; i++)
+                for (int i = 0; i < TM; i++)
 #pragma unroll
-                for (int j = 0; j < TN; j++)
+                    for (int j = 0; j < TN; j++)
 #pragma unroll
-                    for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+                        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+            }
         } else if constexpr (MULTI_KC) {
             if (blk + 1 < nblk) flush(blk == 0);
         }
@@ -2370,6 +2375,7 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
     int ntail = 0, t1 = T, S = 1;
     a.split_s = 1;
     a.order = ctx->tile_order & 3;
+    const bool relaxed_split = (ctx->tile_order & 8) != 0 && (pipe == 1 || pipe == 3 || pipe == 4 || pipe == 7); // igemm_f32_dma_kernel only
     int split_mode = ctx->split_mode, split_req = ctx->split_s;
     if (pipe == 6 && ctx->wave_flavour >= 4) split_mode = 0; // (no split-K form: whole tiles only)
     if (split_mode == 3) { // auto: too few tiles to fill the chip -> cut every tile so that ~num_cus workgroups exist
@@ -2384,7 +2390,8 @@ int32_t launch_cfg(rten_hip_ctx *ctx, GemmArgs &a, int Z) {
         t1 = split_mode == 2 ? 0 : (T / ctx->num_cus) * ctx->num_cus;
         if (S > 1 && t1 < T) {
             ntail = T - t1;
-            a.split_t1 = t1; a.split_s = S; a.split_g = G; a.split_slots = nblk; a.split_ntail = ntail;
+            a.split_t1 = t1; a.split_s = S; a.split_g = G; a.split_slots = relaxed_split ? S : nblk; a.split_ntail = ntail;
+            if (relaxed_split) a.order |= 8;
             const size_t need = 4096 + (size_t)Z * ntail * nblk * BM * BN * sizeof(float);
             char *sc = (char *)rten_scratch(ctx, need);
             if (!sc) return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "split-K slab allocation failed (or attempted during graph capture)");
@@ -2683,7 +2690,7 @@ RTEN_EXPORT int32_t rten_hip_set_gemm_split(rten_hip_ctx *ctx, int32_t mode, int
 // workgroups walk tiles fastest and K groups slowest (each XCD's L2 then holds one K slice of both operands).
 RTEN_EXPORT int32_t rten_hip_set_gemm_order(rten_hip_ctx *ctx, int32_t order) {
     RTEN_CHECK_CTX(ctx);
-    if (order < 0 || (order & ~0x73)) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "set_gemm_order: bits 0-1 (tile walk) and 4-6 (workgroups per compute unit) only");
+    if (order < 0 || (order & ~0x7b)) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "set_gemm_order: bits 0-1 (tile walk), 3 (relaxed split-K, measurement only) and 4-6 (workgroups per compute unit) only");
     ctx->tile_order = order;
     return RTEN_HIP_OK;
 }
