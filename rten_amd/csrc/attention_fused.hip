@@ -38,13 +38,20 @@ struct SdpaArgs {
     float scale;
     int flush_nan;
     int s_tiles;
+    int debug; // ablation bits of the ABL instantiation (RTEN_HIP_DEBUG >> 24, measurement only): 1 no mask, 2 no exp, 4 no PV MFMAs, 8 no QK^T MFMAs, 16 no global loads, 32 no stores
 };
 
 __device__ __forceinline__ constexpr int acc_row(int r) { return (r & 3) + 8 * (r >> 2); }
 
+// ABL: the ablation instantiation (phases switched off by p.debug bits: WRONG results, timing only; tools/probe_sdpa.py); the product launch is ABL = false
+// and carries none of the tests.  MLDS: the additive mask row of a [B, 1, 1, T] mask (row stride 0: every query row of the batch item adds the same
+// T values) is staged in LDS once per workgroup instead of being fetched by 64 broadcast global loads per lane.
+template <bool ABL, bool MLDS>
 __global__ __launch_bounds__(256, 2) void sdpa_fused_kernel(const SdpaArgs p) {
-    __shared__ __attribute__((aligned(16))) float smem[16 * SQ * 4 + 16 * TT * 4]; // Qs | Ks (phase 1) -> Vs [TT][HD] (phase 3)
+    __shared__ __attribute__((aligned(16))) float smem[16 * SQ * 4 + 16 * TT * 4 + (MLDS ? TT : 0)]; // Qs | Ks (phase 1) -> Vs [TT][HD] (phase 3) | mask row
     float *const Qs = smem, *const Ks = smem + 16 * SQ * 4, *const Vs = Ks;
+    [[maybe_unused]] float *const Ms = smem + 16 * SQ * 4 + 16 * TT * 4;
+    const int dbg = ABL ? p.debug : 0;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, half = lane >> 5;
@@ -61,14 +68,14 @@ __global__ __launch_bounds__(256, 2) void sdpa_fused_kernel(const SdpaArgs p) {
     for (int i = 0; i < SQ * 16 / 256; i++) {
         const int f = i * 256 + t, row = f >> 4, dq = f & 15;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (s0 + row < p.s) v = *reinterpret_cast<const f32x4 *>(qb + (long long)(s0 + row) * p.q_rs + dq * 4);
+        if (s0 + row < p.s && !(dbg & 16)) v = *reinterpret_cast<const f32x4 *>(qb + (long long)(s0 + row) * p.q_rs + dq * 4);
         *reinterpret_cast<f32x4 *>(Qs + (dq * SQ + row) * 4) = v;
     }
 #pragma unroll
     for (int i = 0; i < TT * 16 / 256; i++) {
         const int f = i * 256 + t, row = f >> 4, dq = f & 15;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row < p.t) v = *reinterpret_cast<const f32x4 *>(kb + (long long)row * p.k_rs + dq * 4);
+        if (row < p.t && !(dbg & 16)) v = *reinterpret_cast<const f32x4 *>(kb + (long long)row * p.k_rs + dq * 4);
         *reinterpret_cast<f32x4 *>(Ks + (dq * TT + row) * 4) = v;
     }
     f32x4 vreg[TT * 16 / 256];
@@ -76,7 +83,10 @@ __global__ __launch_bounds__(256, 2) void sdpa_fused_kernel(const SdpaArgs p) {
     for (int i = 0; i < TT * 16 / 256; i++) {
         const int f = i * 256 + t, row = f >> 4, dq = f & 15;
         vreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (row < p.t) vreg[i] = *reinterpret_cast<const f32x4 *>(vb + (long long)row * p.v_rs + dq * 4);
+        if (row < p.t && !(dbg & 16)) vreg[i] = *reinterpret_cast<const f32x4 *>(vb + (long long)row * p.v_rs + dq * 4);
+    }
+    if constexpr (MLDS) {
+        if (t < TT) Ms[t] = t < p.t ? p.mask[(long long)b * p.mask_bs + t] : 0.f;
     }
     __syncthreads();
 
@@ -89,6 +99,7 @@ __global__ __launch_bounds__(256, 2) void sdpa_fused_kernel(const SdpaArgs p) {
     {
         const float *Ak = Ks + l31 * 4 + half;               // k = 2kk + half: same quad as 2kk, next element
         const float *Bq = Qs + (wave * 32 + l31) * 4 + half;
+        if (!(dbg & 8)) {
 #pragma unroll
         for (int kk = 0; kk < HD / 2; kk++) {
             const float bq = Bq[(kk >> 1) * SQ * 4 + ((2 * kk) & 3)];
@@ -97,6 +108,7 @@ __global__ __launch_bounds__(256, 2) void sdpa_fused_kernel(const SdpaArgs p) {
                 const float ak = Ak[(kk >> 1) * TT * 4 + ((2 * kk) & 3) + j * 32 * 4];
                 sc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ak, bq, sc[j], 0, 0, 0);
             }
+        }
         }
     }
     __syncthreads(); // Ks is free: park V there ([t][64]) for phase 3
@@ -110,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void sdpa_fused_kernel(const SdpaArgs p) {
     // sc[j][r] is key t = 32j + acc_row(r) + 4*half.
     const int srow = s0 + wave * 32 + l31;
     const float *mrow = nullptr;
-    if (p.mask) mrow = p.mask + (long long)b * p.mask_bs + (long long)(srow < p.s ? srow : 0) * p.mask_rs;
+    if (p.mask && !MLDS && !(dbg & 1)) mrow = p.mask + (long long)b * p.mask_bs + (long long)(srow < p.s ? srow : 0) * p.mask_rs;
     float mx = -3.40282347e+38f; // f32::MIN (softmax.rs:181)
 #pragma unroll
     for (int j = 0; j < 4; j++)
@@ -118,7 +130,8 @@ __global__ __launch_bounds__(256, 2) void sdpa_fused_kernel(const SdpaArgs p) {
         for (int r = 0; r < 16; r++) {
             const int tk = 32 * j + acc_row(r) + 4 * half;
             float v = sc[j][r] * p.scale;               // the GEMM's `t * alpha` store form
-            if (mrow && tk < p.t) v = v + mrow[tk];     // `*qk += m`
+            if constexpr (MLDS) { if (tk < p.t) v = v + Ms[tk]; }      // `*qk += m`, the row from LDS
+            else { if (mrow && tk < p.t) v = v + mrow[tk]; }           // `*qk += m`
             sc[j][r] = v;
             if (tk < p.t) mx = fmaxf(mx, v);
         }
@@ -131,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void sdpa_fused_kernel(const SdpaArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int tk = 32 * j + acc_row(r) + 4 * half;
-            sc[j][r] = tk < p.t ? vm::exp_reduced(sc[j][r] - mx) : 0.f; // a masked key adds +0: the sums are >= 0, bits unchanged
+            sc[j][r] = tk < p.t ? ((dbg & 2) ? sc[j][r] - mx : vm::exp_reduced(sc[j][r] - mx)) : 0.f; // a masked key adds +0: the sums are >= 0, bits unchanged
         }
 #pragma unroll
     for (int j = 0; j < 4; j++)
@@ -188,6 +201,7 @@ __global__ __launch_bounds__(256, 2) void sdpa_fused_kernel(const SdpaArgs p) {
         for (int r = 0; r < 16; r++) oc[jn][r] = 0.f;
     {
         const float *Bv = Vs + half * HD + l31;
+        if (!(dbg & 4)) {
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
@@ -197,6 +211,12 @@ __global__ __launch_bounds__(256, 2) void sdpa_fused_kernel(const SdpaArgs p) {
 #pragma unroll
                 for (int jn = 0; jn < 2; jn++) oc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bv[(32 * j + t0) * HD + jn * 32], oc[jn], 0, 0, 0);
             }
+        } else { // (keep the probabilities alive so that phase 2 is not optimised away)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) oc[j & 1][r] += sc[j][r];
+        }
     }
     // C layout of out: lane column = dv (jn*32 + l31), register r = query row acc_row(r) + 4*half of this wave's 32
 #pragma unroll
@@ -204,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void sdpa_fused_kernel(const SdpaArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int row = s0 + wave * 32 + acc_row(r) + 4 * half;
-            if (row < p.s) ob[(long long)row * p.o_rs + jn * 32 + l31] = oc[jn][r];
+            if (row < p.s && !((dbg & 32) && oc[jn][r] != 12345.f)) ob[(long long)row * p.o_rs + jn * 32 + l31] = oc[jn][r];
         }
 }
 
@@ -438,7 +458,14 @@ int32_t rten_sdpa_fused(rten_hip_ctx *ctx, const rten_hip_sdpa_desc *d, const fl
     const double bytes = 4.0 * d->batch * d->heads * ((double)d->s * (d->d + d->dv) + (double)d->t * (d->d + d->dv));
     if (fast) {
         ProfScope ps(ctx, "sdpa_fused_kernel", flops, bytes);
-        hipLaunchKernelGGL(sdpa_fused_kernel, dim3((unsigned)wgs), dim3(256), 0, ctx->stream, a);
+        // the additive mask of a [B, 1, 1, T] attention mask (row stride 0, at least T values per batch item): one LDS copy per workgroup
+        const bool mlds = mask && d->mask_row_stride == 0 && !(ctx->debug & 0x400000);
+        a.debug = (ctx->debug >> 24) & 63;
+        if (a.debug) {
+            if (mlds) hipLaunchKernelGGL((sdpa_fused_kernel<true, true>), dim3((unsigned)wgs), dim3(256), 0, ctx->stream, a);
+            else hipLaunchKernelGGL((sdpa_fused_kernel<true, false>), dim3((unsigned)wgs), dim3(256), 0, ctx->stream, a);
+        } else if (mlds) hipLaunchKernelGGL((sdpa_fused_kernel<false, true>), dim3((unsigned)wgs), dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((sdpa_fused_kernel<false, false>), dim3((unsigned)wgs), dim3(256), 0, ctx->stream, a);
     } else {
         ProfScope ps(ctx, "sdpa_fused_general_kernel", flops, bytes);
         const int nch = (d->t + TT - 1) / TT; // 1 .. 4 chunks of 128 keys (3 runs as 4: the fourth chunk is zero-filled)
