@@ -31,8 +31,10 @@
 //! downcast) see the operators they know and the backend sees `ConvIntegerToFloat` / `FusedMatMul` / `AddSoftmax` / `MatMulIntegerToFloat`.
 //! Two additions to the reference, both listed in INTEGRATION.md section 2.1: `ModelOptions::set_operator_rewriter` and the accessors
 //! `ConvIntegerToFloat::conv()` / `MatMulIntegerToFloat::matmul()` for fields that are private today.
+mod install;
 mod ops;
 mod subgraph;
+pub use install::{install_resident, load_resident, ResidentPlan};
 pub use subgraph::HipSubgraph;
 
 use std::collections::HashMap;

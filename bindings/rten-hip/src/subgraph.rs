@@ -5,8 +5,10 @@
 //! operator: the reference's own precedent for an operator that owns a graph is `SubgraphOperator` (src/operator.rs:630-646; `If` / `Loop`).
 //! The graph behind this operator is the C++ plan executor exported through the C ABI as `rten_hip_model_*` (include/rten_hip.h;
 //! rten_amd/csrc/graph_abi.cpp): ONNX bytes in, constants uploaded and prepacked once, the reference's fusions applied, a committed launch plan
-//! (profiles/plans/*.json) by step name, the batch run as `chains` independent dim-0 slices on their own streams, each a hipGraph.  `bench.py
-//! --via-executor` measures exactly this path (ResNet-50 f32 batch 32: 2.69 ms; the hand-planned runner: 2.68 ms; same logits).
+//! (profiles/plans/*.json) by step name, the batch run as `chains` independent dim-0 slices on their own streams, each a hipGraph.  `bench.py`
+//! (its default path since round 5) measures exactly this path (ResNet-50 f32 batch 32: 2.72 ms; the hand-planned runner: 2.73 ms on the same box;
+//! same logits).
+//! `install.rs` puts one of these in place of a loaded model's whole graph (`rten_hip::load_resident`).
 //!
 //! NOT COMPILED in the build image -- see lib.rs.  tests/test_abi.py checks that every `sys::` name used here exists in the generated -sys crate
 //! with the arity used.
@@ -51,9 +53,18 @@ impl HipSubgraph {
     pub fn load(hip: Arc<HipContext>, onnx: &[u8], plan_json: Option<&str>, chains: i32, input_shapes: &[(&str, Vec<usize>)]) -> Result<Self, OpError> {
         let plan = plan_json.map(|p| CString::new(p).map_err(|_| OpError::InvalidValue("launch plan contains a NUL byte"))).transpose()?;
         let mut model: *mut sys::rten_hip_model = ptr::null_mut();
-        hip.check(unsafe {
-            sys::rten_hip_model_load(hip.raw(), onnx.as_ptr() as *const c_void, onnx.len(), plan.as_ref().map_or(ptr::null(), |p| p.as_ptr()), chains, 0, &mut model)
-        })?;
+        // `_load_ex`: every chain is created on the device of `hip` (the round-4 entry point took a separate device id, and this binding passed 0
+        // whatever device the context lived on); flags 0 = this process uploads the weights itself
+        let status = unsafe {
+            sys::rten_hip_model_load_ex(hip.raw(), onnx.as_ptr() as *const c_void, onnx.len(), plan.as_ref().map_or(ptr::null(), |p| p.as_ptr()), chains, 0, &mut model)
+        };
+        if status != 0 {
+            // a failed load has no model object: the reason (parse error, operator outside the backend's registry, bad plan file, a batch-coupled
+            // graph with chains > 1) is per calling thread
+            let why = unsafe { CStr::from_ptr(sys::rten_hip_model_load_error()) }.to_string_lossy().into_owned();
+            if !why.is_empty() { eprintln!("rten-hip: subgraph: {why}"); }
+            hip.check(status)?;
+        }
         let mut this = HipSubgraph { model, hip, inputs: Vec::new(), n_outputs: 0, run_lock: Mutex::new(()) };
         let (mut n_in, mut n_out, mut n_steps, mut n_planned) = (0i32, 0i32, 0i32, 0i32);
         this.check(unsafe { sys::rten_hip_model_info(this.model, &mut n_in, &mut n_out, &mut n_steps, &mut n_planned) })?;
@@ -69,6 +80,10 @@ impl HipSubgraph {
         this.check(unsafe { sys::rten_hip_model_prepare(this.model, 0) })?; // buffers planned, launch plan applied, one hipGraph per chain captured
         Ok(this)
     }
+
+    /// Names of the subgraph's inputs in the order `run` expects them (the model file's declaration order), and its output count.
+    pub fn input_names(&self) -> impl Iterator<Item = &str> { self.inputs.iter().map(|b| b.name.as_str()) }
+    pub fn num_outputs(&self) -> usize { self.n_outputs }
 
     /// The backend's status codes as `OpError`s, with the model's own message where it has one (the text is logged: `OpError` carries
     /// `&'static str`s).

@@ -46,12 +46,16 @@ __device__ __forceinline__ constexpr int acc_row(int r) { return (r & 3) + 8 * (
 // ABL: the ablation instantiation (phases switched off by p.debug bits: WRONG results, timing only; tools/probe_sdpa.py); the product launch is ABL = false
 // and carries none of the tests.  MLDS: the additive mask row of a [B, 1, 1, T] mask (row stride 0: every query row of the batch item adds the same
 // T values) is staged in LDS once per workgroup instead of being fetched by 64 broadcast global loads per lane.
-template <bool ABL, bool MLDS>
+// FULL: s is a multiple of 128 and t == 128 (the shape of BERT-base): every `row < s` / `key < t` test is true, and being per-lane tests (the key index
+// depends on the half-wave) each of them costs an exec-mask branch -- 185 of the 5000 instructions of the general form; FLUSH: the NaN -> 0 option.
+template <bool ABL, bool MLDS, bool FULL, bool FLUSH>
 __global__ __launch_bounds__(256, 2) void sdpa_fused_kernel(const SdpaArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[16 * SQ * 4 + 16 * TT * 4 + (MLDS ? TT : 0)]; // Qs | Ks (phase 1) -> Vs [TT][HD] (phase 3) | mask row
     float *const Qs = smem, *const Ks = smem + 16 * SQ * 4, *const Vs = Ks;
     [[maybe_unused]] float *const Ms = smem + 16 * SQ * 4 + 16 * TT * 4;
     const int dbg = ABL ? p.debug : 0;
+    auto in_t = [&](int key) { return FULL || key < p.t; };   // key column exists
+    auto in_s = [&](int row) { return FULL || row < p.s; };   // query row exists
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, half = lane >> 5;
@@ -68,14 +72,14 @@ __global__ __launch_bounds__(256, 2) void sdpa_fused_kernel(const SdpaArgs p) {
     for (int i = 0; i < SQ * 16 / 256; i++) {
         const int f = i * 256 + t, row = f >> 4, dq = f & 15;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (s0 + row < p.s && !(dbg & 16)) v = *reinterpret_cast<const f32x4 *>(qb + (long long)(s0 + row) * p.q_rs + dq * 4);
+        if (in_s(s0 + row) && !(dbg & 16)) v = *reinterpret_cast<const f32x4 *>(qb + (long long)(s0 + row) * p.q_rs + dq * 4);
         *reinterpret_cast<f32x4 *>(Qs + (dq * SQ + row) * 4) = v;
     }
 #pragma unroll
     for (int i = 0; i < TT * 16 / 256; i++) {
         const int f = i * 256 + t, row = f >> 4, dq = f & 15;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row < p.t && !(dbg & 16)) v = *reinterpret_cast<const f32x4 *>(kb + (long long)row * p.k_rs + dq * 4);
+        if (in_t(row) && !(dbg & 16)) v = *reinterpret_cast<const f32x4 *>(kb + (long long)row * p.k_rs + dq * 4);
         *reinterpret_cast<f32x4 *>(Ks + (dq * TT + row) * 4) = v;
     }
     f32x4 vreg[TT * 16 / 256];
@@ -83,10 +87,10 @@ __global__ __launch_bounds__(256, 2) void sdpa_fused_kernel(const SdpaArgs p) {
     for (int i = 0; i < TT * 16 / 256; i++) {
         const int f = i * 256 + t, row = f >> 4, dq = f & 15;
         vreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (row < p.t && !(dbg & 16)) vreg[i] = *reinterpret_cast<const f32x4 *>(vb + (long long)row * p.v_rs + dq * 4);
+        if (in_t(row) && !(dbg & 16)) vreg[i] = *reinterpret_cast<const f32x4 *>(vb + (long long)row * p.v_rs + dq * 4);
     }
     if constexpr (MLDS) {
-        if (t < TT) Ms[t] = t < p.t ? p.mask[(long long)b * p.mask_bs + t] : 0.f;
+        if (t < TT) Ms[t] = in_t(t) ? p.mask[(long long)b * p.mask_bs + t] : 0.f;
     }
     __syncthreads();
 
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void sdpa_fused_kernel(const SdpaArgs p) {
     // sc[j][r] is key t = 32j + acc_row(r) + 4*half.
     const int srow = s0 + wave * 32 + l31;
     const float *mrow = nullptr;
-    if (p.mask && !MLDS && !(dbg & 1)) mrow = p.mask + (long long)b * p.mask_bs + (long long)(srow < p.s ? srow : 0) * p.mask_rs;
+    if (p.mask && !MLDS && !(dbg & 1)) mrow = p.mask + (long long)b * p.mask_bs + (long long)(in_s(srow) ? srow : 0) * p.mask_rs;
     float mx = -3.40282347e+38f; // f32::MIN (softmax.rs:181)
 #pragma unroll
     for (int j = 0; j < 4; j++)
@@ -130,10 +134,10 @@ __global__ __launch_bounds__(256, 2) void sdpa_fused_kernel(const SdpaArgs p) {
         for (int r = 0; r < 16; r++) {
             const int tk = 32 * j + acc_row(r) + 4 * half;
             float v = sc[j][r] * p.scale;               // the GEMM's `t * alpha` store form
-            if constexpr (MLDS) { if (tk < p.t) v = v + Ms[tk]; }      // `*qk += m`, the row from LDS
-            else { if (mrow && tk < p.t) v = v + mrow[tk]; }           // `*qk += m`
+            if constexpr (MLDS) { if (in_t(tk)) v = v + Ms[tk]; }      // `*qk += m`, the row from LDS
+            else { if (mrow && in_t(tk)) v = v + mrow[tk]; }           // `*qk += m`
             sc[j][r] = v;
-            if (tk < p.t) mx = fmaxf(mx, v);
+            if (in_t(tk)) mx = fmaxf(mx, v);
         }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     // exp and the 16 ordered partial sums of the reference's 16-lane SIMD order: partial l adds keys l, l+16, l+32, ...
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void sdpa_fused_kernel(const SdpaArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int tk = 32 * j + acc_row(r) + 4 * half;
-            sc[j][r] = tk < p.t ? ((dbg & 2) ? sc[j][r] - mx : vm::exp_reduced(sc[j][r] - mx)) : 0.f; // a masked key adds +0: the sums are >= 0, bits unchanged
+            sc[j][r] = in_t(tk) ? ((dbg & 2) ? sc[j][r] - mx : vm::exp_reduced(sc[j][r] - mx)) : 0.f; // a masked key adds +0: the sums are >= 0, bits unchanged
         }
 #pragma unroll
     for (int j = 0; j < 4; j++)
@@ -170,8 +174,8 @@ __global__ __launch_bounds__(256, 2) void sdpa_fused_kernel(const SdpaArgs p) {
         for (int r = 0; r < 16; r++) {
             const int tk = 32 * j + acc_row(r) + 4 * half;
             float pr = sc[j][r] * inv;
-            if (p.flush_nan && !(pr == pr)) pr = 0.f;
-            sc[j][r] = tk < p.t ? pr : 0.f; // padded keys: exactly 0 (also when the row is all masked and inv is NaN)
+            if (FLUSH && !(pr == pr)) pr = 0.f;
+            sc[j][r] = in_t(tk) ? pr : 0.f; // padded keys: exactly 0 (also when the row is all masked and inv is NaN)
         }
     // re-pair into MFMA A operands: after the swaps register 4g+c holds keys (8g+c | 8g+c+1) in (half 0 | half 1) and
     // register 4g+c+1 holds keys (8g+4+c | 8g+4+c+1), c in {0, 2}: k-pairs in ascending key order.
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void sdpa_fused_kernel(const SdpaArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int row = s0 + wave * 32 + acc_row(r) + 4 * half;
-            if (row < p.s && !((dbg & 32) && oc[jn][r] != 12345.f)) ob[(long long)row * p.o_rs + jn * 32 + l31] = oc[jn][r];
+            if (in_s(row) && !((dbg & 32) && oc[jn][r] != 12345.f)) ob[(long long)row * p.o_rs + jn * 32 + l31] = oc[jn][r];
         }
 }
 
@@ -461,11 +465,21 @@ int32_t rten_sdpa_fused(rten_hip_ctx *ctx, const rten_hip_sdpa_desc *d, const fl
         // the additive mask of a [B, 1, 1, T] attention mask (row stride 0, at least T values per batch item): one LDS copy per workgroup
         const bool mlds = mask && d->mask_row_stride == 0 && !(ctx->debug & 0x400000);
         a.debug = (ctx->debug >> 24) & 63;
-        if (a.debug) {
-            if (mlds) hipLaunchKernelGGL((sdpa_fused_kernel<true, true>), dim3((unsigned)wgs), dim3(256), 0, ctx->stream, a);
-            else hipLaunchKernelGGL((sdpa_fused_kernel<true, false>), dim3((unsigned)wgs), dim3(256), 0, ctx->stream, a);
-        } else if (mlds) hipLaunchKernelGGL((sdpa_fused_kernel<false, true>), dim3((unsigned)wgs), dim3(256), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((sdpa_fused_kernel<false, false>), dim3((unsigned)wgs), dim3(256), 0, ctx->stream, a);
+        const bool full = d->t == TT && d->s % SQ == 0 && !(ctx->debug & 0x800000); // (bit 0x800000: the general form, A/B)
+        const bool flush = d->flush_nan_to_zero != 0;
+        const dim3 grid((unsigned)wgs), block(256);
+#define RTEN_SDPA_GO(ABLV, MLV, FV, FLV) hipLaunchKernelGGL((sdpa_fused_kernel<ABLV, MLV, FV, FLV>), grid, block, 0, ctx->stream, a)
+#define RTEN_SDPA_PICK(ABLV)                                                                                                             \
+        do {                                                                                                                             \
+            if (mlds) { if (full) { if (flush) RTEN_SDPA_GO(ABLV, true, true, true); else RTEN_SDPA_GO(ABLV, true, true, false); }       \
+                        else { if (flush) RTEN_SDPA_GO(ABLV, true, false, true); else RTEN_SDPA_GO(ABLV, true, false, false); } }        \
+            else { if (full) { if (flush) RTEN_SDPA_GO(ABLV, false, true, true); else RTEN_SDPA_GO(ABLV, false, true, false); }          \
+                   else { if (flush) RTEN_SDPA_GO(ABLV, false, false, true); else RTEN_SDPA_GO(ABLV, false, false, false); } }           \
+        } while (0)
+        if (a.debug) RTEN_SDPA_PICK(true);
+        else RTEN_SDPA_PICK(false);
+#undef RTEN_SDPA_PICK
+#undef RTEN_SDPA_GO
     } else {
         ProfScope ps(ctx, "sdpa_fused_general_kernel", flops, bytes);
         const int nch = (d->t + TT - 1) / TT; // 1 .. 4 chunks of 128 keys (3 runs as 4: the fourth chunk is zero-filled)

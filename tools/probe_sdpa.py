@@ -49,7 +49,8 @@ def run(debug, reps=50):
 
 
 def main():
-    rows = [("product kernel (mask row in LDS)", 0), ("mask fetched per lane (round-4 form)", 0x400000),
+    rows = [("product kernel (FULL-shape instantiation, mask row in LDS)", 0), ("general instantiation (per-lane row / key tests)", 0x800000),
+            ("general + mask fetched per lane (round-4 form)", 0xC00000),
             ("ABL instantiation, no bit effective (64 = unused bit)", 64 << 24), ("- mask add", 1 << 24), ("- exp", 2 << 24), ("- mask - exp", 3 << 24),
             ("- PV MFMAs", 4 << 24), ("- QK^T MFMAs", 8 << 24), ("- both MFMA phases", 12 << 24), ("- global loads", 16 << 24), ("- stores", 32 << 24),
             ("- loads - stores", 48 << 24), ("- everything but the MFMAs (mask, exp, loads, stores)", 51 << 24), ("- everything", 63 << 24)]
