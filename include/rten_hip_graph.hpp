@@ -715,6 +715,20 @@ class Graph {
             if (pit == producer.end()) continue;
             Step &D = steps_[pit->second];
             if (!D.dql_staged || D.removed || !D.dql_staged->stats_in || D.out.empty() || D.out[0] != cs.in[0]) continue; // (a quantizer merged into its producer has no step)
+            // The loader form pays only when the quantizer's own launch DISAPPEARS: every reader of its codes must be a listed, convertible layer.
+            // A stage's first 1x1 shares its quantizer with the shortcut convolution: converting it alone keeps the staging launch and swaps a
+            // 15-22 us convolution for a 44 us one (measured, session r5c) -- the runner's rule too (`_staged_key == geom`: no loader form).
+            {
+                bool all_listed = true;
+                for (auto &other : steps_) {
+                    if (&other == &cs || other.removed) continue;
+                    for (size_t k = 0; k < other.in.size() && k < 1; k++)
+                        if (other.in[k] == D.out[0] && !(other.i8 && opt_.fused_dql.count(other.name))) all_listed = false;
+                    for (size_t k = 1; k < other.in.size(); k++)
+                        if (other.in[k] == D.out[0]) all_listed = false; // the codes read as anything but a convolution's X
+                }
+                if (!all_listed) continue;
+            }
             // geometry the loader form covers: 1x1, stride 1, no padding, groups 1, C % 64 == 0 -- all load-time facts
             const Tensor &w = consts_.at(cs.in[1]);
             const Conv &cv = cs.i8->op->conv;

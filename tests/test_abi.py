@@ -329,5 +329,5 @@ def test_integration_md_names_only_symbols_the_header_declares():
         assert name in declared, f"INTEGRATION.md names {name}, which include/rten_hip.h does not declare"
     sub = open(os.path.join(ROOT, "bindings", "rten-hip", "src", "subgraph.rs")).read()
     assert "impl Operator for HipSubgraph" in sub and "pub use subgraph::HipSubgraph" in open(os.path.join(ROOT, "bindings", "rten-hip", "src", "lib.rs")).read()
-    for fn in ("load", "bind_input", "prepare", "run", "sync", "output", "destroy"):
+    for fn in ("load_ex", "bind_input", "prepare", "run", "sync", "output", "destroy"):
         assert f"sys::rten_hip_model_{fn}(" in sub, fn

@@ -84,11 +84,11 @@ def test_resnet50_int8_batch32_committed_plan_is_the_oracle():
                 m.bind_input("x", x.shape)
                 m.prepare()
                 if text is not None and "qout" in text:
-                    assert m.planned_steps >= len(plan["qout"]), (m.planned_steps, len(plan["qout"]))  # every listed edge + the loader layer(s)
+                    assert m.planned_steps == len(plan["qout"]), (m.planned_steps, len(plan["qout"]))  # every listed edge (no loader layer converts beside them)
                 elif text is None:
                     assert m.planned_steps == 0
                 else:
-                    assert 1 <= m.planned_steps <= len(plan["fused_dql"])  # quantize-on-load layers only
+                    assert m.planned_steps == 5, m.planned_steps  # the listed layers whose quantizer has no other reader (not s1b0c1 / s2b0c1: shared with a shortcut)
                 for got in _run(m, ctx, {"x": x}, reps=3):
                     _bits_equal(got, want, f"int8, plan {'file' if text else 'none'}")
             finally:

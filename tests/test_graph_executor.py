@@ -598,10 +598,11 @@ def test_model_abi_int8_quantized_output_edges_from_the_plan_file():
     ctx = L.Context(0)
     # s0b0c3: a block output -- its f32 tensor is kept for the residual Add; s0b2c3 / s2b5c3: stage outputs, read by the next stage's shortcut AND
     # first convolution through ONE quantizer with two scale products (an edge since round 5: the launch folds the first product, the second
-    # is the graph's own scalar Mul).  The plan also lists quantize-on-load layers ("fused_dql"); the one that is neither a quantized-output
-    # producer itself nor fed by one -- s1b0c1 -- takes the loader form and counts as a planned step.
+    # is the graph's own scalar Mul).  The plan also lists quantize-on-load layers ("fused_dql"): every one of them is either a quantized-output
+    # producer itself, fed by one, or shares its quantizer with a shortcut convolution (the staging launch would stay: no loader form) -- none
+    # converts under this plan, as in the Python runner; tests/test_gpu_model_baseline.py runs the list on its own.
     more = dict(plan, qout=plan["qout"] + ["s0b0c3"])
-    for text, edges in ((json.dumps(more), len(more["qout"]) + 1), (None, 0), (json.dumps({"qout": ["s0b2c3", "no_such_node"]}), 1)):
+    for text, edges in ((json.dumps(more), len(more["qout"])), (None, 0), (json.dumps({"qout": ["s0b2c3", "no_such_node"]}), 1)):
         m = L.Model(ctx, onnx_bytes, text, 1)
         try:
             xp = m.bind_input("x", x.shape)
