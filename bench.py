@@ -49,6 +49,7 @@ F32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X v_mfma_f32_32x32x2_f32 peak (MI355X_MIC
 I8_MATRIX_PEAK_TOPS = 5033.0    # dense i8 MFMA: 2x the bf16 rate (MI355X_MICROARCH.md, "Matrix cores")
 HBM_PEAK_GBS = 8000.0           # HBM3E spec (6.29 TB/s measured with a float4 copy)
 BATCH_PER_GPU = 32
+INT8_DEFAULT_LANES = 1  # (set from the measurement of session r5e: see DESIGN.md section 2)
 
 
 def cpu_baseline(specs, weights, budget_s=12.0):
@@ -418,8 +419,10 @@ def run_via_executor(args):
     plan_text, plan_source = None, "backend defaults (no plan)"
     if not args.no_autotune and not args.autotune and os.path.exists(plan_path):
         plan_text, plan_source = open(plan_path).read(), os.path.relpath(os.path.abspath(plan_path), ROOT)
-    if plan_text and int8 and (args.no_qout or (world > 1 and backend != "nccl")):
-        # quantized-output launches need every workgroup of a launch resident at once: not when several ranks share ONE GPU (the gloo test mode)
+    lanes = args.lanes if args.lanes else (INT8_DEFAULT_LANES if int8 else 1)
+    if plan_text and int8 and (args.no_qout or lanes > 1 or (world > 1 and backend != "nccl")):
+        # quantized-output launches need every workgroup of a launch resident at once and the device to themselves: not when several ranks share ONE
+        # GPU (the gloo test mode), and not when a second replica's launches run beside them (lanes > 1)
         p = json.loads(plan_text)
         p.pop("qout", None)
         plan_text = json.dumps(p)
@@ -441,12 +444,17 @@ def run_via_executor(args):
         plan_text, plan_source = tuned[0], "tuned in this run by rank 0" + (" and broadcast" if world > 1 else "")
         if args.save_plan and rank == 0:
             open(args.save_plan, "w").write(plan_text)
-    model = load(plan_text)
+    # lane 0 lives on `ctx`; every further lane on a context (stream) of its own, with its own copy of the weight arena (int8: 26 MB) and buffers
+    lane_ctx = [ctx] + [(ctx.__class__)(local_rank) for _ in range(lanes - 1)]
+    models = [Model(c, onnx_bytes, plan_text, chains, receive_weights=(rank != 0)) for c in lane_ctx]
+    model = models[0]
 
-    # ---- the one collective: the weight arena, from the rank that loaded the model file for real
+    # ---- the one collective: the weight arena, from the rank that loaded the model file for real (once per lane)
     comm_world = 1
     arena_ptr, arena_bytes = model.weight_arena()
-    if world > 1:
+    for m_l, c_l in (list(zip(models, lane_ctx)) if world > 1 else []):
+        arena_ptr, arena_bytes = m_l.weight_arena()
+        ctx = c_l
         ctx.sync()
         if backend == "nccl":
             uid = [lib.Comm.unique_id(ctx) if rank == 0 else None]
@@ -458,7 +466,7 @@ def run_via_executor(args):
             comm.close()
         else:  # several ranks on one GPU / no GPU at all: torch.distributed (gloo) carries the bytes through the host
             host = torch.empty(arena_bytes, dtype=torch.uint8)
-            dev = DeviceTensor(ctx, (arena_bytes,), np.uint8, ptr=arena_ptr, keepalive=model)
+            dev = DeviceTensor(ctx, (arena_bytes,), np.uint8, ptr=arena_ptr, keepalive=m_l)
             if rank == 0 and not DRY:
                 host.copy_(torch.from_numpy(dev.numpy()))
             dist.broadcast(host, src=0)
@@ -467,29 +475,38 @@ def run_via_executor(args):
             comm_world = dist.get_world_size()
         if DRY and rank == 0:
             print(f"[recording] weight arena {arena_bytes} bytes broadcast to {comm_world} ranks", file=sys.stderr)
-    xptr = model.bind_input("x", (BATCH_PER_GPU, 3, 224, 224))
-    model.prepare()
-    # each rank gets its own (independent) synthetic batch, resident in HBM before timing starts
+    ctx = lane_ctx[0]
+    arena_ptr, arena_bytes = model.weight_arena()
+    # each rank gets its own (independent) synthetic batch, resident in HBM before timing starts (every lane holds a copy: a lane's batch is its own buffer)
     x = np.random.default_rng(1234 + rank).random((BATCH_PER_GPU, 3, 224, 224), dtype=np.float32)
-    xt = DeviceTensor(ctx, x.shape, np.float32, ptr=xptr, keepalive=model)
-    xt.upload(x)
-    ctx.sync()
+    xts = []
+    for m_l, c_l in zip(models, lane_ctx):
+        xp_l = m_l.bind_input("x", (BATCH_PER_GPU, 3, 224, 224))
+        m_l.prepare()
+        xts.append(DeviceTensor(c_l, x.shape, np.float32, ptr=xp_l, keepalive=m_l))
+        xts[-1].upload(x)
+        c_l.sync()
+    xt = xts[0]
+
+    def sync_all():
+        for m_l in models:
+            m_l.sync()
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
     # K steps back to back: the chains are joined ONCE, at the end of the region (the steps are independent batches; model.sync() covers every stream)
-    for _ in range(args.warmup):
-        model.run(join=False)
-    model.sync()
+    for i in range(args.warmup):
+        models[i % lanes].run(join=False)
+    sync_all()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        model.run(join=False)
-    model.sync()
+    for i in range(args.steps):
+        models[i % lanes].run(join=False)  # consecutive batches go to the lanes round robin: step k + 1 overlaps step k
+    sync_all()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
@@ -506,6 +523,13 @@ def run_via_executor(args):
     optr, oshape = model.output(0)
     logits = DeviceTensor(ctx, oshape, np.float32, ptr=optr, keepalive=model).numpy()
     logits_sha = hashlib.sha256(np.ascontiguousarray(logits).tobytes()).hexdigest()[:16]
+    lanes_agree = True
+    for m_l, c_l in zip(models[1:], lane_ctx[1:]):  # every lane ran the same batch: the same bits, whatever ran beside it
+        op_l, os_l = m_l.output(0)
+        lanes_agree = lanes_agree and np.array_equal(DeviceTensor(c_l, os_l, np.float32, ptr=op_l, keepalive=m_l).numpy().view(np.int32), logits.view(np.int32))
+    if not lanes_agree:
+        print("bench.py: the lanes computed different logits for the same batch: results are void", file=sys.stderr)
+        return 3
     plan_sha = hashlib.sha256(json.dumps(json.loads(plan_text), sort_keys=True).encode()).hexdigest()[:16] if plan_text else None
     shard_report = [(rank, logits_sha, plan_sha, model.planned_steps)]
     if dist is not None:
@@ -521,9 +545,10 @@ def run_via_executor(args):
         model.sync()
         lat.append((time.perf_counter() - t1) * 1e3)
     p50 = float(np.median(lat))
+    sync_all()
     t1 = time.perf_counter()
     for _ in range(min(args.steps, 20)):
-        model.run()  # joined on the caller's stream every step, host not blocked
+        model.run()  # ONE lane, joined on the caller's stream every step, host not blocked: no overlap between steps
     model.sync()
     joined_ms = (time.perf_counter() - t1) / min(args.steps, 20) * 1e3
 
@@ -619,6 +644,11 @@ def run_via_executor(args):
                                        "the path a Rust host binds (INTEGRATION.md 2.5); `--via-runner` times the hand-planned Python runner instead",
                           "global_batch": global_batch, "parallelism": f"batch-shard x{world} (weight arena RCCL-broadcast once)" if world > 1 else "single GPU",
                           "launch": "hipGraph replay",
+                          "batch_lanes": {"lanes": lanes,
+                                          "note": "independent replicas of the model (own streams and buffers, own copy of the weight arena); consecutive batches go to "
+                                                  "them round robin, so step k + 1 overlaps step k -- a THROUGHPUT schedule for independent batches (what two request "
+                                                  "threads on two HipSubgraph instances do); `ms_per_step_joined_every_step` / `p50_latency_ms` are ONE batch on one "
+                                                  "replica with nothing beside it; quantized-output launches (which need the device to themselves) are off when lanes > 1"},
                           "batch_chains": {"chains": chains,
                                            "note": "independent sub-batch chains on their own streams, shared weights, logits bit-identical to one chain; in the warm-up and the timed "
                                                    "region the chains free-run across steps and are joined once at the end (`ms_per_step` is a THROUGHPUT figure; "
@@ -654,7 +684,8 @@ def run_via_executor(args):
         from rten_amd.sharding import shard_range
         print(f"[recording] rank {rank} seed {1234 + rank} shard {list(shard_range(BATCH_PER_GPU * world, rank, world))[:1]}..+{BATCH_PER_GPU} graph_launch {c['graph_launch']} "
               f"load {c['model_load']} load_receive {c['model_load_receive']} prepare {c['model_prepare']} h2d {c['rten_hip_memcpy_h2d']}", file=sys.stderr)
-    model.close()
+    for m_l in models:
+        m_l.close()
     if dist is not None:
         dist.barrier()  # rank 0's instrumented pass / JSON line happen before any rank tears the group down
         dist.destroy_process_group()
@@ -702,6 +733,10 @@ def parse_args():
     ap.add_argument("--via-runner", action="store_true",
                     help="time the hand-planned Python runner (rten_amd/workloads/*.py over the per-operator C entry points) instead of the product path -- the C++ "
                          "plan executor behind the C ABI (rten_hip_model_*: ONNX bytes in, committed launch plan, chains, hipGraph replay), which is the default")
+    ap.add_argument("--lanes", type=int, default=None,
+                    help="executor: run this many independent replicas of the model (own streams, own buffers) and hand consecutive BATCHES to them round robin, so "
+                         "that step k + 1 overlaps step k (default: 2 for int8 -- its graph cannot be split into sub-batch chains --, 1 for f32, whose 4 chains "
+                         "already overlap inside a batch).  A throughput schedule: `p50_latency_ms` stays the latency of ONE batch on one replica")
     ap.add_argument("--no-shapes", action="store_true", help="f32: skip the stand-alone per-shape table (`roofline.shapes`)")
     ap.add_argument("--recording-test", action="store_true",
                     help="control-flow test mode (tests/test_bench_world8.py): together with RTEN_BENCH_RECORDING=1, launches are recorded instead of issued")

@@ -155,7 +155,8 @@ def test_resnet50_f32_onnx_graph_bit_exact(tmp_path):
     assert np.array_equal(got.view(np.int32), want.ravel().view(np.int32))
     # per-layer plan selection by measurement + hipGraph replay: any plan the tuner picks must give the same bits
     got2, log2 = _run_model(tmp_path, ow.resnet50_f32(w), x, "logits", "--tune", "--graph", "-n", "3")
-    assert "Tuned the launch plan of 53 convolution steps" in log2 and "Captured the plan into a hipGraph" in log2
+    assert "Tuned the launch plan of 54 convolution / MatMul steps" in log2  # 53 convolutions + the classifier Gemm (MatMul-family steps are tuned since round 5)
+    assert "Captured the plan into a hipGraph" in log2 and "Captured the plan into a hipGraph" in log2
     assert np.array_equal(got2.view(np.int32), want.ravel().view(np.int32))
 
 

@@ -185,7 +185,7 @@ int main(int argc, char **argv) {
         if (tune) {
             const auto t0 = std::chrono::steady_clock::now();
             const size_t n = g.autotune(feeds);
-            std::printf("  Tuned the launch plan of %zu convolution steps in %.2fs\n", n, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+            std::printf("  Tuned the launch plan of %zu convolution / MatMul steps in %.2fs\n", n, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
         }
         std::vector<Tensor> outs;
         const std::vector<Tensor> *result = &outs;
