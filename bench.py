@@ -49,7 +49,10 @@ F32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X v_mfma_f32_32x32x2_f32 peak (MI355X_MIC
 I8_MATRIX_PEAK_TOPS = 5033.0    # dense i8 MFMA: 2x the bf16 rate (MI355X_MICROARCH.md, "Matrix cores")
 HBM_PEAK_GBS = 8000.0           # HBM3E spec (6.29 TB/s measured with a float4 copy)
 BATCH_PER_GPU = 32
-INT8_DEFAULT_LANES = 1  # (set from the measurement of session r5e: see DESIGN.md section 2)
+# Consecutive batches on independent replicas of the model ("lanes", --lanes): measured in session r5e (profiles/r08/lanes.txt) -- int8 1 / 2 / 3 / 4 lanes:
+# 1.502 / 1.052 / 0.971 / 0.950 ms per batch; f32 one chain x 2 lanes 2.494 ms against 2.677 ms for one replica running the batch as 4 sub-batch chains
+INT8_DEFAULT_LANES = 4
+F32_DEFAULT_LANES = 2   # ... of ONE chain each (whole-batch launches: the best per-layer efficiency), unless --chains is given
 
 
 def cpu_baseline(specs, weights, budget_s=12.0):
@@ -412,14 +415,15 @@ def run_via_executor(args):
     else:
         ctx, Model = lib.Context(local_rank), lib.Model  # no CPU fallback: raises if the HIP extension / MI355X is missing
     weights = resnet50.make_weights()
-    chains = 1 if int8 else (4 if args.chains is None else args.chains)
+    # f32 default: ONE chain per replica and two replicas; `--chains N` alone keeps round 4's schedule (one replica, N sub-batch chains)
+    chains = 1 if (int8 or args.chains is None) else args.chains
     onnx_bytes = onnx_writer.resnet50_int8(weights) if int8 else onnx_writer.resnet50_f32(weights)
     default_plan = os.path.join(ROOT, "profiles", "plans", "int8.json" if int8 else f"f32_{chains}chain{'s' if chains > 1 else ''}.json")
     plan_path = args.load_plan or default_plan
     plan_text, plan_source = None, "backend defaults (no plan)"
     if not args.no_autotune and not args.autotune and os.path.exists(plan_path):
         plan_text, plan_source = open(plan_path).read(), os.path.relpath(os.path.abspath(plan_path), ROOT)
-    lanes = args.lanes if args.lanes else (INT8_DEFAULT_LANES if int8 else 1)
+    lanes = args.lanes if args.lanes else (INT8_DEFAULT_LANES if int8 else (F32_DEFAULT_LANES if args.chains is None else 1))
     if plan_text and int8 and (args.no_qout or lanes > 1 or (world > 1 and backend != "nccl")):
         # quantized-output launches need every workgroup of a launch resident at once and the device to themselves: not when several ranks share ONE
         # GPU (the gloo test mode), and not when a second replica's launches run beside them (lanes > 1)
@@ -726,7 +730,8 @@ def parse_args():
     ap.add_argument("--load-plan", default=None, help="use per-layer plans from a JSON file instead of autotuning (profiling runs)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of BASELINE configs[2] (int8 ResNet-50) and configs[3] (BERT-base) reported under \"secondary\"")
     ap.add_argument("--chains", type=int, default=None,
-                    help="f32: run the batch as this many independent sub-batch chains on their own streams (default 4; 1 = one chain). "
+                    help="f32: run the batch as this many independent sub-batch chains on their own streams (round 4's schedule; default since round 5: one chain "
+                         "per replica, two replicas -- see --lanes). "
                          "The int8 graph quantizes each activation over the whole batch, so it always runs as one chain")
     ap.add_argument("--concurrent", action="store_true", help="run the projection shortcuts on a second stream (parallel graph branches)")
     ap.add_argument("--via-executor", action="store_true", help="(the default since round 5; kept so that older command lines still parse)")
@@ -735,8 +740,8 @@ def parse_args():
                          "plan executor behind the C ABI (rten_hip_model_*: ONNX bytes in, committed launch plan, chains, hipGraph replay), which is the default")
     ap.add_argument("--lanes", type=int, default=None,
                     help="executor: run this many independent replicas of the model (own streams, own buffers) and hand consecutive BATCHES to them round robin, so "
-                         "that step k + 1 overlaps step k (default: 2 for int8 -- its graph cannot be split into sub-batch chains --, 1 for f32, whose 4 chains "
-                         "already overlap inside a batch).  A throughput schedule: `p50_latency_ms` stays the latency of ONE batch on one replica")
+                         "that step k + 1 overlaps step k (default: 4 for int8, whose graph cannot be split into sub-batch chains; 2 for f32 with one chain each; "
+                         "1 when --chains is given).  A throughput schedule: `p50_latency_ms` stays the latency of ONE batch on one replica")
     ap.add_argument("--no-shapes", action="store_true", help="f32: skip the stand-alone per-shape table (`roofline.shapes`)")
     ap.add_argument("--recording-test", action="store_true",
                     help="control-flow test mode (tests/test_bench_world8.py): together with RTEN_BENCH_RECORDING=1, launches are recorded instead of issued")

@@ -36,19 +36,23 @@ def test_eight_rank_bench_control_flow_of_the_default_path(config):
     rk = j["ranks"]
     assert rk["world_size"] == 8 and rk["dist_backend"] == "gloo" and rk["weight_broadcast_world"] == 8
     assert rk["input_seed_per_rank"] == [1234 + r_ for r_ in range(8)] and len(rk["ms_per_step_per_rank"]) == 8
-    plan_file = "int8.json" if config == "int8" else "f32_4chains.json"
+    plan_file = "int8.json" if config == "int8" else "f32_1chain.json"
     assert j["config"]["launch_plan"]["source"] == os.path.join("profiles", "plans", plan_file)
     assert len(set(rk["plan_sha16_per_rank"])) == 1 and j["config"]["launch_plan"]["identical_on_all_ranks"] is True
     assert len(set(rk["planned_steps_per_rank"])) == 1
-    assert j["config"]["batch_chains"]["chains"] == (1 if config == "int8" else 4)
+    # the default schedule: whole-batch chains, consecutive batches on independent replicas (lanes)
+    lanes = 4 if config == "int8" else 2
+    assert j["config"]["batch_chains"]["chains"] == 1 and j["config"]["batch_lanes"]["lanes"] == lanes
     import re
     m = re.search(r"\[recording\] weight arena (\d+) bytes broadcast to 8 ranks", r.stderr)
     assert m and int(m.group(1)) == j["config"]["weight_arena_bytes"] > 0
+    assert len(re.findall(r"\[recording\] weight arena \d+ bytes broadcast to 8 ranks", r.stderr)) == lanes  # one broadcast per lane
     rows = {int(m.group(1)): m for m in re.finditer(r"\[recording\] rank (\d+) seed (\d+) shard \[(\d+)\]\.\.\+32 graph_launch (\d+) load (\d+) load_receive (\d+) prepare (\d+) h2d (\d+)", r.stderr)}
     assert sorted(rows) == list(range(8))
     for rank, m in rows.items():
         assert int(m.group(2)) == 1234 + rank and int(m.group(3)) == 32 * rank
-        assert (int(m.group(5)), int(m.group(6))) == ((1, 0) if rank == 0 else (0, 1))  # only rank 0 loads the weights for real
+        # (the counters are those of the rank's FIRST lane: every lane has a context of its own) only rank 0 loads the weights for real
+        assert (int(m.group(5)), int(m.group(6))) == ((1, 0) if rank == 0 else (0, 1))
         assert int(m.group(7)) == 1
     if config == "int8":
         # several ranks per device (the gloo test mode): quantized-output launches stay off, the loader-side quantizers stay in the plan

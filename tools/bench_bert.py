@@ -15,6 +15,9 @@ ap.add_argument("--seq", type=int, default=128)
 ap.add_argument("--no-cpu-baseline", action="store_true")
 ap.add_argument("--via-runner", action="store_true", help="the hand-planned Python runner (rten_amd/workloads/bert.py) instead of the product path (rten_hip_model_*)")
 ap.add_argument("--autotune", action="store_true", help="executor: tune the GEMM launch plans at prepare time instead of loading profiles/plans/bert_base_b32_s128.json")
+ap.add_argument("--lanes", type=int, default=1, help="executor: independent replicas of the model (own stream, own buffers, own weights); consecutive "
+                                                     "batches go to them round robin, so the row-wise / attention kernels of one batch run beside the GEMMs of the next")
+ap.add_argument("--chains", type=int, default=1, help="executor: split the batch into this many independent sub-batch chains (rows are independent in an encoder)")
 ap.add_argument("--save-plan", default=None, help="executor: write the launch plan that ran (rten_hip_model_plan_json) to this file")
 args = ap.parse_args()
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -54,26 +57,37 @@ else:
     onnx_bytes = onnx_writer.bert_encoder(cfg, weights, args.seq)
     plan_path = os.path.join(ROOT, "profiles", "plans", f"bert_base_b{args.batch}_s{args.seq}.json")
     plan_text = None if (args.autotune or not os.path.exists(plan_path)) else open(plan_path).read()
-    model = L.Model(ctx, onnx_bytes, plan_text, 1)
+    if args.chains > 1 and plan_text:  # the committed plan is keyed by the full batch: a sub-batch takes the same per-shape choices
+        pj = json.loads(plan_text)
+        plan_text = json.dumps({str(args.batch // args.chains): next(iter(pj.values()))})
     feeds = {"input_ids": ids.astype(np.int32), "token_type_ids": tts.astype(np.int32), "attention_mask": am.astype(np.int32)}
-    for name in model.inputs:
-        p = model.bind_input(name, feeds[name].shape)
-        DeviceTensor(ctx, feeds[name].shape, np.int32, ptr=p, keepalive=model).upload(feeds[name])
-    model.prepare(tune=plan_text is None)
+    lane_ctx = [ctx] + [L.Context(0) for _ in range(args.lanes - 1)]
+    models = []
+    for c_l in lane_ctx:
+        m_l = L.Model(c_l, onnx_bytes, plan_text, args.chains)
+        for name in m_l.inputs:
+            p = m_l.bind_input(name, feeds[name].shape)
+            DeviceTensor(c_l, feeds[name].shape, np.int32, ptr=p, keepalive=m_l).upload(feeds[name])
+        m_l.prepare(tune=plan_text is None)
+        models.append(m_l)
+    model = models[0]
     if args.save_plan:
         open(args.save_plan, "w").write(model.plan_json())
     import hashlib
     ran = json.loads(model.plan_json())
     plan_note = {"source": os.path.relpath(plan_path, ROOT) if plan_text else "tuned at prepare time in this run", "steps_planned": model.planned_steps, "steps": model.num_steps,
                  "sha16": hashlib.sha256(json.dumps(ran, sort_keys=True).encode()).hexdigest()[:16]}
-    for _ in range(args.warmup):
-        model.run(join=False)
-    model.sync()
+    for i in range(args.warmup):
+        models[i % args.lanes].run(join=False)
+    for m_l in models:
+        m_l.sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        model.run(join=False)
-    model.sync()
+    for i in range(args.steps):
+        models[i % args.lanes].run(join=False)
+    for m_l in models:
+        m_l.sync()
     el = time.perf_counter() - t0
+    plan_note["lanes"], plan_note["chains"] = args.lanes, args.chains
     rep = model.profile_pass(args.steps)
 gem = [r for r in rep if r["kernel"].startswith("igemm_f32")]
 ms = sum(r["ms"] for r in gem); gfl = sum(r["flops"] for r in gem)
