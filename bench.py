@@ -448,17 +448,17 @@ def run_via_executor(args):
         plan_text, plan_source = tuned[0], "tuned in this run by rank 0" + (" and broadcast" if world > 1 else "")
         if args.save_plan and rank == 0:
             open(args.save_plan, "w").write(plan_text)
-    # lane 0 lives on `ctx`; every further lane on a context (stream) of its own, with its own copy of the weight arena (int8: 26 MB) and buffers
+    # lane 0 lives on `ctx`; every further lane is a REPLICA (rten_hip_model_clone) on a context (stream) of its own: own buffers and hipGraphs, lane 0's
+    # constants and prepacked weights
     lane_ctx = [ctx] + [(ctx.__class__)(local_rank) for _ in range(lanes - 1)]
-    models = [Model(c, onnx_bytes, plan_text, chains, receive_weights=(rank != 0)) for c in lane_ctx]
-    model = models[0]
+    model = load(plan_text)
+    models = [model] + [model.clone(c) for c in lane_ctx[1:]]
 
-    # ---- the one collective: the weight arena, from the rank that loaded the model file for real (once per lane)
+    # ---- the one collective: the weight arena (shared by every lane), from the rank that loaded the model file for real
     comm_world = 1
     arena_ptr, arena_bytes = model.weight_arena()
-    for m_l, c_l in (list(zip(models, lane_ctx)) if world > 1 else []):
-        arena_ptr, arena_bytes = m_l.weight_arena()
-        ctx = c_l
+    m_l = model
+    if world > 1:
         ctx.sync()
         if backend == "nccl":
             uid = [lib.Comm.unique_id(ctx) if rank == 0 else None]
@@ -479,8 +479,6 @@ def run_via_executor(args):
             comm_world = dist.get_world_size()
         if DRY and rank == 0:
             print(f"[recording] weight arena {arena_bytes} bytes broadcast to {comm_world} ranks", file=sys.stderr)
-    ctx = lane_ctx[0]
-    arena_ptr, arena_bytes = model.weight_arena()
     # each rank gets its own (independent) synthetic batch, resident in HBM before timing starts (every lane holds a copy: a lane's batch is its own buffer)
     x = np.random.default_rng(1234 + rank).random((BATCH_PER_GPU, 3, 224, 224), dtype=np.float32)
     xts = []
@@ -649,7 +647,7 @@ def run_via_executor(args):
                           "global_batch": global_batch, "parallelism": f"batch-shard x{world} (weight arena RCCL-broadcast once)" if world > 1 else "single GPU",
                           "launch": "hipGraph replay",
                           "batch_lanes": {"lanes": lanes,
-                                          "note": "independent replicas of the model (own streams and buffers, own copy of the weight arena); consecutive batches go to "
+                                          "note": "independent replicas of the model (rten_hip_model_clone: own streams, buffers and hipGraphs, ONE shared weight arena); consecutive batches go to "
                                                   "them round robin, so step k + 1 overlaps step k -- a THROUGHPUT schedule for independent batches (what two request "
                                                   "threads on two HipSubgraph instances do); `ms_per_step_joined_every_step` / `p50_latency_ms` are ONE batch on one "
                                                   "replica with nothing beside it; quantized-output launches (which need the device to themselves) are off when lanes > 1"},
@@ -688,7 +686,7 @@ def run_via_executor(args):
         from rten_amd.sharding import shard_range
         print(f"[recording] rank {rank} seed {1234 + rank} shard {list(shard_range(BATCH_PER_GPU * world, rank, world))[:1]}..+{BATCH_PER_GPU} graph_launch {c['graph_launch']} "
               f"load {c['model_load']} load_receive {c['model_load_receive']} prepare {c['model_prepare']} h2d {c['rten_hip_memcpy_h2d']}", file=sys.stderr)
-    for m_l in models:
+    for m_l in reversed(models):  # replicas before their origin
         m_l.close()
     if dist is not None:
         dist.barrier()  # rank 0's instrumented pass / JSON line happen before any rank tears the group down

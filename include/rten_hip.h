@@ -49,7 +49,8 @@ extern "C" {
 #endif
 
 /* v4 (round 5): + rten_hip_device_id, rten_hip_tuning_save / _restore (a library-level caller on a borrowed context puts the owner's knobs back),
- * rten_hip_model_load_ex (device taken from the context; RTEN_HIP_MODEL_RECEIVE_WEIGHTS), rten_hip_model_load_error, rten_hip_model_weight_arena (one
+ * rten_hip_model_load_ex (device taken from the context; RTEN_HIP_MODEL_RECEIVE_WEIGHTS), rten_hip_model_load_error, rten_hip_model_clone (replicas that
+ * share one weight set: lanes), rten_hip_model_plan_json, rten_hip_model_profile, rten_hip_model_weight_arena (one
  * allocation for every constant of a model: the unit of the one-time RCCL broadcast), plan files may carry {"fused_dql": [...]}, "qout" edges may have
  * several scale products, rten_hip_model_load validates device_id, rten_hip_grid_sync_reset refuses to run inside a capture, scratch buffers a live
  * hipGraph replays from are retired instead of freed, rten_hip_set_gemm_order bit 3 (relaxed split-K: one partial per K group -- NOT bit-exact, tuning /
@@ -510,6 +511,11 @@ int32_t rten_hip_model_load_ex(rten_hip_ctx *ctx, const void *onnx_bytes, size_t
                                uint32_t flags, rten_hip_model **out_model);
 const char *rten_hip_model_load_error(void);
 int32_t rten_hip_model_weight_arena(rten_hip_model *model, void **dev_ptr, size_t *bytes);
+/* Another replica of `model` on `ctx` (same device; `ctx` outlives the replica): the same graph / plan / options, its own buffers, streams and hipGraphs,
+ * and the ORIGIN's constants and prepacked weights -- no second copy of the weight arena.  Independent batches handed to different replicas overlap on
+ * the device ("lanes": bench.py --lanes; the batch-level analogue of sub-batch chains, and the only one a batch-coupled graph -- the dynamically
+ * quantized one -- can use).  Bind inputs and prepare a replica like any model; destroy replicas before their origin (destroy(origin) refuses). */
+int32_t rten_hip_model_clone(rten_hip_model *model, rten_hip_ctx *ctx, rten_hip_model **out_model);
 /* The launch plan a prepared model runs under, as plan-file text keyed by sub-batch size (what prepare(tune = 1) chose / the plan file gave): f32
  * convolution steps AND MatMul / FusedMatMul / Gemm steps (v4: the latter take plan entries and are tuned too).  `*needed` = bytes incl. terminator. */
 int32_t rten_hip_model_plan_json(rten_hip_model *model, char *buf, size_t buf_len, size_t *needed);

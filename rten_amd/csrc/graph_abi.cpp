@@ -126,8 +126,12 @@ struct rten_hip_model {
     std::vector<int64_t> sub, start;                        // sub-batch sizes / first rows
     size_t planned_steps = 0, tuned_steps = 0;
     bool prepared = false;
-    void *arena_ptr = nullptr; // chain 0's coalesced constants (owned by graphs[0])
+    void *arena_ptr = nullptr; // chain 0's coalesced constants (owned by graphs[0]; a clone: its origin's)
     size_t arena_bytes = 0;
+    std::shared_ptr<onnx::Model> parsed; // kept for rten_hip_model_clone
+    Graph::Options opts;
+    rten_hip_model *origin = nullptr;    // a clone shares its origin's constants and must be destroyed first
+    int clones = 0;
     std::string last_error;
 };
 
@@ -169,8 +173,9 @@ RTEN_EXPORT int32_t rten_hip_model_load_ex(rten_hip_ctx *ctx, const void *onnx_b
     g->chains = chains;
     const int32_t device_id = rten_hip_device_id(ctx);
     try {
-        const onnx::Model m = onnx::parse((const uint8_t *)onnx_bytes, onnx_len);
-        Graph::Options opts;
+        g->parsed = std::make_shared<onnx::Model>(onnx::parse((const uint8_t *)onnx_bytes, onnx_len));
+        const onnx::Model &m = *g->parsed;
+        Graph::Options &opts = g->opts;
         opts.skip_large_uploads = (flags & RTEN_HIP_MODEL_RECEIVE_WEIGHTS) != 0;
         if (plan_json && *plan_json) {
             PlanJson pj{plan_json, plan_json + std::strlen(plan_json), {}};
@@ -232,6 +237,51 @@ RTEN_EXPORT int32_t rten_hip_model_load(rten_hip_ctx *ctx, const void *onnx_byte
 }
 
 RTEN_EXPORT const char *rten_hip_model_load_error(void) { return tls_load_error.c_str(); }
+
+// Another REPLICA of a loaded model on another context (stream): the same graph, plan and options, its own buffers and hipGraphs, and the ORIGIN's
+// device constants and prepacked weights (no second copy of the weight arena).  What a host that serves independent batches keeps one of per request
+// stream ("lanes": consecutive batches on different replicas overlap -- bench.py --lanes).  `ctx` must live on the origin's
+// device and, like the origin's context, outlive the replica; replicas are destroyed BEFORE their origin (rten_hip_model_destroy(origin) refuses
+// while one is alive).  Bind inputs and prepare the replica like any model.
+RTEN_EXPORT int32_t rten_hip_model_clone(rten_hip_model *src, rten_hip_ctx *ctx, rten_hip_model **out_model) {
+    if (!out_model) return RTEN_HIP_ERR_INVALID_VALUE;
+    *out_model = nullptr;
+    if (!src || !ctx || !src->parsed) return load_fail(RTEN_HIP_ERR_INVALID_VALUE, "model_clone: null model / context");
+    if (src->origin) src = src->origin; // a clone of a clone shares the same origin
+    if (rten_hip_device_id(ctx) != rten_hip_device_id(src->caller)) return load_fail(RTEN_HIP_ERR_INVALID_VALUE, "model_clone: the context lives on another device than the model");
+    std::unique_ptr<rten_hip_model> g(new rten_hip_model());
+    g->caller = ctx;
+    g->chains = src->chains;
+    g->parsed = src->parsed;
+    g->opts = src->opts;
+    g->plan_flat = src->plan_flat;
+    g->plan_by_batch = src->plan_by_batch;
+    g->have_plan = src->have_plan;
+    g->arena_ptr = src->arena_ptr;
+    g->arena_bytes = src->arena_bytes;
+    try {
+        const int32_t device_id = rten_hip_device_id(ctx);
+        for (int c = 0; c < g->chains; c++) {
+            if (c == 0) g->ctxs.emplace_back(new Context(ctx, Context::Borrow()));
+            else g->ctxs.emplace_back(new Context(device_id));
+            g->ctxs.back()->enable_pool(true);
+            g->graphs.emplace_back(new Graph(*g->ctxs.back(), *g->parsed, g->opts, *src->graphs[0])); // every chain of a replica shares the origin's constants
+        }
+        g->inputs = g->graphs[0]->inputs();
+        g->outputs = g->graphs[0]->outputs();
+    } catch (const OpError &e) {
+        while (!g->graphs.empty()) g->graphs.pop_back();
+        return load_fail(code_of(e), "model_clone: " + OpError::kind_name(e.kind) + ": " + e.msg);
+    } catch (const std::exception &e) {
+        while (!g->graphs.empty()) g->graphs.pop_back();
+        return load_fail(RTEN_HIP_ERR_INVALID_VALUE, std::string("model_clone: ") + e.what());
+    }
+    g->origin = src;
+    src->clones++;
+    tls_load_error.clear();
+    *out_model = g.release();
+    return RTEN_HIP_OK;
+}
 
 // The model's weight arena: ONE device allocation holding every constant of the graph (initializers, constants derived at load, prepacked weights) in a
 // layout that depends only on the model and the load options -- what rank 0 of a batch-sharded job broadcasts once (rten_hip_broadcast: RCCL over xGMI)
@@ -487,6 +537,8 @@ RTEN_EXPORT int32_t rten_hip_model_output(rten_hip_model *g, int32_t i, const vo
 
 RTEN_EXPORT int32_t rten_hip_model_destroy(rten_hip_model *g) {
     if (!g) return RTEN_HIP_OK;
+    if (g->clones > 0) return fail(g, RTEN_HIP_ERR_INVALID_VALUE, "model_destroy: replicas (rten_hip_model_clone) of this model are still alive: destroy them first");
+    if (g->origin) g->origin->clones--;
     for (auto &c : g->ctxs) rten_hip_sync(c->raw());
     g->chain_in.clear();
     g->full_in.clear();

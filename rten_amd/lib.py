@@ -185,6 +185,7 @@ PROTOTYPES = {
     "rten_hip_model_load": (_I32, [_VP, _VP, _SZ, C.c_char_p, _I32, _I32, C.POINTER(_VP)]),
     "rten_hip_model_load_ex": (_I32, [_VP, _VP, _SZ, C.c_char_p, _I32, _U32, C.POINTER(_VP)]),
     "rten_hip_model_load_error": (C.c_char_p, []),
+    "rten_hip_model_clone": (_I32, [_VP, _VP, C.POINTER(_VP)]),
     "rten_hip_model_weight_arena": (_I32, [_VP, C.POINTER(_VP), C.POINTER(_SZ)]),
     "rten_hip_model_plan_json": (_I32, [_VP, C.c_char_p, _SZ, C.POINTER(_SZ)]),
     "rten_hip_model_profile": (_I32, [_VP, _I32, C.c_char_p, _SZ, C.POINTER(_SZ)]),
@@ -393,6 +394,25 @@ class Model:
                                              MODEL_RECEIVE_WEIGHTS if receive_weights else 0, C.byref(h))
         if rc != OK:
             raise HipError(rc, self.lib.rten_hip_model_load_error().decode(errors="replace") or "rten_hip_model_load_ex failed")
+        self._finish_init(h)
+
+    @classmethod
+    def _from_handle(cls, ctx, h, origin):
+        m = cls.__new__(cls)
+        m.ctx, m.lib, m._onnx, m._origin = ctx, ctx.lib, None, origin  # (the origin is kept alive: a replica shares its constants)
+        m._finish_init(h)
+        return m
+
+    def clone(self, ctx: Context) -> "Model":
+        """Another replica of this model on `ctx` (own stream, buffers and hipGraphs; THIS model's constants and prepacked weights): a "lane".
+        Close replicas before their origin."""
+        h = C.c_void_p()
+        rc = self.lib.rten_hip_model_clone(self.h, ctx.h, C.byref(h))
+        if rc != OK:
+            raise HipError(rc, self.lib.rten_hip_model_load_error().decode(errors="replace") or "rten_hip_model_clone failed")
+        return Model._from_handle(ctx, h, self)
+
+    def _finish_init(self, h):
         self.h = h
         ni, no, ns, npl = _I32(), _I32(), _I32(), _I32()
         self._check(self.lib.rten_hip_model_info(h, C.byref(ni), C.byref(no), C.byref(ns), C.byref(npl)))

@@ -110,6 +110,14 @@ class RecordingModel:
     def weight_arena(self):
         return self._arena
 
+    def clone(self, ctx):
+        import json
+        ctx.log.append("model_clone")
+        m = RecordingModel.__new__(RecordingModel)
+        m.__dict__.update(self.__dict__)
+        m.ctx, m.input_ptrs = ctx, {}
+        return m
+
     def bind_input(self, name, shape):
         self._batch = int(shape[0])
         n = 1

@@ -46,7 +46,7 @@ def test_eight_rank_bench_control_flow_of_the_default_path(config):
     import re
     m = re.search(r"\[recording\] weight arena (\d+) bytes broadcast to 8 ranks", r.stderr)
     assert m and int(m.group(1)) == j["config"]["weight_arena_bytes"] > 0
-    assert len(re.findall(r"\[recording\] weight arena \d+ bytes broadcast to 8 ranks", r.stderr)) == lanes  # one broadcast per lane
+    assert len(re.findall(r"\[recording\] weight arena \d+ bytes broadcast to 8 ranks", r.stderr)) == 1  # ONE broadcast: the lanes are replicas that share the arena
     rows = {int(m.group(1)): m for m in re.finditer(r"\[recording\] rank (\d+) seed (\d+) shard \[(\d+)\]\.\.\+32 graph_launch (\d+) load (\d+) load_receive (\d+) prepare (\d+) h2d (\d+)", r.stderr)}
     assert sorted(rows) == list(range(8))
     for rank, m in rows.items():

@@ -56,6 +56,32 @@ def test_resnet50_f32_batch32_four_chains_committed_plan_is_the_oracle():
                 assert ptr and nbytes > 100 << 20  # 25.5 M f32 parameters + their prepacked images, one allocation
                 for got in _run(m, ctx, {"x": x}):
                     _bits_equal(got, want, f"f32 {chains} chain(s)")
+                if chains == 1:
+                    # a REPLICA on a second context (rten_hip_model_clone: own stream / buffers / hipGraphs, the origin's weights) -- bench.py's "lanes":
+                    # consecutive batches on the two overlap on the device; each gives the oracle's bits, run after run, whatever runs beside it
+                    ctx2 = L.Context(0)
+                    r = m.clone(ctx2)
+                    try:
+                        assert r.weight_arena() == m.weight_arena()  # ONE weight set
+                        r.bind_input("x", x.shape)
+                        r.prepare()
+                        assert r.planned_steps == 53
+                        from rten_amd.tensor import DeviceTensor
+                        DeviceTensor(ctx2, x.shape, np.float32, ptr=r.input_ptrs["x"], keepalive=r).upload(x[::-1].copy())
+                        ctx2.sync()
+                        for _ in range(6):
+                            m.run(join=False)
+                            r.run(join=False)
+                        m.sync()
+                        r.sync()
+                        for mm, cc, ww in ((m, ctx, want), (r, ctx2, want[::-1])):
+                            optr, oshape = mm.output(0)
+                            _bits_equal(DeviceTensor(cc, oshape, np.float32, ptr=optr, keepalive=mm).numpy(), np.ascontiguousarray(ww), "f32 origin / replica side by side")
+                        with pytest.raises(L.HipError):  # the origin cannot go while a replica lives
+                            m._check(m.lib.rten_hip_model_destroy(m.h))
+                    finally:
+                        r.close()
+                        ctx2.close()
             finally:
                 m.close()
     finally:

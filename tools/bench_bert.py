@@ -64,7 +64,7 @@ else:
     lane_ctx = [ctx] + [L.Context(0) for _ in range(args.lanes - 1)]
     models = []
     for c_l in lane_ctx:
-        m_l = L.Model(c_l, onnx_bytes, plan_text, args.chains)
+        m_l = L.Model(c_l, onnx_bytes, plan_text, args.chains) if not models else models[0].clone(c_l)  # replicas share the first model's weights
         for name in m_l.inputs:
             p = m_l.bind_input(name, feeds[name].shape)
             DeviceTensor(c_l, feeds[name].shape, np.int32, ptr=p, keepalive=m_l).upload(feeds[name])
