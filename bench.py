@@ -418,12 +418,14 @@ def run_via_executor(args):
     # f32 default: ONE chain per replica and two replicas; `--chains N` alone keeps round 4's schedule (one replica, N sub-batch chains)
     chains = 1 if (int8 or args.chains is None) else args.chains
     onnx_bytes = onnx_writer.resnet50_int8(weights) if int8 else onnx_writer.resnet50_f32(weights)
-    default_plan = os.path.join(ROOT, "profiles", "plans", "int8.json" if int8 else f"f32_{chains}chain{'s' if chains > 1 else ''}.json")
+    lanes = args.lanes if args.lanes else (INT8_DEFAULT_LANES if int8 else (F32_DEFAULT_LANES if args.chains is None else 1))
+    # int8: one replica alone may use quantized-output launches (int8.json); replicas running side by side may not (those launches need the device to
+    # themselves): int8_lanes.json lists only the quantize-on-load layers
+    default_plan = os.path.join(ROOT, "profiles", "plans", ("int8.json" if lanes == 1 else "int8_lanes.json") if int8 else f"f32_{chains}chain{'s' if chains > 1 else ''}.json")
     plan_path = args.load_plan or default_plan
     plan_text, plan_source = None, "backend defaults (no plan)"
     if not args.no_autotune and not args.autotune and os.path.exists(plan_path):
         plan_text, plan_source = open(plan_path).read(), os.path.relpath(os.path.abspath(plan_path), ROOT)
-    lanes = args.lanes if args.lanes else (INT8_DEFAULT_LANES if int8 else (F32_DEFAULT_LANES if args.chains is None else 1))
     if plan_text and int8 and (args.no_qout or lanes > 1 or (world > 1 and backend != "nccl")):
         # quantized-output launches need every workgroup of a launch resident at once and the device to themselves: not when several ranks share ONE
         # GPU (the gloo test mode), and not when a second replica's launches run beside them (lanes > 1)

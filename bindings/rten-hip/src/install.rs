@@ -22,13 +22,16 @@ use std::sync::Arc;
 
 use rten::{Graph, LoadError, Model, ModelOptions, NodeId};
 
-use crate::{accelerate, HipContext, HipSubgraph};
+use crate::{accelerate, HipContext, HipSubgraph, HipSubgraphPool};
 
 /// How the resident form was asked for: the launch-plan file of the model (`profiles/plans/*.json`), the number of sub-batch chains and the
 /// shapes the static plan is built for (one per graph input, by name).
 pub struct ResidentPlan<'a> {
     pub plan_json: Option<&'a str>,
     pub chains: i32,
+    /// replicas of the subgraph behind the one operator (`HipSubgraphPool`): `Model::run` callers on different threads run side by side on the device.
+    /// 1 = a single resident subgraph.  (bench.py's defaults: f32 ResNet-50 2 lanes of one chain, the dynamically quantized graph 4 lanes.)
+    pub lanes: usize,
     pub input_shapes: Vec<(String, Vec<usize>)>,
 }
 
@@ -47,6 +50,16 @@ pub fn install_resident(graph: &mut Graph, hip: &Arc<HipContext>, onnx: &[u8], p
         return Err(rten::ops::OpError::InvalidValue("the resident subgraph and the loaded graph disagree on the number of outputs"));
     }
     // the new node becomes the source of every graph output: the nodes that produced them before are no longer reachable from the outputs
+    if plan.lanes > 1 {
+        // one context (stream) per further lane, on the device of `hip`; the replicas share the first subgraph's weights (rten_hip_model_clone)
+        let device = unsafe { rten_hip_sys::rten_hip_device_id(hip.raw()) };
+        let mut contexts = Vec::new();
+        for _ in 1..plan.lanes {
+            contexts.push(HipContext::new(device).map_err(|_| rten::ops::OpError::InvalidValue("could not create a context for a further lane"))?);
+        }
+        let pool = HipSubgraphPool::new(sub, contexts)?;
+        return Ok(graph.add_op(Some("hip_resident_subgraph"), Arc::new(pool), &inputs, &outputs));
+    }
     Ok(graph.add_op(Some("hip_resident_subgraph"), Arc::new(sub), &inputs, &outputs))
 }
 
@@ -54,7 +67,7 @@ pub fn install_resident(graph: &mut Graph, hip: &Arc<HipContext>, onnx: &[u8], p
 ///
 /// ```ignore
 /// let hip = HipContext::new(0)?;
-/// let plan = ResidentPlan { plan_json: Some(include_str!("f32_4chains.json")), chains: 4, input_shapes: vec![("x".into(), vec![32, 3, 224, 224])] };
+/// let plan = ResidentPlan { plan_json: Some(include_str!("f32_1chain.json")), chains: 1, lanes: 2, input_shapes: vec![("x".into(), vec![32, 3, 224, 224])] };
 /// let model = rten_hip::load_resident(ModelOptions::with_all_ops(), hip, "resnet50.onnx", plan)?;
 /// let logits = model.run_one(batch.view().into(), None)?;      // the reference's call, one H2D + one D2H per run
 /// ```

@@ -35,7 +35,7 @@ mod install;
 mod ops;
 mod subgraph;
 pub use install::{install_resident, load_resident, ResidentPlan};
-pub use subgraph::HipSubgraph;
+pub use subgraph::{HipSubgraph, HipSubgraphPool};
 
 use std::collections::HashMap;
 use std::ffi::{c_void, CStr};

@@ -519,6 +519,9 @@ int32_t rten_hip_model_clone(rten_hip_model *model, rten_hip_ctx *ctx, rten_hip_
 /* The launch plan a prepared model runs under, as plan-file text keyed by sub-batch size (what prepare(tune = 1) chose / the plan file gave): f32
  * convolution steps AND MatMul / FusedMatMul / Gemm steps (v4: the latter take plan entries and are tuned too).  `*needed` = bytes incl. terminator. */
 int32_t rten_hip_model_plan_json(rten_hip_model *model, char *buf, size_t buf_len, size_t *needed);
+/* Replaces the step tables of the model's launch plan (plan-file text) and marks it unprepared; the next rten_hip_model_prepare applies the new plan and
+ * re-captures the chains (the bound inputs stay).  For tuners that measure the whole model under its real schedule (tools/tune_lanes.py). */
+int32_t rten_hip_model_set_plan(rten_hip_model *model, const char *plan_json);
 /* Measurement aid: every chain runs its plan eagerly `steps` times, one chain after the other, under the per-launch profiler (rten_hip_profile_*);
  * result = a JSON array of one rten_hip_profile_report array per chain.  Call it with `buf` NULL / too small to learn `*needed` is NOT supported
  * (the pass would run twice): pass a buffer of 1 MiB. */

@@ -452,6 +452,23 @@ RTEN_EXPORT int32_t rten_hip_model_plan_json(rten_hip_model *g, char *buf, size_
     return RTEN_HIP_OK;
 }
 
+// Replaces the launch plan of a loaded model (the text of a plan file, as for rten_hip_model_load_ex; the step tables only: "qout" / "fused_dql" lists
+// are load-time choices and are ignored here) and marks the model unprepared: the next rten_hip_model_prepare applies it and re-captures the chains.
+// What a tuner that measures whole-model throughput under its real schedule (several replicas side by side: tools/tune_lanes.py) calls between runs.
+RTEN_EXPORT int32_t rten_hip_model_set_plan(rten_hip_model *g, const char *plan_json) {
+    if (!g || !plan_json || !*plan_json) return RTEN_HIP_ERR_INVALID_VALUE;
+    std::map<std::string, std::vector<long long>> flat;
+    std::map<std::string, std::map<std::string, std::vector<long long>>> keyed;
+    PlanJson pj{plan_json, plan_json + std::strlen(plan_json), {}};
+    if (!pj.object(flat, keyed)) return fail(g, RTEN_HIP_ERR_INVALID_VALUE, "set_plan: not the JSON subset of profiles/plans/");
+    for (auto &c : g->ctxs) c->sync();
+    g->plan_flat = std::move(flat);
+    g->plan_by_batch = std::move(keyed);
+    g->have_plan = true;
+    g->prepared = false;
+    return RTEN_HIP_OK;
+}
+
 // Instrumented pass (measurement aid; `bench.py`'s per-kernel roofline figures): every chain runs its plan EAGERLY `steps` times, chain after chain
 // (serialised launches: clean per-kernel durations at the sub-batch shapes actually launched), with the backend's per-launch HIP-event profiler on
 // (rten_hip_profile_*).  Result: a JSON array with one rten_hip_profile_report array per chain.  The captured graphs are untouched (an eager run

@@ -188,6 +188,7 @@ PROTOTYPES = {
     "rten_hip_model_clone": (_I32, [_VP, _VP, C.POINTER(_VP)]),
     "rten_hip_model_weight_arena": (_I32, [_VP, C.POINTER(_VP), C.POINTER(_SZ)]),
     "rten_hip_model_plan_json": (_I32, [_VP, C.c_char_p, _SZ, C.POINTER(_SZ)]),
+    "rten_hip_model_set_plan": (_I32, [_VP, C.c_char_p]),
     "rten_hip_model_profile": (_I32, [_VP, _I32, C.c_char_p, _SZ, C.POINTER(_SZ)]),
     "rten_hip_device_id": (_I32, [_VP]),
     "rten_hip_tuning_save": (_I32, [_VP, C.POINTER(_I32)]),
@@ -438,6 +439,10 @@ class Model:
         p, n = C.c_void_p(), _SZ()
         self._check(self.lib.rten_hip_model_weight_arena(self.h, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def set_plan(self, plan_json: str):
+        """Replace the launch plan's step tables; call prepare() again to apply and re-capture."""
+        self._check(self.lib.rten_hip_model_set_plan(self.h, plan_json.encode()))
 
     def plan_json(self) -> str:
         """The launch plan of the prepared model as plan-file text (keyed by sub-batch size)."""

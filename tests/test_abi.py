@@ -300,6 +300,8 @@ def test_rust_installer_puts_one_resident_operator_behind_the_loaded_graph():
     assert "pub use install::{install_resident, load_resident, ResidentPlan}" in lib_rs
     assert "sys::rten_hip_model_load_ex(" in sub and "sys::rten_hip_model_load_error()" in sub and "sys::rten_hip_model_load(" not in sub  # (no separate device id)
     assert "pub fn input_names" in sub and "pub fn num_outputs" in sub
+    # lanes: replicas that share one weight set behind one operator
+    assert "sys::rten_hip_model_clone(" in sub and "pub fn replica" in sub and "impl Operator for HipSubgraphPool" in sub and "HipSubgraphPool::new(" in inst
     integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     for name in ("load_resident", "install_resident", "set_graph_rewriter", "rten_hip_model_load_ex", "rten_hip_model_weight_arena"):
         assert name in integ, name
@@ -328,6 +330,6 @@ def test_integration_md_names_only_symbols_the_header_declares():
             continue
         assert name in declared, f"INTEGRATION.md names {name}, which include/rten_hip.h does not declare"
     sub = open(os.path.join(ROOT, "bindings", "rten-hip", "src", "subgraph.rs")).read()
-    assert "impl Operator for HipSubgraph" in sub and "pub use subgraph::HipSubgraph" in open(os.path.join(ROOT, "bindings", "rten-hip", "src", "lib.rs")).read()
+    assert "impl Operator for HipSubgraph" in sub and "pub use subgraph::{HipSubgraph, HipSubgraphPool}" in open(os.path.join(ROOT, "bindings", "rten-hip", "src", "lib.rs")).read()
     for fn in ("load_ex", "bind_input", "prepare", "run", "sync", "output", "destroy"):
         assert f"sys::rten_hip_model_{fn}(" in sub, fn

@@ -36,7 +36,7 @@ def test_eight_rank_bench_control_flow_of_the_default_path(config):
     rk = j["ranks"]
     assert rk["world_size"] == 8 and rk["dist_backend"] == "gloo" and rk["weight_broadcast_world"] == 8
     assert rk["input_seed_per_rank"] == [1234 + r_ for r_ in range(8)] and len(rk["ms_per_step_per_rank"]) == 8
-    plan_file = "int8.json" if config == "int8" else "f32_1chain.json"
+    plan_file = "int8_lanes.json" if config == "int8" else "f32_1chain.json"
     assert j["config"]["launch_plan"]["source"] == os.path.join("profiles", "plans", plan_file)
     assert len(set(rk["plan_sha16_per_rank"])) == 1 and j["config"]["launch_plan"]["identical_on_all_ranks"] is True
     assert len(set(rk["planned_steps_per_rank"])) == 1
@@ -56,7 +56,8 @@ def test_eight_rank_bench_control_flow_of_the_default_path(config):
         assert int(m.group(7)) == 1
     if config == "int8":
         # several ranks per device (the gloo test mode): quantized-output launches stay off, the loader-side quantizers stay in the plan
-        plan = json.load(open(os.path.join(ROOT, "profiles", "plans", "int8.json")))
+        plan = json.load(open(os.path.join(ROOT, "profiles", "plans", "int8_lanes.json")))
+        assert "qout" not in plan  # replicas side by side: no launch that needs the device to itself
         assert j["config"]["quantized_output_launches"] == [] and sorted(j["config"]["quantize_on_load_layers"]) == sorted(plan["fused_dql"])
 
 

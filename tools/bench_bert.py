@@ -15,8 +15,9 @@ ap.add_argument("--seq", type=int, default=128)
 ap.add_argument("--no-cpu-baseline", action="store_true")
 ap.add_argument("--via-runner", action="store_true", help="the hand-planned Python runner (rten_amd/workloads/bert.py) instead of the product path (rten_hip_model_*)")
 ap.add_argument("--autotune", action="store_true", help="executor: tune the GEMM launch plans at prepare time instead of loading profiles/plans/bert_base_b32_s128.json")
-ap.add_argument("--lanes", type=int, default=1, help="executor: independent replicas of the model (own stream, own buffers, own weights); consecutive "
-                                                     "batches go to them round robin, so the row-wise / attention kernels of one batch run beside the GEMMs of the next")
+ap.add_argument("--lanes", type=int, default=4, help="executor: independent replicas of the model (own stream, own buffers, own weights); consecutive "
+                                                     "batches go to them round robin, so the row-wise / attention kernels of one batch run beside the GEMMs of the next "
+                                                     "(default 4: 6.85 -> 6.36 ms per batch, session r5g; 1 = one replica)")
 ap.add_argument("--chains", type=int, default=1, help="executor: split the batch into this many independent sub-batch chains (rows are independent in an encoder)")
 ap.add_argument("--save-plan", default=None, help="executor: write the launch plan that ran (rten_hip_model_plan_json) to this file")
 args = ap.parse_args()
