@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--passes", type=int, default=1)
     ap.add_argument("--margin", type=float, default=0.003, help="a candidate must beat the incumbent by this fraction, in two measurements")
+    ap.add_argument("--big-tiles", action="store_true", help="add 128x128 / 128x64 / 64x128 tiles (three and four LDS stages, fragments-first) to every shape's candidates")
     ap.add_argument("--plan", default=os.path.join(ROOT, "profiles", "plans", "f32_1chain.json"))
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "f32_1chain_lanes.json"))
     args = ap.parse_args()
@@ -78,6 +79,8 @@ def main():
         o, c, k, s, h, res = key
         nblk = (c * k * k + 255) // 256
         cands = [[27, 0, 1, 0], [27, 0, 1, 1], [3, 0, 1, 0], [3, 0, 1, 1], [19, 0, 1, 0], [2, 0, 1, 0], [1, 0, 1, 0]]
+        if args.big_tiles:  # larger tiles run closer to the matrix pipe's rate in their k-loop and lose it to tile quantisation when a launch is alone:
+            cands += [[0, 0, 1, 0], [0, 0, 1, 1], [1, 0, 1, 1], [2, 0, 1, 1], [12, 0, 1, 0], [13, 0, 1, 0], [14, 0, 1, 0], [16, 0, 1, 0], [17, 0, 1, 0], [18, 0, 1, 0]]  # with a second replica filling the idle compute units that may flip
         if nblk > 1:
             for g in sorted({2, 3, 4, 5, 6, nblk} & set(range(2, nblk + 1))):
                 cands += [[3, 1, g, 0], [27, 1, g, 0]]
