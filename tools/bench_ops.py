@@ -106,6 +106,10 @@ def main():
     pd = L.Pool2dDesc(32, 64, 112, 112, 3, 3, 2, 2, (C.c_int32 * 4)(1, 1, 1, 1), 56, 56, 0)
     n_in, n_out = 32 * 64 * 112 * 112, 32 * 64 * 56 * 56
     hbm("MaxPool 3x3/2", "32x64x112x112", (lambda: ctx.call("rten_hip_max_pool2d_f32", C.byref(pd), x.vp, y.vp)), 4.0 * (n_in + n_out))
+    st = empty((ctx.lib.rten_hip_minmax_stats_bytes(),), np.uint8)
+    ctx.call("rten_hip_minmax_stats_reset", st.vp, 1)
+    hbm("MaxPool 3x3/2 + statistics for the following DynamicQuantizeLinear", "32x64x112x112",
+        (lambda: ctx.call("rten_hip_max_pool2d_f32_stats", C.byref(pd), x.vp, y.vp, st.vp)), 4.0 * (n_in + n_out))
     hbm("GlobalAveragePool", "32x2048x7x7", (lambda: ctx.call("rten_hip_global_average_pool_f32", 32 * 2048, 49, x.vp, y.vp)), 4.0 * 32 * 2048 * 50)
 
     # depthwise 3x3 (MobileNet-style: 32 x 144 x 56 x 56) and a 2x upsampling ConvTranspose (32 x 64 x 28 x 28 -> 32 x 32 x 56 x 56, 4x4 / 2)

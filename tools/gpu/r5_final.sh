@@ -1,0 +1,60 @@
+#!/bin/bash
+# Round-5 closing session on the final code and the committed launch plans: smoke, the bench lines (the driver's command = executor, one chain x 2 lanes;
+# round 4's schedule and the runner on the same box; int8 at 4 lanes and 1; BERT at 4 lanes and 1), ops microbench, rocprofv3 kernel stats of the bench
+# commands, FETCH / WRITE traffic passes stamped with the plan hashes the lines carry, matrix-pipe counters of the f32 plan.  Every command under its
+# own timeout.        gpurun --timeout 1700 -- 'bash tools/gpu/r5_final.sh r08'
+TAG=${1:-r08}
+R=$(pwd)
+P=$R/profiles/plans
+O=gpurun_out/$TAG
+mkdir -p $O
+export TMPDIR=/tmp
+( rocminfo | grep -E "Marketing Name|gfx|Compute Unit" | head -8; lscpu | grep -E "Model name|^CPU\(s\)|Thread|Core|Socket" ) > $O/hardware.txt 2>&1
+timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log
+timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_n1.json 2> $O/bench_n1.err; echo "bench rc=$?" >> $O/bench_n1.err
+C="--no-secondary --no-cpu-baseline --no-shapes"
+timeout 200 python bench.py $C > $O/bench_default_50_20.json 2> $O/bench_default_50_20.err
+timeout 200 python bench.py --lanes 1 $C > $O/bench_1chain_1lane.json 2> $O/bench_1chain_1lane.err
+timeout 200 python bench.py --chains 4 $C > $O/bench_4chains_1lane.json 2> $O/bench_4chains_1lane.err
+timeout 200 python bench.py --via-runner $C > $O/bench_runner_4chains.json 2> $O/bench_runner_4chains.err
+timeout 200 python bench.py --config int8 --no-secondary > $O/bench_int8_n1.json 2> $O/bench_int8_n1.err
+timeout 200 python bench.py --config int8 --lanes 1 $C > $O/bench_int8_1lane.json 2> $O/bench_int8_1lane.err
+timeout 200 python bench.py --config int8 --lanes 2 $C > $O/bench_int8_2lanes.json 2> $O/bench_int8_2lanes.err
+timeout 200 python bench.py --config int8 --via-runner $C > $O/bench_int8_runner.json 2> $O/bench_int8_runner.err
+timeout 300 python tools/bench_bert.py > $O/bench_bert.json 2> $O/bench_bert.err
+timeout 200 python tools/bench_bert.py --lanes 1 --no-cpu-baseline > $O/bench_bert_1lane.json 2> $O/bench_bert_1lane.err
+timeout 200 python tools/bench_bert.py --via-runner --no-cpu-baseline > $O/bench_bert_runner.json 2> $O/bench_bert_runner.err
+timeout 400 python tools/bench_ops.py > $O/ops_microbench.json 2> $O/ops_microbench.err
+timeout 200 python tools/probe_sdpa.py > $O/sdpa_ablation.txt 2>&1
+cd /tmp
+PC="--steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-shapes"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_f32 -o t -- python $R/bench.py $PC > $R/$O/prof_f32.json 2> $R/$O/prof_f32.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_int8 -o t -- python $R/bench.py --config int8 $PC > $R/$O/prof_int8.json 2> $R/$O/prof_int8.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_bert -o t -- python $R/tools/bench_bert.py --steps 20 --warmup 5 --no-cpu-baseline > $R/$O/prof_bert.json 2> $R/$O/prof_bert.err
+PMCARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-shapes"
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/$O/f32_$c -o t -- python $R/bench.py --lanes 1 $PMCARGS > $R/$O/f32_$c.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/$O/int8_$c -o t -- python $R/bench.py --config int8 --lanes 2 $PMCARGS > $R/$O/int8_$c.log 2>&1
+done
+SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
+timeout 300 rocprofv3 --kernel-trace --pmc $SQ1 --output-format csv -d $R/$O/pmc_f32 -o t -- python $R/bench.py --lanes 1 $PMCARGS > $R/$O/pmc_f32.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc $SQ1 --output-format csv -d $R/$O/pmc_int8 -o t -- python $R/bench.py --config int8 --lanes 2 $PMCARGS > $R/$O/pmc_int8.log 2>&1
+cd $R
+f() { find $O/$1 -name "$2" | head -1; }
+python tools/pmc_traffic.py $(f f32_FETCH_SIZE t_counter_collection.csv) $(f f32_WRITE_SIZE t_counter_collection.csv) $P/f32_1chain.json > $O/hbm_traffic_per_kernel.json
+python tools/pmc_traffic.py $(f int8_FETCH_SIZE t_counter_collection.csv) $(f int8_WRITE_SIZE t_counter_collection.csv) $P/int8_lanes.json > $O/int8_hbm_traffic_per_kernel.json
+python tools/pmc_mfma.py $(f pmc_f32 t_counter_collection.csv) 3 > $O/mfma_util_f32.csv
+python tools/pmc_mfma.py $(f pmc_int8 t_counter_collection.csv) 3 > $O/mfma_util_int8.csv
+for n in f32 int8 bert; do cp $(f prof_$n t_kernel_stats.csv) $O/rocprofv3_kernel_stats_$n.csv 2>/dev/null; done
+find $O -name "t_kernel_trace.csv" -size +2M -delete; find $O -name "t_counter_collection.csv" -size +4M -delete; find $O -name "*.db" -delete
+tail -n 2 $O/smoke.log
+python - <<PY
+import json
+for n in ("bench_n1","bench_default_50_20","bench_1chain_1lane","bench_4chains_1lane","bench_runner_4chains","bench_int8_n1","bench_int8_1lane","bench_int8_2lanes","bench_int8_runner","bench_bert","bench_bert_1lane","bench_bert_runner"):
+    try:
+        d=json.loads(open("$O/%s.json"%n).read().strip().splitlines()[-1]); r=d["roofline"]
+        print(n, d["value"], d["ms_per_step"], d.get("ms_per_step_joined_every_step"), d.get("p50_latency_ms"), r.get("kernel"), (r.get("step") or r)["frac"], r.get("traffic"), (d["config"].get("batch_lanes") or {}).get("lanes"))
+    except Exception as e: print(n, "ERR", e)
+PY
+head -8 $O/mfma_util_f32.csv; head -6 $O/mfma_util_int8.csv
+ls $O | head -60
