@@ -1,22 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- ResNet-50 f32, batch 32 per GPU, on the HIP backend (BASELINE.json configs[1]).
 
-    python bench.py --gpus N --steps K --warmup W [--config f32|int8]
+    python bench.py --gpus N --steps K --warmup W [--config f32|int8] [--lanes L] [--chains C] [--via-runner]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 `--gpus N` always means N ranks, one per GPU: without a launcher the script spawns them itself (torch.distributed.run);
 under a launcher it refuses to run when WORLD_SIZE != N.  `--config int8` runs the dynamically quantized graph
 (BASELINE configs[2]; with --gpus 8: configs[4]) with its own roofline / cpu_baseline objects.
 
-A step = one forward pass of ResNet-50 (53 convs + maxpool + global-avg-pool + fc) over one batch of
-32 synthetic 224x224 images that is already resident in HBM.  One process per GPU; batches are
-independent, so the path shards with no data-path collective (weak scaling: 32 images per GPU); the only
-collective is the one-time RCCL broadcast of the prepacked weight arena from rank 0 at load.
+What is timed is the PRODUCT path: the model as ONNX bytes through the C++ plan executor behind the C ABI (rten_hip_model_load_ex / _prepare / _run:
+what a Rust host binds); `--via-runner` times round 4's hand-planned Python runner instead (A/B).
+A step = one forward pass of ResNet-50 (53 convs + maxpool + global-avg-pool + fc) over one batch of 32 synthetic 224x224 images that is already
+resident in HBM: one hipGraph replay per chain.  Steps are independent batches, so consecutive steps go round robin to `--lanes` REPLICAS of the model
+(rten_hip_model_clone: own stream, buffers and hipGraphs, one shared weight arena) and overlap on the device -- f32: one whole-batch chain per replica,
+2 lanes; int8 (whose quantizers span the batch: no sub-batch chains): 4 lanes.  `ms_per_step` / `value` are therefore THROUGHPUT figures over the K timed
+steps (both synchronisation points cover every stream of every lane); `ms_per_step_joined_every_step` and `p50_latency_ms` are ONE batch on ONE replica.
+`--chains C` alone gives round 4's schedule (one replica, C sub-batch chains).  One process per GPU; batches are independent, so the path shards with no
+data-path collective (weak scaling: 32 images per GPU); the only collective is the one-time RCCL broadcast of the model's weight arena from rank 0.
 
 Rank 0 prints ONE JSON line: metric/value (whole-job inferences/s); `roofline` -- f32: achieved / frac = the conv FLOPs of one batch over the
-TIMED step (the state `value` was measured in: chains overlapping, every kernel and gap included), with the dominant kernel's stand-alone
-figures (HIP events per launch on the backend's stream, an instrumented pass over the same K steps) as `dominant_kernel` / `igemm_family`, and its
-HBM traffic from the committed PMC pass when that pass ran the same launch plan; int8: the dominant kernel against the HBM peak plus the whole step
+TIMED step (every kernel and gap included), with the dominant kernel's stand-alone figures (HIP events per launch, an instrumented eager pass outside the
+timed region) as `dominant_kernel` / `igemm_family`, its HBM traffic from the committed PMC pass when that pass ran the same launch plan, and `shapes`
+(every distinct conv shape stand-alone with its attainable bound); int8: the dominant kernel against the HBM peak plus the whole step
 against the graph's HBM floor -- ; and cpu_baseline (the CPU oracle -- a port of the reference algorithm -- timed on this host's cores on a
 bounded sample; N=1 only).  At N=1 the line also carries `secondary`: the int8 ResNet-50 (configs[2]) and BERT-base (configs[3])
 harnesses run in child processes after the headline measurement.  The per-layer launch plan is the one committed under profiles/plans/
