@@ -33,6 +33,11 @@ __global__ __launch_bounds__(256) void dequant4_kernel(long long words, int K, i
     o[1] = hi;
 }
 
+// (Round 5 measured the obvious alternative -- the 4 * SPL adjacent columns of a workgroup fetched with 16-byte coalesced loads into LDS, lanes reading their
+//  1-4 bytes per step from there; same slots, chains and fold, bit-identical -- and it is SLOWER: 11.3 vs 6.6 us at N = K = 4096, 22.5 vs 12.2 us at
+//  N = 14336 (profiles/r08/matmul_nbits_staging_experiment.txt): the launch is one workgroup per compute unit, so a load phase followed by a compute phase
+//  serialises what the direct form below overlaps with its U-deep register prefetch.  The kernel is bound by VALU issue and the launch floor, not by its
+//  small loads.  Commit "MatMulNBits decode: operands staged through LDS" has the code.)
 constexpr int GEMV_CHUNK = 8192; // LHS elements staged in LDS at a time (32 KB, shared by the four waves of a workgroup)
 
 // SPL = accumulator slots per lane (8, 4 or 2): 64 / SPL lanes share a column, a wave covers SPL columns, a workgroup 4 * SPL.
@@ -160,128 +165,6 @@ __global__ __launch_bounds__(256) void gemv4_kernel(int K, int N, int lbs, const
     if (live && sub == 0) y[(long long)blockIdx.y * N + col] = out;
 }
 
-
-// The same arithmetic with the operands STAGED: the bytes a lane needs of a 64-element step are SPL / 2 (1-4) and sit 32 bytes apart from step to step,
-// so the direct form above issues 1-4-byte loads whose wave instruction touches 64 / SPL separate 32-byte pieces -- 6.6 us for 8.4 MB at N = K = 4096
-// (0.20 of the HBM peak).  The 4 * SPL columns of a workgroup are ADJACENT rows of `quant` / `scales`: one contiguous run per k chunk, fetched here with
-// 16-byte coalesced loads into LDS (quant bytes, scales, the LHS chunk), after which every lane reads its own bytes from LDS.  Same slots, same FMA
-// chains, same fold: bit-identical to the direct form.  LDS: [lhs chunk | quant 4 SPL x chunk / 2 B | scales 4 SPL x chunk / bs f32].
-extern __shared__ __attribute__((aligned(16))) unsigned char gemv_smem[];
-template <int SPL>
-__global__ __launch_bounds__(256) void gemv4_staged_kernel(int K, int N, int lbs, int chunk, const float *__restrict__ a, const unsigned char *__restrict__ quant,
-                                                            const float *__restrict__ scales, float *__restrict__ y) {
-    typedef typename QWord<SPL>::T W;
-    constexpr int LPC = 64 / SPL, NCOL = 4 * SPL;
-    float *lhs = reinterpret_cast<float *>(gemv_smem);
-    unsigned char *qs = gemv_smem + (size_t)chunk * 4;
-    float *ss = reinterpret_cast<float *>(qs + (size_t)NCOL * (chunk / 2));
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane % LPC;
-    const int col_l = wave * SPL + lane / LPC, col0 = blockIdx.x * NCOL, col = col0 + col_l;
-    const bool live = col < N;
-    const int c = live ? col : N - 1;
-    const int kb = K >> lbs;
-    const float *arow = a + (long long)blockIdx.y * K;
-    const unsigned char *qcol = quant + (long long)c * (K / 2);
-    const float *scol = scales + (long long)c * kb;
-    const int kv = K - K % 128;
-
-    v2f acc[SPL / 2];
-#pragma unroll
-    for (int e = 0; e < SPL / 2; e++) acc[e] = (v2f){0.f, 0.f};
-    auto step = [&](unsigned wv, float s, const float *lp) {
-        v2f l[SPL / 2];
-        if constexpr (SPL == 2) {
-            l[0] = *reinterpret_cast<const v2f *>(lp);
-        } else {
-#pragma unroll
-            for (int q = 0; q < SPL / 4; q++) {
-                const float4 t = *reinterpret_cast<const float4 *>(lp + 4 * q);
-                l[2 * q] = (v2f){t.x, t.y};
-                l[2 * q + 1] = (v2f){t.z, t.w};
-            }
-        }
-        const unsigned lo = wv & 0x0F0F0F0Fu, hi = (wv >> 4) & 0x0F0F0F0Fu;
-        const v2f s2 = (v2f){s, s}, m8 = (v2f){-8.0f * s, -8.0f * s};
-#pragma unroll
-        for (int t = 0; t < SPL / 2; t++) {
-            const v2f q = (v2f){(float)((lo >> (8 * t)) & 0xFFu), (float)((hi >> (8 * t)) & 0xFFu)};
-            const v2f w = __builtin_elementwise_fma(q, s2, m8);
-            acc[t] = __builtin_elementwise_fma(l[t], w, acc[t]);
-        }
-    };
-
-    for (int k0 = 0; k0 < kv; k0 += chunk) {
-        const int len = kv - k0 < chunk ? kv - k0 : chunk; // multiple of 128: len / 2 bytes per column, a multiple of 64
-        const int qlen = len / 2, slen = len >> lbs;       // (the host checks chunk % block size == 0: a chunk starts on a block boundary)
-        __syncthreads(); // the previous chunk's readers are done
-        for (int i = threadIdx.x * 4; i < len; i += 1024) *reinterpret_cast<float4 *>(&lhs[i]) = *reinterpret_cast<const float4 *>(arow + k0 + i);
-        for (int i = threadIdx.x * 16; i < NCOL * qlen; i += 256 * 16) {
-            const int cl = i / qlen, off = i - cl * qlen;
-            const int gc = col0 + cl < N ? col0 + cl : N - 1;
-            *reinterpret_cast<uint4 *>(qs + (size_t)cl * (chunk / 2) + off) = *reinterpret_cast<const uint4 *>(quant + (long long)gc * (K / 2) + k0 / 2 + off);
-        }
-        for (int i = threadIdx.x; i < NCOL * slen; i += 256) {
-            const int cl = i / slen, off = i - cl * slen;
-            const int gc = col0 + cl < N ? col0 + cl : N - 1;
-            ss[cl * (chunk >> lbs) + off] = scales[(long long)gc * kb + (k0 >> lbs) + off];
-        }
-        __syncthreads();
-        const unsigned char *qp = qs + (size_t)col_l * (chunk / 2) + (sub * SPL) / 2; // + 32 bytes per step
-        const float *sp = ss + col_l * (chunk >> lbs);
-        const float *lp = &lhs[sub * SPL];
-        const int steps = len / 64, kl = sub * SPL;
-#pragma unroll 4
-        for (int j = 0; j < steps; j++) step(*reinterpret_cast<const W *>(qp + j * 32), sp[(kl + j * 64) >> lbs], lp + j * 64);
-    }
-
-    float accs[SPL];
-#pragma unroll
-    for (int t = 0; t < SPL / 2; t++) { accs[2 * t] = acc[t].x; accs[2 * t + 1] = acc[t].y; }
-    constexpr int order[6] = {16, 32, 8, 4, 2, 1};
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-        const int w = order[i];
-        if (w >= SPL) {
-#pragma unroll
-            for (int e = 0; e < SPL; e++) accs[e] = accs[e] + __shfl_xor(accs[e], w / SPL);
-        } else {
-#pragma unroll
-            for (int e = 0; e < SPL; e++)
-                if (e < w) accs[e] = accs[e] + accs[e + w];
-        }
-    }
-    float out = accs[0];
-    if (kv < K && sub == 0) { // scalar tail (block_quant.rs:351-377): separately rounded products
-        float tail = 0.f;
-        for (int k = kv; k < K; k += 2) {
-            const unsigned byte = qcol[k / 2];
-            const float s = scol[k >> lbs];
-            const float lo = (float)((int)(byte & 0xFu) - 8) * s, hi = (float)((int)(byte >> 4) - 8) * s;
-            const float p0 = __fmul_rn(arow[k], lo), p1 = __fmul_rn(arow[k + 1], hi);
-            tail = tail + (p0 + p1);
-        }
-        out = out + tail;
-    }
-    if (live && sub == 0) y[(long long)blockIdx.y * N + col] = out;
-}
-
-// true: launched.  The staged form needs 16-byte alignment of every column's chunk (K % 32 == 0, aligned bases) and a chunk that is a whole number of blocks.
-template <int SPL>
-bool launch_gemv4_staged(rten_hip_ctx *ctx, int64_t batch, int k, int n, int bs, const float *a, const uint8_t *q, const float *sc, float *y) {
-    const int lbs = __builtin_ctz((unsigned)bs);
-    int chunk = k - k % 128;
-    const int cap = SPL == 8 ? 2048 : 4096; // 32 columns x 1 KB + LHS + scales = 48 KB: three workgroups per compute unit load and compute in turns
-    if (chunk > cap) chunk = cap;
-    if (chunk < 128 || k % 32 || chunk % bs || chunk % 128 || ((uintptr_t)q & 15u) || ((uintptr_t)a & 15u) || (ctx->debug & 0x2000000)) return false; // (bit 0x2000000: the direct form, A/B)
-    const size_t lds = (size_t)chunk * 4 + (size_t)4 * SPL * (chunk / 2) + (size_t)4 * SPL * (chunk >> lbs) * 4;
-    if (lds > 150 * 1024) return false;
-    auto kern = gemv4_staged_kernel<SPL>;
-    if (lds > 64 * 1024) hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const dim3 grid((unsigned)((n + 4 * SPL - 1) / (4 * SPL)), (unsigned)batch);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, k, n, lbs, chunk, a, q, sc, y);
-    return true;
-}
-
 template <int SPL>
 void launch_gemv4(rten_hip_ctx *ctx, int u, int64_t batch, int k, int n, int bs, const float *a, const uint8_t *q, const float *sc, float *y) {
     const int lbs = __builtin_ctz((unsigned)bs);
@@ -316,11 +199,6 @@ RTEN_EXPORT int32_t rten_hip_matmul_nbits_f32(rten_hip_ctx *ctx, int64_t batch, 
         const long long cols = (long long)batch * n, want = 4LL * ctx->num_cus;
         const int spl = forced ? forced : (cols / 8 >= want ? 8 : cols / 4 >= want ? 4 : 2);
         static const int depth = getenv("RTEN_HIP_GEMV_U") ? atoi(getenv("RTEN_HIP_GEMV_U")) : 8;       // tuning only
-        bool staged = false;
-        if (spl == 8) staged = launch_gemv4_staged<8>(ctx, batch, k, n, block_size, a, b_quant, scales, y);
-        else if (spl == 4) staged = launch_gemv4_staged<4>(ctx, batch, k, n, block_size, a, b_quant, scales, y);
-        else staged = launch_gemv4_staged<2>(ctx, batch, k, n, block_size, a, b_quant, scales, y);
-        if (staged) { RTEN_LAUNCH_CHECK(ctx, "gemv4_staged_kernel launch"); return RTEN_HIP_OK; }
         if (spl == 8) launch_gemv4<8>(ctx, depth, batch, k, n, block_size, a, b_quant, scales, y);
         else if (spl == 4) launch_gemv4<4>(ctx, depth, batch, k, n, block_size, a, b_quant, scales, y);
         else launch_gemv4<2>(ctx, depth, batch, k, n, block_size, a, b_quant, scales, y);
