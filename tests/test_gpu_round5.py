@@ -60,3 +60,135 @@ def test_streaming_max_pool_bits_and_statistics(ctx, shape, pads):
     mins, maxs = ord2f(raw[:256][raw[:256] != 0xffffffff]), ord2f(raw[256:512][raw[256:512] != 0])
     finite = want[~np.isnan(want)]
     assert mins.min() == finite.min() and maxs.max() == finite.max()
+
+
+# ------------------------------------------------------------------------------------------ ADVICE round 4, as tests
+def _small_cnn_case(batch=6):
+    from rten_amd import onnx_writer as ow
+    model_bytes, w = ow.small_cnn_f32()
+    x = np.random.default_rng(3).standard_normal((batch, 3, 16, 16)).astype(np.float32)
+    a = ref.conv2d_f32(x, w["c1"][0], w["c1"][1], pads=(1, 1, 1, 1), strides=(2, 2), relu=True)
+    p = ref.max_pool(a, (2, 2), (2, 2))
+    s = ref.conv2d_f32(p, w["c2"][0], w["c2"][1], residual=p, relu=True)
+    g = ref.global_average_pool(s).reshape(batch, -1)
+    want = ref.gemm_f32(g, w["fc"][0].T, c=np.broadcast_to(w["fc"][1], (batch, 5)).astype(np.float32), alpha=1.0, beta=1.0)  # (as tests/test_graph_executor.py)
+    return model_bytes, x, want
+
+
+def test_model_abi_reports_why_and_replans(ctx):
+    """Load errors carry text (there is no model object to ask), a keyed plan without the chain's sub-batch size is an error, a plan that matches no step
+    a warning; rten_hip_model_plan_json / _set_plan round trip and re-capture with the same bits; a scalar-output / dim-0-changing graph is refused for
+    chains > 1 instead of writing past its buffer (ADVICE round 4, low + medium 1)."""
+    import json
+    from rten_amd import onnx_writer as ow
+    model_bytes, x, want = _small_cnn_case()
+    with pytest.raises(L.HipError) as e:
+        L.Model(ctx, b"\x08\x01garbage", None, 1)
+    assert "model_load" in str(e.value) and len(str(e.value)) > 12, str(e.value)
+    with pytest.raises(L.HipError) as e:
+        L.Model(ctx, model_bytes, "{not json", 1)
+    assert "plan file" in str(e.value), str(e.value)
+    # keyed plan that does not name the chain's sub-batch size (6 rows as 2 chains of 3): error at prepare, with text
+    m = L.Model(ctx, model_bytes, json.dumps({"8": {"c1": [3, 0, 1, 0]}}), 2)
+    try:
+        m.bind_input("x", x.shape)
+        with pytest.raises(L.HipError) as e:
+            m.prepare()
+        assert "keyed by sub-batch size" in str(e.value), str(e.value)
+    finally:
+        m.close()
+    # a plan that names no step of this graph: loads, prepares, warns
+    m = L.Model(ctx, model_bytes, json.dumps({"no_such_step": [3, 0, 1, 0]}), 1)
+    try:
+        p = m.bind_input("x", x.shape)
+        m.prepare()
+        assert "matched no step" in m.warning, m.warning
+        xt = DeviceTensor(ctx, x.shape, np.float32, ptr=p, keepalive=m)
+        xt.upload(x)
+        # plan export, re-plan (every conv AND the classifier Gemm on other variants), re-capture: same bits
+        outs = []
+        for plan in (None, {"c1": [3, 0, 1, 1], "c2": [27, 0, 1, 0], "fc": [2, 3, 1, 0]}):
+            if plan is not None:
+                m.set_plan(json.dumps(plan))
+                m.prepare()
+                ran = json.loads(m.plan_json())
+                assert ran[str(x.shape[0])]["c1"] == [3, 0, 1, 1] and ran[str(x.shape[0])]["fc"] == [2, 3, 1, 0], ran
+                assert m.planned_steps == 3 and m.warning == ""
+            m.run(inputs_written_on_caller_stream=True)
+            m.sync()
+            optr, oshape = m.output(0)
+            outs.append(DeviceTensor(ctx, oshape, np.float32, ptr=optr, keepalive=m).numpy())
+        _bits(outs[0], want)
+        _bits(outs[1], want)
+    finally:
+        m.close()
+
+
+def test_executor_leaves_a_borrowed_context_as_it_found_it(ctx):
+    """Chain 0 of a model runs on the CALLER's context: after load / prepare / run / profile the caller's tuning knobs are what the caller set, not the
+    defaults."""
+    import json
+    model_bytes, x, want = _small_cnn_case(batch=4)
+    ctx.call("rten_hip_set_gemm_variant_override", 2)
+    ctx.call("rten_hip_set_gemm_split", 1, 3)
+    ctx.call("rten_hip_set_gemm_order", 1)
+    ctx.call("rten_hip_set_gemv_order", 0, 7)
+    before = (C.c_int32 * 8)()
+    ctx.call("rten_hip_tuning_save", before)
+    try:
+        m = L.Model(ctx, model_bytes, json.dumps({"c1": [3, 0, 1, 0], "c2": [27, 0, 1, 0]}), 3)  # 4 rows as chains of 2 + 1 + 1: lone-row chains flip the gemv order
+        try:
+            p = m.bind_input("x", x.shape)
+            m.prepare()
+            DeviceTensor(ctx, x.shape, np.float32, ptr=p, keepalive=m).upload(x)
+            m.run(inputs_written_on_caller_stream=True)
+            m.sync()
+            m.profile_pass(1)
+            after = (C.c_int32 * 8)()
+            ctx.call("rten_hip_tuning_save", after)
+            assert list(after) == list(before), (list(before), list(after))
+        finally:
+            m.close()
+    finally:
+        ctx.call("rten_hip_set_gemm_variant_override", -1)
+        ctx.call("rten_hip_set_gemm_split", 3, 1)
+        ctx.call("rten_hip_set_gemm_order", 0)
+        ctx.call("rten_hip_set_gemv_order", 1, 0)
+
+
+def test_scratch_a_live_graph_replays_from_is_not_freed(ctx):
+    """A captured hipGraph holds the context's auxiliary scratch pointer (the composed attention path keeps its score tensor there).  A later eager call
+    on the same context that needs a larger buffer must not free the one the graph replays from: the replay still gives the
+    first result."""
+    rng = ref.XorShiftRng(77)
+
+    def case(B, H, S, T):
+        q = rng.f32(B * H * S * 64).reshape(B, H, S, 64) - 0.5
+        k = rng.f32(B * H * T * 64).reshape(B, H, T, 64) - 0.5
+        v = rng.f32(B * H * T * 64).reshape(B, H, T, 64) - 0.5
+        d = L.SdpaDesc(B, H, S, T, 64, 64, H * S * 64, S * 64, 64, H * T * 64, T * 64, 64, H * T * 64, T * 64, 64, H * S * 64, S * 64, 64, 0, 0, 0.125, 0)
+        return d, [DeviceTensor.from_numpy(ctx, t) for t in (q, k, v)], DeviceTensor(ctx, (B, H, S, 64), np.float32), ref.sdpa(q, k, v, scale=0.125, lanes=16, flush_nan=False)
+    ctx.call("rten_hip_set_sdpa_path", 1)  # the composed path: GEMM -> softmax -> GEMM through the auxiliary scratch
+    try:
+        d1, (q1, k1, v1), o1, want1 = case(1, 2, 40, 200)
+        run1 = lambda: ctx.call("rten_hip_sdpa_f32", C.byref(d1), q1.vp, k1.vp, v1.vp, None, o1.vp)
+        run1()
+        ctx.sync()
+        _bits(o1.numpy(), want1)
+        ctx.graph_begin()
+        run1()
+        g = ctx.graph_end()
+        try:
+            d2, (q2, k2, v2), o2, want2 = case(8, 16, 384, 384)  # 8 * 16 * 384 * 384 * 4 B = 75 MB of scores: larger than the first buffer
+            ctx.call("rten_hip_sdpa_f32", C.byref(d2), q2.vp, k2.vp, v2.vp, None, o2.vp)
+            ctx.sync()
+            _bits(o2.numpy(), want2)
+            for _ in range(3):
+                o1.upload(np.zeros(o1.shape, np.float32))
+                ctx.graph_launch(g)
+                ctx.sync()
+                _bits(o1.numpy(), want1)
+        finally:
+            ctx.graph_destroy(g)
+    finally:
+        ctx.call("rten_hip_set_sdpa_path", 0)
