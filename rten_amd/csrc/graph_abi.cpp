@@ -447,7 +447,8 @@ RTEN_EXPORT int32_t rten_hip_model_plan_json(rten_hip_model *g, char *buf, size_
     }
     out += "}";
     if (needed) *needed = out.size() + 1;
-    if (!buf || buf_len < out.size() + 1) return fail(g, RTEN_HIP_ERR_INVALID_VALUE, "plan_json: buffer too small");
+    if (!buf) return RTEN_HIP_ERR_INVALID_VALUE; // a size query: `*needed` is the answer, nothing to report
+    if (buf_len < out.size() + 1) return fail(g, RTEN_HIP_ERR_INVALID_VALUE, "plan_json: buffer too small");
     std::memcpy(buf, out.c_str(), out.size() + 1);
     return RTEN_HIP_OK;
 }
