@@ -533,18 +533,26 @@ def run_via_executor(args):
     logits = DeviceTensor(ctx, oshape, np.float32, ptr=optr, keepalive=model).numpy()
     logits_sha = hashlib.sha256(np.ascontiguousarray(logits).tobytes()).hexdigest()[:16]
     lanes_agree = True
-    for m_l, c_l in zip(models[1:], lane_ctx[1:]):  # every lane ran the same batch: the same bits, whatever ran beside it
+    for l, (m_l, c_l) in enumerate(zip(models, lane_ctx)):  # every lane ran the same batch: the same bits, whatever ran beside it
+        if l == 0 or l >= args.warmup + args.steps:  # (a lane that was never handed a batch has nothing to compare)
+            continue
         op_l, os_l = m_l.output(0)
         lanes_agree = lanes_agree and np.array_equal(DeviceTensor(c_l, os_l, np.float32, ptr=op_l, keepalive=m_l).numpy().view(np.int32), logits.view(np.int32))
     if not lanes_agree:
-        print("bench.py: the lanes computed different logits for the same batch: results are void", file=sys.stderr)
-        return 3
+        logits_sha = "lanes-disagree"  # reported through the collective below: every rank then leaves together
     plan_sha = hashlib.sha256(json.dumps(json.loads(plan_text), sort_keys=True).encode()).hexdigest()[:16] if plan_text else None
     shard_report = [(rank, logits_sha, plan_sha, model.planned_steps)]
     if dist is not None:
         box = [None] * world
         dist.all_gather_object(box, shard_report[0])
         shard_report = sorted(box)
+    if any(r[1] == "lanes-disagree" for r in shard_report):
+        if rank == 0:
+            print("bench.py: the lanes of a rank computed different logits for the same batch: results are void", file=sys.stderr)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return 3
 
     # ---- per-step join (a latency figure: every step waits for all chains) beside the free-running throughput figure above
     lat = []
