@@ -537,7 +537,8 @@ int32_t rten_hip_tuning_save(rten_hip_ctx *ctx, int32_t state[8]);
 int32_t rten_hip_tuning_restore(rten_hip_ctx *ctx, const int32_t state[8]);
 
 /* ---- tuning: per-shape kernel-variant selection by measurement at load time ----
- * variant < 0 restores the built-in heuristic.  Used by the harness's autotuner. */
+ * variant < 0 restores the built-in heuristic.  Used by the harness's autotuner.  Variant 31 (round 5): rten_hip_gemm_f32 calls with one batch and
+ * at most 64 rows stream B through every compute unit, one wave per 16x16 output block per depth block (also what the heuristic picks there). */
 int32_t rten_hip_set_gemm_variant_override(rten_hip_ctx *ctx, int32_t variant);
 int32_t rten_hip_num_gemm_variants(void);
 /* Exact split-K for GEMM / conv (results stay bit-identical: K is only cut at the reference's depth-block

@@ -2325,6 +2325,170 @@ __global__ void im2col_lut_kernel(i32x2 *lut, int K, int Kpad, int KHW, int KW, 
     lut[k] = i32x2{c * HW + ky * dy * W + kx * dx, taps ? 31 - rem : (ky * dy) | ((kx * dx) << 16)};
 }
 
+// =====================================================================================================
+// Small-M weight streaming (variant 31; the automatic choice for M <= 64, one batch): the classifier / projection shape, where the
+// tiled kernels have a handful of 64-row tiles and one of them streams megabytes of B alone (ResNet-50's 32 x 2048 x 1000 Gemm:
+// 16 workgroups, 19-25 us for an 8 MB weight read).  Here a WAVE owns one 16x16 block of C for ONE depth block (kc = 256): a chain of
+// 64 dependent v_mfma_f32_16x16x4_f32 (a k-ordered fmaf chain, tools/probes/mfma_16x16x4_order.hip) -- the reference's micro-kernel
+// chain for that block (rten-gemm/src/kernels/simd_generic.rs:326-367) -- and a workgroup = 4 such waves sharing 16 * MT rows of A and
+// 64 / MT * 16 columns of B through LDS.  grid = column groups x depth blocks, so ceil(N / (64 / MT * 16)) * ceil(K / 256) workgroups stream B
+// (classifier: 32 x 8 = 256, one per compute unit, 64 KB each).  The raw block sums go to the split-K slab; the last workgroup of
+// a 16x16 block to arrive folds them in depth-block order (first block: beta * C + bias; later blocks: separate adds;
+// rten-gemm/src/lib.rs:1008-1013,1221-1255) -- same bits as the unsplit chain, same visibility protocol as split_finish.
+//
+// LDS image of an operand row (an A row or a B column; 256 depths): SM_LD = 260 floats, depth k = 16 j + 4 i + g stored at 16 j + 4 g + i:
+// lane (row = lane % 16, g = lane / 16) reads the operands of its MFMAs 4 j .. 4 j + 3 with ONE ds_read_b128 (banks 4 * row + 16 j + 4 g + {0..3}:
+// conflict free), and a loader lane holding depths 16 j + 4 q + {0..3} of a row writes four words at 16 j + 4 c + q (banks 4 * row + q + ...: conflict free).
+// =====================================================================================================
+constexpr int SM_LD = 260;
+
+template <int MT>
+__global__ __launch_bounds__(256) void gemm_f32_smallm_kernel(const GemmArgs p) {
+    kernarg_prefetch<(int)sizeof(GemmArgs)>();
+    constexpr int NW = 4 / MT;               // 16-column blocks per workgroup
+    constexpr int RA = 16 * MT, RB = 16 * NW; // operand rows in LDS
+    __shared__ __attribute__((aligned(16))) float smem[(RA + RB) * SM_LD];
+    float *As = smem, *Bs = smem + RA * SM_LD;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l15 = lane & 15, quad = lane >> 4;
+    const int gx = blockIdx.x, kb = blockIdx.y;
+    const int n0 = gx * RB, k0 = kb * 256;
+    const int depth = p.K - k0 < 256 ? p.K - k0 : 256;
+    const int nblk = (int)gridDim.y;
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)p.A, 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void *)p.B, 0, (int)p.b_bytes, 0x00020000);
+
+    // ---- stage the operands: depth-contiguous rows take 16-byte loads (a wave covers 16 rows x 64 bytes per depth group j)
+    const bool a_vec = p.tiles_m & 1, b_vec = p.tiles_m & 2; // set by the launcher: depth stride 1, row stride and K multiples of 4, base 16-byte aligned
+    if (a_vec) {
+        f32x4 v[MT * 4];
+#pragma unroll
+        for (int u = 0; u < MT * 4; u++) {
+            const int f = u * 256 + t, q = f & 3, r = (f >> 2) & 15, j = (f >> 6) & 15, rg = f >> 10;
+            const int row = rg * 16 + r, k = 16 * j + 4 * q;
+            v[u] = buf_load4(rsA, (row < p.M && k < depth) ? (unsigned)(((long long)row * p.a_rs + k0 + k) << 2) : OOB, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < MT * 4; u++) {
+            const int f = u * 256 + t, q = f & 3, r = (f >> 2) & 15, j = (f >> 6) & 15, rg = f >> 10;
+            float *dst = As + (rg * 16 + r) * SM_LD + 16 * j + q;
+            dst[0] = v[u][0]; dst[4] = v[u][1]; dst[8] = v[u][2]; dst[12] = v[u][3];
+        }
+    } else if (p.tiles_m & 4) { // A given transposed ([K][M], 16-byte groups of rows): a wave covers 16 depths x 16 rows per load
+        f32x4 v[MT * 4];
+#pragma unroll
+        for (int u = 0; u < MT * 4; u++) {
+            const int f = u * 256 + t, c4 = f & 3, k = 16 * ((f >> 6) & 15) + ((f >> 2) & 15), row = 16 * (f >> 10) + 4 * c4;
+            v[u] = buf_load4(rsA, (row < p.M && k < depth) ? (unsigned)(((long long)(k0 + k) * p.a_cs + row) << 2) : OOB, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < MT * 4; u++) {
+            const int f = u * 256 + t, c4 = f & 3, k = 16 * ((f >> 6) & 15) + ((f >> 2) & 15), row = 16 * (f >> 10) + 4 * c4;
+            float *dst = As + row * SM_LD + (k & ~15) + 4 * (k & 3) + ((k >> 2) & 3); // banks 16 c4 + 4 c + {0..15}: conflict free
+            dst[0] = v[u][0]; dst[SM_LD] = v[u][1]; dst[2 * SM_LD] = v[u][2]; dst[3 * SM_LD] = v[u][3];
+        }
+    } else {
+        const bool along_m = p.a_dir_m; // rows are the contiguous direction (A given transposed): lanes walk rows
+#pragma unroll 8
+        for (int u = 0; u < RA; u++) {
+            const int idx = u * 256 + t;
+            const int row = along_m ? idx % RA : idx >> 8, k = along_m ? idx / RA : idx & 255;
+            const float x = buf_load1(rsA, (row < p.M && k < depth) ? (unsigned)(((long long)row * p.a_rs + (long long)(k0 + k) * p.a_cs) << 2) : OOB, 0);
+            As[row * SM_LD + (k & ~15) + 4 * (k & 3) + ((k >> 2) & 3)] = x;
+        }
+    }
+    if (b_vec) {
+        f32x4 v[NW * 4];
+#pragma unroll
+        for (int u = 0; u < NW * 4; u++) {
+            const int f = u * 256 + t, q = f & 3, r = (f >> 2) & 15, j = (f >> 6) & 15, rg = f >> 10;
+            const int col = n0 + rg * 16 + r, k = 16 * j + 4 * q;
+            v[u] = buf_load4(rsB, (col < p.N && k < depth) ? (unsigned)(((long long)col * p.b_cs + k0 + k) << 2) : OOB, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < NW * 4; u++) {
+            const int f = u * 256 + t, q = f & 3, r = (f >> 2) & 15, j = (f >> 6) & 15, rg = f >> 10;
+            float *dst = Bs + (rg * 16 + r) * SM_LD + 16 * j + q;
+            dst[0] = v[u][0]; dst[4] = v[u][1]; dst[8] = v[u][2]; dst[12] = v[u][3];
+        }
+    } else if (p.tiles_m & 8) { // B as [K][N] (16-byte groups of columns): a wave covers 16 depths x 16 columns per load
+        f32x4 v[NW * 4];
+#pragma unroll
+        for (int u = 0; u < NW * 4; u++) {
+            const int f = u * 256 + t, c4 = f & 3, k = 16 * ((f >> 6) & 15) + ((f >> 2) & 15), c = 16 * (f >> 10) + 4 * c4;
+            v[u] = buf_load4(rsB, (n0 + c < p.N && k < depth) ? (unsigned)(((long long)(k0 + k) * p.b_rs + n0 + c) << 2) : OOB, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < NW * 4; u++) {
+            const int f = u * 256 + t, c4 = f & 3, k = 16 * ((f >> 6) & 15) + ((f >> 2) & 15), c = 16 * (f >> 10) + 4 * c4;
+            float *dst = Bs + c * SM_LD + (k & ~15) + 4 * (k & 3) + ((k >> 2) & 3);
+            dst[0] = v[u][0]; dst[SM_LD] = v[u][1]; dst[2 * SM_LD] = v[u][2]; dst[3 * SM_LD] = v[u][3];
+        }
+    } else {
+        const bool along_n = p.b_dir_n; // columns are the contiguous direction (B as [K][N]): lanes walk columns
+#pragma unroll 8
+        for (int u = 0; u < RB; u++) {
+            const int idx = u * 256 + t;
+            const int c = along_n ? idx % RB : idx >> 8, k = along_n ? idx / RB : idx & 255;
+            const int col = n0 + c;
+            const float x = buf_load1(rsB, (col < p.N && k < depth) ? (unsigned)(((long long)(k0 + k) * p.b_rs + (long long)col * p.b_cs) << 2) : OOB, 0);
+            Bs[c * SM_LD + (k & ~15) + 4 * (k & 3) + ((k >> 2) & 3)] = x;
+        }
+    }
+    __syncthreads();
+
+    // ---- one 16x16 block of C, one depth block: the MFMA chain
+    const int mt = wave % MT, nw = wave / MT;
+    const float *ar = As + (mt * 16 + l15) * SM_LD + 4 * quad, *br = Bs + (nw * 16 + l15) * SM_LD + 4 * quad;
+    f32x4 af[16], bf[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) { af[j] = *(const f32x4 *)(ar + 16 * j); bf[j] = *(const f32x4 *)(br + 16 * j); }
+    f32x4v acc[1][1];
+    acc[0][0] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (16 * j + 4 * i < depth) // (uniform; depths past the end inside the last MFMA are zeros: exact)
+                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j][i], bf[j][i], acc[0][0], 0, 0, 0);
+        }
+    }
+
+    const int mb = mt * 16 + 4 * quad, nb0 = n0 + nw * 16 + l15;
+    if (nblk == 1) {
+        fold_first16<1, 1>(p, 0, acc, acc, mb, nb0, 0);
+        store_out16<1, 1>(p, acc, mb, nb0, 0);
+        return;
+    }
+    // ---- park the raw sums; the last arrival of the column group folds them in depth-block order
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.slab + (long long)gx * nblk * 1024), 0, nblk * 4096, 0x00020000);
+    coherent_store4(rs, (unsigned)((kb * 4 + wave) * 64 + lane) * 16u, acc[0][0]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's write-through store has been acknowledged
+    // per-WAVE arrival (counter gx * 4 + wave): the nblk waves that own the same 16x16 block meet on it, no workgroup barrier on the way
+    unsigned old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(p.split_counters + gx * 4 + wave, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old != (unsigned)nblk - 1u) return;
+    // all of a batch's slots are in flight before the first fold (one memory round trip per 8 depth blocks, not one per block)
+    f32x4v tot[1][1], cur[1][1];
+    f32x4 part[8];
+    for (int s0 = 0; s0 < nblk; s0 += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) part[u] = coherent_load4(rs, s0 + u < nblk ? (unsigned)(((s0 + u) * 4 + wave) * 64 + lane) * 16u : OOB);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (s0 + u < nblk) {
+                cur[0][0] = part[u];
+                if (s0 + u == 0) fold_first16<1, 1>(p, 0, cur, tot, mb, nb0, 0);
+                else fold_next16<1, 1>(p, cur, tot);
+            }
+        }
+    }
+    store_out16<1, 1>(p, tot, mb, nb0, 0);
+    if (lane == 0) p.split_counters[gx * 4 + wave] = 0u;
+}
+
 } // namespace
 
 // =====================================================================================================
@@ -2619,7 +2783,7 @@ int32_t launch_variant(rten_hip_ctx *ctx, GemmArgs &a, int Z, int cfg) {
 }
 
 int pick_cfg(rten_hip_ctx *ctx, int M, long long N, int Z) {
-    if (ctx->gemm_variant_override >= 24 && ctx->gemm_variant_override < 31) return 3; // wave-tile kernels (24..26, 28..29), the two-stage ring (27), image patches (30): 64x64 plans
+    if (ctx->gemm_variant_override >= 24 && ctx->gemm_variant_override < 32) return 3; // small-M streaming (31: calls that are not its shape), wave-tile kernels (24..26, 28..29), the two-stage ring (27), image patches (30): 64x64 plans
     if (ctx->gemm_variant_override >= 0 && ctx->gemm_variant_override < 24) return ctx->gemm_variant_override & 3;
     int best = 3;
     double best_cost = 1e300;
@@ -2664,7 +2828,8 @@ constexpr long long kMaxBufBytes = 0x7fffffffll; // buffer offsets are 32-bit; t
 // Variants 24..26: one wave per 64x64 tile (gemm_f32_wave.hip), k-tiles x LDS stages = 16 x 2, 8 x 4, 16 x 3; 27: 64x64 LDS-DMA with TWO stages;
 // 28..29: one wave per 32x32 tile (barrier-free form of the 64x64 / 4-wave granularity; dense B), 16 x 2 and 16 x 3;
 // 30: 3x3 / stride 1 / padding 1 convolutions with B staged as image patches (gemm_f32_patch.hip); every other launch runs as variant 3.
-RTEN_EXPORT int32_t rten_hip_num_gemm_variants(void) { return 31; }
+// 31: small-M weight streaming (rten_hip_gemm_f32 with one batch and M <= 64: gemm_f32_smallm_kernel; also what -1 = automatic picks there); every other launch runs as variant 3.
+RTEN_EXPORT int32_t rten_hip_num_gemm_variants(void) { return 32; }
 
 RTEN_EXPORT int32_t rten_hip_set_gemm_variant_override(rten_hip_ctx *ctx, int32_t variant) {
     RTEN_CHECK_CTX(ctx);
@@ -2719,6 +2884,35 @@ RTEN_EXPORT int32_t rten_hip_set_gemv_order(rten_hip_ctx *ctx, int32_t on, int32
 }
 
 namespace {
+// Small-M weight streaming (gemm_f32_smallm_kernel): one batch, M <= 64.  Returns RTEN_HIP_ERR_UNSUPPORTED when the call is not its shape.
+int32_t launch_smallm(rten_hip_ctx *ctx, GemmArgs &a, const rten_hip_gemm_desc *d, const float *ap, const float *bp) {
+    if (d->batch != 1 || d->m > 64 || d->k <= 0) return RTEN_HIP_ERR_UNSUPPORTED;
+    const int MT = d->m <= 16 ? 1 : d->m <= 32 ? 2 : 4, RB = 16 * (4 / MT);
+    const long long gx = (d->n + RB - 1) / RB, nblk = (d->k + 255) / 256;
+    if (gx > 0x7fffffff || nblk > 65535) return RTEN_HIP_ERR_UNSUPPORTED;
+    if (nblk > 1) {
+        if (!ctx->split_counters || gx * 4 > rten_hip_ctx::kSplitCounters) return RTEN_HIP_ERR_UNSUPPORTED;
+        char *sc = (char *)rten_scratch(ctx, 4096 + (size_t)gx * (size_t)nblk * 4096);
+        if (!sc) return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "split-K slab allocation failed (or attempted during graph capture)");
+        a.slab = (float *)(sc + 4096);
+        a.split_counters = ctx->split_counters;
+    }
+    const bool k4 = d->k % 4 == 0;
+    // loader forms (16-byte loads): bit 0 / 1 = A / B depth-contiguous; bit 2 / 3 = A rows / B columns contiguous
+    a.tiles_m = ((d->a_cs == 1 && d->a_rs % 4 == 0 && k4 && aligned16(ap)) ? 1 : 0) | ((d->b_rs == 1 && d->b_cs % 4 == 0 && k4 && aligned16(bp)) ? 2 : 0);
+    if (!(a.tiles_m & 1) && d->a_rs == 1 && d->a_cs % 4 == 0 && d->m % 4 == 0 && aligned16(ap)) a.tiles_m |= 4;
+    if (!(a.tiles_m & 2) && d->b_cs == 1 && d->b_rs % 4 == 0 && d->n % 4 == 0 && aligned16(bp)) a.tiles_m |= 8;
+    char kname[64];
+    snprintf(kname, sizeof kname, "gemm_f32_smallm_kernel<%d>", MT);
+    ProfScope ps(ctx, kname, 2.0 * d->m * (double)d->n * d->k, 4.0 * ((double)d->m * d->k + (double)d->k * d->n + (double)d->m * d->n));
+    const dim3 grid((unsigned)gx, (unsigned)nblk);
+    if (MT == 1) hipLaunchKernelGGL((gemm_f32_smallm_kernel<1>), grid, dim3(256), 0, ctx->stream, a);
+    else if (MT == 2) hipLaunchKernelGGL((gemm_f32_smallm_kernel<2>), grid, dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((gemm_f32_smallm_kernel<4>), grid, dim3(256), 0, ctx->stream, a);
+    RTEN_LAUNCH_CHECK(ctx, "gemm_f32_smallm_kernel launch");
+    return RTEN_HIP_OK;
+}
+
 int32_t gemm_f32_entry(rten_hip_ctx *ctx, const rten_hip_gemm_desc *d, const float *a, const float *b, const float *bias, float *c, bool allow_gemv) {
     if (!d) return RTEN_HIP_ERR_INVALID_VALUE;
     if (d->m < 0 || d->n < 0 || d->k < 0 || d->batch < 0)
@@ -2750,6 +2944,12 @@ int32_t gemm_f32_entry(rten_hip_ctx *ctx, const rten_hip_gemm_desc *d, const flo
     if (ab > kMaxBufBytes || bb > kMaxBufBytes || extent_bytes(d->m, d->ldc, d->n, 1) > kMaxBufBytes)
         return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "gemm: operand slices above 2 GiB are not supported");
     g.a_bytes = (unsigned)ab; g.b_bytes = (unsigned)bb;
+
+    // few rows: stream B through every compute unit instead of a handful of 64-row tiles (variant 31; the automatic choice; RTEN_HIP_DEBUG bit 0x40000 = off)
+    if ((ctx->gemm_variant_override == 31 || (ctx->gemm_variant_override < 0 && !(ctx->debug & 0x40000))) && d->m <= 64 && d->batch == 1 && d->k > 0) {
+        const int32_t rc = launch_smallm(ctx, g, d, a, b);
+        if (rc != RTEN_HIP_ERR_UNSUPPORTED) return rc;
+    }
 
     int al = A_SCALAR, bl = B_SCALAR;
     if (d->k > 0) {

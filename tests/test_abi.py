@@ -30,7 +30,7 @@ def test_abi_version_and_variants():
     from rten_amd import lib
     so = lib.load()
     assert so.rten_hip_abi_version() == 4
-    assert so.rten_hip_num_gemm_variants() == 31
+    assert so.rten_hip_num_gemm_variants() == 32
 
 
 def test_struct_layouts_match_header():

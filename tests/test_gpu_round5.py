@@ -192,3 +192,59 @@ def test_scratch_a_live_graph_replays_from_is_not_freed(ctx):
             ctx.graph_destroy(g)
     finally:
         ctx.call("rten_hip_set_sdpa_path", 0)
+
+
+def _gemm(ctx, a, b, c=None, alpha=1.0, beta=0.0, bias=None, bias_kind=0, act=0, variant=-1):
+    """a [m, k], b [k, n]; an operand that is not C-contiguous is uploaded as its (contiguous) transpose and described by strides."""
+    m, k = a.shape
+    n = b.shape[1]
+    out = DeviceTensor.from_numpy(ctx, c if c is not None else np.full((m, n), np.nan, np.float32))
+    if a.flags.c_contiguous:
+        ad = DeviceTensor.from_numpy(ctx, a); a_rs, a_cs = k, 1
+    else:
+        ad = DeviceTensor.from_numpy(ctx, np.ascontiguousarray(a.T)); a_rs, a_cs = 1, m
+    if b.flags.c_contiguous:
+        bd = DeviceTensor.from_numpy(ctx, b); b_rs, b_cs = n, 1
+    else:
+        bd = DeviceTensor.from_numpy(ctx, np.ascontiguousarray(b.T)); b_rs, b_cs = 1, k
+    biasd = DeviceTensor.from_numpy(ctx, bias) if bias is not None else None
+    d = L.gemm_desc(m, n, k, a_rs, a_cs, b_rs, b_cs, n, alpha=alpha, beta=beta, bias_kind=bias_kind, act=act)
+    ctx.set_gemm_variant(variant)
+    try:
+        ctx.call("rten_hip_gemm_f32", C.byref(d), ad.vp, bd.vp, biasd.vp if biasd else None, out.vp)
+    finally:
+        ctx.set_gemm_variant(-1)
+    return out.numpy()
+
+
+@pytest.mark.parametrize("m", [2, 5, 16, 17, 32, 33, 48, 64])
+def test_small_m_streaming_gemm_is_the_blocked_chain(ctx, m):
+    """gemm_f32_smallm_kernel (M <= 64, one batch; variant 31 and the automatic choice): one wave per 16x16 block per depth block, block sums parked and
+    folded by the last arrival in depth-block order -- the bits of rten-gemm's blocked chain (lib.rs:1008-1013, 1221-1255) for one / two / four row
+    blocks, ragged rows and columns, one depth block / a ragged last one / the classifier's eight, 16-byte and scalar loaders of either operand
+    (all four transposition combinations), alpha / beta / both bias kinds / fused activations."""
+    rng = ref.XorShiftRng(900 + m)
+    for k in (3, 64, 256, 258, 700, 2048):
+        for n in (1, 16, 33, 100, 1000):
+            if k * n > 300000 and (m not in (32, 33)):
+                continue
+            a = rng.f32(m * k).reshape(m, k) - 0.5
+            b = rng.f32(k * n).reshape(k, n) - 0.5
+            want = ref.gemm_f32(a, b)
+            at, bt = np.ascontiguousarray(a.T).T, np.ascontiguousarray(b.T).T
+            for aa, bb in ((a, b), (a, bt), (at, b), (at, bt)):
+                _bits(_gemm(ctx, aa, bb, variant=31), want)
+            _bits(_gemm(ctx, a, bt), want)  # what -1 picks
+    k, n = 700, 100
+    a = rng.f32(m * k).reshape(m, k) - 0.5
+    b = rng.f32(k * n).reshape(k, n) - 0.5
+    bt = np.ascontiguousarray(b.T).T
+    c = rng.f32(m * n).reshape(m, n)
+    br, bc = rng.f32(m), rng.f32(n)
+    for alpha, beta in ((1.0, 1.0), (0.5, 0.0), (0.5, 2.0)):
+        _bits(_gemm(ctx, a, bt, c=c, alpha=alpha, beta=beta, variant=31), ref.gemm_f32(a, b, c=c, alpha=alpha, beta=beta))
+    _bits(_gemm(ctx, a, bt, bias=br, bias_kind=L.BIAS_PER_ROW, variant=31), ref.gemm_f32(a, b, bias=br, bias_kind=ref.BIAS_PER_ROW))
+    _bits(_gemm(ctx, a, bt, bias=bc, bias_kind=L.BIAS_PER_COL, act=L.ACT_RELU, variant=31), ref.relu(ref.gemm_f32(a, b, bias=bc, bias_kind=ref.BIAS_PER_COL)))
+    _bits(_gemm(ctx, a, bt, c=c, alpha=0.5, beta=2.0, bias=bc, bias_kind=L.BIAS_PER_COL, act=L.ACT_GELU, variant=31),
+          ref.gelu(ref.gemm_f32(a, b, c=c, alpha=0.5, beta=2.0, bias=bc, bias_kind=ref.BIAS_PER_COL)))
+    assert not np.isnan(_gemm(ctx, a, bt, variant=31)).any()  # beta == 0 never reads C (the output starts as NaN)

@@ -176,6 +176,14 @@ def main():
         a, w, bias, out = dev(rng.standard_normal((m, k), dtype=np.float32)), dev(rng.standard_normal((k, n), dtype=np.float32)), dev(np.zeros(n, np.float32)), empty((m, n))
         d = L.gemm_desc(m, n, k, k, 1, n, 1, n, bias_kind=L.BIAS_PER_COL, act=act)
         mfma(name, f"{m}x{k}x{n}", (lambda: ctx.call("rten_hip_gemm_f32", C.byref(d), a.vp, w.vp, bias.vp, out.vp)), 2.0 * m * k * n, F32_PEAK_TF, "TFLOP/s")
+    # ---- few rows against a big weight matrix (ResNet-50's classifier, Gemm transB = 1; an LLM-decoder projection at 16 rows): bound by streaming B
+    for (m, k, n, trans_b, name) in ((32, 2048, 1000, True, "Gemm classifier"), (16, 4096, 4096, False, "MatMul 16 rows")):
+        a, w, bias, out = dev(rng.standard_normal((m, k), dtype=np.float32)), dev(rng.standard_normal((n, k) if trans_b else (k, n), dtype=np.float32)), dev(np.zeros(n, np.float32)), empty((m, n))
+        d = L.gemm_desc(m, n, k, k, 1, 1 if trans_b else n, k if trans_b else 1, n, bias_kind=L.BIAS_PER_COL)
+        hbm(name, f"{m}x{k}x{n}", (lambda: ctx.call("rten_hip_gemm_f32", C.byref(d), a.vp, w.vp, bias.vp, out.vp)), 4.0 * (m * k + k * n + m * n + n))
+        ctx.set_gemm_variant(3)
+        hbm(name + " (64x64 tiles, round 4)", f"{m}x{k}x{n}", (lambda: ctx.call("rten_hip_gemm_f32", C.byref(d), a.vp, w.vp, bias.vp, out.vp)), 4.0 * (m * k + k * n + m * n + n))
+        ctx.set_gemm_variant(-1)
     # attention core, 12 heads x 64 on [B, S, H*D] projections (strided heads)
     B, S, H, D = 32, 128, 12, 64
     q, kk, v, o = (dev(rng.standard_normal((B, S, H * D), dtype=np.float32)) for _ in range(4))
