@@ -234,6 +234,175 @@ __global__ __launch_bounds__(256, 2) void sdpa_fused_kernel(const SdpaArgs p) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// 16-query form of the kernel above for its FULL shape (head 64, 128 keys, s a multiple of 64; no mask or a [B, 1, 1, T] mask): round 5.
+// Why: the 32-query waves of the kernel above are 1.5 per SIMD at BERT-base's batch 32 (384 workgroups x 4 waves on 1024 SIMDs: half of the SIMDs
+// run two, the other half one) -- a quarter of the matrix pipe's time is lost to that imbalance.  Here a wave owns 16 queries
+// (v_mfma_f32_16x16x4_f32: a k-ordered fmaf chain like the 32x32x2 form, tools/probes/mfma_16x16x4_order.hip), a workgroup 64: 768 workgroups,
+// three waves on every SIMD, 48.5 KB of LDS each (three per compute unit, so one's softmax runs under another's MFMAs).
+// Same operation sequence per output element as above (scores = d-ordered chain, * scale, + mask; max from f32::MIN; ReducedRangeExp; the 16
+// ordered partial sums and their left-to-right fold; e * (1 / sum); PV = key-ordered chain) -- same bits.
+// Layouts.  Scores are computed transposed, S^T = K Q^T, block j = 16 keys x 16 queries, with the block's key ROWS PERMUTED: MFMA row m = 4 q + r
+// carries key 16 j + 4 r + q.  The accumulator register r of lane (query = lane % 16, q = lane / 16) is MFMA row 4 q + r, i.e. key
+// 16 j + 4 r + q = 4 (4 j + r) + q: exactly the B operand (k index = q) of PV step 4 j + r when PV is computed transposed too,
+// out^T = V^T P^T.  The probabilities never move between lanes.  The reference's partial l = key % 16 = 4 r + q sits in register r of quad q
+// (summed over j in-lane, ascending); the left-to-right fold of the 16 partials walks quad 0 -> 1 -> 2 -> 3 four times (15 lane hops).
+// LDS: K and Q rows as 64 floats with depth d = 16 a + 4 i + g stored at 16 a + 4 g + i, 16-byte groups XOR-swizzled by the row (one conflict-free
+// ds_read_b128 = the operands of four MFMA steps); V as [key][64] with the 16-float groups XOR-swizzled by key % 4.
+// out^T's accumulator holds 4 consecutive dv of one query per lane: 16-byte stores.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int SQ16 = 64;
+__device__ __forceinline__ int sd_at(int row, int pos) { return row * HD + (pos ^ ((row & 15) << 2)); }
+
+// ABL: the ablation instantiation (p.debug bits, WRONG results, timing only: 1 no mask add, 2 no exp, 4 no PV MFMAs, 8 no QK^T MFMAs, 16 no global loads, 32 no stores,
+// 64 no softmax arithmetic at all, 128 no LDS staging writes)
+template <bool MASK, bool FLUSH, int ABL = 0> // (ABL is a compile-time constant: run-time switches changed the register allocation of every variant -- first attempt, 290 us)
+__global__ __launch_bounds__(256, 3) void sdpa_fused16_kernel(const SdpaArgs p) {
+    constexpr int dbg = ABL;
+    __shared__ __attribute__((aligned(16))) float smem[SQ16 * HD + TT * HD + TT]; // Qs | Ks (phase 1) -> Vs (phase 3) | mask row
+    float *const Qs = smem, *const Ks = smem + SQ16 * HD, *const Vs = Ks, *const Ms = smem + SQ16 * HD + TT * HD;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l15 = lane & 15, quad = lane >> 4;
+    const int st = blockIdx.x % p.s_tiles, bh = blockIdx.x / p.s_tiles;
+    const int b = bh / p.heads, h = bh - b * p.heads;
+    const int s0 = st * SQ16;
+    const float *qb = p.q + (long long)b * p.q_bs + (long long)h * p.q_hs;
+    const float *kb = p.k + (long long)b * p.k_bs + (long long)h * p.k_hs;
+    const float *vb = p.v + (long long)b * p.v_bs + (long long)h * p.v_hs;
+    float *ob = p.out + (long long)b * p.o_bs + (long long)h * p.o_hs;
+
+    // ---- stage Q and K (depth-permuted rows); V is fetched now and parked in registers until K is dead
+    f32x4 qreg[SQ16 * 16 / 256], kreg[TT * 16 / 256], vreg[TT * 16 / 256];
+#pragma unroll
+    for (int i = 0; i < SQ16 * 16 / 256; i++) {
+        const int f = i * 256 + t, row = f >> 4, dq = f & 15;
+        qreg[i] = (dbg & 16) ? f32x4{0.5f, 0.25f, 0.125f, 1.f} : *reinterpret_cast<const f32x4 *>(qb + (long long)(s0 + row) * p.q_rs + dq * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < TT * 16 / 256; i++) {
+        const int f = i * 256 + t, row = f >> 4, dq = f & 15;
+        kreg[i] = (dbg & 16) ? f32x4{0.5f, 0.25f, 0.125f, 1.f} : *reinterpret_cast<const f32x4 *>(kb + (long long)row * p.k_rs + dq * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < TT * 16 / 256; i++) {
+        const int f = i * 256 + t, row = f >> 4, dq = f & 15;
+        vreg[i] = (dbg & 16) ? f32x4{0.5f, 0.25f, 0.125f, 1.f} : *reinterpret_cast<const f32x4 *>(vb + (long long)row * p.v_rs + dq * 4);
+    }
+    if constexpr (MASK) {
+        if (t < TT) Ms[t] = p.mask[(long long)b * p.mask_bs + t];
+    }
+    // depth d = 4 dq + c is MFMA step dq, k index c: position 16 (dq / 4) + 4 c + dq % 4
+    if (!(dbg & 128)) {
+#pragma unroll
+    for (int i = 0; i < SQ16 * 16 / 256; i++) {
+        const int f = i * 256 + t, row = f >> 4, dq = f & 15, pos = 16 * (dq >> 2) + (dq & 3);
+        Qs[sd_at(row, pos)] = qreg[i][0]; Qs[sd_at(row, pos + 4)] = qreg[i][1]; Qs[sd_at(row, pos + 8)] = qreg[i][2]; Qs[sd_at(row, pos + 12)] = qreg[i][3];
+    }
+#pragma unroll
+    for (int i = 0; i < TT * 16 / 256; i++) {
+        const int f = i * 256 + t, row = f >> 4, dq = f & 15, pos = 16 * (dq >> 2) + (dq & 3);
+        Ks[sd_at(row, pos)] = kreg[i][0]; Ks[sd_at(row, pos + 4)] = kreg[i][1]; Ks[sd_at(row, pos + 8)] = kreg[i][2]; Ks[sd_at(row, pos + 12)] = kreg[i][3];
+    }
+    }
+    __syncthreads();
+
+    // ---- phase 1: S^T blocks j = 0..7 (16 keys x this wave's 16 queries), d ascending: 16 MFMA steps per block, the 8 blocks interleaved
+    f32x4 sc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) sc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+        const int krow = 4 * (l15 & 3) + (l15 >> 2); // MFMA row l15 = 4 q' + r' of block j carries key 16 j + 4 r' + q'
+        const int qrow = wave * 16 + l15;
+#pragma unroll
+        for (int a4 = 0; a4 < 4; a4++) { // MFMA steps 4 a4 .. 4 a4 + 3
+            const f32x4 qf = *reinterpret_cast<const f32x4 *>(Qs + sd_at(qrow, 16 * a4 + 4 * quad));
+            f32x4 kf[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) kf[j] = *reinterpret_cast<const f32x4 *>(Ks + sd_at(16 * j + krow, 16 * a4 + 4 * quad));
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    if (dbg & 8) sc[j][i] += kf[j][i] + qf[i];
+                    else sc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[j][i], qf[i], sc[j], 0, 0, 0);
+                }
+        }
+    }
+    __syncthreads(); // Ks is free: park V there, [key][64] with the 16-float groups swizzled by key % 4
+#pragma unroll
+    for (int i = 0; i < TT * 16 / 256; i++) {
+        const int f = i * 256 + t, row = f >> 4, dq = f & 15;
+        if (!(dbg & 128)) *reinterpret_cast<f32x4 *>(Vs + row * HD + ((dq * 4) ^ ((row & 3) << 4))) = vreg[i];
+    }
+
+    // ---- phase 2: softmax of query s0 + 16 wave + l15, spread over the four lanes l15 + 16 q; sc[j][r] is key 16 j + 4 r + quad
+    if (!(dbg & 64)) {
+    float mx = -3.40282347e+38f; // f32::MIN (softmax.rs:181)
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float v = sc[j][r] * p.scale;                                  // the GEMM's `t * alpha` store form
+            if constexpr (MASK) { if (!(dbg & 1)) v = v + Ms[16 * j + 4 * r + quad]; } // `*qk += m`
+            sc[j][r] = v;
+            mx = fmaxf(mx, v);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float part[4] = {0.f, 0.f, 0.f, 0.f}; // partial 4 r + quad of the reference's 16-lane order: keys 4 r + quad, + 16, + 32, ... ascending
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            sc[j][r] = (dbg & 2) ? sc[j][r] - mx : vm::exp_reduced(sc[j][r] - mx);
+            part[r] = part[r] + sc[j][r];
+        }
+    // fold partials 0..15 left to right (partial 4 r + q lives in quad q)
+    float pq[4][4]; // pq[q][r] = partial 4 r + q: every lane fetches the twelve it does not hold (independent lane reads), then folds all sixteen itself
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) pq[q][r] = __shfl(part[r], 16 * q + l15, 64);
+    float ssum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) ssum = ssum + pq[q][r];
+    const float inv = 1.0f / ssum;
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float pr = sc[j][r] * inv;
+            if (FLUSH && !(pr == pr)) pr = 0.f;
+            sc[j][r] = pr;
+        }
+    }
+    __syncthreads(); // V is in LDS
+
+    // ---- phase 3: out^T[dv][s] = sum over keys (ascending) of V^T[dv][key] P^T[key][s]: step = 4 j + r takes keys 4 step + {0..3}, P^T's operand is sc[j][r] as it stands
+    f32x4 oc[4];
+#pragma unroll
+    for (int jn = 0; jn < 4; jn++) oc[jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int key = 4 * (4 * j + r) + quad; // (key % 4 == quad: the swizzle term is per lane, constant)
+            const float *vr = Vs + key * HD;
+#pragma unroll
+            for (int jn = 0; jn < 4; jn++) {
+                if (dbg & 4) oc[jn][r] += vr[(16 * jn + l15) ^ (quad << 4)] + sc[j][r];
+                else oc[jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[(16 * jn + l15) ^ (quad << 4)], sc[j][r], oc[jn], 0, 0, 0);
+            }
+        }
+    // accumulator register r' of block jn: dv = 16 jn + 4 quad + r', query l15 -> four consecutive floats of one output row
+    float *orow = ob + (long long)(s0 + wave * 16 + l15) * p.o_rs + 4 * quad;
+#pragma unroll
+    for (int jn = 0; jn < 4; jn++)
+        if (!((dbg & 32) && oc[jn][0] != 12345.f)) *reinterpret_cast<f32x4 *>(orow + 16 * jn) = oc[jn];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // General form: head size HD in {32, 64, 128}, up to 128 * NCH <= 512 keys.  Same mapping and the same operation sequence per output
 // element as the kernel above (sdpa_head, src/ops/attention.rs:518-562: scores = gemm(alpha = scale), += mask, softmax with the
 // reference's ordered partial sums, out = gemm), with the key axis walked in chunks of 128 through ONE LDS buffer: K chunk c feeds
@@ -460,7 +629,27 @@ int32_t rten_sdpa_fused(rten_hip_ctx *ctx, const rten_hip_sdpa_desc *d, const fl
     const long long wgs = (long long)d->batch * d->heads * a.s_tiles;
     const double flops = 2.0 * d->batch * d->heads * (double)d->s * d->t * (d->d + d->dv);
     const double bytes = 4.0 * d->batch * d->heads * ((double)d->s * (d->d + d->dv) + (double)d->t * (d->d + d->dv));
-    if (fast) {
+    // 16-query waves (sdpa_fused16_kernel): the FULL shape with no mask or a [B, 1, 1, T] mask, 16-byte aligned output rows (RTEN_HIP_DEBUG bit 0x200000: the 32-query form, A/B)
+    const bool k16 = fast && d->t == TT && d->s % SQ16 == 0 && (!mask || d->mask_row_stride == 0) && !(ctx->debug & 0xa00000) &&
+                     d->o_bs % 4 == 0 && d->o_hs % 4 == 0 && d->o_rs % 4 == 0 && al16(out);
+    if (k16) {
+        ProfScope ps(ctx, "sdpa_fused16_kernel", flops, bytes);
+        a.s_tiles = d->s / SQ16;
+        const dim3 grid((unsigned)((long long)d->batch * d->heads * a.s_tiles)), block(256);
+        const bool flush = d->flush_nan_to_zero != 0;
+        a.debug = (int)((unsigned)ctx->debug >> 24);
+        if (a.debug) { // the ablation ladder of tools/probe_sdpa.py (timing only)
+#define RTEN_SDPA16_ABL(V) case V: if (mask) hipLaunchKernelGGL((sdpa_fused16_kernel<true, false, V>), grid, block, 0, ctx->stream, a); else hipLaunchKernelGGL((sdpa_fused16_kernel<false, false, V>), grid, block, 0, ctx->stream, a); break;
+            switch (a.debug & 255) {
+                RTEN_SDPA16_ABL(1) RTEN_SDPA16_ABL(2) RTEN_SDPA16_ABL(4) RTEN_SDPA16_ABL(8) RTEN_SDPA16_ABL(12) RTEN_SDPA16_ABL(16) RTEN_SDPA16_ABL(32) RTEN_SDPA16_ABL(48)
+                RTEN_SDPA16_ABL(64) RTEN_SDPA16_ABL(128) RTEN_SDPA16_ABL(176) RTEN_SDPA16_ABL(240) RTEN_SDPA16_ABL(76) RTEN_SDPA16_ABL(255)
+            default: if (mask) hipLaunchKernelGGL((sdpa_fused16_kernel<true, false, 0>), grid, block, 0, ctx->stream, a); else hipLaunchKernelGGL((sdpa_fused16_kernel<false, false, 0>), grid, block, 0, ctx->stream, a);
+            }
+#undef RTEN_SDPA16_ABL
+        }
+        else if (mask) { if (flush) hipLaunchKernelGGL((sdpa_fused16_kernel<true, true>), grid, block, 0, ctx->stream, a); else hipLaunchKernelGGL((sdpa_fused16_kernel<true, false>), grid, block, 0, ctx->stream, a); }
+        else { if (flush) hipLaunchKernelGGL((sdpa_fused16_kernel<false, true>), grid, block, 0, ctx->stream, a); else hipLaunchKernelGGL((sdpa_fused16_kernel<false, false>), grid, block, 0, ctx->stream, a); }
+    } else if (fast) {
         ProfScope ps(ctx, "sdpa_fused_kernel", flops, bytes);
         // the additive mask of a [B, 1, 1, T] attention mask (row stride 0, at least T values per batch item): one LDS copy per workgroup
         const bool mlds = mask && d->mask_row_stride == 0 && !(ctx->debug & 0x400000);

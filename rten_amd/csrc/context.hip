@@ -130,7 +130,7 @@ RTEN_EXPORT int32_t rten_hip_init(int32_t device_id, void *external_stream, rten
     rten_hip_ctx *ctx = new rten_hip_ctx();
     ctx->device = device_id;
     ctx->num_cus = prop.multiProcessorCount;
-    if (const char *dbg = getenv("RTEN_HIP_DEBUG")) ctx->debug = atoi(dbg);
+    if (const char *dbg = getenv("RTEN_HIP_DEBUG")) ctx->debug = (int)strtoul(dbg, nullptr, 0); // (all 32 bits; decimal or 0x...)
     if (external_stream) {
         ctx->stream = (hipStream_t)external_stream;
     } else {

@@ -2336,11 +2336,14 @@ __global__ void im2col_lut_kernel(i32x2 *lut, int K, int Kpad, int KHW, int KW, 
 // a 16x16 block to arrive folds them in depth-block order (first block: beta * C + bias; later blocks: separate adds;
 // rten-gemm/src/lib.rs:1008-1013,1221-1255) -- same bits as the unsplit chain, same visibility protocol as split_finish.
 //
-// LDS image of an operand row (an A row or a B column; 256 depths): SM_LD = 260 floats, depth k = 16 j + 4 i + g stored at 16 j + 4 g + i:
-// lane (row = lane % 16, g = lane / 16) reads the operands of its MFMAs 4 j .. 4 j + 3 with ONE ds_read_b128 (banks 4 * row + 16 j + 4 g + {0..3}:
-// conflict free), and a loader lane holding depths 16 j + 4 q + {0..3} of a row writes four words at 16 j + 4 c + q (banks 4 * row + q + ...: conflict free).
+// LDS image of an operand row (an A row or a B column; 256 depths = 1 KB): depth k = 16 j + 4 i + g stored at 16 j + 4 g + i, the 16-byte groups of a
+// row XOR-swizzled by the row (sm_at): lane (row = lane % 16, g = lane / 16) reads the operands of its MFMAs 4 j .. 4 j + 3 with ONE conflict-free
+// ds_read_b128, a loader lane holding depths 16 j + 4 q + {0..3} of a row writes four words (conflict free), and 64 or 80 rows are 64 / 80 KB:
+// TWO workgroups per compute unit, so one's operand fetch runs under the other's MFMA chain.
 // =====================================================================================================
-constexpr int SM_LD = 260;
+constexpr int SM_LD = 256;
+// float index of (operand row, position in the row's image): 16-byte groups XOR-swizzled by the row so that 16 rows at one position fall on 16 different bank groups
+__device__ __forceinline__ int sm_at(int row, int pos) { return row * SM_LD + (pos ^ ((row & 15) << 2)); }
 
 template <int MT>
 __global__ __launch_bounds__(256) void gemm_f32_smallm_kernel(const GemmArgs p) {
@@ -2372,8 +2375,8 @@ __global__ __launch_bounds__(256) void gemm_f32_smallm_kernel(const GemmArgs p) 
 #pragma unroll
         for (int u = 0; u < MT * 4; u++) {
             const int f = u * 256 + t, q = f & 3, r = (f >> 2) & 15, j = (f >> 6) & 15, rg = f >> 10;
-            float *dst = As + (rg * 16 + r) * SM_LD + 16 * j + q;
-            dst[0] = v[u][0]; dst[4] = v[u][1]; dst[8] = v[u][2]; dst[12] = v[u][3];
+            const int row = rg * 16 + r;
+            As[sm_at(row, 16 * j + q)] = v[u][0]; As[sm_at(row, 16 * j + 4 + q)] = v[u][1]; As[sm_at(row, 16 * j + 8 + q)] = v[u][2]; As[sm_at(row, 16 * j + 12 + q)] = v[u][3];
         }
     } else if (p.tiles_m & 4) { // A given transposed ([K][M], 16-byte groups of rows): a wave covers 16 depths x 16 rows per load
         f32x4 v[MT * 4];
@@ -2385,8 +2388,8 @@ __global__ __launch_bounds__(256) void gemm_f32_smallm_kernel(const GemmArgs p) 
 #pragma unroll
         for (int u = 0; u < MT * 4; u++) {
             const int f = u * 256 + t, c4 = f & 3, k = 16 * ((f >> 6) & 15) + ((f >> 2) & 15), row = 16 * (f >> 10) + 4 * c4;
-            float *dst = As + row * SM_LD + (k & ~15) + 4 * (k & 3) + ((k >> 2) & 3); // banks 16 c4 + 4 c + {0..15}: conflict free
-            dst[0] = v[u][0]; dst[SM_LD] = v[u][1]; dst[2 * SM_LD] = v[u][2]; dst[3 * SM_LD] = v[u][3];
+            const int pos = (k & ~15) + 4 * (k & 3) + ((k >> 2) & 3);
+            As[sm_at(row, pos)] = v[u][0]; As[sm_at(row + 1, pos)] = v[u][1]; As[sm_at(row + 2, pos)] = v[u][2]; As[sm_at(row + 3, pos)] = v[u][3];
         }
     } else {
         const bool along_m = p.a_dir_m; // rows are the contiguous direction (A given transposed): lanes walk rows
@@ -2395,7 +2398,7 @@ __global__ __launch_bounds__(256) void gemm_f32_smallm_kernel(const GemmArgs p) 
             const int idx = u * 256 + t;
             const int row = along_m ? idx % RA : idx >> 8, k = along_m ? idx / RA : idx & 255;
             const float x = buf_load1(rsA, (row < p.M && k < depth) ? (unsigned)(((long long)row * p.a_rs + (long long)(k0 + k) * p.a_cs) << 2) : OOB, 0);
-            As[row * SM_LD + (k & ~15) + 4 * (k & 3) + ((k >> 2) & 3)] = x;
+            As[sm_at(row, (k & ~15) + 4 * (k & 3) + ((k >> 2) & 3))] = x;
         }
     }
     if (b_vec) {
@@ -2409,8 +2412,8 @@ __global__ __launch_bounds__(256) void gemm_f32_smallm_kernel(const GemmArgs p) 
 #pragma unroll
         for (int u = 0; u < NW * 4; u++) {
             const int f = u * 256 + t, q = f & 3, r = (f >> 2) & 15, j = (f >> 6) & 15, rg = f >> 10;
-            float *dst = Bs + (rg * 16 + r) * SM_LD + 16 * j + q;
-            dst[0] = v[u][0]; dst[4] = v[u][1]; dst[8] = v[u][2]; dst[12] = v[u][3];
+            const int row = rg * 16 + r;
+            Bs[sm_at(row, 16 * j + q)] = v[u][0]; Bs[sm_at(row, 16 * j + 4 + q)] = v[u][1]; Bs[sm_at(row, 16 * j + 8 + q)] = v[u][2]; Bs[sm_at(row, 16 * j + 12 + q)] = v[u][3];
         }
     } else if (p.tiles_m & 8) { // B as [K][N] (16-byte groups of columns): a wave covers 16 depths x 16 columns per load
         f32x4 v[NW * 4];
@@ -2422,8 +2425,8 @@ __global__ __launch_bounds__(256) void gemm_f32_smallm_kernel(const GemmArgs p) 
 #pragma unroll
         for (int u = 0; u < NW * 4; u++) {
             const int f = u * 256 + t, c4 = f & 3, k = 16 * ((f >> 6) & 15) + ((f >> 2) & 15), c = 16 * (f >> 10) + 4 * c4;
-            float *dst = Bs + c * SM_LD + (k & ~15) + 4 * (k & 3) + ((k >> 2) & 3);
-            dst[0] = v[u][0]; dst[SM_LD] = v[u][1]; dst[2 * SM_LD] = v[u][2]; dst[3 * SM_LD] = v[u][3];
+            const int pos = (k & ~15) + 4 * (k & 3) + ((k >> 2) & 3);
+            Bs[sm_at(c, pos)] = v[u][0]; Bs[sm_at(c + 1, pos)] = v[u][1]; Bs[sm_at(c + 2, pos)] = v[u][2]; Bs[sm_at(c + 3, pos)] = v[u][3];
         }
     } else {
         const bool along_n = p.b_dir_n; // columns are the contiguous direction (B as [K][N]): lanes walk columns
@@ -2433,17 +2436,19 @@ __global__ __launch_bounds__(256) void gemm_f32_smallm_kernel(const GemmArgs p) 
             const int c = along_n ? idx % RB : idx >> 8, k = along_n ? idx / RB : idx & 255;
             const int col = n0 + c;
             const float x = buf_load1(rsB, (col < p.N && k < depth) ? (unsigned)(((long long)(k0 + k) * p.b_rs + (long long)col * p.b_cs) << 2) : OOB, 0);
-            Bs[c * SM_LD + (k & ~15) + 4 * (k & 3) + ((k >> 2) & 3)] = x;
+            Bs[sm_at(c, (k & ~15) + 4 * (k & 3) + ((k >> 2) & 3))] = x;
         }
     }
     __syncthreads();
 
     // ---- one 16x16 block of C, one depth block: the MFMA chain
     const int mt = wave % MT, nw = wave / MT;
-    const float *ar = As + (mt * 16 + l15) * SM_LD + 4 * quad, *br = Bs + (nw * 16 + l15) * SM_LD + 4 * quad;
     f32x4 af[16], bf[16];
 #pragma unroll
-    for (int j = 0; j < 16; j++) { af[j] = *(const f32x4 *)(ar + 16 * j); bf[j] = *(const f32x4 *)(br + 16 * j); }
+    for (int j = 0; j < 16; j++) {
+        af[j] = *(const f32x4 *)(As + sm_at(mt * 16 + l15, 16 * j + 4 * quad));
+        bf[j] = *(const f32x4 *)(Bs + sm_at(nw * 16 + l15, 16 * j + 4 * quad));
+    }
     f32x4v acc[1][1];
     acc[0][0] = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll

@@ -376,6 +376,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
     const int l31 = lane & 31, half = lane >> 5;
 #ifdef RTEN_TRACE // build.sh -DRTEN_TRACE: cycle stamps at the phase boundaries, printed by one wave (tools/debug/i8_trace.py)
     unsigned long long tr_seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_prev = __builtin_readcyclecounter();
+    const unsigned long long tr_c0 = tr_prev, tr_r0 = __builtin_amdgcn_s_memrealtime(); // (100 MHz: cycles per tick x 100 = the shader clock in MHz during this workgroup)
 #define I8_STAMP(i) { const unsigned long long now_ = __builtin_readcyclecounter(); tr_seg[i] += now_ - tr_prev; tr_prev = now_; }
 #else
 #define I8_STAMP(i)
@@ -999,9 +1000,10 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
         I8_STAMP(7) // epilogue (zero-point algebra, scale, bias, residual, statistics, stores issued; QO: + the grid-wide exchange and the quantized stores)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long t_end_ = __builtin_readcyclecounter();
-        if (blockIdx.x == (gridDim.x > 8 ? 8 : 0) && t == 0)
-            printf("[i8 trace] <%d,%d,res=%d,kg=%d,bq=%d,qo=%d,rt=%d> M %d N %d Kp %d grid %u: args+decode %llu, table %llu, operands %llu, residual req %llu, first tiles %llu, k-loop %llu (%d trips), drain+rowc %llu, epilogue %llu, store drain %llu cycles\n",
-                   BM, BN, (int)RES, KG, (int)BQ, (int)QO, (int)RT, p.M, p.N, p.Kp, gridDim.x, tr_seg[0], tr_seg[1], tr_seg[2], tr_seg[3], tr_seg[4], tr_seg[5], nit, tr_seg[6], tr_seg[7], t_end_ - tr_prev);
+        if ((blockIdx.x == (gridDim.x > 8 ? 8 : 0) || (gridDim.x > 64 && blockIdx.x == gridDim.x - 9)) && t == 0) // (an early workgroup and a late one)
+            printf("[i8 trace] <%d,%d,res=%d,kg=%d,bq=%d,qo=%d,rt=%d> M %d N %d Kp %d grid %u: args+decode %llu, table %llu, operands %llu, residual req %llu, first tiles %llu, k-loop %llu (%d trips), drain+rowc %llu, epilogue %llu, store drain %llu cycles; %llu cycles in %llu ticks of 10 ns\n",
+                   BM, BN, (int)RES, KG, (int)BQ, (int)QO, (int)RT, p.M, p.N, p.Kp, gridDim.x, tr_seg[0], tr_seg[1], tr_seg[2], tr_seg[3], tr_seg[4], tr_seg[5], nit, tr_seg[6], tr_seg[7], t_end_ - tr_prev,
+                   t_end_ - tr_c0, (unsigned long long)__builtin_amdgcn_s_memrealtime() - tr_r0);
     }
 #endif
 #undef I8_STAMP

@@ -248,3 +248,40 @@ def test_small_m_streaming_gemm_is_the_blocked_chain(ctx, m):
     _bits(_gemm(ctx, a, bt, c=c, alpha=0.5, beta=2.0, bias=bc, bias_kind=L.BIAS_PER_COL, act=L.ACT_GELU, variant=31),
           ref.gelu(ref.gemm_f32(a, b, c=c, alpha=0.5, beta=2.0, bias=bc, bias_kind=ref.BIAS_PER_COL)))
     assert not np.isnan(_gemm(ctx, a, bt, variant=31)).any()  # beta == 0 never reads C (the output starts as NaN)
+
+
+@pytest.mark.parametrize("layout", ["bhsd", "bshd"])
+def test_sixteen_query_attention_kernel_bits(ctx, layout):
+    """sdpa_fused16_kernel (head 64, 128 keys, s a multiple of 64, no mask or a [B, 1, 1, T] mask): 16-query waves on v_mfma_f32_16x16x4_f32, key rows of a
+    score block permuted so that the probabilities feed PV^T from the registers they were computed in -- against the oracle's sdpa
+    (src/ops/attention.rs:518-626 order: d-ordered scores, * scale, + mask, 16-lane ordered softmax sums, key-ordered PV), for one to four
+    64-query tiles, both memory layouts (heads contiguous, and BERT's [B, S, H * 64] projections), -inf masks, a fully masked batch item with
+    and without the NaN flush."""
+    rng = ref.XorShiftRng(77)
+    T = 128
+    for (B, H, S) in ((1, 1, 64), (2, 3, 128), (1, 2, 192), (2, 12, 256)):
+        q = rng.f32(B * H * S * 64).reshape(B, H, S, 64) - 0.5
+        k = rng.f32(B * H * T * 64).reshape(B, H, T, 64) - 0.5
+        v = rng.f32(B * H * T * 64).reshape(B, H, T, 64) - 0.5
+        m1 = np.where(rng.f32(B * T).reshape(B, 1, 1, T) > 0.3, 0.0, -np.inf).astype(np.float32)
+        m1[0, 0, 0, :] = -np.inf
+        m0 = ((rng.f32(B * T).reshape(B, 1, 1, T) - 0.5) * 6).astype(np.float32)
+        for m in (None, m0, m1):
+            for flush in (True, False):
+                if layout == "bhsd":
+                    qd, kd, vd = (DeviceTensor.from_numpy(ctx, a) for a in (q, k, v))
+                    out = DeviceTensor(ctx, (B, H, S, 64), np.float32)
+                    strides = (H * S * 64, S * 64, 64, H * T * 64, T * 64, 64, H * T * 64, T * 64, 64, H * S * 64, S * 64, 64)
+                else:
+                    qd, kd, vd = (DeviceTensor.from_numpy(ctx, np.ascontiguousarray(a.transpose(0, 2, 1, 3))) for a in (q, k, v))
+                    out = DeviceTensor(ctx, (B, S, H, 64), np.float32)
+                    strides = (S * H * 64, 64, H * 64, T * H * 64, 64, H * 64, T * H * 64, 64, H * 64, S * H * 64, 64, H * 64)
+                d = L.SdpaDesc(B, H, S, T, 64, 64, *strides, 0 if m is None else T, 0, 0.125, 1 if flush else 0)
+                md = DeviceTensor.from_numpy(ctx, m) if m is not None else None
+                ctx.call("rten_hip_sdpa_f32", C.byref(d), qd.vp, kd.vp, vd.vp, md.vp if md is not None else None, out.vp)
+                got = out.numpy() if layout == "bhsd" else out.numpy().transpose(0, 2, 1, 3)
+                want = ref.sdpa(q, k, v, mask=m, scale=0.125, lanes=16, flush_nan=flush)
+                assert got.shape == want.shape
+                gi, wi = np.ascontiguousarray(got).view(np.int32), want.view(np.int32)
+                nan_both = np.isnan(got) & np.isnan(want)  # (NaN payloads are not part of the contract)
+                assert ((gi == wi) | nan_both).all(), (B, H, S, None if m is None else "mask", flush, int(((gi != wi) & ~nan_both).sum()))

@@ -49,12 +49,20 @@ def run(debug, reps=50):
 
 
 def main():
-    rows = [("product kernel (FULL-shape instantiation, mask row in LDS)", 0), ("general instantiation (per-lane row / key tests)", 0x800000),
-            ("general + mask fetched per lane (round-4 form)", 0xC00000),
-            ("ABL instantiation, no bit effective (64 = unused bit)", 64 << 24), ("- mask add", 1 << 24), ("- exp", 2 << 24), ("- mask - exp", 3 << 24),
-            ("- PV MFMAs", 4 << 24), ("- QK^T MFMAs", 8 << 24), ("- both MFMA phases", 12 << 24), ("- global loads", 16 << 24), ("- stores", 32 << 24),
-            ("- loads - stores", 48 << 24), ("- everything but the MFMAs (mask, exp, loads, stores)", 51 << 24), ("- everything", 63 << 24)]
-    print(f"# sdpa_fused_kernel, b={B} heads={NH} s=t={S} d={DH}: 384 workgroups of 256 threads on 256 compute units; {FL/1e9:.2f} GFLOP -> {FL/157.3e12*1e6:.1f} us at the f32 MFMA peak")
+    rows = [("product kernel (16-query waves, 768 workgroups: sdpa_fused16_kernel)", 0), ("32-query waves, FULL-shape instantiation, mask row in LDS", 0x200000),
+            ("32-query waves, general instantiation (per-lane row / key tests)", 0x800000), ("general + mask fetched per lane (round-4 form)", 0xC00000)]
+    # ablation of the 16-query kernel (its ABL instantiation; bits 24..31)
+    abl = [("ABL instantiation, no bit effective (256 = unused bit)", 256), ("- mask add", 1), ("- exp", 2), ("- PV MFMAs", 4), ("- QK^T MFMAs", 8), ("- both MFMA phases", 12),
+           ("- global loads", 16), ("- stores", 32), ("- loads - stores", 48), ("- softmax arithmetic (all of phase 2)", 64), ("- LDS staging writes", 128),
+           ("- loads - stores - staging writes", 176), ("- everything but the MFMAs", 240), ("- MFMAs - softmax (loads, staging, LDS reads, stores left)", 76),
+           ("- everything", 255)]
+    if "--old-ladder" in sys.argv:  # the 32-query kernel's ladder (profiles/r08/sdpa_ablation.txt)
+        rows += [(l, (b << 24) | 0x200000) for l, b in (("32q: ABL, no bit effective", 64), ("32q: - exp", 2), ("32q: - both MFMA phases", 12), ("32q: - loads - stores", 48), ("32q: - everything", 63))]
+    else:
+        rows += [(l, b << 24) for l, b in abl]
+    print(f"# fused attention, b={B} heads={NH} s=t={S} d={DH} (the 32-query form: 384 workgroups of 256 threads on 256 compute units; ablation rows are that form); {FL/1e9:.2f} GFLOP -> {FL/157.3e12*1e6:.1f} us at the f32 MFMA peak")
+    if "--quick" in sys.argv:
+        rows = rows[:3]
     for label, dbg in rows:
         r = run(dbg)
         print(f"{label:62s} mask {r['mask']:6.1f} us ({FL/r['mask']/1e6/157.3:.3f})   no mask {r['no mask']:6.1f} us ({FL/r['no mask']/1e6/157.3:.3f})", flush=True)
