@@ -103,6 +103,85 @@ __global__ __launch_bounds__(256) void depthwise3x3_y4_kernel(const rten_hip_con
     }
 }
 
+// 3 x 3 / stride 1 / dilation 1 with one padding column on either side (out_w == w, w a multiple of 4: MobileNet-style blocks) as a streaming kernel:
+// a thread owns FOUR adjacent output columns x FOUR output rows.  Its window columns 4k - 1 .. 4k + 4 are one aligned 16-byte load per input row plus
+// the last float of the LEFT neighbour's load and the first of the RIGHT neighbour's, which arrive by lane shifts (the four-outputs-per-thread form above:
+// 18 dword requests per four outputs, each input element requested ~3 x; here every byte of the plane is requested once per row group, and the store is
+// 16 bytes).  Each output replays the reference's sequence (accumulator = bias; per in-bounds tap in (k_y, k_x) order one rounded multiply and one add;
+// padding taps not visited: conv/depthwise.rs:95-146): same bits.
+__global__ __launch_bounds__(256) void depthwise3x3s1_stream_kernel(const rten_hip_conv2d_desc d, const float *__restrict__ x, const float *__restrict__ w, int w_stride,
+                                                                   const float *__restrict__ bias, const float *__restrict__ residual, int relu, float *__restrict__ y,
+                                                                   long long total) {
+    const int kq = d.w >> 2, rgs = (d.out_h + 3) >> 2;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool live = gid < total;
+    const long long g2 = live ? gid : total - 1;
+    const unsigned per_plane = (unsigned)(kq * rgs);
+    const long long plane = g2 / per_plane;
+    const unsigned rem = (unsigned)(g2 - plane * per_plane);
+    const int g = (int)(rem / (unsigned)kq), k = (int)(rem - (unsigned)g * (unsigned)kq);
+    const int c = (int)(plane % d.c);
+    const int oy0 = 4 * g, iy0 = oy0 - d.pads[0];
+    const float *in = x + plane * (long long)d.h * d.w + 4 * k;
+    const float *wc = w + (long long)c * 9 * w_stride;
+    float4 v[6];
+    float left[6], right[6], wv[9];
+    bool rok[6];
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        const int iy = iy0 + r;
+        rok[r] = (unsigned)iy < (unsigned)d.h;
+        v[r] = *reinterpret_cast<const float4 *>(in + (long long)(rok[r] ? iy : 0) * d.w);
+    }
+#pragma unroll
+    for (int t = 0; t < 9; t++) wv[t] = wc[t * w_stride];
+    const float b = bias ? bias[c] : 0.0f;
+    // columns 4k - 1 and 4k + 4: the neighbouring lanes hold k - 1 / k + 1 of the SAME row group unless this lane starts / ends a row (those are the padding
+    // columns, never read); the first / last lane of a wave has no such neighbour and fetches the element itself
+#pragma unroll
+    for (int r = 0; r < 6; r++) { left[r] = __shfl_up(v[r].w, 1, 64); right[r] = __shfl_down(v[r].x, 1, 64); }
+    const bool lok = k > 0, rgt = k < kq - 1;
+    if (lane == 0 && lok) {
+#pragma unroll
+        for (int r = 0; r < 6; r++) left[r] = in[(long long)(rok[r] ? iy0 + r : 0) * d.w - 1];
+    }
+    if (lane == 63 && rgt) {
+#pragma unroll
+        for (int r = 0; r < 6; r++) right[r] = in[(long long)(rok[r] ? iy0 + r : 0) * d.w + 4];
+    }
+    if (!live) return;
+    const long long o0 = plane * (long long)d.out_h * d.out_w + 4 * k;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (oy0 + j >= d.out_h) break;
+        float acc[4] = {b, b, b, b};
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++) {
+            const int r = j + ky;
+            if (!rok[r]) continue;
+            const float col[6] = {left[r], v[r].x, v[r].y, v[r].z, v[r].w, right[r]};
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const bool in_w = (i + kx > 0 || lok) && (i + kx < 5 || rgt); // window column 4k + i - 1 + kx
+                    if (in_w) acc[i] = __fadd_rn(acc[i], __fmul_rn(col[i + kx], wv[ky * 3 + kx]));
+                }
+        }
+        const long long oi = o0 + (long long)(oy0 + j) * d.out_w;
+        if (residual) {
+            const float4 rr = *reinterpret_cast<const float4 *>(residual + oi);
+            acc[0] = acc[0] + rr.x; acc[1] = acc[1] + rr.y; acc[2] = acc[2] + rr.z; acc[3] = acc[3] + rr.w;
+        }
+        if (relu) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[i] = vm::relu(acc[i]);
+        }
+        *reinterpret_cast<float4 *>(y + oi) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+
 } // namespace
 
 // Called by rten_hip_conv2d_f32 for groups == C == O geometries (weights OIHW [C,1,kh,kw], or the prepacked form whose
@@ -116,6 +195,16 @@ int32_t rten_depthwise_conv2d_f32(rten_hip_ctx *ctx, const rten_hip_conv2d_desc 
     const int ws = weights_packed ? 4 : 1, relu = (flags & RTEN_HIP_CONV_RELU) ? 1 : 0;
     const float *res = (flags & RTEN_HIP_CONV_RESIDUAL) ? residual : nullptr;
     ProfScope ps(ctx, "depthwise_conv2d_f32", 2.0 * planes * plane * d->kh * d->kw, 4.0 * (planes * (double)d->h * d->w + planes * (double)plane));
+    // the streaming form: 3 x 3, stride 1, dilation 1, one padding column on either side, rows of whole 16-byte groups (RTEN_HIP_DEBUG bit 0x100000: the round-4 kernel, A/B)
+    const bool stream = d->kh == 3 && d->kw == 3 && d->stride_h == 1 && d->stride_w == 1 && d->dil_h == 1 && d->dil_w == 1 && d->pads[1] == 1 && d->out_w == d->w &&
+                        d->w % 4 == 0 && d->out_h >= 1 && ((uintptr_t)x & 15u) == 0 && ((uintptr_t)y & 15u) == 0 && (!res || ((uintptr_t)res & 15u) == 0) &&
+                        !(ctx->debug & 0x100000);
+    if (stream) {
+        const long long threads = planes * (long long)(d->w / 4) * ((d->out_h + 3) / 4);
+        hipLaunchKernelGGL(depthwise3x3s1_stream_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, *d, x, w, ws, bias, res, relu, y, threads);
+        RTEN_LAUNCH_CHECK(ctx, "depthwise3x3s1_stream_kernel launch");
+        return RTEN_HIP_OK;
+    }
     const bool y4 = d->kh == 3 && d->kw == 3 && d->dil_h == 1 && d->dil_w == 1 && (d->stride_h == 1 || d->stride_h == 2) && d->out_h >= 4;
     if (y4) {
         const long long items = (long long)((d->out_h + 3) / 4) * d->out_w;

@@ -285,3 +285,23 @@ def test_sixteen_query_attention_kernel_bits(ctx, layout):
                 gi, wi = np.ascontiguousarray(got).view(np.int32), want.view(np.int32)
                 nan_both = np.isnan(got) & np.isnan(want)  # (NaN payloads are not part of the contract)
                 assert ((gi == wi) | nan_both).all(), (B, H, S, None if m is None else "mask", flush, int(((gi != wi) & ~nan_both).sum()))
+
+
+@pytest.mark.parametrize("shape,pt,pb", [((2, 3, 8, 8), 1, 1), ((1, 5, 9, 12), 0, 1), ((3, 2, 30, 20), 1, 0), ((1, 70, 14, 16), 1, 1), ((2, 144, 56, 56), 1, 1),
+                                          ((1, 1, 7, 4), 1, 1), ((5, 7, 23, 36), 0, 0), ((1, 2, 3, 260), 2, 2)])
+def test_streaming_depthwise_3x3_bits(ctx, shape, pt, pb):
+    """Geometries that take depthwise3x3s1_stream_kernel (3 x 3, stride 1, one padding column either side, W % 4 == 0): ragged row groups, any top / bottom
+    padding, one 16-byte group per row, planes that start mid-wave (the first / last lane of a wave fetches its own neighbour column), rows longer than a
+    wave, thread counts that do not fill the last workgroup; with / without bias, residual Add and Relu, prepacked and plain weights -- bit-identical to the
+    reference's depthwise sequence (conv/depthwise.rs:95-146: accumulator = bias, one rounded multiply and one add per in-bounds tap in (k_y, k_x) order)."""
+    from tests.test_gpu_parity import gpu_conv
+    n, c, h, w = shape
+    rng = np.random.default_rng(11 + h * w + c)
+    x = rng.random(shape, dtype=np.float32) - 0.5
+    wt = rng.random((c, 1, 3, 3), dtype=np.float32) - 0.5
+    pads = (pt, 1, pb, 1)
+    for bias, with_res, relu, prepack in ((None, False, False, False), (rng.random(c, dtype=np.float32) - 0.5, True, True, True), (rng.random(c, dtype=np.float32) - 0.5, False, True, False)):
+        want = ref.conv2d_f32(x, wt, bias, pads=pads, strides=(1, 1), dilations=(1, 1), groups=c)
+        res = (rng.random(want.shape, dtype=np.float32) - 0.5) if with_res else None
+        want = ref.conv2d_f32(x, wt, bias, pads=pads, strides=(1, 1), dilations=(1, 1), groups=c, residual=res, relu=relu)
+        _bits(gpu_conv(ctx, x, wt, bias, pads, (1, 1), (1, 1), c, residual=res, relu=relu, prepack=prepack), want)
