@@ -52,6 +52,151 @@ __global__ __launch_bounds__(256) void col2im_kernel(const rten_hip_conv2d_desc 
     y[((long long)n * d.o + o0 + ol) * plane + e] = acc;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Fused form (round 5): the column matrix never exists.  Conditions: no dilation, one stride s <= 2 for both axes, C_g a multiple of 4 and <= 256 (the
+// reference's GEMM is then ONE depth block per column element, rten-gemm/src/lib.rs:630-633), O_g <= 64, the row class's weights <= 64 KB.
+// An output element is bias, then for (k_y, k_x) ascending the column element that lands on it (col2im, conv_transpose.rs:80-142), and that column
+// element is a c-ordered fmaf chain from zero (gemm_uninit).  Here a WAVE owns one output row and 16 s consecutive columns of it, for all O_g channels:
+// for k_y (the row's stride class), k_x ascending it runs the chain of that tap -- v_mfma_f32_16x16x4_f32, rows = output channels, columns = 16 input
+// pixels i_x0 .. i_x0 + 15 of input row i_y, depth = c -- and adds it to the running outputs of the column class k_x belongs to (a separate add; pixels
+// whose i_x falls outside the row keep their value: "not visited").  Same operations per element in the same order as GEMM + col2im: same bits.
+// Workgroup = 4 waves of one (image, group, row class); the class's weights are staged once in LDS as [tap][c / 4][o][c % 4] (an MFMA A operand is then
+// 64 consecutive floats).  Traffic: input + output + weights instead of writing and re-reading O_g * kh * kw * H * W floats per image.
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef float ctf4 __attribute__((ext_vector_type(4)));
+extern __shared__ __attribute__((aligned(16))) float ct_smem[];
+
+template <int JT, int S, bool FULL> // JT 16-channel blocks of the group's outputs; S = stride (1 or 2); FULL: C_g a multiple of 64 (whole units: no per-step tests)
+__global__ __launch_bounds__(512) void conv_transpose_fused_kernel(const rten_hip_conv2d_desc d, const float *__restrict__ x, const float *__restrict__ w,
+                                                                  const float *__restrict__ bias, float *__restrict__ y, int og, int cg, int chunks, int tasks_per_wg) {
+    constexpr int OGP = 16 * JT, NW = 8; // waves per workgroup: two workgroups (2 x <= 64 KB of weights) keep 16 waves on a compute unit
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l15 = lane & 15, quad = lane >> 4;
+    // blockIdx.x = ((image * groups + group) * S + row class) * chunks + chunk
+    int bi = blockIdx.x;
+    const int chunk = bi % chunks; bi /= chunks;
+    const int cls = bi % S; bi /= S;
+    const int g = bi % d.groups, n = bi / d.groups;
+    const int khw = d.kh * d.kw, nsteps = cg >> 2;
+    // rows of this class: oy with (oy + pad_top) % S == cls; their taps: ky = cls, cls + S, ...
+    const int nky = (d.kh - cls + S - 1) / S; // (cls < kh is checked by the launcher)
+    // ---- stage the class's weights: kernel [C, O_g, kh, kw] -> Ws[(kyi * kw + kx)][c / 4][o][c % 4]; a thread moves one kernel row (kw taps) at a time
+    {
+        const float *wg = w + (long long)g * cg * og * khw;
+        const int rows = cg * og * nky;
+        for (int idx = t; idx < rows; idx += 64 * NW) {
+            const int kyi = idx % nky, co = idx / nky, o = co % og, c = co / og;
+            const float *src = wg + (long long)co * khw + (cls + kyi * S) * d.kw;
+            float *dst = ct_smem + ((long long)(kyi * d.kw) * nsteps + (c >> 2)) * OGP * 4 + o * 4 + (c & 3);
+            for (int kx = 0; kx < d.kw; kx++) dst[(long long)kx * nsteps * OGP * 4] = src[kx];
+        }
+    }
+    __syncthreads();
+    const int first = (cls - d.pads[0] % S + S) % S;          // rows oy = first, first + S, ...: (oy + pad_top) % S == cls
+    const int rows_cls = (d.out_h + S - 1 - first) / S;
+    const int nxb = (d.out_w + 16 * S - 1) / (16 * S);
+    const int ntasks = rows_cls * nxb;
+    float bo[JT][4];
+#pragma unroll
+    for (int j = 0; j < JT; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int o = 16 * j + 4 * quad + r;
+            bo[j][r] = (bias && o < og) ? bias[g * og + o] : 0.0f;
+        }
+    const float *xg = x + ((long long)n * d.c + (long long)g * cg) * d.h * d.w;
+    const long long plane_in = (long long)d.h * d.w;
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)xg, 0, (int)((long long)cg * plane_in * 4), 0x00020000);
+    const int nch = (nsteps + 15) >> 4, nunits = nky * d.kw * nch; // unit = 16 MFMA steps of one tap: its input values are fetched while the previous unit is multiplied
+    for (int task = chunk * tasks_per_wg + wave; task < ntasks && task < (chunk + 1) * tasks_per_wg; task += NW) {
+        const int ri = task / nxb, xb = task - ri * nxb;
+        const int oy = first + ri * S, py = oy + d.pads[0];
+        const int ox0 = xb * 16 * S;
+        ctf4 tot[S][JT], acc[JT];
+#pragma unroll
+        for (int rx = 0; rx < S; rx++)
+#pragma unroll
+            for (int j = 0; j < JT; j++) tot[rx][j] = ctf4{bo[j][0], bo[j][1], bo[j][2], bo[j][3]};
+        // unit u -> (tap, chunk of 16 steps); a tap whose input row does not exist is "not visited".  (Macros, not lambdas: with the value arrays passed
+        // by reference the compiler kept them in scratch memory and drained the load counter in front of every multiply -- first version, 42 us.)
+#define CT_DECODE(U)                                                                                                                     \
+        const int ti_ = (U) / nch, ch_ = (U) - ti_ * nch, kyi_ = ti_ / d.kw, kx_ = ti_ - kyi_ * d.kw, ky_ = cls + kyi_ * S;            \
+        const int iy_ = (py - ky_) / S;                                                                                                  \
+        const int rx_ = ((kx_ - d.pads[1]) % S + S) % S;          /* the column class this tap feeds: (ox + pad_left - kx) % S == 0 */   \
+        const int ix_ = l15 + (ox0 + rx_ + d.pads[1] - kx_) / S;  /* (an exact division) */                                              \
+        const bool row_ = (U) < nunits && ky_ <= py && iy_ < d.h;                                                                        \
+        const bool ok_ = row_ && (unsigned)ix_ < (unsigned)d.w;
+#define CT_FETCH(U, XV)                                                                                                                  \
+        {                                                                                                                                \
+            CT_DECODE(U)                                                                                                                 \
+            /* unconditional buffer loads: an offset beyond the slice returns 0 (a load under a per-lane condition becomes a branch, and the */ \
+            /* load counter is then drained in front of every multiply) */                                                                \
+            const unsigned off_ = ok_ ? (unsigned)(((quad + 64 * ch_) * (int)plane_in + iy_ * d.w + ix_) * 4) : 0x80000000u;             \
+            _Pragma("unroll") for (int v = 0; v < 16; v++)                                                                               \
+                XV[v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, (int)((FULL || 16 * ch_ + v < nsteps) ? off_ : 0x80000000u), (int)((unsigned)(v * 4) * (unsigned)plane_in * 4u), 0)); \
+        }
+#define CT_MULTIPLY(U, XV)                                                                                                               \
+        {                                                                                                                                \
+            CT_DECODE(U)                                                                                                                 \
+            if (row_) { /* (wave-uniform) */                                                                                             \
+                if (ch_ == 0) {                                                                                                          \
+                    _Pragma("unroll") for (int j = 0; j < JT; j++) acc[j] = ctf4{0.f, 0.f, 0.f, 0.f};                                    \
+                }                                                                                                                        \
+                const float *wp_ = ct_smem + ((long long)(kyi_ * d.kw + kx_) * nsteps + 16 * ch_) * OGP * 4 + l15 * 4 + quad;            \
+                _Pragma("unroll") for (int v = 0; v < 16; v++) {                                                                         \
+                    if (FULL || 16 * ch_ + v < nsteps) {                                                                                 \
+                        _Pragma("unroll") for (int j = 0; j < JT; j++)                                                                   \
+                            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp_[(v * OGP + 16 * j) * 4], XV[v], acc[j], 0, 0, 0);         \
+                    }                                                                                                                    \
+                }                                                                                                                        \
+                if (ch_ == nch - 1) { /* the tap's chain is complete: one separate add per output it lands on */                         \
+                    const bool hit0_ = ok_ && rx_ == 0, hit1_ = ok_ && rx_ == S - 1;                                                     \
+                    _Pragma("unroll") for (int j = 0; j < JT; j++) {                                                                     \
+                        const ctf4 s0_ = tot[0][j] + acc[j], s1_ = tot[S - 1][j] + acc[j];                                               \
+                        if (S == 2 || true) {                                                                                            \
+                            _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                              \
+                                if (S == 1) tot[0][j][r] = hit0_ ? s0_[r] : tot[0][j][r];                                                \
+                                else { tot[0][j][r] = hit0_ ? s0_[r] : tot[0][j][r]; tot[S - 1][j][r] = hit1_ ? s1_[r] : tot[S - 1][j][r]; } \
+                            }                                                                                                            \
+                        }                                                                                                                \
+                    }                                                                                                                    \
+                }                                                                                                                        \
+            }                                                                                                                            \
+        }
+        float xa[16], xb2[16];
+        CT_FETCH(0, xa)
+        for (int u = 0; u < nunits; u += 2) {
+            CT_FETCH(u + 1, xb2)
+            CT_MULTIPLY(u, xa)
+            CT_FETCH(u + 2, xa)
+            if (u + 1 < nunits) CT_MULTIPLY(u + 1, xb2)
+        }
+#undef CT_DECODE
+#undef CT_FETCH
+#undef CT_MULTIPLY
+        // ---- store: lane (pixel l15, quad) holds channels 16 j + 4 quad + r of columns ox0 + S l15 + {0 .. S-1}
+        float *yo = y + ((long long)n * d.o + (long long)g * og) * d.out_h * d.out_w + (long long)oy * d.out_w;
+        const bool pair = S == 2 && (d.out_w & 1) == 0 && (((uintptr_t)y) & 7u) == 0; // both columns of a lane as one 8-byte store
+#pragma unroll
+        for (int j = 0; j < JT; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int o = 16 * j + 4 * quad + r;
+                if (o >= og) continue;
+                float *row = yo + (long long)o * d.out_h * d.out_w;
+                const int ox = ox0 + S * l15;
+                if (pair) {
+                    if (ox < d.out_w) *reinterpret_cast<float2 *>(row + ox) = make_float2(tot[0][j][r], tot[S - 1][j][r]);
+                } else {
+#pragma unroll
+                    for (int rx = 0; rx < S; rx++)
+                        if (ox + rx < d.out_w) row[ox + rx] = tot[rx][j][r];
+                }
+            }
+    }
+}
+
 } // namespace
 
 // conv_transpose_output_size_and_padding (conv_transpose.rs:144-224): same checks, same messages.
@@ -98,6 +243,30 @@ RTEN_EXPORT int32_t rten_hip_conv_transpose2d_f32(rten_hip_ctx *ctx, const rten_
     const long long P = (long long)d->h * d->w, M = (long long)Og * d->kh * d->kw, plane = (long long)d->out_h * d->out_w;
     if (M > 0x7fffffffLL || P > 0x7fffffffLL || plane > 65535LL * 256 || (long long)d->n * Og > 0x7fffffffLL)
         return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "conv_transpose: geometry too large");
+    {   // the fused form (no column matrix): see conv_transpose_fused_kernel; RTEN_HIP_DEBUG bit 0x100000 = the GEMM + col2im sequence (A/B)
+        const int S = d->stride_h;
+        const int jt = Og <= 16 ? 1 : Og <= 32 ? 2 : 4;
+        const size_t lds = (size_t)((d->kh + S - 1) / S) * d->kw * Cg * (16 * jt) * sizeof(float);
+        if (!(ctx->debug & 0x100000) && d->dil_h == 1 && d->dil_w == 1 && d->stride_h == d->stride_w && S <= 2 && S <= d->kh && Cg % 4 == 0 && Cg <= 256 && Og <= 64 &&
+            lds <= 64 * 1024 && plane < (1ll << 31) && (long long)Cg * P * 4 < (1ll << 31) && (long long)Cg * Og * d->kh * d->kw < (1ll << 31)) {
+            const int rows_cls = (d->out_h + S - 1) / S, nxb = (d->out_w + 16 * S - 1) / (16 * S);
+            const int tasks_per_wg = 8, chunks = (rows_cls * nxb + tasks_per_wg - 1) / tasks_per_wg; // one task per wave (8 waves)
+            const long long wgs = (long long)d->n * d->groups * S * chunks;
+            if (wgs <= 0x7fffffffLL) {
+                ProfScope ps(ctx, "conv_transpose_fused_kernel", 2.0 * d->n * (double)d->c * P * Og * d->kh * d->kw, 4.0 * ((double)d->n * d->c * P + (double)d->n * d->o * plane));
+                const dim3 grid((unsigned)wgs), block(512);
+#define RTEN_CT_GO2(JTV, SV, FV) do { if (lds > 48 * 1024) hipFuncSetAttribute((const void *)conv_transpose_fused_kernel<JTV, SV, FV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                                      hipLaunchKernelGGL((conv_transpose_fused_kernel<JTV, SV, FV>), grid, block, lds, ctx->stream, *d, x, w, bias, y, Og, Cg, chunks, tasks_per_wg); } while (0)
+#define RTEN_CT_GO(JTV, SV) do { if (Cg % 64 == 0) RTEN_CT_GO2(JTV, SV, true); else RTEN_CT_GO2(JTV, SV, false); } while (0)
+                if (S == 1) { if (jt == 1) RTEN_CT_GO(1, 1); else if (jt == 2) RTEN_CT_GO(2, 1); else RTEN_CT_GO(4, 1); }
+                else { if (jt == 1) RTEN_CT_GO(1, 2); else if (jt == 2) RTEN_CT_GO(2, 2); else RTEN_CT_GO(4, 2); }
+#undef RTEN_CT_GO
+#undef RTEN_CT_GO2
+                RTEN_LAUNCH_CHECK(ctx, "conv_transpose_fused_kernel launch");
+                return RTEN_HIP_OK;
+            }
+        }
+    }
     float *cols = (float *)rten_aux_scratch(ctx, (size_t)d->n * M * P * sizeof(float));
     if (!cols) return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "conv_transpose: column buffer allocation failed (or attempted during graph capture)");
     for (int g = 0; g < d->groups; g++) {

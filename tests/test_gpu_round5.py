@@ -305,3 +305,29 @@ def test_streaming_depthwise_3x3_bits(ctx, shape, pt, pb):
         res = (rng.random(want.shape, dtype=np.float32) - 0.5) if with_res else None
         want = ref.conv2d_f32(x, wt, bias, pads=pads, strides=(1, 1), dilations=(1, 1), groups=c, residual=res, relu=relu)
         _bits(gpu_conv(ctx, x, wt, bias, pads, (1, 1), (1, 1), c, residual=res, relu=relu, prepack=prepack), want)
+
+
+@pytest.mark.parametrize("case", [
+    # N, C, H, W, O_g, kh, kw, pads, stride, groups, output_padding
+    (2, 8, 5, 7, 6, 4, 4, (1, 1, 1, 1), 2, 1, (0, 0)),       # the common 4x4 / 2 upsampler, ragged channel block (6 of 16)
+    (1, 64, 28, 28, 32, 4, 4, (1, 1, 1, 1), 2, 1, (0, 0)),   # the microbenchmark's layer (one image)
+    (2, 4, 9, 33, 20, 3, 3, (0, 1, 2, 0), 2, 1, (1, 0)),      # odd kernel at stride 2: row / column classes with different tap counts, output padding, > 16 s columns
+    (1, 12, 6, 6, 40, 2, 2, (0, 0, 0, 0), 2, 3, (0, 0)),      # kernel == stride (no overlap), three groups, 40 channels per group (three 16-blocks of four)
+    (3, 16, 7, 5, 16, 3, 3, (1, 1, 1, 1), 1, 2, (0, 0)),      # stride 1 (a flipped convolution), two groups
+    (1, 4, 3, 40, 5, 5, 3, (2, 0, 1, 1), 1, 1, (0, 0)),       # stride 1, 5x3 window, rows wider than one 16-column block
+    (2, 8, 4, 4, 64, 1, 1, (0, 0, 0, 0), 2, 1, (1, 1)),       # 1x1 kernel at stride 2: most outputs receive no tap (bias only)
+])
+def test_fused_conv_transpose_bits(ctx, case):
+    """conv_transpose_fused_kernel (no dilation, stride 1 or 2, C_g a multiple of 4): per output element bias, then for (k_y, k_x) ascending the c-ordered chain
+    of the tap that lands on it, added separately -- the reference's GEMM + col2im (conv_transpose.rs:80-142, 226-412) without the column matrix; with and
+    without bias."""
+    from rten_amd import ops
+    n, c, h, w, og, kh, kw, pads, s, groups, opad = case
+    rng = np.random.default_rng(5 + h * w + c + og)
+    x = rng.random((n, c, h, w), dtype=np.float32) - 0.5
+    wt = rng.random((c, og, kh, kw), dtype=np.float32) - 0.5
+    b = rng.random(og * groups, dtype=np.float32) - 0.5
+    op = ops.ConvTranspose(padding=list(pads), groups=groups, strides=[s, s], dilations=[1, 1], output_padding=list(opad))
+    for bias in (b, None):
+        ins = [DeviceTensor.from_numpy(ctx, x), DeviceTensor.from_numpy(ctx, wt)] + ([DeviceTensor.from_numpy(ctx, bias)] if bias is not None else [])
+        _bits(op.run(ctx, ins)[0].numpy(), ref.conv_transpose2d_f32(x, wt, bias, pads, (s, s), (1, 1), groups, opad))
