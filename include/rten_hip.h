@@ -35,8 +35,10 @@
  *    summation-order rounding.  One-row products (M == 1) of rten_hip_gemm_f32 follow the reference's
  *    vector-matrix kernels (rten-gemm/src/lib.rs:668-747,876-891; kernels/simd_generic.rs:14-197) bit for bit
  *    under the thread-count assumption stated by rten_hip_set_gemv_order (the reference's own result depends on
- *    its thread count there).  One-row products INSIDE composite operators (sdpa, ConvTranspose, MatMulNBits
- *    with rows > 1) keep the blocked order: out of contract for the gemv order.
+ *    its thread count there).  So do the one-row products inside composite operators whose reference code calls gemm on unpacked
+ *    operands: sdpa with ONE query row (src/ops/attention.rs:518-562) and ConvTranspose with a one-row kernel matrix
+ *    (O_g = kh = kw = 1, src/ops/conv_transpose.rs:376-383); MatMulNBits' right-hand side is block-quantized, not `Unpacked`, and keeps
+ *    the blocked order for one row too (rten-gemm/src/lib.rs:876).
  */
 #ifndef RTEN_HIP_H
 #define RTEN_HIP_H

@@ -592,7 +592,8 @@ RTO_API int rto_conv_transpose2d_f32(int64_t N, int64_t C, int64_t H, int64_t W,
     for (int64_t g = 0; g < groups; g++)
         for (int64_t n = 0; n < N; n++) {
             /* A[m][k] = kernel[(g*Cg + k)][m]: row stride 1, column stride M (the transposed kernel matrix) */
-            gemm_f32_blocked(M, P, Cg, Wt + g * Cg * M, 1, M, X + (n * C + g * Cg) * P, P, 1, cols, P, 1.0f, 0.0f, NULL, 0);
+            /* (gemm_impl on unpacked operands: a kernel matrix of ONE row -- O_g = kh = kw = 1 -- takes the vector-matrix path, lib.rs:876-891) */
+            rto_gemm_f32(M, P, Cg, Wt + g * Cg * M, 1, M, X + (n * C + g * Cg) * P, P, 1, cols, P, 1.0f, 0.0f, NULL, 0);
             for (int64_t o = 0; o < Og; o++) {
                 float *out = Y + (n * O + g * Og + o) * OH * OW;
                 const float b = bias ? bias[g * Og + o] : 0.0f;
@@ -1028,10 +1029,12 @@ RTO_API void rto_sdpa_head(int64_t S, int64_t T, int64_t D, int64_t Dv, const fl
                            const float *v, const float *mask, int64_t mask_rs, float scale, float *out,
                            int lanes, int flush_nan) {
     float *scores = (float *)malloc((size_t)S * T * sizeof(float));
-    gemm_f32_blocked(S, T, D, q, D, 1, k, 1, D, scores, T, scale, 0.f, NULL, 0);
+    /* both products go through gemm_impl with unpacked operands: ONE query row takes the vector-matrix kernels (lib.rs:876-891), like any other
+     * one-row product; rto_gemm_f32 makes that choice */
+    rto_gemm_f32(S, T, D, q, D, 1, k, 1, D, scores, T, scale, 0.f, NULL, 0);
     for (int64_t s = 0; s < S; s++)
         rto_softmax_row(T, scores + s * T, mask ? mask + s * mask_rs : NULL, scores + s * T, flush_nan, lanes);
-    gemm_f32_blocked(S, Dv, T, scores, T, 1, v, Dv, 1, out, Dv, 1.f, 0.f, NULL, 0);
+    rto_gemm_f32(S, Dv, T, scores, T, 1, v, Dv, 1, out, Dv, 1.f, 0.f, NULL, 0);
     free(scores);
 }
 

@@ -36,7 +36,11 @@ RTEN_EXPORT int32_t rten_hip_sdpa_f32(rten_hip_ctx *ctx, const rten_hip_sdpa_des
     if (mask && ((d->mask_row_stride != 0 && d->mask_row_stride != d->t) ||
                  d->mask_batch_stride != (d->mask_row_stride ? (int64_t)d->s * d->t : (int64_t)d->t)))
         return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "sdpa: mask must be [B,1,1,T] or [B,1,S,T] contiguous");
-    if (ctx->sdpa_path != 1) {
+    // ONE query row: both of sdpa_head's products are one-row products of unpacked operands, for which the reference's gemm_impl takes its vector-matrix
+    // kernels (rten-gemm/src/lib.rs:876-891) -- not the blocked chain the one-kernel forms replay.  The composed path below then calls the GEMM entry
+    // that makes the same choice (rten_hip_set_gemv_order(ctx, 0, ..) restores the blocked order everywhere, e.g. for prepacked weights).
+    const bool one_row = d->s == 1 && ctx->gemv_order != 0;
+    if (ctx->sdpa_path != 1 && !one_row) {
         const int32_t rc = rten_sdpa_fused(ctx, d, q, k, v, mask, out, ctx->sdpa_path == 2);
         if (rc != RTEN_HIP_ERR_UNSUPPORTED) return rc;
     }
@@ -55,7 +59,7 @@ RTEN_EXPORT int32_t rten_hip_sdpa_f32(rten_hip_ctx *ctx, const rten_hip_sdpa_des
     g.a_bs = d->q_bs; g.a_bsi = d->q_hs; g.b_bs = d->k_bs; g.b_bsi = d->k_hs;
     g.c_bs = (int64_t)d->heads * d->s * d->t; g.c_bsi = (int64_t)d->s * d->t;
     g.alpha = d->scale; g.beta = 0.f;
-    int32_t rc = rten_gemm_f32_blocked(ctx, &g, q, k, nullptr, scores);
+    int32_t rc = one_row ? rten_hip_gemm_f32(ctx, &g, q, k, nullptr, scores) : rten_gemm_f32_blocked(ctx, &g, q, k, nullptr, scores);
     if (rc) return rc;
     // row softmax with NaN flush (attention.rs:546-552); score row r = ((b*H + h)*S + qi)
     if (d->t > 0) {
@@ -79,5 +83,5 @@ RTEN_EXPORT int32_t rten_hip_sdpa_f32(rten_hip_ctx *ctx, const rten_hip_sdpa_des
     g.a_bs = (int64_t)d->heads * d->s * d->t; g.a_bsi = (int64_t)d->s * d->t;
     g.b_bs = d->v_bs; g.b_bsi = d->v_hs; g.c_bs = d->o_bs; g.c_bsi = d->o_hs;
     g.alpha = 1.f; g.beta = 0.f;
-    return rten_gemm_f32_blocked(ctx, &g, scores, v, nullptr, out);
+    return one_row ? rten_hip_gemm_f32(ctx, &g, scores, v, nullptr, out) : rten_gemm_f32_blocked(ctx, &g, scores, v, nullptr, out);
 }

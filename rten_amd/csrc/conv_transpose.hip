@@ -247,7 +247,7 @@ RTEN_EXPORT int32_t rten_hip_conv_transpose2d_f32(rten_hip_ctx *ctx, const rten_
         const int S = d->stride_h;
         const int jt = Og <= 16 ? 1 : Og <= 32 ? 2 : 4;
         const size_t lds = (size_t)((d->kh + S - 1) / S) * d->kw * Cg * (16 * jt) * sizeof(float);
-        if (!(ctx->debug & 0x100000) && d->dil_h == 1 && d->dil_w == 1 && d->stride_h == d->stride_w && S <= 2 && S <= d->kh && Cg % 4 == 0 && Cg <= 256 && Og <= 64 &&
+        if (!(ctx->debug & 0x100000) && !(M == 1 && ctx->gemv_order != 0) && d->dil_h == 1 && d->dil_w == 1 && d->stride_h == d->stride_w && S <= 2 && S <= d->kh && Cg % 4 == 0 && Cg <= 256 && Og <= 64 &&
             lds <= 64 * 1024 && plane < (1ll << 31) && (long long)Cg * P * 4 < (1ll << 31) && (long long)Cg * Og * d->kh * d->kw < (1ll << 31)) {
             const int rows_cls = (d->out_h + S - 1) / S, nxb = (d->out_w + 16 * S - 1) / (16 * S);
             const int tasks_per_wg = 8, chunks = (rows_cls * nxb + tasks_per_wg - 1) / tasks_per_wg; // one task per wave (8 waves)
@@ -276,7 +276,9 @@ RTEN_EXPORT int32_t rten_hip_conv_transpose2d_f32(rten_hip_ctx *ctx, const rten_
         gd.b_rs = P; gd.b_cs = 1; gd.ldc = P;
         gd.batch = d->n; gd.a_bs = 0; gd.b_bs = (long long)d->c * P; gd.c_bs = M * P;
         gd.alpha = 1.f; gd.beta = 0.f;
-        const int32_t rc = rten_gemm_f32_blocked(ctx, &gd, w + (long long)g * Cg * M, x + (long long)g * Cg * P, nullptr, cols);
+        // (a kernel matrix of ONE row -- O_g = kh = kw = 1 -- is a one-row product of unpacked operands: the reference's vector-matrix order, lib.rs:876-891)
+        const int32_t rc = (M == 1 && ctx->gemv_order != 0) ? rten_hip_gemm_f32(ctx, &gd, w + (long long)g * Cg * M, x + (long long)g * Cg * P, nullptr, cols)
+                                                            : rten_gemm_f32_blocked(ctx, &gd, w + (long long)g * Cg * M, x + (long long)g * Cg * P, nullptr, cols);
         if (rc) return rc;
         ProfScope ps(ctx, "col2im_f32", 0.0, 4.0 * ((double)d->n * M * P + (double)d->n * Og * plane));
         hipLaunchKernelGGL(col2im_kernel, dim3((unsigned)(d->n * Og), (unsigned)((plane + 255) / 256)), dim3(256), 0, ctx->stream, *d, Og, g * Og, cols, bias, y);

@@ -331,3 +331,36 @@ def test_fused_conv_transpose_bits(ctx, case):
     for bias in (b, None):
         ins = [DeviceTensor.from_numpy(ctx, x), DeviceTensor.from_numpy(ctx, wt)] + ([DeviceTensor.from_numpy(ctx, bias)] if bias is not None else [])
         _bits(op.run(ctx, ins)[0].numpy(), ref.conv_transpose2d_f32(x, wt, bias, pads, (s, s), (1, 1), groups, opad))
+
+
+def test_one_query_attention_and_one_row_conv_transpose_follow_the_vector_matrix_order(ctx):
+    """One query row (a decoder step) makes both of sdpa_head's products one-row products of unpacked operands: the reference's gemm_impl takes its
+    vector-matrix kernels there (rten-gemm/src/lib.rs:876-891), and so does rten_hip_sdpa_f32 (composed path on the GEMM entry that makes that choice;
+    the one-kernel forms replay the blocked chain and are not used).  Same for ConvTranspose with a one-row kernel matrix.  With the gemv order switched
+    off (prepacked-weights semantics) both return to the blocked chain."""
+    rng = ref.XorShiftRng(123)
+    for (B, H, T, D) in ((2, 3, 40, 64), (1, 2, 129, 32), (1, 1, 700, 128), (2, 12, 128, 64)):
+        q = rng.f32(B * H * D).reshape(B, H, 1, D) - 0.5
+        k = rng.f32(B * H * T * D).reshape(B, H, T, D) - 0.5
+        v = rng.f32(B * H * T * D).reshape(B, H, T, D) - 0.5
+        m = np.where(rng.f32(B * T).reshape(B, 1, 1, T) > 0.3, 0.0, -np.inf).astype(np.float32)
+        for mask in (None, m):
+            d = L.SdpaDesc(B, H, 1, T, D, D, H * D, D, D, H * T * D, T * D, D, H * T * D, T * D, D, H * D, D, D, 0 if mask is None else T, 0, 0.125, 1)
+            qd, kd, vd = (DeviceTensor.from_numpy(ctx, a) for a in (q, k, v))
+            md = DeviceTensor.from_numpy(ctx, mask) if mask is not None else None
+            out = DeviceTensor(ctx, (B, H, 1, D), np.float32)
+            ctx.call("rten_hip_sdpa_f32", C.byref(d), qd.vp, kd.vp, vd.vp, md.vp if md is not None else None, out.vp)
+            _bits(out.numpy(), ref.sdpa(q, k, v, mask=mask, scale=0.125, lanes=16, flush_nan=True))
+            ctx.call("rten_hip_set_gemv_order", 0, 0)
+            ref.set_gemv_enabled(False)
+            try:
+                ctx.call("rten_hip_sdpa_f32", C.byref(d), qd.vp, kd.vp, vd.vp, md.vp if md is not None else None, out.vp)
+                _bits(out.numpy(), ref.sdpa(q, k, v, mask=mask, scale=0.125, lanes=16, flush_nan=True))
+            finally:
+                ctx.call("rten_hip_set_gemv_order", 1, 0)
+                ref.set_gemv_enabled(True)
+    from rten_amd import ops
+    x = rng.f32(2 * 300 * 5 * 7).reshape(2, 300, 5, 7) - 0.5
+    w = rng.f32(300).reshape(300, 1, 1, 1) - 0.5
+    got = ops.ConvTranspose(strides=[1, 1]).run(ctx, [DeviceTensor.from_numpy(ctx, x), DeviceTensor.from_numpy(ctx, w)])[0].numpy()
+    _bits(got, ref.conv_transpose2d_f32(x, w, None, (0, 0, 0, 0), (1, 1)))

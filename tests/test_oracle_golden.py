@@ -525,3 +525,35 @@ def test_gemv_path_restated_twice(layout):
         ref.set_gemv_threads(0)
         ref.set_gemv_enabled(True)
     assert np.array_equal(ref.gemm_f32(np.stack([a, a]), b)[1].view(np.uint32), blocked.ravel().view(np.uint32))
+
+
+def test_one_row_products_inside_sdpa_and_conv_transpose_take_the_gemv_order():
+    """sdpa_head (src/ops/attention.rs:518-562) and conv_transpose (src/ops/conv_transpose.rs:376-383) call gemm on UNPACKED operands, so a single query
+    row / a one-row kernel matrix takes gemm_impl's vector-matrix branch (rten-gemm/src/lib.rs:876-891) like any other one-row product: the oracle's
+    composite equals the composition of its own one-row GEMM (which makes that choice), softmax and one-row GEMM -- and, where the two orders differ in
+    the last bits, NOT the blocked chain."""
+    rng = ref.XorShiftRng(99)
+    differs = 0
+    for (T, D) in ((40, 64), (129, 32), (700, 128)):
+        q = rng.f32(D).reshape(1, 1, 1, D) - 0.5
+        k = rng.f32(T * D).reshape(1, 1, T, D) - 0.5
+        v = rng.f32(T * D).reshape(1, 1, T, D) - 0.5
+        m = ((rng.f32(T).reshape(1, 1, 1, T) - 0.5) * 4).astype(np.float32)
+        got = ref.sdpa(q, k, v, mask=m, scale=0.125)
+        scores = ref.gemm_f32(q[0, 0], k[0, 0].T, alpha=0.125)            # one row: the gemv order (transposed B)
+        p = ref.softmax(scores, addend=m.reshape(1, T), flush_nan=True)
+        want = ref.gemm_f32(p, v[0, 0])                                      # one row: the gemv order (row-major B)
+        expect_equal(got[0, 0], want)
+        ref.set_gemv_enabled(False)
+        try:
+            blocked = ref.sdpa(q, k, v, mask=m, scale=0.125)
+        finally:
+            ref.set_gemv_enabled(True)
+        differs += int((blocked.view(np.int32) != got.view(np.int32)).any())
+    assert differs > 0, "the vector-matrix order and the blocked order agreed on every case: the test does not discriminate"
+    # ConvTranspose with a one-row kernel matrix (O_g = kh = kw = 1)
+    x = rng.f32(2 * 300 * 5 * 7).reshape(2, 300, 5, 7) - 0.5
+    w = rng.f32(300).reshape(300, 1, 1, 1) - 0.5
+    got = ref.conv_transpose2d_f32(x, w, None, (0, 0, 0, 0), (1, 1))
+    for n in range(2):
+        expect_equal(got[n, 0].reshape(1, 35), ref.gemm_f32(w.reshape(1, 300), x[n].reshape(300, 35)) + np.float32(0))
