@@ -426,7 +426,11 @@ def run_via_executor(args):
     lanes = args.lanes if args.lanes else (INT8_DEFAULT_LANES if int8 else (F32_DEFAULT_LANES if args.chains is None else 1))
     # int8: one replica alone may use quantized-output launches (int8.json); replicas running side by side may not (those launches need the device to
     # themselves): int8_lanes.json lists only the quantize-on-load layers
-    default_plan = os.path.join(ROOT, "profiles", "plans", ("int8.json" if lanes == 1 else "int8_lanes.json") if int8 else f"f32_{chains}chain{'s' if chains > 1 else ''}.json")
+    # f32 replicas side by side: the one-chain plan plus the classifier on its 64x64 tiles (f32_lanes.json) -- the small-M streaming kernel the backend picks
+    # on its own is the faster launch alone (8 vs 14 us) but spreads over every compute unit, which costs the other replica more than it saves
+    # (same-box A/B, profiles/r08/classifier_under_lanes.txt)
+    f32_plan = "f32_lanes.json" if (lanes > 1 and chains == 1) else f"f32_{chains}chain{'s' if chains > 1 else ''}.json"
+    default_plan = os.path.join(ROOT, "profiles", "plans", ("int8.json" if lanes == 1 else "int8_lanes.json") if int8 else f32_plan)
     plan_path = args.load_plan or default_plan
     plan_text, plan_source = None, "backend defaults (no plan)"
     if not args.no_autotune and not args.autotune and os.path.exists(plan_path):

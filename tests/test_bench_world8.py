@@ -36,7 +36,7 @@ def test_eight_rank_bench_control_flow_of_the_default_path(config):
     rk = j["ranks"]
     assert rk["world_size"] == 8 and rk["dist_backend"] == "gloo" and rk["weight_broadcast_world"] == 8
     assert rk["input_seed_per_rank"] == [1234 + r_ for r_ in range(8)] and len(rk["ms_per_step_per_rank"]) == 8
-    plan_file = "int8_lanes.json" if config == "int8" else "f32_1chain.json"
+    plan_file = "int8_lanes.json" if config == "int8" else "f32_lanes.json"
     assert j["config"]["launch_plan"]["source"] == os.path.join("profiles", "plans", plan_file)
     assert len(set(rk["plan_sha16_per_rank"])) == 1 and j["config"]["launch_plan"]["identical_on_all_ranks"] is True
     assert len(set(rk["planned_steps_per_rank"])) == 1

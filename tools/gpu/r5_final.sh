@@ -33,15 +33,15 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_i
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_bert -o t -- python $R/tools/bench_bert.py --steps 20 --warmup 5 --no-cpu-baseline > $R/$O/prof_bert.json 2> $R/$O/prof_bert.err
 PMCARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-shapes"
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/$O/f32_$c -o t -- python $R/bench.py --lanes 1 $PMCARGS > $R/$O/f32_$c.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/$O/f32_$c -o t -- python $R/bench.py --lanes 1 --load-plan $P/f32_lanes.json $PMCARGS > $R/$O/f32_$c.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/$O/int8_$c -o t -- python $R/bench.py --config int8 --lanes 2 $PMCARGS > $R/$O/int8_$c.log 2>&1
 done
 SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
-timeout 300 rocprofv3 --kernel-trace --pmc $SQ1 --output-format csv -d $R/$O/pmc_f32 -o t -- python $R/bench.py --lanes 1 $PMCARGS > $R/$O/pmc_f32.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc $SQ1 --output-format csv -d $R/$O/pmc_f32 -o t -- python $R/bench.py --lanes 1 --load-plan $P/f32_lanes.json $PMCARGS > $R/$O/pmc_f32.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc $SQ1 --output-format csv -d $R/$O/pmc_int8 -o t -- python $R/bench.py --config int8 --lanes 2 $PMCARGS > $R/$O/pmc_int8.log 2>&1
 cd $R
 f() { find $O/$1 -name "$2" | head -1; }
-python tools/pmc_traffic.py $(f f32_FETCH_SIZE t_counter_collection.csv) $(f f32_WRITE_SIZE t_counter_collection.csv) $P/f32_1chain.json > $O/hbm_traffic_per_kernel.json
+python tools/pmc_traffic.py $(f f32_FETCH_SIZE t_counter_collection.csv) $(f f32_WRITE_SIZE t_counter_collection.csv) $P/f32_lanes.json > $O/hbm_traffic_per_kernel.json
 python tools/pmc_traffic.py $(f int8_FETCH_SIZE t_counter_collection.csv) $(f int8_WRITE_SIZE t_counter_collection.csv) $P/int8_lanes.json > $O/int8_hbm_traffic_per_kernel.json
 python tools/pmc_mfma.py $(f pmc_f32 t_counter_collection.csv) 3 > $O/mfma_util_f32.csv
 python tools/pmc_mfma.py $(f pmc_int8 t_counter_collection.csv) 3 > $O/mfma_util_int8.csv
