@@ -107,3 +107,13 @@ def test_split_batch_covers_the_batch_once():
     assert split_batch(32, 4) == ([8, 8, 8, 8], [0, 8, 16, 24]) and split_batch(5, 2) == ([3, 2], [0, 3])
     with pytest.raises(ValueError):
         split_batch(3, 4)
+
+
+def test_the_lanes_plan_is_the_one_chain_plan_plus_the_classifier_entry():
+    """profiles/plans/f32_lanes.json (the default line's plan: one chain x 2 lanes) differs from f32_1chain.json by ONE entry -- the classifier Gemm pinned to its
+    64x64 tiles (profiles/r08/classifier_under_lanes.txt) -- so the per-shape table and the tuning records of the one-chain plan apply to it unchanged."""
+    import json
+    plans = os.path.join(ROOT, "profiles", "plans")
+    one, lanes = json.load(open(os.path.join(plans, "f32_1chain.json"))), json.load(open(os.path.join(plans, "f32_lanes.json")))
+    assert {k: v for k, v in lanes.items() if k != "fc"} == one
+    assert lanes["fc"] == [3, 3, 1, 0]
