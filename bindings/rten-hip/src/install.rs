@@ -67,7 +67,7 @@ pub fn install_resident(graph: &mut Graph, hip: &Arc<HipContext>, onnx: &[u8], p
 ///
 /// ```ignore
 /// let hip = HipContext::new(0)?;
-/// let plan = ResidentPlan { plan_json: Some(include_str!("f32_1chain.json")), chains: 1, lanes: 2, input_shapes: vec![("x".into(), vec![32, 3, 224, 224])] };
+/// let plan = ResidentPlan { plan_json: Some(include_str!("f32_lanes.json")), chains: 1, lanes: 2, input_shapes: vec![("x".into(), vec![32, 3, 224, 224])] };
 /// let model = rten_hip::load_resident(ModelOptions::with_all_ops(), hip, "resnet50.onnx", plan)?;
 /// let logits = model.run_one(batch.view().into(), None)?;      // the reference's call, one H2D + one D2H per run
 /// ```
