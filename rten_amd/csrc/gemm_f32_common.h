@@ -32,7 +32,7 @@ constexpr unsigned OOB = 0x80000000u; // byte offset beyond every buffer (< 2 Gi
 #ifdef RTEN_TRACE
 // -DRTEN_TRACE builds only (tools/debug/f32_trace.py): every workgroup of the LDS-DMA kernel appends one record of wall-clock stamps
 // (s_memrealtime, 100 MHz, the same counter on every XCD) at its phase boundaries, with its compute unit.  Compiled out of the product build.
-#define TR_DECL unsigned long long tr_t[6] = {0, 0, 0, 0, 0, 0}; unsigned tr_trips = 0;
+#define TR_DECL unsigned long long tr_t[6] = {0, 0, 0, 0, 0, 0}; unsigned tr_trips = 0; const unsigned long long tr_c0 = __builtin_readcyclecounter(), tr_r0 = __builtin_amdgcn_s_memrealtime();
 #define TR_STAMP(i) tr_t[i] = __builtin_amdgcn_s_memrealtime();
 #else
 #define TR_DECL
@@ -77,6 +77,7 @@ struct GemmArgs {
     unsigned long long *trace_buf; // NULL: off
     unsigned trace_cap;
     unsigned trace_base; // first record slot of this launch (host counter: a launch's workgroups own slots base + blockIdx)
+    unsigned long long trace_pad[8]; // (the argument block then spans 7 cache lines: kernarg_prefetch takes 3, 5 or 7)
 #endif
 };
 
@@ -286,7 +287,7 @@ __device__ __forceinline__ void split_finish(const GemmArgs &p, int z, int tile,
 }
 
 #ifdef RTEN_TRACE
-__device__ __forceinline__ void trace_write(const GemmArgs &p, unsigned kid, int tile, int grp, unsigned trips, const unsigned long long (&t)[6]) {
+__device__ __forceinline__ void trace_write(const GemmArgs &p, unsigned kid, int tile, int grp, unsigned trips, const unsigned long long (&t)[6], unsigned long long cycles, unsigned long long ticks) {
     if (threadIdx.x != 0 || p.trace_buf == nullptr) return;
     const unsigned i = p.trace_base + blockIdx.y * gridDim.x + blockIdx.x; // no shared counter: 130k same-address atomics per step serialise (first version: 2.7 -> 11.7 ms)
     if (i >= p.trace_cap) return;
@@ -301,8 +302,9 @@ __device__ __forceinline__ void trace_write(const GemmArgs &p, unsigned kid, int
     r[11] = (unsigned)(grp + 1) | ((unsigned long long)(unsigned)p.split_s << 32);
     r[12] = (unsigned long long)p.C;
     r[13] = blockIdx.y;
+    r[14] = cycles | (ticks << 40); // shader cycles (s_memtime) and 10 ns ticks over the workgroup's life: cycles / ticks x 100 = the shader clock in MHz while it ran
 }
-#define TR_WRITE(kid, tile, grp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TR_STAMP(5) trace_write(p, kid, tile, grp, tr_trips, tr_t); }
+#define TR_WRITE(kid, tile, grp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TR_STAMP(5) trace_write(p, kid, tile, grp, tr_trips, tr_t, __builtin_readcyclecounter() - tr_c0, __builtin_amdgcn_s_memrealtime() - tr_r0); }
 #else
 #define TR_WRITE(kid, tile, grp)
 #endif

@@ -56,6 +56,11 @@ if chains > 1:
     net.variants = {b: {k: to_dma(p) for k, p in t.items()} for b, t in plan.items()}
 else:
     net.variants = {k: tuple(to_dma(p)) for k, p in plan.items()}
+# the launches carry the record buffer in their arguments from the moment they are enqueued (a captured launch for every replay): hand it over BEFORE the capture
+CAP = 1 << 21
+buf = DeviceTensor(ctx, (CAP * 16,), np.uint64)
+ctx.call("rten_hip_memset", buf.vp, 0, C.c_size_t(CAP * 128))
+assert lib.rten_hip_debug_trace_set(ctx.h, buf.vp, CAP) == 0
 net.capture()
 import time
 for _ in range(20):
@@ -66,16 +71,11 @@ for _ in range(50):
     net.run()
 (net.sync() if chains > 1 else ctx.sync())
 step_ms = (time.perf_counter() - t0) / 50 * 1e3
-print(f"[trace] chains={chains} plan={os.path.relpath(plan_path, ROOT)} (DMA-mapped) step (stamps compiled in, buffer off) {step_ms:.4f} ms", flush=True)
+print(f"[trace] chains={chains} plan={os.path.relpath(plan_path, ROOT)} (DMA-mapped) step (stamps compiled in, records written) {step_ms:.4f} ms", flush=True)
 
-CAP = 1 << 21
-buf = DeviceTensor(ctx, (CAP * 16,), np.uint64)
-ctx.call("rten_hip_memset", buf.vp, 0, C.c_size_t(CAP * 128))
+ctx.call("rten_hip_memset", buf.vp, 0, C.c_size_t(CAP * 128))  # drop the records of the warm-up replays: every non-zero record below is from the STEPS replays that follow
 ctx.sync()
-# A launch owns the record slots [base, base + workgroups) handed out on the host when it was enqueued (captured launches keep theirs for
-# every replay), so the kernels share no counter.  The buffer is switched on after warm-up: every non-zero record is the LAST replay's.
 STEPS = 4
-assert lib.rten_hip_debug_trace_set(ctx.h, buf.vp, CAP) == 0
 t0 = time.perf_counter()
 for _ in range(STEPS):
     net.run()
@@ -94,6 +94,13 @@ np.savez_compressed(args.out + f"_{chains}ch.npz", rec=rec[:, :14])
 if os.path.getsize(args.out + f"_{chains}ch.npz") > 24 << 20:
     os.remove(args.out + f"_{chains}ch.npz")  # gpurun merges at most 64 MiB back
 
+# ---- the shader clock while the kernels ran: s_memtime cycles over s_memrealtime ticks (10 ns) of every workgroup's life
+cyc = (rec[:, 14] & ((1 << 40) - 1)).astype(np.float64); tick = (rec[:, 14] >> 40).astype(np.float64)
+okc = tick > 100  # (workgroups that lived at least a microsecond)
+if okc.any():
+    mhz = cyc[okc] / tick[okc] * 100.0
+    print(f"[trace] shader clock over {int(okc.sum())} workgroups: median {np.median(mhz):.0f} MHz, 10th / 90th percentile {np.percentile(mhz, 10):.0f} / {np.percentile(mhz, 90):.0f} MHz "
+          f"(peak figures assume 2400 MHz: at the median clock the f32 MFMA peak is {157.3 * np.median(mhz) / 2400:.1f} TFLOP/s)", flush=True)
 # ---- analysis (100 MHz stamps -> us)
 T = rec[:, 2:8].astype(np.float64) / 100.0
 t_begin = T[:, 0].min()
