@@ -31,6 +31,10 @@ PC="--steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-shapes"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_f32 -o t -- python $R/bench.py $PC > $R/$O/prof_f32.json 2> $R/$O/prof_f32.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_int8 -o t -- python $R/bench.py --config int8 $PC > $R/$O/prof_int8.json 2> $R/$O/prof_int8.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_bert -o t -- python $R/tools/bench_bert.py --steps 20 --warmup 5 --no-cpu-baseline > $R/$O/prof_bert.json 2> $R/$O/prof_bert.err
+# one replica (launches serialised: per-kernel durations comparable with the bench line's per-kernel detail, which comes from the serialised profile pass)
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_f32_1lane -o t -- python $R/bench.py --lanes 1 $PC > $R/$O/prof_f32_1lane.json 2> $R/$O/prof_f32_1lane.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_int8_1lane -o t -- python $R/bench.py --config int8 --lanes 1 $PC > $R/$O/prof_int8_1lane.json 2> $R/$O/prof_int8_1lane.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_bert_1lane -o t -- python $R/tools/bench_bert.py --lanes 1 --steps 20 --warmup 5 --no-cpu-baseline > $R/$O/prof_bert_1lane.json 2> $R/$O/prof_bert_1lane.err
 PMCARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-shapes"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/$O/f32_$c -o t -- python $R/bench.py --lanes 1 --load-plan $P/f32_lanes.json $PMCARGS > $R/$O/f32_$c.log 2>&1
@@ -45,7 +49,7 @@ python tools/pmc_traffic.py $(f f32_FETCH_SIZE t_counter_collection.csv) $(f f32
 python tools/pmc_traffic.py $(f int8_FETCH_SIZE t_counter_collection.csv) $(f int8_WRITE_SIZE t_counter_collection.csv) $P/int8_lanes.json > $O/int8_hbm_traffic_per_kernel.json
 python tools/pmc_mfma.py $(f pmc_f32 t_counter_collection.csv) 3 > $O/mfma_util_f32.csv
 python tools/pmc_mfma.py $(f pmc_int8 t_counter_collection.csv) 3 > $O/mfma_util_int8.csv
-for n in f32 int8 bert; do cp $(f prof_$n t_kernel_stats.csv) $O/rocprofv3_kernel_stats_$n.csv 2>/dev/null; done
+for n in f32 int8 bert f32_1lane int8_1lane bert_1lane; do cp $(f prof_$n t_kernel_stats.csv) $O/rocprofv3_kernel_stats_$n.csv 2>/dev/null; done
 find $O -name "t_kernel_trace.csv" -size +2M -delete; find $O -name "t_counter_collection.csv" -size +4M -delete; find $O -name "*.db" -delete
 tail -n 2 $O/smoke.log
 python - <<PY
