@@ -31,16 +31,19 @@ struct BoundInput {
     name: String,
     shape: Vec<usize>,
     dev: *mut c_void,
+    dtype: i32, // RTEN_HIP_DTYPE_* (rten_hip_model_input_dtype): the element type the device graph reads
 }
 
-/// A resident subgraph as an operator.  Inputs are f32 tensors of the shapes given to `load` (a static plan: the launch plan, the buffer
-/// plan and the captured hipGraphs are per shape); outputs are f32.
+/// A resident subgraph as an operator.  Inputs are tensors of the shapes given to `load` (a static plan: the launch plan, the buffer plan and
+/// the captured hipGraphs are per shape) and of the element types the graph declares -- f32, i32 (ONNX int32 / int64 inputs: token ids, masks,
+/// positions of BERT-class graphs), u8, i8 (`rten_hip_model_input_dtype`); outputs come back with their own types (`rten_hip_model_output_dtype`).
 #[derive(Debug)]
 pub struct HipSubgraph {
     model: *mut sys::rten_hip_model,
     hip: Arc<HipContext>, // chain 0 runs on this context's stream: the context must outlive the model (rten_hip.h), which this Arc guarantees
     inputs: Vec<BoundInput>,
     n_outputs: usize,
+    output_dtypes: Vec<i32>, // RTEN_HIP_DTYPE_* per output (known after prepare)
     run_lock: Mutex<()>, // the model object is not thread-safe (one caller at a time); `Model::run(&self)` may be called from several threads
     origin: Option<Arc<HipSubgraph>>, // a replica (rten_hip_model_clone) shares its origin's weights: the origin outlives it
 }
@@ -67,7 +70,7 @@ impl HipSubgraph {
             if !why.is_empty() { eprintln!("rten-hip: subgraph: {why}"); }
             hip.check(status)?;
         }
-        let mut this = HipSubgraph { model, hip, inputs: Vec::new(), n_outputs: 0, run_lock: Mutex::new(()), origin: None };
+        let mut this = HipSubgraph { model, hip, inputs: Vec::new(), n_outputs: 0, output_dtypes: Vec::new(), run_lock: Mutex::new(()), origin: None };
         this.bind_and_prepare(input_shapes)?;
         Ok(this)
     }
@@ -84,9 +87,16 @@ impl HipSubgraph {
             let dims: Vec<i64> = shape.iter().map(|&d| d as i64).collect();
             let mut dev: *mut c_void = ptr::null_mut();
             this.check(unsafe { sys::rten_hip_model_bind_input(this.model, i, dims.as_ptr(), dims.len() as i32, &mut dev) })?;
-            this.inputs.push(BoundInput { name, shape, dev });
+            let mut dtype = sys::RTEN_HIP_DTYPE_F32;
+            this.check(unsafe { sys::rten_hip_model_input_dtype(this.model, i, &mut dtype) })?;
+            this.inputs.push(BoundInput { name, shape, dev, dtype });
         }
         this.check(unsafe { sys::rten_hip_model_prepare(this.model, 0) })?; // buffers planned, launch plan applied, one hipGraph per chain captured
+        for i in 0..n_out {
+            let mut dtype = sys::RTEN_HIP_DTYPE_F32;
+            this.check(unsafe { sys::rten_hip_model_output_dtype(this.model, i, &mut dtype) })?;
+            this.output_dtypes.push(dtype);
+        }
         Ok(())
     }
 
@@ -104,7 +114,7 @@ impl HipSubgraph {
             hip.check(status)?;
         }
         let shapes: Vec<(&str, Vec<usize>)> = origin.inputs.iter().map(|b| (b.name.as_str(), b.shape.clone())).collect();
-        let mut this = HipSubgraph { model, hip, inputs: Vec::new(), n_outputs: 0, run_lock: Mutex::new(()), origin: Some(origin.clone()) };
+        let mut this = HipSubgraph { model, hip, inputs: Vec::new(), n_outputs: 0, output_dtypes: Vec::new(), run_lock: Mutex::new(()), origin: Some(origin.clone()) };
         this.bind_and_prepare(&shapes)?;
         Ok(this)
     }
@@ -164,21 +174,37 @@ impl Operator for HipSubgraph {
     fn max_inputs(&self) -> Option<usize> { Some(self.inputs.len()) }
     fn max_outputs(&self) -> Option<usize> { Some(self.n_outputs) }
     fn output_types(&self, _ctx: &OutputTypesContext) -> Option<OutputTypeList> {
-        Some((0..self.n_outputs).map(|_| OutputType::Fixed(ValueType::Tensor(DataType::Float))).collect())
+        Some(self.output_dtypes.iter().map(|&d| OutputType::Fixed(ValueType::Tensor(match d {
+            sys::RTEN_HIP_DTYPE_I32 => DataType::Int32,
+            sys::RTEN_HIP_DTYPE_U8 => DataType::UInt8,
+            sys::RTEN_HIP_DTYPE_I8 => DataType::Int8,
+            _ => DataType::Float,
+        }))).collect())
     }
 
     fn run(&self, ctx: &OpRunContext) -> Result<OutputList, OpError> {
         let _one_at_a_time = self.run_lock.lock().unwrap();
         // inputs -> device, once (host-synchronous copies: no ordering flag needed for the run)
         for (i, b) in self.inputs.iter().enumerate() {
-            let x: TensorView<f32> = ctx.inputs().require_as(i)?;
-            if x.shape() != b.shape.as_slice() {
-                eprintln!("rten-hip: subgraph input \"{}\" was bound with another shape", b.name);
-                return Err(OpError::IncompatibleInputShapes("Input shape does not match the shape the subgraph was planned for"));
+            // one upload per input, in the element type the device graph reads (`require_as` fails with the reference's own cast error for another type)
+            macro_rules! upload {
+                ($t:ty) => {{
+                    let x: TensorView<$t> = ctx.inputs().require_as(i)?;
+                    if x.shape() != b.shape.as_slice() {
+                        eprintln!("rten-hip: subgraph input \"{}\" was bound with another shape", b.name);
+                        return Err(OpError::IncompatibleInputShapes("Input shape does not match the shape the subgraph was planned for"));
+                    }
+                    let host = x.to_contiguous_in(ctx.pool());
+                    let data = host.data().ok_or(OpError::InvalidValue("input is not contiguous"))?;
+                    self.hip.check(unsafe { sys::rten_hip_memcpy_h2d(self.hip.raw(), b.dev, data.as_ptr() as *const c_void, std::mem::size_of_val(data)) })?;
+                }};
             }
-            let host = x.to_contiguous_in(ctx.pool());
-            let data = host.data().ok_or(OpError::InvalidValue("input is not contiguous"))?;
-            self.hip.check(unsafe { sys::rten_hip_memcpy_h2d(self.hip.raw(), b.dev, data.as_ptr() as *const c_void, std::mem::size_of_val(data)) })?;
+            match b.dtype {
+                sys::RTEN_HIP_DTYPE_I32 => upload!(i32),
+                sys::RTEN_HIP_DTYPE_U8 => upload!(u8),
+                sys::RTEN_HIP_DTYPE_I8 => upload!(i8),
+                _ => upload!(f32),
+            }
         }
         // every chain replays its hipGraph; the caller's stream is ordered behind them (flags 0), then waited for
         self.check(unsafe { sys::rten_hip_model_run(self.model, 0) })?;
@@ -190,10 +216,20 @@ impl Operator for HipSubgraph {
             self.check(unsafe { sys::rten_hip_model_output(self.model, i as i32, &mut dev, shape.as_mut_ptr(), &mut ndim) })?;
             let dims: Vec<usize> = shape[..ndim as usize].iter().map(|&d| d as usize).collect();
             let len: usize = dims.iter().product();
-            let mut data: Vec<f32> = ctx.pool().alloc(len);
-            data.resize(len, 0.0);
-            self.hip.check(unsafe { sys::rten_hip_memcpy_d2h(self.hip.raw(), data.as_mut_ptr() as *mut c_void, dev, len * 4) })?;
-            out.push(Tensor::from_data(&dims, data).into());
+            macro_rules! download {
+                ($t:ty, $zero:expr) => {{
+                    let mut data: Vec<$t> = ctx.pool().alloc(len);
+                    data.resize(len, $zero);
+                    self.hip.check(unsafe { sys::rten_hip_memcpy_d2h(self.hip.raw(), data.as_mut_ptr() as *mut c_void, dev, len * std::mem::size_of::<$t>()) })?;
+                    out.push(Tensor::from_data(&dims, data).into());
+                }};
+            }
+            match self.output_dtypes[i] {
+                sys::RTEN_HIP_DTYPE_I32 => download!(i32, 0),
+                sys::RTEN_HIP_DTYPE_U8 => download!(u8, 0),
+                sys::RTEN_HIP_DTYPE_I8 => download!(i8, 0),
+                _ => download!(f32, 0.0),
+            }
         }
         Ok(out)
     }

@@ -50,7 +50,9 @@
 extern "C" {
 #endif
 
-/* v4 (round 5): + rten_hip_device_id, rten_hip_tuning_save / _restore (a library-level caller on a borrowed context puts the owner's knobs back),
+/* v5 (round 5b): + rten_hip_model_input_dtype / rten_hip_model_output_dtype (a host that moves the inputs / outputs of a resident subgraph must know
+ * their element types: BERT-class graphs take integer inputs).
+ * v4 (round 5): + rten_hip_device_id, rten_hip_tuning_save / _restore (a library-level caller on a borrowed context puts the owner's knobs back),
  * rten_hip_model_load_ex (device taken from the context; RTEN_HIP_MODEL_RECEIVE_WEIGHTS), rten_hip_model_load_error, rten_hip_model_clone (replicas that
  * share one weight set: lanes), rten_hip_model_plan_json, rten_hip_model_profile, rten_hip_model_weight_arena (one
  * allocation for every constant of a model: the unit of the one-time RCCL broadcast), plan files may carry {"fused_dql": [...]}, "qout" edges may have
@@ -61,7 +63,7 @@ extern "C" {
  * GEMM variants 24-30 (one wave per tile, two-stage ring, image patches), sticky device fault reported by rten_hip_sync / rten_hip_graph_launch.  v2 (round 3) had added
  * rten_hip_graph_abort, rten_hip_conv2d_int8_qout, rten_hip_grid_sync_*, rten_hip_dynamic_quantize_linear_staged_products, rten_hip_max_pool2d_f32_stats and
  * rten_hip_set_sdpa_path mode 2 WITHOUT a bump: a binding built against this header must refuse a library whose rten_hip_abi_version() differs. */
-#define RTEN_HIP_ABI_VERSION 4
+#define RTEN_HIP_ABI_VERSION 5
 
 /* ---- status codes (map onto OpError variants, src/operator.rs:116-144) ---- */
 #define RTEN_HIP_OK 0
@@ -495,6 +497,14 @@ int32_t rten_hip_model_info(const rten_hip_model *model, int32_t *n_inputs, int3
 const char *rten_hip_model_input_name(const rten_hip_model *model, int32_t i);
 const char *rten_hip_model_output_name(const rten_hip_model *model, int32_t i);
 int32_t rten_hip_model_bind_input(rten_hip_model *model, int32_t i, const int64_t *shape, int32_t ndim, void **dev_ptr);
+/* Element type of input i (as bind_input allocates it) / of output i (after prepare), RTEN_HIP_DTYPE_*.  ONNX int64 graph inputs are I32 on the device, like
+ * every 64-bit index tensor in the reference (rten-onnx narrows them at load: a host hands 32-bit integers over). */
+#define RTEN_HIP_DTYPE_F32 0
+#define RTEN_HIP_DTYPE_I32 1
+#define RTEN_HIP_DTYPE_U8 2
+#define RTEN_HIP_DTYPE_I8 3
+int32_t rten_hip_model_input_dtype(const rten_hip_model *model, int32_t i, int32_t *dtype);
+int32_t rten_hip_model_output_dtype(const rten_hip_model *model, int32_t i, int32_t *dtype);
 /* tune != 0 and no plan file: every f32 convolution step times its candidate launch plans once per distinct sub-batch size. */
 int32_t rten_hip_model_prepare(rten_hip_model *model, int32_t tune);
 /* flags bit 0: the inputs were written on the caller context's stream since the last run (the chains wait for it first); bit 1: do not order the

@@ -544,6 +544,22 @@ RTEN_EXPORT int32_t rten_hip_model_sync(rten_hip_model *g) {
     return RTEN_HIP_OK;
 }
 
+namespace {
+int32_t dtype_code(DType t) { return t == DType::F32 ? RTEN_HIP_DTYPE_F32 : t == DType::I32 ? RTEN_HIP_DTYPE_I32 : t == DType::U8 ? RTEN_HIP_DTYPE_U8 : RTEN_HIP_DTYPE_I8; }
+} // namespace
+
+RTEN_EXPORT int32_t rten_hip_model_input_dtype(const rten_hip_model *g, int32_t i, int32_t *dtype) {
+    if (!g || !dtype || i < 0 || (size_t)i >= g->inputs.size()) return RTEN_HIP_ERR_INVALID_VALUE;
+    *dtype = dtype_code(elem_dtype(g->inputs[(size_t)i].elem_type));
+    return RTEN_HIP_OK;
+}
+
+RTEN_EXPORT int32_t rten_hip_model_output_dtype(const rten_hip_model *g, int32_t i, int32_t *dtype) {
+    if (!g || !dtype || !g->prepared || i < 0 || (size_t)i >= g->full_out.size()) return RTEN_HIP_ERR_INVALID_VALUE;
+    *dtype = dtype_code(g->full_out[(size_t)i]->dtype());
+    return RTEN_HIP_OK;
+}
+
 // Output `i` after a run: device pointer of the resident full-batch tensor, its shape (up to 8 dims) and rank.
 RTEN_EXPORT int32_t rten_hip_model_output(rten_hip_model *g, int32_t i, const void **dev_ptr, int64_t *shape, int32_t *ndim) {
     if (!g || !g->prepared || i < 0 || (size_t)i >= g->full_out.size()) return RTEN_HIP_ERR_INVALID_VALUE;

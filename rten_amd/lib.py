@@ -202,6 +202,8 @@ PROTOTYPES = {
     "rten_hip_model_run": (_I32, [_VP, _U32]),
     "rten_hip_model_sync": (_I32, [_VP]),
     "rten_hip_model_output": (_I32, [_VP, _I32, C.POINTER(_VP), C.POINTER(_I64), C.POINTER(_I32)]),
+    "rten_hip_model_input_dtype": (_I32, [_VP, _I32, C.POINTER(_I32)]),
+    "rten_hip_model_output_dtype": (_I32, [_VP, _I32, C.POINTER(_I32)]),
     "rten_hip_model_destroy": (_I32, [_VP]),
 }
 
@@ -491,6 +493,20 @@ class Model:
         sh = (C.c_int64 * 8)()
         self._check(self.lib.rten_hip_model_output(self.h, i, C.byref(p), sh, C.byref(nd)))
         return p.value, tuple(sh[: nd.value])
+
+    _DTYPES = ("float32", "int32", "uint8", "int8")  # RTEN_HIP_DTYPE_* as numpy dtype names
+
+    def input_dtype(self, i: int = 0):
+        """numpy dtype name of input i on the device (ONNX int64 inputs are int32 there, as in the reference)."""
+        d = _I32()
+        self._check(self.lib.rten_hip_model_input_dtype(self.h, i, C.byref(d)))
+        return self._DTYPES[d.value]
+
+    def output_dtype(self, i: int = 0):
+        """numpy dtype name of output i (after prepare)."""
+        d = _I32()
+        self._check(self.lib.rten_hip_model_output_dtype(self.h, i, C.byref(d)))
+        return self._DTYPES[d.value]
 
     def close(self):
         """Destroys the model.  Chain 0 runs on the context the model was loaded with: that context must still be alive (close models first)."""

@@ -138,9 +138,12 @@ def test_bert_base_batch32_seq128_through_the_model_abi_is_the_oracle():
             m = L.Model(ctx, onnx_bytes, text, 1)
             try:
                 feeds = {"input_ids": ids.astype(np.int32), "token_type_ids": tts.astype(np.int32), "attention_mask": am.astype(np.int32)}
-                for name in m.inputs:
+                for i, name in enumerate(m.inputs):
                     m.bind_input(name, feeds[name].shape)
+                    # the element types a host must hand over (rten_hip_model_input_dtype): ONNX int64 ids / masks are int32 on the device, like in the reference
+                    assert m.input_dtype(i) == "int32", (name, m.input_dtype(i))
                 m.prepare()
+                assert m.output_dtype(0) == "float32"
                 if text:
                     assert m.planned_steps >= 48, m.planned_steps  # 4 products per layer x 12 layers took their plan entry
                 for got in _run(m, ctx, feeds):
