@@ -787,6 +787,8 @@ class Graph {
             // MatMul-family steps (row-major A): the LDS-DMA pipelines with three / four stages x tile order (m fastest / n fastest within an XCD's
             // share: which operand stays L2-resident) -- the candidate set of rten_amd/workloads/bert.py::autotune
             for (int v : {0, 1, 2, 3, 12, 13, 14, 15}) if (v < nvar) for (int o = 0; o < 2; o++) plans.push_back(GemmPlan{true, v, 3, 1, o});
+            // + the small-M weight-streaming kernel (variant 31: one batch, M <= 64; any other call runs it as variant 3, i.e. a duplicate candidate)
+            if (31 < nvar) plans.push_back(GemmPlan{true, 31, 3, 1, 0});
         } else {
         const Tensor &w = require(in, 1);
         const int64_t k = w.len() / std::max<int64_t>(w.size(0), 1); // per-group depth C/g * kh * kw
