@@ -18,15 +18,19 @@ steps (both synchronisation points cover every stream of every lane); `ms_per_st
 `--chains C` alone gives round 4's schedule (one replica, C sub-batch chains).  One process per GPU; batches are independent, so the path shards with no
 data-path collective (weak scaling: 32 images per GPU); the only collective is the one-time RCCL broadcast of the model's weight arena from rank 0.
 
-Rank 0 prints ONE JSON line: metric/value (whole-job inferences/s); `roofline` -- f32: achieved / frac = the conv FLOPs of one batch over the
-TIMED step (every kernel and gap included), with the dominant kernel's stand-alone figures (HIP events per launch, an instrumented eager pass outside the
-timed region) as `dominant_kernel` / `igemm_family`, its HBM traffic from the committed PMC pass when that pass ran the same launch plan, and `shapes`
-(every distinct conv shape stand-alone with its attainable bound); int8: the dominant kernel against the HBM peak plus the whole step
-against the graph's HBM floor -- ; and cpu_baseline (the CPU oracle -- a port of the reference algorithm -- timed on this host's cores on a
-bounded sample; N=1 only).  At N=1 the line also carries `secondary`: the int8 ResNet-50 (configs[2]) and BERT-base (configs[3])
-harnesses run in child processes after the headline measurement.  The per-layer launch plan is the one committed under profiles/plans/
-(`--autotune` re-tunes: rank 0 tunes, the plan is broadcast; `config.launch_plan` names what ran).  Defaults: K = 50, W = 20 (the chip needs about 20 ms of
-load to settle its clocks; a run with the driver's own K / W is timed exactly as given).
+Rank 0 prints ONE COMPACT JSON line (at most 4096 bytes: `compact_line`; the driver keeps a bounded tail of stdout, and round 5's 23 KB line came back
+unparsed) as the LAST thing on stdout: the contract fields, `roofline` -- f32: achieved / frac = the conv FLOPs of one batch over the TIMED step (every kernel
+and gap included) with the dominant kernel's stand-alone figures (HIP events per launch, an instrumented eager pass outside the timed region) as
+`dominant_kernel` and its HBM traffic from the committed PMC pass when that pass ran the same launch plan; int8: the dominant kernel against the HBM peak plus
+the whole step against the graph's HBM floor (`step`) --, `cpu_baseline` (the CPU oracle -- a port of the reference algorithm -- timed on this host's cores on a
+bounded sample; N=1 only) and, at N=1, a few numbers per `secondary` config: the f32 batch as 4 chains on one replica (the latency-optimal schedule:
+`p50_latency_ms_4chains`), the int8 ResNet-50 (configs[2]), BERT-base (configs[3]) and the batch-1 latencies (configs[0]), each run in a child process after the
+headline measurement.  The FULL record (per-shape table `roofline.shapes`, per-variant tables, notes, per-rank lists, the PCIe-inclusive pass, every secondary
+line whole) goes to the detail file the line names (`detail`: gpurun_out/bench_detail.json, or --detail-file).
+`ms_per_step` is, in every round-6 line, wall time of the K timed steps / K on the default schedule (lanes: consecutive batches overlap), i.e. a THROUGHPUT
+figure; the time of ONE batch alone is `ms_per_step_joined_every_step` / `p50_latency_ms` (DESIGN.md section 6 fixes these definitions).
+The per-layer launch plan is the one committed under profiles/plans/ (`--autotune` re-tunes: rank 0 tunes, the plan is broadcast; `config.launch_plan` names
+what ran).  Defaults: K = 50, W = 20 (the chip needs about 20 ms of load to settle its clocks; a run with the driver's own K / W is timed exactly as given).
 """
 import argparse
 import json
@@ -58,6 +62,131 @@ BATCH_PER_GPU = 32
 # 1.502 / 1.052 / 0.971 / 0.950 ms per batch; f32 one chain x 2 lanes 2.494 ms against 2.677 ms for one replica running the batch as 4 sub-batch chains
 INT8_DEFAULT_LANES = 4
 F32_DEFAULT_LANES = 2   # ... of ONE chain each (whole-batch launches: the best per-layer efficiency), unless --chains is given
+
+
+LINE_LIMIT = 4096   # the driver keeps a bounded tail of stdout: the final line must fit it whole (round 5's 23 KB line came back `parsed: null`)
+
+
+def _sanitize(o):
+    """JSON has no NaN / Infinity: they become null (json.dumps would print the bare words, which strict parsers reject)."""
+    if isinstance(o, float):
+        return o if o == o and o not in (float("inf"), float("-inf")) else None
+    if isinstance(o, dict):
+        return {str(k): _sanitize(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_sanitize(v) for v in o]
+    if isinstance(o, (np.floating, np.integer)):
+        return _sanitize(o.item())
+    return o
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _compact_roofline(r):
+    if not isinstance(r, dict):
+        return None
+    c = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic"))
+    c.setdefault("traffic", None)
+    if isinstance(r.get("dominant_kernel"), dict):  # f32: stand-alone figures of the dominant kernel (HIP events per launch) beside the whole-step fraction
+        c["dominant_kernel"] = _pick(r["dominant_kernel"], ("achieved", "frac", "avg_launch_us", "launches"))
+    elif "avg_launch_us" in r:
+        c["avg_launch_us"] = r["avg_launch_us"]
+    if isinstance(r.get("step"), dict):             # int8: the whole timed step against the HBM floor of the graph
+        c["step"] = _pick(r["step"], ("algorithmic_bytes", "achieved", "frac"))
+    if isinstance(r.get("mfma"), dict):
+        c["mfma_frac"] = r["mfma"].get("frac")
+    for k in ("gemm_family", "fused_attention", "rowwise"):  # BERT: the three kernel classes, fraction of their own bound
+        if isinstance(r.get(k), dict):
+            c[k + "_frac"] = r[k].get("frac")
+    return c
+
+
+def _compact_cpu(c):
+    if not isinstance(c, dict):
+        return None
+    o = _pick(c, ("value", "unit", "cores", "kind"))
+    if "sample" in c:
+        o["sample"] = str(c["sample"])[:120]
+    if isinstance(c.get("other_cpu_implementation"), dict):
+        o["pytorch_cpu_value"] = c["other_cpu_implementation"].get("value")
+    return o
+
+
+def compact_line(out, detail_path=None):
+    """The ONE line the driver parses: every contract field, the roofline / cpu_baseline objects and a few numbers per secondary config -- at most
+    LINE_LIMIT bytes.  Everything else (`roofline.shapes`, per-variant tables, notes, per-rank lists, the PCIe-inclusive pass) lives in the detail file."""
+    cfg = out.get("config") or {}
+    lp = cfg.get("launch_plan") or {}
+    lanes = (cfg.get("batch_lanes") or {}).get("lanes", lp.get("lanes"))
+    chains = (cfg.get("batch_chains") or {}).get("chains", lp.get("chains"))
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_joined_every_step", "p50_latency_ms",
+                                "p50_latency_ms_4chains", "higher_is_better", "scaling", "vs_baseline", "dtype", "data") if k in out}
+    line["config"] = {"workload": str(cfg.get("workload", ""))[:260], "path": cfg.get("path"), "lanes": lanes, "chains": chains,
+                      "global_batch": cfg.get("global_batch"), "parallelism": cfg.get("parallelism"), "launch": cfg.get("launch"),
+                      "launch_plan": _pick(lp, ("source", "sha16", "identical_on_all_ranks"))}
+    rk = out.get("ranks")
+    if isinstance(rk, dict):
+        line["ranks"] = {"world_size": rk.get("world_size"), "dist_backend": rk.get("dist_backend"), "weight_broadcast_world": rk.get("weight_broadcast_world"),
+                         "ms_per_step_per_rank": rk.get("ms_per_step_per_rank"), "distinct_plans": len(set(map(str, rk.get("plan_sha16_per_rank") or [])))}
+    line["roofline"] = _compact_roofline(out.get("roofline"))
+    line["cpu_baseline"] = _compact_cpu(out.get("cpu_baseline"))
+    if isinstance(out.get("pcie_inclusive"), dict):
+        line["pcie_inclusive_ms_per_step"] = out["pcie_inclusive"].get("ms_per_step")
+    if isinstance(out.get("secondary"), dict):
+        sec = {}
+        for name, s in out["secondary"].items():
+            if not isinstance(s, dict):
+                continue
+            if "error" in s:
+                sec[name] = {"error": str(s["error"])[:160]}
+                continue
+            e = _pick(s, ("value", "unit", "ms_per_step", "ms_per_step_joined_every_step", "ms_per_step_back_to_back", "p50_latency_ms", "dtype"))
+            scfg = s.get("config") or {}
+            e["lanes"] = (scfg.get("batch_lanes") or {}).get("lanes", scfg.get("lanes", (scfg.get("launch_plan") or {}).get("lanes")))
+            e["plan_sha16"] = (scfg.get("launch_plan") or {}).get("sha16")
+            if s.get("roofline"):
+                e["roofline"] = _compact_roofline(s["roofline"])
+            if s.get("cpu_baseline"):
+                e["cpu_baseline"] = _pick(s["cpu_baseline"], ("value", "unit", "cores", "kind"))
+            sec[name] = {k: v for k, v in e.items() if v is not None}
+        line["secondary"] = sec
+    if detail_path:
+        line["detail"] = detail_path
+    line = _sanitize(line)
+    # the size is a CONTRACT: shed optional parts, least important first, until the line fits
+    text = json.dumps(line, separators=(",", ":"), allow_nan=False)
+    for shed in (("secondary", "*", "cpu_baseline", "unit"), ("secondary", "*", "dtype"), ("cpu_baseline", "sample"), ("secondary", "*", "roofline", "kernel"),
+                 ("ranks", "ms_per_step_per_rank"), ("config", "workload"), ("secondary",)):
+        if len(text) <= LINE_LIMIT:
+            break
+        tgt = [line]
+        for key in shed[:-1]:
+            tgt = [v for t in tgt if isinstance(t, dict) for v in (t.values() if key == "*" else [t.get(key)])]
+        for t in tgt:
+            if isinstance(t, dict):
+                t.pop(shed[-1], None)
+        text = json.dumps(line, separators=(",", ":"), allow_nan=False)
+    assert len(text) <= LINE_LIMIT, len(text)
+    return text
+
+
+def emit(out, args, key=None):
+    """Writes the full record to the detail file and prints the compact line (last thing on stdout)."""
+    path = args.detail_file or os.path.join(ROOT, "gpurun_out", f"bench_detail{'_' + key if key else ''}.json")
+    rel = None
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(_sanitize(out), f, indent=1)
+        rel = os.path.relpath(os.path.abspath(path), ROOT)
+        if rel.startswith(".."):
+            rel = os.path.abspath(path)
+    except OSError as e:  # a read-only tree loses the detail, never the line
+        print(f"bench.py: could not write {path}: {e}", file=sys.stderr)
+    sys.stdout.flush()
+    print(compact_line(out, rel), flush=True)
 
 
 def cpu_baseline(specs, weights, budget_s=12.0):
@@ -241,7 +370,11 @@ def secondary_configs():
     import subprocess
     root = os.path.dirname(os.path.abspath(__file__))
     res = {}
-    jobs = (("resnet50_int8_b32", [os.path.join(root, "bench.py"), "--config", "int8", "--no-secondary"]),
+    # the latency-optimal f32 schedule beside the throughput one: ONE replica running the batch as 4 sub-batch chains (round 4's schedule, its own committed
+    # plan), in a process of its own (idle lane streams beside the four chains cost it 25 %: 3.5 vs 2.7-2.8 ms)
+    jobs = (("resnet50_f32_b32_4chains_1lane", [os.path.join(root, "bench.py"), "--chains", "4", "--lanes", "1", "--no-secondary", "--no-cpu-baseline", "--no-shapes",
+                                                "--detail-file", os.path.join(root, "gpurun_out", "bench_detail_f32_4chains.json")]),
+            ("resnet50_int8_b32", [os.path.join(root, "bench.py"), "--config", "int8", "--no-secondary"]),
             ("bert_base_f32_b32_s128", [os.path.join(root, "tools", "bench_bert.py")]),
             ("resnet50_f32_b1_latency", [os.path.join(root, "tools", "bench_resnet50_b1.py")]),
             ("resnet50_int8_b1_latency", [os.path.join(root, "tools", "bench_resnet50_b1.py"), "--config", "int8"]))
@@ -251,10 +384,12 @@ def secondary_configs():
             p = subprocess.run([sys.executable] + cmd, capture_output=True, text=True, timeout=420, cwd=root, env=env)
             line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
             j = json.loads(line)
-            if key == "resnet50_int8_b32":
-                res[key] = {k: j[k] for k in ("metric", "value", "unit", "ms_per_step", "p50_latency_ms", "dtype", "config", "roofline", "cpu_baseline") if k in j}
-                continue
-            res[key] = {k: j[k] for k in ("metric", "value", "unit", "ms_per_step", "p50_latency_ms", "ms_per_step_back_to_back", "dtype", "config", "roofline", "cpu_baseline") if k in j}
+            if j.get("detail"):  # a child that prints a compact line of its own (bench.py --config int8) keeps its full record in a file
+                dpath = j["detail"] if os.path.isabs(j["detail"]) else os.path.join(root, j["detail"])
+                if os.path.exists(dpath):
+                    j = json.load(open(dpath))
+            res[key] = {k: j[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "ms_per_step_joined_every_step", "p50_latency_ms", "ms_per_step_back_to_back",
+                                          "dtype", "config", "roofline", "cpu_baseline") if k in j}
         except Exception as e:  # noqa: BLE001
             res[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
     return res
@@ -698,7 +833,10 @@ def run_via_executor(args):
             out["cpu_baseline"] = None
         if world == 1 and not args.no_secondary and not int8 and not DRY:
             out["secondary"] = secondary_configs()
-        print(json.dumps(out))
+            four = out["secondary"].get("resnet50_f32_b32_4chains_1lane") or {}
+            if "p50_latency_ms" in four:
+                out["p50_latency_ms_4chains"] = four["p50_latency_ms"]
+        emit(out, args, key="int8" if int8 else None)
     if DRY:
         import collections
         c = collections.Counter(ctx.log)
@@ -760,6 +898,7 @@ def parse_args():
                          "that step k + 1 overlaps step k (default: 4 for int8, whose graph cannot be split into sub-batch chains; 2 for f32 with one chain each; "
                          "1 when --chains is given).  A throughput schedule: `p50_latency_ms` stays the latency of ONE batch on one replica")
     ap.add_argument("--no-shapes", action="store_true", help="f32: skip the stand-alone per-shape table (`roofline.shapes`)")
+    ap.add_argument("--detail-file", default=None, help="where the full record goes (default gpurun_out/bench_detail[_<config>].json); the printed line stays compact")
     ap.add_argument("--recording-test", action="store_true",
                     help="control-flow test mode (tests/test_bench_world8.py): together with RTEN_BENCH_RECORDING=1, launches are recorded instead of issued")
     return ap.parse_args()
@@ -1171,7 +1310,7 @@ def run_via_runner(args):
             out["cpu_baseline"] = None
         if n_gpus == 1 and world == 1 and not args.no_secondary and not int8:
             out["secondary"] = secondary_configs()
-        print(json.dumps(out))
+        emit(out, args, key=args.config + "_runner")
     if DRY:
         import collections
         c = collections.Counter(ctx.log)

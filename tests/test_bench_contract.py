@@ -117,3 +117,73 @@ def test_the_lanes_plan_is_the_one_chain_plan_plus_the_classifier_entry():
     one, lanes = json.load(open(os.path.join(plans, "f32_1chain.json"))), json.load(open(os.path.join(plans, "f32_lanes.json")))
     assert {k: v for k, v in lanes.items() if k != "fc"} == one
     assert lanes["fc"] == [3, 3, 1, 0]
+
+
+def _recorded_full_lines():
+    """Full (pre-compaction) records of earlier GPU runs kept under profiles/: the inputs the compact line is built from."""
+    import glob
+    import json
+    out = []
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[6-9]", "bench*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r1*", "bench*detail*.json"))):
+        try:
+            text = open(path).read().strip()
+            j = json.loads(text if text.startswith("{") and "\n{" not in text else [l for l in text.splitlines() if l.startswith("{")][-1])
+        except Exception:  # noqa: BLE001
+            continue
+        if isinstance(j, dict) and "metric" in j and "value" in j:
+            out.append((os.path.relpath(path, ROOT), j))
+    return out
+
+
+def test_the_printed_line_is_compact_and_complete():
+    """The driver keeps a bounded tail of stdout (round 5: a 23 KB line came back `parsed: null`).  The line rank 0 prints is built from the full record by
+    bench.compact_line: at most 4096 bytes, strict JSON (no NaN / Infinity), with every contract field plus `roofline` and `cpu_baseline`."""
+    sys.path.insert(0, ROOT)
+    import json
+    import bench
+    records = _recorded_full_lines()
+    assert len(records) >= 3, records
+    biggest = 0
+    for path, full in records:
+        biggest = max(biggest, len(json.dumps(full)))
+        text = bench.compact_line(full, "gpurun_out/bench_detail.json")
+        assert len(text) <= bench.LINE_LIMIT == 4096, (path, len(text))
+        assert "NaN" not in text and "Infinity" not in text
+        line = json.loads(text)
+        assert json.loads(json.dumps(line)) == line
+        for k in ("metric", "value", "unit", "n_gpus", "ms_per_step", "dtype"):
+            assert line[k] == full[k], (path, k)
+        assert line["detail"] == "gpurun_out/bench_detail.json"
+        if full.get("roofline"):
+            r = line["roofline"]
+            assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(r), (path, r)
+            assert r["frac"] == full["roofline"]["frac"]
+        if full.get("cpu_baseline"):
+            assert {"value", "unit", "cores", "kind"} <= set(line["cpu_baseline"]), path
+        for name, sec in (full.get("secondary") or {}).items():
+            if "error" in sec:
+                continue
+            assert line["secondary"][name]["value"] == sec["value"], (path, name)
+            if sec.get("roofline"):
+                assert line["secondary"][name]["roofline"]["frac"] == sec["roofline"]["frac"]
+            if sec.get("cpu_baseline"):
+                assert line["secondary"][name]["cpu_baseline"]["value"] == sec["cpu_baseline"]["value"]
+    assert biggest > 20000  # round 5's 23 KB record is among the inputs: the case that broke the driver's parse
+
+
+def test_compact_line_survives_hostile_records():
+    """NaN / Infinity become null; a record that is still too long sheds its optional parts (secondary last) instead of overflowing."""
+    sys.path.insert(0, ROOT)
+    import json
+    import bench
+    full = {"metric": "m", "value": float("nan"), "unit": "u", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": float("inf"), "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "w" * 5000, "launch_plan": {"source": "s", "sha16": "0" * 16}},
+            "roofline": {"bound": "mfma", "achieved": 1.0, "peak": 2.0, "unit": "TFLOP/s", "frac": 0.5, "traffic": None, "kernel": "k" * 300, "shapes": [{"x": 1}] * 500},
+            "cpu_baseline": {"value": 1.0, "unit": "u", "cores": 2, "kind": "port", "sample": "s" * 1000},
+            "secondary": {f"cfg{i}": {"value": 1.0, "unit": "u", "ms_per_step": 1.0, "roofline": {"bound": "hbm", "frac": 0.1, "kernel": "k" * 400},
+                                      "cpu_baseline": {"value": 1.0, "unit": "u", "cores": 1, "kind": "port"}} for i in range(12)}}
+    text = bench.compact_line(full)
+    assert len(text) <= 4096
+    line = json.loads(text)
+    assert line["value"] is None and line["ms_per_step"] is None
+    assert line["roofline"]["frac"] == 0.5 and line["cpu_baseline"]["value"] == 1.0

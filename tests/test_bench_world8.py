@@ -17,9 +17,27 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _run(world, config, port, extra=()):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env.update(RTEN_BENCH_RECORDING="1", PYTHONPATH=ROOT + os.pathsep + env.get("PYTHONPATH", ""), OMP_NUM_THREADS="1")
+    import tempfile
+    detail = os.path.join(tempfile.mkdtemp(prefix="rten_bench_"), "detail.json")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--config", config, "--recording-test", *extra]
-    return subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+           os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--config", config, "--recording-test", "--detail-file", detail, *extra]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    r.detail_path = detail
+    return r
+
+
+def _line_and_detail(r):
+    """The ONE compact line rank 0 prints (what the driver parses: at most 4 KB) and the full record it points to."""
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    assert len(lines[0]) <= 4096
+    line = json.loads(lines[0])
+    assert line["detail"] == r.detail_path
+    full = json.load(open(r.detail_path))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "dtype", "data"):
+        assert line[k] == full[k], k
+    assert line["config"]["launch_plan"]["sha16"] == full["config"]["launch_plan"]["sha16"]
+    return line, full
 
 
 @pytest.mark.parametrize("config", ["int8", "f32"])
@@ -28,9 +46,9 @@ def test_eight_rank_bench_control_flow_of_the_default_path(config):
     one broadcast, the committed plan on every rank, per-rank seeds, ONE aggregate line that says which path ran."""
     r = _run(8, config, 29615 if config == "int8" else 29617)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    j = json.loads(lines[0])
+    line, j = _line_and_detail(r)
+    assert line["config"]["path"] == "executor" and line["config"]["lanes"] == (4 if config == "int8" else 2) and line["config"]["chains"] == 1
+    assert line["ranks"]["world_size"] == 8 and line["ranks"]["distinct_plans"] == 1 and len(line["ranks"]["ms_per_step_per_rank"]) == 8
     assert j["config"]["path"] == "executor" and j["n_gpus"] == 8 and j["config"]["global_batch"] == 256 and j["scaling"] == "weak" and j["steps"] == 3
     assert j["data"].startswith("recording") and j["cpu_baseline"] is None and "secondary" not in j
     rk = j["ranks"]
@@ -68,9 +86,8 @@ def test_eight_rank_bench_control_flow(config):
     from rten_amd.workloads import resnet50, resnet50_int8
     r = _run(8, config, 29611 if config == "int8" else 29613, extra=("--via-runner",))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 prints ONE line
-    j = json.loads(lines[0])
+    line, j = _line_and_detail(r)  # rank 0 prints ONE line
+    assert line["config"]["path"] == "runner"
     assert j["n_gpus"] == 8 and j["config"]["global_batch"] == 256 and j["scaling"] == "weak" and j["steps"] == 3 and j["warmup"] == 1
     assert j["data"].startswith("recording") and j["cpu_baseline"] is None and "secondary" not in j
     rk = j["ranks"]

@@ -31,8 +31,10 @@ def test_bench_two_ranks_prints_one_line(config):
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    j = json.loads(lines[0])
+    assert len(lines) == 1 and len(lines[0]) <= 4096, r.stdout[-2000:]
+    line = json.loads(lines[0])  # the compact line the driver parses ...
+    assert line["n_gpus"] == 2 and line["ranks"]["world_size"] == 2 and line["ranks"]["distinct_plans"] == 1 and line["config"]["lanes"] == (2 if config == "f32" else 4)
+    j = json.load(open(os.path.join(ROOT, line["detail"])))  # ... and the full record it points to
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 64 and j["scaling"] == "weak"
     assert j["ranks"]["world_size"] == 2 and len(j["ranks"]["ms_per_step_per_rank"]) == 2 and j["ranks"]["weight_broadcast_world"] == 2
     assert j["cpu_baseline"] is None and j["roofline"]["frac"] > 0
@@ -61,6 +63,7 @@ def test_bench_two_ranks_tuning_run_broadcasts_one_plan():
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    j = json.load(open(os.path.join(ROOT, j["detail"])))
     shas = j["ranks"]["plan_sha16_per_rank"]
     assert len(shas) == 2 and shas[0] == shas[1] and shas[0] is not None
     assert "rank 0" in j["config"]["launch_plan"]["source"]
