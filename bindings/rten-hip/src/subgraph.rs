@@ -6,8 +6,8 @@
 //! The graph behind this operator is the C++ plan executor exported through the C ABI as `rten_hip_model_*` (include/rten_hip.h;
 //! rten_amd/csrc/graph_abi.cpp): ONNX bytes in, constants uploaded and prepacked once, the reference's fusions applied, a committed launch plan
 //! (profiles/plans/*.json) by step name, the batch run as `chains` independent dim-0 slices on their own streams, each a hipGraph.  `bench.py`
-//! (its default path since round 5) measures exactly this path (ResNet-50 f32 batch 32: 2.72 ms; the hand-planned runner: 2.73 ms on the same box;
-//! same logits).
+//! (its default path since round 5) measures exactly this path (ResNet-50 f32 batch 32 as 4 chains on one replica: 2.68 ms, the hand-planned runner the
+//! same within 0.01 ms on the same box, same logits; the default line -- one chain per replica, two replicas -- 2.51-2.56 ms: DESIGN.md section 2).
 //! `install.rs` puts one of these in place of a loaded model's whole graph (`rten_hip::load_resident`).
 //!
 //! NOT COMPILED in the build image -- see lib.rs.  tests/test_abi.py checks that every `sys::` name used here exists in the generated -sys crate

@@ -50,7 +50,11 @@
 extern "C" {
 #endif
 
-/* v5 (round 5b): + rten_hip_model_input_dtype / rten_hip_model_output_dtype (a host that moves the inputs / outputs of a resident subgraph must know
+/* v6 (round 6): + rten_hip_elementwise_nd (Cast / Not / And / Or / Xor / Equal / Less.. / Where / integer arithmetic over strided operands),
+ * rten_hip_gather_axis_b32, rten_hip_copy_rows_b32, rten_hip_tanh_f32, rten_hip_capture_active -- the layout / logic operators an exporter-written
+ * transformer graph carries around its hot-path operators (src/ops/convert.rs, binary_elementwise.rs, gather.rs, concat.rs); rten_hip_model_clone
+ * refuses a model whose plan lists quantized-output edges.
+ * v5 (round 5b): + rten_hip_model_input_dtype / rten_hip_model_output_dtype (a host that moves the inputs / outputs of a resident subgraph must know
  * their element types: BERT-class graphs take integer inputs).
  * v4 (round 5): + rten_hip_device_id, rten_hip_tuning_save / _restore (a library-level caller on a borrowed context puts the owner's knobs back),
  * rten_hip_model_load_ex (device taken from the context; RTEN_HIP_MODEL_RECEIVE_WEIGHTS), rten_hip_model_load_error, rten_hip_model_clone (replicas that
@@ -63,7 +67,7 @@ extern "C" {
  * GEMM variants 24-30 (one wave per tile, two-stage ring, image patches), sticky device fault reported by rten_hip_sync / rten_hip_graph_launch.  v2 (round 3) had added
  * rten_hip_graph_abort, rten_hip_conv2d_int8_qout, rten_hip_grid_sync_*, rten_hip_dynamic_quantize_linear_staged_products, rten_hip_max_pool2d_f32_stats and
  * rten_hip_set_sdpa_path mode 2 WITHOUT a bump: a binding built against this header must refuse a library whose rten_hip_abi_version() differs. */
-#define RTEN_HIP_ABI_VERSION 5
+#define RTEN_HIP_ABI_VERSION 6
 
 /* ---- status codes (map onto OpError variants, src/operator.rs:116-144) ---- */
 #define RTEN_HIP_OK 0
@@ -373,6 +377,9 @@ int32_t rten_hip_batch_norm_f32(rten_hip_ctx *ctx, int32_t n, int32_t c, int64_t
 int32_t rten_hip_relu_f32(rten_hip_ctx *ctx, int64_t n, const float *x, float *y);
 int32_t rten_hip_gelu_f32(rten_hip_ctx *ctx, int64_t n, const float *x, float *y);
 int32_t rten_hip_erf_f32(rten_hip_ctx *ctx, int64_t n, const float *x, float *y);
+/* Tanh (rten-vecmath/src/tanh.rs:12-72: odd polynomial below 0.55, (exp(2|x|) - 1) / (exp(2|x|) + 1) above, 1 from 9.02), bit-identical to the reference's
+ * AVX-512 / AVX2 form (sign handled as bit operations: tanh(+0) = -0 there). */
+int32_t rten_hip_tanh_f32(rten_hip_ctx *ctx, int64_t n, const float *x, float *y);
 /* y[i] = a[i] + b[i % b_len] (b_len == n: same shape; b_len < n: trailing-dims broadcast) */
 int32_t rten_hip_add_f32(rten_hip_ctx *ctx, int64_t n, const float *a, const float *b, int64_t b_len, float *y);
 int32_t rten_hip_mul_f32(rten_hip_ctx *ctx, int64_t n, const float *a, const float *b, int64_t b_len, float *y);
@@ -389,6 +396,46 @@ int32_t rten_hip_transpose_b32(rten_hip_ctx *ctx, int32_t ndim, const int64_t *x
  * diagonal): TensorView::to_tensor / to_contiguous / expand_to of the permuted, diagonal and expanded views that Einsum
  * builds (src/ops/einsum.rs:124-162,255-257,320-329,534-535). */
 int32_t rten_hip_copy_strided_b32(rten_hip_ctx *ctx, int32_t ndim, const int64_t *shape, const int64_t *x_strides, const void *x, void *y);
+/* Layout / logic operators of exporter-written graphs over operands viewed through element strides (0 = broadcast axis; shape[ndim], ndim <= 6; y is
+ * contiguous).  Booleans are int32 0 / 1, as in the reference (onnx_loader.rs:332-339 narrows BOOL to Int32).
+ *   RTEN_HIP_EW_CAST                  y = a as y_dtype (src/ops/convert.rs:18-60; Rust `as`: float -> int truncates toward zero, saturates, NaN -> 0;
+ *                                     int -> narrower int wraps).  Every pair of float32 / int32 / uint8 / int8 except same-type (a plain copy).
+ *   RTEN_HIP_EW_NOT / AND / OR / XOR  int32 operands, int32 0 / 1 result (unary_elementwise.rs:563-565, binary_elementwise.rs:546-598)
+ *   RTEN_HIP_EW_EQUAL .. GREATER_EQ   two float32 or two int32 operands, int32 0 / 1 result (binary_elementwise.rs:733-786)
+ *   RTEN_HIP_EW_WHERE                 y = a != 0 ? b : c; a int32, b / c / y 4-byte elements of one type (binary_elementwise.rs:1189-1247)
+ *   RTEN_HIP_EW_IADD / ISUB / IMUL / IDIV   int32 arithmetic (wrapping; division truncates toward zero; x / 0 = 0 on the device -- the reference
+ *                                     panics -- so hosts reject a constant zero divisor)
+ * Operands an operator does not take are NULL.  Mask and index preparation, never a model's critical path: one scalar kernel, no vector forms. */
+#define RTEN_HIP_DT_F32 0
+#define RTEN_HIP_DT_I32 1
+#define RTEN_HIP_DT_U8 2
+#define RTEN_HIP_DT_I8 3
+#define RTEN_HIP_EW_CAST 0
+#define RTEN_HIP_EW_NOT 1
+#define RTEN_HIP_EW_AND 2
+#define RTEN_HIP_EW_OR 3
+#define RTEN_HIP_EW_XOR 4
+#define RTEN_HIP_EW_EQUAL 5
+#define RTEN_HIP_EW_LESS 6
+#define RTEN_HIP_EW_LESS_EQ 7
+#define RTEN_HIP_EW_GREATER 8
+#define RTEN_HIP_EW_GREATER_EQ 9
+#define RTEN_HIP_EW_WHERE 10
+#define RTEN_HIP_EW_IADD 11
+#define RTEN_HIP_EW_ISUB 12
+#define RTEN_HIP_EW_IMUL 13
+#define RTEN_HIP_EW_IDIV 14
+int32_t rten_hip_elementwise_nd(rten_hip_ctx *ctx, int32_t op, int32_t ndim, const int64_t *shape, const void *a, int32_t a_dtype, const int64_t *a_strides,
+                                const void *b, int32_t b_dtype, const int64_t *b_strides, const void *c, const int64_t *c_strides, void *y, int32_t y_dtype);
+/* Gather along any axis of 4-byte elements (src/ops/gather.rs:21-110): y[o][j][k] = data[o][ids[j]][k] with data viewed as [outer][axis_len][inner];
+ * negative indices count from the end; out-of-range indices are clamped (the reference reports "Entry in indices is out of range"). */
+int32_t rten_hip_gather_axis_b32(rten_hip_ctx *ctx, int64_t outer, int64_t axis_len, int64_t inner, int64_t n_ids, const void *data, const int32_t *ids, void *y);
+/* rows x row_elems 4-byte elements from src (row pitch src_pitch elements) to dst (row pitch dst_pitch >= row_elems): one piece of a Concat
+ * (src/ops/concat.rs:108) written into its slot of the output. */
+int32_t rten_hip_copy_rows_b32(rten_hip_ctx *ctx, int64_t rows, int64_t row_elems, const void *src, int64_t src_pitch, void *dst, int64_t dst_pitch);
+/* 1 while a graph capture is active on `ctx` (rten_hip_graph_begin .. _end): host code must not upload from host memory then -- the copy would be
+ * recorded with the host pointer and re-read at every replay. */
+int32_t rten_hip_capture_active(rten_hip_ctx *ctx);
 /* ReduceSum of a strided view (reduce_sum, src/ops/reduce.rs:414-520,1101-1124; vecmath::Sum, rten-vecmath/src/sum.rs:12-34):
  * y[r] (r = row-major index over the kept dims outer_shape[n_outer]) = sum of the slice spanned by the reduced dims
  * inner_shape[n_inner] walked in row-major order -- the order the reference packs a non-contiguous slice in -- added in the
@@ -526,7 +573,9 @@ int32_t rten_hip_model_weight_arena(rten_hip_model *model, void **dev_ptr, size_
 /* Another replica of `model` on `ctx` (same device; `ctx` outlives the replica): the same graph / plan / options, its own buffers, streams and hipGraphs,
  * and the ORIGIN's constants and prepacked weights -- no second copy of the weight arena.  Independent batches handed to different replicas overlap on
  * the device ("lanes": bench.py --lanes; the batch-level analogue of sub-batch chains, and the only one a batch-coupled graph -- the dynamically
- * quantized one -- can use).  Bind inputs and prepare a replica like any model; destroy replicas before their origin (destroy(origin) refuses). */
+ * quantized one -- can use).  Bind inputs and prepare a replica like any model; destroy replicas before their origin (destroy(origin) refuses).
+ * RTEN_HIP_ERR_INVALID_VALUE (reason in rten_hip_model_load_error) when the origin's plan lists quantized-output edges ("qout"): those launches are
+ * grid-wide exchanges that need the device to themselves, and replicas run side by side -- the rule rten_hip_model_load_ex applies to chains != 1. */
 int32_t rten_hip_model_clone(rten_hip_model *model, rten_hip_ctx *ctx, rten_hip_model **out_model);
 /* The launch plan a prepared model runs under, as plan-file text keyed by sub-batch size (what prepare(tune = 1) chose / the plan file gave): f32
  * convolution steps AND MatMul / FusedMatMul / Gemm steps (v4: the latter take plan entries and are tuned too).  `*needed` = bytes incl. terminator. */

@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <fstream>
 #include <set>
@@ -285,6 +286,217 @@ inline Model load(const std::string &path) {
 }
 
 } // namespace onnx
+
+
+// ======================================================================================================== shape arithmetic on the host
+// Exporter-written graphs (PyTorch / transformers: dynamic-axis `view`s, position-id slices, attention-mask expansion) carry subgraphs whose VALUES depend only
+// on input SHAPES and constants: Shape -> Gather -> Unsqueeze -> Concat -> Reshape, ConstantOfShape -> NonZero (an arange), index arithmetic, comparisons.
+// The reference folds them at load against its symbolic shapes (`propagate_constants`, src/optimize.rs:705; shape inference in src/infer_shapes.rs).  This
+// executor has no shape inference: it evaluates them ON THE HOST while a run walks the plan -- a step whose operands all carry a HostVal computes its result
+// on the host and attaches it to a (cached) device copy; Reshape / Expand / Slice / ConstantOfShape read their shape operands from the HostVal.  Shapes are
+// fixed between `prepare` and the next `bind_input`, so the cached device copies are made once, in the eager warm-up run, and a captured hipGraph contains
+// none of this.  Semantics follow the reference's operators (int32 everywhere: onnx_loader.rs:332-339; wrapping integer arithmetic; booleans 0 / 1).
+namespace hostops {
+constexpr int64_t kMaxHostElems = (int64_t)1 << 22; // beyond this a value is not worth mirroring on the host
+
+inline int64_t wrap32(int64_t v) { return (int64_t)(int32_t)(uint32_t)(uint64_t)v; }
+inline std::vector<int64_t> strides_for(const std::vector<int64_t> &shape, const std::vector<int64_t> &out) { // broadcast strides of `shape` on `out`
+    std::vector<int64_t> st(out.size(), 0);
+    int64_t acc = 1;
+    for (size_t i = shape.size(); i-- > 0;) { st[out.size() - shape.size() + i] = shape[i] == 1 ? 0 : acc; acc *= shape[i]; }
+    return st;
+}
+inline std::vector<int64_t> bshape(const std::vector<const HostVal *> &v) {
+    std::vector<const std::vector<int64_t> *> sh;
+    for (auto *x : v) sh.push_back(&x->shape);
+    return broadcast_shapes(sh).shape;
+}
+// calls f(out_index, offsets[k]) for every element of the broadcast shape
+template <typename F> void for_each_broadcast(const std::vector<int64_t> &out, const std::vector<std::vector<int64_t>> &st, F f) {
+    int64_t n = 1;
+    for (int64_t d : out) n *= d;
+    std::vector<int64_t> idx(out.size(), 0), off(st.size(), 0);
+    for (int64_t i = 0; i < n; i++) {
+        f(i, off);
+        for (size_t d = out.size(); d-- > 0;) {
+            idx[d]++;
+            for (size_t k = 0; k < st.size(); k++) off[k] += st[k][d];
+            if (idx[d] < out[d]) break;
+            for (size_t k = 0; k < st.size(); k++) off[k] -= st[k][d] * out[d];
+            idx[d] = 0;
+        }
+    }
+}
+inline HostVal make_ints(std::vector<int64_t> shape, std::vector<int64_t> v) { HostVal h; h.shape = std::move(shape); h.i = std::move(v); return h; }
+
+// ---- element-wise: Add Sub Mul Div (both types), And Or Xor, Equal Less LessOrEqual Greater GreaterOrEqual
+inline bool binary(const std::string &op, const HostVal &a, const HostVal &b, HostVal &out) {
+    if (a.is_float != b.is_float) return false;
+    out.shape = bshape({&a, &b});
+    if (out.len() > kMaxHostElems) return false;
+    const std::vector<std::vector<int64_t>> st{strides_for(a.shape, out.shape), strides_for(b.shape, out.shape)};
+    const bool arith = op == "Add" || op == "Sub" || op == "Mul" || op == "Div";
+    const bool logic = op == "And" || op == "Or" || op == "Xor";
+    if (logic && a.is_float) return false;
+    out.is_float = arith && a.is_float;
+    const int64_t n = out.len();
+    if (out.is_float) out.f.resize((size_t)n); else out.i.resize((size_t)n);
+    bool ok = true;
+    for_each_broadcast(out.shape, st, [&](int64_t i, const std::vector<int64_t> &o) {
+        if (a.is_float) {
+            const float x = a.f[(size_t)o[0]], y = b.f[(size_t)o[1]];
+            if (op == "Add") out.f[(size_t)i] = x + y; else if (op == "Sub") out.f[(size_t)i] = x - y; else if (op == "Mul") out.f[(size_t)i] = x * y;
+            else if (op == "Div") out.f[(size_t)i] = x / y;
+            else if (op == "Equal") out.i[(size_t)i] = x == y; else if (op == "Less") out.i[(size_t)i] = x < y; else if (op == "LessOrEqual") out.i[(size_t)i] = x <= y;
+            else if (op == "Greater") out.i[(size_t)i] = x > y; else if (op == "GreaterOrEqual") out.i[(size_t)i] = x >= y; else ok = false;
+        } else {
+            const int64_t x = a.i[(size_t)o[0]], y = b.i[(size_t)o[1]];
+            int64_t r = 0;
+            if (op == "Add") r = wrap32(x + y); else if (op == "Sub") r = wrap32(x - y); else if (op == "Mul") r = wrap32(x * y);
+            else if (op == "Div") { if (y == 0) throw OpError(OpError::InvalidValue, "integer division by zero"); r = wrap32(x / y); }
+            else if (op == "And") r = (x != 0) && (y != 0); else if (op == "Or") r = (x != 0) || (y != 0); else if (op == "Xor") r = (x != 0) != (y != 0);
+            else if (op == "Equal") r = x == y; else if (op == "Less") r = x < y; else if (op == "LessOrEqual") r = x <= y;
+            else if (op == "Greater") r = x > y; else if (op == "GreaterOrEqual") r = x >= y; else ok = false;
+            out.i[(size_t)i] = r;
+        }
+    });
+    return ok;
+}
+inline bool where(const HostVal &c, const HostVal &x, const HostVal &y, HostVal &out) {
+    if (c.is_float || x.is_float != y.is_float) return false;
+    out.shape = bshape({&c, &x, &y});
+    if (out.len() > kMaxHostElems) return false;
+    out.is_float = x.is_float;
+    const std::vector<std::vector<int64_t>> st{strides_for(c.shape, out.shape), strides_for(x.shape, out.shape), strides_for(y.shape, out.shape)};
+    if (out.is_float) out.f.resize((size_t)out.len()); else out.i.resize((size_t)out.len());
+    for_each_broadcast(out.shape, st, [&](int64_t i, const std::vector<int64_t> &o) {
+        const bool t = c.i[(size_t)o[0]] != 0;
+        if (out.is_float) out.f[(size_t)i] = t ? x.f[(size_t)o[1]] : y.f[(size_t)o[2]];
+        else out.i[(size_t)i] = t ? x.i[(size_t)o[1]] : y.i[(size_t)o[2]];
+    });
+    return true;
+}
+inline HostVal expand(const HostVal &x, const std::vector<int64_t> &target) {
+    HostVal out;
+    out.is_float = x.is_float;
+    HostVal t; t.shape = target;
+    out.shape = bshape({&x, &t});
+    const std::vector<std::vector<int64_t>> st{strides_for(x.shape, out.shape)};
+    if (out.is_float) out.f.resize((size_t)out.len()); else out.i.resize((size_t)out.len());
+    for_each_broadcast(out.shape, st, [&](int64_t i, const std::vector<int64_t> &o) { if (out.is_float) out.f[(size_t)i] = x.f[(size_t)o[0]]; else out.i[(size_t)i] = x.i[(size_t)o[0]]; });
+    return out;
+}
+inline HostVal cast(const HostVal &x, DType to) { // src/ops/convert.rs: Rust `as`
+    HostVal out;
+    out.shape = x.shape;
+    out.is_float = to == DType::F32;
+    const size_t n = (size_t)x.len();
+    if (out.is_float) { out.f.resize(n); for (size_t k = 0; k < n; k++) out.f[k] = x.is_float ? x.f[k] : (float)(int32_t)x.i[k]; return out; }
+    out.i.resize(n);
+    for (size_t k = 0; k < n; k++) {
+        if (x.is_float) {
+            const float f = x.f[k];
+            const double lo = to == DType::I32 ? -2147483648.0 : to == DType::U8 ? 0.0 : -128.0, hi = to == DType::I32 ? 2147483647.0 : to == DType::U8 ? 255.0 : 127.0;
+            out.i[k] = f != f ? 0 : (int64_t)std::trunc(std::min(std::max((double)f, lo), hi));
+        } else {
+            const int64_t v = x.i[k];
+            out.i[k] = to == DType::I32 ? wrap32(v) : to == DType::U8 ? (v & 0xff) : (int64_t)(int8_t)(v & 0xff);
+        }
+    }
+    return out;
+}
+inline HostVal reshaped(const HostVal &x, std::vector<int64_t> shape) { HostVal o = x; o.shape = std::move(shape); return o; }
+inline HostVal transpose(const HostVal &x, const std::vector<int> &perm_in) {
+    const int nd = (int)x.shape.size();
+    std::vector<int> perm = perm_in;
+    if (perm.empty()) for (int k = nd - 1; k >= 0; k--) perm.push_back(k);
+    if ((int)perm.size() != nd) throw OpError(OpError::InvalidValue, "Permutation is invalid");
+    std::vector<int64_t> xs((size_t)nd, 1);
+    for (int d = nd - 2; d >= 0; d--) xs[(size_t)d] = xs[(size_t)d + 1] * x.shape[(size_t)d + 1];
+    HostVal out;
+    out.is_float = x.is_float;
+    std::vector<int64_t> st((size_t)nd);
+    for (int d = 0; d < nd; d++) {
+        const int pd = perm[(size_t)d] < 0 ? perm[(size_t)d] + nd : perm[(size_t)d];
+        if (pd < 0 || pd >= nd) throw OpError(OpError::InvalidValue, "Permutation is invalid");
+        out.shape.push_back(x.shape[(size_t)pd]);
+        st[(size_t)d] = xs[(size_t)pd];
+    }
+    if (out.is_float) out.f.resize((size_t)out.len()); else out.i.resize((size_t)out.len());
+    for_each_broadcast(out.shape, {st}, [&](int64_t i, const std::vector<int64_t> &o) { if (out.is_float) out.f[(size_t)i] = x.f[(size_t)o[0]]; else out.i[(size_t)i] = x.i[(size_t)o[0]]; });
+    return out;
+}
+inline HostVal gather(const HostVal &x, const HostVal &ids, int axis) { // src/ops/gather.rs:21-110
+    const int nd = (int)x.shape.size();
+    if (nd < 1) throw OpError(OpError::InvalidValue, "Input must have >= 1 dims");
+    const int ax = resolve_axis(axis, nd);
+    const int64_t outer = detail::prod(x.shape, 0, (size_t)ax), alen = x.shape[(size_t)ax], inner = detail::prod(x.shape, (size_t)ax + 1, x.shape.size());
+    HostVal out;
+    out.is_float = x.is_float;
+    out.shape.assign(x.shape.begin(), x.shape.begin() + ax);
+    out.shape.insert(out.shape.end(), ids.shape.begin(), ids.shape.end());
+    out.shape.insert(out.shape.end(), x.shape.begin() + ax + 1, x.shape.end());
+    const int64_t nid = ids.len();
+    for (int64_t o = 0; o < outer; o++)
+        for (int64_t j = 0; j < nid; j++) {
+            int64_t id = ids.i[(size_t)j];
+            if (id < 0) id += alen;
+            if (id < 0 || id >= alen) throw OpError(OpError::InvalidValue, "Entry in indices is out of range");
+            for (int64_t k = 0; k < inner; k++) {
+                const size_t src = (size_t)((o * alen + id) * inner + k);
+                if (out.is_float) out.f.push_back(x.f[src]); else out.i.push_back(x.i[src]);
+            }
+        }
+    return out;
+}
+inline HostVal concat(const std::vector<const HostVal *> &v, int axis) { // src/ops/concat.rs
+    const int nd = (int)v[0]->shape.size();
+    const int ax = resolve_axis(axis, nd);
+    HostVal out;
+    out.is_float = v[0]->is_float;
+    out.shape = v[0]->shape;
+    out.shape[(size_t)ax] = 0;
+    for (auto *x : v) {
+        if ((int)x->shape.size() != nd) throw OpError(OpError::IncompatibleInputShapes, "Tensors must have the same number of dimensions");
+        if (x->is_float != out.is_float) throw OpError(OpError::UnsupportedType, "");
+        out.shape[(size_t)ax] += x->shape[(size_t)ax];
+    }
+    const int64_t outer = detail::prod(out.shape, 0, (size_t)ax), inner = detail::prod(out.shape, (size_t)ax + 1, out.shape.size());
+    for (int64_t o = 0; o < outer; o++)
+        for (auto *x : v) {
+            const int64_t row = x->shape[(size_t)ax] * inner;
+            for (int64_t k = 0; k < row; k++) { if (out.is_float) out.f.push_back(x->f[(size_t)(o * row + k)]); else out.i.push_back(x->i[(size_t)(o * row + k)]); }
+        }
+    return out;
+}
+inline HostVal slice(const HostVal &x, const std::vector<SliceRange> &r) {
+    const int nd = (int)x.shape.size();
+    HostVal out;
+    out.is_float = x.is_float;
+    std::vector<int64_t> st((size_t)nd);
+    int64_t acc = 1, base = 0;
+    for (int d = nd - 1; d >= 0; d--) { out.shape.insert(out.shape.begin(), r[(size_t)d].count); st[(size_t)d] = acc * r[(size_t)d].step; base += acc * r[(size_t)d].start; acc *= x.shape[(size_t)d]; }
+    if (out.is_float) out.f.resize((size_t)out.len()); else out.i.resize((size_t)out.len());
+    for_each_broadcast(out.shape, {st}, [&](int64_t i, const std::vector<int64_t> &o) { if (out.is_float) out.f[(size_t)i] = x.f[(size_t)(base + o[0])]; else out.i[(size_t)i] = x.i[(size_t)(base + o[0])]; });
+    return out;
+}
+inline HostVal nonzero(const HostVal &x) { // src/ops/non_zero.rs: [rank, count] int32 indices of the non-zero elements, row-major order
+    const int nd = (int)x.shape.size();
+    std::vector<std::vector<int64_t>> cols;
+    const int64_t n = x.len();
+    std::vector<int64_t> idx((size_t)nd, 0);
+    for (int64_t i = 0; i < n; i++) {
+        const bool nz = x.is_float ? x.f[(size_t)i] != 0.f : x.i[(size_t)i] != 0;
+        if (nz) cols.push_back(idx);
+        for (int d = nd - 1; d >= 0; d--) { if (++idx[(size_t)d] < x.shape[(size_t)d]) break; idx[(size_t)d] = 0; }
+    }
+    HostVal out;
+    out.shape = {(int64_t)std::max(nd, 1), (int64_t)cols.size()}; // (a scalar input gives [1, 0 or 1] in ONNX; the reference rejects scalars)
+    out.i.resize((size_t)(out.shape[0] * out.shape[1]));
+    for (int d = 0; d < nd; d++) for (size_t c = 0; c < cols.size(); c++) out.i[(size_t)d * cols.size() + c] = cols[c][(size_t)d];
+    return out;
+}
+} // namespace hostops
 
 // ======================================================================================================== executor
 struct GraphError : std::runtime_error { using std::runtime_error::runtime_error; };
@@ -849,8 +1061,8 @@ class Graph {
     static DType dtype_of(int onnx_type, const std::string &what) {
         switch (onnx_type) {
         case onnx::FLOAT: return DType::F32;
-        case onnx::INT32: case onnx::INT64: return DType::I32; // int64 is narrowed to int32 at load (onnx_loader.rs:332-339)
-        case onnx::UINT8: case onnx::BOOL: return DType::U8;
+        case onnx::INT32: case onnx::INT64: case onnx::BOOL: return DType::I32; // int64 and bool are int32 from load on (onnx_loader.rs:332-339,464-492)
+        case onnx::UINT8: return DType::U8;
         case onnx::INT8: return DType::I8;
         default: throw GraphError("unsupported tensor element type " + std::to_string(onnx_type) + " (" + what + ")");
         }
@@ -859,21 +1071,83 @@ class Graph {
     Tensor upload(const onnx::TensorProto &t) {
         const DType dt = dtype_of(t.data_type, t.name);
         const int64_t n = t.len();
-        const size_t esz = t.data_type == onnx::INT64 ? 8 : dtype_size(dt);
+        const size_t esz = t.data_type == onnx::INT64 ? 8 : t.data_type == onnx::BOOL ? 1 : dtype_size(dt);
         if ((size_t)n * esz != t.raw.size()) throw GraphError("initializer " + t.name + ": data size does not match its dims");
-        if (t.data_type == onnx::INT64) {
+        // small integer / float constants keep a host copy: the operands of shape arithmetic (hostops above)
+        constexpr int64_t kHostConst = 4096;
+        if (t.data_type == onnx::INT64 || t.data_type == onnx::BOOL) {
             std::vector<int32_t> narrow((size_t)n);
             for (int64_t i = 0; i < n; i++) {
+                if (t.data_type == onnx::BOOL) { narrow[(size_t)i] = t.raw[(size_t)i] != 0; continue; }
                 int64_t v;
                 std::memcpy(&v, t.raw.data() + 8 * i, 8);
                 narrow[(size_t)i] = (int32_t)std::max<int64_t>(INT32_MIN, std::min<int64_t>(INT32_MAX, v)); // saturating, like the loader
             }
-            return Tensor::from_host<int32_t>(ctx_, t.dims, narrow.data());
+            Tensor d = Tensor::from_host<int32_t>(ctx_, t.dims, narrow.data());
+            if (n <= kHostConst) { auto h = std::make_shared<HostVal>(); h->shape = t.dims; h->i.assign(narrow.begin(), narrow.end()); d.set_host(h); }
+            return d;
         }
         Tensor d(ctx_, t.dims, dt);
         if (d.bytes() && !(opt_.skip_large_uploads && d.bytes() >= ((size_t)64 << 10)))
             ctx_.check(rten_hip_memcpy_h2d(ctx_.raw(), d.ptr(), t.raw.data(), d.bytes()));
+        if (n <= kHostConst && (dt == DType::I32 || dt == DType::F32)) {
+            auto h = std::make_shared<HostVal>();
+            h->shape = t.dims;
+            h->is_float = dt == DType::F32;
+            if (h->is_float) { h->f.resize((size_t)n); std::memcpy(h->f.data(), t.raw.data(), (size_t)n * 4); }
+            else { h->i.resize((size_t)n); for (int64_t i = 0; i < n; i++) { int32_t v; std::memcpy(&v, t.raw.data() + 4 * i, 4); h->i[(size_t)i] = v; } }
+            d.set_host(h);
+        }
         return d;
+    }
+
+    // ---- host-evaluated steps (hostops above).  The device copy of a host-computed value is made once per distinct value and cached with the step: shapes
+    // are fixed between prepare and the next bind_input, so the eager warm-up run that precedes every capture fills the cache and the captured run only
+    // finds hits (an upload inside a capture would be recorded with the host pointer: refused).
+    struct HostCache { std::vector<std::pair<std::shared_ptr<const HostVal>, std::unique_ptr<Tensor>>> entries; };
+    static Tensor materialize(Context &c, HostVal &&hv, HostCache &cache) {
+        for (auto &e : cache.entries)
+            if (*e.first == hv) { Tensor v = Tensor::view_of(*e.second, e.second->shape()); v.set_host(e.first); return v; }
+        if (rten_hip_capture_active(c.raw()))
+            throw GraphError("a shape-dependent constant changed between the warm-up run and the capture (input shapes must stay fixed while a graph is captured)");
+        auto h = std::make_shared<const HostVal>(std::move(hv));
+        std::unique_ptr<Tensor> t;
+        if (h->is_float) t.reset(new Tensor(Tensor::from_host<float>(c, h->shape, h->f.data())));
+        else { std::vector<int32_t> w(h->i.begin(), h->i.end()); t.reset(new Tensor(Tensor::from_host<int32_t>(c, h->shape, w.data()))); }
+        if (cache.entries.size() >= 8) cache.entries.erase(cache.entries.begin()); // (shapes changed a few times: keep the recent ones)
+        cache.entries.emplace_back(h, std::move(t));
+        Tensor v = Tensor::view_of(*cache.entries.back().second, h->shape);
+        v.set_host(h);
+        return v;
+    }
+    static std::vector<int64_t> host_ints(const Tensor *t, const std::string &what) {
+        if (!t) return {};
+        if (!t->host() || t->host()->is_float) throw OpError(OpError::UnsupportedValue, what + " must be a constant or computable from the input shapes (it depends on device data)");
+        return t->host()->i;
+    }
+    // A step that runs on the host when every operand carries a host value (`hf` returns false to decline) and on the device otherwise.
+    using HostFn = std::function<bool(const std::vector<const HostVal *> &, HostVal &)>;
+    using DevFn = std::function<OutputList(Context &, const InputList &)>;
+    static void make_hostable(Step &st, HostFn hf, DevFn df) {
+        auto cache = std::make_shared<HostCache>();
+        st.run = [hf, df, cache](Context &c, const InputList &in) {
+            bool all = true;
+            std::vector<const HostVal *> hv;
+            for (const Tensor *t : in) {
+                if (!t) { hv.push_back(nullptr); continue; }
+                if (!t->host()) { all = false; break; }
+                hv.push_back(t->host());
+            }
+            if (all) {
+                HostVal out;
+                if (hf(hv, out)) {
+                    OutputList o;
+                    o.push_back(materialize(c, std::move(out), *cache));
+                    return o;
+                }
+            }
+            return df(c, in);
+        };
     }
 
     static Padding padding_of(const onnx::Node &n, const char *op) {
@@ -1114,7 +1388,8 @@ class Graph {
                 if (t < 0 || m.nodes[(size_t)t].get_ints("perm", {}) != perm) return "";
                 const long r = made_by(m.nodes[(size_t)t].inputs[0], "Reshape");
                 std::vector<int32_t> shp;
-                if (r < 0 || m.nodes[(size_t)r].inputs.size() < 2 || !const_i32(m.nodes[(size_t)r].inputs[1], shp) || shp.size() != 4 || shp[2] <= 0 || !leading_ok(shp, at, first)) return "";
+                // [.., .., h, d] or [.., .., -1, d]: transformers' exporter spells the head COUNT as -1 (hidden / d, resolved when the step runs)
+                if (r < 0 || m.nodes[(size_t)r].inputs.size() < 2 || !const_i32(m.nodes[(size_t)r].inputs[1], shp) || shp.size() != 4 || (shp[2] <= 0 && !(shp[2] == -1 && shp[3] > 0)) || !leading_ok(shp, at, first)) return "";
                 if (heads && heads != shp[2]) return "";
                 // one head size for q, k and v (the kernel's d == dv); -1 ("the rest") is accepted only if all three say so
                 if (heads && at.head_dim != shp[3]) return "";
@@ -1215,7 +1490,7 @@ class Graph {
             if (af != attn_at.end()) {
                 const Attn &at = af->second;
                 auto op = std::make_shared<MultiHeadSdpa>();
-                op->heads = at.heads; op->scale = at.scale; op->flush_nans_to_zero = false;
+                op->heads = at.heads; op->head_dim = at.head_dim; op->scale = at.scale; op->flush_nans_to_zero = false;
                 Step st;
                 st.pos = i;
                 st.name = at.out;
@@ -1528,14 +1803,6 @@ class Graph {
                         return Softmax().run(c, {&sum[0]});
                     }
                 };
-            } else if (n.op_type == "Transpose") {
-                auto op = std::make_shared<Transpose>();
-                op->perm = n.get_ints("perm", {});
-                st.run = [op](Context &c, const InputList &in) { return op->run(c, in); };
-            } else if (n.op_type == "Gather") {
-                auto op = std::make_shared<Gather>();
-                op->axis = (int)n.get_int("axis", 0);
-                st.run = [op](Context &c, const InputList &in) { return op->run(c, in); };
             } else if (n.op_type == "LayerNormalization") {
                 auto op = std::make_shared<LayerNormalization>();
                 op->axis = (int)n.get_int("axis", -1);
@@ -1562,10 +1829,6 @@ class Graph {
                     op->count_include_pad = n.get_int("count_include_pad", 0) != 0;
                     st.run = [op](Context &c, const InputList &in) { return op->run(c, in); };
                 }
-            } else if (n.op_type == "Cast") {
-                auto op = std::make_shared<Cast>();
-                op->to = dtype_of((int)n.get_int("to", onnx::FLOAT), st.name);
-                st.run = [op](Context &c, const InputList &in) { return op->run(c, in); };
             } else if (n.op_type == "Einsum") {
                 auto op = std::make_shared<Einsum>();
                 if (!n.attr("equation")) throw GraphError("Einsum " + st.name + ": the equation attribute is missing");
@@ -1593,6 +1856,9 @@ class Graph {
             } else if (n.op_type == "Flatten" || n.op_type == "Reshape" || n.op_type == "Squeeze" || n.op_type == "Unsqueeze" || n.op_type == "Identity" ||
                        n.op_type == "Dropout") {
                 make_view_step(st, n, m);
+            } else if (make_layout_step(st, n)) {
+                // Shape / ConstantOfShape / NonZero / Range / Slice / Concat / Expand / Where / comparisons / logic / integer arithmetic / Cast / Gather /
+                // Transpose: host-evaluated when their operands are host values, device kernels otherwise
             } else {
                 static const OpRegistry reg = OpRegistry::with_all_ops();
                 if (!reg.contains(n.op_type))
@@ -1613,6 +1879,194 @@ class Graph {
         plan_liveness();
     }
 
+    // Layout / logic operators around the hot path (src/ops/layout.rs, slice.rs, concat.rs, gather.rs, convert.rs, binary_elementwise.rs, non_zero.rs,
+    // generate.rs): each runs on the host when its operands are host values and as a device kernel otherwise.  Returns false for other operator types.
+    bool make_layout_step(Step &st, const onnx::Node &n) {
+        const std::string op = n.op_type, name = st.name;
+        static const std::map<std::string, int> ew = {{"And", RTEN_HIP_EW_AND}, {"Or", RTEN_HIP_EW_OR}, {"Xor", RTEN_HIP_EW_XOR}, {"Equal", RTEN_HIP_EW_EQUAL},
+                                                      {"Less", RTEN_HIP_EW_LESS}, {"LessOrEqual", RTEN_HIP_EW_LESS_EQ}, {"Greater", RTEN_HIP_EW_GREATER},
+                                                      {"GreaterOrEqual", RTEN_HIP_EW_GREATER_EQ}};
+        static const std::map<std::string, int> arith = {{"Add", RTEN_HIP_EW_IADD}, {"Sub", RTEN_HIP_EW_ISUB}, {"Mul", RTEN_HIP_EW_IMUL}, {"Div", RTEN_HIP_EW_IDIV}};
+        if (op == "Shape") { // src/ops/layout.rs:475-520 (start / end attributes of opset 15)
+            const int64_t start = n.get_int("start", 0);
+            const bool has_end = n.attr("end") != nullptr;
+            const int64_t end = n.get_int("end", 0);
+            auto cache = std::make_shared<HostCache>();
+            st.run = [start, has_end, end, cache](Context &c, const InputList &in) {
+                const Tensor &x = require(in, 0);
+                const int64_t nd = x.ndim();
+                int64_t s = start < 0 ? start + nd : start, e = has_end ? (end < 0 ? end + nd : end) : nd;
+                s = std::min(std::max<int64_t>(s, 0), nd); e = std::min(std::max<int64_t>(e, 0), nd);
+                std::vector<int64_t> dims;
+                for (int64_t d = s; d < e; d++) dims.push_back(x.size((int)d));
+                OutputList o;
+                o.push_back(materialize(c, hostops::make_ints({(int64_t)dims.size()}, dims), *cache));
+                return o;
+            };
+            return true;
+        }
+        if (ew.count(op) || arith.count(op)) {
+            const bool is_arith = arith.count(op) != 0;
+            const int code = is_arith ? arith.at(op) : ew.at(op);
+            std::shared_ptr<Operator> fop;
+            if (is_arith) { static const OpRegistry reg = OpRegistry::with_all_ops(); fop.reset(reg.create(op).release()); }
+            auto dev = std::make_shared<ElementwiseNd>(code, is_arith ? "IntegerArithmetic" : "Logical");
+            make_hostable(st,
+                          [op](const std::vector<const HostVal *> &v, HostVal &out) { return v.size() == 2 && v[0] && v[1] && hostops::binary(op, *v[0], *v[1], out); },
+                          [dev, fop, is_arith](Context &c, const InputList &in) {
+                              if (is_arith && !(require(in, 0).dtype() == DType::I32 && require(in, 1).dtype() == DType::I32)) return fop->run(c, in); // the f32 kernels
+                              if (is_arith && dev->code == RTEN_HIP_EW_IDIV && in[1]->host())
+                                  for (int64_t d : in[1]->host()->i) if (d == 0) throw OpError(OpError::InvalidValue, "integer division by zero");
+                              return dev->run(c, in);
+                          });
+            return true;
+        }
+        if (op == "Not") {
+            auto dev = std::make_shared<ElementwiseNd>(RTEN_HIP_EW_NOT, "Not");
+            make_hostable(st,
+                          [](const std::vector<const HostVal *> &v, HostVal &out) {
+                              if (v.size() != 1 || !v[0] || v[0]->is_float) return false;
+                              out.shape = v[0]->shape;
+                              for (int64_t x : v[0]->i) out.i.push_back(x == 0);
+                              return true;
+                          },
+                          [dev](Context &c, const InputList &in) { return dev->run(c, in); });
+            return true;
+        }
+        if (op == "Where") {
+            auto dev = std::make_shared<Where>();
+            make_hostable(st, [](const std::vector<const HostVal *> &v, HostVal &out) { return v.size() == 3 && v[0] && v[1] && v[2] && hostops::where(*v[0], *v[1], *v[2], out); },
+                          [dev](Context &c, const InputList &in) { return dev->run(c, in); });
+            return true;
+        }
+        if (op == "Cast") {
+            auto dev = std::make_shared<Cast>();
+            dev->to = dtype_of((int)n.get_int("to", onnx::FLOAT), name);
+            const DType to = dev->to;
+            make_hostable(st, [to](const std::vector<const HostVal *> &v, HostVal &out) { if (v.size() != 1 || !v[0] || (to != DType::F32 && to != DType::I32)) return false; out = hostops::cast(*v[0], to); return true; },
+                          [dev](Context &c, const InputList &in) { return dev->run(c, in); });
+            return true;
+        }
+        if (op == "Transpose") {
+            auto dev = std::make_shared<Transpose>();
+            dev->perm = n.get_ints("perm", {});
+            const std::vector<int> perm = dev->perm;
+            make_hostable(st, [perm](const std::vector<const HostVal *> &v, HostVal &out) { if (v.size() != 1 || !v[0]) return false; out = hostops::transpose(*v[0], perm); return true; },
+                          [dev](Context &c, const InputList &in) { return dev->run(c, in); });
+            return true;
+        }
+        if (op == "Gather") {
+            auto dev = std::make_shared<Gather>();
+            dev->axis = (int)n.get_int("axis", 0);
+            const int axis = dev->axis;
+            make_hostable(st, [axis](const std::vector<const HostVal *> &v, HostVal &out) { if (v.size() != 2 || !v[0] || !v[1] || v[1]->is_float) return false; out = hostops::gather(*v[0], *v[1], axis); return true; },
+                          [dev](Context &c, const InputList &in) { return dev->run(c, in); });
+            return true;
+        }
+        if (op == "Concat") {
+            if (!n.attr("axis")) throw GraphError("Concat " + name + ": the axis attribute is missing");
+            const int axis = (int)n.get_int("axis", 0);
+            make_hostable(st,
+                          [axis](const std::vector<const HostVal *> &v, HostVal &out) { for (auto *x : v) if (!x) return false; if (v.empty()) return false; out = hostops::concat(v, axis); return true; },
+                          [axis](Context &c, const InputList &in) { OutputList o; o.push_back(concat_tensors(c, in, axis)); return o; });
+            return true;
+        }
+        if (op == "Slice") { // opset >= 10: starts, ends, axes, steps as inputs (host values); opset 1: attributes
+            std::vector<int64_t> a_starts, a_ends, a_axes;
+            if (const onnx::Attr *a = n.attr("starts")) a_starts = a->ints;
+            if (const onnx::Attr *a = n.attr("ends")) a_ends = a->ints;
+            if (const onnx::Attr *a = n.attr("axes")) a_axes = a->ints;
+            const bool attr_form = n.attr("starts") != nullptr;
+            auto cache = std::make_shared<HostCache>();
+            st.run = [attr_form, a_starts, a_ends, a_axes, cache](Context &c, const InputList &in) {
+                const Tensor &x = require(in, 0);
+                const std::vector<int64_t> starts = attr_form ? a_starts : host_ints(in.size() > 1 ? in[1] : nullptr, "Slice: starts"),
+                                           ends = attr_form ? a_ends : host_ints(in.size() > 2 ? in[2] : nullptr, "Slice: ends"),
+                                           axes = attr_form ? a_axes : host_ints(in.size() > 3 ? in[3] : nullptr, "Slice: axes"),
+                                           steps = attr_form ? std::vector<int64_t>{} : host_ints(in.size() > 4 ? in[4] : nullptr, "Slice: steps");
+                const std::vector<SliceRange> r = resolve_slice(x.shape(), starts, ends, axes, steps);
+                OutputList o;
+                if (x.host()) o.push_back(materialize(c, hostops::slice(*x.host(), r), *cache));
+                else o.push_back(slice_tensor(c, x, r));
+                return o;
+            };
+            return true;
+        }
+        if (op == "Expand") {
+            auto cache = std::make_shared<HostCache>();
+            st.run = [cache](Context &c, const InputList &in) {
+                const Tensor &x = require(in, 0);
+                const std::vector<int64_t> target = host_ints(&require(in, 1), "Expand: the shape input");
+                OutputList o;
+                if (x.host() && detail::prod(target, 0, target.size()) <= hostops::kMaxHostElems) o.push_back(materialize(c, hostops::expand(*x.host(), target), *cache));
+                else o.push_back(expand_to(c, x, target));
+                return o;
+            };
+            return true;
+        }
+        if (op == "ConstantOfShape") { // src/ops/generate.rs: a tensor of `shape` filled with the `value` attribute (default float 0)
+            HostVal fill;
+            fill.is_float = true; fill.f = {0.f};
+            if (const onnx::Attr *v = n.attr("value")) {
+                const onnx::TensorProto &t = v->t;
+                if (t.len() != 1) throw GraphError("ConstantOfShape " + name + ": value must hold one element");
+                if (t.data_type == onnx::FLOAT && t.raw.size() == 4) std::memcpy(&fill.f[0], t.raw.data(), 4);
+                else if (t.data_type == onnx::INT64 && t.raw.size() == 8) { int64_t x; std::memcpy(&x, t.raw.data(), 8); fill.is_float = false; fill.f.clear(); fill.i = {hostops::wrap32(x)}; }
+                else if (t.data_type == onnx::INT32 && t.raw.size() == 4) { int32_t x; std::memcpy(&x, t.raw.data(), 4); fill.is_float = false; fill.f.clear(); fill.i = {x}; }
+                else if (t.data_type == onnx::BOOL && t.raw.size() == 1) { fill.is_float = false; fill.f.clear(); fill.i = {t.raw[0] != 0}; }
+                else throw GraphError("ConstantOfShape " + name + ": unsupported value type");
+            }
+            auto cache = std::make_shared<HostCache>();
+            st.run = [fill, cache](Context &c, const InputList &in) {
+                const std::vector<int64_t> shape = host_ints(&require(in, 0), "ConstantOfShape: the shape input");
+                for (int64_t d : shape) if (d < 0) throw OpError(OpError::InvalidValue, "ConstantOfShape: negative dimension");
+                OutputList o;
+                if (detail::prod(shape, 0, shape.size()) <= hostops::kMaxHostElems) { o.push_back(materialize(c, hostops::expand(fill, shape), *cache)); return o; }
+                Tensor one = materialize(c, HostVal(fill), *cache); // a large fill: expand the one-element device constant
+                o.push_back(expand_to(c, one, shape));
+                return o;
+            };
+            return true;
+        }
+        if (op == "NonZero") { // the output's shape depends on the input's VALUES: only host values (exporters write arange(n) as NonZero(ConstantOfShape(n)))
+            auto cache = std::make_shared<HostCache>();
+            st.run = [cache](Context &c, const InputList &in) {
+                const Tensor &x = require(in, 0);
+                if (!x.host()) throw OpError(OpError::UnsupportedValue, "NonZero of device data: the output shape would depend on values (only shape-derived operands are supported)");
+                OutputList o;
+                o.push_back(materialize(c, hostops::nonzero(*x.host()), *cache));
+                return o;
+            };
+            return true;
+        }
+        if (op == "Range") { // src/ops/generate.rs: start, limit, delta scalars (host values)
+            auto cache = std::make_shared<HostCache>();
+            st.run = [cache](Context &c, const InputList &in) {
+                const Tensor &a = require(in, 0), &b = require(in, 1), &d = require(in, 2);
+                if (!a.host() || !b.host() || !d.host()) throw OpError(OpError::UnsupportedValue, "Range: start / limit / delta must be constants or computable from the input shapes");
+                HostVal out;
+                if (a.host()->is_float) {
+                    const float s = a.host()->f.at(0), l = b.host()->f.at(0), dl = d.host()->f.at(0);
+                    if (dl == 0.f) throw OpError(OpError::InvalidValue, "delta must be non-zero");
+                    out.is_float = true;
+                    const int64_t cnt = std::max<int64_t>((int64_t)std::ceil((l - s) / dl), 0);
+                    for (int64_t k = 0; k < cnt; k++) out.f.push_back(s + (float)k * dl);
+                    out.shape = {cnt};
+                } else {
+                    const int64_t s = a.host()->i.at(0), l = b.host()->i.at(0), dl = d.host()->i.at(0);
+                    if (dl == 0) throw OpError(OpError::InvalidValue, "delta must be non-zero");
+                    for (int64_t v = s; dl > 0 ? v < l : v > l; v += dl) out.i.push_back(v);
+                    out.shape = {(int64_t)out.i.size()};
+                }
+                OutputList o;
+                o.push_back(materialize(c, std::move(out), *cache));
+                return o;
+            };
+            return true;
+        }
+        return false;
+    }
+
     // Shape-only operators: the output aliases the input's buffer (src/ops/layout.rs reshapes in place when it can).
     void make_view_step(Step &st, const onnx::Node &n, const onnx::Model &m) {
         (void)m;
@@ -1620,19 +2074,27 @@ class Graph {
         const int axis = (int)n.get_int("axis", 1);
         std::vector<int64_t> spec; // Reshape target / (Un)Squeeze axes from a constant input (opset >= 13) or the attribute
         bool have_spec = false;
+        bool runtime_spec = false; // the shape / axes operand is computed by the graph (shape arithmetic): read from its host value at run time
         if (n.inputs.size() > 1 && !n.inputs[1].empty()) {
             auto it = ids_.find(n.inputs[1]);
-            if (it == ids_.end() || !consts_.count(it->second)) throw GraphError(kind + " " + st.name + ": the shape / axes input must be a constant");
-            const Tensor &t = consts_.at(it->second);
-            for (int32_t v : t.to_host<int32_t>()) spec.push_back(v);
+            if (it == ids_.end() || !consts_.count(it->second)) {
+                runtime_spec = true;
+                st.in.resize(2);
+            } else {
+                const Tensor &t = consts_.at(it->second);
+                for (int32_t v : t.to_host<int32_t>()) spec.push_back(v);
+                st.in.resize(1);
+            }
             have_spec = true;
-            st.in.resize(1);
         } else if (const onnx::Attr *a = n.attr("axes")) { spec = a->ints; have_spec = true; }
         else if (const onnx::Attr *a2 = n.attr("shape")) { spec = a2->ints; have_spec = true; }
         const bool allowzero = n.get_int("allowzero", 0) != 0;
         st.kind_name = kind + "(view)";
-        st.run = [kind, axis, spec, have_spec, allowzero](Context &, const InputList &in) {
+        const std::string step_name = st.name;
+        st.run = [kind, axis, spec_const = spec, have_spec, allowzero, runtime_spec, step_name](Context &, const InputList &in) {
             const Tensor &x = require(in, 0);
+            const std::vector<int64_t> spec_rt = runtime_spec ? host_ints(&require(in, 1), kind + " " + step_name + ": the shape / axes input") : std::vector<int64_t>();
+            const std::vector<int64_t> &spec = runtime_spec ? spec_rt : spec_const;
             std::vector<int64_t> s = x.shape();
             const int nd = (int)s.size();
             if (kind == "Flatten") {
@@ -1678,6 +2140,7 @@ class Graph {
             }
             OutputList out;
             out.push_back(Tensor::view_of(x, s));
+            if (x.host()) out.back().set_host(std::make_shared<const HostVal>(hostops::reshaped(*x.host(), s))); // the same values under the new shape
             return out;
         };
         st.view = true;

@@ -58,7 +58,7 @@ class Context {
     Context(rten_hip_ctx *borrowed, Borrow) : h_(borrowed), owned_(false) {
         if (!borrowed) throw OpError(OpError::InvalidValue, "null context");
     }
-    ~Context() { if (h_) { trim_pool(); if (one_) rten_hip_free(h_, one_); if (owned_) rten_hip_destroy(h_); } }
+    ~Context() { if (h_) { trim_pool(); if (one_) rten_hip_free(h_, one_); if (zero_) rten_hip_free(h_, zero_); if (owned_) rten_hip_destroy(h_); } }
     Context(const Context &) = delete;
     Context &operator=(const Context &) = delete;
     rten_hip_ctx *raw() const { return h_; }
@@ -88,6 +88,14 @@ class Context {
         for (auto &kv : pool_) for (void *p : kv.second) rten_hip_free(h_, p);
         pool_.clear();
     }
+    const int32_t *zero_i32() { // device-resident int32 0 (x + 0: a raw-word move through the generic element-wise kernel)
+        if (!zero_) {
+            const int32_t v = 0;
+            check(rten_hip_malloc(h_, 4, &zero_));
+            check(rten_hip_memcpy_h2d(h_, zero_, &v, 4));
+        }
+        return (const int32_t *)zero_;
+    }
     const float *one() { // device-resident 1.0f (x * 1.0f is exact: Cast as cast_scale)
         if (!one_) {
             const float v = 1.0f;
@@ -112,7 +120,7 @@ class Context {
     rten_hip_ctx *h_ = nullptr;
     bool owned_ = true;
     bool pool_on_ = false;
-    void *one_ = nullptr;
+    void *one_ = nullptr, *zero_ = nullptr;
     std::map<size_t, std::vector<void *>> pool_;
     std::mutex pool_mu_; // the pool is shared by concurrent Model::run callers (the C ABI context locks itself)
 };
@@ -120,6 +128,23 @@ class Context {
 // ---- device tensor (the backend's `Value`: contiguous, row-major, device resident)
 enum class DType { F32, I32, U8, I8 };
 inline size_t dtype_size(DType t) { return (t == DType::F32 || t == DType::I32) ? 4 : 1; }
+
+// A small tensor whose VALUES the host knows (shape arithmetic: the output of Shape, constants, and what Gather / Concat / Slice / Unsqueeze / arithmetic /
+// comparisons make of them).  The reference folds such subgraphs at load (`propagate_constants`, src/optimize.rs:705, over its symbolic shapes); here
+// the executor evaluates them on the host at run time (rten_hip_graph.hpp: no device work, nothing of it in a captured hipGraph) and attaches the
+// result to the device tensor that carries the value, so that Reshape / Expand / Slice / ConstantOfShape read their shape operands without a
+// device round trip.  Integers and booleans are int32-valued (onnx_loader.rs:332-339), kept in int64 for the arithmetic.
+struct HostVal {
+    std::vector<int64_t> shape;
+    bool is_float = false;
+    std::vector<int64_t> i;
+    std::vector<float> f;
+    int64_t len() const { int64_t n = 1; for (int64_t d : shape) n *= d; return n; }
+    bool operator==(const HostVal &o) const {
+        if (shape != o.shape || is_float != o.is_float || i != o.i || f.size() != o.f.size()) return false;
+        return f.empty() || std::memcmp(f.data(), o.f.data(), f.size() * sizeof(float)) == 0; // bitwise (NaN payloads, -0)
+    }
+};
 
 class Tensor {
   public:
@@ -161,7 +186,7 @@ class Tensor {
     ~Tensor() { release(); }
     Tensor(Tensor &&o) noexcept { *this = std::move(o); }
     Tensor &operator=(Tensor &&o) noexcept {
-        if (this != &o) { release(); ctx_ = o.ctx_; ptr_ = o.ptr_; shape_ = std::move(o.shape_); dtype_ = o.dtype_; cap_ = o.cap_; owns_ = o.owns_; o.ptr_ = nullptr; }
+        if (this != &o) { release(); ctx_ = o.ctx_; ptr_ = o.ptr_; shape_ = std::move(o.shape_); dtype_ = o.dtype_; cap_ = o.cap_; owns_ = o.owns_; host_ = std::move(o.host_); o.ptr_ = nullptr; }
         return *this;
     }
     Tensor(const Tensor &) = delete;
@@ -180,6 +205,10 @@ class Tensor {
         return out;
     }
     void reshape(std::vector<int64_t> s) { shape_ = std::move(s); }
+    // the host's copy of the values, when it has one (see HostVal); views made with view_of() start without one
+    const HostVal *host() const { return host_.get(); }
+    const std::shared_ptr<const HostVal> &host_ptr() const { return host_; }
+    void set_host(std::shared_ptr<const HostVal> h) { host_ = std::move(h); }
 
     template <typename T> static DType dtype_of() {
         if (std::is_same<T, float>::value) return DType::F32;
@@ -196,6 +225,7 @@ class Tensor {
     bool owns_ = true;
     std::vector<int64_t> shape_;
     DType dtype_ = DType::F32;
+    std::shared_ptr<const HostVal> host_;
 };
 
 // ---- Operator interface (src/operator.rs:486-613).  Optional inputs are null pointers (InputList::get).
@@ -923,22 +953,29 @@ struct Transpose : Operator { // layout.rs:669+: perm absent = reverse the axes
     }
 };
 
-// Gather along axis 0 of a float table with int32 indices (gather.rs: the embedding-lookup form).  Out-of-range indices
-// are clamped on the device (the reference reports "Entry in indices is out of range").
+// Gather (src/ops/gather.rs:21-110): 4-byte data, int32 indices, any axis; the embedding-lookup form (axis 0 of a float table) keeps its own kernel.
+// Out-of-range indices are clamped on the device (the reference reports "Entry in indices is out of range").
 struct Gather : Operator {
     int axis = 0;
     const char *name() const override { return "Gather"; }
     int max_inputs() const override { return 2; }
     OutputList run(Context &ctx, const InputList &in) const override {
-        const Tensor &table = want(require(in, 0), DType::F32, "float32");
+        const Tensor &table = require(in, 0);
         const Tensor &ids = want(require(in, 1), DType::I32, "int32");
+        if (dtype_size(table.dtype()) != 4) throw OpError(OpError::UnsupportedType, "");
         if (table.ndim() < 1) throw OpError(OpError::InvalidValue, "Input must have >= 1 dims");
-        if (resolve_axis(axis, table.ndim()) != 0) throw OpError(OpError::UnsupportedValue, "Gather: only axis 0 on the device path");
-        const int64_t row_len = detail::prod(table.shape(), 1, table.shape().size());
-        std::vector<int64_t> oshape = ids.shape();
-        oshape.insert(oshape.end(), table.shape().begin() + 1, table.shape().end());
-        Tensor y(ctx, oshape, DType::F32);
-        if (y.len()) ctx.check(rten_hip_gather_rows_f32(ctx.raw(), ids.len(), (int32_t)row_len, (int32_t)table.size(0), (const float *)table.ptr(), (const int32_t *)ids.ptr(), (float *)y.ptr()));
+        const int ax = resolve_axis(axis, table.ndim());
+        std::vector<int64_t> oshape(table.shape().begin(), table.shape().begin() + ax);
+        oshape.insert(oshape.end(), ids.shape().begin(), ids.shape().end());
+        oshape.insert(oshape.end(), table.shape().begin() + ax + 1, table.shape().end());
+        const int64_t outer = detail::prod(table.shape(), 0, (size_t)ax), inner = detail::prod(table.shape(), (size_t)ax + 1, table.shape().size());
+        Tensor y(ctx, oshape, table.dtype());
+        if (y.len()) {
+            if (ax == 0 && table.dtype() == DType::F32)
+                ctx.check(rten_hip_gather_rows_f32(ctx.raw(), ids.len(), (int32_t)inner, (int32_t)table.size(0), (const float *)table.ptr(), (const int32_t *)ids.ptr(), (float *)y.ptr()));
+            else
+                ctx.check(rten_hip_gather_axis_b32(ctx.raw(), outer, table.size(ax), inner, ids.len(), table.ptr(), (const int32_t *)ids.ptr(), y.ptr()));
+        }
         OutputList out;
         out.push_back(std::move(y));
         return out;
@@ -976,6 +1013,7 @@ struct AddSoftmax : Operator {
 // the *_rs, *_off fields (elements).
 struct MultiHeadSdpa : Operator {
     int heads = 1;
+    int head_dim = 0; // heads <= 0: the graph's Reshape spells the head COUNT as -1 ([B, S, -1, d], transformers' exporter idiom): heads = hidden / head_dim
     float scale = 1.f;
     bool flush_nans_to_zero = false; // the FusedMatMul -> AddSoftmax -> MatMul graph does not flush; sdpa_head does (attention.rs:551)
     int64_t q_rs = 0, k_rs = 0, v_rs = 0;    // row strides (0: the tensor's own last dim)
@@ -989,6 +1027,7 @@ struct MultiHeadSdpa : Operator {
         if (q.ndim() != 3 || k.ndim() != 3 || v.ndim() != 3) throw OpError(OpError::InvalidValue, "expected [batch, seq, hidden] projections");
         const int64_t B = q.size(0), S = q.size(1), T = k.size(1);
         const int64_t Hd = width ? width : q.size(2);
+        const int heads = this->heads > 0 ? this->heads : (head_dim > 0 && Hd % head_dim == 0 ? (int)(Hd / head_dim) : 0);
         if (heads <= 0 || Hd % heads != 0) throw OpError(OpError::InvalidValue, "hidden size is not divisible by the number of heads");
         if (k.size(0) != B || v.size(0) != B || v.size(1) != T) throw OpError(OpError::IncompatibleInputShapes, "q / k / v batch or sequence sizes do not match");
         if (!width && (k.size(2) != Hd || v.size(2) != Hd)) throw OpError(OpError::IncompatibleInputShapes, "q / k / v hidden sizes do not match");
@@ -1229,28 +1268,203 @@ struct DynamicQuantizeLinearStaged : Operator {
 
 // Cast (src/ops/convert.rs): the device path covers what the quantized graphs need, int32 -> float32 (exact conversion with
 // round-to-nearest-even above 2^24, the same instruction cast_scale uses) and identity casts.
-struct Cast : Operator {
+inline int32_t abi_dtype(DType t) { return t == DType::F32 ? RTEN_HIP_DT_F32 : t == DType::I32 ? RTEN_HIP_DT_I32 : t == DType::U8 ? RTEN_HIP_DT_U8 : RTEN_HIP_DT_I8; }
+
+// numpy broadcasting of up to three operands: the common shape and each operand's element strides on it (0 on broadcast axes)
+struct Broadcast {
+    std::vector<int64_t> shape;
+    std::vector<int64_t> strides[3];
+};
+inline Broadcast broadcast_shapes(const std::vector<const std::vector<int64_t> *> &shapes) {
+    Broadcast b;
+    size_t nd = 0;
+    for (auto *sh : shapes) nd = std::max(nd, sh->size());
+    if (nd > 6) throw OpError(OpError::UnsupportedValue, "broadcasting over more than 6 dims is not supported by the device path");
+    b.shape.assign(nd, 1);
+    for (auto *sh : shapes)
+        for (size_t i = 0; i < sh->size(); i++) {
+            const size_t o = nd - sh->size() + i;
+            const int64_t d = (*sh)[i];
+            if (d != 1) {
+                if (b.shape[o] != 1 && b.shape[o] != d) throw OpError(OpError::IncompatibleInputShapes, "Cannot broadcast inputs");
+                b.shape[o] = d;
+            }
+        }
+    for (size_t k = 0; k < shapes.size() && k < 3; k++) {
+        const auto &sh = *shapes[k];
+        b.strides[k].assign(nd, 0);
+        int64_t acc = 1;
+        for (size_t i = sh.size(); i-- > 0;) {
+            b.strides[k][nd - sh.size() + i] = sh[i] == 1 ? 0 : acc;
+            acc *= sh[i];
+        }
+    }
+    return b;
+}
+
+struct Cast : Operator { // src/ops/convert.rs:18-60: every pair of float32 / int32 / uint8 / int8 (`as` casts)
     DType to = DType::F32;
     const char *name() const override { return "Cast"; }
     int max_inputs() const override { return 1; }
     OutputList run(Context &ctx, const InputList &in) const override {
         const Tensor &x = require(in, 0);
         OutputList out;
-        if (x.dtype() == DType::I32 && to == DType::F32) {
-            Tensor y(ctx, x.shape(), DType::F32);
-            if (x.len()) ctx.check(rten_hip_cast_scale(ctx.raw(), x.len(), (const int32_t *)x.ptr(), ctx.one(), 1, (float *)y.ptr()));
-            out.push_back(std::move(y));
-            return out;
-        }
+        Tensor y(ctx, x.shape(), to);
         if (x.dtype() == to) { // identity cast: a copy
-            Tensor y(ctx, x.shape(), to);
             if (x.bytes()) ctx.check(rten_hip_memcpy_d2d(ctx.raw(), y.ptr(), x.ptr(), x.bytes()));
-            out.push_back(std::move(y));
-            return out;
+        } else if (x.dtype() == DType::I32 && to == DType::F32) {
+            if (x.len()) ctx.check(rten_hip_cast_scale(ctx.raw(), x.len(), (const int32_t *)x.ptr(), ctx.one(), 1, (float *)y.ptr()));
+        } else if (x.len()) {
+            const int64_t n = x.len(), one = 1;
+            ctx.check(rten_hip_elementwise_nd(ctx.raw(), RTEN_HIP_EW_CAST, 1, &n, x.ptr(), abi_dtype(x.dtype()), &one, nullptr, 0, nullptr, nullptr, nullptr, y.ptr(), abi_dtype(to)));
         }
-        throw OpError(OpError::UnsupportedValue, "Cast: only int32 -> float32 on the device path");
+        out.push_back(std::move(y));
+        return out;
     }
 };
+
+struct Tanh : UnaryOp<rten_hip_tanh_f32> { Tanh() : UnaryOp("Tanh") {} }; // rten-vecmath/src/tanh.rs (BERT's pooler)
+
+// Not / And / Or / Xor, Equal / Less / LessOrEqual / Greater / GreaterOrEqual, integer Add / Sub / Mul / Div: numpy broadcasting, int32 results
+// (unary_elementwise.rs:563-565, binary_elementwise.rs:546-598,733-786).  `code` = the RTEN_HIP_EW_* operation.
+struct ElementwiseNd : Operator {
+    int code = RTEN_HIP_EW_AND;
+    const char *nm = "And";
+    ElementwiseNd() = default;
+    ElementwiseNd(int c, const char *n) : code(c), nm(n) {}
+    const char *name() const override { return nm; }
+    int max_inputs() const override { return code == RTEN_HIP_EW_NOT ? 1 : 2; }
+    OutputList run(Context &ctx, const InputList &in) const override {
+        const Tensor &a = require(in, 0);
+        OutputList out;
+        if (code == RTEN_HIP_EW_NOT) {
+            want(a, DType::I32, "int32");
+            Tensor y(ctx, a.shape(), DType::I32);
+            const int64_t n = a.len(), one = 1;
+            if (n) ctx.check(rten_hip_elementwise_nd(ctx.raw(), code, 1, &n, a.ptr(), RTEN_HIP_DT_I32, &one, nullptr, 0, nullptr, nullptr, nullptr, y.ptr(), RTEN_HIP_DT_I32));
+            out.push_back(std::move(y));
+            return out;
+        }
+        const Tensor &b = require(in, 1);
+        const bool cmp = code >= RTEN_HIP_EW_EQUAL && code <= RTEN_HIP_EW_GREATER_EQ;
+        if (cmp) { if (a.dtype() != b.dtype() || (a.dtype() != DType::F32 && a.dtype() != DType::I32)) throw OpError(OpError::UnsupportedType, ""); }
+        else { want(a, DType::I32, "int32"); want(b, DType::I32, "int32"); }
+        const Broadcast bc = broadcast_shapes({&a.shape(), &b.shape()});
+        Tensor y(ctx, bc.shape, DType::I32);
+        if (y.len())
+            ctx.check(rten_hip_elementwise_nd(ctx.raw(), code, (int32_t)bc.shape.size(), bc.shape.data(), a.ptr(), abi_dtype(a.dtype()), bc.strides[0].data(), b.ptr(), abi_dtype(b.dtype()),
+                                              bc.strides[1].data(), nullptr, nullptr, y.ptr(), RTEN_HIP_DT_I32));
+        out.push_back(std::move(y));
+        return out;
+    }
+};
+
+struct Where : Operator { // binary_elementwise.rs:1189-1280: cond != 0 ? x : y, the three operands broadcast together
+    const char *name() const override { return "Where"; }
+    int max_inputs() const override { return 3; }
+    OutputList run(Context &ctx, const InputList &in) const override {
+        const Tensor &c = want(require(in, 0), DType::I32, "int32"), &x = require(in, 1), &y = require(in, 2);
+        if (x.dtype() != y.dtype() || dtype_size(x.dtype()) != 4) throw OpError(OpError::UnsupportedType, "");
+        const Broadcast bc = broadcast_shapes({&c.shape(), &x.shape(), &y.shape()});
+        Tensor o(ctx, bc.shape, x.dtype());
+        if (o.len())
+            ctx.check(rten_hip_elementwise_nd(ctx.raw(), RTEN_HIP_EW_WHERE, (int32_t)bc.shape.size(), bc.shape.data(), c.ptr(), RTEN_HIP_DT_I32, bc.strides[0].data(), x.ptr(),
+                                              abi_dtype(x.dtype()), bc.strides[1].data(), y.ptr(), bc.strides[2].data(), o.ptr(), abi_dtype(x.dtype())));
+        OutputList out;
+        out.push_back(std::move(o));
+        return out;
+    }
+};
+
+// Expand (src/ops/layout.rs:177-262): numpy broadcast of x against `shape` (the values of the second input, which the host must know)
+inline Tensor expand_to(Context &ctx, const Tensor &x, const std::vector<int64_t> &target) {
+    if (dtype_size(x.dtype()) != 4) throw OpError(OpError::UnsupportedType, "");
+    const Broadcast bc = broadcast_shapes({&x.shape(), &target});
+    Tensor y(ctx, bc.shape, x.dtype());
+    if (y.len()) ctx.check(rten_hip_copy_strided_b32(ctx.raw(), (int32_t)bc.shape.size(), bc.shape.data(), bc.strides[0].data(), x.ptr(), y.ptr()));
+    return y;
+}
+
+// Slice (src/ops/slice.rs:21-118): per-axis [start, end) with a positive or negative step; clamping rules of the ONNX operator.  Returns the
+// resolved (start, count, step) per axis of `shape`.
+struct SliceRange { int64_t start, count, step; };
+inline std::vector<SliceRange> resolve_slice(const std::vector<int64_t> &shape, const std::vector<int64_t> &starts, const std::vector<int64_t> &ends,
+                                             const std::vector<int64_t> &axes, const std::vector<int64_t> &steps) {
+    const int nd = (int)shape.size();
+    if (starts.size() != ends.size() || (!axes.empty() && axes.size() != starts.size()) || (!steps.empty() && steps.size() != starts.size()))
+        throw OpError(OpError::InvalidValue, "Slice: starts, ends, axes and steps must have the same length");
+    std::vector<SliceRange> r((size_t)nd);
+    for (int d = 0; d < nd; d++) r[(size_t)d] = {0, shape[(size_t)d], 1};
+    for (size_t k = 0; k < starts.size(); k++) {
+        const int ax = resolve_axis((int)(axes.empty() ? (int64_t)k : axes[k]), nd);
+        const int64_t dim = shape[(size_t)ax], step = steps.empty() ? 1 : steps[k];
+        if (step == 0) throw OpError(OpError::InvalidValue, "Slice: steps must be non-zero");
+        int64_t st = starts[k], en = ends[k];
+        if (st < 0) st += dim;
+        if (en < 0) en += dim;
+        if (step > 0) {
+            st = std::min(std::max<int64_t>(st, 0), dim);
+            en = std::min(std::max<int64_t>(en, 0), dim);
+            r[(size_t)ax] = {st, en > st ? (en - st + step - 1) / step : 0, step};
+        } else {
+            st = std::min(std::max<int64_t>(st, -1), dim - 1);
+            en = std::min(std::max<int64_t>(en, -1), dim - 1);
+            r[(size_t)ax] = {st, st > en ? (st - en + (-step) - 1) / (-step) : 0, step};
+        }
+    }
+    return r;
+}
+inline Tensor slice_tensor(Context &ctx, const Tensor &x, const std::vector<SliceRange> &r) {
+    if (dtype_size(x.dtype()) != 4) throw OpError(OpError::UnsupportedType, "");
+    const int nd = x.ndim();
+    if (nd > 6) throw OpError(OpError::UnsupportedValue, "Slice: more than 6 dims on the device path");
+    std::vector<int64_t> oshape((size_t)nd), st((size_t)nd);
+    int64_t acc = 1, base = 0;
+    bool forward = true;
+    for (int d = nd - 1; d >= 0; d--) {
+        oshape[(size_t)d] = r[(size_t)d].count;
+        st[(size_t)d] = acc * r[(size_t)d].step;
+        base += acc * r[(size_t)d].start;
+        if (r[(size_t)d].step < 0) forward = false;
+        acc *= x.size(d);
+    }
+    Tensor y(ctx, oshape, x.dtype());
+    if (!y.len()) return y;
+    if (forward) {
+        ctx.check(rten_hip_copy_strided_b32(ctx.raw(), nd, oshape.data(), st.data(), (const char *)x.ptr() + base * 4, y.ptr()));
+    } else { // negative steps: the strided-copy entry point takes non-negative strides; the generic kernel takes signed ones (Cast int32 -> int32 moves raw words)
+        const int32_t dt = RTEN_HIP_DT_I32;
+        ctx.check(rten_hip_elementwise_nd(ctx.raw(), RTEN_HIP_EW_IADD, nd, oshape.data(), (const char *)x.ptr() + base * 4, dt, st.data(), ctx.zero_i32(), dt,
+                                          std::vector<int64_t>((size_t)nd, 0).data(), nullptr, nullptr, y.ptr(), dt));
+    }
+    return y;
+}
+
+// Concat (src/ops/concat.rs:21-108) of 4-byte tensors along `axis`
+inline Tensor concat_tensors(Context &ctx, const InputList &in, int axis) {
+    const Tensor &first = require(in, 0);
+    const int nd = first.ndim();
+    const int ax = resolve_axis(axis, nd);
+    std::vector<int64_t> oshape = first.shape();
+    oshape[(size_t)ax] = 0;
+    for (size_t k = 0; k < in.size(); k++) {
+        const Tensor &t = require(in, k);
+        if (t.dtype() != first.dtype() || dtype_size(t.dtype()) != 4) throw OpError(OpError::UnsupportedType, "");
+        if (t.ndim() != nd) throw OpError(OpError::IncompatibleInputShapes, "Tensors must have the same number of dimensions");
+        for (int d = 0; d < nd; d++) if (d != ax && t.size(d) != first.size(d)) throw OpError(OpError::IncompatibleInputShapes, "Dimensions must be the same except for concat axis");
+        oshape[(size_t)ax] += t.size(ax);
+    }
+    Tensor y(ctx, oshape, first.dtype());
+    const int64_t outer = detail::prod(oshape, 0, (size_t)ax), inner = detail::prod(oshape, (size_t)ax + 1, oshape.size());
+    const int64_t dst_pitch = oshape[(size_t)ax] * inner;
+    int64_t off = 0;
+    for (size_t k = 0; k < in.size(); k++) {
+        const int64_t row = in[k]->size(ax) * inner;
+        if (row && outer) ctx.check(rten_hip_copy_rows_b32(ctx.raw(), outer, row, in[k]->ptr(), row, (char *)y.ptr() + off * 4, dst_pitch));
+        off += row;
+    }
+    return y;
+}
 
 // ------------------------------------------------------------------------------------------------ Einsum / ReduceSum
 // src/ops/einsum.rs:21-692, rten-shape-inference/src/einsum_parser.rs:68-275, src/ops/reduce.rs:414-520,1101-1165.
@@ -1769,6 +1983,8 @@ class OpRegistry {
         r.register_op<GlobalAveragePool>("GlobalAveragePool");
         r.register_op<DynamicQuantizeLinear>("DynamicQuantizeLinear");
         r.register_op<Cast>("Cast");
+        r.register_op<Tanh>("Tanh");
+        r.register_op<Where>("Where");
         r.register_op<ReduceSum>("ReduceSum");
         r.register_op<ReduceMean>("ReduceMean");
         r.register_op<Einsum>("Einsum");

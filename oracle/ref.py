@@ -336,6 +336,11 @@ def exp(x):
     return _unary("rto_exp", x)
 
 
+def tanh(x):
+    """rten-vecmath/src/tanh.rs: Tanh (the pooler activation of BERT)."""
+    return _unary("rto_tanh", x)
+
+
 def relu(x):
     return _unary("rto_relu", x)
 

@@ -766,6 +766,7 @@ static const float EXP_P0 = 1.0f, EXP_P1 = 1.0f, EXP_P2 = 4.99999851e-1f, EXP_P3
                    EXP_P4 = 4.16695364e-2f, EXP_P5 = 8.37312452e-3f, EXP_P6 = 1.37805939e-3f;
 
 static inline float bits_f32(int32_t i) { float f; memcpy(&f, &i, 4); return f; }
+static inline int32_t f32_bits(float f) { int32_t i; memcpy(&i, &f, 4); return i; }
 
 static inline float exp_poly_reduce(float x, float *jout) {
     float j = fma32(x, INV_LOG2, ROUNDING_MAGIC);
@@ -844,6 +845,27 @@ RTO_API void rto_gelu(int64_t n, const float *x, float *y) {
 }
 RTO_API void rto_erf(int64_t n, const float *x, float *y) {
     for (int64_t i = 0; i < n; i++) y[i] = rto_erf_f32(x[i]);
+}
+RTO_API float rto_tanh_f32(float x) { /* rten-vecmath/src/tanh.rs:12-72 */
+    /* abs / neg are sign-bit operations on the x86 SIMD back ends (rten-simd/src/arch/x86_64/avx512.rs:314-321, avx2.rs likewise) */
+    float ax = bits_f32((int32_t)((uint32_t)f32_bits(x) & 0x7fffffffu));
+    const float p1 = 0.999999940395355224609375f, p3 = -0.33332359790802001953125f, p5 = 0.13310669362545013427734375f,
+                p7 = -5.21197654306888580322265625e-2f, p9 = 1.5497927553951740264892578125e-2f;
+    float x2 = x * x;
+    float ys = fma32(p9, x2, p7);
+    ys = fma32(ys, x2, p5);
+    ys = fma32(ys, x2, p3);
+    ys = fma32(ys, x2, p1);
+    ys = ys * ax;                       /* |x| <= 0.55: odd polynomial */
+    float e = rto_exp_f32(ax * 2.0f);
+    float ym = (e - 1.0f) / (e + 1.0f); /* medium |x| */
+    float y = ax >= 9.02f ? 1.0f : ym;  /* select(one, y_medium, x_cutoff) */
+    y = ax <= 0.55f ? ys : y;           /* select(y_small, y, x_small) */
+    y = ax <= 0.0004f ? ax : y;         /* select(abs_x, y, x_tiny) */
+    return x <= 0.f ? bits_f32((int32_t)((uint32_t)f32_bits(y) ^ 0x80000000u)) : y; /* select(neg(y), y, le(x, 0)) */
+}
+RTO_API void rto_tanh(int64_t n, const float *x, float *y) {
+    for (int64_t i = 0; i < n; i++) y[i] = rto_tanh_f32(x[i]);
 }
 RTO_API void rto_exp(int64_t n, const float *x, float *y) {
     for (int64_t i = 0; i < n; i++) y[i] = rto_exp_f32(x[i]);

@@ -23,12 +23,13 @@ inline int ew_blocks(int64_t work_items) {
     return (int)b;
 }
 
-enum UnaryOp { U_RELU, U_GELU, U_ERF };
+enum UnaryOp { U_RELU, U_GELU, U_ERF, U_TANH };
 
 template <int OP>
 __device__ __forceinline__ float unary(float x) {
     if constexpr (OP == U_RELU) return vm::relu(x);
     else if constexpr (OP == U_GELU) return vm::gelu(x);
+    else if constexpr (OP == U_TANH) return vm::tanh(x);
     else return vm::erf(x);
 }
 
@@ -220,6 +221,9 @@ RTEN_EXPORT int32_t rten_hip_gelu_f32(rten_hip_ctx *ctx, int64_t n, const float 
 RTEN_EXPORT int32_t rten_hip_erf_f32(rten_hip_ctx *ctx, int64_t n, const float *x, float *y) {
     return run_unary<U_ERF>(ctx, n, x, y, "erf_f32");
 }
+RTEN_EXPORT int32_t rten_hip_tanh_f32(rten_hip_ctx *ctx, int64_t n, const float *x, float *y) {
+    return run_unary<U_TANH>(ctx, n, x, y, "tanh_f32");
+}
 RTEN_EXPORT int32_t rten_hip_add_f32(rten_hip_ctx *ctx, int64_t n, const float *a, const float *b, int64_t b_len,
                                      float *y) {
     return run_binary<B_ADD>(ctx, n, a, b, b_len, y, "add_f32");
@@ -365,4 +369,174 @@ RTEN_EXPORT int32_t rten_hip_gather_rows_f32(rten_hip_ctx *ctx, int64_t n_ids, i
                        row_len, table_rows, table, ids, out);
     RTEN_LAUNCH_CHECK(ctx, "gather_rows_kernel");
     return RTEN_HIP_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Layout / logic operators of exporter-written graphs (the executor's "glue" either side of the hot-path operators): Cast, Not / And / Or / Xor,
+// Equal / Less / Greater (...OrEqual), Where, integer Add / Sub / Mul / Div, over operands viewed through element strides (0 = broadcast axis), at most
+// 6 dims, one output element per thread-iteration.  Replaces src/ops/convert.rs:18-60 (`as` casts: float -> int saturates, NaN -> 0; int -> narrower
+// int wraps), src/ops/binary_elementwise.rs:546-598,733-786 (booleans are i32 0 / 1 in the reference: onnx_loader.rs:332-339), :1189-1247 (where_op:
+// cond != 0), unary_elementwise.rs:563-565 (Not).  None of these is on a model's critical path (mask and index preparation): no vector forms.
+namespace {
+struct GenArgs {
+    int32_t ndim, op, a_dt, b_dt, y_dt;
+    int32_t shape[6];
+    int64_t sa[6], sb[6], sc[6];
+    int64_t n;
+};
+struct GenVal { float f; int i; };
+__device__ __forceinline__ GenVal gen_load(const void *p, int dt, int64_t off) {
+    GenVal v;
+    v.f = 0.f; v.i = 0;
+    if (dt == RTEN_HIP_DT_F32) v.f = ((const float *)p)[off];
+    else if (dt == RTEN_HIP_DT_I32) v.i = ((const int32_t *)p)[off];
+    else if (dt == RTEN_HIP_DT_U8) v.i = ((const uint8_t *)p)[off];
+    else v.i = ((const int8_t *)p)[off];
+    return v;
+}
+// Rust `f32 as iN / uN`: truncation toward zero, saturating at the type's bounds, NaN -> 0
+__device__ __forceinline__ int gen_f2i(float f, float lo, float hi, int ilo, int ihi) {
+    if (f != f) return 0;
+    if (f <= lo) return ilo;
+    if (f >= hi) return ihi;
+    return (int)f;
+}
+__global__ __launch_bounds__(EW_THREADS) void generic_nd_kernel(const GenArgs p, const void *__restrict__ a, const void *__restrict__ b, const void *__restrict__ c,
+                                                                void *__restrict__ y) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += stride) {
+        int64_t r = i, ao = 0, bo = 0, co = 0;
+        for (int d = p.ndim - 1; d >= 0; d--) {
+            const int64_t q = r / p.shape[d], k = r - q * p.shape[d];
+            ao += k * p.sa[d]; bo += k * p.sb[d]; co += k * p.sc[d];
+            r = q;
+        }
+        const GenVal va = gen_load(a, p.a_dt, ao);
+        GenVal out;
+        out.f = 0.f; out.i = 0;
+        bool out_f = false;
+        if (p.op == RTEN_HIP_EW_CAST) {
+            const bool af = p.a_dt == RTEN_HIP_DT_F32;
+            if (p.y_dt == RTEN_HIP_DT_F32) { out.f = af ? va.f : (float)va.i; out_f = true; }
+            else if (p.y_dt == RTEN_HIP_DT_I32) out.i = af ? gen_f2i(va.f, -2147483648.f, 2147483648.f, (int)0x80000000, 0x7fffffff) : va.i;
+            else if (p.y_dt == RTEN_HIP_DT_U8) out.i = af ? gen_f2i(va.f, 0.f, 255.f, 0, 255) : (va.i & 0xff);
+            else out.i = af ? gen_f2i(va.f, -128.f, 127.f, -128, 127) : (int)(int8_t)(va.i & 0xff);
+        } else if (p.op == RTEN_HIP_EW_NOT) {
+            out.i = va.i == 0;
+        } else if (p.op == RTEN_HIP_EW_WHERE) {
+            out.i = va.i != 0 ? ((const int32_t *)b)[bo] : ((const int32_t *)c)[co]; // (4-byte payloads moved as raw words)
+        } else {
+            const GenVal vb = gen_load(b, p.b_dt, bo);
+            const bool fl = p.a_dt == RTEN_HIP_DT_F32;
+            switch (p.op) {
+            case RTEN_HIP_EW_AND: out.i = (va.i != 0) && (vb.i != 0); break;
+            case RTEN_HIP_EW_OR: out.i = (va.i != 0) || (vb.i != 0); break;
+            case RTEN_HIP_EW_XOR: out.i = (va.i != 0) != (vb.i != 0); break;
+            case RTEN_HIP_EW_EQUAL: out.i = fl ? va.f == vb.f : va.i == vb.i; break;
+            case RTEN_HIP_EW_LESS: out.i = fl ? va.f < vb.f : va.i < vb.i; break;
+            case RTEN_HIP_EW_LESS_EQ: out.i = fl ? va.f <= vb.f : va.i <= vb.i; break;
+            case RTEN_HIP_EW_GREATER: out.i = fl ? va.f > vb.f : va.i > vb.i; break;
+            case RTEN_HIP_EW_GREATER_EQ: out.i = fl ? va.f >= vb.f : va.i >= vb.i; break;
+            case RTEN_HIP_EW_IADD: out.i = (int)((unsigned)va.i + (unsigned)vb.i); break;
+            case RTEN_HIP_EW_ISUB: out.i = (int)((unsigned)va.i - (unsigned)vb.i); break;
+            case RTEN_HIP_EW_IMUL: out.i = (int)((unsigned)va.i * (unsigned)vb.i); break;
+            default: out.i = vb.i == 0 ? 0 : (va.i == (int)0x80000000 && vb.i == -1 ? va.i : va.i / vb.i); break; // IDIV (the host refuses a constant zero divisor)
+            }
+        }
+        if (p.y_dt == RTEN_HIP_DT_F32) ((float *)y)[i] = out_f ? out.f : __int_as_float(out.i);
+        else if (p.y_dt == RTEN_HIP_DT_I32) ((int32_t *)y)[i] = out.i;
+        else ((uint8_t *)y)[i] = (uint8_t)out.i;
+    }
+}
+
+// y[o][j][k] = data[o][ids[j]][k]: Gather along any axis of 4-byte elements (src/ops/gather.rs:21-110; negative indices count from the end)
+__global__ __launch_bounds__(EW_THREADS) void gather_axis_kernel(int64_t outer, int64_t axis_len, int64_t inner, int64_t n_ids, const uint32_t *__restrict__ data,
+                                                                 const int32_t *__restrict__ ids, uint32_t *__restrict__ y) {
+    const int64_t total = outer * n_ids * inner, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t k = i % inner, j = (i / inner) % n_ids, o = i / (inner * n_ids);
+        int64_t id = ids[j];
+        if (id < 0) id += axis_len;
+        id = id < 0 ? 0 : (id >= axis_len ? axis_len - 1 : id);
+        y[i] = data[(o * axis_len + id) * inner + k];
+    }
+}
+
+// dst[r][0 .. row) = src[r][0 .. row) with independent pitches (elements of 4 bytes): the pieces of a Concat (src/ops/concat.rs:108)
+__global__ __launch_bounds__(EW_THREADS) void copy_rows_kernel(int64_t rows, int64_t row, const uint32_t *__restrict__ src, int64_t src_pitch, uint32_t *__restrict__ dst,
+                                                               int64_t dst_pitch) {
+    const int64_t total = rows * row, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t r = i / row, k = i - r * row;
+        dst[r * dst_pitch + k] = src[r * src_pitch + k];
+    }
+}
+} // namespace
+
+RTEN_EXPORT int32_t rten_hip_elementwise_nd(rten_hip_ctx *ctx, int32_t op, int32_t ndim, const int64_t *shape, const void *a, int32_t a_dtype, const int64_t *a_strides,
+                                            const void *b, int32_t b_dtype, const int64_t *b_strides, const void *c, const int64_t *c_strides, void *y, int32_t y_dtype) {
+    RTEN_CHECK_CTX(ctx);
+    if (op < RTEN_HIP_EW_CAST || op > RTEN_HIP_EW_IDIV || ndim < 0 || ndim > 6 || (ndim && (!shape || !a_strides)))
+        return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "elementwise_nd: unknown op / more than 6 dims");
+    const bool unary = op == RTEN_HIP_EW_CAST || op == RTEN_HIP_EW_NOT, where = op == RTEN_HIP_EW_WHERE;
+    auto dt_ok = [](int32_t d) { return d >= RTEN_HIP_DT_F32 && d <= RTEN_HIP_DT_I8; };
+    if (!dt_ok(a_dtype) || !dt_ok(y_dtype) || (!unary && !where && !dt_ok(b_dtype))) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "elementwise_nd: unknown element type");
+    if (op == RTEN_HIP_EW_CAST) {
+        // every pair of the reference's Cast except same-type (a copy: rten_hip_copy_strided_b32 / memcpy)
+    } else if (where) {
+        if (a_dtype != RTEN_HIP_DT_I32 || (y_dtype != RTEN_HIP_DT_F32 && y_dtype != RTEN_HIP_DT_I32)) return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "elementwise_nd: Where takes an int32 condition and 4-byte operands");
+    } else if (op >= RTEN_HIP_EW_EQUAL && op <= RTEN_HIP_EW_GREATER_EQ) {
+        if ((a_dtype != RTEN_HIP_DT_F32 && a_dtype != RTEN_HIP_DT_I32) || b_dtype != a_dtype || y_dtype != RTEN_HIP_DT_I32) return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "elementwise_nd: comparisons take two float32 or two int32 operands and give int32");
+    } else if (a_dtype != RTEN_HIP_DT_I32 || y_dtype != RTEN_HIP_DT_I32 || (!unary && b_dtype != RTEN_HIP_DT_I32)) {
+        return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "elementwise_nd: logical and integer operators take int32 operands");
+    }
+    GenArgs p = {};
+    p.ndim = ndim; p.op = op; p.a_dt = a_dtype; p.b_dt = b_dtype; p.y_dt = y_dtype;
+    p.n = 1;
+    for (int d = 0; d < ndim; d++) {
+        if (shape[d] < 0 || shape[d] > 0x7fffffff) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "elementwise_nd: bad dimension");
+        p.shape[d] = (int32_t)shape[d];
+        p.sa[d] = a_strides[d];
+        p.sb[d] = (!unary && b_strides) ? b_strides[d] : 0;
+        p.sc[d] = (where && c_strides) ? c_strides[d] : 0;
+        p.n *= shape[d];
+    }
+    if (p.n == 0) return RTEN_HIP_OK;
+    if (!a || !y || (!unary && !b) || (where && !c) || (!unary && ndim && !b_strides) || (where && ndim && !c_strides)) return RTEN_HIP_ERR_INVALID_VALUE;
+    ProfScope ps(ctx, "elementwise_nd", 0.0, 8.0 * p.n);
+    hipLaunchKernelGGL(generic_nd_kernel, dim3(ew_blocks(p.n)), dim3(EW_THREADS), 0, ctx->stream, p, a, b, c, y);
+    RTEN_LAUNCH_CHECK(ctx, "generic_nd_kernel");
+    return RTEN_HIP_OK;
+}
+
+RTEN_EXPORT int32_t rten_hip_gather_axis_b32(rten_hip_ctx *ctx, int64_t outer, int64_t axis_len, int64_t inner, int64_t n_ids, const void *data, const int32_t *ids, void *y) {
+    RTEN_CHECK_CTX(ctx);
+    if (outer < 0 || axis_len <= 0 || inner < 0 || n_ids < 0) return RTEN_HIP_ERR_INVALID_VALUE;
+    const int64_t total = outer * n_ids * inner;
+    if (total == 0) return RTEN_HIP_OK;
+    if (!data || !ids || !y) return RTEN_HIP_ERR_INVALID_VALUE;
+    ProfScope ps(ctx, "gather_axis_b32", 0.0, 8.0 * total);
+    hipLaunchKernelGGL(gather_axis_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, ctx->stream, outer, axis_len, inner, n_ids, (const uint32_t *)data, ids, (uint32_t *)y);
+    RTEN_LAUNCH_CHECK(ctx, "gather_axis_kernel");
+    return RTEN_HIP_OK;
+}
+
+RTEN_EXPORT int32_t rten_hip_copy_rows_b32(rten_hip_ctx *ctx, int64_t rows, int64_t row_elems, const void *src, int64_t src_pitch, void *dst, int64_t dst_pitch) {
+    RTEN_CHECK_CTX(ctx);
+    if (rows < 0 || row_elems < 0 || src_pitch < 0 || dst_pitch < row_elems) return RTEN_HIP_ERR_INVALID_VALUE;
+    if (rows * row_elems == 0) return RTEN_HIP_OK;
+    if (!src || !dst) return RTEN_HIP_ERR_INVALID_VALUE;
+    ProfScope ps(ctx, "copy_rows_b32", 0.0, 8.0 * rows * row_elems);
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(ew_blocks(rows * row_elems)), dim3(EW_THREADS), 0, ctx->stream, rows, row_elems, (const uint32_t *)src, src_pitch, (uint32_t *)dst, dst_pitch);
+    RTEN_LAUNCH_CHECK(ctx, "copy_rows_kernel");
+    return RTEN_HIP_OK;
+}
+
+// 1 while a graph capture is active on the context (host code that would upload from host memory must not do so then: the copy would be recorded with the
+// host pointer and re-read at every replay)
+RTEN_EXPORT int32_t rten_hip_capture_active(rten_hip_ctx *ctx) {
+    if (!ctx) return 0;
+    std::lock_guard<std::recursive_mutex> g(ctx->mu);
+    return ctx->capturing ? 1 : 0;
 }

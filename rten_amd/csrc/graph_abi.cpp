@@ -102,7 +102,7 @@ std::map<std::string, GemmPlan> plan_table(const std::map<std::string, std::vect
 DType elem_dtype(int32_t onnx_type) {
     switch (onnx_type) {
     case onnx::FLOAT: return DType::F32;
-    case onnx::INT32: case onnx::INT64: return DType::I32;
+    case onnx::INT32: case onnx::INT64: case onnx::BOOL: return DType::I32; // int64 and bool are int32 at the API (onnx_loader.rs:332-339)
     case onnx::UINT8: return DType::U8;
     default: return DType::I8;
     }
@@ -249,6 +249,12 @@ RTEN_EXPORT int32_t rten_hip_model_clone(rten_hip_model *src, rten_hip_ctx *ctx,
     if (!src || !ctx || !src->parsed) return load_fail(RTEN_HIP_ERR_INVALID_VALUE, "model_clone: null model / context");
     if (src->origin) src = src->origin; // a clone of a clone shares the same origin
     if (rten_hip_device_id(ctx) != rten_hip_device_id(src->caller)) return load_fail(RTEN_HIP_ERR_INVALID_VALUE, "model_clone: the context lives on another device than the model");
+    // Replicas run side by side on their own streams; a quantized-output launch ("qout" edges of the plan) is a grid-wide exchange that needs the device to
+    // itself (rten_hip.h, rten_hip_conv2d_int8_qout: time-out contract, sticky fault) -- the same reason rten_hip_model_load_ex refuses them with chains != 1.
+    // Refused here, not dropped silently: load the origin from a plan without "qout" (profiles/plans/int8_lanes.json) when replicas are wanted.
+    if (!src->opts.qout.empty())
+        return load_fail(RTEN_HIP_ERR_INVALID_VALUE, "model_clone: the model's plan lists quantized-output edges (\"qout\"), which need the device to themselves; "
+                                                      "replicas run concurrently -- load the origin from a plan without them");
     std::unique_ptr<rten_hip_model> g(new rten_hip_model());
     g->caller = ctx;
     g->chains = src->chains;

@@ -92,6 +92,26 @@ __device__ __forceinline__ float gelu(float x) {
     return half_x * y;
 }
 
+// tanh(x) (rten-vecmath/src/tanh.rs:12-72): odd polynomial for |x| <= 0.55, (exp(2|x|) - 1) / (exp(2|x|) + 1) above it, 1 from 9.02, |x| itself up to
+// 0.0004; the sign is flipped where x <= 0 (so tanh(+0) = -0, as the reference's select on `le(x, 0)` gives)
+__device__ __forceinline__ float tanh(float x) {
+    const float ax = __builtin_fabsf(x);
+    const float p1 = 0.999999940395355224609375f, p3 = -0.33332359790802001953125f, p5 = 0.13310669362545013427734375f,
+                p7 = -5.21197654306888580322265625e-2f, p9 = 1.5497927553951740264892578125e-2f;
+    const float x2 = x * x;
+    float ys = fma(p9, x2, p7);
+    ys = fma(ys, x2, p5);
+    ys = fma(ys, x2, p3);
+    ys = fma(ys, x2, p1);
+    ys = ys * ax;
+    const float e = exp_full(ax * 2.0f);
+    const float ym = (e - 1.0f) / (e + 1.0f);
+    float y = ax >= 9.02f ? 1.0f : ym;
+    y = ax <= 0.55f ? ys : y;
+    y = ax <= 0.0004f ? ax : y;
+    return x <= 0.f ? __int_as_float(__float_as_int(y) ^ (int)0x80000000) : y; // neg = sign-bit xor on the x86 SIMD back ends (rten-simd/src/arch/x86_64/avx512.rs:319-321)
+}
+
 // Relu: f32::max(x, 0) -- NaN -> 0 (unary_elementwise.rs:611-613)
 __device__ __forceinline__ float relu(float x) { return fmaxf(x, 0.f); }
 

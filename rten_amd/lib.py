@@ -155,6 +155,7 @@ PROTOTYPES = {
     "rten_hip_relu_f32": (_I32, [_VP, _I64, _VP, _VP]),
     "rten_hip_gelu_f32": (_I32, [_VP, _I64, _VP, _VP]),
     "rten_hip_erf_f32": (_I32, [_VP, _I64, _VP, _VP]),
+    "rten_hip_tanh_f32": (_I32, [_VP, _I64, _VP, _VP]),
     "rten_hip_add_f32": (_I32, [_VP, _I64, _VP, _VP, _I64, _VP]),
     "rten_hip_mul_f32": (_I32, [_VP, _I64, _VP, _VP, _I64, _VP]),
     "rten_hip_sub_f32": (_I32, [_VP, _I64, _VP, _VP, _I64, _VP]),
@@ -162,6 +163,10 @@ PROTOTYPES = {
     "rten_hip_binary_broadcast_f32": (_I32, [_VP, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP]),
     "rten_hip_transpose_b32": (_I32, [_VP, _I32, _VP, _VP, _VP, _VP]),
     "rten_hip_copy_strided_b32": (_I32, [_VP, _I32, _VP, _VP, _VP, _VP]),
+    "rten_hip_elementwise_nd": (_I32, [_VP, _I32, _I32, _VP, _VP, _I32, _VP, _VP, _I32, _VP, _VP, _VP, _VP, _I32]),
+    "rten_hip_gather_axis_b32": (_I32, [_VP, _I64, _I64, _I64, _I64, _VP, _VP, _VP]),
+    "rten_hip_copy_rows_b32": (_I32, [_VP, _I64, _I64, _VP, _I64, _VP, _I64]),
+    "rten_hip_capture_active": (_I32, [_VP]),
     "rten_hip_reduce_sum_strided_f32": (_I32, [_VP, _I32, _VP, _VP, _I32, _VP, _VP, _VP, _VP]),
     "rten_hip_reduce_mean_strided_f32": (_I32, [_VP, _I32, _VP, _VP, _I32, _VP, _VP, _VP, _VP]),
     "rten_hip_conv_transpose_output_size": (_I32, [_I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP, _I32, _I32, _I32, _I32, _VP, _VP, _VP]),

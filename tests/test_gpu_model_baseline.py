@@ -45,12 +45,14 @@ def test_resnet50_f32_batch32_four_chains_committed_plan_is_the_oracle():
     onnx_bytes = ow.resnet50_f32(bo.resnet_weights())
     ctx = L.Context(0)
     try:
-        for chains, plan in ((4, "f32_4chains.json"), (1, "f32_1chain.json")):
+        # (1, "f32_lanes.json") is the plan of bench.py's DEFAULT line (one chain per replica, two replicas): the one-chain plan + the classifier entry
+        for chains, plan in ((4, "f32_4chains.json"), (1, "f32_1chain.json"), (1, "f32_lanes.json")):
             m = L.Model(ctx, onnx_bytes, _plan(plan), chains)
             try:
                 m.bind_input("x", x.shape)
                 m.prepare()
-                assert m.planned_steps == 53, m.planned_steps  # every convolution took its entry of the committed plan
+                # every convolution took its entry of the committed plan (f32_lanes.json: + the classifier Gemm's)
+                assert m.planned_steps == (54 if plan == "f32_lanes.json" else 53), (plan, m.planned_steps)
                 assert m.warning == "", m.warning
                 ptr, nbytes = m.weight_arena()
                 assert ptr and nbytes > 100 << 20  # 25.5 M f32 parameters + their prepacked images, one allocation
@@ -65,7 +67,7 @@ def test_resnet50_f32_batch32_four_chains_committed_plan_is_the_oracle():
                         assert r.weight_arena() == m.weight_arena()  # ONE weight set
                         r.bind_input("x", x.shape)
                         r.prepare()
-                        assert r.planned_steps == 53
+                        assert r.planned_steps == m.planned_steps
                         from rten_amd.tensor import DeviceTensor
                         DeviceTensor(ctx2, x.shape, np.float32, ptr=r.input_ptrs["x"], keepalive=r).upload(x[::-1].copy())
                         ctx2.sync()
@@ -121,6 +123,53 @@ def test_resnet50_int8_batch32_committed_plan_is_the_oracle():
                 m.close()
     finally:
         ctx.close()
+
+
+def test_resnet50_int8_four_replicas_side_by_side_on_different_batches():
+    """bench.py --config int8 exactly as the default line runs it: profiles/plans/int8_lanes.json (quantize-on-load layers, NO quantized-output edges), four replicas
+    of one model on four contexts, consecutive batches handed round robin -- here two DIFFERENT batches (seeds 1234 / 1235) alternating over the replicas, all in
+    flight together.  Every replica's logits are the oracle's for ITS batch (each batch quantizes with its own statistics).  And the rule that makes the plan
+    what it is: a model whose plan lists quantized-output edges cannot be cloned."""
+    from rten_amd import lib as L, onnx_writer as ow
+    from rten_amd.tensor import DeviceTensor
+    onnx_bytes = ow.resnet50_int8(bo.resnet_weights())
+    seeds = (1234, 1235, 1234, 1235)
+    plan = json.loads(_plan("int8_lanes.json"))
+    assert "qout" not in plan
+    ctxs = [L.Context(0) for _ in seeds]
+    models = []
+    try:
+        q = L.Model(ctxs[0], onnx_bytes, _plan("int8.json"), 1)  # (its plan has "qout" edges)
+        try:
+            with pytest.raises(L.HipError) as e:
+                q.clone(ctxs[1])
+            assert "qout" in str(e.value) and "replicas" in str(e.value), str(e.value)
+        finally:
+            q.close()
+        models.append(L.Model(ctxs[0], onnx_bytes, _plan("int8_lanes.json"), 1))
+        for c in ctxs[1:]:
+            models.append(models[0].clone(c))
+        for m, c, seed in zip(models, ctxs, seeds):
+            x = bo.resnet_input(seed)
+            m.bind_input("x", x.shape)
+            m.prepare()
+            assert m.planned_steps == 5, m.planned_steps  # the listed layers whose quantizer has no other reader
+            assert m.weight_arena() == models[0].weight_arena()
+            DeviceTensor(c, x.shape, np.float32, ptr=m.input_ptrs["x"], keepalive=m).upload(x)
+            c.sync()
+        for _ in range(5):
+            for m in models:
+                m.run(join=False)
+        for m in models:
+            m.sync()
+        for i, (m, c, seed) in enumerate(zip(models, ctxs, seeds)):
+            optr, oshape = m.output(0)
+            _bits_equal(DeviceTensor(c, oshape, np.float32, ptr=optr, keepalive=m).numpy(), bo.resnet50_int8_logits(seed), f"int8 replica {i} (seed {seed}) beside three others")
+    finally:
+        for m in reversed(models):
+            m.close()
+        for c in ctxs:
+            c.close()
 
 
 def test_bert_base_batch32_seq128_through_the_model_abi_is_the_oracle():
