@@ -53,7 +53,9 @@ extern "C" {
 /* v6 (round 6): + rten_hip_elementwise_nd (Cast / Not / And / Or / Xor / Equal / Less.. / Where / integer arithmetic over strided operands),
  * rten_hip_gather_axis_b32, rten_hip_copy_rows_b32, rten_hip_tanh_f32, rten_hip_capture_active -- the layout / logic operators an exporter-written
  * transformer graph carries around its hot-path operators (src/ops/convert.rs, binary_elementwise.rs, gather.rs, concat.rs); rten_hip_model_clone
- * refuses a model whose plan lists quantized-output edges.
+ * refuses a model whose plan lists quantized-output edges; rten_hip_conv2d_int8_qout with sync == NULL = the recompute form (plan key "qout2");
+ * measurement-only paths (rten_hip_set_gemm_order bit 3, RTEN_HIP_DEBUG bits 24-31) exist in -DRTEN_ABLATION builds only; rten_hip_tuning_restore puts
+ * every knob back even when one setter objects.
  * v5 (round 5b): + rten_hip_model_input_dtype / rten_hip_model_output_dtype (a host that moves the inputs / outputs of a resident subgraph must know
  * their element types: BERT-class graphs take integer inputs).
  * v4 (round 5): + rten_hip_device_id, rten_hip_tuning_save / _restore (a library-level caller on a borrowed context puts the owner's knobs back),
@@ -334,7 +336,11 @@ int32_t rten_hip_conv2d_int8_dql(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_d
  * nevertheless waits longer than ~0.5 s for its grid (the device was shared with other work) gives up LOUDLY: it sets the block's time-out flag
  * (rten_hip_grid_sync_timeouts), stores NaN as `next_scale` / `product` -- statistics that miss a workgroup never become plausible codes: every value
  * downstream is NaN -- and raises the context's sticky fault: rten_hip_sync and rten_hip_graph_launch fail with RTEN_HIP_ERR_HIP from then on, until
- * rten_hip_grid_sync_reset (which also clears the fault).  A library-level executor keeps this launch form opt-in (launch plan), never a default. */
+ * rten_hip_grid_sync_reset (which also clears the fault).  A library-level executor keeps this launch form opt-in (launch plan), never a default.
+ * `sync` == NULL (v6) selects the RECOMPUTE form instead: two launches -- the convolution with its epilogue but no stores (statistics into `stats`), then
+ * the convolution again, which folds `stats`, quantizes in its epilogue and writes the same staged image / scale / zero point / product.  No grid-wide
+ * exchange, no residency requirement, no time-out: safe beside other work (replicas, "lanes").  Covered: the single-row-term form (signed weights without
+ * a zero point, one activation zero point) without a residual; RTEN_HIP_ERR_UNSUPPORTED otherwise -> the two-operator sequence. */
 size_t rten_hip_grid_sync_bytes(void);
 int32_t rten_hip_grid_sync_reset(rten_hip_ctx *ctx, void *sync, int32_t count /* consecutive blocks */);
 int32_t rten_hip_conv2d_int8_qout(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *desc, const void *x, const void *w,
@@ -535,6 +541,7 @@ int32_t rten_hip_comm_destroy(rten_hip_ctx *ctx, rten_hip_comm *comm);
  * A plan file may also carry {"qout": [ConvInteger node names]} (profiles/plans/int8.json): with chains == 1 those fused ConvIntegerToFloat steps
  * run the DynamicQuantizeLinear of the one convolution reading their output in the same launch (rten_hip_conv2d_int8_qout above, with its opt-in and
  * time-out contract; an edge whose launch is refused at run time runs the two operators).  rten_hip_model_info's n_planned_steps counts them.
+ * {"qout2": [names]} (v6) lists edges for the recompute form of the same entry point (sync == NULL): no exchange, so they are allowed with replicas.
  * Errors: the usual status codes; rten_hip_model_last_error has the text.  Not thread-safe per model object (one caller at a time). */
 typedef struct rten_hip_model rten_hip_model;
 int32_t rten_hip_model_load(rten_hip_ctx *ctx, const void *onnx_bytes, size_t onnx_len, const char *plan_json /* optional */, int32_t chains,
@@ -618,7 +625,8 @@ int32_t rten_hip_set_gemm_split(rten_hip_ctx *ctx, int32_t mode, int32_t groups)
  * bit 1 = split-K workgroups walk tiles fastest and K groups slowest, so that each XCD's private L2 holds one K
  * slice of both operands; bit 3 = RELAXED split-K (LDS-DMA pipelines, split modes 1-2): a K group's depth blocks accumulate in one register block
  * and one partial per group is folded -- NOT the reference's order (results differ in the last bits): exists to MEASURE what an order-free split would
- * gain (profiles/r08/), never part of a committed plan; bits 4-6 = occupancy cap of the LDS-DMA kernels (workgroups per compute unit, 2..7; 0 = whatever fits:
+ * gain (profiles/r08/), never part of a committed plan, and since v6 ACCEPTED ONLY BY MEASUREMENT BUILDS (build.sh -DRTEN_ABLATION): the product library
+ * rejects it with RTEN_HIP_ERR_INVALID_VALUE, so that no plan file can switch the bit-exactness contract off; bits 4-6 = occupancy cap of the LDS-DMA kernels (workgroups per compute unit, 2..7; 0 = whatever fits:
  * the launch is padded with dynamic LDS it never touches). */
 int32_t rten_hip_set_gemm_order(rten_hip_ctx *ctx, int32_t order);
 /* int8 kernels: 0 = automatic (operands staged chunk-major / padded channel-blocked + 16-byte LDS-DMA MFMA kernel whenever it

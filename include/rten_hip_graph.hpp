@@ -510,6 +510,10 @@ class Graph {
         // runs the DynamicQuantizeLinear of the one convolution reading its output (rten_hip_conv2d_int8_qout).  That launch needs the device to
         // itself (all its workgroups resident at once; rten_hip.h states the time-out contract), so it is never a default.
         std::set<std::string> qout;
+        // The same edges in the RECOMPUTE form (plan key "qout2"; round 6): the producing convolution runs twice -- statistics only, then again with the
+        // consumer's codes as its output -- so there is no grid-wide exchange and no residency requirement: replicas side by side ("lanes") may use it.  The
+        // f32 tensor of the edge is never written or read back (8 B per element of HBM traffic saved for one more pass over small int8 operands).
+        std::set<std::string> qout_recompute;
         // Opt-in, per layer (profiles/plans/int8.json "fused_dql"): pointwise ConvInteger nodes, by name, whose fused ConvIntegerToFloat step runs its
         // DynamicQuantizeLinear inside its own operand loader (rten_hip_conv2d_int8_dql) instead of reading the staged codes.
         std::set<std::string> fused_dql;
@@ -571,6 +575,9 @@ class Graph {
         for (auto &st : steps_) if (st.batch_coupled) return st.kind_name + " \"" + st.name + "\"";
         return "";
     }
+    // ... and what only a RUN can tell (ranks are run-time facts here): a Softmax / LayerNormalization / ReduceSum / ReduceMean whose NEGATIVE axis resolved to
+    // dim 0, or a device Transpose that moved dim 0.  Empty, or the first such step of the last run (rten_hip_model_prepare checks it after its probe run).
+    const std::string &runtime_batch_coupled_step() const { return runtime_coupled_; }
     std::vector<std::string> step_names() const {
         std::vector<std::string> v;
         for (auto &s : steps_) v.push_back(s.kind_name + ":" + s.name);
@@ -656,6 +663,7 @@ class Graph {
         std::vector<const Tensor *> val(names_.size(), nullptr);
         std::vector<std::unique_ptr<Tensor>> owned(names_.size());
         std::vector<int> pending(uses_);
+        runtime_coupled_.clear();
         for (auto &kv : consts_) val[(size_t)kv.first] = &kv.second;
         for (auto &fd : feeds) {
             auto it = ids_.find(fd.first);
@@ -761,6 +769,10 @@ class Graph {
         return packed_.back().get();
     }
     std::vector<Step> steps_;
+    std::string runtime_coupled_;
+    void note_axis(const std::string &kind, const std::string &name, int axis, const Tensor &x) {
+        if (axis < 0 && x.ndim() > 0 && axis + x.ndim() == 0 && runtime_coupled_.empty()) runtime_coupled_ = kind + " \"" + name + "\" (axis " + std::to_string(axis) + " of a rank-" + std::to_string(x.ndim()) + " input is dim 0)";
+    }
     std::vector<int> uses_;
     std::vector<onnx::ValueInfo> inputs_, outputs_;
     size_t fused_away_ = 0;
@@ -866,14 +878,14 @@ class Graph {
             steps_[w.dql].dql_staged->stats_in = blk;
             steps_[w.dql].kind_name = "DynamicQuantizeLinear(staged, producer statistics)";
         }
-        if (opt_.qout.empty()) return;
+        if (opt_.qout.empty() && opt_.qout_recompute.empty()) return;
         // Opt-in edges: the quantizer moves INTO its producer's launch.  The merged step produces the conv's f32 tensor (only if somebody else reads
         // it: a residual Add) and the quantizer's outputs; the quantizer's step disappears.  A launch that is refused at run time (its grid is not
         // resident at once) runs the two operators instead, from then on.
         std::vector<Pending> edges;
         for (auto &w : want_stats) {
             Step &P = steps_[w.producer], &D = steps_[w.dql];
-            if (!P.i8 || !P.i8->to_float || !opt_.qout.count(P.name) || !P.i8->sg.x_staged || !P.i8->sg.packed_weight) continue;
+            if (!P.i8 || !P.i8->to_float || !(opt_.qout.count(P.name) || opt_.qout_recompute.count(P.name)) || !P.i8->sg.x_staged || !P.i8->sg.packed_weight) continue;
             size_t quantizers = 0;
             for (size_t u : consumers[D.in[0]]) if (steps_[u].dql_staged) quantizers++;
             if (quantizers != 1) continue;
@@ -887,16 +899,17 @@ class Graph {
             Step &P = steps_[edges[e].producer], &D = steps_[edges[e].dql];
             bool keep = consumers[D.in[0]].size() > 1;
             for (auto &o : outputs_) if (ids_.at(o.name) == D.in[0]) keep = true;
-            void *sync = (char *)sync_arena_->ptr() + gb * e;
+            const bool recompute = !opt_.qout.count(P.name); // (listed under "qout2" only: no exchange block is used)
+            void *sync = recompute ? nullptr : (char *)sync_arena_->ptr() + gb * e;
             auto state = P.i8;
             state->qout_producer = true;
             auto dql = D.dql_staged;
             auto two_launches = P.run;
-            P.run = [state, dql, two_launches, sync, keep](Context &c, const InputList &in) {
+            P.run = [state, dql, two_launches, sync, keep, recompute](Context &c, const InputList &in) {
                 OutputList out;
                 bool per_channel = false;
                 if (!state->qout_off && i8_fused_form(*state, in, per_channel)) {
-                    if (dql->run_in_producer(c, *state->op, InputList(in.begin(), in.begin() + 4), *in[4], in[5], in[6], state->relu, state->sg, per_channel, sync, keep, out))
+                    if (dql->run_in_producer(c, *state->op, InputList(in.begin(), in.begin() + 4), *in[4], in[5], in[6], state->relu, state->sg, per_channel, sync, keep, out, recompute))
                         return out;
                     state->qout_off = true;
                 }
@@ -906,7 +919,7 @@ class Graph {
                 return out;
             };
             P.out.insert(P.out.end(), D.out.begin(), D.out.end());
-            P.kind_name += " + DynamicQuantizeLinear(staged) in one launch";
+            P.kind_name += recompute ? " + DynamicQuantizeLinear(staged) by recomputation (statistics pass + code pass)" : " + DynamicQuantizeLinear(staged) in one launch";
             D.removed = true;
             fused_away_++;
             qout_edges_++;
@@ -1808,7 +1821,8 @@ class Graph {
                 op->axis = (int)n.get_int("axis", -1);
                 op->epsilon = n.get_float("epsilon", 1e-5f);
                 st.batch_coupled = op->axis == 0;
-                st.run = [op](Context &c, const InputList &in) { return op->run(c, in); };
+                const std::string nm = st.name;
+                st.run = [this, op, nm](Context &c, const InputList &in) { note_axis("LayerNormalization", nm, op->axis, require(in, 0)); return op->run(c, in); };
             } else if (n.op_type == "Gelu" && n.attr("approximate") && n.attr("approximate")->s != "none") {
                 throw GraphError("Gelu " + st.name + ": approximate=\"" + n.attr("approximate")->s + "\" is not supported");
             } else if (n.op_type == "MaxPool" || n.op_type == "AveragePool") {
@@ -1847,12 +1861,14 @@ class Graph {
                     st.in.resize(1);
                 }
                 st.batch_coupled = op->axes.empty() ? !op->noop_with_empty_axes : std::count(op->axes.begin(), op->axes.end(), 0) != 0; // sums over dim 0
-                st.run = [op](Context &c, const InputList &in) { return op->run(c, in); };
+                const std::string kind = n.op_type, nm = st.name;
+                st.run = [this, op, kind, nm](Context &c, const InputList &in) { for (int a : op->axes) note_axis(kind, nm, a, require(in, 0)); return op->run(c, in); };
             } else if (n.op_type == "Softmax") {
                 auto op = std::make_shared<Softmax>();
                 op->axis = (int)n.get_int("axis", -1);
                 st.batch_coupled = op->axis == 0;
-                st.run = [op](Context &c, const InputList &in) { return op->run(c, in); };
+                const std::string nm = st.name;
+                st.run = [this, op, nm](Context &c, const InputList &in) { note_axis("Softmax", nm, op->axis, require(in, 0)); return op->run(c, in); };
             } else if (n.op_type == "Flatten" || n.op_type == "Reshape" || n.op_type == "Squeeze" || n.op_type == "Unsqueeze" || n.op_type == "Identity" ||
                        n.op_type == "Dropout") {
                 make_view_step(st, n, m);
@@ -1952,7 +1968,12 @@ class Graph {
             dev->perm = n.get_ints("perm", {});
             const std::vector<int> perm = dev->perm;
             make_hostable(st, [perm](const std::vector<const HostVal *> &v, HostVal &out) { if (v.size() != 1 || !v[0]) return false; out = hostops::transpose(*v[0], perm); return true; },
-                          [dev](Context &c, const InputList &in) { return dev->run(c, in); });
+                          [this, dev, name](Context &c, const InputList &in) {
+                              const int nd = require(in, 0).ndim(); // a device transpose that moves dim 0 mixes the rows sub-batch chains would split
+                              const int p0 = dev->perm.empty() ? nd - 1 : (dev->perm[0] < 0 ? dev->perm[0] + nd : dev->perm[0]);
+                              if (nd > 1 && p0 != 0 && runtime_coupled_.empty()) runtime_coupled_ = "Transpose \"" + name + "\" (moves dim 0)";
+                              return dev->run(c, in);
+                          });
             return true;
         }
         if (op == "Gather") {

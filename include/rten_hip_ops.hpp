@@ -1222,9 +1222,12 @@ struct DynamicQuantizeLinearStaged : Operator {
     // block.  out = {prod's f32 output (empty unless keep_f32), codes, scale, zero point[, product]}.  Returns false when the launch form does not
     // apply (geometry not covered, or more workgroups than the device holds at once: RTEN_HIP_ERR_UNSUPPORTED): run the two operators then.  Opt-in
     // (launch plan) only: see the time-out contract in rten_hip.h.
+    // `sync` == nullptr with `recompute`: the two-launch recompute form (statistics-only pass, then the convolution again with the codes as its output) -- no
+    // grid-wide exchange, so replicas running side by side may use it.
     bool run_in_producer(Context &ctx, const ConvInteger &prod, const InputList &in, const Tensor &scale, const Tensor *bias, const Tensor *residual, bool relu,
-                         const ConvInteger::Staging &sg, bool per_channel_scale, void *sync, bool keep_f32, OutputList &out) const {
-        if (mul_by.size() > kMaxProducts || !sync || !sg.stats_out || !sg.x_staged || !sg.packed_weight || !sg.packed_weight->len()) return false;
+                         const ConvInteger::Staging &sg, bool per_channel_scale, void *sync, bool keep_f32, OutputList &out, bool recompute = false) const {
+        if (mul_by.size() > kMaxProducts || (!sync && !recompute) || !sg.stats_out || !sg.x_staged || !sg.packed_weight || !sg.packed_weight->len()) return false;
+        if (recompute) sync = nullptr;
         const Tensor &x = require(in, 0), &w = require(in, 1);
         const Tensor *x_zp = get(in, 2), *w_zp = get(in, 3);
         rten_hip_conv2d_int8_desc di = prod.desc(x, w, x_zp, w_zp);

@@ -637,8 +637,12 @@ int32_t rten_sdpa_fused(rten_hip_ctx *ctx, const rten_hip_sdpa_desc *d, const fl
         a.s_tiles = d->s / SQ16;
         const dim3 grid((unsigned)((long long)d->batch * d->heads * a.s_tiles)), block(256);
         const bool flush = d->flush_nan_to_zero != 0;
+        a.debug = 0;
+#ifdef RTEN_ABLATION // measurement builds only (build.sh -DRTEN_ABLATION): the ablation instantiations compute WRONG results; the product library has none
         a.debug = (int)((unsigned)ctx->debug >> 24);
+#endif
         if (a.debug) { // the ablation ladder of tools/probe_sdpa.py (timing only)
+#ifdef RTEN_ABLATION
 #define RTEN_SDPA16_ABL(V) case V: if (mask) hipLaunchKernelGGL((sdpa_fused16_kernel<true, false, V>), grid, block, 0, ctx->stream, a); else hipLaunchKernelGGL((sdpa_fused16_kernel<false, false, V>), grid, block, 0, ctx->stream, a); break;
             switch (a.debug & 255) {
                 RTEN_SDPA16_ABL(1) RTEN_SDPA16_ABL(2) RTEN_SDPA16_ABL(4) RTEN_SDPA16_ABL(8) RTEN_SDPA16_ABL(12) RTEN_SDPA16_ABL(16) RTEN_SDPA16_ABL(32) RTEN_SDPA16_ABL(48)
@@ -646,6 +650,7 @@ int32_t rten_sdpa_fused(rten_hip_ctx *ctx, const rten_hip_sdpa_desc *d, const fl
             default: if (mask) hipLaunchKernelGGL((sdpa_fused16_kernel<true, false, 0>), grid, block, 0, ctx->stream, a); else hipLaunchKernelGGL((sdpa_fused16_kernel<false, false, 0>), grid, block, 0, ctx->stream, a);
             }
 #undef RTEN_SDPA16_ABL
+#endif
         }
         else if (mask) { if (flush) hipLaunchKernelGGL((sdpa_fused16_kernel<true, true>), grid, block, 0, ctx->stream, a); else hipLaunchKernelGGL((sdpa_fused16_kernel<true, false>), grid, block, 0, ctx->stream, a); }
         else { if (flush) hipLaunchKernelGGL((sdpa_fused16_kernel<false, true>), grid, block, 0, ctx->stream, a); else hipLaunchKernelGGL((sdpa_fused16_kernel<false, false>), grid, block, 0, ctx->stream, a); }
@@ -653,7 +658,10 @@ int32_t rten_sdpa_fused(rten_hip_ctx *ctx, const rten_hip_sdpa_desc *d, const fl
         ProfScope ps(ctx, "sdpa_fused_kernel", flops, bytes);
         // the additive mask of a [B, 1, 1, T] attention mask (row stride 0, at least T values per batch item): one LDS copy per workgroup
         const bool mlds = mask && d->mask_row_stride == 0 && !(ctx->debug & 0x400000);
+        a.debug = 0;
+#ifdef RTEN_ABLATION
         a.debug = (ctx->debug >> 24) & 63;
+#endif
         const bool full = d->t == TT && d->s % SQ == 0 && !(ctx->debug & 0x800000); // (bit 0x800000: the general form, A/B)
         const bool flush = d->flush_nan_to_zero != 0;
         const dim3 grid((unsigned)wgs), block(256);
@@ -665,8 +673,11 @@ int32_t rten_sdpa_fused(rten_hip_ctx *ctx, const rten_hip_sdpa_desc *d, const fl
             else { if (full) { if (flush) RTEN_SDPA_GO(ABLV, false, true, true); else RTEN_SDPA_GO(ABLV, false, true, false); }          \
                    else { if (flush) RTEN_SDPA_GO(ABLV, false, false, true); else RTEN_SDPA_GO(ABLV, false, false, false); } }           \
         } while (0)
+#ifdef RTEN_ABLATION
         if (a.debug) RTEN_SDPA_PICK(true);
-        else RTEN_SDPA_PICK(false);
+        else
+#endif
+        RTEN_SDPA_PICK(false);
 #undef RTEN_SDPA_PICK
 #undef RTEN_SDPA_GO
     } else {

@@ -130,7 +130,10 @@ RTEN_EXPORT int32_t rten_hip_init(int32_t device_id, void *external_stream, rten
     rten_hip_ctx *ctx = new rten_hip_ctx();
     ctx->device = device_id;
     ctx->num_cus = prop.multiProcessorCount;
-    if (const char *dbg = getenv("RTEN_HIP_DEBUG")) ctx->debug = (int)strtoul(dbg, nullptr, 0); // (all 32 bits; decimal or 0x...)
+    if (const char *dbg = getenv("RTEN_HIP_DEBUG")) ctx->debug = (int)strtoul(dbg, nullptr, 0); // (decimal or 0x...)
+#ifndef RTEN_ABLATION // bits 24-31 select ablation instantiations (wrong results, timing only): they exist in -DRTEN_ABLATION builds only
+    if ((unsigned)ctx->debug >> 24) { fprintf(stderr, "rten_hip: RTEN_HIP_DEBUG bits 24-31 (ablation kernels) are ignored: this library was not built with -DRTEN_ABLATION\n"); ctx->debug &= 0x00ffffff; }
+#endif
     if (external_stream) {
         ctx->stream = (hipStream_t)external_stream;
     } else {
@@ -424,13 +427,17 @@ RTEN_EXPORT int32_t rten_hip_tuning_save(rten_hip_ctx *ctx, int32_t state[8]) {
 RTEN_EXPORT int32_t rten_hip_tuning_restore(rten_hip_ctx *ctx, const int32_t state[8]) {
     RTEN_CHECK_CTX(ctx);
     if (!state) return RTEN_HIP_ERR_INVALID_VALUE;
-    if (const int32_t rc = rten_hip_set_gemm_variant_override(ctx, state[0])) return rc;
-    if (const int32_t rc = rten_hip_set_gemm_split(ctx, state[1], state[2])) return rc;
-    if (const int32_t rc = rten_hip_set_gemm_order(ctx, state[3])) return rc;
-    if (const int32_t rc = rten_hip_set_gemv_order(ctx, state[4], state[5])) return rc;
+    // every knob is put back even if one setter objects (the values were valid when they were saved; a borrowed context must not be left half restored):
+    // the first error is what the call returns
+    int32_t first = RTEN_HIP_OK;
+    auto keep = [&](int32_t rc) { if (rc != RTEN_HIP_OK && first == RTEN_HIP_OK) first = rc; };
+    keep(rten_hip_set_gemm_variant_override(ctx, state[0]));
+    keep(rten_hip_set_gemm_split(ctx, state[1], state[2]));
+    keep(rten_hip_set_gemm_order(ctx, state[3]));
+    keep(rten_hip_set_gemv_order(ctx, state[4], state[5]));
     ctx->int8_path = state[6];
     ctx->sdpa_path = state[7];
-    return RTEN_HIP_OK;
+    return first;
 }
 
 RTEN_EXPORT int32_t rten_hip_profile_enable(rten_hip_ctx *ctx, int32_t on) {

@@ -2860,7 +2860,12 @@ RTEN_EXPORT int32_t rten_hip_set_gemm_split(rten_hip_ctx *ctx, int32_t mode, int
 // workgroups walk tiles fastest and K groups slowest (each XCD's L2 then holds one K slice of both operands).
 RTEN_EXPORT int32_t rten_hip_set_gemm_order(rten_hip_ctx *ctx, int32_t order) {
     RTEN_CHECK_CTX(ctx);
-    if (order < 0 || (order & ~0x7b)) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "set_gemm_order: bits 0-1 (tile walk), 3 (relaxed split-K, measurement only) and 4-6 (workgroups per compute unit) only");
+#ifdef RTEN_ABLATION // bit 3 = relaxed split-K (one partial per K group: NOT the reference's order, NOT bit-exact): measurement builds only
+    constexpr int allowed = 0x7b;
+#else
+    constexpr int allowed = 0x73;
+#endif
+    if (order < 0 || (order & ~allowed)) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "set_gemm_order: bits 0-1 (tile walk) and 4-6 (workgroups per compute unit) only (bit 3, the relaxed split-K, exists in -DRTEN_ABLATION measurement builds)");
     ctx->tile_order = order;
     return RTEN_HIP_OK;
 }
@@ -2898,7 +2903,8 @@ int32_t launch_smallm(rten_hip_ctx *ctx, GemmArgs &a, const rten_hip_gemm_desc *
     if (nblk > 1) {
         if (!ctx->split_counters || gx * 4 > rten_hip_ctx::kSplitCounters) return RTEN_HIP_ERR_UNSUPPORTED;
         char *sc = (char *)rten_scratch(ctx, 4096 + (size_t)gx * (size_t)nblk * 4096);
-        if (!sc) return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "split-K slab allocation failed (or attempted during graph capture)");
+        // (growing the slab is impossible while a capture is active: decline, the tiled kernels run the product -- ADVICE round 5)
+        if (!sc) return ctx->capturing ? RTEN_HIP_ERR_UNSUPPORTED : rten_set_error(ctx, RTEN_HIP_ERR_HIP, "split-K slab allocation failed");
         a.slab = (float *)(sc + 4096);
         a.split_counters = ctx->split_counters;
     }

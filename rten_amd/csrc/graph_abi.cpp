@@ -186,6 +186,8 @@ RTEN_EXPORT int32_t rten_hip_model_load_ex(rten_hip_ctx *ctx, const void *onnx_b
             if ((pj.names.count("qout") && !pj.names["qout"].empty()) && chains != 1)
                 return load_fail(RTEN_HIP_ERR_INVALID_VALUE, "model_load: the plan lists quantized-output edges (\"qout\"), which need chains == 1");
             if (pj.names.count("qout")) opts.qout.insert(pj.names["qout"].begin(), pj.names["qout"].end());
+            // "qout2": the same kind of edge in the recompute form (two launches, no exchange): allowed with replicas
+            if (pj.names.count("qout2")) opts.qout_recompute.insert(pj.names["qout2"].begin(), pj.names["qout2"].end());
             if (pj.names.count("fused_dql")) opts.fused_dql.insert(pj.names["fused_dql"].begin(), pj.names["fused_dql"].end());
         }
         for (int c = 0; c < chains; c++) {
@@ -387,6 +389,9 @@ RTEN_EXPORT int32_t rten_hip_model_prepare(rten_hip_model *g, int32_t tune) {
             if (lone_row) cx.check(rten_hip_set_gemv_order(cx.raw(), 0, 0));
             if (c == 0) { // resident full-batch outputs, shaped from chain 0's (un-captured) first run
                 const std::vector<Tensor> probe = gr.run(feeds);
+                // what only a run can tell about dim-0 coupling (negative axes resolved against the ranks just seen, device transposes that move dim 0)
+                if (g->chains > 1 && !gr.runtime_batch_coupled_step().empty())
+                    return fail(g, RTEN_HIP_ERR_UNSUPPORTED, "prepare: chains > 1, but " + gr.runtime_batch_coupled_step() + " couples the rows of dim 0");
                 for (size_t o = 0; o < probe.size(); o++) {
                     std::vector<int64_t> s = probe[o].shape();
                     if (s.empty()) return fail(g, RTEN_HIP_ERR_UNSUPPORTED, "a scalar graph output cannot be split over chains");

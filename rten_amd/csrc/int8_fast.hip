@@ -30,6 +30,8 @@
 //     (kernarg_prefetch), index arithmetic by multiply-shift (rten_div), no arithmetic on a loaded value before the main loop (it would drain the
 //     vector-memory counter in front of the first operand request), the launch's single activation zero point through the scalar cache, and the
 //     single-row-term epilogue of the convolution form as a template flag (RT).
+#include <cstring>
+
 #include "internal.h"
 #include "quantize.h"
 #include "vecmath.h"
@@ -80,6 +82,13 @@ struct FastArgs {
     int q_cb, q_Hp, q_Wp, q_pt, q_pl, q_H, q_W, q_pad_mode;
     unsigned q_bytes;
     int debug_flags; // RTEN_HIP_DEBUG tuning switches seen by the kernel (bit 0: general zero-point algebra everywhere)
+    // KS kernels (cross-workgroup K split): `ks` workgroups share one output tile, each sums its slice of the k-tiles, parks the raw int32 partial in `slab`
+    // ([tile][part][wave][register quad][lane] x 16 B) and arrives on the tile's counter; the last arrival adds the others' partials to its own registers
+    // (integer addition: any order gives the same bits) and runs the epilogue
+    int ks;
+    int *slab;
+    unsigned *ks_counters;
+    int no_store; // statistics-only launch (pass 1 of the recompute form of a quantized output): the epilogue runs, nothing is stored
     // exact division by the conv geometry's run-time divisors as multiply + shift (filled by launch_fast): the prologue's per-lane
     // pixel decode and the chunk table otherwise spend ~40 VALU instructions per division, on every resident wave at once
     RtenDiv d_pn, d_ow, d_cpc, d_kw, d_hw, d_qw, d_tile;
@@ -354,8 +363,19 @@ constexpr unsigned kSyncGranules = 2048;  // >= the workgroups the device holds 
 constexpr unsigned kSyncWords = kSyncCtlWords + 2 * kSyncGranules;
 constexpr unsigned long long kGranuleReset = 0x00000000ffffffffull; // {min = 0xffffffff, max = 0}: what a reset leaves, never a real pair
 constexpr unsigned kSyncSpinLimit = 1u << 17;
-template <int BM, int BN, int NSTAGE, bool RES, int KTK = 64, int KG = 1, bool BQ = false, bool QO = false, bool RT = false>
+// KS = cross-workgroup K split (round 6): the launches of stages 2-3 at batch 32 are 52-392 tiles for 256 compute units with 16-72 k-tiles each -- a
+// k-loop of 6-15 thousand cycles on a chip that is mostly empty.  With KS the grid is tiles x p.ks workgroups; part q of a tile walks k-tiles
+// [q * nkt / ks, (q + 1) * nkt / ks), parks its raw int32 accumulators (write-through stores, as the f32 split-K slab) and arrives on the tile's counter;
+// the last arrival reads the other parts back (L2-bypassing loads), adds them to its own registers and runs the unchanged epilogue.  Integer sums are
+// exact in any order: same bits whichever workgroup arrives last (tests: 200 launches, every split count).
+// QO == 2 = the RECOMPUTE form of a quantized output (round 6): the launch before this one ran the same convolution with `no_store` and left the output's
+// min / max in the statistics block (p.in_stats); this launch folds the block in its prologue (as a BQ kernel does), computes the tile again and writes
+// the codes straight into the consumer's staged image.  No grid-wide exchange, no residency requirement, no time-out: replicas side by side ("lanes") may
+// use it, where the i8 pipe is 3-6 % busy and the step is bound by HBM bytes -- the f32 tensor of a single-consumer edge (4 B written + 4 B read back per
+// element) never exists.  Same statistics (min / max are order-free), same dql_params, same quant_u8: the codes of the two-launch sequence.
+template <int BM, int BN, int NSTAGE, bool RES, int KTK = 64, int KG = 1, bool BQ = false, int QO = 0, bool RT = false, bool KS = false>
 __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kernel(const FastArgs p) {
+    static_assert(!KS || (KG == 1 && !BQ && !QO && !RES && RT && KTK == 64), "cross-workgroup K split: the plain single-row-term convolution form only");
     static_assert(!BQ || (KG == 1 && KTK == 64), "quantize-on-load: one k-group, 64-byte k-tiles");
     static_assert(!(BQ && QO), "quantize-on-load and quantized output are separate instantiations");
     constexpr int WM = 2, WN = 2;
@@ -382,10 +402,16 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
 #define I8_STAMP(i)
 #endif
     int tile;
+    [[maybe_unused]] int ks_part = 0;
     {
         const int nt = gridDim.x, id = blockIdx.x;
         const int xcd = id & 7, q = nt >> 3, r = nt & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+        if constexpr (KS) { // an XCD's run of consecutive indices walks neighbouring tiles of ONE K slice: they share that slice of the operand panels
+            const int ntiles = p.tiles_m * p.tiles_n;
+            ks_part = tile / ntiles;
+            tile -= ks_part * ntiles;
+        }
     }
     const int tdiv = p.n_fastest ? p.tiles_n : p.tiles_m, tq = rten_div(tile, p.d_tile), tr = tile - tq * tdiv;
     const int bm = p.n_fastest ? tq : tr, bn = p.n_fastest ? tr : tq;
@@ -424,7 +450,8 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
     // instructions per k-tile, waterfall loops around the DMA included, for two 32-cycle MFMAs (counters: profiles/r05).
     const int nchunks = p.Kp / 16;
     const int nkt = (p.Kp + KTK - 1) / KTK;
-    const int nit = (nkt + KG - 1) / KG;   // loop trips: KG k-tiles per trip
+    [[maybe_unused]] const int kt_first = KS ? (int)((long long)ks_part * nkt / p.ks) : 0; // KS: this part's slice of the k-tiles
+    const int nit = KS ? (int)((long long)(ks_part + 1) * nkt / p.ks) - kt_first : (nkt + KG - 1) / KG;   // loop trips: KG k-tiles per trip
     const int tchunks = ((nkt + KG - 1) / KG + NSTAGE) * KG * (KTK / 16); // chunks the walk can name (>= nchunks; the tail is dead)
     int *const btab = reinterpret_cast<int *>(smem + NSTAGE * STAGE);
     {
@@ -451,22 +478,24 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
     constexpr int NP = BQ ? 4 * BN / 256 : 1; // 16-byte pieces (16 channels of one pixel) per thread per k-tile
     [[maybe_unused]] unsigned q_voff = OOB;   // byte offset of (image, channel 0, pixel) of this thread's pixel
     [[maybe_unused]] int q_slot0 = 0, q_px = 0;
-    if constexpr (BQ) {
+    if constexpr (BQ || QO == 2) {
         float a = __builtin_inff(), b = -__builtin_inff();
-        a = dql::ord2f(p.in_stats[t]);
-        b = dql::ord2f(p.in_stats[dql::kStatSlots + t]);
+        a = dql::ord2f(p.in_stats[t & 255]);
+        b = dql::ord2f(p.in_stats[dql::kStatSlots + (t & 255)]);
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) { a = fminf(a, __shfl_xor(a, o, 64)); b = fmaxf(b, __shfl_xor(b, o, 64)); }
-        float *red = reinterpret_cast<float *>(btab);
-        if (lane == 0) { red[wave_all] = a; red[4 + wave_all] = b; }
+        float *red = reinterpret_cast<float *>(smem + NSTAGE * STAGE + tchunks * 4); // 8 floats behind the chunk table (the launcher sizes the allocation for them)
+        if (lane == 0 && wave_all < 4) { red[wave_all] = a; red[4 + wave_all] = b; }
         __syncthreads();
         const float mn = fminf(fminf(red[0], red[1]), fminf(red[2], red[3])), mx = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
         const dql::QParams q = dql::dql_params(mn, mx);
         q_scale = q.scale; q_inv = q.inv_scale; q_zp = q.zp;
-        if (t == 0 && blockIdx.x == 0) {
+        if (BQ && t == 0 && blockIdx.x == 0) {
             if (p.xs_out) *p.xs_out = q.scale;
             if (p.xz_out) *p.xz_out = (uint8_t)q.zp;
         }
+    }
+    if constexpr (BQ) {
         q_px = t % BN;
         q_slot0 = __builtin_amdgcn_readfirstlane(t / BN); // wave-uniform: BN is a multiple of 64
         const int n = n0 + q_px;
@@ -475,7 +504,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
             q_voff = (unsigned)((img * p.Cin) * p.HW + pp) * 4u;
         }
     }
-    int ch_idx = __builtin_amdgcn_readfirstlane(wave_all); // chunk index of the next piece to issue: wave_all, wave_all + 4 KG, ...
+    int ch_idx = __builtin_amdgcn_readfirstlane(wave_all + (KS ? kt_first * (KTK / 16) : 0)); // chunk index of the next piece to issue: wave_all, wave_all + 4 KG, ...
     // the table entries of this wave's next 64 pieces ride in one vector register (lane i = i-th piece from here) and are picked
     // with v_readlane: no LDS round trip on the issue path.  Refilled every 64 pieces.
     auto bo_fill = [&](int first) {
@@ -690,6 +719,44 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
     I8_STAMP(5) // k-loop
     wait_vmcnt<0>();
     __syncthreads(); // every wave is done with the stage buffers
+    if constexpr (KS) {
+        constexpr int NQ = TM * TN * 4; // 16-byte pieces per lane
+        const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void *)(p.slab + ((long long)tile * p.ks) * (BM * BN)), 0, (int)((unsigned)p.ks * (BM * BN) * 4u), 0x00020000);
+        const unsigned lane_off = (unsigned)(wave * (NQ * 64) + lane) * 16u;
+        const unsigned part_bytes = (unsigned)(BM * BN) * 4u;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) // aux 17 = sc0 sc1: the store writes through to memory (the eight XCD L2s are not coherent with each other inside a kernel)
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{(unsigned)acc[i][j][4 * q], (unsigned)acc[i][j][4 * q + 1], (unsigned)acc[i][j][4 * q + 2], (unsigned)acc[i][j][4 * q + 3]},
+                                                           rsS, (int)(lane_off + (unsigned)(((i * TN + j) * 4 + q) * 64) * 16u), (int)((unsigned)ks_part * part_bytes), 17);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's write-through stores are acknowledged
+        __syncthreads();
+        int *const flag = reinterpret_cast<int *>(smem);
+        if (t == 0) {
+            const unsigned old = __hip_atomic_fetch_add(p.ks_counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = old == (unsigned)p.ks - 1u;
+        }
+        __syncthreads();
+        const bool last = *flag != 0;
+        __syncthreads(); // (the row constants are parked over the same LDS bytes next)
+        if (!last) return;
+        for (int q2 = 0; q2 < p.ks; q2++) {
+            if (q2 == ks_part) continue;
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { // L2-bypassing loads: the other parts were written by workgroups on any XCD
+                        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsS, (int)(lane_off + (unsigned)(((i * TN + j) * 4 + q) * 64) * 16u), (int)((unsigned)q2 * part_bytes), 17);
+                        acc[i][j][4 * q] += (int)v[0]; acc[i][j][4 * q + 1] += (int)v[1]; acc[i][j][4 * q + 2] += (int)v[2]; acc[i][j][4 * q + 3] += (int)v[3];
+                    }
+        }
+        if (t == 0) p.ks_counters[tile] = 0u; // every launch leaves its counters zero
+    }
     if constexpr (KG > 1) {
         // partial sums of k-groups 1 .. KG-1 -> LDS ([group][register][thread of the group]: 1 KiB per wave store), added by group 0
         int *red = reinterpret_cast<int *>(smem);
@@ -746,7 +813,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
         for (int j = 0; j < TN; j++) bzv[j] = (unsigned)zp_from_raw(RT ? raw_u : bz_raw[j], p.b_signed);
     }
     const bool epi = KG == 1 || kg == 0; // the epilogue belongs to k-group 0
-    if (!QO && !epi) return;             // (no barrier follows)
+    if (QO != 1 && !epi) return;         // (no barrier follows; the grid-wide exchange of QO == 1 needs every wave of the workgroup)
 
     // ---- epilogue: zero-point algebra, optional cast_scale / bias / residual / relu, store.  16 accumulator
     // registers (one 32 x 32 block) are finished at a time; all of a block's stores are issued back to back.
@@ -831,7 +898,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[i][j][r] = (int)v[r];
             }
-            if (!QO || p.C) {
+            if ((!QO || p.C) && !p.no_store) {
                 const unsigned vo_col = cok ? basev[j] + half_off : OOB;
                 if (full_rows) {
 #pragma unroll
@@ -846,14 +913,23 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
         }
     }
     } // epi
-    if constexpr (QO) {
+    if constexpr (QO != 0) {
+        dql::QParams q;
+        const unsigned G = gridDim.x;
+        if constexpr (QO == 2) { // the statistics came from the previous launch (folded in the prologue): straight to the codes
+            q.scale = q_scale; q.inv_scale = q_inv; q.zp = q_zp;
+            if (t == 0 && blockIdx.x == 0) {
+                *p.q_scale_out = q.scale;
+                *p.q_zp_out = (uint8_t)q.zp;
+                if (p.q_mul_by) *p.q_product = q.scale * p.q_mul_by[0];
+            }
+        } else {
         // ---- (1) all-gather of the workgroups' min / max.  One hop: every workgroup publishes ONE 8-byte granule {min, max} (ordered-uint
         // images; the pair a reset leaves there, {0xffffffff, 0}, cannot be a real one, so the data is its own flag) with a write-through
         // store and then sweeps all G granules with relaxed agent-scope loads until none is the reset pair.  No counters, no fences, no
         // read-modify-write on the critical path (the first version -- eight arrival counters polled by every workgroup plus the slot
         // atomics -- cost 6 / 9 / 22 us at 200 / 392 / 784 workgroups: profiles/r06/int8_qout_per_layer.txt).
         unsigned long long *const gran = reinterpret_cast<unsigned long long *>(p.sync + kSyncCtlWords);
-        const unsigned G = gridDim.x;
         float *const gred = reinterpret_cast<float *>(smem + 8192); // (the row constants at the start of the stage buffers are dead by now)
         if (epi) {
 #pragma unroll
@@ -911,7 +987,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
         float g_mn = gred[16], g_mx = gred[32];
 #pragma unroll
         for (int wv = 1; wv < 4 * KG; wv++) { g_mn = fminf(g_mn, gred[16 + wv]); g_mx = fmaxf(g_mx, gred[32 + wv]); }
-        const dql::QParams q = dql::dql_params(g_mn, g_mx);
+        q = dql::dql_params(g_mn, g_mx);
         if (t == 0 && blockIdx.x == 0) {
             // (a workgroup that timed out -- before or after this store -- leaves NaN here: whoever gives up first has set the flag)
             const bool void_run = __hip_atomic_load(p.sync + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
@@ -919,6 +995,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void igemm_i8_fast_kerne
             *p.q_zp_out = (uint8_t)q.zp;
             if (p.q_mul_by) *p.q_product = void_run ? __builtin_nanf("") : q.scale * p.q_mul_by[0]; // the Mul(x_scale, w_scale) node of the consumer
         }
+        } // QO == 1
         // ---- (3) codes -> the consumer's staged image [N][C/16][Hp][Wp][16 B] (signed domain).  A lane holds, per 32-row block, four
         // dwords of four consecutive channels each: rows 0-3, 8-11, 16-19, 24-27 (+4 in the upper half of the wave); two
         // v_permlane32_swap give the lower half the sixteen channels 0-15 of its pixel and the upper half channels 16-31.
@@ -1063,7 +1140,7 @@ int resident_capacity(rten_hip_ctx *ctx, const void *kern, int threads, size_t l
 }
 
 // Returns false (nothing launched) when QO is requested and the grid cannot be resident all at once.
-template <int BM, int BN, int NST, int KTK = 64, int KG = 1, bool BQ = false, bool QO = false>
+template <int BM, int BN, int NST, int KTK = 64, int KG = 1, bool BQ = false, int QO = 0, bool KS = false>
 bool launch_fast(rten_hip_ctx *ctx, FastArgs &a, const char *name, double ops, double bytes) {
     static_assert(KTK == 64 || KG == 1, "k-groups walk 64-byte k-tiles");
     a.tiles_m = (a.M + BM - 1) / BM;
@@ -1071,7 +1148,7 @@ bool launch_fast(rten_hip_ctx *ctx, FastArgs &a, const char *name, double ops, d
     constexpr size_t ring = (size_t)NST * KG * (BM + BN) * KTK;
     static_assert(ring <= 128 * 1024, "int8 tile ring exceeds the LDS of a compute unit");
     const int nkt = (a.Kp + KTK - 1) / KTK;
-    const size_t lds = ring + (size_t)((nkt + KG - 1) / KG + NST) * KG * (KTK / 16) * 4; // + the chunk -> B offset table
+    const size_t lds = ring + (size_t)((nkt + KG - 1) / KG + NST) * KG * (KTK / 16) * 4 + 64; // + the chunk -> B offset table + the statistics fold's scratch
     a.d_pn = rten_make_div((long long)a.tiles_n * BN, a.Pn);
     a.d_tile = rten_make_div((long long)a.tiles_m * a.tiles_n, a.n_fastest ? a.tiles_n : a.tiles_m);
     if (BQ) a.d_hw = rten_make_div((long long)a.tiles_n * BN, a.HW);
@@ -1085,15 +1162,25 @@ bool launch_fast(rten_hip_ctx *ctx, FastArgs &a, const char *name, double ops, d
     bool launched = true;
     auto go = [&](auto kern) {
         if (lds > 64 * 1024) hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (QO && ((long long)a.tiles_m * a.tiles_n > resident_capacity(ctx, (const void *)kern, 256 * KG, lds) || (long long)a.tiles_m * a.tiles_n > (long long)kSyncGranules)) {
+        if (QO == 1 && ((long long)a.tiles_m * a.tiles_n > resident_capacity(ctx, (const void *)kern, 256 * KG, lds) || (long long)a.tiles_m * a.tiles_n > (long long)kSyncGranules)) {
             launched = false;
             return;
         }
         ProfScope ps(ctx, name, ops, bytes);
-        hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256 * KG), lds, ctx->stream, a);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles_m * a.tiles_n * (KS ? a.ks : 1))), dim3(256 * KG), lds, ctx->stream, a);
     };
     // RT: the single-row-term zero-point algebra of the convolution form (weight zero point 0 in the signed domain, one activation zero point)
     const bool rt = a.conv && !(a.debug_flags & 1) && a.a_zp == nullptr && a.a_signed && a.b_zp_len <= 1 && !a.need_csum;
+    if constexpr (QO == 2) { // the recompute form is built for the single-row-term convolution without a residual (the single-consumer edges of a bottleneck block)
+        if (!rt || (a.res && a.scale)) { launched = false; return launched; }
+        go(igemm_i8_fast_kernel<BM, BN, NST, false, KTK, KG, BQ, 2, true>);
+        return launched;
+    }
+    if constexpr (KS) { // (the dispatcher checked: RT form, no residual)
+        a.d_tile = rten_make_div((long long)a.tiles_m * a.tiles_n, a.n_fastest ? a.tiles_n : a.tiles_m);
+        go(igemm_i8_fast_kernel<BM, BN, NST, false, KTK, KG, BQ, QO, true, true>);
+        return launched;
+    }
     if (rt) {
         if (a.res && a.scale) go(igemm_i8_fast_kernel<BM, BN, NST, true, KTK, KG, BQ, QO, true>);
         else go(igemm_i8_fast_kernel<BM, BN, NST, false, KTK, KG, BQ, QO, true>);
@@ -1115,6 +1202,20 @@ int32_t dispatch_fast(rten_hip_ctx *ctx, FastArgs &a, double ops, double bytes) 
     // one is fetched into as few of the eight L2s as possible
     a.n_fastest = (double)a.a_bytes > (double)a.b_bytes ? 1 : 0;
     // (256-byte k-tiles were measured and are slower: profiles/r05/int8_notes.md)
+    if (a.q_out && a.in_stats) { // recompute form of a quantized output (QO == 2): the plain kernels' tile choice, nothing to fit
+        const long long t64 = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64);
+        const int nkt = (a.Kp + 63) / 64;
+        const bool kg4 = !(ctx->debug & 0x800) && t64 * 4 <= 5 * ctx->num_cus && nkt >= 16;
+        bool ok;
+        if (tile == 0) ok = launch_fast<128, 128, 3, 64, 1, false, 2>(ctx, a, "igemm_i8_fast_kernel<128,128,qo2>", ops, bytes);
+        else if (tile == 1) ok = launch_fast<128, 64, 3, 64, 1, false, 2>(ctx, a, "igemm_i8_fast_kernel<128,64,qo2>", ops, bytes);
+        else if (tile == 2) ok = launch_fast<64, 128, 3, 64, 1, false, 2>(ctx, a, "igemm_i8_fast_kernel<64,128,qo2>", ops, bytes);
+        else if (kg4) ok = launch_fast<64, 64, 3, 64, 4, false, 2>(ctx, a, "igemm_i8_fast_kernel<64,64,kg4,qo2>", ops, bytes);
+        else ok = launch_fast<64, 64, 3, 64, 1, false, 2>(ctx, a, "igemm_i8_fast_kernel<64,64,qo2>", ops, bytes);
+        if (!ok) return RTEN_HIP_ERR_UNSUPPORTED;
+        RTEN_LAUNCH_CHECK(ctx, "igemm_i8_fast_kernel launch");
+        return RTEN_HIP_OK;
+    }
     if (a.q_out) { // quantized-output form (rten_hip_conv2d_int8_qout): the same tile choice, or the next larger one that fits the chip at once
         const long long t64 = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64);
         const int nkt = (a.Kp + 63) / 64;
@@ -1139,6 +1240,37 @@ int32_t dispatch_fast(rten_hip_ctx *ctx, FastArgs &a, double ops, double bytes) 
         else launch_fast<64, 64, 3, 64, 1, true>(ctx, a, "igemm_i8_fast_kernel<64,64,bq>", ops, bytes);
         RTEN_LAUNCH_CHECK(ctx, "igemm_i8_fast_kernel launch");
         return RTEN_HIP_OK;
+    }
+    // Cross-workgroup K split (KS kernels): under-filled long-K launches of the single-row-term convolution form without a residual.  `a.ks` = the largest
+    // split the caller's slab holds (0: none); RTEN_I8_KS = "<parts>[,<tile>]" selects it (a measurement knob: tile 0 = 128x128, 1 = 128x64, 3 = 64x64).
+    {
+        const bool rt = a.conv && !(a.debug_flags & 1) && a.a_zp == nullptr && a.a_signed && a.b_zp_len <= 1 && !a.need_csum;
+        static const char *env_ks = getenv("RTEN_I8_KS");
+        static const int env_parts = env_ks ? atoi(env_ks) : -1, env_kst = (env_ks && strchr(env_ks, ',')) ? atoi(strchr(env_ks, ',') + 1) : -1;
+        const int nkt = (a.Kp + 63) / 64;
+        const long long t64 = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64);
+        int parts = 0, kst = 3;
+        if (rt && !a.res && a.ks >= 2 && a.slab && a.ks_counters && !(ctx->debug & 0x1000)) {
+            // MEASURED AND NOT USED BY DEFAULT (profiles/r09/int8_cross_workgroup_k_split.txt): every split loses -- s2 3x3 13.7 -> 17.1 us (2 parts, 64x64),
+            // 16.9 (2 parts, 128x64), 19.0 (128x128), 20.8 (4 parts); s3 3x3 12.6 -> 15.7; K = 1024 1x1 9.1 -> 13.6; the int8 step 1.48 -> 1.53 ms (one
+            // replica), 0.89 -> 0.97 (four).  The hand-off (16-64 KB of write-through partials per workgroup, the counter, the L2-bypassing reload) costs 4-7 us
+            // against a k-loop of ~6 us that it can shorten by half at best; the in-workgroup form (k-groups through LDS) stays the rule for stage 3.
+            if (env_parts >= 0) { parts = env_parts; kst = env_kst >= 0 ? env_kst : 3; }
+            if (parts > a.ks) parts = a.ks;
+            if (parts > nkt) parts = nkt;
+        }
+        if (parts >= 2) {
+            a.ks = parts;
+            const long long tiles = kst == 0 ? t128 : kst == 1 ? t12864 : t64;
+            if (tiles <= rten_hip_ctx::kSplitCounters) {
+                if (kst == 0) launch_fast<128, 128, 3, 64, 1, false, false, true>(ctx, a, "igemm_i8_fast_kernel<128,128,ks>", ops, bytes);
+                else if (kst == 1) launch_fast<128, 64, 3, 64, 1, false, false, true>(ctx, a, "igemm_i8_fast_kernel<128,64,ks>", ops, bytes);
+                else launch_fast<64, 64, 3, 64, 1, false, false, true>(ctx, a, "igemm_i8_fast_kernel<64,64,ks>", ops, bytes);
+                RTEN_LAUNCH_CHECK(ctx, "igemm_i8_fast_kernel launch");
+                return RTEN_HIP_OK;
+            }
+        }
+        a.ks = 0;
     }
     // (measured again in round 3 and dropped -- profiles/r06/int8_tile_experiments.txt: 128-byte k-tiles on the 128x64 / 64x128 / 64x64 tiles
     // +5 % on the whole conv time, the next larger tile for the under-filled launches +6 %, four LDS stages +2 %; no layer gains more than 5 %)
@@ -1404,7 +1536,14 @@ int32_t i8_fast_conv_impl(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di
         return (di->weights_packed || di->x_staged) ? rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "conv_int8: staged operands for an unsupported geometry")
                                                     : RTEN_HIP_ERR_UNSUPPORTED;
     const size_t wbytes = di->weights_packed ? 0 : up256((size_t)d->o * cg.Kp) + up256((size_t)d->o * 4);
-    const size_t offA = 4096, offB = offA + wbytes, total = offB + (di->x_staged ? 0 : up256(cg.img));
+    // cross-workgroup K split (KS kernels): a slab for up to kKsMax int32 partials of the (tile-padded) output, for the launches the dispatcher may split
+    constexpr int kKsMax = 4;
+    const long long n_cols = (long long)d->n * cg.P;
+    const long long t64 = (long long)((d->o + 63) / 64) * ((n_cols + 63) / 64);
+    static const bool ks_knob = getenv("RTEN_I8_KS") != nullptr && atoi(getenv("RTEN_I8_KS")) >= 2; // (no slab, no scratch growth, unless the measurement knob is set)
+    const bool ks_candidate = ks_knob && !qo && scale && !(flags & RTEN_HIP_CONV_RESIDUAL) && cg.Kp >= 16 * 64 && t64 <= 3 * (long long)ctx->num_cus && ctx->split_counters;
+    const size_t slab_bytes = ks_candidate ? (size_t)kKsMax * (size_t)((d->o + 127) / 128 * 128) * (size_t)((n_cols + 127) / 128 * 128) * 4 : 0;
+    const size_t offA = 4096, offB = offA + wbytes, offS = offB + (di->x_staged ? 0 : up256(cg.img)), total = offS + slab_bytes;
     char *sc = (char *)rten_scratch(ctx, total);
     if (!sc) return rten_set_error(ctx, RTEN_HIP_ERR_HIP, "int8 staging allocation failed (or attempted during graph capture)");
     const uint8_t *Ap;
@@ -1451,7 +1590,30 @@ int32_t i8_fast_conv_impl(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di
     g.debug_flags = (ctx->debug & 0x200000) ? 1 : 0;
     g.conv = 1; g.OW = d->out_w; g.sy = d->stride_h; g.sx = d->stride_w; g.Hp = cg.Hp; g.Wp = cg.Wp; g.Cp = cg.Cp;
     g.KH = d->kh; g.KW = d->kw; g.dy = d->dil_h; g.dx = d->dil_w;
+    if (slab_bytes) { g.ks = kKsMax; g.slab = (int *)(sc + offS); g.ks_counters = ctx->split_counters; }
     double out_bytes = 4.0 * d->o * g.N;
+    if (qo && !qo->sync) {
+        // Recompute form (no exchange block): launch 1 = this convolution, statistics only (nothing stored); launch 2 = the same convolution again, which
+        // folds those statistics, quantizes in its epilogue and writes the consumer's staged image (+ the f32 tensor when `y` is wanted)
+        if (!stats) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "conv2d_int8_qout (recompute form): a statistics block is required");
+        const bool rt = !(g.debug_flags & 1) && g.a_zp == nullptr && g.a_signed && !g.need_csum;
+        if (!rt || g.res) return RTEN_HIP_ERR_UNSUPPORTED; // (built for the single-row-term form without a residual: the caller runs the two operators)
+        FastArgs g1 = g;
+        g1.no_store = 1;
+        const int32_t rc1 = dispatch_fast(ctx, g1, 2.0 * d->o * (double)g.N * cg.Kreal, (double)d->o * cg.Kreal + (double)d->n * d->c * d->h * d->w);
+        if (rc1 != RTEN_HIP_OK) return rc1;
+        const ConvGeom ng = conv_geom(qo->next);
+        g.in_stats = (const unsigned *)stats;
+        g.stats = nullptr;
+        g.q_out = (uint8_t *)qo->staged;
+        g.q_scale_out = qo->scale; g.q_zp_out = qo->zp; g.q_mul_by = qo->mul_by; g.q_product = qo->product;
+        g.q_cb = ng.Cp / 16; g.q_Hp = ng.Hp; g.q_Wp = ng.Wp; g.q_pt = qo->next->conv.pads[0]; g.q_pl = qo->next->conv.pads[1];
+        g.q_H = d->out_h; g.q_W = d->out_w; g.q_pad_mode = rten_effective_pad_mode(qo->next);
+        g.q_bytes = (unsigned)ng.img;
+        g.ks = 0; g.slab = nullptr;
+        return dispatch_fast(ctx, g, 2.0 * d->o * (double)g.N * cg.Kreal,
+                             (double)d->o * cg.Kreal + (double)d->n * d->c * d->h * d->w + (y ? out_bytes : 0.0) + (double)ng.img);
+    }
     if (qo) {
         const ConvGeom ng = conv_geom(qo->next);
         g.sync = (unsigned *)qo->sync;
@@ -1480,8 +1642,8 @@ RTEN_EXPORT int32_t rten_hip_conv2d_int8_qout(rten_hip_ctx *ctx, const rten_hip_
                                               void *stats, void *sync, const rten_hip_conv2d_int8_desc *next, void *next_staged, float *next_scale,
                                               uint8_t *next_zero_point, const float *mul_by, float *product) {
     RTEN_CHECK_CTX(ctx);
-    if (!di || !x || !w || !scale || !stats || !sync || !next || !next_staged || !next_scale || !next_zero_point || (mul_by && !product))
-        return RTEN_HIP_ERR_INVALID_VALUE;
+    if (!di || !x || !w || !scale || !stats || !next || !next_staged || !next_scale || !next_zero_point || (mul_by && !product))
+        return RTEN_HIP_ERR_INVALID_VALUE; // (sync == NULL: the recompute form -- two launches, no grid-wide exchange, no residency requirement)
     const rten_hip_conv2d_desc *d = &di->conv, *nd = &next->conv;
     if (di->scale_len != 0 && di->scale_len != 1 && di->scale_len != d->o)
         return rten_set_error(ctx, RTEN_HIP_ERR_INCOMPATIBLE_SHAPES, "conv_int8: scale must be a scalar or have one value per output channel");

@@ -355,6 +355,99 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void layer_norm_kernel(int64_t
     }
 }
 
+// Rows in sequence (round 6): the kernel above gives every row a wave of its own, so a [4096, 768] launch is ONE wave of 4096 wavefronts that all load, then all
+// reduce, then all store -- the read stream and the write stream never overlap (6.1 us against 3.8 us for a copy of the same bytes).  Here a wave owns R
+// CONSECUTIVE rows and walks them with the next row's loads in flight under the current row's reductions and stores (two register images, statically
+// alternated), so HBM sees reads and writes together for most of the launch.  Same arithmetic, same order per row: bit-identical.  Register-resident rows
+// (CH x 64 columns) only.
+template <int CH>
+struct LnRow { float xa[CH], aa[CH]; };
+template <int CH, bool ADD>
+__device__ __forceinline__ void ln_load_row(LnRow<CH> &r, const float *__restrict__ xr, const float *__restrict__ ar, int cols, int lane) {
+#pragma unroll
+    for (int c = 0; c < CH; c++) { const int i = c * 64 + lane; r.xa[c] = i < cols ? xr[i] : 0.f; }
+    if constexpr (ADD) {
+#pragma unroll
+        for (int c = 0; c < CH; c++) { const int i = c * 64 + lane; r.aa[c] = i < cols ? ar[i] : 0.f; }
+    }
+}
+template <int CH, bool ADD>
+__device__ __forceinline__ void ln_finish_row(const LnRow<CH> &r, const float *__restrict__ xr, const float *__restrict__ ar, float *__restrict__ yr, int cols, int lane,
+                                              const float (&gv)[CH], const float (&bv)[CH], int mode, float gamma_scalar, float beta_scalar, float eps) {
+    float v[CH];
+#pragma unroll
+    for (int c = 0; c < CH; c++) v[c] = ADD ? r.xa[c] + r.aa[c] : r.xa[c];
+    auto get = [&](int i) -> float { return ADD ? xr[i] + ar[i] : xr[i]; }; // (the < 64-column remainder of a row: cross-lane, served from L1)
+    auto red = [&](auto f) -> float {
+        float acc = 0.f;
+        const int full4 = cols / 64;
+#pragma unroll
+        for (int c = 0; c < CH; c++)
+            if (c < full4) acc = f(acc, v[c]);
+        float a = acc;
+        a = a + lane_bcast(acc, (lane & 15) + 16);
+        a = a + lane_bcast(acc, (lane & 15) + 32);
+        a = a + lane_bcast(acc, (lane & 15) + 48);
+        int i0 = full4 * 64;
+        const int l = lane & 15;
+        for (; i0 + 16 <= cols; i0 += 16) a = f(a, get(i0 + l));
+        if (i0 + l < cols) a = f(a, get(i0 + l));
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) s = s + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), k));
+        return s;
+    };
+    const float mean = red([](float acc, float xv) { return acc + xv; }) / (float)cols;
+    const float var = red([mean](float acc, float xv) { const float d = xv - mean; return vm::fma(d, d, acc); }) / (float)cols;
+    const float ssr = gamma_scalar / sqrtf(var + eps);
+    if (mode == 0) {
+#pragma unroll
+        for (int c = 0; c < CH; c++) v[c] = vm::fma(v[c] - mean, ssr, beta_scalar);
+    } else if (mode == 1) {
+#pragma unroll
+        for (int c = 0; c < CH; c++) v[c] = (v[c] - mean) * (gv[c] * ssr);
+    } else {
+#pragma unroll
+        for (int c = 0; c < CH; c++) v[c] = vm::fma(v[c] - mean, gv[c] * ssr, bv[c] + beta_scalar);
+    }
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const int i = c * 64 + lane;
+        if (i < cols) yr[i] = v[c];
+    }
+}
+template <int CH, bool ADD>
+__global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void layer_norm_stream_kernel(int64_t rows, int cols, const float *__restrict__ x, const float *__restrict__ gamma,
+                                                                                const float *__restrict__ beta, float gamma_scalar, float beta_scalar, float eps,
+                                                                                const float *addend, float *y, int rows_per_wave) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row0 = ((int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6)) * rows_per_wave;
+    if (row0 >= rows) return;
+    const int nrows = (int)(rows - row0 < rows_per_wave ? rows - row0 : rows_per_wave);
+    LnRow<CH> ra, rb;
+    ln_load_row<CH, ADD>(ra, x + row0 * cols, ADD ? addend + row0 * cols : nullptr, cols, lane);
+    float gv[CH], bv[CH];
+#pragma unroll
+    for (int c = 0; c < CH; c++) { gv[c] = 1.0f; bv[c] = 0.f; }
+    if (gamma) {
+#pragma unroll
+        for (int c = 0; c < CH; c++) { const int i = c * 64 + lane; gv[c] = gamma[i < cols ? i : 0]; }
+    }
+    if (beta) {
+#pragma unroll
+        for (int c = 0; c < CH; c++) { const int i = c * 64 + lane; bv[c] = beta[i < cols ? i : 0]; }
+    }
+    const int mode = (!gamma && !beta) ? 0 : ((gamma && !beta && beta_scalar == 0.f) ? 1 : 2);
+    for (int k = 0; k < nrows; k += 2) {
+        const int64_t r0 = row0 + k;
+        if (k + 1 < nrows) ln_load_row<CH, ADD>(rb, x + (r0 + 1) * cols, ADD ? addend + (r0 + 1) * cols : nullptr, cols, lane);
+        ln_finish_row<CH, ADD>(ra, x + r0 * cols, ADD ? addend + r0 * cols : nullptr, y + r0 * cols, cols, lane, gv, bv, mode, gamma_scalar, beta_scalar, eps);
+        if (k + 1 >= nrows) break;
+        if (k + 2 < nrows) ln_load_row<CH, ADD>(ra, x + (r0 + 2) * cols, ADD ? addend + (r0 + 2) * cols : nullptr, cols, lane);
+        ln_finish_row<CH, ADD>(rb, x + (r0 + 1) * cols, ADD ? addend + (r0 + 1) * cols : nullptr, y + (r0 + 1) * cols, cols, lane, gv, bv, mode, gamma_scalar, beta_scalar, eps);
+    }
+}
+
 // GlobalAveragePool (pooling.rs:516-521): Sum(chan) / len in the same SIMD order.
 __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void global_avg_pool_kernel(int64_t rows, int inner,
                                                                               const float *__restrict__ x,
@@ -578,7 +671,30 @@ static int32_t layer_norm_launch(rten_hip_ctx *ctx, int64_t rows, int32_t cols, 
     if (!x || !y) return RTEN_HIP_ERR_INVALID_VALUE;
     const dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(64 * ROWS_PER_BLOCK);
     ProfScope ps(ctx, addend ? "add_layer_norm_f32" : "layer_norm_f32", 0.0, (addend ? 12.0 : 8.0) * rows * cols);
-#define LN_LAUNCH(CH) hipLaunchKernelGGL((layer_norm_kernel<CH>), grid, block, 0, ctx->stream, rows, cols, x, gamma, beta, gamma_scalar, beta_scalar, epsilon, addend, y)
+    // rows in sequence per wave once a launch has more than ~2 waves per SIMD to give (y may alias x / addend only in the one-row-per-wave form: a wave of the
+    // streaming form requests row k + 1 before it stores row k, which is still safe -- rows are disjoint -- so aliasing is fine there too)
+    static const int env_rows = getenv("RTEN_LN_ROWS") ? atoi(getenv("RTEN_LN_ROWS")) : -1; // (tuning: rows per wave; 0 = the one-row form)
+    // measured (profiles/r09/layer_norm_rows.txt): [16384, 768] 18.1 -> 15.9 us at 4 rows per wave (0.70 -> 0.79 of 8 TB/s); [4096, 768] LOSES with any R
+    // (6.3 -> 6.6 / 7.7 / 8.3 us at 2 / 3 / 4): too few waves left to keep HBM busy -- so only from 4 waves per SIMD of 4-row work upwards
+    int rpw = env_rows >= 0 ? env_rows : (rows >= 4 * 4 * 4 * (int64_t)ctx->num_cus ? 4 : 0);
+    if (rpw >= 2 && cols <= 1024 && cols > 128) {
+        const int64_t waves = (rows + rpw - 1) / rpw;
+        const dim3 sgrid((unsigned)((waves + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
+#define LNS_LAUNCH(CH) do { if (addend) hipLaunchKernelGGL((layer_norm_stream_kernel<CH, true>), sgrid, block, 0, ctx->stream, rows, cols, x, gamma, beta, gamma_scalar, beta_scalar, epsilon, addend, y, rpw); \
+                            else hipLaunchKernelGGL((layer_norm_stream_kernel<CH, false>), sgrid, block, 0, ctx->stream, rows, cols, x, gamma, beta, gamma_scalar, beta_scalar, epsilon, addend, y, rpw); } while (0)
+        if (cols <= 256) LNS_LAUNCH(4);
+        else if (cols <= 512) LNS_LAUNCH(8);
+        else if (cols <= 768) LNS_LAUNCH(12);
+        else LNS_LAUNCH(16);
+#undef LNS_LAUNCH
+        RTEN_LAUNCH_CHECK(ctx, "layer_norm_stream_kernel");
+        return RTEN_HIP_OK;
+    }
+    // (tuning knob: a dynamic-LDS request that caps the workgroups per compute unit -- fewer resident waves let the stores of the first waves overlap the
+    //  loads of the later ones instead of queueing behind all of them)
+    static const int env_lds = getenv("RTEN_LN_LDS") ? atoi(getenv("RTEN_LN_LDS")) * 1024 : 0;
+#define LN_LAUNCH(CH) do { if (env_lds > 64 * 1024) hipFuncSetAttribute((const void *)layer_norm_kernel<CH>, hipFuncAttributeMaxDynamicSharedMemorySize, env_lds); \
+                           hipLaunchKernelGGL((layer_norm_kernel<CH>), grid, block, env_lds, ctx->stream, rows, cols, x, gamma, beta, gamma_scalar, beta_scalar, epsilon, addend, y); } while (0)
     if (cols <= 128) LN_LAUNCH(2);
     else if (cols <= 256) LN_LAUNCH(4);
     else if (cols <= 512) LN_LAUNCH(8);

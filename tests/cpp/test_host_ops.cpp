@@ -79,9 +79,9 @@ static void host_only_tests() {
     const rten_hip_conv2d_desc ds = same.geometry({1, 4, 9, 9}, {4, 4, 3, 3});
     CHECK(ds.out_h == 5 && ds.out_w == 5, "conv same padding output size");
     const OpRegistry reg = OpRegistry::with_all_ops();
-    CHECK(reg.contains("Conv") && reg.contains("MatMulInteger") && reg.contains("Einsum") && !reg.contains("Where"), "registry contents");
+    CHECK(reg.contains("Conv") && reg.contains("MatMulInteger") && reg.contains("Einsum") && reg.contains("Where") && reg.contains("Tanh") && !reg.contains("Loop"), "registry contents");
     CHECK(std::string(reg.create("LayerNormalization")->name()) == "LayerNormalization", "registry create");
-    expect_error(OpError::UnsupportedValue, "operator not registered: Where", [&] { reg.create("Where"); }, "registry missing op");
+    expect_error(OpError::UnsupportedValue, "operator not registered: Loop", [&] { reg.create("Loop"); }, "registry missing op");
 }
 
 

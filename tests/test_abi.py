@@ -94,6 +94,11 @@ def test_product_library_is_not_a_trace_or_ablation_build():
     from rten_amd import lib
     blob = open(lib.SO_PATH, "rb").read()
     assert b"[i8 trace]" not in blob and b"[trace] wave" not in blob
+    #  the attention kernels' ablation instantiations -- no exp, no MFMAs, no stores: wrong results -- are compiled only with -DRTEN_ABLATION:
+    # the product library carries the <MASK, FLUSH, 0> forms alone (Itanium mangling of the third template argument: Li0E)
+    import re
+    abl = set(re.findall(rb"sdpa_fused16_kernelILb[01]ELb[01]ELi(\d+)E", blob))
+    assert abl == {b"0"}, abl
 
 
 def test_product_never_imports_oracle():

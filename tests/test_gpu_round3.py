@@ -152,6 +152,31 @@ def test_conv2d_int8_qout_matches_the_separate_operators(ctx, case):
         else:
             assert not y_b.numpy().any()
 
+    # (c) round 6: the RECOMPUTE form of the same entry point (sync == NULL): a statistics-only pass, then the convolution again writing the codes.  No
+    # exchange block, nothing to fit; covered for the form without a residual (UNSUPPORTED otherwise -> the two operators)
+    for rep, want_y in enumerate((False, True, False)):
+        st_c = DeviceTensor(ctx, (sb,), np.uint8)
+        ctx.call("rten_hip_minmax_stats_reset", st_c.vp, 1)
+        staged_c = dev(ctx, np.full(nb, 0xEE, np.uint8))
+        y_c = dev(ctx, np.zeros((n, o, oh, ow), np.float32))
+        xs_c, xz_c, pr_c = DeviceTensor(ctx, (1,), np.float32), DeviceTensor(ctx, (1,), np.uint8), DeviceTensor(ctx, (1,), np.float32)
+        rc = lib.rten_hip_conv2d_int8_qout(ctx.h, C.byref(d), staged_in.vp, packed.vp, xz.vp, None, sc.vp, bias.vp, res.vp if res else None, flags,
+                                           y_c.vp if want_y else None, st_c.vp, None, C.byref(d2), staged_c.vp, xs_c.vp, xz_c.vp, ws2.vp, pr_c.vp)
+        ctx.sync()
+        if with_res:
+            assert rc == L.ERR_UNSUPPORTED
+            break
+        assert rc == 0, ctx.last_error() if hasattr(ctx, "last_error") else rc
+        assert np.array_equal(xs_a.numpy().view(np.uint32), xs_c.numpy().view(np.uint32)) and np.array_equal(xz_a.numpy(), xz_c.numpy())
+        assert np.array_equal(pr_a.numpy().view(np.uint32), pr_c.numpy().view(np.uint32))
+        a, c_ = staged_a.numpy(), staged_c.numpy()
+        assert np.array_equal(a, c_), f"recompute form, rep {rep}: {(a != c_).sum()} of {a.size} staged bytes differ (first at {np.argwhere(a != c_)[0]})"
+        assert np.array_equal(st_a.numpy(), st_c.numpy())  # the statistics block as the two-operator sequence leaves it (a second reader of the f32 output)
+        if want_y:
+            bits_equal(y_c.numpy(), y_a.numpy())
+        else:
+            assert not y_c.numpy().any()
+
 
 def test_conv2d_int8_qout_refuses_a_grid_that_cannot_be_resident(ctx):
     """A launch with more workgroups than the device holds at once must be refused (UNSUPPORTED), never attempted."""

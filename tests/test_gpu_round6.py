@@ -1,0 +1,243 @@
+"""Round-6 kernels against the oracle / numpy: the cross-workgroup K split of the int8 convolution kernel (KS), the streaming LayerNormalization (rows in
+sequence per wave), Tanh, and the layout / logic operators behind rten_hip_elementwise_nd / rten_hip_gather_axis_b32 / rten_hip_copy_rows_b32."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import ref
+from rten_amd import lib as L, ops
+from rten_amd.tensor import DeviceTensor
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = L.Context(0)
+    yield c
+    c.close()
+
+
+def dev(ctx, a):
+    return DeviceTensor.from_numpy(ctx, a)
+
+
+def _bits(a, b):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    same = a.view(np.int32) == b.view(np.int32)
+    assert same.all(), f"{(~same).sum()} of {same.size} differ, first at {tuple(np.argwhere(~same)[0])}"
+
+
+KS_CASES = [(2, 128, 14, 14, 70, 3, (1, 1, 1, 1), (1, 1)),    # K 1152: 18 k-tiles; ragged rows (M = 70)
+            (3, 256, 7, 7, 96, 3, (1, 1, 1, 1), (1, 1)),      # K 2304: 36 k-tiles; N = 147 (ragged columns)
+            (2, 1024, 5, 5, 64, 1, (0, 0, 0, 0), (1, 1)),     # pointwise, K 1024: 16 k-tiles
+            (1, 512, 9, 9, 130, 3, (1, 1, 1, 1), (2, 2)),     # stride 2, K 4608: 72 k-tiles
+            (2, 2048, 3, 3, 200, 1, (0, 0, 0, 0), (1, 1))]    # K 2048, 32 k-tiles, 18 columns
+
+
+def ks_cases_main():
+    """(runs in a child process whose RTEN_I8_KS selects the split: the knob is read once per process)"""
+    c = L.Context(0)
+    for (N, Cc, H, W, O, k, pads, strides) in KS_CASES:
+        rng = ref.XorShiftRng(17 + Cc + O)
+        x = rng.u8(N * Cc * H * W).reshape(N, Cc, H, W)
+        w = rng.i8(O * Cc * k * k, reduced=True).reshape(O, Cc, k, k)
+        x_zp, scale = np.array(117, np.uint8), np.array(0.0071, np.float32)
+        bias = rng.f32(O) - 0.5
+        acc = ref.conv2d_int8(x, w, x_zp=117, pads=pads, strides=strides, pad_mode=ref.PAD_RAW0_I8)
+        want_plain = ref.cast_scale(acc, scale)
+        want_relu = ref.relu(want_plain + bias[None, :, None, None])
+        c.profile_reset()
+        c.profile(True)
+        op = ops.ConvIntegerToFloat(ops.ConvInteger(padding=list(pads), strides=strides))
+        ins = [dev(c, x), dev(c, w), dev(c, x_zp), None, dev(c, scale)]
+        got = op.run(c, ins)[0].numpy()
+        c.sync()
+        c.profile(False)
+        kernels = [r["kernel"] for r in c.profile_report()]
+        assert any(",ks>" in n for n in kernels), kernels  # the split form is what ran
+        _bits(got, want_plain)
+        op_r = ops.ConvIntegerToFloat(ops.ConvInteger(padding=list(pads), strides=strides), fuse_relu=True)
+        first = None
+        for _ in range(40):  # whichever workgroup arrives last: the same bits
+            g = op_r.run(c, ins + [dev(c, bias)])[0].numpy()
+            if first is None:
+                first = g
+                _bits(g, want_relu)
+            else:
+                assert np.array_equal(g.view(np.int32), first.view(np.int32))
+        # a residual keeps the unsplit kernel (the split form does not carry the residual tile): the oracle's bits either way
+        res = rng.f32(want_plain.size).reshape(want_plain.shape) - 0.5
+        g = op_r.run(c, ins + [dev(c, bias), dev(c, res)])[0].numpy()
+        _bits(g, ref.relu(ref.add(want_plain + bias[None, :, None, None], res)))
+    c.close()
+    print("KS CASES OK")
+
+
+@pytest.mark.parametrize("setting", ["2,3", "4,3", "3,1", "2,0"])
+def test_int8_cross_workgroup_k_split_is_bit_exact_and_deterministic(setting):
+    """The KS kernels (a measurement knob since they lose on every ResNet layer: profiles/r09/int8_cross_workgroup_k_split.txt): `parts` workgroups per tile sum
+    disjoint slices of K, the last arrival adds the parked partials.  Integer sums: the oracle's bits, launch after launch, whichever workgroup arrives
+    last; bias, Relu and the output statistics ride the last arrival's epilogue."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RTEN_I8_KS=setting, PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", "from tests.test_gpu_round6 import ks_cases_main; ks_cases_main()"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "KS CASES OK" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
+
+
+@pytest.mark.parametrize("rows,cols", [(16384, 768), (16387, 768), (17001, 200), (16385, 1024), (16500, 129), (20000, 512), (4096, 768)])
+def test_layer_norm_rows_in_sequence_is_bit_exact(ctx, rows, cols):
+    """Launches with at least 16384 rows of 129..1024 columns run layer_norm_stream_kernel (a wave owns four consecutive rows, the next row's loads in flight
+    under the current row's reductions; smaller launches keep one row per wave -- profiles/r09/layer_norm_rows.txt): the reference's 16-lane order per row,
+    ragged last waves, column tails, with and without the fused residual Add, in place."""
+    rng = ref.XorShiftRng(rows + cols)
+    x = (rng.f32(rows * cols).reshape(rows, cols) - 0.5) * 3
+    r = (rng.f32(rows * cols).reshape(rows, cols) - 0.5) * 2
+    g, b = rng.f32(cols) + 0.5, rng.f32(cols) - 0.5
+    xd, rd, gd, bd = dev(ctx, x), dev(ctx, r), dev(ctx, g), dev(ctx, b)
+    out = DeviceTensor(ctx, (rows, cols), np.float32)
+    ctx.profile_reset()
+    ctx.profile(True)
+    ctx.call("rten_hip_layer_norm_f32", rows, cols, xd.vp, gd.vp, bd.vp, 1.0, 0.0, 1e-5, out.vp)
+    ctx.sync()
+    ctx.profile(False)
+    _bits(out.numpy(), ref.layer_norm(x, g, b, 1.0, 0.0, eps=1e-5, lanes=16))
+    ctx.call("rten_hip_layer_norm_f32", rows, cols, xd.vp, gd.vp, None, 1.0, 0.0, 1e-5, out.vp)  # scale only
+    _bits(out.numpy(), ref.layer_norm(x, g, None, 1.0, 0.0, eps=1e-5, lanes=16))
+    ctx.call("rten_hip_layer_norm_f32", rows, cols, xd.vp, None, None, 2.0, 0.5, 1e-5, out.vp)  # scalar scale / bias
+    _bits(out.numpy(), ref.layer_norm(x, None, None, 2.0, 0.5, eps=1e-5, lanes=16))
+    want = ref.layer_norm(ref.add(x, r), g, b, 1.0, 0.0, eps=1e-12, lanes=16)
+    ctx.call("rten_hip_add_layer_norm_f32", rows, cols, xd.vp, rd.vp, gd.vp, bd.vp, 1.0, 0.0, 1e-12, out.vp)
+    _bits(out.numpy(), want)
+    ctx.call("rten_hip_add_layer_norm_f32", rows, cols, xd.vp, rd.vp, gd.vp, bd.vp, 1.0, 0.0, 1e-12, rd.vp)  # in place over the addend (BERT's residual stream)
+    _bits(rd.numpy(), want)
+
+
+def test_tanh_is_the_reference_polynomial_and_exp_forms(ctx):
+    rng = ref.XorShiftRng(21)
+    x = np.concatenate([(rng.f32(200003) - 0.5) * 20, (rng.f32(50000) - 0.5) * 1.2, (rng.f32(5000) - 0.5) * 1e-3,
+                        np.array([0.0, -0.0, 0.0004, 0.00040001, 0.55, 0.55000001, 9.02, 9.0199995, -9.02, 50.0, -50.0, 104.0, np.inf, -np.inf, np.nan, 1e-40, -1e-40], np.float32)]).astype(np.float32)
+    y = DeviceTensor(ctx, x.shape, np.float32)
+    ctx.call("rten_hip_tanh_f32", x.size, dev(ctx, x).vp, y.vp)
+    got, want = y.numpy(), ref.tanh(x)
+    same = (got.view(np.int32) == want.view(np.int32)) | (np.isnan(got) & np.isnan(want))
+    assert same.all(), (x[~same][:5], got[~same][:5], want[~same][:5])
+    fin = np.isfinite(x) & (x != 0)
+    t = np.tanh(x[fin].astype(np.float64)).astype(np.float32)
+    ulp = np.abs(got[fin].view(np.int32).astype(np.int64) - t.view(np.int32).astype(np.int64))
+    assert ulp.max() <= 3  # the reference's own bound (tanh.rs: MAX_TANH_ERROR_ULPS)
+
+
+def _strides(shape, out):
+    st, acc = [0] * len(out), 1
+    for i in range(len(shape) - 1, -1, -1):
+        st[len(out) - len(shape) + i] = 0 if shape[i] == 1 else acc
+        acc *= shape[i]
+    return st
+
+
+def _ew(ctx, op, a, b=None, c=None, y_dtype=np.int32):
+    dt = {np.dtype(np.float32): 0, np.dtype(np.int32): 1, np.dtype(np.uint8): 2, np.dtype(np.int8): 3}
+    shapes = [t.shape for t in (a, b, c) if t is not None]
+    out = np.broadcast_shapes(*shapes)
+    nd = len(out)
+    I64 = C.c_int64 * max(nd, 1)
+    arr = lambda v: I64(*(list(v) + [0] * (max(nd, 1) - len(v))))  # noqa: E731
+    y = DeviceTensor(ctx, out, y_dtype)
+    da, db, dc = dev(ctx, a), dev(ctx, b) if b is not None else None, dev(ctx, c) if c is not None else None  # (alive until y.numpy() below)
+    ctx.call("rten_hip_elementwise_nd", op, nd, arr(out), da.vp, dt[a.dtype], arr(_strides(a.shape, out)), db.vp if db else None, dt[b.dtype] if b is not None else 0,
+             arr(_strides(b.shape, out)) if b is not None else None, dc.vp if dc else None, arr(_strides(c.shape, out)) if c is not None else None, y.vp, dt[np.dtype(y_dtype)])
+    res = y.numpy()
+    del da, db, dc
+    return res
+
+
+def test_elementwise_nd_cast_logic_compare_where(ctx):
+    """src/ops/convert.rs (Rust `as`), binary_elementwise.rs (booleans are int32 0 / 1; numpy broadcasting), where_op."""
+    rng = np.random.default_rng(4)
+    f = np.array([1.9, -1.9, 0.0, -0.0, 3e10, -3e10, np.nan, 255.7, -128.9, 127.5, 1e-3], np.float32)
+    assert _ew(ctx, 0, f, y_dtype=np.int32).tolist() == [1, -1, 0, 0, 2147483647, -2147483648, 0, 255, -128, 127, 0]
+    assert _ew(ctx, 0, f, y_dtype=np.uint8).tolist() == [1, 0, 0, 0, 255, 0, 0, 255, 0, 127, 0]
+    assert _ew(ctx, 0, f, y_dtype=np.int8).tolist() == [1, -1, 0, 0, 127, -128, 0, 127, -128, 127, 0]
+    i = np.array([0, 1, -1, 255, 256, 300, -129, 2147483647], np.int32)
+    assert _ew(ctx, 0, i, y_dtype=np.uint8).tolist() == (i & 0xff).astype(np.uint8).tolist()
+    assert _ew(ctx, 0, i, y_dtype=np.int8).tolist() == i.astype(np.int8).tolist()
+    np.testing.assert_array_equal(_ew(ctx, 0, np.arange(256, dtype=np.uint8), y_dtype=np.float32), np.arange(256, dtype=np.float32))
+    np.testing.assert_array_equal(_ew(ctx, 0, np.arange(-128, 128).astype(np.int8), y_dtype=np.int32), np.arange(-128, 128, dtype=np.int32))
+    a = rng.integers(-3, 4, (2, 1, 5, 1)).astype(np.int32)
+    b = rng.integers(-3, 4, (3, 1, 7)).astype(np.int32)
+    for op, fn in ((2, lambda x, y: (x != 0) & (y != 0)), (3, lambda x, y: (x != 0) | (y != 0)), (4, lambda x, y: (x != 0) ^ (y != 0)), (5, np.equal), (6, np.less),
+                   (7, np.less_equal), (8, np.greater), (9, np.greater_equal), (11, np.add), (12, np.subtract), (13, np.multiply)):
+        np.testing.assert_array_equal(_ew(ctx, op, a, b), fn(a, b).astype(np.int32), err_msg=str(op))
+    np.testing.assert_array_equal(_ew(ctx, 1, a), (a == 0).astype(np.int32))
+    d = np.where(b == 0, 1, b).astype(np.int32)
+    np.testing.assert_array_equal(_ew(ctx, 14, a, d), np.trunc(a / d).astype(np.int32))  # truncation toward zero
+    fa, fb = rng.standard_normal((4, 1, 6)).astype(np.float32), rng.standard_normal((5, 1)).astype(np.float32)
+    fa[0, 0, 0] = np.nan
+    for op, fn in ((5, np.equal), (6, np.less), (9, np.greater_equal)):
+        np.testing.assert_array_equal(_ew(ctx, op, fa, fb), fn(fa, fb).astype(np.int32))
+    cond = rng.integers(0, 2, (2, 1, 8, 1)).astype(np.int32) * 7
+    xs, ys = np.array([0.0], np.float32), np.array([-3.4028234663852886e38], np.float32)
+    got = _ew(ctx, 10, cond, xs, ys, y_dtype=np.float32)
+    np.testing.assert_array_equal(got, np.where(cond != 0, xs, ys))
+    xi, yi = rng.integers(-9, 9, (1, 3, 1, 4)).astype(np.int32), rng.integers(-9, 9, (8, 1)).astype(np.int32)
+    np.testing.assert_array_equal(_ew(ctx, 10, cond, xi, yi), np.where(cond != 0, xi, yi))
+
+
+def test_gather_axis_and_copy_rows(ctx):
+    rng = np.random.default_rng(5)
+    data = rng.standard_normal((3, 5, 7)).astype(np.float32)
+    for axis, ids in ((1, np.array([4, 0, -1, 2], np.int32)), (0, np.array([[2, 0], [1, -3]], np.int32)), (2, np.array(3, np.int32))):
+        outer, inner = int(np.prod(data.shape[:axis])), int(np.prod(data.shape[axis + 1:]))
+        want = np.take(data, ids, axis=axis)
+        y = DeviceTensor(ctx, want.shape, np.float32)
+        dd, di = dev(ctx, data), dev(ctx, ids.reshape(-1))  # (kept alive until the result is read)
+        ctx.call("rten_hip_gather_axis_b32", outer, data.shape[axis], inner, ids.size, dd.vp, di.vp, y.vp)
+        np.testing.assert_array_equal(y.numpy(), want)
+    a, b = rng.integers(0, 100, (4, 3, 5)).astype(np.int32), rng.integers(0, 100, (4, 2, 5)).astype(np.int32)
+    out = DeviceTensor(ctx, (4, 5, 5), np.int32)
+    da, db = dev(ctx, a), dev(ctx, b)
+    ctx.call("rten_hip_copy_rows_b32", 4, 15, da.vp, 15, out.vp, 25)
+    ctx.call("rten_hip_copy_rows_b32", 4, 10, db.vp, 10, C.c_void_p(out.ptr + 15 * 4), 25)
+    np.testing.assert_array_equal(out.numpy(), np.concatenate([a, b], axis=1))
+
+
+@pytest.mark.parametrize("m,k,n", [(16, 2304, 1000), (33, 4096, 4096), (8, 11008, 512), (64, 4096, 1000)])
+def test_small_m_streaming_gemm_beyond_eight_depth_blocks(ctx, m, k, n):
+    """gemm_f32_smallm_kernel is the automatic path for every one-batch GEMM with M <= 64, and its fold loop takes the parked depth blocks
+    eight at a time -- K = 2304 (9 blocks), 4096 (16) and 11008 (43: LLM projections) exercise the second and later passes, which the round-5 tests
+    (K <= 2048) never reached.  The oracle's blocked chain, bit for bit, for the explicit variant and the automatic choice."""
+    from tests.test_gpu_round5 import _gemm
+    rng = ref.XorShiftRng(m + k + n)
+    a = rng.f32(m * k).reshape(m, k) - 0.5
+    b = rng.f32(k * n).reshape(k, n) - 0.5
+    bias = rng.f32(n) - 0.5
+    want = ref.gemm_f32(a, b, bias=bias, bias_kind=ref.BIAS_PER_COL)
+    bt = np.ascontiguousarray(b.T).T
+    _bits(_gemm(ctx, a, bt, bias=bias, bias_kind=L.BIAS_PER_COL, variant=31), want)
+    _bits(_gemm(ctx, a, b, bias=bias, bias_kind=L.BIAS_PER_COL), want)
+
+
+def test_measurement_only_knobs_are_rejected_by_the_product_library(ctx):
+    """rten_hip_set_gemm_order bit 3 (relaxed split-K: not the reference's order) exists in -DRTEN_ABLATION builds only; a plan file cannot switch the
+    bit-exactness contract off.  rten_hip_tuning_restore puts every knob back even when one of the saved values is refused."""
+    assert ctx.lib.rten_hip_set_gemm_order(ctx.h, 8) == L.ERR_INVALID_VALUE
+    assert ctx.lib.rten_hip_set_gemm_order(ctx.h, 3) == 0
+    saved = (C.c_int32 * 8)()
+    ctx.call("rten_hip_tuning_save", saved)
+    assert saved[3] == 3
+    bad = (C.c_int32 * 8)(*saved)
+    bad[3] = 8          # refused ...
+    bad[7] = 1          # ... but the knobs after it are still restored
+    assert ctx.lib.rten_hip_tuning_restore(ctx.h, bad) == L.ERR_INVALID_VALUE
+    now = (C.c_int32 * 8)()
+    ctx.call("rten_hip_tuning_save", now)
+    assert now[7] == 1
+    saved[3] = 0
+    saved[7] = 0
+    ctx.call("rten_hip_tuning_restore", saved)

@@ -110,7 +110,7 @@ def test_transformers_bert_export_runs_resident_and_matches_the_oracle(tmp_path,
         mask[1, S - 5:] = 0
         if B > 2:
             mask[2, 5:] = 0
-        want = om.bert_forward(cfg, w, ids, mask, tts)
+        want = om.bert_forward(cfg, w, ids, mask, tts).reshape(B, S, -1)
         sd = m.state_dict()
         pooled_want = ref.tanh(ref.matmul_f32(np.ascontiguousarray(want[:, 0, :]), np.ascontiguousarray(sd["pooler.dense.weight"].numpy().T), bias=sd["pooler.dense.bias"].numpy()))
         yout, pout = tmp_path / "y.bin", tmp_path / "p.bin"
