@@ -13,7 +13,7 @@ what a Rust host binds); `--via-runner` times round 4's hand
 A step = one forward pass of ResNet-50 (53 convs + maxpool + global-avg-pool + fc) over one batch of 32 synthetic 224x224 images that is already
 resident in HBM: one hipGraph replay per chain.  Steps are independent batches, so consecutive steps go round robin to `--lanes` REPLICAS of the model
 (rten_hip_model_clone: own stream, buffers and hipGraphs, one shared weight arena) and overlap on the device -- f32: one whole-batch chain per replica,
-2 lanes; int8 (whose quantizers span the batch: no sub-batch chains): 4 lanes.  `ms_per_step` / `value` are therefore THROUGHPUT figures over the K timed
+3 lanes; int8 (whose quantizers span the batch: no sub-batch chains): 4 lanes.  `ms_per_step` / `value` are therefore THROUGHPUT figures over the K timed
 steps (both synchronisation points cover every stream of every lane); `ms_per_step_joined_every_step` and `p50_latency_ms` are ONE batch on ONE replica.
 `--chains C` alone gives round 4's schedule (one replica, C sub-batch chains).  One process per GPU; batches are independent, so the path shards with no
 data-path collective (weak scaling: 32 images per GPU); the only collective is the one-time RCCL broadcast of the model's weight arena from rank 0.
@@ -61,7 +61,8 @@ BATCH_PER_GPU = 32
 # Consecutive batches on independent replicas of the model ("lanes", --lanes): measured in session r5e (profiles/r08/lanes.txt) -- int8 1 / 2 / 3 / 4 lanes:
 # 1.502 / 1.052 / 0.971 / 0.950 ms per batch; f32 one chain x 2 lanes 2.494 ms against 2.677 ms for one replica running the batch as 4 sub-batch chains
 INT8_DEFAULT_LANES = 4
-F32_DEFAULT_LANES = 2   # ... of ONE chain each (whole-batch launches: the best per-layer efficiency), unless --chains is given
+F32_DEFAULT_LANES = 3   # ... of ONE chain each (whole-batch launches: the best per-layer efficiency), unless --chains is given.  Round 6, same box, three alternating
+#                         rounds (profiles/r09/f32_lanes_and_plan_ab.txt): 2 lanes 2.475 / 2.502 / 2.504 ms, 3 lanes 2.462 / 2.461 / 2.453, 4 lanes 2.483
 
 
 LINE_LIMIT = 4096   # the driver keeps a bounded tail of stdout: the final line must fit it whole (round 5's 23 KB line came back `parsed: null`)
@@ -896,7 +897,7 @@ def parse_args():
                          "plan executor behind the C ABI (rten_hip_model_*: ONNX bytes in, committed launch plan, chains, hipGraph replay), which is the default")
     ap.add_argument("--lanes", type=int, default=None,
                     help="executor: run this many independent replicas of the model (own streams, own buffers) and hand consecutive BATCHES to them round robin, so "
-                         "that step k + 1 overlaps step k (default: 4 for int8, whose graph cannot be split into sub-batch chains; 2 for f32 with one chain each; "
+                         "that step k + 1 overlaps step k (default: 4 for int8, whose graph cannot be split into sub-batch chains; 3 for f32 with one chain each; "
                          "1 when --chains is given).  A throughput schedule: `p50_latency_ms` stays the latency of ONE batch on one replica")
     ap.add_argument("--no-shapes", action="store_true", help="f32: skip the stand-alone per-shape table (`roofline.shapes`)")
     ap.add_argument("--detail-file", default=None, help="where the full record goes (default gpurun_out/bench_detail[_<config>].json); the printed line stays compact")

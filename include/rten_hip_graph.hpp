@@ -1374,7 +1374,8 @@ class Graph {
         // attention kernel reads in place (bit-identical: every output element is the same k-ordered dot product).
         // lead0 / lead1: leading dims when the Reshapes spell them out ([B, S, h, d], as PyTorch's exporter writes a static-shape
         // `view`) instead of copying them ([0, 0, h, d]); checked against the projections at run time (0 = copied)
-        struct Attn { std::string q, k, v, mask, out, x; int heads = 0; float scale = 1.f; bool merged = false; int wqkv = -1, bqkv = -1; int64_t hidden = 0; int lead0 = 0, lead1 = 0; int head_dim = 0; };
+        struct Attn { std::string q, k, v, mask, out, x; int heads = 0; float scale = 1.f; bool merged = false; int wqkv = -1, bqkv = -1; int64_t hidden = 0; int lead0 = 0, lead1 = 0; int head_dim = 0;
+                      std::string lead_check; }; // a run-time Reshape target (dynamic-axes export): its leading dims are checked against the projection's when the step runs
         std::map<size_t, Attn> attn_at;
         if (opt_.fuse) {
             auto single_use = [&](const std::string &v) { auto it = users.find(v); return !graph_outs.count(v) && it != users.end() && it->second.size() == 1; };
@@ -1395,14 +1396,36 @@ class Graph {
                 if (first) { at.lead0 = shp[0]; at.lead1 = shp[1]; return true; }
                 return at.lead0 == shp[0] && at.lead1 == shp[1];
             };
+            // The target of a head-split / head-merge Reshape: a constant, or -- exports with dynamic axes -- Concat(dim 0, dim 1, [h | -1], [d]) whose leading
+            // entries are computed from a Shape at run time and whose trailing entries are constants.  The run-time form reads as [0, 0, ..] ("copy the
+            // projection's leading dims"); `dyn` names the Concat's output so that the fused step can check that claim against its host value.
+            auto reshape_target = [&](const onnx::Node &rn, std::vector<int32_t> &shp, std::string &dyn) {
+                dyn.clear();
+                if (rn.inputs.size() < 2) return false;
+                if (const_i32(rn.inputs[1], shp)) return true;
+                const long c = made_by(rn.inputs[1], "Concat");
+                if (c < 0 || m.nodes[(size_t)c].get_int("axis", 0) != 0 || m.nodes[(size_t)c].inputs.size() < 3) return false;
+                const onnx::Node &cn = m.nodes[(size_t)c];
+                shp.assign(cn.inputs.size(), 0);
+                for (size_t k = 0; k < cn.inputs.size(); k++) {
+                    std::vector<int32_t> one;
+                    if (k < 2) { if (is_const(cn.inputs[k])) return false; continue; } // (a half-constant leading pair is not this idiom)
+                    if (!const_i32(cn.inputs[k], one) || one.size() != 1) return false;
+                    shp[k] = one[0];
+                }
+                dyn = rn.inputs[1];
+                return true;
+            };
             auto split_heads = [&](const std::string &v, std::vector<int> perm, Attn &at, bool first, std::vector<size_t> &nodes) -> std::string {
                 int &heads = at.heads;
                 const long t = made_by(v, "Transpose");
                 if (t < 0 || m.nodes[(size_t)t].get_ints("perm", {}) != perm) return "";
                 const long r = made_by(m.nodes[(size_t)t].inputs[0], "Reshape");
                 std::vector<int32_t> shp;
+                std::string dyn;
                 // [.., .., h, d] or [.., .., -1, d]: transformers' exporter spells the head COUNT as -1 (hidden / d, resolved when the step runs)
-                if (r < 0 || m.nodes[(size_t)r].inputs.size() < 2 || !const_i32(m.nodes[(size_t)r].inputs[1], shp) || shp.size() != 4 || (shp[2] <= 0 && !(shp[2] == -1 && shp[3] > 0)) || !leading_ok(shp, at, first)) return "";
+                if (r < 0 || !reshape_target(m.nodes[(size_t)r], shp, dyn) || shp.size() != 4 || (shp[2] <= 0 && !(shp[2] == -1 && shp[3] > 0)) || !leading_ok(shp, at, first)) return "";
+                if (first) at.lead_check = dyn;
                 if (heads && heads != shp[2]) return "";
                 // one head size for q, k and v (the kernel's d == dv); -1 ("the rest") is accepted only if all three say so
                 if (heads && at.head_dim != shp[3]) return "";
@@ -1446,7 +1469,8 @@ class Graph {
                 if (tr < 0 || m.nodes[(size_t)tr].get_ints("perm", {}) != std::vector<int>{0, 2, 1, 3}) continue;
                 const long rs = sole_user(m.nodes[(size_t)tr].outputs[0], "Reshape");
                 std::vector<int32_t> shp;
-                if (rs < 0 || m.nodes[(size_t)rs].inputs.size() < 2 || !const_i32(m.nodes[(size_t)rs].inputs[1], shp) || shp.size() != 3 || !leading_ok(shp, at, false)) continue;
+                std::string dyn_out;
+                if (rs < 0 || !reshape_target(m.nodes[(size_t)rs], shp, dyn_out) || shp.size() != 3 || !leading_ok(shp, at, false)) continue;
                 nodes.push_back((size_t)tr); nodes.push_back((size_t)rs);
                 at.out = m.nodes[(size_t)rs].outputs[0];
                 if (!at.mask.empty() && producer.count(at.mask) && producer[at.mask] > i) continue; // mask must exist before the scores
@@ -1528,10 +1552,17 @@ class Graph {
                     st.in = {id_of(at.q), id_of(at.k), id_of(at.v), at.mask.empty() ? -1 : id_of(at.mask)};
                 }
                 st.out = {id_of(at.out)};
+                if (!at.lead_check.empty()) st.in.push_back(id_of(at.lead_check)); // (5th operand: the run-time Reshape target, a host value)
                 const int lead0 = at.lead0, lead1 = at.lead1;
                 st.run = [op, lead0, lead1](Context &c, const InputList &in) {
                     if (lead0 && (require(in, 0).ndim() != 3 || require(in, 0).size(0) != lead0 || require(in, 0).size(1) != lead1))
                         throw OpError(OpError::InvalidValue, "fused attention: the graph's Reshape spells out leading dims that differ from the projection's");
+                    if (in.size() > 4 && in[4]) { // the Reshape target the graph computes at run time must say what the fusion assumed: [B, S, ..] of the projection
+                        const std::vector<int64_t> tgt = host_ints(in[4], "fused attention: the head-split Reshape's target");
+                        if (require(in, 0).ndim() != 3 || tgt.size() != 4 || tgt[0] != require(in, 0).size(0) || tgt[1] != require(in, 0).size(1))
+                            throw OpError(OpError::InvalidValue, "fused attention: the graph's Reshape target differs from the projection's leading dims");
+                        return op->run(c, InputList(in.begin(), in.begin() + 4));
+                    }
                     return op->run(c, in);
                 };
                 steps_.push_back(std::move(st));

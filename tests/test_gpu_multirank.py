@@ -23,7 +23,7 @@ def test_two_ranks_one_gpu_identical_logits():
 def test_bench_two_ranks_prints_one_line(config):
     """`python bench.py --gpus 2` (the form the driver uses on a multi-GPU node), here with both ranks on the one GPU over gloo: the
     script spawns the ranks itself, rank 1 receives the weight arena only by broadcast, rank 0 prints ONE line that says 2 GPUs,
-    carries both ranks' step times and the default schedule (whole-batch chains; consecutive batches on 2 (f32) / 4 (int8) replicas per rank)."""
+    carries both ranks' step times and the default schedule (whole-batch chains; consecutive batches on 3 (f32) / 4 (int8) replicas per rank)."""
     import json
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env.update(RTEN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT="29561" if config == "f32" else "29563")
@@ -33,12 +33,12 @@ def test_bench_two_ranks_prints_one_line(config):
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and len(lines[0]) <= 4096, r.stdout[-2000:]
     line = json.loads(lines[0])  # the compact line the driver parses ...
-    assert line["n_gpus"] == 2 and line["ranks"]["world_size"] == 2 and line["ranks"]["distinct_plans"] == 1 and line["config"]["lanes"] == (2 if config == "f32" else 4)
+    assert line["n_gpus"] == 2 and line["ranks"]["world_size"] == 2 and line["ranks"]["distinct_plans"] == 1 and line["config"]["lanes"] == (3 if config == "f32" else 4)
     j = json.load(open(os.path.join(ROOT, line["detail"])))  # ... and the full record it points to
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 64 and j["scaling"] == "weak"
     assert j["ranks"]["world_size"] == 2 and len(j["ranks"]["ms_per_step_per_rank"]) == 2 and j["ranks"]["weight_broadcast_world"] == 2
     assert j["cpu_baseline"] is None and j["roofline"]["frac"] > 0
-    assert j["config"]["batch_chains"]["chains"] == 1 and j["config"]["batch_lanes"]["lanes"] == (2 if config == "f32" else 4)
+    assert j["config"]["batch_chains"]["chains"] == 1 and j["config"]["batch_lanes"]["lanes"] == (3 if config == "f32" else 4)
     # every rank ran the same launch plan, and rank r's logits are the oracle's for ITS shard (inputs seeded 1234 + r): the parity
     # definition of a batch-sharded run -- for int8 each shard quantizes with its own statistics, like an independent run
     import hashlib

@@ -20,6 +20,10 @@ ap.add_argument("--lanes", type=int, default=4, help="executor: independent repl
                                                      "(default 4: 6.85 -> 6.36 ms per batch, session r5g; 1 = one replica)")
 ap.add_argument("--chains", type=int, default=1, help="executor: split the batch into this many independent sub-batch chains (rows are independent in an encoder)")
 ap.add_argument("--save-plan", default=None, help="executor: write the launch plan that ran (rten_hip_model_plan_json) to this file")
+ap.add_argument("--hf", action="store_true", help="executor: the model is transformers.BertModel (BERT-base config, random init, eager attention) written by torch's ONNX exporter "
+                                                  "(tools/torch_export.py: static shapes) instead of the repo's own writer -- the exporter's mask subgraph, `view`s and decomposed "
+                                                  "LayerNorm / GELU go through the executor's shape arithmetic and canonicalisation; GEMM plans are tuned at prepare time; the result is "
+                                                  "checked against torch's CPU forward on the first two sequences")
 args = ap.parse_args()
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ctx = L.Context(0)
@@ -54,10 +58,19 @@ else:
     # writes them) through the C++ executor behind the C ABI -- attention pre-pass, merged QKV GEMM, fused epilogues, committed launch plan, hipGraph
     from rten_amd import onnx_writer
     from rten_amd.tensor import DeviceTensor
-    weights = bert.make_weights(cfg)
-    onnx_bytes = onnx_writer.bert_encoder(cfg, weights, args.seq)
+    hf_model = None
+    if args.hf:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import torch_export as te
+        hf_model = te.bert_module(layers=12)
+        weights = None
+        onnx_bytes = te.bert_onnx(hf_model, args.batch, args.seq)
+        args.no_cpu_baseline = True  # (the oracle's weights layout is the repo's own; tests/test_shape_arithmetic.py checks the export against the oracle at a small size)
+    else:
+        weights = bert.make_weights(cfg)
+        onnx_bytes = onnx_writer.bert_encoder(cfg, weights, args.seq)
     plan_path = os.path.join(ROOT, "profiles", "plans", f"bert_base_b{args.batch}_s{args.seq}.json")
-    plan_text = None if (args.autotune or not os.path.exists(plan_path)) else open(plan_path).read()
+    plan_text = None if (args.autotune or args.hf or not os.path.exists(plan_path)) else open(plan_path).read()
     if args.chains > 1 and plan_text:  # the committed plan is keyed by the full batch: a sub-batch takes the same per-shape choices
         pj = json.loads(plan_text)
         plan_text = json.dumps({str(args.batch // args.chains): next(iter(pj.values()))})
@@ -69,7 +82,11 @@ else:
         for name in m_l.inputs:
             p = m_l.bind_input(name, feeds[name].shape)
             DeviceTensor(c_l, feeds[name].shape, np.int32, ptr=p, keepalive=m_l).upload(feeds[name])
-        m_l.prepare(tune=plan_text is None)
+        if plan_text is None and models:  # a replica takes the plan the first model tuned (one tuning pass per process, not per lane)
+            m_l.set_plan(models[0].plan_json())
+            m_l.prepare()
+        else:
+            m_l.prepare(tune=plan_text is None)
         models.append(m_l)
     model = models[0]
     if args.save_plan:
@@ -90,6 +107,14 @@ else:
     el = time.perf_counter() - t0
     plan_note["lanes"], plan_note["chains"] = args.lanes, args.chains
     rep = model.profile_pass(args.steps)
+    if hf_model is not None:  # the exported graph on the device against torch's own CPU forward (f32 accumulation-order tolerance)
+        import torch
+        optr, oshape = model.output(0)
+        got = DeviceTensor(ctx, oshape, np.float32, ptr=optr, keepalive=model).numpy()
+        with torch.no_grad():
+            t = hf_model(torch.from_numpy(ids[:2].astype(np.int64)), torch.from_numpy(am[:2].astype(np.int64)), torch.from_numpy(tts[:2].astype(np.int64))).last_hidden_state.numpy()
+        plan_note["hf_export"] = {"producer": "transformers.BertModel via torch.onnx (tools/torch_export.py)", "onnx_bytes": len(onnx_bytes), "steps": model.num_steps,
+                                  "max_abs_diff_vs_torch_cpu_first_2_sequences": float(np.abs(got[:2] - t).max())}
 gem = [r for r in rep if r["kernel"].startswith("igemm_f32")]
 ms = sum(r["ms"] for r in gem); gfl = sum(r["flops"] for r in gem)
 step_ms = el / args.steps * 1e3
@@ -121,7 +146,7 @@ def cpu_baseline(budget_s=12.0):
                       f"({ref.num_threads()} OpenMP threads, {dt:.1f} s)"}
 
 
-out = {"metric": "sequences/sec, BERT-base encoder f32, batch 32 x 128 tokens", "value": round(args.batch * args.steps / el, 2), "unit": "sequences/s",
+out = {"metric": "sequences/sec, BERT-base encoder f32, batch 32 x 128 tokens" + (" (transformers export)" if args.hf else ""), "value": round(args.batch * args.steps / el, 2), "unit": "sequences/s",
        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_ms, 4), "higher_is_better": True, "dtype": "f32",
        "data": "synthetic", "config": {"workload": "BERT-base (12 layers, hidden 768, 12 heads) encoder forward, random-init weights (BASELINE configs[3])",
                                        "path": "runner" if args.via_runner else "executor", "launch_plan": plan_note,
