@@ -559,6 +559,7 @@ class Graph {
             const size_t b = t.bytes();
             if (b) ctx_.check(rten_hip_memcpy_d2d(ctx_.raw(), (char *)arena_->ptr() + off, t.ptr(), b));
             Tensor v = Tensor::view_at(*arena_, off, t.shape(), t.dtype());
+            v.set_host(t.host_ptr()); // a small constant's host mirror (shape arithmetic reads it) moves with it
             ctx_.sync();       // the copy has read the old buffer before it goes back to the allocator
             t = std::move(v);  // same Tensor object (steps hold pointers to it), new storage
             off += pad(b);
@@ -756,7 +757,7 @@ class Graph {
     const Graph *donor_ = nullptr;
     // a constant of this graph: uploaded here, or a non-owning view of the donor's
     void add_const(int id, const std::function<Tensor()> &make) {
-        if (donor_) { const Tensor &d = donor_->consts_.at(id); consts_.emplace(id, Tensor::view_of(d, d.shape())); }
+        if (donor_) { const Tensor &d = donor_->consts_.at(id); Tensor v = Tensor::view_of(d, d.shape()); v.set_host(d.host_ptr()); consts_.emplace(id, std::move(v)); }
         else consts_.emplace(id, make());
     }
     // the prepacked operand of step `name`: packed here, or the donor's

@@ -138,3 +138,54 @@ def test_transformers_bert_export_runs_resident_and_matches_the_oracle(tmp_path,
             t = m(torch.from_numpy(ids.astype(np.int64)), torch.from_numpy(mask.astype(np.int64)), torch.from_numpy(tts.astype(np.int64)))
         np.testing.assert_allclose(got.reshape(B, S, -1), t.last_hidden_state.numpy(), rtol=1e-4, atol=1e-4)
         np.testing.assert_allclose(pooled.reshape(B, -1), t.pooler_output.numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_transformers_bert_export_through_the_model_abi_and_a_replica():
+    """The same export through rten_hip_model_* (what tools/bench_bert.py --hf and a Rust host's `load_resident` use): the model's constants move into ONE weight
+    arena after compile and a replica views the origin's constants -- the small initializers' host mirrors (the operands of ConstantOfShape / Reshape / Expand) must
+    travel with both (round 6, first closing session: `ConstantOfShape_190: the shape input ... depends on device data` at BERT-base size).  Origin and replica run
+    side by side on different inputs; each is the oracle's encoder bit for bit."""
+    from oracle import models as om
+    from rten_amd import lib as L
+    from rten_amd.tensor import DeviceTensor
+    m = _hf_bert(pooler=False)
+    cfg, w = oracle_weights(m)
+    B, S = 3, 16
+    onnx_bytes = _export(m, B, S, False)
+    rng = np.random.default_rng(11)
+    ctxs = [L.Context(0), L.Context(0)]
+    models = []
+    try:
+        models.append(L.Model(ctxs[0], onnx_bytes, None, 1))
+        models.append(models[0].clone(ctxs[1]))
+        wants = []
+        for mdl, c in zip(models, ctxs):
+            ids = rng.integers(0, cfg.vocab, (B, S)).astype(np.int32)
+            tts = rng.integers(0, 2, (B, S)).astype(np.int32)
+            mask = np.ones((B, S), np.int32)
+            mask[1, S - 4:] = 0
+            feeds = {"input_ids": ids, "token_type_ids": tts, "attention_mask": mask}
+            for name in mdl.inputs:
+                p = mdl.bind_input(name, feeds[name].shape)
+                DeviceTensor(c, feeds[name].shape, np.int32, ptr=p, keepalive=mdl).upload(feeds[name])
+            if mdl is models[0]:
+                mdl.prepare(tune=True)
+            else:
+                mdl.set_plan(models[0].plan_json())
+                mdl.prepare()
+            wants.append(om.bert_forward(cfg, w, ids, mask, tts).reshape(B, S, -1))
+        for _ in range(3):
+            for mdl in models:
+                mdl.run(join=False)
+        for mdl in models:
+            mdl.sync()
+        for i, (mdl, c) in enumerate(zip(models, ctxs)):
+            optr, oshape = mdl.output(0)
+            got = DeviceTensor(c, oshape, np.float32, ptr=optr, keepalive=mdl).numpy()
+            assert np.array_equal(got.view(np.int32).ravel(), wants[i].view(np.int32).ravel()), (i, np.abs(got.ravel() - wants[i].ravel()).max())
+    finally:
+        for mdl in reversed(models):
+            mdl.close()
+        for c in ctxs:
+            c.close()
