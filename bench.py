@@ -61,7 +61,7 @@ BATCH_PER_GPU = 32
 # Consecutive batches on independent replicas of the model ("lanes", --lanes): measured in session r5e (profiles/r08/lanes.txt) -- int8 1 / 2 / 3 / 4 lanes:
 # 1.502 / 1.052 / 0.971 / 0.950 ms per batch; f32 one chain x 2 lanes 2.494 ms against 2.677 ms for one replica running the batch as 4 sub-batch chains
 INT8_DEFAULT_LANES = 4
-F32_DEFAULT_LANES = 3   # ... of ONE chain each (whole-batch launches: the best per-layer efficiency), unless --chains is given.  Round 6, same box, three alternating
+F32_DEFAULT_LANES = 4   # ... of ONE chain each (whole-batch launches: the best per-layer efficiency), unless --chains is given.  Round 6, same box, three alternating
 #                         rounds (profiles/r09/f32_lanes_and_plan_ab.txt): 2 lanes 2.475 / 2.502 / 2.504 ms, 3 lanes 2.462 / 2.461 / 2.453, 4 lanes 2.483
 
 
@@ -562,9 +562,10 @@ def run_via_executor(args):
     lanes = args.lanes if args.lanes else (INT8_DEFAULT_LANES if int8 else (F32_DEFAULT_LANES if args.chains is None else 1))
     # int8: one replica alone may use quantized-output launches (int8.json); replicas running side by side may not (those launches need the device to
     # themselves): int8_lanes.json lists only the quantize-on-load layers
-    # f32 replicas side by side: the one-chain plan plus the classifier on its 64x64 tiles (f32_lanes.json) -- the small-M streaming kernel the backend picks
-    # on its own is the faster launch alone (8 vs 14 us) but spreads over every compute unit, which costs the other replica more than it saves
-    # (same-box A/B, profiles/r08/classifier_under_lanes.txt)
+    # f32 replicas side by side: f32_lanes.json -- per-layer plans chosen UNDER CO-RUN (tools/tune_corun.py, round 6: three streams running the same layer; larger tiles
+    # where the other replicas fill their tile-quantisation gaps: fewer bytes through LDS / L2 per FLOP, so the shader clock holds on real operand data,
+    # tools/probes/kloop2.hip) plus the classifier on its 64x64 tiles -- the small-M streaming kernel the backend picks on its own is the faster launch alone
+    # (8 vs 14 us) but spreads over every compute unit, which costs the other replicas more than it saves (same-box A/B, profiles/r08/classifier_under_lanes.txt)
     f32_plan = "f32_lanes.json" if (lanes > 1 and chains == 1) else f"f32_{chains}chain{'s' if chains > 1 else ''}.json"
     default_plan = os.path.join(ROOT, "profiles", "plans", ("int8.json" if lanes == 1 else "int8_lanes.json") if int8 else f32_plan)
     plan_path = args.load_plan or default_plan

@@ -447,9 +447,11 @@ constexpr int MAX_NSTAGE = 6;
 // Waves per SIMD the compiler must leave room for: 64x64 tiles are LDS-limited to 6 (three stages) / 10 (two stages) workgroups per compute unit,
 // so their register budget is set to match (80 VGPRs: the MODE 1 / 2 forms sat at 81-85, i.e. at 5) -- more resident workgroups is what these
 // kernels respond to (tools/debug/f32_trace.py with RTEN_HIP_OCC_CAP: 2 -> 3 -> 6 workgroups per CU = 3.72 -> 3.20 -> 2.95 ms per step).
-constexpr int dma_min_waves(int bm, int bn, int mode) { return bm * bn == 64 * 64 ? (mode == 3 ? 4 : 6) : 2; }
+// (four stages of a 64x64 tile are 32 KB: LDS admits four to five workgroups per compute unit, so asking the compiler for a six-wave register budget only made it
+// report an unmet target -- rounds 3-5; the four-stage forms now ask for what they can have)
+constexpr int dma_min_waves(int bm, int bn, int mode, int nst = 3) { return bm * bn == 64 * 64 ? ((mode == 3 || nst >= 4) ? 4 : 6) : 2; }
 template <int BM, int BN, int AL, int BL, int MODE, int NST = 3, int MFK = 0>
-__global__ __launch_bounds__(NTHREADS, dma_min_waves(BM, BN, MODE)) void igemm_f32_dma_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(NTHREADS, dma_min_waves(BM, BN, MODE, NST)) void igemm_f32_dma_kernel(const GemmArgs p) {
     TR_DECL
     TR_STAMP(0)
     kernarg_prefetch<(int)sizeof(GemmArgs)>();

@@ -109,14 +109,21 @@ def test_split_batch_covers_the_batch_once():
         split_batch(3, 4)
 
 
-def test_the_lanes_plan_is_the_one_chain_plan_plus_the_classifier_entry():
-    """profiles/plans/f32_lanes.json (the default line's plan: one chain x 2 lanes) differs from f32_1chain.json by ONE entry -- the classifier Gemm pinned to its
-    64x64 tiles (profiles/r08/classifier_under_lanes.txt) -- so the per-shape table and the tuning records of the one-chain plan apply to it unchanged."""
+def test_the_lanes_plan_names_the_same_steps_as_the_one_chain_plan():
+    """profiles/plans/f32_lanes.json (the default line's plan: one chain per replica, three replicas side by side) names exactly the steps of f32_1chain.json plus the
+    classifier Gemm, pinned to its 64x64 tiles (profiles/r08/classifier_under_lanes.txt).  Since round 6 its convolution entries are chosen PER LAYER UNDER CO-RUN
+    (tools/tune_corun.py: three streams running the same layer; profiles/r10/tune_corun3_full.txt) -- larger tiles where the other replicas fill their quantisation
+    gaps -- so they differ from the one-replica plan; every entry is a [variant, split mode, K groups, tile order] the backend accepts."""
     import json
     plans = os.path.join(ROOT, "profiles", "plans")
     one, lanes = json.load(open(os.path.join(plans, "f32_1chain.json"))), json.load(open(os.path.join(plans, "f32_lanes.json")))
-    assert {k: v for k, v in lanes.items() if k != "fc"} == one
+    assert set(lanes) == set(one) | {"fc"}
     assert lanes["fc"] == [3, 3, 1, 0]
+    for name, e in lanes.items():
+        assert len(e) == 4 and 0 <= e[0] <= 31 and 0 <= e[1] <= 6 and 1 <= e[2] <= 32 and 0 <= e[3] <= 3, (name, e)
+        assert e[0] != 31 or name == "fc", (name, e)  # (31 = the small-M streaming kernel: a convolution given it runs as variant 3 -- the plan says 3)
+    bert = json.load(open(os.path.join(plans, "bert_base_b32_s128.json"))), json.load(open(os.path.join(plans, "bert_base_b32_s128_lanes.json")))
+    assert list(bert[0]) == list(bert[1]) == ["32"] and set(bert[0]["32"]) == set(bert[1]["32"]) and len(bert[1]["32"]) == 48
 
 
 def _recorded_full_lines():

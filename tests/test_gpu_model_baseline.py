@@ -181,8 +181,8 @@ def test_bert_base_batch32_seq128_through_the_model_abi_is_the_oracle():
     onnx_bytes = ow.bert_encoder(cfg, w, S)
     ctx = L.Context(0)
     try:
-        plan_path = os.path.join(ROOT, "profiles", "plans", "bert_base_b32_s128.json")
-        texts = [None] + ([open(plan_path).read()] if os.path.exists(plan_path) else [])
+        # no plan, the one-replica plan, and the plan of tools/bench_bert.py's default line (four replicas: chosen under co-run, round 6 -- 128x128 tiles)
+        texts = [None] + [open(os.path.join(ROOT, "profiles", "plans", f)).read() for f in ("bert_base_b32_s128.json", "bert_base_b32_s128_lanes.json")]
         for text in texts:
             m = L.Model(ctx, onnx_bytes, text, 1)
             try:

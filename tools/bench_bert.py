@@ -19,6 +19,7 @@ ap.add_argument("--lanes", type=int, default=4, help="executor: independent repl
                                                      "batches go to them round robin, so the row-wise / attention kernels of one batch run beside the GEMMs of the next "
                                                      "(default 4: 6.85 -> 6.36 ms per batch, session r5g; 1 = one replica)")
 ap.add_argument("--chains", type=int, default=1, help="executor: split the batch into this many independent sub-batch chains (rows are independent in an encoder)")
+ap.add_argument("--load-plan", default=None, help="executor: a plan file other than the committed profiles/plans/bert_base_b<batch>_s<seq>.json (A/B runs)")
 ap.add_argument("--save-plan", default=None, help="executor: write the launch plan that ran (rten_hip_model_plan_json) to this file")
 ap.add_argument("--hf", action="store_true", help="executor: the model is transformers.BertModel (BERT-base config, random init, eager attention) written by torch's ONNX exporter "
                                                   "(tools/torch_export.py: static shapes) instead of the repo's own writer -- the exporter's mask subgraph, `view`s and decomposed "
@@ -69,7 +70,12 @@ else:
     else:
         weights = bert.make_weights(cfg)
         onnx_bytes = onnx_writer.bert_encoder(cfg, weights, args.seq)
-    plan_path = os.path.join(ROOT, "profiles", "plans", f"bert_base_b{args.batch}_s{args.seq}.json")
+    plan_path = args.load_plan or os.path.join(ROOT, "profiles", "plans", f"bert_base_b{args.batch}_s{args.seq}.json")
+    # replicas side by side take the plan chosen UNDER co-run (tools/tune_corun_gemm.py, round 6): larger tiles -- fewer bytes through LDS and L2 per FLOP,
+    # so the shader clock holds on real operand data -- whose tile-quantisation gaps the other replicas fill; one replica alone keeps its own plan
+    lanes_plan = os.path.join(ROOT, "profiles", "plans", f"bert_base_b{args.batch}_s{args.seq}_lanes.json")
+    if not args.load_plan and args.lanes > 1 and args.chains == 1 and os.path.exists(lanes_plan):
+        plan_path = lanes_plan
     plan_text = None if (args.autotune or args.hf or not os.path.exists(plan_path)) else open(plan_path).read()
     if args.chains > 1 and plan_text:  # the committed plan is keyed by the full batch: a sub-batch takes the same per-shape choices
         pj = json.loads(plan_text)

@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""Per-layer launch plans chosen UNDER SELF-CO-RUN (round 6): the default schedule of bench.py runs three replicas ("lanes") side by side, so a layer's launch never
+has the chip to itself -- whatever its last partial round of tiles leaves idle, another replica's launch fills.  tools/tune_lanes.py measures a candidate by the
+whole-model throughput, where one layer family (<= 14 % of the FLOPs) changes the step by less than the run-to-run noise.  Here the SAME layer runs on three streams at
+once (three runner networks sharing one weight arena, each on its REAL input activations of that layer -- the operand data matters: the matrix pipe and the data paths
+draw less power on zeros, tools/probes/kloop2.hip), each stream a captured hipGraph of REPS launches, and the figure is launches per second over all three streams.
+
+    python tools/tune_corun.py [--lanes 3] [--out profiles/plans/experiments/f32_corun3.json]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lanes", type=int, default=3)
+    ap.add_argument("--reps", type=int, default=12)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--plan", default=os.path.join(ROOT, "profiles", "plans", "f32_lanes.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "plans", "experiments", "f32_corun3.json"))
+    ap.add_argument("--only", default=None, help="comma-separated layer names (representatives) to restrict the sweep to")
+    ap.add_argument("--margin", type=float, default=0.01)
+    ap.add_argument("--full", action="store_true", help="every plan of the runner's candidate list (all tile variants, thin-tail, persistent, lean, every split form) instead of the short list")
+    args = ap.parse_args()
+    from rten_amd import lib as L
+    from rten_amd.workloads import resnet50
+    weights = resnet50.make_weights()
+    incumbent = json.load(open(args.plan))
+    ctxs = [L.Context(0) for _ in range(args.lanes)]
+    nets = []
+    for i, ctx in enumerate(ctxs):
+        kw = {} if i == 0 else dict(arena_ptr=nets[0].arena.ptr, arena_keepalive=nets[0].arena)
+        net = resnet50.ResNet50(ctx, args.batch, weights, **kw)
+        if i == 0:
+            net.upload_weights()
+            ctx.sync()
+        net.x.upload(np.random.default_rng(1234 + i).random((args.batch, 3, 224, 224), dtype=np.float32))
+        net.variants = {k: tuple(v) for k, v in incumbent.items() if k != "fc"}
+        nets.append(net)
+    specs = nets[0].specs
+    descs = nets[0].descs
+    fams = {}
+    for idx, l in enumerate(specs):
+        d = descs[l["name"]]
+        fams.setdefault((d.o, d.c, d.kh, d.stride_h, d.h, bool(l["res"])), []).append((idx, l))
+
+    def candidates(key):
+        o, c, k, s, h, res = key
+        nblk = (c * k * k + 255) // 256
+        tiles = [27, 3, 1, 2, 0, 13, 14, 12]  # 64x64 (2 / 3 stages), 128x64, 64x128, 128x128, and the four-stage forms of the larger ones
+        if o < 128:
+            tiles = [27, 3, 2, 14]
+        cands = [[v, 0, 1, od] for v in tiles for od in (0, 1)]
+        if nblk > 1:
+            for g in sorted({2, 3, 4, 6, nblk, max(2, nblk // 2), max(2, nblk // 3)} & set(range(2, nblk + 1))):
+                for v in tiles:
+                    cands.append([v, 1, g, 0])
+                    cands += [[v, 2, g, 0], [v, 2, g, 3]]
+        return cands
+
+    def measure(idx, l, plan):
+        graphs = []
+        try:
+            for net in nets:
+                net.variants[l["name"]] = tuple(plan)
+                net._conv(l)  # warm: scratch growth outside the capture
+            for c in ctxs:
+                c.sync()
+            for net in nets:
+                net.ctx.graph_begin()
+                for _ in range(args.reps):
+                    net._conv(l)
+                graphs.append((net.ctx, net.ctx.graph_end()))
+            best = 1e30
+            for _ in range(3):
+                t0 = time.perf_counter()
+                for c, g in graphs:
+                    c.graph_launch(g)
+                for c in ctxs:
+                    c.sync()
+                best = min(best, (time.perf_counter() - t0) / (args.reps * len(nets)) * 1e6)
+            return best
+        finally:
+            for c, g in graphs:
+                c.graph_destroy(g)
+
+    out_plan = dict(incumbent)
+    only = set(args.only.split(",")) if args.only else None
+    total_inc = total_new = 0.0
+    for key, members in sorted(fams.items(), key=lambda kv: -len(kv[1])):
+        idx, l = members[1] if len(members) > 1 else members[0]  # (a stage's first block reads another producer: take a later member when there is one)
+        if only and l["name"] not in only:
+            continue
+        for net in nets:  # this layer's real input (the runner reuses activation buffers: stop the pass right before the layer)
+            net.forward(upto=idx)
+        for c in ctxs:
+            c.sync()
+        d = descs[l["name"]]
+        flops = 2.0 * d.o * (d.c // d.groups) * d.kh * d.kw * d.n * d.out_h * d.out_w
+        inc = list(incumbent[l["name"]])
+        try:
+            t_inc = min(measure(idx, l, inc), measure(idx, l, inc))
+        except L.HipError as e:
+            print(f"{l['name']}: incumbent failed: {e}", flush=True)
+            continue
+        rows = []
+        for cand in ([list(p) for p in nets[0].candidate_plans(l)] if args.full else candidates(key)):
+            if cand == inc:
+                continue
+            try:
+                rows.append((measure(idx, l, cand), cand))
+            except L.HipError:
+                continue
+        rows.sort()
+        best_t, best_c = t_inc, inc
+        for t, cand in rows[:3]:  # confirm the leaders
+            t2 = min(t, measure(idx, l, cand))
+            if t2 < best_t * (1 - args.margin):
+                best_t, best_c = t2, cand
+        tag = f"O{key[0]} C{key[1]} k{key[2]} s{key[3]} {key[4]}x{key[4]}{' +res' if key[5] else ''} x{len(members)}"
+        top = " ".join(f"{c}={t:.1f}" for t, c in rows[:6])
+        print(f"{tag:38s} {l['name']:7s} incumbent {inc} {t_inc:6.1f} us ({flops / t_inc / 1e6:5.1f} TF/s) -> {best_c} {best_t:6.1f} us ({flops / best_t / 1e6:5.1f}) | {top}", flush=True)
+        for _, m in members:
+            out_plan[m["name"]] = best_c
+            net_l = m
+        total_inc += t_inc * len(members)
+        total_new += best_t * len(members)
+        for net in nets:
+            net.variants[l["name"]] = tuple(inc)
+    print(f"# sum over layers (co-run us per launch x layers): incumbent {total_inc:.0f} us, chosen {total_new:.0f} us ({100 * (total_inc - total_new) / max(total_inc, 1e-9):.1f} % less)", flush=True)
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    json.dump(out_plan, open(args.out, "w"))
+
+
+if __name__ == "__main__":
+    main()
