@@ -493,7 +493,8 @@ int32_t rten_hip_global_average_pool_f32(rten_hip_ctx *ctx, int64_t nc, int32_t 
  * out[b,h] = softmax(scale * Q[b,h] K[b,h]^T + mask[b]) V[b,h].  Q/K/V/out are addressed by element
  * strides (batch, head, row; the last dim is contiguous) so both [B,H,S,D] tensors and the
  * [B,S,H*D] projection outputs of BERT (head = column block) are read in place.
- * mask: NULL, or additive f32 [B,1,1,T] (mask_row_stride = 0) / [B,1,S,T] (mask_row_stride = T). */
+ * mask: NULL, or additive f32 [B,1,1,T] (mask_row_stride = 0, mask_batch_stride = T) / [B,1,S,T] (mask_row_stride = T, mask_batch_stride = S * T) /
+ * one shared row per batch item read out of a [B,1,S,T] tensor whose S rows are equal (mask_row_stride = 0, mask_batch_stride = S * T). */
 typedef struct {
     int32_t batch, heads, s, t, d, dv;
     int64_t q_bs, q_hs, q_rs;

@@ -617,6 +617,11 @@ class Graph {
         }
         return n;
     }
+    // Plan entries keyed by the PRODUCT'S SHAPE -- "gemm:MxKxN", M = the rows of A over all its leading dims -- for MatMul-family steps no name entry covers (round
+    // 6): a plan chosen on one writer's graph (profiles/plans/bert_base_b32_s128_lanes.json, its "shapes" table) then applies to another exporter's file of
+    // the same model, whose steps carry other names.  Shapes are run-time facts here, so the lookup happens in run(), once per step (the entry stays).
+    void set_shape_plans(std::map<std::string, GemmPlan> t) { shape_plans_ = std::move(t); shape_planned_ = 0; }
+    size_t num_shape_planned() const { return shape_planned_; }
     std::map<std::string, GemmPlan> plans() const { // what autotune() / apply_plan() left on the convolution steps
         std::map<std::string, GemmPlan> t;
         for (auto &st : steps_) {
@@ -681,6 +686,13 @@ class Graph {
             }
             const auto t0 = std::chrono::steady_clock::now();
             OutputList out;
+            if (st.gemm_plan && !st.gemm_plan->set && !shape_plans_.empty() && tune_reps_ == 0 && in.size() > 1 && in[0] && in[1] && in[0]->ndim() >= 2 && in[1]->ndim() == 2) {
+                const Tensor &a = *in[0], &b = *in[1];
+                const int64_t k = a.size(a.ndim() - 1), mrows = a.len() / std::max<int64_t>(k, 1);
+                const int64_t ncols = b.size(0) == k ? b.size(1) : (b.size(1) == k ? b.size(0) : -1); // [K, N], or [N, K] (Gemm with transB)
+                auto it = ncols < 0 ? shape_plans_.end() : shape_plans_.find("gemm:" + std::to_string(mrows) + "x" + std::to_string(k) + "x" + std::to_string(ncols));
+                if (it != shape_plans_.end()) { *st.gemm_plan = it->second; shape_planned_++; }
+            }
             if (tune_reps_ > 0 && (st.conv || st.gemm_plan)) tune_step(st, in);
             try {
                 out = st.run(ctx_, in);
@@ -780,6 +792,8 @@ class Graph {
     std::set<int> view_values_;
     int tune_reps_ = 0;
     size_t tuned_ = 0;
+    std::map<std::string, GemmPlan> shape_plans_;
+    size_t shape_planned_ = 0;
     size_t stats_blocks_ = 0, staged_dql_ = 0, qout_edges_ = 0, dql_loader_steps_ = 0;
     std::unique_ptr<Tensor> stats_arena_, sync_arena_, arena_;
 

@@ -186,7 +186,7 @@ class Tensor {
     ~Tensor() { release(); }
     Tensor(Tensor &&o) noexcept { *this = std::move(o); }
     Tensor &operator=(Tensor &&o) noexcept {
-        if (this != &o) { release(); ctx_ = o.ctx_; ptr_ = o.ptr_; shape_ = std::move(o.shape_); dtype_ = o.dtype_; cap_ = o.cap_; owns_ = o.owns_; host_ = std::move(o.host_); o.ptr_ = nullptr; }
+        if (this != &o) { release(); ctx_ = o.ctx_; ptr_ = o.ptr_; shape_ = std::move(o.shape_); dtype_ = o.dtype_; cap_ = o.cap_; owns_ = o.owns_; host_ = std::move(o.host_); uniform_ = o.uniform_; o.ptr_ = nullptr; }
         return *this;
     }
     Tensor(const Tensor &) = delete;
@@ -204,7 +204,13 @@ class Tensor {
         if (bytes()) ctx_->check(rten_hip_memcpy_d2h(ctx_->raw(), out.data(), ptr_, bytes())); // synchronises
         return out;
     }
-    void reshape(std::vector<int64_t> s) { shape_ = std::move(s); }
+    void reshape(std::vector<int64_t> s) { shape_ = std::move(s); uniform_ = 0; }
+    // Bit d set = every slice along dim d holds the same values (the tensor is a broadcast along d that was materialised): what an element-wise step knows
+    // about its result when each operand had size 1 there, was itself uniform there, or is a host value that is.  A consumer that broadcasts along d anyway may
+    // then read ONE slice -- the exporter-written attention mask [B, 1, S, T] whose S rows are copies of a [B, 1, 1, T] row takes the fused attention kernel's
+    // shared-mask form (round 6).  Fresh tensors and views start at 0 (nothing known).
+    uint32_t uniform_dims() const { return uniform_; }
+    void set_uniform_dims(uint32_t m) { uniform_ = m; }
     // the host's copy of the values, when it has one (see HostVal); views made with view_of() start without one
     const HostVal *host() const { return host_.get(); }
     const std::shared_ptr<const HostVal> &host_ptr() const { return host_; }
@@ -226,6 +232,7 @@ class Tensor {
     std::vector<int64_t> shape_;
     DType dtype_ = DType::F32;
     std::shared_ptr<const HostVal> host_;
+    uint32_t uniform_ = 0;
 };
 
 // ---- Operator interface (src/operator.rs:486-613).  Optional inputs are null pointers (InputList::get).
@@ -1043,7 +1050,9 @@ struct MultiHeadSdpa : Operator {
         if (mask) {
             want(*mask, DType::F32, "float32");
             if (mask->ndim() == 4 && mask->size(0) == B && mask->size(1) == 1 && mask->size(3) == T && (mask->size(2) == 1 || mask->size(2) == S)) {
-                sd.mask_row_stride = mask->size(2) == 1 ? 0 : T;
+                // (an [B, 1, S, T] mask known to hold S copies of one row -- Tensor::uniform_dims, the exporter's expanded padding mask -- is read as that row)
+                const bool one_row = mask->size(2) == 1 || (mask->uniform_dims() >> 2 & 1u);
+                sd.mask_row_stride = one_row ? 0 : T;
                 sd.mask_batch_stride = mask->size(2) == 1 ? T : S * T;
             } else {
                 // numpy broadcasting of the Add(scores [B, H, S, T], mask): every form without a head axis is the same addend for
@@ -1305,6 +1314,43 @@ inline Broadcast broadcast_shapes(const std::vector<const std::vector<int64_t> *
     return b;
 }
 
+// Which dims of an element-wise result are uniform (Tensor::uniform_dims): dim d of the broadcast shape is, when EVERY operand is constant along it -- its own
+// size there is 1 (or the dim is absent), it carries the flag, or it is a host value whose slices along that dim are equal (checked here, the values are small).
+inline bool host_uniform_along(const HostVal &h, size_t dim) {
+    int64_t inner = 1, n = h.shape[dim];
+    for (size_t i = dim + 1; i < h.shape.size(); i++) inner *= h.shape[i];
+    const int64_t total = h.len();
+    if (n <= 1 || total == 0) return true;
+    for (int64_t base = 0; base < total; base += n * inner)
+        for (int64_t k = 1; k < n; k++)
+            for (int64_t j = 0; j < inner; j++) {
+                const size_t x = (size_t)(base + j), y = (size_t)(base + k * inner + j);
+                if (h.is_float ? std::memcmp(&h.f[x], &h.f[y], 4) != 0 : h.i[x] != h.i[y]) return false;
+            }
+    return true;
+}
+inline uint32_t uniform_after_broadcast(const std::vector<const Tensor *> &ins, const std::vector<int64_t> &out_shape) {
+    uint32_t m = 0;
+    const size_t nd = out_shape.size();
+    for (size_t d = 0; d < nd && d < 32; d++) {
+        if (out_shape[d] <= 1) continue; // (a size-1 dim carries no information; consumers test sizes first)
+        bool all = true;
+        for (const Tensor *t : ins) {
+            if (!t) continue;
+            const size_t tn = (size_t)t->ndim();
+            if (d + tn < nd) continue;               // the operand has no such dim: broadcast along it
+            const size_t td = d - (nd - tn);
+            if (t->size((int)td) == 1) continue;
+            if (t->uniform_dims() >> td & 1u) continue;
+            if (t->host() && t->host()->len() <= (int64_t)1 << 20 && host_uniform_along(*t->host(), td)) continue;
+            all = false;
+            break;
+        }
+        if (all) m |= 1u << d;
+    }
+    return m;
+}
+
 struct Cast : Operator { // src/ops/convert.rs:18-60: every pair of float32 / int32 / uint8 / int8 (`as` casts)
     DType to = DType::F32;
     const char *name() const override { return "Cast"; }
@@ -1321,6 +1367,7 @@ struct Cast : Operator { // src/ops/convert.rs:18-60: every pair of float32 / in
             const int64_t n = x.len(), one = 1;
             ctx.check(rten_hip_elementwise_nd(ctx.raw(), RTEN_HIP_EW_CAST, 1, &n, x.ptr(), abi_dtype(x.dtype()), &one, nullptr, 0, nullptr, nullptr, nullptr, y.ptr(), abi_dtype(to)));
         }
+        y.set_uniform_dims(x.uniform_dims());
         out.push_back(std::move(y));
         return out;
     }
@@ -1345,6 +1392,7 @@ struct ElementwiseNd : Operator {
             Tensor y(ctx, a.shape(), DType::I32);
             const int64_t n = a.len(), one = 1;
             if (n) ctx.check(rten_hip_elementwise_nd(ctx.raw(), code, 1, &n, a.ptr(), RTEN_HIP_DT_I32, &one, nullptr, 0, nullptr, nullptr, nullptr, y.ptr(), RTEN_HIP_DT_I32));
+            y.set_uniform_dims(a.uniform_dims());
             out.push_back(std::move(y));
             return out;
         }
@@ -1357,6 +1405,7 @@ struct ElementwiseNd : Operator {
         if (y.len())
             ctx.check(rten_hip_elementwise_nd(ctx.raw(), code, (int32_t)bc.shape.size(), bc.shape.data(), a.ptr(), abi_dtype(a.dtype()), bc.strides[0].data(), b.ptr(), abi_dtype(b.dtype()),
                                               bc.strides[1].data(), nullptr, nullptr, y.ptr(), RTEN_HIP_DT_I32));
+        y.set_uniform_dims(uniform_after_broadcast({&a, &b}, bc.shape));
         out.push_back(std::move(y));
         return out;
     }
@@ -1373,6 +1422,7 @@ struct Where : Operator { // binary_elementwise.rs:1189-1280: cond != 0 ? x : y,
         if (o.len())
             ctx.check(rten_hip_elementwise_nd(ctx.raw(), RTEN_HIP_EW_WHERE, (int32_t)bc.shape.size(), bc.shape.data(), c.ptr(), RTEN_HIP_DT_I32, bc.strides[0].data(), x.ptr(),
                                               abi_dtype(x.dtype()), bc.strides[1].data(), y.ptr(), bc.strides[2].data(), o.ptr(), abi_dtype(x.dtype())));
+        o.set_uniform_dims(uniform_after_broadcast({&c, &x, &y}, bc.shape));
         OutputList out;
         out.push_back(std::move(o));
         return out;
@@ -1385,6 +1435,7 @@ inline Tensor expand_to(Context &ctx, const Tensor &x, const std::vector<int64_t
     const Broadcast bc = broadcast_shapes({&x.shape(), &target});
     Tensor y(ctx, bc.shape, x.dtype());
     if (y.len()) ctx.check(rten_hip_copy_strided_b32(ctx.raw(), (int32_t)bc.shape.size(), bc.shape.data(), bc.strides[0].data(), x.ptr(), y.ptr()));
+    y.set_uniform_dims(uniform_after_broadcast({&x}, bc.shape));
     return y;
 }
 

@@ -33,8 +33,11 @@ RTEN_EXPORT int32_t rten_hip_sdpa_f32(rten_hip_ctx *ctx, const rten_hip_sdpa_des
     const long long bh = (long long)d->batch * d->heads;
     if (bh == 0 || d->s == 0 || d->dv == 0) return RTEN_HIP_OK;
     if (!q || !k || !v || !out) return RTEN_HIP_ERR_INVALID_VALUE;
+    // [B,1,S,T] contiguous, [B,1,1,T] contiguous, or -- row stride 0 with batch stride S * T -- the FIRST row of each item of a [B,1,S,T] tensor whose S rows
+    // are known to be equal (an exporter's expanded padding mask: rten_hip_ops.hpp, Tensor::uniform_dims)
     if (mask && ((d->mask_row_stride != 0 && d->mask_row_stride != d->t) ||
-                 d->mask_batch_stride != (d->mask_row_stride ? (int64_t)d->s * d->t : (int64_t)d->t)))
+                 (d->mask_row_stride ? d->mask_batch_stride != (int64_t)d->s * d->t
+                                     : (d->mask_batch_stride != (int64_t)d->t && d->mask_batch_stride != (int64_t)d->s * d->t))))
         return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "sdpa: mask must be [B,1,1,T] or [B,1,S,T] contiguous");
     // ONE query row: both of sdpa_head's products are one-row products of unpacked operands, for which the reference's gemm_impl takes its vector-matrix
     // kernels (rten-gemm/src/lib.rs:876-891) -- not the blocked chain the one-kernel forms replay.  The composed path below then calls the GEMM entry
@@ -68,6 +71,13 @@ RTEN_EXPORT int32_t rten_hip_sdpa_f32(rten_hip_ctx *ctx, const rten_hip_sdpa_des
                 float *sb = scores + (long long)b * d->heads * d->s * d->t;
                 rc = rten_hip_softmax_f32(ctx, (int64_t)d->heads * d->s, d->t, sb, mask + (long long)b * d->mask_batch_stride, 1,
                                           d->s, d->flush_nan_to_zero, sb);
+                if (rc) return rc;
+            }
+        } else if (mask && d->mask_batch_stride != d->t) { // one shared row per item, S * T apart: one launch per image
+            for (int b = 0; b < d->batch; b++) {
+                float *sb = scores + (long long)b * d->heads * d->s * d->t;
+                rc = rten_hip_softmax_f32(ctx, (int64_t)d->heads * d->s, d->t, sb, mask + (long long)b * d->mask_batch_stride, (int64_t)d->heads * d->s, 1,
+                                          d->flush_nan_to_zero, sb);
                 if (rc) return rc;
             }
         } else { // no mask, or [B,1,1,T]: addend row = r / (H*S)

@@ -373,6 +373,9 @@ RTEN_EXPORT int32_t rten_hip_model_prepare(rten_hip_model *g, int32_t tune) {
                     return fail(g, RTEN_HIP_ERR_INVALID_VALUE, "prepare: the plan file is keyed by sub-batch size and has no entry for a chain of " + std::to_string(b) + " rows");
                 const size_t n = gr.apply_plan(plan_table(it != g->plan_by_batch.end() ? it->second : g->plan_flat));
                 if (c == 0) g->planned_steps = n;
+                // "shapes": entries by product shape for the MatMul-family steps no name matched (another exporter's file of the same model)
+                auto sh = g->plan_by_batch.find("shapes");
+                if (sh != g->plan_by_batch.end()) gr.set_shape_plans(plan_table(sh->second));
             } else if (tune) {
                 if (!tuned.count(b)) { const size_t n = gr.autotune(feeds); tuned[b] = gr.plans(); if (c == 0) g->tuned_steps = n; }
                 else gr.apply_plan(tuned[b]);
@@ -405,6 +408,7 @@ RTEN_EXPORT int32_t rten_hip_model_prepare(rten_hip_model *g, int32_t tune) {
                     g->full_out.emplace_back(new Tensor(*g->ctxs[0], s, probe[o].dtype()));
                 }
                 cx.sync();
+                g->planned_steps += gr.num_shape_planned(); // (the probe run resolved the shape-keyed entries)
             }
             // a chain's rows go into the resident full-batch outputs INSIDE its captured graph (logits-sized copies): a run is then `chains` graph
             // launches and nothing else

@@ -84,6 +84,10 @@ int main() {
     CHECK(threw);
     // HostVal equality is bitwise on floats (the cache key of a materialised constant)
     CHECK(floats({1}, {0.f}) == floats({1}, {0.f}) && !(floats({1}, {0.f}) == floats({1}, {-0.f})) && !(ints({1}, {0}) == floats({1}, {0.f})));
+    // which dims of a value are "uniform" (every slice along the dim equal): what lets an expanded padding mask [B, 1, S, T] be read as one row per batch item
+    CHECK(host_uniform_along(ints({1, 1, 3, 1}, {1, 1, 1}), 2) && !host_uniform_along(ints({1, 1, 3, 1}, {1, 0, 1}), 2));
+    CHECK(host_uniform_along(ints({2, 3}, {5, 5, 5, 7, 7, 7}), 1) && !host_uniform_along(ints({2, 3}, {5, 5, 5, 7, 7, 7}), 0));
+    CHECK(host_uniform_along(floats({2, 2}, {0.f, 1.f, 0.f, 1.f}), 0) && !host_uniform_along(floats({2, 2}, {0.f, 1.f, -0.f, 1.f}), 0)); // bitwise
     if (failures) { std::printf("%d FAILED\n", failures); return 1; }
     std::printf("ALL OK\n");
     return 0;

@@ -110,7 +110,7 @@ def test_split_batch_covers_the_batch_once():
 
 
 def test_the_lanes_plan_names_the_same_steps_as_the_one_chain_plan():
-    """profiles/plans/f32_lanes.json (the default line's plan: one chain per replica, three replicas side by side) names exactly the steps of f32_1chain.json plus the
+    """profiles/plans/f32_lanes.json (the default line's plan: one chain per replica, four replicas side by side) names exactly the steps of f32_1chain.json plus the
     classifier Gemm, pinned to its 64x64 tiles (profiles/r08/classifier_under_lanes.txt).  Since round 6 its convolution entries are chosen PER LAYER UNDER CO-RUN
     (tools/tune_corun.py: three streams running the same layer; profiles/r10/tune_corun3_full.txt) -- larger tiles where the other replicas fill their quantisation
     gaps -- so they differ from the one-replica plan; every entry is a [variant, split mode, K groups, tile order] the backend accepts."""
@@ -123,7 +123,10 @@ def test_the_lanes_plan_names_the_same_steps_as_the_one_chain_plan():
         assert len(e) == 4 and 0 <= e[0] <= 31 and 0 <= e[1] <= 6 and 1 <= e[2] <= 32 and 0 <= e[3] <= 3, (name, e)
         assert e[0] != 31 or name == "fc", (name, e)  # (31 = the small-M streaming kernel: a convolution given it runs as variant 3 -- the plan says 3)
     bert = json.load(open(os.path.join(plans, "bert_base_b32_s128.json"))), json.load(open(os.path.join(plans, "bert_base_b32_s128_lanes.json")))
-    assert list(bert[0]) == list(bert[1]) == ["32"] and set(bert[0]["32"]) == set(bert[1]["32"]) and len(bert[1]["32"]) == 48
+    assert list(bert[0]) == ["32"] and sorted(bert[1]) == ["32", "shapes"] and set(bert[0]["32"]) == set(bert[1]["32"]) and len(bert[1]["32"]) == 48
+    # "shapes": the same four choices keyed by product shape (gemm:MxKxN), what another exporter's file of the model takes (include/rten_hip_graph.hpp)
+    assert sorted(bert[1]["shapes"]) == ["gemm:4096x3072x768", "gemm:4096x768x2304", "gemm:4096x768x3072", "gemm:4096x768x768"]
+    assert all(v in bert[1]["32"].values() for v in bert[1]["shapes"].values())
 
 
 def _recorded_full_lines():

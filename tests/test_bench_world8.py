@@ -47,7 +47,7 @@ def test_eight_rank_bench_control_flow_of_the_default_path(config):
     r = _run(8, config, 29615 if config == "int8" else 29617)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     line, j = _line_and_detail(r)
-    assert line["config"]["path"] == "executor" and line["config"]["lanes"] == (4 if config == "int8" else 3) and line["config"]["chains"] == 1
+    assert line["config"]["path"] == "executor" and line["config"]["lanes"] == 4 and line["config"]["chains"] == 1
     assert line["ranks"]["world_size"] == 8 and line["ranks"]["distinct_plans"] == 1 and len(line["ranks"]["ms_per_step_per_rank"]) == 8
     assert j["config"]["path"] == "executor" and j["n_gpus"] == 8 and j["config"]["global_batch"] == 256 and j["scaling"] == "weak" and j["steps"] == 3
     assert j["data"].startswith("recording") and j["cpu_baseline"] is None and "secondary" not in j
@@ -59,7 +59,7 @@ def test_eight_rank_bench_control_flow_of_the_default_path(config):
     assert len(set(rk["plan_sha16_per_rank"])) == 1 and j["config"]["launch_plan"]["identical_on_all_ranks"] is True
     assert len(set(rk["planned_steps_per_rank"])) == 1
     # the default schedule: whole-batch chains, consecutive batches on independent replicas (lanes)
-    lanes = 4 if config == "int8" else 3
+    lanes = 4
     assert j["config"]["batch_chains"]["chains"] == 1 and j["config"]["batch_lanes"]["lanes"] == lanes
     import re
     m = re.search(r"\[recording\] weight arena (\d+) bytes broadcast to 8 ranks", r.stderr)

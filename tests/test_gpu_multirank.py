@@ -33,12 +33,12 @@ def test_bench_two_ranks_prints_one_line(config):
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and len(lines[0]) <= 4096, r.stdout[-2000:]
     line = json.loads(lines[0])  # the compact line the driver parses ...
-    assert line["n_gpus"] == 2 and line["ranks"]["world_size"] == 2 and line["ranks"]["distinct_plans"] == 1 and line["config"]["lanes"] == (3 if config == "f32" else 4)
+    assert line["n_gpus"] == 2 and line["ranks"]["world_size"] == 2 and line["ranks"]["distinct_plans"] == 1 and line["config"]["lanes"] == 4
     j = json.load(open(os.path.join(ROOT, line["detail"])))  # ... and the full record it points to
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 64 and j["scaling"] == "weak"
     assert j["ranks"]["world_size"] == 2 and len(j["ranks"]["ms_per_step_per_rank"]) == 2 and j["ranks"]["weight_broadcast_world"] == 2
     assert j["cpu_baseline"] is None and j["roofline"]["frac"] > 0
-    assert j["config"]["batch_chains"]["chains"] == 1 and j["config"]["batch_lanes"]["lanes"] == (3 if config == "f32" else 4)
+    assert j["config"]["batch_chains"]["chains"] == 1 and j["config"]["batch_lanes"]["lanes"] == 4
     # every rank ran the same launch plan, and rank r's logits are the oracle's for ITS shard (inputs seeded 1234 + r): the parity
     # definition of a batch-sharded run -- for int8 each shard quantizes with its own statistics, like an independent run
     import hashlib

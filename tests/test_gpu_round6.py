@@ -241,3 +241,42 @@ def test_measurement_only_knobs_are_rejected_by_the_product_library(ctx):
     saved[3] = 0
     saved[7] = 0
     ctx.call("rten_hip_tuning_restore", saved)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 128, 128, 64), (2, 2, 64, 128, 64), (2, 2, 40, 72, 64), (1, 2, 48, 200, 32)])
+def test_sdpa_reads_one_shared_mask_row_out_of_an_expanded_mask(ctx, shape):
+    """rten_hip_sdpa_f32 with mask_row_stride = 0 and mask_batch_stride = S * T: the mask operand is a [B, 1, S, T] tensor whose S rows are copies of one row
+    (an exporter's expanded padding mask; the executor knows it from Tensor::uniform_dims) and only the first row of each batch item is read.  Same bits as the
+    [B, 1, S, T] form and as the compact [B, 1, 1, T] form, on the 16-query kernel (first shape), the 32-query kernel, the general one-kernel form and the
+    composed GEMM / softmax / GEMM path."""
+    B, H, S, T, D = shape
+    rng = ref.XorShiftRng(S + T + D)
+    q = rng.f32(B * H * S * D).reshape(B, H, S, D) - 0.5
+    k = rng.f32(B * H * T * D).reshape(B, H, T, D) - 0.5
+    v = rng.f32(B * H * T * D).reshape(B, H, T, D) - 0.5
+    row = np.where(rng.f32(B * T).reshape(B, 1, 1, T) > 0.3, 0.0, -3.4028234663852886e38).astype(np.float32)
+    full = np.ascontiguousarray(np.broadcast_to(row, (B, 1, S, T)))
+    qd, kd, vd = (DeviceTensor.from_numpy(ctx, a) for a in (q, k, v))
+    strides = (H * S * D, S * D, D, H * T * D, T * D, D, H * T * D, T * D, D, H * S * D, S * D, D)
+    scale = float(np.float32(1.0 / np.sqrt(D)))
+    want = ref.sdpa(q, k, v, mask=row, scale=scale, lanes=16, flush_nan=False)
+    outs = []
+    for path in (0, 1):  # automatic (a one-kernel form where one covers the shape), composed only
+        ctx.call("rten_hip_set_sdpa_path", path)
+        try:
+            for (m, mbs, mrs) in ((row, T, 0), (full, S * T, T), (full, S * T, 0)):
+                out = DeviceTensor(ctx, (B, H, S, D), np.float32)
+                d = L.SdpaDesc(B, H, S, T, D, D, *strides, mbs, mrs, scale, 0)
+                md = DeviceTensor.from_numpy(ctx, m)
+                ctx.call("rten_hip_sdpa_f32", C.byref(d), qd.vp, kd.vp, vd.vp, md.vp, out.vp)
+                outs.append(out.numpy())
+        finally:
+            ctx.call("rten_hip_set_sdpa_path", 0)
+    for got in outs:
+        _bits(got, want)
+    # a batch stride that is neither T nor S * T is still refused
+    d = L.SdpaDesc(B, H, S, T, D, D, *strides, 2 * T, 0, scale, 0)
+    out = DeviceTensor(ctx, (B, H, S, D), np.float32)
+    md = DeviceTensor.from_numpy(ctx, full)
+    rc = ctx.lib.rten_hip_sdpa_f32(ctx.h, C.byref(d), qd.vp, kd.vp, vd.vp, md.vp, out.vp)
+    assert rc == (L.ERR_UNSUPPORTED if S != 2 else 0), rc

@@ -184,6 +184,27 @@ def test_transformers_bert_export_through_the_model_abi_and_a_replica():
             optr, oshape = mdl.output(0)
             got = DeviceTensor(c, oshape, np.float32, ptr=optr, keepalive=mdl).numpy()
             assert np.array_equal(got.view(np.int32).ravel(), wants[i].view(np.int32).ravel()), (i, np.abs(got.ravel() - wants[i].ravel()).max())
+        # plan entries keyed by PRODUCT SHAPE ("shapes": {"gemm:MxKxN": plan}): what lets a plan chosen on one writer's graph apply to this exporter's file, whose
+        # steps carry other names.  The four products of each layer (48 rows = 3 x 16 tokens; hidden 64, FFN 128) take their entries; same bits.
+        import json
+        shapes = {"gemm:48x64x192": [1, 3, 1, 0], "gemm:48x64x64": [3, 3, 1, 1], "gemm:48x64x128": [2, 3, 1, 0], "gemm:48x128x64": [3, 1, 2, 0]}
+        mdl = L.Model(ctxs[0], onnx_bytes, json.dumps({"shapes": shapes}), 1)
+        models.append(mdl)
+        ids = rng.integers(0, cfg.vocab, (B, S)).astype(np.int32)
+        tts = np.zeros((B, S), np.int32)
+        mask = np.ones((B, S), np.int32)
+        feeds = {"input_ids": ids, "token_type_ids": tts, "attention_mask": mask}
+        for name in mdl.inputs:
+            p = mdl.bind_input(name, feeds[name].shape)
+            DeviceTensor(ctxs[0], feeds[name].shape, np.int32, ptr=p, keepalive=mdl).upload(feeds[name])
+        mdl.prepare()
+        assert mdl.planned_steps == 4 * cfg.layers and mdl.warning == "", (mdl.planned_steps, mdl.warning)
+        assert sorted(json.loads(mdl.plan_json())[str(B)].values()) == sorted(list(shapes.values()) * cfg.layers)
+        mdl.run()
+        optr, oshape = mdl.output(0)
+        got = DeviceTensor(ctxs[0], oshape, np.float32, ptr=optr, keepalive=mdl).numpy()
+        want = om.bert_forward(cfg, w, ids, mask, tts).reshape(B, S, -1)
+        assert np.array_equal(got.view(np.int32).ravel(), want.view(np.int32).ravel()), np.abs(got.ravel() - want.ravel()).max()
     finally:
         for mdl in reversed(models):
             mdl.close()

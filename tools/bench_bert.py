@@ -77,6 +77,9 @@ else:
     if not args.load_plan and args.lanes > 1 and args.chains == 1 and os.path.exists(lanes_plan):
         plan_path = lanes_plan
     plan_text = None if (args.autotune or args.hf or not os.path.exists(plan_path)) else open(plan_path).read()
+    if args.hf and not args.autotune and args.lanes > 1 and os.path.exists(plan_path) and "shapes" in json.load(open(plan_path)):
+        # another exporter's file of the same model: its steps carry other names, its products have the same shapes -> the lanes plan's entries by shape
+        plan_text = json.dumps({"shapes": json.load(open(plan_path))["shapes"]})
     if args.chains > 1 and plan_text:  # the committed plan is keyed by the full batch: a sub-batch takes the same per-shape choices
         pj = json.loads(plan_text)
         plan_text = json.dumps({str(args.batch // args.chains): next(iter(pj.values()))})
