@@ -61,8 +61,8 @@ BATCH_PER_GPU = 32
 # Consecutive batches on independent replicas of the model ("lanes", --lanes): measured in session r5e (profiles/r08/lanes.txt) -- int8 1 / 2 / 3 / 4 lanes:
 # 1.502 / 1.052 / 0.971 / 0.950 ms per batch; f32 one chain x 2 lanes 2.494 ms against 2.677 ms for one replica running the batch as 4 sub-batch chains
 INT8_DEFAULT_LANES = 4
-F32_DEFAULT_LANES = 4   # ... of ONE chain each (whole-batch launches: the best per-layer efficiency), unless --chains is given.  Round 6, same box, three alternating
-#                         rounds (profiles/r09/f32_lanes_and_plan_ab.txt): 2 lanes 2.475 / 2.502 / 2.504 ms, 3 lanes 2.462 / 2.461 / 2.453, 4 lanes 2.483
+F32_DEFAULT_LANES = 4   # ... of ONE chain each (whole-batch launches), unless --chains is given.  Round 6, per-layer plans chosen under co-run (f32_lanes.json), same box, two
+#                         alternating rounds (profiles/r10/f32_lanes_sweep_corun_plan.txt): 2 lanes 2.55 / 2.56 ms, 3 lanes 2.42 / 2.43, 4 lanes 2.39 / 2.40, 5 lanes 2.46 / 2.45
 
 
 LINE_LIMIT = 4096   # the driver keeps a bounded tail of stdout: the final line must fit it whole (round 5's 23 KB line came back `parsed: null`)
