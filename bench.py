@@ -92,6 +92,8 @@ def _compact_roofline(r):
     c.setdefault("traffic", None)
     if isinstance(r.get("dominant_kernel"), dict):  # f32: stand-alone figures of the dominant kernel (HIP events per launch) beside the whole-step fraction
         c["dominant_kernel"] = _pick(r["dominant_kernel"], ("achieved", "frac", "avg_launch_us", "launches"))
+        if isinstance(r["dominant_kernel"].get("co_run"), dict):  # ... and of its layer family under the schedule that is timed: the same layer on `streams` streams at once
+            c["dominant_kernel"]["co_run"] = _pick(r["dominant_kernel"]["co_run"], ("layer", "streams", "avg_launch_us", "achieved", "frac"))
     elif "avg_launch_us" in r:
         c["avg_launch_us"] = r["avg_launch_us"]
     if isinstance(r.get("step"), dict):             # int8: the whole timed step against the HBM floor of the graph
@@ -362,6 +364,30 @@ def int8_algorithmic_bytes(net, as_launched=False):
     total += 4.0 * last[0] * last[1] * (last[2] * last[3] + 1)      # GlobalAveragePool
     total += 2048.0 * net.num_classes + 8.0 * last[0] * net.num_classes + 9.0 * last[0] * 2048  # classifier
     return total
+
+
+def dominant_co_run(plan, streams):
+    """The convolution family with the largest share of the FLOPs (stage 2's 3x3 layers) under its committed plan entry, timed the way the lanes plans are chosen
+    (rten_amd/workloads/corun.py): `streams` runner networks sharing one weight arena run the SAME layer at once on their real input activations, a captured graph
+    of 12 launches per stream; microseconds per launch over all streams, and 2 M N K of the layer over that."""
+    import gc
+    from rten_amd.workloads.corun import CoRun
+    cr = CoRun(streams, BATCH_PER_GPU, plan)
+    try:
+        fams = cr.families()
+        key = max(fams, key=lambda k: sum(cr.flops(l["name"]) for _, l in fams[k]))
+        idx, l = fams[key][1] if len(fams[key]) > 1 else fams[key][0]
+        entry = list(plan[l["name"]])
+        us = min(cr.measure(idx, entry) for _ in range(2))
+        fl = cr.flops(l["name"])
+        return {"layer": l["name"], "layers_of_this_family": len(fams[key]), "share_of_conv_flops": round(fl * len(fams[key]) / sum(cr.flops(x["name"]) for x in cr.specs), 4),
+                "plan": entry, "streams": streams, "avg_launch_us": round(us, 2), "achieved": round(fl / us / 1e6, 2), "unit": "TFLOP/s",
+                "frac": round(fl / us / 1e6 / F32_MATRIX_PEAK_TFLOPS, 4),
+                "what": "the same layer on `streams` streams at once (each on its real input activations, a captured graph of 12 launches per stream): time per launch over "
+                        "all streams -- the state a launch of the timed lanes schedule runs in, and how the plan's entries were chosen (tools/tune_corun.py)"}
+    finally:
+        cr.close()
+        gc.collect()
 
 
 def secondary_configs():
@@ -781,6 +807,16 @@ def run_via_executor(args):
                                         "share_of_serialised_pass": round(fam_ms / max(tot_ms, 1e-9), 4),
                                         "variants": {r["kernel"]: {"launches": r["launches"], "ms": round(r["ms"], 4), "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2)} for r in conv}}
             attach_traffic(roof, plan_sha, int8=False)
+            if world == 1 and not DRY and not args.no_shapes and lanes > 1 and chains == 1 and plan_text and "dominant_kernel" in roof:
+                # the lanes plan is chosen per layer UNDER CO-RUN (tools/tune_corun.py): its launch forms are slower when a launch has the device to itself (which is what
+                # the serialised figures above show) and faster where other replicas fill their tile-quantisation gaps.  The per-kernel figure that belongs to the
+                # timed schedule: the dominant layer family, the same layer on `lanes` streams at once, time per launch over all streams.
+                for m_l in models:
+                    m_l.sync()
+                try:
+                    roof["dominant_kernel"]["co_run"] = dominant_co_run(json.loads(plan_text), lanes)
+                except Exception as e:  # noqa: BLE001  (a measurement aid must not cost the line)
+                    roof["dominant_kernel"]["co_run"] = {"error": f"{type(e).__name__}: {e}"[:200]}
             if world == 1 and not DRY and not args.no_shapes:
                 p1 = os.path.join(ROOT, "profiles", "plans", "f32_1chain.json")
                 model.sync()

@@ -31,26 +31,10 @@ def main():
     ap.add_argument("--full", action="store_true", help="every plan of the runner's candidate list (all tile variants, thin-tail, persistent, lean, every split form) instead of the short list")
     args = ap.parse_args()
     from rten_amd import lib as L
-    from rten_amd.workloads import resnet50
-    weights = resnet50.make_weights()
+    from rten_amd.workloads.corun import CoRun
     incumbent = json.load(open(args.plan))
-    ctxs = [L.Context(0) for _ in range(args.lanes)]
-    nets = []
-    for i, ctx in enumerate(ctxs):
-        kw = {} if i == 0 else dict(arena_ptr=nets[0].arena.ptr, arena_keepalive=nets[0].arena)
-        net = resnet50.ResNet50(ctx, args.batch, weights, **kw)
-        if i == 0:
-            net.upload_weights()
-            ctx.sync()
-        net.x.upload(np.random.default_rng(1234 + i).random((args.batch, 3, 224, 224), dtype=np.float32))
-        net.variants = {k: tuple(v) for k, v in incumbent.items() if k != "fc"}
-        nets.append(net)
-    specs = nets[0].specs
-    descs = nets[0].descs
-    fams = {}
-    for idx, l in enumerate(specs):
-        d = descs[l["name"]]
-        fams.setdefault((d.o, d.c, d.kh, d.stride_h, d.h, bool(l["res"])), []).append((idx, l))
+    cr = CoRun(args.lanes, args.batch, incumbent)
+    nets, specs, descs, fams = cr.nets, cr.specs, cr.descs, cr.families()
 
     def candidates(key):
         o, c, k, s, h, res = key
@@ -67,30 +51,7 @@ def main():
         return cands
 
     def measure(idx, l, plan):
-        graphs = []
-        try:
-            for net in nets:
-                net.variants[l["name"]] = tuple(plan)
-                net._conv(l)  # warm: scratch growth outside the capture
-            for c in ctxs:
-                c.sync()
-            for net in nets:
-                net.ctx.graph_begin()
-                for _ in range(args.reps):
-                    net._conv(l)
-                graphs.append((net.ctx, net.ctx.graph_end()))
-            best = 1e30
-            for _ in range(3):
-                t0 = time.perf_counter()
-                for c, g in graphs:
-                    c.graph_launch(g)
-                for c in ctxs:
-                    c.sync()
-                best = min(best, (time.perf_counter() - t0) / (args.reps * len(nets)) * 1e6)
-            return best
-        finally:
-            for c, g in graphs:
-                c.graph_destroy(g)
+        return cr.measure(idx, plan, reps=args.reps)
 
     out_plan = dict(incumbent)
     only = set(args.only.split(",")) if args.only else None
@@ -99,12 +60,9 @@ def main():
         idx, l = members[1] if len(members) > 1 else members[0]  # (a stage's first block reads another producer: take a later member when there is one)
         if only and l["name"] not in only:
             continue
-        for net in nets:  # this layer's real input (the runner reuses activation buffers: stop the pass right before the layer)
-            net.forward(upto=idx)
-        for c in ctxs:
-            c.sync()
+        cr.position(idx)  # this layer's real input (the runner reuses activation buffers: the pass stops right before the layer)
         d = descs[l["name"]]
-        flops = 2.0 * d.o * (d.c // d.groups) * d.kh * d.kw * d.n * d.out_h * d.out_w
+        flops = cr.flops(l["name"])
         inc = list(incumbent[l["name"]])
         try:
             t_inc = min(measure(idx, l, inc), measure(idx, l, inc))
