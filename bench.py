@@ -366,13 +366,13 @@ def int8_algorithmic_bytes(net, as_launched=False):
     return total
 
 
-def dominant_co_run(plan, streams):
+def dominant_co_run(plan, streams, ctxs=None):
     """The convolution family with the largest share of the FLOPs (stage 2's 3x3 layers) under its committed plan entry, timed the way the lanes plans are chosen
     (rten_amd/workloads/corun.py): `streams` runner networks sharing one weight arena run the SAME layer at once on their real input activations, a captured graph
     of 12 launches per stream; microseconds per launch over all streams, and 2 M N K of the layer over that."""
     import gc
     from rten_amd.workloads.corun import CoRun
-    cr = CoRun(streams, BATCH_PER_GPU, plan)
+    cr = CoRun(streams, BATCH_PER_GPU, plan, ctxs=ctxs)  # (on the lanes' own contexts: their streams already hold a hardware queue each)
     try:
         fams = cr.families()
         key = max(fams, key=lambda k: sum(cr.flops(l["name"]) for _, l in fams[k]))
@@ -814,7 +814,7 @@ def run_via_executor(args):
                 for m_l in models:
                     m_l.sync()
                 try:
-                    roof["dominant_kernel"]["co_run"] = dominant_co_run(json.loads(plan_text), lanes)
+                    roof["dominant_kernel"]["co_run"] = dominant_co_run(json.loads(plan_text), lanes, lane_ctx)
                 except Exception as e:  # noqa: BLE001  (a measurement aid must not cost the line)
                     roof["dominant_kernel"]["co_run"] = {"error": f"{type(e).__name__}: {e}"[:200]}
             if world == 1 and not DRY and not args.no_shapes:

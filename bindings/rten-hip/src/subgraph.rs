@@ -7,7 +7,7 @@
 //! rten_amd/csrc/graph_abi.cpp): ONNX bytes in, constants uploaded and prepacked once, the reference's fusions applied, a committed launch plan
 //! (profiles/plans/*.json) by step name, the batch run as `chains` independent dim-0 slices on their own streams, each a hipGraph.  `bench.py`
 //! (its default path since round 5) measures exactly this path (ResNet-50 f32 batch 32 as 4 chains on one replica: 2.68 ms, the hand-planned runner the
-//! same within 0.01 ms on the same box, same logits; the default line -- one chain per replica, two replicas -- 2.51-2.56 ms: DESIGN.md section 2).
+//! same within 0.01 ms on the same box, same logits; the default line -- one chain per replica, four replicas, plans chosen under co-run -- 2.39-2.44 ms: DESIGN.md section 2).
 //! `install.rs` puts one of these in place of a loaded model's whole graph (`rten_hip::load_resident`).
 //!
 //! NOT COMPILED in the build image -- see lib.rs.  tests/test_abi.py checks that every `sys::` name used here exists in the generated -sys crate
@@ -103,7 +103,7 @@ impl HipSubgraph {
     /// Another REPLICA of this subgraph on `hip` (a context -- a stream -- of its own on the same device): the same graph and plan, its own buffers and
     /// hipGraphs, THIS subgraph's constants and prepacked weights (`rten_hip_model_clone`).  Independent batches handed to different replicas overlap
     /// on the device: the batch-level analogue of sub-batch chains, and the only one a batch-coupled graph (the dynamically quantized ResNet-50) can
-    /// use.  Measured (`bench.py --lanes`): int8 ResNet-50 1.50 -> 0.90 ms per batch of 32 at 4 replicas, f32 2.74 -> 2.58 ms at 2.
+    /// use.  Measured (`bench.py --lanes`): int8 ResNet-50 1.50 -> 0.90 ms per batch of 32 at 4 replicas, f32 2.70 -> 2.40 ms at 4 (with the lanes plan), BERT-base 6.67 -> 5.85.
     pub fn replica(self: &Arc<Self>, hip: Arc<HipContext>) -> Result<HipSubgraph, OpError> {
         let origin = self.origin.clone().unwrap_or_else(|| self.clone());
         let mut model: *mut sys::rten_hip_model = ptr::null_mut();

@@ -16,8 +16,11 @@ from . import resnet50
 
 
 class CoRun:
-    def __init__(self, streams, batch=32, plan=None, weights=None, device=0):
-        self.ctxs = [L.Context(device) for _ in range(streams)]
+    def __init__(self, streams, batch=32, plan=None, weights=None, device=0, ctxs=None):
+        # `ctxs`: borrowed contexts (bench.py hands over its lanes' own: every stream of a process should keep a hardware queue of its own -- two streams on one
+        # queue cost a co-run ~20 %, the placement effect of DESIGN.md / docs/KERNELS.md "streams map onto hardware queues")
+        self._own = ctxs is None
+        self.ctxs = [L.Context(device) for _ in range(streams)] if ctxs is None else list(ctxs)[:streams]
         self.nets = []
         weights = weights if weights is not None else resnet50.make_weights()
         for i, ctx in enumerate(self.ctxs):
@@ -85,6 +88,7 @@ class CoRun:
 
     def close(self):
         self.nets = []
-        for c in self.ctxs:
-            c.close()
+        if self._own:
+            for c in self.ctxs:
+                c.close()
         self.ctxs = []

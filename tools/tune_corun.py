@@ -17,6 +17,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # every stream a hardware queue of its own, as in bench.py (must be set before the HIP runtime starts)
 
 
 def main():
@@ -28,6 +29,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "plans", "experiments", "f32_corun3.json"))
     ap.add_argument("--only", default=None, help="comma-separated layer names (representatives) to restrict the sweep to")
     ap.add_argument("--margin", type=float, default=0.01)
+    ap.add_argument("--exclude", default="", help="comma-separated kernel variants to leave out of the candidates (e.g. 28,29,31: the barrier-free 32x32-wave forms and the small-M alias, which measure like variant 3 on every dense layer)")
     ap.add_argument("--full", action="store_true", help="every plan of the runner's candidate list (all tile variants, thin-tail, persistent, lean, every split form) instead of the short list")
     args = ap.parse_args()
     from rten_amd import lib as L
@@ -70,8 +72,9 @@ def main():
             print(f"{l['name']}: incumbent failed: {e}", flush=True)
             continue
         rows = []
+        skip = {int(v) for v in args.exclude.split(",") if v}
         for cand in ([list(p) for p in nets[0].candidate_plans(l)] if args.full else candidates(key)):
-            if cand == inc:
+            if cand == inc or cand[0] in skip:
                 continue
             try:
                 rows.append((measure(idx, l, cand), cand))
