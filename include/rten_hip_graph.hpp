@@ -620,7 +620,12 @@ class Graph {
     // Plan entries keyed by the PRODUCT'S SHAPE -- "gemm:MxKxN", M = the rows of A over all its leading dims -- for MatMul-family steps no name entry covers (round
     // 6): a plan chosen on one writer's graph (profiles/plans/bert_base_b32_s128_lanes.json, its "shapes" table) then applies to another exporter's file of
     // the same model, whose steps carry other names.  Shapes are run-time facts here, so the lookup happens in run(), once per step (the entry stays).
-    void set_shape_plans(std::map<std::string, GemmPlan> t) { shape_plans_ = std::move(t); shape_planned_ = 0; }
+    void set_shape_plans(std::map<std::string, GemmPlan> t) {
+        for (size_t i : shape_planned_steps_) *steps_[i].gemm_plan = GemmPlan{}; // (a re-plan: entries a previous table left on steps go with that table)
+        shape_planned_steps_.clear();
+        shape_plans_ = std::move(t);
+        shape_planned_ = 0;
+    }
     size_t num_shape_planned() const { return shape_planned_; }
     std::map<std::string, GemmPlan> plans() const { // what autotune() / apply_plan() left on the convolution steps
         std::map<std::string, GemmPlan> t;
@@ -691,7 +696,7 @@ class Graph {
                 const int64_t k = a.size(a.ndim() - 1), mrows = a.len() / std::max<int64_t>(k, 1);
                 const int64_t ncols = b.size(0) == k ? b.size(1) : (b.size(1) == k ? b.size(0) : -1); // [K, N], or [N, K] (Gemm with transB)
                 auto it = ncols < 0 ? shape_plans_.end() : shape_plans_.find("gemm:" + std::to_string(mrows) + "x" + std::to_string(k) + "x" + std::to_string(ncols));
-                if (it != shape_plans_.end()) { *st.gemm_plan = it->second; shape_planned_++; }
+                if (it != shape_plans_.end()) { *st.gemm_plan = it->second; shape_planned_++; shape_planned_steps_.push_back((size_t)(&st - steps_.data())); }
             }
             if (tune_reps_ > 0 && (st.conv || st.gemm_plan)) tune_step(st, in);
             try {
@@ -794,6 +799,7 @@ class Graph {
     size_t tuned_ = 0;
     std::map<std::string, GemmPlan> shape_plans_;
     size_t shape_planned_ = 0;
+    std::vector<size_t> shape_planned_steps_;
     size_t stats_blocks_ = 0, staged_dql_ = 0, qout_edges_ = 0, dql_loader_steps_ = 0;
     std::unique_ptr<Tensor> stats_arena_, sync_arena_, arena_;
 

@@ -371,11 +371,12 @@ RTEN_EXPORT int32_t rten_hip_model_prepare(rten_hip_model *g, int32_t tune) {
                 for (auto &kv : g->plan_by_batch) if (!kv.first.empty() && kv.first.find_first_not_of("0123456789") == std::string::npos) keyed = true;
                 if (keyed && it == g->plan_by_batch.end() && g->plan_flat.empty())
                     return fail(g, RTEN_HIP_ERR_INVALID_VALUE, "prepare: the plan file is keyed by sub-batch size and has no entry for a chain of " + std::to_string(b) + " rows");
+                // "shapes": entries by product shape for the MatMul-family steps no name matches (another exporter's file of the same model); set first -- it also
+                // takes back what a previous table left on steps -- then the entries by name
+                auto sh = g->plan_by_batch.find("shapes");
+                gr.set_shape_plans(sh != g->plan_by_batch.end() ? plan_table(sh->second) : std::map<std::string, GemmPlan>());
                 const size_t n = gr.apply_plan(plan_table(it != g->plan_by_batch.end() ? it->second : g->plan_flat));
                 if (c == 0) g->planned_steps = n;
-                // "shapes": entries by product shape for the MatMul-family steps no name matched (another exporter's file of the same model)
-                auto sh = g->plan_by_batch.find("shapes");
-                if (sh != g->plan_by_batch.end()) gr.set_shape_plans(plan_table(sh->second));
             } else if (tune) {
                 if (!tuned.count(b)) { const size_t n = gr.autotune(feeds); tuned[b] = gr.plans(); if (c == 0) g->tuned_steps = n; }
                 else gr.apply_plan(tuned[b]);
