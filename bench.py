@@ -13,7 +13,7 @@ what a Rust host binds); `--via-runner` times round 4's hand
 A step = one forward pass of ResNet-50 (53 convs + maxpool + global-avg-pool + fc) over one batch of 32 synthetic 224x224 images that is already
 resident in HBM: one hipGraph replay per chain.  Steps are independent batches, so consecutive steps go round robin to `--lanes` REPLICAS of the model
 (rten_hip_model_clone: own stream, buffers and hipGraphs, one shared weight arena) and overlap on the device -- f32: one whole-batch chain per replica,
-3 lanes; int8 (whose quantizers span the batch: no sub-batch chains): 4 lanes.  `ms_per_step` / `value` are therefore THROUGHPUT figures over the K timed
+4 lanes under per-layer plans chosen under co-run (profiles/plans/f32_lanes.json, tools/tune_corun.py); int8 (whose quantizers span the batch: no sub-batch chains): 4 lanes.  `ms_per_step` / `value` are therefore THROUGHPUT figures over the K timed
 steps (both synchronisation points cover every stream of every lane); `ms_per_step_joined_every_step` and `p50_latency_ms` are ONE batch on ONE replica.
 `--chains C` alone gives round 4's schedule (one replica, C sub-batch chains).  One process per GPU; batches are independent, so the path shards with no
 data-path collective (weak scaling: 32 images per GPU); the only collective is the one-time RCCL broadcast of the model's weight arena from rank 0.
@@ -21,7 +21,8 @@ data-path collective (weak scaling: 32 images per GPU); the only collective is t
 Rank 0 prints ONE COMPACT JSON line (at most 4096 bytes: `compact_line`; the driver keeps a bounded tail of stdout, and round 5's 23 KB line came back
 unparsed) as the LAST thing on stdout: the contract fields, `roofline` -- f32: achieved / frac = the conv FLOPs of one batch over the TIMED step (every kernel
 and gap included) with the dominant kernel's stand-alone figures (HIP events per launch, an instrumented eager pass outside the timed region) as
-`dominant_kernel` and its HBM traffic from the committed PMC pass when that pass ran the same launch plan; int8: the dominant kernel against the HBM peak plus
+`dominant_kernel` -- plus, under lanes, `dominant_kernel.co_run`: the dominant layer family on `lanes` streams at once, the state a launch of the timed schedule
+runs in and the way the lanes plan's entries were chosen (rten_amd/workloads/corun.py) -- and its HBM traffic from the committed PMC pass when that pass ran the same launch plan; int8: the dominant kernel against the HBM peak plus
 the whole step against the graph's HBM floor (`step`) --, `cpu_baseline` (the CPU oracle -- a port of the reference algorithm -- timed on this host's cores on a
 bounded sample; N=1 only) and, at N=1, a few numbers per `secondary` config: the f32 batch as 4 chains on one replica (the latency-optimal schedule:
 `p50_latency_ms_4chains`), the int8 ResNet-50 (configs[2]), BERT-base (configs[3]) and the batch-1 latencies (configs[0]), each run in a child process after the
