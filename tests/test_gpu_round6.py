@@ -280,3 +280,37 @@ def test_sdpa_reads_one_shared_mask_row_out_of_an_expanded_mask(ctx, shape):
     md = DeviceTensor.from_numpy(ctx, full)
     rc = ctx.lib.rten_hip_sdpa_f32(ctx.h, C.byref(d), qd.vp, kd.vp, vd.vp, md.vp, out.vp)
     assert rc == (L.ERR_UNSUPPORTED if S != 2 else 0), rc
+
+
+def test_co_run_measurement_on_borrowed_contexts():
+    """rten_amd/workloads/corun.py (what tools/tune_corun.py sweeps with and what bench.py reports as `roofline.dominant_kernel.co_run`): the same layer on two
+    streams at once, on contexts the caller keeps -- a positive time per launch for two plans of one layer, the networks' activations in place (the layer's output
+    equals a plain launch of the same layer), and the borrowed contexts still usable afterwards."""
+    from rten_amd.workloads.corun import CoRun
+    ctxs = [L.Context(0), L.Context(0)]
+    try:
+        cr = CoRun(2, batch=2, plan={}, ctxs=ctxs)
+        fams = cr.families()
+        key = max(fams, key=lambda k: sum(cr.flops(l["name"]) for _, l in fams[k]))
+        idx, l = fams[key][1]
+        t_a = cr.measure(idx, [3, 0, 1, 0], reps=4, rounds=2)
+        t_b = cr.measure(idx, [27, 2, 3, 0], reps=4, rounds=2)
+        assert 1.0 < t_a < 1e5 and 1.0 < t_b < 1e5, (t_a, t_b)
+        outs = []
+        for net in cr.nets:  # both plans are bit-identical launch forms of the same convolution on the same inputs
+            net.variants[l["name"]] = (3, 0, 1, 0)
+            net._conv(l)
+            net.ctx.sync()
+            a = net._act(l["dst"]).numpy().copy()
+            net.variants[l["name"]] = (27, 2, 3, 0)
+            net._conv(l)
+            net.ctx.sync()
+            _bits(net._act(l["dst"]).numpy(), a)
+            outs.append(a)
+        assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 0
+        cr.close()
+        x = dev(ctxs[0], np.arange(16, dtype=np.float32))  # the borrowed contexts live on
+        assert np.array_equal(x.numpy(), np.arange(16, dtype=np.float32))
+    finally:
+        for c in ctxs:
+            c.close()
