@@ -122,9 +122,11 @@ __device__ __forceinline__ constexpr int acc_row(int r) { return (r & 3) + 8 * (
 
 // rows of a strided u8/i8 matrix -> chunk-major signed operand [Kp/16][rows][16 B] (+ row sums).  With khw > 1 the
 // source k index is (c, tap) (OIHW weights) and the destination k index is (tap, c) with channels padded to Cp.
+// `pk_nch` > 0: the few-channel PACKED destination order (conv_geom, round 6): chunk (ky, j) holds kernel columns j * pk_cpc .. + pk_cpc - 1 of row ky, byte
+// col * C + channel; columns past the kernel's width and the bytes past pk_cpc * C are zero weights.
 __global__ __launch_bounds__(256) void i8_pack_rows_kernel(const uint8_t *__restrict__ src, long long row_stride, long long k_stride, int K,
                                                           int C, int khw, int Cp, int Kp, int rows, unsigned flip, uint8_t *__restrict__ dst,
-                                                          int *__restrict__ sums) {
+                                                          int *__restrict__ sums, int pk_nch = 0, int pk_cpc = 0, int pk_kw = 0) {
     const int r = blockIdx.x;
     const uint8_t *s = src + (long long)r * row_stride;
     int sum = 0;
@@ -133,8 +135,14 @@ __global__ __launch_bounds__(256) void i8_pack_rows_kernel(const uint8_t *__rest
 #pragma unroll
         for (int b = 0; b < 4; b++) {
             const int kd = kq + b;
-            const int tap = kd / Cp, c = kd - tap * Cp;
-            const bool ok = tap < khw && c < C;
+            int tap = kd / Cp, c = kd - tap * Cp;
+            bool ok = tap < khw && c < C;
+            if (pk_nch > 0) { // (Cp == 16 here; `khw` = kernel rows x kernel columns of the REAL kernel)
+                const int vt = kd >> 4, slot = kd & 15, ky = vt / pk_nch, j = vt - ky * pk_nch, col = slot / C, kx = j * pk_cpc + col;
+                c = slot - col * C;
+                ok = ky * pk_kw < khw && col < pk_cpc && kx < pk_kw;
+                tap = ky * pk_kw + kx;
+            }
             const int ks = c * khw + tap;
             const unsigned v = ok ? ((unsigned)s[(long long)(ks < K ? ks : 0) * k_stride] ^ flip) & 0xffu : 0u;
             w |= v << (8 * b);
@@ -221,6 +229,53 @@ __device__ __forceinline__ void stage_blocked_tile(const T *__restrict__ x, uint
     }
 }
 
+// Few-channel PACKED staging (round 6; conv_geom): a convolution with C <= 4 input channels (the 7x7 / stride 2 stem of ResNet-50: C = 3) staged as a 16-channel
+// block moves 16 bytes per pixel for 3 of data and multiplies 13 zeros per tap (K = 49 x 16 = 784 for 147 real terms).  Here a 16-byte chunk holds `cpc` = 16 / C
+// horizontally adjacent kernel COLUMNS x C channels of one kernel row, and every OUTPUT column gets its own `nch` = ceil(KW / cpc) chunks per padded input row
+// (columns ox * stride - pad + j * cpc + col): image [N][Hp][OW * nch][16 B], which the unchanged kernel walks as a convolution with 16 channels, KW = nch and
+// stride nch over "virtual columns" -- K = KH x nch x 16 (224 for the stem).  A thread writes one chunk: all its (clamped) loads first, then `prep()`.
+template <typename T, int C, int NCH, typename Prep>
+__device__ __forceinline__ void stage_packed_chunks(const T *__restrict__ x, uint8_t *__restrict__ xp, int H, int W, int Hp, int OW, int KW, int sx, int dx, int pt, int pl,
+                                                    Prep prep) {
+    // a thread owns one OUTPUT column of one padded input row: the NCH chunks of that column (32 consecutive bytes for the stem); grid = (OW / 128, Hp / 2, N).  The
+    // channel count and the chunk count are compile-time, so the slot -> (kernel column, channel) map costs nothing; every load is issued (clamped) before prep().
+    constexpr int CPC = 16 / C;
+    // (256 threads = two padded rows x 128 output columns: prep()'s statistics fold is written for 256-thread workgroups)
+    const int ox = blockIdx.x * 128 + (threadIdx.x & 127), ypr = blockIdx.y * 2 + (threadIdx.x >> 7), n = blockIdx.z;
+    const int oxc = ox < OW ? ox : OW - 1, yp = ypr < Hp ? ypr : Hp - 1;
+    const int y = yp - pt, x0 = oxc * sx - pl; // kernel column kx reads input column ox * stride - pad + kx * dilation
+    const bool row_in = (unsigned)y < (unsigned)H;
+    const long long plane = (long long)H * W;
+    const T *row = x + (long long)n * C * plane + (long long)(row_in ? y : 0) * W;
+    T raw[NCH * CPC][C];
+#pragma unroll
+    for (int kx = 0; kx < NCH * CPC; kx++) {
+        const int xx = x0 + kx * dx;
+        const bool in = kx < KW && row_in && (unsigned)xx < (unsigned)W;
+#pragma unroll
+        for (int ch = 0; ch < C; ch++) raw[kx][ch] = row[in ? ch * plane + xx : 0];
+    }
+    const auto map = prep();
+#pragma unroll
+    for (int j = 0; j < NCH; j++) {
+        unsigned w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int col = 0; col < CPC; col++) {
+            const int kx = j * CPC + col, xx = x0 + kx * dx;
+            const bool real = kx < KW;                                        // a kernel column (else: a zero weight multiplies the byte, and the byte is 0)
+            const bool in = real && row_in && (unsigned)xx < (unsigned)W;
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) {
+                constexpr int dummy = 0; (void)dummy;
+                const int slot = col * C + ch;
+                const unsigned v = in ? map.byte(raw[kx][ch]) & 0xffu : (real ? map.fill : 0u);
+                w[slot >> 2] |= v << (8 * (slot & 3));
+            }
+        }
+        if (ox < OW && ypr < Hp) *reinterpret_cast<uint4 *>(xp + ((((long long)n * Hp + yp) * OW + ox) * NCH + j) * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
 // Small feature maps (fewer than 128 pixels per plane, e.g. 7x7): 64 consecutive PADDED positions x 64 channels per
 // workgroup, one pixel per lane, so the lanes stay busy where the 256-pixel tile above would idle.
 template <typename T, typename Prep>
@@ -303,6 +358,18 @@ struct ScaleProducts {
     float *product[kMaxProducts];
 };
 
+template <int C, int NCH>
+__global__ __launch_bounds__(256) void i8_pad_packed_kernel(const uint8_t *__restrict__ x, uint8_t *__restrict__ xp, int H, int W, int Hp, int OW, int KW, int sx, int dx, int pt,
+                                                           int pl, unsigned flip, const uint8_t *__restrict__ x_zp, int x_signed, int pad_mode) {
+    auto prep = [&]() {
+        int pad_s = 0;
+        if (pad_mode == RTEN_HIP_PAD_ZERO_POINT) pad_s = zp_signed(x_zp, 0, x_signed);
+        else if (pad_mode == RTEN_HIP_PAD_RAW0_U8) pad_s = -128;
+        return FlipMap{(unsigned)pad_s & 0xffu, flip};
+    };
+    stage_packed_chunks<uint8_t, C, NCH>(x, xp, H, W, Hp, OW, KW, sx, dx, pt, pl, prep);
+}
+
 template <int KIND>
 __global__ __launch_bounds__(256) void i8_quantize_stage_kernel(const float *__restrict__ x, const float *__restrict__ ws, int nparts, uint8_t *__restrict__ xp,
                                                                int C, int H, int W, int Hp, int Wp, int Cp, int pt, int pl, int pad_mode,
@@ -329,6 +396,46 @@ __global__ __launch_bounds__(256) void i8_quantize_stage_kernel(const float *__r
     if constexpr (KIND == 0) stage_blocked_tile_small(x, xp, C, H, W, Hp, Wp, Cp, pt, pl, prep);
     else stage_blocked_tile<float, KIND == 2>(x, xp, C, H, W, Hp, Wp, Cp, pt, pl, prep);
 }
+
+// ... and DynamicQuantizeLinear's quantize sweep into the few-channel packed image (same prep as i8_quantize_stage_kernel: same codes)
+template <int C, int NCH>
+__global__ __launch_bounds__(256) void i8_quantize_packed_kernel(const float *__restrict__ x, const float *__restrict__ ws, int nparts, uint8_t *__restrict__ xp, int H, int W, int Hp,
+                                                                int OW, int KW, int sx, int dx, int pt, int pl, int pad_mode, float *scale_out, uint8_t *zp_out,
+                                                                const ScaleProducts sp) {
+    auto prep = [&]() {
+        float x_min, x_max;
+        if (nparts < 0) dql::block_minmax_slots(reinterpret_cast<const unsigned *>(ws), x_min, x_max);
+        else dql::block_minmax(ws, nparts, x_min, x_max);
+        const dql::QParams q = dql::dql_params(x_min, x_max);
+        if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+            *scale_out = q.scale;
+            *zp_out = (uint8_t)q.zp;
+#pragma unroll
+            for (int i = 0; i < kMaxProducts; i++)
+                if (i < sp.count) *sp.product[i] = q.scale * sp.mul_by[i][0];
+        }
+        int pad_s = 0;
+        if (pad_mode == RTEN_HIP_PAD_ZERO_POINT) pad_s = q.zp - 128;
+        else if (pad_mode == RTEN_HIP_PAD_RAW0_U8) pad_s = -128;
+        return QuantMap{(unsigned)pad_s & 0xffu, q.inv_scale, q.zp};
+    };
+    stage_packed_chunks<float, C, NCH>(x, xp, H, W, Hp, OW, KW, sx, dx, pt, pl, prep);
+}
+
+// (channel count x chunks per output column: the instantiations conv_geom admits)
+#define RTEN_PACKED_DISPATCH(KERNEL, c, nch, grid, ...)                                                                                  \
+    do {                                                                                                                                 \
+        switch ((c) * 4 + (nch)) {                                                                                                       \
+        case 1 * 4 + 1: hipLaunchKernelGGL((KERNEL<1, 1>), grid, dim3(256), 0, ctx->stream, __VA_ARGS__); break;                         \
+        case 1 * 4 + 2: hipLaunchKernelGGL((KERNEL<1, 2>), grid, dim3(256), 0, ctx->stream, __VA_ARGS__); break;                         \
+        case 2 * 4 + 1: hipLaunchKernelGGL((KERNEL<2, 1>), grid, dim3(256), 0, ctx->stream, __VA_ARGS__); break;                         \
+        case 2 * 4 + 2: hipLaunchKernelGGL((KERNEL<2, 2>), grid, dim3(256), 0, ctx->stream, __VA_ARGS__); break;                         \
+        case 3 * 4 + 1: hipLaunchKernelGGL((KERNEL<3, 1>), grid, dim3(256), 0, ctx->stream, __VA_ARGS__); break;                         \
+        case 3 * 4 + 2: hipLaunchKernelGGL((KERNEL<3, 2>), grid, dim3(256), 0, ctx->stream, __VA_ARGS__); break;                         \
+        case 4 * 4 + 1: hipLaunchKernelGGL((KERNEL<4, 1>), grid, dim3(256), 0, ctx->stream, __VA_ARGS__); break;                         \
+        default: hipLaunchKernelGGL((KERNEL<4, 2>), grid, dim3(256), 0, ctx->stream, __VA_ARGS__); break;                                \
+        }                                                                                                                                \
+    } while (0)
 
 // ---------------------------------------------------------------------------------------------------------
 // main kernel
@@ -1366,7 +1473,12 @@ int32_t rten_i8_fast_gemm(rten_hip_ctx *ctx, const rten_hip_gemm_int8_desc *d, c
 }
 
 namespace {
-struct ConvGeom { int Cp, Hp, Wp, taps, Kreal, Kp, P; size_t img; bool ok; };
+// `packed` (round 6): the few-channel form of stage_packed_chunks -- C <= 4 input channels and a kernel at least two columns wide.  The choice depends on C, KW
+// and the group count ONLY: weights are prepacked from a descriptor that knows nothing else (ConvInteger::prepack), and every zero-point form stays exact -- the
+// unused bytes of a chunk are 0 in the signed domain on BOTH operands, like the padded channels of the 16-channel-block form, so they add nothing to the product,
+// the row sums or the column sums.  Cp / Wp / taps / Kp / img then describe the VIRTUAL convolution the kernel walks (16 channels, KW = nch, stride nch over
+// OW * nch virtual columns); sx / kw / dx say so to the launch.
+struct ConvGeom { int Cp, Hp, Wp, taps, Kreal, Kp, P; size_t img; bool ok; bool packed; int nch, cpc, sx, kw, dx; };
 ConvGeom conv_geom(const rten_hip_conv2d_int8_desc *di) {
     const rten_hip_conv2d_desc *d = &di->conv;
     ConvGeom g = {};
@@ -1375,12 +1487,25 @@ ConvGeom conv_geom(const rten_hip_conv2d_int8_desc *di) {
     g.Wp = d->w + d->pads[1] + d->pads[3];
     g.taps = d->kh * d->kw;
     g.Kreal = d->c * g.taps;
-    g.Kp = (g.taps * g.Cp + KT - 1) / KT * KT;
     g.P = d->out_h * d->out_w;
+    g.sx = d->stride_w; g.kw = d->kw; g.dx = d->dil_w;
+    static const bool no_pack = getenv("RTEN_I8_NO_PACK") != nullptr; // (A/B switch: the 16-channel-block form for every geometry)
+    if (!no_pack && d->groups == 1 && d->c >= 1 && d->c <= 4 && d->kw >= 2 && d->out_w > 0) {
+        g.cpc = 16 / d->c;
+        g.nch = (d->kw + g.cpc - 1) / g.cpc;
+        if (g.nch < d->kw && g.nch <= 2) { // fewer chunks per kernel row than taps: the smaller product (one or two chunks per output column are instantiated)
+            g.packed = true;
+            g.Cp = 16;
+            g.Wp = d->out_w * g.nch;
+            g.taps = d->kh * g.nch;
+            g.sx = g.nch; g.kw = g.nch; g.dx = 1;
+        }
+    }
+    g.Kp = (g.taps * g.Cp + KT - 1) / KT * KT;
     g.img = (size_t)d->n * g.Hp * g.Wp * g.Cp;
     g.ok = d->groups == 1 && d->c > 0 && d->o > 0 && g.Kp <= (1 << 18) && // (the kernel's chunk -> offset table lives in LDS)
            // the chunk walk addresses taps on the padded image: the window must fit (true for valid conv geometry)
-           (d->out_h - 1) * d->stride_h + (d->kh - 1) * d->dil_h < g.Hp && (d->out_w - 1) * d->stride_w + (d->kw - 1) * d->dil_w < g.Wp &&
+           (d->out_h - 1) * d->stride_h + (d->kh - 1) * d->dil_h < g.Hp && (d->out_w - 1) * g.sx + (g.kw - 1) * g.dx < g.Wp &&
            g.img < (1ull << 31) && (size_t)d->o * g.Kp < (1ull << 31) && (long long)d->n * d->o * g.P < (1ll << 29);
     return g;
 }
@@ -1395,6 +1520,12 @@ ScaleProducts one_product(const float *mul_by, float *product) {
 
 void launch_quantize_stage(rten_hip_ctx *ctx, const rten_hip_conv2d_desc *d, const ConvGeom &g, const float *x, const float *ws, int nparts, void *staged,
                            int pad_mode, float *scale, uint8_t *zero_point, const ScaleProducts &sp) {
+    if (g.packed) {
+        const dim3 pgrid((unsigned)((d->out_w + 127) / 128), (unsigned)((g.Hp + 1) / 2), (unsigned)d->n);
+        RTEN_PACKED_DISPATCH(i8_quantize_packed_kernel, d->c, g.nch, pgrid, x, ws, nparts, (uint8_t *)staged, d->h, d->w, g.Hp, d->out_w, d->kw, d->stride_w, d->dil_w, d->pads[0],
+                             d->pads[1], pad_mode, scale, zero_point, sp);
+        return;
+    }
     const dim3 grid((unsigned)((d->h * d->w + 255) / 256), (unsigned)d->n, (unsigned)(g.Cp / 16));
     const dim3 grid_small((unsigned)((g.Hp * g.Wp + 63) / 64), (unsigned)d->n, (unsigned)((g.Cp + 63) / 64));
     const bool vec = (d->h * d->w) % 4 == 0 && ((uintptr_t)x & 15) == 0;
@@ -1418,8 +1549,9 @@ RTEN_EXPORT int32_t rten_hip_conv2d_int8_prepack(rten_hip_ctx *ctx, const rten_h
     const ConvGeom g = conv_geom(di);
     if (!g.ok) return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "conv_int8 prepack: geometry not covered by the staged kernel (packed_bytes == 0)");
     const rten_hip_conv2d_desc *d = &di->conv;
-    hipLaunchKernelGGL(i8_pack_rows_kernel, dim3((unsigned)d->o), dim3(256), 0, ctx->stream, (const uint8_t *)w, (long long)g.Kreal, 1ll, g.Kreal, d->c, g.taps,
-                       g.Cp, g.Kp, d->o, di->w_signed ? 0u : 0x80u, (uint8_t *)packed, (int *)((char *)packed + up256((size_t)d->o * g.Kp)));
+    hipLaunchKernelGGL(i8_pack_rows_kernel, dim3((unsigned)d->o), dim3(256), 0, ctx->stream, (const uint8_t *)w, (long long)g.Kreal, 1ll, g.Kreal, d->c, d->kh * d->kw,
+                       g.Cp, g.Kp, d->o, di->w_signed ? 0u : 0x80u, (uint8_t *)packed, (int *)((char *)packed + up256((size_t)d->o * g.Kp)), g.packed ? g.nch : 0, g.cpc,
+                       d->kw);
     RTEN_LAUNCH_CHECK(ctx, "i8_pack_rows_kernel launch");
     return RTEN_HIP_OK;
 }
@@ -1555,9 +1687,13 @@ int32_t i8_fast_conv_impl(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di
         Ap = (const uint8_t *)(sc + offA);
         rsum = (const int *)(sc + offA + up256((size_t)d->o * cg.Kp));
         hipLaunchKernelGGL(i8_pack_rows_kernel, dim3((unsigned)d->o), dim3(256), 0, ctx->stream, (const uint8_t *)w, (long long)cg.Kreal, 1ll, cg.Kreal, d->c,
-                           cg.taps, cg.Cp, cg.Kp, d->o, di->w_signed ? 0u : 0x80u, (uint8_t *)Ap, (int *)rsum);
+                           d->kh * d->kw, cg.Cp, cg.Kp, d->o, di->w_signed ? 0u : 0x80u, (uint8_t *)Ap, (int *)rsum, cg.packed ? cg.nch : 0, cg.cpc, d->kw);
     }
-    if (!di->x_staged)
+    if (!di->x_staged && cg.packed) {
+        const dim3 pgrid((unsigned)((d->out_w + 127) / 128), (unsigned)((cg.Hp + 1) / 2), (unsigned)d->n);
+        RTEN_PACKED_DISPATCH(i8_pad_packed_kernel, d->c, cg.nch, pgrid, (const uint8_t *)x, (uint8_t *)(sc + offB), d->h, d->w, cg.Hp, d->out_w, d->kw, d->stride_w, d->dil_w,
+                             d->pads[0], d->pads[1], di->x_signed ? 0u : 0x80u, (const uint8_t *)x_zp, di->x_signed, rten_effective_pad_mode(di));
+    } else if (!di->x_staged)
     {
         const dim3 grid((unsigned)((d->h * d->w + 255) / 256), (unsigned)d->n, (unsigned)(cg.Cp / 16));
         const dim3 grid_small((unsigned)((cg.Hp * cg.Wp + 63) / 64), (unsigned)d->n, (unsigned)((cg.Cp + 63) / 64));
@@ -1588,8 +1724,8 @@ int32_t i8_fast_conv_impl(rten_hip_ctx *ctx, const rten_hip_conv2d_int8_desc *di
     g.stats = scale ? (unsigned *)stats : nullptr;
     g.need_csum = (di->w_zp_len != 0 || !di->w_signed) ? 1 : 0; // weight zero point may be non-zero in the signed domain
     g.debug_flags = (ctx->debug & 0x200000) ? 1 : 0;
-    g.conv = 1; g.OW = d->out_w; g.sy = d->stride_h; g.sx = d->stride_w; g.Hp = cg.Hp; g.Wp = cg.Wp; g.Cp = cg.Cp;
-    g.KH = d->kh; g.KW = d->kw; g.dy = d->dil_h; g.dx = d->dil_w;
+    g.conv = 1; g.OW = d->out_w; g.sy = d->stride_h; g.sx = cg.sx; g.Hp = cg.Hp; g.Wp = cg.Wp; g.Cp = cg.Cp;
+    g.KH = d->kh; g.KW = cg.kw; g.dy = d->dil_h; g.dx = cg.dx; // (cg.sx / kw / dx: the virtual geometry of a few-channel packed image, else the convolution's own)
     if (slab_bytes) { g.ks = kKsMax; g.slab = (int *)(sc + offS); g.ks_counters = ctx->split_counters; }
     double out_bytes = 4.0 * d->o * g.N;
     if (qo && !qo->sync) {
@@ -1651,7 +1787,7 @@ RTEN_EXPORT int32_t rten_hip_conv2d_int8_qout(rten_hip_ctx *ctx, const rten_hip_
     if (nd->n != d->n || nd->c != d->o || nd->h != d->out_h || nd->w != d->out_w)
         return rten_set_error(ctx, RTEN_HIP_ERR_INCOMPATIBLE_SHAPES, "conv2d_int8_qout: the consumer's input is not this convolution's output");
     const ConvGeom cg = conv_geom(di), ng = conv_geom(next);
-    if (!cg.ok || !ng.ok || next->x_signed || !di->weights_packed || !di->x_staged || d->o % 16 != 0)
+    if (!cg.ok || !ng.ok || ng.packed || next->x_signed || !di->weights_packed || !di->x_staged || d->o % 16 != 0)
         return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "conv2d_int8_qout: staged operands, O % 16 == 0 and a consumer covered by the staged kernel only");
     if (d->n == 0 || d->out_h == 0 || d->out_w == 0) return RTEN_HIP_OK;
     const QOutArgs qo = {next, sync, next_staged, next_scale, next_zero_point, mul_by, product};

@@ -314,3 +314,51 @@ def test_co_run_measurement_on_borrowed_contexts():
     finally:
         for c in ctxs:
             c.close()
+
+
+@pytest.mark.parametrize("pm", [L.PAD_ZERO_POINT, L.PAD_RAW0_I8, L.PAD_RAW0_U8])
+def test_few_channel_packed_int8_convolution_is_bit_exact(ctx, pm):
+    """Convolutions with C <= 4 input channels take the PACKED staging form (int8_fast.hip, conv_geom: a 16-byte chunk = 16 / C kernel columns x C channels of one
+    kernel row, per output column; the stem of ResNet-50 goes from K = 784 to 224): every channel count, kernel widths that fill a chunk exactly / partly / need
+    several, strides 1-3, dilation, asymmetric padding on both axes, both signednesses of both operands with no / a scalar / a per-channel weight zero point on the
+    plain path (the unused bytes of a chunk are zero on both operands, so every term of the zero-point algebra is exact), and DynamicQuantizeLinear's staged image +
+    prepacked weights on the product's path -- against the oracle's ConvInteger under the three padding conventions."""
+    rng = ref.XorShiftRng(pm + 5)
+    cases = ((2, 3, 23, 20, 8, 7, 7, (3, 3, 3, 3), (2, 2), (1, 1)), (1, 1, 9, 30, 5, 3, 11, (1, 5, 1, 5), (1, 2), (1, 1)), (2, 4, 12, 13, 70, 3, 3, (1, 1, 1, 1), (1, 1), (1, 1)),
+             (3, 2, 8, 17, 6, 1, 9, (0, 2, 0, 3), (1, 3), (1, 1)), (1, 3, 32, 32, 64, 7, 7, (3, 3, 3, 3), (2, 2), (1, 1)), (2, 4, 10, 9, 4, 5, 2, (2, 0, 1, 1), (2, 1), (1, 1)),
+             (1, 3, 6, 40, 3, 2, 6, (0, 0, 1, 0), (1, 4), (1, 1)), (2, 3, 14, 19, 6, 3, 5, (2, 4, 2, 4), (1, 1), (2, 2)), (1, 2, 9, 21, 5, 2, 3, (1, 3, 0, 3), (1, 2), (1, 3)))
+    for (N, Cc, H, W, O, kh, kw, pads, strides, dil) in cases:
+        oh = (H + pads[0] + pads[2] - dil[0] * (kh - 1) - 1) // strides[0] + 1
+        ow = (W + pads[1] + pads[3] - dil[1] * (kw - 1) - 1) // strides[1] + 1
+        for xdt, wdt in ((np.uint8, np.int8), (np.int8, np.uint8), (np.uint8, np.uint8), (np.int8, np.int8)):  # plain operands: the u8 / i8 -> packed image staging launch
+            x = (rng.u8(N * Cc * H * W) if xdt == np.uint8 else rng.i8(N * Cc * H * W)).reshape(N, Cc, H, W)
+            wn = O * Cc * kh * kw
+            w = (rng.u8(wn, reduced=True) if wdt == np.uint8 else rng.i8(wn, reduced=True)).reshape(O, Cc, kh, kw)
+            x_zp = np.array(rng.u8(1)[0] if xdt == np.uint8 else rng.i8(1)[0], xdt)
+            op = ops.ConvInteger(dilations=dil, padding=list(pads), strides=strides, pad_mode=pm)
+            for w_zp in (None, np.array(3, wdt), (rng.u8(O, reduced=True) if wdt == np.uint8 else rng.i8(O, reduced=True))):
+                got = op.run(ctx, [dev(ctx, x), dev(ctx, w), dev(ctx, x_zp), dev(ctx, w_zp) if w_zp is not None else None])[0].numpy()
+                _bits(got, ref.conv2d_int8(x, w, x_zp=int(x_zp), w_zp=w_zp, pads=pads, strides=strides, dilations=dil, pad_mode=pm))
+        if dil != (1, 1):
+            continue
+        # the product's path: DynamicQuantizeLinear writing the packed image, prepacked weights, ConvIntegerToFloat + bias + Relu
+        w = rng.i8(O * Cc * kh * kw, reduced=True).reshape(O, Cc, kh, kw)
+        xf = (rng.f32(N * Cc * H * W) - 0.4).reshape(N, Cc, H, W) * 3
+        w_scale, bias = np.array([0.003], np.float32), rng.f32(O) - 0.5
+        cd = L.Conv2dDesc(N, Cc, H, W, O, kh, kw, (C.c_int32 * 4)(*pads), strides[0], strides[1], 1, 1, 1, oh, ow)
+        d = L.Conv2dInt8Desc(cd, 0, 1, 0, pm, 1, 1)
+        staged = DeviceTensor(ctx, (ctx.lib.rten_hip_conv2d_int8_staged_bytes(C.byref(d)),), np.uint8)
+        packed = DeviceTensor(ctx, (ctx.lib.rten_hip_conv2d_int8_packed_bytes(C.byref(d)),), np.uint8)
+        xd, wd, bd, wsd = dev(ctx, xf), dev(ctx, w), dev(ctx, bias), dev(ctx, w_scale)
+        xs, xz, sc = DeviceTensor(ctx, (1,), np.float32), DeviceTensor(ctx, (1,), np.uint8), DeviceTensor(ctx, (1,), np.float32)
+        out = DeviceTensor(ctx, (N, O, oh, ow), np.float32)
+        ctx.call("rten_hip_conv2d_int8_prepack", C.byref(d), wd.vp, packed.vp)
+        ctx.call("rten_hip_dynamic_quantize_linear_staged", C.byref(d), xd.vp, staged.vp, xs.vp, xz.vp, wsd.vp, sc.vp)
+        ctx.call("rten_hip_conv2d_int8", C.byref(d), staged.vp, packed.vp, xz.vp, None, sc.vp, bd.vp, None, L.CONV_RELU, out.vp)
+        q, s, z = ref.dynamic_quantize_linear(xf)
+        assert xs.numpy()[0] == s and xz.numpy()[0] == z
+        acc = ref.conv2d_int8(q, w, x_zp=int(z), pads=pads, strides=strides, pad_mode=pm)
+        _bits(out.numpy(), ref.relu(ref.cast_scale(acc, np.float32(np.float32(s) * w_scale[0])) + bias[None, :, None, None]))
+        # the packed image has fewer chunks per output pixel than the 16-channel-block form has taps, and is what staged_bytes sizes
+        nch = -(-kw // (16 // Cc))
+        assert nch < kw and ctx.lib.rten_hip_conv2d_int8_staged_bytes(C.byref(d)) >= N * (H + pads[0] + pads[2]) * ow * nch * 16
