@@ -50,7 +50,10 @@
 extern "C" {
 #endif
 
-/* v6 (round 6): + rten_hip_elementwise_nd (Cast / Not / And / Or / Xor / Equal / Less.. / Where / integer arithmetic over strided operands),
+/* v7 (round 6, second part): + rten_hip_set_int8_tile (the int8 kernels' workgroup tile as a context knob: a launch plan may carry a per-layer entry for an int8
+ * convolution step); rten_hip_sdpa_desc: mask_row_stride = 0 with mask_batch_stride = S * T reads one shared row per batch item out of an expanded mask; plan files
+ * may key MatMul-family entries by product shape ("shapes"); convolutions with C <= 4 stage their input in the few-channel packed form (opaque layouts only).
+ * v6 (round 6): + rten_hip_elementwise_nd (Cast / Not / And / Or / Xor / Equal / Less.. / Where / integer arithmetic over strided operands),
  * rten_hip_gather_axis_b32, rten_hip_copy_rows_b32, rten_hip_tanh_f32, rten_hip_capture_active -- the layout / logic operators an exporter-written
  * transformer graph carries around its hot-path operators (src/ops/convert.rs, binary_elementwise.rs, gather.rs, concat.rs); rten_hip_model_clone
  * refuses a model whose plan lists quantized-output edges; rten_hip_conv2d_int8_qout with sync == NULL = the recompute form (plan key "qout2");
@@ -69,7 +72,7 @@ extern "C" {
  * GEMM variants 24-30 (one wave per tile, two-stage ring, image patches), sticky device fault reported by rten_hip_sync / rten_hip_graph_launch.  v2 (round 3) had added
  * rten_hip_graph_abort, rten_hip_conv2d_int8_qout, rten_hip_grid_sync_*, rten_hip_dynamic_quantize_linear_staged_products, rten_hip_max_pool2d_f32_stats and
  * rten_hip_set_sdpa_path mode 2 WITHOUT a bump: a binding built against this header must refuse a library whose rten_hip_abi_version() differs. */
-#define RTEN_HIP_ABI_VERSION 6
+#define RTEN_HIP_ABI_VERSION 7
 
 /* ---- status codes (map onto OpError variants, src/operator.rs:116-144) ---- */
 #define RTEN_HIP_OK 0
@@ -633,6 +636,10 @@ int32_t rten_hip_set_gemm_order(rten_hip_ctx *ctx, int32_t order);
 /* int8 kernels: 0 = automatic (operands staged chunk-major / padded channel-blocked + 16-byte LDS-DMA MFMA kernel whenever it
  * covers the call), 1 = generic byte-gather kernel only.  Both produce the reference's bits. */
 int32_t rten_hip_set_int8_path(rten_hip_ctx *ctx, int32_t mode);
+/* int8 convolution / GEMM workgroup tile (tuning knob, sticky, default -1; v7): -1 = the backend's per-shape rule (the largest tile that still gives every compute
+ * unit a workgroup), 0 = 128x128, 1 = 128x64, 2 = 64x128, 3 = 64x64.  `previous` (optional) receives the value it replaces, so that a scope can put it back.  Every
+ * tile computes the same integer sums: a launch plan's per-layer entry for an int8 convolution step (profiles/plans/int8*.json: "<step>": [tile, 0, 1, 0]) changes time only. */
+int32_t rten_hip_set_int8_tile(rten_hip_ctx *ctx, int32_t tile, int32_t *previous);
 /* attention: 0 = automatic (one fused kernel -- QK^T, mask, softmax and PV without a score tensor in memory -- for head size 32 / 64 / 128
  * and key length <= 128, where it is the faster form), 1 = composed path only (batched GEMM, row softmax, batched GEMM), 2 = the fused
  * kernel wherever it covers the shape (head size 32 / 64 / 128, key length <= 512).  Same bits on every path. */

@@ -608,10 +608,14 @@ class Graph {
     size_t apply_plan(const std::map<std::string, GemmPlan> &table) {
         size_t n = 0;
         for (auto &st : steps_) {
-            if (!st.conv && !st.gemm_plan) continue;
+            if (!st.conv && !st.gemm_plan && !st.i8) continue;
             auto it = table.find(st.name);
-            if (it == table.end()) continue;
-            if (st.conv) st.conv->plan = it->second;
+            if (it == table.end()) { if (st.i8) st.i8->tile = -1; continue; }
+            if (st.i8) { // an int8 convolution step: the entry's first number is its workgroup tile (round 6: "<step>": [tile, 0, 1, 0])
+                if (it->second.variant < 0 || it->second.variant > 3) continue;
+                st.i8->tile = it->second.variant;
+            }
+            else if (st.conv) st.conv->plan = it->second;
             else *st.gemm_plan = it->second;
             n++;
         }
@@ -632,6 +636,7 @@ class Graph {
         for (auto &st : steps_) {
             if (st.conv && st.conv->plan.set) t[st.name] = st.conv->plan;
             if (st.gemm_plan && st.gemm_plan->set) t[st.name] = *st.gemm_plan;
+            if (st.i8 && st.i8->tile >= 0) t[st.name] = GemmPlan{true, st.i8->tile, 0, 1, 0};
         }
         return t;
     }
@@ -700,6 +705,14 @@ class Graph {
             }
             if (tune_reps_ > 0 && (st.conv || st.gemm_plan)) tune_step(st, in);
             try {
+                if (st.i8 && st.i8->tile >= 0) { // the plan's workgroup tile around this step's launches (the caller's own setting comes back)
+                    struct TileScope {
+                        Context &c; int32_t prev = -1; bool on = false;
+                        TileScope(Context &c_, int tile) : c(c_) { on = rten_hip_set_int8_tile(c.raw(), tile, &prev) == RTEN_HIP_OK; }
+                        ~TileScope() { if (on) rten_hip_set_int8_tile(c.raw(), prev, nullptr); }
+                    } scope(ctx_, st.i8->tile);
+                    out = st.run(ctx_, in);
+                } else
                 out = st.run(ctx_, in);
             } catch (const OpError &e) { // name the node, like the reference's RunError::OperatorError { name, error }
                 throw OpError(e.kind, "operator " + st.kind_name + " \"" + st.name + "\": " + e.msg);
@@ -746,6 +759,7 @@ class Graph {
         ConvInteger::Staging sg;
         bool to_float = false;
         bool relu = false;
+        int tile = -1;         // a launch plan's per-layer workgroup tile for this step's int8 kernel (rten_hip_set_int8_tile; -1 = the backend's rule)
         bool qout_off = false; // the one-launch form was refused once (grid not resident at once): the two-launch sequence from then on
         bool qout_producer = false; // this step also runs its consumer's quantizer (Options::qout): it keeps reading staged codes itself
     };

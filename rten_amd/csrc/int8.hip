@@ -399,3 +399,11 @@ RTEN_EXPORT int32_t rten_hip_set_int8_path(rten_hip_ctx *ctx, int32_t mode) {
     ctx->int8_path = mode;
     return RTEN_HIP_OK;
 }
+
+RTEN_EXPORT int32_t rten_hip_set_int8_tile(rten_hip_ctx *ctx, int32_t tile, int32_t *previous) {
+    RTEN_CHECK_CTX(ctx);
+    if (tile < -1 || tile > 3) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "set_int8_tile: tile must be -1 (per-shape rule), 0 (128x128), 1 (128x64), 2 (64x128) or 3 (64x64)");
+    if (previous) *previous = ctx->int8_tile;
+    ctx->int8_tile = tile;
+    return RTEN_HIP_OK;
+}

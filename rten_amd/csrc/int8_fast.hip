@@ -1304,7 +1304,7 @@ int32_t dispatch_fast(rten_hip_ctx *ctx, FastArgs &a, double ops, double bytes) 
     const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     const long long t12864 = (long long)((a.M + 127) / 128) * ((a.N + 63) / 64);
     static const int env_tile = getenv("RTEN_I8_TILE") ? atoi(getenv("RTEN_I8_TILE")) : -1; // (tuning: 0 = 128x128, 1 = 128x64, 2 = 64x128, 3 = 64x64)
-    const int tile = env_tile >= 0 ? env_tile : (a.M <= 64 ? 2 : (t128 >= ctx->num_cus ? 0 : (t12864 >= ctx->num_cus ? 1 : 3)));
+    const int tile = env_tile >= 0 ? env_tile : (ctx->int8_tile >= 0 ? ctx->int8_tile : (a.M <= 64 ? 2 : (t128 >= ctx->num_cus ? 0 : (t12864 >= ctx->num_cus ? 1 : 3))));
     // tile order: consecutive workgroup ids (one XCD's share) walk the axis of the SMALLER operand, so that the larger
     // one is fetched into as few of the eight L2s as possible
     a.n_fastest = (double)a.a_bytes > (double)a.b_bytes ? 1 : 0;

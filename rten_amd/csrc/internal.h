@@ -55,6 +55,7 @@ struct rten_hip_ctx {
     int num_cus = 256;
     int sdpa_path = 0;  // 0 automatic (fused attention kernel when it covers the shape), 1 composed path only
     int int8_path = 0;  // 0 automatic (fast staging path when it covers the call), 1 generic kernel only
+    int int8_tile = -1; // rten_hip_set_int8_tile: -1 = per-shape rule, 0..3 = 128x128 / 128x64 / 64x128 / 64x64
     int tile_order = 0; // workgroup -> tile order bits (rten_hip_set_gemm_order)
     int split_mode = 3, split_s = 1; // exact split-K plan: 0 off, 1 tail tiles, 2 all tiles, 3 automatic (gemm_f32.hip)
     int gemv_order = 1;          // m == 1 products of rten_hip_gemm_f32 follow the reference's gemv kernels (gemv_f32.hip); 0: the blocked order

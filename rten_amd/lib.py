@@ -185,6 +185,7 @@ PROTOTYPES = {
     "rten_hip_stream_wait": (_I32, [_VP, _VP]),
     "rten_hip_set_gemm_order": (_I32, [_VP, _I32]),
     "rten_hip_set_int8_path": (_I32, [_VP, _I32]),
+    "rten_hip_set_int8_tile": (_I32, [_VP, _I32, C.POINTER(C.c_int32)]),
     "rten_hip_set_sdpa_path": (_I32, [_VP, _I32]),
     # the plan executor behind the C ABI (csrc/graph_abi.cpp)
     "rten_hip_model_load": (_I32, [_VP, _VP, _SZ, C.c_char_p, _I32, _I32, C.POINTER(_VP)]),

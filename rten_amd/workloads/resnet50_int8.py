@@ -278,6 +278,17 @@ class ResNet50Int8(ResNet50):
         return n.value
 
     def _conv(self, l, ctx=None):
+        # a per-layer workgroup tile (rten_hip_set_int8_tile; what a plan file's "<layer>": [tile, 0, 1, 0] entry gives the executor's step): {layer: 0..3}
+        t = getattr(self, "tiles", {}).get(l["name"], -1)
+        if t < 0:
+            return self._conv_impl(l, ctx)
+        self.ctx.call("rten_hip_set_int8_tile", t, None)
+        try:
+            return self._conv_impl(l, ctx)
+        finally:
+            self.ctx.call("rten_hip_set_int8_tile", -1, None)
+
+    def _conv_impl(self, l, ctx=None):
         if self.fused_qout and not self.concurrent:
             return self._conv_q(l)
         ctx = self.ctx

@@ -153,7 +153,9 @@ def test_resnet50_int8_four_replicas_side_by_side_on_different_batches():
             x = bo.resnet_input(seed)
             m.bind_input("x", x.shape)
             m.prepare()
-            assert m.planned_steps == 5, m.planned_steps  # the listed layers whose quantizer has no other reader
+            # the quantize-on-load layers whose quantizer has no other reader (5) + the per-layer workgroup tiles chosen under co-run (round 6: "<layer>": [tile, 0, 1, 0])
+            n_tiles = sum(1 for k, v in plan.items() if k not in ("fused_dql", "qout", "qout2") and isinstance(v, list) and len(v) == 4)
+            assert n_tiles >= 10 and m.planned_steps == 5 + n_tiles, (m.planned_steps, n_tiles)
             assert m.weight_arena() == models[0].weight_arena()
             DeviceTensor(c, x.shape, np.float32, ptr=m.input_ptrs["x"], keepalive=m).upload(x)
             c.sync()

@@ -362,3 +362,34 @@ def test_few_channel_packed_int8_convolution_is_bit_exact(ctx, pm):
         # the packed image has fewer chunks per output pixel than the 16-channel-block form has taps, and is what staged_bytes sizes
         nch = -(-kw // (16 // Cc))
         assert nch < kw and ctx.lib.rten_hip_conv2d_int8_staged_bytes(C.byref(d)) >= N * (H + pads[0] + pads[2]) * ow * nch * 16
+
+
+def test_int8_workgroup_tile_knob_changes_time_only(ctx):
+    """rten_hip_set_int8_tile (ABI v7: what a launch plan's per-layer entry for an int8 convolution step sets around the step): every tile computes the same integer
+    sums -- ConvIntegerToFloat with bias / residual / Relu on a stage-2-like and a stage-0-like shape, and MatMulInteger; out-of-range values are refused and the
+    previous value is reported."""
+    rng = ref.XorShiftRng(99)
+    prev = C.c_int32(123)
+    assert ctx.lib.rten_hip_set_int8_tile(ctx.h, 4, None) == L.ERR_INVALID_VALUE and ctx.lib.rten_hip_set_int8_tile(ctx.h, -2, None) == L.ERR_INVALID_VALUE
+    ctx.call("rten_hip_set_int8_tile", 2, C.byref(prev))
+    assert prev.value == -1
+    ctx.call("rten_hip_set_int8_tile", -1, C.byref(prev))
+    assert prev.value == 2
+    for (N, Cc, H, W, O, k, pad, stride) in ((2, 64, 14, 14, 130, 3, 1, 1), (3, 32, 20, 20, 64, 1, 0, 1), (1, 128, 9, 9, 256, 3, 1, 2)):
+        x = rng.u8(N * Cc * H * W).reshape(N, Cc, H, W)
+        w = rng.i8(O * Cc * k * k, reduced=True).reshape(O, Cc, k, k)
+        x_zp, scale, bias = np.array(117, np.uint8), np.array(0.01, np.float32), rng.f32(O) - 0.5
+        oh = (H + 2 * pad - k) // stride + 1
+        res = (rng.f32(N * O * oh * oh) - 0.5).reshape(N, O, oh, oh)
+        want = None
+        for tile in (-1, 0, 1, 2, 3):
+            ctx.call("rten_hip_set_int8_tile", tile, None)
+            try:
+                op = ops.ConvIntegerToFloat(ops.ConvInteger(padding=[pad] * 4, strides=(stride, stride)), fuse_relu=True)
+                got = op.run(ctx, [dev(ctx, x), dev(ctx, w), dev(ctx, x_zp), None, dev(ctx, scale), dev(ctx, bias), dev(ctx, res)])[0].numpy()
+            finally:
+                ctx.call("rten_hip_set_int8_tile", -1, None)
+            if want is None:
+                acc = ref.conv2d_int8(x, w, x_zp=int(x_zp), pads=(pad,) * 4, strides=(stride, stride), pad_mode=ref.PAD_RAW0_I8)
+                want = ref.relu(ref.cast_scale(acc, scale) + bias[None, :, None, None] + res)
+            _bits(got, want)
