@@ -50,7 +50,9 @@
 extern "C" {
 #endif
 
-/* v7 (round 6, second part): + rten_hip_set_int8_tile (the int8 kernels' workgroup tile as a context knob: a launch plan may carry a per-layer entry for an int8
+/* v8 (round 6, third part): + rten_hip_conv2d_f32_pair / _pair_supported (an expand layer and the next block's reduce layer in one launch; a launch plan
+ * lists the pairs: "pairs").
+ * v7 (round 6, second part): + rten_hip_set_int8_tile (the int8 kernels' workgroup tile as a context knob: a launch plan may carry a per-layer entry for an int8
  * convolution step); rten_hip_sdpa_desc: mask_row_stride = 0 with mask_batch_stride = S * T reads one shared row per batch item out of an expanded mask; plan files
  * may key MatMul-family entries by product shape ("shapes"); convolutions with C <= 4 stage their input in the few-channel packed form (opaque layouts only).
  * v6 (round 6): + rten_hip_elementwise_nd (Cast / Not / And / Or / Xor / Equal / Less.. / Where / integer arithmetic over strided operands),
@@ -72,7 +74,7 @@ extern "C" {
  * GEMM variants 24-30 (one wave per tile, two-stage ring, image patches), sticky device fault reported by rten_hip_sync / rten_hip_graph_launch.  v2 (round 3) had added
  * rten_hip_graph_abort, rten_hip_conv2d_int8_qout, rten_hip_grid_sync_*, rten_hip_dynamic_quantize_linear_staged_products, rten_hip_max_pool2d_f32_stats and
  * rten_hip_set_sdpa_path mode 2 WITHOUT a bump: a binding built against this header must refuse a library whose rten_hip_abi_version() differs. */
-#define RTEN_HIP_ABI_VERSION 7
+#define RTEN_HIP_ABI_VERSION 8
 
 /* ---- status codes (map onto OpError variants, src/operator.rs:116-144) ---- */
 #define RTEN_HIP_OK 0
@@ -248,6 +250,17 @@ int32_t rten_hip_conv2d_f32_prepack(rten_hip_ctx *ctx, const rten_hip_conv2d_des
 int32_t rten_hip_conv2d_f32(rten_hip_ctx *ctx, const rten_hip_conv2d_desc *desc, const float *x, const float *w,
                             int32_t weights_packed, const float *bias, const float *residual, uint32_t flags,
                             float *y);
+
+/* Two pointwise convolutions in ONE launch (v8): y1 = act1(conv1x1(x, w1) + bias1 [+ residual]), y2 = act2(conv1x1(y1, w2) + bias2) -- an expand
+ * layer of a bottleneck block and the reduce layer of the next block (src/ops/conv.rs:248-284 twice).  y1 is written as always; the second
+ * convolution reads it from on-chip memory instead of from HBM.  Both weights PREPACKED (rten_hip_conv2d_f32_prepack); both results are bit-identical
+ * to two rten_hip_conv2d_f32 calls.  Forms: unit-stride unpadded 1x1 convolutions, groups 1, d1->c == 64, d1->o a multiple of 64 up to 256 (= d2->c),
+ * d2->o 64 or 128, out_h * out_w a multiple of 4; anything else: RTEN_HIP_ERR_UNSUPPORTED (ask rten_hip_conv2d_f32_pair_supported first, 1 / 0).
+ * flags2 must not carry RTEN_HIP_CONV_RESIDUAL. */
+int32_t rten_hip_conv2d_f32_pair_supported(const rten_hip_conv2d_desc *d1, const rten_hip_conv2d_desc *d2);
+int32_t rten_hip_conv2d_f32_pair(rten_hip_ctx *ctx, const rten_hip_conv2d_desc *d1, const float *x, const float *w1_packed, const float *bias1,
+                                 const float *residual, uint32_t flags1, float *y1, const rten_hip_conv2d_desc *d2, const float *w2_packed,
+                                 const float *bias2, uint32_t flags2, float *y2);
 
 /* ---- Conv (int8): ConvInteger / ConvIntegerToFloat, src/ops/conv.rs:421-476,495-526,571-578 ----
  * x u8|i8 NCHW, w i8|u8 OIHW, x_zp: device scalar of x's type, w_zp: device, length 1 or o.

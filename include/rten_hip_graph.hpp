@@ -517,6 +517,10 @@ class Graph {
         // Opt-in, per layer (profiles/plans/int8.json "fused_dql"): pointwise ConvInteger nodes, by name, whose fused ConvIntegerToFloat step runs its
         // DynamicQuantizeLinear inside its own operand loader (rten_hip_conv2d_int8_dql) instead of reading the staged codes.
         std::set<std::string> fused_dql;
+        // Opt-in, per layer (a launch plan: profiles/plans/f32_lanes.json "pairs"): f32 Conv steps, by name, that also run the ONE pointwise convolution reading
+        // their output -- a bottleneck block's expand layer and the next block's reduce layer in one launch (rten_hip_conv2d_f32_pair; round 6): the
+        // second layer takes its operand from LDS instead of reading the tensor back from HBM.  Same bits; a pair the kernel has no form for runs as two launches.
+        std::set<std::string> pairs;
         // A rank that RECEIVES the weight arena (coalesce_constants() + one broadcast from the rank that loaded the file for real): initializers of
         // 64 KB and more are allocated but not uploaded.  Everything derived from them on the device (prepacked weights) is computed on whatever the
         // buffers hold and overwritten by the broadcast, which covers every constant buffer of the graph.
@@ -540,6 +544,7 @@ class Graph {
     size_t num_staged_quantizers() const { return staged_dql_; }
     size_t num_qout_edges() const { return qout_edges_; } // quantizers merged into their producer's launch (Options::qout)
     size_t num_stats_blocks() const { return stats_blocks_; }
+    size_t num_conv_pairs() const { return conv_pairs_; } // convolution pairs that run as one launch (Options::pairs)
     size_t num_dql_loader_steps() const { return dql_loader_steps_; } // convolutions that quantize in their own loader (Options::fused_dql)
 
     // Moves every device constant of this graph -- uploaded initializers, constants derived at load (merged QKV weights), prepacked conv / MatMul
@@ -808,6 +813,7 @@ class Graph {
     std::vector<int> uses_;
     std::vector<onnx::ValueInfo> inputs_, outputs_;
     size_t fused_away_ = 0;
+    size_t conv_pairs_ = 0;
     std::set<int> view_values_;
     int tune_reps_ = 0;
     size_t tuned_ = 0;
@@ -959,6 +965,68 @@ class Graph {
             fused_away_++;
             qout_edges_++;
         }
+    }
+    // Opt-in per layer (Options::pairs): the f32 Conv step `A` (with whatever Add / Relu it absorbed) and the one f32 Conv step `B` whose input is A's output
+    // become ONE step with two outputs, at A's place.  B must take A's output as its data input, constant weights, no residual; the kernel's forms (unit-stride
+    // pointwise, K1 = 64, M1 <= 256, M2 in {64, 128}: rten_hip_conv2d_f32_pair_supported) are run-time facts, checked per run -- a pair outside them runs A's and
+    // B's own steps one after the other, as the graph spells them.  A's output stays a value of its own: other steps (the next block's residual Add, a downsample
+    // layer) still read it.
+    void plan_conv_pairs() {
+        if (opt_.pairs.empty()) return;
+        auto packed_lookup = [&](const std::string &name) -> const Tensor * {
+            const auto &tbl = donor_ ? donor_->packed_of_ : packed_of_;
+            auto it = tbl.find(name);
+            return it == tbl.end() ? nullptr : it->second;
+        };
+        for (size_t i = 0; i < steps_.size(); i++) {
+            Step &A = steps_[i];
+            if (!A.conv || A.removed || !opt_.pairs.count(A.name) || A.out.empty() || A.out[0] < 0 || A.in.size() < 4) continue;
+            Step *Bp = nullptr;
+            for (size_t k = i + 1; k < steps_.size(); k++) {
+                Step &c = steps_[k];
+                if (c.conv && !c.removed && c.in.size() >= 4 && c.in[0] == A.out[0] && c.in[3] < 0 && c.in[1] >= 0 && consts_.count(c.in[1]) && (c.in[2] < 0 || consts_.count(c.in[2]))) { Bp = &c; break; }
+            }
+            if (!Bp) continue;
+            Step &B = *Bp;
+            const Tensor *pa = packed_lookup(A.name), *pb = packed_lookup(B.name);
+            if (!pa || !pb) continue;
+            const std::shared_ptr<Conv> opa = A.conv, opb = B.conv;
+            const auto run_a = A.run, run_b = B.run;
+            A.in.push_back(B.in[1]);
+            A.in.push_back(B.in[2]);
+            A.out.push_back(B.out[0]);
+            A.kind_name += ">" + B.kind_name;
+            A.conv.reset(); // (not a tunable step any more: the one-launch form has no launch plan)
+            A.run = [opa, opb, pa, pb, run_a, run_b](Context &c, const InputList &in) -> OutputList {
+                const Tensor &x = require(in, 0), &w1 = require(in, 1), &w2 = require(in, 4);
+                const Tensor *b1 = get(in, 2), *res = get(in, 3), *b2 = get(in, 5);
+                bool ok = x.dtype() == DType::F32 && x.ndim() == 4 && w1.ndim() == 4 && w2.ndim() == 4 && w1.dtype() == DType::F32 && w2.dtype() == DType::F32 && opa->groups == 1 && opb->groups == 1;
+                rten_hip_conv2d_desc d1{}, d2{};
+                if (ok) {
+                    d1 = opa->geometry(x.shape(), w1.shape());
+                    d2 = opb->geometry({d1.n, d1.o, d1.out_h, d1.out_w}, w2.shape());
+                    ok = rten_hip_conv2d_f32_pair_supported(&d1, &d2) == 1 && (!res || (res->dtype() == DType::F32 && res->shape() == std::vector<int64_t>{d1.n, d1.o, d1.out_h, d1.out_w})) &&
+                         (!b1 || (b1->dtype() == DType::F32 && b1->len() == d1.o)) && (!b2 || (b2->dtype() == DType::F32 && b2->len() == d2.o));
+                }
+                if (!ok) { // the two steps as they were
+                    OutputList y1 = run_a(c, {in[0], in[1], in[2], in[3]});
+                    OutputList y2 = run_b(c, {&y1[0], in[4], in[5], nullptr});
+                    y1.push_back(std::move(y2[0]));
+                    return y1;
+                }
+                OutputList out;
+                out.emplace_back(c, std::vector<int64_t>{d1.n, d1.o, d1.out_h, d1.out_w}, DType::F32);
+                out.emplace_back(c, std::vector<int64_t>{d2.n, d2.o, d2.out_h, d2.out_w}, DType::F32);
+                const uint32_t f1 = (opa->fuse_relu ? RTEN_HIP_CONV_RELU : 0u) | (res ? RTEN_HIP_CONV_RESIDUAL : 0u), f2 = opb->fuse_relu ? RTEN_HIP_CONV_RELU : 0u;
+                c.check(rten_hip_conv2d_f32_pair(c.raw(), &d1, (const float *)x.ptr(), (const float *)pa->ptr(), (const float *)vp(b1), (const float *)vp(res), f1, (float *)out[0].ptr(),
+                                                 &d2, (const float *)pb->ptr(), (const float *)vp(b2), f2, (float *)out[1].ptr()));
+                return out;
+            };
+            B.removed = true;
+            fused_away_++;
+            conv_pairs_++;
+        }
+        steps_.erase(std::remove_if(steps_.begin(), steps_.end(), [](const Step &st) { return st.removed; }), steps_.end());
     }
     // Opt-in per layer (Options::fused_dql, the runner's `fused_layers`): a pointwise ConvIntegerToFloat step whose input comes from a staged
     // quantizer with producer statistics reads the quantizer's f32 INPUT and quantizes in its own operand loader (rten_hip_conv2d_int8_dql:
@@ -1956,7 +2024,7 @@ class Graph {
             if (!ids_.count(o.name)) throw GraphError("graph output " + o.name + " is not produced by any node");
         std::stable_sort(steps_.begin(), steps_.end(), [](const Step &a, const Step &b) { return a.pos < b.pos; });
         for (auto &st : steps_) if (st.view && st.out[0] >= 0) view_values_.insert(st.out[0]);
-        if (opt_.fuse) { plan_int8_staging(); plan_dql_loaders(); }
+        if (opt_.fuse) { plan_int8_staging(); plan_dql_loaders(); plan_conv_pairs(); }
         for (auto &st : steps_) if (st.kind_name.find("DynamicQuantizeLinear") != std::string::npos) st.batch_coupled = true; // min / max over the whole tensor
         plan_liveness();
     }

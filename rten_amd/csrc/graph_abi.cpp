@@ -189,6 +189,7 @@ RTEN_EXPORT int32_t rten_hip_model_load_ex(rten_hip_ctx *ctx, const void *onnx_b
             // "qout2": the same kind of edge in the recompute form (two launches, no exchange): allowed with replicas
             if (pj.names.count("qout2")) opts.qout_recompute.insert(pj.names["qout2"].begin(), pj.names["qout2"].end());
             if (pj.names.count("fused_dql")) opts.fused_dql.insert(pj.names["fused_dql"].begin(), pj.names["fused_dql"].end());
+            if (pj.names.count("pairs")) opts.pairs.insert(pj.names["pairs"].begin(), pj.names["pairs"].end());
         }
         for (int c = 0; c < chains; c++) {
             // chain 0 runs on the CALLER's context (its stream): a model with N chains owns N - 1 streams.  One stream more than chains costs real
@@ -309,7 +310,7 @@ RTEN_EXPORT int32_t rten_hip_model_info(const rten_hip_model *g, int32_t *n_inpu
     if (n_inputs) *n_inputs = (int32_t)g->inputs.size();
     if (n_outputs) *n_outputs = (int32_t)g->outputs.size();
     if (n_steps) *n_steps = (int32_t)g->graphs[0]->num_steps();
-    if (n_planned_steps) *n_planned_steps = (int32_t)(g->planned_steps + g->tuned_steps + g->graphs[0]->num_qout_edges() + g->graphs[0]->num_dql_loader_steps());
+    if (n_planned_steps) *n_planned_steps = (int32_t)(g->planned_steps + g->tuned_steps + g->graphs[0]->num_qout_edges() + g->graphs[0]->num_dql_loader_steps() + g->graphs[0]->num_conv_pairs());
     return RTEN_HIP_OK;
 }
 RTEN_EXPORT const char *rten_hip_model_input_name(const rten_hip_model *g, int32_t i) { return (g && i >= 0 && (size_t)i < g->inputs.size()) ? g->inputs[(size_t)i].name.c_str() : nullptr; }
@@ -429,7 +430,7 @@ RTEN_EXPORT int32_t rten_hip_model_prepare(rten_hip_model *g, int32_t tune) {
         for (auto &c : g->ctxs) c->sync();
         g->prepared = true;
         g->last_error.clear();
-        if (g->have_plan && g->planned_steps + g->graphs[0]->num_qout_edges() + g->graphs[0]->num_dql_loader_steps() == 0)
+        if (g->have_plan && g->planned_steps + g->graphs[0]->num_qout_edges() + g->graphs[0]->num_dql_loader_steps() + g->graphs[0]->num_conv_pairs() == 0)
             g->last_error = "warning: the plan file matched no step of this graph (every launch runs the backend's automatic plan)";
     } catch (const OpError &e) {
         return fail(g, code_of(e), e.msg);

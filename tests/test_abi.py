@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_variants():
     from rten_amd import lib
     so = lib.load()
-    assert so.rten_hip_abi_version() == 7
+    assert so.rten_hip_abi_version() == 8
     assert so.rten_hip_num_gemm_variants() == 32
 
 

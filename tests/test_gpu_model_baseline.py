@@ -52,7 +52,10 @@ def test_resnet50_f32_batch32_four_chains_committed_plan_is_the_oracle():
                 m.bind_input("x", x.shape)
                 m.prepare()
                 # every convolution took its entry of the committed plan (f32_lanes.json: + the classifier Gemm's)
-                assert m.planned_steps == (54 if plan == "f32_lanes.json" else 53), (plan, m.planned_steps)
+                # (a pair of convolutions that runs as ONE launch -- the plan's "pairs" -- counts once: its two layers' own entries are not used)
+                n_pairs = len(json.loads(_plan(plan)).get("pairs", []))
+                assert (plan == "f32_1chain.json") == (n_pairs == 0)  # the lanes plan and the four-chain plan run stage 0's three expand -> reduce pairs in one launch each
+                assert m.planned_steps == (54 if plan == "f32_lanes.json" else 53) - n_pairs, (plan, m.planned_steps)
                 assert m.warning == "", m.warning
                 ptr, nbytes = m.weight_arena()
                 assert ptr and nbytes > 100 << 20  # 25.5 M f32 parameters + their prepacked images, one allocation

@@ -393,3 +393,56 @@ def test_int8_workgroup_tile_knob_changes_time_only(ctx):
                 acc = ref.conv2d_int8(x, w, x_zp=int(x_zp), pads=(pad,) * 4, strides=(stride, stride), pad_mode=ref.PAD_RAW0_I8)
                 want = ref.relu(ref.cast_scale(acc, scale) + bias[None, :, None, None] + res)
             _bits(got, want)
+
+
+@pytest.mark.gpu
+def test_two_pointwise_convolutions_in_one_launch_are_bit_exact():
+    """rten_hip_conv2d_f32_pair (ABI v8: a bottleneck block's expand layer -- bias, residual Add, Relu -- and the next block's reduce layer in ONE launch, the second
+    reading the first's output from LDS): both outputs bit-identical to the oracle's two convolutions (src/ops/conv.rs:248-284) and to two rten_hip_conv2d_f32
+    launches, on ragged column counts (pixels per image not a multiple of the workgroup's columns, a last tile past the end), with / without residual, bias and
+    activations, M1 in {64, 128, 256}, M2 in {64, 128}; unsupported shapes are refused, not computed."""
+    ctx = L.Context(0)
+    try:
+        rng = ref.XorShiftRng(4242)
+        cases = ((2, 64, 14, 14, 256, 64, True, True, True, True), (3, 64, 10, 6, 128, 128, True, False, True, True), (1, 64, 28, 28, 256, 128, False, True, False, True),
+                 (5, 64, 6, 6, 64, 64, True, True, True, False), (2, 64, 56, 56, 256, 64, True, True, True, True))
+        for (N, C1, H, W, M1, M2, res, relu1, bias, relu2) in cases:
+            x = (rng.f32(N * C1 * H * W) - 0.5).reshape(N, C1, H, W)
+            w1 = (rng.f32(M1 * C1) - 0.5).reshape(M1, C1, 1, 1) * 0.2
+            w2 = (rng.f32(M2 * M1) - 0.5).reshape(M2, M1, 1, 1) * 0.1
+            b1 = rng.f32(M1) - 0.5 if bias else None
+            b2 = rng.f32(M2) - 0.5 if bias else None
+            r = (rng.f32(N * M1 * H * W) - 0.5).reshape(N, M1, H, W) if res else None
+            want1 = ref.conv2d_f32(x, w1, b1, residual=r, relu=relu1)
+            want2 = ref.conv2d_f32(want1, w2, b2, relu=relu2)
+            d1 = L.Conv2dDesc(N, C1, H, W, M1, 1, 1, (C.c_int32 * 4)(0, 0, 0, 0), 1, 1, 1, 1, 1, H, W)
+            d2 = L.Conv2dDesc(N, M1, H, W, M2, 1, 1, (C.c_int32 * 4)(0, 0, 0, 0), 1, 1, 1, 1, 1, H, W)
+            assert ctx.lib.rten_hip_conv2d_f32_pair_supported(C.byref(d1), C.byref(d2)) == 1
+            xd, w1d, w2d = dev(ctx, x), dev(ctx, w1), dev(ctx, w2)
+            p1 = DeviceTensor(ctx, (ctx.lib.rten_hip_conv2d_f32_packed_bytes(C.byref(d1)) // 4,), np.float32)
+            p2 = DeviceTensor(ctx, (ctx.lib.rten_hip_conv2d_f32_packed_bytes(C.byref(d2)) // 4,), np.float32)
+            ctx.call("rten_hip_conv2d_f32_prepack", C.byref(d1), w1d.vp, p1.vp)
+            ctx.call("rten_hip_conv2d_f32_prepack", C.byref(d2), w2d.vp, p2.vp)
+            b1d, b2d, rd = (dev(ctx, b1) if bias else None), (dev(ctx, b2) if bias else None), (dev(ctx, r) if res else None)
+            y1, y2 = DeviceTensor(ctx, (N, M1, H, W), np.float32), DeviceTensor(ctx, (N, M2, H, W), np.float32)
+            f1 = (L.CONV_RELU if relu1 else 0) | (L.CONV_RESIDUAL if res else 0)
+            f2 = L.CONV_RELU if relu2 else 0
+            ctx.call("rten_hip_conv2d_f32_pair", C.byref(d1), xd.vp, p1.vp, b1d.vp if bias else None, rd.vp if res else None, f1, y1.vp,
+                     C.byref(d2), p2.vp, b2d.vp if bias else None, f2, y2.vp)
+            _bits(y1.numpy(), want1)
+            _bits(y2.numpy(), want2)
+            # ... and the two separate launches (what the pair replaces)
+            s1, s2 = DeviceTensor(ctx, (N, M1, H, W), np.float32), DeviceTensor(ctx, (N, M2, H, W), np.float32)
+            ctx.call("rten_hip_conv2d_f32", C.byref(d1), xd.vp, p1.vp, 1, b1d.vp if bias else None, rd.vp if res else None, f1, s1.vp)
+            ctx.call("rten_hip_conv2d_f32", C.byref(d2), s1.vp, p2.vp, 1, b2d.vp if bias else None, None, f2, s2.vp)
+            _bits(y1.numpy(), s1.numpy())
+            _bits(y2.numpy(), s2.numpy())
+        # shapes without a one-launch form
+        for (C1, M1, M2, k) in ((128, 256, 64, 1), (64, 512, 64, 1), (64, 256, 256, 1), (64, 256, 64, 3)):
+            d1 = L.Conv2dDesc(1, C1, 8, 8, M1, 1, 1, (C.c_int32 * 4)(0, 0, 0, 0), 1, 1, 1, 1, 1, 8, 8)
+            d2 = L.Conv2dDesc(1, M1, 8, 8, M2, k, k, (C.c_int32 * 4)(k // 2, k // 2, k // 2, k // 2), 1, 1, 1, 1, 1, 8, 8)
+            assert ctx.lib.rten_hip_conv2d_f32_pair_supported(C.byref(d1), C.byref(d2)) == 0
+            a = DeviceTensor(ctx, (1 << 16,), np.float32)
+            assert ctx.lib.rten_hip_conv2d_f32_pair(ctx.h, C.byref(d1), a.vp, a.vp, None, None, 0, a.vp, C.byref(d2), a.vp, None, 0, a.vp) == L.ERR_UNSUPPORTED
+    finally:
+        ctx.close()

@@ -545,7 +545,10 @@ def test_model_abi_chains_and_plan_file_give_the_oracle_bits():
     flat["s1b1c2"] = [24, 2, 2, 0]   # a wave-tile split-K plan
     flat["s2b1c2"] = [1, 1, 3, 0]
     keyed = {"2": flat, "1": {k: [3, 0, 1, 1] for k in flat}}
-    for chains, plan in ((3, keyed), (1, flat), (2, None)):
+    # "pairs" (round 6): an expand layer and the next block's reduce layer as ONE step / one launch (rten_hip_conv2d_f32_pair).  s1b0c3 is listed although the kernel has
+    # no form for its 128 input channels: that step runs its two convolutions one after the other
+    paired = dict(flat, pairs=["s0b0c3", "s0b1c3", "s0b2c3", "s1b0c3"])
+    for chains, plan in ((3, keyed), (1, flat), (2, None), (1, paired), (3, dict(keyed, pairs=paired["pairs"]))):
         m = L.Model(ctx, onnx_bytes, json.dumps(plan) if plan else None, chains)
         try:
             _check_model(m, ctx, x, want, plan, chains)
@@ -564,10 +567,11 @@ def test_model_abi_chains_and_plan_file_give_the_oracle_bits():
 
 def _check_model(m, ctx, x, want, plan, chains):
     from rten_amd.tensor import DeviceTensor
-    assert m.inputs == ["x"] and m.outputs == ["logits"] and m.num_steps == 57
+    n_pairs = len(plan.get("pairs", [])) if plan else 0
+    assert m.inputs == ["x"] and m.outputs == ["logits"] and m.num_steps == 57 - n_pairs
     xp = m.bind_input("x", x.shape)
     m.prepare()
-    assert m.planned_steps == (53 if plan else 0)
+    assert m.planned_steps == (53 - n_pairs if plan else 0)  # (a pair counts once; its two layers' own entries are not used)
     xt = DeviceTensor(ctx, x.shape, np.float32, ptr=xp, keepalive=m)
     for rep in range(2):
         xt.upload(x if rep == 0 else x[::-1].copy())
