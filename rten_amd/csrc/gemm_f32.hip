@@ -2790,7 +2790,7 @@ int32_t launch_variant(rten_hip_ctx *ctx, GemmArgs &a, int Z, int cfg) {
 }
 
 int pick_cfg(rten_hip_ctx *ctx, int M, long long N, int Z) {
-    if (ctx->gemm_variant_override >= 24 && ctx->gemm_variant_override < 32) return 3; // small-M streaming (31: calls that are not its shape), wave-tile kernels (24..26, 28..29), the two-stage ring (27), image patches (30): 64x64 plans
+    if (ctx->gemm_variant_override >= 24 && ctx->gemm_variant_override <= 32) return 3; // small-M streaming (31: calls that are not its shape), wave-tile kernels (24..26, 28..29), the two-stage ring (27), image patches (30): 64x64 plans
     if (ctx->gemm_variant_override >= 0 && ctx->gemm_variant_override < 24) return ctx->gemm_variant_override & 3;
     int best = 3;
     double best_cost = 1e300;
@@ -2836,7 +2836,8 @@ constexpr long long kMaxBufBytes = 0x7fffffffll; // buffer offsets are 32-bit; t
 // 28..29: one wave per 32x32 tile (barrier-free form of the 64x64 / 4-wave granularity; dense B), 16 x 2 and 16 x 3;
 // 30: 3x3 / stride 1 / padding 1 convolutions with B staged as image patches (gemm_f32_patch.hip); every other launch runs as variant 3.
 // 31: small-M weight streaming (rten_hip_gemm_f32 with one batch and M <= 64: gemm_f32_smallm_kernel; also what -1 = automatic picks there); every other launch runs as variant 3.
-RTEN_EXPORT int32_t rten_hip_num_gemm_variants(void) { return 32; }
+// 32: 3-channel 7x7 stride-2 convolutions with prepacked weights as a direct implicit GEMM (gemm_f32_stem.hip: the input patch of a 16 x 16 output tile in LDS); every other launch runs as variant 3.
+RTEN_EXPORT int32_t rten_hip_num_gemm_variants(void) { return 33; }
 
 RTEN_EXPORT int32_t rten_hip_set_gemm_variant_override(rten_hip_ctx *ctx, int32_t variant) {
     RTEN_CHECK_CTX(ctx);
@@ -3030,6 +3031,10 @@ const i32x2 *get_im2col_lut(rten_hip_ctx *ctx, int Cg, int kh, int kw, int dy, i
 }
 } // namespace
 
+// gemm_f32_stem.hip (GEMM variant 32)
+bool rten_small_c_conv_f32_supported(const rten_hip_conv2d_desc *d, int weights_packed, const float *residual);
+int32_t rten_small_c_conv_f32(rten_hip_ctx *ctx, const rten_hip_conv2d_desc *d, const float *x, const float *w_packed, const float *bias, uint32_t flags, float *y);
+
 // depthwise.hip
 int32_t rten_depthwise_conv2d_f32(rten_hip_ctx *ctx, const rten_hip_conv2d_desc *d, const float *x, const float *w, int32_t weights_packed, const float *bias,
                                   const float *residual, uint32_t flags, float *y);
@@ -3072,6 +3077,10 @@ RTEN_EXPORT int32_t rten_hip_conv2d_f32(rten_hip_ctx *ctx, const rten_hip_conv2d
                         d->pads[0] == 0 && d->pads[1] == 0 && d->pads[2] == 0 && d->pads[3] == 0;
         if (!pw && d->c == d->o && d->groups == d->c) return rten_depthwise_conv2d_f32(ctx, d, x, w, weights_packed, bias, residual, flags, y);
     }
+    // variant 32 (also what -1 = automatic picks there): 3-channel 7x7 stride-2 convolutions (a ResNet stem) as a direct implicit GEMM over an image patch in LDS
+    // (gemm_f32_stem.hip); same bits
+    if ((ctx->gemm_variant_override == 32 || ctx->gemm_variant_override < 0) && aligned16(w) && rten_small_c_conv_f32_supported(d, weights_packed, (flags & RTEN_HIP_CONV_RESIDUAL) ? residual : nullptr))
+        return rten_small_c_conv_f32(ctx, d, x, w, bias, flags, y);
     const int Cg = d->c / d->groups, Og = d->o / d->groups, Og4 = (Og + 3) & ~3;
     const int K = Cg * d->kh * d->kw;
     const int P = d->out_h * d->out_w;

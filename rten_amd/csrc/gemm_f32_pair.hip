@@ -66,6 +66,7 @@ __device__ __forceinline__ void mma_block(const float *As, int lda, const float 
 #pragma unroll
             for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
     }
+    __builtin_amdgcn_iglp_opt(0);
 }
 
 template <int BN, int M2, int K1>
@@ -204,16 +205,16 @@ __global__ __launch_bounds__(256, (K1 * 64 + 64 * M2 + 64 * BN) * 4 <= 53 * 1024
         for (int j = 0; j < TN; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc1[0][j][r] = 0.f;
-        if (!(PAIR_DBG(p) & 4)) { // A fragments from W1s (double buffered across k-pairs), B fragments from registers
-            float af[2];
-            af[0] = a1[0];
+        if (!(PAIR_DBG(p) & 4)) { // A fragments from W1s -- all of the chunk's requested up front: one accumulator per wave, so nothing should sit between its MFMAs --, B fragments from registers
+            float afa[K1 / 2];
 #pragma unroll
-            for (int kk = 0; kk < K1 / 2; kk++) {
-                const int cur = kk & 1, nxt = cur ^ 1;
-                if (kk + 1 < K1 / 2) af[nxt] = a1[2 * (kk + 1) * 64];
+            for (int kk = 0; kk < K1 / 2; kk++) afa[kk] = a1[2 * kk * 64];
+            __builtin_amdgcn_sched_barrier(0); // every ds_read of the chunk is issued before its first MFMA
 #pragma unroll
-                for (int j = 0; j < TN; j++) acc1[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur], xb[kk][j], acc1[0][j], 0, 0, 0);
-            }
+            for (int kk = 0; kk < K1 / 2; kk++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) acc1[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(afa[kk], xb[kk][j], acc1[0][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
 
         wait_vmcnt<0>(); // W2 chunk mc (requested before the MFMAs above), this chunk's residual rows and the previous chunk's stores (a whole phase old)

@@ -30,7 +30,7 @@ def test_abi_version_and_variants():
     from rten_amd import lib
     so = lib.load()
     assert so.rten_hip_abi_version() == 8
-    assert so.rten_hip_num_gemm_variants() == 32
+    assert so.rten_hip_num_gemm_variants() == 33
 
 
 def test_struct_layouts_match_header():

@@ -125,7 +125,7 @@ def test_the_lanes_plan_names_the_same_steps_as_the_one_chain_plan():
     assert pairs == ["s0b0c3", "s0b1c3", "s0b2c3"] and all(p in one for p in pairs) and "pairs" not in one
     assert json.load(open(os.path.join(plans, "f32_4chains.json")))["pairs"] == pairs
     for name, e in lanes.items():
-        assert len(e) == 4 and 0 <= e[0] <= 31 and 0 <= e[1] <= 6 and 1 <= e[2] <= 32 and 0 <= e[3] <= 3, (name, e)
+        assert len(e) == 4 and 0 <= e[0] <= 32 and 0 <= e[1] <= 6 and 1 <= e[2] <= 32 and 0 <= e[3] <= 3, (name, e)
         assert e[0] != 31 or name == "fc", (name, e)  # (31 = the small-M streaming kernel: a convolution given it runs as variant 3 -- the plan says 3)
     bert = json.load(open(os.path.join(plans, "bert_base_b32_s128.json"))), json.load(open(os.path.join(plans, "bert_base_b32_s128_lanes.json")))
     assert list(bert[0]) == ["32"] and sorted(bert[1]) == ["32", "shapes"] and set(bert[0]["32"]) == set(bert[1]["32"]) and len(bert[1]["32"]) == 48

@@ -446,3 +446,47 @@ def test_two_pointwise_convolutions_in_one_launch_are_bit_exact():
             assert ctx.lib.rten_hip_conv2d_f32_pair(ctx.h, C.byref(d1), a.vp, a.vp, None, None, 0, a.vp, C.byref(d2), a.vp, None, 0, a.vp) == L.ERR_UNSUPPORTED
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_stem_convolution_direct_form_is_bit_exact(ctx):
+    """GEMM variant 32 (gemm_f32_stem.hip): 3-channel 7x7 stride-2 convolutions with prepacked weights as a direct implicit GEMM over an image patch in LDS --
+    bit-identical to the oracle (src/ops/conv.rs:124-365) and to variant 3 on ResNet's stem shape, ragged outputs (tiles past the image's edge), asymmetric and zero
+    padding, fewer than 64 / odd output channel counts, with and without bias / Relu; shapes outside its form run as variant 3."""
+    rng = ref.XorShiftRng(777)
+    cases = ((2, 224, 224, 64, (3, 3, 3, 3), True, True), (1, 50, 45, 64, (3, 3, 3, 3), True, False), (3, 33, 70, 24, (2, 3, 3, 2), False, True), (1, 21, 19, 7, (0, 0, 0, 0), True, True),
+             (2, 64, 64, 61, (3, 3, 2, 2), True, True))
+    for (N, H, W, O, pads, bias, relu) in cases:
+        oh, ow = (H + pads[0] + pads[2] - 7) // 2 + 1, (W + pads[1] + pads[3] - 7) // 2 + 1
+        x = (rng.f32(N * 3 * H * W) - 0.5).reshape(N, 3, H, W)
+        w = (rng.f32(O * 3 * 49) - 0.5).reshape(O, 3, 7, 7) * 0.2
+        b = rng.f32(O) - 0.5 if bias else None
+        want = ref.conv2d_f32(x, w, b, pads=pads, strides=(2, 2), relu=relu)
+        d = L.Conv2dDesc(N, 3, H, W, O, 7, 7, (C.c_int32 * 4)(*pads), 2, 2, 1, 1, 1, oh, ow)
+        xd, wd, bd = dev(ctx, x), dev(ctx, w), (dev(ctx, b) if bias else None)
+        pk = DeviceTensor(ctx, (ctx.lib.rten_hip_conv2d_f32_packed_bytes(C.byref(d)) // 4,), np.float32)
+        ctx.call("rten_hip_conv2d_f32_prepack", C.byref(d), wd.vp, pk.vp)
+        outs = []
+        for variant in (32, 3):
+            ctx.set_gemm_variant(variant)
+            y = DeviceTensor(ctx, (N, O, oh, ow), np.float32)
+            ctx.call("rten_hip_conv2d_f32", C.byref(d), xd.vp, pk.vp, 1, bd.vp if bias else None, None, L.CONV_RELU if relu else 0, y.vp)
+            outs.append(y.numpy())
+        ctx.set_gemm_variant(-1)
+        _bits(outs[0], want)
+        _bits(outs[1], want)
+    # not its form (5x5 kernel; four channels; unpacked weights): variant 32 runs them as variant 3
+    for (Cc, k, packed) in ((3, 5, True), (4, 7, True), (3, 7, False)):
+        x = (rng.f32(1 * Cc * 20 * 20) - 0.5).reshape(1, Cc, 20, 20)
+        w = (rng.f32(8 * Cc * k * k) - 0.5).reshape(8, Cc, k, k)
+        oh = (20 + 2 * (k // 2) - k) // 2 + 1
+        want = ref.conv2d_f32(x, w, None, pads=(k // 2,) * 4, strides=(2, 2))
+        d = L.Conv2dDesc(1, Cc, 20, 20, 8, k, k, (C.c_int32 * 4)(*((k // 2,) * 4)), 2, 2, 1, 1, 1, oh, oh)
+        xd, wd = dev(ctx, x), dev(ctx, w)
+        pk = DeviceTensor(ctx, (ctx.lib.rten_hip_conv2d_f32_packed_bytes(C.byref(d)) // 4,), np.float32)
+        ctx.call("rten_hip_conv2d_f32_prepack", C.byref(d), wd.vp, pk.vp)
+        ctx.set_gemm_variant(32)
+        y = DeviceTensor(ctx, (1, 8, oh, oh), np.float32)
+        ctx.call("rten_hip_conv2d_f32", C.byref(d), xd.vp, pk.vp if packed else wd.vp, 1 if packed else 0, None, None, 0, y.vp)
+        ctx.set_gemm_variant(-1)
+        _bits(y.numpy(), want)
