@@ -299,7 +299,7 @@ RTEN_EXPORT int32_t rten_hip_conv2d_f32_pair_supported(const rten_hip_conv2d_des
     if (d2->o != 64 && d2->o != 128) return 0;
     const long long P = (long long)d1->out_h * d1->out_w;
     if (P % 4 || P <= 0 || d1->n <= 0) return 0;
-    if ((long long)d1->n * d1->o * P * 4 > 0x7fffffffLL || (long long)d1->n * d1->c * P * 4 > 0x7fffffffLL) return 0; // 32-bit buffer offsets
+    if ((long long)d1->n * d1->o * P * 4 > 0x7fffffffLL || (long long)d1->n * d1->c * P * 4 > 0x7fffffffLL || (long long)d2->n * d2->o * P * 4 > 0x7fffffffLL) return 0; // 32-bit buffer offsets
     return 1;
 }
 

@@ -470,7 +470,7 @@ RTEN_EXPORT int32_t rten_hip_model_plan_json(rten_hip_model *g, char *buf, size_
     return RTEN_HIP_OK;
 }
 
-// Replaces the launch plan of a loaded model (the text of a plan file, as for rten_hip_model_load_ex; the step tables only: "qout" / "fused_dql" lists
+// Replaces the launch plan of a loaded model (the text of a plan file, as for rten_hip_model_load_ex; the step tables only: "qout" / "fused_dql" / "pairs" lists
 // are load-time choices and are ignored here) and marks the model unprepared: the next rten_hip_model_prepare applies it and re-captures the chains.
 // What a tuner that measures whole-model throughput under its real schedule (several replicas side by side: tools/tune_lanes.py) calls between runs.
 RTEN_EXPORT int32_t rten_hip_model_set_plan(rten_hip_model *g, const char *plan_json) {
