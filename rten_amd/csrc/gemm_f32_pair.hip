@@ -255,7 +255,9 @@ __global__ __launch_bounds__(256, (K1 * 64 + 64 * M2 + 64 * BN) * 4 <= 53 * 1024
         asm volatile("" ::: "memory");
 
         if (!(PAIR_DBG(p) & 8)) mma_block<TM2, TN, 32>(a2, M2, bt, BN, acc2);
-        wait_vmcnt<YOUNGER>(); // W1 chunk mc + 1 has landed (the stores / requests issued after it may still be in flight)
+        // W1 chunk mc + 1 has landed: exactly the stores / requests issued after its DMA may still be in flight (without a residual there are 16 * TN fewer of them)
+        if (has_res) wait_vmcnt<YOUNGER>();
+        else wait_vmcnt<YOUNGER - 16 * TN>();
         __builtin_amdgcn_s_barrier(); // [E] ... for everyone; W2s and Ts are free
     }
 
