@@ -462,6 +462,19 @@ RTEN_EXPORT int32_t rten_hip_model_plan_json(rten_hip_model *g, char *buf, size_
         }
         out += "}";
     }
+    // the load-time lists the model was built with travel with the step tables: a plan written out and loaded again builds the same steps
+    auto names = [&](const char *key, const std::set<std::string> &v) {
+        if (v.empty()) return;
+        if (out.size() > 1) out += ", ";
+        out += std::string("\"") + key + "\": [";
+        bool first = true;
+        for (auto &n : v) { out += std::string(first ? "" : ", ") + "\"" + n + "\""; first = false; }
+        out += "]";
+    };
+    names("pairs", g->opts.pairs);
+    names("fused_dql", g->opts.fused_dql);
+    names("qout", g->opts.qout);
+    names("qout2", g->opts.qout_recompute);
     out += "}";
     if (needed) *needed = out.size() + 1;
     if (!buf) return RTEN_HIP_ERR_INVALID_VALUE; // a size query: `*needed` is the answer, nothing to report

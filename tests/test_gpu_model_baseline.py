@@ -56,6 +56,7 @@ def test_resnet50_f32_batch32_four_chains_committed_plan_is_the_oracle():
                 n_pairs = len(json.loads(_plan(plan)).get("pairs", []))
                 assert (plan == "f32_1chain.json") == (n_pairs == 0)  # the lanes plan and the four-chain plan run stage 0's three expand -> reduce pairs in one launch each
                 assert m.planned_steps == (54 if plan == "f32_lanes.json" else 53) - n_pairs, (plan, m.planned_steps)
+                assert sorted(json.loads(m.plan_json()).get("pairs", [])) == sorted(json.loads(_plan(plan)).get("pairs", []))  # the exported plan names the pairs it was built with
                 assert m.warning == "", m.warning
                 ptr, nbytes = m.weight_arena()
                 assert ptr and nbytes > 100 << 20  # 25.5 M f32 parameters + their prepacked images, one allocation
