@@ -51,7 +51,8 @@ extern "C" {
 #endif
 
 /* v8 (round 6, third part): + rten_hip_conv2d_f32_pair / _pair_supported (an expand layer and the next block's reduce layer in one launch; a launch plan
- * lists the pairs: "pairs").
+ * lists the pairs: "pairs"), rten_hip_conv2d_f32_pair_shortcut / _supported (the same with the block's shortcut convolution computed in the launch: "pair_shortcuts");
+ * GEMM variant 32 (the direct stem kernel); rten_hip_model_plan_json also names the load-time lists.
  * v7 (round 6, second part): + rten_hip_set_int8_tile (the int8 kernels' workgroup tile as a context knob: a launch plan may carry a per-layer entry for an int8
  * convolution step); rten_hip_sdpa_desc: mask_row_stride = 0 with mask_batch_stride = S * T reads one shared row per batch item out of an expanded mask; plan files
  * may key MatMul-family entries by product shape ("shapes"); convolutions with C <= 4 stage their input in the few-channel packed form (opaque layouts only).
@@ -261,6 +262,15 @@ int32_t rten_hip_conv2d_f32_pair_supported(const rten_hip_conv2d_desc *d1, const
 int32_t rten_hip_conv2d_f32_pair(rten_hip_ctx *ctx, const rten_hip_conv2d_desc *d1, const float *x, const float *w1_packed, const float *bias1,
                                  const float *residual, uint32_t flags1, float *y1, const rten_hip_conv2d_desc *d2, const float *w2_packed,
                                  const float *bias2, uint32_t flags2, float *y2);
+
+/* ... with the first convolution's residual COMPUTED in the launch (v8): residual = conv1x1(xd, wd) + biasd, a 64-channel unit-stride pointwise convolution over the same
+ * pixels with d1's output channels -- the shortcut layer of a stage's first bottleneck block, whose output no other operator reads: it is neither written nor read back.
+ * ds->c == 64, ds->o == d1->o, d2->o == 64; flags1 / flags2 must not carry RTEN_HIP_CONV_RESIDUAL.  Same bits as the three launches (the shortcut's value is rounded to
+ * f32 with its bias before it is added, as the tensor would have been). */
+int32_t rten_hip_conv2d_f32_pair_shortcut_supported(const rten_hip_conv2d_desc *d1, const rten_hip_conv2d_desc *ds, const rten_hip_conv2d_desc *d2);
+int32_t rten_hip_conv2d_f32_pair_shortcut(rten_hip_ctx *ctx, const rten_hip_conv2d_desc *d1, const float *x, const float *w1_packed, const float *bias1,
+                                          const rten_hip_conv2d_desc *ds, const float *xd, const float *wd_packed, const float *biasd, uint32_t flags1, float *y1,
+                                          const rten_hip_conv2d_desc *d2, const float *w2_packed, const float *bias2, uint32_t flags2, float *y2);
 
 /* ---- Conv (int8): ConvInteger / ConvIntegerToFloat, src/ops/conv.rs:421-476,495-526,571-578 ----
  * x u8|i8 NCHW, w i8|u8 OIHW, x_zp: device scalar of x's type, w_zp: device, length 1 or o.

@@ -521,6 +521,10 @@ class Graph {
         // their output -- a bottleneck block's expand layer and the next block's reduce layer in one launch (rten_hip_conv2d_f32_pair; round 6): the
         // second layer takes its operand from LDS instead of reading the tensor back from HBM.  Same bits; a pair the kernel has no form for runs as two launches.
         std::set<std::string> pairs;
+        // ... and, of those, the pairs that ALSO compute their first convolution's residual in the launch (plan key "pair_shortcuts"): the residual is the output of a
+        // 64-channel pointwise Conv step nothing else reads -- a stage's shortcut layer -- which then has no launch and no tensor of its own
+        // (rten_hip_conv2d_f32_pair_shortcut).
+        std::set<std::string> pair_shortcuts;
         // A rank that RECEIVES the weight arena (coalesce_constants() + one broadcast from the rank that loaded the file for real): initializers of
         // 64 KB and more are allocated but not uploaded.  Everything derived from them on the device (prepacked weights) is computed on whatever the
         // buffers hold and overwritten by the broadcast, which covers every constant buffer of the graph.
@@ -981,10 +985,21 @@ class Graph {
         for (size_t i = 0; i < steps_.size(); i++) {
             Step &A = steps_[i];
             if (!A.conv || A.removed || !opt_.pairs.count(A.name) || A.out.empty() || A.out[0] < 0 || A.in.size() < 4) continue;
+            // B: a Conv step reading A's output (constant weights, no residual).  A stage's last block has two such readers -- the next stage's reduce layer and its
+            // strided shortcut layer: the one whose attributes fit the kernel (1x1, unit stride, no padding, one group) is taken, whichever comes first in the graph
+            auto unit_pointwise = [&](const Step &c) {
+                const Tensor &w = consts_.at(c.in[1]);
+                const Conv &op = *c.conv;
+                return w.ndim() == 4 && w.size(2) == 1 && w.size(3) == 1 && op.groups == 1 && op.strides == std::vector<int>{1, 1} &&
+                       (op.padding.same || op.padding.fixed == std::vector<int>{0, 0, 0, 0});
+            };
             Step *Bp = nullptr;
             for (size_t k = i + 1; k < steps_.size(); k++) {
                 Step &c = steps_[k];
-                if (c.conv && !c.removed && c.in.size() >= 4 && c.in[0] == A.out[0] && c.in[3] < 0 && c.in[1] >= 0 && consts_.count(c.in[1]) && (c.in[2] < 0 || consts_.count(c.in[2]))) { Bp = &c; break; }
+                if (c.conv && !c.removed && c.in.size() >= 4 && c.in[0] == A.out[0] && c.in[3] < 0 && c.in[1] >= 0 && consts_.count(c.in[1]) && (c.in[2] < 0 || consts_.count(c.in[2]))) {
+                    if (!Bp) Bp = &c;
+                    if (unit_pointwise(c)) { Bp = &c; break; }
+                }
             }
             if (!Bp) continue;
             Step &B = *Bp;
@@ -992,14 +1007,59 @@ class Graph {
             if (!pa || !pb) continue;
             const std::shared_ptr<Conv> opa = A.conv, opb = B.conv;
             const auto run_a = A.run, run_b = B.run;
+            // the shortcut form: A's residual is the output of a Conv step D (constant weights, no residual, no Relu) that only A reads
+            Step *Dp = nullptr;
+            const Tensor *pd = nullptr;
+            if (opt_.pair_shortcuts.count(A.name) && A.in[3] >= 0) {
+                size_t readers = 0;
+                for (auto &o : outputs_) if (ids_.at(o.name) == A.in[3]) readers += 2;
+                for (auto &st : steps_) if (!st.removed) for (int id : st.in) if (id == A.in[3]) readers++;
+                for (size_t k = 0; k < i && readers == 1; k++) {
+                    Step &c = steps_[k];
+                    if (c.conv && !c.removed && !c.out.empty() && c.out[0] == A.in[3] && c.in.size() >= 4 && c.in[3] < 0 && !c.conv->fuse_relu && c.in[1] >= 0 && consts_.count(c.in[1]) &&
+                        (c.in[2] < 0 || consts_.count(c.in[2])) && (pd = packed_lookup(c.name)) != nullptr) { Dp = &c; break; }
+                }
+            }
+            const std::shared_ptr<Conv> opd = Dp ? Dp->conv : nullptr;
+            const auto run_d = Dp ? Dp->run : run_a;
+            if (Dp) A.in[3] = Dp->in[0]; // the step now reads the shortcut's INPUT where it read the shortcut's output
             A.in.push_back(B.in[1]);
             A.in.push_back(B.in[2]);
+            if (Dp) { A.in.push_back(Dp->in[1]); A.in.push_back(Dp->in[2]); }
             A.out.push_back(B.out[0]);
             A.kind_name += ">" + B.kind_name;
             A.conv.reset(); // (not a tunable step any more: the one-launch form has no launch plan)
-            A.run = [opa, opb, pa, pb, run_a, run_b](Context &c, const InputList &in) -> OutputList {
+            A.run = [opa, opb, opd, pa, pb, pd, run_a, run_b, run_d](Context &c, const InputList &in) -> OutputList {
                 const Tensor &x = require(in, 0), &w1 = require(in, 1), &w2 = require(in, 4);
                 const Tensor *b1 = get(in, 2), *res = get(in, 3), *b2 = get(in, 5);
+                if (opd) { // shortcut form: in[3] is the shortcut's input, in[6] / in[7] its weights / bias
+                    const Tensor &xd = require(in, 3), &wd = require(in, 6);
+                    const Tensor *bd = get(in, 7);
+                    bool ok = x.dtype() == DType::F32 && xd.dtype() == DType::F32 && x.ndim() == 4 && xd.ndim() == 4 && w1.ndim() == 4 && w2.ndim() == 4 && wd.ndim() == 4 &&
+                              opa->groups == 1 && opb->groups == 1 && opd->groups == 1;
+                    rten_hip_conv2d_desc d1{}, d2{}, dd{};
+                    if (ok) {
+                        d1 = opa->geometry(x.shape(), w1.shape());
+                        d2 = opb->geometry({d1.n, d1.o, d1.out_h, d1.out_w}, w2.shape());
+                        dd = opd->geometry(xd.shape(), wd.shape());
+                        ok = rten_hip_conv2d_f32_pair_shortcut_supported(&d1, &dd, &d2) == 1 && (!b1 || (b1->dtype() == DType::F32 && b1->len() == d1.o)) &&
+                             (!b2 || (b2->dtype() == DType::F32 && b2->len() == d2.o)) && (!bd || (bd->dtype() == DType::F32 && bd->len() == dd.o));
+                    }
+                    if (!ok) { // the three steps as they were
+                        OutputList r = run_d(c, {in[3], in[6], in[7], nullptr});
+                        OutputList y1 = run_a(c, {in[0], in[1], in[2], &r[0]});
+                        OutputList y2 = run_b(c, {&y1[0], in[4], in[5], nullptr});
+                        y1.push_back(std::move(y2[0]));
+                        return y1;
+                    }
+                    OutputList out;
+                    out.emplace_back(c, std::vector<int64_t>{d1.n, d1.o, d1.out_h, d1.out_w}, DType::F32);
+                    out.emplace_back(c, std::vector<int64_t>{d2.n, d2.o, d2.out_h, d2.out_w}, DType::F32);
+                    c.check(rten_hip_conv2d_f32_pair_shortcut(c.raw(), &d1, (const float *)x.ptr(), (const float *)pa->ptr(), (const float *)vp(b1), &dd, (const float *)xd.ptr(),
+                                                              (const float *)pd->ptr(), (const float *)vp(bd), opa->fuse_relu ? RTEN_HIP_CONV_RELU : 0u, (float *)out[0].ptr(), &d2,
+                                                              (const float *)pb->ptr(), (const float *)vp(b2), opb->fuse_relu ? RTEN_HIP_CONV_RELU : 0u, (float *)out[1].ptr()));
+                    return out;
+                }
                 bool ok = x.dtype() == DType::F32 && x.ndim() == 4 && w1.ndim() == 4 && w2.ndim() == 4 && w1.dtype() == DType::F32 && w2.dtype() == DType::F32 && opa->groups == 1 && opb->groups == 1;
                 rten_hip_conv2d_desc d1{}, d2{};
                 if (ok) {
@@ -1025,6 +1085,7 @@ class Graph {
             B.removed = true;
             fused_away_++;
             conv_pairs_++;
+            if (Dp) { Dp->removed = true; fused_away_++; conv_pairs_++; A.kind_name = Dp->kind_name + "+" + A.kind_name; }
         }
         steps_.erase(std::remove_if(steps_.begin(), steps_.end(), [](const Step &st) { return st.removed; }), steps_.end());
     }

@@ -32,9 +32,15 @@ struct PairArgs {
     unsigned x_bytes, w1_bytes, w2_bytes;
     int act1, act2;
     int dbg;     // -DRTEN_ABLATE tuning builds: 1 = no residual, 2 = no y1 store, 4 / 8 = no first- / second-layer MFMAs, 16 = weights loaded once
-    int pad_[6]; // (the block spans 3 cache lines: kernarg_prefetch takes 3, 5 or 7)
+    // the shortcut form (DS): the residual is itself a pointwise convolution of another tensor -- a stage's first block, whose shortcut 64 -> M1 layer is computed HERE,
+    // chunk by chunk, instead of being written by its own launch and read back
+    const float *Xd, *Wd, *Bd;
+    long long xd_ns;
+    int wd_cs;
+    unsigned xd_bytes, wd_bytes;
+    int pad_[18]; // (the block spans 5 cache lines: kernarg_prefetch takes 3, 5 or 7)
 };
-static_assert(sizeof(PairArgs) > 128 && sizeof(PairArgs) <= 192, "PairArgs: three cache lines");
+static_assert(sizeof(PairArgs) > 256 && sizeof(PairArgs) <= 320, "PairArgs: five cache lines");
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 #ifdef RTEN_ABLATE
@@ -69,11 +75,11 @@ __device__ __forceinline__ void mma_block(const float *As, int lda, const float 
     __builtin_amdgcn_iglp_opt(0);
 }
 
-template <int BN, int M2, int K1>
-__global__ __launch_bounds__(256, (K1 * 64 + 64 * M2 + 64 * BN) * 4 <= 53 * 1024 ? 3 : ((K1 * 64 + 64 * M2 + 64 * BN) * 4 <= 80 * 1024 ? 2 : 1)) void conv_pair_f32_kernel(const PairArgs p) {
+template <int BN, int M2, int K1, bool DS = false>
+__global__ __launch_bounds__(256, ((K1 + (DS ? 64 : 0)) * 64 + 64 * M2 + 64 * BN) * 4 <= 53 * 1024 ? 3 : (((K1 + (DS ? 64 : 0)) * 64 + 64 * M2 + 64 * BN) * 4 <= 80 * 1024 ? 2 : 1)) void conv_pair_f32_kernel(const PairArgs p) {
     kernarg_prefetch<(int)sizeof(PairArgs)>();
     constexpr int TN = BN / 64, TM2 = M2 / 64;
-    constexpr int W1S = 0, W2S = W1S + K1 * 64, TS = W2S + 64 * M2, TOTAL = TS + 64 * BN;
+    constexpr int W1S = 0, WDS = W1S + K1 * 64, W2S = WDS + (DS ? 64 * 64 : 0), TS = W2S + 64 * M2, TOTAL = TS + 64 * BN; // (the shortcut's depth is 64)
     __shared__ __attribute__((aligned(16))) float smem[TOTAL];
     constexpr int NW1 = K1 * 64 / 1024, NW2 = 64 * M2 / 1024; // dwordx4 DMA instructions per wave
     static_assert(NW1 >= 1 && NW2 >= 1, "tiles too small for the four-wave DMA split");
@@ -120,7 +126,18 @@ __global__ __launch_bounds__(256, (K1 * 64 + 64 * M2 + 64 * BN) * 4 <= 53 * 1024
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW2, (lds_ptr_t)(smem + W2S + (wave * NW2 + j) * 256), 16, (int)voff, (int)soff, 0, 0);
         }
     };
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsWd = __builtin_amdgcn_make_buffer_rsrc((void *)(DS ? p.Wd : p.W1), 0, DS ? (int)p.wd_bytes : 0, 0x00020000);
+    [[maybe_unused]] auto issue_wd = [&](int mc) { // the shortcut's weights: depth rows [0, 64) x output channels [64 mc, 64 mc + 64)
+        const unsigned soff = (unsigned)mc * 256u;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int f = (wave * 4 + j) * 256 + lane * 4;
+            const unsigned voff = mc < nch ? (unsigned)(((f >> 6) * p.wd_cs + (f & 63)) * 4) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsWd, (lds_ptr_t)(smem + WDS + (wave * 4 + j) * 256), 16, (int)voff, (int)soff, 0, 0);
+        }
+    };
     issue_w1(0);
+    if constexpr (DS) issue_wd(0);
 
     // ---- this lane's output columns: offsets into y1 / residual and y2 (column part; the row rides in the scalar offset)
     unsigned col1[TN], col2[TN];
@@ -158,15 +175,35 @@ __global__ __launch_bounds__(256, (K1 * 64 + 64 * M2 + 64 * BN) * 4 <= 53 * 1024
 #pragma unroll
         for (int kk = 0; kk < K1 / 2; kk++) xb[kk][j] = buf_load1(rsX, colx, (unsigned)(2 * kk) * rs4);
     }
-    const bool has_res = p.R != nullptr && !(PAIR_DBG(p) & 1);
+    // (DS: the same for the shortcut's operand -- another tensor of 64 channels over the same pixels)
+    [[maybe_unused]] float xdb[DS ? 32 : 1][TN];
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsXd = __builtin_amdgcn_make_buffer_rsrc((void *)(DS ? p.Xd : p.X), 0, DS ? (int)p.xd_bytes : 0, 0x00020000);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsBd = __builtin_amdgcn_make_buffer_rsrc((void *)((DS && p.Bd) ? p.Bd : p.W1), 0, (DS && p.Bd) ? p.M1 * 4 : 0, 0x00020000);
+    if constexpr (DS) {
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int n = n0 + wn * (BN / 2) + j * 32 + l31;
+            const bool ok = n < p.N;
+            const int nn = ok ? n : 0;
+            const int nb = nn / p.Pn, np = nn - nb * p.Pn;
+            const unsigned colx = ok ? (unsigned)(((long long)nb * p.xd_ns + np + (long long)half * p.Pn) * 4) : OOB;
+#pragma unroll
+            for (int kk = 0; kk < 32; kk++) xdb[kk][j] = buf_load1(rsXd, colx, (unsigned)(2 * kk) * rs4);
+        }
+    }
+    const bool has_res = !DS && p.R != nullptr && !(PAIR_DBG(p) & 1);
 
     // residual and bias of one chunk: requested a phase before their use
     float rr[TN][16], b1[16];
+    [[maybe_unused]] float bd[16];
     auto fetch_res = [&](int mc) {
         const unsigned row0 = (unsigned)(mc * 64); // wave-uniform
 #pragma unroll
         for (int r = 0; r < 16; r++) b1[r] = buf_load1(rsB1, brow1, (row0 + (unsigned)acc_row(r)) << 2);
-        if (has_res) {
+        if constexpr (DS) { // the shortcut's bias rows of this chunk take the place of the residual requests (rr itself is computed, below)
+#pragma unroll
+            for (int r = 0; r < 16; r++) bd[r] = buf_load1(rsBd, brow1, (row0 + (unsigned)acc_row(r)) << 2);
+        } else if (has_res) {
 #pragma unroll
             for (int j = 0; j < TN; j++)
 #pragma unroll
@@ -184,6 +221,7 @@ __global__ __launch_bounds__(256, (K1 * 64 + 64 * M2 + 64 * BN) * 4 <= 53 * 1024
             for (int r = 0; r < 16; r++) acc2[i][j][r] = 0.f;
 
     const float *a1 = smem + W1S + half * 64 + wm * 32 + l31;
+    [[maybe_unused]] const float *ad = smem + WDS + half * 64 + wm * 32 + l31;
     const float *a2 = smem + W2S + half * M2 + wm * (M2 / 2) + l31;
     const float *bt = smem + TS + half * BN + wn * (BN / 2) + l31;
     float *tw = smem + TS + (wm * 32 + 4 * half) * BN + wn * (BN / 2) + l31;
@@ -217,6 +255,27 @@ __global__ __launch_bounds__(256, (K1 * 64 + 64 * M2 + 64 * BN) * 4 <= 53 * 1024
             __builtin_amdgcn_sched_barrier(0);
         }
 
+        if constexpr (DS) { // the shortcut's chunk: Wd[:, 64 mc ..] . xd on an accumulator of its own, then + its bias = the value the separate launch would have written
+            f32x16 accd[TN];
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) accd[j][r] = 0.f;
+            float afd[32];
+#pragma unroll
+            for (int kk = 0; kk < 32; kk++) afd[kk] = ad[2 * kk * 64];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < 32; kk++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) accd[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(afd[kk], xdb[kk][j], accd[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            wait_vmcnt<0>(); // (the bias rows)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) rr[j][r] = p.Bd ? accd[j][r] + bd[r] : accd[j][r];
+        }
         wait_vmcnt<0>(); // W2 chunk mc (requested before the MFMAs above), this chunk's residual rows and the previous chunk's stores (a whole phase old)
         const unsigned row0 = (unsigned)(mc * 64);
         f32x16 v[TN];
@@ -227,7 +286,7 @@ __global__ __launch_bounds__(256, (K1 * 64 + 64 * M2 + 64 * BN) * 4 <= 53 * 1024
 #pragma unroll
                 for (int r = 0; r < 16; r++) v[j][r] = v[j][r] + b1[r];
             }
-            if (has_res) {
+            if (DS || has_res) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) v[j][r] = v[j][r] + rr[j][r];
             }
@@ -242,6 +301,7 @@ __global__ __launch_bounds__(256, (K1 * 64 + 64 * M2 + 64 * BN) * 4 <= 53 * 1024
         __builtin_amdgcn_s_barrier(); // [B] Ts complete, W2s landed for everyone; nobody reads W1s any more
 
         if (!(PAIR_DBG(p) & 16)) issue_w1(mc + 1);
+        if constexpr (DS) issue_wd(mc + 1);
         asm volatile("" ::: "memory"); // (program order: the DMA above is older than everything below)
         if (!(PAIR_DBG(p) & 2)) {
             // the finished chunk goes to memory from its LDS image: 16 bytes per lane, a row of BN pixels = BN * 4 contiguous bytes
@@ -256,7 +316,8 @@ __global__ __launch_bounds__(256, (K1 * 64 + 64 * M2 + 64 * BN) * 4 <= 53 * 1024
 
         if (!(PAIR_DBG(p) & 8)) mma_block<TM2, TN, 32>(a2, M2, bt, BN, acc2);
         // W1 chunk mc + 1 has landed: exactly the stores / requests issued after its DMA may still be in flight (without a residual there are 16 * TN fewer of them)
-        if (has_res) wait_vmcnt<YOUNGER>();
+        if constexpr (DS) wait_vmcnt<(16 + 16 + NSTORE)>(); // (two bias requests of 16 rows, the stores)
+        else if (has_res) wait_vmcnt<YOUNGER>();
         else wait_vmcnt<YOUNGER - 16 * TN>();
         __builtin_amdgcn_s_barrier(); // [E] ... for everyone; W2s and Ts are free
     }
@@ -331,5 +392,44 @@ RTEN_EXPORT int32_t rten_hip_conv2d_f32_pair(rten_hip_ctx *ctx, const rten_hip_c
     if (a.M2 == 64) hipLaunchKernelGGL((conv_pair_f32_kernel<64, 64, 64>), dim3(tiles), dim3(256), 0, ctx->stream, a);
     else hipLaunchKernelGGL((conv_pair_f32_kernel<64, 128, 64>), dim3(tiles), dim3(256), 0, ctx->stream, a);
     RTEN_LAUNCH_CHECK(ctx, "conv_pair_f32_kernel launch");
+    return RTEN_HIP_OK;
+}
+
+// The same with the first layer's residual computed in the launch: residual = conv1x1(xd, wd) + biasd, a 64-channel pointwise convolution over the same pixels (a stage's
+// first block: its shortcut layer).  1 / 0 as above.
+RTEN_EXPORT int32_t rten_hip_conv2d_f32_pair_shortcut_supported(const rten_hip_conv2d_desc *d1, const rten_hip_conv2d_desc *ds, const rten_hip_conv2d_desc *d2) {
+    if (!ds || !rten_hip_conv2d_f32_pair_supported(d1, d2) || !pointwise_unit(ds)) return 0;
+    if (d2->o != 64 || ds->c != 64 || ds->o != d1->o || ds->n != d1->n || ds->h != d1->h || ds->w != d1->w) return 0;
+    return 1;
+}
+
+RTEN_EXPORT int32_t rten_hip_conv2d_f32_pair_shortcut(rten_hip_ctx *ctx, const rten_hip_conv2d_desc *d1, const float *x, const float *w1_packed, const float *bias1,
+                                                      const rten_hip_conv2d_desc *ds, const float *xd, const float *wd_packed, const float *biasd, uint32_t flags1, float *y1,
+                                                      const rten_hip_conv2d_desc *d2, const float *w2_packed, const float *bias2, uint32_t flags2, float *y2) {
+    RTEN_CHECK_CTX(ctx);
+    if (!d1 || !ds || !d2 || !x || !w1_packed || !xd || !wd_packed || !w2_packed || !y1 || !y2) return rten_set_error(ctx, RTEN_HIP_ERR_INVALID_VALUE, "conv pair: NULL operand");
+    if ((flags1 | flags2) & RTEN_HIP_CONV_RESIDUAL) return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "conv pair (shortcut form): the residual is the shortcut convolution; no residual tensor");
+    if (!rten_hip_conv2d_f32_pair_shortcut_supported(d1, ds, d2)) return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "conv pair (shortcut form): no one-launch form for these convolutions (rten_hip_conv2d_f32_pair_shortcut_supported)");
+    if (((uintptr_t)x | (uintptr_t)xd | (uintptr_t)w1_packed | (uintptr_t)wd_packed | (uintptr_t)w2_packed) & 15) return rten_set_error(ctx, RTEN_HIP_ERR_UNSUPPORTED, "conv pair: operands must be 16-byte aligned");
+    const int P = d1->out_h * d1->out_w;
+    PairArgs a = {};
+    a.X = x; a.W1 = w1_packed; a.B1 = bias1; a.R = nullptr; a.W2 = w2_packed; a.B2 = bias2;
+    a.Y1 = y1; a.Y2 = y2;
+    a.M1 = d1->o; a.K1 = d1->c; a.M2 = d2->o; a.N = d1->n * P; a.Pn = P;
+    a.x_ns = (long long)d1->c * P; a.y1_ns = (long long)d1->o * P; a.y2_ns = (long long)d2->o * P;
+    a.w1_cs = (d1->o + 3) & ~3; a.w2_cs = (d2->o + 3) & ~3;
+    a.x_bytes = (unsigned)((long long)d1->n * d1->c * P * 4);
+    a.w1_bytes = (unsigned)((long long)d1->c * a.w1_cs * 4);
+    a.w2_bytes = (unsigned)((long long)d2->c * a.w2_cs * 4);
+    a.act1 = (flags1 & RTEN_HIP_CONV_RELU) ? RTEN_HIP_ACT_RELU : RTEN_HIP_ACT_NONE;
+    a.act2 = (flags2 & RTEN_HIP_CONV_RELU) ? RTEN_HIP_ACT_RELU : RTEN_HIP_ACT_NONE;
+    a.dbg = ctx->debug >> 8;
+    a.Xd = xd; a.Wd = wd_packed; a.Bd = biasd;
+    a.xd_ns = (long long)ds->c * P; a.wd_cs = (ds->o + 3) & ~3;
+    a.xd_bytes = (unsigned)((long long)ds->n * ds->c * P * 4);
+    a.wd_bytes = (unsigned)((long long)ds->c * a.wd_cs * 4);
+    const int tiles = (a.N + 63) / 64;
+    hipLaunchKernelGGL((conv_pair_f32_kernel<64, 64, 64, true>), dim3(tiles), dim3(256), 0, ctx->stream, a);
+    RTEN_LAUNCH_CHECK(ctx, "conv_pair_f32_kernel (shortcut form) launch");
     return RTEN_HIP_OK;
 }

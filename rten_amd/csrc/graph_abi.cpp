@@ -190,6 +190,7 @@ RTEN_EXPORT int32_t rten_hip_model_load_ex(rten_hip_ctx *ctx, const void *onnx_b
             if (pj.names.count("qout2")) opts.qout_recompute.insert(pj.names["qout2"].begin(), pj.names["qout2"].end());
             if (pj.names.count("fused_dql")) opts.fused_dql.insert(pj.names["fused_dql"].begin(), pj.names["fused_dql"].end());
             if (pj.names.count("pairs")) opts.pairs.insert(pj.names["pairs"].begin(), pj.names["pairs"].end());
+            if (pj.names.count("pair_shortcuts")) opts.pair_shortcuts.insert(pj.names["pair_shortcuts"].begin(), pj.names["pair_shortcuts"].end());
         }
         for (int c = 0; c < chains; c++) {
             // chain 0 runs on the CALLER's context (its stream): a model with N chains owns N - 1 streams.  One stream more than chains costs real
@@ -472,6 +473,7 @@ RTEN_EXPORT int32_t rten_hip_model_plan_json(rten_hip_model *g, char *buf, size_
         out += "]";
     };
     names("pairs", g->opts.pairs);
+    names("pair_shortcuts", g->opts.pair_shortcuts);
     names("fused_dql", g->opts.fused_dql);
     names("qout", g->opts.qout);
     names("qout2", g->opts.qout_recompute);
@@ -483,7 +485,7 @@ RTEN_EXPORT int32_t rten_hip_model_plan_json(rten_hip_model *g, char *buf, size_
     return RTEN_HIP_OK;
 }
 
-// Replaces the launch plan of a loaded model (the text of a plan file, as for rten_hip_model_load_ex; the step tables only: "qout" / "fused_dql" / "pairs" lists
+// Replaces the launch plan of a loaded model (the text of a plan file, as for rten_hip_model_load_ex; the step tables only: "qout" / "fused_dql" / "pairs" / "pair_shortcuts" lists
 // are load-time choices and are ignored here) and marks the model unprepared: the next rten_hip_model_prepare applies it and re-captures the chains.
 // What a tuner that measures whole-model throughput under its real schedule (several replicas side by side: tools/tune_lanes.py) calls between runs.
 RTEN_EXPORT int32_t rten_hip_model_set_plan(rten_hip_model *g, const char *plan_json) {

@@ -132,6 +132,8 @@ PROTOTYPES = {
     "rten_hip_conv2d_f32": (_I32, [_VP, C.POINTER(Conv2dDesc), _VP, _VP, _I32, _VP, _VP, _U32, _VP]),
     "rten_hip_conv2d_f32_pair_supported": (_I32, [C.POINTER(Conv2dDesc), C.POINTER(Conv2dDesc)]),
     "rten_hip_conv2d_f32_pair": (_I32, [_VP, C.POINTER(Conv2dDesc), _VP, _VP, _VP, _VP, _U32, _VP, C.POINTER(Conv2dDesc), _VP, _VP, _U32, _VP]),
+    "rten_hip_conv2d_f32_pair_shortcut_supported": (_I32, [C.POINTER(Conv2dDesc), C.POINTER(Conv2dDesc), C.POINTER(Conv2dDesc)]),
+    "rten_hip_conv2d_f32_pair_shortcut": (_I32, [_VP, C.POINTER(Conv2dDesc), _VP, _VP, _VP, C.POINTER(Conv2dDesc), _VP, _VP, _VP, _U32, _VP, C.POINTER(Conv2dDesc), _VP, _VP, _U32, _VP]),
     "rten_hip_conv2d_int8": (_I32, [_VP, C.POINTER(Conv2dInt8Desc), _VP, _VP, _VP, _VP, _VP, _VP, _VP, _U32, _VP]),
     "rten_hip_conv2d_int8_packed_bytes": (_SZ, [C.POINTER(Conv2dInt8Desc)]),
     "rten_hip_conv2d_int8_prepack": (_I32, [_VP, C.POINTER(Conv2dInt8Desc), _VP, _VP]),

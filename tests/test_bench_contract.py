@@ -117,13 +117,16 @@ def test_the_lanes_plan_names_the_same_steps_as_the_one_chain_plan():
     import json
     plans = os.path.join(ROOT, "profiles", "plans")
     one, lanes = json.load(open(os.path.join(plans, "f32_1chain.json"))), json.load(open(os.path.join(plans, "f32_lanes.json")))
-    assert set(lanes) == set(one) | {"fc", "pairs"}
+    assert set(lanes) == set(one) | {"fc", "pairs", "pair_shortcuts"}
     assert lanes["fc"] == [3, 3, 1, 0]
     # "pairs" (round 6, third part): stage 0's three expand layers each run WITH the reduce layer that reads them, in one launch (rten_hip_conv2d_f32_pair: the second
     # convolution takes its operand from LDS; profiles/r11/f32_pairs_ab.txt).  The four-chain plan lists them too; the one-replica one-chain plan gains nothing from them
     pairs = lanes.pop("pairs")
     assert pairs == ["s0b0c3", "s0b1c3", "s0b2c3"] and all(p in one for p in pairs) and "pairs" not in one
     assert json.load(open(os.path.join(plans, "f32_4chains.json")))["pairs"] == pairs
+    # "pair_shortcuts": the first pair also computes its residual -- stage 0's shortcut convolution, which nothing else reads -- in the launch
+    # (rten_hip_conv2d_f32_pair_shortcut; profiles/r11/f32_pair_shortcut_ab.txt)
+    assert lanes.pop("pair_shortcuts") == ["s0b0c3"] and json.load(open(os.path.join(plans, "f32_4chains.json")))["pair_shortcuts"] == ["s0b0c3"]
     for name, e in lanes.items():
         assert len(e) == 4 and 0 <= e[0] <= 32 and 0 <= e[1] <= 6 and 1 <= e[2] <= 32 and 0 <= e[3] <= 3, (name, e)
         assert e[0] != 31 or name == "fc", (name, e)  # (31 = the small-M streaming kernel: a convolution given it runs as variant 3 -- the plan says 3)

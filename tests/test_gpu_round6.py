@@ -499,3 +499,46 @@ def test_stem_convolution_direct_form_is_bit_exact(ctx):
         ctx.set_gemm_variant(-1)
         _bits(y.numpy(), want)
 
+
+
+@pytest.mark.gpu
+def test_pair_with_the_shortcut_convolution_inside_is_bit_exact():
+    """rten_hip_conv2d_f32_pair_shortcut (ABI v8): a stage's FIRST bottleneck block -- the expand layer's residual is the shortcut layer, a 64-channel pointwise
+    convolution of the block's input, computed in the same launch chunk by chunk instead of being written and read back -- with the next block's reduce layer behind
+    it.  Both outputs bit-identical to the oracle's three convolutions (shortcut, expand + Add + Relu, reduce) on ragged column counts, with / without biases, run
+    several times (every launch the same bits); shapes outside the form are refused."""
+    ctx = L.Context(0)
+    try:
+        rng = ref.XorShiftRng(9191)
+        for (N, H, W, M1, bias, relu1, relu2) in ((2, 14, 14, 256, True, True, True), (3, 10, 6, 128, False, True, False), (4, 56, 56, 256, True, True, True), (1, 6, 6, 64, True, False, True)):
+            x = (rng.f32(N * 64 * H * W) - 0.5).reshape(N, 64, H, W)
+            xd = (rng.f32(N * 64 * H * W) - 0.5).reshape(N, 64, H, W)
+            w1 = (rng.f32(M1 * 64) - 0.5).reshape(M1, 64, 1, 1) * 0.2
+            wds = (rng.f32(M1 * 64) - 0.5).reshape(M1, 64, 1, 1) * 0.2
+            w2 = (rng.f32(64 * M1) - 0.5).reshape(64, M1, 1, 1) * 0.1
+            b1, bds, b2 = ((rng.f32(M1) - 0.5, rng.f32(M1) - 0.5, rng.f32(64) - 0.5) if bias else (None, None, None))
+            short = ref.conv2d_f32(xd, wds, bds)
+            want1 = ref.conv2d_f32(x, w1, b1, residual=short, relu=relu1)
+            want2 = ref.conv2d_f32(want1, w2, b2, relu=relu2)
+            mk = lambda c, o: L.Conv2dDesc(N, c, H, W, o, 1, 1, (C.c_int32 * 4)(0, 0, 0, 0), 1, 1, 1, 1, 1, H, W)  # noqa: E731
+            d1, dsd, d2 = mk(64, M1), mk(64, M1), mk(M1, 64)
+            assert ctx.lib.rten_hip_conv2d_f32_pair_shortcut_supported(C.byref(d1), C.byref(dsd), C.byref(d2)) == 1
+            dv = [dev(ctx, a) for a in (x, xd, w1, wds, w2)]
+            pk = []
+            for d, wt in ((d1, dv[2]), (dsd, dv[3]), (d2, dv[4])):
+                t = DeviceTensor(ctx, (ctx.lib.rten_hip_conv2d_f32_packed_bytes(C.byref(d)) // 4,), np.float32)
+                ctx.call("rten_hip_conv2d_f32_prepack", C.byref(d), wt.vp, t.vp)
+                pk.append(t)
+            bv = [dev(ctx, a) if bias else None for a in (b1, bds, b2)]
+            y1, y2 = DeviceTensor(ctx, (N, M1, H, W), np.float32), DeviceTensor(ctx, (N, 64, H, W), np.float32)
+            for _ in range(3):
+                ctx.call("rten_hip_conv2d_f32_pair_shortcut", C.byref(d1), dv[0].vp, pk[0].vp, bv[0].vp if bias else None, C.byref(dsd), dv[1].vp, pk[1].vp, bv[1].vp if bias else None,
+                         L.CONV_RELU if relu1 else 0, y1.vp, C.byref(d2), pk[2].vp, bv[2].vp if bias else None, L.CONV_RELU if relu2 else 0, y2.vp)
+                _bits(y1.numpy(), want1)
+                _bits(y2.numpy(), want2)
+        d1, dsd, d2 = mk(64, 256), mk(128, 256), mk(256, 64)  # a shortcut of 128 channels: no form
+        assert ctx.lib.rten_hip_conv2d_f32_pair_shortcut_supported(C.byref(d1), C.byref(dsd), C.byref(d2)) == 0
+        d2 = mk(256, 128)  # ... nor a reduce layer of 128 channels
+        assert ctx.lib.rten_hip_conv2d_f32_pair_shortcut_supported(C.byref(d1), C.byref(mk(64, 256)), C.byref(d2)) == 0
+    finally:
+        ctx.close()

@@ -548,7 +548,10 @@ def test_model_abi_chains_and_plan_file_give_the_oracle_bits():
     # "pairs" (round 6): an expand layer and the next block's reduce layer as ONE step / one launch (rten_hip_conv2d_f32_pair).  s1b0c3 is listed although the kernel has
     # no form for its 128 input channels: that step runs its two convolutions one after the other
     paired = dict(flat, pairs=["s0b0c3", "s0b1c3", "s0b2c3", "s1b0c3"])
-    for chains, plan in ((3, keyed), (1, flat), (2, None), (1, paired), (3, dict(keyed, pairs=paired["pairs"]))):
+    # "pair_shortcuts": a listed pair also computes its residual -- the stage's shortcut convolution, which nothing else reads -- in the launch
+    # (rten_hip_conv2d_f32_pair_shortcut); s1b0c3's shortcut is a stride-2 layer the kernel has no form for: its three convolutions run one after the other
+    short = dict(paired, pair_shortcuts=["s0b0c3", "s1b0c3", "s0b1c3"])  # (s0b1c3's residual is a block output other steps read: it keeps its plain pair)
+    for chains, plan in ((3, keyed), (1, flat), (2, None), (1, paired), (3, dict(keyed, pairs=paired["pairs"])), (1, short), (3, dict(keyed, pairs=short["pairs"], pair_shortcuts=short["pair_shortcuts"]))):
         m = L.Model(ctx, onnx_bytes, json.dumps(plan) if plan else None, chains)
         try:
             _check_model(m, ctx, x, want, plan, chains)
@@ -568,10 +571,11 @@ def test_model_abi_chains_and_plan_file_give_the_oracle_bits():
 def _check_model(m, ctx, x, want, plan, chains):
     from rten_amd.tensor import DeviceTensor
     n_pairs = len(plan.get("pairs", [])) if plan else 0
-    assert m.inputs == ["x"] and m.outputs == ["logits"] and m.num_steps == 57 - n_pairs
+    n_short = 2 if plan and plan.get("pair_shortcuts") else 0  # (of the three listed, two pairs have a shortcut convolution of their own behind their residual)
+    assert m.inputs == ["x"] and m.outputs == ["logits"] and m.num_steps == 57 - n_pairs - n_short
     xp = m.bind_input("x", x.shape)
     m.prepare()
-    assert m.planned_steps == (53 - n_pairs if plan else 0)  # (a pair counts once; its two layers' own entries are not used)
+    assert m.planned_steps == (53 - n_pairs if plan else 0)  # (a pair counts once, its two layers' own entries are not used; a shortcut inside counts once for its unused entry)
     xt = DeviceTensor(ctx, x.shape, np.float32, ptr=xp, keepalive=m)
     for rep in range(2):
         xt.upload(x if rep == 0 else x[::-1].copy())
